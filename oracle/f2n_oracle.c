@@ -1,0 +1,898 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU oracle for the f2-nerf per-ray hot path.
+ *
+ * A plain-C restatement of the reference algorithm (Totoro97/f2-nerf), each function citing the
+ * reference file:line it follows (paths relative to /root/reference/src).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library -- never the product.
+ *
+ * Pinning status:
+ *   - sampler / hash grid / SH / FlexOps / CustomOps / Scatter / occupancy functions are pinned
+ *     BIT-EXACTLY against the reference's own kernels compiled on CPU (oracle/_ref, built by
+ *     oracle/build_ref.py; tests/test_oracle_vs_ref.py) and against tests/golden/ vectors generated
+ *     from that library (tests/golden/make_golden.py).
+ *   - the fully-fused MLP (tiny-cuda-nn, NVlabs, un-vendored submodule with no recoverable pinned
+ *     commit; call sites Field/TCNNWP.cpp:94-97,150-154,217-227) is absent from the reference tree:
+ *     its restatement below follows the published FullyFusedMLP contract (fp16 weights, fp16
+ *     inter-layer activations, ReLU, no bias, output padded to 16) with fp32 accumulation --
+ *     PARITY UNPINNED for the MLP bits; the tolerance contract is |dRGB| <= 1e-3.
+ *
+ * Floating-point discipline: build with -ffp-contract=off -fno-fast-math.  Reduction orders follow
+ * Eigen 3.4's scalar (non-vectorised) fixed-size unrollers, which is what the reference's device code
+ * instantiates: a length-n reduction is split recursively in halves (n/2 | n - n/2).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Types: byte-compatible with the reference structs (PtsSampler/PersSampler.h:15-37).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  float center[3];      /* @0  */
+  float side_len;       /* @12 */
+  int32_t parent;       /* @16 */
+  int32_t childs[8];    /* @20 */
+  uint8_t is_leaf_node; /* @52 */
+  uint8_t pad0[3];
+  int32_t trans_idx;    /* @56 */
+  uint8_t pad1[4];
+} OrTreeNode;           /* 64 B */
+
+typedef struct {
+  float w2xz[12][2][4]; /* @0   12 x (2x4 row-major) */
+  float weight[3][12];  /* @384 3x12 row-major */
+  float center[3];      /* @528 */
+  float dis_summary;    /* @540 */
+} OrTransInfo;          /* 544 B */
+
+typedef struct {
+  int32_t t_idx_a, t_idx_b;
+  float center[3], dir_0[3], dir_1[3];
+  uint8_t pad[20];
+} OrEdgePool;           /* 64 B */
+
+typedef char or_assert_node[(sizeof(OrTreeNode) == 64) ? 1 : -1];
+typedef char or_assert_trans[(sizeof(OrTransInfo) == 544) ? 1 : -1];
+typedef char or_assert_edge[(sizeof(OrEdgePool) == 64) ? 1 : -1];
+
+#define OR_MAX_STACK 24          /* MAX_STACK_SIZE 48 ints = 24 (node, child cursor) pairs, PersSampler.cu:7 */
+#define OR_MAX_SAMPLE_PER_RAY 1024 /* PersSampler.cu:9 */
+#define OR_N_PROS 12
+
+/* ------------------------------------------------------------------------------------------------
+ * binary16 helpers (round-to-nearest-even), used wherever the reference stores __half.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint16_t or_f2h(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x47800000u) { /* |f| >= 65536, inf or nan */
+    if (x > 0x7f800000u) return (uint16_t) (sign | 0x7e00u);
+    return (uint16_t) (sign | 0x7c00u);
+  }
+  if (x < 0x38800000u) { /* below the smallest normal half: fixed-point round of |f| * 2^24 */
+    float a;
+    memcpy(&a, &x, 4);
+    float r = nearbyintf(a * 16777216.0f);
+    return (uint16_t) (sign | (uint32_t) r);
+  }
+  uint32_t h = (((x >> 23) - 112u) << 10) | ((x & 0x7fffffu) >> 13);
+  uint32_t rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+  return (uint16_t) (sign | h);
+}
+
+static inline float or_h2f(uint16_t h) {
+  uint32_t sign = ((uint32_t) h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+  if (e == 0) {
+    if (m == 0) {
+      x = sign;
+    } else {
+      float v = (float) m * 5.9604644775390625e-08f; /* m * 2^-24, exact */
+      memcpy(&x, &v, 4);
+      x |= sign;
+    }
+  } else if (e == 31) {
+    x = sign | 0x7f800000u | (m << 13);
+  } else {
+    x = sign | ((e + 112u) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+void oracle_f2h(int n, const float* in, uint16_t* out) { for (int i = 0; i < n; i++) out[i] = or_f2h(in[i]); }
+void oracle_h2f(int n, const uint16_t* in, float* out) { for (int i = 0; i < n; i++) out[i] = or_h2f(in[i]); }
+
+/* Eigen scalar reductions (see header comment). */
+static inline float or_sum3(float a, float b, float c) { return a + (b + c); }
+static inline float or_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
+static inline float or_sum12(const float* e) {
+  return ((e[0] + (e[1] + e[2])) + (e[3] + (e[4] + e[5]))) + ((e[6] + (e[7] + e[8])) + (e[9] + (e[10] + e[11])));
+}
+static inline float or_norm3(const float* v) { return sqrtf(or_sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2])); }
+
+/* ------------------------------------------------------------------------------------------------
+ * a5: ray / octree intersection.  PersSampler.cu:21-51 (slab test), :53-152 (DFS).
+ * ---------------------------------------------------------------------------------------------- */
+static inline void or_slab(const float* o, const float* d, const float* c, float side, float* near, float* far) {
+  float lo[3], hi[3];
+  float hf = side * .5f;
+  for (int i = 0; i < 3; i++) {
+    if (d[i] < 1e-6f && d[i] > -1e-6f) { /* parallel-axis guard, :31-38 */
+      if (o[i] > c[i] - hf && o[i] < c[i] + hf) { lo[i] = -1e6f; hi[i] = 1e6f; }
+      else { lo[i] = 1e6f; hi[i] = -1e6f; }
+    } else if (d[i] > 0) {
+      lo[i] = (c[i] - hf - o[i]) / d[i];
+      hi[i] = (c[i] + hf - o[i]) / d[i];
+    } else {
+      lo[i] = (c[i] + hf - o[i]) / d[i];
+      hi[i] = (c[i] - hf - o[i]) / d[i];
+    }
+  }
+  *near = fmaxf(*near, fmaxf(lo[0], fmaxf(lo[1], lo[2])));
+  *far = fminf(*far, fminf(hi[0], fminf(hi[1], hi[2])));
+}
+
+/* One ray: front-to-back list of valid leaves.  Writes at most max_hits entries when out_idx != NULL.
+ * Returns the number of hits. */
+static int or_ray_leaves(const OrTreeNode* nodes, const uint8_t* search_order, const float* o, const float* d,
+                         float g_near, float g_far, int max_hits, int32_t* out_idx, float* out_nf) {
+  int node_stack[OR_MAX_STACK], cur_stack[OR_MAX_STACK];
+  int sp = 0, cnt = 0;
+  node_stack[0] = 0; /* root */
+  cur_stack[0] = -1;
+  int octant = ((d[0] > 0.f) << 2) | ((d[1] > 0.f) << 1) | (d[2] > 0.f); /* :87 */
+  const uint8_t* order = search_order + octant * 8;
+  while (sp >= 0 && cnt < max_hits) {
+    int u = node_stack[sp];
+    const OrTreeNode* nd = nodes + u;
+    int child;
+    if (cur_stack[sp] == -1) { /* first visit of u: test the box */
+      float near = g_near, far = g_far;
+      or_slab(o, d, nd->center, nd->side_len, &near, &far);
+      if (!(near < far)) { sp--; continue; }
+      child = 0;
+      while (child < 8 && nd->childs[order[child]] < 0) child++;
+      if (child >= 8) { /* no live children: a leaf */
+        if (nd->trans_idx >= 0) {
+          if (out_idx) { out_idx[cnt] = u; out_nf[2 * cnt] = near; out_nf[2 * cnt + 1] = far; }
+          cnt++;
+        }
+        sp--;
+        continue;
+      }
+    } else { /* returning from a child: advance the cursor */
+      child = cur_stack[sp] + 1;
+      while (child < 8 && nd->childs[order[child]] < 0) child++;
+      if (child >= 8) { sp--; continue; }
+    }
+    cur_stack[sp] = child;
+    sp++;
+    node_stack[sp] = nd->childs[order[child]];
+    cur_stack[sp] = -1;
+  }
+  return cnt;
+}
+
+/* PersSampler.cu:325-366.  bounds are overridden to [near, far=1e8] for every ray (:322-323).
+ * Segments are laid out in RAY ORDER (the reference allocates them with a racing atomicAdd, so its
+ * segment order is unspecified; per-ray contents are what is defined).
+ * Returns K = total hits; if K > cap returns -K and leaves oct_idx/near_far untouched. */
+int oracle_oct_intersect(int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                         const float* rays_d, float g_near, float g_far, const uint8_t* tree_nodes,
+                         int32_t* oct_start_end, int cap, int32_t* oct_idx, float* near_far) {
+  const OrTreeNode* nodes = (const OrTreeNode*) tree_nodes;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < n_rays; r++) {
+    oct_start_end[2 * r + 1] = or_ray_leaves(nodes, search_order, rays_o + 3 * r, rays_d + 3 * r, g_near, g_far,
+                                             max_hits, NULL, NULL);
+  }
+  int acc = 0;
+  for (int r = 0; r < n_rays; r++) {
+    int c = oct_start_end[2 * r + 1];
+    oct_start_end[2 * r] = acc;
+    acc += c;
+    oct_start_end[2 * r + 1] = acc;
+  }
+  if (acc > cap) return -acc;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < n_rays; r++) {
+    int s = oct_start_end[2 * r], c = oct_start_end[2 * r + 1] - s;
+    or_ray_leaves(nodes, search_order, rays_o + 3 * r, rays_d + 3 * r, g_near, g_far, c, oct_idx + s,
+                  near_far + 2 * s);
+  }
+  return acc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a6: perspective warp and its Jacobian.  PersSampler.cu:155-187.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void or_proj(const float m[2][4], const float* p, float* x, float* z) {
+  /* (2x4)*(x,y,z,1): Eigen 4-term reduction (a+b)+(c+d); the last product is m[.][3]*1.f */
+  *x = or_sum4(m[0][0] * p[0], m[0][1] * p[1], m[0][2] * p[2], m[0][3] * 1.f);
+  *z = or_sum4(m[1][0] * p[0], m[1][1] * p[1], m[1][2] * p[2], m[1][3] * 1.f);
+}
+
+static void or_warp(const OrTransInfo* tr, const float* p, float* out) { /* :155-169 */
+  float v[OR_N_PROS];
+  for (int i = 0; i < OR_N_PROS; i++) {
+    float x, z;
+    or_proj(tr->w2xz[i], p, &x, &z);
+    v[i] = x / z;
+  }
+  for (int r = 0; r < 3; r++) {
+    float e[OR_N_PROS];
+    for (int i = 0; i < OR_N_PROS; i++) e[i] = tr->weight[r][i] * v[i];
+    out[r] = or_sum12(e);
+  }
+}
+
+static void or_warp_jac(const OrTransInfo* tr, const float* p, float jac[3][3]) { /* :171-187 */
+  float tj[OR_N_PROS][3];
+  for (int i = 0; i < OR_N_PROS; i++) {
+    float x, z;
+    or_proj(tr->w2xz[i], p, &x, &z);
+    float d0 = 1 / z;
+    float d1 = -x / (z * z);
+    for (int c = 0; c < 3; c++) tj[i][c] = d0 * tr->w2xz[i][0][c] + d1 * tr->w2xz[i][1][c];
+  }
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      float e[OR_N_PROS];
+      for (int i = 0; i < OR_N_PROS; i++) e[i] = tr->weight[r][i] * tj[i][c];
+      jac[r][c] = or_sum12(e);
+    }
+}
+
+typedef struct {
+  float* pts;     /* warped coords [N,3] */
+  float* dirs;    /* [N,3] */
+  float* dt;      /* warped-space step length [N] */
+  float* t;       /* world distance [N] */
+  int32_t* anchors; /* [N,3]: trans_idx, oct node idx, (unwritten in the reference; 0 here) */
+} OrMarchOut;
+
+/* One ray of RayMarchKernel (:189-314).  out == NULL: count only.  noise points at rays_noise + ray_idx. */
+static int or_march_ray(const float* o, const float* d, const float* noise, float sample_l, int scale_by_dis,
+                        int n_oct, const int32_t* oct_idx, const float* near_far, const OrTreeNode* nodes,
+                        const OrTransInfo* transes, int max_n, const OrMarchOut* out, int base) {
+  if (max_n <= 0) return 0;
+  int oct_ptr = 0, n = 0, first = 1;
+  int cur_oct = oct_idx[0]; /* NB: read even when n_oct == 0 in the reference (:241); callers guard */
+  float cur_t = near_far[0], cur_far = near_far[1], cur_near;
+  float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
+  while (n < max_n && oct_ptr < n_oct) {
+    const OrTreeNode* nd = nodes + cur_oct;
+    const OrTransInfo* tr = transes + nd->trans_idx;
+    float rel[3] = {o[0] - tr->center[0], o[1] - tr->center[1], o[2] - tr->center[2]};
+    float radius = or_norm3(rel) / tr->dis_summary;
+    float radius_clip = fmaxf(radius, 1.f);
+    float jac[3][3], pj[3];
+    or_warp_jac(tr, xyz, jac);
+    for (int r = 0; r < 3; r++) pj[r] = or_sum3(jac[r][0] * d[0], jac[r][1] * d[1], jac[r][2] * d[2]);
+    float step_warp = sample_l * noise[n];
+    float step = step_warp / (or_norm3(pj) + 1e-6f);
+    if (scale_by_dis) step *= radius_clip;
+    float march = step;
+    if (!first) { /* the first point of a ray is never emitted, :274-289 */
+      if (out) {
+        int k = base + n;
+        float w[3];
+        or_warp(tr, xyz, w);
+        out->t[k] = cur_t;
+        out->dt[k] = step * (or_norm3(pj) + 1e-6f);
+        for (int c = 0; c < 3; c++) { out->pts[3 * k + c] = w[c]; out->dirs[3 * k + c] = d[c]; }
+        out->anchors[3 * k] = nd->trans_idx;
+        out->anchors[3 * k + 1] = cur_oct;
+        out->anchors[3 * k + 2] = 0;
+      }
+      n++;
+    }
+    while (cur_t + march > cur_far) { /* leaf crossing, :291-301 */
+      oct_ptr++;
+      if (oct_ptr >= n_oct) break;
+      cur_oct = oct_idx[oct_ptr];
+      cur_near = near_far[2 * oct_ptr];
+      cur_far = near_far[2 * oct_ptr + 1];
+      int ex = (int) ceilf(fmaxf((cur_near - cur_t) / step, 1.f));
+      march = step * (float) ex;
+    }
+    cur_t += march;
+    for (int c = 0; c < 3; c++) xyz[c] = o[c] + d[c] * cur_t;
+    first = 0;
+  }
+  return n;
+}
+
+/* PersSampler.cu:369-423 (count, inclusive cumsum, fill).  noise has OR_MAX_SAMPLE_PER_RAY+n_rays+10
+ * floats and is indexed [ray + k] (shared, overlapping: :203,:266).  Returns N; -N if N > cap. */
+int oracle_ray_march(int n_rays, float sample_l, int scale_by_dis, const float* rays_o, const float* rays_d,
+                     const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                     const float* near_far, const uint8_t* tree_nodes, const uint8_t* transes,
+                     int32_t* pts_start_end, int cap, float* pts, float* dirs, float* dt, float* t,
+                     int32_t* anchors, float* first_oct_dis) {
+  const OrTreeNode* nodes = (const OrTreeNode*) tree_nodes;
+  const OrTransInfo* tr = (const OrTransInfo*) transes;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int r = 0; r < n_rays; r++) {
+    int s = oct_start_end[2 * r], e = oct_start_end[2 * r + 1];
+    int c = 0;
+    if (e > s)
+      c = or_march_ray(rays_o + 3 * r, rays_d + 3 * r, noise + r, sample_l, scale_by_dis, e - s, oct_idx + s,
+                       near_far + 2 * s, nodes, tr, OR_MAX_SAMPLE_PER_RAY, NULL, 0);
+    pts_start_end[2 * r + 1] = c;
+  }
+  int acc = 0;
+  for (int r = 0; r < n_rays; r++) {
+    int c = pts_start_end[2 * r + 1];
+    pts_start_end[2 * r] = acc;
+    acc += c;
+    pts_start_end[2 * r + 1] = acc;
+  }
+  if (acc > cap) return -acc;
+  OrMarchOut out = {pts, dirs, dt, t, anchors};
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int r = 0; r < n_rays; r++) {
+    int s = oct_start_end[2 * r], e = oct_start_end[2 * r + 1];
+    first_oct_dis[r] = (e > s) ? near_far[2 * s] : 1e9f; /* :226-231 */
+    int ps = pts_start_end[2 * r], pc = pts_start_end[2 * r + 1] - ps;
+    if (e > s && pc > 0)
+      or_march_ray(rays_o + 3 * r, rays_d + 3 * r, noise + r, sample_l, scale_by_dis, e - s, oct_idx + s,
+                   near_far + 2 * s, nodes, tr, pc, &out, ps);
+  }
+  return acc;
+}
+
+/* a8: PersSampler.cu:436-452 */
+void oracle_edge_samples(int n_pts, const uint8_t* edge_pool, const uint8_t* transes, const int32_t* edge_idx,
+                         const float* edge_coords, float* out_pts, int32_t* out_idx) {
+  const OrEdgePool* ep = (const OrEdgePool*) edge_pool;
+  const OrTransInfo* tr = (const OrTransInfo*) transes;
+  for (int i = 0; i < n_pts; i++) {
+    const OrEdgePool* e = ep + edge_idx[i];
+    float w[3];
+    for (int c = 0; c < 3; c++)
+      w[c] = (e->center[c] + e->dir_0[c] * edge_coords[2 * i]) + e->dir_1[c] * edge_coords[2 * i + 1];
+    or_warp(tr + e->t_idx_a, w, out_pts + 6 * i);
+    or_warp(tr + e->t_idx_b, w, out_pts + 6 * i + 3);
+    out_idx[2 * i] = e->t_idx_a;
+    out_idx[2 * i + 1] = e->t_idx_b;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a7: occupancy votes and node statistics.  PersSampler.cu:475-603.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void or_vote(int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt, int node, float w,
+                           float a, float w_thres, float a_thres, int visits) {
+  int wv = (w > w_thres) ? 512 : -1; /* OCC_WEIGHT_BASE */
+  int av = (a > a_thres) ? 32 : -1;  /* OCC_ALPHA_BASE  */
+  if (wv > w_adder[node]) w_adder[node] = wv;
+  if (av > a_adder[node]) a_adder[node] = av;
+  if (visits > cnt[node]) cnt[node] = visits;
+  mark[node] = 1;
+}
+
+/* MarkVistNodeKernel, :475-526.  oct_indices = anchors[:,1] gathered contiguous. */
+void oracle_mark_visit(int n_rays, const int32_t* pts_start_end, const int32_t* oct_indices, const float* weights,
+                       const float* alphas, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt) {
+  for (int r = 0; r < n_rays; r++) {
+    int s = pts_start_end[2 * r], e = pts_start_end[2 * r + 1];
+    if (s >= e) continue;
+    float mw = 0.f, ma = 0.f;
+    for (int i = s; i < e; i++) { mw = fmaxf(mw, weights[i]); ma = fmaxf(ma, alphas[i]); }
+    /* REL_*_THRES 0.1 / ABS_WEIGHT_THRES 0.01 / ABS_ALPHA_THRES 0.02 are double literals in the
+     * reference: float*double -> double, fminf() then narrows both arguments to float. */
+    float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
+    float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
+    float cw = 0.f, ca = 0.f;
+    int cur = -1, visits = 0;
+    for (int i = s; i < e; i++) {
+      if (cur != oct_indices[i]) {
+        if (cur >= 0) or_vote(w_adder, a_adder, mark, cnt, cur, cw, ca, w_thres, a_thres, visits);
+        cur = oct_indices[i];
+        cw = 0.f; ca = 0.f; visits = 0;
+      }
+      cw = fmaxf(cw, weights[i]);
+      ca = fmaxf(ca, alphas[i]);
+      visits++;
+    }
+    if (cur >= 0) or_vote(w_adder, a_adder, mark, cnt, cur, cw, ca, w_thres, a_thres, visits);
+  }
+}
+
+/* The torch integer ops of UpdateOctNodes (:579-593) followed by MarkInvalidNodes (:528-534):
+ *   stats = max(stats, (adder>0)*adder); stats += mark*(1-(adder>0))*adder; clamp(-100, 1<<20);
+ *   trans_idx = -1 where either stat < 0. */
+void oracle_update_node_stats(int n_nodes, const int32_t* w_adder, const int32_t* a_adder, const int32_t* mark,
+                              int32_t* w_stats, int32_t* a_stats, uint8_t* tree_nodes) {
+  OrTreeNode* nodes = (OrTreeNode*) tree_nodes;
+  for (int i = 0; i < n_nodes; i++) {
+    const int32_t* adders[2] = {w_adder, a_adder};
+    int32_t* stats[2] = {w_stats, a_stats};
+    for (int k = 0; k < 2; k++) {
+      int occ = adders[k][i] > 0;
+      int v = stats[k][i];
+      int pos = occ * adders[k][i];
+      if (pos > v) v = pos;
+      v += mark[i] * (1 - occ) * adders[k][i];
+      if (v < -100) v = -100;
+      if (v > (1 << 20)) v = 1 << 20;
+      stats[k][i] = v;
+    }
+    if (w_stats[i] < 0 || a_stats[i] < 0) nodes[i].trans_idx = -1;
+  }
+}
+
+/* MarkInvisibleNodesKernel + CheckVisible, :618-661 */
+void oracle_mark_invisible(int n_nodes, int n_cams, uint8_t* tree_nodes, const float* intris, const float* w2cs,
+                           const float* bounds) {
+  OrTreeNode* nodes = (OrTreeNode*) tree_nodes;
+  for (int i = 0; i < n_nodes; i++) {
+    int visible = 0;
+    const float* c = nodes[i].center;
+    float radius = (float) ((double) nodes[i].side_len * 0.707);
+    for (int k = 0; k < n_cams; k++) {
+      const float* m = w2cs + 12 * k;
+      const float* K = intris + 9 * k;
+      float p[3];
+      for (int r = 0; r < 3; r++)
+        p[r] = or_sum4(m[4 * r] * c[0], m[4 * r + 1] * c[1], m[4 * r + 2] * c[2], m[4 * r + 3] * 1.f);
+      if (-p[2] < bounds[2 * k] - radius || -p[2] > bounds[2 * k + 1] + radius) continue;
+      if (or_norm3(p) < radius) { visible++; continue; }
+      float cx = K[2], cy = K[5], fx = K[0], fy = K[4];
+      float bx = radius / -p[2] * fx, by = radius / -p[2] * fy;
+      float ix = p[0] / -p[2] * fx, iy = p[1] / -p[2] * fy;
+      if (ix + bx < -cx || ix > cx + bx || iy + by < -cy || iy > cy + by) continue;
+      visible++;
+    }
+    if (visible < 1) nodes[i].trans_idx = -1;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a10/a11: anchored multi-resolution hash grid.  Field/Hash3DAnchored.cu:11-155.
+ * ---------------------------------------------------------------------------------------------- */
+/* float -> unsigned the way CUDA's cvt.rzi.u32.f32 and AMD's v_cvt_u32_f32 do it: saturating.
+ * (x86 casts of negative floats are UB; the reference relies on the device behaviour.) */
+static inline uint32_t or_f2u_sat(float f) {
+  if (!(f > 0.f)) return 0u; /* negatives and NaN */
+  if (f >= 4294967296.f) return 0xffffffffu;
+  return (uint32_t) f;
+}
+
+/* The 16 per-level scales exp2f((10-3)*l/15 + 3) of Hash3DAnchored.cu:28, evaluated once with the host
+ * libm; the HIP path takes this table as an input so both sides use identical scale bits. */
+void oracle_level_scales(float* out16) {
+  for (int l = 0; l < 16; l++) out16[l] = exp2f((10.f - 3.f) * (float) l / (float) (16 - 1) + 3.f);
+}
+
+typedef struct { uint32_t pos[8]; float w[8]; } OrCell;
+
+static inline void or_hash_cell(const float* pt01, float mul, const int32_t* prim, const float* bias,
+                                uint32_t local_size, OrCell* c) {
+  float q[3];
+  for (int k = 0; k < 3; k++) q[k] = pt01[k] * mul + bias[k]; /* mul then add, :29,:41 */
+  float fl[3] = {floorf(q[0]), floorf(q[1]), floorf(q[2])};
+  uint32_t px = or_f2u_sat(fl[0]), py = or_f2u_sat(fl[1]), pz = or_f2u_sat(fl[2]);
+  uint32_t pa = (uint32_t) prim[0], pb = (uint32_t) prim[1], pc = (uint32_t) prim[2];
+  for (int corner = 0; corner < 8; corner++) { /* order 000,001,010,011,100,101,110,111 = (x,y,z) bits */
+    uint32_t x = px + ((corner >> 2) & 1u), y = py + ((corner >> 1) & 1u), z = pz + (corner & 1u);
+    c->pos[corner] = ((x * pa) ^ (y * pb) ^ (z * pc)) % local_size;
+  }
+  float a = q[0] - fl[0], b = q[1] - fl[1], cc = q[2] - fl[2];
+  c->w[0] = (1.f - a) * (1.f - b) * (1.f - cc);
+  c->w[1] = (1.f - a) * (1.f - b) * cc;
+  c->w[2] = (1.f - a) * b * (1.f - cc);
+  c->w[3] = (1.f - a) * b * cc;
+  c->w[4] = a * (1.f - b) * (1.f - cc);
+  c->w[5] = a * (1.f - b) * cc;
+  c->w[6] = a * b * (1.f - cc);
+  c->w[7] = a * b * cc;
+}
+
+/* Forward, Hash3DAnchored.cu:11-79.  points are the QUERY points ((p+1)/2 already applied,
+ * Hash3DAnchored.cpp:91).  feat_pool/out are binary16 bit patterns.  The level base is applied as an
+ * offset of local_idx[l] HALVES on the half pointer (:37) while entries are addressed as pos*2+k
+ * (:74-77) -- adjacent levels overlap by 50 %; replicated on purpose. */
+void oracle_hash_fwd(int n_points, int n_volumes, const uint16_t* feat_pool, const int32_t* prim_pool,
+                     const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                     const float* level_scale, const float* points, const int32_t* volume_idx, int vol_stride,
+                     uint16_t* out_feat) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_points; i++) {
+    int v = volume_idx[(size_t) i * vol_stride];
+    for (int l = 0; l < 16; l++) {
+      OrCell c;
+      int tf = l * n_volumes + v;
+      or_hash_cell(points + 3 * (size_t) i, level_scale[l], prim_pool + 3 * tf, bias_pool + 3 * tf,
+                   (uint32_t) local_size[l], &c);
+      const uint16_t* base = feat_pool + local_idx[l];
+      for (int k = 0; k < 2; k++) {
+        float s = c.w[0] * or_h2f(base[c.pos[0] * 2 + k]);
+        for (int d = 1; d < 8; d++) s = s + c.w[d] * or_h2f(base[c.pos[d] * 2 + k]);
+        out_feat[(size_t) i * 32 + l * 2 + k] = or_f2h(s);
+      }
+    }
+  }
+}
+
+/* Backward, Hash3DAnchored.cu:81-155: half2 atomicAdd of (half)(g*w) per corner, skipped when both
+ * channel grads are zero.  grad_in is binary16 (already scaled by 128, :220); grad_out (binary16,
+ * same addressing as the table) is ACCUMULATED into, in point-major / level / corner order.  Serial on
+ * purpose: the accumulation order is what defines the fp16 result. */
+void oracle_hash_bwd(int n_points, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
+                     const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                     const float* points, const int32_t* volume_idx, int vol_stride, const uint16_t* grad_in,
+                     uint16_t* grad_out) {
+  for (int l = 0; l < 16; l++) { /* grid.y = level is the slow launch dimension */
+    for (int i = 0; i < n_points; i++) {
+      int v = volume_idx[(size_t) i * vol_stride];
+      OrCell c;
+      int tf = l * n_volumes + v;
+      or_hash_cell(points + 3 * (size_t) i, level_scale[l], prim_pool + 3 * tf, bias_pool + 3 * tf,
+                   (uint32_t) local_size[l], &c);
+      float g0 = or_h2f(grad_in[(size_t) i * 32 + l * 2]), g1 = or_h2f(grad_in[(size_t) i * 32 + l * 2 + 1]);
+      if (g0 == 0.f && g1 == 0.f) continue;
+      uint16_t* base = grad_out + local_idx[l];
+      for (int d = 0; d < 8; d++) {
+        uint16_t a0 = or_f2h(g0 * c.w[d]), a1 = or_f2h(g1 * c.w[d]);
+        uint16_t* p = base + c.pos[d] * 2;
+        p[0] = or_f2h(or_h2f(p[0]) + or_h2f(a0));
+        p[1] = or_f2h(or_h2f(p[1]) + or_h2f(a1));
+      }
+    }
+  }
+}
+
+/* Same scatter with fp32 accumulation -- the "fp32-accumulated oracle" of SURVEY 8(c) that order-
+ * dependent fp16 atomics are compared against (grad_out32 has the table's addressing, in floats). */
+void oracle_hash_bwd_f32(int n_points, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
+                         const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                         const float* points, const int32_t* volume_idx, int vol_stride,
+                         const uint16_t* grad_in, float* grad_out32) {
+  for (int i = 0; i < n_points; i++) {
+    int v = volume_idx[(size_t) i * vol_stride];
+    for (int l = 0; l < 16; l++) {
+      OrCell c;
+      int tf = l * n_volumes + v;
+      or_hash_cell(points + 3 * (size_t) i, level_scale[l], prim_pool + 3 * tf, bias_pool + 3 * tf,
+                   (uint32_t) local_size[l], &c);
+      float g0 = or_h2f(grad_in[(size_t) i * 32 + l * 2]), g1 = or_h2f(grad_in[(size_t) i * 32 + l * 2 + 1]);
+      if (g0 == 0.f && g1 == 0.f) continue;
+      float* base = grad_out32 + local_idx[l];
+      for (int d = 0; d < 8; d++) {
+        base[c.pos[d] * 2] += or_h2f(or_f2h(g0 * c.w[d]));
+        base[c.pos[d] * 2 + 1] += or_h2f(or_f2h(g1 * c.w[d]));
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a13: real spherical harmonics, degree <= 4.  Shader/SHShader.cu:10-106 (polynomial forms and op
+ * order kept; all configs use degree 4).
+ * ---------------------------------------------------------------------------------------------- */
+int oracle_sh_encode(int n, int degree, const float* dirs, float* out) {
+  if (degree < 1 || degree > 4) return -1;
+  int width = degree * degree;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
+    float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float* o = out + (size_t) i * width;
+    o[0] = 0.28209479177387814f;
+    if (degree <= 1) continue;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    if (degree <= 2) continue;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    if (degree <= 3) continue;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a15/a16/a17: per-ray segmented ops.  Renderer/Renderer.cu:8-18, Utils/CustomOps/FlexOps.cu:5-93,
+ * CustomOps.cu:12-80, Scatter.cu:10-40,110-120.  One sequential left-to-right walk per ray.
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_count_valid(int n_rays, const int32_t* se, const int32_t* mask, int32_t* out) {
+  for (int r = 0; r < n_rays; r++) {
+    int c = 0;
+    for (int i = se[2 * r]; i < se[2 * r + 1]; i++) c += mask[i];
+    out[r] = c;
+  }
+}
+
+/* FilterIdxBounds, Renderer.cu:20-50: new bounds = cumsum of kept counts (relies on ray order). */
+void oracle_filter_idx_bounds(int n_rays, const int32_t* se, const int32_t* mask, int32_t* new_se) {
+  int acc = 0;
+  for (int r = 0; r < n_rays; r++) {
+    int c = 0;
+    for (int i = se[2 * r]; i < se[2 * r + 1]; i++) c += mask[i];
+    new_se[2 * r] = acc;
+    acc += c;
+    new_se[2 * r + 1] = acc;
+  }
+}
+
+void oracle_flex_sum_fwd(int n, int c, const float* val, const int32_t* se, float* sum) {
+  for (int r = 0; r < n; r++)
+    for (int j = 0; j < c; j++) {
+      float s = 0.f;
+      for (int i = se[2 * r]; i < se[2 * r + 1]; i++) s += val[(size_t) i * c + j];
+      sum[(size_t) r * c + j] = s;
+    }
+}
+
+void oracle_flex_sum_bwd(int n, int c, const float* dsum, const int32_t* se, float* dval) {
+  for (int r = 0; r < n; r++)
+    for (int j = 0; j < c; j++)
+      for (int i = se[2 * r]; i < se[2 * r + 1]; i++) dval[(size_t) i * c + j] = dsum[(size_t) r * c + j];
+}
+
+void oracle_flex_acc_fwd(int n, int include_this, const float* val, const int32_t* se, float* sum) {
+  for (int r = 0; r < n; r++) {
+    float s = 0.f;
+    for (int i = se[2 * r]; i < se[2 * r + 1]; i++) {
+      if (include_this) { s += val[i]; sum[i] = s; }
+      else { sum[i] = s; s += val[i]; }
+    }
+  }
+}
+
+void oracle_flex_acc_bwd(int n, int include_this, const float* dsum, const int32_t* se, float* dval) {
+  for (int r = 0; r < n; r++) {
+    float wp = 0.f;
+    for (int i = se[2 * r + 1] - 1; i >= se[2 * r]; i--) {
+      if (include_this) { wp += dsum[i]; dval[i] = wp; }
+      else { dval[i] = wp; wp += dsum[i]; }
+    }
+  }
+}
+
+static void or_wv_stats(const float* w, int n, float* mean_out, float* wsum_out) {
+  float mean = 0.f, ws = 1e-6f;
+  for (int i = 0; i < n; i++) {
+    mean += w[i] * ((float) i / 16.f);
+    ws += w[i];
+  }
+  *mean_out = mean / ws;
+  *wsum_out = ws;
+}
+
+void oracle_weight_var_fwd(int n, const float* weights, const int32_t* se, float* out) {
+  for (int r = 0; r < n; r++) {
+    int s = se[2 * r], e = se[2 * r + 1];
+    if (s >= e) { out[r] = 0.f; continue; }
+    float mean, ws;
+    or_wv_stats(weights + s, e - s, &mean, &ws);
+    float var = 0.f;
+    for (int i = 0; i + s < e; i++) {
+      float b = (float) i / 16.f - mean;
+      var += weights[i + s] * b * b;
+    }
+    out[r] = var;
+  }
+}
+
+void oracle_weight_var_bwd(int n, const float* weights, const int32_t* se, const float* dvar, float* dw) {
+  for (int r = 0; r < n; r++) {
+    int s = se[2 * r], e = se[2 * r + 1];
+    if (s >= e) continue;
+    float mean, ws;
+    or_wv_stats(weights + s, e - s, &mean, &ws);
+    float tmp = 0.f;
+    for (int i = 0; i + s < e; i++) {
+      float b = (float) i / 16.f - mean;
+      tmp += weights[i + s] * 2.f * b;
+    }
+    for (int i = 0; i + s < e; i++) {
+      float b = (float) i / 16.f - mean;
+      float g = (b * b + tmp * -((float) i / 16.f) / ws);
+      dw[i + s] = dvar[r] * g;
+    }
+  }
+}
+
+void oracle_grad_scaling_bwd(int n_rays, int c, float progress, const int32_t* se, float* vals) {
+  for (int r = 0; r < n_rays; r++) {
+    int s = se[2 * r], e = se[2 * r + 1];
+    for (int i = 0; i + s < e; i++) {
+      float a = ((float) i + .5f) / (float) (e - s);
+      float sc = progress + (1.f - progress) * a * a;
+      for (int j = 0; j < c; j++) vals[(size_t) (i + s) * c + j] *= sc;
+    }
+  }
+}
+
+void oracle_scatter_idx(int n_rays, const int32_t* se, const int32_t* emb_idx, int32_t* all_idx) {
+  for (int r = 0; r < n_rays; r++)
+    for (int i = se[2 * r]; i < se[2 * r + 1]; i++) all_idx[i] = emb_idx[r];
+}
+
+void oracle_scatter_add_fwd(int n_all, int c, const float* emb, const int32_t* idx, float* to_add) {
+  for (int i = 0; i < n_all; i++)
+    for (int j = 0; j < c; j++) to_add[(size_t) i * c + j] += emb[(size_t) idx[i] * c + j];
+}
+
+/* Scatter.cu:20-40 + :77-96: two-stage (block of ~sqrt(n) samples, then sum over blocks). */
+void oracle_scatter_add_bwd(int n_emb, int n_all, int c, const int32_t* idx, const float* dsum, float* demb) {
+  int block_size = ((int) sqrt((double) (n_all + 1024)) >> 5) << 5;
+  int n_blocks = (n_all + block_size - 1) / block_size;
+  float* pool = (float*) calloc((size_t) n_emb * n_blocks * c, sizeof(float));
+  for (int b = 0; b < n_blocks; b++) {
+    int lo = b * block_size, hi = lo + block_size;
+    if (hi > n_all) hi = n_all;
+    for (int i = lo; i < hi; i++) {
+      float* p = pool + ((size_t) idx[i] * n_blocks + b) * c;
+      for (int j = 0; j < c; j++) p[j] += dsum[(size_t) i * c + j];
+    }
+  }
+  for (int e = 0; e < n_emb; e++)
+    for (int j = 0; j < c; j++) {
+      float s = 0.f;
+      for (int b = 0; b < n_blocks; b++) s += pool[((size_t) e * n_blocks + b) * c + j];
+      demb[(size_t) e * c + j] = s;
+    }
+  free(pool);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a12/a13: fully-fused MLP contract (tiny-cuda-nn FullyFusedMLP as used by Field/TCNNWP.cpp:79-243).
+ *   PARITY UNPINNED (tcnn is not in the reference tree) -- this states the function class:
+ *   params: fp32 master, used as binary16 (TCNNWP.cpp:111); layout = layers first->last, each
+ *           [n_out, n_in] row-major; the last layer has 16 (padded) output rows.
+ *   forward: x -> fp16; h_l = fp16(relu(W_l h_{l-1})) with fp32 accumulation in k order; the output
+ *           layer has no activation and is stored as fp16 (TCNNWP.cpp:143-144 output precision).
+ *   backward: dL/dy is multiplied by loss_scale and rounded to fp16 (:174,:187); hidden gradients are
+ *           kept in fp16; dL/dW is accumulated in fp32 over the batch then rounded to fp16 (param
+ *           precision, :214-215) before the /loss_scale (:232); dL/dx is fp32 /loss_scale (:231).
+ * ---------------------------------------------------------------------------------------------- */
+#define OR_MLP_MAX_W 64
+#define OR_MLP_MAX_L 4
+
+static void or_mlp_dims(int d_in, int d_hidden, int n_hidden, int* n_layers, int* rows, int* cols) {
+  int L = n_hidden + 1;
+  for (int l = 0; l < L; l++) {
+    cols[l] = (l == 0) ? d_in : d_hidden;
+    rows[l] = (l == L - 1) ? 16 : d_hidden;
+  }
+  *n_layers = L;
+}
+
+int oracle_mlp_n_params(int d_in, int d_hidden, int n_hidden) {
+  int L, rows[OR_MLP_MAX_L], cols[OR_MLP_MAX_L], n = 0;
+  or_mlp_dims(d_in, d_hidden, n_hidden, &L, rows, cols);
+  for (int l = 0; l < L; l++) n += rows[l] * cols[l];
+  return n;
+}
+
+/* acts (optional, may be NULL): fp16 activations of every hidden layer, [n, n_hidden, d_hidden]. */
+int oracle_mlp_fwd(int n, int d_in, int d_hidden, int n_hidden, const float* params, const float* x,
+                   uint16_t* out_h /* [n,16] */, uint16_t* acts) {
+  if (d_in > OR_MLP_MAX_W || d_hidden > OR_MLP_MAX_W || n_hidden + 1 > OR_MLP_MAX_L) return -1;
+  int L, rows[OR_MLP_MAX_L], cols[OR_MLP_MAX_L];
+  or_mlp_dims(d_in, d_hidden, n_hidden, &L, rows, cols);
+  int np = oracle_mlp_n_params(d_in, d_hidden, n_hidden);
+  float* w = (float*) malloc(sizeof(float) * np); /* fp16-rounded weights, widened */
+  for (int i = 0; i < np; i++) w[i] = or_h2f(or_f2h(params[i]));
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    float cur[OR_MLP_MAX_W], nxt[OR_MLP_MAX_W];
+    for (int k = 0; k < d_in; k++) cur[k] = or_h2f(or_f2h(x[(size_t) i * d_in + k]));
+    const float* wl = w;
+    for (int l = 0; l < L; l++) {
+      for (int j = 0; j < rows[l]; j++) {
+        float s = 0.f;
+        for (int k = 0; k < cols[l]; k++) s += wl[j * cols[l] + k] * cur[k];
+        if (l < L - 1) s = s > 0.f ? s : 0.f;
+        nxt[j] = or_h2f(or_f2h(s));
+      }
+      if (l < L - 1) {
+        if (acts)
+          for (int j = 0; j < d_hidden; j++)
+            acts[((size_t) i * n_hidden + l) * d_hidden + j] = or_f2h(nxt[j]);
+        memcpy(cur, nxt, sizeof(float) * rows[l]);
+      } else {
+        for (int j = 0; j < 16; j++) out_h[(size_t) i * 16 + j] = or_f2h(nxt[j]);
+      }
+      wl += rows[l] * cols[l];
+    }
+  }
+  free(w);
+  return 0;
+}
+
+/* dparams (fp32, already divided by loss_scale, after the fp16 rounding of the scaled gradient);
+ * dx (fp32 [n,d_in], already divided by loss_scale) may be NULL.
+ * dx_scaled_h (optional): the fp16 value of loss_scale*dL/dx, which is what the hash backward
+ * consumes after its own *128 -> fp16 round trip (Hash3DAnchored.cu:220). */
+int oracle_mlp_bwd(int n, int d_in, int d_hidden, int n_hidden, float loss_scale, const float* params,
+                   const float* x, const uint16_t* acts, const float* dy /* [n,16] */, float* dparams, float* dx,
+                   uint16_t* dx_scaled_h) {
+  if (d_in > OR_MLP_MAX_W || d_hidden > OR_MLP_MAX_W || n_hidden + 1 > OR_MLP_MAX_L) return -1;
+  int L, rows[OR_MLP_MAX_L], cols[OR_MLP_MAX_L], off[OR_MLP_MAX_L];
+  or_mlp_dims(d_in, d_hidden, n_hidden, &L, rows, cols);
+  int np = 0;
+  for (int l = 0; l < L; l++) { off[l] = np; np += rows[l] * cols[l]; }
+  float* w = (float*) malloc(sizeof(float) * np);
+  for (int i = 0; i < np; i++) w[i] = or_h2f(or_f2h(params[i]));
+  int nthreads = 1;
+#ifdef _OPENMP
+  nthreads = omp_get_max_threads();
+#endif
+  float* acc = (float*) calloc((size_t) np * nthreads, sizeof(float));
+#pragma omp parallel
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    float* my = acc + (size_t) np * tid;
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {
+      float g[OR_MLP_MAX_W], gp[OR_MLP_MAX_W], in[OR_MLP_MAX_W];
+      for (int j = 0; j < 16; j++) g[j] = or_h2f(or_f2h(dy[(size_t) i * 16 + j] * loss_scale));
+      for (int l = L - 1; l >= 0; l--) {
+        /* input activations of layer l */
+        if (l == 0) for (int k = 0; k < d_in; k++) in[k] = or_h2f(or_f2h(x[(size_t) i * d_in + k]));
+        else for (int k = 0; k < d_hidden; k++) in[k] = or_h2f(acts[((size_t) i * n_hidden + (l - 1)) * d_hidden + k]);
+        const float* wl = w + off[l];
+        for (int j = 0; j < rows[l]; j++)
+          for (int k = 0; k < cols[l]; k++) my[off[l] + j * cols[l] + k] += g[j] * in[k];
+        if (l > 0 || dx || dx_scaled_h) {
+          for (int k = 0; k < cols[l]; k++) {
+            float s = 0.f;
+            for (int j = 0; j < rows[l]; j++) s += wl[j * cols[l] + k] * g[j];
+            if (l > 0) s = (in[k] > 0.f) ? s : 0.f; /* ReLU mask from the stored fp16 activation */
+            gp[k] = s;
+          }
+          if (l > 0) for (int k = 0; k < cols[l]; k++) g[k] = or_h2f(or_f2h(gp[k]));
+          else {
+            for (int k = 0; k < d_in; k++) {
+              if (dx) dx[(size_t) i * d_in + k] = gp[k] / loss_scale;
+              if (dx_scaled_h) dx_scaled_h[(size_t) i * d_in + k] = or_f2h(gp[k]);
+            }
+          }
+        }
+      }
+    }
+  }
+  for (int p = 0; p < np; p++) {
+    float s = 0.f;
+    for (int t = 0; t < nthreads; t++) s += acc[(size_t) np * t + p];
+    dparams[p] = or_h2f(or_f2h(s)) / loss_scale;
+  }
+  free(acc);
+  free(w);
+  return 0;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,145 @@
+"""CPU: randomized bit-exact comparison of the oracle restatement against the reference's own kernels
+(oracle/_ref, built from /root/reference by oracle/build_ref.py).  Skipped where _ref is not built; the
+committed goldens (test_golden.py) are the travelling pin."""
+import numpy as np
+import pytest
+
+from oracle import capi, ref
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def same(a, b):
+    assert a.shape == b.shape and a.dtype == b.dtype
+    np.testing.assert_array_equal(bits(a), bits(b))
+
+
+def _rays(st, rng, n, all_cams=True):
+    cams = np.arange(len(st["poses"])) if all_cams else st["train_set"]
+    cam = cams[rng.integers(0, len(cams), n)].astype(np.int32)
+    ij = np.stack([rng.integers(0, 960, n), rng.integers(0, 540, n)], -1).astype(np.float32) + np.float32(.5)
+    o, d = ref.img2world(st["poses"], st["intri"], st["dist_params"], cam, ij)
+    return o, (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32), cam
+
+
+def test_layout_facts():
+    lay = ref.struct_layout().tolist()
+    assert lay == [64, 0, 12, 16, 20, 52, 56, 544, 0, 384, 528, 540, 64, 0, 4, 8, 20, 32]
+    same(ref.search_order_table(), capi.search_order_table())
+
+
+@pytest.mark.parametrize("seed,fineness,scale_by_dis,max_hits", [(1, 4.0, True, 1024), (2, 1.0, False, 1024),
+                                                                  (3, 16.0, True, 5)])
+def test_sampler_random(fox_state, seed, fineness, scale_by_dis, max_hits):
+    st = fox_state
+    rng = np.random.default_rng(seed)
+    n = 600
+    o, d, _ = _rays(st, rng, n)
+    # a few degenerate rays: axis-parallel directions (the +-1e-6 guard) and a ray that misses everything
+    d[0] = [1, 0, 0]; d[1] = [0, -1, 0]; d[2] = [0, 0, 1]; o[3] = [1e4, 1e4, 1e4]; d[3] = [1, 0, 0]
+    a = ref.oct_intersect(st["search_order"], o, d, 0.01, 1e8, st["tree_nodes"], max_hits)
+    b = capi.oct_intersect(st["search_order"], o, d, 0.01, 1e8, st["tree_nodes"], max_hits)
+    for x, y in zip(a, b):
+        same(x, y)
+    noise = ((rng.random(1024 + n + 10, dtype=np.float32) - np.float32(.5)) + np.float32(1.)) * np.float32(fineness)
+    ma = ref.ray_march(o, d, noise, 1. / 256., scale_by_dis, *a, st["tree_nodes"], st["pers_trans"])
+    mb = capi.ray_march(o, d, noise, 1. / 256., scale_by_dis, *b, st["tree_nodes"], st["pers_trans"])
+    for k in mb:
+        same(ma[k], mb[k])
+    counts = mb["pts_idx_bounds"][:, 1] - mb["pts_idx_bounds"][:, 0]
+    assert counts.max() <= 1024 and counts[3] == 0
+
+
+def test_hash_random(fox_state):
+    st = fox_state
+    rng = np.random.default_rng(5)
+    nv = int(st["n_volumes"])
+    for log2_t in (10, 14):
+        local = 1 << log2_t
+        table = (rng.standard_normal(16 * local * 2).astype(np.float32)).astype(np.float16)
+        li = (np.arange(16) * local).astype(np.int32)
+        ls = np.full(16, local, np.int32)
+        n = 3000
+        q = (rng.random((n, 3), dtype=np.float32) * np.float32(1.6) - np.float32(0.3))  # includes q01 < 0 (saturation)
+        vol = rng.integers(0, nv, n).astype(np.int32)
+        fa = ref.hash_fwd(table.view(np.uint16), st["prim_pool"], li, ls, st["bias_pool"], q, vol, nv)
+        fb = capi.hash_fwd(table.view(np.uint16), st["prim_pool"], li, ls, st["bias_pool"], q, vol, nv)
+        same(fa, fb)
+        gin = (rng.standard_normal((n, 32)) * 0.1).astype(np.float16)
+        gin[::5] = 0
+        ga = ref.hash_bwd(table.size, st["prim_pool"], li, ls, st["bias_pool"], q, vol, nv, gin.view(np.uint16))
+        gb = capi.hash_bwd(table.size, st["prim_pool"], li, ls, st["bias_pool"], q, vol, nv, gin.view(np.uint16))
+        same(ga, gb)
+    # zero bias (rand_bias: false): all queries with negative coordinates saturate to cell 0
+    zb = np.zeros_like(st["bias_pool"])
+    same(ref.hash_fwd(table.view(np.uint16), st["prim_pool"], li, ls, zb, q, vol, nv),
+         capi.hash_fwd(table.view(np.uint16), st["prim_pool"], li, ls, zb, q, vol, nv))
+
+
+def test_small_ops_random():
+    rng = np.random.default_rng(9)
+    R = 300
+    cnt = rng.integers(0, 40, R)
+    cnt[::17] = 0
+    end = np.cumsum(cnt)
+    se = np.stack([end - cnt, end], -1).astype(np.int32)
+    n = int(end[-1])
+    val, vec = rng.random(n, dtype=np.float32), rng.standard_normal((n, 3)).astype(np.float32)
+    d1, d3 = rng.random(R, dtype=np.float32), rng.random((R, 3), dtype=np.float32)
+    same(ref.flex_sum(val, se), capi.flex_sum(val, se))
+    same(ref.flex_sum(vec, se), capi.flex_sum(vec, se))
+    same(ref.flex_sum_bwd(d1, se, n), capi.flex_sum_bwd(d1, se, n))
+    same(ref.flex_sum_bwd(d3, se, n), capi.flex_sum_bwd(d3, se, n))
+    for inc in (False, True):
+        same(ref.flex_acc(val, se, inc), capi.flex_acc(val, se, inc))
+        same(ref.flex_acc_bwd(val, se, inc), capi.flex_acc_bwd(val, se, inc))
+    same(ref.weight_var(val, se), capi.weight_var(val, se))
+    same(ref.weight_var_bwd(val, se, d1), capi.weight_var_bwd(val, se, d1))
+    for p in (0.0, 0.3, 1.0):
+        same(ref.grad_scaling_bwd(vec, se, p), capi.grad_scaling_bwd(vec, se, p))
+        same(ref.grad_scaling_bwd(val, se, p), capi.grad_scaling_bwd(val, se, p))
+    mask = (val > 0.5).astype(np.int32)
+    same(ref.count_valid(se, mask), capi.count_valid(se, mask))
+    dirs = rng.standard_normal((500, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    for deg in (1, 2, 3, 4):
+        same(ref.sh_encode(dirs, deg), capi.sh_encode(dirs, deg))
+    emb = rng.standard_normal((43, 16)).astype(np.float32)
+    eidx = rng.integers(0, 43, R).astype(np.int32)
+    ai = capi.scatter_idx(n, se, eidx)
+    same(ref.scatter_idx(n, se, eidx), ai)
+    ta = rng.standard_normal((n, 16)).astype(np.float32)
+    same(ref.scatter_add(emb, ai, ta), capi.scatter_add(emb, ai, ta))
+    same(ref.scatter_add_bwd(43, ai, ta), capi.scatter_add_bwd(43, ai, ta))
+
+
+def test_occupancy_random(fox_state):
+    st = fox_state
+    rng = np.random.default_rng(11)
+    o, d, _ = _rays(st, rng, 400, all_cams=False)
+    hits = capi.oct_intersect(st["search_order"], o, d, 0.01, 1e8, st["tree_nodes"])
+    noise = np.full(1024 + 400 + 10, 8.0, np.float32)
+    m = capi.ray_march(o, d, noise, 1. / 256., True, *hits, st["tree_nodes"], st["pers_trans"])
+    n = len(m["t"])
+    n_nodes = st["tree_nodes"].size // 64
+    w = (rng.random(n, dtype=np.float32) ** 8).astype(np.float32) * np.float32(0.2)
+    a = (rng.random(n, dtype=np.float32) ** 8).astype(np.float32) * np.float32(0.3)
+    oi = np.ascontiguousarray(m["anchors"][:, 1])
+    cnt0 = rng.integers(0, 3, n_nodes).astype(np.int32)
+    ra = ref.mark_visit(n_nodes, m["pts_idx_bounds"], oi, w, a, cnt0)
+    rb = capi.mark_visit(n_nodes, m["pts_idx_bounds"], oi, w, a, cnt0)
+    for x, y in zip(ra, rb):
+        same(x, y)
+    # stats update (torch integer ops restated) followed by MarkInvalidNodes (reference kernel)
+    ws = rng.integers(-2, 5, n_nodes).astype(np.int32)
+    as_ = rng.integers(-2, 5, n_nodes).astype(np.int32)
+    w2, a2, nodes2 = capi.update_node_stats(rb[0], rb[1], rb[2], ws, as_, st["tree_nodes"])
+    occ = (rb[0] > 0).astype(np.int32)
+    exp_w = np.clip(np.maximum(ws, occ * rb[0]) + rb[2] * (1 - occ) * rb[0], -100, 1 << 20)
+    same(w2, exp_w.astype(np.int32))
+    same(nodes2, ref.mark_invalid(w2, a2, st["tree_nodes"]))
