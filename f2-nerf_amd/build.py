@@ -1,0 +1,121 @@
+"""In-tree build of the native parts (no cmake/ninja needed):
+
+  libf2n_hip.so   the C-ABI library (include/f2n_abi.h): csrc/*.hip compiled by hipcc for gfx950
+  _f2n_host*.so   the C++/LibTorch host layer (csrc/host/*.cpp, pybind11 module) linked against it
+
+Both land next to this file so that they travel with a `gpurun` snapshot.  `-ffp-contract=off` is part of the
+numerical contract with the oracle (integer outputs of the sampler / hash grid depend on the fp32 op order).
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libf2n_hip.so")
+OBJ = os.path.join(HERE, "build")
+
+HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip"]
+HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", os.path.join(INCLUDE, "f2n_abi.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    jobs = []
+    objs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([_hipcc()] + HIPCC_FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-6000:]))
+        return r.stderr
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn.strip():
+                print(warn[-3000:])
+    if force or jobs or not os.path.exists(LIB):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    return LIB
+
+
+def host_module_path():
+    import sysconfig
+    return os.path.join(HERE, "_f2n_host" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_host(force=False, verbose=False):
+    """C++/LibTorch host layer as a pybind11 extension, compiled with g++ against the pip wheel's headers."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    host_dir = os.path.join(CSRC, "host")
+    srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp"))
+    hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")] + [os.path.join(INCLUDE, "f2n_abi.h")]
+    out = host_module_path()
+    os.makedirs(OBJ, exist_ok=True)
+    inc = ["-I" + p for p in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I" + INCLUDE,
+                                                      "-I/opt/rocm/include"]
+    cxx11 = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-DTORCH_EXTENSION_NAME=_f2n_host", "-DTORCH_API_INCLUDE_EXTENSION_H",
+             "-D_GLIBCXX_USE_CXX11_ABI=%d" % cxx11, "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-w"]
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, "host_" + os.path.basename(s).replace(".cpp", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append(["g++"] + flags + inc + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd[:8]), "...", cmd[-3], flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or not os.path.exists(out):
+        libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+        link = ["g++", "-shared"] + objs + ["-o", out, "-L" + libdir, "-L" + HERE, "-Wl,-rpath," + libdir,
+                                            "-Wl,-rpath,$ORIGIN", "-lf2n_hip", "-lc10", "-ltorch_cpu", "-ltorch",
+                                            "-ltorch_python", "-lc10_hip", "-ltorch_hip"]
+        run(link)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    lib = build_hip(force, verbose)
+    host = None
+    if os.path.isdir(os.path.join(CSRC, "host")):
+        host = build_host(force, verbose)
+    return lib, host
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,264 @@
+"""ctypes binding of libf2n_hip.so (include/f2n_abi.h) for torch tensors on a HIP device.
+
+Thin by design: every function checks dtype/contiguity/device, passes raw device pointers and the current
+torch HIP stream, and raises on a non-zero status.  No computation happens here and nothing falls back to
+torch ops or to the CPU oracle."""
+import ctypes
+import os
+
+import torch
+
+from . import build
+
+_lib = None
+
+
+class F2nError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(build.LIB):
+            raise F2nError("native library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % build.LIB)
+        _lib = ctypes.CDLL(build.LIB)
+        _lib.f2n_build_info.restype = ctypes.c_char_p
+    return _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_DT = {"f32": torch.float32, "i32": torch.int32, "u8": torch.uint8, "h16": torch.float16}
+
+
+def _p(t, kind=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return ctypes.c_void_p(0)
+        raise F2nError("required tensor is None")
+    if not t.is_cuda:
+        raise F2nError("tensor must live on the HIP device (no CPU path)")
+    if not t.is_contiguous():
+        raise F2nError("tensor must be contiguous")
+    if kind is not None and t.dtype != _DT[kind]:
+        raise F2nError("expected dtype %s, got %s" % (kind, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _ck(rc, name):
+    if rc != 0:
+        raise F2nError("%s failed with status %d" % (name, rc))
+
+
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+
+def build_info():
+    return lib().f2n_build_info().decode()
+
+
+# ---------------------------------------------------------------- sampler
+def oct_intersect_count(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, hit_counts):
+    _ck(lib().f2n_oct_intersect_count(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
+                                      _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(hit_counts, "i32")),
+        "f2n_oct_intersect_count")
+
+
+def segment_scan(n, counts, start_end, total):
+    _ck(lib().f2n_segment_scan(_stream(), _i(n), _p(counts, "i32"), _p(start_end, "i32"), _p(total, "i32")),
+        "f2n_segment_scan")
+
+
+def oct_intersect_fill(n_rays, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf):
+    _ck(lib().f2n_oct_intersect_fill(_stream(), _i(n_rays), _p(search_order, "u8"), _p(rays_o, "f32"), _p(rays_d, "f32"),
+                                     _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"), _p(oct_idx, "i32"),
+                                     _p(oct_nf, "f32")), "f2n_oct_intersect_fill")
+
+
+def ray_march_count(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes, transes,
+                    counts):
+    _ck(lib().f2n_ray_march_count(_stream(), _i(n_rays), _f(sample_l), _i(int(scale_by_dis)), _p(rays_o, "f32"),
+                                  _p(rays_d, "f32"), _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"),
+                                  _p(oct_nf, "f32"), _p(tree_nodes, "u8"), _p(transes, "u8"), _p(counts, "i32")),
+        "f2n_ray_march_count")
+
+
+def ray_march_fill(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes, transes,
+                   pts_se, pts, dirs, dt, t, anchors, first_oct_dis):
+    _ck(lib().f2n_ray_march_fill(_stream(), _i(n_rays), _f(sample_l), _i(int(scale_by_dis)), _p(rays_o, "f32"),
+                                 _p(rays_d, "f32"), _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"),
+                                 _p(oct_nf, "f32"), _p(tree_nodes, "u8"), _p(transes, "u8"), _p(pts_se, "i32"),
+                                 _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"), _p(anchors, "i32"),
+                                 _p(first_oct_dis, "f32")), "f2n_ray_march_fill")
+
+
+def edge_samples(n, edge_pool, transes, edge_idx, edge_coords, out_pts, out_idx):
+    _ck(lib().f2n_edge_samples(_stream(), _i(n), _p(edge_pool, "u8"), _p(transes, "u8"), _p(edge_idx, "i32"),
+                               _p(edge_coords, "f32"), _p(out_pts, "f32"), _p(out_idx, "i32")), "f2n_edge_samples")
+
+
+def oct_mark_visit(n_rays, pts_se, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt):
+    _ck(lib().f2n_oct_mark_visit(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(anchors, "i32"), _i(anchor_stride),
+                                 _p(weights, "f32"), _p(alphas, "f32"), _p(w_adder, "i32"), _p(a_adder, "i32"),
+                                 _p(mark, "i32"), _p(visit_cnt, "i32")), "f2n_oct_mark_visit")
+
+
+def oct_update_stats(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes):
+    _ck(lib().f2n_oct_update_stats(_stream(), _i(n_nodes), _p(w_adder, "i32"), _p(a_adder, "i32"), _p(mark, "i32"),
+                                   _p(w_stats, "i32"), _p(a_stats, "i32"), _p(tree_nodes, "u8")), "f2n_oct_update_stats")
+
+
+def oct_mark_invisible(n_nodes, n_cams, tree_nodes, intris, w2cs, bounds):
+    _ck(lib().f2n_oct_mark_invisible(_stream(), _i(n_nodes), _i(n_cams), _p(tree_nodes, "u8"), _p(intris, "f32"),
+                                     _p(w2cs, "f32"), _p(bounds, "f32")), "f2n_oct_mark_invisible")
+
+
+# ---------------------------------------------------------------- hash grid / MLP / field
+def hash_fwd(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale, pts, pts_are_warped,
+             volume_idx, vol_stride, out_h):
+    _ck(lib().f2n_hash_fwd(_stream(), _i(n), _i(n_volumes), _p(table_h, "h16"), _p(prim_pool, "i32"), _p(local_idx, "i32"),
+                           _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"), _p(pts, "f32"),
+                           _i(int(pts_are_warped)), _p(volume_idx, "i32"), _i(vol_stride), _p(out_h, "h16")), "f2n_hash_fwd")
+
+
+def hash_bwd(n, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts, pts_are_warped, volume_idx,
+             vol_stride, grad_in_h, grad_table_h):
+    _ck(lib().f2n_hash_bwd(_stream(), _i(n), _i(n_volumes), _p(prim_pool, "i32"), _p(local_idx, "i32"),
+                           _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"), _p(pts, "f32"),
+                           _i(int(pts_are_warped)), _p(volume_idx, "i32"), _i(vol_stride), _p(grad_in_h, "h16"),
+                           _p(grad_table_h, "h16")), "f2n_hash_bwd")
+
+
+def mlp_n_params(d_in, d_hidden, n_hidden):
+    return lib().f2n_mlp_n_params(_i(d_in), _i(d_hidden), _i(n_hidden))
+
+
+def mlp_init_params(seed, d_in, d_hidden, n_hidden, params_f32):
+    _ck(lib().f2n_mlp_init_params(_stream(), ctypes.c_uint64(seed), _i(d_in), _i(d_hidden), _i(n_hidden),
+                                  _p(params_f32, "f32")), "f2n_mlp_init_params")
+
+
+def params_to_h16(n, params_f32, params_h):
+    _ck(lib().f2n_params_to_h16(_stream(), _i(n), _p(params_f32, "f32"), _p(params_h, "h16")), "f2n_params_to_h16")
+
+
+def mlp_fwd(n, d_in, d_hidden, n_hidden, params_h, x, out_h):
+    _ck(lib().f2n_mlp_fwd(_stream(), _i(n), _i(d_in), _i(d_hidden), _i(n_hidden), _p(params_h, "h16"), _p(x, "f32"),
+                          _p(out_h, "h16")), "f2n_mlp_fwd")
+
+
+def mlp_bwd(n, d_in, d_hidden, n_hidden, loss_scale, params_h, x, dy, dparams_scaled, dx):
+    _ck(lib().f2n_mlp_bwd(_stream(), _i(n), _i(d_in), _i(d_hidden), _i(n_hidden), _f(loss_scale), _p(params_h, "h16"),
+                          _p(x, "f32"), _p(dy, "f32"), _p(dparams_scaled, "f32"), _p(dx, "f32", True)), "f2n_mlp_bwd")
+
+
+def field_fwd(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped, volume_idx,
+              vol_stride, mlp_params_h, out_feat, out_f0, save_x_h):
+    _ck(lib().f2n_field_fwd(_stream(), _i(n), _i(n_volumes), _p(table_h, "h16"), _p(prim_pool, "i32"), _p(local_idx, "i32"),
+                            _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"), _p(pts_warped, "f32"),
+                            _p(volume_idx, "i32"), _i(vol_stride), _p(mlp_params_h, "h16"), _p(out_feat, "f32", True),
+                            _p(out_f0, "f32", True), _p(save_x_h, "h16", True)), "f2n_field_fwd")
+
+
+def field_bwd(n, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped, volume_idx, vol_stride,
+              mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_scaled, grad_table_h):
+    _ck(lib().f2n_field_bwd(_stream(), _i(n), _i(n_volumes), _p(prim_pool, "i32"), _p(local_idx, "i32"),
+                            _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"), _p(pts_warped, "f32"),
+                            _p(volume_idx, "i32"), _i(vol_stride), _p(mlp_params_h, "h16"), _p(saved_x_h, "h16"),
+                            _p(dfeat, "f32"), _f(loss_scale), _p(dparams_scaled, "f32"), _p(grad_table_h, "h16")),
+        "f2n_field_bwd")
+
+
+# ---------------------------------------------------------------- shader
+def sh_encode(n, degree, dirs, out):
+    _ck(lib().f2n_sh_encode(_stream(), _i(n), _i(degree), _p(dirs, "f32"), _p(out, "f32")), "f2n_sh_encode")
+
+
+def scatter_idx(n_rays, start_end, ray_val, out):
+    _ck(lib().f2n_scatter_idx(_stream(), _i(n_rays), _p(start_end, "i32"), _p(ray_val, "i32"), _p(out, "i32")),
+        "f2n_scatter_idx")
+
+
+def shade_fwd(n, feat, dirs, app_emb, sample_emb_idx, mlp_params_h, rgb, save_x_h):
+    _ck(lib().f2n_shade_fwd(_stream(), _i(n), _p(feat, "f32"), _p(dirs, "f32"), _p(app_emb, "f32", True),
+                            _p(sample_emb_idx, "i32", True), _p(mlp_params_h, "h16"), _p(rgb, "f32"),
+                            _p(save_x_h, "h16", True)), "f2n_shade_fwd")
+
+
+def shade_bwd(n, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_scaled, dapp_emb):
+    _ck(lib().f2n_shade_bwd(_stream(), _i(n), _p(drgb, "f32"), _p(sample_emb_idx, "i32", True), _p(mlp_params_h, "h16"),
+                            _p(saved_x_h, "h16"), _f(loss_scale), _p(dfeat, "f32"), _p(dparams_scaled, "f32"),
+                            _p(dapp_emb, "f32", True)), "f2n_shade_bwd")
+
+
+# ---------------------------------------------------------------- renderer
+def early_stop(n_rays, pts_se, f0, f0_stride, dt, weights, alphas, mask, kept):
+    _ck(lib().f2n_early_stop(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(f0, "f32"), _i(f0_stride), _p(dt, "f32"),
+                             _p(weights, "f32"), _p(alphas, "f32"), _p(mask, "i32"), _p(kept, "i32")), "f2n_early_stop")
+
+
+def compact_samples(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors):
+    _ck(lib().f2n_compact_samples(_stream(), _i(n_rays), _p(old_se, "i32"), _p(new_se, "i32"), _p(mask, "i32"),
+                                  _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"), _p(anchors, "i32"),
+                                  _p(o_pts, "f32"), _p(o_dirs, "f32"), _p(o_dt, "f32"), _p(o_t, "f32"),
+                                  _p(o_anchors, "i32")), "f2n_compact_samples")
+
+
+def composite_fwd(n_rays, pts_se, feat, dt, t, rgb, bg, colors, disparity, depth, weights):
+    _ck(lib().f2n_composite_fwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _p(dt, "f32"), _p(t, "f32"),
+                                _p(rgb, "f32"), _p(bg, "f32"), _p(colors, "f32"), _p(disparity, "f32"), _p(depth, "f32"),
+                                _p(weights, "f32")), "f2n_composite_fwd")
+
+
+def composite_bwd(n_rays, pts_se, feat, dt, t, rgb, bg, dcolors, ddisp, ddepth, dweights, gs_progress, drgb, dfeat):
+    _ck(lib().f2n_composite_bwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _p(dt, "f32"), _p(t, "f32"),
+                                _p(rgb, "f32"), _p(bg, "f32"), _p(dcolors, "f32", True), _p(ddisp, "f32", True),
+                                _p(ddepth, "f32", True), _p(dweights, "f32", True), _f(gs_progress), _p(drgb, "f32"),
+                                _p(dfeat, "f32")), "f2n_composite_bwd")
+
+
+def weight_var_fwd(n_rays, weights, pts_se, out):
+    _ck(lib().f2n_weight_var_fwd(_stream(), _i(n_rays), _p(weights, "f32"), _p(pts_se, "i32"), _p(out, "f32")),
+        "f2n_weight_var_fwd")
+
+
+def weight_var_bwd(n_rays, weights, pts_se, dvars, dweights):
+    _ck(lib().f2n_weight_var_bwd(_stream(), _i(n_rays), _p(weights, "f32"), _p(pts_se, "i32"), _p(dvars, "f32"),
+                                 _p(dweights, "f32")), "f2n_weight_var_bwd")
+
+
+def flex_sum_fwd(n_rays, vec, val, se, out):
+    _ck(lib().f2n_flex_sum_fwd(_stream(), _i(n_rays), _i(vec), _p(val, "f32"), _p(se, "i32"), _p(out, "f32")), "f2n_flex_sum_fwd")
+
+
+def flex_sum_bwd(n_rays, vec, dsum, se, out):
+    _ck(lib().f2n_flex_sum_bwd(_stream(), _i(n_rays), _i(vec), _p(dsum, "f32"), _p(se, "i32"), _p(out, "f32")), "f2n_flex_sum_bwd")
+
+
+def flex_acc_fwd(n_rays, include_this, val, se, out):
+    _ck(lib().f2n_flex_acc_fwd(_stream(), _i(n_rays), _i(int(include_this)), _p(val, "f32"), _p(se, "i32"), _p(out, "f32")),
+        "f2n_flex_acc_fwd")
+
+
+def flex_acc_bwd(n_rays, include_this, dsum, se, out):
+    _ck(lib().f2n_flex_acc_bwd(_stream(), _i(n_rays), _i(int(include_this)), _p(dsum, "f32"), _p(se, "i32"), _p(out, "f32")),
+        "f2n_flex_acc_bwd")
+
+
+# ---------------------------------------------------------------- optimiser
+def adam_step(n, param, grad, grad_scale, grad_round_h16, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h):
+    _ck(lib().f2n_adam_step(_stream(), _i(n), _p(param, "f32"), _p(grad, "f32"), _f(grad_scale), _i(int(grad_round_h16)),
+                            _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _f(beta1), _f(beta2), _f(eps),
+                            _f(wd), _p(param_h, "h16", True)), "f2n_adam_step")
+
+
+def adam_step_h16grad(n, param, grad_h, grad_scale, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
+                      zero_grad):
+    _ck(lib().f2n_adam_step_h16grad(_stream(), _i(n), _p(param, "f32"), _p(grad_h, "h16"), _f(grad_scale),
+                                    _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _f(beta1), _f(beta2),
+                                    _f(eps), _f(wd), _p(param_h, "h16"), _i(int(zero_grad))), "f2n_adam_step_h16grad")

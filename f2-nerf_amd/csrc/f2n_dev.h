@@ -1,0 +1,109 @@
+// Shared device-side definitions for the gfx950 kernels of the f2-nerf hot path.
+// Everything in csrc/ is built with -ffp-contract=off: the oracle (oracle/f2n_oracle.c) fixes the fp32
+// operation order, and integer outputs (sample counts, leaf lists, hash cells) depend on it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/f2n_abi.h"
+
+#define F2N_WAVE 64
+
+typedef _Float16 half_t;
+typedef half_t half2_t __attribute__((ext_vector_type(2)));
+typedef half_t half4_t __attribute__((ext_vector_type(4)));
+typedef half_t half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// Byte-compatible with PtsSampler/PersSampler.h:15-37 (checked against the reference build in
+// tests/test_oracle_vs_ref.py::test_layout_facts).
+struct alignas(32) F2nTreeNode {
+  float center[3];       // @0
+  float side_len;        // @12
+  int32_t parent;        // @16
+  int32_t childs[8];     // @20
+  uint8_t is_leaf_node;  // @52
+  uint8_t pad0[3];
+  int32_t trans_idx;     // @56
+  uint8_t pad1[4];
+};
+struct alignas(32) F2nTransInfo {
+  float w2xz[12][2][4];  // @0
+  float weight[3][12];   // @384
+  float center[3];       // @528
+  float dis_summary;     // @540
+};
+struct alignas(32) F2nEdgePool {
+  int32_t t_idx_a, t_idx_b;
+  float center[3], dir_0[3], dir_1[3];
+  uint8_t pad[20];
+};
+static_assert(sizeof(F2nTreeNode) == 64 && sizeof(F2nTransInfo) == 544 && sizeof(F2nEdgePool) == 64, "layout");
+
+static inline int f2n_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? F2N_OK : -(1000 + (int) e);
+}
+
+static inline unsigned f2n_div_up(long a, long b) { return (unsigned) ((a + b - 1) / b); }
+
+// ---- reductions in the order Eigen's scalar fixed-size unrollers use (n/2 | n - n/2 recursive split) ----
+__device__ __forceinline__ float f2n_sum3(float a, float b, float c) { return a + (b + c); }
+__device__ __forceinline__ float f2n_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
+__device__ __forceinline__ float f2n_sum12(const float* e) {
+  return ((e[0] + (e[1] + e[2])) + (e[3] + (e[4] + e[5]))) + ((e[6] + (e[7] + e[8])) + (e[9] + (e[10] + e[11])));
+}
+__device__ __forceinline__ float f2n_norm3(float x, float y, float z) { return sqrtf(f2n_sum3(x * x, y * y, z * z)); }
+
+// float -> u32 with the saturating semantics of v_cvt_u32_f32 / CUDA cvt.rzi.u32.f32, spelled out so the
+// compiler cannot treat the out-of-range cast as undefined behaviour.
+__device__ __forceinline__ uint32_t f2n_f2u_sat(float f) {
+  if (!(f > 0.f)) return 0u;
+  if (f >= 4294967296.f) return 0xffffffffu;
+  return (uint32_t) f;
+}
+
+// Warp of one point by one leaf's perspective transform (PersSampler.cu:155-169) and its Jacobian (:171-187).
+__device__ __forceinline__ void f2n_proj(const float* __restrict__ m /*2x4*/, const float* p, float& x, float& z) {
+  x = f2n_sum4(m[0] * p[0], m[1] * p[1], m[2] * p[2], m[3] * 1.f);
+  z = f2n_sum4(m[4] * p[0], m[5] * p[1], m[6] * p[2], m[7] * 1.f);
+}
+
+__device__ __forceinline__ void f2n_warp(const F2nTransInfo* __restrict__ tr, const float* p, float* out) {
+  float v[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    float x, z;
+    f2n_proj(&tr->w2xz[i][0][0], p, x, z);
+    v[i] = x / z;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float e[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) e[i] = tr->weight[r][i] * v[i];
+    out[r] = f2n_sum12(e);
+  }
+}
+
+__device__ __forceinline__ void f2n_warp_jac(const F2nTransInfo* __restrict__ tr, const float* p, float jac[3][3]) {
+  float tj[12][3];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    float x, z;
+    f2n_proj(&tr->w2xz[i][0][0], p, x, z);
+    float d0 = 1 / z;
+    float d1 = -x / (z * z);
+#pragma unroll
+    for (int c = 0; c < 3; c++) tj[i][c] = d0 * tr->w2xz[i][0][c] + d1 * tr->w2xz[i][1][c];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float e[12];
+#pragma unroll
+      for (int i = 0; i < 12; i++) e[i] = tr->weight[r][i] * tj[i][c];
+      jac[r][c] = f2n_sum12(e);
+    }
+}

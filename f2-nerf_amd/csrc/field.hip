@@ -1,0 +1,447 @@
+// Hash3DAnchored on gfx950: the 16-level anchored hash-grid gather / scatter (Field/Hash3DAnchored.cu:11-233)
+// fused with the density MLP (Field/TCNNWP.cpp call sites).  One wave64 owns 16 samples at a time; lane
+// (c = sample, g = lane >> 4) gathers the four levels {2g, 2g+1, 8+2g, 9+2g} of its sample, which are exactly
+// the K-slots of the MFMA fragment it has to supply (mlp_dev.h), so features go from the L2/Infinity-Cache
+// resident table straight into matrix-core operands: no LDS staging, no HBM round trip of the [n,32] features.
+#include "mlp_dev.h"
+
+struct F2nHashArgs {
+  const half_t* table;        // h16 [pool, 2]
+  const int32_t* prim_pool;   // [16, V, 3]
+  const float* bias_pool;     // [16*V, 3]
+  int n_volumes;
+};
+
+struct F2nLevelTab {  // staged in LDS once per block
+  float scale[F2N_N_LEVELS];
+  int32_t base[F2N_N_LEVELS];   // level offset in HALVES (Hash3DAnchored.cu:37: added to a half pointer)
+  uint32_t size[F2N_N_LEVELS];  // entries addressed per level
+};
+
+__device__ __forceinline__ void f2n_level_tab_fill(F2nLevelTab& s, const float* level_scale, const int32_t* local_idx,
+                                                   const int32_t* local_size, int tid) {
+  if (tid < F2N_N_LEVELS) {
+    s.scale[tid] = level_scale[tid];
+    s.base[tid] = local_idx[tid];
+    s.size[tid] = (uint32_t) local_size[tid];
+  }
+}
+
+// The level a lane group serves for feature-pair j = 0..3 (features sigma(g, 2j..2j+1)).
+__device__ __forceinline__ int f2n_level_of(int g, int j) { return (j < 2) ? 2 * g + j : 8 + 2 * g + (j - 2); }
+
+struct F2nCell {
+  uint32_t pos[8];
+  float w[8];
+};
+
+// Cell lookup of one (point, level): Hash3DAnchored.cu:27-69.  p01 is the query point in [0,1] coordinates.
+__device__ __forceinline__ void f2n_hash_cell(const float* p01, float mul, const int32_t* __restrict__ prim3,
+                                              const float* __restrict__ bias3, uint32_t lsize, F2nCell& cell) {
+  float q[3], fl[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    q[k] = p01[k] * mul + bias3[k];
+    fl[k] = floorf(q[k]);
+  }
+  const uint32_t px = f2n_f2u_sat(fl[0]), py = f2n_f2u_sat(fl[1]), pz = f2n_f2u_sat(fl[2]);
+  const uint32_t pa = (uint32_t) prim3[0], pb = (uint32_t) prim3[1], pc = (uint32_t) prim3[2];
+  const uint32_t hx[2] = {px * pa, (px + 1u) * pa}, hy[2] = {py * pb, (py + 1u) * pb}, hz[2] = {pz * pc, (pz + 1u) * pc};
+  const bool pow2 = (lsize & (lsize - 1u)) == 0u;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {  // 000,001,010,011,100,101,110,111 = (x,y,z) bits
+    const uint32_t h = hx[(corner >> 2) & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner & 1];
+    cell.pos[corner] = pow2 ? (h & (lsize - 1u)) : (h % lsize);
+  }
+  const float a = q[0] - fl[0], b = q[1] - fl[1], c = q[2] - fl[2];
+  cell.w[0] = (1.f - a) * (1.f - b) * (1.f - c);
+  cell.w[1] = (1.f - a) * (1.f - b) * c;
+  cell.w[2] = (1.f - a) * b * (1.f - c);
+  cell.w[3] = (1.f - a) * b * c;
+  cell.w[4] = a * (1.f - b) * (1.f - c);
+  cell.w[5] = a * (1.f - b) * c;
+  cell.w[6] = a * b * (1.f - c);
+  cell.w[7] = a * b * c;
+}
+
+// Gathers this lane's four levels of one sample: returns the X row fragment (8 halves).
+__device__ __forceinline__ half8_t f2n_gather_frag(const F2nHashArgs& h, const F2nLevelTab& lt, const float* p01, int vol,
+                                                   int g, bool valid) {
+  half8_t xf;
+  F2nCell cell[4];
+  half2_t v[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int l = f2n_level_of(g, j);
+    const int tf = l * h.n_volumes + vol;
+    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell[j]);
+    const half2_t* base = (const half2_t*) (h.table + lt.base[l]);
+#pragma unroll
+    for (int d = 0; d < 8; d++) v[j][d] = base[cell[j].pos[d]];  // 32 independent 4-byte gathers in flight
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    float s0 = cell[j].w[0] * (float) v[j][0][0];
+    float s1 = cell[j].w[0] * (float) v[j][0][1];
+#pragma unroll
+    for (int d = 1; d < 8; d++) {
+      s0 = s0 + cell[j].w[d] * (float) v[j][d][0];
+      s1 = s1 + cell[j].w[d] * (float) v[j][d][1];
+    }
+    xf[2 * j] = valid ? (half_t) s0 : (half_t) 0.f;
+    xf[2 * j + 1] = valid ? (half_t) s1 : (half_t) 0.f;
+  }
+  return xf;
+}
+
+// Scatters this lane's four levels: gx[2j + ch] is the f16 (loss-scaled) gradient of feature sigma(g, 2j+ch).
+// global_atomic_pk_add_f16 == the reference's atomicAdd(__half2*) (Hash3DAnchored.cu:150-151).
+__device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2nLevelTab& lt, half_t* __restrict__ grad_table,
+                                                 const float* p01, int vol, int g, half8_t gx) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float g0 = (float) gx[2 * j], g1 = (float) gx[2 * j + 1];
+    if (g0 == 0.f && g1 == 0.f) continue;  // :149
+    const int l = f2n_level_of(g, j);
+    const int tf = l * h.n_volumes + vol;
+    F2nCell cell;
+    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
+    half2_t* base = (half2_t*) (grad_table + lt.base[l]);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      half2_t val = {(half_t) (g0 * cell.w[d]), (half_t) (g1 * cell.w[d])};
+      __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (base + cell.pos[d]), val);
+    }
+  }
+}
+
+__device__ __forceinline__ void f2n_load_point(const float* __restrict__ pts, int s, bool warped, float* p01) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float p = pts[3 * (size_t) s + k];
+    p01[k] = warped ? (p + 1.f) * .5f : p;  // Hash3DAnchored.cpp:91
+  }
+}
+
+// X row fragment from a row-major [n][32] array (h16 or fp32).
+__device__ __forceinline__ half8_t f2n_load_xfrag_h(const half_t* __restrict__ x, int s, int g, bool valid) {
+  if (!valid) return half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  return f2n_rowfrag(x, F2N_D_IN, s, 0, g);
+}
+__device__ __forceinline__ half8_t f2n_load_xfrag_f32(const float* __restrict__ x, int s, int g, bool valid) {
+  half8_t r = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (valid) {
+    const float4_t lo = *(const float4_t*) (x + (size_t) s * F2N_D_IN + 4 * g);
+    const float4_t hi = *(const float4_t*) (x + (size_t) s * F2N_D_IN + 16 + 4 * g);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      r[i] = (half_t) lo[i];
+      r[4 + i] = (half_t) hi[i];
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ void f2n_store_xfrag_h(half_t* __restrict__ x, int s, int g, half8_t xf) {
+  half_t* p = x + (size_t) s * F2N_D_IN + 4 * g;
+  *(half4_t*) p = __builtin_shufflevector(xf, xf, 0, 1, 2, 3);
+  *(half4_t*) (p + 16) = __builtin_shufflevector(xf, xf, 4, 5, 6, 7);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Forward: hash gather (optional) -> MLP (optional).  4 waves per block, each wave strides over
+// 16-sample blocks.
+// ---------------------------------------------------------------------------------------------------
+#define F2N_FWD_THREADS 256
+
+template <int NH, bool DO_HASH, bool DO_MLP>
+__global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
+    int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
+    const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
+    const int32_t* __restrict__ volume_idx, int vol_stride, const float* __restrict__ x_f32,
+    const half_t* __restrict__ params, float* __restrict__ out_feat_f32, half_t* __restrict__ out_feat_h,
+    float* __restrict__ out_f0, half_t* __restrict__ save_x) {
+  __shared__ F2nLevelTab lt;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  if (DO_HASH) {
+    f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+    __syncthreads();
+  }
+  F2nMlpFwdW<NH> w;
+  if (DO_MLP) w.load(params, c, g);
+  const int n_blocks = (n + 15) / 16;
+  const int wave_global = blockIdx.x * (F2N_FWD_THREADS / 64) + (tid >> 6);
+  const int wave_stride = gridDim.x * (F2N_FWD_THREADS / 64);
+  for (int blk = wave_global; blk < n_blocks; blk += wave_stride) {
+    const int s = blk * 16 + c;
+    const bool valid = s < n;
+    const int sc = valid ? s : n - 1;
+    half8_t xf;
+    if (DO_HASH) {
+      float p01[3];
+      f2n_load_point(pts, sc, pts_are_warped != 0, p01);
+      const int vol = volume_idx[(size_t) sc * vol_stride];
+      xf = f2n_gather_frag(h, lt, p01, vol, g, valid);
+    } else {
+      xf = f2n_load_xfrag_f32(x_f32, sc, g, valid);
+    }
+    if (save_x != nullptr && valid) f2n_store_xfrag_h(save_x, s, g, xf);
+    if (DO_MLP) {
+      const float4_t o = w.forward(xf);  // lane (c = sample, g): outputs 4g..4g+3
+      if (valid) {
+        half4_t oh;
+        float4_t of;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          oh[r] = (half_t) o[r];  // output precision is f16 (TCNNWP.cpp:143-144)
+          of[r] = (float) oh[r];
+        }
+        if (out_feat_f32 != nullptr) *(float4_t*) (out_feat_f32 + (size_t) s * F2N_D_OUT + 4 * g) = of;
+        if (out_feat_h != nullptr) *(half4_t*) (out_feat_h + (size_t) s * F2N_D_OUT + 4 * g) = oh;
+        if (out_f0 != nullptr && g == 0) out_f0[s] = of[0];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward: MLP backward (recompute + both orientations, mlp_dev.h) chained into the hash scatter.
+// One wave handles 32-sample super-blocks (two 16-sample halves) so that the weight-gradient contraction
+// over samples fills a K = 32 MFMA.
+// ---------------------------------------------------------------------------------------------------
+#define F2N_BWD_THREADS 256
+
+template <int NH>
+union F2nBwdSmem {
+  F2nMlpLds<NH> w;
+  float acc[F2N_D_HID * F2N_D_IN + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0) + F2N_D_OUT * F2N_D_HID];
+};
+
+template <int NH, bool DO_HASH>
+__global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
+    int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
+    const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
+    const int32_t* __restrict__ volume_idx, int vol_stride, const half_t* __restrict__ params,
+    const half_t* __restrict__ x_h, const float* __restrict__ x_f32, const float* __restrict__ dy, float loss_scale,
+    float* __restrict__ dparams, float* __restrict__ dx_f32, half_t* __restrict__ grad_table) {
+  __shared__ F2nBwdSmem<NH> sm;
+  __shared__ F2nLevelTab lt;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  if (DO_HASH) f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+  f2n_mlp_lds_fill<NH>(sm.w, params, tid, F2N_BWD_THREADS);
+  __syncthreads();
+  const half8_t idf[2] = {f2n_identity_frag(0, c, g), f2n_identity_frag(1, c, g)};
+  F2nMlpGradAcc<NH> acc;
+  acc.zero();
+  const int n_super = (n + 31) / 32;
+  const int wave_global = blockIdx.x * (F2N_BWD_THREADS / 64) + (tid >> 6);
+  const int wave_stride = gridDim.x * (F2N_BWD_THREADS / 64);
+  const float inv_scale = 1.f / loss_scale;
+  for (int sb = wave_global; sb < n_super; sb += wave_stride) {
+    F2nHalfBwd<NH> hb[2];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int s = sb * 32 + half * 16 + c;
+      const bool valid = s < n;
+      const int sc = valid ? s : n - 1;
+      const half8_t xf = (x_h != nullptr) ? f2n_load_xfrag_h(x_h, sc, g, valid) : f2n_load_xfrag_f32(x_f32, sc, g, valid);
+      half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid) {
+        const float4_t d4 = *(const float4_t*) (dy + (size_t) s * F2N_D_OUT + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dyf[r] = (half_t) ((float) (half_t) d4[r] * loss_scale);  // f16 cast by autograd, then *scale (TCNNWP.cpp:174)
+      }
+      f2n_mlp_half_bwd<NH, 2>(sm.w, xf, dyf, idf, c, g, hb[half]);
+      if (valid) {
+        if (dx_f32 != nullptr) {
+#pragma unroll
+          for (int ft = 0; ft < 2; ft++) {
+            float4_t v;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = hb[half].dxT[ft][r] * inv_scale;  // TCNNWP.cpp:231
+            *(float4_t*) (dx_f32 + (size_t) s * F2N_D_IN + 16 * ft + 4 * g) = v;
+          }
+        }
+        if (DO_HASH) {
+          float p01[3];
+          f2n_load_point(pts, s, pts_are_warped != 0, p01);
+          const int vol = volume_idx[(size_t) s * vol_stride];
+          const half8_t gx = f2n_pack<false>(hb[half].dxT[0], hb[half].dxT[1]);  // (dL/dx * 128) -> f16, Hash3DAnchored.cu:220
+          f2n_scatter_frag(h, lt, grad_table, p01, vol, g, gx);
+        }
+      }
+    }
+    f2n_mlp_accumulate_dw<NH>(hb[0], hb[1], acc);
+  }
+  __syncthreads();  // everyone is done with the LDS weights: reuse the space for the block reduction
+  const int n_params = F2N_D_HID * F2N_D_IN + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0) + F2N_D_OUT * F2N_D_HID;
+  for (int i = tid; i < n_params; i += F2N_BWD_THREADS) sm.acc[i] = 0.f;
+  __syncthreads();
+  f2n_mlp_flush_dw<NH>(acc, sm.acc, dparams, c, g, tid, F2N_BWD_THREADS);
+}
+
+// Stand-alone hash scatter (seam-level f2n_hash_bwd): grad_in is h16 [n,32].
+__global__ __launch_bounds__(256) void hash_bwd_kernel(int n, F2nHashArgs h, const int32_t* __restrict__ local_idx,
+                                                       const int32_t* __restrict__ local_size,
+                                                       const float* __restrict__ level_scale, const float* __restrict__ pts,
+                                                       int pts_are_warped, const int32_t* __restrict__ volume_idx,
+                                                       int vol_stride, const half_t* __restrict__ grad_in,
+                                                       half_t* __restrict__ grad_table) {
+  __shared__ F2nLevelTab lt;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+  __syncthreads();
+  const int n_blocks = (n + 15) / 16;
+  const int wave_global = blockIdx.x * 4 + (tid >> 6);
+  const int wave_stride = gridDim.x * 4;
+  for (int blk = wave_global; blk < n_blocks; blk += wave_stride) {
+    const int s = blk * 16 + c;
+    if (s >= n) continue;
+    float p01[3];
+    f2n_load_point(pts, s, pts_are_warped != 0, p01);
+    const int vol = volume_idx[(size_t) s * vol_stride];
+    const half8_t gx = f2n_rowfrag(grad_in, F2N_D_IN, s, 0, g);
+    f2n_scatter_frag(h, lt, grad_table, p01, vol, g, gx);
+  }
+}
+
+__global__ void mlp_init_kernel(uint64_t seed, int d_in, int d_hidden, int n_hidden, float* __restrict__ params) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n0 = d_hidden * d_in, n1 = (n_hidden - 1) * d_hidden * d_hidden, no = F2N_D_OUT * d_hidden;
+  if (i >= n0 + n1 + no) return;
+  int fan_in, fan_out;
+  if (i < n0) { fan_in = d_in; fan_out = d_hidden; }
+  else if (i < n0 + n1) { fan_in = d_hidden; fan_out = d_hidden; }
+  else { fan_in = d_hidden; fan_out = F2N_D_OUT; }
+  // splitmix64 counter hash -> U[0,1) -> Xavier uniform
+  uint64_t zz = seed + 0x9e3779b97f4a7c15ull * (uint64_t) (i + 1);
+  zz = (zz ^ (zz >> 30)) * 0xbf58476d1ce4e5b9ull;
+  zz = (zz ^ (zz >> 27)) * 0x94d049bb133111ebull;
+  zz = zz ^ (zz >> 31);
+  const float u = (float) (zz >> 40) * (1.f / 16777216.f);
+  const float scale = sqrtf(6.f / (float) (fan_in + fan_out));
+  params[i] = (u * 2.f - 1.f) * scale;
+}
+
+__global__ void to_h16_kernel(int n, const float* __restrict__ in, half_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (half_t) in[i];
+}
+
+static inline unsigned f2n_wave_grid(int n_units, int waves_per_block) {
+  // enough blocks to fill 256 CUs several times over, capped so that each wave still amortises its setup
+  long blocks = ((long) n_units + waves_per_block - 1) / waves_per_block;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (unsigned) blocks;
+}
+
+static inline bool f2n_mlp_shape_ok(int d_in, int d_hidden, int n_hidden) {
+  return d_in == F2N_D_IN && d_hidden == F2N_D_HID && (n_hidden == 1 || n_hidden == 2);
+}
+
+extern "C" {
+
+int f2n_mlp_n_params(int d_in, int d_hidden, int n_hidden) {
+  if (d_in <= 0 || d_hidden <= 0 || n_hidden < 1) return F2N_ERR_INVALID_ARG;
+  return d_hidden * d_in + (n_hidden - 1) * d_hidden * d_hidden + F2N_D_OUT * d_hidden;
+}
+
+int f2n_mlp_init_params(void* stream, uint64_t seed, int d_in, int d_hidden, int n_hidden, float* params_f32) {
+  const int n = f2n_mlp_n_params(d_in, d_hidden, n_hidden);
+  if (n < 0) return n;
+  hipLaunchKernelGGL(mlp_init_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, seed, d_in, d_hidden,
+                     n_hidden, params_f32);
+  return f2n_launch_status();
+}
+
+int f2n_params_to_h16(void* stream, int n, const float* params_f32, void* params_h) {
+  if (n < 0) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(to_h16_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n, params_f32,
+                     (half_t*) params_h);
+  return f2n_launch_status();
+}
+
+int f2n_hash_fwd(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                 const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                 const float* pts, int pts_are_warped, const int32_t* volume_idx, int vol_stride, void* out_h) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
+  hipLaunchKernelGGL((field_fwd_kernel<1, true, false>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
+                     (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx,
+                     vol_stride, nullptr, nullptr, nullptr, nullptr, nullptr, (half_t*) out_h);
+  return f2n_launch_status();
+}
+
+int f2n_hash_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
+                 const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts,
+                 int pts_are_warped, const int32_t* volume_idx, int vol_stride, const void* grad_in_h, void* grad_table_h) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
+  hipLaunchKernelGGL(hash_bwd_kernel, dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, h,
+                     local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride,
+                     (const half_t*) grad_in_h, (half_t*) grad_table_h);
+  return f2n_launch_status();
+}
+
+int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const void* params_h, const float* x, void* out_h) {
+  if (n < 0) return F2N_ERR_INVALID_ARG;
+  if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
+  const dim3 grid(f2n_wave_grid((n + 15) / 16, 4)), block(F2N_FWD_THREADS);
+  if (n_hidden == 1)
+    hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL((field_fwd_kernel<2, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float loss_scale, const void* params_h,
+                const float* x, const float* dy, float* dparams_f32_scaled, float* dx_f32) {
+  if (n < 0 || !(loss_scale > 0.f)) return F2N_ERR_INVALID_ARG;
+  if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
+  const dim3 grid(f2n_wave_grid((n + 31) / 32, 4 * 4)), block(F2N_BWD_THREADS);
+  if (n_hidden == 1)
+    hipLaunchKernelGGL((field_bwd_kernel<1, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, dparams_f32_scaled, dx_f32, nullptr);
+  else
+    hipLaunchKernelGGL((field_bwd_kernel<2, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, dparams_f32_scaled, dx_f32, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                  const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                  const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
+                  float* out_feat_f32, float* out_f0, void* save_x_h) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
+  hipLaunchKernelGGL((field_fwd_kernel<1, true, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
+                     (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
+                     nullptr, (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h);
+  return f2n_launch_status();
+}
+
+int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
+                  const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts_warped,
+                  const int32_t* volume_idx, int vol_stride, const void* mlp_params_h, const void* saved_x_h,
+                  const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f)) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
+  hipLaunchKernelGGL((field_bwd_kernel<1, true>), dim3(f2n_wave_grid((n + 31) / 32, 4 * 2)), dim3(F2N_BWD_THREADS), 0,
+                     (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
+                     (const half_t*) mlp_params_h, (const half_t*) saved_x_h, nullptr, dfeat, loss_scale,
+                     dparams_f32_scaled, nullptr, (half_t*) grad_table_h);
+  return f2n_launch_status();
+}
+
+}  // extern "C"

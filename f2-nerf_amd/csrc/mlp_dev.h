@@ -1,0 +1,350 @@
+// Register-resident fully-fused MLP on the gfx950 matrix cores (v_mfma_f32_16x16x32_f16).
+//
+// Replaces tiny-cuda-nn's FullyFusedMLP (Field/TCNNWP.cpp:79-243 call sites) for the two networks of the
+// reference configs: 32 -> 64 (-> 64) -> 16, ReLU, no bias, fp16 weights and inter-layer activations, fp32
+// accumulation.  This is NOT a WMMA-shaped tiling recompiled for AMD: there is no LDS staging of activations
+// and no block-level barrier in the forward path.  One wave64 owns 16 samples at a time and the whole layer
+// chain lives in its VGPRs:
+//
+//   mfma(A,B): D[i][j] = sum_k A[i][k] * B[k][j];  lane l = (c = l & 15, g = l >> 4)
+//     A operand: lane holds A[c][slot(g, 0..7)]      B operand: lane holds B[slot(g, 0..7)][c]
+//     D result : lane holds D[4g + r][c], r = 0..3
+//
+//   "row fragment" of a matrix M[rows][K] (tile row0, k0): lane (c,g) holds M[row0 + c][k0 + sigma(g,e)],
+//   e = 0..7, with the K-slot map  sigma(g,e) = 16*(e>>2) + 4g + (e&3).
+//   Because A and B use the SAME slot map the contraction is independent of how the hardware labels K.
+//   sigma is chosen so that the D tiles of one MFMA ARE the row fragment of the next one: the four fp32
+//   results a lane holds for output tile 2q (rows 4g..4g+3) and tile 2q+1 fill slots e = 0..3 and 4..7 of the
+//   K-block q of the following layer.  Hence:
+//
+//     sample-column orientation:  T[neuron][sample] = mfma(A = W row fragment, B = X row fragment)
+//        -> relu -> cvt f16 -> is the X row fragment of the next layer (no transpose, no LDS).
+//     sample-row orientation:     T'[sample][neuron] = mfma(A = X row fragment, B = W row fragment)
+//        -> lanes hold 4 consecutive SAMPLES of one neuron: exactly the row fragment needed when the
+//           contraction runs over samples (weight gradients).  Any tile can be re-oriented with one MFMA
+//           against an identity fragment (exact for f16 data).
+#pragma once
+#include "f2n_dev.h"
+
+#define F2N_D_IN 32
+#define F2N_D_HID 64
+#define F2N_D_OUT 16
+
+__device__ __forceinline__ float4_t f2n_mfma(half8_t a, half8_t b, float4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ half8_t f2n_cat(half4_t lo, half4_t hi) {
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Row fragment straight from memory (global or LDS): M is row-major with leading dimension ld (halves).
+__device__ __forceinline__ half8_t f2n_rowfrag(const half_t* M, int ld, int row, int k0, int g) {
+  const half_t* p = M + (size_t) row * ld + k0 + 4 * g;
+  return f2n_cat(*(const half4_t*) p, *(const half4_t*) (p + 16));
+}
+
+// Two fp32 D tiles -> f16 row fragment of the next contraction (optionally through ReLU).
+template <bool RELU>
+__device__ __forceinline__ half8_t f2n_pack(float4_t a, float4_t b) {
+  half8_t r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float x = a[i], y = b[i];
+    if (RELU) {
+      x = x > 0.f ? x : 0.f;
+      y = y > 0.f ? y : 0.f;
+    }
+    r[i] = (half_t) x;
+    r[4 + i] = (half_t) y;
+  }
+  return r;
+}
+
+template <bool RELU>
+__device__ __forceinline__ half4_t f2n_cvt4(float4_t a) {
+  half4_t r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r[i] = (half_t) ((RELU && !(a[i] > 0.f)) ? 0.f : a[i]);
+  return r;
+}
+
+// D tile masked by the sign of a pre-activation tile (ReLU backward), both in the same orientation.
+__device__ __forceinline__ float4_t f2n_relu_mask(float4_t grad, float4_t pre) {
+  float4_t r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r[i] = pre[i] > 0.f ? grad[i] : 0.f;
+  return r;
+}
+
+// Identity row fragment: I_ft[c][k] = (k == 16*ft + c).  mfma(A = X fragment, B = this) re-orients a tile.
+__device__ __forceinline__ half8_t f2n_identity_frag(int ft, int c, int g) {
+  half8_t r;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int k = 16 * (e >> 2) + 4 * g + (e & 3);
+    r[e] = (k == 16 * ft + c) ? (half_t) 1.f : (half_t) 0.f;
+  }
+  return r;
+}
+
+// Weight fragments of one MLP held in registers for the forward chain.
+template <int NH>
+struct F2nMlpFwdW {
+  half8_t w0[4];                   // layer 0: 64x32, tiles of 16 neurons
+  half8_t w1[NH == 2 ? 8 : 1];     // layer 1: 64x64, [tile][k-block]
+  half8_t wo[2];                   // output: 16x64, [k-block]
+
+  __device__ __forceinline__ void load(const half_t* __restrict__ params, int c, int g) {
+    const half_t* p = params;
+#pragma unroll
+    for (int t = 0; t < 4; t++) w0[t] = f2n_rowfrag(p, F2N_D_IN, 16 * t + c, 0, g);
+    p += F2N_D_HID * F2N_D_IN;
+    if (NH == 2) {
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) w1[t * 2 + q] = f2n_rowfrag(p, F2N_D_HID, 16 * t + c, 32 * q, g);
+      p += F2N_D_HID * F2N_D_HID;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) wo[q] = f2n_rowfrag(p, F2N_D_HID, c, 32 * q, g);
+  }
+
+  // xf: row fragment of X[sample][32].  Returns O^T tile: lane (c = sample, g) holds outputs 4g..4g+3 (fp32,
+  // not yet rounded to the f16 output precision).
+  __device__ __forceinline__ float4_t forward(half8_t xf) const {
+    const float4_t z = {0.f, 0.f, 0.f, 0.f};
+    float4_t t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = f2n_mfma(w0[i], xf, z);
+    half8_t h0 = f2n_pack<true>(t[0], t[1]), h1 = f2n_pack<true>(t[2], t[3]);
+    if (NH == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        t[i] = f2n_mfma(w1[i * 2], h0, z);
+        t[i] = f2n_mfma(w1[i * 2 + 1], h1, t[i]);
+      }
+      h0 = f2n_pack<true>(t[0], t[1]);
+      h1 = f2n_pack<true>(t[2], t[3]);
+    }
+    float4_t o = f2n_mfma(wo[0], h0, z);
+    return f2n_mfma(wo[1], h1, o);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Backward: weights and their transposes live in LDS (padded rows: +4 halves keeps ds_read_b64 fragment
+// reads conflict-free), weight-gradient accumulators live in registers for the whole kernel.
+// ---------------------------------------------------------------------------------------------------
+#define F2N_LD32 36  // leading dimension of [*][32] LDS matrices
+#define F2N_LD64 68  // leading dimension of [*][64] LDS matrices
+
+template <int NH>
+struct F2nMlpLds {
+  half_t w0[F2N_D_HID * F2N_LD32];                      // W0   [64][32]
+  half_t w0t[F2N_D_IN * F2N_LD64];                      // W0^T [32][64]
+  half_t w1[NH == 2 ? F2N_D_HID * F2N_LD64 : 4];        // W1   [64][64]
+  half_t w1t[NH == 2 ? F2N_D_HID * F2N_LD64 : 4];       // W1^T [64][64]
+  half_t wot[F2N_D_HID * F2N_LD32];                     // Wo^T [64][16 | 16 zeros]
+};
+
+template <int NH>
+__device__ __forceinline__ void f2n_mlp_lds_fill(F2nMlpLds<NH>& s, const half_t* __restrict__ params, int tid, int nthreads) {
+  const half_t* p0 = params;
+  const half_t* p1 = params + F2N_D_HID * F2N_D_IN;
+  const half_t* po = p1 + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0);
+  for (int i = tid; i < F2N_D_HID * F2N_D_IN; i += nthreads) {
+    const int r = i / F2N_D_IN, k = i % F2N_D_IN;
+    const half_t v = p0[i];
+    s.w0[r * F2N_LD32 + k] = v;
+    s.w0t[k * F2N_LD64 + r] = v;
+  }
+  if (NH == 2) {
+    for (int i = tid; i < F2N_D_HID * F2N_D_HID; i += nthreads) {
+      const int r = i / F2N_D_HID, k = i % F2N_D_HID;
+      const half_t v = p1[i];
+      s.w1[r * F2N_LD64 + k] = v;
+      s.w1t[k * F2N_LD64 + r] = v;
+    }
+  }
+  for (int i = tid; i < F2N_D_HID * 32; i += nthreads) {
+    const int j = i / 32, o = i % 32;
+    s.wot[j * F2N_LD32 + o] = (o < F2N_D_OUT) ? po[o * F2N_D_HID + j] : (half_t) 0.f;
+  }
+}
+
+template <int NH>
+struct F2nMlpGradAcc {
+  float4_t dwo[4];                    // [16 o][64 j]: tile t -> j = 16t + c, o = 4g + r
+  float4_t dw1[NH == 2 ? 16 : 1];     // [64][64]: tile (to, ti) -> j_in = 16ti + c, j_out = 16to + 4g + r
+  float4_t dw0[8];                    // [64][32]: tile (t, ft) -> i = 16ft + c, j = 16t + 4g + r
+
+  __device__ __forceinline__ void zero() {
+    const float4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; i++) dwo[i] = z;
+#pragma unroll
+    for (int i = 0; i < (NH == 2 ? 16 : 1); i++) dw1[i] = z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) dw0[i] = z;
+  }
+};
+
+// Everything the backward of one 16-sample half produces in the sample-ROW orientation (inputs to the
+// sample-contracted weight-gradient MFMAs) plus dX^T in the sample-COLUMN orientation.
+template <int NH>
+struct F2nHalfBwd {
+  float4_t dxT[2];                  // dX^T tiles ft: lane (c = sample, g) holds features 16ft + 4g + r (scaled)
+  // sample-row tiles, already rounded to f16 (that is the precision they are consumed in): 2 VGPRs per tile
+  half4_t dyR;                      // dY      [sample][o]      lane (c = o,      g): samples 4g + r
+  half4_t xR[2];                    // X       [sample][16ft+c]
+  half4_t hlR[4];                   // H_last  [sample][16t+c]  (post-ReLU)
+  half4_t glR[4];                   // G_last  [sample][16t+c]  (masked hidden gradient of the last hidden layer)
+  half4_t h0R[NH == 2 ? 4 : 1];     // H_0     (NH == 2 only)
+  half4_t g0R[NH == 2 ? 4 : 1];     // G_0     (NH == 2 only)
+};
+
+// xf: X row fragment; dyf: dY row fragment (K = output index, slots >= 16 are zero), already loss-scaled f16.
+template <int NH, int N_DX_TILES>
+__device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t xf, half8_t dyf, const half8_t* idf /*[2]*/,
+                                                 int c, int g, F2nHalfBwd<NH>& out) {
+  const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  // ---- sample-column orientation: recompute pre-activations, then the hidden-gradient chain ----
+  float4_t t0[4], t1[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) t0[t] = f2n_mfma(f2n_rowfrag(s.w0, F2N_LD32, 16 * t + c, 0, g), xf, z);
+  half8_t h0f[2] = {f2n_pack<true>(t0[0], t0[1]), f2n_pack<true>(t0[2], t0[3])};
+  if (NH == 2) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      t1[t] = f2n_mfma(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 0, g), h0f[0], z);
+      t1[t] = f2n_mfma(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 32, g), h0f[1], t1[t]);
+    }
+  }
+  float4_t gl[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    gl[t] = f2n_mfma(f2n_rowfrag(s.wot, F2N_LD32, 16 * t + c, 0, g), dyf, z);
+    gl[t] = f2n_relu_mask(gl[t], NH == 2 ? t1[t] : t0[t]);
+  }
+  half8_t gff[2] = {f2n_pack<false>(gl[0], gl[1]), f2n_pack<false>(gl[2], gl[3])};  // G_last row fragments
+  half8_t glf[2] = {gff[0], gff[1]};
+  if (NH == 2) {
+    float4_t g0[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      g0[t] = f2n_mfma(f2n_rowfrag(s.w1t, F2N_LD64, 16 * t + c, 0, g), glf[0], z);
+      g0[t] = f2n_mfma(f2n_rowfrag(s.w1t, F2N_LD64, 16 * t + c, 32, g), glf[1], g0[t]);
+      g0[t] = f2n_relu_mask(g0[t], t0[t]);
+    }
+    gff[0] = f2n_pack<false>(g0[0], g0[1]);
+    gff[1] = f2n_pack<false>(g0[2], g0[3]);
+  }
+#pragma unroll
+  for (int ft = 0; ft < N_DX_TILES; ft++) {
+    out.dxT[ft] = f2n_mfma(f2n_rowfrag(s.w0t, F2N_LD64, 16 * ft + c, 0, g), gff[0], z);
+    out.dxT[ft] = f2n_mfma(f2n_rowfrag(s.w0t, F2N_LD64, 16 * ft + c, 32, g), gff[1], out.dxT[ft]);
+  }
+  // ---- sample-row orientation: the same quantities with samples in the register index ----
+  float4_t t0r[4], t1r[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) t0r[t] = f2n_mfma(xf, f2n_rowfrag(s.w0, F2N_LD32, 16 * t + c, 0, g), z);
+  if (NH == 2) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      t1r[t] = f2n_mfma(h0f[0], f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 0, g), z);
+      t1r[t] = f2n_mfma(h0f[1], f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 32, g), t1r[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const float4_t pre = NH == 2 ? t1r[t] : t0r[t];
+    float4_t gr = f2n_mfma(dyf, f2n_rowfrag(s.wot, F2N_LD32, 16 * t + c, 0, g), z);
+    out.glR[t] = f2n_cvt4<false>(f2n_relu_mask(gr, pre));
+    out.hlR[t] = f2n_cvt4<true>(pre);
+  }
+  if (NH == 2) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      float4_t gr = f2n_mfma(glf[0], f2n_rowfrag(s.w1t, F2N_LD64, 16 * t + c, 0, g), z);
+      gr = f2n_mfma(glf[1], f2n_rowfrag(s.w1t, F2N_LD64, 16 * t + c, 32, g), gr);
+      out.g0R[t] = f2n_cvt4<false>(f2n_relu_mask(gr, t0r[t]));
+      out.h0R[t] = f2n_cvt4<true>(t0r[t]);
+    }
+  }
+  out.dyR = f2n_cvt4<false>(f2n_mfma(dyf, idf[0], z));
+  out.xR[0] = f2n_cvt4<false>(f2n_mfma(xf, idf[0], z));
+  out.xR[1] = f2n_cvt4<false>(f2n_mfma(xf, idf[1], z));
+}
+
+// Weight-gradient MFMAs over one 32-sample super-block (halves a and b supply K-slots 0..3 / 4..7).
+template <int NH>
+__device__ __forceinline__ void f2n_mlp_accumulate_dw(const F2nHalfBwd<NH>& a, const F2nHalfBwd<NH>& b, F2nMlpGradAcc<NH>& acc) {
+  const half8_t dyT = f2n_cat(a.dyR, b.dyR);
+  half8_t hlT[4], glT[4], xT[2];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    hlT[t] = f2n_cat(a.hlR[t], b.hlR[t]);
+    glT[t] = f2n_cat(a.glR[t], b.glR[t]);
+  }
+  xT[0] = f2n_cat(a.xR[0], b.xR[0]);
+  xT[1] = f2n_cat(a.xR[1], b.xR[1]);
+#pragma unroll
+  for (int t = 0; t < 4; t++) acc.dwo[t] = f2n_mfma(dyT, hlT[t], acc.dwo[t]);
+  if (NH == 2) {
+    half8_t h0T[4], g0T[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      h0T[t] = f2n_cat(a.h0R[t], b.h0R[t]);
+      g0T[t] = f2n_cat(a.g0R[t], b.g0R[t]);
+    }
+#pragma unroll
+    for (int to = 0; to < 4; to++)
+#pragma unroll
+      for (int ti = 0; ti < 4; ti++) acc.dw1[to * 4 + ti] = f2n_mfma(glT[to], h0T[ti], acc.dw1[to * 4 + ti]);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int ft = 0; ft < 2; ft++) acc.dw0[t * 2 + ft] = f2n_mfma(g0T[t], xT[ft], acc.dw0[t * 2 + ft]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int ft = 0; ft < 2; ft++) acc.dw0[t * 2 + ft] = f2n_mfma(glT[t], xT[ft], acc.dw0[t * 2 + ft]);
+  }
+}
+
+// Block-level reduction of the per-wave accumulators through LDS, then one fp32 atomic per parameter per
+// block into the (loss-scaled) global gradient.  s_acc must hold n_params floats and be zero on entry.
+template <int NH>
+__device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, float* s_acc, float* __restrict__ dparams,
+                                                 int c, int g, int tid, int nthreads) {
+  const int off1 = F2N_D_HID * F2N_D_IN;
+  const int offo = off1 + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0);
+  const int n_params = offo + F2N_D_OUT * F2N_D_HID;
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) atomicAdd(&s_acc[(16 * t + 4 * g + r) * F2N_D_IN + 16 * ft + c], acc.dw0[t * 2 + ft][r]);
+  if (NH == 2) {
+#pragma unroll
+    for (int to = 0; to < 4; to++)
+#pragma unroll
+      for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          atomicAdd(&s_acc[off1 + (16 * to + 4 * g + r) * F2N_D_HID + 16 * ti + c], acc.dw1[to * 4 + ti][r]);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) atomicAdd(&s_acc[offo + (4 * g + r) * F2N_D_HID + 16 * t + c], acc.dwo[t][r]);
+  __syncthreads();
+  for (int i = tid; i < n_params; i += nthreads) {
+    const float v = s_acc[i];
+    if (v != 0.f) atomicAdd(dparams + i, v);
+  }
+}

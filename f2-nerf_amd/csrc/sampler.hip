@@ -1,0 +1,453 @@
+// PersSampler on gfx950: ray / octree intersection, perspective-warped ray marching, edge samples and
+// occupancy bookkeeping.  Semantics follow PtsSampler/PersSampler.cu:21-680 of the reference (cited per
+// kernel); the structure does not: two-phase count / device-side scan / fill with ray-ordered segments
+// and no host read-back, wave64 blocks, LDS-resident DFS stacks.
+#include "f2n_dev.h"
+
+#define F2N_STACK_DEPTH 24  // MAX_STACK_SIZE 48 ints = 24 (node, cursor) pairs, PersSampler.cu:7
+#define F2N_RAY_BLOCK 64
+
+// ---------------------------------------------------------------------------------------------------
+// Slab test, PersSampler.cu:21-51.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void f2n_slab(const float* o, const float* d, const float* c, float side, float& near_,
+                                         float& far_) {
+  float lo[3], hi[3];
+  float hf = side * .5f;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (d[i] < 1e-6f && d[i] > -1e-6f) {
+      bool inside = o[i] > c[i] - hf && o[i] < c[i] + hf;
+      lo[i] = inside ? -1e6f : 1e6f;
+      hi[i] = inside ? 1e6f : -1e6f;
+    } else if (d[i] > 0) {
+      lo[i] = (c[i] - hf - o[i]) / d[i];
+      hi[i] = (c[i] + hf - o[i]) / d[i];
+    } else {
+      lo[i] = (c[i] + hf - o[i]) / d[i];
+      hi[i] = (c[i] - hf - o[i]) / d[i];
+    }
+  }
+  near_ = fmaxf(near_, fmaxf(lo[0], fmaxf(lo[1], lo[2])));
+  far_ = fminf(far_, fminf(hi[0], fminf(hi[1], hi[2])));
+}
+
+// Front-to-back DFS over the octree for one ray per lane (PersSampler.cu:53-152).  The per-lane stack
+// lives in LDS, transposed ([slot][lane]) so that the 64 lanes of the wave never bank-conflict.
+template <bool FILL>
+__global__ __launch_bounds__(F2N_RAY_BLOCK) void oct_intersect_kernel(
+    int n_rays, int max_hits, const uint8_t* __restrict__ search_order, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, float g_near, float g_far, const F2nTreeNode* __restrict__ nodes,
+    const int32_t* __restrict__ oct_start_end, int32_t* __restrict__ hit_counts, int32_t* __restrict__ oct_idx,
+    float* __restrict__ oct_near_far) {
+  __shared__ int s_node[F2N_STACK_DEPTH][F2N_RAY_BLOCK];
+  __shared__ int s_cur[F2N_STACK_DEPTH][F2N_RAY_BLOCK];
+  const int lane = threadIdx.x;
+  const int ray = blockIdx.x * F2N_RAY_BLOCK + lane;
+  if (ray >= n_rays) return;
+  const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+  const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+  int limit = max_hits;
+  int base = 0;
+  if (FILL) {
+    base = oct_start_end[2 * ray];
+    limit = oct_start_end[2 * ray + 1] - base;
+  }
+  const int octant = (int(d[0] > 0.f) << 2) | (int(d[1] > 0.f) << 1) | int(d[2] > 0.f);
+  // the 8-entry visiting order of this ray's octant packed into two registers
+  uint32_t ord_lo = 0, ord_hi = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    ord_lo |= (uint32_t) search_order[octant * 8 + k] << (8 * k);
+    ord_hi |= (uint32_t) search_order[octant * 8 + 4 + k] << (8 * k);
+  }
+  auto order = [&](int k) -> int { return (int) (((k < 4 ? ord_lo : ord_hi) >> (8 * (k & 3))) & 0xffu); };
+
+  int sp = 0, cnt = 0;
+  s_node[0][lane] = 0;
+  s_cur[0][lane] = -1;
+  while (sp >= 0 && cnt < limit) {
+    const int u = s_node[sp][lane];
+    const F2nTreeNode* nd = nodes + u;
+    int child;
+    const int cursor = s_cur[sp][lane];
+    if (cursor == -1) {
+      float near_ = g_near, far_ = g_far;
+      f2n_slab(o, d, nd->center, nd->side_len, near_, far_);
+      if (!(near_ < far_)) { sp--; continue; }
+      child = 0;
+      while (child < 8 && nd->childs[order(child)] < 0) child++;
+      if (child >= 8) {  // no live children: a leaf; valid iff it still owns a warp
+        if (nd->trans_idx >= 0) {
+          if (FILL) {
+            oct_idx[base + cnt] = u;
+            oct_near_far[2 * (base + cnt)] = near_;
+            oct_near_far[2 * (base + cnt) + 1] = far_;
+          }
+          cnt++;
+        }
+        sp--;
+        continue;
+      }
+    } else {
+      child = cursor + 1;
+      while (child < 8 && nd->childs[order(child)] < 0) child++;
+      if (child >= 8) { sp--; continue; }
+    }
+    s_cur[sp][lane] = child;
+    if (sp + 1 < F2N_STACK_DEPTH) {
+      sp++;
+      s_node[sp][lane] = nd->childs[order(child)];
+      s_cur[sp][lane] = -1;
+    }
+  }
+  if (!FILL) hit_counts[ray] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ray-ordered segment allocation.  One 1024-thread workgroup walks the count array in chunks of
+// 1024 x ITEMS with a running carry; wave-level inclusive scans use DPP-free __shfl_up on 64 lanes.
+// ---------------------------------------------------------------------------------------------------
+#define F2N_SCAN_THREADS 1024
+#define F2N_SCAN_ITEMS 4
+__global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, const int32_t* __restrict__ counts,
+                                                                        int32_t* __restrict__ start_end,
+                                                                        int32_t* __restrict__ total) {
+  __shared__ int s_wave[F2N_SCAN_THREADS / F2N_WAVE];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int chunk = 0; chunk < n; chunk += F2N_SCAN_THREADS * F2N_SCAN_ITEMS) {
+    const int i0 = chunk + tid * F2N_SCAN_ITEMS;
+    int v[F2N_SCAN_ITEMS];
+    int local = 0;
+#pragma unroll
+    for (int k = 0; k < F2N_SCAN_ITEMS; k++) {
+      v[k] = (i0 + k < n) ? counts[i0 + k] : 0;
+      local += v[k];
+    }
+    int incl = local;  // inclusive scan of per-thread sums across the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+    int run = s_carry + wave_off + incl - local;
+#pragma unroll
+    for (int k = 0; k < F2N_SCAN_ITEMS; k++) {
+      if (i0 + k < n) {
+        start_end[2 * (i0 + k)] = run;
+        run += v[k];
+        start_end[2 * (i0 + k) + 1] = run;
+      }
+    }
+    __syncthreads();
+    if (tid == F2N_SCAN_THREADS - 1) s_carry = run;  // last thread holds the chunk's inclusive total
+    __syncthreads();
+  }
+  if (tid == 0) total[0] = s_carry;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Perspective-warped ray marching, one ray per lane (PersSampler.cu:189-314).
+// ---------------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(F2N_RAY_BLOCK) void ray_march_kernel(
+    int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ noise_all, const int32_t* __restrict__ oct_start_end, const int32_t* __restrict__ oct_idx_all,
+    const float* __restrict__ near_far_all, const F2nTreeNode* __restrict__ nodes, const F2nTransInfo* __restrict__ transes,
+    const int32_t* __restrict__ pts_start_end, int32_t* __restrict__ pts_counts, float* __restrict__ pts,
+    float* __restrict__ dirs, float* __restrict__ dts, float* __restrict__ ts, int32_t* __restrict__ anchors,
+    float* __restrict__ first_oct_dis) {
+  const int ray = blockIdx.x * F2N_RAY_BLOCK + threadIdx.x;
+  if (ray >= n_rays) return;
+  const int oct_s = oct_start_end[2 * ray], n_oct = oct_start_end[2 * ray + 1] - oct_s;
+  int max_n = F2N_MAX_SAMPLE_PER_RAY, base = 0;
+  if (FILL) {
+    base = pts_start_end[2 * ray];
+    max_n = pts_start_end[2 * ray + 1] - base;
+    first_oct_dis[ray] = n_oct > 0 ? near_far_all[2 * oct_s] : 1e9f;  // :226-231
+  }
+  int n = 0;
+  if (n_oct > 0 && max_n > 0) {
+    const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+    const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+    const float* noise = noise_all + ray;  // shared, overlapping window (:203)
+    const int32_t* oct_idx = oct_idx_all + oct_s;
+    const float* near_far = near_far_all + 2 * oct_s;
+    int oct_ptr = 0;
+    bool first = true;
+    int cur_oct = oct_idx[0];
+    float cur_t = near_far[0], cur_far = near_far[1];
+    float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
+    while (n < max_n && oct_ptr < n_oct) {
+      const int tidx = nodes[cur_oct].trans_idx;
+      const F2nTransInfo* tr = transes + tidx;
+      const float radius = f2n_norm3(o[0] - tr->center[0], o[1] - tr->center[1], o[2] - tr->center[2]) / tr->dis_summary;
+      const float radius_clip = fmaxf(radius, 1.f);
+      float jac[3][3];
+      f2n_warp_jac(tr, xyz, jac);
+      float pj[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) pj[r] = f2n_sum3(jac[r][0] * d[0], jac[r][1] * d[1], jac[r][2] * d[2]);
+      const float pj_norm = f2n_norm3(pj[0], pj[1], pj[2]) + 1e-6f;
+      const float step_warp = sample_l * noise[n];
+      float step = step_warp / pj_norm;
+      if (scale_by_dis) step *= radius_clip;
+      float march = step;
+      if (!first) {  // the first point of a ray is never emitted (:274-289)
+        if (FILL) {
+          const int k = base + n;
+          float w[3];
+          f2n_warp(tr, xyz, w);
+          ts[k] = cur_t;
+          dts[k] = step * pj_norm;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            pts[3 * k + c] = w[c];
+            dirs[3 * k + c] = d[c];
+          }
+          anchors[3 * k] = tidx;
+          anchors[3 * k + 1] = cur_oct;
+          anchors[3 * k + 2] = 0;
+        }
+        n++;
+      }
+      while (cur_t + march > cur_far) {  // leaf crossing (:291-301)
+        oct_ptr++;
+        if (oct_ptr >= n_oct) break;
+        cur_oct = oct_idx[oct_ptr];
+        const float cur_near = near_far[2 * oct_ptr];
+        cur_far = near_far[2 * oct_ptr + 1];
+        const int ex = (int) ceilf(fmaxf((cur_near - cur_t) / step, 1.f));
+        march = step * (float) ex;
+      }
+      cur_t += march;
+#pragma unroll
+      for (int c = 0; c < 3; c++) xyz[c] = o[c] + d[c] * cur_t;
+      first = false;
+    }
+  }
+  if (!FILL) pts_counts[ray] = n;
+}
+
+// GetEdgeSamplesKernel, PersSampler.cu:436-452.
+__global__ void edge_samples_kernel(int n_pts, const F2nEdgePool* __restrict__ edge_pool,
+                                    const F2nTransInfo* __restrict__ transes, const int32_t* __restrict__ edge_idx,
+                                    const float* __restrict__ edge_coords, float* __restrict__ out_pts,
+                                    int32_t* __restrict__ out_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pts) return;
+  const F2nEdgePool* e = edge_pool + edge_idx[i];
+  float w[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    w[c] = (e->center[c] + e->dir_0[c] * edge_coords[2 * i]) + e->dir_1[c] * edge_coords[2 * i + 1];
+  float a[3], b[3];
+  f2n_warp(transes + e->t_idx_a, w, a);
+  f2n_warp(transes + e->t_idx_b, w, b);
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    out_pts[6 * i + c] = a[c];
+    out_pts[6 * i + 3 + c] = b[c];
+  }
+  out_idx[2 * i] = e->t_idx_a;
+  out_idx[2 * i + 1] = e->t_idx_b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Occupancy votes, PersSampler.cu:475-526 (one ray per lane, integer atomics).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void f2n_vote(int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt, int node,
+                                         float w, float a, float w_thres, float a_thres, int visits) {
+  atomicMax(w_adder + node, w > w_thres ? 512 : -1);  // OCC_WEIGHT_BASE
+  atomicMax(a_adder + node, a > a_thres ? 32 : -1);   // OCC_ALPHA_BASE
+  atomicMax(cnt + node, visits);
+  mark[node] = 1;
+}
+
+__global__ void mark_visit_kernel(int n_rays, const int32_t* __restrict__ pts_start_end, const int32_t* __restrict__ anchors,
+                                  int anchor_stride, const float* __restrict__ weights, const float* __restrict__ alphas,
+                                  int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n_rays) return;
+  const int s = pts_start_end[2 * ray], e = pts_start_end[2 * ray + 1];
+  if (s >= e) return;
+  float mw = 0.f, ma = 0.f;
+  for (int i = s; i < e; i++) {
+    mw = fmaxf(mw, weights[i]);
+    ma = fmaxf(ma, alphas[i]);
+  }
+  // 0.1 / 0.01 / 0.02 are double literals in the reference (:12-17): float*double, then narrowed by fminf
+  const float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
+  const float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
+  float cw = 0.f, ca = 0.f;
+  int cur = -1, visits = 0;
+  for (int i = s; i < e; i++) {
+    const int node = anchors[(size_t) i * anchor_stride + 1];
+    if (cur != node) {
+      if (cur >= 0) f2n_vote(w_adder, a_adder, mark, cnt, cur, cw, ca, w_thres, a_thres, visits);
+      cur = node;
+      cw = 0.f;
+      ca = 0.f;
+      visits = 0;
+    }
+    cw = fmaxf(cw, weights[i]);
+    ca = fmaxf(ca, alphas[i]);
+    visits++;
+  }
+  if (cur >= 0) f2n_vote(w_adder, a_adder, mark, cnt, cur, cw, ca, w_thres, a_thres, visits);
+}
+
+// PersSampler.cu:579-593 (torch integer ops) + MarkInvalidNodes (:528-534), one node per lane.
+__global__ void update_stats_kernel(int n_nodes, const int32_t* __restrict__ w_adder, const int32_t* __restrict__ a_adder,
+                                    const int32_t* __restrict__ mark, int32_t* __restrict__ w_stats,
+                                    int32_t* __restrict__ a_stats, F2nTreeNode* __restrict__ nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int m = mark[i];
+  int st[2];
+  const int add[2] = {w_adder[i], a_adder[i]};
+  st[0] = w_stats[i];
+  st[1] = a_stats[i];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int occ = add[k] > 0 ? 1 : 0;
+    int v = max(st[k], occ * add[k]);
+    v += m * (1 - occ) * add[k];
+    st[k] = min(max(v, -100), 1 << 20);
+  }
+  w_stats[i] = st[0];
+  a_stats[i] = st[1];
+  if (st[0] < 0 || st[1] < 0) nodes[i].trans_idx = -1;
+}
+
+// MarkInvisibleNodesKernel + CheckVisible, PersSampler.cu:618-661.
+__global__ void mark_invisible_kernel(int n_nodes, int n_cams, F2nTreeNode* __restrict__ nodes,
+                                      const float* __restrict__ intris, const float* __restrict__ w2cs,
+                                      const float* __restrict__ bounds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const float c[3] = {nodes[i].center[0], nodes[i].center[1], nodes[i].center[2]};
+  const float radius = (float) ((double) nodes[i].side_len * 0.707);
+  int visible = 0;
+  for (int k = 0; k < n_cams; k++) {
+    const float* m = w2cs + 12 * k;
+    const float* K = intris + 9 * k;
+    float p[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) p[r] = f2n_sum4(m[4 * r] * c[0], m[4 * r + 1] * c[1], m[4 * r + 2] * c[2], m[4 * r + 3] * 1.f);
+    if (-p[2] < bounds[2 * k] - radius || -p[2] > bounds[2 * k + 1] + radius) continue;
+    if (f2n_norm3(p[0], p[1], p[2]) < radius) { visible++; continue; }
+    const float cx = K[2], cy = K[5], fx = K[0], fy = K[4];
+    const float bx = radius / -p[2] * fx, by = radius / -p[2] * fy;
+    const float ix = p[0] / -p[2] * fx, iy = p[1] / -p[2] * fy;
+    if (ix + bx < -cx || ix > cx + bx || iy + by < -cy || iy > cy + by) continue;
+    visible++;
+  }
+  if (visible < 1) nodes[i].trans_idx = -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                            const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* hit_counts) {
+  if (n_rays < 0 || max_hits < 0) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(oct_intersect_kernel<false>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
+                     (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
+                     (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end, int32_t* total) {
+  if (n < 0) return F2N_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(segment_scan_kernel, dim3(1), dim3(F2N_SCAN_THREADS), 0, (hipStream_t) stream, n, counts,
+                     start_end, total);
+  return f2n_launch_status();
+}
+
+int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order, const float* rays_o,
+                           const float* rays_d, float near_, float far_, const void* tree_nodes,
+                           const int32_t* oct_start_end, int32_t* oct_idx, float* oct_near_far) {
+  if (n_rays < 0) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(oct_intersect_kernel<true>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
+                     (hipStream_t) stream, n_rays, 0, search_order, rays_o, rays_d, near_, far_,
+                     (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far);
+  return f2n_launch_status();
+}
+
+int f2n_ray_march_count(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o,
+                        const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                        const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts) {
+  if (n_rays < 0) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(ray_march_kernel<false>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
+                     (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
+                     oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_ray_march_fill(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o,
+                       const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                       const float* oct_near_far, const void* tree_nodes, const void* transes,
+                       const int32_t* pts_start_end, float* pts, float* dirs, float* dt, float* t, int32_t* anchors,
+                       float* first_oct_dis) {
+  if (n_rays < 0) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(ray_march_kernel<true>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
+                     (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
+                     oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, pts_start_end, nullptr,
+                     pts, dirs, dt, t, anchors, first_oct_dis);
+  return f2n_launch_status();
+}
+
+int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,
+                     const float* edge_coords, float* out_pts, int32_t* out_idx) {
+  if (n_pts < 0) return F2N_ERR_INVALID_ARG;
+  if (n_pts == 0) return F2N_OK;
+  hipLaunchKernelGGL(edge_samples_kernel, dim3(f2n_div_up(n_pts, 64)), dim3(64), 0, (hipStream_t) stream, n_pts,
+                     (const F2nEdgePool*) edge_pool, (const F2nTransInfo*) transes, edge_idx, edge_coords, out_pts,
+                     out_idx);
+  return f2n_launch_status();
+}
+
+int f2n_oct_mark_visit(void* stream, int n_rays, const int32_t* pts_start_end, const int32_t* anchors, int anchor_stride,
+                       const float* weights, const float* alphas, int32_t* w_adder, int32_t* a_adder, int32_t* mark,
+                       int32_t* visit_cnt) {
+  if (n_rays < 0 || anchor_stride < 2) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(mark_visit_kernel, dim3(f2n_div_up(n_rays, 64)), dim3(64), 0, (hipStream_t) stream, n_rays,
+                     pts_start_end, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt);
+  return f2n_launch_status();
+}
+
+int f2n_oct_update_stats(void* stream, int n_nodes, const int32_t* w_adder, const int32_t* a_adder, const int32_t* mark,
+                         int32_t* w_stats, int32_t* a_stats, void* tree_nodes) {
+  if (n_nodes < 0) return F2N_ERR_INVALID_ARG;
+  if (n_nodes == 0) return F2N_OK;
+  hipLaunchKernelGGL(update_stats_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, n_nodes,
+                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes);
+  return f2n_launch_status();
+}
+
+int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris,
+                           const float* w2cs, const float* bounds) {
+  if (n_nodes < 0 || n_cams < 0) return F2N_ERR_INVALID_ARG;
+  if (n_nodes == 0) return F2N_OK;
+  hipLaunchKernelGGL(mark_invisible_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, n_nodes,
+                     n_cams, (F2nTreeNode*) tree_nodes, intris, w2cs, bounds);
+  return f2n_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// SHShader on gfx950: real spherical harmonics (Shader/SHShader.cu:10-118) + appearance embedding
+// (Utils/CustomOps/Scatter.cu:10-40) + colour MLP 32->64->64->16 + scaled sigmoid (Shader/SHShader.cpp:23-29),
+// fused: the MLP input row fragment is assembled in registers from feat/app_emb/dir and never stored as fp32.
+#include "mlp_dev.h"
+
+// Degree-4 real SH basis in the reference's polynomial forms and operation order (SHShader.cu:25-50).
+__device__ __forceinline__ void f2n_sh16(float x, float y, float z, float* o) {
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+  o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+  o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+__global__ void sh_encode_kernel(int n, int degree, const float* __restrict__ dirs, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sh[16];
+  f2n_sh16(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], sh);
+  const int w = degree * degree;
+  for (int k = 0; k < w; k++) out[(size_t) i * w + k] = sh[k];
+}
+
+// ScatterIdxKernal, Scatter.cu:110-120: broadcast a per-ray value to the ray's samples (one wave per ray).
+__global__ void scatter_idx_kernel(int n_rays, const int32_t* __restrict__ start_end, const int32_t* __restrict__ ray_val,
+                                   int32_t* __restrict__ out) {
+  const int ray = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int s = start_end[2 * ray], e = start_end[2 * ray + 1], v = ray_val[ray];
+  for (int i = s + (threadIdx.x & 63); i < e; i += 64) out[i] = v;
+}
+
+// Row fragment of the colour-MLP input for sample s: slots 0..3 = shading features 4g..4g+3
+// ([1 | feat[1:16]] + app_emb, Renderer.cpp:181-187), slots 4..7 = SH coefficients 4g..4g+3.
+__device__ __forceinline__ half8_t f2n_shade_input_frag(const float* __restrict__ feat, const float* __restrict__ dirs,
+                                                        const float* __restrict__ app_emb, const int32_t* __restrict__ sample_emb_idx,
+                                                        int s, int g, bool valid) {
+  half8_t xf = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!valid) return xf;
+  float4_t f = *(const float4_t*) (feat + (size_t) s * F2N_D_OUT + 4 * g);
+  if (g == 0) f[0] = 1.f;
+  if (app_emb != nullptr) {
+    const float4_t e = *(const float4_t*) (app_emb + (size_t) sample_emb_idx[s] * 16 + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r++) f[r] = f[r] + e[r];
+  }
+  float sh[16];
+  f2n_sh16(dirs[3 * (size_t) s], dirs[3 * (size_t) s + 1], dirs[3 * (size_t) s + 2], sh);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    xf[r] = (half_t) f[r];
+    const float v = (g == 0) ? sh[r] : (g == 1) ? sh[4 + r] : (g == 2) ? sh[8 + r] : sh[12 + r];
+    xf[4 + r] = (half_t) v;
+  }
+  return xf;
+}
+
+__device__ __forceinline__ half8_t f2n_load_xfrag(const half_t* __restrict__ x, int s, int g, bool valid) {
+  if (!valid) return half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  return f2n_rowfrag(x, F2N_D_IN, s, 0, g);
+}
+
+#define F2N_SHADE_EPS 1e-3f
+
+__global__ __launch_bounds__(256) void shade_fwd_kernel(int n, const float* __restrict__ feat, const float* __restrict__ dirs,
+                                                        const float* __restrict__ app_emb,
+                                                        const int32_t* __restrict__ sample_emb_idx,
+                                                        const half_t* __restrict__ params, float* __restrict__ rgb,
+                                                        half_t* __restrict__ save_x) {
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  F2nMlpFwdW<2> w;
+  w.load(params, c, g);
+  const int n_blocks = (n + 15) / 16;
+  const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
+  for (int blk = wave_global; blk < n_blocks; blk += wave_stride) {
+    const int s = blk * 16 + c;
+    const bool valid = s < n;
+    const half8_t xf = f2n_shade_input_frag(feat, dirs, app_emb, sample_emb_idx, s, g, valid);
+    if (save_x != nullptr && valid) {
+      half_t* p = save_x + (size_t) s * F2N_D_IN + 4 * g;
+      *(half4_t*) p = __builtin_shufflevector(xf, xf, 0, 1, 2, 3);
+      *(half4_t*) (p + 16) = __builtin_shufflevector(xf, xf, 4, 5, 6, 7);
+    }
+    const float4_t o = w.forward(xf);
+    if (valid && g == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float ov = (float) (half_t) o[r];  // f16 output precision, then fp32 torch ops (SHShader.cpp:28)
+        rgb[3 * (size_t) s + r] = (1.f + 2.f * F2N_SHADE_EPS) / (1.f + expf(-ov)) - F2N_SHADE_EPS;
+      }
+    }
+  }
+}
+
+union F2nShadeSmem {
+  F2nMlpLds<2> w;
+  float acc[F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID];
+};
+
+__global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __restrict__ drgb,
+                                                        const int32_t* __restrict__ sample_emb_idx,
+                                                        const half_t* __restrict__ params, const half_t* __restrict__ x_h,
+                                                        float loss_scale, float* __restrict__ dfeat,
+                                                        float* __restrict__ dparams, float* __restrict__ dapp_emb) {
+  __shared__ F2nShadeSmem sm;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  f2n_mlp_lds_fill<2>(sm.w, params, tid, 256);
+  __syncthreads();
+  const half8_t idf[2] = {f2n_identity_frag(0, c, g), f2n_identity_frag(1, c, g)};
+  // forward output layer fragments (needed to recompute o for the sigmoid derivative)
+  const half_t* po = params + F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID;
+  const half8_t wo[2] = {f2n_rowfrag(po, F2N_D_HID, c, 0, g), f2n_rowfrag(po, F2N_D_HID, c, 32, g)};
+  F2nMlpGradAcc<2> acc;
+  acc.zero();
+  const int n_super = (n + 31) / 32;
+  const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
+  const float inv_scale = 1.f / loss_scale;
+  const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  for (int sb = wave_global; sb < n_super; sb += wave_stride) {
+    F2nHalfBwd<2> hb[2];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int s = sb * 32 + half * 16 + c;
+      const bool valid = s < n;
+      const half8_t xf = f2n_load_xfrag(x_h, valid ? s : n - 1, g, valid);
+      // recompute the network output o (sample-column orientation) for d(rgb)/d(o)
+      float4_t t[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) t[i] = f2n_mfma(f2n_rowfrag(sm.w.w0, F2N_LD32, 16 * i + c, 0, g), xf, z);
+      half8_t h0 = f2n_pack<true>(t[0], t[1]), h1 = f2n_pack<true>(t[2], t[3]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        t[i] = f2n_mfma(f2n_rowfrag(sm.w.w1, F2N_LD64, 16 * i + c, 0, g), h0, z);
+        t[i] = f2n_mfma(f2n_rowfrag(sm.w.w1, F2N_LD64, 16 * i + c, 32, g), h1, t[i]);
+      }
+      h0 = f2n_pack<true>(t[0], t[1]);
+      h1 = f2n_pack<true>(t[2], t[3]);
+      float4_t o = f2n_mfma(wo[0], h0, z);
+      o = f2n_mfma(wo[1], h1, o);
+      half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid && g == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const float ov = (float) (half_t) o[r];
+          const float e = expf(-ov);
+          const float dsig = (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
+          dyf[r] = (half_t) ((float) (half_t) (drgb[3 * (size_t) s + r] * dsig) * loss_scale);
+        }
+      }
+      f2n_mlp_half_bwd<2, 1>(sm.w, xf, dyf, idf, c, g, hb[half]);
+      // d(shading_feat) = dX[:, 0:16]: lane (c = sample, g) holds features 4g..4g+3
+      float4_t dsf;
+#pragma unroll
+      for (int r = 0; r < 4; r++) dsf[r] = valid ? hb[half].dxT[0][r] * inv_scale : 0.f;
+      if (valid) {
+        float* p = dfeat + (size_t) s * F2N_D_OUT + 4 * g;
+        if (g == 0) {  // column 0 belongs to the density path (constant-1 shading input)
+          p[1] = dsf[1];
+          p[2] = dsf[2];
+          p[3] = dsf[3];
+        } else {
+          *(float4_t*) p = dsf;
+        }
+      }
+      if (dapp_emb != nullptr) {
+        // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples.  16 samples of one wave half
+        // usually share a ray, hence an image: reduce across the 16 sample lanes first, then 1 atomic.
+        const int img = valid ? sample_emb_idx[s] : -1;
+        const int img0 = __shfl(img, lane & 48);  // sample 0 of this lane group
+        const bool uniform = __all(img == img0);
+        if (uniform) {
+          if (img0 >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              float v = dsf[r];
+#pragma unroll
+              for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+              if (c == 0) atomicAdd(dapp_emb + (size_t) img0 * 16 + 4 * g + r, v);
+            }
+          }
+        } else if (valid) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) atomicAdd(dapp_emb + (size_t) img * 16 + 4 * g + r, dsf[r]);
+        }
+      }
+    }
+    f2n_mlp_accumulate_dw<2>(hb[0], hb[1], acc);
+  }
+  __syncthreads();
+  const int n_params = F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID;
+  for (int i = tid; i < n_params; i += 256) sm.acc[i] = 0.f;
+  __syncthreads();
+  f2n_mlp_flush_dw<2>(acc, sm.acc, dparams, c, g, tid, 256);
+}
+
+static inline unsigned f2n_shade_grid(int n_units, int per_block) {
+  long blocks = ((long) n_units + per_block - 1) / per_block;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (unsigned) blocks;
+}
+
+extern "C" {
+
+int f2n_sh_encode(void* stream, int n, int degree, const float* dirs, float* out) {
+  if (n < 0) return F2N_ERR_INVALID_ARG;
+  if (degree < 1 || degree > 4) return F2N_ERR_UNSUPPORTED;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(sh_encode_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n, degree, dirs, out);
+  return f2n_launch_status();
+}
+
+int f2n_scatter_idx(void* stream, int n_rays, const int32_t* start_end, const int32_t* ray_val, int32_t* out) {
+  if (n_rays < 0) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(scatter_idx_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, start_end,
+                     ray_val, out);
+  return f2n_launch_status();
+}
+
+int f2n_shade_fwd(void* stream, int n, const float* feat, const float* dirs, const float* app_emb,
+                  const int32_t* sample_emb_idx, const void* mlp_params_h, float* rgb, void* save_x_h) {
+  if (n < 0 || (app_emb != nullptr && sample_emb_idx == nullptr)) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(shade_fwd_kernel, dim3(f2n_shade_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, feat,
+                     dirs, app_emb, sample_emb_idx, (const half_t*) mlp_params_h, rgb, (half_t*) save_x_h);
+  return f2n_launch_status();
+}
+
+int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
+                  const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled, float* dapp_emb) {
+  if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && sample_emb_idx == nullptr)) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(shade_bwd_kernel, dim3(f2n_shade_grid((n + 31) / 32, 4 * 4)), dim3(256), 0, (hipStream_t) stream, n, drgb,
+                     sample_emb_idx, (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat,
+                     dparams_f32_scaled, dapp_emb);
+  return f2n_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+/* f2n_abi.h -- C-ABI of the MI355X-native (gfx950, HIP) implementation of F2-NeRF's per-ray hot path.
+ *
+ * The reference (Totoro97/f2-nerf) has no FFI: its hot path is a set of first-party CUDA kernels launched
+ * from C++ plugin classes (PersSampler / Hash3DAnchored / SHShader / Renderer) plus the third-party
+ * tiny-cuda-nn `tcnn::cpp::Module`.  This header declares, seam for seam, what a binding for that path
+ * would bind; each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/src).  INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call only ENQUEUES work on
+ *     that stream; nothing here synchronises, allocates or frees caller-visible memory.
+ *   - All pointers are DEVICE pointers to contiguous buffers in exactly the layouts named below, unless
+ *     the parameter is documented as host data.  TreeNode = 64 B, TransInfo = 544 B, EdgePool = 64 B as in
+ *     PtsSampler/PersSampler.h:15-37.  "h16" = IEEE binary16.
+ *   - Return value: 0 on success, F2N_ERR_* (< 0) otherwise; a HIP launch error e is returned as
+ *     -(1000 + e).  Callable from any host thread (e.g. the autograd engine thread); the caller selects
+ *     the device (hipSetDevice) before calling.
+ *   - Variable-length results use count -> f2n_segment_scan -> fill, so no host read-back is needed:
+ *     callers may size outputs for the worst case (n_rays * 1024) and read totals lazily.
+ */
+#ifndef F2N_ABI_H
+#define F2N_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F2N_OK 0
+#define F2N_ERR_INVALID_ARG (-1)
+#define F2N_ERR_UNSUPPORTED (-2)
+
+#define F2N_N_LEVELS 16            /* Field/Hash3DAnchored.h:16 */
+#define F2N_N_CHANNELS 2           /* Field/Hash3DAnchored.h:15 */
+#define F2N_MAX_SAMPLE_PER_RAY 1024 /* PtsSampler/PersSampler.cu:9 */
+#define F2N_MLP_OUT_PAD 16         /* tcnn FullyFusedMLP pads the output width to 16 */
+
+/* Library / device introspection (host-only). */
+int f2n_abi_version(void);
+const char* f2n_build_info(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Sampler -- replaces PersSampler::GetSamples' kernels (PtsSampler/PersSampler.cu:21-434).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* FindRayOctreeIntersectionKernel<false> (PersSampler.cu:53-152, launched :342-351).
+ * rays_d must already be unit length (GetSamples normalises at :319); [near, far] is the global bound the
+ * reference substitutes for its `bounds` argument (:322-323: near = pts_sampler.near, far = 1e8).
+ * hit_counts[r] = number of valid leaves hit by ray r, capped at max_hits. */
+int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_t* search_order /*[64]*/,
+                            const float* rays_o /*[R,3]*/, const float* rays_d /*[R,3]*/, float near_, float far_,
+                            const void* tree_nodes, int32_t* hit_counts /*[R]*/);
+
+/* Ray-ordered segment allocation: start_end[i] = (sum_{j<i} counts[j], sum_{j<=i} counts[j]);
+ * total[0] = sum.  Replaces the racing atomicAdd allocator (PersSampler.cu:144) and the
+ * torch::cumsum + .item() host sync (:395-397); also FilterIdxBounds' cumsum (Renderer/Renderer.cu:44-48). */
+int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end /*[n,2]*/, int32_t* total /*[1]*/);
+
+/* FindRayOctreeIntersectionKernel<true> (PersSampler.cu:357-366): fills each ray's segment with
+ * (leaf node index, t_near, t_far), front to back. */
+int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order, const float* rays_o,
+                           const float* rays_d, float near_, float far_, const void* tree_nodes,
+                           const int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[K]*/,
+                           float* oct_near_far /*[K,2]*/);
+
+/* RayMarchKernel<false> (PersSampler.cu:189-314, launched :383-393).  noise has
+ * F2N_MAX_SAMPLE_PER_RAY + n_rays + 10 floats, already multiplied by ray_march_fineness (:372-381), and is
+ * indexed [ray + k] exactly as in the reference (:203,:266). */
+int f2n_ray_march_count(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o,
+                        const float* rays_d, const float* noise, const int32_t* oct_start_end,
+                        const int32_t* oct_idx, const float* oct_near_far, const void* tree_nodes,
+                        const void* transes, int32_t* pts_counts /*[R]*/);
+
+/* RayMarchKernel<true> (PersSampler.cu:407-423).  Outputs are the SampleResultFlex tensors
+ * (PtsSampler/PtsSampler.h:13-22): pts = WARPED coordinates, dirs = unit world direction, dt = warped-space
+ * step, t = world distance, anchors[:,0] = trans_idx, anchors[:,1] = leaf node index, anchors[:,2] = 0. */
+int f2n_ray_march_fill(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o,
+                       const float* rays_d, const float* noise, const int32_t* oct_start_end,
+                       const int32_t* oct_idx, const float* oct_near_far, const void* tree_nodes,
+                       const void* transes, const int32_t* pts_start_end /*[R,2]*/, float* pts /*[N,3]*/,
+                       float* dirs /*[N,3]*/, float* dt /*[N]*/, float* t /*[N]*/, int32_t* anchors /*[N,3]*/,
+                       float* first_oct_dis /*[R]*/);
+
+/* GetEdgeSamplesKernel (PersSampler.cu:436-452).  edge_idx/edge_coords are the random draws of :456-457. */
+int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,
+                     const float* edge_coords /*[n,2]*/, float* out_pts /*[n,2,3]*/, int32_t* out_idx /*[n,2]*/);
+
+/* MarkVistNodeKernel (PersSampler.cu:475-526).  oct node index of sample i = anchors[i*anchor_stride + 1].
+ * w_adder/a_adder must be pre-filled with -1, mark with 0 (:555-557); visit_cnt is persistent state. */
+int f2n_oct_mark_visit(void* stream, int n_rays, const int32_t* pts_start_end, const int32_t* anchors,
+                       int anchor_stride, const float* weights, const float* alphas, int32_t* w_adder,
+                       int32_t* a_adder, int32_t* mark, int32_t* visit_cnt);
+
+/* The integer stat update of UpdateOctNodes (PersSampler.cu:579-593) fused with MarkInvalidNodes
+ * (:528-534, :595-603): stats = clamp(max(stats, pos vote) + visited negative vote, -100, 2^20);
+ * trans_idx = -1 where either stat < 0. */
+int f2n_oct_update_stats(void* stream, int n_nodes, const int32_t* w_adder, const int32_t* a_adder,
+                         const int32_t* mark, int32_t* w_stats, int32_t* a_stats, void* tree_nodes);
+
+/* MarkInvisibleNodesKernel (PersSampler.cu:618-680). */
+int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris /*[C,3,3]*/,
+                           const float* w2cs /*[C,3,4]*/, const float* bounds /*[C,2]*/);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Hash grid -- replaces Hash3DAnchoredFunction::forward/backward (Field/Hash3DAnchored.cu:11-233).
+ * `table_h` is the binary16 table [pool,2]; level l lives at table_h + local_idx[l] HALVES and is
+ * addressed as pos*2+k with pos < local_size[l] (the 50 % level-overlap quirk of :37/:74-77 is kept).
+ * level_scale[16] are the per-level multipliers exp2f(7*l/15+3) (:28) supplied by the host so that both
+ * sides of a parity test use identical bits.  If pts_are_warped != 0 the kernel applies the
+ * ((p + 1) * .5) of Hash3DAnchored.cpp:91 itself.  volume index of point i = volume_idx[i*vol_stride].
+ * ------------------------------------------------------------------------------------------------- */
+int f2n_hash_fwd(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool /*[16,V,3]*/,
+                 const int32_t* local_idx /*[16]*/, const int32_t* local_size /*[16]*/,
+                 const float* bias_pool /*[16*V,3]*/, const float* level_scale /*[16]*/, const float* pts /*[n,3]*/,
+                 int pts_are_warped, const int32_t* volume_idx, int vol_stride, void* out_h /*[n,32] h16*/);
+
+/* grad_in_h: dL/dfeat already scaled by 128 and rounded to h16 (Hash3DAnchored.cu:220).  grad_table_h is
+ * ACCUMULATED into with packed-h16 atomics (global_atomic_pk_add_f16 == the reference's half2 atomicAdd,
+ * :151) and must be zeroed by the caller (:222).  The /128 and fp32 widening of :232 are left to the
+ * optimiser step (f2n_adam_step_h16grad). */
+int f2n_hash_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
+                 const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts,
+                 int pts_are_warped, const int32_t* volume_idx, int vol_stride, const void* grad_in_h /*[n,32]*/,
+                 void* grad_table_h);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fully-fused MLP -- replaces the tcnn::cpp::Module surface used by Field/TCNNWP.cpp:94-97,150-154,
+ * 217-227 ("FullyFusedMLP", ReLU, no output activation, no bias).  Supported shapes: d_in = 32,
+ * d_hidden = 64, n_hidden in {1,2}, d_out <= 16 (padded to 16) -- the two networks of the reference
+ * configs.  Parameter layout (fp32 master and h16 working copy alike): layers first->last, each
+ * [n_out, n_in] row-major, last layer has 16 rows.
+ * ------------------------------------------------------------------------------------------------- */
+int f2n_mlp_n_params(int d_in, int d_hidden, int n_hidden);               /* Module::n_params() */
+/* Module::initialize_params(seed, float*): Xavier-uniform from a counter-based generator (tcnn's pcg32
+ * stream cannot be reproduced; weights are exchanged as flat fp32 arrays instead). */
+int f2n_mlp_init_params(void* stream, uint64_t seed, int d_in, int d_hidden, int n_hidden, float* params_f32);
+int f2n_params_to_h16(void* stream, int n, const float* params_f32, void* params_h); /* TCNNWP.cpp:111 */
+/* Module::inference / forward: x is fp32 [n,32] (tcnn input precision), out is h16 [n,16]
+ * (output_precision()).  No activations are stored: the backward recomputes them on the matrix cores. */
+int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const void* params_h, const float* x,
+                void* out_h);
+/* Module::backward: dy fp32 [n,16] is multiplied by loss_scale and rounded to h16 (TCNNWP.cpp:174);
+ * dparams_f32 [n_params] is ACCUMULATED (fp32 atomics) in the SCALED domain -- divide by loss_scale
+ * afterwards (:232); dx_f32 (may be NULL) receives dL/dx / loss_scale (:231). */
+int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float loss_scale, const void* params_h,
+                const float* x, const float* dy, float* dparams_f32_scaled, float* dx_f32);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused field = hash gather + density MLP (Hash3DAnchored::AnchoredQuery, Field/Hash3DAnchored.cpp:84-99).
+ * Features never leave the register file between the gather and the matrix cores.
+ *   out_feat_f32 [n,16]   (may be NULL) the AnchoredQuery result (h16 values widened, TCNNWP.cpp:112)
+ *   out_f0       [n]      (may be NULL) channel 0 only: the density pre-activation for the no-grad
+ *                         pre-pass of Renderer::Render (Renderer/Renderer.cpp:105-137)
+ *   save_x_h     [n,32]   (may be NULL) the h16 hash features, kept for f2n_field_bwd
+ * ------------------------------------------------------------------------------------------------- */
+int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                  const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                  const float* level_scale, const float* pts_warped, const int32_t* volume_idx, int vol_stride,
+                  const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h);
+
+/* Backward of the fused field: MLP backward (dparams accumulated, scaled domain) chained straight into
+ * the hash scatter; dL/dx never touches HBM.  dfeat fp32 [n,16]. */
+int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
+                  const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                  const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
+                  const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled,
+                  void* grad_table_h);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Shader -- replaces SHShader::Query (Shader/SHShader.cpp:23-29) and SHKenerl (Shader/SHShader.cu:10-118).
+ * ------------------------------------------------------------------------------------------------- */
+int f2n_sh_encode(void* stream, int n, int degree /*1..4*/, const float* dirs /*[n,3]*/, float* out /*[n,degree^2]*/);
+
+/* ScatterIdxKernal (Utils/CustomOps/Scatter.cu:110-120): out[i] = ray_val[r] for every sample i of ray r. */
+int f2n_scatter_idx(void* stream, int n_rays, const int32_t* start_end, const int32_t* ray_val, int32_t* out /*[n]*/);
+
+/* Fused colour path of Renderer::Render (Renderer/Renderer.cpp:181-189):
+ *   shading_feat = [1 | feat[:,1:16]] (+ app_emb[sample_emb_idx[i]] when app_emb != NULL, Scatter.cu:10-18),
+ *   input = [shading_feat | SH4(dir)] -> colour MLP 32->64->64->16 -> rgb = (1+2e-3)/(1+exp(-o)) - 1e-3.
+ * sample_emb_idx [n] is the ScatterIdx result (image index per sample), only read when app_emb != NULL.
+ * save_x_h [n,32] (may be NULL) keeps the h16 MLP input for the backward. */
+int f2n_shade_fwd(void* stream, int n, const float* feat /*[n,16]*/, const float* dirs /*[n,3]*/,
+                  const float* app_emb /*[n_img,16] or NULL*/, const int32_t* sample_emb_idx /*[n] or NULL*/,
+                  const void* mlp_params_h, float* rgb /*[n,3]*/, void* save_x_h);
+
+/* drgb [n,3] -> dfeat[:,1:16] written (column 0 is left untouched: it belongs to the density path),
+ * dparams accumulated (scaled domain), dapp_emb [n_img,16] accumulated UNSCALED (fp32 atomics) or NULL.
+ * The network output needed for the sigmoid derivative is recomputed from saved_x_h on the matrix cores. */
+int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
+                  const void* saved_x_h, float loss_scale, float* dfeat /*[n,16]*/, float* dparams_f32_scaled,
+                  float* dapp_emb);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Renderer -- replaces the per-ray glue of Renderer::Render (Renderer/Renderer.cpp:105-208), i.e.
+ * TruncExp (CustomOps.cpp:9-18), FlexOps::Sum/AccumulateSum (FlexOps.cu:5-93), CountValidPts /
+ * FilterIdxBounds (Renderer.cu:8-50), GradientScaling (CustomOps.cu:68-80).  One sequential left-to-right
+ * walk per ray, as in the reference (the add order is part of the parity contract).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* No-grad pre-pass (Renderer.cpp:115-137): sigma = exp(f0-3), sec = sigma*dt, alpha = 1-exp(-sec),
+ * T = exp(-exclusive_cumsum(sec)), w = T*alpha, mask = T > 1e-4.  f0 of sample i = f0[i*f0_stride].
+ * kept[r] = number of samples of ray r with mask set. */
+int f2n_early_stop(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride,
+                   const float* dt, float* weights /*[N]*/, float* alphas /*[N]*/, int32_t* mask /*[N]*/,
+                   int32_t* kept /*[R]*/);
+
+/* Compaction of the surviving samples (Renderer.cpp:128-135: the five index-gathers).  Sample order is
+ * preserved; new_start_end comes from f2n_segment_scan(kept). */
+int f2n_compact_samples(void* stream, int n_rays, const int32_t* old_start_end, const int32_t* new_start_end,
+                        const int32_t* mask, const float* pts, const float* dirs, const float* dt, const float* t,
+                        const int32_t* anchors, float* o_pts, float* o_dirs, float* o_dt, float* o_t,
+                        int32_t* o_anchors);
+
+/* Compositing (Renderer.cpp:196-208): colors = sum w*c + T_last*bg, disparity = sum w/(t+.01),
+ * depth = sum w*(t+.01) / (1 - T_last + 1e-4); weights [M] is also returned (RenderResult, Renderer.h:18-27).
+ * f0 of sample i = feat[i*16]. */
+int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat /*[M,16]*/,
+                      const float* dt, const float* t, const float* rgb /*[M,3]*/, const float* bg /*[R,3]*/,
+                      float* colors /*[R,3]*/, float* disparity /*[R]*/, float* depth /*[R]*/, float* weights /*[M]*/);
+
+/* Backward of the above through TruncExp; gradient scaling (CustomOps.cu:68-80) is applied to dsigma and
+ * drgb when grad_scaling_progress < 1.  Any of dcolors/ddisparity/ddepth/dweights may be NULL (= zero).
+ * Writes drgb [M,3] and dfeat[:,0] (dfeat [M,16], other columns untouched). */
+int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat, const float* dt,
+                      const float* t, const float* rgb, const float* bg, const float* dcolors,
+                      const float* ddisparity, const float* ddepth, const float* dweights,
+                      float grad_scaling_progress, float* drgb, float* dfeat);
+
+/* WeightVarLoss forward/backward (CustomOps.cu:12-66). */
+int f2n_weight_var_fwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, float* out_vars);
+int f2n_weight_var_bwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end,
+                       const float* dvars, float* dweights);
+
+/* Seam-level FlexOps (FlexOps.cu:5-93) for callers that keep the reference's op-by-op structure. */
+int f2n_flex_sum_fwd(void* stream, int n_rays, int vec, const float* val, const int32_t* start_end, float* sum);
+int f2n_flex_sum_bwd(void* stream, int n_rays, int vec, const float* dsum, const int32_t* start_end, float* dval);
+int f2n_flex_acc_fwd(void* stream, int n_rays, int include_this, const float* val, const int32_t* start_end, float* sum);
+int f2n_flex_acc_bwd(void* stream, int n_rays, int include_this, const float* dsum, const int32_t* start_end, float* dval);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Optimiser -- replaces torch::optim::Adam::step over the groups of Hash3DAnchored::OptimParamGroups
+ * (Field/Hash3DAnchored.cpp:124-150), SHShader (Shader/SHShader.cpp:44-56), Renderer (Renderer.cpp:238-258):
+ * beta = (0.9, 0.99), eps = 1e-15, L2 weight decay added to the gradient (torch Adam semantics).
+ * ------------------------------------------------------------------------------------------------- */
+/* fp32 gradient (grad * grad_scale is the true gradient); optionally refreshes an h16 working copy.
+ * grad_round_h16 != 0 reproduces the two binary16 roundings the reference applies to MLP parameter gradients:
+ * g = f16(f16(grad) * grad_scale) (tcnn param-precision output while loss-scaled, Field/TCNNWP.cpp:214-215, then
+ * autograd's cast of the unscaled gradient to the f16 dtype of the Function input, :111,:242). */
+int f2n_adam_step(void* stream, int n, float* param, const float* grad, float grad_scale, int grad_round_h16,
+                  float* exp_avg, float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, void* param_h_or_null);
+/* h16 gradient table produced by f2n_hash_bwd / f2n_field_bwd (true gradient = float(grad_h) * grad_scale,
+ * grad_scale = 1/128): fuses the fp16->fp32 cast, the /128 (Hash3DAnchored.cu:232), Adam, the fp32->fp16
+ * refresh of the table (Hash3DAnchored.cu:186) and the re-zeroing of the gradient (:222) in one pass. */
+int f2n_adam_step_h16grad(void* stream, int n, float* param, void* grad_h, float grad_scale, float* exp_avg,
+                          float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, void* param_h, int zero_grad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F2N_ABI_H */

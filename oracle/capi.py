@@ -9,7 +9,11 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libf2n_oracle.so")
+# Two builds of the same source: the serial one is what the tests load (safe next to torch's bundled OpenMP
+# runtime); the OpenMP one is only loaded when F2N_ORACLE_OMP=1, by bench.py's cpu_baseline leg in a
+# subprocess that does not import torch (two OpenMP runtimes in one process crash).
+USE_OMP = os.environ.get("F2N_ORACLE_OMP", "0") == "1"
+SO = os.path.join(HERE, "libf2n_oracle_omp.so" if USE_OMP else "libf2n_oracle.so")
 SRC = os.path.join(HERE, "f2n_oracle.c")
 
 TREE_NODE_BYTES = 64
@@ -24,8 +28,11 @@ _lib = None
 def build(force=False):
     """gcc-compile the oracle (seconds).  -ffp-contract=off is part of the contract."""
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(SRC):
-        cmd = ["gcc", "-O2", "-std=c11", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-shared",
-               "-fPIC", SRC, "-o", SO, "-lm"]
+        cmd = ["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", SRC, "-o", SO, "-lm"]
+        if USE_OMP:
+            cmd.insert(1, "-fopenmp")
+        else:
+            cmd.insert(1, "-Wno-unknown-pragmas")
         subprocess.check_call(cmd)
     return SO
 
@@ -42,7 +49,7 @@ def _p(a):
     if a is None:
         return ctypes.c_void_p(0)
     assert a.flags["C_CONTIGUOUS"], "array must be contiguous"
-    return ctypes.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(ctypes.c_void_p)  # keeps a reference to `a` alive for the duration of the call
 
 
 def _f32(a):

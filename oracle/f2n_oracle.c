@@ -765,7 +765,8 @@ void oracle_scatter_add_bwd(int n_emb, int n_all, int c, const int32_t* idx, con
  *           [n_out, n_in] row-major; the last layer has 16 (padded) output rows.
  *   forward: x -> fp16; h_l = fp16(relu(W_l h_{l-1})) with fp32 accumulation in k order; the output
  *           layer has no activation and is stored as fp16 (TCNNWP.cpp:143-144 output precision).
- *   backward: dL/dy is multiplied by loss_scale and rounded to fp16 (:174,:187); hidden gradients are
+ *   backward: dL/dy is rounded to fp16 (autograd cast to the f16 output dtype, :112), multiplied by
+ *           loss_scale in fp16 (:174,:187); hidden gradients are
  *           kept in fp16; dL/dW is accumulated in fp32 over the batch then rounded to fp16 (param
  *           precision, :214-215) before the /loss_scale (:232); dL/dx is fp32 /loss_scale (:231).
  * ---------------------------------------------------------------------------------------------- */
@@ -853,7 +854,7 @@ int oracle_mlp_bwd(int n, int d_in, int d_hidden, int n_hidden, float loss_scale
 #pragma omp for schedule(static)
     for (int i = 0; i < n; i++) {
       float g[OR_MLP_MAX_W], gp[OR_MLP_MAX_W], in[OR_MLP_MAX_W];
-      for (int j = 0; j < 16; j++) g[j] = or_h2f(or_f2h(dy[(size_t) i * 16 + j] * loss_scale));
+      for (int j = 0; j < 16; j++) g[j] = or_h2f(or_f2h(or_h2f(or_f2h(dy[(size_t) i * 16 + j])) * loss_scale));
       for (int l = L - 1; l >= 0; l--) {
         /* input activations of layer l */
         if (l == 0) for (int k = 0; k < d_in; k++) in[k] = or_h2f(or_f2h(x[(size_t) i * d_in + k]));
@@ -882,7 +883,8 @@ int oracle_mlp_bwd(int n, int d_in, int d_hidden, int n_hidden, float loss_scale
   for (int p = 0; p < np; p++) {
     float s = 0.f;
     for (int t = 0; t < nthreads; t++) s += acc[(size_t) np * t + p];
-    dparams[p] = or_h2f(or_f2h(s)) / loss_scale;
+    /* scaled sum -> f16 (tcnn param precision) -> /scale -> f16 again (autograd cast to the f16 `params` input) */
+    dparams[p] = or_h2f(or_f2h(or_h2f(or_f2h(s)) / loss_scale));
   }
   free(acc);
   free(w);

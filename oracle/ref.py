@@ -30,7 +30,7 @@ def _p(a):
     if a is None:
         return ctypes.c_void_p(0)
     assert a.flags["C_CONTIGUOUS"]
-    return ctypes.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(ctypes.c_void_p)  # keeps a reference to `a` alive for the duration of the call
 
 
 def _f32(a):

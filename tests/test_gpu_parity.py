@@ -1,0 +1,593 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every hot-path kernel is called THROUGH THE C-ABI
+(f2-nerf_amd/capi.py -> libf2n_hip.so) and compared with the CPU oracle on the same seeded inputs and with the
+committed golden vectors.  Integer / index outputs are bit-exact; fp32 sampler outputs are bit-exact (both
+sides are built with -ffp-contract=off and IEEE div/sqrt); fp16 hash features are bit-exact; MLP-dependent
+values use the tolerances stated next to each assert (north-star contract: rendered RGB within 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capi as oc  # noqa: E402
+from oracle import pipeline as op  # noqa: E402
+
+DEV = "cuda:0"
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import capi
+    capi.lib()  # fails loudly if the native library is missing
+    return capi
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def assert_same(a, b, what=""):
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = bits(a) != bits(b)
+    assert not bad.any(), "%s: %d / %d elements differ" % (what, int(bad.sum()), bad.size)
+
+
+# ---------------------------------------------------------------------------------------------------
+# sampler
+# ---------------------------------------------------------------------------------------------------
+def gpu_sample(hip, st, rays_o, rays_d, noise, sample_l, scale_by_dis, near=0.01, far=1e8, max_hits=1024):
+    R = rays_o.shape[0]
+    so, tn, tr = T(st["search_order"]), T(st["tree_nodes"]), T(st["pers_trans"])
+    ro, rd, nz = T(rays_o), T(rays_d), T(noise)
+    cnt = torch.empty(R, dtype=torch.int32, device=DEV)
+    se = torch.empty((R, 2), dtype=torch.int32, device=DEV)
+    tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.oct_intersect_count(R, max_hits, so, ro, rd, near, far, tn, cnt)
+    hip.segment_scan(R, cnt, se, tot)
+    K = int(tot.item())
+    oidx = torch.empty(max(K, 1), dtype=torch.int32, device=DEV)
+    onf = torch.empty((max(K, 1), 2), dtype=torch.float32, device=DEV)
+    hip.oct_intersect_fill(R, so, ro, rd, near, far, tn, se, oidx, onf)
+    pcnt = torch.empty(R, dtype=torch.int32, device=DEV)
+    pse = torch.empty((R, 2), dtype=torch.int32, device=DEV)
+    hip.ray_march_count(R, sample_l, scale_by_dis, ro, rd, nz, se, oidx, onf, tn, tr, pcnt)
+    hip.segment_scan(R, pcnt, pse, tot)
+    n = int(tot.item())
+    m = max(n, 1)
+    out = dict(pts=torch.empty((m, 3), device=DEV), dirs=torch.empty((m, 3), device=DEV), dt=torch.empty(m, device=DEV),
+               t=torch.empty(m, device=DEV), anchors=torch.zeros((m, 3), dtype=torch.int32, device=DEV),
+               first_oct_dis=torch.empty(R, device=DEV))
+    hip.ray_march_fill(R, sample_l, scale_by_dis, ro, rd, nz, se, oidx, onf, tn, tr, pse, out["pts"], out["dirs"],
+                       out["dt"], out["t"], out["anchors"], out["first_oct_dis"])
+    torch.cuda.synchronize()
+    res = {k: N(v)[:n] if k != "first_oct_dis" else N(v).reshape(R, 1) for k, v in out.items()}
+    res["pts_idx_bounds"] = N(pse)
+    return (N(se), N(oidx)[:K], N(onf)[:K]), res
+
+
+def fox_rays(st, rng, n):
+    cam = st["train_set"][rng.integers(0, len(st["train_set"]), n)].astype(np.int32)
+    pose = st["poses"][cam]
+    K = st["intri"][cam]
+    i = rng.integers(0, 960, n).astype(F32) + F32(.5)
+    j = rng.integers(0, 540, n).astype(F32) + F32(.5)
+    d_cam = np.stack([(j - K[:, 0, 2]) / K[:, 0, 0], -(i - K[:, 1, 2]) / K[:, 1, 1], -np.ones(n, F32)], -1).astype(F32)
+    d = np.einsum("nij,nj->ni", pose[:, :3, :3], d_cam).astype(F32)
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(F32)
+    return np.ascontiguousarray(pose[:, :3, 3]).astype(F32), d, cam
+
+
+def test_sampler_golden(hip, fox_state, fox_golden):
+    g = fox_golden
+    hits, m = gpu_sample(hip, fox_state, g["rays_o"], g["rays_d"], g["noise"], float(g["sample_l"]), True)
+    assert_same(hits[0], g["oct_start_end"], "oct_start_end")
+    assert_same(hits[1], g["oct_idx"], "oct_idx")
+    assert_same(hits[2], g["oct_near_far"], "oct_near_far")
+    for k in ("pts", "dirs", "dt", "t", "anchors", "pts_idx_bounds", "first_oct_dis"):
+        assert_same(m[k], g["march_" + k], k)
+
+
+@pytest.mark.parametrize("seed,fineness,scale_by_dis,max_hits,n", [(1, 8.0, True, 1024, 1500), (2, 2.0, False, 1024, 700),
+                                                                    (3, 16.0, True, 5, 513)])
+def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hits, n):
+    st = fox_state
+    rng = np.random.default_rng(seed)
+    o, d, _ = fox_rays(st, rng, n)
+    d[0] = [1, 0, 0]; d[1] = [0, -1, 0]; d[2] = [0, 0, 1]; o[3] = [1e4, 1e4, 1e4]; d[3] = [1, 0, 0]
+    noise = ((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(fineness)
+    hits, m = gpu_sample(hip, st, o, d, noise, 1. / 256., scale_by_dis, max_hits=max_hits)
+    ref_hits = oc.oct_intersect(st["search_order"], o, d, 0.01, 1e8, st["tree_nodes"], max_hits)
+    for a, b, w in zip(hits, ref_hits, ("se", "idx", "nf")):
+        assert_same(a, b, w)
+    ref = oc.ray_march(o, d, noise, 1. / 256., scale_by_dis, *ref_hits, st["tree_nodes"], st["pers_trans"])
+    for k in ref:
+        assert_same(m[k], ref[k], k)
+
+
+def test_sampler_full_size_properties(hip, fox_state):
+    """BASELINE config 2 size (8192 rays): size-independent properties + run-to-run determinism."""
+    st = fox_state
+    rng = np.random.default_rng(7)
+    R = 8192
+    o, d, _ = fox_rays(st, rng, R)
+    noise = ((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(16.0)
+    hits, m = gpu_sample(hip, st, o, d, noise, 1. / 256., True)
+    hits2, m2 = gpu_sample(hip, st, o, d, noise, 1. / 256., True)
+    for k in m:
+        assert_same(m[k], m2[k], "determinism " + k)
+    se = m["pts_idx_bounds"]
+    assert se[0, 0] == 0 and (se[1:, 0] == se[:-1, 1]).all() and (se[:, 1] >= se[:, 0]).all()
+    assert se[-1, 1] == len(m["t"]) and (se[:, 1] - se[:, 0]).max() <= 1024
+    # t strictly increases along every ray; samples lie inside the leaf they are anchored to
+    ray_of = np.repeat(np.arange(R), se[:, 1] - se[:, 0])
+    same_ray = ray_of[1:] == ray_of[:-1]
+    assert (np.diff(m["t"])[same_ray] > 0).all()
+    from oracle.octree_construct import NODE_DT
+    nodes = st["tree_nodes"].view(NODE_DT)
+    nd = nodes[m["anchors"][:, 1]]
+    assert (nd["trans_idx"] == m["anchors"][:, 0]).all()
+    world = o[ray_of] + d[ray_of] * m["t"][:, None]
+    assert (np.abs(world - nd["center"]).max(-1) <= nd["side_len"] * 0.5 * (1 + 1e-4) + 1e-5).all()
+    # a subset checked bit-exactly against the oracle
+    sub = slice(0, 512)
+    ref_hits = oc.oct_intersect(st["search_order"], o[sub], d[sub], 0.01, 1e8, st["tree_nodes"])
+    ref = oc.ray_march(o[sub], d[sub], noise[:1024 + 512 + 10], 1. / 256., True, *ref_hits, st["tree_nodes"], st["pers_trans"])
+    # the noise window of ray r is noise[r : r+1024] on both sides, independent of the batch size
+    n_sub = int(se[511, 1])
+    assert_same(m["t"][:n_sub], ref["t"], "t subset")
+    assert_same(m["pts"][:n_sub], ref["pts"], "pts subset")
+
+
+def test_segment_scan(hip):
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 64, 4096, 4097, 8192, 100003):
+        c = rng.integers(0, 1000, n).astype(np.int32)
+        se = torch.empty((n, 2), dtype=torch.int32, device=DEV)
+        tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+        hip.segment_scan(n, T(c), se, tot)
+        end = np.cumsum(c).astype(np.int32)
+        assert_same(N(se)[:, 1], end)
+        assert_same(N(se)[:, 0], (end - c).astype(np.int32))
+        assert int(tot.item()) == int(end[-1])
+    tot = torch.full((1,), 5, dtype=torch.int32, device=DEV)
+    hip.segment_scan(0, torch.empty(1, dtype=torch.int32, device=DEV), torch.empty((1, 2), dtype=torch.int32, device=DEV), tot)
+    assert int(tot.item()) == 0  # empty input
+
+
+def test_edge_samples_and_occupancy(hip, fox_state, fox_golden):
+    st, g = fox_state, fox_golden
+    n = len(g["edge_idx"])
+    pts = torch.empty((n, 2, 3), device=DEV)
+    idx = torch.empty((n, 2), dtype=torch.int32, device=DEV)
+    hip.edge_samples(n, T(st["edge_pool"]), T(st["pers_trans"]), T(g["edge_idx"]), T(g["edge_coord"]), pts, idx)
+    assert_same(N(pts), g["edge_pts"], "edge pts")
+    assert_same(N(idx), g["edge_out_idx"], "edge idx")
+    # occupancy votes on the golden march
+    n_nodes = st["tree_nodes"].size // 64
+    w = (g["seg_val"] * F32(0.01)).astype(F32)
+    wa = torch.full((n_nodes,), -1, dtype=torch.int32, device=DEV)
+    aa = torch.full((n_nodes,), -1, dtype=torch.int32, device=DEV)
+    mk = torch.zeros(n_nodes, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(n_nodes, dtype=torch.int32, device=DEV)
+    R = len(g["cam"])
+    hip.oct_mark_visit(R, T(g["march_pts_idx_bounds"]), T(g["march_anchors"]), 3, T(w), T(g["occ_alpha"]), wa, aa, mk, cnt)
+    for a, b in ((wa, "occ_w_adder"), (aa, "occ_a_adder"), (mk, "occ_mark"), (cnt, "occ_cnt")):
+        assert_same(N(a), g[b], b)
+    rng = np.random.default_rng(3)
+    ws = rng.integers(-2, 5, n_nodes).astype(np.int32)
+    as_ = rng.integers(-2, 5, n_nodes).astype(np.int32)
+    ew, ea, enodes = oc.update_node_stats(N(wa), N(aa), N(mk), ws, as_, st["tree_nodes"])
+    tw, ta, tn = T(ws), T(as_), T(st["tree_nodes"])
+    hip.oct_update_stats(n_nodes, wa, aa, mk, tw, ta, tn)
+    assert_same(N(tw), ew); assert_same(N(ta), ea); assert_same(N(tn), enodes)
+    ts = st["train_set"]
+    tn2 = T(st["tree_nodes"])
+    hip.oct_mark_invisible(n_nodes, len(ts), tn2, T(st["intri"][ts]), T(st["w2c"][ts]), T(st["bounds"][ts]))
+    from oracle.octree_construct import NODE_DT
+    assert_same(N(tn2).view(NODE_DT)["trans_idx"].copy(), g["invisible_trans_idx"], "invisible")
+
+
+# ---------------------------------------------------------------------------------------------------
+# hash grid
+# ---------------------------------------------------------------------------------------------------
+def make_grid(st, rng, log2_t, scale=1.0):
+    local = 1 << log2_t
+    table = (rng.standard_normal((16 * local, 2)).astype(F32) * F32(scale))
+    return op.HashGrid(table, st["prim_pool"], st["bias_pool"], int(st["n_volumes"]), log2_t)
+
+
+def grid_dev(grid):
+    return dict(table_h=T(grid.table_h.view(np.float16)), prim=T(grid.prim_pool), lidx=T(grid.local_idx),
+                lsize=T(grid.local_size), bias=T(grid.bias_pool), scale=T(grid.scales))
+
+
+@pytest.mark.parametrize("log2_t,n", [(10, 1000), (19, 5000)])
+def test_hash_forward_bit_exact(hip, fox_state, log2_t, n):
+    rng = np.random.default_rng(log2_t)
+    grid = make_grid(fox_state, rng, log2_t)
+    q = (rng.random((n, 3), dtype=F32) * F32(1.6) - F32(0.3))  # includes q < 0: saturating float->u32
+    vol = rng.integers(0, grid.n_volumes, n).astype(np.int32)
+    gd = grid_dev(grid)
+    out = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    hip.hash_fwd(n, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(q), False,
+                 T(vol), 1, out)
+    ref = oc.hash_fwd(grid.table_h, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q, vol, grid.n_volumes)
+    assert_same(N(out).view(np.uint16), ref, "hash features")
+    # warped input + strided volume index (anchors[:,0] read in place)
+    anchors = np.zeros((n, 3), np.int32)
+    anchors[:, 0] = vol
+    pw = (q * F32(2.) - F32(1.)).astype(F32)
+    out2 = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    hip.hash_fwd(n, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pw), True,
+                 T(anchors), 3, out2)
+    q2 = ((pw + F32(1.)) * F32(.5)).astype(F32)
+    ref2 = oc.hash_fwd(grid.table_h, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q2, vol, grid.n_volumes)
+    assert_same(N(out2).view(np.uint16), ref2, "hash features (warped)")
+
+
+def test_hash_forward_golden_and_linearity(hip, fox_state, fox_golden):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_golden import _hash_setup
+    g = fox_golden
+    table, li, ls, q01, vol = _hash_setup(fox_state, g)
+    n = len(vol)
+    scale = T(oc.level_scales())
+    out = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    args = (n, int(fox_state["n_volumes"]))
+    rest = (T(fox_state["prim_pool"]), T(li), T(ls), T(fox_state["bias_pool"]), scale, T(q01), False, T(vol), 1)
+    hip.hash_fwd(*args, T(table), *rest, out)
+    assert_same(N(out).view(np.uint16), g["hash_feat"], "golden hash features")
+    # linearity in the table: scaling every entry by 2 (exact in fp16) doubles every feature exactly
+    out2 = torch.zeros_like(out)
+    hip.hash_fwd(*args, T((table.astype(F32) * 2).astype(np.float16)), *rest, out2)
+    assert_same((N(out).astype(F32) * 2).astype(np.float16).view(np.uint16), N(out2).view(np.uint16), "linearity")
+
+
+def test_hash_backward(hip, fox_state):
+    rng = np.random.default_rng(11)
+    grid = make_grid(fox_state, rng, 12)
+    n = 4000
+    q = rng.random((n, 3), dtype=F32)
+    vol = rng.integers(0, grid.n_volumes, n).astype(np.int32)
+    gin = (rng.standard_normal((n, 32)) * 0.05).astype(np.float16)
+    gin[::7] = 0
+    gd = grid_dev(grid)
+    gtab = torch.zeros(grid.table_f32.size, dtype=torch.float16, device=DEV)
+    hip.hash_bwd(n, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(q), False, T(vol), 1, T(gin),
+                 gtab)
+    ref32 = oc.hash_bwd(grid.table_f32.size, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q, vol,
+                        grid.n_volumes, gin.view(np.uint16), fp32_accumulate=True)
+    got = N(gtab).astype(F32)
+    # fp16 atomics accumulate in arbitrary order: compare with the fp32-accumulated oracle at fp16 resolution of the
+    # running sums (each of <= ~40 additions may round by half an ulp of the partial sum)
+    tol = 2e-3 * np.abs(ref32).max() + 8 * 2.0 ** -11 * np.abs(ref32)
+    assert (np.abs(got - ref32) <= tol).all(), float(np.abs(got - ref32).max())
+    assert (got != 0).sum() == (ref32 != 0).sum() or abs(int((got != 0).sum()) - int((ref32 != 0).sum())) < 50
+    # collision-free case is bit-exact against the sequential fp16 oracle: one point only
+    gtab1 = torch.zeros_like(gtab)
+    hip.hash_bwd(1, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(q[1:2]), False, T(vol[1:2]),
+                 1, T(gin[1:2]), gtab1)
+    ref1 = oc.hash_bwd(grid.table_f32.size, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q[1:2], vol[1:2],
+                       grid.n_volumes, gin[1:2].view(np.uint16))
+    same_cell_twice = False
+    got1 = N(gtab1).view(np.uint16)
+    if not same_cell_twice:
+        mism = (got1 != ref1).sum()
+        assert mism <= 4, mism  # two corners of one level may hash to the same entry (order-dependent rounding)
+
+
+# ---------------------------------------------------------------------------------------------------
+# MLP
+# ---------------------------------------------------------------------------------------------------
+def rand_params(rng, n_hidden):
+    n = oc.mlp_n_params(32, 64, n_hidden)
+    p = np.zeros(n, F32)
+    off = 0
+    for rows, cols in [(64, 32)] + [(64, 64)] * (n_hidden - 1) + [(16, 64)]:
+        s = np.sqrt(6.0 / (rows + cols))
+        p[off:off + rows * cols] = rng.uniform(-s, s, rows * cols).astype(F32)
+        off += rows * cols
+    return p
+
+
+def torch_mlp_ref(params, x, n_hidden):
+    """Plain fp32 PyTorch reference of the same network (no fp16 rounding) for a sanity bound."""
+    h = torch.from_numpy(x)
+    off = 0
+    dims = [(64, 32)] + [(64, 64)] * (n_hidden - 1) + [(16, 64)]
+    for li, (rows, cols) in enumerate(dims):
+        w = torch.from_numpy(params[off:off + rows * cols].reshape(rows, cols))
+        off += rows * cols
+        h = h @ w.t()
+        if li < len(dims) - 1:
+            h = torch.relu(h)
+    return h.numpy()
+
+
+@pytest.mark.parametrize("n_hidden,n", [(1, 1000), (2, 1000), (1, 17), (2, 16)])
+def test_mlp_forward(hip, n_hidden, n):
+    rng = np.random.default_rng(n_hidden * 100 + n)
+    params = rand_params(rng, n_hidden)
+    x = rng.standard_normal((n, 32)).astype(F32)
+    ph = T(oc.f2h(params).view(np.float16))
+    out = torch.zeros((n, 16), dtype=torch.float16, device=DEV)
+    hip.mlp_fwd(n, 32, 64, n_hidden, ph, T(x), out)
+    got = N(out).astype(F32)
+    ref = oc.h2f(oc.mlp_fwd(params, x, 64, n_hidden))
+    # same rounding points (fp16 weights/activations, fp32 accumulate); only the fp32 summation order differs, which
+    # can flip an fp16 rounding of a hidden activation: tolerance = a few fp16 ulps of the output scale
+    tol = 4 * 2.0 ** -11 * max(1.0, np.abs(ref).max())
+    assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), tol)
+    assert (np.abs(got - ref) > 0).mean() < 0.2
+    full = torch_mlp_ref(params, x, n_hidden)
+    assert np.abs(got - full).max() <= 2e-2 * max(1.0, np.abs(full).max())
+
+
+@pytest.mark.parametrize("n_hidden,n", [(1, 2048), (2, 2048), (1, 33), (2, 31)])
+def test_mlp_backward(hip, n_hidden, n):
+    rng = np.random.default_rng(n_hidden * 7 + n)
+    params = rand_params(rng, n_hidden)
+    x = rng.standard_normal((n, 32)).astype(F32)
+    dy = (rng.standard_normal((n, 16)) * 1e-2).astype(F32)
+    ph = T(oc.f2h(params).view(np.float16))
+    dparams = torch.zeros(params.size, device=DEV)
+    dx = torch.zeros((n, 32), device=DEV)
+    hip.mlp_bwd(n, 32, 64, n_hidden, 128.0, ph, T(x), T(dy), dparams, dx)
+    _, acts = oc.mlp_fwd(params, x, 64, n_hidden, want_acts=True)
+    rdp, rdx, _ = oc.mlp_bwd(params, x, acts, dy, 64, n_hidden, 128.0)
+    gdp = N(dparams) / F32(128.)
+    gdx = N(dx)
+    assert np.abs(gdx - rdx).max() <= 3e-3 * np.abs(rdx).max() + 1e-7, np.abs(gdx - rdx).max()
+    # the oracle rounds dparams to fp16 twice (reference behaviour); compare at that resolution
+    assert np.abs(gdp - rdp).max() <= 4e-3 * np.abs(rdp).max() + 1e-7, (np.abs(gdp - rdp).max(), np.abs(rdp).max())
+    # independent fp32 autograd check (no fp16 anywhere): loose bound
+    xt = torch.from_numpy(x).requires_grad_(True)
+    pt = torch.from_numpy(params).requires_grad_(True)
+    off, h = 0, xt
+    dims = [(64, 32)] + [(64, 64)] * (n_hidden - 1) + [(16, 64)]
+    for li, (rows, cols) in enumerate(dims):
+        h = h @ pt[off:off + rows * cols].reshape(rows, cols).t()
+        off += rows * cols
+        if li < len(dims) - 1:
+            h = torch.relu(h)
+    (h * torch.from_numpy(dy)).sum().backward()
+    assert np.abs(gdp - pt.grad.numpy()).max() <= 3e-2 * np.abs(pt.grad.numpy()).max()
+    edx = np.abs(gdx - xt.grad.numpy())  # fp16 activations flip a few ReLU masks relative to the fp32 network
+    assert edx.max() <= 0.12 * np.abs(xt.grad.numpy()).max() and edx.mean() <= 2e-3 * np.abs(xt.grad.numpy()).max()
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused field / shader
+# ---------------------------------------------------------------------------------------------------
+def test_field_fused_forward_backward(hip, fox_state, fox_golden):
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(21)
+    grid = make_grid(st, rng, 14, scale=0.5)
+    params = rand_params(rng, 1)
+    pts, anchors = g["march_pts"], g["march_anchors"]
+    n = len(pts)
+    gd = grid_dev(grid)
+    ph = T(oc.f2h(params).view(np.float16))
+    feat = torch.zeros((n, 16), device=DEV)
+    f0 = torch.zeros(n, device=DEV)
+    sx = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    hip.field_fwd(n, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts),
+                  T(anchors), 3, ph, feat, f0, sx)
+    rfeat, ctx = op.field_fwd(grid, params, pts, anchors[:, 0], want_ctx=True)
+    assert_same(N(sx).view(np.uint16), ctx["x_h"], "fused hash features (saved)")
+    tol = 4 * 2.0 ** -11 * max(1.0, np.abs(rfeat).max())
+    assert np.abs(N(feat) - rfeat).max() <= tol
+    assert_same(N(f0), N(feat)[:, 0].copy(), "f0 == feat[:,0]")
+    # backward
+    dfeat = (rng.standard_normal((n, 16)) * 1e-3).astype(F32)
+    dparams = torch.zeros(params.size, device=DEV)
+    gtab = torch.zeros(grid.table_f32.size, dtype=torch.float16, device=DEV)
+    hip.field_bwd(n, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts), T(anchors), 3, ph, sx,
+                  T(dfeat), 128.0, dparams, gtab)
+    rdp, rgt, _ = op.field_bwd(grid, params, ctx, dfeat, 128.0, fp32_accumulate=True)
+    gdp = N(dparams) / F32(128.)
+    assert np.abs(gdp - rdp).max() <= 4e-3 * np.abs(rdp).max() + 1e-7
+    ggt = N(gtab).astype(F32) / F32(128.)
+    assert np.abs(ggt - rgt).max() <= 1e-2 * np.abs(rgt).max(), (np.abs(ggt - rgt).max(), np.abs(rgt).max())
+    cos = float((ggt * rgt).sum() / (np.linalg.norm(ggt) * np.linalg.norm(rgt)))
+    assert cos > 0.9999, cos
+
+
+@pytest.mark.parametrize("use_emb", [False, True])
+def test_shade_fused_forward_backward(hip, fox_golden, use_emb):
+    g = fox_golden
+    rng = np.random.default_rng(31)
+    params = rand_params(rng, 2)
+    dirs, se = g["march_dirs"], g["march_pts_idx_bounds"]
+    n = len(dirs)
+    feat = rng.standard_normal((n, 16)).astype(F32)
+    emb = (rng.standard_normal((50, 16)) * 0.1).astype(F32) if use_emb else None
+    sidx = oc.scatter_idx(n, se, g["cam"]) if use_emb else None
+    ph = T(oc.f2h(params).view(np.float16))
+    rgb = torch.zeros((n, 3), device=DEV)
+    sx = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    d_sidx = None
+    if use_emb:
+        d_sidx = torch.zeros(n, dtype=torch.int32, device=DEV)
+        hip.scatter_idx(len(se), T(se), T(g["cam"]), d_sidx)
+        assert_same(N(d_sidx), sidx, "scatter idx")
+    hip.shade_fwd(n, T(feat), T(dirs), T(emb) if use_emb else None, d_sidx, ph, rgb, sx)
+    rrgb, ctx = op.shade_fwd(params, feat, dirs, emb, sidx, want_ctx=True)
+    assert_same(N(sx).view(np.uint16), oc.f2h(ctx["x"]), "colour MLP input (h16)")
+    assert np.abs(N(rgb) - rrgb).max() <= 1e-3  # north-star tolerance on rendered colour
+    drgb = (rng.standard_normal((n, 3)) * 1e-3).astype(F32)
+    dfeat = torch.full((n, 16), 7.0, device=DEV)
+    dparams = torch.zeros(params.size, device=DEV)
+    demb = torch.zeros((50, 16), device=DEV) if use_emb else None
+    hip.shade_bwd(n, T(drgb), d_sidx, ph, sx, 128.0, dfeat, dparams, demb)
+    rdp, rdfeat, rdemb = op.shade_bwd(params, ctx, drgb, 50 if use_emb else 0, sidx, 128.0)
+    gdf = N(dfeat)
+    assert (gdf[:, 0] == 7.0).all()  # column 0 untouched
+    assert np.abs(gdf[:, 1:] - rdfeat[:, 1:]).max() <= 4e-3 * np.abs(rdfeat).max() + 1e-8
+    assert np.abs(N(dparams) / F32(128.) - rdp).max() <= 4e-3 * np.abs(rdp).max() + 1e-8
+    if use_emb:
+        assert np.abs(N(demb) - rdemb).max() <= 4e-3 * np.abs(rdemb).max() + 1e-8
+
+
+def test_sh_encode(hip, fox_golden):
+    d = fox_golden["march_dirs"][::7]
+    for deg, key in ((4, "sh4"),):
+        out = torch.zeros((len(d), deg * deg), device=DEV)
+        hip.sh_encode(len(d), deg, T(d), out)
+        assert_same(N(out), fox_golden[key], key)
+    d3 = fox_golden["march_dirs"][::31]
+    out = torch.zeros((len(d3), 9), device=DEV)
+    hip.sh_encode(len(d3), 3, T(d3), out)
+    assert_same(N(out), fox_golden["sh3"], "sh3")
+    with pytest.raises(Exception):
+        hip.sh_encode(4, 5, T(d[:4]), torch.zeros((4, 25), device=DEV))  # unsupported degree fails loudly
+
+
+# ---------------------------------------------------------------------------------------------------
+# renderer glue
+# ---------------------------------------------------------------------------------------------------
+def ragged(rng, R, hi=60):
+    cnt = rng.integers(0, hi, R)
+    cnt[::13] = 0
+    end = np.cumsum(cnt)
+    return np.stack([end - cnt, end], -1).astype(np.int32), int(end[-1])
+
+
+def test_segmented_ops_bit_exact(hip, fox_golden):
+    g = fox_golden
+    se, val, vec, dsum = g["march_pts_idx_bounds"], g["seg_val"], g["seg_vec"], g["seg_dsum"]
+    R, n = len(se), len(val)
+    o1 = torch.zeros(R, device=DEV)
+    hip.flex_sum_fwd(R, 1, T(val), T(se), o1)
+    assert_same(N(o1), g["flex_sum"])
+    o3 = torch.zeros((R, 3), device=DEV)
+    hip.flex_sum_fwd(R, 3, T(vec), T(se), o3)
+    assert_same(N(o3), g["flex_sum_vec"])
+    for inc, kf, kb in ((False, "flex_acc_excl", "flex_acc_bwd_excl"), (True, "flex_acc_incl", "flex_acc_bwd_incl")):
+        o = torch.zeros(n, device=DEV)
+        hip.flex_acc_fwd(R, inc, T(val), T(se), o)
+        assert_same(N(o), g[kf])
+        hip.flex_acc_bwd(R, inc, T(val), T(se), o)
+        assert_same(N(o), g[kb])
+    o = torch.zeros(n, device=DEV)
+    hip.flex_sum_bwd(R, 1, T(dsum), T(se), o)
+    assert_same(N(o), g["flex_sum_bwd"])
+    w = (val * F32(0.01)).astype(F32)
+    ov = torch.zeros(R, device=DEV)
+    hip.weight_var_fwd(R, T(w), T(se), ov)
+    assert_same(N(ov), g["weight_var"])
+    od = torch.zeros(n, device=DEV)
+    hip.weight_var_bwd(R, T(w), T(se), T(dsum), od)
+    assert_same(N(od), g["weight_var_bwd"])
+
+
+def test_early_stop_and_compaction(hip):
+    rng = np.random.default_rng(5)
+    R = 700
+    se, n = ragged(rng, R, 90)
+    f0 = (rng.standard_normal(n) * 2 + 3).astype(F32)
+    dt = (rng.random(n, dtype=F32) * F32(0.05)).astype(F32)
+    w = torch.zeros(n, device=DEV); a = torch.zeros(n, device=DEV)
+    mask = torch.zeros(n, dtype=torch.int32, device=DEV); kept = torch.zeros(R, dtype=torch.int32, device=DEV)
+    feat = np.zeros((n, 16), F32); feat[:, 0] = f0
+    hip.early_stop(R, T(se), T(feat), 16, T(dt), w, a, mask, kept)
+    rw, ra, rmask, rse = op.early_stop(f0, dt, se)
+    assert np.abs(N(w) - rw).max() <= 2e-6 and np.abs(N(a) - ra).max() <= 2e-6
+    # expf differs by an ulp between libms: the mask may flip only where T is within 1e-9 of the threshold
+    flips = (N(mask) != rmask).sum()
+    assert flips <= 2, flips
+    new_se = torch.zeros((R, 2), dtype=torch.int32, device=DEV); tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.segment_scan(R, kept, new_se, tot)
+    if flips == 0:
+        assert_same(N(new_se), rse, "FilterIdxBounds")
+    m = int(tot.item())
+    pts = rng.standard_normal((n, 3)).astype(F32); dirs = rng.standard_normal((n, 3)).astype(F32)
+    t = rng.random(n, dtype=F32); anchors = rng.integers(0, 100, (n, 3)).astype(np.int32)
+    o = [torch.zeros((m, 3), device=DEV), torch.zeros((m, 3), device=DEV), torch.zeros(m, device=DEV), torch.zeros(m, device=DEV),
+         torch.zeros((m, 3), dtype=torch.int32, device=DEV)]
+    hip.compact_samples(R, T(se), new_se, mask, T(pts), T(dirs), T(dt), T(t), T(anchors), *o)
+    exp = op.compact(N(mask), pts, dirs, dt, t, anchors)
+    for got, e in zip(o, exp):
+        assert_same(N(got), e, "compaction")
+
+
+@pytest.mark.parametrize("gs", [1.0, 0.3])
+def test_composite_forward_backward(hip, gs):
+    rng = np.random.default_rng(9)
+    R = 600
+    se, n = ragged(rng, R, 70)
+    feat = rng.standard_normal((n, 16)).astype(F32); feat[:, 0] = feat[:, 0] * 2 + 2
+    dt = (rng.random(n, dtype=F32) * F32(0.03)).astype(F32)
+    t = np.sort(rng.random(n, dtype=F32) * 5)
+    rgb = rng.random((n, 3), dtype=F32); bg = rng.random((R, 3), dtype=F32)
+    col = torch.zeros((R, 3), device=DEV); disp = torch.zeros(R, device=DEV); dep = torch.zeros(R, device=DEV)
+    wts = torch.zeros(n, device=DEV)
+    hip.composite_fwd(R, T(se), T(feat), T(dt), T(t), T(rgb), T(bg), col, disp, dep, wts)
+    ref = op.composite_fwd(feat, dt, t, rgb, bg, se, want_ctx=True)
+    for got, k in ((col, "colors"), (disp, "disparity"), (dep, "depth"), (wts, "weights")):
+        assert np.abs(N(got) - ref[k]).max() <= 2e-5 * max(1.0, np.abs(ref[k]).max()), k
+    # conservation: sum of weights + last transmittance == 1 per non-empty ray
+    wsum = oc.flex_sum(N(wts), se)
+    assert np.abs(wsum + ref["ctx"]["last_trans"] - 1)[se[:, 1] > se[:, 0]].max() < 1e-4
+    dcol = rng.standard_normal((R, 3)).astype(F32); ddisp = rng.standard_normal(R).astype(F32)
+    ddep = rng.standard_normal(R).astype(F32) * F32(0.1); dw = rng.standard_normal(n).astype(F32) * F32(0.1)
+    drgb = torch.zeros((n, 3), device=DEV); dfeat = torch.full((n, 16), 5.0, device=DEV)
+    hip.composite_bwd(R, T(se), T(feat), T(dt), T(t), T(rgb), T(bg), T(dcol), T(ddisp), T(ddep), T(dw), gs, drgb, dfeat)
+    rdrgb, rdf0 = op.composite_bwd(ref["ctx"], dt, rgb, bg, se, dcol, ddisp, ddep, dw, gs)
+    assert np.abs(N(drgb) - rdrgb).max() <= 1e-5 * max(1.0, np.abs(rdrgb).max())
+    assert np.abs(N(dfeat)[:, 0] - rdf0).max() <= 2e-4 * max(1.0, np.abs(rdf0).max()), np.abs(N(dfeat)[:, 0] - rdf0).max()
+    assert (N(dfeat)[:, 1:] == 5.0).all()
+    # empty batch and NULL gradient inputs are accepted
+    hip.composite_bwd(R, T(se), T(feat), T(dt), T(t), T(rgb), T(bg), T(dcol), None, None, None, 1.0, drgb, dfeat)
+    rdrgb2, _ = op.composite_bwd(ref["ctx"], dt, rgb, bg, se, dcol)
+    assert np.abs(N(drgb) - rdrgb2).max() <= 1e-5 * max(1.0, np.abs(rdrgb2).max())
+
+
+def test_adam(hip):
+    rng = np.random.default_rng(13)
+    n = 4096 * 3
+    p = rng.standard_normal(n).astype(F32); g = (rng.standard_normal(n) * 1e-3).astype(F32); g[::3] = 0
+    m = (rng.standard_normal(n) * 1e-3).astype(F32); v = (rng.random(n) * 1e-6).astype(F32)
+    for step, wd in ((1, 0.0), (10, 1e-6)):
+        tp, tm, tv = T(p), T(m), T(v)
+        ph = torch.zeros(n, dtype=torch.float16, device=DEV)
+        hip.adam_step(n, tp, T(g * 128), 1.0 / 128, False, tm, tv, step, 1e-2, 0.9, 0.99, 1e-15, wd, ph)
+        rp, rm, rv = op.adam_step(p, g, m, v, step, 1e-2, 0.9, 0.99, 1e-15, wd)
+        assert np.abs(N(tp) - rp).max() <= 1e-6 * np.abs(rp).max() + 1e-7
+        assert np.abs(N(tm) - rm).max() <= 1e-9 and np.abs(N(tv) - rv).max() <= 1e-12
+        assert_same(N(ph).view(np.uint16), oc.f2h(N(tp)), "h16 refresh")
+    # h16-gradient variant (hash table): grad is consumed and re-zeroed
+    gh = (g * 128).astype(np.float16)
+    tp, tm, tv, tg = T(p), T(m), T(v), T(gh)
+    ph = torch.zeros(n, dtype=torch.float16, device=DEV)
+    hip.adam_step_h16grad(n, tp, tg, 1.0 / 128, tm, tv, 3, 1e-2, 0.9, 0.99, 1e-15, 0.0, ph, True)
+    rp, rm, rv = op.adam_step(p, gh.astype(F32) / F32(128), m, v, 3, 1e-2)
+    assert np.abs(N(tp) - rp).max() <= 1e-6 * np.abs(rp).max() + 1e-7
+    assert (N(tg).view(np.uint16) == 0).all()
+    assert_same(N(ph).view(np.uint16), oc.f2h(N(tp)), "table refresh")
+    # entries with zero gradient and zero moments do not move (dense Adam == sparse Adam there)
+    z = np.zeros(8, F32)
+    tz = T(z + 1); hip.adam_step(8, tz, T(z), 1.0, False, T(z), T(z), 5, 1e-2, 0.9, 0.99, 1e-15, 0.0, None)
+    assert (N(tz) == 1).all()
+
+
+def test_errors_are_loud(hip):
+    x = torch.zeros((4, 32), device=DEV)
+    with pytest.raises(Exception):
+        hip.mlp_fwd(4, 16, 64, 1, torch.zeros(10, dtype=torch.float16, device=DEV), x, torch.zeros((4, 16), dtype=torch.float16, device=DEV))
+    with pytest.raises(Exception):
+        hip.mlp_fwd(4, 32, 64, 1, torch.zeros(3072, dtype=torch.float16), x, torch.zeros((4, 16), dtype=torch.float16, device=DEV))  # CPU tensor

@@ -1,0 +1,129 @@
+"""CPU: self-consistency of the oracle's host-pipeline restatement (oracle/pipeline.py): its hand-written
+backward chains are checked against float64 torch autograd of the same formulas, and the MLP restatement
+against a plain fp32 network."""
+import numpy as np
+import torch
+
+from oracle import capi as oc
+from oracle import pipeline as op
+
+F32 = np.float32
+
+
+def ragged(rng, R, hi=40):
+    cnt = rng.integers(0, hi, R)
+    cnt[::11] = 0
+    end = np.cumsum(cnt)
+    return np.stack([end - cnt, end], -1).astype(np.int32), int(end[-1])
+
+
+def test_composite_backward_matches_autograd():
+    rng = np.random.default_rng(1)
+    R = 120
+    se, n = ragged(rng, R)
+    feat = rng.standard_normal((n, 16)).astype(F32); feat[:, 0] = feat[:, 0] + 2
+    dt = (rng.random(n) * 0.03).astype(F32); t = (rng.random(n) * 5).astype(F32)
+    rgb = rng.random((n, 3)).astype(F32); bg = rng.random((R, 3)).astype(F32)
+    dcol = rng.standard_normal((R, 3)).astype(F32); ddisp = rng.standard_normal(R).astype(F32)
+    ddep = (rng.standard_normal(R) * 0.1).astype(F32); dw = (rng.standard_normal(n) * 0.1).astype(F32)
+    out = op.composite_fwd(feat, dt, t, rgb, bg, se, want_ctx=True)
+    drgb, df0 = op.composite_bwd(out["ctx"], dt, rgb, bg, se, dcol, ddisp, ddep, dw, 1.0)
+    # float64 autograd of the same maths
+    f0 = torch.tensor(feat[:, 0], dtype=torch.float64, requires_grad=True)
+    c = torch.tensor(rgb, dtype=torch.float64, requires_grad=True)
+    loss = 0
+    cols, disps, deps, ws = [], [], [], []
+    for r in range(R):
+        s, e = se[r]
+        sig = torch.exp(f0[s:e] - 3); sec = sig * torch.tensor(dt[s:e], dtype=torch.float64)
+        acc = torch.cumsum(sec, 0) - sec
+        T = torch.exp(-acc); w = T * (1 - torch.exp(-sec)); last = torch.exp(-sec.sum())
+        tt = torch.tensor(t[s:e], dtype=torch.float64) + 1e-2
+        col = (w[:, None] * c[s:e]).sum(0) + last * torch.tensor(bg[r], dtype=torch.float64)
+        loss = loss + (col * torch.tensor(dcol[r], dtype=torch.float64)).sum() + (w / tt).sum() * float(ddisp[r]) \
+            + (w * tt).sum() / (1 - last + 1e-4) * float(ddep[r]) + (w * torch.tensor(dw[s:e], dtype=torch.float64)).sum()
+        cols.append(col.detach().numpy())
+    loss.backward()
+    np.testing.assert_allclose(out["colors"], np.array(cols), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(drgb, c.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(df0, f0.grad.numpy(), rtol=2e-3, atol=2e-5)
+    # gradient scaling only rescales per-sample gradients
+    drgb2, df02 = op.composite_bwd(out["ctx"], dt, rgb, bg, se, dcol, ddisp, ddep, dw, 0.25)
+    sc = oc.grad_scaling_bwd(np.ones(n, F32), se, 0.25)
+    np.testing.assert_allclose(drgb2, drgb * sc[:, None], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(df02, df0 * sc, rtol=1e-5, atol=1e-9)
+
+
+def _params(rng, n_hidden):
+    n = oc.mlp_n_params(32, 64, n_hidden)
+    return (rng.standard_normal(n) * 0.15).astype(F32)
+
+
+def _torch_mlp(params, x, n_hidden):
+    off, h = 0, x
+    dims = [(64, 32)] + [(64, 64)] * (n_hidden - 1) + [(16, 64)]
+    for li, (r, c) in enumerate(dims):
+        h = h @ params[off:off + r * c].reshape(r, c).t()
+        off += r * c
+        if li < len(dims) - 1:
+            h = torch.relu(h)
+    return h
+
+
+def test_mlp_restatement_close_to_fp32_network():
+    rng = np.random.default_rng(2)
+    for nh in (1, 2):
+        p = _params(rng, nh)
+        x = rng.standard_normal((300, 32)).astype(F32)
+        out_h, acts = oc.mlp_fwd(p, x, 64, nh, want_acts=True)
+        pt = torch.tensor(p, requires_grad=True); xt = torch.tensor(x, requires_grad=True)
+        y = _torch_mlp(pt, xt, nh)
+        np.testing.assert_allclose(oc.h2f(out_h), y.detach().numpy(), rtol=0, atol=2e-2)
+        dy = (rng.standard_normal((300, 16)) * 1e-2).astype(F32)
+        (y * torch.tensor(dy)).sum().backward()
+        dp, dx, dxh = oc.mlp_bwd(p, x, acts, dy, 64, nh, 128.0)
+        assert np.abs(dp - pt.grad.numpy()).max() <= 3e-2 * np.abs(pt.grad.numpy()).max()
+        # fp16 activations flip a few ReLU masks relative to the fp32 network: rare elements move by a few percent
+        edx = np.abs(dx - xt.grad.numpy())
+        assert edx.max() <= 0.12 * np.abs(xt.grad.numpy()).max() and edx.mean() <= 2e-3 * np.abs(xt.grad.numpy()).max()
+        np.testing.assert_array_equal(dxh, oc.f2h(dx * F32(128.)))
+
+
+def test_shade_and_field_pipeline_shapes(fox_state, fox_golden):
+    rng = np.random.default_rng(3)
+    g = fox_golden
+    n = 500
+    grid = op.HashGrid((rng.standard_normal((16 << 10, 2)) * 0.5).astype(F32), fox_state["prim_pool"], fox_state["bias_pool"],
+                       int(fox_state["n_volumes"]), 10)
+    p1, p2 = _params(rng, 1), _params(rng, 2)
+    feat, ctx = op.field_fwd(grid, p1, g["march_pts"][:n], g["march_anchors"][:n, 0], want_ctx=True)
+    assert feat.shape == (n, 16)
+    dparams, gtab, _ = op.field_bwd(grid, p1, ctx, (rng.standard_normal((n, 16)) * 1e-3).astype(F32))
+    assert dparams.shape == (3072,) and gtab.shape == (grid.table_f32.size,)
+    # only halves [0, 17 * 2^(log2-1)*... ) are addressed: the level-overlap quirk
+    touched = np.nonzero(gtab)[0]
+    assert touched.max() < 17 * (1 << 10)
+    rgb, sctx = op.shade_fwd(p2, feat, g["march_dirs"][:n], want_ctx=True)
+    assert rgb.shape == (n, 3) and (rgb > -1e-3 - 1e-6).all() and (rgb < 1 + 1e-3 + 1e-6).all()
+    dp, dfeat, demb = op.shade_bwd(p2, sctx, (rng.standard_normal((n, 3)) * 1e-3).astype(F32))
+    assert dp.shape == (7168,) and (dfeat[:, 0] == 0).all() and demb is None
+
+
+def test_early_stop_prefix_and_adam():
+    rng = np.random.default_rng(4)
+    se, n = ragged(rng, 200, 80)
+    f0 = (rng.standard_normal(n) * 2 + 4).astype(F32); dt = (rng.random(n) * 0.05).astype(F32)
+    w, a, mask, nse = op.early_stop(f0, dt, se)
+    for s, e in se:  # the kept set of every ray is a prefix (T is non-increasing)
+        m = mask[s:e]
+        assert (np.diff(m) <= 0).all()
+    assert nse[-1, 1] == mask.sum()
+    p = rng.standard_normal(1000).astype(F32); g = (rng.standard_normal(1000) * 1e-3).astype(F32)
+    pt = torch.tensor(p.copy(), requires_grad=True)
+    opt = torch.optim.Adam([pt], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6)
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for step in range(1, 4):
+        pt.grad = torch.tensor(g)
+        opt.step()
+        p, m, v = op.adam_step(p, g, m, v, step, 1e-2, 0.9, 0.99, 1e-15, 1e-6)
+        np.testing.assert_allclose(p, pt.detach().numpy(), rtol=2e-6, atol=1e-7)
