@@ -1,0 +1,164 @@
+// ExpRunner: the training / rendering driver of the hot path (mirrors src/ExpRunner.h/.cpp of the reference:
+// loss terms, NaN-skip, LR / fineness / gradient-scaling schedules, checkpoint state order).  Dataset handling
+// (image loading, ray generation) is outside the hot path: rays and ground-truth colours are inputs here.
+// The optimiser is the fused Adam of csrc/optim.hip driven over the modules' parameter groups; multi-GPU data
+// parallelism hooks in through `grad_sync_hook_` (called after backward, before the step).
+#include "ExpRunner.h"
+
+namespace f2n {
+
+ExpRunner::ExpRunner(const std::map<std::string, std::string>& flat_config, int n_images) {
+  global_data_pool_ = std::make_unique<GlobalDataPool>();
+  global_data_pool_->config_.kv = flat_config;
+  const auto& c = global_data_pool_->config_;
+  pts_batch_size_ = c.Int("train.pts_batch_size");  // ExpRunner.cpp:28-45
+  end_iter_ = c.Int("train.end_iter");
+  learning_rate_ = c.Float("train.learning_rate");
+  learning_rate_alpha_ = c.Float("train.learning_rate_alpha");
+  learning_rate_warm_up_end_iter_ = c.Int("train.learning_rate_warm_up_end_iter");
+  ray_march_init_fineness_ = c.Float("train.ray_march_init_fineness");
+  ray_march_fineness_decay_end_iter_ = c.Int("train.ray_march_fineness_decay_end_iter");
+  tv_loss_weight_ = c.Float("train.tv_loss_weight");
+  disp_loss_weight_ = c.Float("train.disp_loss_weight");
+  var_loss_weight_ = c.Float("train.var_loss_weight");
+  var_loss_start_ = c.Int("train.var_loss_start");
+  var_loss_end_ = c.Int("train.var_loss_end");
+  gradient_scaling_start_ = c.Int("train.gradient_scaling_start");
+  gradient_scaling_end_ = c.Int("train.gradient_scaling_end");
+  global_data_pool_->n_volumes_ = c.Has("runtime.n_volumes") ? c.Int("runtime.n_volumes") : 1;
+  renderer_ = std::make_unique<Renderer>(global_data_pool_.get(), n_images);
+  BuildOptimizer();
+  UpdateAdaParams();
+}
+
+void ExpRunner::BuildOptimizer() {
+  groups_ = renderer_->OptimParamGroups();
+  exp_avg_.clear();
+  exp_avg_sq_.clear();
+  for (auto& g : groups_) {
+    exp_avg_.push_back(torch::zeros_like(g.param.detach()));
+    exp_avg_sq_.push_back(torch::zeros_like(g.param.detach()));
+  }
+  optim_steps_ = 0;
+}
+
+void ExpRunner::LoadStates(const std::vector<Tensor>& states) {
+  int used = renderer_->LoadStates(states, 0);
+  TORCH_CHECK(used == (int) states.size(), "state vector has ", states.size(), " tensors, consumed ", used);
+  BuildOptimizer();  // parameter tensors may have been re-created (primes, nodes): re-bind the groups
+}
+
+// ExpRunner.cpp:221-254
+void ExpRunner::UpdateAdaParams() {
+  auto* gdp = global_data_pool_.get();
+  if (iter_step_ >= ray_march_fineness_decay_end_iter_) {
+    gdp->ray_march_fineness_ = 1.f;
+  } else {
+    float progress = float(iter_step_) / float(ray_march_fineness_decay_end_iter_);
+    gdp->ray_march_fineness_ = std::exp(std::log(1.f) * progress + std::log(ray_march_init_fineness_) * (1.f - progress));
+  }
+  float lr_factor;
+  if (iter_step_ >= learning_rate_warm_up_end_iter_) {
+    float progress = float(iter_step_ - learning_rate_warm_up_end_iter_) / float(end_iter_ - learning_rate_warm_up_end_iter_);
+    lr_factor = (1.f - learning_rate_alpha_) * (std::cos(progress * float(M_PI)) * .5f + .5f) + learning_rate_alpha_;
+  } else {
+    lr_factor = float(iter_step_) / float(learning_rate_warm_up_end_iter_);
+  }
+  cur_lr_ = learning_rate_ * lr_factor;
+  float progress = 1.f;
+  if (iter_step_ < gradient_scaling_end_) {
+    progress = std::max(0.f, (float(iter_step_) - gradient_scaling_start_) / (gradient_scaling_end_ - gradient_scaling_start_ + 1e-9f));
+  }
+  gdp->gradient_scaling_progress_ = progress;
+  gdp->iter_step_ = iter_step_;
+}
+
+int ExpRunner::CurBatchSize() const {  // ExpRunner.cpp:86
+  return int(pts_batch_size_ / global_data_pool_->meaningful_sampled_pts_per_ray_) >> 4 << 4;
+}
+
+void ExpRunner::OptimStep() {
+  optim_steps_ += 1;
+  void* st = CurStream();
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  torch::NoGradGuard no_grad;
+  for (size_t i = 0; i < groups_.size(); i++) {
+    auto& g = groups_[i];
+    const int64_t n = g.active > 0 ? g.active : g.param.numel();
+    float scale = g.grad_scale;
+    if (scale < 0.f) scale = 1.f / (g.name == "color_mlp" ? shader->mlp_->loss_scale_ : field->mlp_->loss_scale_);
+    if (g.grad_is_h16) {
+      F2N_CALL(f2n_adam_step_h16grad(st, (int) n, F32P(g.param), VoidP(g.grad), scale, F32P(exp_avg_[i]),
+                                     F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
+                                     VoidP(g.param_h), /*zero_grad=*/1));
+    } else {
+      F2N_CALL(f2n_adam_step(st, (int) n, F32P(g.param), F32P(g.grad), scale, g.grad_round_h16 ? 1 : 0, F32P(exp_avg_[i]),
+                             F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
+                             g.param_h.defined() ? VoidP(g.param_h) : nullptr));
+    }
+  }
+}
+
+// One iteration of ExpRunner::Train (ExpRunner.cpp:82-143) for a given ray batch.
+TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
+                                const Tensor& emb_idx, bool apply_optimizer) {
+  auto* gdp = global_data_pool_.get();
+  gdp->mode_ = RunningMode::TRAIN;
+  gdp->backward_nan_ = false;
+  const int batch = rays_o.size(0);
+  auto rr = renderer_->Render(rays_o, rays_d, bounds, emb_idx);
+  TrainStats stats;
+  stats.n_rays = batch;
+  stats.n_samples = renderer_->last_n_all_pts_;
+  stats.n_meaningful = renderer_->last_n_kept_pts_;
+  Tensor pred_colors = rr.colors.index({Slc(0, batch)});
+  Tensor color_loss = torch::sqrt((pred_colors - gt_colors).square() + 1e-4f).mean();
+  Tensor loss = color_loss;
+  if (rr.weights.defined()) {
+    Tensor disparity_loss = rr.disparity.square().mean();
+    Tensor tv_loss = (rr.edge_feats.index({Slc(), 0}) - rr.edge_feats.index({Slc(), 1})).square().mean();
+    Tensor sampled_var = CustomOps::WeightVar(rr.weights, rr.idx_start_end);
+    Tensor var_loss = (sampled_var + 1e-2).sqrt().mean();
+    float var_w = 0.f;  // ExpRunner.cpp:108-114
+    if (iter_step_ > var_loss_end_) var_w = var_loss_weight_;
+    else if (iter_step_ > var_loss_start_) var_w = float(iter_step_ - var_loss_start_) / float(var_loss_end_ - var_loss_start_) * var_loss_weight_;
+    loss = color_loss + var_loss * var_w + disparity_loss * disp_loss_weight_ + tv_loss * tv_loss_weight_;
+  }
+  stats.loss = loss.detach();
+  stats.mse = (pred_colors.detach() - gt_colors).square().mean();
+  if (loss.requires_grad()) {
+    renderer_->ZeroGrad();
+    loss.backward();
+    if (grad_sync_hook_) grad_sync_hook_();  // data-parallel all-reduce of the gradient buffers (RCCL)
+    if (check_nan_) {  // TCNNWP.cpp:234-240 + ExpRunner.cpp:131-134
+      auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+      auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+      bool ok = field->mlp_->CheckGradFinite();
+      ok = shader->mlp_->CheckGradFinite() && ok;
+      (void) ok;
+    }
+    if (gdp->backward_nan_) {
+      stats.skipped_nan = true;
+      return stats;  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
+    }
+    if (apply_optimizer) OptimStep();
+  }
+  if (apply_optimizer) {
+    iter_step_++;
+    UpdateAdaParams();
+  }
+  return stats;
+}
+
+// ExpRunner::RenderWholeImage chunk body (ExpRunner.cpp:268-287), VALIDATE mode.
+std::vector<Tensor> ExpRunner::RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  torch::NoGradGuard no_grad;
+  auto prev = global_data_pool_->mode_;
+  global_data_pool_->mode_ = RunningMode::VALIDATE;
+  auto rr = renderer_->Render(rays_o, rays_d, bounds, Tensor());
+  global_data_pool_->mode_ = prev;
+  return {rr.colors, rr.disparity, rr.first_oct_dis, rr.depth};
+}
+
+}  // namespace f2n

@@ -1,0 +1,47 @@
+// ExpRunner (mirrors src/ExpRunner.h): owns GlobalDataPool, Renderer and the optimiser state.
+#pragma once
+#include <functional>
+
+#include "Renderer.h"
+
+namespace f2n {
+
+struct TrainStats {
+  Tensor loss, mse;  // device scalars (read them only when reporting: no per-iteration host sync)
+  int n_rays = 0, n_samples = 0, n_meaningful = 0;
+  bool skipped_nan = false;
+};
+
+class ExpRunner {
+ public:
+  ExpRunner(const std::map<std::string, std::string>& flat_config, int n_images);
+  void LoadStates(const std::vector<Tensor>& states);  // checkpoint order, see SURVEY.md section 5
+  std::vector<Tensor> States() { return renderer_->States(); }
+  TrainStats TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
+                       const Tensor& emb_idx, bool apply_optimizer = true);
+  std::vector<Tensor> RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
+  void UpdateAdaParams();
+  void OptimStep();
+  void BuildOptimizer();
+  int CurBatchSize() const;
+
+  int iter_step_ = 0, end_iter_;
+  int pts_batch_size_;
+  float learning_rate_, learning_rate_alpha_, learning_rate_warm_up_end_iter_;
+  float ray_march_init_fineness_;
+  int ray_march_fineness_decay_end_iter_;
+  float tv_loss_weight_, disp_loss_weight_, var_loss_weight_;
+  int var_loss_start_, var_loss_end_;
+  float gradient_scaling_start_, gradient_scaling_end_;
+  float cur_lr_ = 0.f;
+  bool check_nan_ = true;
+  int optim_steps_ = 0;
+  std::function<void()> grad_sync_hook_;
+
+  std::unique_ptr<GlobalDataPool> global_data_pool_;
+  std::unique_ptr<Renderer> renderer_;
+  std::vector<ParamGroup> groups_;
+  std::vector<Tensor> exp_avg_, exp_avg_sq_;
+};
+
+}  // namespace f2n

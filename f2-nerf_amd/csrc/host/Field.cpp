@@ -1,0 +1,248 @@
+// FusedMLP + Hash3DAnchored host logic.
+#include "Hash3DAnchored.h"
+
+namespace f2n {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+// ---------------------------------------------------------------------------------------------------------
+// FusedMLP
+// ---------------------------------------------------------------------------------------------------------
+FusedMLP::FusedMLP(GlobalDataPool* gdp, int d_in, int d_out, int d_hidden, int n_hidden_layers) {
+  global_data_pool_ = gdp;
+  d_in_ = d_in; d_out_ = d_out; d_hidden_ = d_hidden; n_hidden_layers_ = n_hidden_layers;
+  n_params_ = f2n_mlp_n_params(d_in, d_hidden, n_hidden_layers);
+  TORCH_CHECK(n_params_ > 0 && d_out <= F2N_MLP_OUT_PAD, "unsupported MLP shape");
+  params_ = torch::zeros({n_params_}, DevF32());
+  params_h_ = torch::zeros({n_params_}, DevF16());
+  grad_scaled_ = torch::zeros({n_params_}, DevF32());
+  InitParams();
+  params_.requires_grad_(true);
+}
+
+void FusedMLP::InitParams() {
+  torch::NoGradGuard g;
+  const uint64_t seed = 19970826;  // TCNNWP.cpp:96
+  F2N_CALL(f2n_mlp_init_params(CurStream(), seed + (uint64_t) n_hidden_layers_, d_in_, d_hidden_, n_hidden_layers_,
+                               F32P(params_)));
+  SyncHalf();
+}
+
+void FusedMLP::SyncHalf() {
+  F2N_CALL(f2n_params_to_h16(CurStream(), n_params_, F32P(params_), VoidP(params_h_)));
+}
+
+void FusedMLP::ZeroGrad() { grad_scaled_.zero_(); }
+
+Tensor FusedMLP::GradUnscaled() {
+  return ((grad_scaled_.to(torch::kFloat16).to(torch::kFloat32) / loss_scale_).to(torch::kFloat16)).to(torch::kFloat32);
+}
+
+bool FusedMLP::CheckGradFinite() {  // TCNNWP.cpp:234-240
+  bool finite = torch::all(torch::isfinite(grad_scaled_)).item<bool>();
+  if (!finite) {
+    global_data_pool_->backward_nan_ = true;
+    loss_scale_ = std::max(loss_scale_ / 2.f, 1.f);
+  }
+  return finite;
+}
+
+namespace {
+
+struct MlpFunction : public torch::autograd::Function<MlpFunction> {
+  static variable_list forward(AutogradContext* ctx, Tensor x, Tensor params, int64_t mlp_ptr) {
+    auto* mlp = reinterpret_cast<FusedMLP*>(mlp_ptr);
+    ctx->saved_data["mlp"] = mlp_ptr;
+    ctx->save_for_backward({x});
+    const int n = x.size(0);
+    Tensor out = torch::empty({n, F2N_MLP_OUT_PAD}, DevF16());
+    F2N_CALL(f2n_mlp_fwd(CurStream(), n, mlp->d_in_, mlp->d_hidden_, mlp->n_hidden_layers_, VoidP(mlp->params_h_),
+                         F32P(x), VoidP(out)));
+    return {out.to(torch::kFloat32)};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_output) {
+    auto* mlp = reinterpret_cast<FusedMLP*>(ctx->saved_data["mlp"].toInt());
+    Tensor x = ctx->get_saved_variables()[0];
+    Tensor dy = grad_output[0].contiguous();
+    const int n = x.size(0);
+    Tensor dx = torch::empty({n, mlp->d_in_}, DevF32());
+    F2N_CALL(f2n_mlp_bwd(CurStream(), n, mlp->d_in_, mlp->d_hidden_, mlp->n_hidden_layers_, mlp->loss_scale_,
+                         VoidP(mlp->params_h_), F32P(x), F32P(dy), F32P(mlp->grad_scaled_), F32P(dx)));
+    return {dx, Tensor(), Tensor()};  // parameter gradient is delivered through mlp->grad_scaled_
+  }
+};
+
+}  // namespace
+
+Tensor FusedMLP::Query(const Tensor& pts) {  // TCNNWP.cpp:102-113 (no 128-row padding needed here)
+  Tensor x = pts.contiguous();
+  CheckDev(x, torch::kFloat32, "mlp input");
+  TORCH_CHECK(x.size(1) == d_in_, "mlp input width");
+  Tensor out = MlpFunction::apply(x, params_, reinterpret_cast<int64_t>(this))[0];
+  return out.index({Slc(), Slc(0, d_out_)}).contiguous();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Hash3DAnchored
+// ---------------------------------------------------------------------------------------------------------
+Hash3DAnchored::Hash3DAnchored(GlobalDataPool* gdp) {  // Hash3DAnchored.cpp:19-82
+  global_data_pool_ = gdp;
+  gdp->scene_field_ = this;
+  const auto& c = gdp->config_;
+  pool_size_ = (1 << c.Int("field.log2_table_size")) * N_LEVELS;
+  mlp_hidden_dim_ = c.Int("field.mlp_hidden_dim");
+  mlp_out_dim_ = c.Int("field.mlp_out_dim");
+  n_hidden_layers_ = c.Int("field.n_hidden_layers");
+  n_volumes_ = gdp->n_volumes_;
+  feat_pool_ = (torch::rand({pool_size_, N_CHANNELS}, DevF32()) * .2f - 1.f) * 1e-4f;
+  feat_pool_.requires_grad_(true);
+  feat_pool_h_ = torch::zeros({pool_size_, N_CHANNELS}, DevF16());
+  grad_h_ = torch::zeros({pool_size_, N_CHANNELS}, DevF16());
+  // primes / biases are part of the serialised state (checkpoint order); placeholders until LoadStates
+  prim_pool_ = torch::ones({N_LEVELS, n_volumes_, 3}, DevI32());
+  bias_pool_ = torch::zeros({N_LEVELS * n_volumes_, 3}, DevF32());
+  int local_size = pool_size_ / N_LEVELS;
+  local_size = (local_size >> 4) << 4;
+  feat_local_size_ = torch::full({N_LEVELS}, local_size, DevI32());
+  feat_local_idx_ = (torch::arange(N_LEVELS, DevI32()) * local_size).contiguous();
+  std::vector<float> scales(N_LEVELS);
+  for (int l = 0; l < N_LEVELS; l++)  // Hash3DAnchored.cu:28, evaluated once on the host
+    scales[l] = exp2f((RES_FINE_POW_2 - RES_BASE_POW_2) * float(l) / float(N_LEVELS - 1) + RES_BASE_POW_2);
+  level_scale_ = torch::from_blob(scales.data(), {N_LEVELS}, CpuF32()).to(torch::kCUDA).contiguous();
+  // level l addresses halves [l*local, l*local + 2*local): the union is [0, (N_LEVELS+1)*local)
+  active_halves_ = std::min<int64_t>(int64_t(N_LEVELS + 1) * local_size, int64_t(pool_size_) * N_CHANNELS);
+  mlp_ = std::make_unique<FusedMLP>(gdp, N_LEVELS * N_CHANNELS, mlp_out_dim_, mlp_hidden_dim_, n_hidden_layers_);
+  SyncHalf();
+}
+
+void Hash3DAnchored::SyncHalf() {  // Hash3DAnchored.cu:186 (done once here; afterwards by the optimiser step)
+  torch::NoGradGuard g;
+  F2N_CALL(f2n_params_to_h16(CurStream(), pool_size_ * N_CHANNELS, F32P(feat_pool_), VoidP(feat_pool_h_)));
+  mlp_->SyncHalf();
+}
+
+void Hash3DAnchored::ZeroGrad() {
+  grad_h_.zero_();
+  mlp_->ZeroGrad();
+}
+
+Tensor Hash3DAnchored::TableGradUnscaled() { return grad_h_.to(torch::kFloat32) / 128.f; }
+
+namespace {
+
+struct AnchorView {
+  Tensor t;
+  int stride;
+};
+AnchorView ViewAnchors(const Tensor& anchors) {
+  Tensor a = anchors.contiguous();
+  CheckDev(a, torch::kInt32, "anchors");
+  if (a.dim() == 2) return {a, (int) a.size(1)};
+  return {a, 1};
+}
+
+struct FieldFunction : public torch::autograd::Function<FieldFunction> {
+  static variable_list forward(AutogradContext* ctx, Tensor feat_pool, Tensor mlp_params, Tensor points, Tensor anchors,
+                               int64_t field_ptr) {
+    auto* f = reinterpret_cast<Hash3DAnchored*>(field_ptr);
+    const int n = points.size(0);
+    AnchorView av = ViewAnchors(anchors);
+    Tensor feat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
+    Tensor saved_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
+    F2N_CALL(f2n_field_fwd(CurStream(), n, f->n_volumes_, VoidP(f->feat_pool_h_), I32P(f->prim_pool_),
+                           I32P(f->feat_local_idx_), I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_),
+                           F32P(points), I32P(av.t), av.stride, VoidP(f->mlp_->params_h_), F32P(feat), nullptr,
+                           VoidP(saved_x)));
+    ctx->saved_data["field"] = field_ptr;
+    ctx->save_for_backward({points, av.t, saved_x});
+    ctx->saved_data["stride"] = (int64_t) av.stride;
+    return {feat};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_output) {
+    auto* f = reinterpret_cast<Hash3DAnchored*>(ctx->saved_data["field"].toInt());
+    auto saved = ctx->get_saved_variables();
+    Tensor dfeat = grad_output[0].contiguous();
+    const int n = saved[0].size(0);
+    F2N_CALL(f2n_field_bwd(CurStream(), n, f->n_volumes_, I32P(f->prim_pool_), I32P(f->feat_local_idx_),
+                           I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_), F32P(saved[0]),
+                           I32P(saved[1]), (int) ctx->saved_data["stride"].toInt(), VoidP(f->mlp_->params_h_),
+                           VoidP(saved[2]), F32P(dfeat), f->mlp_->loss_scale_, F32P(f->mlp_->grad_scaled_), VoidP(f->grad_h_)));
+    // gradients live in f->grad_h_ (fp16, x128) and f->mlp_->grad_scaled_: consumed by the fused optimiser step
+    return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+}  // namespace
+
+Tensor Hash3DAnchored::AnchoredQuery(const Tensor& points, const Tensor& anchors) {  // Hash3DAnchored.cpp:84-99
+  Tensor pts = points.contiguous();
+  CheckDev(pts, torch::kFloat32, "points");
+  Tensor feat = FieldFunction::apply(feat_pool_, mlp_->params_, pts, anchors, reinterpret_cast<int64_t>(this))[0];
+  return mlp_out_dim_ == F2N_MLP_OUT_PAD ? feat : feat.index({Slc(), Slc(0, mlp_out_dim_)}).contiguous();
+}
+
+Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& anchors) {
+  torch::NoGradGuard g;
+  Tensor pts = points.contiguous();
+  CheckDev(pts, torch::kFloat32, "points");
+  AnchorView av = ViewAnchors(anchors);
+  const int n = pts.size(0);
+  Tensor f0 = torch::empty({n}, DevF32());
+  F2N_CALL(f2n_field_fwd(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_), I32P(feat_local_idx_),
+                         I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), I32P(av.t), av.stride,
+                         VoidP(mlp_->params_h_), nullptr, F32P(f0), nullptr));
+  return f0;
+}
+
+int Hash3DAnchored::LoadStates(const std::vector<Tensor>& states, int idx) {  // Hash3DAnchored.cpp:101-110
+  torch::NoGradGuard g;
+  feat_pool_.copy_(states[idx++].to(torch::kCUDA).to(torch::kFloat32).reshape({pool_size_, N_CHANNELS}));
+  prim_pool_ = states[idx++].clone().to(torch::kCUDA).to(torch::kInt32).contiguous();
+  bias_pool_ = states[idx++].clone().to(torch::kCUDA).to(torch::kFloat32).contiguous();
+  n_volumes_ = states[idx++].item<int>();
+  TORCH_CHECK(prim_pool_.numel() == int64_t(N_LEVELS) * n_volumes_ * 3 && bias_pool_.numel() == int64_t(N_LEVELS) * n_volumes_ * 3,
+              "prime/bias pools do not match n_volumes");
+  mlp_->params_.copy_(states[idx++].to(torch::kCUDA).to(torch::kFloat32));
+  SyncHalf();
+  return idx;
+}
+
+std::vector<Tensor> Hash3DAnchored::States() {  // Hash3DAnchored.cpp:112-122
+  return {feat_pool_.detach(), prim_pool_, bias_pool_, torch::full({1}, n_volumes_, CpuI32()), mlp_->params_.detach()};
+}
+
+std::vector<ParamGroup> Hash3DAnchored::OptimParamGroups() {  // Hash3DAnchored.cpp:124-150
+  ParamGroup table;
+  table.name = "feat_pool";
+  table.param = feat_pool_;
+  table.grad = grad_h_;
+  table.param_h = feat_pool_h_;
+  table.grad_scale = 1.f / 128.f;
+  table.grad_is_h16 = true;
+  table.active = active_halves_;
+  ParamGroup mlp;
+  mlp.name = "field_mlp";
+  mlp.param = mlp_->params_;
+  mlp.grad = mlp_->grad_scaled_;
+  mlp.param_h = mlp_->params_h_;
+  mlp.weight_decay = 1e-6f;
+  mlp.grad_round_h16 = true;
+  mlp.grad_scale = -1.f;  // resolved at step time from mlp_->loss_scale_ (it can halve on NaN)
+  return {table, mlp};
+}
+
+void Hash3DAnchored::Reset() {  // Hash3DAnchored.cpp:152-155
+  torch::NoGradGuard g;
+  feat_pool_.uniform_(-1e-2f, 1e-2f);
+  mlp_->InitParams();
+  SyncHalf();
+}
+
+std::unique_ptr<Field> ConstructField(GlobalDataPool* gdp) {  // FieldFactory.cpp:7-16
+  const std::string type = gdp->config_.Str("field.type");
+  TORCH_CHECK(type == "Hash3DAnchored", "unknown field.type: ", type);
+  return std::make_unique<Hash3DAnchored>(gdp);
+}
+
+}  // namespace f2n

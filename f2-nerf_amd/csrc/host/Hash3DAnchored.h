@@ -1,0 +1,41 @@
+// Hash3DAnchored host side (mirrors src/Field/Hash3DAnchored.h/.cpp).
+#pragma once
+#include "FusedMLP.h"
+
+namespace f2n {
+
+#define N_CHANNELS 2
+#define N_LEVELS 16
+#define RES_FINE_POW_2 10.f
+#define RES_BASE_POW_2 3.f
+
+class Hash3DAnchored : public Field {
+ public:
+  explicit Hash3DAnchored(GlobalDataPool* global_data_pool);
+  // points: warped coords [n,3]; anchors: [n] (trans idx) or the sampler's [n,3] anchors read in place
+  Tensor AnchoredQuery(const Tensor& points, const Tensor& anchors) override;
+  // no-grad density pre-activation only (channel 0) for Renderer's early-stop pre-pass
+  Tensor QueryDensityPreAct(const Tensor& points, const Tensor& anchors);
+
+  int LoadStates(const std::vector<Tensor>& states, int idx) override;
+  std::vector<Tensor> States() override;
+  std::vector<ParamGroup> OptimParamGroups() override;
+  void Reset() override;
+  void SyncHalf();
+  void ZeroGrad();
+  Tensor TableGradUnscaled();  // fp32 [pool,2] = grad_h / 128 (Hash3DAnchored.cu:232)
+
+  int pool_size_;
+  int mlp_hidden_dim_, mlp_out_dim_, n_hidden_layers_;
+  Tensor feat_pool_;       // [pool_size_, 2] fp32 master
+  Tensor feat_pool_h_;     // fp16 working table (what the kernels gather from)
+  Tensor grad_h_;          // fp16 gradient table, loss-scaled by 128 (packed-f16 atomics)
+  Tensor prim_pool_;       // [16, V, 3] int32
+  Tensor bias_pool_;       // [16*V, 3]
+  Tensor feat_local_idx_, feat_local_size_, level_scale_;
+  std::unique_ptr<FusedMLP> mlp_;
+  int n_volumes_;
+  int64_t active_halves_;  // halves [0, active) are the only ones any level can address (level-overlap quirk)
+};
+
+}  // namespace f2n

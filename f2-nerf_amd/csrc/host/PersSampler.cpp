@@ -1,0 +1,349 @@
+// PersSampler host logic: orchestration of the sampler kernels through the C-ABI, occupancy bookkeeping and
+// the host-side octree maintenance.  Behaviour follows src/PtsSampler/PersSampler.cu:317-615 and
+// src/PtsSampler/PersSampler.cpp:120-330,664-733 of the reference (cited inline); the control flow does not:
+// leaf-hit storage is a persistent worst-case workspace, segments are laid out in ray order by a device-side
+// scan, and the only host read-back of a GetSamples call is the pair (K, N) at its very end.
+#include "PersSampler.h"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+
+namespace f2n {
+
+namespace {
+
+// PersSampler.cpp:106-117 -- child visiting order for each of the 8 ray octants.
+Tensor BuildSearchOrder() {
+  std::vector<int> search_order;
+  for (int st = 0; st < 8; st++) {
+    auto cmp = [st](int a, int b) {
+      int bt = ((a ^ b) & -(a ^ b));
+      return ((a & bt) ^ (st & bt)) != 0;
+    };
+    for (int i = 0; i < 8; i++) search_order.push_back(i);
+    std::sort(search_order.begin() + st * 8, search_order.begin() + (st + 1) * 8, cmp);
+  }
+  return torch::from_blob(search_order.data(), {64}, CpuI32()).to(torch::kUInt8).to(torch::kCUDA).contiguous();
+}
+
+}  // namespace
+
+PersSampler::PersSampler(GlobalDataPool* global_data_pool) {
+  global_data_pool_ = global_data_pool;
+  global_data_pool_->pts_sampler_ = this;
+  const auto& c = global_data_pool->config_;
+  sub_div_milestones_ = c.IntList("pts_sampler.sub_div_milestones");
+  std::reverse(sub_div_milestones_.begin(), sub_div_milestones_.end());
+  compact_freq_ = c.Int("pts_sampler.compact_freq");
+  max_oct_intersect_per_ray_ = c.Int("pts_sampler.max_oct_intersect_per_ray");
+  global_near_ = c.Float("pts_sampler.near");
+  scale_by_dis_ = c.Bool("pts_sampler.scale_by_dis");
+  sample_l_ = c.Float("pts_sampler.sample_l");
+  pers_octree_ = std::make_unique<PersOctree>();
+  pers_octree_->node_search_order_ = BuildSearchOrder();
+}
+
+void PersOctree::UploadNodes() {
+  tree_nodes_gpu_ = torch::from_blob(tree_nodes_.data(), {int64_t(tree_nodes_.size() * sizeof(TreeNode))}, CpuU8())
+                        .to(torch::kCUDA).contiguous();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GetSamples, PersSampler.cu:317-434
+// ---------------------------------------------------------------------------------------------------------
+SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, const Tensor& /*bounds*/) {
+  Tensor rays_o = rays_o_raw.contiguous();
+  Tensor rays_d = (rays_d_raw / torch::linalg_norm(rays_d_raw, 2, -1, true)).contiguous();  // :319
+  CheckDev(rays_o, torch::kFloat32, "rays_o");
+  const int n_rays = rays_o.size(0);
+  auto& oct = *pers_octree_;
+  void* st = CurStream();
+  const float far = 1e8f;  // the `bounds` argument is ignored by the reference too (:322-323)
+
+  Tensor counts = torch::empty({n_rays}, DevI32());
+  Tensor oct_se = torch::empty({n_rays, 2}, DevI32());
+  Tensor totals = torch::zeros({2}, DevI32());  // [K, N]
+  F2N_CALL(f2n_oct_intersect_count(st, n_rays, max_oct_intersect_per_ray_, oct.node_search_order_.data_ptr<uint8_t>(),
+                                   F32P(rays_o), F32P(rays_d), global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(counts)));
+  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(oct_se), I32P(totals)));
+  // worst-case leaf-hit workspace (n_rays * max_oct_intersect_per_ray entries, 12 B each): no host sync here
+  const int64_t k_cap = int64_t(n_rays) * max_oct_intersect_per_ray_;
+  Tensor oct_idx = torch::empty({k_cap}, DevI32());
+  Tensor oct_nf = torch::empty({k_cap, 2}, DevF32());
+  F2N_CALL(f2n_oct_intersect_fill(st, n_rays, oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d),
+                                  global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf)));
+
+  Tensor rays_noise;  // :372-381
+  if (forced_noise_.defined()) {
+    rays_noise = forced_noise_.contiguous();
+    TORCH_CHECK(rays_noise.numel() >= F2N_MAX_SAMPLE_PER_RAY + n_rays + 10, "forced noise too short");
+  } else if (global_data_pool_->mode_ == RunningMode::VALIDATE) {
+    rays_noise = torch::ones({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32());
+    rays_noise.mul_(global_data_pool_->ray_march_fineness_);
+  } else {
+    rays_noise = ((torch::rand({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32()) - .5f) + 1.f).contiguous();
+    rays_noise.mul_(global_data_pool_->ray_march_fineness_);
+  }
+
+  Tensor pts_se = torch::empty({n_rays, 2}, DevI32());
+  F2N_CALL(f2n_ray_march_count(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
+                               I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
+                               VoidP(oct.pers_trans_gpu_), I32P(counts)));
+  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(pts_se), I32P(totals) + 1));
+
+  Tensor totals_cpu = totals.cpu();  // the single host read-back of this call
+  const int n_all_oct = totals_cpu.data_ptr<int32_t>()[0];
+  const int n_all_pts = totals_cpu.data_ptr<int32_t>()[1];
+  if (global_data_pool_->mode_ == RunningMode::TRAIN) {
+    float per_ray = float(n_all_oct) / float(n_rays);
+    global_data_pool_->sampled_oct_per_ray_ = global_data_pool_->sampled_oct_per_ray_ * .9f + per_ray * .1f;
+  }
+
+  SampleResultFlex res;
+  res.pts = torch::empty({n_all_pts, 3}, DevF32());
+  res.dirs = torch::empty({n_all_pts, 3}, DevF32());
+  res.dt = torch::empty({n_all_pts}, DevF32());
+  res.t = torch::empty({n_all_pts}, DevF32());
+  res.anchors = torch::empty({n_all_pts, 3}, DevI32());
+  res.pts_idx_bounds = pts_se;
+  res.first_oct_dis = torch::empty({n_rays, 1}, DevF32());
+  F2N_CALL(f2n_ray_march_fill(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
+                              I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
+                              VoidP(oct.pers_trans_gpu_), I32P(pts_se), F32P(res.pts), F32P(res.dirs), F32P(res.dt),
+                              F32P(res.t), I32P(res.anchors), F32P(res.first_oct_dis)));
+  return res;
+}
+
+// PersSampler.cu:454-473
+std::tuple<Tensor, Tensor> PersSampler::GetEdgeSamples(int n_pts) {
+  const int n_edges = pers_octree_->n_edges_;
+  TORCH_CHECK(n_edges > 0, "edge pool is empty: call SetEdgePool");
+  Tensor edge_idx = forced_edge_idx_.defined() ? forced_edge_idx_.contiguous()
+                                                : torch::randint(0, n_edges, {n_pts}, DevI32()).contiguous();
+  Tensor edge_coord = forced_edge_coords_.defined() ? forced_edge_coords_.contiguous()
+                                                    : (torch::rand({n_pts, 2}, DevF32()) * 2.f - 1.f).contiguous();
+  Tensor out_pts = torch::empty({n_pts, 2, 3}, DevF32());
+  Tensor out_idx = torch::empty({n_pts, 2}, DevI32());
+  F2N_CALL(f2n_edge_samples(CurStream(), n_pts, VoidP(pers_octree_->edge_pool_gpu_), VoidP(pers_octree_->pers_trans_gpu_),
+                            I32P(edge_idx), F32P(edge_coord), F32P(out_pts), I32P(out_idx)));
+  return {out_pts, out_idx};
+}
+
+// PersSampler.cu:536-615
+void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weight,
+                                 const Tensor& sampled_alpha) {
+  auto& oct = *pers_octree_;
+  const int n_nodes = oct.tree_nodes_.size();
+  const int n_rays = sample_result.pts_idx_bounds.size(0);
+  CheckDev(sampled_weight, torch::kFloat32, "sampled_weight");
+  CheckDev(sampled_alpha, torch::kFloat32, "sampled_alpha");
+  Tensor adders = torch::full({2, n_nodes}, -1, DevI32());  // visit_weight_adder, visit_alpha_adder (:555-556)
+  Tensor visit_mark = torch::zeros({n_nodes}, DevI32());
+  void* st = CurStream();
+  F2N_CALL(f2n_oct_mark_visit(st, n_rays, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
+                              F32P(sampled_weight), F32P(sampled_alpha), I32P(adders), I32P(adders) + n_nodes,
+                              I32P(visit_mark), I32P(oct.tree_visit_cnt_)));
+  F2N_CALL(f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
+                                I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_)));
+
+  while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610
+    oct.ProcOctree(true, true, sub_div_milestones_.back() <= 0);
+    oct.MarkInvisibleNodes();
+    oct.ProcOctree(true, false, false);
+    sub_div_milestones_.pop_back();
+  }
+  if (global_data_pool_->iter_step_ % compact_freq_ == 0) {  // :612-614
+    oct.ProcOctree(true, false, false);
+  }
+}
+
+void PersOctree::MarkInvisibleNodes() {  // PersSampler.cu:663-680
+  TORCH_CHECK(w2c_.defined(), "training cameras not set: call SetTrainCameras");
+  F2N_CALL(f2n_oct_mark_invisible(CurStream(), (int) tree_nodes_.size(), (int) intri_.size(0), VoidP(tree_nodes_gpu_),
+                                  F32P(intri_), F32P(w2c_), F32P(bound_)));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ProcOctree, PersSampler.cpp:120-330: compaction of dead leaves, path compression, subdivision of visited
+// leaves.  Host code over a D2H copy of the node array, as in the reference.
+// ---------------------------------------------------------------------------------------------------------
+void PersOctree::ProcOctree(bool compact, bool subdivide, bool brute_force) {
+  Tensor nodes_cpu = tree_nodes_gpu_.to(torch::kCPU).contiguous();
+  Tensor w_cpu = tree_weight_stats_.to(torch::kCPU).contiguous();
+  Tensor a_cpu = tree_alpha_stats_.to(torch::kCPU).contiguous();
+  Tensor v_cpu = tree_visit_cnt_.to(torch::kCPU).contiguous();
+  const int n_before = (int) tree_nodes_.size();
+  std::vector<TreeNode> nb(n_before);
+  std::memcpy((void*) nb.data(), nodes_cpu.data_ptr(), size_t(n_before) * sizeof(TreeNode));
+  const int* w_before = w_cpu.data_ptr<int>();
+  const int* a_before = a_cpu.data_ptr<int>();
+  const int* visit_cnt = v_cpu.data_ptr<int>();
+
+  while (compact) {
+    for (int u = 0; u < n_before; u++) {
+      if (!nb[u].is_leaf_node) continue;
+      if (nb[u].trans_idx < 0 && nb[u].parent >= 0) {
+        int v = nb[u].parent;
+        for (int st = 0; st < 8; st++)
+          if (nb[v].childs[st] == u) nb[v].childs[st] = -1;
+      }
+    }
+    bool update_flag = false;
+    for (int u = 1; u < n_before; u++) {  // the root can not become a leaf
+      bool has_valid = false;
+      for (int st = 0; st < 8; st++)
+        if (nb[u].childs[st] >= 0) { has_valid = true; break; }
+      if (!has_valid) {
+        if (!nb[u].is_leaf_node) update_flag = true;
+        nb[u].is_leaf_node = true;
+      }
+    }
+    if (!update_flag) break;
+  }
+  if (compact) {  // splice out chains of single-child interior nodes
+    auto single_child = [&nb](int u) {
+      int cnt = 0, ret = -1;
+      for (int i = 0; i < 8; i++)
+        if (nb[u].childs[i] >= 0) { ret = i; cnt++; }
+      return cnt == 1 ? ret : -1;
+    };
+    for (int u = 0; u < n_before; u++) {
+      if (nb[u].is_leaf_node && nb[u].trans_idx < 0) continue;
+      int v = nb[u].parent;
+      while (v >= 0 && nb[v].parent >= 0 && single_child(v) >= 0) {
+        int vv = nb[v].parent;
+        for (int i = 0; i < 8; i++)
+          if (nb[vv].childs[i] == v) nb[vv].childs[i] = u;
+        nb[u].parent = vv;
+        nb[v].trans_idx = -1;
+        nb[v].is_leaf_node = true;  // flagged for removal
+        v = vv;
+      }
+    }
+  }
+  std::vector<int> new_idx(n_before, -1), inv_idx;
+  int n_kept = 0;
+  for (int u = 0; u < n_before; u++) {
+    if (!nb[u].is_leaf_node || nb[u].trans_idx >= 0) {
+      new_idx[u] = n_kept++;
+      inv_idx.push_back(u);
+    }
+  }
+  TORCH_CHECK(new_idx[0] == 0, "octree root was removed");
+  std::vector<TreeNode> new_nodes;
+  std::vector<int> new_w, new_a;
+  for (int u = 0; u < n_before; u++) {
+    if (new_idx[u] < 0) continue;
+    TreeNode node = nb[u];
+    if (node.parent >= 0) node.parent = new_idx[node.parent];
+    for (int st = 0; st < 8; st++)
+      if (node.childs[st] >= 0) node.childs[st] = new_idx[node.childs[st]];
+    new_nodes.push_back(node);
+    new_w.push_back(w_before[u]);
+    new_a.push_back(a_before[u]);
+  }
+  if (subdivide) {
+    std::vector<TreeNode> wp = std::move(new_nodes);
+    std::vector<int> wwp = std::move(new_w), awp = std::move(new_a);
+    new_nodes.clear(); new_w.clear(); new_a.clear();
+    std::function<int(int, int)> rec = [&](int u, int pa) -> int {
+      int new_u = (int) new_nodes.size();
+      new_nodes.push_back(wp[u]);
+      new_w.push_back(wwp[u]);
+      new_a.push_back(awp[u]);
+      new_nodes[new_u].parent = pa;
+      if (wp[u].is_leaf_node) {
+        if (!brute_force && visit_cnt[inv_idx[u]] <= 4) return new_u;
+        for (int st = 0; st < 8; st++) {
+          const float off[3] = {float((st >> 2) & 1) - .5f, float((st >> 1) & 1) - .5f, float(st & 1) - .5f};
+          int v = (int) new_nodes.size();
+          new_nodes.emplace_back();
+          TreeNode& ch = new_nodes[v];
+          TreeNode& pr = new_nodes[new_u];
+          pr.childs[st] = v;
+          for (int k = 0; k < 3; k++) ch.center[k] = pr.center[k] + pr.side_len * .5f * off[k];
+          ch.side_len = pr.side_len * .5f;
+          ch.parent = new_u;
+          for (int k = 0; k < 8; k++) ch.childs[k] = -1;
+          ch.is_leaf_node = true;
+          ch.trans_idx = pr.trans_idx;  // children inherit the parent's warp
+          new_w.push_back(new_w[new_u]);
+          new_a.push_back(new_a[new_u]);
+        }
+        new_nodes[new_u].is_leaf_node = false;
+        new_nodes[new_u].trans_idx = -1;
+        new_w[new_u] = INIT_NODE_STAT;
+        new_a[new_u] = INIT_NODE_STAT;
+      } else {
+        for (int st = 0; st < 8; st++) {
+          if (new_nodes[new_u].childs[st] >= 0) {
+            int v = rec(new_nodes[new_u].childs[st], new_u);
+            new_nodes[new_u].childs[st] = v;
+          }
+        }
+      }
+      return new_u;
+    };
+    rec(0, -1);
+  }
+  tree_nodes_ = std::move(new_nodes);
+  UploadNodes();
+  const int64_t n = (int64_t) tree_nodes_.size();
+  tree_weight_stats_ = torch::from_blob(new_w.data(), {n}, CpuI32()).to(torch::kCUDA).contiguous();
+  tree_alpha_stats_ = torch::from_blob(new_a.data(), {n}, CpuI32()).to(torch::kCUDA).contiguous();
+  tree_visit_cnt_ = torch::zeros({n}, DevI32());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// States / LoadStates, PersSampler.cpp:692-733 (checkpoint order: nodes, warps, visit counts, milestones)
+// ---------------------------------------------------------------------------------------------------------
+std::vector<Tensor> PersSampler::States() {
+  std::vector<Tensor> ret;
+  ret.push_back(pers_octree_->tree_nodes_gpu_);
+  ret.push_back(pers_octree_->pers_trans_gpu_);
+  ret.push_back(pers_octree_->tree_visit_cnt_);
+  ret.push_back(torch::from_blob(sub_div_milestones_.data(), {(int64_t) sub_div_milestones_.size()}, CpuI32()).to(torch::kCUDA));
+  return ret;
+}
+
+int PersSampler::LoadStates(const std::vector<Tensor>& states, int idx) {
+  auto& oct = *pers_octree_;
+  oct.tree_nodes_gpu_ = states[idx++].clone().to(torch::kCUDA).to(torch::kUInt8).contiguous();
+  oct.pers_trans_gpu_ = states[idx++].clone().to(torch::kCUDA).to(torch::kUInt8).contiguous();
+  oct.tree_visit_cnt_ = states[idx++].clone().to(torch::kCUDA).to(torch::kInt32).contiguous();
+  Tensor milestones = states[idx++].clone().to(torch::kCPU).to(torch::kInt32).contiguous();
+  TORCH_CHECK(oct.tree_nodes_gpu_.numel() % sizeof(TreeNode) == 0 && oct.pers_trans_gpu_.numel() % sizeof(TransInfo) == 0,
+              "state blobs do not match the TreeNode/TransInfo layout");
+  Tensor nodes_cpu = oct.tree_nodes_gpu_.to(torch::kCPU);
+  oct.tree_nodes_.resize(nodes_cpu.numel() / sizeof(TreeNode));
+  std::memcpy((void*) oct.tree_nodes_.data(), nodes_cpu.data_ptr(), nodes_cpu.numel());
+  sub_div_milestones_.resize(milestones.numel());
+  std::memcpy(sub_div_milestones_.data(), milestones.data_ptr(), milestones.numel() * sizeof(int));
+  const int64_t n = (int64_t) oct.tree_nodes_.size();
+  TORCH_CHECK(oct.tree_visit_cnt_.numel() == n, "visit_cnt size mismatch");
+  oct.tree_weight_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());  // stats are NOT checkpointed (:721-722)
+  oct.tree_alpha_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());
+  global_data_pool_->n_volumes_ = int(oct.pers_trans_gpu_.numel() / sizeof(TransInfo));
+  return idx;
+}
+
+void PersSampler::SetEdgePool(const Tensor& edge_pool_bytes) {
+  TORCH_CHECK(edge_pool_bytes.numel() % sizeof(EdgePool) == 0, "edge pool blob does not match the EdgePool layout");
+  pers_octree_->edge_pool_gpu_ = edge_pool_bytes.clone().to(torch::kCUDA).to(torch::kUInt8).contiguous();
+  pers_octree_->n_edges_ = int(edge_pool_bytes.numel() / sizeof(EdgePool));
+}
+
+void PersSampler::SetTrainCameras(const Tensor& w2c, const Tensor& intri, const Tensor& bounds) {
+  pers_octree_->w2c_ = w2c.to(torch::kCUDA).to(torch::kFloat32).contiguous();
+  pers_octree_->intri_ = intri.to(torch::kCUDA).to(torch::kFloat32).contiguous();
+  pers_octree_->bound_ = bounds.to(torch::kCUDA).to(torch::kFloat32).contiguous();
+}
+
+std::unique_ptr<PtsSampler> ConstructPtsSampler(GlobalDataPool* global_data_pool) {  // PtsSamplerFactory.cpp:7-13
+  const std::string type = global_data_pool->config_.Str("pts_sampler.type");
+  TORCH_CHECK(type == "PersSampler", "unknown pts_sampler.type: ", type);
+  return std::make_unique<PersSampler>(global_data_pool);
+}
+
+}  // namespace f2n

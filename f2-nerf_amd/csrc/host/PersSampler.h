@@ -1,0 +1,73 @@
+// PersSampler / PersOctree host side (mirrors src/PtsSampler/PersSampler.h).  Kernels: csrc/sampler.hip via
+// the C-ABI.  The octree is created from a serialised state (the reference's checkpoint byte layout); the
+// per-milestone maintenance (ProcOctree) is host code as in the reference.
+#pragma once
+#include "PtsSampler.h"
+
+namespace f2n {
+
+#define INIT_NODE_STAT 1000
+#define N_PROS 12
+
+struct alignas(32) TransInfo {   // 544 B, PersSampler.h:15-20 of the reference
+  float w2xz[N_PROS][2][4];
+  float weight[3][N_PROS];
+  float center[3];
+  float dis_summary;
+};
+struct alignas(32) TreeNode {    // 64 B, PersSampler.h:22-29 of the reference
+  float center[3];
+  float side_len;
+  int parent;
+  int childs[8];
+  bool is_leaf_node;
+  int trans_idx;
+};
+struct alignas(32) EdgePool {    // 64 B
+  int t_idx_a, t_idx_b;
+  float center[3], dir_0[3], dir_1[3];
+};
+static_assert(sizeof(TransInfo) == 544 && sizeof(TreeNode) == 64 && sizeof(EdgePool) == 64, "checkpoint layout");
+
+class PersOctree {
+ public:
+  void ProcOctree(bool compact, bool subdivide, bool brute_force);
+  void MarkInvisibleNodes();
+  void UploadNodes();
+
+  Tensor w2c_, intri_, bound_;  // training cameras, for MarkInvisibleNodes
+  std::vector<TreeNode> tree_nodes_;
+  Tensor tree_nodes_gpu_;
+  Tensor tree_weight_stats_, tree_alpha_stats_, tree_visit_cnt_;
+  Tensor node_search_order_;
+  Tensor pers_trans_gpu_;
+  Tensor edge_pool_gpu_;
+  int n_edges_ = 0;
+};
+
+class PersSampler : public PtsSampler {
+ public:
+  explicit PersSampler(GlobalDataPool* global_data_pool);
+  SampleResultFlex GetSamples(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) override;
+  std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;
+  void UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weights,
+                      const Tensor& sampled_alpha) override;
+  std::vector<Tensor> States() override;
+  int LoadStates(const std::vector<Tensor>& states, int idx) override;
+
+  // Not part of the reference checkpoint (LoadStates there keeps the constructor's edge pool / cameras).
+  void SetEdgePool(const Tensor& edge_pool_bytes);
+  void SetTrainCameras(const Tensor& w2c, const Tensor& intri, const Tensor& bounds);
+
+  std::unique_ptr<PersOctree> pers_octree_;
+  std::vector<int> sub_div_milestones_;
+  int compact_freq_;
+  int max_oct_intersect_per_ray_;
+  float global_near_;
+  float sample_l_;
+  bool scale_by_dis_;
+  // explicit random draws for parity tests (empty = draw from torch's generator like the reference)
+  Tensor forced_noise_, forced_edge_idx_, forced_edge_coords_;
+};
+
+}  // namespace f2n

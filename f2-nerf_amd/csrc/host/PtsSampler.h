@@ -1,0 +1,29 @@
+// Plugin interface of the point sampler (mirrors src/PtsSampler/PtsSampler.h:13-48).
+#pragma once
+#include "GlobalDataPool.h"
+#include "Pipe.h"
+
+namespace f2n {
+
+struct SampleResultFlex {
+  Tensor pts;             // [ n_all_pts, 3 ]  warped coordinates
+  Tensor dirs;            // [ n_all_pts, 3 ]
+  Tensor dt;              // [ n_all_pts ]
+  Tensor t;               // [ n_all_pts ]
+  Tensor anchors;         // [ n_all_pts, 3 ]  (trans_idx, leaf node idx, 0)
+  Tensor pts_idx_bounds;  // [ n_rays, 2 ]     start, end
+  Tensor first_oct_dis;   // [ n_rays, 1 ]
+};
+
+class PtsSampler : public Pipe {
+ public:
+  virtual SampleResultFlex GetSamples(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) = 0;
+  virtual std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) = 0;
+  virtual void UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weights,
+                              const Tensor& sampled_alpha) = 0;
+  GlobalDataPool* global_data_pool_ = nullptr;
+};
+
+std::unique_ptr<PtsSampler> ConstructPtsSampler(GlobalDataPool* global_data_pool);
+
+}  // namespace f2n

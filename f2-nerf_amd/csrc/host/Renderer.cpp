@@ -1,0 +1,314 @@
+// SHShader + Renderer host logic.  Behaviour follows src/Shader/SHShader.cpp and src/Renderer/Renderer.cpp:52-258
+// of the reference (cited inline).  Where the reference strings ~40 ATen ops and 6 FlexOps launches per Render
+// call, this issues: field pre-pass -> early_stop -> scan -> compact -> (mark_visit, update_stats) -> edge
+// samples -> fused field -> scatter_idx -> fused shade -> composite, with two host read-backs in total (N, M).
+#include "Renderer.h"
+
+namespace f2n {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+// ---------------------------------------------------------------------------------------------------------
+// SHShader
+// ---------------------------------------------------------------------------------------------------------
+SHShader::SHShader(GlobalDataPool* gdp) {  // SHShader.cpp:9-20
+  global_data_pool_ = gdp;
+  gdp->shader_ = this;
+  const auto& c = gdp->config_;
+  d_in_ = c.Int("shader.d_in");
+  d_out_ = c.Int("shader.d_out");
+  degree_ = c.Int("shader.degree");
+  d_hidden_ = c.Int("shader.d_hidden");
+  n_hiddens_ = c.Int("shader.n_hiddens");
+  TORCH_CHECK(degree_ >= 1 && degree_ <= 4, "SH degree ", degree_, " is not supported (1..4)");
+  mlp_ = std::make_unique<FusedMLP>(gdp, d_in_, d_out_, d_hidden_, n_hiddens_);
+}
+
+Tensor SHShader::SHEncode(const Tensor& dirs) {  // SHShader.cu:108-118
+  Tensor d = dirs.contiguous();
+  CheckDev(d, torch::kFloat32, "dirs");
+  const int n = d.size(0);
+  Tensor out = torch::empty({n, degree_ * degree_}, DevF32());
+  F2N_CALL(f2n_sh_encode(CurStream(), n, degree_, F32P(d), F32P(out)));
+  return out;
+}
+
+Tensor SHShader::Query(const Tensor& feats, const Tensor& dirs) {  // SHShader.cpp:23-29, op by op
+  Tensor enc = SHEncode(dirs);
+  Tensor input = torch::cat({feats, enc}, -1);
+  Tensor output = mlp_->Query(input);
+  const float eps = 1e-3f;
+  return (1.f + 2.f * eps) / (1.f + torch::exp(-output)) - eps;
+}
+
+namespace {
+
+struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
+  static variable_list forward(AutogradContext* ctx, Tensor field_feats, Tensor color_params, Tensor app_emb, Tensor dirs,
+                               Tensor sample_emb_idx, int64_t shader_ptr, int64_t emb_grad_ptr) {
+    auto* sh = reinterpret_cast<SHShader*>(shader_ptr);
+    Tensor feats = field_feats.contiguous();
+    CheckDev(feats, torch::kFloat32, "field feats");
+    TORCH_CHECK(feats.size(1) == 16 && sh->degree_ == 4 && sh->n_hiddens_ == 2, "fused shading needs 16 feats + SH4 + 2 hidden");
+    const int n = feats.size(0);
+    const bool emb = app_emb.defined() && sample_emb_idx.defined();
+    Tensor rgb = torch::empty({n, 3}, DevF32());
+    Tensor saved_x = torch::empty({n, 32}, DevF16());
+    F2N_CALL(f2n_shade_fwd(CurStream(), n, F32P(feats), F32P(dirs), emb ? F32P(app_emb) : nullptr,
+                           emb ? I32P(sample_emb_idx) : nullptr, VoidP(sh->mlp_->params_h_), F32P(rgb), VoidP(saved_x)));
+    ctx->saved_data["shader"] = shader_ptr;
+    ctx->saved_data["emb_grad"] = emb_grad_ptr;
+    ctx->saved_data["emb"] = emb;
+    ctx->save_for_backward({saved_x, emb ? sample_emb_idx : Tensor()});
+    return {rgb};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_output) {
+    auto* sh = reinterpret_cast<SHShader*>(ctx->saved_data["shader"].toInt());
+    auto* emb_grad = reinterpret_cast<Tensor*>(ctx->saved_data["emb_grad"].toInt());
+    const bool emb = ctx->saved_data["emb"].toBool();
+    auto saved = ctx->get_saved_variables();
+    Tensor drgb = grad_output[0].contiguous();
+    const int n = saved[0].size(0);
+    Tensor dfeat = torch::zeros({n, 16}, DevF32());
+    F2N_CALL(f2n_shade_bwd(CurStream(), n, F32P(drgb), emb ? I32P(saved[1]) : nullptr, VoidP(sh->mlp_->params_h_),
+                           VoidP(saved[0]), sh->mlp_->loss_scale_, F32P(dfeat), F32P(sh->mlp_->grad_scaled_),
+                           (emb && emb_grad != nullptr) ? F32P(*emb_grad) : nullptr));
+    return {dfeat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// Volume rendering (Renderer.cpp:190-208) as one autograd node.
+struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
+  static variable_list forward(AutogradContext* ctx, Tensor feat, Tensor rgb, Tensor dt, Tensor t, Tensor bg, Tensor se,
+                               double gs_progress) {
+    ctx->set_materialize_grads(false);
+    const int n_rays = se.size(0), m = feat.size(0);
+    Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
+    Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({m}, DevF32());
+    F2N_CALL(f2n_composite_fwd(CurStream(), n_rays, I32P(se), F32P(feat), F32P(dt), F32P(t), F32P(rgb), F32P(bg),
+                               F32P(colors), F32P(disparity), F32P(depth), F32P(weights)));
+    ctx->save_for_backward({feat, rgb, dt, t, bg, se});
+    ctx->saved_data["gs"] = gs_progress;
+    return {colors, disparity, depth, weights};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto s = ctx->get_saved_variables();
+    const int n_rays = s[5].size(0), m = s[0].size(0);
+    Tensor gc = g[0].defined() ? g[0].contiguous() : Tensor(), gd = g[1].defined() ? g[1].contiguous() : Tensor();
+    Tensor gz = g[2].defined() ? g[2].contiguous() : Tensor(), gw = g[3].defined() ? g[3].contiguous() : Tensor();
+    Tensor drgb = torch::zeros({m, 3}, DevF32());
+    Tensor dfeat = torch::zeros({m, 16}, DevF32());
+    F2N_CALL(f2n_composite_bwd(CurStream(), n_rays, I32P(s[5]), F32P(s[0]), F32P(s[2]), F32P(s[3]), F32P(s[1]), F32P(s[4]),
+                               gc.defined() ? F32P(gc) : nullptr, gd.defined() ? F32P(gd) : nullptr,
+                               gz.defined() ? F32P(gz) : nullptr, gw.defined() ? F32P(gw) : nullptr,
+                               (float) ctx->saved_data["gs"].toDouble(), F32P(drgb), F32P(dfeat)));
+    return {dfeat, drgb, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+struct WeightVarFunction : public torch::autograd::Function<WeightVarFunction> {
+  static variable_list forward(AutogradContext* ctx, Tensor weights, Tensor se) {
+    const int n = se.size(0);
+    Tensor out = torch::empty({n}, DevF32());
+    F2N_CALL(f2n_weight_var_fwd(CurStream(), n, F32P(weights), I32P(se), F32P(out)));
+    ctx->save_for_backward({weights, se});
+    return {out};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto s = ctx->get_saved_variables();
+    Tensor dvar = g[0].contiguous();
+    Tensor dw = torch::zeros_like(s[0]);
+    F2N_CALL(f2n_weight_var_bwd(CurStream(), (int) s[1].size(0), F32P(s[0]), I32P(s[1]), F32P(dvar), F32P(dw)));
+    return {dw, Tensor()};
+  }
+};
+
+}  // namespace
+
+Tensor CustomOps::WeightVar(Tensor weights, Tensor idx_start_end) {
+  return WeightVarFunction::apply(weights.contiguous(), idx_start_end.contiguous())[0];
+}
+
+Tensor SHShader::QueryFromField(const Tensor& field_feats, const Tensor& dirs, const Tensor& app_emb,
+                                const Tensor& sample_emb_idx, Tensor* app_emb_grad) {
+  return ShadeFunction::apply(field_feats, mlp_->params_, app_emb, dirs.contiguous(), sample_emb_idx,
+                              reinterpret_cast<int64_t>(this), reinterpret_cast<int64_t>(app_emb_grad))[0];
+}
+
+int SHShader::LoadStates(const std::vector<Tensor>& states, int idx) {
+  torch::NoGradGuard g;
+  mlp_->params_.copy_(states[idx++].to(torch::kCUDA).to(torch::kFloat32));
+  mlp_->SyncHalf();
+  return idx;
+}
+std::vector<Tensor> SHShader::States() { return {mlp_->params_.detach()}; }
+std::vector<ParamGroup> SHShader::OptimParamGroups() {  // SHShader.cpp:44-56
+  ParamGroup g;
+  g.name = "color_mlp";
+  g.param = mlp_->params_;
+  g.grad = mlp_->grad_scaled_;
+  g.param_h = mlp_->params_h_;
+  g.weight_decay = 1e-6f;
+  g.grad_round_h16 = true;
+  g.grad_scale = -1.f;
+  return {g};
+}
+void SHShader::Reset() { mlp_->InitParams(); }
+
+std::unique_ptr<Shader> ConstructShader(GlobalDataPool* gdp) {  // ShaderFactory.cpp:8-17
+  const std::string type = gdp->config_.Str("shader.type");
+  TORCH_CHECK(type == "SHShader", "unknown shader.type: ", type);
+  return std::make_unique<SHShader>(gdp);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Renderer
+// ---------------------------------------------------------------------------------------------------------
+Renderer::Renderer(GlobalDataPool* gdp, int n_images) {  // Renderer.cpp:22-49
+  global_data_pool_ = gdp;
+  gdp->renderer_ = this;
+  pts_sampler_ = ConstructPtsSampler(gdp);
+  RegisterSubPipe(pts_sampler_.get());
+  scene_field_ = ConstructField(gdp);
+  RegisterSubPipe(scene_field_.get());
+  shader_ = ConstructShader(gdp);
+  RegisterSubPipe(shader_.get());
+  use_app_emb_ = gdp->config_.Bool("renderer.use_app_emb");
+  app_emb_ = torch::randn({n_images, 16}, DevF32()) * .1f;
+  app_emb_.requires_grad_(true);
+  app_emb_grad_ = torch::zeros({n_images, 16}, DevF32());
+  const std::string bg = gdp->config_.Str("renderer.bg_color");
+  bg_color_type_ = bg == "white" ? BGColorType::white : (bg == "black" ? BGColorType::black : BGColorType::rand_noise);
+}
+
+void Renderer::ZeroGrad() {
+  static_cast<Hash3DAnchored*>(scene_field_.get())->ZeroGrad();
+  static_cast<SHShader*>(shader_.get())->mlp_->ZeroGrad();
+  app_emb_grad_.zero_();
+}
+
+RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx) {
+  auto* gdp = global_data_pool_;
+  auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
+  auto* shader = static_cast<SHShader*>(shader_.get());
+  const bool train = gdp->mode_ == RunningMode::TRAIN;
+  const int n_rays = rays_o.size(0);
+  sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
+  int n_all_pts = sample_result_.pts.size(0);
+  last_n_all_pts_ = n_all_pts;
+  if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;
+
+  Tensor bg_color;  // Renderer.cpp:67-81
+  if (forced_bg_.defined()) bg_color = forced_bg_.contiguous();
+  else if (bg_color_type_ == BGColorType::white) bg_color = torch::ones({n_rays, 3}, DevF32());
+  else if (bg_color_type_ == BGColorType::rand_noise) bg_color = train ? torch::rand({n_rays, 3}, DevF32()) : torch::ones({n_rays, 3}, DevF32()) * .5f;
+  else bg_color = torch::zeros({n_rays, 3}, DevF32());
+
+  if (n_all_pts <= 0) {  // Renderer.cpp:83-97
+    if (train) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f;
+    last_n_kept_pts_ = 0;
+    return {bg_color, torch::zeros({n_rays, 1}, DevF32()), torch::zeros({n_rays}, DevF32()), Tensor(),
+            torch::full({n_rays}, 512.f, DevF32()), Tensor(), Tensor()};
+  }
+  void* st = CurStream();
+
+  // ---- no-grad pre-pass: density of every sample, early stop (Renderer.cpp:105-137) ----
+  SampleResultFlex es;
+  Tensor pts_all, vol_all;
+  int n_kept = 0;
+  const int n_edge = train ? n_edge_pts_ : 0;
+  {
+    torch::NoGradGuard no_grad;
+    Tensor f0 = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors);
+    Tensor weights = torch::empty({n_all_pts}, DevF32()), alphas = torch::empty({n_all_pts}, DevF32());
+    Tensor mask = torch::empty({n_all_pts}, DevI32()), kept = torch::empty({n_rays}, DevI32());
+    F2N_CALL(f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), F32P(f0), 1, F32P(sample_result_.dt),
+                            F32P(weights), F32P(alphas), I32P(mask), I32P(kept)));
+    Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::zeros({1}, DevI32());
+    F2N_CALL(f2n_segment_scan(st, n_rays, I32P(kept), I32P(new_se), I32P(total)));  // FilterIdxBounds, Renderer.cu:20-50
+    n_kept = total.item<int>();  // second (and last) host read-back of a Render call
+    last_n_kept_pts_ = n_kept;
+    pts_all = torch::empty({n_kept + 2 * n_edge, 3}, DevF32());
+    vol_all = torch::empty({n_kept + 2 * n_edge}, DevI32());
+    es.pts = pts_all.slice(0, 0, n_kept);
+    es.dirs = torch::empty({n_kept, 3}, DevF32());
+    es.dt = torch::empty({n_kept}, DevF32());
+    es.t = torch::empty({n_kept}, DevF32());
+    es.anchors = torch::empty({n_kept, 3}, DevI32());
+    es.first_oct_dis = sample_result_.first_oct_dis.clone();
+    es.pts_idx_bounds = new_se;
+    F2N_CALL(f2n_compact_samples(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
+                                 F32P(sample_result_.pts), F32P(sample_result_.dirs), F32P(sample_result_.dt),
+                                 F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all), F32P(es.dirs),
+                                 F32P(es.dt), F32P(es.t), I32P(es.anchors)));
+    if (n_kept > 0) vol_all.slice(0, 0, n_kept).copy_(es.anchors.select(1, 0));
+    if (train) {  // Renderer.cpp:140-149
+      pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);
+      gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(n_rays)) * 0.1f;
+    }
+    if (train) {  // edge samples for the TV loss go straight behind the surviving samples (Renderer.cpp:159-166)
+      auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+      auto& oct = *ps->pers_octree_;
+      Tensor edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
+                                                       : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
+      Tensor edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
+                                                            : (torch::rand({n_edge, 2}, DevF32()) * 2.f - 1.f).contiguous();
+      F2N_CALL(f2n_edge_samples(st, n_edge, VoidP(oct.edge_pool_gpu_), VoidP(oct.pers_trans_gpu_), I32P(edge_idx),
+                                F32P(edge_coord), F32P(pts_all) + 3 * (int64_t) n_kept, I32P(vol_all) + n_kept));
+    }
+  }
+
+  // ---- grad pass (Renderer.cpp:152-208) ----
+  Tensor all_feat = scene_field_->AnchoredQuery(pts_all, vol_all);  // [M + 2E, 16]
+  Tensor scene_feat = all_feat.slice(0, 0, n_kept);
+  Tensor edge_feat;
+  if (train) edge_feat = all_feat.slice(0, n_kept, n_kept + 2 * n_edge).reshape({n_edge, 2, -1});
+
+  Tensor sample_emb_idx;
+  const bool emb = train && use_app_emb_ && emb_idx.defined();
+  if (emb) {  // CustomOps::ScatterIdx, Renderer.cpp:185
+    Tensor ei = emb_idx.contiguous();
+    CheckDev(ei, torch::kInt32, "emb_idx");
+    sample_emb_idx = torch::empty({std::max(n_kept, 1)}, DevI32());
+    F2N_CALL(f2n_scatter_idx(st, n_rays, I32P(es.pts_idx_bounds), I32P(ei), I32P(sample_emb_idx)));
+  }
+  Tensor sampled_colors = shader->QueryFromField(scene_feat, es.dirs, emb ? app_emb_ : Tensor(), sample_emb_idx,
+                                                 emb ? &app_emb_grad_ : nullptr);
+  auto out = CompositeFunction::apply(scene_feat, sampled_colors, es.dt, es.t, bg_color, es.pts_idx_bounds,
+                                      (double) gdp->gradient_scaling_progress_);
+  sample_result_ = SampleResultFlex();  // drop the pre-early-stop buffers
+  return {out[0], es.first_oct_dis, out[1], edge_feat, out[2], out[3], es.pts_idx_bounds};
+}
+
+int Renderer::LoadStates(const std::vector<Tensor>& states, int idx) {  // Renderer.cpp:216-224
+  for (auto pipe : sub_pipes_) idx = pipe->LoadStates(states, idx);
+  torch::NoGradGuard g;
+  Tensor e = states[idx++].clone().to(torch::kCUDA).to(torch::kFloat32).contiguous();
+  TORCH_CHECK(e.sizes() == app_emb_.sizes(), "app_emb shape mismatch");
+  app_emb_.copy_(e);
+  return idx;
+}
+
+std::vector<Tensor> Renderer::States() {  // Renderer.cpp:226-236
+  std::vector<Tensor> ret;
+  for (auto pipe : sub_pipes_) {
+    auto cur = pipe->States();
+    ret.insert(ret.end(), cur.begin(), cur.end());
+  }
+  ret.push_back(app_emb_.detach());
+  return ret;
+}
+
+std::vector<ParamGroup> Renderer::OptimParamGroups() {  // Renderer.cpp:238-258
+  std::vector<ParamGroup> ret = Pipe::OptimParamGroups();
+  ParamGroup g;
+  g.name = "app_emb";
+  g.param = app_emb_;
+  g.grad = app_emb_grad_;
+  g.weight_decay = 1e-6f;
+  ret.push_back(g);
+  return ret;
+}
+
+}  // namespace f2n

@@ -1,0 +1,66 @@
+// SHShader + Renderer host side (mirror src/Shader/SHShader.h, src/Renderer/Renderer.h).
+#pragma once
+#include "Hash3DAnchored.h"
+#include "PersSampler.h"
+
+namespace f2n {
+
+class SHShader : public Shader {
+ public:
+  explicit SHShader(GlobalDataPool* global_data_pool);
+  Tensor Query(const Tensor& feats, const Tensor& dirs) override;  // feats = the 16 shading features, dirs [n,3]
+  // The Renderer's path: feats are the RAW field features [n,16]; the "[1 | feat[1:]] + app_emb[img]" assembly of
+  // Renderer.cpp:181-187 happens inside the kernel.  sample_emb_idx/app_emb may be undefined.
+  Tensor QueryFromField(const Tensor& field_feats, const Tensor& dirs, const Tensor& app_emb, const Tensor& sample_emb_idx,
+                        Tensor* app_emb_grad);
+  Tensor SHEncode(const Tensor& dirs);
+  std::vector<Tensor> States() override;
+  std::vector<ParamGroup> OptimParamGroups() override;
+  int LoadStates(const std::vector<Tensor>& states, int idx) override;
+  void Reset() override;
+
+  std::unique_ptr<FusedMLP> mlp_;
+  int d_hidden_, n_hiddens_, degree_;
+};
+
+struct RenderResult {  // Renderer.h:18-27 of the reference
+  Tensor colors;
+  Tensor first_oct_dis;
+  Tensor disparity;
+  Tensor edge_feats;
+  Tensor depth;
+  Tensor weights;
+  Tensor idx_start_end;
+};
+
+class Renderer : public Pipe {
+  enum BGColorType { white, black, rand_noise };
+
+ public:
+  Renderer(GlobalDataPool* global_data_pool, int n_images);
+  RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
+
+  int LoadStates(const std::vector<Tensor>& states, int idx) override;
+  std::vector<Tensor> States() override;
+  std::vector<ParamGroup> OptimParamGroups() override;
+  void ZeroGrad();
+
+  GlobalDataPool* global_data_pool_;
+  std::unique_ptr<PtsSampler> pts_sampler_;
+  std::unique_ptr<Field> scene_field_;
+  std::unique_ptr<Shader> shader_;
+  bool use_app_emb_;
+  Tensor app_emb_;       // [n_images, 16]
+  Tensor app_emb_grad_;  // fp32, unscaled
+  BGColorType bg_color_type_ = BGColorType::rand_noise;
+  SampleResultFlex sample_result_;
+  Tensor forced_bg_;  // explicit background colours for parity tests (undefined = as the reference)
+  int n_edge_pts_ = 8192;
+  int last_n_all_pts_ = 0, last_n_kept_pts_ = 0;
+};
+
+namespace CustomOps {
+Tensor WeightVar(Tensor weights, Tensor idx_start_end);  // CustomOps.cu:12-66 via f2n_weight_var_*
+}
+
+}  // namespace f2n

@@ -1,0 +1,109 @@
+// pybind11 surface of the C++/LibTorch host layer (used by bench.py, __graft_entry__.smoke() and the
+// end-to-end tests).  Thin: object lifetime + tensor hand-over only.
+#include <torch/extension.h>
+
+#include "ExpRunner.h"
+
+using namespace f2n;
+
+namespace {
+
+Hash3DAnchored* FieldOf(ExpRunner& r) { return static_cast<Hash3DAnchored*>(r.renderer_->scene_field_.get()); }
+SHShader* ShaderOf(ExpRunner& r) { return static_cast<SHShader*>(r.renderer_->shader_.get()); }
+PersSampler* SamplerOf(ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get()); }
+
+py::dict StatsToDict(const TrainStats& s) {
+  py::dict d;
+  d["loss"] = s.loss;
+  d["mse"] = s.mse;
+  d["n_rays"] = s.n_rays;
+  d["n_samples"] = s.n_samples;
+  d["n_meaningful"] = s.n_meaningful;
+  d["skipped_nan"] = s.skipped_nan;
+  return d;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "f2-nerf hot path: C++/LibTorch host layer over libf2n_hip.so";
+  py::class_<ExpRunner>(m, "ExpRunner")
+      .def(py::init<const std::map<std::string, std::string>&, int>(), py::arg("flat_config"), py::arg("n_images"))
+      .def("load_states", &ExpRunner::LoadStates)
+      .def("states", &ExpRunner::States)
+      .def("train_step",
+           [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply) {
+             return StatsToDict(r.TrainStep(ro, rd, b, gt, emb, apply));
+           },
+           py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
+           py::arg("apply_optimizer") = true)
+      .def("render_rays", &ExpRunner::RenderRays)
+      .def("render_train",
+           [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& emb) {
+             r.global_data_pool_->mode_ = RunningMode::TRAIN;
+             auto rr = r.renderer_->Render(ro, rd, b, emb);
+             py::dict d;
+             d["colors"] = rr.colors; d["first_oct_dis"] = rr.first_oct_dis; d["disparity"] = rr.disparity;
+             d["edge_feats"] = rr.edge_feats; d["depth"] = rr.depth; d["weights"] = rr.weights;
+             d["idx_start_end"] = rr.idx_start_end;
+             return d;
+           })
+      .def("get_samples",
+           [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b) {
+             auto s = r.renderer_->pts_sampler_->GetSamples(ro, rd, b);
+             py::dict d;
+             d["pts"] = s.pts; d["dirs"] = s.dirs; d["dt"] = s.dt; d["t"] = s.t; d["anchors"] = s.anchors;
+             d["pts_idx_bounds"] = s.pts_idx_bounds; d["first_oct_dis"] = s.first_oct_dis;
+             return d;
+           })
+      .def("anchored_query", [](ExpRunner& r, const Tensor& pts, const Tensor& anchors) { return r.renderer_->scene_field_->AnchoredQuery(pts, anchors); })
+      .def("shader_query", [](ExpRunner& r, const Tensor& feats, const Tensor& dirs) { return r.renderer_->shader_->Query(feats, dirs); })
+      .def("zero_grad", [](ExpRunner& r) { r.renderer_->ZeroGrad(); })
+      .def("optim_step", &ExpRunner::OptimStep)
+      .def("grads",
+           [](ExpRunner& r) {
+             py::dict d;
+             d["feat_pool"] = FieldOf(r)->TableGradUnscaled();
+             d["field_mlp"] = FieldOf(r)->mlp_->GradUnscaled();
+             d["color_mlp"] = ShaderOf(r)->mlp_->GradUnscaled();
+             d["app_emb"] = r.renderer_->app_emb_grad_.clone();
+             return d;
+           })
+      .def("grad_buffers",  // raw buffers for the data-parallel all-reduce (RCCL): hash table (f16 x128), MLPs, app_emb
+           [](ExpRunner& r) {
+             return std::vector<Tensor>{FieldOf(r)->grad_h_, FieldOf(r)->mlp_->grad_scaled_, ShaderOf(r)->mlp_->grad_scaled_,
+                                        r.renderer_->app_emb_grad_};
+           })
+      .def("occupancy_buffers",
+           [](ExpRunner& r) {
+             auto& o = *SamplerOf(r)->pers_octree_;
+             return std::vector<Tensor>{o.tree_weight_stats_, o.tree_alpha_stats_, o.tree_visit_cnt_};
+           })
+      .def("set_grad_sync_hook", [](ExpRunner& r, py::function f) { r.grad_sync_hook_ = [f]() { py::gil_scoped_acquire g; f(); }; })
+      .def("set_edge_pool", [](ExpRunner& r, const Tensor& e) { SamplerOf(r)->SetEdgePool(e); })
+      .def("set_train_cameras", [](ExpRunner& r, const Tensor& w2c, const Tensor& intri, const Tensor& b) { SamplerOf(r)->SetTrainCameras(w2c, intri, b); })
+      .def("set_forced_randoms",
+           [](ExpRunner& r, const Tensor& noise, const Tensor& bg, const Tensor& edge_idx, const Tensor& edge_coords) {
+             SamplerOf(r)->forced_noise_ = noise;
+             r.renderer_->forced_bg_ = bg;
+             SamplerOf(r)->forced_edge_idx_ = edge_idx;
+             SamplerOf(r)->forced_edge_coords_ = edge_coords;
+           })
+      .def("clear_forced_randoms",
+           [](ExpRunner& r) {
+             SamplerOf(r)->forced_noise_ = Tensor(); r.renderer_->forced_bg_ = Tensor();
+             SamplerOf(r)->forced_edge_idx_ = Tensor(); SamplerOf(r)->forced_edge_coords_ = Tensor();
+           })
+      .def("n_nodes", [](ExpRunner& r) { return (int) SamplerOf(r)->pers_octree_->tree_nodes_.size(); })
+      .def("proc_octree", [](ExpRunner& r, bool compact, bool subdivide, bool brute) { SamplerOf(r)->pers_octree_->ProcOctree(compact, subdivide, brute); })
+      .def("tree_nodes", [](ExpRunner& r) { return SamplerOf(r)->pers_octree_->tree_nodes_gpu_; })
+      .def("cur_batch_size", &ExpRunner::CurBatchSize)
+      .def_readwrite("iter_step", &ExpRunner::iter_step_)
+      .def_readwrite("check_nan", &ExpRunner::check_nan_)
+      .def_readonly("cur_lr", &ExpRunner::cur_lr_)
+      .def_property("n_edge_pts", [](ExpRunner& r) { return r.renderer_->n_edge_pts_; }, [](ExpRunner& r, int n) { r.renderer_->n_edge_pts_ = n; })
+      .def_property_readonly("fineness", [](ExpRunner& r) { return r.global_data_pool_->ray_march_fineness_; })
+      .def_property_readonly("meaningful_per_ray", [](ExpRunner& r) { return r.global_data_pool_->meaningful_sampled_pts_per_ray_; })
+      .def_property_readonly("n_volumes", [](ExpRunner& r) { return r.global_data_pool_->n_volumes_; })
+      .def("update_ada_params", &ExpRunner::UpdateAdaParams);
+}

@@ -1,0 +1,213 @@
+"""GPU end-to-end parity (run with `-m gpu`): the C++/LibTorch host layer (ExpRunner -> Renderer -> PersSampler /
+Hash3DAnchored / SHShader over the C-ABI) against the CPU oracle pipeline on BASELINE config 1 (ngp_fox,
+wanjinyou.yaml, 256 rays), identical state and identical explicit random draws on both sides.
+Contract (north star): bit-exact sample indices; rendered RGB within 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capi as oc  # noqa: E402
+from oracle import pipeline as op  # noqa: E402
+from oracle import octree_construct as octc  # noqa: E402
+
+F32 = np.float32
+N_EDGE = 2048
+
+
+@pytest.fixture(scope="module")
+def rt():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    runtime.host()
+    return runtime
+
+
+def fox_batch(st, rng, n):
+    cam = st["train_set"][rng.integers(0, len(st["train_set"]), n)].astype(np.int32)
+    pose, K = st["poses"][cam], st["intri"][cam]
+    i = rng.integers(0, 960, n).astype(F32) + F32(.5)
+    j = rng.integers(0, 540, n).astype(F32) + F32(.5)
+    d_cam = np.stack([(j - K[:, 0, 2]) / K[:, 0, 0], -(i - K[:, 1, 2]) / K[:, 1, 1], -np.ones(n, F32)], -1).astype(F32)
+    d = np.einsum("nij,nj->ni", pose[:, :3, :3], d_cam).astype(F32)
+    return np.ascontiguousarray(pose[:, :3, 3]).astype(F32), d, st["bounds"][cam].astype(F32), cam
+
+
+def oracle_train_iteration(st, cfg, arrays, rays_o, rays_d_raw, emb_idx, gt, noise, bg, edge_idx, edge_coords, iter_step):
+    """ExpRunner::Train body on the oracle: returns outputs and true gradients."""
+    tn, tr, _, _, table, prim, bias, nvol, p_field, p_color, app_emb = arrays
+    nvol = int(nvol[0])
+    log2 = int(cfg["field"]["log2_table_size"])
+    grid = op.HashGrid(table, prim, bias, nvol, log2)
+    # torch.linalg_norm + divide on the GPU side; same fp32 formula here
+    rays_d = torch.from_numpy(rays_d_raw)
+    rays_d = (rays_d / torch.linalg.norm(rays_d, 2, -1, True)).numpy()
+    ps = cfg["pts_sampler"]
+    hits = oc.oct_intersect(st["search_order"], rays_o, rays_d, float(ps["near"]), 1e8, tn, int(ps["max_oct_intersect_per_ray"]))
+    smp = oc.ray_march(rays_o, rays_d, noise, float(ps["sample_l"]), bool(ps["scale_by_dis"]), *hits, tn, tr)
+    feat_all = op.field_fwd(grid, p_field, smp["pts"], smp["anchors"][:, 0])
+    w_pre, a_pre, mask, new_se = op.early_stop(feat_all[:, 0], smp["dt"], smp["pts_idx_bounds"])
+    pts, dirs, dt, t, anchors = op.compact(mask, smp["pts"], smp["dirs"], smp["dt"], smp["t"], smp["anchors"])
+    m = len(pts)
+    e_pts, e_idx = oc.edge_samples(st["edge_pool"], tr, edge_idx, edge_coords)
+    q_pts = np.concatenate([pts, e_pts.reshape(-1, 3)], 0)
+    q_vol = np.concatenate([anchors[:, 0], e_idx.reshape(-1)], 0).astype(np.int32)
+    feat, fctx = op.field_fwd(grid, p_field, q_pts, q_vol, want_ctx=True)
+    scene_feat, edge_feat = feat[:m], feat[m:].reshape(len(edge_idx), 2, 16)
+    use_emb = bool(cfg["renderer"]["use_app_emb"])
+    sidx = oc.scatter_idx(m, new_se, emb_idx) if use_emb else None
+    rgb, sctx = op.shade_fwd(p_color, scene_feat, dirs, app_emb if use_emb else None, sidx, want_ctx=True)
+    comp = op.composite_fwd(scene_feat, dt, t, rgb, bg, new_se, want_ctx=True)
+    tcfg = cfg["train"]
+    var_w = 0.0
+    if iter_step > tcfg["var_loss_end"]:
+        var_w = tcfg["var_loss_weight"]
+    elif iter_step > tcfg["var_loss_start"]:
+        var_w = (iter_step - tcfg["var_loss_start"]) / (tcfg["var_loss_end"] - tcfg["var_loss_start"]) * tcfg["var_loss_weight"]
+    lg = op.losses_and_grads(comp["colors"], gt, comp["disparity"], comp["weights"], new_se, edge_feat, var_w,
+                             float(tcfg["disp_loss_weight"]), float(tcfg["tv_loss_weight"]))
+    gs0, gs1 = float(tcfg["gradient_scaling_start"]), float(tcfg["gradient_scaling_end"])
+    gs = 1.0 if iter_step >= gs1 else max(0.0, (iter_step - gs0) / (gs1 - gs0 + 1e-9))
+    drgb, df0 = op.composite_bwd(comp["ctx"], dt, rgb, bg, new_se, lg["dcolors"], lg["ddisparity"], None,
+                                 lg["dweights"] if var_w != 0 else None, gs)
+    dp_color, dfeat_sh, demb = op.shade_bwd(p_color, sctx, drgb, len(app_emb) if use_emb else 0, sidx)
+    dfeat = np.zeros_like(feat)
+    dfeat[:m] = dfeat_sh
+    dfeat[:m, 0] += df0
+    dfeat[m:] = lg["dedge"].reshape(-1, 16)
+    dp_field, gtab, _ = op.field_bwd(grid, p_field, fctx, dfeat, 128.0, fp32_accumulate=True)
+    return dict(smp=smp, hits=hits, mask=mask, new_se=new_se, n_kept=m, colors=comp["colors"], disparity=comp["disparity"],
+                depth=comp["depth"], weights=comp["weights"], edge_feat=edge_feat, loss=lg["loss"], w_pre=w_pre, a_pre=a_pre,
+                grads=dict(feat_pool=gtab.reshape(-1, 2), field_mlp=dp_field, color_mlp=dp_color, app_emb=demb))
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_config1_end_to_end_parity(rt, fox_state):
+    st = fox_state
+    rng = np.random.default_rng(42)
+    R = 256
+    overrides = ["field.log2_table_size=14"]
+    runner, cfg, arrays = rt.make_runner(st, "wanjinyou", overrides, seed=7, table_init=0.3)
+    runner.n_edge_pts = N_EDGE
+    runner.iter_step = 1  # keep the iteration-0 compaction (iter % compact_freq == 0) out of the comparison
+    runner.update_ada_params()
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    gt = rng.random((R, 3), dtype=F32)
+    fineness = float(runner.fineness)
+    noise = (((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(fineness)).astype(F32)
+    bg = rng.random((R, 3), dtype=F32)
+    n_edges = st["edge_pool"].size // 64
+    eidx = rng.integers(0, n_edges, N_EDGE).astype(np.int32)
+    ecoord = (rng.random((N_EDGE, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32)
+    d = rt.to_dev(ro, rd, bounds, gt, cam, noise, bg, eidx, ecoord)
+    runner.set_forced_randoms(d[5], d[6], d[7], d[8])
+
+    # --- sampler: bit-exact sample indices and positions ---
+    s = runner.get_samples(d[0], d[1], d[2])
+    ref = oracle_train_iteration(st, cfg, arrays, ro, rd, cam, gt, noise, bg, eidx, ecoord, iter_step=1)
+    for k in ("pts_idx_bounds", "anchors", "t", "dt", "pts", "dirs"):
+        got = s[k].cpu().numpy()
+        exp = ref["smp"][k]
+        assert got.shape == exp.shape, k
+        assert (got.view(np.uint32) == exp.view(np.uint32)).all() if got.dtype == F32 else (got == exp).all(), k
+
+    # --- one training iteration without the optimiser step ---
+    stats = runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
+    assert stats["n_samples"] == len(ref["smp"]["t"])
+    assert abs(stats["n_meaningful"] - ref["n_kept"]) <= 2  # early-stop threshold vs 1-ulp expf differences
+    out = runner.render_train(d[0], d[1], d[2], d[4])
+    colors = out["colors"].detach().cpu().numpy()
+    assert np.abs(colors - ref["colors"]).max() <= 1e-3, np.abs(colors - ref["colors"]).max()  # north-star RGB tolerance
+    mse_g, mse_r = float(((colors - gt) ** 2).mean()), float(((ref["colors"] - gt) ** 2).mean())
+    assert abs(10 * np.log10(1 / mse_g) - 10 * np.log10(1 / mse_r)) <= 1e-3  # PSNR within 1e-3 dB
+    assert np.abs(out["disparity"].detach().cpu().numpy() - ref["disparity"]).max() <= 1e-3 * max(1.0, np.abs(ref["disparity"]).max())
+    if stats["n_meaningful"] == ref["n_kept"]:
+        assert (out["idx_start_end"].cpu().numpy() == ref["new_se"]).all()
+        assert np.abs(out["weights"].detach().cpu().numpy() - ref["weights"]).max() <= 1e-3
+        assert np.abs(out["edge_feats"].detach().cpu().numpy() - ref["edge_feat"]).max() <= 4 * 2.0 ** -11 * max(1.0, np.abs(ref["edge_feat"]).max())
+    assert abs(float(stats["loss"]) - ref["loss"]) <= 1e-3 * max(1.0, abs(ref["loss"]))
+
+    # --- gradients (true, unscaled) ---
+    runner.zero_grad()
+    stats = runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
+    g = {k: v.cpu().numpy() for k, v in runner.grads().items()}
+    rg = ref["grads"]
+    assert rel_err(g["color_mlp"], rg["color_mlp"]) <= 3e-2, rel_err(g["color_mlp"], rg["color_mlp"])
+    assert rel_err(g["field_mlp"], rg["field_mlp"]) <= 3e-2, rel_err(g["field_mlp"], rg["field_mlp"])
+    assert rel_err(g["app_emb"], rg["app_emb"]) <= 3e-2, rel_err(g["app_emb"], rg["app_emb"])
+    gt_tab, rt_tab = g["feat_pool"].reshape(-1), rg["feat_pool"].reshape(-1)
+    cos = float((gt_tab * rt_tab).sum() / (np.linalg.norm(gt_tab) * np.linalg.norm(rt_tab)))
+    assert cos > 0.999, cos
+    assert rel_err(gt_tab, rt_tab) <= 5e-2, rel_err(gt_tab, rt_tab)
+
+
+def test_validate_render_and_training_sanity(rt, fox_state):
+    st = fox_state
+    rng = np.random.default_rng(5)
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=16", "train.learning_rate_warm_up_end_iter=10"], seed=3)
+    runner.n_edge_pts = 1024
+    R = 1024
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    gt = np.tile(np.array([[0.2, 0.5, 0.8]], F32), (R, 1))
+    d = rt.to_dev(ro, rd, bounds, gt, cam)
+    cols0 = runner.render_rays(d[0], d[1], d[2])[0].cpu().numpy()
+    assert cols0.shape == (R, 3) and np.isfinite(cols0).all()
+    losses = []
+    for it in range(60):
+        s = runner.train_step(d[0], d[1], d[2], d[3], d[4], True)
+        losses.append(float(s["mse"]))
+        assert not s["skipped_nan"]
+    assert runner.iter_step == 60
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])  # it learns the constant target
+    cols1 = runner.render_rays(d[0], d[1], d[2])[0].cpu().numpy()
+    assert ((cols1 - gt) ** 2).mean() < ((cols0 - gt) ** 2).mean()
+    # checkpoint round trip in the reference's state order
+    states = runner.states()
+    assert len(states) == 11
+    runner2, _, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=16"], seed=99)
+    runner2.load_states([t.cpu() for t in states])
+    a = runner.render_rays(d[0], d[1], d[2])[0].cpu().numpy()
+    b = runner2.render_rays(d[0], d[1], d[2])[0].cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-6
+
+
+def test_proc_octree_matches_restatement(rt, fox_state):
+    """Host-side octree maintenance (compaction / path compression / subdivision) against the oracle's restatement
+    of PersSampler.cpp:120-330 on the same node array and statistics."""
+    st = fox_state
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=12"], seed=1)
+    nodes = st["tree_nodes"].view(octc.NODE_DT).copy()
+    n = len(nodes)
+    rng = np.random.default_rng(8)
+    # kill a random third of the valid leaves, give the rest random visit counts
+    valid = np.nonzero(nodes["trans_idx"] >= 0)[0]
+    dead = rng.choice(valid, len(valid) // 3, replace=False)
+    nodes["trans_idx"][dead] = -1
+    visit = rng.integers(0, 10, n).astype(np.int32)
+    states = runner.states()
+    states = [t.cpu() for t in states]
+    states[0] = torch.from_numpy(nodes.view(np.uint8).reshape(-1).copy())
+    states[2] = torch.from_numpy(visit)
+    runner.load_states(states)
+    w = np.full(n, 1000, np.int32)
+    exp_nodes, exp_w, exp_a = octc.proc_octree(nodes, w, w, visit, True, True, False)
+    runner.proc_octree(True, True, False)
+    got = runner.tree_nodes().cpu().numpy().view(octc.NODE_DT)
+    assert len(got) == len(exp_nodes) == runner.n_nodes()
+    for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"):
+        assert (got[f] == exp_nodes[f]).all(), f
+    wst, ast, vcnt = [t.cpu().numpy() for t in runner.occupancy_buffers()]
+    assert (wst == exp_w).all() and (ast == exp_a).all() and (vcnt == 0).all()
+    # compaction only
+    exp2, _, _ = octc.proc_octree(exp_nodes, exp_w, exp_a, np.zeros(len(exp_nodes), np.int32), True, False, False)
+    runner.proc_octree(True, False, False)
+    got2 = runner.tree_nodes().cpu().numpy().view(octc.NODE_DT)
+    assert len(got2) == len(exp2)
+    for f in ("parent", "childs", "is_leaf_node", "trans_idx"):
+        assert (got2[f] == exp2[f]).all(), f
