@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the F2-NeRF per-ray hot path on MI355X (BASELINE.json metric).
+
+A "step" is one full training iteration of the hot path over one batch of synthetic random-pose rays that is
+already resident in HBM: PersSampler (octree intersection + perspective-warped march) -> no-grad density pre-pass
++ early stop -> occupancy update -> fused hash-grid/field MLP -> fused SH/colour MLP -> compositing -> losses ->
+backward (compositing, colour MLP, field MLP, hash scatter) -> fused Adam.  Nothing is skipped or cached.
+
+Workload at N=1: BASELINE config[1] "ngp_fox wanjinyou.yaml, 8192 rays/batch, 1xMI355X fp16 fused MLP" on the
+serialised fox scene state (tests/golden/fox_state.npz), fresh-initialised table (training start: fineness 16).
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): rays shard across ranks (weak scaling: 8192
+rays per rank); one RCCL all-reduce (AVG) of the gradient buffers per step + one all-reduce (MAX) of the octree
+occupancy votes so that every replica prunes identically.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description): metric/value/unit, ms_per_step, plus
+  roofline     -- HBM-roofline fraction of the dominant kernel, its duration measured live with HIP events on
+                  the launch stream during the timed region (algorithmic bytes per sample: DESIGN.md section 4)
+  cpu_baseline -- the CPU oracle (port of the reference path; the reference has no CPU path) timed on this box's
+                  host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per sample of the three field kernels (DESIGN.md section 4 / SURVEY.md section 8(d)):
+# 16 levels x 8 corners x 4 B of table traffic + the per-sample streams each kernel must touch
+ALGO_BYTES = {
+    "field_prepass": 512 + 12 + 4 + 4,        # gather + pts + trans idx + f0 out
+    "field_fwd": 512 + 12 + 4 + 64 + 64,      # gather + pts + idx + feat out (fp32x16) + saved features (f16x32)
+    "field_bwd": 512 + 12 + 4 + 64 + 64,      # atomic payload + pts + idx + dfeat in + saved features
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=8192)
+    ap.add_argument("--preset", default="wanjinyou")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(dev)
+
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
+    runner, cfg, _ = runtime.make_runner(st, args.preset, seed=2022, device=dev)   # identical replica on every rank
+    log2 = int(cfg["field"]["log2_table_size"])
+    active_halves = 17 << log2  # halves any level can address (level-overlap quirk)
+
+    if world > 1:
+        bufs = runner.grad_buffers()
+        table_flat = bufs[0].view(-1)[:active_halves]
+
+        def grad_sync():
+            dist.all_reduce(table_flat, op=dist.ReduceOp.AVG)       # 17*2^log2 fp16 halves, x128 loss-scaled
+            for b in bufs[1:]:
+                dist.all_reduce(b, op=dist.ReduceOp.AVG)            # field MLP, colour MLP, app_emb (fp32)
+
+        def occupancy_sync(adders, mark, cnt):
+            dist.all_reduce(adders, op=dist.ReduceOp.MAX)
+            dist.all_reduce(mark, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+
+        runner.set_grad_sync_hook(grad_sync)
+        runner.set_occupancy_sync_hook(occupancy_sync)
+
+    # synthetic random-pose batches, resident in HBM before the timed region (per-rank RNG stream)
+    rng = np.random.default_rng(1000 + rank)
+    n_batches = 8
+    batches = [runtime.to_dev(*runtime.synthetic_ray_batch(st, args.rays, rng), device=dev) for _ in range(n_batches)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        b = batches[i % n_batches]
+        return runner.train_step(b[0], b[1], b[2], b[3], b[4], True)
+
+    for i in range(args.warmup):
+        step(i)
+    host = runtime.host()
+    if rank == 0:
+        host.ExpRunner.enable_kernel_timing(list(ALGO_BYTES))
+    barrier()
+    t0 = time.perf_counter()
+    n_marched = n_meaningful = 0
+    for i in range(args.steps):
+        s = step(args.warmup + i)
+        n_marched += s["n_samples"]
+        n_meaningful += s["n_meaningful"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = host.ExpRunner.collect_kernel_timing() if rank == 0 else {}
+    host.ExpRunner.disable_kernel_timing()
+
+    counts = torch.tensor([elapsed, float(n_meaningful), float(n_marched)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = counts[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = counts[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, n_meaningful, n_marched = float(tmax[0]), float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_meaningful / elapsed
+        rho = n_marched / max(n_meaningful, 1.0)
+        # --- roofline of the dominant kernel (longest total time among the field kernels) ---
+        per_step_local = {"field_prepass": n_marched / world / args.steps,
+                          "field_fwd": n_meaningful / world / args.steps + 2 * runner.n_edge_pts,
+                          "field_bwd": n_meaningful / world / args.steps + 2 * runner.n_edge_pts}
+        roofline = None
+        if timing:
+            dom = max(timing, key=lambda k: timing[k][1])
+            launches, total_ms = timing[dom]
+            avg_ms = total_ms / max(launches, 1)
+            achieved = per_step_local[dom] * ALGO_BYTES[dom] / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_kernel_ms": round(avg_ms, 4),
+                        "bytes_per_sample": ALGO_BYTES[dom], "samples_per_launch": int(per_step_local[dom]),
+                        "field_kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in timing.items()}}
+        cpu_baseline = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                env = dict(os.environ, F2N_ORACLE_OMP="1")
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "baseline.py")], capture_output=True,
+                                     text=True, timeout=600, env=env)
+                cpu_baseline = json.loads(out.stdout.strip().splitlines()[-1])
+            except Exception as e:  # the baseline is a reported extra, never the thing measured
+                cpu_baseline = {"error": str(e)[:200]}
+        line = {
+            "metric": "training ray-samples/s (ngp_fox)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "ngp_fox %s.yaml, %d rays/batch/GPU, fresh-initialised 2^%d x16 table, fineness %.1f, "
+                                   "synthetic random-pose rays, full train step (fwd+bwd+Adam+octree update)"
+                                   % (args.preset, args.rays, log2, runner.fineness),
+                       "rays_per_batch": args.rays, "parallelism": "ray-dp%d" % world,
+                       "rays_per_s": args.rays * world * args.steps / elapsed,
+                       "marched_samples_per_s": n_marched / elapsed, "rho_marched_over_meaningful": rho,
+                       "meaningful_samples_per_step": n_meaningful / args.steps},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+
+    if args.breakdown and rank == 0:
+        host.ExpRunner.enable_kernel_timing(["*"])
+        for i in range(5):
+            step(i)
+        torch.cuda.synchronize()
+        t = host.ExpRunner.collect_kernel_timing()
+        host.ExpRunner.disable_kernel_timing()
+        tot = sum(v[1] for v in t.values())
+        for k, v in sorted(t.items(), key=lambda kv: -kv[1][1]):
+            print("  %-22s launches %3d  %8.3f ms/step  %5.1f%%" % (k, v[0] // 5, v[1] / 5, 100 * v[1] / tot), file=sys.stderr)
+        print("  sum of timed kernels: %.3f ms/step" % (tot / 5), file=sys.stderr)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,7 @@
 // Host-side common definitions (mirrors the role of src/Common.h of the reference).
 #pragma once
 #include <torch/torch.h>
+#include <ATen/hip/HIPEvent.h>
 #include <c10/hip/HIPStream.h>
 
 #include <cmath>
@@ -43,6 +44,62 @@ inline void CheckDev(const Tensor& t, c10::ScalarType dt, const char* what) {
   TORCH_CHECK(t.is_contiguous(), what, ": must be contiguous");
   TORCH_CHECK(t.scalar_type() == dt, what, ": wrong dtype");
 }
+// Optional HIP-event timing of individual kernel launches on the stream they are enqueued on (what bench.py's
+// `roofline` object is computed from).  Disabled by default: two event records per launch when enabled.
+class KernelTimers {
+ public:
+  static KernelTimers& Get() {
+    static KernelTimers inst;
+    return inst;
+  }
+  void Enable(const std::vector<std::string>& names) {
+    enabled_.clear();
+    for (auto& n : names) enabled_[n] = true;
+    all_ = names.size() == 1 && names[0] == "*";
+  }
+  void Disable() { enabled_.clear(); all_ = false; }
+  bool On(const char* name) const { return all_ || (!enabled_.empty() && enabled_.count(name) > 0); }
+  void Begin(const char* name) {
+    if (!On(name)) return;
+    auto e = std::make_unique<at::cuda::CUDAEvent>(hipEventDefault);
+    e->record();
+    pending_[name] = std::move(e);
+  }
+  void End(const char* name) {
+    if (!On(name)) return;
+    auto e = std::make_unique<at::cuda::CUDAEvent>(hipEventDefault);
+    e->record();
+    spans_[name].emplace_back(std::move(pending_[name]), std::move(e));
+  }
+  // Synchronises, returns {name: (launches, total milliseconds)} and clears the recorded spans.
+  std::map<std::string, std::pair<int, double>> Collect() {
+    std::map<std::string, std::pair<int, double>> out;
+    for (auto& kv : spans_) {
+      double ms = 0;
+      for (auto& se : kv.second) {
+        se.second->synchronize();
+        ms += se.first->elapsed_time(*se.second);
+      }
+      out[kv.first] = {(int) kv.second.size(), ms};
+    }
+    spans_.clear();
+    return out;
+  }
+
+ private:
+  std::map<std::string, bool> enabled_;
+  bool all_ = false;
+  std::map<std::string, std::unique_ptr<at::cuda::CUDAEvent>> pending_;
+  std::map<std::string, std::vector<std::pair<std::unique_ptr<at::cuda::CUDAEvent>, std::unique_ptr<at::cuda::CUDAEvent>>>> spans_;
+};
+
+#define F2N_TIMED_CALL(name, expr)      \
+  do {                                  \
+    KernelTimers::Get().Begin(name);    \
+    F2N_CALL(expr);                     \
+    KernelTimers::Get().End(name);      \
+  } while (0)
+
 inline float* F32P(const Tensor& t) { return t.data_ptr<float>(); }
 inline int32_t* I32P(const Tensor& t) { return t.data_ptr<int32_t>(); }
 inline void* VoidP(const Tensor& t) { return t.data_ptr(); }

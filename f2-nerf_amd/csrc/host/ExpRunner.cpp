@@ -89,11 +89,11 @@ void ExpRunner::OptimStep() {
     float scale = g.grad_scale;
     if (scale < 0.f) scale = 1.f / (g.name == "color_mlp" ? shader->mlp_->loss_scale_ : field->mlp_->loss_scale_);
     if (g.grad_is_h16) {
-      F2N_CALL(f2n_adam_step_h16grad(st, (int) n, F32P(g.param), VoidP(g.grad), scale, F32P(exp_avg_[i]),
+      F2N_TIMED_CALL("adam_table", f2n_adam_step_h16grad(st, (int) n, F32P(g.param), VoidP(g.grad), scale, F32P(exp_avg_[i]),
                                      F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
                                      VoidP(g.param_h), /*zero_grad=*/1));
     } else {
-      F2N_CALL(f2n_adam_step(st, (int) n, F32P(g.param), F32P(g.grad), scale, g.grad_round_h16 ? 1 : 0, F32P(exp_avg_[i]),
+      F2N_TIMED_CALL("adam", f2n_adam_step(st, (int) n, F32P(g.param), F32P(g.grad), scale, g.grad_round_h16 ? 1 : 0, F32P(exp_avg_[i]),
                              F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
                              g.param_h.defined() ? VoidP(g.param_h) : nullptr));
     }

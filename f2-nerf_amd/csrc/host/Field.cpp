@@ -57,7 +57,7 @@ struct MlpFunction : public torch::autograd::Function<MlpFunction> {
     ctx->save_for_backward({x});
     const int n = x.size(0);
     Tensor out = torch::empty({n, F2N_MLP_OUT_PAD}, DevF16());
-    F2N_CALL(f2n_mlp_fwd(CurStream(), n, mlp->d_in_, mlp->d_hidden_, mlp->n_hidden_layers_, VoidP(mlp->params_h_),
+    F2N_TIMED_CALL("mlp_fwd", f2n_mlp_fwd(CurStream(), n, mlp->d_in_, mlp->d_hidden_, mlp->n_hidden_layers_, VoidP(mlp->params_h_),
                          F32P(x), VoidP(out)));
     return {out.to(torch::kFloat32)};
   }
@@ -67,7 +67,7 @@ struct MlpFunction : public torch::autograd::Function<MlpFunction> {
     Tensor dy = grad_output[0].contiguous();
     const int n = x.size(0);
     Tensor dx = torch::empty({n, mlp->d_in_}, DevF32());
-    F2N_CALL(f2n_mlp_bwd(CurStream(), n, mlp->d_in_, mlp->d_hidden_, mlp->n_hidden_layers_, mlp->loss_scale_,
+    F2N_TIMED_CALL("mlp_bwd", f2n_mlp_bwd(CurStream(), n, mlp->d_in_, mlp->d_hidden_, mlp->n_hidden_layers_, mlp->loss_scale_,
                          VoidP(mlp->params_h_), F32P(x), F32P(dy), F32P(mlp->grad_scaled_), F32P(dx)));
     return {dx, Tensor(), Tensor()};  // parameter gradient is delivered through mlp->grad_scaled_
   }
@@ -150,7 +150,7 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
     AnchorView av = ViewAnchors(anchors);
     Tensor feat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
     Tensor saved_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
-    F2N_CALL(f2n_field_fwd(CurStream(), n, f->n_volumes_, VoidP(f->feat_pool_h_), I32P(f->prim_pool_),
+    F2N_TIMED_CALL("field_fwd", f2n_field_fwd(CurStream(), n, f->n_volumes_, VoidP(f->feat_pool_h_), I32P(f->prim_pool_),
                            I32P(f->feat_local_idx_), I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_),
                            F32P(points), I32P(av.t), av.stride, VoidP(f->mlp_->params_h_), F32P(feat), nullptr,
                            VoidP(saved_x)));
@@ -164,7 +164,7 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
     auto saved = ctx->get_saved_variables();
     Tensor dfeat = grad_output[0].contiguous();
     const int n = saved[0].size(0);
-    F2N_CALL(f2n_field_bwd(CurStream(), n, f->n_volumes_, I32P(f->prim_pool_), I32P(f->feat_local_idx_),
+    F2N_TIMED_CALL("field_bwd", f2n_field_bwd(CurStream(), n, f->n_volumes_, I32P(f->prim_pool_), I32P(f->feat_local_idx_),
                            I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_), F32P(saved[0]),
                            I32P(saved[1]), (int) ctx->saved_data["stride"].toInt(), VoidP(f->mlp_->params_h_),
                            VoidP(saved[2]), F32P(dfeat), f->mlp_->loss_scale_, F32P(f->mlp_->grad_scaled_), VoidP(f->grad_h_)));
@@ -189,7 +189,7 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
   AnchorView av = ViewAnchors(anchors);
   const int n = pts.size(0);
   Tensor f0 = torch::empty({n}, DevF32());
-  F2N_CALL(f2n_field_fwd(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_), I32P(feat_local_idx_),
+  F2N_TIMED_CALL("field_prepass", f2n_field_fwd(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_), I32P(feat_local_idx_),
                          I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), I32P(av.t), av.stride,
                          VoidP(mlp_->params_h_), nullptr, F32P(f0), nullptr));
   return f0;

@@ -64,14 +64,14 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   Tensor counts = torch::empty({n_rays}, DevI32());
   Tensor oct_se = torch::empty({n_rays, 2}, DevI32());
   Tensor totals = torch::zeros({2}, DevI32());  // [K, N]
-  F2N_CALL(f2n_oct_intersect_count(st, n_rays, max_oct_intersect_per_ray_, oct.node_search_order_.data_ptr<uint8_t>(),
+  F2N_TIMED_CALL("oct_intersect_count", f2n_oct_intersect_count(st, n_rays, max_oct_intersect_per_ray_, oct.node_search_order_.data_ptr<uint8_t>(),
                                    F32P(rays_o), F32P(rays_d), global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(counts)));
   F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(oct_se), I32P(totals)));
   // worst-case leaf-hit workspace (n_rays * max_oct_intersect_per_ray entries, 12 B each): no host sync here
   const int64_t k_cap = int64_t(n_rays) * max_oct_intersect_per_ray_;
   Tensor oct_idx = torch::empty({k_cap}, DevI32());
   Tensor oct_nf = torch::empty({k_cap, 2}, DevF32());
-  F2N_CALL(f2n_oct_intersect_fill(st, n_rays, oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d),
+  F2N_TIMED_CALL("oct_intersect_fill", f2n_oct_intersect_fill(st, n_rays, oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d),
                                   global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf)));
 
   Tensor rays_noise;  // :372-381
@@ -87,7 +87,7 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   }
 
   Tensor pts_se = torch::empty({n_rays, 2}, DevI32());
-  F2N_CALL(f2n_ray_march_count(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
+  F2N_TIMED_CALL("ray_march_count", f2n_ray_march_count(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
                                I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
                                VoidP(oct.pers_trans_gpu_), I32P(counts)));
   F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(pts_se), I32P(totals) + 1));
@@ -108,7 +108,7 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   res.anchors = torch::empty({n_all_pts, 3}, DevI32());
   res.pts_idx_bounds = pts_se;
   res.first_oct_dis = torch::empty({n_rays, 1}, DevF32());
-  F2N_CALL(f2n_ray_march_fill(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
+  F2N_TIMED_CALL("ray_march_fill", f2n_ray_march_fill(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
                               I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
                               VoidP(oct.pers_trans_gpu_), I32P(pts_se), F32P(res.pts), F32P(res.dirs), F32P(res.dt),
                               F32P(res.t), I32P(res.anchors), F32P(res.first_oct_dis)));
@@ -141,10 +141,11 @@ void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Te
   Tensor adders = torch::full({2, n_nodes}, -1, DevI32());  // visit_weight_adder, visit_alpha_adder (:555-556)
   Tensor visit_mark = torch::zeros({n_nodes}, DevI32());
   void* st = CurStream();
-  F2N_CALL(f2n_oct_mark_visit(st, n_rays, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
+  F2N_TIMED_CALL("oct_mark_visit", f2n_oct_mark_visit(st, n_rays, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
                               F32P(sampled_weight), F32P(sampled_alpha), I32P(adders), I32P(adders) + n_nodes,
                               I32P(visit_mark), I32P(oct.tree_visit_cnt_)));
-  F2N_CALL(f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
+  if (occupancy_sync_hook_) occupancy_sync_hook_(adders, visit_mark, oct.tree_visit_cnt_);
+  F2N_TIMED_CALL("oct_update_stats",f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
                                 I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_)));
 
   while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610

@@ -2,6 +2,8 @@
 // the C-ABI.  The octree is created from a serialised state (the reference's checkpoint byte layout); the
 // per-milestone maintenance (ProcOctree) is host code as in the reference.
 #pragma once
+#include <functional>
+
 #include "PtsSampler.h"
 
 namespace f2n {
@@ -66,6 +68,8 @@ class PersSampler : public PtsSampler {
   float global_near_;
   float sample_l_;
   bool scale_by_dis_;
+  // data-parallel hook: called between MarkVisit and the stats update with (adders [2,n], mark [n], visit_cnt [n])
+  std::function<void(Tensor, Tensor, Tensor)> occupancy_sync_hook_;
   // explicit random draws for parity tests (empty = draw from torch's generator like the reference)
   Tensor forced_noise_, forced_edge_idx_, forced_edge_coords_;
 };

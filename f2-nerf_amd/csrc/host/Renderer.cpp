@@ -55,7 +55,7 @@ struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
     const bool emb = app_emb.defined() && sample_emb_idx.defined();
     Tensor rgb = torch::empty({n, 3}, DevF32());
     Tensor saved_x = torch::empty({n, 32}, DevF16());
-    F2N_CALL(f2n_shade_fwd(CurStream(), n, F32P(feats), F32P(dirs), emb ? F32P(app_emb) : nullptr,
+    F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(CurStream(), n, F32P(feats), F32P(dirs), emb ? F32P(app_emb) : nullptr,
                            emb ? I32P(sample_emb_idx) : nullptr, VoidP(sh->mlp_->params_h_), F32P(rgb), VoidP(saved_x)));
     ctx->saved_data["shader"] = shader_ptr;
     ctx->saved_data["emb_grad"] = emb_grad_ptr;
@@ -71,7 +71,7 @@ struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
     Tensor drgb = grad_output[0].contiguous();
     const int n = saved[0].size(0);
     Tensor dfeat = torch::zeros({n, 16}, DevF32());
-    F2N_CALL(f2n_shade_bwd(CurStream(), n, F32P(drgb), emb ? I32P(saved[1]) : nullptr, VoidP(sh->mlp_->params_h_),
+    F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd(CurStream(), n, F32P(drgb), emb ? I32P(saved[1]) : nullptr, VoidP(sh->mlp_->params_h_),
                            VoidP(saved[0]), sh->mlp_->loss_scale_, F32P(dfeat), F32P(sh->mlp_->grad_scaled_),
                            (emb && emb_grad != nullptr) ? F32P(*emb_grad) : nullptr));
     return {dfeat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
@@ -86,7 +86,7 @@ struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
     const int n_rays = se.size(0), m = feat.size(0);
     Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
     Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({m}, DevF32());
-    F2N_CALL(f2n_composite_fwd(CurStream(), n_rays, I32P(se), F32P(feat), F32P(dt), F32P(t), F32P(rgb), F32P(bg),
+    F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(CurStream(), n_rays, I32P(se), F32P(feat), F32P(dt), F32P(t), F32P(rgb), F32P(bg),
                                F32P(colors), F32P(disparity), F32P(depth), F32P(weights)));
     ctx->save_for_backward({feat, rgb, dt, t, bg, se});
     ctx->saved_data["gs"] = gs_progress;
@@ -99,7 +99,7 @@ struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
     Tensor gz = g[2].defined() ? g[2].contiguous() : Tensor(), gw = g[3].defined() ? g[3].contiguous() : Tensor();
     Tensor drgb = torch::zeros({m, 3}, DevF32());
     Tensor dfeat = torch::zeros({m, 16}, DevF32());
-    F2N_CALL(f2n_composite_bwd(CurStream(), n_rays, I32P(s[5]), F32P(s[0]), F32P(s[2]), F32P(s[3]), F32P(s[1]), F32P(s[4]),
+    F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(CurStream(), n_rays, I32P(s[5]), F32P(s[0]), F32P(s[2]), F32P(s[3]), F32P(s[1]), F32P(s[4]),
                                gc.defined() ? F32P(gc) : nullptr, gd.defined() ? F32P(gd) : nullptr,
                                gz.defined() ? F32P(gz) : nullptr, gw.defined() ? F32P(gw) : nullptr,
                                (float) ctx->saved_data["gs"].toDouble(), F32P(drgb), F32P(dfeat)));
@@ -111,7 +111,7 @@ struct WeightVarFunction : public torch::autograd::Function<WeightVarFunction> {
   static variable_list forward(AutogradContext* ctx, Tensor weights, Tensor se) {
     const int n = se.size(0);
     Tensor out = torch::empty({n}, DevF32());
-    F2N_CALL(f2n_weight_var_fwd(CurStream(), n, F32P(weights), I32P(se), F32P(out)));
+    F2N_TIMED_CALL("weight_var_fwd", f2n_weight_var_fwd(CurStream(), n, F32P(weights), I32P(se), F32P(out)));
     ctx->save_for_backward({weights, se});
     return {out};
   }
@@ -119,7 +119,7 @@ struct WeightVarFunction : public torch::autograd::Function<WeightVarFunction> {
     auto s = ctx->get_saved_variables();
     Tensor dvar = g[0].contiguous();
     Tensor dw = torch::zeros_like(s[0]);
-    F2N_CALL(f2n_weight_var_bwd(CurStream(), (int) s[1].size(0), F32P(s[0]), I32P(s[1]), F32P(dvar), F32P(dw)));
+    F2N_TIMED_CALL("weight_var_bwd", f2n_weight_var_bwd(CurStream(), (int) s[1].size(0), F32P(s[0]), I32P(s[1]), F32P(dvar), F32P(dw)));
     return {dw, Tensor()};
   }
 };
@@ -223,7 +223,7 @@ RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const 
     Tensor f0 = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors);
     Tensor weights = torch::empty({n_all_pts}, DevF32()), alphas = torch::empty({n_all_pts}, DevF32());
     Tensor mask = torch::empty({n_all_pts}, DevI32()), kept = torch::empty({n_rays}, DevI32());
-    F2N_CALL(f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), F32P(f0), 1, F32P(sample_result_.dt),
+    F2N_TIMED_CALL("early_stop", f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), F32P(f0), 1, F32P(sample_result_.dt),
                             F32P(weights), F32P(alphas), I32P(mask), I32P(kept)));
     Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::zeros({1}, DevI32());
     F2N_CALL(f2n_segment_scan(st, n_rays, I32P(kept), I32P(new_se), I32P(total)));  // FilterIdxBounds, Renderer.cu:20-50
@@ -238,7 +238,7 @@ RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const 
     es.anchors = torch::empty({n_kept, 3}, DevI32());
     es.first_oct_dis = sample_result_.first_oct_dis.clone();
     es.pts_idx_bounds = new_se;
-    F2N_CALL(f2n_compact_samples(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
+    F2N_TIMED_CALL("compact_samples", f2n_compact_samples(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
                                  F32P(sample_result_.pts), F32P(sample_result_.dirs), F32P(sample_result_.dt),
                                  F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all), F32P(es.dirs),
                                  F32P(es.dt), F32P(es.t), I32P(es.anchors)));

@@ -80,7 +80,22 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              return std::vector<Tensor>{o.tree_weight_stats_, o.tree_alpha_stats_, o.tree_visit_cnt_};
            })
       .def("set_grad_sync_hook", [](ExpRunner& r, py::function f) { r.grad_sync_hook_ = [f]() { py::gil_scoped_acquire g; f(); }; })
-      .def("set_edge_pool", [](ExpRunner& r, const Tensor& e) { SamplerOf(r)->SetEdgePool(e); })
+      .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically
+           [](ExpRunner& r, py::function f) {
+             SamplerOf(r)->occupancy_sync_hook_ = [f](Tensor adders, Tensor mark, Tensor cnt) {
+               py::gil_scoped_acquire g;
+               f(adders, mark, cnt);
+             };
+           })
+      .def_static("enable_kernel_timing", [](const std::vector<std::string>& names) { KernelTimers::Get().Enable(names); })
+      .def_static("disable_kernel_timing", []() { KernelTimers::Get().Disable(); })
+      .def_static("collect_kernel_timing",
+                  []() {
+                    py::dict d;
+                    for (auto& kv : KernelTimers::Get().Collect()) d[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
+                    return d;
+                  })
+      .def("set_edge_pool",[](ExpRunner& r, const Tensor& e) { SamplerOf(r)->SetEdgePool(e); })
       .def("set_train_cameras", [](ExpRunner& r, const Tensor& w2c, const Tensor& intri, const Tensor& b) { SamplerOf(r)->SetTrainCameras(w2c, intri, b); })
       .def("set_forced_randoms",
            [](ExpRunner& r, const Tensor& noise, const Tensor& bg, const Tensor& edge_idx, const Tensor& edge_coords) {
