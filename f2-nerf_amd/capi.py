@@ -63,6 +63,10 @@ def build_info():
 
 
 # ---------------------------------------------------------------- sampler
+def normalize_dirs(n, dirs, out):
+    _ck(lib().f2n_normalize_dirs(_stream(), _i(n), _p(dirs, "f32"), _p(out, "f32")), "f2n_normalize_dirs")
+
+
 def oct_intersect_count(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, hit_counts):
     _ck(lib().f2n_oct_intersect_count(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
                                       _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(hit_counts, "i32")),

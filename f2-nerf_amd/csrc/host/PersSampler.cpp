@@ -54,11 +54,14 @@ void PersOctree::UploadNodes() {
 // ---------------------------------------------------------------------------------------------------------
 SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, const Tensor& /*bounds*/) {
   Tensor rays_o = rays_o_raw.contiguous();
-  Tensor rays_d = (rays_d_raw / torch::linalg_norm(rays_d_raw, 2, -1, true)).contiguous();  // :319
+  Tensor rays_d_in = rays_d_raw.contiguous();
   CheckDev(rays_o, torch::kFloat32, "rays_o");
+  CheckDev(rays_d_in, torch::kFloat32, "rays_d");
   const int n_rays = rays_o.size(0);
   auto& oct = *pers_octree_;
   void* st = CurStream();
+  Tensor rays_d = torch::empty_like(rays_d_in);  // :319, with a fixed (oracle-restatable) summation order
+  F2N_CALL(f2n_normalize_dirs(st, n_rays, F32P(rays_d_in), F32P(rays_d)));
   const float far = 1e8f;  // the `bounds` argument is ignored by the reference too (:322-323)
 
   Tensor counts = torch::empty({n_rays}, DevI32());

@@ -52,7 +52,7 @@ struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
     CheckDev(feats, torch::kFloat32, "field feats");
     TORCH_CHECK(feats.size(1) == 16 && sh->degree_ == 4 && sh->n_hiddens_ == 2, "fused shading needs 16 feats + SH4 + 2 hidden");
     const int n = feats.size(0);
-    const bool emb = app_emb.defined() && sample_emb_idx.defined();
+    const bool emb = app_emb.defined() && sample_emb_idx.defined() && app_emb.numel() > 0 && sample_emb_idx.numel() > 0;
     Tensor rgb = torch::empty({n, 3}, DevF32());
     Tensor saved_x = torch::empty({n, 32}, DevF16());
     F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(CurStream(), n, F32P(feats), F32P(dirs), emb ? F32P(app_emb) : nullptr,
@@ -60,7 +60,7 @@ struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
     ctx->saved_data["shader"] = shader_ptr;
     ctx->saved_data["emb_grad"] = emb_grad_ptr;
     ctx->saved_data["emb"] = emb;
-    ctx->save_for_backward({saved_x, emb ? sample_emb_idx : Tensor()});
+    ctx->save_for_backward({saved_x, sample_emb_idx});
     return {rgb};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grad_output) {
@@ -273,8 +273,10 @@ RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const 
     sample_emb_idx = torch::empty({std::max(n_kept, 1)}, DevI32());
     F2N_CALL(f2n_scatter_idx(st, n_rays, I32P(es.pts_idx_bounds), I32P(ei), I32P(sample_emb_idx)));
   }
-  Tensor sampled_colors = shader->QueryFromField(scene_feat, es.dirs, emb ? app_emb_ : Tensor(), sample_emb_idx,
-                                                 emb ? &app_emb_grad_ : nullptr);
+  // autograd::Function inputs must be defined tensors: empty placeholders stand for "no appearance embedding"
+  if (!emb) sample_emb_idx = torch::empty({0}, DevI32());
+  Tensor sampled_colors = shader->QueryFromField(scene_feat, es.dirs, emb ? app_emb_ : torch::empty({0}, DevF32()),
+                                                 sample_emb_idx, emb ? &app_emb_grad_ : nullptr);
   auto out = CompositeFunction::apply(scene_feat, sampled_colors, es.dt, es.t, bg_color, es.pts_idx_bounds,
                                       (double) gdp->gradient_scaling_progress_);
   sample_result_ = SampleResultFlex();  // drop the pre-early-stop buffers

@@ -33,7 +33,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("states", &ExpRunner::States)
       .def("train_step",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply) {
-             return StatsToDict(r.TrainStep(ro, rd, b, gt, emb, apply));
+             TrainStats s;
+             {
+               py::gil_scoped_release no_gil;  // the autograd engine must not be entered while holding the GIL
+               s = r.TrainStep(ro, rd, b, gt, emb, apply);
+             }
+             return StatsToDict(s);
            },
            py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
            py::arg("apply_optimizer") = true)

@@ -236,6 +236,19 @@ __global__ __launch_bounds__(F2N_RAY_BLOCK) void ray_march_kernel(
   if (!FILL) pts_counts[ray] = n;
 }
 
+// rays_d / ||rays_d|| (PersSampler.cu:319).  The reference uses torch::linalg_norm, whose summation order is an
+// implementation detail of the ATen reduction; here the order is fixed -- sqrt((x*x + y*y) + z*z) -- so that the
+// oracle can restate it bit for bit (everything downstream of the sampler depends on these bits).
+__global__ void normalize_dirs_kernel(int n, const float* __restrict__ in, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+  const float nrm = sqrtf((x * x + y * y) + z * z);
+  out[3 * i] = x / nrm;
+  out[3 * i + 1] = y / nrm;
+  out[3 * i + 2] = z / nrm;
+}
+
 // GetEdgeSamplesKernel, PersSampler.cu:436-452.
 __global__ void edge_samples_kernel(int n_pts, const F2nEdgePool* __restrict__ edge_pool,
                                     const F2nTransInfo* __restrict__ transes, const int32_t* __restrict__ edge_idx,
@@ -357,6 +370,13 @@ __global__ void mark_invisible_kernel(int n_nodes, int n_cams, F2nTreeNode* __re
 // C-ABI
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
+
+int f2n_normalize_dirs(void* stream, int n, const float* dirs, float* out) {
+  if (n < 0) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(normalize_dirs_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n, dirs, out);
+  return f2n_launch_status();
+}
 
 int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                             const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* hit_counts) {

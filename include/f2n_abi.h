@@ -44,6 +44,10 @@ const char* f2n_build_info(void);
  * Sampler -- replaces PersSampler::GetSamples' kernels (PtsSampler/PersSampler.cu:21-434).
  * ------------------------------------------------------------------------------------------------- */
 
+/* rays_d / ||rays_d|| (PersSampler.cu:319, torch::linalg_norm there).  Fixed fp32 order: sqrt((x*x + y*y) + z*z),
+ * IEEE division, so that the CPU oracle restates it bit for bit.  out may alias dirs. */
+int f2n_normalize_dirs(void* stream, int n, const float* dirs /*[n,3]*/, float* out /*[n,3]*/);
+
 /* FindRayOctreeIntersectionKernel<false> (PersSampler.cu:53-152, launched :342-351).
  * rays_d must already be unit length (GetSamples normalises at :319); [near, far] is the global bound the
  * reference substitutes for its `bounds` argument (:322-323: near = pts_sampler.near, far = 1e8).

@@ -107,6 +107,13 @@ def search_order_table():
     return np.array(out, np.uint8)
 
 
+def normalize_dirs(dirs):
+    dirs = _f32(dirs)
+    out = np.empty_like(dirs)
+    lib().oracle_normalize_dirs(ctypes.c_int(dirs.shape[0]), _p(dirs), _p(out))
+    return out
+
+
 def oct_intersect(search_order, rays_o, rays_d, near, far, tree_nodes, max_hits=1024):
     rays_o, rays_d = _f32(rays_o), _f32(rays_d)
     n = rays_o.shape[0]

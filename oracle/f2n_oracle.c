@@ -119,6 +119,18 @@ static inline float or_sum12(const float* e) {
 }
 static inline float or_norm3(const float* v) { return sqrtf(or_sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2])); }
 
+/* PersSampler.cu:319: rays_d / linalg_norm(rays_d).  ATen's reduction order is unspecified; the contract fixed
+ * with the HIP side (f2n_normalize_dirs) is sqrt((x*x + y*y) + z*z) and IEEE division. */
+void oracle_normalize_dirs(int n, const float* in, float* out) {
+  for (int i = 0; i < n; i++) {
+    float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+    float nrm = sqrtf((x * x + y * y) + z * z);
+    out[3 * i] = x / nrm;
+    out[3 * i + 1] = y / nrm;
+    out[3 * i + 2] = z / nrm;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * a5: ray / octree intersection.  PersSampler.cu:21-51 (slab test), :53-152 (DFS).
  * ---------------------------------------------------------------------------------------------- */

@@ -42,9 +42,7 @@ def oracle_train_iteration(st, cfg, arrays, rays_o, rays_d_raw, emb_idx, gt, noi
     nvol = int(nvol[0])
     log2 = int(cfg["field"]["log2_table_size"])
     grid = op.HashGrid(table, prim, bias, nvol, log2)
-    # torch.linalg_norm + divide on the GPU side; same fp32 formula here
-    rays_d = torch.from_numpy(rays_d_raw)
-    rays_d = (rays_d / torch.linalg.norm(rays_d, 2, -1, True)).numpy()
+    rays_d = oc.normalize_dirs(rays_d_raw)  # PersSampler.cu:319 with the fixed summation order (f2n_normalize_dirs)
     ps = cfg["pts_sampler"]
     hits = oc.oct_intersect(st["search_order"], rays_o, rays_d, float(ps["near"]), 1e8, tn, int(ps["max_oct_intersect_per_ray"]))
     smp = oc.ray_march(rays_o, rays_d, noise, float(ps["sample_l"]), bool(ps["scale_by_dis"]), *hits, tn, tr)
@@ -172,6 +170,8 @@ def test_validate_render_and_training_sanity(rt, fox_state):
     assert len(states) == 11
     runner2, _, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=16"], seed=99)
     runner2.load_states([t.cpu() for t in states])
+    runner2.iter_step = runner.iter_step  # scalars.pt of the reference checkpoint (ExpRunner.cpp:188-194)
+    runner2.update_ada_params()
     a = runner.render_rays(d[0], d[1], d[2])[0].cpu().numpy()
     b = runner2.render_rays(d[0], d[1], d[2])[0].cpu().numpy()
     assert np.abs(a - b).max() <= 1e-6

@@ -151,6 +151,14 @@ def test_sampler_full_size_properties(hip, fox_state):
     assert_same(m["pts"][:n_sub], ref["pts"], "pts subset")
 
 
+def test_normalize_dirs(hip):
+    rng = np.random.default_rng(17)
+    d = (rng.standard_normal((5000, 3)) * np.exp(rng.standard_normal((5000, 1)) * 3)).astype(F32)
+    out = torch.empty((5000, 3), device=DEV)
+    hip.normalize_dirs(5000, T(d), out)
+    assert_same(N(out), oc.normalize_dirs(d), "normalized dirs")
+
+
 def test_segment_scan(hip):
     rng = np.random.default_rng(0)
     for n in (1, 63, 64, 4096, 4097, 8192, 100003):
