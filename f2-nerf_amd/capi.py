@@ -73,6 +73,12 @@ def oct_intersect_count(n_rays, max_hits, search_order, rays_o, rays_d, near, fa
         "f2n_oct_intersect_count")
 
 
+def oct_intersect_strided(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total):
+    _ck(lib().f2n_oct_intersect_strided(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
+                                        _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
+                                        _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32")), "f2n_oct_intersect_strided")
+
+
 def segment_scan(n, counts, start_end, total):
     _ck(lib().f2n_segment_scan(_stream(), _i(n), _p(counts, "i32"), _p(start_end, "i32"), _p(total, "i32")),
         "f2n_segment_scan")
@@ -107,7 +113,7 @@ def edge_samples(n, edge_pool, transes, edge_idx, edge_coords, out_pts, out_idx)
 
 
 def oct_mark_visit(n_rays, pts_se, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt):
-    _ck(lib().f2n_oct_mark_visit(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(anchors, "i32"), _i(anchor_stride),
+    _ck(lib().f2n_oct_mark_visit(_stream(), _i(n_rays), _i(w_adder.numel()), _p(pts_se, "i32"), _p(anchors, "i32"), _i(anchor_stride),
                                  _p(weights, "f32"), _p(alphas, "f32"), _p(w_adder, "i32"), _p(a_adder, "i32"),
                                  _p(mark, "i32"), _p(visit_cnt, "i32")), "f2n_oct_mark_visit")
 
@@ -197,7 +203,7 @@ def shade_fwd(n, feat, dirs, app_emb, sample_emb_idx, mlp_params_h, rgb, save_x_
 def shade_bwd(n, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_scaled, dapp_emb):
     _ck(lib().f2n_shade_bwd(_stream(), _i(n), _p(drgb, "f32"), _p(sample_emb_idx, "i32", True), _p(mlp_params_h, "h16"),
                             _p(saved_x_h, "h16"), _f(loss_scale), _p(dfeat, "f32"), _p(dparams_scaled, "f32"),
-                            _p(dapp_emb, "f32", True)), "f2n_shade_bwd")
+                            _p(dapp_emb, "f32", True), _i(0 if dapp_emb is None else dapp_emb.shape[0])), "f2n_shade_bwd")
 
 
 # ---------------------------------------------------------------- renderer

@@ -47,6 +47,13 @@ static inline int f2n_launch_status() {
 
 static inline unsigned f2n_div_up(long a, long b) { return (unsigned) ((a + b - 1) / b); }
 
+// workspace.hip: internal per-device scratch + the partial-sum reduction used by the backward kernels
+void* f2n_ws_get(int slot, size_t bytes);
+int f2n_reduce_partials(void* stream, int n, int n_blocks, const float* partials, float* out);
+#define F2N_WS_FIELD_DW 0
+#define F2N_WS_SHADE_DW 1
+#define F2N_WS_SHADE_EMB 2
+
 // ---- reductions in the order Eigen's scalar fixed-size unrollers use (n/2 | n - n/2 recursive split) ----
 __device__ __forceinline__ float f2n_sum3(float a, float b, float c) { return a + (b + c); }
 __device__ __forceinline__ float f2n_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }

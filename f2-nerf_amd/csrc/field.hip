@@ -335,6 +335,15 @@ static inline unsigned f2n_wave_grid(int n_units, int waves_per_block) {
   return (unsigned) blocks;
 }
 
+// Backward kernels hold their weight-gradient accumulators in registers (1 wave per SIMD, 1 block per CU) and pay
+// one LDS + global-atomic flush of all parameters per BLOCK: exactly one resident block per CU minimises that.
+static inline unsigned f2n_bwd_grid(int n_super) {
+  long blocks = ((long) n_super + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  return (unsigned) blocks;
+}
+
 static inline bool f2n_mlp_shape_ok(int d_in, int d_hidden, int n_hidden) {
   return d_in == F2N_D_IN && d_hidden == F2N_D_HID && (n_hidden == 1 || n_hidden == 2);
 }
@@ -407,14 +416,19 @@ int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float
   if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
-  const dim3 grid(f2n_wave_grid((n + 31) / 32, 4 * 4)), block(F2N_BWD_THREADS);
+  const dim3 grid(f2n_bwd_grid((n + 31) / 32)), block(F2N_BWD_THREADS);
+  const int n_params = f2n_mlp_n_params(d_in, d_hidden, n_hidden);
+  float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) grid.x * n_params);
+  if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_hidden == 1)
     hipLaunchKernelGGL((field_bwd_kernel<1, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, dparams_f32_scaled, dx_f32, nullptr);
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr);
   else
     hipLaunchKernelGGL((field_bwd_kernel<2, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, dparams_f32_scaled, dx_f32, nullptr);
-  return f2n_launch_status();
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr);
+  int rc = f2n_launch_status();
+  if (rc != F2N_OK) return rc;
+  return f2n_reduce_partials(stream, n_params, (int) grid.x, partials, dparams_f32_scaled);
 }
 
 int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
@@ -437,11 +451,17 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
   if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f)) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
-  hipLaunchKernelGGL((field_bwd_kernel<1, true>), dim3(f2n_wave_grid((n + 31) / 32, 4 * 2)), dim3(F2N_BWD_THREADS), 0,
+  const unsigned blocks = f2n_bwd_grid((n + 31) / 32);
+  const int n_params = f2n_mlp_n_params(F2N_D_IN, F2N_D_HID, 1);
+  float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) blocks * n_params);
+  if (partials == nullptr) return F2N_ERR_INVALID_ARG;
+  hipLaunchKernelGGL((field_bwd_kernel<1, true>), dim3(blocks), dim3(F2N_BWD_THREADS), 0,
                      (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
                      (const half_t*) mlp_params_h, (const half_t*) saved_x_h, nullptr, dfeat, loss_scale,
-                     dparams_f32_scaled, nullptr, (half_t*) grad_table_h);
-  return f2n_launch_status();
+                     partials, nullptr, (half_t*) grad_table_h);
+  int rc = f2n_launch_status();
+  if (rc != F2N_OK) return rc;
+  return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
 }
 
 }  // extern "C"

@@ -67,15 +67,15 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   Tensor counts = torch::empty({n_rays}, DevI32());
   Tensor oct_se = torch::empty({n_rays, 2}, DevI32());
   Tensor totals = torch::zeros({2}, DevI32());  // [K, N]
-  F2N_TIMED_CALL("oct_intersect_count", f2n_oct_intersect_count(st, n_rays, max_oct_intersect_per_ray_, oct.node_search_order_.data_ptr<uint8_t>(),
-                                   F32P(rays_o), F32P(rays_d), global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(counts)));
-  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(oct_se), I32P(totals)));
-  // worst-case leaf-hit workspace (n_rays * max_oct_intersect_per_ray entries, 12 B each): no host sync here
+  // Leaf hits go into fixed-stride per-ray slots of a worst-case workspace (n_rays * max_oct_intersect_per_ray
+  // entries of 12 B: ~100 MB at 8192 rays, nothing next to 288 GB of HBM): ONE DFS pass instead of the reference's
+  // count pass + host sync + fill pass (PersSampler.cu:342-366).
   const int64_t k_cap = int64_t(n_rays) * max_oct_intersect_per_ray_;
   Tensor oct_idx = torch::empty({k_cap}, DevI32());
   Tensor oct_nf = torch::empty({k_cap, 2}, DevF32());
-  F2N_TIMED_CALL("oct_intersect_fill", f2n_oct_intersect_fill(st, n_rays, oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d),
-                                  global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf)));
+  F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided(st, n_rays, max_oct_intersect_per_ray_,
+                                  oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
+                                  VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals)));
 
   Tensor rays_noise;  // :372-381
   if (forced_noise_.defined()) {
@@ -144,7 +144,7 @@ void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Te
   Tensor adders = torch::full({2, n_nodes}, -1, DevI32());  // visit_weight_adder, visit_alpha_adder (:555-556)
   Tensor visit_mark = torch::zeros({n_nodes}, DevI32());
   void* st = CurStream();
-  F2N_TIMED_CALL("oct_mark_visit", f2n_oct_mark_visit(st, n_rays, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
+  F2N_TIMED_CALL("oct_mark_visit", f2n_oct_mark_visit(st, n_rays, n_nodes, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
                               F32P(sampled_weight), F32P(sampled_alpha), I32P(adders), I32P(adders) + n_nodes,
                               I32P(visit_mark), I32P(oct.tree_visit_cnt_)));
   if (occupancy_sync_hook_) occupancy_sync_hook_(adders, visit_mark, oct.tree_visit_cnt_);

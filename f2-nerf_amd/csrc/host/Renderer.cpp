@@ -73,7 +73,8 @@ struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
     Tensor dfeat = torch::zeros({n, 16}, DevF32());
     F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd(CurStream(), n, F32P(drgb), emb ? I32P(saved[1]) : nullptr, VoidP(sh->mlp_->params_h_),
                            VoidP(saved[0]), sh->mlp_->loss_scale_, F32P(dfeat), F32P(sh->mlp_->grad_scaled_),
-                           (emb && emb_grad != nullptr) ? F32P(*emb_grad) : nullptr));
+                           (emb && emb_grad != nullptr) ? F32P(*emb_grad) : nullptr,
+                           (emb && emb_grad != nullptr) ? (int) emb_grad->size(0) : 0));
     return {dfeat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };

@@ -315,10 +315,12 @@ __device__ __forceinline__ void f2n_mlp_accumulate_dw(const F2nHalfBwd<NH>& a, c
   }
 }
 
-// Block-level reduction of the per-wave accumulators through LDS, then one fp32 atomic per parameter per
-// block into the (loss-scaled) global gradient.  s_acc must hold n_params floats and be zero on entry.
+// Block-level reduction of the per-wave accumulators through LDS (ds_add_f32), then the block's partial parameter
+// gradient is written with plain coalesced stores to partials[blockIdx.x][n_params]; f2n_reduce_partials sums the
+// blocks afterwards.  (Global fp32 atomics here would put gridDim.x-deep dependent chains on every parameter.)
+// s_acc must hold n_params floats and be zero on entry.
 template <int NH>
-__device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, float* s_acc, float* __restrict__ dparams,
+__device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, float* s_acc, float* __restrict__ partials,
                                                  int c, int g, int tid, int nthreads) {
   const int off1 = F2N_D_HID * F2N_D_IN;
   const int offo = off1 + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0);
@@ -343,8 +345,6 @@ __device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, f
 #pragma unroll
     for (int r = 0; r < 4; r++) atomicAdd(&s_acc[offo + (4 * g + r) * F2N_D_HID + 16 * t + c], acc.dwo[t][r]);
   __syncthreads();
-  for (int i = tid; i < n_params; i += nthreads) {
-    const float v = s_acc[i];
-    if (v != 0.f) atomicAdd(dparams + i, v);
-  }
+  float* dst = partials + (size_t) blockIdx.x * n_params;
+  for (int i = tid; i < n_params; i += nthreads) dst[i] = s_acc[i];
 }

@@ -34,25 +34,31 @@ __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const f
 
 // Front-to-back DFS over the octree for one ray per lane (PersSampler.cu:53-152).  The per-lane stack
 // lives in LDS, transposed ([slot][lane]) so that the 64 lanes of the wave never bank-conflict.
-template <bool FILL>
+// MODE 0: count only.  MODE 1: fill a compact, ray-ordered list (segments from f2n_segment_scan).
+// MODE 2: single pass into fixed-stride per-ray segments [ray*max_hits, ray*max_hits + cnt): no count pass, no scan.
+template <int MODE>
 __global__ __launch_bounds__(F2N_RAY_BLOCK) void oct_intersect_kernel(
     int n_rays, int max_hits, const uint8_t* __restrict__ search_order, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, float g_near, float g_far, const F2nTreeNode* __restrict__ nodes,
     const int32_t* __restrict__ oct_start_end, int32_t* __restrict__ hit_counts, int32_t* __restrict__ oct_idx,
-    float* __restrict__ oct_near_far) {
+    float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total) {
+  constexpr bool FILL = MODE != 0;
   __shared__ int s_node[F2N_STACK_DEPTH][F2N_RAY_BLOCK];
   __shared__ int s_cur[F2N_STACK_DEPTH][F2N_RAY_BLOCK];
   const int lane = threadIdx.x;
-  const int ray = blockIdx.x * F2N_RAY_BLOCK + lane;
-  if (ray >= n_rays) return;
+  const int ray_raw = blockIdx.x * F2N_RAY_BLOCK + lane;
+  const bool in_range = ray_raw < n_rays;
+  if (MODE != 2 && !in_range) return;
+  const int ray = in_range ? ray_raw : 0;  // MODE 2 keeps every lane alive for the wave-level hit total
   const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
   const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
-  int limit = max_hits;
+  int limit = in_range ? max_hits : 0;
   int base = 0;
-  if (FILL) {
+  if (MODE == 1) {
     base = oct_start_end[2 * ray];
     limit = oct_start_end[2 * ray + 1] - base;
   }
+  if (MODE == 2) base = ray * max_hits;
   const int octant = (int(d[0] > 0.f) << 2) | (int(d[1] > 0.f) << 1) | int(d[2] > 0.f);
   // the 8-entry visiting order of this ray's octant packed into two registers
   uint32_t ord_lo = 0, ord_hi = 0;
@@ -101,7 +107,17 @@ __global__ __launch_bounds__(F2N_RAY_BLOCK) void oct_intersect_kernel(
       s_cur[sp][lane] = -1;
     }
   }
-  if (!FILL) hit_counts[ray] = cnt;
+  if (MODE == 0) hit_counts[ray] = cnt;
+  if (MODE == 2) {
+    if (in_range) {
+      se_out[2 * ray] = base;
+      se_out[2 * ray + 1] = base + cnt;
+    }
+    int s = cnt;  // wave-level sum, one atomic per wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) atomicAdd(total, s);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -281,16 +297,37 @@ __device__ __forceinline__ void f2n_vote(int32_t* w_adder, int32_t* a_adder, int
   atomicMax(w_adder + node, w > w_thres ? 512 : -1);  // OCC_WEIGHT_BASE
   atomicMax(a_adder + node, a > a_thres ? 32 : -1);   // OCC_ALPHA_BASE
   atomicMax(cnt + node, visits);
-  mark[node] = 1;
+  if (mark != nullptr) mark[node] = 1;
 }
 
-__global__ void mark_visit_kernel(int n_rays, const int32_t* __restrict__ pts_start_end, const int32_t* __restrict__ anchors,
-                                  int anchor_stride, const float* __restrict__ weights, const float* __restrict__ alphas,
-                                  int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt) {
+// USE_LDS: the votes of a block's rays are first max-combined in LDS (ds_max_i32) and flushed once per block.
+// A few hundred leaves receive tens of thousands of votes per batch; as global atomics those are long
+// same-address dependent chains (~1 us each at the memory-side atomic unit).
+template <bool USE_LDS>
+__global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __restrict__ pts_start_end,
+                                  const int32_t* __restrict__ anchors, int anchor_stride, const float* __restrict__ weights,
+                                  const float* __restrict__ alphas, int32_t* g_w_adder, int32_t* g_a_adder, int32_t* g_mark,
+                                  int32_t* g_cnt) {
+  extern __shared__ int32_t s_votes[];  // [3][n_nodes]: weight vote, alpha vote, visit count
+  int32_t* w_adder = USE_LDS ? s_votes : g_w_adder;
+  int32_t* a_adder = USE_LDS ? s_votes + n_nodes : g_a_adder;
+  int32_t* cnt = USE_LDS ? s_votes + 2 * n_nodes : g_cnt;
+  int32_t* mark = USE_LDS ? nullptr : g_mark;  // LDS path: "visited" <=> block-local visit count >= 1
+  if (USE_LDS) {
+    for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
+      s_votes[i] = -2;
+      s_votes[n_nodes + i] = -2;
+      s_votes[2 * n_nodes + i] = 0;
+    }
+    __syncthreads();
+  }
   const int ray = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ray >= n_rays) return;
-  const int s = pts_start_end[2 * ray], e = pts_start_end[2 * ray + 1];
-  if (s >= e) return;
+  int s = 0, e = 0;
+  if (ray < n_rays) {
+    s = pts_start_end[2 * ray];
+    e = pts_start_end[2 * ray + 1];
+  }
+  if (s < e) {
   float mw = 0.f, ma = 0.f;
   for (int i = s; i < e; i++) {
     mw = fmaxf(mw, weights[i]);
@@ -315,6 +352,19 @@ __global__ void mark_visit_kernel(int n_rays, const int32_t* __restrict__ pts_st
     visits++;
   }
   if (cur >= 0) f2n_vote(w_adder, a_adder, mark, cnt, cur, cw, ca, w_thres, a_thres, visits);
+  }
+  if (USE_LDS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
+      const int visits = s_votes[2 * n_nodes + i];
+      if (visits > 0) {
+        atomicMax(g_w_adder + i, s_votes[i]);
+        atomicMax(g_a_adder + i, s_votes[n_nodes + i]);
+        atomicMax(g_cnt + i, visits);
+        g_mark[i] = 1;
+      }
+    }
+  }
 }
 
 // PersSampler.cu:579-593 (torch integer ops) + MarkInvalidNodes (:528-534), one node per lane.
@@ -382,9 +432,20 @@ int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_
                             const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* hit_counts) {
   if (n_rays < 0 || max_hits < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(oct_intersect_kernel<false>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
+  hipLaunchKernelGGL(oct_intersect_kernel<0>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr);
+                     (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                              const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
+                              int32_t* oct_idx, float* oct_near_far, int32_t* total) {
+  if (n_rays < 0 || max_hits < 1) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(oct_intersect_kernel<2>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
+                     (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
+                     (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total);
   return f2n_launch_status();
 }
 
@@ -400,9 +461,9 @@ int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order
                            const int32_t* oct_start_end, int32_t* oct_idx, float* oct_near_far) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(oct_intersect_kernel<true>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
+  hipLaunchKernelGGL(oct_intersect_kernel<1>, dim3(f2n_div_up(n_rays, F2N_RAY_BLOCK)), dim3(F2N_RAY_BLOCK), 0,
                      (hipStream_t) stream, n_rays, 0, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far);
+                     (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -442,13 +503,19 @@ int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void*
   return f2n_launch_status();
 }
 
-int f2n_oct_mark_visit(void* stream, int n_rays, const int32_t* pts_start_end, const int32_t* anchors, int anchor_stride,
-                       const float* weights, const float* alphas, int32_t* w_adder, int32_t* a_adder, int32_t* mark,
-                       int32_t* visit_cnt) {
-  if (n_rays < 0 || anchor_stride < 2) return F2N_ERR_INVALID_ARG;
+int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts_start_end, const int32_t* anchors,
+                       int anchor_stride, const float* weights, const float* alphas, int32_t* w_adder, int32_t* a_adder,
+                       int32_t* mark, int32_t* visit_cnt) {
+  if (n_rays < 0 || n_nodes < 1 || anchor_stride < 2) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(mark_visit_kernel, dim3(f2n_div_up(n_rays, 64)), dim3(64), 0, (hipStream_t) stream, n_rays,
-                     pts_start_end, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt);
+  const size_t lds = sizeof(int32_t) * 3 * (size_t) n_nodes;
+  if (lds <= 60 * 1024) {  // block-local vote combining in LDS (12 B per octree node; 64 KB default LDS limit)
+    hipLaunchKernelGGL(mark_visit_kernel<true>, dim3(f2n_div_up(n_rays, 256)), dim3(256), lds, (hipStream_t) stream, n_rays,
+                       n_nodes, pts_start_end, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt);
+  } else {
+    hipLaunchKernelGGL(mark_visit_kernel<false>, dim3(f2n_div_up(n_rays, 64)), dim3(64), 0, (hipStream_t) stream, n_rays,
+                       n_nodes, pts_start_end, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt);
+  }
   return f2n_launch_status();
 }
 

@@ -113,10 +113,15 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
                                                         const int32_t* __restrict__ sample_emb_idx,
                                                         const half_t* __restrict__ params, const half_t* __restrict__ x_h,
                                                         float loss_scale, float* __restrict__ dfeat,
-                                                        float* __restrict__ dparams, float* __restrict__ dapp_emb) {
+                                                        float* __restrict__ dparams, int n_emb,
+                                                        float* __restrict__ emb_partials) {
   __shared__ F2nShadeSmem sm;
+  extern __shared__ float s_emb[];  // [n_emb * 16] per-block appearance-embedding gradient (ds_add_f32)
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   f2n_mlp_lds_fill<2>(sm.w, params, tid, 256);
+  const bool do_emb = emb_partials != nullptr;
+  if (do_emb)
+    for (int i = tid; i < n_emb * 16; i += 256) s_emb[i] = 0.f;
   __syncthreads();
   const half8_t idf[2] = {f2n_identity_frag(0, c, g), f2n_identity_frag(1, c, g)};
   // forward output layer fragments (needed to recompute o for the sigmoid derivative)
@@ -174,9 +179,9 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
           *(float4_t*) p = dsf;
         }
       }
-      if (dapp_emb != nullptr) {
-        // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples.  16 samples of one wave half
-        // usually share a ray, hence an image: reduce across the 16 sample lanes first, then 1 atomic.
+      if (do_emb) {
+        // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples, accumulated in LDS.  The 16 samples
+        // of one wave half usually share a ray, hence an image: reduce across the 16 sample lanes first.
         const int img = valid ? sample_emb_idx[s] : -1;
         const int img0 = __shfl(img, lane & 48);  // sample 0 of this lane group
         const bool uniform = __all(img == img0);
@@ -187,12 +192,12 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
               float v = dsf[r];
 #pragma unroll
               for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-              if (c == 0) atomicAdd(dapp_emb + (size_t) img0 * 16 + 4 * g + r, v);
+              if (c == 0) atomicAdd(&s_emb[img0 * 16 + 4 * g + r], v);
             }
           }
         } else if (valid) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) atomicAdd(dapp_emb + (size_t) img * 16 + 4 * g + r, dsf[r]);
+          for (int r = 0; r < 4; r++) atomicAdd(&s_emb[img * 16 + 4 * g + r], dsf[r]);
         }
       }
     }
@@ -203,6 +208,10 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
   for (int i = tid; i < n_params; i += 256) sm.acc[i] = 0.f;
   __syncthreads();
   f2n_mlp_flush_dw<2>(acc, sm.acc, dparams, c, g, tid, 256);
+  if (do_emb) {  // s_emb is complete since the __syncthreads() above
+    float* dst = emb_partials + (size_t) blockIdx.x * n_emb * 16;
+    for (int i = tid; i < n_emb * 16; i += 256) dst[i] = s_emb[i];
+  }
 }
 
 static inline unsigned f2n_shade_grid(int n_units, int per_block) {
@@ -240,13 +249,30 @@ int f2n_shade_fwd(void* stream, int n, const float* feat, const float* dirs, con
 }
 
 int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
-                  const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled, float* dapp_emb) {
-  if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && sample_emb_idx == nullptr)) return F2N_ERR_INVALID_ARG;
+                  const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled, float* dapp_emb,
+                  int n_emb) {
+  if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1))) return F2N_ERR_INVALID_ARG;
+  if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 31 KB of weights
   if (n == 0) return F2N_OK;
-  hipLaunchKernelGGL(shade_bwd_kernel, dim3(f2n_shade_grid((n + 31) / 32, 4 * 4)), dim3(256), 0, (hipStream_t) stream, n, drgb,
-                     sample_emb_idx, (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat,
-                     dparams_f32_scaled, dapp_emb);
-  return f2n_launch_status();
+  unsigned blocks = f2n_shade_grid((n + 31) / 32, 4);
+  if (blocks > 256) blocks = 256;  // one resident block per CU (the kernel owns the whole register file)
+  const int n_params = F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID;
+  float* partials = (float*) f2n_ws_get(F2N_WS_SHADE_DW, sizeof(float) * (size_t) blocks * n_params);
+  float* emb_partials = nullptr;
+  size_t dyn_lds = 0;
+  if (dapp_emb != nullptr) {
+    emb_partials = (float*) f2n_ws_get(F2N_WS_SHADE_EMB, sizeof(float) * (size_t) blocks * n_emb * 16);
+    dyn_lds = sizeof(float) * (size_t) n_emb * 16;
+    if (emb_partials == nullptr) return F2N_ERR_INVALID_ARG;
+  }
+  if (partials == nullptr) return F2N_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(256), dyn_lds, (hipStream_t) stream, n, drgb, sample_emb_idx,
+                     (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat, partials, n_emb, emb_partials);
+  int rc = f2n_launch_status();
+  if (rc != F2N_OK) return rc;
+  rc = f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
+  if (rc != F2N_OK || dapp_emb == nullptr) return rc;
+  return f2n_reduce_partials(stream, n_emb * 16, (int) blocks, emb_partials, dapp_emb);
 }
 
 }  // extern "C"

@@ -68,6 +68,15 @@ int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order
                            const int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[K]*/,
                            float* oct_near_far /*[K,2]*/);
 
+/* Single-pass variant of count + scan + fill for callers that do not need a compact list: ray r owns the fixed
+ * slot range [r*max_hits, r*max_hits + hits_r) of oct_idx / oct_near_far (both sized n_rays*max_hits);
+ * oct_start_end[r] = that range, total[0] += sum of hits (must be zeroed by the caller).  Per-ray contents are
+ * identical to the count/fill pair; the march kernels accept either segment layout. */
+int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                              const float* rays_d, float near_, float far_, const void* tree_nodes,
+                              int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[R*max_hits]*/,
+                              float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/);
+
 /* RayMarchKernel<false> (PersSampler.cu:189-314, launched :383-393).  noise has
  * F2N_MAX_SAMPLE_PER_RAY + n_rays + 10 floats, already multiplied by ray_march_fineness (:372-381), and is
  * indexed [ray + k] exactly as in the reference (:203,:266). */
@@ -92,7 +101,7 @@ int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void*
 
 /* MarkVistNodeKernel (PersSampler.cu:475-526).  oct node index of sample i = anchors[i*anchor_stride + 1].
  * w_adder/a_adder must be pre-filled with -1, mark with 0 (:555-557); visit_cnt is persistent state. */
-int f2n_oct_mark_visit(void* stream, int n_rays, const int32_t* pts_start_end, const int32_t* anchors,
+int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts_start_end, const int32_t* anchors,
                        int anchor_stride, const float* weights, const float* alphas, int32_t* w_adder,
                        int32_t* a_adder, int32_t* mark, int32_t* visit_cnt);
 
@@ -193,7 +202,7 @@ int f2n_shade_fwd(void* stream, int n, const float* feat /*[n,16]*/, const float
  * The network output needed for the sigmoid derivative is recomputed from saved_x_h on the matrix cores. */
 int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
                   const void* saved_x_h, float loss_scale, float* dfeat /*[n,16]*/, float* dparams_f32_scaled,
-                  float* dapp_emb);
+                  float* dapp_emb /*[n_emb,16] or NULL*/, int n_emb);
 
 /* ---------------------------------------------------------------------------------------------------
  * Renderer -- replaces the per-ray glue of Renderer::Render (Renderer/Renderer.cpp:105-208), i.e.

@@ -115,6 +115,24 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
     ref = oc.ray_march(o, d, noise, 1. / 256., scale_by_dis, *ref_hits, st["tree_nodes"], st["pers_trans"])
     for k in ref:
         assert_same(m[k], ref[k], k)
+    # single-pass strided variant: same per-ray leaf lists in fixed slots, and the march accepts that layout
+    so, tn, tr = T(st["search_order"]), T(st["tree_nodes"]), T(st["pers_trans"])
+    se2 = torch.zeros((n, 2), dtype=torch.int32, device=DEV)
+    oi2 = torch.zeros(n * max_hits, dtype=torch.int32, device=DEV)
+    nf2 = torch.zeros((n * max_hits, 2), device=DEV)
+    tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.oct_intersect_strided(n, max_hits, so, T(o), T(d), 0.01, 1e8, tn, se2, oi2, nf2, tot)
+    se2n, oi2n, nf2n = N(se2), N(oi2), N(nf2)
+    rse = ref_hits[0]
+    assert int(tot.item()) == len(ref_hits[1])
+    assert (se2n[:, 0] == np.arange(n) * max_hits).all() and ((se2n[:, 1] - se2n[:, 0]) == (rse[:, 1] - rse[:, 0])).all()
+    for r in range(0, n, 37):
+        c = rse[r, 1] - rse[r, 0]
+        assert_same(oi2n[r * max_hits:r * max_hits + c], ref_hits[1][rse[r, 0]:rse[r, 1]], "strided idx")
+        assert_same(nf2n[r * max_hits:r * max_hits + c], ref_hits[2][rse[r, 0]:rse[r, 1]], "strided near/far")
+    pcnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+    hip.ray_march_count(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, pcnt)
+    assert_same(N(pcnt), (ref["pts_idx_bounds"][:, 1] - ref["pts_idx_bounds"][:, 0]).astype(np.int32), "march count on strided hits")
 
 
 def test_sampler_full_size_properties(hip, fox_state):
