@@ -72,21 +72,10 @@ def main():
     active_halves = 17 << log2  # halves any level can address (level-overlap quirk)
 
     if world > 1:
-        bufs = runner.grad_buffers()
-        table_flat = bufs[0].view(-1)[:active_halves]
-
-        def grad_sync():
-            dist.all_reduce(table_flat, op=dist.ReduceOp.AVG)       # 17*2^log2 fp16 halves, x128 loss-scaled
-            for b in bufs[1:]:
-                dist.all_reduce(b, op=dist.ReduceOp.AVG)            # field MLP, colour MLP, app_emb (fp32)
-
-        def occupancy_sync(adders, mark, cnt):
-            dist.all_reduce(adders, op=dist.ReduceOp.MAX)
-            dist.all_reduce(mark, op=dist.ReduceOp.MAX)
-            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-
-        runner.set_grad_sync_hook(grad_sync)
-        runner.set_occupancy_sync_hook(occupancy_sync)
+        from f2_nerf_amd import parallel
+        # per step: all-reduce(AVG) of the 17*2^log2-half active prefix of the fp16 hash-gradient table + MLP/app_emb
+        # gradients, and all-reduce(MAX) of the octree occupancy votes (f2-nerf_amd/parallel.py)
+        parallel.attach(runner, log2)
 
     # synthetic random-pose batches, resident in HBM before the timed region (per-rank RNG stream)
     rng = np.random.default_rng(1000 + rank)

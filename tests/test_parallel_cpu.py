@@ -1,0 +1,88 @@
+"""CPU, world_size 2, gloo: the data-parallel collectives of f2-nerf_amd/parallel.py.
+  * gradient sync: every rank ends with the mean of the per-rank gradients, only on the active table prefix;
+  * occupancy sync: two ranks that each saw HALF of a ray batch end, after all-reduce(MAX) of their votes, with exactly
+    the node statistics and pruning decisions of one process that saw the WHOLE batch (oracle restatement of
+    PersSampler.cu:475-603), i.e. replicas stay identical and equal to the single-GPU semantics."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import parallel
+    from oracle import capi as oc
+    # ---- gradient sync ----
+    log2 = 6
+    rng = np.random.default_rng(100 + rank)
+    table = torch.from_numpy(rng.standard_normal((16 << log2, 2)).astype(np.float16))
+    mlp1 = torch.from_numpy(rng.standard_normal(3072).astype(np.float32))
+    mlp2 = torch.from_numpy(rng.standard_normal(7168).astype(np.float32))
+    emb = torch.from_numpy(rng.standard_normal((50, 16)).astype(np.float32))
+    before = table.clone()
+    parallel.make_grad_sync([table, mlp1, mlp2, emb], log2)()
+    np.save(os.path.join(out_dir, "g_table_%d.npy" % rank), table.numpy())
+    np.save(os.path.join(out_dir, "g_table_before_%d.npy" % rank), before.numpy())
+    np.save(os.path.join(out_dir, "g_mlp2_%d.npy" % rank), mlp2.numpy())
+    # ---- occupancy sync ----
+    st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_golden.npz")))
+    se = g["march_pts_idx_bounds"]
+    R = len(se)
+    half = slice(0, R // 2) if rank == 0 else slice(R // 2, R)
+    n_nodes = st["tree_nodes"].size // 64
+    w = (g["seg_val"] * np.float32(0.01)).astype(np.float32)
+    oi = np.ascontiguousarray(g["march_anchors"][:, 1])
+    wa, aa, mk, cnt = oc.mark_visit(n_nodes, se[half], oi, w, g["occ_alpha"], np.zeros(n_nodes, np.int32))
+    adders = torch.from_numpy(np.stack([wa, aa]))
+    mark, vcnt = torch.from_numpy(mk), torch.from_numpy(cnt)
+    parallel.occupancy_sync(adders, mark, vcnt)
+    ws = np.full(n_nodes, 3, np.int32)
+    w2, a2, nodes2 = oc.update_node_stats(adders[0].numpy(), adders[1].numpy(), mark.numpy(), ws, ws, st["tree_nodes"])
+    np.save(os.path.join(out_dir, "occ_%d.npy" % rank), np.concatenate([w2, a2, vcnt.numpy(), nodes2.view(np.int32)]))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_collectives_gloo(tmp_path, fox_state, fox_golden):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    t = [np.load(tmp_path / ("g_table_%d.npy" % r)).astype(np.float32) for r in range(world)]
+    b = [np.load(tmp_path / ("g_table_before_%d.npy" % r)).astype(np.float32) for r in range(world)]
+    active = 17 << 6
+    mean = ((b[0] + b[1]) / 2).astype(np.float16).astype(np.float32).reshape(-1)
+    for r in range(world):
+        flat = t[r].reshape(-1)
+        np.testing.assert_array_equal(flat[:active], mean[:active])            # averaged on the active prefix
+        np.testing.assert_array_equal(flat[active:], b[r].reshape(-1)[active:])  # untouched beyond it
+    m = [np.load(tmp_path / ("g_mlp2_%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(m[0], m[1])
+    # occupancy: both ranks identical, and identical to the single-process result on the full batch
+    o = [np.load(tmp_path / ("occ_%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(o[0], o[1])
+    from oracle import capi as oc
+    st, g = fox_state, fox_golden
+    n_nodes = st["tree_nodes"].size // 64
+    w = (g["seg_val"] * np.float32(0.01)).astype(np.float32)
+    wa, aa, mk, cnt = oc.mark_visit(n_nodes, g["march_pts_idx_bounds"], np.ascontiguousarray(g["march_anchors"][:, 1]), w,
+                                    g["occ_alpha"], np.zeros(n_nodes, np.int32))
+    ws = np.full(n_nodes, 3, np.int32)
+    w2, a2, nodes2 = oc.update_node_stats(wa, aa, mk, ws, ws, st["tree_nodes"])
+    np.testing.assert_array_equal(o[0], np.concatenate([w2, a2, cnt, nodes2.view(np.int32)]))
