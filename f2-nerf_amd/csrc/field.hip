@@ -64,6 +64,59 @@ __device__ __forceinline__ void f2n_hash_cell(const float* p01, float mul, const
   cell.w[7] = a * b * c;
 }
 
+// XCD-aware level-partitioned gather.  The 8 XCDs of an MI355X have private 4 MiB L2s; a wave that gathers all 16
+// levels touches the whole 17 MiB of addressed table and runs at the chip's random-access rate out of the Infinity
+// Cache (~90 G 4-byte gathers/s measured, tools/xcd_probe.py).  Here block b serves level pair (2p, 2p+1), p = b % 8
+// -- the XCD the dispatcher is observed to place it on -- so each L2 only ever sees a 3 MiB slice (260 G gathers/s
+// measured).  Placement is a speed assumption only: any mapping gives the same result.  Features leave through
+// f16 "planes" [8][n][4] (8 B per sample and level pair, coalesced), from which the MLP kernel's lane (c,g) reads
+// exactly its K-slots: plane g (features 4g..4g+3) and plane 4+g (features 16+4g..).
+#define F2N_N_PARTS 8
+__global__ __launch_bounds__(256) void hash_gather_planes_kernel(
+    int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
+    const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
+    const int32_t* __restrict__ volume_idx, int vol_stride, half_t* __restrict__ planes) {
+  __shared__ F2nLevelTab lt;
+  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, threadIdx.x);
+  __syncthreads();
+  const int part = blockIdx.x % F2N_N_PARTS;
+  const int q = blockIdx.x / F2N_N_PARTS, nq = gridDim.x / F2N_N_PARTS;
+  for (int s = q * 256 + (int) threadIdx.x; s < n; s += nq * 256) {
+    float p01[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float p = pts[3 * (size_t) s + k];
+      p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
+    }
+    const int vol = volume_idx[(size_t) s * vol_stride];
+    F2nCell cell[2];
+    half2_t v[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int l = 2 * part + j;
+      const int tf = l * h.n_volumes + vol;
+      f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell[j]);
+      const half2_t* base = (const half2_t*) (h.table + lt.base[l]);
+#pragma unroll
+      for (int d = 0; d < 8; d++) v[j][d] = base[cell[j].pos[d]];
+    }
+    half4_t out;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {  // same fp32 summation order as f2n_gather_frag / the oracle
+      float s0 = cell[j].w[0] * (float) v[j][0][0];
+      float s1 = cell[j].w[0] * (float) v[j][0][1];
+#pragma unroll
+      for (int d = 1; d < 8; d++) {
+        s0 = s0 + cell[j].w[d] * (float) v[j][d][0];
+        s1 = s1 + cell[j].w[d] * (float) v[j][d][1];
+      }
+      out[2 * j] = (half_t) s0;
+      out[2 * j + 1] = (half_t) s1;
+    }
+    *(half4_t*) (planes + ((size_t) part * n + s) * 4) = out;
+  }
+}
+
 // Gathers this lane's four levels of one sample: returns the X row fragment (8 halves).
 __device__ __forceinline__ half8_t f2n_gather_frag(const F2nHashArgs& h, const F2nLevelTab& lt, const float* p01, int vol,
                                                    int g, bool valid) {
@@ -159,7 +212,7 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
     const int32_t* __restrict__ volume_idx, int vol_stride, const float* __restrict__ x_f32,
     const half_t* __restrict__ params, float* __restrict__ out_feat_f32, half_t* __restrict__ out_feat_h,
-    float* __restrict__ out_f0, half_t* __restrict__ save_x) {
+    float* __restrict__ out_f0, half_t* __restrict__ save_x, const half_t* __restrict__ x_planes) {
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   if (DO_HASH) {
@@ -181,6 +234,10 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
       f2n_load_point(pts, sc, pts_are_warped != 0, p01);
       const int vol = volume_idx[(size_t) sc * vol_stride];
       xf = f2n_gather_frag(h, lt, p01, vol, g, valid);
+    } else if (x_planes != nullptr) {  // features gathered by hash_gather_planes_kernel
+      xf = f2n_cat(*(const half4_t*) (x_planes + ((size_t) g * n + sc) * 4),
+                   *(const half4_t*) (x_planes + ((size_t) (4 + g) * n + sc) * 4));
+      if (!valid) xf = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
     } else {
       xf = f2n_load_xfrag_f32(x_f32, sc, g, valid);
     }
@@ -379,7 +436,7 @@ int f2n_hash_fwd(void* stream, int n, int n_volumes, const void* table_h, const 
   F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
   hipLaunchKernelGGL((field_fwd_kernel<1, true, false>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                      (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx,
-                     vol_stride, nullptr, nullptr, nullptr, nullptr, nullptr, (half_t*) out_h);
+                     vol_stride, nullptr, nullptr, nullptr, nullptr, nullptr, (half_t*) out_h, nullptr);
   return f2n_launch_status();
 }
 
@@ -403,10 +460,10 @@ int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const
   const dim3 grid(f2n_wave_grid((n + 15) / 16, 4)), block(F2N_FWD_THREADS);
   if (n_hidden == 1)
     hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
-                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr);
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr);
   else
     hipLaunchKernelGGL((field_fwd_kernel<2, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
-                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr);
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -438,9 +495,25 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
   if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
-  hipLaunchKernelGGL((field_fwd_kernel<1, true, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
-                     (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                     nullptr, (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h);
+  if (n < F2N_PARTITION_MIN_N) {  // small batches: one launch, features stay in registers between gather and MFMA
+    hipLaunchKernelGGL((field_fwd_kernel<1, true, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
+                       (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
+                       nullptr, (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr);
+    return f2n_launch_status();
+  }
+  // large batches: XCD-aware level-partitioned gather into f16 planes (64 B/sample of internal workspace), then the
+  // same MLP kernel reads its MFMA K-slots from the planes.  ~130 B/sample of extra streaming buys ~3x on the gathers.
+  half_t* planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, sizeof(half_t) * 32 * (size_t) n);
+  if (planes == nullptr) return F2N_ERR_INVALID_ARG;
+  long per_part = ((long) n + 255) / 256;
+  if (per_part > 256) per_part = 256;  // 32 CUs per XCD x 8 resident 256-thread blocks
+  hipLaunchKernelGGL(hash_gather_planes_kernel, dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), 0, (hipStream_t) stream, n, h,
+                     local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, planes);
+  int rc = f2n_launch_status();
+  if (rc != F2N_OK) return rc;
+  hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
+                     (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr,
+                     (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, planes);
   return f2n_launch_status();
 }
 

@@ -402,13 +402,15 @@ def test_mlp_backward(hip, n_hidden, n):
 # ---------------------------------------------------------------------------------------------------
 # fused field / shader
 # ---------------------------------------------------------------------------------------------------
-def test_field_fused_forward_backward(hip, fox_state, fox_golden):
+@pytest.mark.parametrize("n_use", [None, 1500])  # >= 4096 samples: XCD-partitioned gather + MLP; below: single fused launch
+def test_field_fused_forward_backward(hip, fox_state, fox_golden, n_use):
     st, g = fox_state, fox_golden
     rng = np.random.default_rng(21)
     grid = make_grid(st, rng, 14, scale=0.5)
     params = rand_params(rng, 1)
-    pts, anchors = g["march_pts"], g["march_anchors"]
+    pts, anchors = g["march_pts"][:n_use], g["march_anchors"][:n_use]
     n = len(pts)
+    assert (n >= 4096) == (n_use is None)
     gd = grid_dev(grid)
     ph = T(oc.f2h(params).view(np.float16))
     feat = torch.zeros((n, 16), device=DEV)
