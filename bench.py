@@ -34,8 +34,9 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per sample of the three field kernels (DESIGN.md section 4 / SURVEY.md section 8(d)):
 # 16 levels x 8 corners x 4 B of table traffic + the per-sample streams each kernel must touch
 ALGO_BYTES = {
-    "field_prepass": 512 + 12 + 4 + 4,        # gather + pts + trans idx + f0 out
-    "field_fwd": 512 + 12 + 4 + 64 + 64,      # gather + pts + idx + feat out (fp32x16) + saved features (f16x32)
+    "field_prepass": 512 + 12 + 4 + 4 + 64,   # gather + pts + trans idx + f0 out + feature cache (f16x32)
+    "field_fwd_cached": 64 + 4 + 64 + 64,     # cached feature row + row index + feat out (fp32x16) + saved features
+    "field_fwd": 512 + 12 + 4 + 64 + 64,      # (edge samples only) gather + pts + idx + feat out + saved features
     "field_bwd": 512 + 12 + 4 + 64 + 64,      # atomic payload + pts + idx + dfeat in + saved features
 }
 HBM_PEAK_GBS = 8000.0
@@ -69,7 +70,6 @@ def main():
     st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
     runner, cfg, _ = runtime.make_runner(st, args.preset, seed=2022, device=dev)   # identical replica on every rank
     log2 = int(cfg["field"]["log2_table_size"])
-    active_halves = 17 << log2  # halves any level can address (level-overlap quirk)
 
     if world > 1:
         from f2_nerf_amd import parallel
@@ -122,7 +122,8 @@ def main():
         rho = n_marched / max(n_meaningful, 1.0)
         # --- roofline of the dominant kernel (longest total time among the field kernels) ---
         per_step_local = {"field_prepass": n_marched / world / args.steps,
-                          "field_fwd": n_meaningful / world / args.steps + 2 * runner.n_edge_pts,
+                          "field_fwd_cached": n_meaningful / world / args.steps,
+                          "field_fwd": 2 * runner.n_edge_pts,
                           "field_bwd": n_meaningful / world / args.steps + 2 * runner.n_edge_pts}
         roofline = None
         if timing:

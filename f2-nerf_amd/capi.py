@@ -175,6 +175,12 @@ def field_fwd(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool
                             _p(out_f0, "f32", True), _p(save_x_h, "h16", True)), "f2n_field_fwd")
 
 
+def field_fwd_cached(n, n_cache, src_rows, x_cache_h, mlp_params_h, out_feat, out_f0, save_x_h):
+    _ck(lib().f2n_field_fwd_cached(_stream(), _i(n), _i(n_cache), _p(src_rows, "i32", True), _p(x_cache_h, "h16"),
+                                   _p(mlp_params_h, "h16"), _p(out_feat, "f32", True), _p(out_f0, "f32", True),
+                                   _p(save_x_h, "h16", True)), "f2n_field_fwd_cached")
+
+
 def field_bwd(n, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped, volume_idx, vol_stride,
               mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_scaled, grad_table_h):
     _ck(lib().f2n_field_bwd(_stream(), _i(n), _i(n_volumes), _p(prim_pool, "i32"), _p(local_idx, "i32"),
@@ -217,6 +223,13 @@ def compact_samples(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_p
                                   _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"), _p(anchors, "i32"),
                                   _p(o_pts, "f32"), _p(o_dirs, "f32"), _p(o_dt, "f32"), _p(o_t, "f32"),
                                   _p(o_anchors, "i32")), "f2n_compact_samples")
+
+
+def compact_samples_src(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src):
+    _ck(lib().f2n_compact_samples_src(_stream(), _i(n_rays), _p(old_se, "i32"), _p(new_se, "i32"), _p(mask, "i32"),
+                                      _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"), _p(anchors, "i32"),
+                                      _p(o_pts, "f32"), _p(o_dirs, "f32"), _p(o_dt, "f32"), _p(o_t, "f32"),
+                                      _p(o_anchors, "i32"), _p(o_src, "i32")), "f2n_compact_samples_src")
 
 
 def composite_fwd(n_rays, pts_se, feat, dt, t, rgb, bg, colors, disparity, depth, weights):

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
     const int32_t* __restrict__ volume_idx, int vol_stride, const float* __restrict__ x_f32,
     const half_t* __restrict__ params, float* __restrict__ out_feat_f32, half_t* __restrict__ out_feat_h,
-    float* __restrict__ out_f0, half_t* __restrict__ save_x, const half_t* __restrict__ x_planes) {
+    float* __restrict__ out_f0, half_t* __restrict__ save_x, const half_t* __restrict__ x_planes,
+    const half_t* __restrict__ x_cache, const int32_t* __restrict__ src_rows) {
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   if (DO_HASH) {
@@ -238,6 +239,8 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
       xf = f2n_cat(*(const half4_t*) (x_planes + ((size_t) g * n + sc) * 4),
                    *(const half4_t*) (x_planes + ((size_t) (4 + g) * n + sc) * 4));
       if (!valid) xf = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    } else if (x_cache != nullptr) {  // h16 feature rows of an earlier query of the same table (f2n_field_fwd_cached)
+      xf = f2n_load_xfrag_h(x_cache, src_rows != nullptr ? src_rows[sc] : sc, g, valid);
     } else {
       xf = f2n_load_xfrag_f32(x_f32, sc, g, valid);
     }
@@ -436,7 +439,7 @@ int f2n_hash_fwd(void* stream, int n, int n_volumes, const void* table_h, const 
   F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
   hipLaunchKernelGGL((field_fwd_kernel<1, true, false>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                      (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx,
-                     vol_stride, nullptr, nullptr, nullptr, nullptr, nullptr, (half_t*) out_h, nullptr);
+                     vol_stride, nullptr, nullptr, nullptr, nullptr, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -460,10 +463,10 @@ int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const
   const dim3 grid(f2n_wave_grid((n + 15) / 16, 4)), block(F2N_FWD_THREADS);
   if (n_hidden == 1)
     hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
-                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr);
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr, nullptr, nullptr);
   else
     hipLaunchKernelGGL((field_fwd_kernel<2, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
-                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr);
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -498,7 +501,7 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
   if (n < F2N_PARTITION_MIN_N) {  // small batches: one launch, features stay in registers between gather and MFMA
     hipLaunchKernelGGL((field_fwd_kernel<1, true, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                        (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                       nullptr, (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr);
+                       nullptr, (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr, nullptr, nullptr);
     return f2n_launch_status();
   }
   // large batches: XCD-aware level-partitioned gather into f16 planes (64 B/sample of internal workspace), then the
@@ -513,7 +516,19 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
   if (rc != F2N_OK) return rc;
   hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                      (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr,
-                     (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, planes);
+                     (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, planes, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_field_fwd_cached(void* stream, int n, int n_cache, const int32_t* src_rows, const void* x_cache_h,
+                         const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h) {
+  if (n < 0 || n_cache < 0 || (n > 0 && x_cache_h == nullptr) || (src_rows == nullptr && n > n_cache)) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
+  hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
+                     (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr,
+                     (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr,
+                     (const half_t*) x_cache_h, src_rows);
   return f2n_launch_status();
 }
 

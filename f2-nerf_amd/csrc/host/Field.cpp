@@ -143,17 +143,26 @@ AnchorView ViewAnchors(const Tensor& anchors) {
 }
 
 struct FieldFunction : public torch::autograd::Function<FieldFunction> {
+  // Samples [0, n_reuse) take their hash features from the pre-pass cache (row src_rows[i]); the rest are gathered.
   static variable_list forward(AutogradContext* ctx, Tensor feat_pool, Tensor mlp_params, Tensor points, Tensor anchors,
-                               int64_t field_ptr) {
+                               Tensor src_rows, int64_t n_reuse, int64_t field_ptr) {
     auto* f = reinterpret_cast<Hash3DAnchored*>(field_ptr);
     const int n = points.size(0);
     AnchorView av = ViewAnchors(anchors);
     Tensor feat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
     Tensor saved_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
-    F2N_TIMED_CALL("field_fwd", f2n_field_fwd(CurStream(), n, f->n_volumes_, VoidP(f->feat_pool_h_), I32P(f->prim_pool_),
-                           I32P(f->feat_local_idx_), I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_),
-                           F32P(points), I32P(av.t), av.stride, VoidP(f->mlp_->params_h_), F32P(feat), nullptr,
-                           VoidP(saved_x)));
+    const int n_cached = (int) n_reuse, n_tail = n - n_cached;
+    if (n_cached > 0) {
+      TORCH_CHECK(f->prepass_x_.defined() && src_rows.numel() == n_cached, "no pre-pass feature cache for this query");
+      F2N_TIMED_CALL("field_fwd_cached", f2n_field_fwd_cached(CurStream(), n_cached, (int) f->prepass_x_.size(0), I32P(src_rows),
+                             VoidP(f->prepass_x_), VoidP(f->mlp_->params_h_), F32P(feat), nullptr, VoidP(saved_x)));
+    }
+    if (n_tail > 0)
+      F2N_TIMED_CALL("field_fwd", f2n_field_fwd(CurStream(), n_tail, f->n_volumes_, VoidP(f->feat_pool_h_), I32P(f->prim_pool_),
+                             I32P(f->feat_local_idx_), I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_),
+                             F32P(points) + 3 * (int64_t) n_cached, I32P(av.t) + (int64_t) av.stride * n_cached, av.stride,
+                             VoidP(f->mlp_->params_h_), F32P(feat) + (int64_t) F2N_MLP_OUT_PAD * n_cached, nullptr,
+                             static_cast<void*>(saved_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * n_cached)));
     ctx->saved_data["field"] = field_ptr;
     ctx->save_for_backward({points, av.t, saved_x});
     ctx->saved_data["stride"] = (int64_t) av.stride;
@@ -169,7 +178,7 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
                            I32P(saved[1]), (int) ctx->saved_data["stride"].toInt(), VoidP(f->mlp_->params_h_),
                            VoidP(saved[2]), F32P(dfeat), f->mlp_->loss_scale_, F32P(f->mlp_->grad_scaled_), VoidP(f->grad_h_)));
     // gradients live in f->grad_h_ (fp16, x128) and f->mlp_->grad_scaled_: consumed by the fused optimiser step
-    return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -178,20 +187,34 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
 Tensor Hash3DAnchored::AnchoredQuery(const Tensor& points, const Tensor& anchors) {  // Hash3DAnchored.cpp:84-99
   Tensor pts = points.contiguous();
   CheckDev(pts, torch::kFloat32, "points");
-  Tensor feat = FieldFunction::apply(feat_pool_, mlp_->params_, pts, anchors, reinterpret_cast<int64_t>(this))[0];
+  Tensor feat = FieldFunction::apply(feat_pool_, mlp_->params_, pts, anchors, torch::empty({0}, DevI32()), (int64_t) 0,
+                                     reinterpret_cast<int64_t>(this))[0];
   return mlp_out_dim_ == F2N_MLP_OUT_PAD ? feat : feat.index({Slc(), Slc(0, mlp_out_dim_)}).contiguous();
 }
 
-Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& anchors) {
+Tensor Hash3DAnchored::AnchoredQueryReuse(const Tensor& points, const Tensor& anchors, const Tensor& src_rows, int n_reuse) {
+  Tensor pts = points.contiguous();
+  CheckDev(pts, torch::kFloat32, "points");
+  Tensor rows = src_rows.contiguous();
+  CheckDev(rows, torch::kInt32, "src_rows");
+  TORCH_CHECK(n_reuse >= 0 && n_reuse <= pts.size(0) && rows.numel() >= n_reuse, "bad reuse range");
+  Tensor feat = FieldFunction::apply(feat_pool_, mlp_->params_, pts, anchors, rows.slice(0, 0, n_reuse), (int64_t) n_reuse,
+                                     reinterpret_cast<int64_t>(this))[0];
+  prepass_x_ = Tensor();  // one consumer per pre-pass; the table may change after this step
+  return mlp_out_dim_ == F2N_MLP_OUT_PAD ? feat : feat.index({Slc(), Slc(0, mlp_out_dim_)}).contiguous();
+}
+
+Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& anchors, bool keep_features) {
   torch::NoGradGuard g;
   Tensor pts = points.contiguous();
   CheckDev(pts, torch::kFloat32, "points");
   AnchorView av = ViewAnchors(anchors);
   const int n = pts.size(0);
   Tensor f0 = torch::empty({n}, DevF32());
+  prepass_x_ = keep_features ? torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16()) : Tensor();
   F2N_TIMED_CALL("field_prepass", f2n_field_fwd(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_), I32P(feat_local_idx_),
                          I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), I32P(av.t), av.stride,
-                         VoidP(mlp_->params_h_), nullptr, F32P(f0), nullptr));
+                         VoidP(mlp_->params_h_), nullptr, F32P(f0), keep_features ? VoidP(prepass_x_) : nullptr));
   return f0;
 }
 

@@ -15,7 +15,11 @@ class Hash3DAnchored : public Field {
   // points: warped coords [n,3]; anchors: [n] (trans idx) or the sampler's [n,3] anchors read in place
   Tensor AnchoredQuery(const Tensor& points, const Tensor& anchors) override;
   // no-grad density pre-activation only (channel 0) for Renderer's early-stop pre-pass
-  Tensor QueryDensityPreAct(const Tensor& points, const Tensor& anchors);
+  // keep_features: also keep the gathered h16 hash features [n,32] of every point for AnchoredQueryReuse
+  Tensor QueryDensityPreAct(const Tensor& points, const Tensor& anchors, bool keep_features = false);
+  // AnchoredQuery whose first n_reuse points are points src_rows[i] of the preceding QueryDensityPreAct (same table,
+  // same coordinates): their 128 gathers are not repeated.  Bit-identical to AnchoredQuery(points, anchors).
+  Tensor AnchoredQueryReuse(const Tensor& points, const Tensor& anchors, const Tensor& src_rows, int n_reuse);
 
   int LoadStates(const std::vector<Tensor>& states, int idx) override;
   std::vector<Tensor> States() override;
@@ -33,6 +37,7 @@ class Hash3DAnchored : public Field {
   Tensor prim_pool_;       // [16, V, 3] int32
   Tensor bias_pool_;       // [16*V, 3]
   Tensor feat_local_idx_, feat_local_size_, level_scale_;
+  Tensor prepass_x_;       // h16 [n,32] features of the last QueryDensityPreAct(keep_features = true), or undefined
   std::unique_ptr<FusedMLP> mlp_;
   int n_volumes_;
   int64_t active_halves_;  // halves [0, active) are the only ones any level can address (level-overlap quirk)

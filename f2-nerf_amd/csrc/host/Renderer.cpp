@@ -216,12 +216,13 @@ RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const 
 
   // ---- no-grad pre-pass: density of every sample, early stop (Renderer.cpp:105-137) ----
   SampleResultFlex es;
-  Tensor pts_all, vol_all;
+  Tensor pts_all, vol_all, src_rows;
   int n_kept = 0;
   const int n_edge = train ? n_edge_pts_ : 0;
   {
     torch::NoGradGuard no_grad;
-    Tensor f0 = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors);
+    // the pre-pass keeps the hash features it gathers: the grad pass below reuses them for the surviving samples
+    Tensor f0 = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors, /*keep_features=*/true);
     Tensor weights = torch::empty({n_all_pts}, DevF32()), alphas = torch::empty({n_all_pts}, DevF32());
     Tensor mask = torch::empty({n_all_pts}, DevI32()), kept = torch::empty({n_rays}, DevI32());
     F2N_TIMED_CALL("early_stop", f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), F32P(f0), 1, F32P(sample_result_.dt),
@@ -239,10 +240,11 @@ RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const 
     es.anchors = torch::empty({n_kept, 3}, DevI32());
     es.first_oct_dis = sample_result_.first_oct_dis.clone();
     es.pts_idx_bounds = new_se;
-    F2N_TIMED_CALL("compact_samples", f2n_compact_samples(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
+    src_rows = torch::empty({std::max(n_kept, 1)}, DevI32());
+    F2N_TIMED_CALL("compact_samples", f2n_compact_samples_src(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
                                  F32P(sample_result_.pts), F32P(sample_result_.dirs), F32P(sample_result_.dt),
                                  F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all), F32P(es.dirs),
-                                 F32P(es.dt), F32P(es.t), I32P(es.anchors)));
+                                 F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows)));
     if (n_kept > 0) vol_all.slice(0, 0, n_kept).copy_(es.anchors.select(1, 0));
     if (train) {  // Renderer.cpp:140-149
       pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);
@@ -261,7 +263,7 @@ RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const 
   }
 
   // ---- grad pass (Renderer.cpp:152-208) ----
-  Tensor all_feat = scene_field_->AnchoredQuery(pts_all, vol_all);  // [M + 2E, 16]
+  Tensor all_feat = field->AnchoredQueryReuse(pts_all, vol_all, src_rows, n_kept);  // [M + 2E, 16]
   Tensor scene_feat = all_feat.slice(0, 0, n_kept);
   Tensor edge_feat;
   if (train) edge_feat = all_feat.slice(0, n_kept, n_kept + 2 * n_edge).reshape({n_edge, 2, -1});

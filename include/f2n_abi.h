@@ -172,6 +172,16 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
                   const float* level_scale, const float* pts_warped, const int32_t* volume_idx, int vol_stride,
                   const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h);
 
+/* AnchoredQuery for samples whose hash features are already known: Renderer::Render queries the field twice per
+ * step with an unchanged table -- the no-grad density pre-pass over every marched sample (Renderer.cpp:115-123)
+ * and the grad pass over the survivors (:152-166) -- so the 128 gathers per surviving sample of the second query
+ * are a pure recomputation.  x_cache_h [n_cache,32] is the save_x_h of the pre-pass; sample i of this call takes
+ * row src_rows[i] (NULL = row i).  Outputs as f2n_field_fwd: bit-identical to it by construction (same h16
+ * features through the same MLP kernel).  save_x_h [n,32] (may be NULL) receives the gathered rows in call order,
+ * ready for f2n_field_bwd. */
+int f2n_field_fwd_cached(void* stream, int n, int n_cache, const int32_t* src_rows, const void* x_cache_h,
+                         const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h);
+
 /* Backward of the fused field: MLP backward (dparams accumulated, scaled domain) chained straight into
  * the hash scatter; dL/dx never touches HBM.  dfeat fp32 [n,16]. */
 int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
@@ -224,6 +234,12 @@ int f2n_compact_samples(void* stream, int n_rays, const int32_t* old_start_end, 
                         const int32_t* mask, const float* pts, const float* dirs, const float* dt, const float* t,
                         const int32_t* anchors, float* o_pts, float* o_dirs, float* o_dt, float* o_t,
                         int32_t* o_anchors);
+/* Same, and o_src[k] = index of surviving sample k in the uncompacted arrays (the row of the pre-pass feature
+ * cache that f2n_field_fwd_cached reuses for it). */
+int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_end, const int32_t* new_start_end,
+                            const int32_t* mask, const float* pts, const float* dirs, const float* dt, const float* t,
+                            const int32_t* anchors, float* o_pts, float* o_dirs, float* o_dt, float* o_t,
+                            int32_t* o_anchors, int32_t* o_src /*[M]*/);
 
 /* Compositing (Renderer.cpp:196-208): colors = sum w*c + T_last*bg, disparity = sum w/(t+.01),
  * depth = sum w*(t+.01) / (1 - T_last + 1e-4); weights [M] is also returned (RenderResult, Renderer.h:18-27).

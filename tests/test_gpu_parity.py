@@ -438,6 +438,38 @@ def test_field_fused_forward_backward(hip, fox_state, fox_golden, n_use):
     assert cos > 0.9999, cos
 
 
+def test_field_forward_from_prepass_cache(hip, fox_state, fox_golden):
+    """f2n_field_fwd_cached (hash features memoised by the pre-pass) must equal a fresh f2n_field_fwd bit for bit,
+    for an arbitrary (compaction-like, order-preserving) subset and for the identity mapping."""
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(23)
+    grid = make_grid(st, rng, 14, scale=0.5)
+    params = rand_params(rng, 1)
+    pts, anchors = g["march_pts"], g["march_anchors"]
+    n = len(pts)
+    gd = grid_dev(grid)
+    ph = T(oc.f2h(params).view(np.float16))
+    f0_pre = torch.zeros(n, device=DEV)
+    cache = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    hip.field_fwd(n, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts),
+                  T(anchors), 3, ph, None, f0_pre, cache)
+    rows = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.int32)
+    for src in (rows, None):
+        idx = rows if src is not None else np.arange(n, dtype=np.int32)
+        m = len(idx)
+        want_feat = torch.zeros((m, 16), device=DEV); want_sx = torch.zeros((m, 32), dtype=torch.float16, device=DEV)
+        hip.field_fwd(m, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"],
+                      T(pts[idx]), T(anchors[idx]), 3, ph, want_feat, None, want_sx)
+        got_feat = torch.zeros((m, 16), device=DEV); got_f0 = torch.zeros(m, device=DEV)
+        got_sx = torch.zeros((m, 32), dtype=torch.float16, device=DEV)
+        hip.field_fwd_cached(m, n, None if src is None else T(src), cache, ph, got_feat, got_f0, got_sx)
+        assert_same(N(got_feat), N(want_feat), "cached forward == fresh forward")
+        assert_same(N(got_sx).view(np.uint16), N(want_sx).view(np.uint16), "cached saved features")
+        assert_same(N(got_f0), N(f0_pre)[idx], "f0 of the pre-pass")
+    with pytest.raises(hip.F2nError):  # identity mapping over more samples than the cache holds
+        hip.field_fwd_cached(n + 1, n, None, cache, ph, torch.zeros((n + 1, 16), device=DEV), None, None)
+
+
 @pytest.mark.parametrize("use_emb", [False, True])
 def test_shade_fused_forward_backward(hip, fox_golden, use_emb):
     g = fox_golden
@@ -554,6 +586,12 @@ def test_early_stop_and_compaction(hip):
     exp = op.compact(N(mask), pts, dirs, dt, t, anchors)
     for got, e in zip(o, exp):
         assert_same(N(got), e, "compaction")
+    o2 = [torch.zeros_like(x) for x in o]
+    src = torch.zeros(max(m, 1), dtype=torch.int32, device=DEV)
+    hip.compact_samples_src(R, T(se), new_se, mask, T(pts), T(dirs), T(dt), T(t), T(anchors), *o2, src)
+    for got, e in zip(o2, exp):
+        assert_same(N(got), e, "compaction (+src)")
+    assert_same(N(src)[:m], np.nonzero(N(mask))[0].astype(np.int32), "source rows")
 
 
 @pytest.mark.parametrize("gs", [1.0, 0.3])
