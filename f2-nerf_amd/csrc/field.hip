@@ -33,6 +33,7 @@ __device__ __forceinline__ int f2n_level_of(int g, int j) { return (j < 2) ? 2 *
 struct F2nCell {
   uint32_t pos[8];
   float w[8];
+  uint32_t p[3];  // integer cell coordinates: with the transform index, the identity of the cell
 };
 
 // Cell lookup of one (point, level): Hash3DAnchored.cu:27-69.  p01 is the query point in [0,1] coordinates.
@@ -46,6 +47,9 @@ __device__ __forceinline__ void f2n_hash_cell(const float* p01, float mul, const
   }
   const uint32_t px = f2n_f2u_sat(fl[0]), py = f2n_f2u_sat(fl[1]), pz = f2n_f2u_sat(fl[2]);
   const uint32_t pa = (uint32_t) prim3[0], pb = (uint32_t) prim3[1], pc = (uint32_t) prim3[2];
+  cell.p[0] = px;
+  cell.p[1] = py;
+  cell.p[2] = pz;
   const uint32_t hx[2] = {px * pa, (px + 1u) * pa}, hy[2] = {py * pb, (py + 1u) * pb}, hz[2] = {pz * pc, (pz + 1u) * pc};
   const bool pow2 = (lsize & (lsize - 1u)) == 0u;
 #pragma unroll
@@ -147,23 +151,76 @@ __device__ __forceinline__ half8_t f2n_gather_frag(const F2nHashArgs& h, const F
   return xf;
 }
 
+// DPP row shifts inside the 16-lane row that holds the 16 samples of one level group.
+template <int K>
+__device__ __forceinline__ float f2n_row_shr(float v) {  // lane c reads lane c-K of its row; lanes c < K read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + K, 0xF, 0xF, false));
+}
+template <int K>
+__device__ __forceinline__ int f2n_row_shr_i(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x110 + K, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int f2n_row_shl1_i(int v, int fill) {  // lane c reads lane c+1; lane 15 reads `fill`
+  return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xF, 0xF, false);
+}
+
 // Scatters this lane's four levels: gx[2j + ch] is the f16 (loss-scaled) gradient of feature sigma(g, 2j+ch).
 // global_atomic_pk_add_f16 == the reference's atomicAdd(__half2*) (Hash3DAnchored.cu:150-151).
+//
+// The chip retires ~21 G lane-atomics/s whatever their flavour, placement or locality (tools/atomic_probe.py), so the
+// scatter is priced by its atomic COUNT.  The 16 lanes of a row hold 16 consecutive samples of a ray, ~1/512 apart
+// in [0,1] warp space, while a cell of level l is 2^-(3+7l/15) wide: at the coarse and middle levels most of the row
+// sits in one or two cells.  Runs of equal (cell, transform) are therefore summed inside the row first -- a
+// segmented Hillis-Steele scan over DPP row shifts, in fp32 -- and only the last lane of each run issues the 8
+// atomics, with the run total rounded to f16 once (the reference rounds every addend and every partial sum; this is
+// the same sum with fewer roundings).  Contributions that round to (0, 0) are not issued at all: adding zero is a
+// no-op.  EVERY lane of the wave must call this (invalid samples pass gx = 0).
 __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2nLevelTab& lt, half_t* __restrict__ grad_table,
-                                                 const float* p01, int vol, int g, half8_t gx) {
+                                                 const float* p01, int vol, int g, int c, half8_t gx) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const float g0 = (float) gx[2 * j], g1 = (float) gx[2 * j + 1];
-    if (g0 == 0.f && g1 == 0.f) continue;  // :149
+    if (__ballot(g0 != 0.f || g1 != 0.f) == 0ull) continue;  // :149, wave-uniform
     const int l = f2n_level_of(g, j);
     const int tf = l * h.n_volumes + vol;
     F2nCell cell;
     f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
-    half2_t* base = (half2_t*) (grad_table + lt.base[l]);
+    // run heads: first lane of the row, or a different cell / transform than the lane before
+    const bool same_as_prev = c > 0 && f2n_row_shr_i<1>((int) cell.p[0], -1) == (int) cell.p[0] &&
+                              f2n_row_shr_i<1>((int) cell.p[1], -1) == (int) cell.p[1] &&
+                              f2n_row_shr_i<1>((int) cell.p[2], -1) == (int) cell.p[2] && f2n_row_shr_i<1>(vol, -1) == vol;
+    int head = same_as_prev ? 0 : 1;
+    const bool tail = f2n_row_shl1_i(head, 1) != 0;
+    float v[16];
 #pragma unroll
     for (int d = 0; d < 8; d++) {
-      half2_t val = {(half_t) (g0 * cell.w[d]), (half_t) (g1 * cell.w[d])};
-      __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (base + cell.pos[d]), val);
+      v[2 * d] = g0 * cell.w[d];
+      v[2 * d + 1] = g1 * cell.w[d];
+    }
+    int f = head;
+#define F2N_SEG_STEP(K)                                   \
+  {                                                       \
+    const int tf_ = f2n_row_shr_i<K>(f, 1);               \
+    const bool take = c >= K && f == 0;                   \
+    _Pragma("unroll") for (int i = 0; i < 16; i++) {      \
+      const float t_ = f2n_row_shr<K>(v[i]);              \
+      v[i] = take ? v[i] + t_ : v[i];                     \
+    }                                                     \
+    if (c >= K) f |= tf_;                                 \
+  }
+    F2N_SEG_STEP(1)
+    F2N_SEG_STEP(2)
+    F2N_SEG_STEP(4)
+    F2N_SEG_STEP(8)
+#undef F2N_SEG_STEP
+    if (tail) {
+      half2_t* base = (half2_t*) (grad_table + lt.base[l]);
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        const half2_t val = {(half_t) v[2 * d], (half_t) v[2 * d + 1]};
+        if ((float) val[0] != 0.f || (float) val[1] != 0.f)
+          __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (base + cell.pos[d]), val);
+      }
     }
   }
 }
@@ -321,13 +378,14 @@ __global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
             *(float4_t*) (dx_f32 + (size_t) s * F2N_D_IN + 16 * ft + 4 * g) = v;
           }
         }
-        if (DO_HASH) {
-          float p01[3];
-          f2n_load_point(pts, s, pts_are_warped != 0, p01);
-          const int vol = volume_idx[(size_t) s * vol_stride];
-          const half8_t gx = f2n_pack<false>(hb[half].dxT[0], hb[half].dxT[1]);  // (dL/dx * 128) -> f16, Hash3DAnchored.cu:220
-          f2n_scatter_frag(h, lt, grad_table, p01, vol, g, gx);
-        }
+      }
+      if (DO_HASH) {  // every lane takes part in the row-level combining; out-of-range samples carry zero gradient
+        float p01[3];
+        f2n_load_point(pts, sc, pts_are_warped != 0, p01);
+        const int vol = volume_idx[(size_t) sc * vol_stride];
+        half8_t gx = f2n_pack<false>(hb[half].dxT[0], hb[half].dxT[1]);  // (dL/dx * 128) -> f16, Hash3DAnchored.cu:220
+        if (!valid) gx = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        f2n_scatter_frag(h, lt, grad_table, p01, vol, g, c, gx);
       }
     }
     f2n_mlp_accumulate_dw<NH>(hb[0], hb[1], acc);
@@ -355,12 +413,14 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(int n, F2nHashArgs h, con
   const int wave_stride = gridDim.x * 4;
   for (int blk = wave_global; blk < n_blocks; blk += wave_stride) {
     const int s = blk * 16 + c;
-    if (s >= n) continue;
+    const bool valid = s < n;
+    const int sc = valid ? s : n - 1;
     float p01[3];
-    f2n_load_point(pts, s, pts_are_warped != 0, p01);
-    const int vol = volume_idx[(size_t) s * vol_stride];
-    const half8_t gx = f2n_rowfrag(grad_in, F2N_D_IN, s, 0, g);
-    f2n_scatter_frag(h, lt, grad_table, p01, vol, g, gx);
+    f2n_load_point(pts, sc, pts_are_warped != 0, p01);
+    const int vol = volume_idx[(size_t) sc * vol_stride];
+    half8_t gx = f2n_rowfrag(grad_in, F2N_D_IN, sc, 0, g);
+    if (!valid) gx = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    f2n_scatter_frag(h, lt, grad_table, p01, vol, g, c, gx);
   }
 }
 

@@ -1,37 +1,76 @@
 // Renderer glue on gfx950: early-stop pre-pass, sample compaction, volume-rendering compositing forward /
 // backward, WeightVar loss and the seam-level FlexOps.  Semantics: Renderer/Renderer.cpp:105-208,
 // Renderer/Renderer.cu:8-50, Utils/CustomOps/{FlexOps.cu:5-93, CustomOps.cu:12-80, CustomOps.cpp:9-18}.
-// The per-ray fp32 accumulations are sequential left-to-right walks, one ray per lane, because that order is
-// part of the parity contract; everything that the reference spreads over a dozen ATen
-// element-wise launches is done inside the same walk.
+// The per-ray fp32 accumulations add left to right, one term after the other, because that order is part of the
+// parity contract; everything that the reference spreads over a dozen ATen element-wise
+// launches is done inside the same walk.
 #include "f2n_dev.h"
 
 #define F2N_DENSITY_SHIFT 3.f  // Renderer.cpp:101-104
 #define F2N_T_EPS 1e-4f        // early-stop threshold, Renderer.cpp:125
 #define F2N_T_BIAS 1e-2f       // sampled_t = t + 1e-2, Renderer.cpp:118,197
 
+// ---------------------------------------------------------------------------------------------------
+// One DPP row (16 lanes) per ray, four rays per wave.  The reference walks every ray left to right with one
+// thread; that keeps 8192 rays on 128 waves and serialises ~100 exp-laden iterations per lane.  Here the 16 lanes
+// of a row take 16 consecutive samples: all element-wise maths (exp, divisions) runs in parallel, and only the
+// running sums are serial -- a 16-step DPP chain in which lane k adds its own term to lane k-1's finished prefix.
+// The chain performs exactly the additions of the sequential loop in exactly its order, so results are bit-identical
+// to the one-lane-per-ray walk (the summation order is part of the parity contract), at ~2 instructions per sample.
+// ---------------------------------------------------------------------------------------------------
+#define F2N_ROW_RAYS_PER_BLOCK 16  // 256 threads
+
+__device__ __forceinline__ float f2n_row_shr1(float v) {  // lane c reads lane c-1 of its row (lane 0 reads 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false));
+}
+// Inclusive left-to-right running sum over the row: lane k returns ((carry + x_0) + x_1) + ... + x_k.
+__device__ __forceinline__ float f2n_row_seq_scan(float x, float carry, int c) {
+  float p = carry + x;
+#pragma unroll
+  for (int k = 1; k < 16; k++) {
+    const float t = f2n_row_shr1(p) + x;
+    p = (c == k) ? t : p;
+  }
+  return p;
+}
+__device__ __forceinline__ float f2n_row_last(float v) { return __shfl(v, 15, 16); }
+// the prefix that excludes the lane's own term
+__device__ __forceinline__ float f2n_row_exclusive(float incl, float carry, int c) {
+  const float prev = f2n_row_shr1(incl);
+  return c == 0 ? carry : prev;
+}
+
 // Renderer.cpp:115-126
-__global__ void early_stop_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ f0, int f0_stride,
-                                  const float* __restrict__ dt, float* __restrict__ weights, float* __restrict__ alphas,
-                                  int32_t* __restrict__ mask, int32_t* __restrict__ kept) {
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void early_stop_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ f0,
+                                                         int f0_stride, const float* __restrict__ dt, float* __restrict__ weights,
+                                                         float* __restrict__ alphas, int32_t* __restrict__ mask,
+                                                         int32_t* __restrict__ kept) {
+  const int c = threadIdx.x & 15;
+  const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
   const int s = se[2 * ray], e = se[2 * ray + 1];
   float acc = 0.f;
   int cnt = 0;
-  for (int i = s; i < e; i++) {
-    const float sigma = expf(f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT);
-    const float sec = sigma * dt[i];
+  for (int base = s; base < e; base += 16) {
+    const int i = base + c;
+    const bool in = i < e;
+    float sec = 0.f;
+    if (in) sec = expf(f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT) * dt[i];
     const float alpha = 1.f - expf(-sec);
-    const float trans = expf(-acc);  // exclusive cumulative density
-    acc += sec;
-    weights[i] = trans * alpha;
-    alphas[i] = alpha;
-    const int m = trans > F2N_T_EPS ? 1 : 0;
-    mask[i] = m;
+    const float incl = f2n_row_seq_scan(sec, acc, c);
+    const float trans = expf(-f2n_row_exclusive(incl, acc, c));  // exclusive cumulative density
+    acc = f2n_row_last(incl);
+    const int m = (in && trans > F2N_T_EPS) ? 1 : 0;
+    if (in) {
+      weights[i] = trans * alpha;
+      alphas[i] = alpha;
+      mask[i] = m;
+    }
     cnt += m;
   }
-  kept[ray] = cnt;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 16);
+  if (c == 0) kept[ray] = cnt;
 }
 
 // Renderer.cpp:128-135: order-preserving compaction of masked samples; one wave per ray.  The mask of a ray is
@@ -69,45 +108,58 @@ __global__ __launch_bounds__(256) void compact_kernel(int n_rays, const int32_t*
 }
 
 // Renderer.cpp:190-208 forward.
-__global__ void composite_fwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ feat,
-                                     const float* __restrict__ dt, const float* __restrict__ t, const float* __restrict__ rgb,
-                                     const float* __restrict__ bg, float* __restrict__ colors, float* __restrict__ disparity,
-                                     float* __restrict__ depth, float* __restrict__ weights) {
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ feat,
+                                                            const float* __restrict__ dt, const float* __restrict__ t,
+                                                            const float* __restrict__ rgb, const float* __restrict__ bg,
+                                                            float* __restrict__ colors, float* __restrict__ disparity,
+                                                            float* __restrict__ depth, float* __restrict__ weights) {
+  const int c = threadIdx.x & 15;
+  const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
   const int s = se[2 * ray], e = se[2 * ray + 1];
   float acc = 0.f, col[3] = {0.f, 0.f, 0.f}, disp = 0.f, dep = 0.f;
-  for (int i = s; i < e; i++) {
-    const float sigma = expf(feat[(size_t) i * 16] - F2N_DENSITY_SHIFT);
-    const float sec = sigma * dt[i];
+  for (int base = s; base < e; base += 16) {
+    const int i = base + c;
+    const bool in = i < e;
+    float sec = 0.f, tt = 1.f, cr[3] = {0.f, 0.f, 0.f};
+    if (in) {
+      sec = expf(feat[(size_t) i * 16] - F2N_DENSITY_SHIFT) * dt[i];
+      tt = t[i] + F2N_T_BIAS;
+#pragma unroll
+      for (int k = 0; k < 3; k++) cr[k] = rgb[3 * (size_t) i + k];
+    }
     const float alpha = 1.f - expf(-sec);
-    const float trans = expf(-acc);
-    acc += sec;
-    const float w = trans * alpha;
-    weights[i] = w;
-    const float tt = t[i] + F2N_T_BIAS;
+    const float incl = f2n_row_seq_scan(sec, acc, c);
+    const float trans = expf(-f2n_row_exclusive(incl, acc, c));
+    acc = f2n_row_last(incl);
+    const float w = in ? trans * alpha : 0.f;  // lanes past the end add exact zeros to the running sums
+    if (in) weights[i] = w;
 #pragma unroll
-    for (int c = 0; c < 3; c++) col[c] += w * rgb[3 * (size_t) i + c];
-    disp += w / tt;
-    dep += w * tt;
+    for (int k = 0; k < 3; k++) col[k] = f2n_row_last(f2n_row_seq_scan(w * cr[k], col[k], c));
+    disp = f2n_row_last(f2n_row_seq_scan(w / tt, disp, c));
+    dep = f2n_row_last(f2n_row_seq_scan(w * tt, dep, c));
   }
-  const float last_trans = expf(-acc);
+  if (c == 0) {
+    const float last_trans = expf(-acc);
 #pragma unroll
-  for (int c = 0; c < 3; c++) colors[3 * ray + c] = col[c] + last_trans * bg[3 * ray + c];
-  disparity[ray] = disp;
-  depth[ray] = dep / (1.f - last_trans + 1e-4f);
+    for (int k = 0; k < 3; k++) colors[3 * ray + k] = col[k] + last_trans * bg[3 * ray + k];
+    disparity[ray] = disp;
+    depth[ray] = dep / (1.f - last_trans + 1e-4f);
+  }
 }
 
 // Backward of the compositing chain (FlexOps backward kernels FlexOps.cu:17-26,42-53,75-93; TruncExp backward
 // CustomOps.cpp:15-18; GradientScaling backward CustomOps.cu:68-80) in two walks per ray: a forward walk to
-// rebuild T_i / w_i and the ray totals, and a reverse walk carrying the suffix sum of d(acc).
-__global__ void composite_bwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ feat,
-                                     const float* __restrict__ dt, const float* __restrict__ t, const float* __restrict__ rgb,
-                                     const float* __restrict__ bg, const float* __restrict__ dcolors,
-                                     const float* __restrict__ ddisparity, const float* __restrict__ ddepth,
-                                     const float* __restrict__ dweights, float gs_progress, float* __restrict__ drgb,
-                                     float* __restrict__ dfeat) {
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+// rebuild T_i / w_i and the ray totals, and a reverse walk carrying the suffix sum of d(acc).  In the reverse walk
+// lane c of a row takes sample hi-1-c, so the left-to-right row chain runs over descending sample indices.
+__global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ feat,
+                                                            const float* __restrict__ dt, const float* __restrict__ t,
+                                                            const float* __restrict__ rgb, const float* __restrict__ bg,
+                                                            const float* __restrict__ dcolors, const float* __restrict__ ddisparity,
+                                                            const float* __restrict__ ddepth, const float* __restrict__ dweights,
+                                                            float gs_progress, float* __restrict__ drgb, float* __restrict__ dfeat) {
+  const int c = threadIdx.x & 15;
+  const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
   const int s = se[2 * ray], e = se[2 * ray + 1];
   if (s >= e) return;
@@ -117,11 +169,18 @@ __global__ void composite_bwd_kernel(int n_rays, const int32_t* __restrict__ se,
   const float dDep = ddepth != nullptr ? ddepth[ray] : 0.f;
   // walk 1: totals
   float acc = 0.f, dep_sum = 0.f;
-  for (int i = s; i < e; i++) {
-    const float sec = expf(feat[(size_t) i * 16] - F2N_DENSITY_SHIFT) * dt[i];
-    const float w = expf(-acc) * (1.f - expf(-sec));
-    acc += sec;
-    dep_sum += w * (t[i] + F2N_T_BIAS);
+  for (int base = s; base < e; base += 16) {
+    const int i = base + c;
+    const bool in = i < e;
+    float sec = 0.f, tt = 1.f;
+    if (in) {
+      sec = expf(feat[(size_t) i * 16] - F2N_DENSITY_SHIFT) * dt[i];
+      tt = t[i] + F2N_T_BIAS;
+    }
+    const float incl = f2n_row_seq_scan(sec, acc, c);
+    const float w = in ? expf(-f2n_row_exclusive(incl, acc, c)) * (1.f - expf(-sec)) : 0.f;
+    acc = f2n_row_last(incl);
+    dep_sum = f2n_row_last(f2n_row_seq_scan(w * tt, dep_sum, c));
   }
   const float total = acc;
   const float last_trans = expf(-total);
@@ -133,81 +192,106 @@ __global__ void composite_bwd_kernel(int n_rays, const int32_t* __restrict__ se,
   const float dDepW = dDep / denom;
   // walk 2: reverse, suffix carries sum_{j>i} d(acc_j)
   float suffix = 0.f;
-  for (int i = e - 1; i >= s; i--) {
-    const float x = feat[(size_t) i * 16] - F2N_DENSITY_SHIFT;
-    const float sigma = expf(x);
-    const float sec = sigma * dt[i];
-    acc -= sec;  // exclusive cumulative density of sample i (rebuilt backwards)
-    const float trans = expf(-acc);
+  for (int hi = e; hi > s; hi -= 16) {
+    const int i = hi - 1 - c;
+    const bool in = i >= s;
+    float x = 0.f, dti = 0.f, sigma = 0.f, tt = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dwi = 0.f;
+    if (in) {
+      x = feat[(size_t) i * 16] - F2N_DENSITY_SHIFT;
+      sigma = expf(x);
+      dti = dt[i];
+      tt = t[i] + F2N_T_BIAS;
+      c0 = rgb[3 * (size_t) i]; c1 = rgb[3 * (size_t) i + 1]; c2 = rgb[3 * (size_t) i + 2];
+      if (dweights != nullptr) dwi = dweights[i];
+    }
+    const float sec = in ? sigma * dti : 0.f;
+    // acc -= sec, rebuilt backwards: the exclusive cumulative density of sample i
+    const float acc_i = f2n_row_seq_scan(-sec, acc, c);
+    acc = f2n_row_last(acc_i);
+    const float trans = expf(-acc_i);
     const float ems = expf(-sec);
     const float alpha = 1.f - ems;
     const float w = trans * alpha;
-    const float tt = t[i] + F2N_T_BIAS;
-    const float c0 = rgb[3 * (size_t) i], c1 = rgb[3 * (size_t) i + 1], c2 = rgb[3 * (size_t) i + 2];
     float dw = (dC[0] * c0 + dC[1] * c1 + dC[2] * c2) + dDisp / tt + dDepW * tt;
-    if (dweights != nullptr) dw += dweights[i];
+    if (dweights != nullptr) dw += dwi;
     // w = trans*alpha ; trans = exp(-acc_excl) ; alpha = 1 - exp(-sec)
-    const float d_acc = -dw * w;
-    const float d_sec = dw * trans * ems + suffix + d_total;
-    suffix += d_acc;
-    float d_sigma = d_sec * dt[i];
-    float g0 = dC[0] * w, g1 = dC[1] * w, g2 = dC[2] * w;
-    if (gs_progress < 1.f) {  // CustomOps.cu:68-80
-      const float a = ((float) (i - s) + .5f) / (float) (e - s);
-      const float sc = gs_progress + (1.f - gs_progress) * a * a;
-      d_sigma *= sc;
-      g0 *= sc; g1 *= sc; g2 *= sc;
+    const float d_acc = in ? -dw * w : 0.f;
+    const float suf_incl = f2n_row_seq_scan(d_acc, suffix, c);
+    const float suf_i = f2n_row_exclusive(suf_incl, suffix, c);
+    suffix = f2n_row_last(suf_incl);
+    if (in) {
+      const float d_sec = dw * trans * ems + suf_i + d_total;
+      float d_sigma = d_sec * dti;
+      float g0 = dC[0] * w, g1 = dC[1] * w, g2 = dC[2] * w;
+      if (gs_progress < 1.f) {  // CustomOps.cu:68-80
+        const float a = ((float) (i - s) + .5f) / (float) (e - s);
+        const float sc = gs_progress + (1.f - gs_progress) * a * a;
+        d_sigma *= sc;
+        g0 *= sc; g1 *= sc; g2 *= sc;
+      }
+      drgb[3 * (size_t) i] = g0;
+      drgb[3 * (size_t) i + 1] = g1;
+      drgb[3 * (size_t) i + 2] = g2;
+      // TruncExp backward: grad * exp(clamp(x, -100, 5))
+      dfeat[(size_t) i * 16] = d_sigma * expf(fminf(fmaxf(x, -100.f), 5.f));
     }
-    drgb[3 * (size_t) i] = g0;
-    drgb[3 * (size_t) i + 1] = g1;
-    drgb[3 * (size_t) i + 2] = g2;
-    // TruncExp backward: grad * exp(clamp(x, -100, 5))
-    dfeat[(size_t) i * 16] = d_sigma * expf(fminf(fmaxf(x, -100.f), 5.f));
   }
 }
 
-// CustomOps.cu:12-66
-__device__ __forceinline__ void f2n_wv_stats(const float* __restrict__ w, int n, float& mean, float& wsum) {
+// CustomOps.cu:12-66.  mean = (sum w_i * i/16) / (1e-6 + sum w_i), both sums left to right.
+__device__ __forceinline__ void f2n_wv_stats(const float* __restrict__ w, int n, int c, float& mean, float& wsum) {
   float m = 0.f, ws = 1e-6f;
-  for (int i = 0; i < n; i++) {
-    m += w[i] * ((float) i / 16.f);
-    ws += w[i];
+  for (int base = 0; base < n; base += 16) {
+    const int i = base + c;
+    const float wi = i < n ? w[i] : 0.f;
+    m = f2n_row_last(f2n_row_seq_scan(wi * ((float) i / 16.f), m, c));
+    ws = f2n_row_last(f2n_row_seq_scan(wi, ws, c));
   }
   mean = m / ws;
   wsum = ws;
 }
 
-__global__ void weight_var_fwd_kernel(int n_rays, const float* __restrict__ weights, const int32_t* __restrict__ se,
-                                      float* __restrict__ out) {
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void weight_var_fwd_kernel(int n_rays, const float* __restrict__ weights,
+                                                             const int32_t* __restrict__ se, float* __restrict__ out) {
+  const int c = threadIdx.x & 15;
+  const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
   const int s = se[2 * ray], e = se[2 * ray + 1];
-  if (s >= e) { out[ray] = 0.f; return; }
-  float mean, ws;
-  f2n_wv_stats(weights + s, e - s, mean, ws);
-  float var = 0.f;
-  for (int i = 0; i + s < e; i++) {
-    const float b = (float) i / 16.f - mean;
-    var += weights[i + s] * b * b;
+  if (s >= e) {
+    if (c == 0) out[ray] = 0.f;
+    return;
   }
-  out[ray] = var;
+  float mean, ws;
+  f2n_wv_stats(weights + s, e - s, c, mean, ws);
+  float var = 0.f;
+  for (int base = 0; base + s < e; base += 16) {
+    const int i = base + c;
+    const float b = (float) i / 16.f - mean;
+    const float wi = i + s < e ? weights[i + s] : 0.f;
+    var = f2n_row_last(f2n_row_seq_scan(wi * b * b, var, c));
+  }
+  if (c == 0) out[ray] = var;
 }
 
-__global__ void weight_var_bwd_kernel(int n_rays, const float* __restrict__ weights, const int32_t* __restrict__ se,
-                                      const float* __restrict__ dvars, float* __restrict__ dw) {
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void weight_var_bwd_kernel(int n_rays, const float* __restrict__ weights,
+                                                             const int32_t* __restrict__ se, const float* __restrict__ dvars,
+                                                             float* __restrict__ dw) {
+  const int c = threadIdx.x & 15;
+  const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
   const int s = se[2 * ray], e = se[2 * ray + 1];
   if (s >= e) return;
   float mean, ws;
-  f2n_wv_stats(weights + s, e - s, mean, ws);
+  f2n_wv_stats(weights + s, e - s, c, mean, ws);
   float tmp = 0.f;
-  for (int i = 0; i + s < e; i++) {
+  for (int base = 0; base + s < e; base += 16) {
+    const int i = base + c;
     const float b = (float) i / 16.f - mean;
-    tmp += weights[i + s] * 2.f * b;
+    const float wi = i + s < e ? weights[i + s] : 0.f;
+    tmp = f2n_row_last(f2n_row_seq_scan(wi * 2.f * b, tmp, c));
   }
   const float dv = dvars[ray];
-  for (int i = 0; i + s < e; i++) {
+  for (int i = c; i + s < e; i += 16) {
     const float b = (float) i / 16.f - mean;
     const float g = (b * b + tmp * -((float) i / 16.f) / ws);
     dw[i + s] = dv * g;
@@ -263,12 +347,21 @@ __global__ void flex_acc_bwd_kernel(int n, int include_this, const float* __rest
     return f2n_launch_status();                                                                                      \
   } while (0)
 
+#define F2N_ROW_LAUNCH(kernel, n_rays, ...)                                                                          \
+  do {                                                                                                               \
+    if ((n_rays) < 0) return F2N_ERR_INVALID_ARG;                                                                    \
+    if ((n_rays) == 0) return F2N_OK;                                                                                \
+    hipLaunchKernelGGL(kernel, dim3(f2n_div_up((n_rays), F2N_ROW_RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t) stream, \
+                       (n_rays), __VA_ARGS__);                                                                       \
+    return f2n_launch_status();                                                                                      \
+  } while (0)
+
 extern "C" {
 
 int f2n_early_stop(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
                    float* weights, float* alphas, int32_t* mask, int32_t* kept) {
   if (f0_stride < 1) return F2N_ERR_INVALID_ARG;
-  F2N_RAY_LAUNCH(early_stop_kernel, n_rays, pts_start_end, f0, f0_stride, dt, weights, alphas, mask, kept);
+  F2N_ROW_LAUNCH(early_stop_kernel, n_rays, pts_start_end, f0, f0_stride, dt, weights, alphas, mask, kept);
 }
 
 int f2n_compact_samples(void* stream, int n_rays, const int32_t* old_start_end, const int32_t* new_start_end,
@@ -295,23 +388,23 @@ int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_e
 int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat, const float* dt,
                       const float* t, const float* rgb, const float* bg, float* colors, float* disparity, float* depth,
                       float* weights) {
-  F2N_RAY_LAUNCH(composite_fwd_kernel, n_rays, pts_start_end, feat, dt, t, rgb, bg, colors, disparity, depth, weights);
+  F2N_ROW_LAUNCH(composite_fwd_kernel, n_rays, pts_start_end, feat, dt, t, rgb, bg, colors, disparity, depth, weights);
 }
 
 int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat, const float* dt,
                       const float* t, const float* rgb, const float* bg, const float* dcolors, const float* ddisparity,
                       const float* ddepth, const float* dweights, float grad_scaling_progress, float* drgb, float* dfeat) {
-  F2N_RAY_LAUNCH(composite_bwd_kernel, n_rays, pts_start_end, feat, dt, t, rgb, bg, dcolors, ddisparity, ddepth, dweights,
+  F2N_ROW_LAUNCH(composite_bwd_kernel, n_rays, pts_start_end, feat, dt, t, rgb, bg, dcolors, ddisparity, ddepth, dweights,
                  grad_scaling_progress, drgb, dfeat);
 }
 
 int f2n_weight_var_fwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, float* out_vars) {
-  F2N_RAY_LAUNCH(weight_var_fwd_kernel, n_rays, weights, pts_start_end, out_vars);
+  F2N_ROW_LAUNCH(weight_var_fwd_kernel, n_rays, weights, pts_start_end, out_vars);
 }
 
 int f2n_weight_var_bwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, const float* dvars,
                        float* dweights) {
-  F2N_RAY_LAUNCH(weight_var_bwd_kernel, n_rays, weights, pts_start_end, dvars, dweights);
+  F2N_ROW_LAUNCH(weight_var_bwd_kernel, n_rays, weights, pts_start_end, dvars, dweights);
 }
 
 int f2n_flex_sum_fwd(void* stream, int n_rays, int vec, const float* val, const int32_t* start_end, float* sum) {
