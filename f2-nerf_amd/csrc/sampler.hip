@@ -402,7 +402,7 @@ __global__ void edge_samples_kernel(int n_pts, const F2nEdgePool* __restrict__ e
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Occupancy votes, PersSampler.cu:475-526 (one ray per lane, integer atomics).
+// Occupancy votes, PersSampler.cu:475-526 (integer atomic maxima).
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void f2n_vote(int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt, int node,
                                          float w, float a, float w_thres, float a_thres, int visits) {
@@ -433,37 +433,70 @@ __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __rest
     }
     __syncthreads();
   }
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  // one 16-lane row per ray (the votes are integer maxima: order-free); a vote is cast by the last sample of each
+  // run of equal leaves, which learns the run's maxima and start from a segmented max-scan over DPP row shifts
+  const int c = threadIdx.x & 15;
+  const int ray = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
   int s = 0, e = 0;
   if (ray < n_rays) {
     s = pts_start_end[2 * ray];
     e = pts_start_end[2 * ray + 1];
   }
   if (s < e) {
-  float mw = 0.f, ma = 0.f;
-  for (int i = s; i < e; i++) {
-    mw = fmaxf(mw, weights[i]);
-    ma = fmaxf(ma, alphas[i]);
-  }
-  // 0.1 / 0.01 / 0.02 are double literals in the reference (:12-17): float*double, then narrowed by fminf
-  const float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
-  const float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
-  float cw = 0.f, ca = 0.f;
-  int cur = -1, visits = 0;
-  for (int i = s; i < e; i++) {
-    const int node = anchors[(size_t) i * anchor_stride + 1];
-    if (cur != node) {
-      if (cur >= 0) f2n_vote(w_adder, a_adder, mark, cnt, cur, cw, ca, w_thres, a_thres, visits);
-      cur = node;
-      cw = 0.f;
-      ca = 0.f;
-      visits = 0;
+    float mw = 0.f, ma = 0.f;
+    for (int i = s + c; i < e; i += 16) {
+      mw = fmaxf(mw, weights[i]);
+      ma = fmaxf(ma, alphas[i]);
     }
-    cw = fmaxf(cw, weights[i]);
-    ca = fmaxf(ca, alphas[i]);
-    visits++;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      mw = fmaxf(mw, __shfl_xor(mw, off, 16));
+      ma = fmaxf(ma, __shfl_xor(ma, off, 16));
+    }
+    // 0.1 / 0.01 / 0.02 are double literals in the reference (:12-17): float*double, then narrowed by fminf
+    const float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
+    const float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
+    float carry_w = 0.f, carry_a = 0.f;
+    int carry_start = s;
+    for (int base = s; base < e; base += 16) {
+      const int i = base + c;
+      const bool in = i < e;
+      const int ic = in ? i : e - 1;
+      const int node = anchors[(size_t) ic * anchor_stride + 1];
+      const int prev = ic > s ? anchors[(size_t) (ic - 1) * anchor_stride + 1] : -1;
+      const int next = ic + 1 < e ? anchors[(size_t) (ic + 1) * anchor_stride + 1] : -1;
+      const bool head = node != prev;
+      float cw = fmaxf(0.f, weights[ic]), ca = fmaxf(0.f, alphas[ic]);  // the reference's running maxima start at 0
+      int start = head ? ic : (int) 0x80000000;
+      if (c == 0 && !head) {  // the run continues from the previous chunk
+        cw = fmaxf(cw, carry_w);
+        ca = fmaxf(ca, carry_a);
+        start = carry_start;
+      }
+      int f = head ? 1 : 0;
+#define F2N_SEGMAX_STEP(K)                                                                     \
+  {                                                                                            \
+    const float tw = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cw), 0x110 + K, 0xF, 0xF, false)); \
+    const float ta = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ca), 0x110 + K, 0xF, 0xF, false)); \
+    const int ts = __builtin_amdgcn_update_dpp((int) 0x80000000, start, 0x110 + K, 0xF, 0xF, false);              \
+    const int tf = __builtin_amdgcn_update_dpp(1, f, 0x110 + K, 0xF, 0xF, false);                                 \
+    if (c >= K && f == 0) {                                                                    \
+      cw = fmaxf(cw, tw);                                                                      \
+      ca = fmaxf(ca, ta);                                                                      \
+      start = max(start, ts);                                                                  \
+    }                                                                                          \
+    if (c >= K) f |= tf;                                                                       \
   }
-  if (cur >= 0) f2n_vote(w_adder, a_adder, mark, cnt, cur, cw, ca, w_thres, a_thres, visits);
+      F2N_SEGMAX_STEP(1)
+      F2N_SEGMAX_STEP(2)
+      F2N_SEGMAX_STEP(4)
+      F2N_SEGMAX_STEP(8)
+#undef F2N_SEGMAX_STEP
+      if (in && node != next) f2n_vote(w_adder, a_adder, mark, cnt, node, cw, ca, w_thres, a_thres, ic - start + 1);
+      carry_w = __shfl(cw, 15, 16);
+      carry_a = __shfl(ca, 15, 16);
+      carry_start = __shfl(start, 15, 16);
+    }
   }
   if (USE_LDS) {
     __syncthreads();
@@ -622,10 +655,10 @@ int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts
   if (n_rays == 0) return F2N_OK;
   const size_t lds = sizeof(int32_t) * 3 * (size_t) n_nodes;
   if (lds <= 60 * 1024) {  // block-local vote combining in LDS (12 B per octree node; 64 KB default LDS limit)
-    hipLaunchKernelGGL(mark_visit_kernel<true>, dim3(f2n_div_up(n_rays, 256)), dim3(256), lds, (hipStream_t) stream, n_rays,
+    hipLaunchKernelGGL(mark_visit_kernel<true>, dim3(f2n_div_up(n_rays, 64)), dim3(1024), lds, (hipStream_t) stream, n_rays,
                        n_nodes, pts_start_end, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt);
   } else {
-    hipLaunchKernelGGL(mark_visit_kernel<false>, dim3(f2n_div_up(n_rays, 64)), dim3(64), 0, (hipStream_t) stream, n_rays,
+    hipLaunchKernelGGL(mark_visit_kernel<false>, dim3(f2n_div_up(n_rays, 16)), dim3(256), 0, (hipStream_t) stream, n_rays,
                        n_nodes, pts_start_end, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt);
   }
   return f2n_launch_status();
