@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--preset", default="wanjinyou")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
+    ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,6 +71,8 @@ def main():
     st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
     runner, cfg, _ = runtime.make_runner(st, args.preset, seed=2022, device=dev)   # identical replica on every rank
     log2 = int(cfg["field"]["log2_table_size"])
+    if args.diag_no_nan_check:
+        runner.check_nan = False
 
     if world > 1:
         from f2_nerf_amd import parallel

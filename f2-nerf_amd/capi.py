@@ -274,14 +274,29 @@ def flex_acc_bwd(n_rays, include_this, dsum, se, out):
 
 
 # ---------------------------------------------------------------- optimiser
-def adam_step(n, param, grad, grad_scale, grad_round_h16, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h):
+def adam_step(n, param, grad, grad_scale, grad_round_h16, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
+              skip_flag=None):
     _ck(lib().f2n_adam_step(_stream(), _i(n), _p(param, "f32"), _p(grad, "f32"), _f(grad_scale), _i(int(grad_round_h16)),
                             _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _f(beta1), _f(beta2), _f(eps),
-                            _f(wd), _p(param_h, "h16", True)), "f2n_adam_step")
+                            _f(wd), _p(param_h, "h16", True), _p(skip_flag, "i32", True)), "f2n_adam_step")
 
 
 def adam_step_h16grad(n, param, grad_h, grad_scale, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
-                      zero_grad):
+                      zero_grad, skip_flag=None):
     _ck(lib().f2n_adam_step_h16grad(_stream(), _i(n), _p(param, "f32"), _p(grad_h, "h16"), _f(grad_scale),
                                     _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _f(beta1), _f(beta2),
-                                    _f(eps), _f(wd), _p(param_h, "h16"), _i(int(zero_grad))), "f2n_adam_step_h16grad")
+                                    _f(eps), _f(wd), _p(param_h, "h16"), _i(int(zero_grad)),
+                                    _p(skip_flag, "i32", True)), "f2n_adam_step_h16grad")
+
+
+def train_loss(n_rays, pred, gt, disparity, sampled_var, n_edge, feat_dim, edge_feats, var_w, disp_w, tv_w, out_losses,
+               dcolors, ddisparity, dvar, dedge_feats):
+    _ck(lib().f2n_train_loss(_stream(), _i(n_rays), _p(pred, "f32"), _p(gt, "f32"), _p(disparity, "f32", True),
+                             _p(sampled_var, "f32", True), _i(n_edge), _i(feat_dim), _p(edge_feats, "f32", True), _f(var_w),
+                             _f(disp_w), _f(tv_w), _p(out_losses, "f32"), _p(dcolors, "f32", True), _p(ddisparity, "f32", True),
+                             _p(dvar, "f32", True), _p(dedge_feats, "f32", True)), "f2n_train_loss")
+
+
+def nonfinite_flags(n_a, a, n_b, b, flags):
+    _ck(lib().f2n_nonfinite_flags(_stream(), _i(n_a), _p(a, "f32", True), _i(n_b), _p(b, "f32", True), _p(flags, "i32")),
+        "f2n_nonfinite_flags")

@@ -77,7 +77,7 @@ int ExpRunner::CurBatchSize() const {  // ExpRunner.cpp:86
   return int(pts_batch_size_ / global_data_pool_->meaningful_sampled_pts_per_ray_) >> 4 << 4;
 }
 
-void ExpRunner::OptimStep() {
+void ExpRunner::OptimStep(const int32_t* skip_flag) {
   optim_steps_ += 1;
   void* st = CurStream();
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
@@ -91,17 +91,75 @@ void ExpRunner::OptimStep() {
     if (g.grad_is_h16) {
       F2N_TIMED_CALL("adam_table", f2n_adam_step_h16grad(st, (int) n, F32P(g.param), VoidP(g.grad), scale, F32P(exp_avg_[i]),
                                      F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
-                                     VoidP(g.param_h), /*zero_grad=*/1));
+                                     VoidP(g.param_h), /*zero_grad=*/1, skip_flag));
+      if (g.name == "feat_pool") field->grad_clean_ = true;
     } else {
       F2N_TIMED_CALL("adam", f2n_adam_step(st, (int) n, F32P(g.param), F32P(g.grad), scale, g.grad_round_h16 ? 1 : 0, F32P(exp_avg_[i]),
                              F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
-                             g.param_h.defined() ? VoidP(g.param_h) : nullptr));
+                             g.param_h.defined() ? VoidP(g.param_h) : nullptr, skip_flag));
     }
   }
 }
 
-// One iteration of ExpRunner::Train (ExpRunner.cpp:82-143) for a given ray batch.
+// Loss weights of the current iteration (ExpRunner.cpp:108-114).
+float ExpRunner::CurVarLossWeight() const {
+  if (iter_step_ > var_loss_end_) return var_loss_weight_;
+  if (iter_step_ > var_loss_start_) return float(iter_step_ - var_loss_start_) / float(var_loss_end_ - var_loss_start_) * var_loss_weight_;
+  return 0.f;
+}
+
+// One iteration of ExpRunner::Train (ExpRunner.cpp:82-143) for a given ray batch: untaped forward + loss + backward
+// (Renderer::TrainForwardBackward), device-side finiteness flags, Adam predicated on them, ONE flag read-back.
 TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
+                                const Tensor& emb_idx, bool apply_optimizer) {
+  auto* gdp = global_data_pool_.get();
+  gdp->mode_ = RunningMode::TRAIN;
+  gdp->backward_nan_ = false;
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  renderer_->ZeroGrad();
+  TrainOutputs out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(),
+                                                     disp_loss_weight_, tv_loss_weight_);
+  TrainStats stats;
+  stats.n_rays = rays_o.size(0);
+  stats.n_samples = renderer_->last_n_all_pts_;
+  stats.n_meaningful = renderer_->last_n_kept_pts_;
+  stats.loss = out.losses.slice(0, 0, 1).squeeze(0);
+  stats.mse = out.losses.slice(0, 5, 6).squeeze(0);
+  if (out.has_samples) {
+    if (grad_sync_hook_) grad_sync_hook_();  // data-parallel all-reduce of the gradient buffers (RCCL)
+    const int32_t* skip = nullptr;
+    if (check_nan_) {  // TCNNWP.cpp:234-240, on the device
+      if (!nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
+      F2N_CALL(f2n_nonfinite_flags(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
+                                   F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_)));
+      skip = I32P(nan_flags_) + 2;
+    }
+    if (apply_optimizer) OptimStep(skip);  // a no-op on the device when the flags say so
+    if (check_nan_) {
+      Tensor h = nan_flags_.cpu();  // the iteration's only read-back besides the two sample counts
+      const int32_t* f = h.data_ptr<int32_t>();
+      if (f[0]) field->mlp_->loss_scale_ = std::max(field->mlp_->loss_scale_ / 2.f, 1.f);
+      if (f[1]) shader->mlp_->loss_scale_ = std::max(shader->mlp_->loss_scale_ / 2.f, 1.f);
+      if (f[2]) {  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
+        gdp->backward_nan_ = true;
+        stats.skipped_nan = true;
+        if (apply_optimizer) optim_steps_ -= 1;
+        return stats;
+      }
+    }
+  }
+  if (apply_optimizer) {
+    iter_step_++;
+    UpdateAdaParams();
+  }
+  return stats;
+}
+
+// The same iteration on the autograd tape, op for op as the reference spells it (ExpRunner.cpp:82-143): Render(),
+// ATen loss, loss.backward(), per-MLP host finiteness checks.  Kept as the cross-check of the fused TrainStep
+// (tests/test_gpu_e2e.py); ~100 more launches and four host round trips per iteration.
+TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                 const Tensor& emb_idx, bool apply_optimizer) {
   auto* gdp = global_data_pool_.get();
   gdp->mode_ = RunningMode::TRAIN;
@@ -120,9 +178,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     Tensor tv_loss = (rr.edge_feats.index({Slc(), 0}) - rr.edge_feats.index({Slc(), 1})).square().mean();
     Tensor sampled_var = CustomOps::WeightVar(rr.weights, rr.idx_start_end);
     Tensor var_loss = (sampled_var + 1e-2).sqrt().mean();
-    float var_w = 0.f;  // ExpRunner.cpp:108-114
-    if (iter_step_ > var_loss_end_) var_w = var_loss_weight_;
-    else if (iter_step_ > var_loss_start_) var_w = float(iter_step_ - var_loss_start_) / float(var_loss_end_ - var_loss_start_) * var_loss_weight_;
+    const float var_w = CurVarLossWeight();
     loss = color_loss + var_loss * var_w + disparity_loss * disp_loss_weight_ + tv_loss * tv_loss_weight_;
   }
   stats.loss = loss.detach();

@@ -19,9 +19,12 @@ class ExpRunner {
   std::vector<Tensor> States() { return renderer_->States(); }
   TrainStats TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                        const Tensor& emb_idx, bool apply_optimizer = true);
+  TrainStats TrainStepAutograd(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
+                               const Tensor& emb_idx, bool apply_optimizer = true);
+  float CurVarLossWeight() const;
   std::vector<Tensor> RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   void UpdateAdaParams();
-  void OptimStep();
+  void OptimStep(const int32_t* skip_flag = nullptr);  // skip_flag: device int, != 0 drops the update
   void BuildOptimizer();
   int CurBatchSize() const;
 
@@ -37,6 +40,7 @@ class ExpRunner {
   bool check_nan_ = true;
   int optim_steps_ = 0;
   std::function<void()> grad_sync_hook_;
+  Tensor nan_flags_;  // device int32 [4]: field MLP, colour MLP, either
 
   std::unique_ptr<GlobalDataPool> global_data_pool_;
   std::unique_ptr<Renderer> renderer_;

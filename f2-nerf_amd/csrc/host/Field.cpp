@@ -123,7 +123,8 @@ void Hash3DAnchored::SyncHalf() {  // Hash3DAnchored.cu:186 (done once here; aft
 }
 
 void Hash3DAnchored::ZeroGrad() {
-  grad_h_.zero_();
+  if (!grad_clean_) grad_h_.zero_();  // the fused optimiser step already re-zeroes the table gradient it consumed
+  grad_clean_ = true;
   mlp_->ZeroGrad();
 }
 
@@ -151,18 +152,7 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
     AnchorView av = ViewAnchors(anchors);
     Tensor feat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
     Tensor saved_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
-    const int n_cached = (int) n_reuse, n_tail = n - n_cached;
-    if (n_cached > 0) {
-      TORCH_CHECK(f->prepass_x_.defined() && src_rows.numel() == n_cached, "no pre-pass feature cache for this query");
-      F2N_TIMED_CALL("field_fwd_cached", f2n_field_fwd_cached(CurStream(), n_cached, (int) f->prepass_x_.size(0), I32P(src_rows),
-                             VoidP(f->prepass_x_), VoidP(f->mlp_->params_h_), F32P(feat), nullptr, VoidP(saved_x)));
-    }
-    if (n_tail > 0)
-      F2N_TIMED_CALL("field_fwd", f2n_field_fwd(CurStream(), n_tail, f->n_volumes_, VoidP(f->feat_pool_h_), I32P(f->prim_pool_),
-                             I32P(f->feat_local_idx_), I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_),
-                             F32P(points) + 3 * (int64_t) n_cached, I32P(av.t) + (int64_t) av.stride * n_cached, av.stride,
-                             VoidP(f->mlp_->params_h_), F32P(feat) + (int64_t) F2N_MLP_OUT_PAD * n_cached, nullptr,
-                             static_cast<void*>(saved_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * n_cached)));
+    f->ForwardRaw(points, av.t, av.stride, src_rows, (int) n_reuse, feat, saved_x);
     ctx->saved_data["field"] = field_ptr;
     ctx->save_for_backward({points, av.t, saved_x});
     ctx->saved_data["stride"] = (int64_t) av.stride;
@@ -171,18 +161,39 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
   static variable_list backward(AutogradContext* ctx, variable_list grad_output) {
     auto* f = reinterpret_cast<Hash3DAnchored*>(ctx->saved_data["field"].toInt());
     auto saved = ctx->get_saved_variables();
-    Tensor dfeat = grad_output[0].contiguous();
-    const int n = saved[0].size(0);
-    F2N_TIMED_CALL("field_bwd", f2n_field_bwd(CurStream(), n, f->n_volumes_, I32P(f->prim_pool_), I32P(f->feat_local_idx_),
-                           I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_), F32P(saved[0]),
-                           I32P(saved[1]), (int) ctx->saved_data["stride"].toInt(), VoidP(f->mlp_->params_h_),
-                           VoidP(saved[2]), F32P(dfeat), f->mlp_->loss_scale_, F32P(f->mlp_->grad_scaled_), VoidP(f->grad_h_)));
+    f->BackwardRaw(saved[0], saved[1], (int) ctx->saved_data["stride"].toInt(), saved[2], grad_output[0].contiguous());
     // gradients live in f->grad_h_ (fp16, x128) and f->mlp_->grad_scaled_: consumed by the fused optimiser step
     return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
 }  // namespace
+
+void Hash3DAnchored::ForwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& src_rows, int n_reuse,
+                                Tensor& feat, Tensor& saved_x) {
+  const int n = points.size(0);
+  const int n_cached = n_reuse, n_tail = n - n_cached;
+  if (n_cached > 0) {
+    TORCH_CHECK(prepass_x_.defined() && src_rows.numel() >= n_cached, "no pre-pass feature cache for this query");
+    F2N_TIMED_CALL("field_fwd_cached", f2n_field_fwd_cached(CurStream(), n_cached, (int) prepass_x_.size(0), I32P(src_rows),
+                           VoidP(prepass_x_), VoidP(mlp_->params_h_), F32P(feat), nullptr, VoidP(saved_x)));
+  }
+  if (n_tail > 0)
+    F2N_TIMED_CALL("field_fwd", f2n_field_fwd(CurStream(), n_tail, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),
+                           I32P(feat_local_idx_), I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_),
+                           F32P(points) + 3 * (int64_t) n_cached, I32P(anchors) + (int64_t) stride * n_cached, stride,
+                           VoidP(mlp_->params_h_), F32P(feat) + (int64_t) F2N_MLP_OUT_PAD * n_cached, nullptr,
+                           static_cast<void*>(saved_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * n_cached)));
+}
+
+void Hash3DAnchored::BackwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& saved_x, const Tensor& dfeat) {
+  const int n = points.size(0);
+  grad_clean_ = false;
+  F2N_TIMED_CALL("field_bwd", f2n_field_bwd(CurStream(), n, n_volumes_, I32P(prim_pool_), I32P(feat_local_idx_),
+                         I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(points), I32P(anchors), stride,
+                         VoidP(mlp_->params_h_), VoidP(saved_x), F32P(dfeat), mlp_->loss_scale_, F32P(mlp_->grad_scaled_),
+                         VoidP(grad_h_)));
+}
 
 Tensor Hash3DAnchored::AnchoredQuery(const Tensor& points, const Tensor& anchors) {  // Hash3DAnchored.cpp:84-99
   Tensor pts = points.contiguous();

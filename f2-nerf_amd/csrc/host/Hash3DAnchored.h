@@ -20,6 +20,11 @@ class Hash3DAnchored : public Field {
   // AnchoredQuery whose first n_reuse points are points src_rows[i] of the preceding QueryDensityPreAct (same table,
   // same coordinates): their 128 gathers are not repeated.  Bit-identical to AnchoredQuery(points, anchors).
   Tensor AnchoredQueryReuse(const Tensor& points, const Tensor& anchors, const Tensor& src_rows, int n_reuse);
+  // The kernels behind the autograd node, callable directly (the fused train step does): feat [n,16] fp32 and
+  // saved_x [n,32] h16 are written; BackwardRaw scatters into grad_h_ / mlp_->grad_scaled_.
+  void ForwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& src_rows, int n_reuse, Tensor& feat,
+                  Tensor& saved_x);
+  void BackwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& saved_x, const Tensor& dfeat);
 
   int LoadStates(const std::vector<Tensor>& states, int idx) override;
   std::vector<Tensor> States() override;
@@ -37,6 +42,7 @@ class Hash3DAnchored : public Field {
   Tensor prim_pool_;       // [16, V, 3] int32
   Tensor bias_pool_;       // [16*V, 3]
   Tensor feat_local_idx_, feat_local_size_, level_scale_;
+  bool grad_clean_ = false;  // grad_h_ is known to be all zero
   Tensor prepass_x_;       // h16 [n,32] features of the last QueryDensityPreAct(keep_features = true), or undefined
   std::unique_ptr<FusedMLP> mlp_;
   int n_volumes_;

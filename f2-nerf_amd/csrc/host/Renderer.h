@@ -33,12 +33,33 @@ struct RenderResult {  // Renderer.h:18-27 of the reference
   Tensor idx_start_end;
 };
 
+// Everything Render() knows after sampling, pre-pass, early stop, compaction and the occupancy update.
+struct RenderFront {
+  bool empty = false;        // no sample at all (Renderer.cpp:83-97)
+  SampleResultFlex es;       // surviving samples
+  Tensor pts_all, vol_all;   // [M + 2E] surviving samples followed by the edge (TV) samples
+  Tensor src_rows;           // row of every surviving sample in the pre-pass feature cache
+  Tensor bg_color, sample_emb_idx;
+  int n_kept = 0, n_edge = 0;
+  bool emb = false;
+};
+
+struct TrainOutputs {
+  Tensor losses;  // device [8]: loss, color, var, disp, tv, mse, 0, 0 (f2n_train_loss)
+  Tensor colors;
+  bool has_samples = false;
+};
+
 class Renderer : public Pipe {
   enum BGColorType { white, black, rand_noise };
 
  public:
   Renderer(GlobalDataPool* global_data_pool, int n_images);
   RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
+  RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
+  // forward + ExpRunner::Train's loss + backward into the gradient buffers, without the autograd tape
+  TrainOutputs TrainForwardBackward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
+                                    const Tensor& emb_idx, float var_w, float disp_w, float tv_w);
 
   int LoadStates(const std::vector<Tensor>& states, int idx) override;
   std::vector<Tensor> States() override;

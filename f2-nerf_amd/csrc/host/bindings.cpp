@@ -42,6 +42,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            },
            py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
            py::arg("apply_optimizer") = true)
+      .def("train_step_autograd",
+           [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply) {
+             TrainStats s;
+             {
+               py::gil_scoped_release no_gil;  // the autograd engine must not be entered while holding the GIL
+               s = r.TrainStepAutograd(ro, rd, b, gt, emb, apply);
+             }
+             return StatsToDict(s);
+           },
+           py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
+           py::arg("apply_optimizer") = true)
       .def("render_rays", &ExpRunner::RenderRays)
       .def("render_train",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& emb) {
@@ -64,7 +75,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("anchored_query", [](ExpRunner& r, const Tensor& pts, const Tensor& anchors) { return r.renderer_->scene_field_->AnchoredQuery(pts, anchors); })
       .def("shader_query", [](ExpRunner& r, const Tensor& feats, const Tensor& dirs) { return r.renderer_->shader_->Query(feats, dirs); })
       .def("zero_grad", [](ExpRunner& r) { r.renderer_->ZeroGrad(); })
-      .def("optim_step", &ExpRunner::OptimStep)
+      .def("optim_step", [](ExpRunner& r) { r.OptimStep(nullptr); })
       .def("grads",
            [](ExpRunner& r) {
              py::dict d;

@@ -278,13 +278,34 @@ int f2n_flex_acc_bwd(void* stream, int n_rays, int include_this, const float* ds
  * autograd's cast of the unscaled gradient to the f16 dtype of the Function input, :111,:242). */
 int f2n_adam_step(void* stream, int n, float* param, const float* grad, float grad_scale, int grad_round_h16,
                   float* exp_avg, float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, void* param_h_or_null);
+                  float weight_decay, void* param_h_or_null, const int32_t* skip_flag /*device, or NULL*/);
 /* h16 gradient table produced by f2n_hash_bwd / f2n_field_bwd (true gradient = float(grad_h) * grad_scale,
  * grad_scale = 1/128): fuses the fp16->fp32 cast, the /128 (Hash3DAnchored.cu:232), Adam, the fp32->fp16
  * refresh of the table (Hash3DAnchored.cu:186) and the re-zeroing of the gradient (:222) in one pass. */
 int f2n_adam_step_h16grad(void* stream, int n, float* param, void* grad_h, float grad_scale, float* exp_avg,
                           float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, void* param_h, int zero_grad);
+                          float weight_decay, void* param_h, int zero_grad, const int32_t* skip_flag /*device, or NULL*/);
+/* skip_flag (both steps): when *skip_flag != 0 on the device the update is dropped -- parameters and moments stay,
+ * an h16 gradient table is still cleared when zero_grad is set.  This is the `continue` of ExpRunner.cpp:131-134
+ * without a host round trip between the finiteness check and the optimiser. */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Training loss -- replaces the ~30 ATen element-wise / reduction ops (and their autograd mirror images) of
+ * ExpRunner::Train (ExpRunner.cpp:95-120) by one pass that returns the loss terms AND their gradients:
+ *   color = mean sqrt((pred-gt)^2 + 1e-4), disp = mean disparity^2, var = mean sqrt(sampled_var + 1e-2),
+ *   tv = mean (edge_feats[:,0,:] - edge_feats[:,1,:])^2, loss = color + var_w*var + disp_w*disp + tv_w*tv.
+ * out_losses [8] = {loss, color, var, disp, tv, mse, 0, 0}.  Gradients of `loss`: dcolors [R,3], ddisparity [R],
+ * dvar [R], dedge_feats [E,2,feat_dim]; any gradient pointer may be NULL, and disparity / sampled_var /
+ * edge_feats may be NULL (term = 0), as on the reference's no-sample early return (Renderer.cpp:83-97).
+ * ------------------------------------------------------------------------------------------------- */
+int f2n_train_loss(void* stream, int n_rays, const float* pred_colors /*[R,3]*/, const float* gt_colors /*[R,3]*/,
+                   const float* disparity /*[R]*/, const float* sampled_var /*[R]*/, int n_edge, int feat_dim,
+                   const float* edge_feats /*[E,2,feat_dim]*/, float var_w, float disp_w, float tv_w,
+                   float* out_losses /*[8]*/, float* dcolors, float* ddisparity, float* dvar, float* dedge_feats);
+
+/* Gradient finiteness check of the two MLPs (Field/TCNNWP.cpp:234-240), device side:
+ * flags[0] = a has a non-finite value, flags[1] = b has one, flags[2] = either (the optimiser's skip_flag). */
+int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags /*[3]*/);
 
 #ifdef __cplusplus
 }

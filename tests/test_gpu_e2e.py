@@ -144,6 +144,18 @@ def test_config1_end_to_end_parity(rt, fox_state):
     assert cos > 0.999, cos
     assert rel_err(gt_tab, rt_tab) <= 5e-2, rel_err(gt_tab, rt_tab)
 
+    # --- the untaped train step (what bench.py times) and the autograd-taped one are the same computation ---
+    stats_a = runner.train_step_autograd(d[0], d[1], d[2], d[3], d[4], False)
+    ga = {k: v.cpu().numpy() for k, v in runner.grads().items()}
+    assert stats_a["n_samples"] == stats["n_samples"] and stats_a["n_meaningful"] == stats["n_meaningful"]
+    assert abs(float(stats_a["loss"]) - float(stats["loss"])) <= 1e-6 * max(1.0, abs(float(stats["loss"])))
+    assert abs(float(stats_a["mse"]) - float(stats["mse"])) <= 1e-6
+    for k in ("color_mlp", "field_mlp", "app_emb"):
+        assert rel_err(g[k], ga[k]) <= 2e-3, (k, rel_err(g[k], ga[k]))
+    ta = ga["feat_pool"].reshape(-1)
+    assert float((gt_tab * ta).sum() / (np.linalg.norm(gt_tab) * np.linalg.norm(ta))) > 0.99999
+    assert rel_err(gt_tab, ta) <= 1e-2, rel_err(gt_tab, ta)
+
 
 def test_validate_render_and_training_sanity(rt, fox_state):
     st = fox_state

@@ -657,6 +657,64 @@ def test_adam(hip):
     assert (N(tz) == 1).all()
 
 
+def test_train_loss_and_gradients(hip):
+    """f2n_train_loss against the reference's formulas (ExpRunner.cpp:95-120) evaluated in float64."""
+    rng = np.random.default_rng(17)
+    R, E, D = 777, 300, 16
+    pred = rng.random((R, 3), dtype=F32); gt = rng.random((R, 3), dtype=F32)
+    disp = rng.random(R, dtype=F32) * F32(3.); var = rng.random(R, dtype=F32) * F32(.2)
+    edge = rng.standard_normal((E, 2, D)).astype(F32)
+    var_w, disp_w, tv_w = 0.01, 0.0005, 0.1
+    losses = torch.zeros(8, device=DEV)
+    dc = torch.zeros((R, 3), device=DEV); dd = torch.zeros(R, device=DEV); dv = torch.zeros(R, device=DEV)
+    de = torch.zeros((E, 2, D), device=DEV)
+    hip.train_loss(R, T(pred), T(gt), T(disp), T(var), E, D, T(edge), var_w, disp_w, tv_w, losses, dc, dd, dv, de)
+    p64, g64 = pred.astype(np.float64), gt.astype(np.float64)
+    r = np.sqrt((p64 - g64) ** 2 + 1e-4)
+    color, mse = r.mean(), ((p64 - g64) ** 2).mean()
+    dl, vl = (disp.astype(np.float64) ** 2).mean(), np.sqrt(var.astype(np.float64) + 1e-2).mean()
+    diff = edge[:, 0].astype(np.float64) - edge[:, 1].astype(np.float64)
+    tv = (diff ** 2).mean()
+    want = np.array([color + var_w * vl + disp_w * dl + tv_w * tv, color, vl, dl, tv, mse])
+    assert np.abs(N(losses)[:6] - want).max() <= 2e-6 * np.abs(want).max(), (N(losses), want)
+    close = lambda a, b: np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+    assert close(N(dc), (p64 - g64) / r / (3 * R))
+    assert close(N(dd), disp_w * 2 * disp.astype(np.float64) / R)
+    assert close(N(dv), var_w * .5 / np.sqrt(var.astype(np.float64) + 1e-2) / R)
+    assert close(N(de)[:, 0], tv_w * 2 * diff / (E * D)) and close(N(de)[:, 1], -tv_w * 2 * diff / (E * D))
+    # the no-sample case of Renderer.cpp:83-97: colour term only
+    hip.train_loss(R, T(pred), T(gt), None, None, 0, 0, None, var_w, disp_w, tv_w, losses, None, None, None, None)
+    assert abs(float(losses[0]) - color) <= 2e-6 * color and float(losses[2]) == 0.0 and float(losses[4]) == 0.0
+
+
+def test_nonfinite_flags_and_skipped_adam(hip):
+    rng = np.random.default_rng(19)
+    a = rng.standard_normal(3072).astype(F32); b = rng.standard_normal(7168).astype(F32)
+    flags = torch.full((3,), 7, dtype=torch.int32, device=DEV)
+    hip.nonfinite_flags(a.size, T(a), b.size, T(b), flags)
+    assert N(flags).tolist() == [0, 0, 0]
+    b2 = b.copy(); b2[5000] = np.inf
+    hip.nonfinite_flags(a.size, T(a), b.size, T(b2), flags)
+    assert N(flags).tolist() == [0, 1, 1]
+    a2 = a.copy(); a2[-1] = np.nan
+    hip.nonfinite_flags(a.size, T(a2), b.size, T(b), flags)
+    assert N(flags).tolist() == [1, 0, 1]
+    # Adam predicated on flags[2]: nothing moves, but a consumed h16 gradient table is still cleared
+    n = 4096
+    p = rng.standard_normal(n).astype(F32); g = rng.standard_normal(n).astype(F32)
+    m = rng.standard_normal(n).astype(F32); v = rng.random(n, dtype=F32)
+    tp, tm, tv = T(p), T(m), T(v)
+    ph = torch.ones(n, dtype=torch.float16, device=DEV)
+    hip.adam_step(n, tp, T(g), 1.0, False, tm, tv, 2, 1e-2, 0.9, 0.99, 1e-15, 1e-6, ph, flags[2:])
+    assert_same(N(tp), p); assert_same(N(tm), m); assert_same(N(tv), v); assert (N(ph) == 1).all()
+    tg = T(g.astype(np.float16))
+    hip.adam_step_h16grad(n, tp, tg, 1.0 / 128, tm, tv, 2, 1e-2, 0.9, 0.99, 1e-15, 0.0, ph, True, flags[2:])
+    assert_same(N(tp), p); assert_same(N(tm), m); assert (N(tg).view(np.uint16) == 0).all() and (N(ph) == 1).all()
+    flags.zero_()
+    hip.adam_step(n, tp, T(g), 1.0, False, tm, tv, 2, 1e-2, 0.9, 0.99, 1e-15, 1e-6, ph, flags[2:])
+    assert (N(tp) != p).any()
+
+
 def test_errors_are_loud(hip):
     x = torch.zeros((4, 32), device=DEV)
     with pytest.raises(Exception):
