@@ -137,11 +137,11 @@ def hash_fwd(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool,
 
 
 def hash_bwd(n, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts, pts_are_warped, volume_idx,
-             vol_stride, grad_in_h, grad_table_h):
+             vol_stride, grad_in_h, grad_table_h, level_entries=0):
     _ck(lib().f2n_hash_bwd(_stream(), _i(n), _i(n_volumes), _p(prim_pool, "i32"), _p(local_idx, "i32"),
                            _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"), _p(pts, "f32"),
                            _i(int(pts_are_warped)), _p(volume_idx, "i32"), _i(vol_stride), _p(grad_in_h, "h16"),
-                           _p(grad_table_h, "h16")), "f2n_hash_bwd")
+                           _p(grad_table_h, "h16"), _i(level_entries)), "f2n_hash_bwd")
 
 
 def mlp_n_params(d_in, d_hidden, n_hidden):
@@ -182,12 +182,12 @@ def field_fwd_cached(n, n_cache, src_rows, x_cache_h, mlp_params_h, out_feat, ou
 
 
 def field_bwd(n, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped, volume_idx, vol_stride,
-              mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_scaled, grad_table_h):
+              mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_scaled, grad_table_h, level_entries=0):
     _ck(lib().f2n_field_bwd(_stream(), _i(n), _i(n_volumes), _p(prim_pool, "i32"), _p(local_idx, "i32"),
                             _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"), _p(pts_warped, "f32"),
                             _p(volume_idx, "i32"), _i(vol_stride), _p(mlp_params_h, "h16"), _p(saved_x_h, "h16"),
-                            _p(dfeat, "f32"), _f(loss_scale), _p(dparams_scaled, "f32"), _p(grad_table_h, "h16")),
-        "f2n_field_bwd")
+                            _p(dfeat, "f32"), _f(loss_scale), _p(dparams_scaled, "f32"), _p(grad_table_h, "h16"),
+                            _i(level_entries)), "f2n_field_bwd")
 
 
 # ---------------------------------------------------------------- shader

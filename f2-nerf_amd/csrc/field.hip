@@ -164,40 +164,24 @@ __device__ __forceinline__ int f2n_row_shl1_i(int v, int fill) {  // lane c read
   return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xF, 0xF, false);
 }
 
-// Scatters this lane's four levels: gx[2j + ch] is the f16 (loss-scaled) gradient of feature sigma(g, 2j+ch).
-// global_atomic_pk_add_f16 == the reference's atomicAdd(__half2*) (Hash3DAnchored.cu:150-151).
-//
-// The chip retires ~21 G lane-atomics/s whatever their flavour, placement or locality (tools/atomic_probe.py), so the
-// scatter is priced by its atomic COUNT.  The 16 lanes of a row hold 16 consecutive samples of a ray, ~1/512 apart
-// in [0,1] warp space, while a cell of level l is 2^-(3+7l/15) wide: at the coarse and middle levels most of the row
-// sits in one or two cells.  Runs of equal (cell, transform) are therefore summed inside the row first -- a
-// segmented Hillis-Steele scan over DPP row shifts, in fp32 -- and only the last lane of each run issues the 8
-// atomics, with the run total rounded to f16 once (the reference rounds every addend and every partial sum; this is
-// the same sum with fewer roundings).  Contributions that round to (0, 0) are not issued at all: adding zero is a
-// no-op.  EVERY lane of the wave must call this (invalid samples pass gx = 0).
-__device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2nLevelTab& lt, half_t* __restrict__ grad_table,
-                                                 const float* p01, int vol, int g, int c, half8_t gx) {
+// Run combining.  The 16 lanes of a row hold 16 consecutive samples of a ray, a few 1/100 apart in [0,1] warp space,
+// while a cell of level l is 2^-(3+7l/15) wide: at the coarse levels most of a row sits in one or two cells.  Runs of
+// equal (cell, transform) are summed inside the row -- a segmented Hillis-Steele scan over DPP row shifts, in fp32 --
+// and only the last lane of each run owns a contribution: v[2d + ch] = run total for corner d, channel ch (the
+// reference rounds every addend to f16 and every partial sum; this is the same sum with fewer roundings).
+// Returns true on the last lane of a run.  EVERY lane of the wave must call this (lanes without a sample pass 0).
+__device__ __forceinline__ bool f2n_combine_runs(const F2nCell& cell, int vol, int c, float g0, float g1, float* v) {
+  const bool same_as_prev = c > 0 && f2n_row_shr_i<1>((int) cell.p[0], -1) == (int) cell.p[0] &&
+                            f2n_row_shr_i<1>((int) cell.p[1], -1) == (int) cell.p[1] &&
+                            f2n_row_shr_i<1>((int) cell.p[2], -1) == (int) cell.p[2] && f2n_row_shr_i<1>(vol, -1) == vol;
+  const int head = same_as_prev ? 0 : 1;
+  const bool tail = f2n_row_shl1_i(head, 1) != 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const float g0 = (float) gx[2 * j], g1 = (float) gx[2 * j + 1];
-    if (__ballot(g0 != 0.f || g1 != 0.f) == 0ull) continue;  // :149, wave-uniform
-    const int l = f2n_level_of(g, j);
-    const int tf = l * h.n_volumes + vol;
-    F2nCell cell;
-    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
-    // run heads: first lane of the row, or a different cell / transform than the lane before
-    const bool same_as_prev = c > 0 && f2n_row_shr_i<1>((int) cell.p[0], -1) == (int) cell.p[0] &&
-                              f2n_row_shr_i<1>((int) cell.p[1], -1) == (int) cell.p[1] &&
-                              f2n_row_shr_i<1>((int) cell.p[2], -1) == (int) cell.p[2] && f2n_row_shr_i<1>(vol, -1) == vol;
-    int head = same_as_prev ? 0 : 1;
-    const bool tail = f2n_row_shl1_i(head, 1) != 0;
-    float v[16];
-#pragma unroll
-    for (int d = 0; d < 8; d++) {
-      v[2 * d] = g0 * cell.w[d];
-      v[2 * d + 1] = g1 * cell.w[d];
-    }
-    int f = head;
+  for (int d = 0; d < 8; d++) {
+    v[2 * d] = g0 * cell.w[d];
+    v[2 * d + 1] = g1 * cell.w[d];
+  }
+  int f = head;
 #define F2N_SEG_STEP(K)                                   \
   {                                                       \
     const int tf_ = f2n_row_shr_i<K>(f, 1);               \
@@ -208,12 +192,32 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
     }                                                     \
     if (c >= K) f |= tf_;                                 \
   }
-    F2N_SEG_STEP(1)
-    F2N_SEG_STEP(2)
-    F2N_SEG_STEP(4)
-    F2N_SEG_STEP(8)
+  F2N_SEG_STEP(1)
+  F2N_SEG_STEP(2)
+  F2N_SEG_STEP(4)
+  F2N_SEG_STEP(8)
 #undef F2N_SEG_STEP
-    if (tail) {
+  return tail;
+}
+
+// Direct scatter of this lane's four levels with packed-f16 global atomics (== the reference's atomicAdd(__half2*),
+// Hash3DAnchored.cu:150-151): gx[2j + ch] is the f16 (loss-scaled) gradient of feature sigma(g, 2j+ch).  The chip
+// retires ~21 G lane-atomics/s in total whatever their flavour, scope, placement or locality (one XCD alone reaches
+// 16.5 G/s: a shared, memory-side unit -- tools/atomic_probe.py), so this path is only used for small batches; large
+// ones go through the owner-binned pipeline below.  Contributions that round to (0, 0) are not issued: adding zero is
+// a no-op.
+__device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2nLevelTab& lt, half_t* __restrict__ grad_table,
+                                                 const float* p01, int vol, int g, int c, half8_t gx) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float g0 = (float) gx[2 * j], g1 = (float) gx[2 * j + 1];
+    if (__ballot(g0 != 0.f || g1 != 0.f) == 0ull) continue;  // :149, wave-uniform
+    const int l = f2n_level_of(g, j);
+    const int tf = l * h.n_volumes + vol;
+    F2nCell cell;
+    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
+    float v[16];
+    if (f2n_combine_runs(cell, vol, c, g0, g1, v)) {
       half2_t* base = (half2_t*) (grad_table + lt.base[l]);
 #pragma unroll
       for (int d = 0; d < 8; d++) {
@@ -221,6 +225,122 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
         if ((float) val[0] != 0.f || (float) val[1] != 0.f)
           __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (base + cell.pos[d]), val);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Owner-binned scatter (large batches).  Measured on MI355X: global atomics cap at ~21 G/s chip-wide, while plain
+// read-modify-write out of an XCD's own L2 runs at ~135 G/s and LDS atomics are cheaper still.  So contributions are
+// not applied where they are produced.  (1) hash_bin_kernel: block (level l, chunk B) walks its samples, combines
+// runs, and appends every non-zero contribution as an 8-byte record {entry index inside its 8192-entry slice,
+// packed f16 pair} to the private queue segment (l, slice, B) -- slots come from LDS counters, so no global atomic and
+// no synchronisation between blocks.  (2) hash_bin_accumulate_kernel: one owner block per (level, slice) adds all
+// records of its slice into a 64 KB fp32 LDS image (ds_add_f32) and then adds the image to the f16 gradient table
+// with plain loads and stores.  Level l addresses halves [l*L, l*L + 2L): equal-parity levels are disjoint, so the
+// owners run in two launches (even levels, then odd) and no two blocks ever touch the same table entry.
+// A full segment (cannot happen for hashed positions short of adversarial input) falls back to the atomic.
+// ---------------------------------------------------------------------------------------------------
+#define F2N_BIN_SHIFT 13
+#define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
+#define F2N_BIN_NB 64         // sample chunks (producer blocks) per level
+#define F2N_BIN_MAX_BINS 256  // tables up to 2^21 entries per level
+
+struct F2nBinQueues {
+  uint2* rec;      // [16 levels][n_bins][NB][cap]
+  int32_t* cnt;    // [16 levels][n_bins][NB]
+  int cap, n_bins;
+};
+
+__global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHashArgs h, const int32_t* __restrict__ local_idx,
+                                                       const int32_t* __restrict__ local_size,
+                                                       const float* __restrict__ level_scale, const float* __restrict__ pts,
+                                                       int pts_are_warped, const int32_t* __restrict__ volume_idx, int vol_stride,
+                                                       const half_t* __restrict__ gx, long gx_sample_stride,
+                                                       long gx_pair_stride, F2nBinQueues q, half_t* __restrict__ grad_table) {
+  __shared__ F2nLevelTab lt;
+  __shared__ int s_cnt[F2N_BIN_MAX_BINS];
+  const int tid = threadIdx.x, c = tid & 15;
+  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+  for (int i = tid; i < q.n_bins; i += 256) s_cnt[i] = 0;
+  __syncthreads();
+  const int l = blockIdx.x % F2N_N_LEVELS, B = blockIdx.x / F2N_N_LEVELS;
+  const int s_begin = B * chunk, s_end = min(n, s_begin + chunk);
+  const half_t* gl = gx + (size_t) (l >> 1) * gx_pair_stride + 2 * (l & 1);
+  half2_t* tab = (half2_t*) (grad_table + lt.base[l]);
+  for (int base = s_begin; base < s_end; base += 256) {
+    const int s = base + tid;
+    const bool valid = s < s_end;
+    const int sc = valid ? s : s_end - 1;
+    const half2_t gpair = *(const half2_t*) (gl + (size_t) sc * gx_sample_stride);
+    const float g0 = valid ? (float) gpair[0] : 0.f, g1 = valid ? (float) gpair[1] : 0.f;
+    if (__ballot(g0 != 0.f || g1 != 0.f) == 0ull) continue;  // Hash3DAnchored.cu:149, wave-uniform
+    float p01[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float p = pts[3 * (size_t) sc + k];
+      p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
+    }
+    const int vol = volume_idx[(size_t) sc * vol_stride];
+    const int tf = l * h.n_volumes + vol;
+    F2nCell cell;
+    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
+    float v[16];
+    if (f2n_combine_runs(cell, vol, c, g0, g1, v)) {
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        const half2_t val = {(half_t) v[2 * d], (half_t) v[2 * d + 1]};
+        if ((float) val[0] != 0.f || (float) val[1] != 0.f) {
+          const uint32_t pos = cell.pos[d];
+          const int bin = (int) (pos >> F2N_BIN_SHIFT);
+          const int slot = atomicAdd(&s_cnt[bin], 1);
+          if (slot < q.cap) {
+            uint2 r;
+            r.x = pos & (F2N_BIN_ENTRIES - 1);
+            r.y = __builtin_bit_cast(uint32_t, val);
+            q.rec[(((size_t) l * q.n_bins + bin) * F2N_BIN_NB + B) * q.cap + slot] = r;
+          } else {
+            __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (tab + pos), val);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) l * q.n_bins + i) * F2N_BIN_NB + B] = min(s_cnt[i], q.cap);
+}
+
+__global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(int parity, F2nBinQueues q, const int32_t* __restrict__ local_idx,
+                                                                  const int32_t* __restrict__ local_size,
+                                                                  half_t* __restrict__ grad_table) {
+  __shared__ float s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp32 image of this block's slice
+  const int tid = threadIdx.x;
+  const int l = 2 * (blockIdx.x / q.n_bins) + parity, bin = blockIdx.x % q.n_bins;
+  for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  const size_t seg0 = ((size_t) l * q.n_bins + bin) * F2N_BIN_NB;
+  int total = 0;
+  for (int B = 0; B < F2N_BIN_NB; B++) {
+    const int cnt = q.cnt[seg0 + B];
+    total += cnt;
+    const uint2* r = q.rec + (seg0 + B) * q.cap;
+    for (int i = tid; i < cnt; i += 256) {
+      const uint2 rec = r[i];
+      const half2_t val = __builtin_bit_cast(half2_t, rec.y);
+      atomicAdd(&s_acc[2 * rec.x], (float) val[0]);
+      atomicAdd(&s_acc[2 * rec.x + 1], (float) val[1]);
+    }
+  }
+  if (total == 0) return;  // block-uniform: nothing landed in this slice
+  __syncthreads();
+  const uint32_t size = (uint32_t) local_size[l];
+  half2_t* tab = (half2_t*) (grad_table + local_idx[l]);
+  for (int e = tid; e < F2N_BIN_ENTRIES; e += 256) {
+    const uint32_t pos = (uint32_t) bin * F2N_BIN_ENTRIES + e;
+    const float a0 = s_acc[2 * e], a1 = s_acc[2 * e + 1];
+    if (pos < size && (a0 != 0.f || a1 != 0.f)) {
+      const half2_t old = tab[pos];
+      tab[pos] = half2_t{(half_t) ((float) old[0] + a0), (half_t) ((float) old[1] + a1)};
     }
   }
 }
@@ -339,7 +459,7 @@ __global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
     const int32_t* __restrict__ volume_idx, int vol_stride, const half_t* __restrict__ params,
     const half_t* __restrict__ x_h, const float* __restrict__ x_f32, const float* __restrict__ dy, float loss_scale,
-    float* __restrict__ dparams, float* __restrict__ dx_f32, half_t* __restrict__ grad_table) {
+    float* __restrict__ dparams, float* __restrict__ dx_f32, half_t* __restrict__ grad_table, half_t* __restrict__ dx_planes) {
   __shared__ F2nBwdSmem<NH> sm;
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -379,13 +499,20 @@ __global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
           }
         }
       }
-      if (DO_HASH) {  // every lane takes part in the row-level combining; out-of-range samples carry zero gradient
-        float p01[3];
-        f2n_load_point(pts, sc, pts_are_warped != 0, p01);
-        const int vol = volume_idx[(size_t) sc * vol_stride];
+      if (DO_HASH) {
         half8_t gx = f2n_pack<false>(hb[half].dxT[0], hb[half].dxT[1]);  // (dL/dx * 128) -> f16, Hash3DAnchored.cu:220
-        if (!valid) gx = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        f2n_scatter_frag(h, lt, grad_table, p01, vol, g, c, gx);
+        if (dx_planes != nullptr) {  // large batches: the owner-binned scatter consumes f16 planes [8][n][4]
+          if (valid) {
+            *(half4_t*) (dx_planes + ((size_t) g * n + s) * 4) = __builtin_shufflevector(gx, gx, 0, 1, 2, 3);
+            *(half4_t*) (dx_planes + ((size_t) (4 + g) * n + s) * 4) = __builtin_shufflevector(gx, gx, 4, 5, 6, 7);
+          }
+        } else {  // every lane takes part in the row-level combining; out-of-range samples carry zero gradient
+          float p01[3];
+          f2n_load_point(pts, sc, pts_are_warped != 0, p01);
+          const int vol = volume_idx[(size_t) sc * vol_stride];
+          if (!valid) gx = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+          f2n_scatter_frag(h, lt, grad_table, p01, vol, g, c, gx);
+        }
       }
     }
     f2n_mlp_accumulate_dw<NH>(hb[0], hb[1], acc);
@@ -468,6 +595,32 @@ static inline bool f2n_mlp_shape_ok(int d_in, int d_hidden, int n_hidden) {
   return d_in == F2N_D_IN && d_hidden == F2N_D_HID && (n_hidden == 1 || n_hidden == 2);
 }
 
+#define F2N_BIN_MIN_N 32768  // below this the direct atomics cost less than the two extra launches
+
+// Owner-binned scatter of f16 gradients gx (pair (l, ch) of sample s at gx[s*ss + (l>>1)*ps + 2*(l&1) + ch]).
+static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const int32_t* local_idx, const int32_t* local_size,
+                              const float* level_scale, const float* pts, int warped, const int32_t* volume_idx, int vol_stride,
+                              const half_t* gx, long ss, long ps, half_t* grad_table, int level_entries) {
+  F2nBinQueues q;
+  q.n_bins = (level_entries + F2N_BIN_ENTRIES - 1) >> F2N_BIN_SHIFT;
+  const int chunk = (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255;
+  q.cap = (int) (1.25 * 8.0 * (double) chunk / (double) q.n_bins) + 256;
+  const size_t n_seg = (size_t) F2N_N_LEVELS * q.n_bins * F2N_BIN_NB;
+  q.rec = (uint2*) f2n_ws_get(F2N_WS_BIN_REC, n_seg * q.cap * sizeof(uint2));
+  q.cnt = (int32_t*) f2n_ws_get(F2N_WS_BIN_CNT, n_seg * sizeof(int32_t));
+  if (q.rec == nullptr || q.cnt == nullptr) return F2N_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
+                     level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, q, grad_table);
+  for (int parity = 0; parity < 2; parity++)
+    hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS / 2) * q.n_bins), dim3(256), 0, st, parity, q, local_idx,
+                       local_size, grad_table);
+  return f2n_launch_status();
+}
+
+static inline bool f2n_use_bins(int n, int level_entries) {
+  return n >= F2N_BIN_MIN_N && level_entries > 0 && ((level_entries + F2N_BIN_ENTRIES - 1) >> F2N_BIN_SHIFT) <= F2N_BIN_MAX_BINS;
+}
+
 extern "C" {
 
 int f2n_mlp_n_params(int d_in, int d_hidden, int n_hidden) {
@@ -505,10 +658,14 @@ int f2n_hash_fwd(void* stream, int n, int n_volumes, const void* table_h, const 
 
 int f2n_hash_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
                  const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts,
-                 int pts_are_warped, const int32_t* volume_idx, int vol_stride, const void* grad_in_h, void* grad_table_h) {
-  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
+                 int pts_are_warped, const int32_t* volume_idx, int vol_stride, const void* grad_in_h, void* grad_table_h,
+                 int level_entries) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1 || level_entries < 0) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
+  if (f2n_use_bins(n, level_entries))  // row-major [n][32]: pair (l, ch) at 32*s + 2*l + ch
+    return f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx,
+                              vol_stride, (const half_t*) grad_in_h, F2N_D_IN, 4, (half_t*) grad_table_h, level_entries);
   hipLaunchKernelGGL(hash_bwd_kernel, dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, h,
                      local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride,
                      (const half_t*) grad_in_h, (half_t*) grad_table_h);
@@ -542,10 +699,10 @@ int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_hidden == 1)
     hipLaunchKernelGGL((field_bwd_kernel<1, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr);
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr);
   else
     hipLaunchKernelGGL((field_bwd_kernel<2, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr);
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   return f2n_reduce_partials(stream, n_params, (int) grid.x, partials, dparams_f32_scaled);
@@ -595,20 +752,30 @@ int f2n_field_fwd_cached(void* stream, int n, int n_cache, const int32_t* src_ro
 int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
                   const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts_warped,
                   const int32_t* volume_idx, int vol_stride, const void* mlp_params_h, const void* saved_x_h,
-                  const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h) {
-  if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f)) return F2N_ERR_INVALID_ARG;
+                  const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h, int level_entries) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f) || level_entries < 0) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
   const unsigned blocks = f2n_bwd_grid((n + 31) / 32);
   const int n_params = f2n_mlp_n_params(F2N_D_IN, F2N_D_HID, 1);
   float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) blocks * n_params);
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
+  half_t* dx_planes = nullptr;
+  if (f2n_use_bins(n, level_entries)) {
+    dx_planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, sizeof(half_t) * 32 * (size_t) n);
+    if (dx_planes == nullptr) return F2N_ERR_INVALID_ARG;
+  }
   hipLaunchKernelGGL((field_bwd_kernel<1, true>), dim3(blocks), dim3(F2N_BWD_THREADS), 0,
                      (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
                      (const half_t*) mlp_params_h, (const half_t*) saved_x_h, nullptr, dfeat, loss_scale,
-                     partials, nullptr, (half_t*) grad_table_h);
+                     partials, nullptr, (half_t*) grad_table_h, dx_planes);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
+  if (dx_planes != nullptr) {  // planes [8][n][4]: pair (l, ch) at (l>>1)*4n + 4*s + 2*(l&1) + ch
+    rc = f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
+                            dx_planes, 4, 4 * (long) n, (half_t*) grad_table_h, level_entries);
+    if (rc != F2N_OK) return rc;
+  }
   return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
 }
 

@@ -192,7 +192,7 @@ void Hash3DAnchored::BackwardRaw(const Tensor& points, const Tensor& anchors, in
   F2N_TIMED_CALL("field_bwd", f2n_field_bwd(CurStream(), n, n_volumes_, I32P(prim_pool_), I32P(feat_local_idx_),
                          I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(points), I32P(anchors), stride,
                          VoidP(mlp_->params_h_), VoidP(saved_x), F32P(dfeat), mlp_->loss_scale_, F32P(mlp_->grad_scaled_),
-                         VoidP(grad_h_)));
+                         VoidP(grad_h_), pool_size_ / N_LEVELS));
 }
 
 Tensor Hash3DAnchored::AnchoredQuery(const Tensor& points, const Tensor& anchors) {  // Hash3DAnchored.cpp:84-99

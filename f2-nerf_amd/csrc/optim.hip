@@ -139,14 +139,18 @@ __global__ __launch_bounds__(256) void train_loss_kernel(F2nLossArgs a, float* _
   if (threadIdx.x < F2N_LOSS_TERMS) partials[blockIdx.x * F2N_LOSS_TERMS + threadIdx.x] = s_red[threadIdx.x][0];
 }
 
-__global__ void train_loss_finalize_kernel(F2nLossArgs a, int n_blocks, const float* __restrict__ partials, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void train_loss_finalize_kernel(F2nLossArgs a, int n_blocks, const float* __restrict__ partials,
+                                                                 float* __restrict__ out) {
   float t[F2N_LOSS_TERMS];
-  for (int k = 0; k < F2N_LOSS_TERMS; k++) {
+#pragma unroll
+  for (int k = 0; k < F2N_LOSS_TERMS; k++) {  // one wave: lane b owns block b's partial, fixed butterfly order
     float s = 0.f;
-    for (int b = 0; b < n_blocks; b++) s += partials[b * F2N_LOSS_TERMS + k];
+    for (int b = threadIdx.x; b < n_blocks; b += 64) s += partials[b * F2N_LOSS_TERMS + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     t[k] = s;
   }
+  if (threadIdx.x != 0) return;
   const float n_col = (float) max(3 * a.n_rays, 1), n_ray = (float) max(a.n_rays, 1), n_tv = (float) max(a.n_edge * a.feat_dim, 1);
   const float color = t[0] / n_col, var = a.var != nullptr ? t[1] / n_ray : 0.f, disp = a.disp != nullptr ? t[2] / n_ray : 0.f;
   const float tv = a.edge != nullptr ? t[3] / n_tv : 0.f;

@@ -34,16 +34,29 @@ void* f2n_ws_get(int slot, size_t bytes) {
   return s.ptr;
 }
 
-// out[i] += sum_b partials[b * n + i]
-__global__ void f2n_reduce_partials_kernel(int n, int n_blocks, const float* __restrict__ partials, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < n_blocks; b++) s += partials[(size_t) b * n + i];
-  out[i] += s;
+// out[i] += sum_b partials[b * n + i].  A block handles 64 parameters x 4 groups of source blocks; every thread keeps
+// 8 independent loads in flight (the sequential one-thread-per-parameter loop was a 256-deep chain of dependent
+// ~0.25 us reads: 60 us per call, three calls per training step).
+__global__ __launch_bounds__(256) void f2n_reduce_partials_kernel(int n, int n_blocks, const float* __restrict__ partials,
+                                                                  float* __restrict__ out) {
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    int b = grp;
+    for (; b + 28 < n_blocks; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += partials[(size_t) (b + 4 * u) * n + i];
+    }
+    for (; b < n_blocks; b += 4) acc[0] += partials[(size_t) b * n + i];
+  }
+  s_part[grp][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (grp == 0 && i < n) out[i] += (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
 }
 
 int f2n_reduce_partials(void* stream, int n, int n_blocks, const float* partials, float* out) {
-  hipLaunchKernelGGL(f2n_reduce_partials_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n, n_blocks, partials, out);
+  hipLaunchKernelGGL(f2n_reduce_partials_kernel, dim3(f2n_div_up(n, 64)), dim3(256), 0, (hipStream_t) stream, n, n_blocks, partials, out);
   return f2n_launch_status();
 }

@@ -129,13 +129,17 @@ int f2n_hash_fwd(void* stream, int n, int n_volumes, const void* table_h, const 
                  int pts_are_warped, const int32_t* volume_idx, int vol_stride, void* out_h /*[n,32] h16*/);
 
 /* grad_in_h: dL/dfeat already scaled by 128 and rounded to h16 (Hash3DAnchored.cu:220).  grad_table_h is
- * ACCUMULATED into with packed-h16 atomics (global_atomic_pk_add_f16 == the reference's half2 atomicAdd,
- * :151) and must be zeroed by the caller (:222).  The /128 and fp32 widening of :232 are left to the
- * optimiser step (f2n_adam_step_h16grad). */
+ * ACCUMULATED into (the reference's half2 atomicAdd, :151) and must be zeroed by the caller (:222).  The /128 and
+ * fp32 widening of :232 are left to the optimiser step (f2n_adam_step_h16grad).
+ * level_entries: HOST copy of max_l local_size[l] (the device array cannot be read without a sync).  > 0 lets large
+ * batches use the owner-binned scatter (records binned per 8192-entry slice of a level, summed in LDS in fp32,
+ * added to the table with plain stores: no global atomics); it requires that levels of equal parity address
+ * disjoint table ranges, which holds for the reference's layout local_idx[l] = l * local_size (Hash3DAnchored.cpp:60-70).
+ * 0 = always packed-h16 global atomics, no layout requirement. */
 int f2n_hash_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
                  const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts,
                  int pts_are_warped, const int32_t* volume_idx, int vol_stride, const void* grad_in_h /*[n,32]*/,
-                 void* grad_table_h);
+                 void* grad_table_h, int level_entries);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fully-fused MLP -- replaces the tcnn::cpp::Module surface used by Field/TCNNWP.cpp:94-97,150-154,
@@ -182,13 +186,14 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
 int f2n_field_fwd_cached(void* stream, int n, int n_cache, const int32_t* src_rows, const void* x_cache_h,
                          const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h);
 
-/* Backward of the fused field: MLP backward (dparams accumulated, scaled domain) chained straight into
- * the hash scatter; dL/dx never touches HBM.  dfeat fp32 [n,16]. */
+/* Backward of the fused field: MLP backward (dparams accumulated, scaled domain) chained into the hash scatter.
+ * dfeat fp32 [n,16].  level_entries as in f2n_hash_bwd (0: dL/dx goes straight from registers into global atomics;
+ * > 0 and a large batch: through 64 B/sample of f16 workspace into the owner-binned scatter). */
 int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, const int32_t* local_idx,
                   const int32_t* local_size, const float* bias_pool, const float* level_scale,
                   const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
                   const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled,
-                  void* grad_table_h);
+                  void* grad_table_h, int level_entries);
 
 /* ---------------------------------------------------------------------------------------------------
  * Shader -- replaces SHShader::Query (Shader/SHShader.cpp:23-29) and SHKenerl (Shader/SHShader.cu:10-118).

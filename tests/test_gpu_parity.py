@@ -319,6 +319,42 @@ def test_hash_backward(hip, fox_state):
         assert mism <= 4, mism  # two corners of one level may hash to the same entry (order-dependent rounding)
 
 
+def test_hash_backward_owner_binned(hip, fox_state):
+    """Large batches take the owner-binned scatter (queues -> LDS accumulation -> plain stores).  It must agree with
+    the direct packed-f16 atomics of the small-batch path and with the fp32-accumulated oracle; rays of consecutive,
+    closely spaced samples exercise the in-row run combining, a short ragged tail the chunk boundaries."""
+    rng = np.random.default_rng(12)
+    log2 = 14
+    grid = make_grid(fox_state, rng, log2)
+    n = 40000 + 37
+    n_rays = n // 50 + 1
+    o = rng.random((n_rays, 3), dtype=F32) * F32(.6) + F32(.2)
+    dvec = rng.standard_normal((n_rays, 3)).astype(F32); dvec /= np.linalg.norm(dvec, axis=1, keepdims=True)
+    ray = np.repeat(np.arange(n_rays), 50)[:n]
+    step = (np.arange(n) % 50).astype(F32) * F32(0.004)
+    q = np.clip(o[ray] + dvec[ray] * step[:, None], 0.01, 0.99).astype(F32)
+    vol = rng.integers(0, grid.n_volumes, n_rays).astype(np.int32)[ray]
+    gin = (rng.standard_normal((n, 32)) * 0.05).astype(np.float16)
+    gin[rng.random(n) < 0.5] = 0
+    gd = grid_dev(grid)
+    args = (n, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(q), False, T(vol), 1, T(gin))
+    g_atomic = torch.zeros(grid.table_f32.size, dtype=torch.float16, device=DEV)
+    hip.hash_bwd(*args, g_atomic)  # level_entries = 0: direct atomics
+    g_binned = torch.zeros_like(g_atomic)
+    hip.hash_bwd(*args, g_binned, 1 << log2)
+    ref32 = oc.hash_bwd(grid.table_f32.size, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q, vol,
+                        grid.n_volumes, gin.view(np.uint16), fp32_accumulate=True)
+    a, b = N(g_atomic).astype(F32), N(g_binned).astype(F32)
+    tol = 2e-3 * np.abs(ref32).max() + 8 * 2.0 ** -11 * np.abs(ref32)
+    assert (np.abs(b - ref32) <= tol).all(), float(np.abs(b - ref32).max())
+    # the binned path sums in fp32 and rounds once per (slice, level): it is the closer of the two to the oracle
+    assert np.abs(b - ref32).sum() <= np.abs(a - ref32).sum()
+    assert np.abs(b - ref32).max() <= 2.0 ** -9 * np.abs(ref32).max()
+    # accumulates into an existing table (even / odd level overlap, second call)
+    hip.hash_bwd(*args, g_binned, 1 << log2)
+    assert np.abs(N(g_binned).astype(F32) - 2 * ref32).max() <= 2.0 ** -8 * np.abs(ref32).max()
+
+
 # ---------------------------------------------------------------------------------------------------
 # MLP
 # ---------------------------------------------------------------------------------------------------
@@ -428,7 +464,7 @@ def test_field_fused_forward_backward(hip, fox_state, fox_golden, n_use):
     dparams = torch.zeros(params.size, device=DEV)
     gtab = torch.zeros(grid.table_f32.size, dtype=torch.float16, device=DEV)
     hip.field_bwd(n, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts), T(anchors), 3, ph, sx,
-                  T(dfeat), 128.0, dparams, gtab)
+                  T(dfeat), 128.0, dparams, gtab, 1 << 14)
     rdp, rgt, _ = op.field_bwd(grid, params, ctx, dfeat, 128.0, fp32_accumulate=True)
     gdp = N(dparams) / F32(128.)
     assert np.abs(gdp - rdp).max() <= 4e-3 * np.abs(rdp).max() + 1e-7

@@ -7,6 +7,7 @@ __device__ __forceinline__ uint32_t rnd(uint32_t& s) { s = s * 1664525u + 101390
 // kind: 0 pk_f16, 1 f32, 2 i32, 3 u64, 4 f32 x2 (two adjacent floats), 5 pk_f16 with wave-uniform duplicate addresses
 __global__ void atomic_probe_kernel(uint32_t* table, uint32_t span_dwords, int kind, int part_mode, int iters) {
   uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) * 9781u + 12345u;
+  if (part_mode == 2 && (blockIdx.x % 8u) != 0u) return;  // one XCD only
   const uint32_t region = part_mode ? (blockIdx.x % 8u) : 0u;
   const uint32_t span = part_mode ? span_dwords / 8u : span_dwords;
   uint32_t* base = table + (part_mode ? region * (size_t) span : 0);
@@ -22,6 +23,14 @@ __global__ void atomic_probe_kernel(uint32_t* table, uint32_t span_dwords, int k
       atomicAdd((int*) (base + idx), 3);
     } else if (kind == 3) {
       atomicAdd((unsigned long long*) (base + (idx & ~1u)), 0x0000000100000001ull);
+    } else if (kind == 6) {
+      __hip_atomic_fetch_add((float*) (base + idx), 0.001f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else if (kind == 7) {
+      float old = atomicAdd((float*) (base + idx), 0.001f);
+      if (old == 123.456f) base[0] = 1;  // keep the returned value alive
+    } else if (kind == 8) {  // plain (racy) read-modify-write: the no-atomic upper bound
+      float* q = (float*) (base + idx);
+      *q = *q + 0.001f;
     } else if (kind == 4) {
       atomicAdd((float*) (base + (idx & ~1u)), 0.001f);
       atomicAdd((float*) (base + (idx | 1u)), 0.002f);
