@@ -181,6 +181,7 @@ __device__ __forceinline__ bool f2n_combine_runs(const F2nCell& cell, int vol, i
     v[2 * d] = g0 * cell.w[d];
     v[2 * d + 1] = g1 * cell.w[d];
   }
+  if (__ballot(same_as_prev) == 0ull) return tail;  // no run longer than one sample in this wave (the fine levels)
   int f = head;
 #define F2N_SEG_STEP(K)                                   \
   {                                                       \
@@ -230,21 +231,23 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Owner-binned scatter (large batches).  Measured on MI355X: global atomics cap at ~21 G/s chip-wide, while plain
-// read-modify-write out of an XCD's own L2 runs at ~135 G/s and LDS atomics are cheaper still.  So contributions are
-// not applied where they are produced.  (1) hash_bin_kernel: block (level l, chunk B) walks its samples, combines
-// runs, and appends every non-zero contribution as an 8-byte record {entry index inside its 8192-entry slice,
-// packed f16 pair} to the private queue segment (l, slice, B) -- slots come from LDS counters, so no global atomic and
-// no synchronisation between blocks.  (2) hash_bin_accumulate_kernel: one owner block per (level, slice) adds all
-// records of its slice into a 64 KB fp32 LDS image (ds_add_f32) and then adds the image to the f16 gradient table
-// with plain loads and stores.  Level l addresses halves [l*L, l*L + 2L): equal-parity levels are disjoint, so the
-// owners run in two launches (even levels, then odd) and no two blocks ever touch the same table entry.
+// Owner-binned scatter (large batches).  Measured on MI355X (tools/atomic_probe.py, tools/lds_atomic_probe.py):
+// global atomics cap at ~21 G/s chip-wide; plain read-modify-write out of an XCD's own L2 runs at ~135 G/s; LDS
+// atomics run at 0.33 lane-ops/clk/CU for ds_add_f32 / ds_pk_add_f16 but >= 1.4 for ds_add_u32 / u64 / f64.  So
+// contributions are not applied where they are produced.  (1) hash_bin_kernel: block (level l, chunk B) walks its
+// samples, combines runs, and appends every non-zero contribution as an 8-byte record {entry index inside its
+// 4096-entry slice, packed f16 pair} to the private queue segment (l, slice, B) -- slots come from LDS integer
+// counters, so no global atomic and no synchronisation between blocks.  (2) hash_bin_accumulate_kernel: one owner
+// block per 4096-entry slice of the TABLE sums every record that lands there into a 64 KB fp64 LDS image (ds_add_f64)
+// and adds the image to the f16 gradient table with plain loads and stores; nobody else touches those entries.
+// Level l addresses table pairs [l*E/2, l*E/2 + E) (E = entries per level, the reference's 50% level overlap,
+// Hash3DAnchored.cpp:60-70), so a table slice receives records from at most two levels.
 // A full segment (cannot happen for hashed positions short of adversarial input) falls back to the atomic.
 // ---------------------------------------------------------------------------------------------------
-#define F2N_BIN_SHIFT 13
+#define F2N_BIN_SHIFT 12
 #define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
-#define F2N_BIN_NB 64         // sample chunks (producer blocks) per level
-#define F2N_BIN_MAX_BINS 256  // tables up to 2^21 entries per level
+#define F2N_BIN_NB 128        // sample chunks (producer blocks) per level
+#define F2N_BIN_MAX_BINS 512  // tables up to 2^21 entries per level
 
 struct F2nBinQueues {
   uint2* rec;      // [16 levels][n_bins][NB][cap]
@@ -268,79 +271,128 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   const int s_begin = B * chunk, s_end = min(n, s_begin + chunk);
   const half_t* gl = gx + (size_t) (l >> 1) * gx_pair_stride + 2 * (l & 1);
   half2_t* tab = (half2_t*) (grad_table + lt.base[l]);
+  uint2* my_rec = q.rec + ((size_t) l * q.n_bins * F2N_BIN_NB + B) * q.cap;  // segment (l, bin, B) = my_rec + bin * bin_stride
+  const size_t bin_stride = (size_t) F2N_BIN_NB * q.cap;
+  // software pipeline: the next tile's gradient pair, point and transform index are in flight while this tile is
+  // hashed and appended (three dependent HBM round trips per tile otherwise)
+  struct Tile {
+    half2_t gpair;
+    float p[3];
+    int vol;
+  };
+  auto load_tile = [&](int base, Tile& t) {
+    const int sc = min(base + tid, s_end - 1);
+    t.gpair = *(const half2_t*) (gl + (size_t) sc * gx_sample_stride);
+#pragma unroll
+    for (int k = 0; k < 3; k++) t.p[k] = pts[3 * (size_t) sc + k];
+    t.vol = volume_idx[(size_t) sc * vol_stride];
+  };
+  Tile cur, nxt;
+  if (s_begin < s_end) load_tile(s_begin, cur);
   for (int base = s_begin; base < s_end; base += 256) {
-    const int s = base + tid;
-    const bool valid = s < s_end;
-    const int sc = valid ? s : s_end - 1;
-    const half2_t gpair = *(const half2_t*) (gl + (size_t) sc * gx_sample_stride);
-    const float g0 = valid ? (float) gpair[0] : 0.f, g1 = valid ? (float) gpair[1] : 0.f;
-    if (__ballot(g0 != 0.f || g1 != 0.f) == 0ull) continue;  // Hash3DAnchored.cu:149, wave-uniform
-    float p01[3];
+    if (base + 256 < s_end) load_tile(base + 256, nxt);
+    const bool valid = base + tid < s_end;
+    const float g0 = valid ? (float) cur.gpair[0] : 0.f, g1 = valid ? (float) cur.gpair[1] : 0.f;
+    if (__ballot(g0 != 0.f || g1 != 0.f) != 0ull) {  // Hash3DAnchored.cu:149, wave-uniform
+      float p01[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const float p = pts[3 * (size_t) sc + k];
-      p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
-    }
-    const int vol = volume_idx[(size_t) sc * vol_stride];
-    const int tf = l * h.n_volumes + vol;
-    F2nCell cell;
-    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
-    float v[16];
-    if (f2n_combine_runs(cell, vol, c, g0, g1, v)) {
+      for (int k = 0; k < 3; k++) p01[k] = pts_are_warped ? (cur.p[k] + 1.f) * .5f : cur.p[k];
+      const int vol = cur.vol;
+      const int tf = l * h.n_volumes + vol;
+      F2nCell cell;
+      f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
+      float v[16];
+      if (f2n_combine_runs(cell, vol, c, g0, g1, v)) {
 #pragma unroll
-      for (int d = 0; d < 8; d++) {
-        const half2_t val = {(half_t) v[2 * d], (half_t) v[2 * d + 1]};
-        if ((float) val[0] != 0.f || (float) val[1] != 0.f) {
-          const uint32_t pos = cell.pos[d];
-          const int bin = (int) (pos >> F2N_BIN_SHIFT);
-          const int slot = atomicAdd(&s_cnt[bin], 1);
-          if (slot < q.cap) {
-            uint2 r;
-            r.x = pos & (F2N_BIN_ENTRIES - 1);
-            r.y = __builtin_bit_cast(uint32_t, val);
-            q.rec[(((size_t) l * q.n_bins + bin) * F2N_BIN_NB + B) * q.cap + slot] = r;
-          } else {
-            __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (tab + pos), val);
+        for (int d = 0; d < 8; d++) {
+          const half2_t val = {(half_t) v[2 * d], (half_t) v[2 * d + 1]};
+          const uint32_t bits = __builtin_bit_cast(uint32_t, val);
+          if ((bits & 0x7fff7fffu) != 0u) {  // not (+-0, +-0)
+            const uint32_t pos = cell.pos[d];
+            const int bin = (int) (pos >> F2N_BIN_SHIFT);
+            const int slot = atomicAdd(&s_cnt[bin], 1);
+            if (slot < q.cap) {
+              uint2 r;
+              r.x = pos & (F2N_BIN_ENTRIES - 1);
+              r.y = bits;
+              my_rec[(size_t) bin * bin_stride + slot] = r;
+            } else {
+              __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (tab + pos), val);
+            }
           }
         }
       }
     }
+    cur = nxt;
   }
   __syncthreads();
   for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) l * q.n_bins + i) * F2N_BIN_NB + B] = min(s_cnt[i], q.cap);
 }
 
-__global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(int parity, F2nBinQueues q, const int32_t* __restrict__ local_idx,
-                                                                  const int32_t* __restrict__ local_size,
+__global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
                                                                   half_t* __restrict__ grad_table) {
-  __shared__ float s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp32 image of this block's slice
-  const int tid = threadIdx.x;
-  const int l = 2 * (blockIdx.x / q.n_bins) + parity, bin = blockIdx.x % q.n_bins;
-  for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.f;
+  __shared__ double s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp64 image of this block's table slice
+  __shared__ int s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // table slice g <- (level l1 = g / H, local slice g - l1*H) and (level l1 - 1, local slice g - l1*H + H)
+  const int H = slices_per_half_level, g = blockIdx.x;
+  const int l1 = g / H, b1 = g - l1 * H;
+  // 2 sources x F2N_BIN_NB segments; wave w owns segments w, w+4, ...: lane j keeps the length of segment w + 4j
+  const int seg = wave + 4 * lane;                       // 0 .. 2*NB-1
+  const int src = seg / F2N_BIN_NB, B = seg % F2N_BIN_NB;
+  const int l = l1 - src, bl = b1 + src * H;
+  const bool live = l >= 0 && l < F2N_N_LEVELS && bl < q.n_bins;
+  const size_t my_seg = ((size_t) (live ? l : 0) * q.n_bins + (live ? bl : 0)) * F2N_BIN_NB + B;
+  const int my_cnt = live ? q.cnt[my_seg] : 0;
+  if (tid == 0) s_total = 0;
   __syncthreads();
-  const size_t seg0 = ((size_t) l * q.n_bins + bin) * F2N_BIN_NB;
-  int total = 0;
-  for (int B = 0; B < F2N_BIN_NB; B++) {
-    const int cnt = q.cnt[seg0 + B];
-    total += cnt;
-    const uint2* r = q.rec + (seg0 + B) * q.cap;
-    for (int i = tid; i < cnt; i += 256) {
-      const uint2 rec = r[i];
+  int wsum = my_cnt;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off);
+  if (lane == 0 && wsum > 0) atomicAdd(&s_total, wsum);
+  __syncthreads();
+  if (s_total == 0) return;  // block-uniform: nothing landed in this slice
+  for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.0;
+  __syncthreads();
+  // Four segments at a time, the first 128 records of each with one coalesced 8-byte load per lane: eight independent
+  // loads in flight per lane (the records were written by other XCDs a moment ago -- every read is a fabric round trip).
+  auto add = [&](uint2 rec) {
+    if (rec.y != 0u) {  // a stored record is never (+0, +0); padding is
       const half2_t val = __builtin_bit_cast(half2_t, rec.y);
-      atomicAdd(&s_acc[2 * rec.x], (float) val[0]);
-      atomicAdd(&s_acc[2 * rec.x + 1], (float) val[1]);
+      atomicAdd(&s_acc[2 * rec.x], (double) val[0]);
+      atomicAdd(&s_acc[2 * rec.x + 1], (double) val[1]);
     }
+  };
+  for (int sg = 0; sg < 64; sg += 4) {
+    uint2 rec[8];
+    int cnt[4];
+    const uint2* r[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      cnt[u] = __shfl(my_cnt, sg + u);
+      const unsigned long long sidx = __shfl((unsigned long long) my_seg, sg + u);
+      r[u] = q.rec + sidx * q.cap;
+      rec[2 * u] = lane < cnt[u] ? r[u][lane] : uint2{0u, 0u};
+      rec[2 * u + 1] = lane + 64 < cnt[u] ? r[u][lane + 64] : uint2{0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) add(rec[u]);
+#pragma unroll
+    for (int u = 0; u < 4; u++)  // long segments: the rest
+      for (int i = lane + 128; i < cnt[u]; i += 64) add(r[u][i]);
   }
-  if (total == 0) return;  // block-uniform: nothing landed in this slice
   __syncthreads();
-  const uint32_t size = (uint32_t) local_size[l];
-  half2_t* tab = (half2_t*) (grad_table + local_idx[l]);
-  for (int e = tid; e < F2N_BIN_ENTRIES; e += 256) {
-    const uint32_t pos = (uint32_t) bin * F2N_BIN_ENTRIES + e;
-    const float a0 = s_acc[2 * e], a1 = s_acc[2 * e + 1];
-    if (pos < size && (a0 != 0.f || a1 != 0.f)) {
-      const half2_t old = tab[pos];
-      tab[pos] = half2_t{(half_t) ((float) old[0] + a0), (half_t) ((float) old[1] + a1)};
+  half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
+  for (int e0 = tid; e0 < F2N_BIN_ENTRIES; e0 += 256 * 8) {  // eight independent table reads in flight per thread
+    half2_t old[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) old[u] = tab[e0 + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + 256 * u;
+      const double a0 = s_acc[2 * e], a1 = s_acc[2 * e + 1];
+      if (a0 != 0.0 || a1 != 0.0)
+        tab[e] = half2_t{(half_t) (float) ((double) (float) old[u][0] + a0), (half_t) (float) ((double) (float) old[u][1] + a1)};
     }
   }
 }
@@ -602,23 +654,25 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
                               const float* level_scale, const float* pts, int warped, const int32_t* volume_idx, int vol_stride,
                               const half_t* gx, long ss, long ps, half_t* grad_table, int level_entries) {
   F2nBinQueues q;
-  q.n_bins = (level_entries + F2N_BIN_ENTRIES - 1) >> F2N_BIN_SHIFT;
+  q.n_bins = level_entries >> F2N_BIN_SHIFT;
   const int chunk = (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255;
-  q.cap = (int) (1.25 * 8.0 * (double) chunk / (double) q.n_bins) + 256;
+  q.cap = (int) (1.25 * 8.0 * (double) chunk / (double) q.n_bins) + 64;
   const size_t n_seg = (size_t) F2N_N_LEVELS * q.n_bins * F2N_BIN_NB;
   q.rec = (uint2*) f2n_ws_get(F2N_WS_BIN_REC, n_seg * q.cap * sizeof(uint2));
   q.cnt = (int32_t*) f2n_ws_get(F2N_WS_BIN_CNT, n_seg * sizeof(int32_t));
   if (q.rec == nullptr || q.cnt == nullptr) return F2N_ERR_INVALID_ARG;
   hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
                      level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, q, grad_table);
-  for (int parity = 0; parity < 2; parity++)
-    hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS / 2) * q.n_bins), dim3(256), 0, st, parity, q, local_idx,
-                       local_size, grad_table);
+  const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels
+  hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS + 1) * H), dim3(256), 0, st, q, H, grad_table);
   return f2n_launch_status();
 }
 
+// The binned path needs the reference's table layout -- local_idx[l] = l * E halves, local_size[l] = E entries with E a
+// power of two -- and whole 4096-entry slices per half level.
 static inline bool f2n_use_bins(int n, int level_entries) {
-  return n >= F2N_BIN_MIN_N && level_entries > 0 && ((level_entries + F2N_BIN_ENTRIES - 1) >> F2N_BIN_SHIFT) <= F2N_BIN_MAX_BINS;
+  return n >= F2N_BIN_MIN_N && level_entries >= 2 * F2N_BIN_ENTRIES && (level_entries & (level_entries - 1)) == 0 &&
+         (level_entries >> F2N_BIN_SHIFT) <= F2N_BIN_MAX_BINS;
 }
 
 extern "C" {

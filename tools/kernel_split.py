@@ -46,9 +46,12 @@ p2 = T(arrays[9]).to(torch.float16); dp2 = torch.zeros(7168, device=dev)
 print("mlp_bwd NH=2 alone (no dx)           %.3f ms" % timeit(lambda: capi.mlp_bwd(n, 32, 64, 2, 128.0, p2, x32, dy, dp2, None)))
 gin = (torch.randn((n, 32), device=dev) * 0.05).to(torch.float16)
 gtab = torch.zeros(16 * local * 2, dtype=torch.float16, device=dev)
-print("hash_bwd alone (dense random grads)  %.3f ms" % timeit(lambda: capi.hash_bwd(n, nv, prim, lidx, lsize, bias, scale, pts, True, anchors, 3, gin, gtab)))
-gin_sparse = gin.clone(); gin_sparse[:, 8:] = 0
-print("hash_bwd alone (levels 0-3 only)     %.3f ms" % timeit(lambda: capi.hash_bwd(n, nv, prim, lidx, lsize, bias, scale, pts, True, anchors, 3, gin_sparse, gtab)))
-gin_fine = gin.clone(); gin_fine[:, :24] = 0
-print("hash_bwd alone (levels 12-15 only)   %.3f ms" % timeit(lambda: capi.hash_bwd(n, nv, prim, lidx, lsize, bias, scale, pts, True, anchors, 3, gin_fine, gtab)))
-print("field_bwd fused                      %.3f ms" % timeit(lambda: capi.field_bwd(n, nv, prim, lidx, lsize, bias, scale, pts, anchors, 3, ph, xh, dy, 128.0, dp, gtab)))
+sparse20 = gin.clone(); sparse20[torch.rand(n, device=dev) > 0.2] = 0  # ~ the bench's share of non-zero gradients
+variants = {"dense random grads": gin, "20% of samples non-zero": sparse20}
+for lo, hi in ((0, 4), (4, 8), (8, 12), (12, 16)):
+    g = torch.zeros_like(gin); g[:, 2 * lo:2 * hi] = gin[:, 2 * lo:2 * hi]
+    variants["levels %d-%d only" % (lo, hi - 1)] = g
+for name, g in variants.items():
+    for le, tag in ((0, "atomics"), (local, "binned ")):
+        print("hash_bwd %s (%-24s) %.3f ms" % (tag, name, timeit(lambda: capi.hash_bwd(n, nv, prim, lidx, lsize, bias, scale, pts, True, anchors, 3, g, gtab, le))))
+print("field_bwd fused (binned)              %.3f ms" % timeit(lambda: capi.field_bwd(n, nv, prim, lidx, lsize, bias, scale, pts, anchors, 3, ph, xh, dy, 128.0, dp, gtab, local)))
