@@ -33,12 +33,15 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per sample of the three field kernels (DESIGN.md section 4 / SURVEY.md section 8(d)):
 # 16 levels x 8 corners x 4 B of table traffic + the per-sample streams each kernel must touch
-ALGO_BYTES = {
-    "field_prepass": 512 + 12 + 4 + 4 + 64,   # gather + pts + trans idx + f0 out + feature cache (f16x32)
-    "field_fwd_cached": 64 + 4 + 64 + 64,     # cached feature row + row index + feat out (fp32x16) + saved features
-    "field_fwd": 512 + 12 + 4 + 64 + 64,      # (edge samples only) gather + pts + idx + feat out + saved features
-    "field_bwd": 512 + 12 + 4 + 64 + 64,      # atomic payload + pts + idx + dfeat in + saved features
-}
+# The dominant kernel of a step is hash_gather_planes_kernel: the 16-level gather of the density pre-pass, one launch
+# per step over every marched sample (profiles/*_kernel_stats.csv).  Algorithmic bytes per sample: 16 levels x 8
+# corners x 4 B of table reads + point (12) + transform index (4) + the 64 B of f16 feature planes it writes.
+DOMINANT = "hash_gather"
+ALGO_BYTES = {"hash_gather": 512 + 12 + 4 + 64}
+# HBM-side bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate counter passes,
+# profiles/run_profiles.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), recorded per round in
+# profiles/<tag>_traffic.json; null when that file is absent.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
 HBM_PEAK_GBS = 8000.0
 
 
@@ -98,7 +101,8 @@ def main():
         step(i)
     host = runtime.host()
     if rank == 0:
-        host.ExpRunner.enable_kernel_timing(list(ALGO_BYTES))
+        host.ExpRunner.enable_kernel_timing([DOMINANT, "field_mlp_prepass", "field_fwd_cached", "field_fwd", "field_bwd",
+                                             "shade_fwd", "shade_bwd"])
     barrier()
     t0 = time.perf_counter()
     n_marched = n_meaningful = 0
@@ -123,21 +127,22 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_meaningful / elapsed
         rho = n_marched / max(n_meaningful, 1.0)
-        # --- roofline of the dominant kernel (longest total time among the field kernels) ---
-        per_step_local = {"field_prepass": n_marched / world / args.steps,
-                          "field_fwd_cached": n_meaningful / world / args.steps,
-                          "field_fwd": 2 * runner.n_edge_pts,
-                          "field_bwd": n_meaningful / world / args.steps + 2 * runner.n_edge_pts}
+        # --- roofline of the dominant kernel ---
         roofline = None
-        if timing:
-            dom = max(timing, key=lambda k: timing[k][1])
-            launches, total_ms = timing[dom]
+        if timing and DOMINANT in timing:
+            launches, total_ms = timing[DOMINANT]
             avg_ms = total_ms / max(launches, 1)
-            achieved = per_step_local[dom] * ALGO_BYTES[dom] / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_kernel_ms": round(avg_ms, 4),
-                        "bytes_per_sample": ALGO_BYTES[dom], "samples_per_launch": int(per_step_local[dom]),
-                        "field_kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in timing.items()}}
+            samples_per_launch = n_marched / world / args.steps
+            achieved = samples_per_launch * ALGO_BYTES[DOMINANT] / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            if os.path.exists(TRAFFIC_FILE):
+                with open(TRAFFIC_FILE) as f:
+                    traffic = json.load(f).get("hash_gather_planes_kernel", {}).get("hbm_bytes_per_launch")
+            roofline = {"bound": "hbm", "kernel": "hash_gather_planes_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "avg_kernel_ms": round(avg_ms, 4), "launches": launches, "bytes_per_sample": ALGO_BYTES[DOMINANT],
+                        "samples_per_launch": int(samples_per_launch),
+                        "timed_calls_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in timing.items()}}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             try:

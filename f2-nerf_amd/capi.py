@@ -175,6 +175,19 @@ def field_fwd(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool
                             _p(out_f0, "f32", True), _p(save_x_h, "h16", True)), "f2n_field_fwd")
 
 
+def hash_gather_planes(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale, pts, pts_are_warped,
+                       volume_idx, vol_stride, planes_h):
+    _ck(lib().f2n_hash_gather_planes(_stream(), _i(n), _i(n_volumes), _p(table_h, "h16"), _p(prim_pool, "i32"),
+                                     _p(local_idx, "i32"), _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"),
+                                     _p(pts, "f32"), _i(int(pts_are_warped)), _p(volume_idx, "i32"), _i(vol_stride),
+                                     _p(planes_h, "h16")), "f2n_hash_gather_planes")
+
+
+def field_mlp_planes(n, planes_h, mlp_params_h, out_feat, out_f0, save_x_h):
+    _ck(lib().f2n_field_mlp_planes(_stream(), _i(n), _p(planes_h, "h16"), _p(mlp_params_h, "h16"), _p(out_feat, "f32", True),
+                                   _p(out_f0, "f32", True), _p(save_x_h, "h16", True)), "f2n_field_mlp_planes")
+
+
 def field_fwd_cached(n, n_cache, src_rows, x_cache_h, mlp_params_h, out_feat, out_f0, save_x_h):
     _ck(lib().f2n_field_fwd_cached(_stream(), _i(n), _i(n_cache), _p(src_rows, "i32", True), _p(x_cache_h, "h16"),
                                    _p(mlp_params_h, "h16"), _p(out_feat, "f32", True), _p(out_f0, "f32", True),

@@ -248,6 +248,7 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 #define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
 #define F2N_BIN_NB 128        // sample chunks (producer blocks) per level
 #define F2N_BIN_MAX_BINS 512  // tables up to 2^21 entries per level
+#define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
 struct F2nBinQueues {
   uint2* rec;      // [16 levels][n_bins][NB][cap]
@@ -260,9 +261,12 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
                                                        const float* __restrict__ level_scale, const float* __restrict__ pts,
                                                        int pts_are_warped, const int32_t* __restrict__ volume_idx, int vol_stride,
                                                        const half_t* __restrict__ gx, long gx_sample_stride,
-                                                       long gx_pair_stride, F2nBinQueues q, half_t* __restrict__ grad_table) {
+                                                       long gx_pair_stride, const uint16_t* __restrict__ nz_mask,
+                                                       F2nBinQueues q, half_t* __restrict__ grad_table) {
   __shared__ F2nLevelTab lt;
   __shared__ int s_cnt[F2N_BIN_MAX_BINS];
+  __shared__ uint16_t s_idx[F2N_BIN_MAX_CHUNK];  // offsets (inside the chunk) of the samples with a non-zero gradient
+  __shared__ int s_wave_tot[4], s_n_nz;
   const int tid = threadIdx.x, c = tid & 15;
   f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
   for (int i = tid; i < q.n_bins; i += 256) s_cnt[i] = 0;
@@ -273,6 +277,41 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   half2_t* tab = (half2_t*) (grad_table + lt.base[l]);
   uint2* my_rec = q.rec + ((size_t) l * q.n_bins * F2N_BIN_NB + B) * q.cap;  // segment (l, bin, B) = my_rec + bin * bin_stride
   const size_t bin_stride = (size_t) F2N_BIN_NB * q.cap;
+  // Samples whose whole f16 gradient is zero (most of them while the loss-scaled gradients sit at the f16 underflow
+  // boundary) are dropped up front: nz_mask has one bit per sample (16-sample words, written by the MLP backward).
+  // Order is preserved, so runs of equal cells stay adjacent.
+  int n_nz = s_end - s_begin;
+  if (nz_mask != nullptr && n_nz > 0) {
+    if (tid == 0) s_n_nz = 0;
+    __syncthreads();
+    const int n_words = (s_end - s_begin + 15) / 16;  // s_begin is a multiple of 256
+    for (int w0 = 0; w0 < n_words; w0 += 256) {
+      const int w = w0 + tid;
+      unsigned m = w < n_words ? nz_mask[s_begin / 16 + w] : 0u;
+      if (w < n_words && s_begin + 16 * w + 16 > s_end) m &= (1u << (s_end - s_begin - 16 * w)) - 1u;
+      const int cnt = __popc(m);
+      int incl = cnt;  // block-wide exclusive prefix of the popcounts
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += up;
+      }
+      if ((tid & 63) == 63) s_wave_tot[tid >> 6] = incl;
+      __syncthreads();
+      int base = s_n_nz;
+      for (int k = 0; k < (tid >> 6); k++) base += s_wave_tot[k];
+      int dst = base + incl - cnt;
+      while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1u;
+        s_idx[dst++] = (uint16_t) (16 * w + b);
+      }
+      __syncthreads();
+      if (tid == 255) s_n_nz = base + incl;
+      __syncthreads();
+    }
+    n_nz = s_n_nz;
+  }
   // software pipeline: the next tile's gradient pair, point and transform index are in flight while this tile is
   // hashed and appended (three dependent HBM round trips per tile otherwise)
   struct Tile {
@@ -280,18 +319,19 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
     float p[3];
     int vol;
   };
-  auto load_tile = [&](int base, Tile& t) {
-    const int sc = min(base + tid, s_end - 1);
+  auto load_tile = [&](int i0, Tile& t) {
+    const int i = min(i0 + tid, n_nz - 1);
+    const int sc = s_begin + (nz_mask != nullptr ? (int) s_idx[i] : i);
     t.gpair = *(const half2_t*) (gl + (size_t) sc * gx_sample_stride);
 #pragma unroll
     for (int k = 0; k < 3; k++) t.p[k] = pts[3 * (size_t) sc + k];
     t.vol = volume_idx[(size_t) sc * vol_stride];
   };
   Tile cur, nxt;
-  if (s_begin < s_end) load_tile(s_begin, cur);
-  for (int base = s_begin; base < s_end; base += 256) {
-    if (base + 256 < s_end) load_tile(base + 256, nxt);
-    const bool valid = base + tid < s_end;
+  if (n_nz > 0) load_tile(0, cur);
+  for (int i0 = 0; i0 < n_nz; i0 += 256) {
+    if (i0 + 256 < n_nz) load_tile(i0 + 256, nxt);
+    const bool valid = i0 + tid < n_nz;
     const float g0 = valid ? (float) cur.gpair[0] : 0.f, g1 = valid ? (float) cur.gpair[1] : 0.f;
     if (__ballot(g0 != 0.f || g1 != 0.f) != 0ull) {  // Hash3DAnchored.cu:149, wave-uniform
       float p01[3];
@@ -511,7 +551,8 @@ __global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
     const int32_t* __restrict__ volume_idx, int vol_stride, const half_t* __restrict__ params,
     const half_t* __restrict__ x_h, const float* __restrict__ x_f32, const float* __restrict__ dy, float loss_scale,
-    float* __restrict__ dparams, float* __restrict__ dx_f32, half_t* __restrict__ grad_table, half_t* __restrict__ dx_planes) {
+    float* __restrict__ dparams, float* __restrict__ dx_f32, half_t* __restrict__ grad_table, half_t* __restrict__ dx_planes,
+    uint16_t* __restrict__ nz_mask) {
   __shared__ F2nBwdSmem<NH> sm;
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -554,10 +595,16 @@ __global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
       if (DO_HASH) {
         half8_t gx = f2n_pack<false>(hb[half].dxT[0], hb[half].dxT[1]);  // (dL/dx * 128) -> f16, Hash3DAnchored.cu:220
         if (dx_planes != nullptr) {  // large batches: the owner-binned scatter consumes f16 planes [8][n][4]
+          bool nz = false;
+#pragma unroll
+          for (int e = 0; e < 8; e++) nz |= (float) gx[e] != 0.f;
+          const unsigned long long bal = __ballot(nz && valid);  // bit 16g + c: lane (c, g) of this half
           if (valid) {
             *(half4_t*) (dx_planes + ((size_t) g * n + s) * 4) = __builtin_shufflevector(gx, gx, 0, 1, 2, 3);
             *(half4_t*) (dx_planes + ((size_t) (4 + g) * n + s) * 4) = __builtin_shufflevector(gx, gx, 4, 5, 6, 7);
           }
+          if (lane == 0 && sb * 32 + half * 16 < n)  // one 16-bit word per half: sample c has a non-zero gradient
+            nz_mask[sb * 2 + half] = (uint16_t) ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull);
         } else {  // every lane takes part in the row-level combining; out-of-range samples carry zero gradient
           float p01[3];
           f2n_load_point(pts, sc, pts_are_warped != 0, p01);
@@ -652,7 +699,7 @@ static inline bool f2n_mlp_shape_ok(int d_in, int d_hidden, int n_hidden) {
 // Owner-binned scatter of f16 gradients gx (pair (l, ch) of sample s at gx[s*ss + (l>>1)*ps + 2*(l&1) + ch]).
 static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const int32_t* local_idx, const int32_t* local_size,
                               const float* level_scale, const float* pts, int warped, const int32_t* volume_idx, int vol_stride,
-                              const half_t* gx, long ss, long ps, half_t* grad_table, int level_entries) {
+                              const half_t* gx, long ss, long ps, const uint16_t* nz_mask, half_t* grad_table, int level_entries) {
   F2nBinQueues q;
   q.n_bins = level_entries >> F2N_BIN_SHIFT;
   const int chunk = (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255;
@@ -662,7 +709,7 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   q.cnt = (int32_t*) f2n_ws_get(F2N_WS_BIN_CNT, n_seg * sizeof(int32_t));
   if (q.rec == nullptr || q.cnt == nullptr) return F2N_ERR_INVALID_ARG;
   hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
-                     level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, q, grad_table);
+                     level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table);
   const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels
   hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS + 1) * H), dim3(256), 0, st, q, H, grad_table);
   return f2n_launch_status();
@@ -671,7 +718,7 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
 // The binned path needs the reference's table layout -- local_idx[l] = l * E halves, local_size[l] = E entries with E a
 // power of two -- and whole 4096-entry slices per half level.
 static inline bool f2n_use_bins(int n, int level_entries) {
-  return n >= F2N_BIN_MIN_N && level_entries >= 2 * F2N_BIN_ENTRIES && (level_entries & (level_entries - 1)) == 0 &&
+  return n >= F2N_BIN_MIN_N && n <= F2N_BIN_NB * (F2N_BIN_MAX_CHUNK - 256) && level_entries >= 2 * F2N_BIN_ENTRIES && (level_entries & (level_entries - 1)) == 0 &&
          (level_entries >> F2N_BIN_SHIFT) <= F2N_BIN_MAX_BINS;
 }
 
@@ -719,7 +766,7 @@ int f2n_hash_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, c
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
   if (f2n_use_bins(n, level_entries))  // row-major [n][32]: pair (l, ch) at 32*s + 2*l + ch
     return f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx,
-                              vol_stride, (const half_t*) grad_in_h, F2N_D_IN, 4, (half_t*) grad_table_h, level_entries);
+                              vol_stride, (const half_t*) grad_in_h, F2N_D_IN, 4, nullptr, (half_t*) grad_table_h, level_entries);
   hipLaunchKernelGGL(hash_bwd_kernel, dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, h,
                      local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride,
                      (const half_t*) grad_in_h, (half_t*) grad_table_h);
@@ -753,10 +800,10 @@ int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_hidden == 1)
     hipLaunchKernelGGL((field_bwd_kernel<1, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr);
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr);
   else
     hipLaunchKernelGGL((field_bwd_kernel<2, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr);
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   return f2n_reduce_partials(stream, n_params, (int) grid.x, partials, dparams_f32_scaled);
@@ -779,15 +826,34 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
   // same MLP kernel reads its MFMA K-slots from the planes.  ~130 B/sample of extra streaming buys ~3x on the gathers.
   half_t* planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, sizeof(half_t) * 32 * (size_t) n);
   if (planes == nullptr) return F2N_ERR_INVALID_ARG;
+  int rc = f2n_hash_gather_planes(stream, n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale,
+                                  pts_warped, 1, volume_idx, vol_stride, planes);
+  if (rc != F2N_OK) return rc;
+  return f2n_field_mlp_planes(stream, n, planes, mlp_params_h, out_feat_f32, out_f0, save_x_h);
+}
+
+int f2n_hash_gather_planes(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                           const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                           const float* pts, int pts_are_warped, const int32_t* volume_idx, int vol_stride, void* planes_h) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
   long per_part = ((long) n + 255) / 256;
   if (per_part > 256) per_part = 256;  // 32 CUs per XCD x 8 resident 256-thread blocks
   hipLaunchKernelGGL(hash_gather_planes_kernel, dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), 0, (hipStream_t) stream, n, h,
-                     local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, planes);
-  int rc = f2n_launch_status();
-  if (rc != F2N_OK) return rc;
+                     local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride, (half_t*) planes_h);
+  return f2n_launch_status();
+}
+
+int f2n_field_mlp_planes(void* stream, int n, const void* planes_h, const void* mlp_params_h, float* out_feat_f32, float* out_f0,
+                         void* save_x_h) {
+  if (n < 0 || (n > 0 && planes_h == nullptr)) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
   hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                      (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr,
-                     (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, planes, nullptr, nullptr);
+                     (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, (const half_t*) planes_h,
+                     nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -815,19 +881,22 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
   float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) blocks * n_params);
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   half_t* dx_planes = nullptr;
-  if (f2n_use_bins(n, level_entries)) {
-    dx_planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, sizeof(half_t) * 32 * (size_t) n);
+  uint16_t* nz_mask = nullptr;
+  if (f2n_use_bins(n, level_entries)) {  // planes [8][n][4] followed by one non-zero bit per sample
+    const size_t plane_bytes = sizeof(half_t) * 32 * (size_t) n;
+    dx_planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, plane_bytes + sizeof(uint16_t) * ((size_t) n / 16 + 2));
     if (dx_planes == nullptr) return F2N_ERR_INVALID_ARG;
+    nz_mask = (uint16_t*) ((char*) dx_planes + plane_bytes);
   }
   hipLaunchKernelGGL((field_bwd_kernel<1, true>), dim3(blocks), dim3(F2N_BWD_THREADS), 0,
                      (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
                      (const half_t*) mlp_params_h, (const half_t*) saved_x_h, nullptr, dfeat, loss_scale,
-                     partials, nullptr, (half_t*) grad_table_h, dx_planes);
+                     partials, nullptr, (half_t*) grad_table_h, dx_planes, nz_mask);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   if (dx_planes != nullptr) {  // planes [8][n][4]: pair (l, ch) at (l>>1)*4n + 4*s + 2*(l&1) + ch
     rc = f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                            dx_planes, 4, 4 * (long) n, (half_t*) grad_table_h, level_entries);
+                            dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries);
     if (rc != F2N_OK) return rc;
   }
   return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);

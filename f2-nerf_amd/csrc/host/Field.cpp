@@ -223,9 +223,18 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
   const int n = pts.size(0);
   Tensor f0 = torch::empty({n}, DevF32());
   prepass_x_ = keep_features ? torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16()) : Tensor();
-  F2N_TIMED_CALL("field_prepass", f2n_field_fwd(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_), I32P(feat_local_idx_),
-                         I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), I32P(av.t), av.stride,
-                         VoidP(mlp_->params_h_), nullptr, F32P(f0), keep_features ? VoidP(prepass_x_) : nullptr));
+  if (n >= 32768) {  // the two kernels of the large-batch path, issued (and timed) separately
+    Tensor planes = torch::empty({8, n, 4}, DevF16());
+    F2N_TIMED_CALL("hash_gather", f2n_hash_gather_planes(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),
+                           I32P(feat_local_idx_), I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), 1,
+                           I32P(av.t), av.stride, VoidP(planes)));
+    F2N_TIMED_CALL("field_mlp_prepass", f2n_field_mlp_planes(CurStream(), n, VoidP(planes), VoidP(mlp_->params_h_), nullptr, F32P(f0),
+                           keep_features ? VoidP(prepass_x_) : nullptr));
+  } else {
+    F2N_TIMED_CALL("field_prepass", f2n_field_fwd(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_), I32P(feat_local_idx_),
+                           I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), I32P(av.t), av.stride,
+                           VoidP(mlp_->params_h_), nullptr, F32P(f0), keep_features ? VoidP(prepass_x_) : nullptr));
+  }
   return f0;
 }
 

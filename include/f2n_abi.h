@@ -177,6 +177,19 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
                   const float* level_scale, const float* pts_warped, const int32_t* volume_idx, int vol_stride,
                   const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h);
 
+/* The two halves of f2n_field_fwd's large-batch path, callable on their own.
+ * f2n_hash_gather_planes: the 16-level gather with an XCD-aware partition -- workgroup b serves levels (2p, 2p+1),
+ * p = b % 8, so that each of the 8 private 4 MiB L2s of an MI355X only ever sees a 3 MiB slice of the table
+ * (~2.6x the rate of one wave gathering all 16 levels).  Output: h16 "planes" [8][n][4], plane p = features
+ * 4p..4p+3 (levels 2p, 2p+1) of every sample; numerically the same features as f2n_hash_fwd (same fp32 order).
+ * f2n_field_mlp_planes: the density MLP on such planes; outputs as f2n_field_fwd. */
+int f2n_hash_gather_planes(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                           const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                           const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
+                           int vol_stride, void* planes_h /*[8,n,4] h16*/);
+int f2n_field_mlp_planes(void* stream, int n, const void* planes_h, const void* mlp_params_h, float* out_feat_f32,
+                         float* out_f0, void* save_x_h);
+
 /* AnchoredQuery for samples whose hash features are already known: Renderer::Render queries the field twice per
  * step with an unchanged table -- the no-grad density pre-pass over every marched sample (Renderer.cpp:115-123)
  * and the grad pass over the survivors (:152-166) -- so the 128 gathers per surviving sample of the second query

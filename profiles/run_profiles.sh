@@ -2,6 +2,8 @@
 # Collects the rocprofv3 evidence behind bench.py's numbers (run on the GPU box through gpurun):
 #   1. --kernel-trace --stats : per-kernel durations          -> profiles/<tag>_kernel_stats.csv
 #   2. --pmc FETCH_SIZE       : HBM-side read traffic          -> profiles/<tag>_pmc_fetch_size.csv   (own pass: 3 of 4 TCC slots)
+#   2b. --pmc WRITE_SIZE      : HBM-side write traffic         -> profiles/<tag>_pmc_write_size.csv  (own pass)
+#       both -> profiles/<tag>_traffic.json (bytes per launch; FETCH_SIZE doubled, the gfx950 correction of the guide)
 #   3. --pmc SQ_*             : issue / wait breakdown         -> profiles/<tag>_pmc_sq.csv
 # Counter passes never share a run with tracing (gpurun refuses that combination).
 set -u
@@ -13,16 +15,19 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $OUT/sq -- $BENCH > /dev/null 2> $OUT/sq.err
 cd $ROOT
-for k in stats fetch sq; do
+for k in stats fetch write sq; do
   DB=$(find $OUT/$k -name "*.db" | head -1)
   echo "$k: $DB"
   case $k in
     stats) python profiles/summarize_rocpd.py stats $DB $OUT/${TAG}_kernel_stats.csv ;;
     fetch) python profiles/summarize_rocpd.py pmc $DB $OUT/${TAG}_pmc_fetch_size.csv ;;
+    write) python profiles/summarize_rocpd.py pmc $DB $OUT/${TAG}_pmc_write_size.csv ;;
     sq) python profiles/summarize_rocpd.py pmc $DB $OUT/${TAG}_pmc_sq.csv ;;
   esac
 done
+python profiles/summarize_rocpd.py traffic $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv $OUT/${TAG}_traffic.json
 find $OUT -name "*.db" -delete
 ls -la $OUT

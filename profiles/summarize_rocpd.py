@@ -40,5 +40,29 @@ def pmc(db, out):
             w.writerow([short(n), cn, c, "%.3f" % float(v), "%.0f" % float(d)])
 
 
+def traffic(fetch_csv, write_csv, out_json):
+    """HBM-side bytes per launch = 2 x FETCH_SIZE (gfx950: rocprofv3 tallies 128-B read requests at 64 B, see
+    MI355X_MICROARCH.md, HBM section) + WRITE_SIZE (uncalibrated), both reported by rocprofv3 in KiB."""
+    import json
+    acc = {}
+    for path, key, mult in ((fetch_csv, "fetch", 2.0), (write_csv, "write", 1.0)):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = r["kernel"].split("(")[0]
+                for tag in ("hash_gather_planes_kernel", "hash_bin_kernel", "hash_bin_accumulate_kernel", "field_bwd_kernel",
+                            "shade_bwd_kernel", "shade_fwd_kernel", "ray_march_kernel<true>", "ray_march_kernel<false>"):
+                    if tag in name:
+                        name = tag
+                d = acc.setdefault(name, {"dispatches": int(r["dispatches"])})
+                d[key + "_bytes_per_launch"] = float(r["avg_value"]) * 1024.0 * mult
+    for d in acc.values():
+        d["hbm_bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0.0) + d.get("write_bytes_per_launch", 0.0)
+    with open(out_json, "w") as f:
+        json.dump(acc, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

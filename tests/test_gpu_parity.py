@@ -438,7 +438,33 @@ def test_mlp_backward(hip, n_hidden, n):
 # ---------------------------------------------------------------------------------------------------
 # fused field / shader
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n_use", [None, 1500])  # >= 4096 samples: XCD-partitioned gather + MLP; below: single fused launch
+def test_partitioned_gather_equals_fused_forward(hip, fox_state, fox_golden):
+    """The large-batch path (XCD-partitioned gather into planes + MLP on planes) and the single fused launch compute
+    the same bits; both are reachable through f2n_field_fwd depending on n."""
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(22)
+    grid = make_grid(st, rng, 14, scale=0.5)
+    params = rand_params(rng, 1)
+    pts, anchors = g["march_pts"], g["march_anchors"]
+    n = len(pts)
+    gd = grid_dev(grid)
+    ph = T(oc.f2h(params).view(np.float16))
+    feat_a = torch.zeros((n, 16), device=DEV); f0_a = torch.zeros(n, device=DEV); sx_a = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    hip.field_fwd(n, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts),
+                  T(anchors), 3, ph, feat_a, f0_a, sx_a)
+    planes = torch.zeros((8, n, 4), dtype=torch.float16, device=DEV)
+    hip.hash_gather_planes(n, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts),
+                           True, T(anchors), 3, planes)
+    feat_b = torch.zeros_like(feat_a); f0_b = torch.zeros_like(f0_a); sx_b = torch.zeros_like(sx_a)
+    hip.field_mlp_planes(n, planes, ph, feat_b, f0_b, sx_b)
+    assert_same(N(sx_a).view(np.uint16), N(sx_b).view(np.uint16), "features")
+    assert_same(N(feat_a), N(feat_b), "field output")
+    assert_same(N(f0_a), N(f0_b), "f0")
+    # plane p holds features 4p..4p+3 of every sample
+    assert_same(N(planes).view(np.uint16).transpose(1, 0, 2).reshape(n, 32), N(sx_a).view(np.uint16), "plane layout")
+
+
+@pytest.mark.parametrize("n_use", [None, 1500])
 def test_field_fused_forward_backward(hip, fox_state, fox_golden, n_use):
     st, g = fox_state, fox_golden
     rng = np.random.default_rng(21)
@@ -446,7 +472,6 @@ def test_field_fused_forward_backward(hip, fox_state, fox_golden, n_use):
     params = rand_params(rng, 1)
     pts, anchors = g["march_pts"][:n_use], g["march_anchors"][:n_use]
     n = len(pts)
-    assert (n >= 4096) == (n_use is None)
     gd = grid_dev(grid)
     ph = T(oc.f2h(params).view(np.float16))
     feat = torch.zeros((n, 16), device=DEV)
