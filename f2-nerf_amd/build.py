@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libf2n_hip.so")
 OBJ = os.path.join(HERE, "build")
 
-HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip", "workspace.hip"]
+HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip", "workspace.hip", "dataset.hip"]
 HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", os.path.join(INCLUDE, "f2n_abi.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                "-Wall", "-Wno-unused-function"]

@@ -225,6 +225,18 @@ def shade_bwd(n, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfea
                             _p(dapp_emb, "f32", True), _i(0 if dapp_emb is None else dapp_emb.shape[0])), "f2n_shade_bwd")
 
 
+# ---------------------------------------------------------------- ray generation
+def img2world_rays(n, poses, intri, dist_params, cam_idx, ij, rays_o, rays_d):
+    _ck(lib().f2n_img2world_rays(_stream(), _i(n), _p(poses, "f32"), _p(intri, "f32"), _p(dist_params, "f32"), _p(cam_idx, "i32"),
+                                 _p(ij, "i32"), _p(rays_o, "f32"), _p(rays_d, "f32")), "f2n_img2world_rays")
+
+
+def gather_pixels(n, height, width, images, cam_bounds, cam_idx, ij, gt_colors, bounds):
+    _ck(lib().f2n_gather_pixels(_stream(), _i(n), _i(height), _i(width), _p(images, "f32", True), _p(cam_bounds, "f32", True),
+                                _p(cam_idx, "i32"), _p(ij, "i32"), _p(gt_colors, "f32", True), _p(bounds, "f32", True)),
+        "f2n_gather_pixels")
+
+
 # ---------------------------------------------------------------- renderer
 def early_stop(n_rays, pts_se, f0, f0_stride, dt, weights, alphas, mask, kept):
     _ck(lib().f2n_early_stop(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(f0, "f32"), _i(f0_stride), _p(dt, "f32"),

@@ -217,4 +217,37 @@ std::vector<Tensor> ExpRunner::RenderRays(const Tensor& rays_o, const Tensor& ra
   return {rr.colors, rr.disparity, rr.first_oct_dis, rr.depth};
 }
 
+// ExpRunner::RenderWholeImage (ExpRunner.cpp:255-292): all rays of a view in 8192-ray chunks, VALIDATE mode.  The
+// reference bounces every chunk through the CPU; here rays and results stay in HBM.
+std::vector<Tensor> ExpRunner::RenderWholeImage(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  torch::NoGradGuard no_grad;
+  const int n_rays = rays_d.size(0);
+  Tensor pred_colors = torch::zeros({n_rays, 3}, DevF32());
+  Tensor first_oct_disp = torch::full({n_rays, 1}, 1.f, DevF32());
+  Tensor pred_disp = torch::zeros({n_rays, 1}, DevF32());
+  const int ray_batch_size = 8192;
+  for (int i = 0; i < n_rays; i += ray_batch_size) {
+    const int hi = std::min(i + ray_batch_size, n_rays);
+    auto out = RenderRays(rays_o.index({Slc(i, hi)}).contiguous(), rays_d.index({Slc(i, hi)}).contiguous(),
+                          bounds.index({Slc(i, hi)}).contiguous());
+    pred_colors.index_put_({Slc(i, hi)}, out[0]);
+    pred_disp.index_put_({Slc(i, hi)}, out[1].reshape({-1, 1}));
+    if (out[2].defined() && out[2].numel() == hi - i) first_oct_disp.index_put_({Slc(i, hi)}, out[2].reshape({-1, 1}));
+  }
+  pred_disp = pred_disp / pred_disp.max();
+  first_oct_disp = first_oct_disp.min() / first_oct_disp;
+  return {pred_colors, first_oct_disp, pred_disp};
+}
+
+// The per-image body of ExpRunner::TestImages (ExpRunner.cpp:333-372): render camera idx of the data set, PSNR against
+// the resident ground truth (fp32, no 8-bit quantisation of the prediction).
+float ExpRunner::TestImagePSNR(Dataset& dataset, int idx) {
+  TORCH_CHECK(dataset.image_tensors_.defined(), "no ground-truth images resident");
+  auto rays = dataset.RaysOfCamera(idx);
+  auto out = RenderWholeImage(rays.origins, rays.dirs, rays.bounds);
+  Tensor gt = dataset.image_tensors_[idx].reshape({-1, 3});
+  const float mse = (out[0] - gt).square().mean().item<float>();
+  return 20.f * std::log10(1.f / std::sqrt(mse));
+}
+
 }  // namespace f2n

@@ -2,6 +2,7 @@
 #pragma once
 #include <functional>
 
+#include "Dataset.h"
 #include "Renderer.h"
 
 namespace f2n {
@@ -23,6 +24,8 @@ class ExpRunner {
                                const Tensor& emb_idx, bool apply_optimizer = true);
   float CurVarLossWeight() const;
   std::vector<Tensor> RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
+  std::vector<Tensor> RenderWholeImage(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
+  float TestImagePSNR(Dataset& dataset, int idx);
   void UpdateAdaParams();
   void OptimStep(const int32_t* skip_flag = nullptr);  // skip_flag: device int, != 0 drops the update
   void BuildOptimizer();

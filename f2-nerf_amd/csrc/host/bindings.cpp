@@ -27,6 +27,32 @@ py::dict StatsToDict(const TrainStats& s) {
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "f2-nerf hot path: C++/LibTorch host layer over libf2n_hip.so";
+  auto bounded = [](const BoundedRays& r) { return std::vector<Tensor>{r.origins, r.dirs, r.bounds}; };
+  auto ray_data = [](const std::tuple<BoundedRays, Tensor, Tensor>& t) {
+    const auto& r = std::get<0>(t);
+    return std::vector<Tensor>{r.origins, r.dirs, r.bounds, std::get<1>(t), std::get<2>(t)};  // + gt colours, image index
+  };
+  py::class_<Dataset>(m, "Dataset")
+      .def(py::init<const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, int, int, const std::vector<int>&,
+                    const std::vector<int>&, const std::vector<int>&>(),
+           py::arg("poses"), py::arg("intri"), py::arg("dist_params"), py::arg("bounds"), py::arg("images"), py::arg("height"),
+           py::arg("width"), py::arg("train_set"), py::arg("test_set"), py::arg("val_set"))
+      .def("img2world_ray_flex", [](Dataset& d, const Tensor& cam, const Tensor& ij) { auto r = d.Img2WorldRayFlex(cam, ij); return std::vector<Tensor>{r.origins, r.dirs}; })
+      .def("gather_colors", &Dataset::GatherColors)
+      .def("rays_of_camera", [bounded](Dataset& d, int idx) { return bounded(d.RaysOfCamera(idx)); })
+      .def("rays_from_pose", [bounded](Dataset& d, const Tensor& pose, int reso) { return bounded(d.RaysFromPose(pose, reso)); },
+           py::arg("pose"), py::arg("reso_level") = 1)
+      .def("rand_rays_from_pose", [bounded](Dataset& d, int n, const Tensor& pose) { return bounded(d.RandRaysFromPose(n, pose)); })
+      .def("rand_rays_whole_space", [bounded](Dataset& d, int n) { return bounded(d.RandRaysWholeSpace(n)); })
+      .def("rand_rays_data", [ray_data](Dataset& d, int n, int sets) { return ray_data(d.RandRaysData(n, sets)); },
+           py::arg("batch_size"), py::arg("sets") = DATA_TRAIN_SET)
+      .def("rand_rays_data_of_camera", [ray_data](Dataset& d, int idx, int n) { return ray_data(d.RandRaysDataOfCamera(idx, n)); })
+      .def_static("pose_interpolate", &PoseInterpolate)
+      .def_readonly("last_cam_indices", &Dataset::last_cam_indices_)
+      .def_readonly("last_ij", &Dataset::last_ij_)
+      .def_readonly("n_images", &Dataset::n_images_)
+      .def_readonly("height", &Dataset::height_)
+      .def_readonly("width", &Dataset::width_);
   py::class_<ExpRunner>(m, "ExpRunner")
       .def(py::init<const std::map<std::string, std::string>&, int>(), py::arg("flat_config"), py::arg("n_images"))
       .def("load_states", &ExpRunner::LoadStates)
@@ -54,6 +80,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
            py::arg("apply_optimizer") = true)
       .def("render_rays", &ExpRunner::RenderRays)
+      .def("render_whole_image", &ExpRunner::RenderWholeImage)
+      .def("test_image_psnr", &ExpRunner::TestImagePSNR)
       .def("render_train",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& emb) {
              r.global_data_pool_->mode_ = RunningMode::TRAIN;

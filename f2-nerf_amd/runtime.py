@@ -80,6 +80,15 @@ def make_runner(state, preset="wanjinyou", overrides=None, seed=2022, table_init
     return runner, cfg, arrays
 
 
+def make_dataset(state, images=None):
+    """Device-resident ray source (host C++ `Dataset`) for the serialised scene; `images` fp32 [C,H,W,3] or None."""
+    H, W = [int(v) for v in state["image_hw"]]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    img = torch.empty(0) if images is None else (images if torch.is_tensor(images) else t(np.asarray(images, np.float32)))
+    return host().Dataset(t(state["poses"]), t(state["intri"]), t(state["dist_params"]), t(state["bounds"]), img, H, W,
+                          [int(v) for v in state["train_set"]], [int(v) for v in state["test_set"]], [])
+
+
 # ---------------------------------------------------------------------------------------------------------
 # synthetic rays (throughput runs): Dataset::RandRaysWholeSpace semantics (Dataset/Dataset.cpp:245-255)
 # ---------------------------------------------------------------------------------------------------------

@@ -287,6 +287,21 @@ int f2n_flex_acc_fwd(void* stream, int n_rays, int include_this, const float* va
 int f2n_flex_acc_bwd(void* stream, int n_rays, int include_this, const float* dsum, const int32_t* start_end, float* dval);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Ray generation -- replaces Dataset::Img2WorldRayFlex / CameraUndistort
+ * (Dataset/Dataset.cu:13-152) and the colour / bounds gathers of Dataset::RandRaysData (Dataset/Dataset.cpp:275-298).
+ * ------------------------------------------------------------------------------------------------- */
+/* Img2WorldRayKernel (Dataset.cu:93-123): ij int32 [n,2] = (row, column); the half-pixel shift of :126 is applied
+ * inside.  poses [C,3,4] row-major c2w, intri [C,3,3], dist_params [C,4] = (k1,k2,p1,p2); Newton undistortion with
+ * central differences, <= 100 iterations (:30-72).  rays_d is NOT normalised (GetSamples does that, :319). */
+int f2n_img2world_rays(void* stream, int n_rays, const float* poses, const float* intri, const float* dist_params,
+                       const int32_t* cam_indices /*[n]*/, const int32_t* ij /*[n,2]*/, float* rays_o /*[n,3]*/,
+                       float* rays_d /*[n,3]*/);
+/* gt_colors[r] = images[cam][i][j][0:3] (images fp32 [C,H,W,3], resident in HBM) and bounds[r] = cam_bounds[cam]
+ * ([C,2]); either output may be NULL. */
+int f2n_gather_pixels(void* stream, int n_rays, int height, int width, const float* images, const float* cam_bounds,
+                      const int32_t* cam_indices, const int32_t* ij, float* gt_colors /*[n,3]*/, float* bounds /*[n,2]*/);
+
+/* ---------------------------------------------------------------------------------------------------
  * Optimiser -- replaces torch::optim::Adam::step over the groups of Hash3DAnchored::OptimParamGroups
  * (Field/Hash3DAnchored.cpp:124-150), SHShader (Shader/SHShader.cpp:44-56), Renderer (Renderer.cpp:238-258):
  * beta = (0.9, 0.99), eps = 1e-15, L2 weight decay added to the gradient (torch Adam semantics).

@@ -114,6 +114,18 @@ def normalize_dirs(dirs):
     return out
 
 
+def img2world(poses, intri, dist, cam_idx, ij):
+    """ij: integer (row, column) pixel indices; the half-pixel shift is applied inside (Dataset.cu:126)."""
+    poses, intri, dist = _f32(poses), _f32(intri), _f32(dist)
+    cam_idx = np.ascontiguousarray(cam_idx, np.int32)
+    ij = np.ascontiguousarray(ij, np.int32)
+    n = cam_idx.shape[0]
+    o = np.empty((n, 3), np.float32)
+    d = np.empty((n, 3), np.float32)
+    lib().oracle_img2world(ctypes.c_int(n), _p(poses), _p(intri), _p(dist), _p(cam_idx), _p(ij), _p(o), _p(d))
+    return o, d
+
+
 def oct_intersect(search_order, rays_o, rays_d, near, far, tree_nodes, max_hits=1024):
     rays_o, rays_d = _f32(rays_o), _f32(rays_d)
     n = rays_o.shape[0]

@@ -132,6 +132,70 @@ void oracle_normalize_dirs(int n, const float* in, float* out) {
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * pixel -> world ray.  Dataset.cu:13-72 (distortion model + Newton undistortion, "from
+ * instant-ngp") and :93-123 (Img2WorldRayKernel).  Eigen 2x2 inverse as in Eigen/src/LU/InverseImpl.h (size-2
+ * helper: invdet = 1/det, det = m00*m11 - m10*m01), 3-term dot products in Eigen's a + (b + c) order.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void or_distort(const float* k, float u, float v, float* du, float* dv) { /* Dataset.cu:13-27 */
+  const float k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3];
+  const float u2 = u * u, uv = u * v, v2 = v * v;
+  const float r2 = u2 + v2;
+  const float radial = k1 * r2 + k2 * r2 * r2;
+  *du = u * radial + 2.f * p1 * uv + p2 * (r2 + 2.f * u2);
+  *dv = v * radial + 2.f * p2 * uv + p1 * (r2 + 2.f * v2);
+}
+
+static inline void or_undistort(const float* k, float* u, float* v) { /* Dataset.cu:30-72 */
+  const float eps = 1.1920928955078125e-07f; /* std::numeric_limits<float>::epsilon() */
+  const float x0[2] = {*u, *v};
+  float x[2] = {*u, *v};
+  for (int it = 0; it < 100; it++) {
+    const float step0 = fmaxf(eps, fabsf(1e-6f * x[0]));
+    const float step1 = fmaxf(eps, fabsf(1e-6f * x[1]));
+    float dx[2], d0b[2], d0f[2], d1b[2], d1f[2];
+    or_distort(k, x[0], x[1], &dx[0], &dx[1]);
+    or_distort(k, x[0] - step0, x[1], &d0b[0], &d0b[1]);
+    or_distort(k, x[0] + step0, x[1], &d0f[0], &d0f[1]);
+    or_distort(k, x[0], x[1] - step1, &d1b[0], &d1b[1]);
+    or_distort(k, x[0], x[1] + step1, &d1f[0], &d1f[1]);
+    const float j00 = 1.f + (d0f[0] - d0b[0]) / (2.f * step0);
+    const float j01 = (d1f[0] - d1b[0]) / (2.f * step1);
+    const float j10 = (d0f[1] - d0b[1]) / (2.f * step0);
+    const float j11 = 1.f + (d1f[1] - d1b[1]) / (2.f * step1);
+    const float invdet = 1.f / (j00 * j11 - j10 * j01);
+    const float i00 = j11 * invdet, i10 = -j10 * invdet, i01 = -j01 * invdet, i11 = j00 * invdet;
+    const float r0 = x[0] + dx[0] - x0[0], r1 = x[1] + dx[1] - x0[1];
+    const float s0 = i00 * r0 + i01 * r1, s1 = i10 * r0 + i11 * r1;
+    x[0] -= s0;
+    x[1] -= s1;
+    if (s0 * s0 + s1 * s1 < 1e-10f) break;
+  }
+  *u = x[0];
+  *v = x[1];
+}
+
+/* poses [C,3,4] row-major, intri [C,3,3], dist [C,4] = (k1,k2,p1,p2), ij int32 [n,2] = (row, column); the half-pixel
+ * shift of Dataset.cu:126 (`ij + .5f`) is applied here. */
+void oracle_img2world(int n_rays, const float* poses, const float* intri, const float* dist, const int32_t* cam_idx,
+                      const int32_t* ij, float* rays_o, float* rays_d) {
+  for (int r = 0; r < n_rays; r++) {
+    const int c = cam_idx[r];
+    const float* K = intri + 9 * c;
+    const float* P = poses + 12 * c;
+    const float i = (float) ij[2 * r] + .5f, j = (float) ij[2 * r + 1] + .5f;
+    const float cx = K[2], cy = K[5], fx = K[0], fy = K[4];
+    float u = (j - cx) / fx;
+    float v = (i - cy) / fy; /* OpenCV style */
+    or_undistort(dist + 4 * c, &u, &v);
+    const float dir[3] = {u, -v, -1.f}; /* OpenGL style */
+    for (int a = 0; a < 3; a++) {
+      rays_d[3 * r + a] = or_sum3(P[4 * a] * dir[0], P[4 * a + 1] * dir[1], P[4 * a + 2] * dir[2]);
+      rays_o[3 * r + a] = P[4 * a + 3];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * a5: ray / octree intersection.  PersSampler.cu:21-51 (slab test), :53-152 (DFS).
  * ---------------------------------------------------------------------------------------------- */
 static inline void or_slab(const float* o, const float* d, const float* c, float side, float* near, float* far) {

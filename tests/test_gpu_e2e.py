@@ -223,3 +223,42 @@ def test_proc_octree_matches_restatement(rt, fox_state):
     assert len(got2) == len(exp2)
     for f in ("parent", "childs", "is_leaf_node", "trans_idx"):
         assert (got2[f] == exp2[f]).all(), f
+
+
+def test_dataset_rays_and_whole_image_render(rt, fox_state):
+    """device-resident ray generation (host `Dataset`) and whole-image rendering."""
+    st = fox_state
+    H, W = [int(v) for v in st["image_hw"]]
+    rng = np.random.default_rng(8)
+    n_img = len(st["poses"])
+    images = torch.from_numpy(rng.random((n_img, H // 8, W // 8, 3), dtype=F32))  # small synthetic "photos"
+    small = dict(st); small["image_hw"] = np.array([H // 8, W // 8]); small["intri"] = st["intri"].copy()
+    small["intri"][:, :2, :] /= 8.0
+    ds = rt.make_dataset(small, images)
+    torch.manual_seed(5)
+    ro, rd, bounds, gt, cam = ds.rand_rays_data(4096, 1)
+    cam_np, ij_np = cam.cpu().numpy(), ds.last_ij.cpu().numpy()
+    assert set(cam_np.tolist()) <= set(int(v) for v in st["train_set"]) and len(set(cam_np.tolist())) > 20
+    assert ij_np[:, 0].max() < H // 8 and ij_np[:, 1].max() < W // 8 and ij_np.min() >= 0
+    from oracle import capi as oc
+    eo, ed = oc.img2world(small["poses"], small["intri"], small["dist_params"], cam_np, ij_np)
+    assert (ro.cpu().numpy().view(np.uint32) == eo.view(np.uint32)).all() and (rd.cpu().numpy().view(np.uint32) == ed.view(np.uint32)).all()
+    assert (gt.cpu().numpy() == images.numpy()[cam_np, ij_np[:, 0], ij_np[:, 1]]).all()
+    assert (bounds.cpu().numpy() == st["bounds"][cam_np]).all()
+    # random-pose rays: unit-norm rotation, origin inside the hull of the blended cameras' window
+    wo, wd, wb = ds.rand_rays_whole_space(1000)
+    assert wo.shape == (1000, 3) and torch.isfinite(wd).all() and float((wo - wo[0]).abs().max()) == 0.0
+    pa = ds.pose_interpolate(torch.from_numpy(st["poses"][3]), torch.from_numpy(st["poses"][7]), 0.25).numpy()
+    R = pa[:, :3]
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5 and np.allclose(pa[:, 3], 0.75 * st["poses"][3][:, 3] + 0.25 * st["poses"][7][:, 3], atol=1e-6)
+    assert np.allclose(ds.pose_interpolate(torch.from_numpy(st["poses"][3]), torch.from_numpy(st["poses"][7]), 0.0).numpy(), st["poses"][3], atol=1e-5)
+    # whole-image render == the same rays rendered chunk by chunk; PSNR helper agrees with its definition
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=14"], seed=3, table_init=0.3)
+    co, cd, cb = ds.rays_of_camera(int(st["test_set"][0]))
+    assert co.shape[0] == (H // 8) * (W // 8)
+    img, first_oct, disp = runner.render_whole_image(co, cd, cb)
+    chunks = [runner.render_rays(co[i:i + 8192], cd[i:i + 8192], cb[i:i + 8192])[0] for i in range(0, co.shape[0], 8192)]
+    assert (torch.cat(chunks) == img).all() and float(disp.max()) == 1.0 and torch.isfinite(first_oct).all()
+    psnr = runner.test_image_psnr(ds, int(st["test_set"][0]))
+    mse = float(((img.cpu() - images[int(st["test_set"][0])].reshape(-1, 3)) ** 2).mean())
+    assert abs(psnr - 10 * np.log10(1.0 / mse)) < 1e-3

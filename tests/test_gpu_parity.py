@@ -776,6 +776,40 @@ def test_nonfinite_flags_and_skipped_adam(hip):
     assert (N(tp) != p).any()
 
 
+def test_img2world_rays_and_pixel_gather(hip, fox_state, fox_golden):
+    """Dataset.cu:93-123 on the device: bit-exact against the oracle (itself pinned on the reference kernel), for the fox
+    cameras, for strongly distorted synthetic cameras, and against the committed golden rays."""
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(41)
+    n = 20000
+    H, W = [int(v) for v in st["image_hw"]]
+    cam = rng.integers(0, len(st["poses"]), n).astype(np.int32)
+    ij = np.stack([rng.integers(0, H, n), rng.integers(0, W, n)], -1).astype(np.int32)
+    strong = (rng.standard_normal(st["dist_params"].shape) * [0.2, 0.05, 0.01, 0.01]).astype(F32)
+    for dist in (st["dist_params"], strong):
+        o = torch.zeros((n, 3), device=DEV); d = torch.zeros((n, 3), device=DEV)
+        hip.img2world_rays(n, T(st["poses"]), T(st["intri"]), T(dist), T(cam), T(ij), o, d)
+        ro, rd = oc.img2world(st["poses"], st["intri"], dist, cam, ij)
+        assert_same(N(o), ro, "ray origins")
+        ok = ~np.isnan(rd)
+        assert ok.mean() > 0.99 and (np.isnan(N(d)) == ~ok).all()
+        assert (N(d).view(np.uint32)[ok] == rd.view(np.uint32)[ok]).all(), "ray directions"
+    gij = (g["ij"] - F32(.5)).astype(np.int32)
+    m = len(gij)
+    o = torch.zeros((m, 3), device=DEV); d = torch.zeros((m, 3), device=DEV)
+    hip.img2world_rays(m, T(st["poses"]), T(st["intri"]), T(st["dist_params"]), T(g["cam"]), T(gij), o, d)
+    assert_same(N(o), g["rays_o"], "golden origins"); assert_same(N(d), g["rays_d_raw"], "golden directions")
+    # pixel / bounds gather from resident images
+    C, h, w = 5, 13, 17
+    images = rng.random((C, h, w, 3), dtype=F32)
+    cb = rng.random((C, 2), dtype=F32)
+    cam2 = rng.integers(0, C, 3000).astype(np.int32)
+    ij2 = np.stack([rng.integers(0, h, 3000), rng.integers(0, w, 3000)], -1).astype(np.int32)
+    col = torch.zeros((3000, 3), device=DEV); bnd = torch.zeros((3000, 2), device=DEV)
+    hip.gather_pixels(3000, h, w, T(images), T(cb), T(cam2), T(ij2), col, bnd)
+    assert_same(N(col), images[cam2, ij2[:, 0], ij2[:, 1]], "pixels"); assert_same(N(bnd), cb[cam2], "bounds")
+
+
 def test_errors_are_loud(hip):
     x = torch.zeros((4, 32), device=DEV)
     with pytest.raises(Exception):

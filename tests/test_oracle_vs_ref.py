@@ -27,6 +27,24 @@ def _rays(st, rng, n, all_cams=True):
     return o, (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32), cam
 
 
+def test_img2world_rays_bit_exact(fox_state):
+    """Dataset.cu:13-123 (pixel -> world ray with Newton undistortion): restatement == reference kernel, bit for bit,
+    on the fox cameras and on synthetic cameras with strong distortion (many Newton iterations)."""
+    st = fox_state
+    rng = np.random.default_rng(3)
+    n = 5000
+    cam = rng.integers(0, len(st["poses"]), n).astype(np.int32)
+    ij = np.stack([rng.integers(0, 960, n), rng.integers(0, 540, n)], -1).astype(np.int32)
+    for dist in (st["dist_params"], (rng.standard_normal(st["dist_params"].shape) * [0.3, 0.1, 0.02, 0.02]).astype(np.float32),
+                 np.zeros_like(st["dist_params"])):
+        want_o, want_d = ref.img2world(st["poses"], st["intri"], dist, cam, ij.astype(np.float32) + np.float32(.5))
+        got_o, got_d = capi.img2world(st["poses"], st["intri"], dist, cam, ij)
+        assert (got_o.view(np.uint32) == want_o.view(np.uint32)).all()
+        nan = np.isnan(want_d)  # a diverged Newton iteration (possible under the strong synthetic distortion): NaN on both
+        assert (np.isnan(got_d) == nan).all() and nan.mean() < 0.01
+        assert (got_d.view(np.uint32)[~nan] == want_d.view(np.uint32)[~nan]).all()
+
+
 def test_layout_facts():
     lay = ref.struct_layout().tolist()
     assert lay == [64, 0, 12, 16, 20, 52, 56, 544, 0, 384, 528, 540, 64, 0, 4, 8, 20, 32]  # SURVEY 8(a) a1-a3
