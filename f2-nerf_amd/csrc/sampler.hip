@@ -239,7 +239,11 @@ __device__ __forceinline__ float f2n_quad_sum(float p) {
   return t + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));           // [2,3,0,1]
 }
 
-template <bool FILL>
+// MODE 0: count only.  MODE 1: fill ray-ordered compact arrays (segments from f2n_segment_scan).  MODE 2: ONE pass into
+// fixed-stride per-ray slots [ray * 1024 + k] (pts, dt, t, anchors as (trans, node) pairs; dirs are not written) plus the
+// per-ray counts -- f2n_pack_samples then copies the filled prefix of every slot into the compact arrays, which costs a
+// few tens of MB of streaming instead of a second march.
+template <int MODE>
 __global__ __launch_bounds__(64) void ray_march_kernel(
     int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ noise_all, const int32_t* __restrict__ oct_start_end, const int32_t* __restrict__ oct_idx_all,
@@ -251,12 +255,15 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
   const int ray = blockIdx.x * F2N_MARCH_RAYS_PER_BLOCK + (threadIdx.x >> 2);
   if (ray >= n_rays) return;  // whole quads leave together
   const int oct_s = oct_start_end[2 * ray], n_oct = oct_start_end[2 * ray + 1] - oct_s;
-  int max_n = F2N_MAX_SAMPLE_PER_RAY, base = 0;
-  if (FILL) {
-    base = pts_start_end[2 * ray];
-    max_n = pts_start_end[2 * ray + 1] - base;
-    if (j == 0) first_oct_dis[ray] = n_oct > 0 ? near_far_all[2 * oct_s] : 1e9f;  // :226-231
+  constexpr bool FILL = MODE != 0;
+  int max_n = F2N_MAX_SAMPLE_PER_RAY;
+  size_t base = 0;
+  if (MODE == 1) {
+    base = (size_t) pts_start_end[2 * ray];
+    max_n = pts_start_end[2 * ray + 1] - (int) base;
   }
+  if (MODE == 2) base = (size_t) ray * F2N_MAX_SAMPLE_PER_RAY;
+  if (FILL && j == 0) first_oct_dis[ray] = n_oct > 0 ? near_far_all[2 * oct_s] : 1e9f;  // :226-231
   int n = 0;
   if (n_oct > 0 && max_n > 0) {
     const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
       float march = step;
       if (!first) {  // the first point of a ray is never emitted (:274-289)
         if (FILL) {
-          const int k = base + n;
+          const size_t k = base + (size_t) n;
           float w[3];  // the warped point (:155-169) shares the projections with the Jacobian
           float v[3];
 #pragma unroll
@@ -330,15 +337,20 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
 #pragma unroll
             for (int c = 0; c < 3; c++) pts[3 * k + c] = w[c];
           } else if (j == 1) {
+            if (MODE == 1) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) dirs[3 * k + c] = d[c];
+              for (int c = 0; c < 3; c++) dirs[3 * k + c] = d[c];
+            }
           } else if (j == 2) {
             ts[k] = cur_t;
             dts[k] = step * pj_norm;
-          } else {
+          } else if (MODE == 1) {
             anchors[3 * k] = tidx;
             anchors[3 * k + 1] = cur_oct;
             anchors[3 * k + 2] = 0;
+          } else {
+            anchors[2 * k] = tidx;
+            anchors[2 * k + 1] = cur_oct;
           }
         }
         n++;
@@ -361,7 +373,32 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
       first = false;
     }
   }
-  if (!FILL && j == 0) pts_counts[ray] = n;
+  if (MODE != 1 && j == 0) pts_counts[ray] = n;
+}
+
+// Strided slots -> ray-ordered compact SampleResultFlex arrays (one wave per ray, coalesced copies).
+__global__ __launch_bounds__(256) void pack_samples_kernel(int n_rays, const int32_t* __restrict__ pts_start_end,
+                                                           const float* __restrict__ rays_d, const float* __restrict__ s_pts,
+                                                           const float* __restrict__ s_dt, const float* __restrict__ s_t,
+                                                           const int32_t* __restrict__ s_anchors, float* __restrict__ pts,
+                                                           float* __restrict__ dirs, float* __restrict__ dt, float* __restrict__ t,
+                                                           int32_t* __restrict__ anchors) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int s = pts_start_end[2 * ray], cnt = pts_start_end[2 * ray + 1] - s;
+  const size_t src = (size_t) ray * F2N_MAX_SAMPLE_PER_RAY;
+  const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+  for (int i = lane; i < 3 * cnt; i += 64) {
+    pts[3 * (size_t) s + i] = s_pts[3 * src + i];
+    dirs[3 * (size_t) s + i] = d[i % 3];
+    const int k = i / 3, c = i - 3 * k;
+    anchors[3 * (size_t) s + i] = c < 2 ? s_anchors[2 * (src + k) + c] : 0;
+  }
+  for (int i = lane; i < cnt; i += 64) {
+    dt[s + i] = s_dt[src + i];
+    t[s + i] = s_t[src + i];
+  }
 }
 
 // rays_d / ||rays_d|| (PersSampler.cu:319).  The reference uses torch::linalg_norm, whose summation order is an
@@ -617,7 +654,7 @@ int f2n_ray_march_count(void* stream, int n_rays, float sample_l, int scale_by_d
                         const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(ray_march_kernel<false>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
+  hipLaunchKernelGGL(ray_march_kernel<0>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -631,10 +668,33 @@ int f2n_ray_march_fill(void* stream, int n_rays, float sample_l, int scale_by_di
                        float* first_oct_dis) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(ray_march_kernel<true>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
+  hipLaunchKernelGGL(ray_march_kernel<1>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, pts_start_end, nullptr,
                      pts, dirs, dt, t, anchors, first_oct_dis);
+  return f2n_launch_status();
+}
+
+int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o, const float* rays_d,
+                          const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx, const float* oct_near_far,
+                          const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts, float* s_dt, float* s_t,
+                          int32_t* s_anchors, float* first_oct_dis) {
+  if (n_rays < 0) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
+                     (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
+                     oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
+                     nullptr, s_dt, s_t, s_anchors, first_oct_dis);
+  return f2n_launch_status();
+}
+
+int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_d, const float* s_pts,
+                     const float* s_dt, const float* s_t, const int32_t* s_anchors, float* pts, float* dirs, float* dt, float* t,
+                     int32_t* anchors) {
+  if (n_rays < 0) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(pack_samples_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, pts_start_end,
+                     rays_d, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors);
   return f2n_launch_status();
 }
 

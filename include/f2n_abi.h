@@ -95,6 +95,21 @@ int f2n_ray_march_fill(void* stream, int n_rays, float sample_l, int scale_by_di
                        float* dirs /*[N,3]*/, float* dt /*[N]*/, float* t /*[N]*/, int32_t* anchors /*[N,3]*/,
                        float* first_oct_dis /*[R]*/);
 
+/* Single-pass variant of count + scan + fill: ONE march writes every ray's samples into its fixed-stride slot
+ * [r*F2N_MAX_SAMPLE_PER_RAY, ...) of s_pts [R*1024,3], s_dt / s_t [R*1024], s_anchors [R*1024,2] = (trans_idx, node)
+ * and its sample count into pts_counts[r]; after f2n_segment_scan(pts_counts), f2n_pack_samples copies the filled
+ * prefixes into the ray-ordered compact SampleResultFlex arrays (dirs come from rays_d, anchors[:,2] = 0).
+ * Per-ray contents are identical to the count/fill pair (same march, executed once instead of twice); the slot
+ * buffers are scratch of which only the filled prefixes are ever touched. */
+int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o,
+                          const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                          const float* oct_near_far, const void* tree_nodes, const void* transes,
+                          int32_t* pts_counts /*[R]*/, float* s_pts, float* s_dt, float* s_t, int32_t* s_anchors,
+                          float* first_oct_dis /*[R]*/);
+int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end /*[R,2]*/, const float* rays_d,
+                     const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors, float* pts /*[N,3]*/,
+                     float* dirs /*[N,3]*/, float* dt /*[N]*/, float* t /*[N]*/, int32_t* anchors /*[N,3]*/);
+
 /* GetEdgeSamplesKernel (PersSampler.cu:436-452).  edge_idx/edge_coords are the random draws of :456-457. */
 int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,
                      const float* edge_coords /*[n,2]*/, float* out_pts /*[n,2,3]*/, int32_t* out_idx /*[n,2]*/);

@@ -133,6 +133,23 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
     pcnt = torch.zeros(n, dtype=torch.int32, device=DEV)
     hip.ray_march_count(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, pcnt)
     assert_same(N(pcnt), (ref["pts_idx_bounds"][:, 1] - ref["pts_idx_bounds"][:, 0]).astype(np.int32), "march count on strided hits")
+    # single-pass march (strided slots + pack) == the count / scan / fill triple, bit for bit
+    S = 1024
+    cnt2 = torch.zeros(n, dtype=torch.int32, device=DEV)
+    s_pts = torch.zeros((n * S, 3), device=DEV); s_dt = torch.zeros(n * S, device=DEV); s_t = torch.zeros(n * S, device=DEV)
+    s_an = torch.zeros((n * S, 2), dtype=torch.int32, device=DEV); fod = torch.zeros(n, device=DEV)
+    hip.ray_march_strided(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, cnt2, s_pts, s_dt, s_t, s_an, fod)
+    assert_same(N(cnt2), N(pcnt), "single-pass counts")
+    pse2 = torch.zeros((n, 2), dtype=torch.int32, device=DEV)
+    hip.segment_scan(n, cnt2, pse2, tot)
+    tot_n = int(tot.item()); mm = max(tot_n, 1)
+    packed = dict(pts=torch.zeros((mm, 3), device=DEV), dirs=torch.zeros((mm, 3), device=DEV), dt=torch.zeros(mm, device=DEV),
+                  t=torch.zeros(mm, device=DEV), anchors=torch.full((mm, 3), -7, dtype=torch.int32, device=DEV))
+    hip.pack_samples(n, pse2, T(d), s_pts, s_dt, s_t, s_an, packed["pts"], packed["dirs"], packed["dt"], packed["t"], packed["anchors"])
+    assert_same(N(pse2), ref["pts_idx_bounds"], "single-pass bounds")
+    for k in ("pts", "dirs", "dt", "t", "anchors"):
+        assert_same(N(packed[k])[:tot_n], ref[k], "single-pass " + k)
+    assert_same(N(fod).reshape(n, 1), ref["first_oct_dis"], "single-pass first_oct_dis")
 
 
 def test_sampler_full_size_properties(hip, fox_state):
