@@ -73,10 +73,12 @@ def oct_intersect_count(n_rays, max_hits, search_order, rays_o, rays_d, near, fa
         "f2n_oct_intersect_count")
 
 
-def oct_intersect_strided(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total):
+def oct_intersect_strided(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total,
+                          oct_trans=None):
     _ck(lib().f2n_oct_intersect_strided(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
                                         _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
-                                        _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32")), "f2n_oct_intersect_strided")
+                                        _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True)),
+        "f2n_oct_intersect_strided")
 
 
 def segment_scan(n, counts, start_end, total):
@@ -108,11 +110,11 @@ def ray_march_fill(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se
 
 
 def ray_march_strided(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes, transes, counts,
-                      s_pts, s_dt, s_t, s_anchors, first_oct_dis):
+                      s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans=None):
     _ck(lib().f2n_ray_march_strided(_stream(), _i(n_rays), _f(sample_l), _i(int(scale_by_dis)), _p(rays_o, "f32"), _p(rays_d, "f32"),
                                     _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(tree_nodes, "u8"),
                                     _p(transes, "u8"), _p(counts, "i32"), _p(s_pts, "f32"), _p(s_dt, "f32"), _p(s_t, "f32"),
-                                    _p(s_anchors, "i32"), _p(first_oct_dis, "f32")), "f2n_ray_march_strided")
+                                    _p(s_anchors, "i32"), _p(first_oct_dis, "f32"), _p(oct_trans, "i32", True)), "f2n_ray_march_strided")
 
 
 def pack_samples(n_rays, pts_se, rays_d, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors):

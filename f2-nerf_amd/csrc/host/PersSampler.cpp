@@ -73,9 +73,10 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   const int64_t k_cap = int64_t(n_rays) * max_oct_intersect_per_ray_;
   Tensor oct_idx = torch::empty({k_cap}, DevI32());
   Tensor oct_nf = torch::empty({k_cap, 2}, DevF32());
+  Tensor oct_tr = torch::empty({k_cap}, DevI32());  // trans_idx of every listed leaf (the march would re-read the node)
   F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided(st, n_rays, max_oct_intersect_per_ray_,
                                   oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
-                                  VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals)));
+                                  VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr)));
 
   Tensor rays_noise;  // :372-381
   if (forced_noise_.defined()) {
@@ -100,7 +101,7 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   F2N_TIMED_CALL("ray_march", f2n_ray_march_strided(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
                                  I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
                                  VoidP(oct.pers_trans_gpu_), I32P(counts), F32P(s_pts), F32P(s_dt), F32P(s_t), I32P(s_anchors),
-                                 F32P(res.first_oct_dis)));
+                                 F32P(res.first_oct_dis), I32P(oct_tr)));
   F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(pts_se), I32P(totals) + 1));
 
   Tensor totals_cpu = totals.cpu();  // the single host read-back of this call

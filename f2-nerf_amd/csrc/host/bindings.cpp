@@ -162,6 +162,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_readonly("cur_lr", &ExpRunner::cur_lr_)
       .def_property("n_edge_pts", [](ExpRunner& r) { return r.renderer_->n_edge_pts_; }, [](ExpRunner& r, int n) { r.renderer_->n_edge_pts_ = n; })
       .def_property_readonly("fineness", [](ExpRunner& r) { return r.global_data_pool_->ray_march_fineness_; })
+      .def_property_readonly("oct_per_ray", [](ExpRunner& r) { return r.global_data_pool_->sampled_oct_per_ray_; })
+      .def_property_readonly("sampled_per_ray", [](ExpRunner& r) { return r.global_data_pool_->sampled_pts_per_ray_; })
       .def_property_readonly("meaningful_per_ray", [](ExpRunner& r) { return r.global_data_pool_->meaningful_sampled_pts_per_ray_; })
       .def_property_readonly("n_volumes", [](ExpRunner& r) { return r.global_data_pool_->n_volumes_; })
       .def("update_ada_params", &ExpRunner::UpdateAdaParams);

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     int n_rays, int max_hits, const uint8_t* __restrict__ search_order, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, float g_near, float g_far, const F2nTreeNode* __restrict__ nodes,
     const int32_t* __restrict__ oct_start_end, int32_t* __restrict__ hit_counts, int32_t* __restrict__ oct_idx,
-    float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total) {
+    float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total,
+    int32_t* __restrict__ oct_trans) {
   __shared__ int s_node[F2N_STACK_DEPTH][F2N_COOP_RAYS_PER_BLOCK];
   __shared__ int s_rem[F2N_STACK_DEPTH][F2N_COOP_RAYS_PER_BLOCK];
   const int tid = threadIdx.x, k = tid & 7, grp = tid >> 3;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
           oct_idx[base] = 0;
           oct_near_far[2 * base] = near_;
           oct_near_far[2 * base + 1] = far_;
+          if (oct_trans != nullptr) oct_trans[base] = nodes[0].trans_idx;
         }
         cnt = 1;
       }
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     }
     // ---- test this lane's child of `cur` ----
     bool hit = false, interior = false, valid_leaf = false;
-    int child = -1;
+    int child = -1, child_trans = -1;
     float near_ = g_near, far_ = g_far;
     if (active && ((rem >> k) & 1)) {
       child = nodes[cur].childs[my_slot];
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
         if (hit) {
 #pragma unroll
           for (int c = 0; c < 8; c++) interior |= nd->childs[c] >= 0;
-          valid_leaf = !interior && nd->trans_idx >= 0;
+          child_trans = nd->trans_idx;
+          valid_leaf = !interior && child_trans >= 0;
         }
       }
     }
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
           oct_idx[base + cnt + rank] = child;
           oct_near_far[2 * (base + cnt + rank)] = near_;
           oct_near_far[2 * (base + cnt + rank) + 1] = far_;
+          if (oct_trans != nullptr) oct_trans[base + cnt + rank] = child_trans;  // saves the march a dependent node read
         }
       }
       cnt = min(limit, cnt + __popc(front));
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
     const float* __restrict__ near_far_all, const F2nTreeNode* __restrict__ nodes, const F2nTransInfo* __restrict__ transes,
     const int32_t* __restrict__ pts_start_end, int32_t* __restrict__ pts_counts, float* __restrict__ pts,
     float* __restrict__ dirs, float* __restrict__ dts, float* __restrict__ ts, int32_t* __restrict__ anchors,
-    float* __restrict__ first_oct_dis) {
+    float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all) {
   const int j = threadIdx.x & 3;
   const int ray = blockIdx.x * F2N_MARCH_RAYS_PER_BLOCK + (threadIdx.x >> 2);
   if (ray >= n_rays) return;  // whole quads leave together
@@ -273,9 +277,27 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
     const float* near_far = near_far_all + 2 * oct_s;
     int oct_ptr = 0;
     bool first = true;
-    int cur_oct = oct_idx[0];
-    int tidx = nodes[cur_oct].trans_idx, cached_tidx = -1;
-    float cur_t = near_far[0], cur_far = near_far[1];
+    // A window of the next four leaf entries (node, transform, near, far) lives in registers: a leaf crossing is a
+    // register select, and the window is refilled with independent loads every fourth crossing.  In a converged scene a
+    // ray crosses ~100 leaves; one dependent L2 round trip (entry -> node -> transform) per crossing was the march's
+    // critical path there.
+    const int32_t* oct_trans = oct_trans_all != nullptr ? oct_trans_all + oct_s : nullptr;
+    int w_idx[4], w_tr[4], win_base = 0;
+    float w_near[4], w_far[4];
+    auto fill_window = [&](int b) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int e = min(b + q, n_oct - 1);
+        w_idx[q] = oct_idx[e];
+        w_near[q] = near_far[2 * e];
+        w_far[q] = near_far[2 * e + 1];
+        w_tr[q] = oct_trans != nullptr ? oct_trans[e] : -2;
+      }
+    };
+    fill_window(0);
+    int cur_oct = w_idx[0];
+    int tidx = w_tr[0] != -2 ? w_tr[0] : nodes[cur_oct].trans_idx, cached_tidx = -1;
+    float cur_t = w_near[0], cur_far = w_far[0];
     float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
     float m[3][8], wg[3][3], radius_clip = 1.f;  // this lane's share of the current TransInfo
     while (n < max_n && oct_ptr < n_oct) {
@@ -356,17 +378,24 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
         n++;
       }
       bool crossed = false;
+      int new_tr = -2;
       while (cur_t + march > cur_far) {  // leaf crossing (:291-301)
         oct_ptr++;
         if (oct_ptr >= n_oct) break;
-        cur_oct = oct_idx[oct_ptr];
+        if (oct_ptr - win_base >= 4) {
+          win_base = oct_ptr;
+          fill_window(win_base);
+        }
+        const int q = oct_ptr - win_base;
+        cur_oct = q == 0 ? w_idx[0] : q == 1 ? w_idx[1] : q == 2 ? w_idx[2] : w_idx[3];
+        new_tr = q == 0 ? w_tr[0] : q == 1 ? w_tr[1] : q == 2 ? w_tr[2] : w_tr[3];
+        const float cur_near = q == 0 ? w_near[0] : q == 1 ? w_near[1] : q == 2 ? w_near[2] : w_near[3];
+        cur_far = q == 0 ? w_far[0] : q == 1 ? w_far[1] : q == 2 ? w_far[2] : w_far[3];
         crossed = true;
-        const float cur_near = near_far[2 * oct_ptr];
-        cur_far = near_far[2 * oct_ptr + 1];
         const int ex = (int) ceilf(fmaxf((cur_near - cur_t) / step, 1.f));
         march = step * (float) ex;
       }
-      if (crossed) tidx = nodes[cur_oct].trans_idx;
+      if (crossed) tidx = new_tr != -2 ? new_tr : nodes[cur_oct].trans_idx;
       cur_t += march;
 #pragma unroll
       for (int c = 0; c < 3; c++) xyz[c] = o[c] + d[c] * cur_t;
@@ -616,18 +645,18 @@ int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(oct_intersect_coop_kernel<0>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr, nullptr, nullptr);
+                     (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
 int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                               const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
-                              int32_t* oct_idx, float* oct_near_far, int32_t* total) {
+                              int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans) {
   if (n_rays < 0 || max_hits < 1) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(oct_intersect_coop_kernel<2>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total);
+                     (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total, oct_trans);
   return f2n_launch_status();
 }
 
@@ -645,7 +674,7 @@ int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(oct_intersect_coop_kernel<1>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, 0, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far, nullptr, nullptr);
+                     (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -657,7 +686,7 @@ int f2n_ray_march_count(void* stream, int n_rays, float sample_l, int scale_by_d
   hipLaunchKernelGGL(ray_march_kernel<0>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -671,20 +700,20 @@ int f2n_ray_march_fill(void* stream, int n_rays, float sample_l, int scale_by_di
   hipLaunchKernelGGL(ray_march_kernel<1>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, pts_start_end, nullptr,
-                     pts, dirs, dt, t, anchors, first_oct_dis);
+                     pts, dirs, dt, t, anchors, first_oct_dis, nullptr);
   return f2n_launch_status();
 }
 
 int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o, const float* rays_d,
                           const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx, const float* oct_near_far,
                           const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts, float* s_dt, float* s_t,
-                          int32_t* s_anchors, float* first_oct_dis) {
+                          int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
-                     nullptr, s_dt, s_t, s_anchors, first_oct_dis);
+                     nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans);
   return f2n_launch_status();
 }
 

@@ -75,7 +75,8 @@ int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order
 int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                               const float* rays_d, float near_, float far_, const void* tree_nodes,
                               int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[R*max_hits]*/,
-                              float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/);
+                              float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/,
+                              int32_t* oct_trans /*[R*max_hits] or NULL: trans_idx of every listed leaf*/);
 
 /* RayMarchKernel<false> (PersSampler.cu:189-314, launched :383-393).  noise has
  * F2N_MAX_SAMPLE_PER_RAY + n_rays + 10 floats, already multiplied by ray_march_fineness (:372-381), and is
@@ -105,7 +106,8 @@ int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by
                           const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
                           const float* oct_near_far, const void* tree_nodes, const void* transes,
                           int32_t* pts_counts /*[R]*/, float* s_pts, float* s_dt, float* s_t, int32_t* s_anchors,
-                          float* first_oct_dis /*[R]*/);
+                          float* first_oct_dis /*[R]*/,
+                          const int32_t* oct_trans /*NULL, or f2n_oct_intersect_strided's: spares a node read per leaf*/);
 int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end /*[R,2]*/, const float* rays_d,
                      const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors, float* pts /*[N,3]*/,
                      float* dirs /*[N,3]*/, float* dt /*[N]*/, float* t /*[N]*/, int32_t* anchors /*[N,3]*/);

@@ -121,7 +121,8 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
     oi2 = torch.zeros(n * max_hits, dtype=torch.int32, device=DEV)
     nf2 = torch.zeros((n * max_hits, 2), device=DEV)
     tot = torch.zeros(1, dtype=torch.int32, device=DEV)
-    hip.oct_intersect_strided(n, max_hits, so, T(o), T(d), 0.01, 1e8, tn, se2, oi2, nf2, tot)
+    tr2 = torch.full((n * max_hits,), -9, dtype=torch.int32, device=DEV)
+    hip.oct_intersect_strided(n, max_hits, so, T(o), T(d), 0.01, 1e8, tn, se2, oi2, nf2, tot, tr2)
     se2n, oi2n, nf2n = N(se2), N(oi2), N(nf2)
     rse = ref_hits[0]
     assert int(tot.item()) == len(ref_hits[1])
@@ -130,6 +131,8 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
         c = rse[r, 1] - rse[r, 0]
         assert_same(oi2n[r * max_hits:r * max_hits + c], ref_hits[1][rse[r, 0]:rse[r, 1]], "strided idx")
         assert_same(nf2n[r * max_hits:r * max_hits + c], ref_hits[2][rse[r, 0]:rse[r, 1]], "strided near/far")
+        node_trans = st["tree_nodes"].view(np.int32).reshape(-1, 16)[:, 14]  # TreeNode.trans_idx @56
+        assert_same(N(tr2)[r * max_hits:r * max_hits + c], node_trans[oi2n[r * max_hits:r * max_hits + c]], "strided trans idx")
     pcnt = torch.zeros(n, dtype=torch.int32, device=DEV)
     hip.ray_march_count(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, pcnt)
     assert_same(N(pcnt), (ref["pts_idx_bounds"][:, 1] - ref["pts_idx_bounds"][:, 0]).astype(np.int32), "march count on strided hits")
@@ -138,7 +141,8 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
     cnt2 = torch.zeros(n, dtype=torch.int32, device=DEV)
     s_pts = torch.zeros((n * S, 3), device=DEV); s_dt = torch.zeros(n * S, device=DEV); s_t = torch.zeros(n * S, device=DEV)
     s_an = torch.zeros((n * S, 2), dtype=torch.int32, device=DEV); fod = torch.zeros(n, device=DEV)
-    hip.ray_march_strided(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, cnt2, s_pts, s_dt, s_t, s_an, fod)
+    hip.ray_march_strided(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, cnt2, s_pts, s_dt, s_t, s_an, fod,
+                          tr2 if seed != 2 else None)
     assert_same(N(cnt2), N(pcnt), "single-pass counts")
     pse2 = torch.zeros((n, 2), dtype=torch.int32, device=DEV)
     hip.segment_scan(n, cnt2, pse2, tot)

@@ -64,6 +64,8 @@ if args.breakdown:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t1) / 20
     t = host.ExpRunner.collect_kernel_timing(); host.ExpRunner.disable_kernel_timing()
     tot = sum(v[1] for v in t.values())
+    print("leaf hits per ray %.1f, marched samples per ray %.1f, meaningful per ray %.1f, octree nodes %d" %
+          (runner.oct_per_ray, runner.sampled_per_ray, runner.meaningful_per_ray, runner.n_nodes()))
     print("final state: %d rays/step, %.0f marched, %.0f meaningful samples/step, %.3f ms/step (with event timing)" % (b, na / 20, nm / 20, dt * 1e3))
     for k, v in sorted(t.items(), key=lambda kv: -kv[1][1]):
         print("  %-22s launches %4.1f  %8.3f ms/step  %5.1f%%" % (k, v[0] / 20, v[1] / 20, 100 * v[1] / tot))
