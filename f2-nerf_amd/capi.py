@@ -67,18 +67,18 @@ def normalize_dirs(n, dirs, out):
     _ck(lib().f2n_normalize_dirs(_stream(), _i(n), _p(dirs, "f32"), _p(out, "f32")), "f2n_normalize_dirs")
 
 
-def oct_intersect_count(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, hit_counts):
+def oct_intersect_count(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, hit_counts, child_blocks=None):
     _ck(lib().f2n_oct_intersect_count(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
-                                      _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(hit_counts, "i32")),
-        "f2n_oct_intersect_count")
+                                      _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(hit_counts, "i32"),
+                                      _p(child_blocks, "u8", True)), "f2n_oct_intersect_count")
 
 
 def oct_intersect_strided(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total,
-                          oct_trans=None):
+                          oct_trans=None, child_blocks=None):
     _ck(lib().f2n_oct_intersect_strided(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
                                         _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
-                                        _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True)),
-        "f2n_oct_intersect_strided")
+                                        _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True),
+                                        _p(child_blocks, "u8", True)), "f2n_oct_intersect_strided")
 
 
 def segment_scan(n, counts, start_end, total):
@@ -86,10 +86,10 @@ def segment_scan(n, counts, start_end, total):
         "f2n_segment_scan")
 
 
-def oct_intersect_fill(n_rays, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf):
+def oct_intersect_fill(n_rays, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, child_blocks=None):
     _ck(lib().f2n_oct_intersect_fill(_stream(), _i(n_rays), _p(search_order, "u8"), _p(rays_o, "f32"), _p(rays_d, "f32"),
                                      _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"), _p(oct_idx, "i32"),
-                                     _p(oct_nf, "f32")), "f2n_oct_intersect_fill")
+                                     _p(oct_nf, "f32"), _p(child_blocks, "u8", True)), "f2n_oct_intersect_fill")
 
 
 def ray_march_count(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes, transes,
@@ -134,9 +134,15 @@ def oct_mark_visit(n_rays, pts_se, anchors, anchor_stride, weights, alphas, w_ad
                                  _p(mark, "i32"), _p(visit_cnt, "i32")), "f2n_oct_mark_visit")
 
 
-def oct_update_stats(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes):
+def oct_update_stats(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes, child_blocks=None):
     _ck(lib().f2n_oct_update_stats(_stream(), _i(n_nodes), _p(w_adder, "i32"), _p(a_adder, "i32"), _p(mark, "i32"),
-                                   _p(w_stats, "i32"), _p(a_stats, "i32"), _p(tree_nodes, "u8")), "f2n_oct_update_stats")
+                                   _p(w_stats, "i32"), _p(a_stats, "i32"), _p(tree_nodes, "u8"),
+                                   _p(child_blocks, "u8", True)), "f2n_oct_update_stats")
+
+
+def oct_build_child_blocks(n_nodes, tree_nodes, child_blocks):
+    _ck(lib().f2n_oct_build_child_blocks(_stream(), _i(n_nodes), _p(tree_nodes, "u8"), _p(child_blocks, "u8")),
+        "f2n_oct_build_child_blocks")
 
 
 def oct_mark_invisible(n_nodes, n_cams, tree_nodes, intris, w2cs, bounds):

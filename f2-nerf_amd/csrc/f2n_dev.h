@@ -38,6 +38,17 @@ struct alignas(32) F2nEdgePool {
   float center[3], dir_0[3], dir_1[3];
   uint8_t pad[20];
 };
+// Derived acceleration structure for the octree DFS (not a reference type): entry [u][c] describes child slot c of node u,
+// so that expanding a node is ONE 256-byte read instead of "8 child indices, then 8 child nodes".
+struct alignas(32) F2nChildInfo {
+  float center[3];
+  float side_len;
+  int32_t child;      // node index, -1 = no child in this slot
+  int32_t trans_idx;  // the child's trans_idx
+  int32_t interior;   // the child has at least one child of its own
+  int32_t pad;
+};
+static_assert(sizeof(F2nChildInfo) == 32, "layout");
 static_assert(sizeof(F2nTreeNode) == 64 && sizeof(F2nTransInfo) == 544 && sizeof(F2nEdgePool) == 64, "layout");
 
 static inline int f2n_launch_status() {

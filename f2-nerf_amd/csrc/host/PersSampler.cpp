@@ -47,6 +47,13 @@ PersSampler::PersSampler(GlobalDataPool* global_data_pool) {
 void PersOctree::UploadNodes() {
   tree_nodes_gpu_ = torch::from_blob(tree_nodes_.data(), {int64_t(tree_nodes_.size() * sizeof(TreeNode))}, CpuU8())
                         .to(torch::kCUDA).contiguous();
+  RebuildChildBlocks();
+}
+
+void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of the tree (f2n_oct_build_child_blocks)
+  const int n = (int) tree_nodes_.size();
+  child_blocks_gpu_ = torch::empty({int64_t(n) * 8 * 32}, torch::TensorOptions().dtype(torch::kUInt8).device(torch::kCUDA));
+  F2N_CALL(f2n_oct_build_child_blocks(CurStream(), n, VoidP(tree_nodes_gpu_), VoidP(child_blocks_gpu_)));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -76,7 +83,8 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   Tensor oct_tr = torch::empty({k_cap}, DevI32());  // trans_idx of every listed leaf (the march would re-read the node)
   F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided(st, n_rays, max_oct_intersect_per_ray_,
                                   oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
-                                  VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr)));
+                                  VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
+                                  VoidP(oct.child_blocks_gpu_)));
 
   Tensor rays_noise;  // :372-381
   if (forced_noise_.defined()) {
@@ -154,7 +162,8 @@ void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Te
                               I32P(visit_mark), I32P(oct.tree_visit_cnt_)));
   if (occupancy_sync_hook_) occupancy_sync_hook_(adders, visit_mark, oct.tree_visit_cnt_);
   F2N_TIMED_CALL("oct_update_stats",f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
-                                I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_)));
+                                I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
+                                VoidP(oct.child_blocks_gpu_)));
 
   while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610
     oct.ProcOctree(true, true, sub_div_milestones_.back() <= 0);
@@ -171,6 +180,7 @@ void PersOctree::MarkInvisibleNodes() {  // PersSampler.cu:663-680
   TORCH_CHECK(w2c_.defined(), "training cameras not set: call SetTrainCameras");
   F2N_CALL(f2n_oct_mark_invisible(CurStream(), (int) tree_nodes_.size(), (int) intri_.size(0), VoidP(tree_nodes_gpu_),
                                   F32P(intri_), F32P(w2c_), F32P(bound_)));
+  RebuildChildBlocks();  // trans_idx of invisible leaves changed on the device
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -334,6 +344,7 @@ int PersSampler::LoadStates(const std::vector<Tensor>& states, int idx) {
   oct.tree_weight_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());  // stats are NOT checkpointed (:721-722)
   oct.tree_alpha_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());
   global_data_pool_->n_volumes_ = int(oct.pers_trans_gpu_.numel() / sizeof(TransInfo));
+  oct.RebuildChildBlocks();
   return idx;
 }
 

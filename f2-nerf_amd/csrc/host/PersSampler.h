@@ -36,10 +36,12 @@ class PersOctree {
   void ProcOctree(bool compact, bool subdivide, bool brute_force);
   void MarkInvisibleNodes();
   void UploadNodes();
+  void RebuildChildBlocks();
 
   Tensor w2c_, intri_, bound_;  // training cameras, for MarkInvisibleNodes
   std::vector<TreeNode> tree_nodes_;
   Tensor tree_nodes_gpu_;
+  Tensor child_blocks_gpu_;  // [n_nodes][8] x 32 B, derived from tree_nodes_gpu_ (f2n_oct_build_child_blocks)
   Tensor tree_weight_stats_, tree_alpha_stats_, tree_visit_cnt_;
   Tensor node_search_order_;
   Tensor pers_trans_gpu_;

@@ -4,7 +4,6 @@
 // and no host read-back, wave64 blocks, LDS-resident DFS stacks.
 #include "f2n_dev.h"
 
-#define F2N_STACK_DEPTH 24  // MAX_STACK_SIZE 48 ints = 24 (node, cursor) pairs, PersSampler.cu:7
 
 // ---------------------------------------------------------------------------------------------------
 // Slab test, PersSampler.cu:21-51.
@@ -43,15 +42,22 @@ __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const f
 // MODE 2: single pass into fixed-stride per-ray segments [ray*max_hits, ray*max_hits + cnt): no count pass, no scan.
 // ---------------------------------------------------------------------------------------------------
 #define F2N_COOP_RAYS_PER_BLOCK 32  // 256 threads
+#define F2N_COOP_STACK 56            // parked siblings per ray (7 per level of a path; deeper paths drop the farthest)
 template <int MODE>
 __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     int n_rays, int max_hits, const uint8_t* __restrict__ search_order, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, float g_near, float g_far, const F2nTreeNode* __restrict__ nodes,
     const int32_t* __restrict__ oct_start_end, int32_t* __restrict__ hit_counts, int32_t* __restrict__ oct_idx,
     float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total,
-    int32_t* __restrict__ oct_trans) {
-  __shared__ int s_node[F2N_STACK_DEPTH][F2N_COOP_RAYS_PER_BLOCK];
-  __shared__ int s_rem[F2N_STACK_DEPTH][F2N_COOP_RAYS_PER_BLOCK];
+    int32_t* __restrict__ oct_trans, const F2nChildInfo* __restrict__ child_blocks) {
+  // Work stack of a ray: every hit sibling behind the first interior hit of an expanded node is parked here, nearest on
+  // top -- interior nodes as (index >= 0), valid leaves as (~index, near, far, trans) to be emitted when popped.  A node
+  // is therefore expanded exactly once (parking only a "remaining siblings" mask meant re-reading and re-testing all
+  // eight children of a node once per interior child: ~3x the memory round trips in a deep, converged tree).
+  __shared__ int s_node[F2N_COOP_STACK][F2N_COOP_RAYS_PER_BLOCK];
+  __shared__ int s_tr[F2N_COOP_STACK][F2N_COOP_RAYS_PER_BLOCK];
+  __shared__ float s_near[F2N_COOP_STACK][F2N_COOP_RAYS_PER_BLOCK];
+  __shared__ float s_far[F2N_COOP_STACK][F2N_COOP_RAYS_PER_BLOCK];
   const int tid = threadIdx.x, k = tid & 7, grp = tid >> 3;
   const int shift = ((tid & 63) >> 3) * 8;  // position of this group's 8 bits inside a wave ballot
   const int ray_raw = blockIdx.x * F2N_COOP_RAYS_PER_BLOCK + grp;
@@ -70,7 +76,6 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
 
   int cnt = 0, sp = -1;
   int cur = -1;        // node to expand next (-1: pop from the stack)
-  int rem = 0xff;      // order positions of `cur` still to be processed
   bool active = limit > 0;
   if (active) {        // the root is tested on its own box first (:93-95); a childless root is itself the only leaf
     float near_ = g_near, far_ = g_far;
@@ -96,13 +101,24 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     }
   }
   while (__any(active)) {
-    // ---- pick the node to expand ----
+    // ---- pick the node to expand; parked leaves are emitted on the way ----
     if (active && cur < 0) {
       if (sp < 0) {
         active = false;
       } else {
-        cur = s_node[sp][grp];
-        rem = s_rem[sp][grp];
+        const int e = s_node[sp][grp];
+        if (e >= 0) {
+          cur = e;
+        } else {  // a parked leaf: it is the nearest thing left
+          if (MODE != 0 && k == 0) {
+            oct_idx[base + cnt] = ~e;
+            oct_near_far[2 * (base + cnt)] = s_near[sp][grp];
+            oct_near_far[2 * (base + cnt) + 1] = s_far[sp][grp];
+            if (oct_trans != nullptr) oct_trans[base + cnt] = s_tr[sp][grp];
+          }
+          cnt++;
+          if (cnt >= limit) active = false;
+        }
         sp--;
       }
     }
@@ -110,23 +126,41 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     bool hit = false, interior = false, valid_leaf = false;
     int child = -1, child_trans = -1;
     float near_ = g_near, far_ = g_far;
-    if (active && ((rem >> k) & 1)) {
-      child = nodes[cur].childs[my_slot];
-      if (child >= 0) {
-        const F2nTreeNode* nd = nodes + child;
-        f2n_slab(o, d, nd->center, nd->side_len, near_, far_);
-        hit = near_ < far_;
-        if (hit) {
+    const bool expanding = active && cur >= 0;
+    if (expanding) {
+      if (child_blocks != nullptr) {  // one 32-byte record per child slot: no dependent second read
+        const float4_t* rec = (const float4_t*) (child_blocks + (size_t) cur * 8 + my_slot);
+        const float4_t cs = rec[0];
+        const float4_t meta = rec[1];
+        child = __float_as_int(meta[0]);
+        if (child >= 0) {
+          const float cc[3] = {cs[0], cs[1], cs[2]};
+          f2n_slab(o, d, cc, cs[3], near_, far_);
+          hit = near_ < far_;
+          if (hit) {
+            child_trans = __float_as_int(meta[1]);
+            interior = __float_as_int(meta[2]) != 0;
+            valid_leaf = !interior && child_trans >= 0;
+          }
+        }
+      } else {
+        child = nodes[cur].childs[my_slot];
+        if (child >= 0) {
+          const F2nTreeNode* nd = nodes + child;
+          f2n_slab(o, d, nd->center, nd->side_len, near_, far_);
+          hit = near_ < far_;
+          if (hit) {
 #pragma unroll
-          for (int c = 0; c < 8; c++) interior |= nd->childs[c] >= 0;
-          child_trans = nd->trans_idx;
-          valid_leaf = !interior && child_trans >= 0;
+            for (int c = 0; c < 8; c++) interior |= nd->childs[c] >= 0;
+            child_trans = nd->trans_idx;
+            valid_leaf = !interior && child_trans >= 0;
+          }
         }
       }
     }
     const unsigned long long b_int = __ballot(hit && interior);
     const unsigned long long b_leaf = __ballot(hit && valid_leaf);
-    if (active) {
+    if (expanding) {
       const int m_int = (int) ((b_int >> shift) & 0xffull);
       const int m_leaf = (int) ((b_leaf >> shift) & 0xffull);
       const int k_int = m_int ? __ffs(m_int) - 1 : 8;          // first interior hit (order position)
@@ -144,16 +178,22 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
       if (cnt >= limit) {
         active = false;
       } else if (k_int < 8) {
-        const int rest = rem & ~((2 << k_int) - 1);             // positions behind the interior child
-        if (rest && sp + 1 < F2N_STACK_DEPTH) {
-          sp++;
-          if (k == 0) {
-            s_node[sp][grp] = cur;
-            s_rem[sp][grp] = rest;
-          }
+        // park every hit behind the first interior child, farthest first so that the nearest ends on top
+        int rest = (m_int | m_leaf) & ~((2 << k_int) - 1);
+        int n_rest = __popc(rest);
+        while (sp + n_rest >= F2N_COOP_STACK) {  // full (paths deeper than the reference's own 48-int stack): drop the farthest
+          rest &= ~(1 << (31 - __clz(rest)));
+          n_rest--;
         }
+        if ((rest >> k) & 1) {
+          const int pos = sp + 1 + __popc(rest >> (k + 1));
+          s_node[pos][grp] = interior ? child : ~child;
+          s_near[pos][grp] = near_;
+          s_far[pos][grp] = far_;
+          s_tr[pos][grp] = child_trans;
+        }
+        sp += n_rest;
         cur = __shfl(child, (tid & 56) + k_int);                // the interior child's node index (lane k_int)
-        rem = 0xff;
       } else {
         cur = -1;
       }
@@ -224,29 +264,40 @@ __global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, c
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Perspective-warped ray marching (PersSampler.cu:189-314), four lanes per ray.
+// Perspective-warped ray marching (PersSampler.cu:189-314), sixteen lanes per ray.
 //
-// A march step is a strictly sequential chain (the step length comes from the warp Jacobian at the current point),
-// so a one-ray-per-lane kernel runs 8192 rays as 128 lonely waves, each issuing ~1200 dependent-ish instructions
-// (36 IEEE divisions) per step.  The Jacobian is a 12-term sum over the leaf's 12 camera projections, and the
-// reference's (Eigen) summation tree is  ((e0+(e1+e2)) + (e3+(e4+e5))) + ((e6+(e7+e8)) + (e9+(e10+e11))):
-// lane j of a quad owns projections 3j..3j+2, forms p_j = e[3j] + (e[3j+1] + e[3j+2]) and the quad finishes with two
-// DPP quad_perm exchanges, (p0+p1) + (p2+p3) -- the same tree, bit for bit, with a quarter of the instructions per
-// lane, a quarter of the TransInfo registers (33 floats, reloaded only when the leaf's transform changes) and four
-// times as many waves in flight.
-// ---------------------------------------------------------------------------------------------------
-#define F2N_MARCH_RAYS_PER_BLOCK 16  // one wave per block: 512 blocks for 8192 rays
-
-__device__ __forceinline__ float f2n_quad_sum(float p) {
-  // (p0 + p1) + (p2 + p3) in every lane of the quad; fp add commutes, so all four lanes hold identical bits
-  const float t = p + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p), 0xB1, 0xF, 0xF, true));  // [1,0,3,2]
-  return t + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));           // [2,3,0,1]
-}
-
+// A march step is a strictly sequential chain (the step length comes from the warp Jacobian at the current point):
+// a one-ray-per-lane kernel runs 8192 rays as 128 lonely waves, each issuing ~1200 dependent-ish instructions (36
+// IEEE divisions) per step.  The Jacobian is a 12-term sum over the leaf's 12 camera projections in Eigen's tree
+// ((e0+(e1+e2)) + (e3+(e4+e5))) + ((e6+(e7+e8)) + (e9+(e10+e11))), which maps onto DPP exchanges bit for bit.
+// History: 1 lane/ray 0.73 ms, 4 lanes/ray (3 projections each) 0.32 ms, one pass instead of count+fill 0.18 ms,
+// 16 lanes/ray 0.17 ms (fresh scene, 8192 rays x 97 samples); converged scene (13 k rays, 5..250 samples): 0.47 -> 0.37 ms.
+//
 // MODE 0: count only.  MODE 1: fill ray-ordered compact arrays (segments from f2n_segment_scan).  MODE 2: ONE pass into
 // fixed-stride per-ray slots [ray * 1024 + k] (pts, dt, t, anchors as (trans, node) pairs; dirs are not written) plus the
 // per-ray counts -- f2n_pack_samples then copies the filled prefix of every slot into the compact arrays, which costs a
 // few tens of MB of streaming instead of a second march.
+// ---------------------------------------------------------------------------------------------------
+// Sum of one value per projection over the 12 projections of a 16-lane row, in Eigen's order (see ray_march16_kernel).
+__device__ __forceinline__ float f2n_row12_sum(float e) {
+  // lane 1 of each quad: e1 + e2
+  const float t = e + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xE8, 0xF, 0xF, true));   // quad_perm [0,2,2,3]
+  // every lane of the quad: e0 + (e1 + e2)
+  const float t1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x55, 0xF, 0xF, true));      // quad_perm [1,1,1,1]
+  const float p = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x00, 0xF, 0xF, true)) + t1;  // quad_perm [0,0,0,0]
+  // groups (0,1) and (2,3): quads (0,3) and (1,2) are row_mirror images of each other
+  const float u = p + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p), 0x140, 0xF, 0xF, true));
+  // the two halves of the row
+  return u + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(u), 0x141, 0xF, 0xF, true));
+}
+
+// Sixteen lanes per ray: one projection per lane (12 of the 16 lanes of a DPP row; lane 3 of every quad idles).  The
+// kernel's duration is the LONGEST ray's step count times the latency of one step (a converged scene has rays of
+// 250+ samples next to rays of 5), and that latency is a dependent chain of VALU instructions -- so the per-lane
+// instruction count is what matters, not the lane count.  Quad q of a row holds Eigen group G(q) = {0, 2, 3, 1}[q] of
+// the 12-term tree ((e0+(e1+e2)) + (e3+(e4+e5))) + ((e6+(e7+e8)) + (e9+(e10+e11))): the triple sum is two quad_perm
+// steps, row_mirror pairs quads (0,3) = groups (0,1) and (1,2) = groups (2,3), row_half_mirror pairs the two halves --
+// every lane ends with the full sum, added in exactly the reference's order (fp add commutes, association is kept).
 template <int MODE>
 __global__ __launch_bounds__(64) void ray_march_kernel(
     int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -255,9 +306,12 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
     const int32_t* __restrict__ pts_start_end, int32_t* __restrict__ pts_counts, float* __restrict__ pts,
     float* __restrict__ dirs, float* __restrict__ dts, float* __restrict__ ts, int32_t* __restrict__ anchors,
     float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all) {
-  const int j = threadIdx.x & 3;
-  const int ray = blockIdx.x * F2N_MARCH_RAYS_PER_BLOCK + (threadIdx.x >> 2);
-  if (ray >= n_rays) return;  // whole quads leave together
+  const int lane16 = threadIdx.x & 15, kq = lane16 & 3, quad = lane16 >> 2;
+  const int grp = quad == 0 ? 0 : quad == 1 ? 2 : quad == 2 ? 3 : 1;  // Eigen group of this quad (see above)
+  const int proj = 3 * grp + min(kq, 2);                               // lane 3 of a quad shadows projection 3g+2 (unused)
+  const int j = lane16;                                                // emission role
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 4);
+  if (ray >= n_rays) return;  // whole rows leave together
   const int oct_s = oct_start_end[2 * ray], n_oct = oct_start_end[2 * ray + 1] - oct_s;
   constexpr bool FILL = MODE != 0;
   int max_n = F2N_MAX_SAMPLE_PER_RAY;
@@ -299,45 +353,36 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
     int tidx = w_tr[0] != -2 ? w_tr[0] : nodes[cur_oct].trans_idx, cached_tidx = -1;
     float cur_t = w_near[0], cur_far = w_far[0];
     float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
-    float m[3][8], wg[3][3], radius_clip = 1.f;  // this lane's share of the current TransInfo
+    float m[8], wg[3], radius_clip = 1.f;  // this lane's projection of the current TransInfo
     while (n < max_n && oct_ptr < n_oct) {
       if (tidx != cached_tidx) {
         const float* T = (const float*) (transes + tidx);
-        const float4_t* src = (const float4_t*) (T + 24 * j);  // w2xz[3j .. 3j+2]
+        const float4_t a4 = *(const float4_t*) (T + 8 * proj), b4 = *(const float4_t*) (T + 8 * proj + 4);  // w2xz[proj]
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-          const float4_t v4 = src[q];
-          m[q >> 1][4 * (q & 1)] = v4[0];
-          m[q >> 1][4 * (q & 1) + 1] = v4[1];
-          m[q >> 1][4 * (q & 1) + 2] = v4[2];
-          m[q >> 1][4 * (q & 1) + 3] = v4[3];
+        for (int q = 0; q < 4; q++) {
+          m[q] = a4[q];
+          m[4 + q] = b4[q];
         }
 #pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int ii = 0; ii < 3; ii++) wg[r][ii] = T[96 + 12 * r + 3 * j + ii];
+        for (int r = 0; r < 3; r++) wg[r] = T[96 + 12 * r + proj];
         const float4_t cd = *(const float4_t*) (T + 132);  // center, dis_summary
         const float radius = f2n_norm3(o[0] - cd[0], o[1] - cd[1], o[2] - cd[2]) / cd[3];
         radius_clip = fmaxf(radius, 1.f);
         cached_tidx = tidx;
       }
-      // this lane's three projections and their contribution to the Jacobian (:171-187)
-      float px[3], pz[3], tj[3][3];
+      // this lane's projection and its contribution to the Jacobian (:171-187)
+      const float px = f2n_sum4(m[0] * xyz[0], m[1] * xyz[1], m[2] * xyz[2], m[3] * 1.f);
+      const float pz = f2n_sum4(m[4] * xyz[0], m[5] * xyz[1], m[6] * xyz[2], m[7] * 1.f);
+      const float d0 = 1 / pz;
+      const float d1 = -px / (pz * pz);
+      float tj[3];
 #pragma unroll
-      for (int ii = 0; ii < 3; ii++) {
-        px[ii] = f2n_sum4(m[ii][0] * xyz[0], m[ii][1] * xyz[1], m[ii][2] * xyz[2], m[ii][3] * 1.f);
-        pz[ii] = f2n_sum4(m[ii][4] * xyz[0], m[ii][5] * xyz[1], m[ii][6] * xyz[2], m[ii][7] * 1.f);
-        const float d0 = 1 / pz[ii];
-        const float d1 = -px[ii] / (pz[ii] * pz[ii]);
-#pragma unroll
-        for (int c = 0; c < 3; c++) tj[ii][c] = d0 * m[ii][c] + d1 * m[ii][4 + c];
-      }
+      for (int c = 0; c < 3; c++) tj[c] = d0 * m[c] + d1 * m[4 + c];
       float jac[3][3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-          jac[r][c] = f2n_quad_sum(wg[r][0] * tj[0][c] + (wg[r][1] * tj[1][c] + wg[r][2] * tj[2][c]));
+        for (int c = 0; c < 3; c++) jac[r][c] = f2n_row12_sum(wg[r] * tj[c]);
       float pj[3];
 #pragma unroll
       for (int r = 0; r < 3; r++) pj[r] = f2n_sum3(jac[r][0] * d[0], jac[r][1] * d[1], jac[r][2] * d[2]);
@@ -349,12 +394,10 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
       if (!first) {  // the first point of a ray is never emitted (:274-289)
         if (FILL) {
           const size_t k = base + (size_t) n;
-          float w[3];  // the warped point (:155-169) shares the projections with the Jacobian
-          float v[3];
+          float w[3];  // the warped point (:155-169) shares the projection with the Jacobian
+          const float v = px / pz;
 #pragma unroll
-          for (int ii = 0; ii < 3; ii++) v[ii] = px[ii] / pz[ii];
-#pragma unroll
-          for (int r = 0; r < 3; r++) w[r] = f2n_quad_sum(wg[r][0] * v[0] + (wg[r][1] * v[1] + wg[r][2] * v[2]));
+          for (int r = 0; r < 3; r++) w[r] = f2n_row12_sum(wg[r] * v);
           if (j == 0) {
 #pragma unroll
             for (int c = 0; c < 3; c++) pts[3 * k + c] = w[c];
@@ -366,13 +409,15 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
           } else if (j == 2) {
             ts[k] = cur_t;
             dts[k] = step * pj_norm;
-          } else if (MODE == 1) {
-            anchors[3 * k] = tidx;
-            anchors[3 * k + 1] = cur_oct;
-            anchors[3 * k + 2] = 0;
-          } else {
-            anchors[2 * k] = tidx;
-            anchors[2 * k + 1] = cur_oct;
+          } else if (j == 3) {
+            if (MODE == 1) {
+              anchors[3 * k] = tidx;
+              anchors[3 * k + 1] = cur_oct;
+              anchors[3 * k + 2] = 0;
+            } else {
+              anchors[2 * k] = tidx;
+              anchors[2 * k + 1] = cur_oct;
+            }
           }
         }
         n++;
@@ -581,7 +626,8 @@ __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __rest
 // PersSampler.cu:579-593 (torch integer ops) + MarkInvalidNodes (:528-534), one node per lane.
 __global__ void update_stats_kernel(int n_nodes, const int32_t* __restrict__ w_adder, const int32_t* __restrict__ a_adder,
                                     const int32_t* __restrict__ mark, int32_t* __restrict__ w_stats,
-                                    int32_t* __restrict__ a_stats, F2nTreeNode* __restrict__ nodes) {
+                                    int32_t* __restrict__ a_stats, F2nTreeNode* __restrict__ nodes,
+                                    F2nChildInfo* __restrict__ child_blocks) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const int m = mark[i];
@@ -598,7 +644,42 @@ __global__ void update_stats_kernel(int n_nodes, const int32_t* __restrict__ w_a
   }
   w_stats[i] = st[0];
   a_stats[i] = st[1];
-  if (st[0] < 0 || st[1] < 0) nodes[i].trans_idx = -1;
+  if (st[0] < 0 || st[1] < 0) {
+    nodes[i].trans_idx = -1;
+    const int pa = nodes[i].parent;
+    if (child_blocks != nullptr && pa >= 0) {  // the parent's copy of this node's record
+#pragma unroll
+      for (int c = 0; c < 8; c++)
+        if (nodes[pa].childs[c] == i) child_blocks[(size_t) pa * 8 + c].trans_idx = -1;
+    }
+  }
+}
+
+// child_blocks[u][c] <- what the DFS needs to know about child slot c of node u
+__global__ void build_child_blocks_kernel(int n_nodes, const F2nTreeNode* __restrict__ nodes, F2nChildInfo* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_nodes * 8) return;
+  const int u = t >> 3, c = t & 7;
+  F2nChildInfo e;
+  e.center[0] = e.center[1] = e.center[2] = 0.f;
+  e.side_len = 0.f;
+  e.child = nodes[u].childs[c];
+  e.trans_idx = -1;
+  e.interior = 0;
+  e.pad = 0;
+  if (e.child >= 0) {
+    const F2nTreeNode* nd = nodes + e.child;
+    e.center[0] = nd->center[0];
+    e.center[1] = nd->center[1];
+    e.center[2] = nd->center[2];
+    e.side_len = nd->side_len;
+    e.trans_idx = nd->trans_idx;
+    int interior = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) interior |= nd->childs[k] >= 0;
+    e.interior = interior;
+  }
+  out[t] = e;
 }
 
 // MarkInvisibleNodesKernel + CheckVisible, PersSampler.cu:618-661.
@@ -640,23 +721,27 @@ int f2n_normalize_dirs(void* stream, int n, const float* dirs, float* out) {
 }
 
 int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
-                            const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* hit_counts) {
+                            const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* hit_counts,
+                            const void* child_blocks) {
   if (n_rays < 0 || max_hits < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(oct_intersect_coop_kernel<0>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr, nullptr, nullptr, nullptr);
+                     (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     (const F2nChildInfo*) child_blocks);
   return f2n_launch_status();
 }
 
 int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                               const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
-                              int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans) {
+                              int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans,
+                              const void* child_blocks) {
   if (n_rays < 0 || max_hits < 1) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(oct_intersect_coop_kernel<2>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total, oct_trans);
+                     (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total, oct_trans,
+                     (const F2nChildInfo*) child_blocks);
   return f2n_launch_status();
 }
 
@@ -669,12 +754,13 @@ int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_
 
 int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order, const float* rays_o,
                            const float* rays_d, float near_, float far_, const void* tree_nodes,
-                           const int32_t* oct_start_end, int32_t* oct_idx, float* oct_near_far) {
+                           const int32_t* oct_start_end, int32_t* oct_idx, float* oct_near_far, const void* child_blocks) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(oct_intersect_coop_kernel<1>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, 0, search_order, rays_o, rays_d, near_, far_,
-                     (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far, nullptr, nullptr, nullptr);
+                     (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far, nullptr, nullptr, nullptr,
+                     (const F2nChildInfo*) child_blocks);
   return f2n_launch_status();
 }
 
@@ -683,7 +769,7 @@ int f2n_ray_march_count(void* stream, int n_rays, float sample_l, int scale_by_d
                         const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(ray_march_kernel<0>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
+  hipLaunchKernelGGL(ray_march_kernel<0>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -697,7 +783,7 @@ int f2n_ray_march_fill(void* stream, int n_rays, float sample_l, int scale_by_di
                        float* first_oct_dis) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(ray_march_kernel<1>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
+  hipLaunchKernelGGL(ray_march_kernel<1>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, pts_start_end, nullptr,
                      pts, dirs, dt, t, anchors, first_oct_dis, nullptr);
@@ -710,7 +796,7 @@ int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by
                           int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, F2N_MARCH_RAYS_PER_BLOCK)), dim3(64), 0,
+  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
                      nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans);
@@ -754,11 +840,19 @@ int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts
 }
 
 int f2n_oct_update_stats(void* stream, int n_nodes, const int32_t* w_adder, const int32_t* a_adder, const int32_t* mark,
-                         int32_t* w_stats, int32_t* a_stats, void* tree_nodes) {
+                         int32_t* w_stats, int32_t* a_stats, void* tree_nodes, void* child_blocks) {
   if (n_nodes < 0) return F2N_ERR_INVALID_ARG;
   if (n_nodes == 0) return F2N_OK;
   hipLaunchKernelGGL(update_stats_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, n_nodes,
-                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes);
+                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks);
+  return f2n_launch_status();
+}
+
+int f2n_oct_build_child_blocks(void* stream, int n_nodes, const void* tree_nodes, void* child_blocks) {
+  if (n_nodes < 0) return F2N_ERR_INVALID_ARG;
+  if (n_nodes == 0) return F2N_OK;
+  hipLaunchKernelGGL(build_child_blocks_kernel, dim3(f2n_div_up((long) n_nodes * 8, 256)), dim3(256), 0, (hipStream_t) stream,
+                     n_nodes, (const F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks);
   return f2n_launch_status();
 }
 

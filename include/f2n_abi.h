@@ -54,7 +54,7 @@ int f2n_normalize_dirs(void* stream, int n, const float* dirs /*[n,3]*/, float* 
  * hit_counts[r] = number of valid leaves hit by ray r, capped at max_hits. */
 int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_t* search_order /*[64]*/,
                             const float* rays_o /*[R,3]*/, const float* rays_d /*[R,3]*/, float near_, float far_,
-                            const void* tree_nodes, int32_t* hit_counts /*[R]*/);
+                            const void* tree_nodes, int32_t* hit_counts /*[R]*/, const void* child_blocks /*or NULL*/);
 
 /* Ray-ordered segment allocation: start_end[i] = (sum_{j<i} counts[j], sum_{j<=i} counts[j]);
  * total[0] = sum.  Replaces the racing atomicAdd allocator (PersSampler.cu:144) and the
@@ -66,7 +66,7 @@ int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_
 int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order, const float* rays_o,
                            const float* rays_d, float near_, float far_, const void* tree_nodes,
                            const int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[K]*/,
-                           float* oct_near_far /*[K,2]*/);
+                           float* oct_near_far /*[K,2]*/, const void* child_blocks /*or NULL*/);
 
 /* Single-pass variant of count + scan + fill for callers that do not need a compact list: ray r owns the fixed
  * slot range [r*max_hits, r*max_hits + hits_r) of oct_idx / oct_near_far (both sized n_rays*max_hits);
@@ -76,7 +76,15 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
                               const float* rays_d, float near_, float far_, const void* tree_nodes,
                               int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[R*max_hits]*/,
                               float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/,
-                              int32_t* oct_trans /*[R*max_hits] or NULL: trans_idx of every listed leaf*/);
+                              int32_t* oct_trans /*[R*max_hits] or NULL: trans_idx of every listed leaf*/,
+                              const void* child_blocks /*or NULL*/);
+
+/* Optional acceleration structure for the three intersection entry points: child_blocks [n_nodes][8] x 32 B, entry
+ * [u][c] = {center xyz, side_len, child index (-1: none), child's trans_idx, child has children, pad} of child slot c of
+ * node u.  With it, expanding a node is one coalesced 256-byte read instead of the reference's dependent pair
+ * "childs[] of the node, then the child nodes" (PersSampler.cu:93-120); results are identical.  Rebuild after every
+ * host-side change of the tree; f2n_oct_update_stats keeps the trans_idx copies current when given the pointer. */
+int f2n_oct_build_child_blocks(void* stream, int n_nodes, const void* tree_nodes, void* child_blocks);
 
 /* RayMarchKernel<false> (PersSampler.cu:189-314, launched :383-393).  noise has
  * F2N_MAX_SAMPLE_PER_RAY + n_rays + 10 floats, already multiplied by ray_march_fineness (:372-381), and is
@@ -126,7 +134,8 @@ int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts
  * (:528-534, :595-603): stats = clamp(max(stats, pos vote) + visited negative vote, -100, 2^20);
  * trans_idx = -1 where either stat < 0. */
 int f2n_oct_update_stats(void* stream, int n_nodes, const int32_t* w_adder, const int32_t* a_adder,
-                         const int32_t* mark, int32_t* w_stats, int32_t* a_stats, void* tree_nodes);
+                         const int32_t* mark, int32_t* w_stats, int32_t* a_stats, void* tree_nodes,
+                         void* child_blocks /*or NULL*/);
 
 /* MarkInvisibleNodesKernel (PersSampler.cu:618-680). */
 int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris /*[C,3,3]*/,

@@ -122,7 +122,10 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
     nf2 = torch.zeros((n * max_hits, 2), device=DEV)
     tot = torch.zeros(1, dtype=torch.int32, device=DEV)
     tr2 = torch.full((n * max_hits,), -9, dtype=torch.int32, device=DEV)
-    hip.oct_intersect_strided(n, max_hits, so, T(o), T(d), 0.01, 1e8, tn, se2, oi2, nf2, tot, tr2)
+    n_nodes = st["tree_nodes"].size // 64
+    cb = torch.zeros(n_nodes * 8 * 32, dtype=torch.uint8, device=DEV)  # the one-read-per-node view of the tree
+    hip.oct_build_child_blocks(n_nodes, tn, cb)
+    hip.oct_intersect_strided(n, max_hits, so, T(o), T(d), 0.01, 1e8, tn, se2, oi2, nf2, tot, tr2, cb if seed != 3 else None)
     se2n, oi2n, nf2n = N(se2), N(oi2), N(nf2)
     rse = ref_hits[0]
     assert int(tot.item()) == len(ref_hits[1])
