@@ -322,6 +322,23 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
   }
   if (MODE == 2) base = (size_t) ray * F2N_MAX_SAMPLE_PER_RAY;
   if (FILL && j == 0) first_oct_dis[ray] = n_oct > 0 ? near_far_all[2 * oct_s] : 1e9f;  // :226-231
+  // Output roles of the 16 lanes of a row: lanes 0-2 pts.xyz, 3 t, 4 dt, 5-6 anchors (trans, node); in MODE 1 also lane 7
+  // anchors[2] = 0 and lanes 8-10 dirs.xyz.  Every writer lane keeps ONE running pointer (4-byte units).
+  uint32_t* out_ptr = nullptr;
+  int out_stride = 0;
+  uint32_t out_const = 0u;
+  if (FILL) {
+    if (j < 3) { out_ptr = (uint32_t*) pts + 3 * base + j; out_stride = 3; }
+    else if (j == 3) { out_ptr = (uint32_t*) ts + base; out_stride = 1; }
+    else if (j == 4) { out_ptr = (uint32_t*) dts + base; out_stride = 1; }
+    else if (MODE == 2 && j < 7) { out_ptr = (uint32_t*) anchors + 2 * base + (j - 5); out_stride = 2; }
+    else if (MODE == 1 && j < 8) { out_ptr = (uint32_t*) anchors + 3 * base + (j - 5); out_stride = 3; }
+    else if (MODE == 1 && j < 11) {
+      out_ptr = (uint32_t*) dirs + 3 * base + (j - 8);
+      out_stride = 3;
+      out_const = __float_as_uint(rays_d[3 * ray + (j - 8)]);
+    }
+  }
   int n = 0;
   if (n_oct > 0 && max_n > 0) {
     const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
@@ -354,7 +371,24 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
     float cur_t = w_near[0], cur_far = w_far[0];
     float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
     float m[8], wg[3], radius_clip = 1.f;  // this lane's projection of the current TransInfo
+    // noise[n] sits on the step's critical path (it scales the step length): four values at a time, the next four
+    // already in flight.  The buffer has 1024 + n_rays + 10 floats, so ray + n + 7 stays inside it.
+    float nz[4], nz_next[4];
+    int nz_base = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      nz[q] = noise[q];
+      nz_next[q] = noise[4 + q];
+    }
     while (n < max_n && oct_ptr < n_oct) {
+      if (n - nz_base >= 4) {
+        nz_base += 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          nz[q] = nz_next[q];
+          nz_next[q] = noise[nz_base + 4 + q];
+        }
+      }
       if (tidx != cached_tidx) {
         const float* T = (const float*) (transes + tidx);
         const float4_t a4 = *(const float4_t*) (T + 8 * proj), b4 = *(const float4_t*) (T + 8 * proj + 4);  // w2xz[proj]
@@ -387,37 +421,24 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
 #pragma unroll
       for (int r = 0; r < 3; r++) pj[r] = f2n_sum3(jac[r][0] * d[0], jac[r][1] * d[1], jac[r][2] * d[2]);
       const float pj_norm = f2n_norm3(pj[0], pj[1], pj[2]) + 1e-6f;
-      const float step_warp = sample_l * noise[n];
+      const int nq = n - nz_base;
+      const float step_warp = sample_l * (nq == 0 ? nz[0] : nq == 1 ? nz[1] : nq == 2 ? nz[2] : nz[3]);
       float step = step_warp / pj_norm;
       if (scale_by_dis) step *= radius_clip;
       float march = step;
       if (!first) {  // the first point of a ray is never emitted (:274-289)
         if (FILL) {
-          const size_t k = base + (size_t) n;
           float w[3];  // the warped point (:155-169) shares the projection with the Jacobian
           const float v = px / pz;
 #pragma unroll
           for (int r = 0; r < 3; r++) w[r] = f2n_row12_sum(wg[r] * v);
-          if (j == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) pts[3 * k + c] = w[c];
-          } else if (j == 1) {
-            if (MODE == 1) {
-#pragma unroll
-              for (int c = 0; c < 3; c++) dirs[3 * k + c] = d[c];
-            }
-          } else if (j == 2) {
-            ts[k] = cur_t;
-            dts[k] = step * pj_norm;
-          } else if (j == 3) {
-            if (MODE == 1) {
-              anchors[3 * k] = tidx;
-              anchors[3 * k + 1] = cur_oct;
-              anchors[3 * k + 2] = 0;
-            } else {
-              anchors[2 * k] = tidx;
-              anchors[2 * k + 1] = cur_oct;
-            }
+          // one 4-byte store per writer lane (roles fixed before the loop) instead of per-array branches
+          const uint32_t val = j == 0 ? __float_as_uint(w[0]) : j == 1 ? __float_as_uint(w[1]) : j == 2 ? __float_as_uint(w[2])
+                             : j == 3 ? __float_as_uint(cur_t) : j == 4 ? __float_as_uint(step * pj_norm)
+                             : j == 5 ? (uint32_t) tidx : j == 6 ? (uint32_t) cur_oct : out_const;
+          if (out_ptr != nullptr) {
+            *out_ptr = val;
+            out_ptr += out_stride;
           }
         }
         n++;

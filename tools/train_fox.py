@@ -66,6 +66,10 @@ if args.breakdown:
     tot = sum(v[1] for v in t.values())
     print("leaf hits per ray %.1f, marched samples per ray %.1f, meaningful per ray %.1f, octree nodes %d" %
           (runner.oct_per_ray, runner.sampled_per_ray, runner.meaningful_per_ray, runner.n_nodes()))
+    smp = runner.get_samples(ro, rd, bounds)
+    per_ray = (smp["pts_idx_bounds"][:, 1] - smp["pts_idx_bounds"][:, 0]).cpu().numpy()
+    print("marched samples per ray: mean %.1f  p50 %d  p90 %d  p99 %d  p99.9 %d  max %d  (rays with 0: %.1f%%)" %
+          (per_ray.mean(), *np.percentile(per_ray, [50, 90, 99, 99.9]).astype(int), per_ray.max(), 100 * (per_ray == 0).mean()))
     print("final state: %d rays/step, %.0f marched, %.0f meaningful samples/step, %.3f ms/step (with event timing)" % (b, na / 20, nm / 20, dt * 1e3))
     for k, v in sorted(t.items(), key=lambda kv: -kv[1][1]):
         print("  %-22s launches %4.1f  %8.3f ms/step  %5.1f%%" % (k, v[0] / 20, v[1] / 20, 100 * v[1] / tot))
