@@ -42,6 +42,25 @@ void ExpRunner::BuildOptimizer() {
   optim_steps_ = 0;
 }
 
+// Re-homes the three small fp32 gradient buffers (field MLP, colour MLP, app_emb) in ONE flat tensor, so that a
+// data-parallel run reduces them with a single collective instead of three latency-bound ones.  Returns the flat tensor.
+Tensor ExpRunner::FlattenSmallGrads() {
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  const int64_t n1 = field->mlp_->grad_scaled_.numel(), n2 = shader->mlp_->grad_scaled_.numel(),
+                n3 = renderer_->app_emb_grad_.numel();
+  Tensor flat = torch::zeros({n1 + n2 + n3}, DevF32());
+  field->mlp_->grad_scaled_ = flat.narrow(0, 0, n1);
+  shader->mlp_->grad_scaled_ = flat.narrow(0, n1, n2);
+  renderer_->app_emb_grad_ = flat.narrow(0, n1 + n2, n3).view(renderer_->app_emb_grad_.sizes());
+  for (auto& g : groups_) {  // the optimiser groups hold handles to the old buffers
+    if (g.name == "field_mlp") g.grad = field->mlp_->grad_scaled_;
+    if (g.name == "color_mlp") g.grad = shader->mlp_->grad_scaled_;
+    if (g.name == "app_emb") g.grad = renderer_->app_emb_grad_;
+  }
+  return flat;
+}
+
 void ExpRunner::LoadStates(const std::vector<Tensor>& states) {
   int used = renderer_->LoadStates(states, 0);
   TORCH_CHECK(used == (int) states.size(), "state vector has ", states.size(), " tensors, consumed ", used);

@@ -29,6 +29,7 @@ class ExpRunner {
   void UpdateAdaParams();
   void OptimStep(const int32_t* skip_flag = nullptr);  // skip_flag: device int, != 0 drops the update
   void BuildOptimizer();
+  Tensor FlattenSmallGrads();
   int CurBatchSize() const;
 
   int iter_step_ = 0, end_iter_;

@@ -154,13 +154,19 @@ void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Te
   const int n_rays = sample_result.pts_idx_bounds.size(0);
   CheckDev(sampled_weight, torch::kFloat32, "sampled_weight");
   CheckDev(sampled_alpha, torch::kFloat32, "sampled_alpha");
-  Tensor adders = torch::full({2, n_nodes}, -1, DevI32());  // visit_weight_adder, visit_alpha_adder (:555-556)
-  Tensor visit_mark = torch::zeros({n_nodes}, DevI32());
+  // one [4, n_nodes] buffer: weight votes, alpha votes (init -1, :555-556), visited marks (0), running visit counts -- a
+  // data-parallel run max-combines it across ranks with ONE collective
+  Tensor occ = torch::empty({4, n_nodes}, DevI32());
+  occ.slice(0, 0, 2).fill_(-1);
+  occ.select(0, 2).zero_();
+  occ.select(0, 3).copy_(oct.tree_visit_cnt_);
   void* st = CurStream();
   F2N_TIMED_CALL("oct_mark_visit", f2n_oct_mark_visit(st, n_rays, n_nodes, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
-                              F32P(sampled_weight), F32P(sampled_alpha), I32P(adders), I32P(adders) + n_nodes,
-                              I32P(visit_mark), I32P(oct.tree_visit_cnt_)));
-  if (occupancy_sync_hook_) occupancy_sync_hook_(adders, visit_mark, oct.tree_visit_cnt_);
+                              F32P(sampled_weight), F32P(sampled_alpha), I32P(occ), I32P(occ) + n_nodes,
+                              I32P(occ) + 2 * (int64_t) n_nodes, I32P(occ) + 3 * (int64_t) n_nodes));
+  if (occupancy_sync_hook_) occupancy_sync_hook_(occ);
+  oct.tree_visit_cnt_ = occ.select(0, 3);
+  Tensor adders = occ.slice(0, 0, 2), visit_mark = occ.select(0, 2);
   F2N_TIMED_CALL("oct_update_stats",f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
                                 I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
                                 VoidP(oct.child_blocks_gpu_)));

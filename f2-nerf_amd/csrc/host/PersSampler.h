@@ -71,7 +71,7 @@ class PersSampler : public PtsSampler {
   float sample_l_;
   bool scale_by_dis_;
   // data-parallel hook: called between MarkVisit and the stats update with (adders [2,n], mark [n], visit_cnt [n])
-  std::function<void(Tensor, Tensor, Tensor)> occupancy_sync_hook_;
+  std::function<void(Tensor)> occupancy_sync_hook_;  // gets the [4, n_nodes] vote / mark / visit-count buffer
   // explicit random draws for parity tests (empty = draw from torch's generator like the reference)
   Tensor forced_noise_, forced_edge_idx_, forced_edge_coords_;
 };

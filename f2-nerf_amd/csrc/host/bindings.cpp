@@ -118,6 +118,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              return std::vector<Tensor>{FieldOf(r)->grad_h_, FieldOf(r)->mlp_->grad_scaled_, ShaderOf(r)->mlp_->grad_scaled_,
                                         r.renderer_->app_emb_grad_};
            })
+      .def("flatten_small_grads", &ExpRunner::FlattenSmallGrads)
       .def("occupancy_buffers",
            [](ExpRunner& r) {
              auto& o = *SamplerOf(r)->pers_octree_;
@@ -126,9 +127,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("set_grad_sync_hook", [](ExpRunner& r, py::function f) { r.grad_sync_hook_ = [f]() { py::gil_scoped_acquire g; f(); }; })
       .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically
            [](ExpRunner& r, py::function f) {
-             SamplerOf(r)->occupancy_sync_hook_ = [f](Tensor adders, Tensor mark, Tensor cnt) {
+             SamplerOf(r)->occupancy_sync_hook_ = [f](Tensor occ) {
                py::gil_scoped_acquire g;
-               f(adders, mark, cnt);
+               f(occ);
              };
            })
       .def_static("enable_kernel_timing", [](const std::vector<std::string>& names) { KernelTimers::Get().Enable(names); })

@@ -4,11 +4,13 @@ xGMI on MI355X, "gloo" on CPU for tests).
 The reference is single-GPU (no distributed code).  Rays are independent given replicated model +
 octree, so each rank renders its own ray batch and the replicas exchange exactly two things per step:
 
-  1. gradients -- one all-reduce(AVG) per buffer: the ACTIVE prefix of the fp16 (x128 loss-scaled) hash-gradient table
-     (17 * 2^log2_table_size halves: the only entries any level can address), the two MLP gradient vectors and app_emb;
+  1. gradients -- two all-reduce(AVG): the ACTIVE prefix of the fp16 (x128 loss-scaled) hash-gradient table
+     (17 * 2^log2_table_size halves: the only entries any level can address) and ONE flat fp32 buffer holding the two MLP
+     gradient vectors and app_emb (ExpRunner::FlattenSmallGrads: small collectives are latency-bound, ~30 us each);
      averaging keeps the loss semantics of `mean` over the global batch;
-  2. octree occupancy votes -- all-reduce(MAX) of (weight votes, alpha votes, visited marks, visit counts) between
-     MarkVisit and the stats update (PersSampler.cu:555-603), so that every replica prunes / subdivides identically.
+  2. octree occupancy votes -- ONE all-reduce(MAX) of the [4, n_nodes] buffer (weight votes, alpha votes, visited marks,
+     visit counts) between MarkVisit and the stats update (PersSampler.cu:555-603), so that every replica prunes /
+     subdivides identically.
 
 xGMI note (point-to-point, 7 links x ~153 GB/s per GPU): the table gradient is 17 MiB in its fp16 form -- half of what an
 fp32 all-reduce of the same gradient would move, and 47 % less than the full 32 MiB allocation -- so a ring moves
@@ -51,12 +53,13 @@ def make_grad_sync(grad_buffers, log2_table_size, group=None):
     return sync
 
 
-def occupancy_sync(adders, mark, visit_cnt, group=None):
-    for t in (adders, mark, visit_cnt):
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+def occupancy_sync(occ, group=None):
+    """occ: int32 [4, n_nodes] = weight votes, alpha votes, visited marks, visit counts (all max-combinable)."""
+    dist.all_reduce(occ, op=dist.ReduceOp.MAX, group=group)
 
 
 def attach(runner, log2_table_size, group=None):
-    """Wire both collectives into an ExpRunner (csrc/host/ExpRunner.cpp hooks)."""
-    runner.set_grad_sync_hook(make_grad_sync(runner.grad_buffers(), log2_table_size, group))
-    runner.set_occupancy_sync_hook(lambda a, m, c: occupancy_sync(a, m, c, group))
+    """Wire both collectives into an ExpRunner (csrc/host/ExpRunner.cpp hooks): 3 collectives per training step."""
+    flat = runner.flatten_small_grads()
+    runner.set_grad_sync_hook(make_grad_sync([runner.grad_buffers()[0], flat], log2_table_size, group))
+    runner.set_occupancy_sync_hook(lambda occ: occupancy_sync(occ, group))

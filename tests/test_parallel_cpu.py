@@ -52,9 +52,9 @@ def _worker(rank, world, port, out_dir):
     w = (g["seg_val"] * np.float32(0.01)).astype(np.float32)
     oi = np.ascontiguousarray(g["march_anchors"][:, 1])
     wa, aa, mk, cnt = oc.mark_visit(n_nodes, se[half], oi, w, g["occ_alpha"], np.zeros(n_nodes, np.int32))
-    adders = torch.from_numpy(np.stack([wa, aa]))
-    mark, vcnt = torch.from_numpy(mk), torch.from_numpy(cnt)
-    parallel.occupancy_sync(adders, mark, vcnt)
+    occ = torch.from_numpy(np.stack([wa, aa, mk, cnt]))  # the [4, n_nodes] buffer of PersSampler::UpdateOctNodes
+    parallel.occupancy_sync(occ)
+    adders, mark, vcnt = occ[:2], occ[2], occ[3]
     ws = np.full(n_nodes, 3, np.int32)
     w2, a2, nodes2 = oc.update_node_stats(adders[0].numpy(), adders[1].numpy(), mark.numpy(), ws, ws, st["tree_nodes"])
     np.save(os.path.join(out_dir, "occ_%d.npy" % rank), np.concatenate([w2, a2, vcnt.numpy(), nodes2.view(np.int32)]))
