@@ -134,8 +134,16 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   auto* gdp = global_data_pool_.get();
   gdp->mode_ = RunningMode::TRAIN;
   gdp->backward_nan_ = false;
-  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
-  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  const bool pipelined = pipelined_sync_ && apply_optimizer;
+  if (pipelined) {
+    // The previous step's gradient all-reduce is still in flight on RCCL's stream.  Ray sampling reads neither the
+    // parameters nor the gradients, so it is issued first and runs under the collective; only then is the collective
+    // awaited and the previous step's (flag-predicated) Adam applied.
+    renderer_->PreSample(rays_o, rays_d, bounds);
+    FinishPending();
+  } else {
+    FinishPending();
+  }
   renderer_->ZeroGrad();
   TrainOutputs out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(),
                                                      disp_loss_weight_, tv_loss_weight_);
@@ -146,24 +154,14 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   stats.loss = out.losses.slice(0, 0, 1).squeeze(0);
   stats.mse = out.losses.slice(0, 5, 6).squeeze(0);
   if (out.has_samples) {
-    if (grad_sync_hook_) grad_sync_hook_();  // data-parallel all-reduce of the gradient buffers (RCCL)
-    const int32_t* skip = nullptr;
-    if (check_nan_) {  // TCNNWP.cpp:234-240, on the device
-      if (!nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
-      F2N_CALL(f2n_nonfinite_flags(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
-                                   F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_)));
-      skip = I32P(nan_flags_) + 2;
-    }
-    if (apply_optimizer) OptimStep(skip);  // a no-op on the device when the flags say so
-    if (check_nan_) {
-      Tensor h = nan_flags_.cpu();  // the iteration's only read-back besides the two sample counts
-      const int32_t* f = h.data_ptr<int32_t>();
-      if (f[0]) field->mlp_->loss_scale_ = std::max(field->mlp_->loss_scale_ / 2.f, 1.f);
-      if (f[1]) shader->mlp_->loss_scale_ = std::max(shader->mlp_->loss_scale_ / 2.f, 1.f);
-      if (f[2]) {  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
-        gdp->backward_nan_ = true;
-        stats.skipped_nan = true;
-        if (apply_optimizer) optim_steps_ -= 1;
+    if (pipelined) {
+      if (grad_sync_begin_hook_) grad_sync_begin_hook_();  // asynchronous all-reduce; awaited in the next step (or Flush)
+      pending_ = true;
+      pending_lr_ = cur_lr_;
+    } else {
+      if (grad_sync_hook_) grad_sync_hook_();  // data-parallel all-reduce of the gradient buffers (RCCL)
+      if (ApplyGradients(apply_optimizer)) {
+        stats.skipped_nan = true;  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
         return stats;
       }
     }
@@ -173,6 +171,52 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     UpdateAdaParams();
   }
   return stats;
+}
+
+// Finiteness flags (TCNNWP.cpp:234-240, on the device), Adam predicated on them, ONE flag read-back.  Returns true when
+// the gradients were not finite (loss scales halved, nothing applied).
+bool ExpRunner::ApplyGradients(bool apply_optimizer) {
+  auto* gdp = global_data_pool_.get();
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  const int32_t* skip = nullptr;
+  if (check_nan_) {
+    if (!nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
+    F2N_CALL(f2n_nonfinite_flags(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
+                                 F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_)));
+    skip = I32P(nan_flags_) + 2;
+  }
+  if (apply_optimizer) OptimStep(skip);  // a no-op on the device when the flags say so
+  if (check_nan_) {
+    Tensor h = nan_flags_.cpu();  // the iteration's only read-back besides the two sample counts
+    const int32_t* f = h.data_ptr<int32_t>();
+    if (f[0]) field->mlp_->loss_scale_ = std::max(field->mlp_->loss_scale_ / 2.f, 1.f);
+    if (f[1]) shader->mlp_->loss_scale_ = std::max(shader->mlp_->loss_scale_ / 2.f, 1.f);
+    if (f[2]) {
+      gdp->backward_nan_ = true;
+      if (apply_optimizer) optim_steps_ -= 1;
+      return true;
+    }
+  }
+  return false;
+}
+
+// Pipelined data-parallel mode: completes the step whose gradients are still being reduced (awaits the collective,
+// applies Adam with that step's learning rate).  A non-finite gradient drops that step after the fact: the iteration
+// counter is taken back by one (the sampling of the step in between has already used the advanced schedule -- the one
+// deviation from the unpipelined order, and only on that rare path).
+void ExpRunner::FinishPending() {
+  if (!pending_) return;
+  pending_ = false;
+  if (grad_sync_end_hook_) grad_sync_end_hook_();
+  const float lr_now = cur_lr_;
+  cur_lr_ = pending_lr_;
+  const bool nan = ApplyGradients(true);
+  cur_lr_ = lr_now;
+  if (nan) {
+    iter_step_ = std::max(0, iter_step_ - 1);
+    UpdateAdaParams();
+  }
 }
 
 // The same iteration on the autograd tape, op for op as the reference spells it (ExpRunner.cpp:82-143): Render(),
@@ -228,6 +272,7 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
 
 // ExpRunner::RenderWholeImage chunk body (ExpRunner.cpp:268-287), VALIDATE mode.
 std::vector<Tensor> ExpRunner::RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  FinishPending();
   torch::NoGradGuard no_grad;
   auto prev = global_data_pool_->mode_;
   global_data_pool_->mode_ = RunningMode::VALIDATE;

@@ -17,7 +17,12 @@ class ExpRunner {
  public:
   ExpRunner(const std::map<std::string, std::string>& flat_config, int n_images);
   void LoadStates(const std::vector<Tensor>& states);  // checkpoint order, see SURVEY.md section 5
-  std::vector<Tensor> States() { return renderer_->States(); }
+  std::vector<Tensor> States() {
+    FinishPending();
+    return renderer_->States();
+  }
+  bool ApplyGradients(bool apply_optimizer);
+  void FinishPending();  // pipelined data-parallel mode: complete the step whose all-reduce is still in flight
   TrainStats TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                        const Tensor& emb_idx, bool apply_optimizer = true);
   TrainStats TrainStepAutograd(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
@@ -44,6 +49,11 @@ class ExpRunner {
   bool check_nan_ = true;
   int optim_steps_ = 0;
   std::function<void()> grad_sync_hook_;
+  // pipelined variant: begin = launch the asynchronous all-reduce right after backward; end = make the compute stream
+  // wait for it -- called in the NEXT TrainStep after ray sampling has been issued (or by FinishPending / Flush)
+  std::function<void()> grad_sync_begin_hook_, grad_sync_end_hook_;
+  bool pipelined_sync_ = false, pending_ = false;
+  float pending_lr_ = 0.f;
   Tensor nan_flags_;  // device int32 [4]: field MLP, colour MLP, either
 
   std::unique_ptr<GlobalDataPool> global_data_pool_;

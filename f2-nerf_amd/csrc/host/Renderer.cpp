@@ -191,12 +191,23 @@ void Renderer::ZeroGrad() {
   app_emb_grad_.zero_();
 }
 
+void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
+  has_presample_ = true;
+}
+
 RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx) {
   auto* gdp = global_data_pool_;
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
-  sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
+  if (has_presample_) {  // PreSample() already marched these rays
+    sample_result_ = std::move(presampled_);
+    presampled_ = SampleResultFlex();
+    has_presample_ = false;
+  } else {
+    sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
+  }
   int n_all_pts = sample_result_.pts.size(0);
   last_n_all_pts_ = n_all_pts;
   if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;

@@ -56,6 +56,8 @@ class Renderer : public Pipe {
  public:
   Renderer(GlobalDataPool* global_data_pool, int n_images);
   RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
+  // issues the ray sampling of the next SampleAndFilter / TrainForwardBackward call ahead of time (same rays!)
+  void PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
   // forward + ExpRunner::Train's loss + backward into the gradient buffers, without the autograd tape
   TrainOutputs TrainForwardBackward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
@@ -74,7 +76,8 @@ class Renderer : public Pipe {
   Tensor app_emb_;       // [n_images, 16]
   Tensor app_emb_grad_;  // fp32, unscaled
   BGColorType bg_color_type_ = BGColorType::rand_noise;
-  SampleResultFlex sample_result_;
+  SampleResultFlex sample_result_, presampled_;
+  bool has_presample_ = false;
   Tensor forced_bg_;  // explicit background colours for parity tests (undefined = as the reference)
   int n_edge_pts_ = 8192;
   int last_n_all_pts_ = 0, last_n_kept_pts_ = 0;

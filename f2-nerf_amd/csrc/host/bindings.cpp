@@ -125,6 +125,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              return std::vector<Tensor>{o.tree_weight_stats_, o.tree_alpha_stats_, o.tree_visit_cnt_};
            })
       .def("set_grad_sync_hook", [](ExpRunner& r, py::function f) { r.grad_sync_hook_ = [f]() { py::gil_scoped_acquire g; f(); }; })
+      .def("set_pipelined_grad_sync",
+           [](ExpRunner& r, py::function begin, py::function end) {
+             r.grad_sync_begin_hook_ = [begin]() { py::gil_scoped_acquire g; begin(); };
+             r.grad_sync_end_hook_ = [end]() { py::gil_scoped_acquire g; end(); };
+             r.pipelined_sync_ = true;
+           })
+      .def("flush", [](ExpRunner& r) { py::gil_scoped_release no_gil; r.FinishPending(); })
       .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically
            [](ExpRunner& r, py::function f) {
              SamplerOf(r)->occupancy_sync_hook_ = [f](Tensor occ) {

@@ -58,8 +58,30 @@ def occupancy_sync(occ, group=None):
     dist.all_reduce(occ, op=dist.ReduceOp.MAX, group=group)
 
 
-def attach(runner, log2_table_size, group=None):
-    """Wire both collectives into an ExpRunner (csrc/host/ExpRunner.cpp hooks): 3 collectives per training step."""
+def attach(runner, log2_table_size, group=None, overlap=None):
+    """Wire both collectives into an ExpRunner (csrc/host/ExpRunner.cpp hooks): 3 collectives per training step.
+
+    overlap (default: on for the nccl/RCCL backend): the two gradient all-reduces are launched asynchronously right
+    after backward and only awaited in the NEXT train_step, after its ray sampling (which reads neither parameters nor
+    gradients) has been issued -- the 17 MiB table reduction over xGMI then runs under ~0.3 ms of sampler kernels
+    instead of in front of the optimiser.  Call runner.flush() before reading parameters outside train_step /
+    render_rays / states() (those flush themselves)."""
     flat = runner.flatten_small_grads()
-    runner.set_grad_sync_hook(make_grad_sync([runner.grad_buffers()[0], flat], log2_table_size, group))
+    table = runner.grad_buffers()[0].view(-1)[:active_table_halves(log2_table_size)]
+    if overlap is None:
+        overlap = dist.get_backend(group) == "nccl"
+    if overlap:
+        works = []
+
+        def begin():
+            works.append(dist.all_reduce(table, op=dist.ReduceOp.AVG, group=group, async_op=True))
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=True))
+
+        def end():
+            for w in works:
+                w.wait()  # the compute stream waits for RCCL's stream; the host does not block
+            works.clear()
+        runner.set_pipelined_grad_sync(begin, end)
+    else:
+        runner.set_grad_sync_hook(make_grad_sync([table, flat], log2_table_size, group))
     runner.set_occupancy_sync_hook(lambda occ: occupancy_sync(occ, group))
