@@ -272,11 +272,16 @@ def compact_samples(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_p
                                   _p(o_anchors, "i32")), "f2n_compact_samples")
 
 
-def compact_samples_src(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src):
+def compact_samples_src(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src,
+                        o_vol=None):
     _ck(lib().f2n_compact_samples_src(_stream(), _i(n_rays), _p(old_se, "i32"), _p(new_se, "i32"), _p(mask, "i32"),
                                       _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"), _p(anchors, "i32"),
                                       _p(o_pts, "f32"), _p(o_dirs, "f32"), _p(o_dt, "f32"), _p(o_t, "f32"),
-                                      _p(o_anchors, "i32"), _p(o_src, "i32")), "f2n_compact_samples_src")
+                                      _p(o_anchors, "i32"), _p(o_src, "i32"), _p(o_vol, "i32", True)), "f2n_compact_samples_src")
+
+
+def march_noise(n, u, fineness, out):
+    _ck(lib().f2n_march_noise(_stream(), _i(n), _p(u, "f32"), _f(fineness), _p(out, "f32")), "f2n_march_noise")
 
 
 def composite_fwd(n_rays, pts_se, feat, dt, t, rgb, bg, colors, disparity, depth, weights):

@@ -28,6 +28,7 @@ ExpRunner::ExpRunner(const std::map<std::string, std::string>& flat_config, int 
   global_data_pool_->n_volumes_ = c.Has("runtime.n_volumes") ? c.Int("runtime.n_volumes") : 1;
   renderer_ = std::make_unique<Renderer>(global_data_pool_.get(), n_images);
   BuildOptimizer();
+  FlattenSmallGrads();
   UpdateAdaParams();
 }
 
@@ -45,6 +46,7 @@ void ExpRunner::BuildOptimizer() {
 // Re-homes the three small fp32 gradient buffers (field MLP, colour MLP, app_emb) in ONE flat tensor, so that a
 // data-parallel run reduces them with a single collective instead of three latency-bound ones.  Returns the flat tensor.
 Tensor ExpRunner::FlattenSmallGrads() {
+  if (renderer_->small_grads_flat_.defined()) return renderer_->small_grads_flat_;
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
   const int64_t n1 = field->mlp_->grad_scaled_.numel(), n2 = shader->mlp_->grad_scaled_.numel(),
@@ -58,6 +60,7 @@ Tensor ExpRunner::FlattenSmallGrads() {
     if (g.name == "color_mlp") g.grad = shader->mlp_->grad_scaled_;
     if (g.name == "app_emb") g.grad = renderer_->app_emb_grad_;
   }
+  renderer_->small_grads_flat_ = flat;
   return flat;
 }
 

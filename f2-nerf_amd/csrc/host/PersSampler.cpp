@@ -94,8 +94,8 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
     rays_noise = torch::ones({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32());
     rays_noise.mul_(global_data_pool_->ray_march_fineness_);
   } else {
-    rays_noise = ((torch::rand({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32()) - .5f) + 1.f).contiguous();
-    rays_noise.mul_(global_data_pool_->ray_march_fineness_);
+    rays_noise = torch::rand({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32());
+    F2N_CALL(f2n_march_noise(st, (int) rays_noise.numel(), F32P(rays_noise), global_data_pool_->ray_march_fineness_, F32P(rays_noise)));
   }
 
   // ONE march into fixed-stride per-ray slots (28 B x 1024 per ray of scratch, of which only the filled prefixes are

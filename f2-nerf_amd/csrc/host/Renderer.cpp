@@ -186,7 +186,14 @@ Renderer::Renderer(GlobalDataPool* gdp, int n_images) {  // Renderer.cpp:22-49
 }
 
 void Renderer::ZeroGrad() {
-  static_cast<Hash3DAnchored*>(scene_field_.get())->ZeroGrad();
+  auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
+  if (small_grads_flat_.defined()) {  // field MLP, colour MLP and app_emb gradients are views of one tensor: one fill
+    if (!field->grad_clean_) field->grad_h_.zero_();
+    field->grad_clean_ = true;
+    small_grads_flat_.zero_();
+    return;
+  }
+  field->ZeroGrad();
   static_cast<SHShader*>(shader_.get())->mlp_->ZeroGrad();
   app_emb_grad_.zero_();
 }
@@ -252,14 +259,13 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     es.dt = torch::empty({n_kept}, DevF32());
     es.t = torch::empty({n_kept}, DevF32());
     es.anchors = torch::empty({n_kept, 3}, DevI32());
-    es.first_oct_dis = sample_result_.first_oct_dis.clone();
+    es.first_oct_dis = sample_result_.first_oct_dis;
     es.pts_idx_bounds = new_se;
     src_rows = torch::empty({std::max(n_kept, 1)}, DevI32());
     F2N_TIMED_CALL("compact_samples", f2n_compact_samples_src(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
                                  F32P(sample_result_.pts), F32P(sample_result_.dirs), F32P(sample_result_.dt),
                                  F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all), F32P(es.dirs),
-                                 F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows)));
-    if (n_kept > 0) vol_all.slice(0, 0, n_kept).copy_(es.anchors.select(1, 0));
+                                 F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows), I32P(vol_all)));
     if (train) {  // Renderer.cpp:140-149
       pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);
       gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(n_rays)) * 0.1f;

@@ -75,6 +75,7 @@ class Renderer : public Pipe {
   bool use_app_emb_;
   Tensor app_emb_;       // [n_images, 16]
   Tensor app_emb_grad_;  // fp32, unscaled
+  Tensor small_grads_flat_;  // when defined: the flat home of the three small gradient buffers (ExpRunner::FlattenSmallGrads)
   BGColorType bg_color_type_ = BGColorType::rand_noise;
   SampleResultFlex sample_result_, presampled_;
   bool has_presample_ = false;

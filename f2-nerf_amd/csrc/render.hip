@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void compact_kernel(int n_rays, const int32_t*
                                                       const float* __restrict__ dt, const float* __restrict__ t,
                                                       const int32_t* __restrict__ anchors, float* __restrict__ o_pts,
                                                       float* __restrict__ o_dirs, float* __restrict__ o_dt, float* __restrict__ o_t,
-                                                      int32_t* __restrict__ o_anchors, int32_t* __restrict__ o_src) {
+                                                      int32_t* __restrict__ o_anchors, int32_t* __restrict__ o_src,
+                                                      int32_t* __restrict__ o_vol) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void compact_kernel(int n_rays, const int32_t*
       o_dt[k] = dt[i];
       o_t[k] = t[i];
       if (o_src != nullptr) o_src[k] = i;
+      if (o_vol != nullptr) o_vol[k] = anchors[3 * (size_t) i];  // trans idx as a unit-stride array (the field's volume index)
     }
     dst += __popcll(bal);
   }
@@ -370,18 +372,18 @@ int f2n_compact_samples(void* stream, int n_rays, const int32_t* old_start_end, 
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(compact_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, old_start_end,
-                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, nullptr);
+                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, nullptr, nullptr);
   return f2n_launch_status();
 }
 
 int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_end, const int32_t* new_start_end,
                             const int32_t* mask, const float* pts, const float* dirs, const float* dt, const float* t,
                             const int32_t* anchors, float* o_pts, float* o_dirs, float* o_dt, float* o_t, int32_t* o_anchors,
-                            int32_t* o_src) {
+                            int32_t* o_src, int32_t* o_vol) {
   if (n_rays < 0 || o_src == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(compact_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, old_start_end,
-                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src);
+                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src, o_vol);
   return f2n_launch_status();
 }
 

@@ -732,7 +732,19 @@ __global__ void mark_invisible_kernel(int n_nodes, int n_cams, F2nTreeNode* __re
 // ---------------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------------
+__global__ void march_noise_kernel(int n, const float* __restrict__ u, float fineness, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ((u[i] - .5f) + 1.f) * fineness;
+}
+
 extern "C" {
+
+int f2n_march_noise(void* stream, int n, const float* u, float fineness, float* out) {
+  if (n < 0) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(march_noise_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n, u, fineness, out);
+  return f2n_launch_status();
+}
 
 int f2n_normalize_dirs(void* stream, int n, const float* dirs, float* out) {
   if (n < 0) return F2N_ERR_INVALID_ARG;

@@ -86,6 +86,10 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
  * host-side change of the tree; f2n_oct_update_stats keeps the trans_idx copies current when given the pointer. */
 int f2n_oct_build_child_blocks(void* stream, int n_nodes, const void* tree_nodes, void* child_blocks);
 
+/* The march noise of PersSampler.cu:372-381 from uniform draws u in [0,1): out = ((u - 0.5) + 1) * fineness, in that
+ * fp32 order (the reference: three ATen launches). */
+int f2n_march_noise(void* stream, int n, const float* u, float fineness, float* out);
+
 /* RayMarchKernel<false> (PersSampler.cu:189-314, launched :383-393).  noise has
  * F2N_MAX_SAMPLE_PER_RAY + n_rays + 10 floats, already multiplied by ray_march_fineness (:372-381), and is
  * indexed [ray + k] exactly as in the reference (:203,:266). */
@@ -284,7 +288,8 @@ int f2n_compact_samples(void* stream, int n_rays, const int32_t* old_start_end, 
 int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_end, const int32_t* new_start_end,
                             const int32_t* mask, const float* pts, const float* dirs, const float* dt, const float* t,
                             const int32_t* anchors, float* o_pts, float* o_dirs, float* o_dt, float* o_t,
-                            int32_t* o_anchors, int32_t* o_src /*[M]*/);
+                            int32_t* o_anchors, int32_t* o_src /*[M]*/,
+                            int32_t* o_vol /*[M] or NULL: anchors[:,0] of the survivors as a unit-stride array*/);
 
 /* Compositing (Renderer.cpp:196-208): colors = sum w*c + T_last*bg, disparity = sum w/(t+.01),
  * depth = sum w*(t+.01) / (1 - T_last + 1e-4); weights [M] is also returned (RenderResult, Renderer.h:18-27).
