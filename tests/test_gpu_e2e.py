@@ -304,3 +304,25 @@ def test_data_parallel_hooks_on_one_gpu(rt, fox_state):
                 assert float((a.float() - b.float()).abs().max()) <= 1e-4 * max(float(a.float().abs().max()), 1e-6)
             else:
                 assert (a == b).all()
+
+
+@pytest.mark.parametrize("preset,overrides", [("llff", []), ("nerf-360", []), ("wanjinyou_big", ["field.log2_table_size=20"]), ("free", [])])
+def test_other_presets_train(rt, fox_state, preset, overrides):
+    """BASELINE configs 3-5 as plumbing cases: the presets that differ in sampler step (sample_l 1/512), scale_by_dis,
+    appearance embedding and table size must train (finite, decreasing loss) through the same fused step."""
+    st = fox_state
+    rng = np.random.default_rng(15)
+    runner, cfg, _ = rt.make_runner(st, preset, overrides + ["train.learning_rate_warm_up_end_iter=10"], seed=4)
+    runner.n_edge_pts = 512
+    R = 512
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    gt = np.tile(np.array([[0.7, 0.4, 0.1]], F32), (R, 1))
+    d = rt.to_dev(ro, rd, bounds, gt, cam)
+    mse = []
+    for it in range(40):
+        s = runner.train_step(d[0], d[1], d[2], d[3], d[4], True)
+        assert not s["skipped_nan"] and s["n_samples"] > 0
+        mse.append(float(s["mse"]))
+    assert np.isfinite(mse).all() and mse[-1] < 0.7 * mse[0], (preset, mse[0], mse[-1])
+    cols = runner.render_rays(d[0], d[1], d[2])[0]
+    assert torch.isfinite(cols).all()

@@ -159,6 +159,23 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
     assert_same(N(fod).reshape(n, 1), ref["first_oct_dis"], "single-pass first_oct_dis")
 
 
+def test_sampler_sample_cap(hip, fox_state):
+    """Maximum size: with a very fine step every ray runs into the 1024-samples-per-ray cap (PersSampler.cu:9); counts,
+    bounds and the samples themselves must still match the oracle bit for bit."""
+    st = fox_state
+    rng = np.random.default_rng(9)
+    n = 64
+    o, d, _ = fox_rays(st, rng, n)
+    noise = ((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(0.02)
+    hits, m = gpu_sample(hip, st, o, d, noise, 1. / 256., True)
+    ref_hits = oc.oct_intersect(st["search_order"], o, d, 0.01, 1e8, st["tree_nodes"], 1024)
+    ref = oc.ray_march(o, d, noise, 1. / 256., True, *ref_hits, st["tree_nodes"], st["pers_trans"])
+    per_ray = ref["pts_idx_bounds"][:, 1] - ref["pts_idx_bounds"][:, 0]
+    assert per_ray.max() == 1024 and (per_ray == 1024).mean() > 0.5
+    for k in ref:
+        assert_same(m[k], ref[k], k)
+
+
 def test_sampler_full_size_properties(hip, fox_state):
     """BASELINE config 2 size (8192 rays): size-independent properties + run-to-run determinism."""
     st = fox_state
@@ -343,12 +360,12 @@ def test_hash_backward(hip, fox_state):
         assert mism <= 4, mism  # two corners of one level may hash to the same entry (order-dependent rounding)
 
 
-def test_hash_backward_owner_binned(hip, fox_state):
+@pytest.mark.parametrize("log2", [14, 20])
+def test_hash_backward_owner_binned(hip, fox_state, log2):
     """Large batches take the owner-binned scatter (queues -> LDS accumulation -> plain stores).  It must agree with
     the direct packed-f16 atomics of the small-batch path and with the fp32-accumulated oracle; rays of consecutive,
     closely spaced samples exercise the in-row run combining, a short ragged tail the chunk boundaries."""
     rng = np.random.default_rng(12)
-    log2 = 14
     grid = make_grid(fox_state, rng, log2)
     n = 40000 + 37
     n_rays = n // 50 + 1
