@@ -113,12 +113,13 @@ def ray_march_strided(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct
                       s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans=None):
     _ck(lib().f2n_ray_march_strided(_stream(), _i(n_rays), _f(sample_l), _i(int(scale_by_dis)), _p(rays_o, "f32"), _p(rays_d, "f32"),
                                     _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(tree_nodes, "u8"),
-                                    _p(transes, "u8"), _p(counts, "i32"), _p(s_pts, "f32"), _p(s_dt, "f32"), _p(s_t, "f32"),
+                                    _p(transes, "u8"), _p(counts, "i32"), _p(s_pts, "f32", True), _p(s_dt, "f32"), _p(s_t, "f32"),
                                     _p(s_anchors, "i32"), _p(first_oct_dis, "f32"), _p(oct_trans, "i32", True)), "f2n_ray_march_strided")
 
 
-def pack_samples(n_rays, pts_se, rays_d, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors):
-    _ck(lib().f2n_pack_samples(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(rays_d, "f32"), _p(s_pts, "f32"), _p(s_dt, "f32"),
+def pack_samples(n_rays, pts_se, rays_o, rays_d, transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors):
+    _ck(lib().f2n_pack_samples(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(rays_o, "f32", True), _p(rays_d, "f32"),
+                               _p(transes, "u8", True), _p(s_pts, "f32", True), _p(s_dt, "f32"),
                                _p(s_t, "f32"), _p(s_anchors, "i32"), _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"),
                                _p(anchors, "i32")), "f2n_pack_samples")
 

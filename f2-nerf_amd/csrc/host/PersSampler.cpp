@@ -102,13 +102,13 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   // touched) + the per-ray counts; the reference marches twice (count pass, host sync, fill pass: :383-423).
   Tensor pts_se = torch::empty({n_rays, 2}, DevI32());
   const int64_t slots = int64_t(n_rays) * F2N_MAX_SAMPLE_PER_RAY;
-  Tensor s_pts = torch::empty({slots, 3}, DevF32()), s_dt = torch::empty({slots}, DevF32()), s_t = torch::empty({slots}, DevF32());
+  Tensor s_dt = torch::empty({slots}, DevF32()), s_t = torch::empty({slots}, DevF32());  // warped points: computed by pack
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
   SampleResultFlex res;
   res.first_oct_dis = torch::empty({n_rays, 1}, DevF32());
   F2N_TIMED_CALL("ray_march", f2n_ray_march_strided(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
                                  I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
-                                 VoidP(oct.pers_trans_gpu_), I32P(counts), F32P(s_pts), F32P(s_dt), F32P(s_t), I32P(s_anchors),
+                                 VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t), I32P(s_anchors),
                                  F32P(res.first_oct_dis), I32P(oct_tr)));
   F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(pts_se), I32P(totals) + 1));
 
@@ -126,7 +126,7 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   res.t = torch::empty({n_all_pts}, DevF32());
   res.anchors = torch::empty({n_all_pts, 3}, DevI32());
   res.pts_idx_bounds = pts_se;
-  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(pts_se), F32P(rays_d), F32P(s_pts), F32P(s_dt), F32P(s_t),
+  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(pts_se), F32P(rays_o), F32P(rays_d), VoidP(oct.pers_trans_gpu_), nullptr, F32P(s_dt), F32P(s_t),
                                     I32P(s_anchors), F32P(res.pts), F32P(res.dirs), F32P(res.dt), F32P(res.t), I32P(res.anchors)));
   return res;
 }

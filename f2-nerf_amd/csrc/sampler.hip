@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
   int out_stride = 0;
   uint32_t out_const = 0u;
   if (FILL) {
-    if (j < 3) { out_ptr = (uint32_t*) pts + 3 * base + j; out_stride = 3; }
+    if (j < 3) { if (pts != nullptr) { out_ptr = (uint32_t*) pts + 3 * base + j; out_stride = 3; } }
     else if (j == 3) { out_ptr = (uint32_t*) ts + base; out_stride = 1; }
     else if (j == 4) { out_ptr = (uint32_t*) dts + base; out_stride = 1; }
     else if (MODE == 2 && j < 7) { out_ptr = (uint32_t*) anchors + 2 * base + (j - 5); out_stride = 2; }
@@ -428,10 +428,12 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
       float march = step;
       if (!first) {  // the first point of a ray is never emitted (:274-289)
         if (FILL) {
-          float w[3];  // the warped point (:155-169) shares the projection with the Jacobian
-          const float v = px / pz;
+          float w[3] = {0.f, 0.f, 0.f};  // the warped point (:155-169) shares the projection with the Jacobian
+          if (MODE == 1 || pts != nullptr) {  // (MODE 2 without a pts buffer: f2n_pack_samples computes it, in parallel)
+            const float v = px / pz;
 #pragma unroll
-          for (int r = 0; r < 3; r++) w[r] = f2n_row12_sum(wg[r] * v);
+            for (int r = 0; r < 3; r++) w[r] = f2n_row12_sum(wg[r] * v);
+          }
           // one 4-byte store per writer lane (roles fixed before the loop) instead of per-array branches
           const uint32_t val = j == 0 ? __float_as_uint(w[0]) : j == 1 ? __float_as_uint(w[1]) : j == 2 ? __float_as_uint(w[2])
                              : j == 3 ? __float_as_uint(cur_t) : j == 4 ? __float_as_uint(step * pj_norm)
@@ -471,9 +473,13 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
   if (MODE != 1 && j == 0) pts_counts[ray] = n;
 }
 
-// Strided slots -> ray-ordered compact SampleResultFlex arrays (one wave per ray, coalesced copies).
+// Strided slots -> ray-ordered compact SampleResultFlex arrays (one wave per ray, coalesced copies).  When the march
+// did not store warped points (s_pts == nullptr) they are computed here, one sample per lane and all samples in
+// parallel: pts = W * (x_i / z_i) at xyz = o + d * t -- the very expressions of the march (:155-169, :303), so the bits
+// are the same, but off the march's sequential critical path.
 __global__ __launch_bounds__(256) void pack_samples_kernel(int n_rays, const int32_t* __restrict__ pts_start_end,
-                                                           const float* __restrict__ rays_d, const float* __restrict__ s_pts,
+                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                           const F2nTransInfo* __restrict__ transes, const float* __restrict__ s_pts,
                                                            const float* __restrict__ s_dt, const float* __restrict__ s_t,
                                                            const int32_t* __restrict__ s_anchors, float* __restrict__ pts,
                                                            float* __restrict__ dirs, float* __restrict__ dt, float* __restrict__ t,
@@ -485,14 +491,23 @@ __global__ __launch_bounds__(256) void pack_samples_kernel(int n_rays, const int
   const size_t src = (size_t) ray * F2N_MAX_SAMPLE_PER_RAY;
   const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
   for (int i = lane; i < 3 * cnt; i += 64) {
-    pts[3 * (size_t) s + i] = s_pts[3 * src + i];
+    if (s_pts != nullptr) pts[3 * (size_t) s + i] = s_pts[3 * src + i];
     dirs[3 * (size_t) s + i] = d[i % 3];
     const int k = i / 3, c = i - 3 * k;
     anchors[3 * (size_t) s + i] = c < 2 ? s_anchors[2 * (src + k) + c] : 0;
   }
+  const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
   for (int i = lane; i < cnt; i += 64) {
+    const float ti = s_t[src + i];
     dt[s + i] = s_dt[src + i];
-    t[s + i] = s_t[src + i];
+    t[s + i] = ti;
+    if (s_pts == nullptr) {
+      const float xyz[3] = {o[0] + d[0] * ti, o[1] + d[1] * ti, o[2] + d[2] * ti};
+      float w[3];
+      f2n_warp(transes + s_anchors[2 * (src + i)], xyz, w);
+#pragma unroll
+      for (int c = 0; c < 3; c++) pts[3 * (size_t) (s + i) + c] = w[c];
+    }
   }
 }
 
@@ -836,13 +851,13 @@ int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by
   return f2n_launch_status();
 }
 
-int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_d, const float* s_pts,
-                     const float* s_dt, const float* s_t, const int32_t* s_anchors, float* pts, float* dirs, float* dt, float* t,
-                     int32_t* anchors) {
-  if (n_rays < 0) return F2N_ERR_INVALID_ARG;
+int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
+                     const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
+                     float* pts, float* dirs, float* dt, float* t, int32_t* anchors) {
+  if (n_rays < 0 || (s_pts == nullptr && (rays_o == nullptr || transes == nullptr))) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(pack_samples_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, pts_start_end,
-                     rays_d, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors);
+                     rays_o, rays_d, (const F2nTransInfo*) transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors);
   return f2n_launch_status();
 }
 

@@ -120,9 +120,13 @@ int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by
                           int32_t* pts_counts /*[R]*/, float* s_pts, float* s_dt, float* s_t, int32_t* s_anchors,
                           float* first_oct_dis /*[R]*/,
                           const int32_t* oct_trans /*NULL, or f2n_oct_intersect_strided's: spares a node read per leaf*/);
-int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end /*[R,2]*/, const float* rays_d,
-                     const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors, float* pts /*[N,3]*/,
-                     float* dirs /*[N,3]*/, float* dt /*[N]*/, float* t /*[N]*/, int32_t* anchors /*[N,3]*/);
+/* s_pts may be NULL in both calls: the march then skips the warped point (one division and three reductions less on its
+ * sequential path) and f2n_pack_samples computes pts = warp(o + d*t) for all samples in parallel -- same expressions,
+ * same bits (PersSampler.cu:155-169); rays_o and transes are only read in that case. */
+int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end /*[R,2]*/, const float* rays_o,
+                     const float* rays_d, const void* transes, const float* s_pts, const float* s_dt, const float* s_t,
+                     const int32_t* s_anchors, float* pts /*[N,3]*/, float* dirs /*[N,3]*/, float* dt /*[N]*/,
+                     float* t /*[N]*/, int32_t* anchors /*[N,3]*/);
 
 /* GetEdgeSamplesKernel (PersSampler.cu:436-452).  edge_idx/edge_coords are the random draws of :456-457. */
 int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,

@@ -152,10 +152,18 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
     tot_n = int(tot.item()); mm = max(tot_n, 1)
     packed = dict(pts=torch.zeros((mm, 3), device=DEV), dirs=torch.zeros((mm, 3), device=DEV), dt=torch.zeros(mm, device=DEV),
                   t=torch.zeros(mm, device=DEV), anchors=torch.full((mm, 3), -7, dtype=torch.int32, device=DEV))
-    hip.pack_samples(n, pse2, T(d), s_pts, s_dt, s_t, s_an, packed["pts"], packed["dirs"], packed["dt"], packed["t"], packed["anchors"])
+    hip.pack_samples(n, pse2, T(o), T(d), tr, s_pts, s_dt, s_t, s_an, packed["pts"], packed["dirs"], packed["dt"], packed["t"],
+                     packed["anchors"])
     assert_same(N(pse2), ref["pts_idx_bounds"], "single-pass bounds")
     for k in ("pts", "dirs", "dt", "t", "anchors"):
         assert_same(N(packed[k])[:tot_n], ref[k], "single-pass " + k)
+    # without a slot buffer for the warped points: the pack computes them (same bits)
+    hip.ray_march_strided(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, cnt2, None, s_dt, s_t, s_an, fod, tr2)
+    packed["pts"].zero_()
+    hip.pack_samples(n, pse2, T(o), T(d), tr, None, s_dt, s_t, s_an, packed["pts"], packed["dirs"], packed["dt"], packed["t"],
+                     packed["anchors"])
+    for k in ("pts", "dirs", "dt", "t", "anchors"):
+        assert_same(N(packed[k])[:tot_n], ref[k], "pack-computed " + k)
     assert_same(N(fod).reshape(n, 1), ref["first_oct_dis"], "single-pass first_oct_dis")
 
 

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20000)
 ap.add_argument("--preset", default="wanjinyou")
 ap.add_argument("--log-every", type=int, default=2000)
+ap.add_argument("--dump-sampler", default="", help="save the final octree + one ray batch (input of tools/sampler_bench.py)")
 ap.add_argument("--breakdown", action="store_true", help="per-kernel HIP-event breakdown of 20 more steps in the final state")
 args = ap.parse_args()
 
@@ -74,3 +75,11 @@ if args.breakdown:
     for k, v in sorted(t.items(), key=lambda kv: -kv[1][1]):
         print("  %-22s launches %4.1f  %8.3f ms/step  %5.1f%%" % (k, v[0] / 20, v[1] / 20, 100 * v[1] / tot))
     print("  sum of timed calls: %.3f ms/step" % (tot / 20))
+
+if args.dump_sampler:
+    b = max(16, runner.cur_batch_size())
+    ro, rd, bounds, gt, cam = ds.rand_rays_data(b, 1)
+    np.savez_compressed(args.dump_sampler, tree_nodes=runner.tree_nodes().cpu().numpy(), pers_trans=st["pers_trans"],
+                        search_order=st["search_order"], rays_o=ro.cpu().numpy(), rays_d=rd.cpu().numpy(),
+                        fineness=np.float32(runner.fineness))
+    print("dumped", args.dump_sampler)
