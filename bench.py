@@ -96,8 +96,10 @@ def main():
         torch.cuda.synchronize()
 
     def step(i):
-        b = batches[i % n_batches]
-        return runner.train_step(b[0], b[1], b[2], b[3], b[4], True)
+        # the next batch's rays are handed over as well: their sampling is prefetched on a side stream underneath this
+        # step's backward kernels (the reference draws its rays at the top of every iteration, ExpRunner.cpp:88-91)
+        b, nb = batches[i % n_batches], batches[(i + 1) % n_batches]
+        return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
 
     for i in range(args.warmup):
         step(i)

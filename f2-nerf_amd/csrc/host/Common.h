@@ -2,6 +2,8 @@
 #pragma once
 #include <torch/torch.h>
 #include <ATen/hip/HIPEvent.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 
 #include <cmath>

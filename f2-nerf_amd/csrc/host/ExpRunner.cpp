@@ -133,20 +133,20 @@ float ExpRunner::CurVarLossWeight() const {
 // One iteration of ExpRunner::Train (ExpRunner.cpp:82-143) for a given ray batch: untaped forward + loss + backward
 // (Renderer::TrainForwardBackward), device-side finiteness flags, Adam predicated on them, ONE flag read-back.
 TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
-                                const Tensor& emb_idx, bool apply_optimizer) {
+                                const Tensor& emb_idx, bool apply_optimizer, const Tensor& next_rays_o,
+                                const Tensor& next_rays_d, const Tensor& next_bounds) {
   auto* gdp = global_data_pool_.get();
   gdp->mode_ = RunningMode::TRAIN;
   gdp->backward_nan_ = false;
   const bool pipelined = pipelined_sync_ && apply_optimizer;
+  const bool prefetch = apply_optimizer && next_rays_o.defined() && next_rays_d.defined();
   if (pipelined) {
     // The previous step's gradient all-reduce is still in flight on RCCL's stream.  Ray sampling reads neither the
-    // parameters nor the gradients, so it is issued first and runs under the collective; only then is the collective
-    // awaited and the previous step's (flag-predicated) Adam applied.
+    // parameters nor the gradients, so it is issued first (unless the previous step already prefetched it) and runs
+    // under the collective; only then is the collective awaited and the previous step's (flag-predicated) Adam applied.
     renderer_->PreSample(rays_o, rays_d, bounds);
-    FinishPending();
-  } else {
-    FinishPending();
   }
+  FinishPending();
   renderer_->ZeroGrad();
   TrainOutputs out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(),
                                                      disp_loss_weight_, tv_loss_weight_);
@@ -156,6 +156,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   stats.n_meaningful = renderer_->last_n_kept_pts_;
   stats.loss = out.losses.slice(0, 0, 1).squeeze(0);
   stats.mse = out.losses.slice(0, 5, 6).squeeze(0);
+  bool applied = false;
   if (out.has_samples) {
     if (pipelined) {
       if (grad_sync_begin_hook_) grad_sync_begin_hook_();  // asynchronous all-reduce; awaited in the next step (or Flush)
@@ -163,23 +164,29 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
       pending_lr_ = cur_lr_;
     } else {
       if (grad_sync_hook_) grad_sync_hook_();  // data-parallel all-reduce of the gradient buffers (RCCL)
-      if (ApplyGradients(apply_optimizer)) {
-        stats.skipped_nan = true;  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
-        return stats;
-      }
+      EnqueueApply(apply_optimizer);           // finiteness flags + predicated Adam, with this iteration's learning rate
+      applied = true;
     }
   }
   if (apply_optimizer) {
     iter_step_++;
     UpdateAdaParams();
   }
+  // Prefetch: the NEXT batch's rays are marched now, on a side stream, underneath the kernels of this step that are still
+  // queued (the host is ~1 ms ahead of the GPU here).  Needs the next iteration's fineness, hence after UpdateAdaParams.
+  if (prefetch) renderer_->PreSampleAsync(next_rays_o, next_rays_d, next_bounds);
+  if (applied && ResolveFlags(apply_optimizer)) {
+    stats.skipped_nan = true;  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
+    if (apply_optimizer) {
+      iter_step_ = std::max(0, iter_step_ - 1);
+      UpdateAdaParams();
+    }
+  }
   return stats;
 }
 
-// Finiteness flags (TCNNWP.cpp:234-240, on the device), Adam predicated on them, ONE flag read-back.  Returns true when
-// the gradients were not finite (loss scales halved, nothing applied).
-bool ExpRunner::ApplyGradients(bool apply_optimizer) {
-  auto* gdp = global_data_pool_.get();
+// Finiteness flags (TCNNWP.cpp:234-240, on the device) and Adam predicated on them: enqueue only.
+void ExpRunner::EnqueueApply(bool apply_optimizer) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
   const int32_t* skip = nullptr;
@@ -190,18 +197,30 @@ bool ExpRunner::ApplyGradients(bool apply_optimizer) {
     skip = I32P(nan_flags_) + 2;
   }
   if (apply_optimizer) OptimStep(skip);  // a no-op on the device when the flags say so
-  if (check_nan_) {
-    Tensor h = nan_flags_.cpu();  // the iteration's only read-back besides the two sample counts
-    const int32_t* f = h.data_ptr<int32_t>();
-    if (f[0]) field->mlp_->loss_scale_ = std::max(field->mlp_->loss_scale_ / 2.f, 1.f);
-    if (f[1]) shader->mlp_->loss_scale_ = std::max(shader->mlp_->loss_scale_ / 2.f, 1.f);
-    if (f[2]) {
-      gdp->backward_nan_ = true;
-      if (apply_optimizer) optim_steps_ -= 1;
-      return true;
-    }
+}
+
+// The iteration's only read-back besides the two sample counts.  Returns true when the gradients were not finite (loss
+// scales halved, nothing was applied).
+bool ExpRunner::ResolveFlags(bool apply_optimizer) {
+  if (!check_nan_) return false;
+  auto* gdp = global_data_pool_.get();
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  Tensor h = nan_flags_.cpu();
+  const int32_t* f = h.data_ptr<int32_t>();
+  if (f[0]) field->mlp_->loss_scale_ = std::max(field->mlp_->loss_scale_ / 2.f, 1.f);
+  if (f[1]) shader->mlp_->loss_scale_ = std::max(shader->mlp_->loss_scale_ / 2.f, 1.f);
+  if (f[2]) {
+    gdp->backward_nan_ = true;
+    if (apply_optimizer) optim_steps_ -= 1;
+    return true;
   }
   return false;
+}
+
+bool ExpRunner::ApplyGradients(bool apply_optimizer) {
+  EnqueueApply(apply_optimizer);
+  return ResolveFlags(apply_optimizer);
 }
 
 // Pipelined data-parallel mode: completes the step whose gradients are still being reduced (awaits the collective,

@@ -23,8 +23,12 @@ class ExpRunner {
   }
   bool ApplyGradients(bool apply_optimizer);
   void FinishPending();  // pipelined data-parallel mode: complete the step whose all-reduce is still in flight
+  // next_*: optionally the NEXT iteration's rays (already resident): their sampling is prefetched on a side stream
   TrainStats TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
-                       const Tensor& emb_idx, bool apply_optimizer = true);
+                       const Tensor& emb_idx, bool apply_optimizer = true, const Tensor& next_rays_o = Tensor(),
+                       const Tensor& next_rays_d = Tensor(), const Tensor& next_bounds = Tensor());
+  void EnqueueApply(bool apply_optimizer);
+  bool ResolveFlags(bool apply_optimizer);
   TrainStats TrainStepAutograd(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                const Tensor& emb_idx, bool apply_optimizer = true);
   float CurVarLossWeight() const;

@@ -199,8 +199,25 @@ void Renderer::ZeroGrad() {
 }
 
 void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  if (has_presample_ && presample_key_ == rays_o.data_ptr()) return;  // already marched (asynchronously) for these rays
   presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   has_presample_ = true;
+  presample_async_ = false;
+  presample_key_ = rays_o.data_ptr();
+}
+
+void Renderer::PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  if (!side_stream_)
+    side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+  octree_ready_ev_.block(*side_stream_);  // the only dependency on this step: its occupancy update / ProcOctree
+  {
+    c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
+    presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);  // (its one read-back only waits for the side stream)
+    presample_done_ev_.record(*side_stream_);
+  }
+  has_presample_ = true;
+  presample_async_ = true;
+  presample_key_ = rays_o.data_ptr();
 }
 
 RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx) {
@@ -208,11 +225,20 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
-  if (has_presample_) {  // PreSample() already marched these rays
+  if (has_presample_ && presample_key_ == rays_o.data_ptr()) {  // PreSample[Async]() already marched these rays
     sample_result_ = std::move(presampled_);
+    if (presample_async_) {  // produced on the side stream: order it before this stream, and tell the allocator
+      auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
+      presample_done_ev_.block(cur);
+      for (Tensor* t : {&sample_result_.pts, &sample_result_.dirs, &sample_result_.dt, &sample_result_.t, &sample_result_.anchors,
+                        &sample_result_.pts_idx_bounds, &sample_result_.first_oct_dis})
+        if (t->defined()) t->record_stream(cur);
+    }
     presampled_ = SampleResultFlex();
     has_presample_ = false;
   } else {
+    presampled_ = SampleResultFlex();  // a presample for other rays is of no use
+    has_presample_ = false;
     sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   }
   int n_all_pts = sample_result_.pts.size(0);
@@ -231,6 +257,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     if (train) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f;
     last_n_kept_pts_ = 0;
     fr.empty = true;
+    octree_ready_ev_.record();
     return fr;
   }
   void* st = CurStream();
@@ -294,6 +321,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     fr.sample_emb_idx = torch::empty({0}, DevI32());  // autograd::Function inputs must be defined tensors
   }
   sample_result_ = SampleResultFlex();  // drop the pre-early-stop buffers
+  octree_ready_ev_.record();            // everything the NEXT step's ray sampling depends on has been issued
   return fr;
 }
 

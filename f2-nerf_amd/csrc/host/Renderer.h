@@ -58,6 +58,9 @@ class Renderer : public Pipe {
   RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
   // issues the ray sampling of the next SampleAndFilter / TrainForwardBackward call ahead of time (same rays!)
   void PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
+  // The same on a SIDE stream that only waits for this step's octree update: the sampler kernels (latency-bound: few
+  // waves, long dependent chains) then run underneath the remaining forward/backward kernels of the current step.
+  void PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
   // forward + ExpRunner::Train's loss + backward into the gradient buffers, without the autograd tape
   TrainOutputs TrainForwardBackward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
@@ -78,7 +81,10 @@ class Renderer : public Pipe {
   Tensor small_grads_flat_;  // when defined: the flat home of the three small gradient buffers (ExpRunner::FlattenSmallGrads)
   BGColorType bg_color_type_ = BGColorType::rand_noise;
   SampleResultFlex sample_result_, presampled_;
-  bool has_presample_ = false;
+  bool has_presample_ = false, presample_async_ = false;
+  const void* presample_key_ = nullptr;  // rays_o.data_ptr() the presample belongs to
+  at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_;
+  std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;
   Tensor forced_bg_;  // explicit background colours for parity tests (undefined = as the reference)
   int n_edge_pts_ = 8192;
   int last_n_all_pts_ = 0, last_n_kept_pts_ = 0;

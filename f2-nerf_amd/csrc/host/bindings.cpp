@@ -58,16 +58,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("load_states", &ExpRunner::LoadStates)
       .def("states", &ExpRunner::States)
       .def("train_step",
-           [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply) {
+           [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply,
+              const std::optional<Tensor>& nro, const std::optional<Tensor>& nrd, const std::optional<Tensor>& nb) {
              TrainStats s;
              {
-               py::gil_scoped_release no_gil;  // the autograd engine must not be entered while holding the GIL
-               s = r.TrainStep(ro, rd, b, gt, emb, apply);
+               py::gil_scoped_release no_gil;  // hooks re-acquire the GIL themselves
+               s = r.TrainStep(ro, rd, b, gt, emb, apply, nro.value_or(Tensor()), nrd.value_or(Tensor()), nb.value_or(Tensor()));
              }
              return StatsToDict(s);
            },
            py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
-           py::arg("apply_optimizer") = true)
+           py::arg("apply_optimizer") = true, py::arg("next_rays_o") = py::none(), py::arg("next_rays_d") = py::none(),
+           py::arg("next_bounds") = py::none())
       .def("train_step_autograd",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply) {
              TrainStats s;

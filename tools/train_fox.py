@@ -34,10 +34,12 @@ def test_psnr():
 
 log = []
 torch.cuda.synchronize(); t0 = time.perf_counter(); n_mean = 0; n_rays = 0; t_last = t0; m_last = 0
+nxt = ds.rand_rays_data(max(16, runner.cur_batch_size()), 1)
 for it in range(args.iters):
-    b = max(16, runner.cur_batch_size())
-    ro, rd, bounds, gt, cam = ds.rand_rays_data(b, 1)
-    s = runner.train_step(ro, rd, bounds, gt, cam, True)
+    ro, rd, bounds, gt, cam = nxt
+    b = ro.shape[0]
+    nxt = ds.rand_rays_data(max(16, runner.cur_batch_size()), 1)  # drawn one iteration ahead: its sampling is prefetched
+    s = runner.train_step(ro, rd, bounds, gt, cam, True, nxt[0], nxt[1], nxt[2])
     n_mean += s["n_meaningful"]; n_rays += b
     if (it + 1) % args.log_every == 0 or it + 1 == args.iters:
         torch.cuda.synchronize(); now = time.perf_counter()
