@@ -394,8 +394,8 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   if (s_total == 0) return;  // block-uniform: nothing landed in this slice
   for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.0;
   __syncthreads();
-  // Four segments at a time, the first 128 records of each with one coalesced 8-byte load per lane: eight independent
-  // loads in flight per lane (the records were written by other XCDs a moment ago -- every read is a fabric round trip).
+  // Segments in batches, the first 128 records of each with one coalesced 8-byte load per lane (the records were written
+  // by other XCDs a moment ago -- every read is a fabric round trip, so as many as possible are kept in flight).
   auto add = [&](uint2 rec) {
     if (rec.y != 0u) {  // a stored record is never (+0, +0); padding is
       const half2_t val = __builtin_bit_cast(half2_t, rec.y);
@@ -403,12 +403,12 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
       atomicAdd(&s_acc[2 * rec.x + 1], (double) val[1]);
     }
   };
-  for (int sg = 0; sg < 64; sg += 4) {
-    uint2 rec[8];
-    int cnt[4];
-    const uint2* r[4];
+  for (int sg = 0; sg < 64; sg += 8) {  // eight segments at a time: up to sixteen independent loads in flight per lane
+    uint2 rec[16];
+    int cnt[8];
+    const uint2* r[8];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < 8; u++) {
       cnt[u] = __shfl(my_cnt, sg + u);
       const unsigned long long sidx = __shfl((unsigned long long) my_seg, sg + u);
       r[u] = q.rec + sidx * q.cap;
@@ -416,9 +416,9 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
       rec[2 * u + 1] = lane + 64 < cnt[u] ? r[u][lane + 64] : uint2{0u, 0u};
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) add(rec[u]);
+    for (int u = 0; u < 16; u++) add(rec[u]);
 #pragma unroll
-    for (int u = 0; u < 4; u++)  // long segments: the rest
+    for (int u = 0; u < 8; u++)  // long segments: the rest
       for (int i = lane + 128; i < cnt[u]; i += 64) add(r[u][i]);
   }
   __syncthreads();
