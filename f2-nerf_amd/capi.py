@@ -281,6 +281,12 @@ def compact_samples_src(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors,
                                       _p(o_anchors, "i32"), _p(o_src, "i32"), _p(o_vol, "i32", True)), "f2n_compact_samples_src")
 
 
+def oct_visible_cams(n_boxes, n_cams, boxes, c2w, bounds, fx, fy, cx, cy, res_h, res_w, pix_i, pix_j, visible):
+    _ck(lib().f2n_oct_visible_cams(_stream(), _i(n_boxes), _i(n_cams), _p(boxes, "f32"), _p(c2w, "f32"), _p(bounds, "f32"), _f(fx),
+                                   _f(fy), _f(cx), _f(cy), _i(res_h), _i(res_w), _p(pix_i, "f32"), _p(pix_j, "f32"),
+                                   _p(visible, "u8")), "f2n_oct_visible_cams")
+
+
 def march_noise(n, u, fineness, out):
     _ck(lib().f2n_march_noise(_stream(), _i(n), _p(u, "f32"), _f(fineness), _p(out, "f32")), "f2n_march_noise")
 

@@ -99,9 +99,35 @@ Hash3DAnchored::Hash3DAnchored(GlobalDataPool* gdp) {  // Hash3DAnchored.cpp:19-
   feat_pool_.requires_grad_(true);
   feat_pool_h_ = torch::zeros({pool_size_, N_CHANNELS}, DevF16());
   grad_h_ = torch::zeros({pool_size_, N_CHANNELS}, DevF16());
-  // primes / biases are part of the serialised state (checkpoint order); placeholders until LoadStates
-  prim_pool_ = torch::ones({N_LEVELS, n_volumes_, 3}, DevI32());
-  bias_pool_ = torch::zeros({N_LEVELS * n_volumes_, 3}, DevF32());
+  // Per-(level, warp) hash primes in [2^28, 2^30) by rejection sampling and random biases in [100, 1100)
+  // (Hash3DAnchored.cpp:40-66); both are part of the serialised state, so LoadStates replaces them on resume.
+  {
+    std::vector<int> small;  // primes up to sqrt(2^30)
+    std::vector<char> sieve(32769, 1);
+    for (int i = 2; i <= 32768; i++) {
+      if (!sieve[i]) continue;
+      small.push_back(i);
+      for (int64_t k = (int64_t) i * i; k <= 32768; k += i) sieve[k] = 0;
+    }
+    const int64_t need = int64_t(3) * N_LEVELS * n_volumes_;
+    std::vector<int> chosen;
+    chosen.reserve(need);
+    while ((int64_t) chosen.size() < need) {
+      Tensor cand = torch::randint(1 << 28, 1 << 30, {std::max<int64_t>(4096, 24 * (need - (int64_t) chosen.size()))}, CpuI32());
+      const int* c = cand.data_ptr<int>();
+      for (int64_t k = 0; k < cand.numel() && (int64_t) chosen.size() < need; k++) {
+        bool prime = true;
+        for (int p : small) {
+          if ((int64_t) p * p > c[k]) break;
+          if (c[k] % p == 0) { prime = false; break; }
+        }
+        if (prime) chosen.push_back(c[k]);
+      }
+    }
+    prim_pool_ = torch::from_blob(chosen.data(), {N_LEVELS, n_volumes_, 3}, CpuI32()).clone().to(torch::kCUDA).contiguous();
+  }
+  if (c.Bool("field.rand_bias")) bias_pool_ = (torch::rand({N_LEVELS * n_volumes_, 3}, DevF32()) * 1000.f + 100.f).contiguous();
+  else bias_pool_ = torch::zeros({N_LEVELS * n_volumes_, 3}, DevF32());
   int local_size = pool_size_ / N_LEVELS;
   local_size = (local_size >> 4) << 4;
   feat_local_size_ = torch::full({N_LEVELS}, local_size, DevI32());

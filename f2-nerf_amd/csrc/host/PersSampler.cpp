@@ -354,6 +354,27 @@ int PersSampler::LoadStates(const std::vector<Tensor>& states, int idx) {
   return idx;
 }
 
+// Installs a freshly constructed octree (BuildPersOctree): what the reference's PersSampler constructor leaves behind
+// (PersSampler.cpp:84-101, :688): nodes, warps, zeroed visit counts, initial occupancy stats, edge pool.
+void PersSampler::InstallOctree(const Tensor& tree_nodes_bytes, const Tensor& pers_trans_bytes, const Tensor& edge_pool_bytes) {
+  auto& oct = *pers_octree_;
+  TORCH_CHECK(tree_nodes_bytes.numel() % sizeof(TreeNode) == 0 && pers_trans_bytes.numel() % sizeof(TransInfo) == 0,
+              "blobs do not match the TreeNode/TransInfo layout");
+  Tensor nodes_cpu = tree_nodes_bytes.to(torch::kCPU).to(torch::kUInt8).contiguous();
+  oct.tree_nodes_.resize(nodes_cpu.numel() / sizeof(TreeNode));
+  std::memcpy((void*) oct.tree_nodes_.data(), nodes_cpu.data_ptr(), nodes_cpu.numel());
+  oct.pers_trans_gpu_ = pers_trans_bytes.clone().to(torch::kCUDA).to(torch::kUInt8).contiguous();
+  const int64_t n = (int64_t) oct.tree_nodes_.size();
+  oct.tree_visit_cnt_ = torch::zeros({n}, DevI32());
+  oct.tree_weight_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());
+  oct.tree_alpha_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());
+  oct.UploadNodes();
+  TORCH_CHECK(global_data_pool_->n_volumes_ == int(oct.pers_trans_gpu_.numel() / sizeof(TransInfo)),
+              "the octree has ", oct.pers_trans_gpu_.numel() / sizeof(TransInfo), " warps but the field was built for ",
+              global_data_pool_->n_volumes_, " (runtime.n_volumes)");
+  SetEdgePool(edge_pool_bytes);
+}
+
 void PersSampler::SetEdgePool(const Tensor& edge_pool_bytes) {
   TORCH_CHECK(edge_pool_bytes.numel() % sizeof(EdgePool) == 0, "edge pool blob does not match the EdgePool layout");
   pers_octree_->edge_pool_gpu_ = edge_pool_bytes.clone().to(torch::kCUDA).to(torch::kUInt8).contiguous();

@@ -31,6 +31,17 @@ struct alignas(32) EdgePool {    // 64 B
 };
 static_assert(sizeof(TransInfo) == 544 && sizeof(TreeNode) == 64 && sizeof(EdgePool) == 64, "checkpoint layout");
 
+// Construction from the training cameras (OctreeBuilder.cpp)
+struct OctreeBuildResult {
+  std::vector<TreeNode> nodes;
+  std::vector<TransInfo> trans;
+  std::vector<EdgePool> edges;
+};
+TransInfo ConstructTrans(const Tensor& rand_pts, const Tensor& c2w_vis, const Tensor& intri0, const Tensor& center, int first_cam);
+std::vector<EdgePool> ConstructEdgePool(const std::vector<TreeNode>& nodes);
+OctreeBuildResult BuildPersOctree(const Tensor& c2w, const Tensor& intri, const Tensor& bounds, int max_depth, float bbox_side_len,
+                                  float split_dist_thres, int n_rand_pts = 32 * 32 * 32);
+
 class PersOctree {
  public:
   void ProcOctree(bool compact, bool subdivide, bool brute_force);
@@ -60,6 +71,7 @@ class PersSampler : public PtsSampler {
   int LoadStates(const std::vector<Tensor>& states, int idx) override;
 
   // Not part of the reference checkpoint (LoadStates there keeps the constructor's edge pool / cameras).
+  void InstallOctree(const Tensor& tree_nodes_bytes, const Tensor& pers_trans_bytes, const Tensor& edge_pool_bytes);
   void SetEdgePool(const Tensor& edge_pool_bytes);
   void SetTrainCameras(const Tensor& w2c, const Tensor& intri, const Tensor& bounds);
 

@@ -32,6 +32,40 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     const auto& r = std::get<0>(t);
     return std::vector<Tensor>{r.origins, r.dirs, r.bounds, std::get<1>(t), std::get<2>(t)};  // + gt colours, image index
   };
+  // octree / warp construction from cameras: byte blobs in the reference's checkpoint layout
+  m.def("build_octree",
+        [](const Tensor& c2w, const Tensor& intri, const Tensor& bounds, int max_depth, float bbox_side_len, float split_dist_thres,
+           int n_rand_pts) {
+          OctreeBuildResult r = BuildPersOctree(c2w, intri, bounds, max_depth, bbox_side_len, split_dist_thres, n_rand_pts);
+          auto blob = [](const void* p, size_t bytes) {
+            Tensor t = torch::empty({(int64_t) bytes}, CpuU8());
+            if (bytes) std::memcpy(t.data_ptr(), p, bytes);
+            return t;
+          };
+          py::dict d;
+          d["tree_nodes"] = blob(r.nodes.data(), r.nodes.size() * sizeof(TreeNode));
+          d["pers_trans"] = blob(r.trans.data(), r.trans.size() * sizeof(TransInfo));
+          d["edge_pool"] = blob(r.edges.data(), r.edges.size() * sizeof(EdgePool));
+          d["n_volumes"] = (int) r.trans.size();
+          return d;
+        },
+        py::arg("c2w"), py::arg("intri"), py::arg("bounds"), py::arg("max_depth"), py::arg("bbox_side_len"),
+        py::arg("split_dist_thres"), py::arg("n_rand_pts") = 32 * 32 * 32);
+  m.def("construct_trans", [](const Tensor& rand_pts, const Tensor& c2w_vis, const Tensor& intri0, const Tensor& center, int first_cam) {
+    TransInfo t = ConstructTrans(rand_pts, c2w_vis, intri0, center, first_cam);
+    Tensor out = torch::empty({(int64_t) sizeof(TransInfo)}, CpuU8());
+    std::memcpy(out.data_ptr(), &t, sizeof(TransInfo));
+    return out;
+  });
+  m.def("construct_edge_pool", [](const Tensor& tree_nodes_bytes) {
+    Tensor b = tree_nodes_bytes.to(torch::kCPU).contiguous();
+    std::vector<TreeNode> nodes(b.numel() / sizeof(TreeNode));
+    std::memcpy((void*) nodes.data(), b.data_ptr(), nodes.size() * sizeof(TreeNode));
+    auto e = ConstructEdgePool(nodes);
+    Tensor out = torch::empty({(int64_t) (e.size() * sizeof(EdgePool))}, CpuU8());
+    if (!e.empty()) std::memcpy(out.data_ptr(), e.data(), e.size() * sizeof(EdgePool));
+    return out;
+  });
   py::class_<Dataset>(m, "Dataset")
       .def(py::init<const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, int, int, const std::vector<int>&,
                     const std::vector<int>&, const std::vector<int>&>(),
@@ -149,6 +183,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     for (auto& kv : KernelTimers::Get().Collect()) d[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
                     return d;
                   })
+      .def("install_octree", [](ExpRunner& r, const Tensor& n, const Tensor& t, const Tensor& e) { SamplerOf(r)->InstallOctree(n, t, e); })
       .def("set_edge_pool",[](ExpRunner& r, const Tensor& e) { SamplerOf(r)->SetEdgePool(e); })
       .def("set_train_cameras", [](ExpRunner& r, const Tensor& w2c, const Tensor& intri, const Tensor& b) { SamplerOf(r)->SetTrainCameras(w2c, intri, b); })
       .def("set_forced_randoms",

@@ -747,12 +747,67 @@ __global__ void mark_invisible_kernel(int n_nodes, int n_cams, F2nTreeNode* __re
 // ---------------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------------
+// GetVisiCams (PersSampler.cpp:27-66) for a whole frontier of candidate boxes at once: block (box, camera) casts the
+// camera's pixel-grid ray bundle (res_h x res_w, pixel centres given as arrays) at the box -- slab test clipped to the
+// camera's [near, far] -- and reports whether ANY ray hits.  The reference evaluates this with broadcast ATen ops, one
+// node at a time, inside its recursive constructor; here the octree is built level by level, so one launch serves every
+// node of a depth.
+__global__ __launch_bounds__(256) void visible_cams_kernel(int n_cams, const float* __restrict__ boxes,
+                                                           const float* __restrict__ c2w, const float* __restrict__ bounds,
+                                                           float fx, float fy, float cx, float cy, int res_h, int res_w,
+                                                           const float* __restrict__ pix_i, const float* __restrict__ pix_j,
+                                                           uint8_t* __restrict__ visible) {
+  __shared__ int s_hit;
+  const int box = blockIdx.x, cam = blockIdx.y;
+  if (threadIdx.x == 0) s_hit = 0;
+  __syncthreads();
+  const float* P = c2w + 12 * (size_t) cam;
+  const float o[3] = {P[3], P[7], P[11]};
+  const float bc[3] = {boxes[4 * box], boxes[4 * box + 1], boxes[4 * box + 2]};
+  const float half = boxes[4 * box + 3] * .5f;
+  const float lo[3] = {bc[0] - half, bc[1] - half, bc[2] - half}, hi[3] = {bc[0] + half, bc[1] + half, bc[2] + half};
+  const float b_near = bounds[2 * cam], b_far = bounds[2 * cam + 1];
+  bool hit = false;
+  for (int p = threadIdx.x; p < res_h * res_w && !hit; p += 256) {
+    const float i = pix_i[p / res_w], j = pix_j[p % res_w];
+    const float dc[3] = {(j - cx) / fx, -(i - cy) / fy, -1.f};
+    float near_ = -3.4e38f, far_ = 3.4e38f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float d = (P[4 * a] * dc[0] + P[4 * a + 1] * dc[1]) + P[4 * a + 2] * dc[2];
+      float ta = (lo[a] - o[a]) / d, tb = (hi[a] - o[a]) / d;
+      // torch::nan_to_num(x, 0, 1e6, -1e6)
+      ta = ta != ta ? 0.f : (ta > 3.4e38f ? 1e6f : (ta < -3.4e38f ? -1e6f : ta));
+      tb = tb != tb ? 0.f : (tb > 3.4e38f ? 1e6f : (tb < -3.4e38f ? -1e6f : tb));
+      far_ = fminf(far_, fmaxf(ta, tb));
+      near_ = fmaxf(near_, fminf(ta, tb));
+    }
+    far_ = fminf(far_, b_far);
+    near_ = fmaxf(near_, b_near);
+    hit = far_ > near_;
+  }
+  if (hit) s_hit = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) visible[(size_t) box * n_cams + cam] = (uint8_t) s_hit;
+}
+
 __global__ void march_noise_kernel(int n, const float* __restrict__ u, float fineness, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = ((u[i] - .5f) + 1.f) * fineness;
 }
 
 extern "C" {
+
+int f2n_oct_visible_cams(void* stream, int n_boxes, int n_cams, const float* boxes, const float* c2w, const float* bounds, float fx,
+                         float fy, float cx, float cy, int res_h, int res_w, const float* pix_i, const float* pix_j,
+                         uint8_t* visible) {
+  if (n_boxes < 0 || n_cams < 0 || res_h <= 0 || res_w <= 0) return F2N_ERR_INVALID_ARG;
+  if (n_boxes == 0 || n_cams == 0) return F2N_OK;
+  if (n_cams > 65535) return F2N_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(visible_cams_kernel, dim3(n_boxes, n_cams), dim3(256), 0, (hipStream_t) stream, n_cams, boxes, c2w, bounds, fx, fy,
+                     cx, cy, res_h, res_w, pix_i, pix_j, visible);
+  return f2n_launch_status();
+}
 
 int f2n_march_noise(void* stream, int n, const float* u, float fineness, float* out) {
   if (n < 0) return F2N_ERR_INVALID_ARG;

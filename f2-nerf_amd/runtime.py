@@ -80,6 +80,28 @@ def make_runner(state, preset="wanjinyou", overrides=None, seed=2022, table_init
     return runner, cfg, arrays
 
 
+def make_runner_from_cameras(poses, intri, bounds, train_set, preset="wanjinyou", overrides=None, device="cuda:0"):
+    """A fresh ExpRunner for a NEW scene: octree, perspective warps and edge pool are constructed from the training
+    cameras on the device (host().build_octree), table / primes / biases / MLPs are initialised as the
+    reference's constructors do.  poses [C,3,4] normalised c2w, intri [C,3,3], bounds [C,2] (already relaxed)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device: the hot path has no CPU implementation")
+    torch.cuda.set_device(device)
+    cfg = config.preset(preset, overrides)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32))
+    ts = np.asarray(train_set)
+    ps = cfg["pts_sampler"]
+    built = host().build_octree(t(poses[ts]), t(intri[ts]), t(bounds[ts]), int(ps["max_level"]),
+                                float(1 << (int(ps["bbox_levels"]) - 1)), float(ps["split_dist_thres"]))
+    flat = config.flatten(cfg)
+    flat["runtime.n_volumes"] = str(int(built["n_volumes"]))
+    runner = host().ExpRunner(flat, len(poses))
+    runner.install_octree(built["tree_nodes"], built["pers_trans"], built["edge_pool"])
+    w2c = np.linalg.inv(np.concatenate([poses, np.tile(np.array([[[0, 0, 0, 1]]], np.float32), (len(poses), 1, 1))], 1))[:, :3]
+    runner.set_train_cameras(t(w2c[ts]), t(intri[ts]), t(bounds[ts]))
+    return runner, cfg, built
+
+
 def make_dataset(state, images=None):
     """Device-resident ray source (host C++ `Dataset`) for the serialised scene; `images` fp32 [C,H,W,3] or None."""
     H, W = [int(v) for v in state["image_hw"]]

@@ -86,6 +86,14 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
  * host-side change of the tree; f2n_oct_update_stats keeps the trans_idx copies current when given the pointer. */
 int f2n_oct_build_child_blocks(void* stream, int n_nodes, const void* tree_nodes, void* child_blocks);
 
+/* GetVisiCams (PtsSampler/PersSampler.cpp:27-66) for n_boxes candidate octree nodes at once:
+ * visible[b, c] = 1 iff any ray of camera c's res_h x res_w pixel-grid bundle (pixel centres pix_i [res_h] rows,
+ * pix_j [res_w] columns; direction ((j-cx)/fx, -(i-cy)/fy, -1) rotated by c2w[c]) hits box b = (centre xyz, side)
+ * within the camera's [near, far] bounds.  boxes [n_boxes,4], c2w [n_cams,3,4], bounds [n_cams,2]. */
+int f2n_oct_visible_cams(void* stream, int n_boxes, int n_cams, const float* boxes, const float* c2w,
+                         const float* bounds, float fx, float fy, float cx, float cy, int res_h, int res_w,
+                         const float* pix_i, const float* pix_j, uint8_t* visible /*[n_boxes,n_cams]*/);
+
 /* The march noise of PersSampler.cu:372-381 from uniform draws u in [0,1): out = ((u - 0.5) + 1) * fineness, in that
  * fp32 order (the reference: three ATen launches). */
 int f2n_march_noise(void* stream, int n, const float* u, float fineness, float* out);

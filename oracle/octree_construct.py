@@ -133,7 +133,7 @@ def _angle_axis(angle, axis):
                      [C * x * z - s * y, C * y * z + s * x, c + C * z * z]], np.float32)
 
 
-def construct_trans(rand_pts, c2w, intri, center, gen):
+def construct_trans(rand_pts, c2w, intri, center, gen, first_cam=None):
     n_virt = N_PROS // 2
     n_cur = c2w.shape[0]
     cam_pos = c2w[:, :3, 3].contiguous()
@@ -143,7 +143,7 @@ def construct_trans(rand_pts, c2w, intri, center, gen):
     normed = (cam_pos - center[None]) / dis[:, None]
     dis_pairs = torch.linalg.norm(normed[None] - normed[:, None], 2, -1).numpy()
     # greedy farthest-point selection of 6 spread cameras, :461-488
-    good = [int(torch.randint(n_cur, (1,), generator=gen).item())]
+    good = [int(torch.randint(n_cur, (1,), generator=gen).item()) if first_cam is None else int(first_cam)]
     marks = np.zeros(n_cur, bool)
     marks[good[0]] = True
     for _ in range(1, min(n_virt, n_cur)):
