@@ -580,7 +580,7 @@ __global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; r++) dyf[r] = (half_t) ((float) (half_t) d4[r] * loss_scale);  // f16 cast by autograd, then *scale (TCNNWP.cpp:174)
       }
-      f2n_mlp_half_bwd<NH, 2>(sm.w, xf, dyf, idf, c, g, hb[half]);
+      f2n_mlp_half_bwd<NH, 2>(sm.w, xf, [&](half8_t, half8_t) { return dyf; }, idf, c, g, hb[half]);
       if (valid) {
         if (dx_f32 != nullptr) {
 #pragma unroll

@@ -205,9 +205,12 @@ struct F2nHalfBwd {
   half4_t g0R[NH == 2 ? 4 : 1];     // G_0     (NH == 2 only)
 };
 
-// xf: X row fragment; dyf: dY row fragment (K = output index, slots >= 16 are zero), already loss-scaled f16.
-template <int NH, int N_DX_TILES>
-__device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t xf, half8_t dyf, const half8_t* idf /*[2]*/,
+// xf: X row fragment.  dy_fn(hl0, hl1) returns the dY row fragment (K = output index, slots >= 16 zero, already
+// loss-scaled f16) given the post-ReLU activations of the last hidden layer as row fragments -- a caller whose dY
+// depends on the network output (the colour path: sigmoid derivative) computes it from them instead of running the
+// forward chain a second time; a caller with a given dY ignores the arguments.
+template <int NH, int N_DX_TILES, typename DyFn>
+__device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t xf, DyFn dy_fn, const half8_t* idf /*[2]*/,
                                                  int c, int g, F2nHalfBwd<NH>& out) {
   const float4_t z = {0.f, 0.f, 0.f, 0.f};
   // ---- sample-column orientation: recompute pre-activations, then the hidden-gradient chain ----
@@ -222,6 +225,7 @@ __device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t
       t1[t] = f2n_mfma(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 32, g), h0f[1], t1[t]);
     }
   }
+  const half8_t dyf = NH == 2 ? dy_fn(f2n_pack<true>(t1[0], t1[1]), f2n_pack<true>(t1[2], t1[3])) : dy_fn(h0f[0], h0f[1]);
   float4_t gl[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) {

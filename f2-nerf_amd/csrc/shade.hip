@@ -140,31 +140,24 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
       const int s = sb * 32 + half * 16 + c;
       const bool valid = s < n;
       const half8_t xf = f2n_load_xfrag(x_h, valid ? s : n - 1, g, valid);
-      // recompute the network output o (sample-column orientation) for d(rgb)/d(o)
-      float4_t t[4];
+      // d(rgb)/d(o) needs the network output o: computed inside the backward's own forward recomputation from the
+      // last hidden layer's activations (no second forward chain)
+      auto dy_fn = [&](half8_t h0, half8_t h1) {
+        float4_t o = f2n_mfma(wo[0], h0, z);
+        o = f2n_mfma(wo[1], h1, o);
+        half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid && g == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) t[i] = f2n_mfma(f2n_rowfrag(sm.w.w0, F2N_LD32, 16 * i + c, 0, g), xf, z);
-      half8_t h0 = f2n_pack<true>(t[0], t[1]), h1 = f2n_pack<true>(t[2], t[3]);
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        t[i] = f2n_mfma(f2n_rowfrag(sm.w.w1, F2N_LD64, 16 * i + c, 0, g), h0, z);
-        t[i] = f2n_mfma(f2n_rowfrag(sm.w.w1, F2N_LD64, 16 * i + c, 32, g), h1, t[i]);
-      }
-      h0 = f2n_pack<true>(t[0], t[1]);
-      h1 = f2n_pack<true>(t[2], t[3]);
-      float4_t o = f2n_mfma(wo[0], h0, z);
-      o = f2n_mfma(wo[1], h1, o);
-      half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (valid && g == 0) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          const float ov = (float) (half_t) o[r];
-          const float e = expf(-ov);
-          const float dsig = (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
-          dyf[r] = (half_t) ((float) (half_t) (drgb[3 * (size_t) s + r] * dsig) * loss_scale);
+          for (int r = 0; r < 3; r++) {
+            const float ov = (float) (half_t) o[r];
+            const float e = expf(-ov);
+            const float dsig = (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
+            dyf[r] = (half_t) ((float) (half_t) (drgb[3 * (size_t) s + r] * dsig) * loss_scale);
+          }
         }
-      }
-      f2n_mlp_half_bwd<2, 1>(sm.w, xf, dyf, idf, c, g, hb[half]);
+        return dyf;
+      };
+      f2n_mlp_half_bwd<2, 1>(sm.w, xf, dy_fn, idf, c, g, hb[half]);
       // d(shading_feat) = dX[:, 0:16]: lane (c = sample, g) holds features 4g..4g+3
       float4_t dsf;
 #pragma unroll
