@@ -225,7 +225,12 @@ __device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t
       t1[t] = f2n_mfma(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 32, g), h0f[1], t1[t]);
     }
   }
-  const half8_t dyf = NH == 2 ? dy_fn(f2n_pack<true>(t1[0], t1[1]), f2n_pack<true>(t1[2], t1[3])) : dy_fn(h0f[0], h0f[1]);
+  half8_t hlf[2] = {h0f[0], h0f[1]};  // post-ReLU activations of the LAST hidden layer, as row fragments
+  if (NH == 2) {
+    hlf[0] = f2n_pack<true>(t1[0], t1[1]);
+    hlf[1] = f2n_pack<true>(t1[2], t1[3]);
+  }
+  const half8_t dyf = dy_fn(hlf[0], hlf[1]);
   float4_t gl[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
@@ -250,31 +255,16 @@ __device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t
     out.dxT[ft] = f2n_mfma(f2n_rowfrag(s.w0t, F2N_LD64, 16 * ft + c, 0, g), gff[0], z);
     out.dxT[ft] = f2n_mfma(f2n_rowfrag(s.w0t, F2N_LD64, 16 * ft + c, 32, g), gff[1], out.dxT[ft]);
   }
-  // ---- sample-row orientation: the same quantities with samples in the register index ----
-  float4_t t0r[4], t1r[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) t0r[t] = f2n_mfma(xf, f2n_rowfrag(s.w0, F2N_LD32, 16 * t + c, 0, g), z);
-  if (NH == 2) {
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      t1r[t] = f2n_mfma(h0f[0], f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 0, g), z);
-      t1r[t] = f2n_mfma(h0f[1], f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 32, g), t1r[t]);
-    }
-  }
+  // ---- sample-row orientation: the SAME f16 quantities with samples in the register index, obtained by re-orienting the
+  // packed fragments with one identity MFMA per 16-neuron tile (exact for f16 data) -- not by recomputing the chain with
+  // swapped operands, which cost 24 weight-fragment LDS reads and 24 MFMAs per 16 samples instead of 16 MFMAs and none ----
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const float4_t pre = NH == 2 ? t1r[t] : t0r[t];
-    float4_t gr = f2n_mfma(dyf, f2n_rowfrag(s.wot, F2N_LD32, 16 * t + c, 0, g), z);
-    out.glR[t] = f2n_cvt4<false>(f2n_relu_mask(gr, pre));
-    out.hlR[t] = f2n_cvt4<true>(pre);
-  }
-  if (NH == 2) {
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      float4_t gr = f2n_mfma(glf[0], f2n_rowfrag(s.w1t, F2N_LD64, 16 * t + c, 0, g), z);
-      gr = f2n_mfma(glf[1], f2n_rowfrag(s.w1t, F2N_LD64, 16 * t + c, 32, g), gr);
-      out.g0R[t] = f2n_cvt4<false>(f2n_relu_mask(gr, t0r[t]));
-      out.h0R[t] = f2n_cvt4<true>(t0r[t]);
+    out.hlR[t] = f2n_cvt4<false>(f2n_mfma(hlf[t >> 1], idf[t & 1], z));
+    out.glR[t] = f2n_cvt4<false>(f2n_mfma(glf[t >> 1], idf[t & 1], z));
+    if (NH == 2) {
+      out.h0R[t] = f2n_cvt4<false>(f2n_mfma(h0f[t >> 1], idf[t & 1], z));
+      out.g0R[t] = f2n_cvt4<false>(f2n_mfma(gff[t >> 1], idf[t & 1], z));
     }
   }
   out.dyR = f2n_cvt4<false>(f2n_mfma(dyf, idf[0], z));
