@@ -546,7 +546,7 @@ union F2nBwdSmem {
 };
 
 template <int NH, bool DO_HASH>
-__global__ __launch_bounds__(F2N_BWD_THREADS) void field_bwd_kernel(
+__global__ __launch_bounds__(F2N_BWD_THREADS, (NH == 1 ? 2 : 1)) void field_bwd_kernel(
     int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
     const int32_t* __restrict__ volume_idx, int vol_stride, const half_t* __restrict__ params,
@@ -683,9 +683,9 @@ static inline unsigned f2n_wave_grid(int n_units, int waves_per_block) {
 
 // Backward kernels hold their weight-gradient accumulators in registers (1 wave per SIMD, 1 block per CU) and pay
 // one LDS + global-atomic flush of all parameters per BLOCK: exactly one resident block per CU minimises that.
-static inline unsigned f2n_bwd_grid(int n_super) {
+static inline unsigned f2n_bwd_grid(int n_super, int blocks_per_cu = 1) {
   long blocks = ((long) n_super + 3) / 4;
-  if (blocks > 256) blocks = 256;
+  if (blocks > 256 * blocks_per_cu) blocks = 256 * blocks_per_cu;
   if (blocks < 1) blocks = 1;
   return (unsigned) blocks;
 }
@@ -794,7 +794,7 @@ int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float
   if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
-  const dim3 grid(f2n_bwd_grid((n + 31) / 32)), block(F2N_BWD_THREADS);
+  const dim3 grid(f2n_bwd_grid((n + 31) / 32, n_hidden == 1 ? 2 : 1)), block(F2N_BWD_THREADS);
   const int n_params = f2n_mlp_n_params(d_in, d_hidden, n_hidden);
   float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) grid.x * n_params);
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
@@ -876,7 +876,7 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
   if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f) || level_entries < 0) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
-  const unsigned blocks = f2n_bwd_grid((n + 31) / 32);
+  const unsigned blocks = f2n_bwd_grid((n + 31) / 32, 2);  // the NH = 1 kernel fits two blocks per CU (256 registers)
   const int n_params = f2n_mlp_n_params(F2N_D_IN, F2N_D_HID, 1);
   float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) blocks * n_params);
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
