@@ -247,7 +247,7 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 #define F2N_BIN_SHIFT 12
 #define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
 #define F2N_BIN_NB 128        // sample chunks (producer blocks) per level
-#define F2N_BIN_MAX_BINS 512  // tables up to 2^21 entries per level
+#define F2N_BIN_MAX_BINS 1024  // tables up to 2^22 entries per level (BASELINE config 5)
 #define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
 struct F2nBinQueues {
