@@ -336,4 +336,33 @@ float ExpRunner::TestImagePSNR(Dataset& dataset, int idx) {
   return 20.f * std::log10(1.f / std::sqrt(mse));
 }
 
+// The loop of ExpRunner::Train (ExpRunner.cpp:82-143) without its reporting / checkpoint branches: adaptive ray batch
+// (pts_batch_size / meaningful samples per ray, :86), Dataset::RandRaysData on the device, one fused TrainStep per
+// iteration with the NEXT batch drawn one iteration ahead so that its ray sampling is prefetched.  Runs until
+// iter_step_ reaches `until_iter` (or end_iter_); returns the iterations executed (skipped NaN iterations included).
+int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
+  const int target = until_iter > 0 ? std::min(until_iter, end_iter_) : end_iter_;
+  int executed = 0;
+  auto draw = [&]() { return dataset.RandRaysData(std::max(16, CurBatchSize()), sets); };
+  auto next = draw();
+  last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;
+  while (iter_step_ < target) {
+    auto cur = std::move(next);
+    next = draw();
+    const BoundedRays& r = std::get<0>(cur);
+    const BoundedRays& nr = std::get<0>(next);
+    Tensor gt = std::get<1>(cur);
+    TORCH_CHECK(gt.defined(), "Train needs resident ground-truth images in the Dataset");
+    TrainStats s = TrainStep(r.origins, r.dirs, r.bounds, gt, std::get<2>(cur), true, nr.origins, nr.dirs, nr.bounds);
+    last_train_meaningful_ += s.n_meaningful;
+    last_train_marched_ += s.n_samples;
+    last_train_rays_ += s.n_rays;
+    last_train_stats_ = s;
+    executed++;
+    if (executed > 4 * (target + 16)) break;  // every iteration non-finite: give up instead of spinning
+  }
+  FinishPending();
+  return executed;
+}
+
 }  // namespace f2n

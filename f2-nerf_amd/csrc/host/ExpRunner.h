@@ -35,6 +35,9 @@ class ExpRunner {
   std::vector<Tensor> RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   std::vector<Tensor> RenderWholeImage(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   float TestImagePSNR(Dataset& dataset, int idx);
+  int Train(Dataset& dataset, int until_iter = -1, int sets = DATA_TRAIN_SET);
+  int64_t last_train_meaningful_ = 0, last_train_marched_ = 0, last_train_rays_ = 0;  // totals of the last Train call
+  TrainStats last_train_stats_;
   void UpdateAdaParams();
   void OptimStep(const int32_t* skip_flag = nullptr);  // skip_flag: device int, != 0 drops the update
   void BuildOptimizer();

@@ -118,6 +118,21 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("render_rays", &ExpRunner::RenderRays)
       .def("render_whole_image", &ExpRunner::RenderWholeImage)
       .def("test_image_psnr", &ExpRunner::TestImagePSNR)
+      .def("train",
+           [](ExpRunner& r, Dataset& ds, int until_iter, int sets) {
+             int n;
+             {
+               py::gil_scoped_release no_gil;
+               n = r.Train(ds, until_iter, sets);
+             }
+             py::dict d = StatsToDict(r.last_train_stats_);
+             d["iterations"] = n;
+             d["total_meaningful"] = r.last_train_meaningful_;
+             d["total_marched"] = r.last_train_marched_;
+             d["total_rays"] = r.last_train_rays_;
+             return d;
+           },
+           py::arg("dataset"), py::arg("until_iter") = -1, py::arg("sets") = DATA_TRAIN_SET)
       .def("render_train",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& emb) {
              r.global_data_pool_->mode_ = RunningMode::TRAIN;

@@ -33,22 +33,20 @@ def test_psnr():
     return float(np.mean([runner.test_image_psnr(ds, i) for i in test_set]))
 
 log = []
-torch.cuda.synchronize(); t0 = time.perf_counter(); n_mean = 0; n_rays = 0; t_last = t0; m_last = 0
-nxt = ds.rand_rays_data(max(16, runner.cur_batch_size()), 1)
-for it in range(args.iters):
-    ro, rd, bounds, gt, cam = nxt
-    b = ro.shape[0]
-    nxt = ds.rand_rays_data(max(16, runner.cur_batch_size()), 1)  # drawn one iteration ahead: its sampling is prefetched
-    s = runner.train_step(ro, rd, bounds, gt, cam, True, nxt[0], nxt[1], nxt[2])
-    n_mean += s["n_meaningful"]; n_rays += b
-    if (it + 1) % args.log_every == 0 or it + 1 == args.iters:
-        torch.cuda.synchronize(); now = time.perf_counter()
-        mse = float(s["mse"])
-        rec = {"iter": it + 1, "train_psnr_batch": round(10 * np.log10(1 / max(mse, 1e-12)), 2), "rays_per_batch": b,
-               "meaningful_per_ray": round(runner.meaningful_per_ray, 1), "n_nodes": runner.n_nodes(),
-               "samples_per_s_window": round((n_mean - m_last) / (now - t_last)), "elapsed_s": round(now - t0, 1)}
-        log.append(rec); print(json.dumps(rec), flush=True)
-        t_last, m_last = now, n_mean
+torch.cuda.synchronize(); t0 = time.perf_counter(); n_mean = 0; n_rays = 0; t_last = t0
+it = 0
+while it < args.iters:  # ExpRunner::Train in windows (the C++ loop draws rays on the device and prefetches their sampling)
+    target = min(args.iters, it + args.log_every)
+    s = runner.train(ds, target, 1)
+    it = runner.iter_step
+    torch.cuda.synchronize(); now = time.perf_counter()
+    n_mean += s["total_meaningful"]; n_rays += s["total_rays"]
+    mse = float(s["mse"])
+    rec = {"iter": it, "train_psnr_batch": round(10 * np.log10(1 / max(mse, 1e-12)), 2), "rays_per_batch": s["n_rays"],
+           "meaningful_per_ray": round(runner.meaningful_per_ray, 1), "n_nodes": runner.n_nodes(),
+           "samples_per_s_window": round(s["total_meaningful"] / (now - t_last)), "elapsed_s": round(now - t0, 1)}
+    log.append(rec); print(json.dumps(rec), flush=True)
+    t_last = now
 torch.cuda.synchronize(); wall = time.perf_counter() - t0
 print(json.dumps({"iters": args.iters, "train_wall_s": round(wall, 1), "ray_samples_per_s": round(n_mean / wall),
                   "rays_per_s": round(n_rays / wall), "test_psnr": round(test_psnr(), 3), "test_views": test_set,
