@@ -76,14 +76,32 @@ __device__ __forceinline__ void f2n_hash_cell(const float* p01, float mul, const
 // f16 "planes" [8][n][4] (8 B per sample and level pair, coalesced), from which the MLP kernel's lane (c,g) reads
 // exactly its K-slots: plane g (features 4g..4g+3) and plane 4+g (features 16+4g..).
 #define F2N_N_PARTS 8
+// STAGED: the per-(level, transform) hash constants of the block's two levels (prim_pool / bias_pool rows, 24 B each)
+// are copied into LDS once per block: 12 of the 32 vector-memory instructions a sample issues were those -- broadcast
+// loads that cost no bandwidth but a texture-address issue slot each, the resource this kernel is bound by.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void hash_gather_planes_kernel(
     int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
     const int32_t* __restrict__ volume_idx, int vol_stride, half_t* __restrict__ planes) {
   __shared__ F2nLevelTab lt;
-  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, threadIdx.x);
-  __syncthreads();
+  extern __shared__ uint32_t pb_lds[];  // STAGED: [2 levels][V][prim xyz, bias xyz]
   const int part = blockIdx.x % F2N_N_PARTS;
+  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, threadIdx.x);
+  // Levels {2 part, 2 part + 1}: the block's two feature pairs are one 8-byte plane element.  (Pairing a coarse with a
+  // fine level per XCD, {part, 15 - part}, to even out L1 hit rates was measured 8 % SLOWER: the split 4-byte stores
+  // cost more than the balance gains.)
+  const int lv[2] = {2 * part, 2 * part + 1};
+  if (STAGED) {
+    for (int i = threadIdx.x; i < 2 * 3 * h.n_volumes; i += 256) {
+      const int j = i >= 3 * h.n_volumes, i1 = i - j * 3 * h.n_volumes;
+      const int r = i1 / 3, k = i1 - 3 * r;
+      const size_t src = 3 * (size_t) lv[j] * h.n_volumes + i1;
+      pb_lds[6 * (j * h.n_volumes + r) + k] = (uint32_t) h.prim_pool[src];
+      pb_lds[6 * (j * h.n_volumes + r) + 3 + k] = __float_as_uint(h.bias_pool[src]);
+    }
+  }
+  __syncthreads();
   const int q = blockIdx.x / F2N_N_PARTS, nq = gridDim.x / F2N_N_PARTS;
   for (int s = q * 256 + (int) threadIdx.x; s < n; s += nq * 256) {
     float p01[3];
@@ -97,9 +115,16 @@ __global__ __launch_bounds__(256) void hash_gather_planes_kernel(
     half2_t v[2][8];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      const int l = 2 * part + j;
-      const int tf = l * h.n_volumes + vol;
-      f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell[j]);
+      const int l = lv[j];
+      if (STAGED) {
+        const uint32_t* row = pb_lds + 6 * (j * h.n_volumes + vol);
+        const int32_t prim3[3] = {(int32_t) row[0], (int32_t) row[1], (int32_t) row[2]};
+        const float bias3[3] = {__uint_as_float(row[3]), __uint_as_float(row[4]), __uint_as_float(row[5])};
+        f2n_hash_cell(p01, lt.scale[l], prim3, bias3, lt.size[l], cell[j]);
+      } else {
+        const int tf = l * h.n_volumes + vol;
+        f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell[j]);
+      }
       const half2_t* base = (const half2_t*) (h.table + lt.base[l]);
 #pragma unroll
       for (int d = 0; d < 8; d++) v[j][d] = base[cell[j].pos[d]];
@@ -566,20 +591,42 @@ __global__ __launch_bounds__(F2N_BWD_THREADS, (NH == 1 ? 2 : 1)) void field_bwd_
   const int wave_global = blockIdx.x * (F2N_BWD_THREADS / 64) + (tid >> 6);
   const int wave_stride = gridDim.x * (F2N_BWD_THREADS / 64);
   const float inv_scale = 1.f / loss_scale;
+  // Inputs are fetched one super-block ahead into registers (see shade_bwd_kernel: with one or two waves per SIMD a load
+  // issued at its point of use exposes its whole latency).
+  struct In {
+    half8_t xf;
+    float4_t d4;
+  };
+  auto fetch = [&](int sb, int half, In& o) {
+    const int s = sb * 32 + half * 16 + c;
+    const int sc = s < n ? s : n - 1;
+    o.xf = (x_h != nullptr) ? f2n_load_xfrag_h(x_h, sc, g, true) : f2n_load_xfrag_f32(x_f32, sc, g, true);
+    o.d4 = *(const float4_t*) (dy + (size_t) sc * F2N_D_OUT + 4 * g);
+  };
+  In cur[2];
+  if (wave_global < n_super) {
+    fetch(wave_global, 0, cur[0]);
+    fetch(wave_global, 1, cur[1]);
+  }
   for (int sb = wave_global; sb < n_super; sb += wave_stride) {
+    In nxt[2];
+    {
+      const int sbn = sb + wave_stride < n_super ? sb + wave_stride : sb;  // last round: a harmless re-read
+      fetch(sbn, 0, nxt[0]);
+      fetch(sbn, 1, nxt[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     F2nHalfBwd<NH> hb[2];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int s = sb * 32 + half * 16 + c;
       const bool valid = s < n;
       const int sc = valid ? s : n - 1;
-      const half8_t xf = (x_h != nullptr) ? f2n_load_xfrag_h(x_h, sc, g, valid) : f2n_load_xfrag_f32(x_f32, sc, g, valid);
+      const half8_t xf = valid ? cur[half].xf : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
       half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (valid) {
-        const float4_t d4 = *(const float4_t*) (dy + (size_t) s * F2N_D_OUT + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; r++) dyf[r] = (half_t) ((float) (half_t) d4[r] * loss_scale);  // f16 cast by autograd, then *scale (TCNNWP.cpp:174)
-      }
+      for (int r = 0; r < 4; r++)  // f16 cast by autograd, then *scale (TCNNWP.cpp:174)
+        dyf[r] = valid ? (half_t) ((float) (half_t) cur[half].d4[r] * loss_scale) : (half_t) 0.f;
       f2n_mlp_half_bwd<NH, 2>(sm.w, xf, [&](half8_t, half8_t) { return dyf; }, idf, c, g, hb[half]);
       if (valid) {
         if (dx_f32 != nullptr) {
@@ -615,11 +662,10 @@ __global__ __launch_bounds__(F2N_BWD_THREADS, (NH == 1 ? 2 : 1)) void field_bwd_
       }
     }
     f2n_mlp_accumulate_dw<NH>(hb[0], hb[1], acc);
+    cur[0] = nxt[0];
+    cur[1] = nxt[1];
   }
   __syncthreads();  // everyone is done with the LDS weights: reuse the space for the block reduction
-  const int n_params = F2N_D_HID * F2N_D_IN + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0) + F2N_D_OUT * F2N_D_HID;
-  for (int i = tid; i < n_params; i += F2N_BWD_THREADS) sm.acc[i] = 0.f;
-  __syncthreads();
   f2n_mlp_flush_dw<NH>(acc, sm.acc, dparams, c, g, tid, F2N_BWD_THREADS);
 }
 
@@ -790,7 +836,7 @@ int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const
 
 int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float loss_scale, const void* params_h,
                 const float* x, const float* dy, float* dparams_f32_scaled, float* dx_f32) {
-  if (n < 0 || !(loss_scale > 0.f)) return F2N_ERR_INVALID_ARG;
+  if (n < 0 || !(loss_scale > 0.f) || ((uintptr_t) params_h & 15)) return F2N_ERR_INVALID_ARG;  // 16-byte loads of the weights
   if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
@@ -840,8 +886,15 @@ int f2n_hash_gather_planes(void* stream, int n, int n_volumes, const void* table
   F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
   long per_part = ((long) n + 255) / 256;
   if (per_part > 256) per_part = 256;  // 32 CUs per XCD x 8 resident 256-thread blocks
-  hipLaunchKernelGGL(hash_gather_planes_kernel, dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), 0, (hipStream_t) stream, n, h,
-                     local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride, (half_t*) planes_h);
+  const size_t stage_bytes = (size_t) 2 * n_volumes * 6 * sizeof(uint32_t);
+  if (stage_bytes <= 20000 && n >= 64 * 256)  // keeps 8 blocks per CU resident; not worth the copy for small batches
+    hipLaunchKernelGGL(hash_gather_planes_kernel<true>, dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), stage_bytes,
+                       (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride,
+                       (half_t*) planes_h);
+  else
+    hipLaunchKernelGGL(hash_gather_planes_kernel<false>, dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), 0,
+                       (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride,
+                       (half_t*) planes_h);
   return f2n_launch_status();
 }
 
@@ -873,7 +926,8 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
                   const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts_warped,
                   const int32_t* volume_idx, int vol_stride, const void* mlp_params_h, const void* saved_x_h,
                   const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h, int level_entries) {
-  if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f) || level_entries < 0) return F2N_ERR_INVALID_ARG;
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f) || level_entries < 0 || ((uintptr_t) mlp_params_h & 15))
+    return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
   const unsigned blocks = f2n_bwd_grid((n + 31) / 32, 2);  // the NH = 1 kernel fits two blocks per CU (256 registers)

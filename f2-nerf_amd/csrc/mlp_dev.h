@@ -149,29 +149,44 @@ struct F2nMlpLds {
   half_t wot[F2N_D_HID * F2N_LD32];                     // Wo^T [64][16 | 16 zeros]
 };
 
+// params must be 16-byte aligned (every MLP parameter block of the host is a tensor allocation).  All global loads are
+// issued before the first LDS write: a 256-thread block with nothing else resident pays ONE memory round trip here,
+// not one per element (the element-wise version of this fill was ~15 % of the backward kernels' time).
 template <int NH>
 __device__ __forceinline__ void f2n_mlp_lds_fill(F2nMlpLds<NH>& s, const half_t* __restrict__ params, int tid, int nthreads) {
-  const half_t* p0 = params;
-  const half_t* p1 = params + F2N_D_HID * F2N_D_IN;
-  const half_t* po = p1 + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0);
-  for (int i = tid; i < F2N_D_HID * F2N_D_IN; i += nthreads) {
-    const int r = i / F2N_D_IN, k = i % F2N_D_IN;
-    const half_t v = p0[i];
-    s.w0[r * F2N_LD32 + k] = v;
-    s.w0t[k * F2N_LD64 + r] = v;
+  constexpr int C0 = F2N_D_HID * F2N_D_IN / 8;                  // 8-half chunks of W0 rows
+  constexpr int C1 = NH == 2 ? F2N_D_HID * F2N_D_HID / 8 : 0;  // ... of W1 rows
+  constexpr int CO = F2N_D_OUT * F2N_D_HID / 8;                 // ... of Wo rows
+  constexpr int ROUNDS = (C0 + C1 + CO + 255) / 256;            // nthreads >= 256 at every call site
+  half8_t v[ROUNDS];
+#pragma unroll
+  for (int it = 0; it < ROUNDS; it++) {
+    const int i = tid + it * nthreads;
+    v[it] = *(const half8_t*) (params + 8 * (size_t) (i < C0 + C1 + CO ? i : 0));
   }
-  if (NH == 2) {
-    for (int i = tid; i < F2N_D_HID * F2N_D_HID; i += nthreads) {
-      const int r = i / F2N_D_HID, k = i % F2N_D_HID;
-      const half_t v = p1[i];
-      s.w1[r * F2N_LD64 + k] = v;
-      s.w1t[k * F2N_LD64 + r] = v;
+#pragma unroll
+  for (int it = 0; it < ROUNDS; it++) {
+    const int i = tid + it * nthreads;
+    const half4_t lo = __builtin_shufflevector(v[it], v[it], 0, 1, 2, 3), hi = __builtin_shufflevector(v[it], v[it], 4, 5, 6, 7);
+    if (i < C0) {
+      const int r = i / (F2N_D_IN / 8), k = (i % (F2N_D_IN / 8)) * 8;
+      *(half4_t*) (s.w0 + r * F2N_LD32 + k) = lo;
+      *(half4_t*) (s.w0 + r * F2N_LD32 + k + 4) = hi;
+#pragma unroll
+      for (int e = 0; e < 8; e++) s.w0t[(k + e) * F2N_LD64 + r] = v[it][e];
+    } else if (i < C0 + C1) {
+      const int j = i - C0, r = j / (F2N_D_HID / 8), k = (j % (F2N_D_HID / 8)) * 8;
+      *(half4_t*) (s.w1 + r * F2N_LD64 + k) = lo;
+      *(half4_t*) (s.w1 + r * F2N_LD64 + k + 4) = hi;
+#pragma unroll
+      for (int e = 0; e < 8; e++) s.w1t[(k + e) * F2N_LD64 + r] = v[it][e];
+    } else if (i < C0 + C1 + CO) {
+      const int j = i - C0 - C1, o = j / (F2N_D_HID / 8), k = (j % (F2N_D_HID / 8)) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; e++) s.wot[(k + e) * F2N_LD32 + o] = v[it][e];
     }
   }
-  for (int i = tid; i < F2N_D_HID * 32; i += nthreads) {
-    const int j = i / 32, o = i % 32;
-    s.wot[j * F2N_LD32 + o] = (o < F2N_D_OUT) ? po[o * F2N_D_HID + j] : (half_t) 0.f;
-  }
+  for (int i = tid; i < F2N_D_HID * 16; i += nthreads) s.wot[(i >> 4) * F2N_LD32 + 16 + (i & 15)] = (half_t) 0.f;
 }
 
 template <int NH>
@@ -309,36 +324,44 @@ __device__ __forceinline__ void f2n_mlp_accumulate_dw(const F2nHalfBwd<NH>& a, c
   }
 }
 
-// Block-level reduction of the per-wave accumulators through LDS (ds_add_f32), then the block's partial parameter
-// gradient is written with plain coalesced stores to partials[blockIdx.x][n_params]; f2n_reduce_partials sums the
-// blocks afterwards.  (Global fp32 atomics here would put gridDim.x-deep dependent chains on every parameter.)
-// s_acc must hold n_params floats and be zero on entry.
+// Block-level reduction of the per-wave accumulators through LDS, then the block's partial parameter gradient is
+// written with plain coalesced stores to partials[blockIdx.x][n_params]; f2n_reduce_partials sums the blocks afterwards.
+// The waves take turns on the LDS image with plain read-add-write (wave 0 stores): ds_add_f32 runs at 0.33 lane-ops/clk
+// per CU on gfx950 (tools/lds_atomic_probe), which made the atomic version of this flush ~35 us for the colour network;
+// the turn order also makes the sum deterministic.  s_acc holds n_params floats; no initialisation needed.  The caller
+// must have a __syncthreads() between the last use of whatever s_acc aliases and this call.
 template <int NH>
 __device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, float* s_acc, float* __restrict__ partials,
                                                  int c, int g, int tid, int nthreads) {
   const int off1 = F2N_D_HID * F2N_D_IN;
   const int offo = off1 + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0);
   const int n_params = offo + F2N_D_OUT * F2N_D_HID;
+  const int wave = tid >> 6, n_waves = nthreads >> 6;
+  for (int w = 0; w < n_waves; w++) {
+    if (wave == w) {
+      const bool first = w == 0;
+      auto put = [&](int idx, float v) { s_acc[idx] = first ? v : s_acc[idx] + v; };
 #pragma unroll
-  for (int t = 0; t < 4; t++)
+      for (int t = 0; t < 4; t++)
 #pragma unroll
-    for (int ft = 0; ft < 2; ft++)
+        for (int ft = 0; ft < 2; ft++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) atomicAdd(&s_acc[(16 * t + 4 * g + r) * F2N_D_IN + 16 * ft + c], acc.dw0[t * 2 + ft][r]);
-  if (NH == 2) {
+          for (int r = 0; r < 4; r++) put((16 * t + 4 * g + r) * F2N_D_IN + 16 * ft + c, acc.dw0[t * 2 + ft][r]);
+      if (NH == 2) {
 #pragma unroll
-    for (int to = 0; to < 4; to++)
+        for (int to = 0; to < 4; to++)
 #pragma unroll
-      for (int ti = 0; ti < 4; ti++)
+          for (int ti = 0; ti < 4; ti++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-          atomicAdd(&s_acc[off1 + (16 * to + 4 * g + r) * F2N_D_HID + 16 * ti + c], acc.dw1[to * 4 + ti][r]);
+            for (int r = 0; r < 4; r++) put(off1 + (16 * to + 4 * g + r) * F2N_D_HID + 16 * ti + c, acc.dw1[to * 4 + ti][r]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) put(offo + (4 * g + r) * F2N_D_HID + 16 * t + c, acc.dwo[t][r]);
+    }
+    __syncthreads();
   }
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) atomicAdd(&s_acc[offo + (4 * g + r) * F2N_D_HID + 16 * t + c], acc.dwo[t][r]);
-  __syncthreads();
   float* dst = partials + (size_t) blockIdx.x * n_params;
   for (int i = tid; i < n_params; i += nthreads) dst[i] = s_acc[i];
 }

@@ -133,27 +133,56 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
   const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
   const float inv_scale = 1.f / loss_scale;
   const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  // Per-sample inputs are fetched one super-block AHEAD into registers: this kernel runs one wave per SIMD (it owns the
+  // register file), so a load issued where its value is needed exposes its whole latency -- three dependent round trips
+  // per half (x, d rgb, image index) were ~80 % of the kernel's time.
+  struct In {
+    half8_t xf;
+    float d[3];
+    int img;
+  };
+  auto fetch = [&](int sb, int half, In& o) {
+    const int s = sb * 32 + half * 16 + c;
+    const int sc = s < n ? s : n - 1;  // always in range: no branch around the loads
+    o.xf = f2n_rowfrag(x_h, F2N_D_IN, sc, 0, g);
+#pragma unroll
+    for (int r = 0; r < 3; r++) o.d[r] = drgb[3 * (size_t) sc + r];
+    o.img = do_emb ? sample_emb_idx[sc] : -1;
+  };
+  In cur[2];
+  if (wave_global < n_super) {
+    fetch(wave_global, 0, cur[0]);
+    fetch(wave_global, 1, cur[1]);
+  }
   for (int sb = wave_global; sb < n_super; sb += wave_stride) {
+    In nxt[2];
+    {
+      const int sbn = sb + wave_stride < n_super ? sb + wave_stride : sb;  // last round: a harmless re-read
+      fetch(sbn, 0, nxt[0]);
+      fetch(sbn, 1, nxt[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads up here; their s_waitcnt lands at the bottom of the round
     F2nHalfBwd<2> hb[2];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int s = sb * 32 + half * 16 + c;
       const bool valid = s < n;
-      const half8_t xf = f2n_load_xfrag(x_h, valid ? s : n - 1, g, valid);
+      const half8_t xf = valid ? cur[half].xf : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      const float d0 = cur[half].d[0], d1 = cur[half].d[1], d2 = cur[half].d[2];
       // d(rgb)/d(o) needs the network output o: computed inside the backward's own forward recomputation from the
       // last hidden layer's activations (no second forward chain)
       auto dy_fn = [&](half8_t h0, half8_t h1) {
         float4_t o = f2n_mfma(wo[0], h0, z);
         o = f2n_mfma(wo[1], h1, o);
         half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (valid && g == 0) {
+        const float dv[3] = {d0, d1, d2};
 #pragma unroll
-          for (int r = 0; r < 3; r++) {
-            const float ov = (float) (half_t) o[r];
-            const float e = expf(-ov);
-            const float dsig = (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
-            dyf[r] = (half_t) ((float) (half_t) (drgb[3 * (size_t) s + r] * dsig) * loss_scale);
-          }
+        for (int r = 0; r < 3; r++) {
+          const float ov = (float) (half_t) o[r];
+          const float e = expf(-ov);
+          const float dsig = (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
+          const half_t v = (half_t) ((float) (half_t) (dv[r] * dsig) * loss_scale);
+          dyf[r] = (valid && g == 0) ? v : (half_t) 0.f;
         }
         return dyf;
       };
@@ -175,7 +204,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
       if (do_emb) {
         // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples, accumulated in LDS.  The 16 samples
         // of one wave half usually share a ray, hence an image: reduce across the 16 sample lanes first.
-        const int img = valid ? sample_emb_idx[s] : -1;
+        const int img = valid ? cur[half].img : -1;
         const int img0 = __shfl(img, lane & 48);  // sample 0 of this lane group
         const bool uniform = __all(img == img0);
         if (uniform) {
@@ -195,10 +224,9 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
       }
     }
     f2n_mlp_accumulate_dw<2>(hb[0], hb[1], acc);
+    cur[0] = nxt[0];
+    cur[1] = nxt[1];
   }
-  __syncthreads();
-  const int n_params = F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID;
-  for (int i = tid; i < n_params; i += 256) sm.acc[i] = 0.f;
   __syncthreads();
   f2n_mlp_flush_dw<2>(acc, sm.acc, dparams, c, g, tid, 256);
   if (do_emb) {  // s_emb is complete since the __syncthreads() above
@@ -244,7 +272,8 @@ int f2n_shade_fwd(void* stream, int n, const float* feat, const float* dirs, con
 int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
                   const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled, float* dapp_emb,
                   int n_emb) {
-  if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1))) return F2N_ERR_INVALID_ARG;
+  if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1)) || ((uintptr_t) mlp_params_h & 15))
+    return F2N_ERR_INVALID_ARG;
   if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 31 KB of weights
   if (n == 0) return F2N_OK;
   unsigned blocks = f2n_shade_grid((n + 31) / 32, 4);

@@ -189,7 +189,8 @@ int f2n_hash_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, c
  * 217-227 ("FullyFusedMLP", ReLU, no output activation, no bias).  Supported shapes: d_in = 32,
  * d_hidden = 64, n_hidden in {1,2}, d_out <= 16 (padded to 16) -- the two networks of the reference
  * configs.  Parameter layout (fp32 master and h16 working copy alike): layers first->last, each
- * [n_out, n_in] row-major, last layer has 16 rows.
+ * [n_out, n_in] row-major, last layer has 16 rows.  The h16 parameter block handed to the *_bwd entry points must be
+ * 16-byte aligned (F2N_ERR_INVALID_ARG otherwise).
  * ------------------------------------------------------------------------------------------------- */
 int f2n_mlp_n_params(int d_in, int d_hidden, int n_hidden);               /* Module::n_params() */
 /* Module::initialize_params(seed, float*): Xavier-uniform from a counter-based generator (tcnn's pcg32
