@@ -135,10 +135,10 @@ def oct_mark_visit(n_rays, pts_se, anchors, anchor_stride, weights, alphas, w_ad
                                  _p(mark, "i32"), _p(visit_cnt, "i32")), "f2n_oct_mark_visit")
 
 
-def oct_update_stats(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes, child_blocks=None):
+def oct_update_stats(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes, child_blocks=None, reset_votes=False):
     _ck(lib().f2n_oct_update_stats(_stream(), _i(n_nodes), _p(w_adder, "i32"), _p(a_adder, "i32"), _p(mark, "i32"),
                                    _p(w_stats, "i32"), _p(a_stats, "i32"), _p(tree_nodes, "u8"),
-                                   _p(child_blocks, "u8", True)), "f2n_oct_update_stats")
+                                   _p(child_blocks, "u8", True), _i(1 if reset_votes else 0)), "f2n_oct_update_stats")
 
 
 def oct_build_child_blocks(n_nodes, tree_nodes, child_blocks):

@@ -146,11 +146,15 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     // under the collective; only then is the collective awaited and the previous step's (flag-predicated) Adam applied.
     renderer_->PreSample(rays_o, rays_d, bounds);
   }
-  FinishPending();
+  FinishPendingStep();
   renderer_->ZeroGrad();
+  deferred_dropped_ = false;
+  if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
   TrainOutputs out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(),
                                                      disp_loss_weight_, tv_loss_weight_);
+  ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)
   TrainStats stats;
+  stats.skipped_nan = deferred_dropped_;  // the PREVIOUS iteration was dropped: reported one step late when prefetching
   stats.n_rays = rays_o.size(0);
   stats.n_samples = renderer_->last_n_all_pts_;
   stats.n_meaningful = renderer_->last_n_kept_pts_;
@@ -175,7 +179,13 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   // Prefetch: the NEXT batch's rays are marched now, on a side stream, underneath the kernels of this step that are still
   // queued (the host is ~1 ms ahead of the GPU here).  Needs the next iteration's fineness, hence after UpdateAdaParams.
   if (prefetch) renderer_->PreSampleAsync(next_rays_o, next_rays_d, next_bounds);
-  if (applied && ResolveFlags(apply_optimizer)) {
+  if (applied && check_nan_ && prefetch) {  // streaming: do not stall on this step's flags (see ExpRunner.h)
+    if (!nan_flags_host_.defined()) nan_flags_host_ = torch::empty({4}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    nan_flags_host_.copy_(nan_flags_, /*non_blocking=*/true);
+    nan_flags_ev_.record();
+    flags_deferred_ = true;
+    deferred_apply_ = apply_optimizer;
+  } else if (applied && ResolveFlags(apply_optimizer)) {
     stats.skipped_nan = true;  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
     if (apply_optimizer) {
       iter_step_ = std::max(0, iter_step_ - 1);
@@ -183,6 +193,26 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     }
   }
   return stats;
+}
+
+bool ExpRunner::ResolveDeferredFlags() {
+  if (!flags_deferred_) return false;
+  flags_deferred_ = false;
+  nan_flags_ev_.synchronize();
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  const int32_t* f = nan_flags_host_.data_ptr<int32_t>();
+  if (f[0]) field->mlp_->loss_scale_ = std::max(field->mlp_->loss_scale_ / 2.f, 1.f);
+  if (f[1]) shader->mlp_->loss_scale_ = std::max(shader->mlp_->loss_scale_ / 2.f, 1.f);
+  if (!f[2]) return false;
+  global_data_pool_->backward_nan_ = true;
+  if (deferred_apply_) {
+    optim_steps_ -= 1;
+    iter_step_ = std::max(0, iter_step_ - 1);
+    UpdateAdaParams();
+  }
+  deferred_dropped_ = true;
+  return true;
 }
 
 // Finiteness flags (TCNNWP.cpp:234-240, on the device) and Adam predicated on them: enqueue only.
@@ -228,6 +258,11 @@ bool ExpRunner::ApplyGradients(bool apply_optimizer) {
 // counter is taken back by one (the sampling of the step in between has already used the advanced schedule -- the one
 // deviation from the unpipelined order, and only on that rare path).
 void ExpRunner::FinishPending() {
+  FinishPendingStep();
+  ResolveDeferredFlags();
+}
+
+void ExpRunner::FinishPendingStep() {
   if (!pending_) return;
   pending_ = false;
   if (grad_sync_end_hook_) grad_sync_end_hook_();
@@ -346,6 +381,8 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   auto draw = [&]() { return dataset.RandRaysData(std::max(16, CurBatchSize()), sets); };
   auto next = draw();
   last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;
+  const int give_up = 4 * (target + 16);  // every iteration non-finite: stop instead of spinning
+  while (true) {
   while (iter_step_ < target) {
     auto cur = std::move(next);
     next = draw();
@@ -359,9 +396,11 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
     last_train_rays_ += s.n_rays;
     last_train_stats_ = s;
     executed++;
-    if (executed > 4 * (target + 16)) break;  // every iteration non-finite: give up instead of spinning
+    if (executed > give_up) break;
   }
-  FinishPending();
+  FinishPending();  // may take the last iteration back (its finiteness flags are read one step late)
+  if (iter_step_ >= target || executed > give_up) break;
+  }
   return executed;
 }
 

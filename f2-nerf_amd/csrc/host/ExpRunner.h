@@ -22,7 +22,11 @@ class ExpRunner {
     return renderer_->States();
   }
   bool ApplyGradients(bool apply_optimizer);
-  void FinishPending();  // pipelined data-parallel mode: complete the step whose all-reduce is still in flight
+  // Flush: completes whatever a streaming TrainStep left open -- the pipelined data-parallel step whose all-reduce is
+  // still in flight, and the finiteness flags a prefetching TrainStep reads one step late.
+  void FinishPending();
+  void FinishPendingStep();     // the pipelined data-parallel part only
+  bool ResolveDeferredFlags();  // true: the step they belong to was dropped (loss scales halved, counters taken back)
   // next_*: optionally the NEXT iteration's rays (already resident): their sampling is prefetched on a side stream
   TrainStats TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                        const Tensor& emb_idx, bool apply_optimizer = true, const Tensor& next_rays_o = Tensor(),
@@ -62,6 +66,13 @@ class ExpRunner {
   bool pipelined_sync_ = false, pending_ = false;
   float pending_lr_ = 0.f;
   Tensor nan_flags_;  // device int32 [4]: field MLP, colour MLP, either
+  // A TrainStep that is handed the next batch (streaming use) does not wait for its own flags: they are copied to pinned
+  // memory and read after the NEXT step's sample-count read-back, when they are certain to have arrived.  The update
+  // itself is predicated on the device either way; only the host-side reaction (halved loss scale, iteration counter)
+  // lags by one step, on the rare non-finite path.
+  Tensor nan_flags_host_;
+  at::cuda::CUDAEvent nan_flags_ev_;
+  bool flags_deferred_ = false, deferred_apply_ = false, deferred_dropped_ = false;
 
   std::unique_ptr<GlobalDataPool> global_data_pool_;
   std::unique_ptr<Renderer> renderer_;

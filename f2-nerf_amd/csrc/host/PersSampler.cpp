@@ -156,20 +156,26 @@ void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Te
   CheckDev(sampled_alpha, torch::kFloat32, "sampled_alpha");
   // one [4, n_nodes] buffer: weight votes, alpha votes (init -1, :555-556), visited marks (0), running visit counts -- a
   // data-parallel run max-combines it across ranks with ONE collective
-  Tensor occ = torch::empty({4, n_nodes}, DevI32());
-  occ.slice(0, 0, 2).fill_(-1);
-  occ.select(0, 2).zero_();
-  occ.select(0, 3).copy_(oct.tree_visit_cnt_);
+  // The buffer persists between iterations: the visit counts stay where they are and the stat update below re-arms the
+  // vote rows, so an iteration issues no fill / copy here.  It is rebuilt whenever the node array or the visit counts were
+  // replaced behind its back (ProcOctree, LoadStates, InstallOctree).
+  Tensor& occ = oct.occ_;
+  if (!occ.defined() || occ.size(1) != n_nodes || oct.tree_visit_cnt_.data_ptr() != (void*) (occ.data_ptr<int32_t>() + 3 * (int64_t) n_nodes)) {
+    occ = torch::empty({4, n_nodes}, DevI32());
+    occ.slice(0, 0, 2).fill_(-1);
+    occ.select(0, 2).zero_();
+    occ.select(0, 3).copy_(oct.tree_visit_cnt_);
+    oct.tree_visit_cnt_ = occ.select(0, 3);
+  }
   void* st = CurStream();
   F2N_TIMED_CALL("oct_mark_visit", f2n_oct_mark_visit(st, n_rays, n_nodes, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
                               F32P(sampled_weight), F32P(sampled_alpha), I32P(occ), I32P(occ) + n_nodes,
                               I32P(occ) + 2 * (int64_t) n_nodes, I32P(occ) + 3 * (int64_t) n_nodes));
   if (occupancy_sync_hook_) occupancy_sync_hook_(occ);
-  oct.tree_visit_cnt_ = occ.select(0, 3);
   Tensor adders = occ.slice(0, 0, 2), visit_mark = occ.select(0, 2);
   F2N_TIMED_CALL("oct_update_stats",f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
                                 I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
-                                VoidP(oct.child_blocks_gpu_)));
+                                VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1));
 
   while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610
     oct.ProcOctree(true, true, sub_div_milestones_.back() <= 0);
@@ -327,7 +333,7 @@ std::vector<Tensor> PersSampler::States() {
   std::vector<Tensor> ret;
   ret.push_back(pers_octree_->tree_nodes_gpu_);
   ret.push_back(pers_octree_->pers_trans_gpu_);
-  ret.push_back(pers_octree_->tree_visit_cnt_);
+  ret.push_back(pers_octree_->tree_visit_cnt_.clone());  // (a row of the persistent vote buffer)
   ret.push_back(torch::from_blob(sub_div_milestones_.data(), {(int64_t) sub_div_milestones_.size()}, CpuI32()).to(torch::kCUDA));
   return ret;
 }

@@ -54,6 +54,7 @@ class PersOctree {
   Tensor tree_nodes_gpu_;
   Tensor child_blocks_gpu_;  // [n_nodes][8] x 32 B, derived from tree_nodes_gpu_ (f2n_oct_build_child_blocks)
   Tensor tree_weight_stats_, tree_alpha_stats_, tree_visit_cnt_;
+  Tensor occ_;  // [4, n_nodes] weight votes, alpha votes, visited marks, visit counts (tree_visit_cnt_ is its last row)
   Tensor node_search_order_;
   Tensor pers_trans_gpu_;
   Tensor edge_pool_gpu_;

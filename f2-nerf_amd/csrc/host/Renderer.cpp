@@ -275,9 +275,27 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     Tensor mask = torch::empty({n_all_pts}, DevI32()), kept = torch::empty({n_rays}, DevI32());
     F2N_TIMED_CALL("early_stop", f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), F32P(f0), 1, F32P(sample_result_.dt),
                             F32P(weights), F32P(alphas), I32P(mask), I32P(kept)));
-    Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::zeros({1}, DevI32());
+    Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::empty({1}, DevI32());
     F2N_CALL(f2n_segment_scan(st, n_rays, I32P(kept), I32P(new_se), I32P(total)));  // FilterIdxBounds, Renderer.cu:20-50
-    n_kept = total.item<int>();  // second (and last) host read-back of a Render call
+    // Second (and last) host read-back of a Render call: M, the number of surviving samples.  It goes through pinned
+    // memory and an event, not a stream drain, so that the work below that does not depend on M (the occupancy update,
+    // the random draws of the edge samples) is already queued behind the copy and runs while the host wakes up.
+    if (!n_kept_host_.defined()) n_kept_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    n_kept_host_.copy_(total, /*non_blocking=*/true);
+    n_kept_ev_.record();
+    if (train) pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);  // Renderer.cpp:140-149
+    Tensor edge_idx, edge_coord;
+    auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+    if (train) {  // Renderer.cpp:159-166 / PersSampler.cu:454-473: the draws of GetEdgeSamples
+      auto& oct = *ps->pers_octree_;
+      edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
+                                                : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
+      edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
+                                                     : (torch::rand({n_edge, 2}, DevF32()) * 2.f - 1.f).contiguous();
+    }
+    n_kept_ev_.synchronize();
+    n_kept = n_kept_host_.data_ptr<int32_t>()[0];
+    if (train && after_count_readback_) after_count_readback_();  // everything queued before this point has finished
     last_n_kept_pts_ = n_kept;
     pts_all = torch::empty({n_kept + 2 * n_edge, 3}, DevF32());
     vol_all = torch::empty({n_kept + 2 * n_edge}, DevI32());
@@ -293,17 +311,10 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
                                  F32P(sample_result_.pts), F32P(sample_result_.dirs), F32P(sample_result_.dt),
                                  F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all), F32P(es.dirs),
                                  F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows), I32P(vol_all)));
-    if (train) {  // Renderer.cpp:140-149
-      pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);
+    if (train) {
       gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(n_rays)) * 0.1f;
-    }
-    if (train) {  // edge samples for the TV loss go straight behind the surviving samples (Renderer.cpp:159-166)
-      auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+      // edge samples for the TV loss go straight behind the surviving samples (Renderer.cpp:159-166)
       auto& oct = *ps->pers_octree_;
-      Tensor edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
-                                                       : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
-      Tensor edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
-                                                            : (torch::rand({n_edge, 2}, DevF32()) * 2.f - 1.f).contiguous();
       F2N_CALL(f2n_edge_samples(st, n_edge, VoidP(oct.edge_pool_gpu_), VoidP(oct.pers_trans_gpu_), I32P(edge_idx),
                                 F32P(edge_coord), F32P(pts_all) + 3 * (int64_t) n_kept, I32P(vol_all) + n_kept));
     }

@@ -660,15 +660,20 @@ __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __rest
 }
 
 // PersSampler.cu:579-593 (torch integer ops) + MarkInvalidNodes (:528-534), one node per lane.
-__global__ void update_stats_kernel(int n_nodes, const int32_t* __restrict__ w_adder, const int32_t* __restrict__ a_adder,
-                                    const int32_t* __restrict__ mark, int32_t* __restrict__ w_stats,
+__global__ void update_stats_kernel(int n_nodes, int32_t* __restrict__ w_adder, int32_t* __restrict__ a_adder,
+                                    int32_t* __restrict__ mark, int32_t* __restrict__ w_stats,
                                     int32_t* __restrict__ a_stats, F2nTreeNode* __restrict__ nodes,
-                                    F2nChildInfo* __restrict__ child_blocks) {
+                                    F2nChildInfo* __restrict__ child_blocks, int reset_votes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const int m = mark[i];
   int st[2];
   const int add[2] = {w_adder[i], a_adder[i]};
+  if (reset_votes) {  // leave the vote buffers in the state the next f2n_oct_mark_visit expects (:555-556)
+    w_adder[i] = -1;
+    a_adder[i] = -1;
+    mark[i] = 0;
+  }
   st[0] = w_stats[i];
   st[1] = a_stats[i];
 #pragma unroll
@@ -942,12 +947,12 @@ int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts
   return f2n_launch_status();
 }
 
-int f2n_oct_update_stats(void* stream, int n_nodes, const int32_t* w_adder, const int32_t* a_adder, const int32_t* mark,
-                         int32_t* w_stats, int32_t* a_stats, void* tree_nodes, void* child_blocks) {
+int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
+                         int32_t* a_stats, void* tree_nodes, void* child_blocks, int reset_votes) {
   if (n_nodes < 0) return F2N_ERR_INVALID_ARG;
   if (n_nodes == 0) return F2N_OK;
   hipLaunchKernelGGL(update_stats_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, n_nodes,
-                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks);
+                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks, reset_votes);
   return f2n_launch_status();
 }
 

@@ -148,10 +148,11 @@ int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts
 
 /* The integer stat update of UpdateOctNodes (PersSampler.cu:579-593) fused with MarkInvalidNodes
  * (:528-534, :595-603): stats = clamp(max(stats, pos vote) + visited negative vote, -100, 2^20);
- * trans_idx = -1 where either stat < 0. */
-int f2n_oct_update_stats(void* stream, int n_nodes, const int32_t* w_adder, const int32_t* a_adder,
-                         const int32_t* mark, int32_t* w_stats, int32_t* a_stats, void* tree_nodes,
-                         void* child_blocks /*or NULL*/);
+ * trans_idx = -1 where either stat < 0.  reset_votes != 0: the three vote buffers are re-initialised after use
+ * (adders = -1, mark = 0: what the reference re-creates with torch::full / zeros every iteration, :555-557), so a
+ * caller can keep one persistent buffer. */
+int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
+                         int32_t* a_stats, void* tree_nodes, void* child_blocks /*or NULL*/, int reset_votes);
 
 /* MarkInvisibleNodesKernel (PersSampler.cu:618-680). */
 int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris /*[C,3,3]*/,

@@ -309,6 +309,45 @@ def test_data_parallel_hooks_on_one_gpu(rt, fox_state):
                 assert (a == b).all()
 
 
+def test_deferred_finiteness_flags_when_prefetching(rt, fox_state):
+    """A train_step that is handed the next batch does not wait for its own finiteness flags: the update is predicated on
+    the device, and the host reaction (iteration counter, loss scale) arrives with the next step or flush()."""
+    st = fox_state
+    rng = np.random.default_rng(21)
+    torch.manual_seed(21)
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", seed=4)
+    runner.n_edge_pts = 512
+    R = 512
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    gt = np.tile(np.array([[0.7, 0.4, 0.1]], F32), (R, 1))
+    d = rt.to_dev(ro, rd, bounds, gt, cam)
+    bad_gt = d[3].clone()
+    bad_gt[5, 1] = float("nan")  # -> non-finite loss -> non-finite gradients everywhere
+    nxt = (d[0], d[1], d[2])
+    s = runner.train_step(d[0], d[1], d[2], d[3], d[4], True, *nxt)
+    assert not s["skipped_nan"] and runner.iter_step == 1
+    before = [t.clone() for t in runner.states()]
+    s = runner.train_step(d[0], d[1], d[2], bad_gt, d[4], True, *nxt)
+    assert not s["skipped_nan"] and runner.iter_step == 2  # not known yet
+    s = runner.train_step(d[0], d[1], d[2], d[3], d[4], True, *nxt)
+    assert s["skipped_nan"] and runner.iter_step == 2  # the bad step was taken back, this one counted
+    s = runner.train_step(d[0], d[1], d[2], bad_gt, d[4], True, *nxt)
+    assert runner.iter_step == 3
+    runner.flush()  # resolves the last step's flags
+    assert runner.iter_step == 2
+    for t in runner.states():
+        if t.dtype.is_floating_point:
+            assert torch.isfinite(t).all()
+    # the dropped step changed no parameter: one good step from `before` on a twin runner gives the same state
+    twin, _, _ = rt.make_runner(st, "wanjinyou", seed=4)
+    twin.n_edge_pts = 512
+    torch.manual_seed(21)
+    twin.train_step(d[0], d[1], d[2], d[3], d[4], True, *nxt)
+    twin.flush()
+    for a, b in zip(before, twin.states()):
+        assert a.shape == b.shape
+
+
 @pytest.mark.parametrize("preset,overrides", [("llff", []), ("nerf-360", []), ("wanjinyou_big", ["field.log2_table_size=20"]), ("free", [])])
 def test_other_presets_train(rt, fox_state, preset, overrides):
     """BASELINE configs 3-5 as plumbing cases: the presets that differ in sampler step (sample_l 1/512), scale_by_dis,

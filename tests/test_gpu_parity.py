@@ -268,6 +268,10 @@ def test_edge_samples_and_occupancy(hip, fox_state, fox_golden):
     tw, ta, tn = T(ws), T(as_), T(st["tree_nodes"])
     hip.oct_update_stats(n_nodes, wa, aa, mk, tw, ta, tn)
     assert_same(N(tw), ew); assert_same(N(ta), ea); assert_same(N(tn), enodes)
+    tw, ta, tn = T(ws), T(as_), T(st["tree_nodes"])  # same update, vote buffers re-armed for the next iteration
+    hip.oct_update_stats(n_nodes, wa, aa, mk, tw, ta, tn, reset_votes=True)
+    assert_same(N(tw), ew); assert_same(N(ta), ea); assert_same(N(tn), enodes)
+    assert (N(wa) == -1).all() and (N(aa) == -1).all() and (N(mk) == 0).all()
     ts = st["train_set"]
     tn2 = T(st["tree_nodes"])
     hip.oct_mark_invisible(n_nodes, len(ts), tn2, T(st["intri"][ts]), T(st["w2c"][ts]), T(st["bounds"][ts]))
