@@ -43,6 +43,11 @@ ALGO_BYTES = {"hash_gather": 512 + 12 + 4 + 64}
 # profiles/<tag>_traffic.json; null when that file is absent.
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
 HBM_PEAK_GBS = 8000.0
+# What actually bounds that kernel: 128 independent 4-byte reads per sample from an L2-resident table slice.  The chip
+# serves at most ~263 G such lane-requests/s whatever the cache policy or access width (tools/gather_policy_probe.py,
+# profiles/r01_gather_policy_probe.txt: each request moves a whole line from L2 into a CU's L1) -- reported next to the
+# HBM fraction as roofline.request_ceiling.
+GATHER_REQ_PEAK = 263.0e9
 
 
 def main():
@@ -147,6 +152,9 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "avg_kernel_ms": round(avg_ms, 4), "launches": launches, "bytes_per_sample": ALGO_BYTES[DOMINANT],
                         "samples_per_launch": int(samples_per_launch),
+                        "request_ceiling": {"achieved": round(samples_per_launch * 128 / (avg_ms * 1e-3) / 1e9, 1),
+                                            "peak": GATHER_REQ_PEAK / 1e9, "unit": "G 4-byte gathers/s",
+                                            "frac": round(samples_per_launch * 128 / (avg_ms * 1e-3) / GATHER_REQ_PEAK, 4)},
                         "timed_calls_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in timing.items()}}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
