@@ -567,7 +567,7 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
 template <int NH>
 union F2nBwdSmem {
   F2nMlpLds<NH> w;
-  float acc[F2N_D_HID * F2N_D_IN + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0) + F2N_D_OUT * F2N_D_HID];
+  float acc[2 * (F2N_D_HID * F2N_D_IN + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0) + F2N_D_OUT * F2N_D_HID)];  // two images, see f2n_mlp_flush_dw
 };
 
 template <int NH, bool DO_HASH>

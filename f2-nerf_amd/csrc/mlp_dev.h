@@ -328,8 +328,9 @@ __device__ __forceinline__ void f2n_mlp_accumulate_dw(const F2nHalfBwd<NH>& a, c
 // written with plain coalesced stores to partials[blockIdx.x][n_params]; f2n_reduce_partials sums the blocks afterwards.
 // The waves take turns on the LDS image with plain read-add-write (wave 0 stores): ds_add_f32 runs at 0.33 lane-ops/clk
 // per CU on gfx950 (tools/lds_atomic_probe), which made the atomic version of this flush ~35 us for the colour network;
-// the turn order also makes the sum deterministic.  s_acc holds n_params floats; no initialisation needed.  The caller
-// must have a __syncthreads() between the last use of whatever s_acc aliases and this call.
+// the turn order also makes the sum deterministic.  s_acc holds TWO images of n_params floats (even / odd waves: half the
+// turns); no initialisation needed.  The caller must have a __syncthreads() between the last use of whatever s_acc
+// aliases and this call.
 template <int NH>
 __device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, float* s_acc, float* __restrict__ partials,
                                                  int c, int g, int tid, int nthreads) {
@@ -337,10 +338,11 @@ __device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, f
   const int offo = off1 + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0);
   const int n_params = offo + F2N_D_OUT * F2N_D_HID;
   const int wave = tid >> 6, n_waves = nthreads >> 6;
-  for (int w = 0; w < n_waves; w++) {
-    if (wave == w) {
+  for (int w = 0; w < n_waves; w += 2) {
+    if ((wave & ~1) == w) {
       const bool first = w == 0;
-      auto put = [&](int idx, float v) { s_acc[idx] = first ? v : s_acc[idx] + v; };
+      float* img = s_acc + (wave & 1) * n_params;
+      auto put = [&](int idx, float v) { img[idx] = first ? v : img[idx] + v; };
 #pragma unroll
       for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -363,5 +365,5 @@ __device__ __forceinline__ void f2n_mlp_flush_dw(const F2nMlpGradAcc<NH>& acc, f
     __syncthreads();
   }
   float* dst = partials + (size_t) blockIdx.x * n_params;
-  for (int i = tid; i < n_params; i += nthreads) dst[i] = s_acc[i];
+  for (int i = tid; i < n_params; i += nthreads) dst[i] = s_acc[i] + s_acc[n_params + i];
 }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(int n, const float* __re
 
 union F2nShadeSmem {
   F2nMlpLds<2> w;
-  float acc[F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID];
+  float acc[2 * (F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID)];  // two images, see f2n_mlp_flush_dw
 };
 
 __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __restrict__ drgb,
@@ -274,7 +274,7 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
                   int n_emb) {
   if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1)) || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
-  if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 31 KB of weights
+  if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 57 KB of weights / reduction images
   if (n == 0) return F2N_OK;
   unsigned blocks = f2n_shade_grid((n + 31) / 32, 4);
   if (blocks > 256) blocks = 256;  // one resident block per CU (the kernel owns the whole register file)
@@ -288,6 +288,14 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
     if (emb_partials == nullptr) return F2N_ERR_INVALID_ARG;
   }
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
+  if (dyn_lds > 4096) {  // 57 KB of static LDS + the per-image accumulator can pass 64 KB (a gfx950 workgroup may own all 160 KB)
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute((const void*) shade_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 480 * 16 * (int) sizeof(float)) != hipSuccess)
+        return F2N_ERR_UNSUPPORTED;
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(256), dyn_lds, (hipStream_t) stream, n, drgb, sample_emb_idx,
                      (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat, partials, n_emb, emb_partials);
   int rc = f2n_launch_status();

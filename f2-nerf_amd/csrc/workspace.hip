@@ -34,29 +34,36 @@ void* f2n_ws_get(int slot, size_t bytes) {
   return s.ptr;
 }
 
-// out[i] += sum_b partials[b * n + i].  A block handles 64 parameters x 4 groups of source blocks; every thread keeps
-// 8 independent loads in flight (the sequential one-thread-per-parameter loop was a 256-deep chain of dependent
-// ~0.25 us reads: 60 us per call, three calls per training step).
-__global__ __launch_bounds__(256) void f2n_reduce_partials_kernel(int n, int n_blocks, const float* __restrict__ partials,
-                                                                  float* __restrict__ out) {
-  __shared__ float s_part[4][64];
+// out[i] += sum_b partials[b * n + i].  A 1024-thread block handles 64 parameters x 16 groups of source blocks; every
+// thread keeps 8 independent loads in flight (the sequential one-thread-per-parameter loop was a 256-deep chain of
+// dependent ~0.25 us reads: 60 us per call, three calls per training step; 4 groups: 14 us; 16 groups: two load rounds
+// for 256 source blocks).  The summation order is fixed: the result does not depend on scheduling.
+#define F2N_RED_GROUPS 16
+__global__ __launch_bounds__(64 * F2N_RED_GROUPS) void f2n_reduce_partials_kernel(int n, int n_blocks, const float* __restrict__ partials,
+                                                                                   float* __restrict__ out) {
+  __shared__ float s_part[F2N_RED_GROUPS][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (i < n) {
     int b = grp;
-    for (; b + 28 < n_blocks; b += 32) {
+    for (; b + 7 * F2N_RED_GROUPS < n_blocks; b += 8 * F2N_RED_GROUPS) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc[u] += partials[(size_t) (b + 4 * u) * n + i];
+      for (int u = 0; u < 8; u++) acc[u] += partials[(size_t) (b + F2N_RED_GROUPS * u) * n + i];
     }
-    for (; b < n_blocks; b += 4) acc[0] += partials[(size_t) b * n + i];
+    for (; b < n_blocks; b += F2N_RED_GROUPS) acc[0] += partials[(size_t) b * n + i];
   }
   s_part[grp][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (grp == 0 && i < n) out[i] += (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+  if (grp == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < F2N_RED_GROUPS; k += 4) t += (s_part[k][lane] + s_part[k + 1][lane]) + (s_part[k + 2][lane] + s_part[k + 3][lane]);
+    out[i] += t;
+  }
 }
 
 int f2n_reduce_partials(void* stream, int n, int n_blocks, const float* partials, float* out) {
-  hipLaunchKernelGGL(f2n_reduce_partials_kernel, dim3(f2n_div_up(n, 64)), dim3(256), 0, (hipStream_t) stream, n, n_blocks, partials, out);
+  hipLaunchKernelGGL(f2n_reduce_partials_kernel, dim3(f2n_div_up(n, 64)), dim3(64 * F2N_RED_GROUPS), 0, (hipStream_t) stream, n, n_blocks, partials, out);
   return f2n_launch_status();
 }

@@ -584,15 +584,16 @@ def test_field_forward_from_prepass_cache(hip, fox_state, fox_golden):
         hip.field_fwd_cached(n + 1, n, None, cache, ph, torch.zeros((n + 1, 16), device=DEV), None, None)
 
 
-@pytest.mark.parametrize("use_emb", [False, True])
-def test_shade_fused_forward_backward(hip, fox_golden, use_emb):
+@pytest.mark.parametrize("n_emb", [0, 50, 480])  # 480: the largest per-block LDS image the backward accepts (> 64 KB of LDS)
+def test_shade_fused_forward_backward(hip, fox_golden, n_emb):
+    use_emb = n_emb > 0
     g = fox_golden
     rng = np.random.default_rng(31)
     params = rand_params(rng, 2)
     dirs, se = g["march_dirs"], g["march_pts_idx_bounds"]
     n = len(dirs)
     feat = rng.standard_normal((n, 16)).astype(F32)
-    emb = (rng.standard_normal((50, 16)) * 0.1).astype(F32) if use_emb else None
+    emb = (rng.standard_normal((n_emb, 16)) * 0.1).astype(F32) if use_emb else None
     sidx = oc.scatter_idx(n, se, g["cam"]) if use_emb else None
     ph = T(oc.f2h(params).view(np.float16))
     rgb = torch.zeros((n, 3), device=DEV)
@@ -609,9 +610,9 @@ def test_shade_fused_forward_backward(hip, fox_golden, use_emb):
     drgb = (rng.standard_normal((n, 3)) * 1e-3).astype(F32)
     dfeat = torch.full((n, 16), 7.0, device=DEV)
     dparams = torch.zeros(params.size, device=DEV)
-    demb = torch.zeros((50, 16), device=DEV) if use_emb else None
+    demb = torch.zeros((n_emb, 16), device=DEV) if use_emb else None
     hip.shade_bwd(n, T(drgb), d_sidx, ph, sx, 128.0, dfeat, dparams, demb)
-    rdp, rdfeat, rdemb = op.shade_bwd(params, ctx, drgb, 50 if use_emb else 0, sidx, 128.0)
+    rdp, rdfeat, rdemb = op.shade_bwd(params, ctx, drgb, n_emb, sidx, 128.0)
     gdf = N(dfeat)
     assert (gdf[:, 0] == 7.0).all()  # column 0 untouched
     assert np.abs(gdf[:, 1:] - rdfeat[:, 1:]).max() <= 4e-3 * np.abs(rdfeat).max() + 1e-8
