@@ -51,6 +51,18 @@ struct alignas(32) F2nChildInfo {
 static_assert(sizeof(F2nChildInfo) == 32, "layout");
 static_assert(sizeof(F2nTreeNode) == 64 && sizeof(F2nTransInfo) == 544 && sizeof(F2nEdgePool) == 64, "layout");
 
+#if defined(__HIPCC__)
+// Sum over the 16 lanes of a DPP row, result in every lane (quad butterflies, row_half_mirror, row_mirror): four VALU
+// instructions, no LDS round trip (a __shfl_xor ladder is four dependent ds_bpermute, ~100 cycles each for a lone wave).
+__device__ __forceinline__ float f2n_row16_allsum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+#endif
+
 static inline int f2n_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? F2N_OK : -(1000 + (int) e);

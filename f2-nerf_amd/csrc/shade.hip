@@ -205,15 +205,14 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
         // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples, accumulated in LDS.  The 16 samples
         // of one wave half usually share a ray, hence an image: reduce across the 16 sample lanes first.
         const int img = valid ? cur[half].img : -1;
-        const int img0 = __shfl(img, lane & 48);  // sample 0 of this lane group
+        // sample 0's image, without an LDS round trip: every row of 16 lanes holds the same 16 samples
+        const int img0 = __builtin_amdgcn_readfirstlane(img);
         const bool uniform = __all(img == img0);
         if (uniform) {
           if (img0 >= 0) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              float v = dsf[r];
-#pragma unroll
-              for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+              const float v = f2n_row16_allsum(dsf[r]);
               if (c == 0) atomicAdd(&s_emb[img0 * 16 + 4 * g + r], v);
             }
           }
