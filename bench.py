@@ -155,6 +155,10 @@ def main():
                         "request_ceiling": {"achieved": round(samples_per_launch * 128 / (avg_ms * 1e-3) / 1e9, 1),
                                             "peak": GATHER_REQ_PEAK / 1e9, "unit": "G 4-byte gathers/s",
                                             "frac": round(samples_per_launch * 128 / (avg_ms * 1e-3) / GATHER_REQ_PEAK, 4)},
+                        # whole-path fractions from the same run -- table bytes 512*(rho+2) per meaningful sample
+                        # against 8 TB/s, MLP flops (61440 + 6144 rho) against the 2.5 PFLOP/s dense f16 peak
+                        "whole_path": {"gather_scatter_frac_of_hbm": round(value / max(world, 1) * 512 * (rho + 2) / 8.0e12, 5),
+                                       "mlp_frac_of_mfma": round(value / max(world, 1) * (61440 + 6144 * rho) / 2.5e15, 5)},
                         "timed_calls_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in timing.items()}}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
