@@ -334,10 +334,10 @@ def flex_acc_bwd(n_rays, include_this, dsum, se, out):
 
 # ---------------------------------------------------------------- optimiser
 def adam_step(n, param, grad, grad_scale, grad_round_h16, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
-              skip_flag=None):
+              skip_flag=None, zero_grad=False):
     _ck(lib().f2n_adam_step(_stream(), _i(n), _p(param, "f32"), _p(grad, "f32"), _f(grad_scale), _i(int(grad_round_h16)),
                             _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _f(beta1), _f(beta2), _f(eps),
-                            _f(wd), _p(param_h, "h16", True), _p(skip_flag, "i32", True)), "f2n_adam_step")
+                            _f(wd), _p(param_h, "h16", True), _i(int(zero_grad)), _p(skip_flag, "i32", True)), "f2n_adam_step")
 
 
 def adam_step_h16grad(n, param, grad_h, grad_scale, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,

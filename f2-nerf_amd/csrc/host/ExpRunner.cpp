@@ -118,9 +118,10 @@ void ExpRunner::OptimStep(const int32_t* skip_flag) {
     } else {
       F2N_TIMED_CALL("adam", f2n_adam_step(st, (int) n, F32P(g.param), F32P(g.grad), scale, g.grad_round_h16 ? 1 : 0, F32P(exp_avg_[i]),
                              F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
-                             g.param_h.defined() ? VoidP(g.param_h) : nullptr, skip_flag));
+                             g.param_h.defined() ? VoidP(g.param_h) : nullptr, /*zero_grad=*/1, skip_flag));
     }
   }
+  renderer_->small_grads_clean_ = true;  // every group's gradient was consumed and cleared (also on the skipped path)
 }
 
 // Loss weights of the current iteration (ExpRunner.cpp:108-114).

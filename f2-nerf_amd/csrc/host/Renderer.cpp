@@ -187,6 +187,12 @@ Renderer::Renderer(GlobalDataPool* gdp, int n_images) {  // Renderer.cpp:22-49
 
 void Renderer::ZeroGrad() {
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
+  if (small_grads_clean_) {  // the fused Adam step cleared everything it consumed: no fill kernels this iteration
+    small_grads_clean_ = false;
+    if (!field->grad_clean_) field->grad_h_.zero_();
+    field->grad_clean_ = true;
+    return;
+  }
   if (small_grads_flat_.defined()) {  // field MLP, colour MLP and app_emb gradients are views of one tensor: one fill
     if (!field->grad_clean_) field->grad_h_.zero_();
     field->grad_clean_ = true;

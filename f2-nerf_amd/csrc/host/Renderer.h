@@ -84,6 +84,7 @@ class Renderer : public Pipe {
   bool has_presample_ = false, presample_async_ = false;
   const void* presample_key_ = nullptr;  // rays_o.data_ptr() the presample belongs to
   at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_, n_kept_ev_;
+  bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
   Tensor n_kept_host_;  // pinned int32[1]: the surviving-sample count, read back through n_kept_ev_
   std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;

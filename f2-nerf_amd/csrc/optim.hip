@@ -22,13 +22,17 @@ __device__ __forceinline__ float f2n_adam_update(float p, float g, float& m, flo
 // grad_round_h16: reproduce the two binary16 roundings the reference applies to MLP parameter gradients
 // (tcnn writes dL/dparams in param precision while still loss-scaled, Field/TCNNWP.cpp:214-215; autograd then
 // casts the unscaled fp32 gradient back to the f16 dtype of the Function's `params` input, :111,:242).
-__global__ void adam_kernel(int n, float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
+__global__ void adam_kernel(int n, float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
                             float* __restrict__ exp_avg_sq, F2nAdamCoef k, int grad_round_h16, half_t* __restrict__ param_h,
-                            const int32_t* __restrict__ skip_flag) {
+                            int zero_grad, const int32_t* __restrict__ skip_flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (skip_flag != nullptr && *skip_flag != 0) return;  // non-finite gradients: the iteration is dropped (ExpRunner.cpp:131-134)
+  if (skip_flag != nullptr && *skip_flag != 0) {  // non-finite gradients: the iteration is dropped (ExpRunner.cpp:131-134)
+    if (zero_grad) grad[i] = 0.f;
+    return;
+  }
   float g = grad[i];
+  if (zero_grad) grad[i] = 0.f;  // optimizer.zero_grad() of the next iteration (ExpRunner.cpp:135), fused
   if (grad_round_h16) g = (float) (half_t) ((float) (half_t) g * k.grad_scale);
   else g = g * k.grad_scale;
   float m = exp_avg[i], v = exp_avg_sq[i];
@@ -202,14 +206,14 @@ static F2nAdamCoef f2n_adam_coef(int step, float lr, float beta1, float beta2, f
 
 extern "C" {
 
-int f2n_adam_step(void* stream, int n, float* param, const float* grad, float grad_scale, int grad_round_h16, float* exp_avg,
+int f2n_adam_step(void* stream, int n, float* param, float* grad, float grad_scale, int grad_round_h16, float* exp_avg,
                   float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                  void* param_h_or_null, const int32_t* skip_flag) {
+                  void* param_h_or_null, int zero_grad, const int32_t* skip_flag) {
   if (n < 0 || step < 1) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   const F2nAdamCoef k = f2n_adam_coef(step, lr, beta1, beta2, eps, weight_decay, grad_scale);
   hipLaunchKernelGGL(adam_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n, param, grad, exp_avg,
-                     exp_avg_sq, k, grad_round_h16, (half_t*) param_h_or_null, skip_flag);
+                     exp_avg_sq, k, grad_round_h16, (half_t*) param_h_or_null, zero_grad, skip_flag);
   return f2n_launch_status();
 }
 

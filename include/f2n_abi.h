@@ -355,9 +355,10 @@ int f2n_gather_pixels(void* stream, int n_rays, int height, int width, const flo
  * grad_round_h16 != 0 reproduces the two binary16 roundings the reference applies to MLP parameter gradients:
  * g = f16(f16(grad) * grad_scale) (tcnn param-precision output while loss-scaled, Field/TCNNWP.cpp:214-215, then
  * autograd's cast of the unscaled gradient to the f16 dtype of the Function input, :111,:242). */
-int f2n_adam_step(void* stream, int n, float* param, const float* grad, float grad_scale, int grad_round_h16,
+int f2n_adam_step(void* stream, int n, float* param, float* grad, float grad_scale, int grad_round_h16,
                   float* exp_avg, float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, void* param_h_or_null, const int32_t* skip_flag /*device, or NULL*/);
+                  float weight_decay, void* param_h_or_null, int zero_grad /* clear grad after use (also when skipped) */,
+                  const int32_t* skip_flag /*device, or NULL*/);
 /* h16 gradient table produced by f2n_hash_bwd / f2n_field_bwd (true gradient = float(grad_h) * grad_scale,
  * grad_scale = 1/128): fuses the fp16->fp32 cast, the /128 (Hash3DAnchored.cu:232), Adam, the fp32->fp16
  * refresh of the table (Hash3DAnchored.cu:186) and the re-zeroing of the gradient (:222) in one pass. */

@@ -828,6 +828,13 @@ def test_nonfinite_flags_and_skipped_adam(hip):
     flags.zero_()
     hip.adam_step(n, tp, T(g), 1.0, False, tm, tv, 2, 1e-2, 0.9, 0.99, 1e-15, 1e-6, ph, flags[2:])
     assert (N(tp) != p).any()
+    # fused zero_grad: the fp32 gradient is cleared after use -- on the applied and on the skipped path
+    for bad in (False, True):
+        tg = T(g)
+        hip.nonfinite_flags(a.size, T(a2 if bad else a), b.size, T(b), flags)
+        before = N(tp).copy()
+        hip.adam_step(n, tp, tg, 1.0, False, tm, tv, 3, 1e-2, 0.9, 0.99, 1e-15, 1e-6, ph, flags[2:], zero_grad=True)
+        assert (N(tg) == 0).all() and bool((N(tp) == before).all()) == bad
 
 
 def test_img2world_rays_and_pixel_gather(hip, fox_state, fox_golden):
