@@ -871,6 +871,65 @@ def test_img2world_rays_and_pixel_gather(hip, fox_state, fox_golden):
     assert_same(N(col), images[cam2, ij2[:, 0], ij2[:, 1]], "pixels"); assert_same(N(bnd), cb[cam2], "bounds")
 
 
+def test_empty_and_ragged_inputs(hip, fox_state):
+    """Every entry point accepts an empty batch (status OK, nothing written), and the per-ray kernels accept rays
+    without samples between rays with samples."""
+    st = fox_state
+    S = 123.0
+    f = lambda *shape: torch.full(shape, S, device=DEV)
+    i = lambda *shape: torch.full(shape, 77, dtype=torch.int32, device=DEV)
+    h = lambda *shape: torch.full(shape, S, dtype=torch.float16, device=DEV)
+    ph1, ph2 = h(3072), h(7168)
+    log2 = 10
+    local = 1 << log2
+    lidx = T((np.arange(16) * local).astype(np.int32)); lsize = T(np.full(16, local, np.int32)); scale = T(oc.level_scales())
+    prim, bias, nv = T(st["prim_pool"]), T(st["bias_pool"]), int(st["n_volumes"])
+    table = h(16 * local, 2)
+    outs = []
+    def keep(t):
+        outs.append(t)
+        return t
+    hip.normalize_dirs(0, f(4, 3), keep(f(4, 3)))
+    hip.hash_fwd(0, nv, table, prim, lidx, lsize, bias, scale, f(4, 3), True, i(4), 1, keep(h(4, 32)))
+    hip.hash_bwd(0, nv, prim, lidx, lsize, bias, scale, f(4, 3), True, i(4), 1, h(4, 32), keep(h(16 * local, 2)), local)
+    hip.mlp_fwd(0, 32, 64, 1, ph1, f(4, 32), keep(h(4, 16)))
+    hip.mlp_bwd(0, 32, 64, 2, 128.0, ph2, f(4, 32), f(4, 16), keep(f(7168)), keep(f(4, 32)))
+    hip.field_fwd(0, nv, table, prim, lidx, lsize, bias, scale, f(4, 3), i(4), 1, ph1, keep(f(4, 16)), keep(f(4)), keep(h(4, 32)))
+    hip.field_bwd(0, nv, prim, lidx, lsize, bias, scale, f(4, 3), i(4), 1, ph1, h(4, 32), f(4, 16), 128.0, keep(f(3072)),
+                  keep(h(16 * local, 2)), local)
+    hip.sh_encode(0, 4, f(4, 3), keep(f(4, 16)))
+    hip.shade_fwd(0, f(4, 16), f(4, 3), None, None, ph2, keep(f(4, 3)), keep(h(4, 32)))
+    hip.shade_bwd(0, f(4, 3), None, ph2, h(4, 32), 128.0, keep(f(4, 16)), keep(f(7168)), None)
+    hip.scatter_idx(0, i(4, 2), i(4), keep(i(4)))
+    hip.early_stop(0, i(4, 2), f(4), 1, f(4), keep(f(4)), keep(f(4)), keep(i(4)), keep(i(4)))
+    hip.composite_fwd(0, i(4, 2), f(4, 16), f(4), f(4), f(4, 3), f(4, 3), keep(f(4, 3)), keep(f(4)), keep(f(4)), keep(f(4)))
+    hip.weight_var_fwd(0, f(4), i(4, 2), keep(f(4)))
+    hip.adam_step(0, keep(f(8)), f(8), 1.0, False, keep(f(8)), keep(f(8)), 1, 1e-2, 0.9, 0.99, 1e-15, 0.0, None)
+    hip.adam_step_h16grad(0, keep(f(8)), h(8), 1.0, keep(f(8)), keep(f(8)), 1, 1e-2, 0.9, 0.99, 1e-15, 0.0, h(8), True)
+    hip.img2world_rays(0, f(1, 3, 4), f(1, 3, 3), f(1, 4), i(4), i(4, 2), keep(f(4, 3)), keep(f(4, 3)))
+    torch.cuda.synchronize()
+    for t in outs:
+        v = t.float()
+        assert bool(((v == S) | (v == 77)).all()), "an empty call wrote to its outputs"
+    # segment_scan of nothing: total 0
+    tot = i(1)
+    hip.segment_scan(0, i(4), i(4, 2), tot)
+    assert int(tot[0]) == 0
+    # ragged rays: empty segments in front, in the middle and at the end
+    se = np.array([[0, 0], [0, 5], [5, 5], [5, 5], [5, 21], [21, 21]], np.int32)
+    n, R = 21, len(se)
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((n, 16)).astype(F32); dt = rng.random(n, dtype=F32) * F32(0.01) + F32(1e-3)
+    tt = np.cumsum(dt).astype(F32); rgb = rng.random((n, 3), dtype=F32); bg = rng.random((R, 3), dtype=F32)
+    colors, disp, depth, w = f(R, 3), f(R), f(R), f(n)
+    hip.composite_fwd(R, T(se), T(feat), T(dt), T(tt), T(rgb), T(bg), colors, disp, depth, w)
+    ref = op.composite_fwd(feat, dt, tt, rgb, bg, se)
+    for got, k in ((colors, "colors"), (disp, "disparity"), (w, "weights")):
+        assert np.abs(N(got) - ref[k]).max() <= 2e-5 * max(1.0, np.abs(ref[k]).max()), k
+    for r in (0, 2, 3, 5):
+        assert_same(N(colors)[r], bg[r])  # nothing on the ray: the background
+
+
 def test_errors_are_loud(hip):
     x = torch.zeros((4, 32), device=DEV)
     with pytest.raises(Exception):
