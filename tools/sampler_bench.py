@@ -40,10 +40,21 @@ def march():
     capi.ray_march_strided(n, 1. / 256., True, ro, rd, noise, se, oi, nf, tn, tr, cnt, None, s_dt, s_t, s_an, fod, otr)
 def march_count():
     capi.ray_march_count(n, 1. / 256., True, ro, rd, noise, se, oi, nf, tn, tr, cnt)
+flush_buf = torch.empty(192 * 1024 * 1024, device=dev)  # 768 MB: evicts the L2s and the 256 MB Infinity Cache
+def cold(fn, reps=5):
+    tot_ms = 0.0
+    for r in range(reps):
+        flush_buf.fill_(float(r)); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        tot_ms += e0.elapsed_time(e1)
+    return tot_ms / reps
 print("rays %d nodes %d" % (n, n_nodes))
+print("oct_intersect_strided cold caches %.3f ms" % cold(isect))
 print("oct_intersect_strided %.3f ms" % timeit(isect))
 print("ray_march_strided     %.3f ms" % timeit(march))
 print("ray_march_count       %.3f ms" % timeit(march_count))
+print("ray_march_strided cold caches %.3f ms" % cold(march))
 c = cnt.cpu().numpy(); h = (se[:, 1] - se[:, 0]).cpu().numpy()
 print("samples/ray mean %.1f max %d ; leaf hits/ray mean %.1f max %d" % (c.mean(), c.max(), h.mean(), h.max()))
 # how often does the transform change along a ray?
