@@ -242,10 +242,11 @@ def shade_fwd(n, feat, dirs, app_emb, sample_emb_idx, mlp_params_h, rgb, save_x_
                             _p(save_x_h, "h16", True)), "f2n_shade_fwd")
 
 
-def shade_bwd(n, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_scaled, dapp_emb):
+def shade_bwd(n, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_scaled, dapp_emb, df0=None):
     _ck(lib().f2n_shade_bwd(_stream(), _i(n), _p(drgb, "f32"), _p(sample_emb_idx, "i32", True), _p(mlp_params_h, "h16"),
                             _p(saved_x_h, "h16"), _f(loss_scale), _p(dfeat, "f32"), _p(dparams_scaled, "f32"),
-                            _p(dapp_emb, "f32", True), _i(0 if dapp_emb is None else dapp_emb.shape[0])), "f2n_shade_bwd")
+                            _p(dapp_emb, "f32", True), _i(0 if dapp_emb is None else dapp_emb.shape[0]), _p(df0, "f32", True)),
+        "f2n_shade_bwd")
 
 
 # ---------------------------------------------------------------- ray generation
@@ -291,17 +292,19 @@ def march_noise(n, u, fineness, out):
     _ck(lib().f2n_march_noise(_stream(), _i(n), _p(u, "f32"), _f(fineness), _p(out, "f32")), "f2n_march_noise")
 
 
-def composite_fwd(n_rays, pts_se, feat, dt, t, rgb, bg, colors, disparity, depth, weights):
-    _ck(lib().f2n_composite_fwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _p(dt, "f32"), _p(t, "f32"),
-                                _p(rgb, "f32"), _p(bg, "f32"), _p(colors, "f32"), _p(disparity, "f32"), _p(depth, "f32"),
-                                _p(weights, "f32")), "f2n_composite_fwd")
+def composite_fwd(n_rays, pts_se, feat, dt, t, rgb, bg, colors, disparity, depth, weights, f0_stride=16):
+    """feat: the field output [M,16] (f0_stride 16, column 0 is read) or a compact density array [M] (f0_stride 1)."""
+    _ck(lib().f2n_composite_fwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _i(f0_stride), _p(dt, "f32"),
+                                _p(t, "f32"), _p(rgb, "f32"), _p(bg, "f32"), _p(colors, "f32"), _p(disparity, "f32"),
+                                _p(depth, "f32"), _p(weights, "f32")), "f2n_composite_fwd")
 
 
-def composite_bwd(n_rays, pts_se, feat, dt, t, rgb, bg, dcolors, ddisp, ddepth, dweights, gs_progress, drgb, dfeat):
-    _ck(lib().f2n_composite_bwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _p(dt, "f32"), _p(t, "f32"),
-                                _p(rgb, "f32"), _p(bg, "f32"), _p(dcolors, "f32", True), _p(ddisp, "f32", True),
+def composite_bwd(n_rays, pts_se, feat, dt, t, rgb, bg, dcolors, ddisp, ddepth, dweights, gs_progress, drgb, dfeat, f0_stride=16,
+                  df0_stride=16):
+    _ck(lib().f2n_composite_bwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _i(f0_stride), _p(dt, "f32"),
+                                _p(t, "f32"), _p(rgb, "f32"), _p(bg, "f32"), _p(dcolors, "f32", True), _p(ddisp, "f32", True),
                                 _p(ddepth, "f32", True), _p(dweights, "f32", True), _f(gs_progress), _p(drgb, "f32"),
-                                _p(dfeat, "f32")), "f2n_composite_bwd")
+                                _p(dfeat, "f32"), _i(df0_stride)), "f2n_composite_bwd")
 
 
 def weight_var_fwd(n_rays, weights, pts_se, out):

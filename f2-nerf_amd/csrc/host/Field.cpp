@@ -196,13 +196,14 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
 }  // namespace
 
 void Hash3DAnchored::ForwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& src_rows, int n_reuse,
-                                Tensor& feat, Tensor& saved_x) {
+                                Tensor& feat, Tensor& saved_x, Tensor* f0_cached) {
   const int n = points.size(0);
   const int n_cached = n_reuse, n_tail = n - n_cached;
   if (n_cached > 0) {
     TORCH_CHECK(prepass_x_.defined() && src_rows.numel() >= n_cached, "no pre-pass feature cache for this query");
     F2N_TIMED_CALL("field_fwd_cached", f2n_field_fwd_cached(CurStream(), n_cached, (int) prepass_x_.size(0), I32P(src_rows),
-                           VoidP(prepass_x_), VoidP(mlp_->params_h_), F32P(feat), nullptr, VoidP(saved_x)));
+                           VoidP(prepass_x_), VoidP(mlp_->params_h_), F32P(feat), f0_cached != nullptr ? F32P(*f0_cached) : nullptr,
+                           VoidP(saved_x)));
   }
   if (n_tail > 0)
     F2N_TIMED_CALL("field_fwd", f2n_field_fwd(CurStream(), n_tail, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),

@@ -22,8 +22,9 @@ class Hash3DAnchored : public Field {
   Tensor AnchoredQueryReuse(const Tensor& points, const Tensor& anchors, const Tensor& src_rows, int n_reuse);
   // The kernels behind the autograd node, callable directly (the fused train step does): feat [n,16] fp32 and
   // saved_x [n,32] h16 are written; BackwardRaw scatters into grad_h_ / mlp_->grad_scaled_.
+  // f0_cached (optional): compact density pre-activations [n_reuse] of the rows served from the pre-pass cache
   void ForwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& src_rows, int n_reuse, Tensor& feat,
-                  Tensor& saved_x);
+                  Tensor& saved_x, Tensor* f0_cached = nullptr);
   void BackwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& saved_x, const Tensor& dfeat);
 
   int LoadStates(const std::vector<Tensor>& states, int idx) override;

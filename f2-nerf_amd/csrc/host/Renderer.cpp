@@ -76,7 +76,7 @@ struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
     F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd(CurStream(), n, F32P(drgb), emb ? I32P(saved[1]) : nullptr, VoidP(sh->mlp_->params_h_),
                            VoidP(saved[0]), sh->mlp_->loss_scale_, F32P(dfeat), F32P(sh->mlp_->grad_scaled_),
                            (emb && emb_grad != nullptr) ? F32P(*emb_grad) : nullptr,
-                           (emb && emb_grad != nullptr) ? (int) emb_grad->size(0) : 0));
+                           (emb && emb_grad != nullptr) ? (int) emb_grad->size(0) : 0, nullptr));
     return {dfeat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
@@ -89,7 +89,7 @@ struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
     const int n_rays = se.size(0), m = feat.size(0);
     Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
     Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({m}, DevF32());
-    F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(CurStream(), n_rays, I32P(se), F32P(feat), F32P(dt), F32P(t), F32P(rgb), F32P(bg),
+    F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(CurStream(), n_rays, I32P(se), F32P(feat), F2N_MLP_OUT_PAD, F32P(dt), F32P(t), F32P(rgb), F32P(bg),
                                F32P(colors), F32P(disparity), F32P(depth), F32P(weights)));
     ctx->save_for_backward({feat, rgb, dt, t, bg, se});
     ctx->saved_data["gs"] = gs_progress;
@@ -102,10 +102,10 @@ struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
     Tensor gz = g[2].defined() ? g[2].contiguous() : Tensor(), gw = g[3].defined() ? g[3].contiguous() : Tensor();
     Tensor drgb = torch::zeros({m, 3}, DevF32());
     Tensor dfeat = torch::zeros({m, 16}, DevF32());
-    F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(CurStream(), n_rays, I32P(s[5]), F32P(s[0]), F32P(s[2]), F32P(s[3]), F32P(s[1]), F32P(s[4]),
+    F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(CurStream(), n_rays, I32P(s[5]), F32P(s[0]), F2N_MLP_OUT_PAD, F32P(s[2]), F32P(s[3]), F32P(s[1]), F32P(s[4]),
                                gc.defined() ? F32P(gc) : nullptr, gd.defined() ? F32P(gd) : nullptr,
                                gz.defined() ? F32P(gz) : nullptr, gw.defined() ? F32P(gw) : nullptr,
-                               (float) ctx->saved_data["gs"].toDouble(), F32P(drgb), F32P(dfeat)));
+                               (float) ctx->saved_data["gs"].toDouble(), F32P(drgb), F32P(dfeat), F2N_MLP_OUT_PAD));
     return {dfeat, drgb, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
@@ -398,7 +398,11 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
 
   // ---- forward ----
   Tensor feat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32()), field_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
-  field->ForwardRaw(fr.pts_all, fr.vol_all, 1, fr.src_rows, n_kept, feat, field_x);
+  // the density pre-activations of the surviving samples also leave as a compact array: compositing then reads 4 B per
+  // sample instead of one 64-byte line of `feat` per sample, and its backward writes a compact d f0 that the colour
+  // backward merges into the dfeat rows it writes anyway (column 0 written in place was a read-modify-write of every line)
+  Tensor f0c = torch::empty({std::max(n_kept, 1)}, DevF32()), df0c = torch::empty({std::max(n_kept, 1)}, DevF32());
+  field->ForwardRaw(fr.pts_all, fr.vol_all, 1, fr.src_rows, n_kept, feat, field_x, &f0c);
   field->prepass_x_ = Tensor();
   Tensor rgb = torch::empty({std::max(n_kept, 1), 3}, DevF32()), shade_x = torch::empty({std::max(n_kept, 1), 32}, DevF16());
   Tensor app = fr.emb ? app_emb_ : Tensor();
@@ -407,7 +411,7 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
   Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({std::max(n_kept, 1)}, DevF32());
   Tensor bg = fr.bg_color.contiguous();
-  F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(feat), F32P(es.dt), F32P(es.t), F32P(rgb),
+  F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
                              F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights)));
   Tensor var = torch::empty({n_rays}, DevF32());
   F2N_TIMED_CALL("weight_var_fwd", f2n_weight_var_fwd(st, n_rays, F32P(weights), I32P(es.pts_idx_bounds), F32P(var)));
@@ -422,13 +426,13 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   // ---- backward ----
   Tensor dweights = torch::empty({std::max(n_kept, 1)}, DevF32()), drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());
   F2N_TIMED_CALL("weight_var_bwd", f2n_weight_var_bwd(st, n_rays, F32P(weights), I32P(es.pts_idx_bounds), F32P(dvar), F32P(dweights)));
-  F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(feat), F32P(es.dt), F32P(es.t), F32P(rgb), F32P(bg),
+  F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb), F32P(bg),
                              F32P(dcolors), F32P(ddisp), nullptr, F32P(dweights), gdp->gradient_scaling_progress_, F32P(drgb),
-                             F32P(dfeat)));
+                             F32P(df0c), 1));
   F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd(st, n_kept, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
                          VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat),
                          F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,
-                         fr.emb ? (int) app_emb_grad_.size(0) : 0));
+                         fr.emb ? (int) app_emb_grad_.size(0) : 0, F32P(df0c)));
   field->BackwardRaw(fr.pts_all, fr.vol_all, 1, field_x, dfeat);
   out.colors = colors;
   out.has_samples = true;

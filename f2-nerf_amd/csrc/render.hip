@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void compact_kernel(int n_rays, const int32_t*
 }
 
 // Renderer.cpp:190-208 forward.
-__global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ feat,
-                                                            const float* __restrict__ dt, const float* __restrict__ t,
+__global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ f0,
+                                                            int f0_stride, const float* __restrict__ dt, const float* __restrict__ t,
                                                             const float* __restrict__ rgb, const float* __restrict__ bg,
                                                             float* __restrict__ colors, float* __restrict__ disparity,
                                                             float* __restrict__ depth, float* __restrict__ weights) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const in
     const bool in = i < e;
     float sec = 0.f, tt = 1.f, cr[3] = {0.f, 0.f, 0.f};
     if (in) {
-      sec = expf(feat[(size_t) i * 16] - F2N_DENSITY_SHIFT) * dt[i];
+      sec = expf(f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT) * dt[i];
       tt = t[i] + F2N_T_BIAS;
 #pragma unroll
       for (int k = 0; k < 3; k++) cr[k] = rgb[3 * (size_t) i + k];
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const in
 // CustomOps.cpp:15-18; GradientScaling backward CustomOps.cu:68-80) in two walks per ray: a forward walk to
 // rebuild T_i / w_i and the ray totals, and a reverse walk carrying the suffix sum of d(acc).  In the reverse walk
 // lane c of a row takes sample hi-1-c, so the left-to-right row chain runs over descending sample indices.
-__global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ feat,
-                                                            const float* __restrict__ dt, const float* __restrict__ t,
+__global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ f0,
+                                                            int f0_stride, const float* __restrict__ dt, const float* __restrict__ t,
                                                             const float* __restrict__ rgb, const float* __restrict__ bg,
                                                             const float* __restrict__ dcolors, const float* __restrict__ ddisparity,
                                                             const float* __restrict__ ddepth, const float* __restrict__ dweights,
-                                                            float gs_progress, float* __restrict__ drgb, float* __restrict__ dfeat) {
+                                                            float gs_progress, float* __restrict__ drgb, float* __restrict__ df0, int df0_stride) {
   const int c = threadIdx.x & 15;
   const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
     const bool in = i < e;
     float sec = 0.f, tt = 1.f;
     if (in) {
-      sec = expf(feat[(size_t) i * 16] - F2N_DENSITY_SHIFT) * dt[i];
+      sec = expf(f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT) * dt[i];
       tt = t[i] + F2N_T_BIAS;
     }
     const float incl = f2n_row_seq_scan(sec, acc, c);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
     const bool in = i >= s;
     float x = 0.f, dti = 0.f, sigma = 0.f, tt = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dwi = 0.f;
     if (in) {
-      x = feat[(size_t) i * 16] - F2N_DENSITY_SHIFT;
+      x = f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT;
       sigma = expf(x);
       dti = dt[i];
       tt = t[i] + F2N_T_BIAS;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
       drgb[3 * (size_t) i + 1] = g1;
       drgb[3 * (size_t) i + 2] = g2;
       // TruncExp backward: grad * exp(clamp(x, -100, 5))
-      dfeat[(size_t) i * 16] = d_sigma * expf(fminf(fmaxf(x, -100.f), 5.f));
+      df0[(size_t) i * df0_stride] = d_sigma * expf(fminf(fmaxf(x, -100.f), 5.f));
     }
   }
 }
@@ -387,17 +387,20 @@ int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_e
   return f2n_launch_status();
 }
 
-int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat, const float* dt,
+int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
                       const float* t, const float* rgb, const float* bg, float* colors, float* disparity, float* depth,
                       float* weights) {
-  F2N_ROW_LAUNCH(composite_fwd_kernel, n_rays, pts_start_end, feat, dt, t, rgb, bg, colors, disparity, depth, weights);
+  if (f0_stride < 1) return F2N_ERR_INVALID_ARG;
+  F2N_ROW_LAUNCH(composite_fwd_kernel, n_rays, pts_start_end, f0, f0_stride, dt, t, rgb, bg, colors, disparity, depth, weights);
 }
 
-int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat, const float* dt,
+int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
                       const float* t, const float* rgb, const float* bg, const float* dcolors, const float* ddisparity,
-                      const float* ddepth, const float* dweights, float grad_scaling_progress, float* drgb, float* dfeat) {
-  F2N_ROW_LAUNCH(composite_bwd_kernel, n_rays, pts_start_end, feat, dt, t, rgb, bg, dcolors, ddisparity, ddepth, dweights,
-                 grad_scaling_progress, drgb, dfeat);
+                      const float* ddepth, const float* dweights, float grad_scaling_progress, float* drgb, float* df0,
+                      int df0_stride) {
+  if (f0_stride < 1 || df0_stride < 1) return F2N_ERR_INVALID_ARG;
+  F2N_ROW_LAUNCH(composite_bwd_kernel, n_rays, pts_start_end, f0, f0_stride, dt, t, rgb, bg, dcolors, ddisparity, ddepth, dweights,
+                 grad_scaling_progress, drgb, df0, df0_stride);
 }
 
 int f2n_weight_var_fwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, float* out_vars) {

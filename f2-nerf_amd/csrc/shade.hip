@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
                                                         const half_t* __restrict__ params, const half_t* __restrict__ x_h,
                                                         float loss_scale, float* __restrict__ dfeat,
                                                         float* __restrict__ dparams, int n_emb,
-                                                        float* __restrict__ emb_partials) {
+                                                        float* __restrict__ emb_partials, const float* __restrict__ df0) {
   __shared__ F2nShadeSmem sm;
   extern __shared__ float s_emb[];  // [n_emb * 16] per-block appearance-embedding gradient (ds_add_f32)
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
     half8_t xf;
     float d[3];
     int img;
+    float df0;  // the density path's gradient of dfeat[:,0] (compact array from f2n_composite_bwd), merged into the row store
   };
   auto fetch = [&](int sb, int half, In& o) {
     const int s = sb * 32 + half * 16 + c;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
 #pragma unroll
     for (int r = 0; r < 3; r++) o.d[r] = drgb[3 * (size_t) sc + r];
     o.img = do_emb ? sample_emb_idx[sc] : -1;
+    o.df0 = df0 != nullptr ? df0[sc] : 0.f;
   };
   In cur[2];
   if (wave_global < n_super) {
@@ -193,7 +195,11 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
       for (int r = 0; r < 4; r++) dsf[r] = valid ? hb[half].dxT[0][r] * inv_scale : 0.f;
       if (valid) {
         float* p = dfeat + (size_t) s * F2N_D_OUT + 4 * g;
-        if (g == 0) {  // column 0 belongs to the density path (constant-1 shading input)
+        if (g == 0 && df0 != nullptr) {  // column 0 belongs to the density path (constant-1 shading input): merged here
+          float4_t row = dsf;  // (dsf[0] itself still feeds the appearance-embedding gradient below)
+          row[0] = cur[half].df0;
+          *(float4_t*) p = row;
+        } else if (g == 0) {  // ... or left untouched for whoever writes it in place
           p[1] = dsf[1];
           p[2] = dsf[2];
           p[3] = dsf[3];
@@ -270,7 +276,7 @@ int f2n_shade_fwd(void* stream, int n, const float* feat, const float* dirs, con
 
 int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
                   const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled, float* dapp_emb,
-                  int n_emb) {
+                  int n_emb, const float* df0) {
   if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1)) || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
   if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 57 KB of weights / reduction images
@@ -296,7 +302,7 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
     }
   }
   hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(256), dyn_lds, (hipStream_t) stream, n, drgb, sample_emb_idx,
-                     (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat, partials, n_emb, emb_partials);
+                     (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat, partials, n_emb, emb_partials, df0);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   rc = f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);

@@ -270,12 +270,13 @@ int f2n_shade_fwd(void* stream, int n, const float* feat /*[n,16]*/, const float
                   const float* app_emb /*[n_img,16] or NULL*/, const int32_t* sample_emb_idx /*[n] or NULL*/,
                   const void* mlp_params_h, float* rgb /*[n,3]*/, void* save_x_h);
 
-/* drgb [n,3] -> dfeat[:,1:16] written (column 0 is left untouched: it belongs to the density path),
- * dparams accumulated (scaled domain), dapp_emb [n_img,16] accumulated UNSCALED (fp32 atomics) or NULL.
+/* drgb [n,3] -> dfeat[:,1:16] written; column 0 belongs to the density path: left untouched when df0 is NULL, or
+ * filled from the compact array df0 [n] (f2n_composite_bwd with df0_stride 1) so that every dfeat row is written once,
+ * as whole cache lines.  dparams accumulated (scaled domain), dapp_emb [n_img,16] accumulated UNSCALED or NULL.
  * The network output needed for the sigmoid derivative is recomputed from saved_x_h on the matrix cores. */
 int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
                   const void* saved_x_h, float loss_scale, float* dfeat /*[n,16]*/, float* dparams_f32_scaled,
-                  float* dapp_emb /*[n_emb,16] or NULL*/, int n_emb);
+                  float* dapp_emb /*[n_emb,16] or NULL*/, int n_emb, const float* df0 /*[n] or NULL*/);
 
 /* ---------------------------------------------------------------------------------------------------
  * Renderer -- replaces the per-ray glue of Renderer::Render (Renderer/Renderer.cpp:105-208), i.e.
@@ -307,18 +308,20 @@ int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_e
 
 /* Compositing (Renderer.cpp:196-208): colors = sum w*c + T_last*bg, disparity = sum w/(t+.01),
  * depth = sum w*(t+.01) / (1 - T_last + 1e-4); weights [M] is also returned (RenderResult, Renderer.h:18-27).
- * f0 of sample i = feat[i*16]. */
-int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat /*[M,16]*/,
+ * f0 of sample i = f0[i * f0_stride]: stride 16 reads column 0 of the field output [M,16] as the reference does,
+ * stride 1 reads a compact density array (f2n_field_fwd*'s out_f0: a quarter of the cache lines). */
+int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride,
                       const float* dt, const float* t, const float* rgb /*[M,3]*/, const float* bg /*[R,3]*/,
                       float* colors /*[R,3]*/, float* disparity /*[R]*/, float* depth /*[R]*/, float* weights /*[M]*/);
 
 /* Backward of the above through TruncExp; gradient scaling (CustomOps.cu:68-80) is applied to dsigma and
  * drgb when grad_scaling_progress < 1.  Any of dcolors/ddisparity/ddepth/dweights may be NULL (= zero).
- * Writes drgb [M,3] and dfeat[:,0] (dfeat [M,16], other columns untouched). */
-int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* feat, const float* dt,
-                      const float* t, const float* rgb, const float* bg, const float* dcolors,
+ * Writes drgb [M,3] and d f0: df0[i * df0_stride] (stride 16 = column 0 of dfeat [M,16], other columns untouched;
+ * stride 1 = a compact array that f2n_shade_bwd merges into the dfeat rows it writes anyway). */
+int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride,
+                      const float* dt, const float* t, const float* rgb, const float* bg, const float* dcolors,
                       const float* ddisparity, const float* ddepth, const float* dweights,
-                      float grad_scaling_progress, float* drgb, float* dfeat);
+                      float grad_scaling_progress, float* drgb, float* df0, int df0_stride);
 
 /* WeightVarLoss forward/backward (CustomOps.cu:12-66). */
 int f2n_weight_var_fwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, float* out_vars);

@@ -619,6 +619,14 @@ def test_shade_fused_forward_backward(hip, fox_golden, n_emb):
     assert np.abs(N(dparams) / F32(128.) - rdp).max() <= 4e-3 * np.abs(rdp).max() + 1e-8
     if use_emb:
         assert np.abs(N(demb) - rdemb).max() <= 4e-3 * np.abs(rdemb).max() + 1e-8
+    # column 0 merged from a compact array instead of left untouched: same rows otherwise
+    df0 = torch.from_numpy(rng.standard_normal(n).astype(F32)).to(DEV)
+    dfeat2 = torch.full((n, 16), 7.0, device=DEV)
+    demb2 = torch.zeros((n_emb, 16), device=DEV) if use_emb else None
+    hip.shade_bwd(n, T(drgb), d_sidx, ph, sx, 128.0, dfeat2, torch.zeros(params.size, device=DEV), demb2, df0=df0)
+    assert_same(N(dfeat2)[:, 0].copy(), N(df0)); assert_same(N(dfeat2)[:, 1:].copy(), gdf[:, 1:].copy())
+    if use_emb:  # the embedding gradient's column 0 is the shading input's gradient, not the merged density gradient
+        assert np.abs(N(demb2) - rdemb).max() <= 4e-3 * np.abs(rdemb).max() + 1e-8
 
 
 def test_sh_encode(hip, fox_golden):
@@ -738,6 +746,16 @@ def test_composite_forward_backward(hip, gs):
     assert np.abs(N(drgb) - rdrgb).max() <= 1e-5 * max(1.0, np.abs(rdrgb).max())
     assert np.abs(N(dfeat)[:, 0] - rdf0).max() <= 2e-4 * max(1.0, np.abs(rdf0).max()), np.abs(N(dfeat)[:, 0] - rdf0).max()
     assert (N(dfeat)[:, 1:] == 5.0).all()
+    # compact density arrays (stride 1) in and out: bit-identical to the strided column-0 accesses
+    f0c = T(np.ascontiguousarray(feat[:, 0]))
+    col2 = torch.zeros((R, 3), device=DEV); disp2 = torch.zeros(R, device=DEV); dep2 = torch.zeros(R, device=DEV)
+    wts2 = torch.zeros(n, device=DEV)
+    hip.composite_fwd(R, T(se), f0c, T(dt), T(t), T(rgb), T(bg), col2, disp2, dep2, wts2, f0_stride=1)
+    assert_same(N(col2), N(col)); assert_same(N(disp2), N(disp)); assert_same(N(dep2), N(dep)); assert_same(N(wts2), N(wts))
+    drgb2 = torch.zeros((n, 3), device=DEV); df0c = torch.zeros(n, device=DEV)
+    hip.composite_bwd(R, T(se), f0c, T(dt), T(t), T(rgb), T(bg), T(dcol), T(ddisp), T(ddep), T(dw), gs, drgb2, df0c, f0_stride=1,
+                      df0_stride=1)
+    assert_same(N(drgb2), N(drgb)); assert_same(N(df0c), N(dfeat)[:, 0].copy())
     # empty batch and NULL gradient inputs are accepted
     hip.composite_bwd(R, T(se), T(feat), T(dt), T(t), T(rgb), T(bg), T(dcol), None, None, None, 1.0, drgb, dfeat)
     rdrgb2, _ = op.composite_bwd(ref["ctx"], dt, rgb, bg, se, dcol)
