@@ -559,8 +559,9 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Backward: MLP backward (recompute + both orientations, mlp_dev.h) chained into the hash scatter.
-// One wave handles 32-sample super-blocks (two 16-sample halves) so that the weight-gradient contraction
-// over samples fills a K = 32 MFMA.
+// One wave handles 16-sample tiles; the weight gradients contract a tile's 16 samples with K = 16 MFMAs
+// (v_mfma_f32_16x16x16_f16), so nothing but the accumulators is carried between tiles and the register budget allows
+// two or three resident blocks per CU.
 // ---------------------------------------------------------------------------------------------------
 #define F2N_BWD_THREADS 256
 
@@ -570,8 +571,10 @@ union F2nBwdSmem {
   float acc[2 * (F2N_D_HID * F2N_D_IN + (NH == 2 ? F2N_D_HID * F2N_D_HID : 0) + F2N_D_OUT * F2N_D_HID)];  // two images, see f2n_mlp_flush_dw
 };
 
-template <int NH, bool DO_HASH>
-__global__ __launch_bounds__(F2N_BWD_THREADS, (NH == 1 ? 2 : 1)) void field_bwd_kernel(
+// HASH: 0 = MLP only (dL/dx to fp32), 1 = chained into the packed-f16 atomic scatter (small batches), 2 = dL/dx leaves as
+// f16 planes + non-zero mask for the owner-binned scatter.  BPC = resident blocks per CU the register budget is cut for.
+template <int NH, int HASH, int BPC>
+__global__ __launch_bounds__(F2N_BWD_THREADS, BPC) void field_bwd_kernel(
     int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
     const int32_t* __restrict__ volume_idx, int vol_stride, const half_t* __restrict__ params,
@@ -581,77 +584,72 @@ __global__ __launch_bounds__(F2N_BWD_THREADS, (NH == 1 ? 2 : 1)) void field_bwd_
   __shared__ F2nBwdSmem<NH> sm;
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
-  if (DO_HASH) f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+  if (HASH == 1) f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
   f2n_mlp_lds_fill<NH>(sm.w, params, tid, F2N_BWD_THREADS);
   __syncthreads();
   const half8_t idf[2] = {f2n_identity_frag(0, c, g), f2n_identity_frag(1, c, g)};
   F2nMlpGradAcc<NH> acc;
   acc.zero();
-  const int n_super = (n + 31) / 32;
   const int wave_global = blockIdx.x * (F2N_BWD_THREADS / 64) + (tid >> 6);
   const int wave_stride = gridDim.x * (F2N_BWD_THREADS / 64);
   const float inv_scale = 1.f / loss_scale;
-  // Inputs are fetched one super-block ahead into registers (see shade_bwd_kernel: with one or two waves per SIMD a load
-  // issued at its point of use exposes its whole latency).
+  // One 16-sample tile per round, the next tile's inputs in flight in registers (see shade_bwd_kernel: with one or two
+  // waves per SIMD a load issued at its point of use exposes its whole latency).
   struct In {
     half8_t xf;
     float4_t d4;
   };
-  auto fetch = [&](int sb, int half, In& o) {
-    const int s = sb * 32 + half * 16 + c;
+  auto fetch = [&](int tile, In& o) {
+    const int s = tile * 16 + c;
     const int sc = s < n ? s : n - 1;
     o.xf = (x_h != nullptr) ? f2n_load_xfrag_h(x_h, sc, g, true) : f2n_load_xfrag_f32(x_f32, sc, g, true);
     o.d4 = *(const float4_t*) (dy + (size_t) sc * F2N_D_OUT + 4 * g);
   };
-  In cur[2];
-  if (wave_global < n_super) {
-    fetch(wave_global, 0, cur[0]);
-    fetch(wave_global, 1, cur[1]);
-  }
-  for (int sb = wave_global; sb < n_super; sb += wave_stride) {
-    In nxt[2];
-    {
-      const int sbn = sb + wave_stride < n_super ? sb + wave_stride : sb;  // last round: a harmless re-read
-      fetch(sbn, 0, nxt[0]);
-      fetch(sbn, 1, nxt[1]);
-    }
+  const int n_tiles = (n + 15) / 16;
+  In cur;
+  if (wave_global < n_tiles) fetch(wave_global, cur);
+  for (int tile = wave_global; tile < n_tiles; tile += wave_stride) {
+    In nxt;
+    fetch(tile + wave_stride < n_tiles ? tile + wave_stride : tile, nxt);  // last round: a harmless re-read
     __builtin_amdgcn_sched_barrier(0);
-    F2nHalfBwd<NH> hb[2];
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const int s = sb * 32 + half * 16 + c;
+    {
+      F2nHalfBwd<NH> hb;
+      int lds_off = 0;  // weight fragments are read from LDS where they are used, not hoisted (see shade_bwd_kernel)
+      asm volatile("" : "+v"(lds_off));
+      const F2nMlpLds<NH>& wl = *(const F2nMlpLds<NH>*) ((const char*) &sm.w + lds_off);
+      const int s = tile * 16 + c;
       const bool valid = s < n;
       const int sc = valid ? s : n - 1;
-      const half8_t xf = valid ? cur[half].xf : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      const half8_t xf = valid ? cur.xf : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
       half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int r = 0; r < 4; r++)  // f16 cast by autograd, then *scale (TCNNWP.cpp:174)
-        dyf[r] = valid ? (half_t) ((float) (half_t) cur[half].d4[r] * loss_scale) : (half_t) 0.f;
-      f2n_mlp_half_bwd<NH, 2>(sm.w, xf, [&](half8_t, half8_t) { return dyf; }, idf, c, g, hb[half]);
+        dyf[r] = valid ? (half_t) ((float) (half_t) cur.d4[r] * loss_scale) : (half_t) 0.f;
+      f2n_mlp_half_bwd<NH, 2>(wl, xf, [&](half8_t, half8_t) { return dyf; }, idf, c, g, hb);
       if (valid) {
         if (dx_f32 != nullptr) {
 #pragma unroll
           for (int ft = 0; ft < 2; ft++) {
             float4_t v;
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = hb[half].dxT[ft][r] * inv_scale;  // TCNNWP.cpp:231
+            for (int r = 0; r < 4; r++) v[r] = hb.dxT[ft][r] * inv_scale;  // TCNNWP.cpp:231
             *(float4_t*) (dx_f32 + (size_t) s * F2N_D_IN + 16 * ft + 4 * g) = v;
           }
         }
       }
-      if (DO_HASH) {
-        half8_t gx = f2n_pack<false>(hb[half].dxT[0], hb[half].dxT[1]);  // (dL/dx * 128) -> f16, Hash3DAnchored.cu:220
-        if (dx_planes != nullptr) {  // large batches: the owner-binned scatter consumes f16 planes [8][n][4]
+      if (HASH != 0) {
+        half8_t gx = f2n_pack<false>(hb.dxT[0], hb.dxT[1]);  // (dL/dx * 128) -> f16, Hash3DAnchored.cu:220
+        if (HASH == 2) {  // large batches: the owner-binned scatter consumes f16 planes [8][n][4]
           bool nz = false;
 #pragma unroll
           for (int e = 0; e < 8; e++) nz |= (float) gx[e] != 0.f;
-          const unsigned long long bal = __ballot(nz && valid);  // bit 16g + c: lane (c, g) of this half
+          const unsigned long long bal = __ballot(nz && valid);  // bit 16g + c: lane (c, g) of this tile
           if (valid) {
             *(half4_t*) (dx_planes + ((size_t) g * n + s) * 4) = __builtin_shufflevector(gx, gx, 0, 1, 2, 3);
             *(half4_t*) (dx_planes + ((size_t) (4 + g) * n + s) * 4) = __builtin_shufflevector(gx, gx, 4, 5, 6, 7);
           }
-          if (lane == 0 && sb * 32 + half * 16 < n)  // one 16-bit word per half: sample c has a non-zero gradient
-            nz_mask[sb * 2 + half] = (uint16_t) ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull);
+          if (lane == 0)  // one 16-bit word per tile: sample c has a non-zero gradient
+            nz_mask[tile] = (uint16_t) ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull);
         } else {  // every lane takes part in the row-level combining; out-of-range samples carry zero gradient
           float p01[3];
           f2n_load_point(pts, sc, pts_are_warped != 0, p01);
@@ -660,10 +658,9 @@ __global__ __launch_bounds__(F2N_BWD_THREADS, (NH == 1 ? 2 : 1)) void field_bwd_
           f2n_scatter_frag(h, lt, grad_table, p01, vol, g, c, gx);
         }
       }
+      f2n_mlp_accumulate_dw_half<NH>(hb, acc);
     }
-    f2n_mlp_accumulate_dw<NH>(hb[0], hb[1], acc);
-    cur[0] = nxt[0];
-    cur[1] = nxt[1];
+    cur = nxt;
   }
   __syncthreads();  // everyone is done with the LDS weights: reuse the space for the block reduction
   f2n_mlp_flush_dw<NH>(acc, sm.acc, dparams, c, g, tid, F2N_BWD_THREADS);
@@ -840,15 +837,16 @@ int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float
   if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
-  const dim3 grid(f2n_bwd_grid((n + 31) / 32, n_hidden == 1 ? 2 : 1)), block(F2N_BWD_THREADS);
+  // resident blocks per CU by register budget: the one-hidden-layer kernel needs ~150 registers (3), the two-layer one 244 (2)
+  const dim3 grid(f2n_bwd_grid((n + 31) / 32, n_hidden == 1 ? 3 : 2)), block(F2N_BWD_THREADS);
   const int n_params = f2n_mlp_n_params(d_in, d_hidden, n_hidden);
   float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) grid.x * n_params);
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_hidden == 1)
-    hipLaunchKernelGGL((field_bwd_kernel<1, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((field_bwd_kernel<1, 0, 3>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
                        0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr);
   else
-    hipLaunchKernelGGL((field_bwd_kernel<2, false>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((field_bwd_kernel<2, 0, 2>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
                        0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
@@ -930,22 +928,27 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
     return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
-  const unsigned blocks = f2n_bwd_grid((n + 31) / 32, 2);  // the NH = 1 kernel fits two blocks per CU (256 registers)
+  const bool bins = f2n_use_bins(n, level_entries);
+  const unsigned blocks = f2n_bwd_grid((n + 31) / 32, bins ? 3 : 2);  // 154 / 186 registers: three / two resident blocks per CU
   const int n_params = f2n_mlp_n_params(F2N_D_IN, F2N_D_HID, 1);
   float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) blocks * n_params);
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   half_t* dx_planes = nullptr;
   uint16_t* nz_mask = nullptr;
-  if (f2n_use_bins(n, level_entries)) {  // planes [8][n][4] followed by one non-zero bit per sample
+  if (bins) {  // planes [8][n][4] followed by one non-zero bit per sample
     const size_t plane_bytes = sizeof(half_t) * 32 * (size_t) n;
     dx_planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, plane_bytes + sizeof(uint16_t) * ((size_t) n / 16 + 2));
     if (dx_planes == nullptr) return F2N_ERR_INVALID_ARG;
     nz_mask = (uint16_t*) ((char*) dx_planes + plane_bytes);
   }
-  hipLaunchKernelGGL((field_bwd_kernel<1, true>), dim3(blocks), dim3(F2N_BWD_THREADS), 0,
-                     (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                     (const half_t*) mlp_params_h, (const half_t*) saved_x_h, nullptr, dfeat, loss_scale,
-                     partials, nullptr, (half_t*) grad_table_h, dx_planes, nz_mask);
+#define F2N_LAUNCH_FIELD_BWD(HASH, BPC)                                                                                      \
+  hipLaunchKernelGGL((field_bwd_kernel<1, HASH, BPC>), dim3(blocks), dim3(F2N_BWD_THREADS), 0, (hipStream_t) stream, n, h,  \
+                     local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, (const half_t*) mlp_params_h, \
+                     (const half_t*) saved_x_h, nullptr, dfeat, loss_scale, partials, nullptr, (half_t*) grad_table_h,       \
+                     dx_planes, nz_mask)
+  if (!bins) F2N_LAUNCH_FIELD_BWD(1, 2);
+  else F2N_LAUNCH_FIELD_BWD(2, 3);
+#undef F2N_LAUNCH_FIELD_BWD
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   if (dx_planes != nullptr) {  // planes [8][n][4]: pair (l, ch) at (l>>1)*4n + 4*s + 2*(l&1) + ch

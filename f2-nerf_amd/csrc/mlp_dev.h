@@ -324,6 +324,35 @@ __device__ __forceinline__ void f2n_mlp_accumulate_dw(const F2nHalfBwd<NH>& a, c
   }
 }
 
+// Weight-gradient MFMAs of ONE 16-sample half: v_mfma_f32_16x16x16_f16 contracts exactly the 16 samples a half's
+// sample-row tiles hold (lane (c = neuron, g): samples 4g..4g+3 = K-slots 4g..4g+3 of both operands), so a half's tiles
+// are consumed as soon as they exist instead of being held until its partner half is done (K = 32 needs both): ~40
+// fewer live registers in the backward loops.
+__device__ __forceinline__ float4_t f2n_mfma16(half4_t a, half4_t b, float4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+
+template <int NH>
+__device__ __forceinline__ void f2n_mlp_accumulate_dw_half(const F2nHalfBwd<NH>& a, F2nMlpGradAcc<NH>& acc) {
+#pragma unroll
+  for (int t = 0; t < 4; t++) acc.dwo[t] = f2n_mfma16(a.dyR, a.hlR[t], acc.dwo[t]);
+  if (NH == 2) {
+#pragma unroll
+    for (int to = 0; to < 4; to++)
+#pragma unroll
+      for (int ti = 0; ti < 4; ti++) acc.dw1[to * 4 + ti] = f2n_mfma16(a.glR[to], a.h0R[ti], acc.dw1[to * 4 + ti]);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int ft = 0; ft < 2; ft++) acc.dw0[t * 2 + ft] = f2n_mfma16(a.g0R[t], a.xR[ft], acc.dw0[t * 2 + ft]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int ft = 0; ft < 2; ft++) acc.dw0[t * 2 + ft] = f2n_mfma16(a.glR[t], a.xR[ft], acc.dw0[t * 2 + ft]);
+  }
+}
+
 // Block-level reduction of the per-wave accumulators through LDS, then the block's partial parameter gradient is
 // written with plain coalesced stores to partials[blockIdx.x][n_params]; f2n_reduce_partials sums the blocks afterwards.
 // The waves take turns on the LDS image with plain read-add-write (wave 0 stores): ds_add_f32 runs at 0.33 lane-ops/clk

@@ -109,7 +109,7 @@ union F2nShadeSmem {
   float acc[2 * (F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID)];  // two images, see f2n_mlp_flush_dw
 };
 
-__global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __restrict__ drgb,
+__global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* __restrict__ drgb,
                                                         const int32_t* __restrict__ sample_emb_idx,
                                                         const half_t* __restrict__ params, const half_t* __restrict__ x_h,
                                                         float loss_scale, float* __restrict__ dfeat,
@@ -129,21 +129,23 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
   const half8_t wo[2] = {f2n_rowfrag(po, F2N_D_HID, c, 0, g), f2n_rowfrag(po, F2N_D_HID, c, 32, g)};
   F2nMlpGradAcc<2> acc;
   acc.zero();
-  const int n_super = (n + 31) / 32;
   const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
   const float inv_scale = 1.f / loss_scale;
   const float4_t z = {0.f, 0.f, 0.f, 0.f};
-  // Per-sample inputs are fetched one super-block AHEAD into registers: this kernel runs one wave per SIMD (it owns the
-  // register file), so a load issued where its value is needed exposes its whole latency -- three dependent round trips
-  // per half (x, d rgb, image index) were ~80 % of the kernel's time.
+  // Per-sample inputs are fetched one tile AHEAD into registers: with two waves per SIMD a load issued where its value
+  // is needed exposes most of its latency -- three dependent round trips per tile (x, d rgb, image index) were ~80 % of
+  // the first version's time.  Register budget (254 per lane, two resident blocks per CU): 112 weight-gradient
+  // accumulators, one tile's fragments, nothing hoisted -- a lone wave issues one instruction per ~4 cycles whatever the
+  // SIMD could take, so the second resident wave is worth more than anything a 512-register body can keep in registers
+  // (measured: 0.121 -> 0.097 ms for 8e5 samples, tools/mlp_bwd_bench.py).
   struct In {
     half8_t xf;
     float d[3];
     int img;
     float df0;  // the density path's gradient of dfeat[:,0] (compact array from f2n_composite_bwd), merged into the row store
   };
-  auto fetch = [&](int sb, int half, In& o) {
-    const int s = sb * 32 + half * 16 + c;
+  auto fetch = [&](int tile, In& o) {
+    const int s = tile * 16 + c;
     const int sc = s < n ? s : n - 1;  // always in range: no branch around the loads
     o.xf = f2n_rowfrag(x_h, F2N_D_IN, sc, 0, g);
 #pragma unroll
@@ -151,26 +153,26 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
     o.img = do_emb ? sample_emb_idx[sc] : -1;
     o.df0 = df0 != nullptr ? df0[sc] : 0.f;
   };
-  In cur[2];
-  if (wave_global < n_super) {
-    fetch(wave_global, 0, cur[0]);
-    fetch(wave_global, 1, cur[1]);
-  }
-  for (int sb = wave_global; sb < n_super; sb += wave_stride) {
-    In nxt[2];
-    {
-      const int sbn = sb + wave_stride < n_super ? sb + wave_stride : sb;  // last round: a harmless re-read
-      fetch(sbn, 0, nxt[0]);
-      fetch(sbn, 1, nxt[1]);
-    }
+  // One 16-sample tile per round (the weight gradients contract a tile's 16 samples with K = 16 MFMAs, so nothing is
+  // carried from one tile to the next but the accumulators), the next tile's inputs in flight.
+  const int n_tiles = (n + 15) / 16;
+  In cur;
+  if (wave_global < n_tiles) fetch(wave_global, cur);
+  for (int tile = wave_global; tile < n_tiles; tile += wave_stride) {
+    In nxt;
+    fetch(tile + wave_stride < n_tiles ? tile + wave_stride : tile, nxt);  // last round: a harmless re-read
     __builtin_amdgcn_sched_barrier(0);  // keep the loads up here; their s_waitcnt lands at the bottom of the round
-    F2nHalfBwd<2> hb[2];
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const int s = sb * 32 + half * 16 + c;
+    {
+      F2nHalfBwd<2> hb;
+      // the weight fragments are re-read from LDS where they are used: an address the compiler cannot prove loop-invariant
+      // keeps it from hoisting ~100 registers of fragments out of the loop (and then spilling them)
+      int lds_off = 0;
+      asm volatile("" : "+v"(lds_off));
+      const F2nMlpLds<2>& wl = *(const F2nMlpLds<2>*) ((const char*) &sm.w + lds_off);
+      const int s = tile * 16 + c;
       const bool valid = s < n;
-      const half8_t xf = valid ? cur[half].xf : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      const float d0 = cur[half].d[0], d1 = cur[half].d[1], d2 = cur[half].d[2];
+      const half8_t xf = valid ? cur.xf : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      const float d0 = cur.d[0], d1 = cur.d[1], d2 = cur.d[2];
       // d(rgb)/d(o) needs the network output o: computed inside the backward's own forward recomputation from the
       // last hidden layer's activations (no second forward chain)
       auto dy_fn = [&](half8_t h0, half8_t h1) {
@@ -188,16 +190,16 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
         }
         return dyf;
       };
-      f2n_mlp_half_bwd<2, 1>(sm.w, xf, dy_fn, idf, c, g, hb[half]);
+      f2n_mlp_half_bwd<2, 1>(wl, xf, dy_fn, idf, c, g, hb);
       // d(shading_feat) = dX[:, 0:16]: lane (c = sample, g) holds features 4g..4g+3
       float4_t dsf;
 #pragma unroll
-      for (int r = 0; r < 4; r++) dsf[r] = valid ? hb[half].dxT[0][r] * inv_scale : 0.f;
+      for (int r = 0; r < 4; r++) dsf[r] = valid ? hb.dxT[0][r] * inv_scale : 0.f;
       if (valid) {
         float* p = dfeat + (size_t) s * F2N_D_OUT + 4 * g;
         if (g == 0 && df0 != nullptr) {  // column 0 belongs to the density path (constant-1 shading input): merged here
           float4_t row = dsf;  // (dsf[0] itself still feeds the appearance-embedding gradient below)
-          row[0] = cur[half].df0;
+          row[0] = cur.df0;
           *(float4_t*) p = row;
         } else if (g == 0) {  // ... or left untouched for whoever writes it in place
           p[1] = dsf[1];
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
       }
       if (do_emb) {
         // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples, accumulated in LDS.  The 16 samples
-        // of one wave half usually share a ray, hence an image: reduce across the 16 sample lanes first.
-        const int img = valid ? cur[half].img : -1;
+        // of a tile usually share a ray, hence an image: reduce across the 16 sample lanes first.
+        const int img = valid ? cur.img : -1;
         // sample 0's image, without an LDS round trip: every row of 16 lanes holds the same 16 samples
         const int img0 = __builtin_amdgcn_readfirstlane(img);
         const bool uniform = __all(img == img0);
@@ -227,10 +229,9 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(int n, const float* __re
           for (int r = 0; r < 4; r++) atomicAdd(&s_emb[img * 16 + 4 * g + r], dsf[r]);
         }
       }
+      f2n_mlp_accumulate_dw_half<2>(hb, acc);
     }
-    f2n_mlp_accumulate_dw<2>(hb[0], hb[1], acc);
-    cur[0] = nxt[0];
-    cur[1] = nxt[1];
+    cur = nxt;
   }
   __syncthreads();
   f2n_mlp_flush_dw<2>(acc, sm.acc, dparams, c, g, tid, 256);
@@ -282,7 +283,7 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
   if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 57 KB of weights / reduction images
   if (n == 0) return F2N_OK;
   unsigned blocks = f2n_shade_grid((n + 31) / 32, 4);
-  if (blocks > 256) blocks = 256;  // one resident block per CU (the kernel owns the whole register file)
+  if (blocks > 512) blocks = 512;  // two resident blocks per CU (254 registers per lane)
   const int n_params = F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID;
   float* partials = (float*) f2n_ws_get(F2N_WS_SHADE_DW, sizeof(float) * (size_t) blocks * n_params);
   float* emb_partials = nullptr;
