@@ -287,43 +287,6 @@ __device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t
   out.xR[1] = f2n_cvt4<false>(f2n_mfma(xf, idf[1], z));
 }
 
-// Weight-gradient MFMAs over one 32-sample super-block (halves a and b supply K-slots 0..3 / 4..7).
-template <int NH>
-__device__ __forceinline__ void f2n_mlp_accumulate_dw(const F2nHalfBwd<NH>& a, const F2nHalfBwd<NH>& b, F2nMlpGradAcc<NH>& acc) {
-  const half8_t dyT = f2n_cat(a.dyR, b.dyR);
-  half8_t hlT[4], glT[4], xT[2];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    hlT[t] = f2n_cat(a.hlR[t], b.hlR[t]);
-    glT[t] = f2n_cat(a.glR[t], b.glR[t]);
-  }
-  xT[0] = f2n_cat(a.xR[0], b.xR[0]);
-  xT[1] = f2n_cat(a.xR[1], b.xR[1]);
-#pragma unroll
-  for (int t = 0; t < 4; t++) acc.dwo[t] = f2n_mfma(dyT, hlT[t], acc.dwo[t]);
-  if (NH == 2) {
-    half8_t h0T[4], g0T[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      h0T[t] = f2n_cat(a.h0R[t], b.h0R[t]);
-      g0T[t] = f2n_cat(a.g0R[t], b.g0R[t]);
-    }
-#pragma unroll
-    for (int to = 0; to < 4; to++)
-#pragma unroll
-      for (int ti = 0; ti < 4; ti++) acc.dw1[to * 4 + ti] = f2n_mfma(glT[to], h0T[ti], acc.dw1[to * 4 + ti]);
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-      for (int ft = 0; ft < 2; ft++) acc.dw0[t * 2 + ft] = f2n_mfma(g0T[t], xT[ft], acc.dw0[t * 2 + ft]);
-  } else {
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-      for (int ft = 0; ft < 2; ft++) acc.dw0[t * 2 + ft] = f2n_mfma(glT[t], xT[ft], acc.dw0[t * 2 + ft]);
-  }
-}
-
 // Weight-gradient MFMAs of ONE 16-sample half: v_mfma_f32_16x16x16_f16 contracts exactly the 16 samples a half's
 // sample-row tiles hold (lane (c = neuron, g): samples 4g..4g+3 = K-slots 4g..4g+3 of both operands), so a half's tiles
 // are consumed as soon as they exist instead of being held until its partner half is done (K = 32 needs both): ~40
