@@ -339,6 +339,11 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
       out_const = __float_as_uint(rays_d[3 * ray + (j - 8)]);
     }
   }
+  // role masks: the emitted word is an AND/OR blend of the candidates (a `j == k ? ... : ...` ladder compiles to a
+  // divergent branch tree of ~50 issue slots per step, and a lone wave pays ~4 cycles for every slot)
+  const uint32_t m_w0 = j == 0 ? ~0u : 0u, m_w1 = j == 1 ? ~0u : 0u, m_w2 = j == 2 ? ~0u : 0u, m_t = j == 3 ? ~0u : 0u;
+  const uint32_t m_dt = j == 4 ? ~0u : 0u, m_tr = j == 5 ? ~0u : 0u, m_oct = j == 6 ? ~0u : 0u;
+  const uint32_t out_fixed = j >= 7 ? out_const : 0u;
   int n = 0;
   if (n_oct > 0 && max_n > 0) {
     const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
@@ -435,9 +440,10 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
             for (int r = 0; r < 3; r++) w[r] = f2n_row12_sum(wg[r] * v);
           }
           // one 4-byte store per writer lane (roles fixed before the loop) instead of per-array branches
-          const uint32_t val = j == 0 ? __float_as_uint(w[0]) : j == 1 ? __float_as_uint(w[1]) : j == 2 ? __float_as_uint(w[2])
-                             : j == 3 ? __float_as_uint(cur_t) : j == 4 ? __float_as_uint(step * pj_norm)
-                             : j == 5 ? (uint32_t) tidx : j == 6 ? (uint32_t) cur_oct : out_const;
+          uint32_t val = out_fixed | (__float_as_uint(cur_t) & m_t) | (__float_as_uint(step * pj_norm) & m_dt) |
+                         ((uint32_t) tidx & m_tr) | ((uint32_t) cur_oct & m_oct);
+          if (MODE == 1 || pts != nullptr)
+            val |= (__float_as_uint(w[0]) & m_w0) | (__float_as_uint(w[1]) & m_w1) | (__float_as_uint(w[2]) & m_w2);
           if (out_ptr != nullptr) {
             *out_ptr = val;
             out_ptr += out_stride;
