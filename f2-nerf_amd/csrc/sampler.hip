@@ -10,21 +10,20 @@
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const float* c, float side, float& near_,
                                          float& far_) {
+  // Straight-line form of the reference's three-way branch per axis: both quotients are always formed and the result is
+  // selected (the same IEEE operations on the selected path, so the same bits).  The rays of a wave differ in the signs
+  // of d, so the branchy form executed the positive AND the negative arm of every axis -- twelve divisions per test
+  // instead of six -- behind exec-mask juggling that a lone wave pays ~4 cycles per instruction for.
   float lo[3], hi[3];
   float hf = side * .5f;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    if (d[i] < 1e-6f && d[i] > -1e-6f) {
-      bool inside = o[i] > c[i] - hf && o[i] < c[i] + hf;
-      lo[i] = inside ? -1e6f : 1e6f;
-      hi[i] = inside ? 1e6f : -1e6f;
-    } else if (d[i] > 0) {
-      lo[i] = (c[i] - hf - o[i]) / d[i];
-      hi[i] = (c[i] + hf - o[i]) / d[i];
-    } else {
-      lo[i] = (c[i] + hf - o[i]) / d[i];
-      hi[i] = (c[i] - hf - o[i]) / d[i];
-    }
+    const bool par = d[i] < 1e-6f && d[i] > -1e-6f, pos = d[i] > 0;  // ray constants: hoisted out of the DFS loop
+    const float cm = c[i] - hf, cp = c[i] + hf;
+    const float qm = (cm - o[i]) / d[i], qp = (cp - o[i]) / d[i];
+    const bool inside = o[i] > cm && o[i] < cp;
+    lo[i] = par ? (inside ? -1e6f : 1e6f) : (pos ? qm : qp);
+    hi[i] = par ? (inside ? 1e6f : -1e6f) : (pos ? qp : qm);
   }
   near_ = fmaxf(near_, fmaxf(lo[0], fmaxf(lo[1], lo[2])));
   far_ = fminf(far_, fminf(hi[0], fminf(hi[1], hi[2])));
