@@ -24,7 +24,14 @@ void* f2n_ws_get(int slot, size_t bytes) {
   std::lock_guard<std::mutex> lock(g_mu);
   Slot& s = g_slots[dev][slot];
   if (s.bytes < bytes) {
-    if (s.ptr) (void) hipFree(s.ptr);
+    // Growth is rare (sizes settle after a few iterations) but the host runs up to an iteration ahead of the device:
+    // kernels that were handed the old buffer may still be queued.  Drain the device before the buffer goes away
+    // (hipFree alone was observed not to wait: an intermittent memory-access fault in long trainings, once the
+    // edge-sample forward and the field backward of one iteration shared F2N_WS_FIELD_PLANES).
+    if (s.ptr) {
+      (void) hipDeviceSynchronize();
+      (void) hipFree(s.ptr);
+    }
     s.ptr = nullptr;
     s.bytes = 0;
     size_t want = bytes + bytes / 4;

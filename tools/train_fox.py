@@ -29,8 +29,8 @@ runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % arg
 torch.manual_seed(2022)
 test_set = [int(v) for v in st["test_set"]]
 
-def test_psnr():
-    return float(np.mean([runner.test_image_psnr(ds, i) for i in test_set]))
+def test_psnr_views():
+    return [float(runner.test_image_psnr(ds, i)) for i in test_set]
 
 log = []
 torch.cuda.synchronize(); t0 = time.perf_counter(); n_mean = 0; n_rays = 0; t_last = t0
@@ -48,8 +48,11 @@ while it < args.iters:  # ExpRunner::Train in windows (the C++ loop draws rays o
     log.append(rec); print(json.dumps(rec), flush=True)
     t_last = now
 torch.cuda.synchronize(); wall = time.perf_counter() - t0
+views = test_psnr_views()
+views2 = test_psnr_views()  # rendered twice: evaluation is deterministic, so the two passes must agree
+print(json.dumps({"test_psnr_per_view": [round(v, 2) for v in views], "second_pass_max_abs_diff": round(max(abs(a - b) for a, b in zip(views, views2)), 4)}), flush=True)
 print(json.dumps({"iters": args.iters, "train_wall_s": round(wall, 1), "ray_samples_per_s": round(n_mean / wall),
-                  "rays_per_s": round(n_rays / wall), "test_psnr": round(test_psnr(), 3), "test_views": test_set,
+                  "rays_per_s": round(n_rays / wall), "test_psnr": round(float(np.mean(views)), 3), "test_views": test_set,
                   "image_hw": [int(v) for v in images.shape[1:3]], "data": "ngp_fox photographs at 1/8 resolution"}), flush=True)
 
 if args.breakdown:
