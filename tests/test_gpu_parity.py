@@ -552,6 +552,43 @@ def test_field_fused_forward_backward(hip, fox_state, fox_golden, n_use):
     assert cos > 0.9999, cos
 
 
+def test_workspace_growth_with_queued_kernels(hip, fox_state, fox_golden):
+    """The internal workspaces grow on demand.  Kernels that were handed the previous buffer may still be queued when a
+    later call of the same iteration needs a bigger one (edge-sample forward, then the field backward): the forward's
+    results must survive that (regression test of an intermittent memory-access fault in long trainings)."""
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(77)
+    grid = make_grid(st, rng, 14, scale=0.5)
+    gd = grid_dev(grid)
+    ph = T(oc.f2h(rand_params(rng, 1)).view(np.float16))
+    pts0, anc0 = g["march_pts"], g["march_anchors"]
+    def batch(n):
+        idx = rng.integers(0, len(pts0), n)
+        return T(pts0[idx]), T(np.ascontiguousarray(anc0[idx]))
+    n_small = 16384  # partitioned forward: uses the plane workspace
+    ps, as_ = batch(n_small)
+    ref = torch.zeros((n_small, 16), device=DEV)
+    hip.field_fwd(n_small, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], ps, as_, 3,
+                  ph, ref, None, None)
+    torch.cuda.synchronize()
+    n_big = 40000
+    for rep in range(12):  # every round asks for a bigger backward workspace while the forward is still queued
+        n_big = int(n_big * 1.4)
+        pb, ab = batch(n_big)
+        sx = torch.zeros((n_big, 32), dtype=torch.float16, device=DEV)
+        dfeat = torch.zeros((n_big, 16), device=DEV)
+        dparams = torch.zeros(3072, device=DEV)
+        gtab = torch.zeros(grid.table_f32.size, dtype=torch.float16, device=DEV)
+        out = torch.zeros((n_small, 16), device=DEV)
+        for _ in range(4):  # a few queued users of the current buffer
+            hip.field_fwd(n_small, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], ps,
+                          as_, 3, ph, out, None, None)
+        hip.field_bwd(n_big, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], pb, ab, 3, ph, sx, dfeat,
+                      128.0, dparams, gtab, 1 << 14)
+        torch.cuda.synchronize()
+        assert_same(N(out), N(ref), "forward queued in front of a workspace growth")
+
+
 def test_field_forward_from_prepass_cache(hip, fox_state, fox_golden):
     """f2n_field_fwd_cached (hash features memoised by the pre-pass) must equal a fresh f2n_field_fwd bit for bit,
     for an arbitrary (compaction-like, order-preserving) subset and for the identity mapping."""
