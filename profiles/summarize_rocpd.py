@@ -13,31 +13,50 @@ def short(name):
             tmpl = ""
             if "field_fwd_kernelILi1ELb1ELb1" in name:
                 tmpl = "<NH=1,hash,mlp>"
-            elif "field_bwd_kernelILi1ELb1" in name:
-                tmpl = "<NH=1,hash>"
+            elif "field_bwd_kernelILi1ELi2" in name:
+                tmpl = "<NH=1,planes>"
+            elif "field_bwd_kernelILi1ELi1" in name:
+                tmpl = "<NH=1,atomics>"
+            elif "field_bwd_kernelILi2" in name:
+                tmpl = "<NH=2>"
             return k + tmpl
     return name.split("(")[0].replace("void ", "")[:70]
 
 
 def stats(db, out):
+    """One row per kernel (rocprofv3's own top_kernels view), plus one row per launch shape for kernels that are launched with
+    more than one grid (e.g. the hash gather: once over every marched sample, once over the 16384 edge samples) -- an
+    average over both shapes says nothing about either."""
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    shapes = {}
+    try:
+        for n, g, c, tot in cur.execute("select name, grid_x, count(*), sum(duration) from kernels group by name, grid_x"):
+            shapes.setdefault(n, []).append((int(g), int(c), float(tot)))
+    except sqlite3.Error:
+        shapes = {}
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
         for n, c, t, a, p in rows:
             w.writerow([short(n), c, "%.1f" % float(t), "%.2f" % float(a), "%.2f" % float(p)])
+            sh = shapes.get(n, [])
+            if len(sh) > 1:
+                unit = float(t) / max(sum(x[2] for x in sh), 1e-9)  # kernels.duration -> the unit top_kernels reports in
+                for g, cc, tot in sorted(sh, key=lambda x: -x[2]):
+                    w.writerow(["  %s [grid_x=%d]" % (short(n), g), cc, "%.1f" % (tot * unit), "%.2f" % (tot * unit / cc), ""])
 
 
 def pmc(db, out):
+    """Counter averages per kernel AND launch shape (grid size)."""
     cur = sqlite3.connect(db).cursor()
-    q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
-         "group by kernel_name, counter_name order by sum(duration) desc")
+    q = ("select kernel_name, grid_size, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+         "group by kernel_name, grid_size, counter_name order by sum(duration) desc")
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "counter", "dispatches", "avg_value", "avg_duration_ns"])
-        for n, cn, c, v, d in cur.execute(q):
-            w.writerow([short(n), cn, c, "%.3f" % float(v), "%.0f" % float(d)])
+        w.writerow(["kernel", "grid_size", "counter", "dispatches", "avg_value", "avg_duration_ns"])
+        for n, g, cn, c, v, d in cur.execute(q):
+            w.writerow([short(n), g, cn, c, "%.3f" % float(v), "%.0f" % float(d)])
 
 
 def traffic(fetch_csv, write_csv, out_json):
@@ -46,6 +65,7 @@ def traffic(fetch_csv, write_csv, out_json):
     import json
     acc = {}
     for path, key, mult in ((fetch_csv, "fetch", 2.0), (write_csv, "write", 1.0)):
+        best = {}  # per kernel: the launch shape with the longest average duration (the full-batch launch)
         with open(path) as f:
             for r in csv.DictReader(f):
                 name = r["kernel"].split("(")[0]
@@ -53,16 +73,32 @@ def traffic(fetch_csv, write_csv, out_json):
                             "shade_bwd_kernel", "shade_fwd_kernel", "ray_march_kernel<true>", "ray_march_kernel<false>"):
                     if tag in name:
                         name = tag
-                d = acc.setdefault(name, {"dispatches": int(r["dispatches"])})
-                d[key + "_bytes_per_launch"] = float(r["avg_value"]) * 1024.0 * mult
+                if name not in best or float(r["avg_duration_ns"]) > float(best[name]["avg_duration_ns"]):
+                    best[name] = r
+        for name, r in best.items():
+            d = acc.setdefault(name, {"dispatches": int(r["dispatches"]), "grid_size": int(r.get("grid_size", 0) or 0)})
+            d[key + "_bytes_per_launch"] = float(r["avg_value"]) * 1024.0 * mult
     for d in acc.values():
         d["hbm_bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0.0) + d.get("write_bytes_per_launch", 0.0)
     with open(out_json, "w") as f:
         json.dump(acc, f, indent=1, sort_keys=True)
 
 
+def schema(db, out):
+    cur = sqlite3.connect(db).cursor()
+    with open(out, "w") as f:
+        for name, typ in list(cur.execute("select name, type from sqlite_master where type in ('table','view') order by name")):
+            try:
+                cols = [r[1] for r in cur.execute("pragma table_info('%s')" % name)]
+            except Exception as e:  # noqa: BLE001
+                cols = [str(e)]
+            f.write("%s %s: %s\n" % (typ, name, ", ".join(cols)))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "traffic":
+    if sys.argv[1] == "schema":
+        schema(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
