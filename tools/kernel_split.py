@@ -4,7 +4,6 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import f2_nerf_amd
 from f2_nerf_amd import runtime, capi
-from oracle import capi as oc
 
 st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
 runner, cfg, arrays = runtime.make_runner(st, "wanjinyou", seed=2022)
@@ -19,7 +18,7 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 log2 = 19; local = 1 << log2
 table_h = torch.from_numpy(arrays[4]).to(dev).to(torch.float16)
 prim, bias = T(arrays[5]), T(arrays[6]); nv = int(arrays[7][0])
-lidx = T((np.arange(16) * local).astype(np.int32)); lsize = T(np.full(16, local, np.int32)); scale = T(oc.level_scales())
+lidx = T((np.arange(16) * local).astype(np.int32)); lsize = T(np.full(16, local, np.int32)); scale = T(np.exp2(3.0 + 7.0 * np.arange(16) / 15.0).astype(np.float32))  # Hash3DAnchored.cu:28
 ph = T(arrays[8]).to(torch.float16)
 
 def timeit(fn, reps=5):
