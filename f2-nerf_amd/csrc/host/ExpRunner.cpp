@@ -71,14 +71,15 @@ void ExpRunner::LoadStates(const std::vector<Tensor>& states) {
 }
 
 // ExpRunner.cpp:221-254
+float ExpRunner::FinenessAt(int iter) const {  // ExpRunner.cpp:221-231
+  if (iter >= ray_march_fineness_decay_end_iter_) return 1.f;
+  float progress = float(iter) / float(ray_march_fineness_decay_end_iter_);
+  return std::exp(std::log(1.f) * progress + std::log(ray_march_init_fineness_) * (1.f - progress));
+}
+
 void ExpRunner::UpdateAdaParams() {
   auto* gdp = global_data_pool_.get();
-  if (iter_step_ >= ray_march_fineness_decay_end_iter_) {
-    gdp->ray_march_fineness_ = 1.f;
-  } else {
-    float progress = float(iter_step_) / float(ray_march_fineness_decay_end_iter_);
-    gdp->ray_march_fineness_ = std::exp(std::log(1.f) * progress + std::log(ray_march_init_fineness_) * (1.f - progress));
-  }
+  gdp->ray_march_fineness_ = FinenessAt(iter_step_);
   float lr_factor;
   if (iter_step_ >= learning_rate_warm_up_end_iter_) {
     float progress = float(iter_step_ - learning_rate_warm_up_end_iter_) / float(end_iter_ - learning_rate_warm_up_end_iter_);
@@ -151,8 +152,18 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   renderer_->ZeroGrad();
   deferred_dropped_ = false;
   if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
+  if (prefetch) {
+    // The NEXT batch's sampling only depends on this step's octree update: its kernels are issued (on a side stream) from
+    // inside SampleAndFilter, right behind that update, with the next iteration's fineness; the host comes back for its
+    // counts after this step's backward has been queued (PreSampleFinish below).
+    const float fin = FinenessAt(iter_step_ + 1);
+    renderer_->after_octree_update_ = [this, fin, &next_rays_o, &next_rays_d, &next_bounds]() {
+      renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, fin);
+    };
+  }
   TrainOutputs out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(),
                                                      disp_loss_weight_, tv_loss_weight_);
+  renderer_->after_octree_update_ = nullptr;
   ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)
   TrainStats stats;
   stats.skipped_nan = deferred_dropped_;  // the PREVIOUS iteration was dropped: reported one step late when prefetching
@@ -177,9 +188,12 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     iter_step_++;
     UpdateAdaParams();
   }
-  // Prefetch: the NEXT batch's rays are marched now, on a side stream, underneath the kernels of this step that are still
-  // queued (the host is ~1 ms ahead of the GPU here).  Needs the next iteration's fineness, hence after UpdateAdaParams.
-  if (prefetch) renderer_->PreSampleAsync(next_rays_o, next_rays_d, next_bounds);
+  // Prefetch, second half: the NEXT batch's march has been running on the side stream since this step's octree update;
+  // now that everything of this step is queued the host waits for its sample counts and issues the pack.
+  if (prefetch) {
+    if (renderer_->PreSampleBegun()) renderer_->PreSampleFinish();
+    else renderer_->PreSampleAsync(next_rays_o, next_rays_d, next_bounds);  // (a batch without samples never reached the hook)
+  }
   if (applied && check_nan_ && prefetch) {  // streaming: do not stall on this step's flags (see ExpRunner.h)
     if (!nan_flags_host_.defined()) nan_flags_host_ = torch::empty({4}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
     nan_flags_host_.copy_(nan_flags_, /*non_blocking=*/true);

@@ -43,6 +43,7 @@ class ExpRunner {
   int64_t last_train_meaningful_ = 0, last_train_marched_ = 0, last_train_rays_ = 0;  // totals of the last Train call
   TrainStats last_train_stats_;
   void UpdateAdaParams();
+  float FinenessAt(int iter) const;
   void OptimStep(const int32_t* skip_flag = nullptr);  // skip_flag: device int, != 0 drops the update
   void BuildOptimizer();
   Tensor FlattenSmallGrads();

@@ -60,6 +60,12 @@ void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of 
 // GetSamples, PersSampler.cu:317-434
 // ---------------------------------------------------------------------------------------------------------
 SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, const Tensor& /*bounds*/) {
+  PendingSamples p;
+  BeginSamples(rays_o_raw, rays_d_raw, global_data_pool_->ray_march_fineness_, p);
+  return FinishSamples(p);
+}
+
+void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, float fineness, PendingSamples& p) {
   Tensor rays_o = rays_o_raw.contiguous();
   Tensor rays_d_in = rays_d_raw.contiguous();
   CheckDev(rays_o, torch::kFloat32, "rays_o");
@@ -92,10 +98,10 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
     TORCH_CHECK(rays_noise.numel() >= F2N_MAX_SAMPLE_PER_RAY + n_rays + 10, "forced noise too short");
   } else if (global_data_pool_->mode_ == RunningMode::VALIDATE) {
     rays_noise = torch::ones({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32());
-    rays_noise.mul_(global_data_pool_->ray_march_fineness_);
+    rays_noise.mul_(fineness);
   } else {
     rays_noise = torch::rand({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32());
-    F2N_CALL(f2n_march_noise(st, (int) rays_noise.numel(), F32P(rays_noise), global_data_pool_->ray_march_fineness_, F32P(rays_noise)));
+    F2N_CALL(f2n_march_noise(st, (int) rays_noise.numel(), F32P(rays_noise), fineness, F32P(rays_noise)));
   }
 
   // ONE march into fixed-stride per-ray slots (28 B x 1024 per ray of scratch, of which only the filled prefixes are
@@ -104,30 +110,47 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   const int64_t slots = int64_t(n_rays) * F2N_MAX_SAMPLE_PER_RAY;
   Tensor s_dt = torch::empty({slots}, DevF32()), s_t = torch::empty({slots}, DevF32());  // warped points: computed by pack
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
-  SampleResultFlex res;
-  res.first_oct_dis = torch::empty({n_rays, 1}, DevF32());
+  Tensor first_oct_dis = torch::empty({n_rays, 1}, DevF32());
   F2N_TIMED_CALL("ray_march", f2n_ray_march_strided(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
                                  I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
                                  VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t), I32P(s_anchors),
-                                 F32P(res.first_oct_dis), I32P(oct_tr)));
+                                 F32P(first_oct_dis), I32P(oct_tr)));
   F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(pts_se), I32P(totals) + 1));
+  // the single host read-back of a GetSamples call: through pinned memory and an event (no stream drain)
+  Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+  totals_host.copy_(totals, /*non_blocking=*/true);
+  p.counts_ready.record();
+  p.active = true;
+  p.n_rays = n_rays;
+  p.rays_o = rays_o; p.rays_d = rays_d; p.counts = counts; p.oct_se = oct_se; p.totals = totals; p.totals_host = totals_host;
+  p.oct_idx = oct_idx; p.oct_nf = oct_nf; p.oct_tr = oct_tr; p.noise = rays_noise; p.pts_se = pts_se; p.s_dt = s_dt; p.s_t = s_t;
+  p.s_anchors = s_anchors; p.first_oct_dis = first_oct_dis;
+}
 
-  Tensor totals_cpu = totals.cpu();  // the single host read-back of this call
-  const int n_all_oct = totals_cpu.data_ptr<int32_t>()[0];
-  const int n_all_pts = totals_cpu.data_ptr<int32_t>()[1];
+SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
+  TORCH_CHECK(p.active, "FinishSamples without BeginSamples");
+  auto& oct = *pers_octree_;
+  void* st = CurStream();
+  const int n_rays = p.n_rays;
+  p.counts_ready.synchronize();
+  const int n_all_oct = p.totals_host.data_ptr<int32_t>()[0];
+  const int n_all_pts = p.totals_host.data_ptr<int32_t>()[1];
   if (global_data_pool_->mode_ == RunningMode::TRAIN) {
     float per_ray = float(n_all_oct) / float(n_rays);
     global_data_pool_->sampled_oct_per_ray_ = global_data_pool_->sampled_oct_per_ray_ * .9f + per_ray * .1f;
   }
-
+  SampleResultFlex res;
+  res.first_oct_dis = p.first_oct_dis;
   res.pts = torch::empty({n_all_pts, 3}, DevF32());
   res.dirs = torch::empty({n_all_pts, 3}, DevF32());
   res.dt = torch::empty({n_all_pts}, DevF32());
   res.t = torch::empty({n_all_pts}, DevF32());
   res.anchors = torch::empty({n_all_pts, 3}, DevI32());
-  res.pts_idx_bounds = pts_se;
-  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(pts_se), F32P(rays_o), F32P(rays_d), VoidP(oct.pers_trans_gpu_), nullptr, F32P(s_dt), F32P(s_t),
-                                    I32P(s_anchors), F32P(res.pts), F32P(res.dirs), F32P(res.dt), F32P(res.t), I32P(res.anchors)));
+  res.pts_idx_bounds = p.pts_se;
+  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
+                                    F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(res.pts), F32P(res.dirs), F32P(res.dt), F32P(res.t),
+                                    I32P(res.anchors)));
+  p = PendingSamples();  // the scratch goes back to the allocator (of the stream it was allocated on)
   return res;
 }
 

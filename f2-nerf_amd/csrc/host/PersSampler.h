@@ -61,10 +61,25 @@ class PersOctree {
   int n_edges_ = 0;
 };
 
+// A GetSamples call cut at its one host read-back: BeginSamples issues everything up to the sample counts (intersection,
+// march, scan, the counts on their way to pinned memory) without blocking the host; FinishSamples waits for the counts,
+// allocates the outputs and issues the pack.  A training step begins the NEXT batch's sampling as soon as its own octree
+// update is issued and finishes it after its own backward has been queued, so the host never sits in the sampler's
+// read-back while the step's kernels are still to be issued.
+struct PendingSamples {
+  bool active = false;
+  int n_rays = 0;
+  Tensor rays_o, rays_d, counts, oct_se, totals, totals_host, oct_idx, oct_nf, oct_tr, noise, pts_se, s_dt, s_t, s_anchors,
+      first_oct_dis;
+  at::cuda::CUDAEvent counts_ready;
+};
+
 class PersSampler : public PtsSampler {
  public:
   explicit PersSampler(GlobalDataPool* global_data_pool);
   SampleResultFlex GetSamples(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) override;
+  void BeginSamples(const Tensor& rays_o, const Tensor& rays_d, float fineness, PendingSamples& p);
+  SampleResultFlex FinishSamples(PendingSamples& p);
   std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;
   void UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weights,
                       const Tensor& sampled_alpha) override;

@@ -204,26 +204,56 @@ void Renderer::ZeroGrad() {
   app_emb_grad_.zero_();
 }
 
+// A prefetched sampling is identified by the ray tensors it was made for.  The renderer HOLDS those tensors: an address
+// alone can be recycled by the allocator for other rays (a test image rendered right after training picked up the
+// samples prefetched for the next training batch that way, once in ~10 runs).
+bool Renderer::PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) const {
+  return has_presample_ && presample_rays_o_.defined() && presample_rays_d_.defined() &&
+         rays_o.data_ptr() == presample_rays_o_.data_ptr() && rays_d.data_ptr() == presample_rays_d_.data_ptr() &&
+         rays_o.sizes() == presample_rays_o_.sizes();
+}
+
 void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
-  if (has_presample_ && presample_key_ == rays_o.data_ptr()) return;  // already marched (asynchronously) for these rays
+  if (PresampleMatches(rays_o, rays_d)) return;  // already marched (asynchronously) for these rays
   presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   has_presample_ = true;
   presample_async_ = false;
-  presample_key_ = rays_o.data_ptr();
+  presample_rays_o_ = rays_o;
+  presample_rays_d_ = rays_d;
 }
 
 void Renderer::PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  PreSampleBegin(rays_o, rays_d, bounds, global_data_pool_->ray_march_fineness_);
+  PreSampleFinish();
+}
+
+// First half of the prefetch: everything up to the sample counts, issued on the side stream without blocking the host.
+// Called from inside SampleAndFilter as soon as this step's occupancy update (the only thing the next batch's sampling
+// depends on) has been issued; the kernels then run underneath this step's forward/backward.
+void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& /*bounds*/, float fineness) {
   if (!side_stream_)
     side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
   octree_ready_ev_.block(*side_stream_);  // the only dependency on this step: its occupancy update / ProcOctree
+  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
+  static_cast<PersSampler*>(pts_sampler_.get())->BeginSamples(rays_o, rays_d, fineness, pending_samples_);
+  pending_rays_o_ = rays_o;
+  pending_rays_d_ = rays_d;
+}
+
+// Second half: wait for the counts (by now the march has usually finished), allocate, pack.
+void Renderer::PreSampleFinish() {
+  TORCH_CHECK(pending_samples_.active, "PreSampleFinish without PreSampleBegin");
   {
     c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
-    presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);  // (its one read-back only waits for the side stream)
+    presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pending_samples_);
     presample_done_ev_.record(*side_stream_);
   }
   has_presample_ = true;
   presample_async_ = true;
-  presample_key_ = rays_o.data_ptr();
+  presample_rays_o_ = pending_rays_o_;
+  presample_rays_d_ = pending_rays_d_;
+  pending_rays_o_ = Tensor();
+  pending_rays_d_ = Tensor();
 }
 
 RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx) {
@@ -231,7 +261,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
-  if (has_presample_ && presample_key_ == rays_o.data_ptr()) {  // PreSample[Async]() already marched these rays
+  if (train && PresampleMatches(rays_o, rays_d)) {  // PreSample[Async]() already marched these rays
     sample_result_ = std::move(presampled_);
     if (presample_async_) {  // produced on the side stream: order it before this stream, and tell the allocator
       auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
@@ -242,9 +272,11 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     }
     presampled_ = SampleResultFlex();
     has_presample_ = false;
+    presample_rays_o_ = presample_rays_d_ = Tensor();
   } else {
-    presampled_ = SampleResultFlex();  // a presample for other rays is of no use
+    presampled_ = SampleResultFlex();  // a presample for other rays (or made for training, in a render) is of no use
     has_presample_ = false;
+    presample_rays_o_ = presample_rays_d_ = Tensor();
     sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   }
   int n_all_pts = sample_result_.pts.size(0);
@@ -297,7 +329,15 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
                                                 : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
       edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
-                                                     : (torch::rand({n_edge, 2}, DevF32()) * 2.f - 1.f).contiguous();
+                                                     : torch::empty({n_edge, 2}, DevF32()).uniform_(-1.f, 1.f);  // one launch (rand*2-1: three)
+    }
+    if (train) {
+      octree_ready_ev_.record();  // everything the NEXT step's ray sampling depends on has been issued ...
+      if (after_octree_update_) {  // ... so a prefetching TrainStep starts that sampling now (draw order: bg, edge, noise)
+        auto f = std::move(after_octree_update_);
+        after_octree_update_ = nullptr;
+        f();
+      }
     }
     n_kept_ev_.synchronize();
     n_kept = n_kept_host_.data_ptr<int32_t>()[0];

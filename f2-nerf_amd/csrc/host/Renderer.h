@@ -61,6 +61,12 @@ class Renderer : public Pipe {
   // The same on a SIDE stream that only waits for this step's octree update: the sampler kernels (latency-bound: few
   // waves, long dependent chains) then run underneath the remaining forward/backward kernels of the current step.
   void PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
+  void PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, float fineness);
+  void PreSampleFinish();
+  bool PreSampleBegun() const { return pending_samples_.active; }
+  std::function<void()> after_octree_update_;  // one-shot: called in SampleAndFilter right after the occupancy update
+  PendingSamples pending_samples_;
+  Tensor pending_rays_o_, pending_rays_d_;
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
   // forward + ExpRunner::Train's loss + backward into the gradient buffers, without the autograd tape
   TrainOutputs TrainForwardBackward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
@@ -82,7 +88,8 @@ class Renderer : public Pipe {
   BGColorType bg_color_type_ = BGColorType::rand_noise;
   SampleResultFlex sample_result_, presampled_;
   bool has_presample_ = false, presample_async_ = false;
-  const void* presample_key_ = nullptr;  // rays_o.data_ptr() the presample belongs to
+  Tensor presample_rays_o_, presample_rays_d_;  // the rays the presample belongs to (held: see PresampleMatches)
+  bool PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) const;
   at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_, n_kept_ev_;
   bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
