@@ -275,11 +275,12 @@ def compact_samples(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_p
 
 
 def compact_samples_src(n_rays, old_se, new_se, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src,
-                        o_vol=None):
+                        o_vol=None, ray_val=None, o_ray_val=None):
     _ck(lib().f2n_compact_samples_src(_stream(), _i(n_rays), _p(old_se, "i32"), _p(new_se, "i32"), _p(mask, "i32"),
                                       _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"), _p(anchors, "i32"),
                                       _p(o_pts, "f32"), _p(o_dirs, "f32"), _p(o_dt, "f32"), _p(o_t, "f32"),
-                                      _p(o_anchors, "i32"), _p(o_src, "i32"), _p(o_vol, "i32", True)), "f2n_compact_samples_src")
+                                      _p(o_anchors, "i32"), _p(o_src, "i32"), _p(o_vol, "i32", True), _p(ray_val, "i32", True),
+                                      _p(o_ray_val, "i32", True)), "f2n_compact_samples_src")
 
 
 def oct_visible_cams(n_boxes, n_cams, boxes, c2w, bounds, fx, fy, cx, cy, res_h, res_w, pix_i, pix_j, visible):
@@ -292,19 +293,20 @@ def march_noise(n, u, fineness, out):
     _ck(lib().f2n_march_noise(_stream(), _i(n), _p(u, "f32"), _f(fineness), _p(out, "f32")), "f2n_march_noise")
 
 
-def composite_fwd(n_rays, pts_se, feat, dt, t, rgb, bg, colors, disparity, depth, weights, f0_stride=16):
+def composite_fwd(n_rays, pts_se, feat, dt, t, rgb, bg, colors, disparity, depth, weights, f0_stride=16, out_vars=None):
     """feat: the field output [M,16] (f0_stride 16, column 0 is read) or a compact density array [M] (f0_stride 1)."""
     _ck(lib().f2n_composite_fwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _i(f0_stride), _p(dt, "f32"),
                                 _p(t, "f32"), _p(rgb, "f32"), _p(bg, "f32"), _p(colors, "f32"), _p(disparity, "f32"),
-                                _p(depth, "f32"), _p(weights, "f32")), "f2n_composite_fwd")
+                                _p(depth, "f32"), _p(weights, "f32"), _p(out_vars, "f32", True)), "f2n_composite_fwd")
 
 
 def composite_bwd(n_rays, pts_se, feat, dt, t, rgb, bg, dcolors, ddisp, ddepth, dweights, gs_progress, drgb, dfeat, f0_stride=16,
-                  df0_stride=16):
+                  df0_stride=16, var_weights=None, dvars=None):
     _ck(lib().f2n_composite_bwd(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(feat, "f32"), _i(f0_stride), _p(dt, "f32"),
                                 _p(t, "f32"), _p(rgb, "f32"), _p(bg, "f32"), _p(dcolors, "f32", True), _p(ddisp, "f32", True),
                                 _p(ddepth, "f32", True), _p(dweights, "f32", True), _f(gs_progress), _p(drgb, "f32"),
-                                _p(dfeat, "f32"), _i(df0_stride)), "f2n_composite_bwd")
+                                _p(dfeat, "f32"), _i(df0_stride), _p(var_weights, "f32", True), _p(dvars, "f32", True)),
+        "f2n_composite_bwd")
 
 
 def weight_var_fwd(n_rays, weights, pts_se, out):

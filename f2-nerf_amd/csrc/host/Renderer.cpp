@@ -90,7 +90,7 @@ struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
     Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
     Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({m}, DevF32());
     F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(CurStream(), n_rays, I32P(se), F32P(feat), F2N_MLP_OUT_PAD, F32P(dt), F32P(t), F32P(rgb), F32P(bg),
-                               F32P(colors), F32P(disparity), F32P(depth), F32P(weights)));
+                               F32P(colors), F32P(disparity), F32P(depth), F32P(weights), nullptr));
     ctx->save_for_backward({feat, rgb, dt, t, bg, se});
     ctx->saved_data["gs"] = gs_progress;
     return {colors, disparity, depth, weights};
@@ -105,7 +105,7 @@ struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
     F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(CurStream(), n_rays, I32P(s[5]), F32P(s[0]), F2N_MLP_OUT_PAD, F32P(s[2]), F32P(s[3]), F32P(s[1]), F32P(s[4]),
                                gc.defined() ? F32P(gc) : nullptr, gd.defined() ? F32P(gd) : nullptr,
                                gz.defined() ? F32P(gz) : nullptr, gw.defined() ? F32P(gw) : nullptr,
-                               (float) ctx->saved_data["gs"].toDouble(), F32P(drgb), F32P(dfeat), F2N_MLP_OUT_PAD));
+                               (float) ctx->saved_data["gs"].toDouble(), F32P(drgb), F32P(dfeat), F2N_MLP_OUT_PAD, nullptr, nullptr));
     return {dfeat, drgb, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
@@ -353,10 +353,19 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     es.first_oct_dis = sample_result_.first_oct_dis;
     es.pts_idx_bounds = new_se;
     src_rows = torch::empty({std::max(n_kept, 1)}, DevI32());
+    // CustomOps::ScatterIdx (Renderer.cpp:185) rides along with the compaction: every survivor gets its ray's image index
+    const bool want_emb = train && use_app_emb_ && emb_idx.defined();
+    Tensor emb_contig;
+    if (want_emb) {
+      emb_contig = emb_idx.contiguous();
+      CheckDev(emb_contig, torch::kInt32, "emb_idx");
+      fr.sample_emb_idx = torch::empty({std::max(n_kept, 1)}, DevI32());
+    }
     F2N_TIMED_CALL("compact_samples", f2n_compact_samples_src(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
                                  F32P(sample_result_.pts), F32P(sample_result_.dirs), F32P(sample_result_.dt),
                                  F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all), F32P(es.dirs),
-                                 F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows), I32P(vol_all)));
+                                 F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows), I32P(vol_all),
+                                 want_emb ? I32P(emb_contig) : nullptr, want_emb ? I32P(fr.sample_emb_idx) : nullptr));
     if (train) {
       gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(n_rays)) * 0.1f;
       // edge samples for the TV loss go straight behind the surviving samples (Renderer.cpp:159-166)
@@ -369,14 +378,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   fr.n_kept = n_kept;
   fr.n_edge = n_edge;
   fr.emb = train && use_app_emb_ && emb_idx.defined();
-  if (fr.emb) {  // CustomOps::ScatterIdx, Renderer.cpp:185
-    Tensor ei = emb_idx.contiguous();
-    CheckDev(ei, torch::kInt32, "emb_idx");
-    fr.sample_emb_idx = torch::empty({std::max(n_kept, 1)}, DevI32());
-    F2N_CALL(f2n_scatter_idx(st, n_rays, I32P(es.pts_idx_bounds), I32P(ei), I32P(fr.sample_emb_idx)));
-  } else {
-    fr.sample_emb_idx = torch::empty({0}, DevI32());  // autograd::Function inputs must be defined tensors
-  }
+  if (!fr.emb) fr.sample_emb_idx = torch::empty({0}, DevI32());  // autograd::Function inputs must be defined tensors
   sample_result_ = SampleResultFlex();  // drop the pre-early-stop buffers
   octree_ready_ev_.record();            // everything the NEXT step's ray sampling depends on has been issued
   return fr;
@@ -451,10 +453,9 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
   Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({std::max(n_kept, 1)}, DevF32());
   Tensor bg = fr.bg_color.contiguous();
-  F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
-                             F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights)));
   Tensor var = torch::empty({n_rays}, DevF32());
-  F2N_TIMED_CALL("weight_var_fwd", f2n_weight_var_fwd(st, n_rays, F32P(weights), I32P(es.pts_idx_bounds), F32P(var)));
+  F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
+                             F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights), F32P(var)));  // (+ WeightVarLoss fwd)
 
   // ---- loss and its gradients; the TV gradient goes straight into the edge rows of dfeat ----
   Tensor dfeat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
@@ -464,11 +465,10 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
                           F32P(ddisp), F32P(dvar), F32P(dfeat) + (int64_t) F2N_MLP_OUT_PAD * n_kept));
 
   // ---- backward ----
-  Tensor dweights = torch::empty({std::max(n_kept, 1)}, DevF32()), drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());
-  F2N_TIMED_CALL("weight_var_bwd", f2n_weight_var_bwd(st, n_rays, F32P(weights), I32P(es.pts_idx_bounds), F32P(dvar), F32P(dweights)));
+  Tensor drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());  // (WeightVarLoss backward rides inside composite_bwd)
   F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb), F32P(bg),
-                             F32P(dcolors), F32P(ddisp), nullptr, F32P(dweights), gdp->gradient_scaling_progress_, F32P(drgb),
-                             F32P(df0c), 1));
+                             F32P(dcolors), F32P(ddisp), nullptr, nullptr, gdp->gradient_scaling_progress_, F32P(drgb),
+                             F32P(df0c), 1, F32P(weights), F32P(dvar)));
   F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd(st, n_kept, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
                          VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat),
                          F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,

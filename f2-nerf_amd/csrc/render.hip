@@ -82,12 +82,14 @@ __global__ __launch_bounds__(256) void compact_kernel(int n_rays, const int32_t*
                                                       const int32_t* __restrict__ anchors, float* __restrict__ o_pts,
                                                       float* __restrict__ o_dirs, float* __restrict__ o_dt, float* __restrict__ o_t,
                                                       int32_t* __restrict__ o_anchors, int32_t* __restrict__ o_src,
-                                                      int32_t* __restrict__ o_vol) {
+                                                      int32_t* __restrict__ o_vol, const int32_t* __restrict__ ray_val,
+                                                      int32_t* __restrict__ o_ray_val) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
   const int s = old_se[2 * ray], e = old_se[2 * ray + 1];
   int dst = new_se[2 * ray];
+  const int rv = o_ray_val != nullptr ? ray_val[ray] : 0;  // ScatterIdx (Scatter.cu:110-120) of the survivors, for free
   for (int base = s; base < e; base += 64) {
     const int i = base + lane;
     const bool keep = i < e && mask[i] != 0;
@@ -104,17 +106,32 @@ __global__ __launch_bounds__(256) void compact_kernel(int n_rays, const int32_t*
       o_t[k] = t[i];
       if (o_src != nullptr) o_src[k] = i;
       if (o_vol != nullptr) o_vol[k] = anchors[3 * (size_t) i];  // trans idx as a unit-stride array (the field's volume index)
+      if (o_ray_val != nullptr) o_ray_val[k] = rv;
     }
     dst += __popcll(bal);
   }
 }
 
 // Renderer.cpp:190-208 forward.
+// CustomOps.cu:12-66.  mean = (sum w_i * i/16) / (1e-6 + sum w_i), both sums left to right.
+__device__ __forceinline__ void f2n_wv_stats(const float* __restrict__ w, int n, int c, float& mean, float& wsum) {
+  float m = 0.f, ws = 1e-6f;
+  for (int base = 0; base < n; base += 16) {
+    const int i = base + c;
+    const float wi = i < n ? w[i] : 0.f;
+    m = f2n_row_last(f2n_row_seq_scan(wi * ((float) i / 16.f), m, c));
+    ws = f2n_row_last(f2n_row_seq_scan(wi, ws, c));
+  }
+  mean = m / ws;
+  wsum = ws;
+}
+
 __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ f0,
                                                             int f0_stride, const float* __restrict__ dt, const float* __restrict__ t,
                                                             const float* __restrict__ rgb, const float* __restrict__ bg,
                                                             float* __restrict__ colors, float* __restrict__ disparity,
-                                                            float* __restrict__ depth, float* __restrict__ weights) {
+                                                            float* __restrict__ depth, float* __restrict__ weights,
+                                                            float* __restrict__ out_vars) {
   const int c = threadIdx.x & 15;
   const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
@@ -148,6 +165,20 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const in
     disparity[ray] = disp;
     depth[ray] = dep / (1.f - last_trans + 1e-4f);
   }
+  if (out_vars != nullptr) {  // WeightVarLoss forward (weight_var_fwd_kernel) on the weights this row has just written
+    float var = 0.f;
+    if (s < e) {
+      float mean, ws;
+      f2n_wv_stats(weights + s, e - s, c, mean, ws);
+      for (int base = 0; base + s < e; base += 16) {
+        const int i = base + c;
+        const float b = (float) i / 16.f - mean;
+        const float wi = i + s < e ? weights[i + s] : 0.f;
+        var = f2n_row_last(f2n_row_seq_scan(wi * b * b, var, c));
+      }
+    }
+    if (c == 0) out_vars[ray] = var;
+  }
 }
 
 // Backward of the compositing chain (FlexOps backward kernels FlexOps.cu:17-26,42-53,75-93; TruncExp backward
@@ -159,7 +190,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
                                                             const float* __restrict__ rgb, const float* __restrict__ bg,
                                                             const float* __restrict__ dcolors, const float* __restrict__ ddisparity,
                                                             const float* __restrict__ ddepth, const float* __restrict__ dweights,
-                                                            float gs_progress, float* __restrict__ drgb, float* __restrict__ df0, int df0_stride) {
+                                                            float gs_progress, float* __restrict__ drgb, float* __restrict__ df0, int df0_stride,
+                                                            const float* __restrict__ var_weights, const float* __restrict__ dvars) {
   const int c = threadIdx.x & 15;
   const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
@@ -192,6 +224,19 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
                        dDep * dep_sum / (denom * denom);
   const float d_total = -last_trans * d_last;  // last_trans = exp(-sum sec): every sec_i receives this
   const float dDepW = dDep / denom;
+  // WeightVarLoss backward (weight_var_bwd_kernel) folded in: d var / d w_i = dv * (b_i^2 - tmp * (i/16) / ws)
+  float wv_mean = 0.f, wv_ws = 1.f, wv_tmp = 0.f, wv_dv = 0.f;
+  const bool with_var = var_weights != nullptr && dvars != nullptr;
+  if (with_var) {
+    f2n_wv_stats(var_weights + s, e - s, c, wv_mean, wv_ws);
+    for (int base = 0; base + s < e; base += 16) {
+      const int i = base + c;
+      const float b = (float) i / 16.f - wv_mean;
+      const float wi = i + s < e ? var_weights[i + s] : 0.f;
+      wv_tmp = f2n_row_last(f2n_row_seq_scan(wi * 2.f * b, wv_tmp, c));
+    }
+    wv_dv = dvars[ray];
+  }
   // walk 2: reverse, suffix carries sum_{j>i} d(acc_j)
   float suffix = 0.f;
   for (int hi = e; hi > s; hi -= 16) {
@@ -216,6 +261,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
     const float w = trans * alpha;
     float dw = (dC[0] * c0 + dC[1] * c1 + dC[2] * c2) + dDisp / tt + dDepW * tt;
     if (dweights != nullptr) dw += dwi;
+    if (with_var && in) {
+      const float r = (float) (i - s) / 16.f, b = r - wv_mean;
+      dw += wv_dv * (b * b + wv_tmp * -r / wv_ws);
+    }
     // w = trans*alpha ; trans = exp(-acc_excl) ; alpha = 1 - exp(-sec)
     const float d_acc = in ? -dw * w : 0.f;
     const float suf_incl = f2n_row_seq_scan(d_acc, suffix, c);
@@ -238,19 +287,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
       df0[(size_t) i * df0_stride] = d_sigma * expf(fminf(fmaxf(x, -100.f), 5.f));
     }
   }
-}
-
-// CustomOps.cu:12-66.  mean = (sum w_i * i/16) / (1e-6 + sum w_i), both sums left to right.
-__device__ __forceinline__ void f2n_wv_stats(const float* __restrict__ w, int n, int c, float& mean, float& wsum) {
-  float m = 0.f, ws = 1e-6f;
-  for (int base = 0; base < n; base += 16) {
-    const int i = base + c;
-    const float wi = i < n ? w[i] : 0.f;
-    m = f2n_row_last(f2n_row_seq_scan(wi * ((float) i / 16.f), m, c));
-    ws = f2n_row_last(f2n_row_seq_scan(wi, ws, c));
-  }
-  mean = m / ws;
-  wsum = ws;
 }
 
 __global__ __launch_bounds__(256) void weight_var_fwd_kernel(int n_rays, const float* __restrict__ weights,
@@ -372,35 +408,38 @@ int f2n_compact_samples(void* stream, int n_rays, const int32_t* old_start_end, 
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(compact_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, old_start_end,
-                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, nullptr, nullptr);
+                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, nullptr, nullptr, nullptr,
+                     nullptr);
   return f2n_launch_status();
 }
 
 int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_end, const int32_t* new_start_end,
                             const int32_t* mask, const float* pts, const float* dirs, const float* dt, const float* t,
                             const int32_t* anchors, float* o_pts, float* o_dirs, float* o_dt, float* o_t, int32_t* o_anchors,
-                            int32_t* o_src, int32_t* o_vol) {
-  if (n_rays < 0 || o_src == nullptr) return F2N_ERR_INVALID_ARG;
+                            int32_t* o_src, int32_t* o_vol, const int32_t* ray_val, int32_t* o_ray_val) {
+  if (n_rays < 0 || o_src == nullptr || (o_ray_val != nullptr && ray_val == nullptr)) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(compact_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, old_start_end,
-                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src, o_vol);
+                     new_start_end, mask, pts, dirs, dt, t, anchors, o_pts, o_dirs, o_dt, o_t, o_anchors, o_src, o_vol, ray_val,
+                     o_ray_val);
   return f2n_launch_status();
 }
 
 int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
                       const float* t, const float* rgb, const float* bg, float* colors, float* disparity, float* depth,
-                      float* weights) {
+                      float* weights, float* out_vars) {
   if (f0_stride < 1) return F2N_ERR_INVALID_ARG;
-  F2N_ROW_LAUNCH(composite_fwd_kernel, n_rays, pts_start_end, f0, f0_stride, dt, t, rgb, bg, colors, disparity, depth, weights);
+  F2N_ROW_LAUNCH(composite_fwd_kernel, n_rays, pts_start_end, f0, f0_stride, dt, t, rgb, bg, colors, disparity, depth, weights,
+                 out_vars);
 }
 
 int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
                       const float* t, const float* rgb, const float* bg, const float* dcolors, const float* ddisparity,
                       const float* ddepth, const float* dweights, float grad_scaling_progress, float* drgb, float* df0,
-                      int df0_stride) {
-  if (f0_stride < 1 || df0_stride < 1) return F2N_ERR_INVALID_ARG;
+                      int df0_stride, const float* var_weights, const float* dvars) {
+  if (f0_stride < 1 || df0_stride < 1 || ((var_weights == nullptr) != (dvars == nullptr))) return F2N_ERR_INVALID_ARG;
   F2N_ROW_LAUNCH(composite_bwd_kernel, n_rays, pts_start_end, f0, f0_stride, dt, t, rgb, bg, dcolors, ddisparity, ddepth, dweights,
-                 grad_scaling_progress, drgb, df0, df0_stride);
+                 grad_scaling_progress, drgb, df0, df0_stride, var_weights, dvars);
 }
 
 int f2n_weight_var_fwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, float* out_vars) {

@@ -304,7 +304,9 @@ int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_e
                             const int32_t* mask, const float* pts, const float* dirs, const float* dt, const float* t,
                             const int32_t* anchors, float* o_pts, float* o_dirs, float* o_dt, float* o_t,
                             int32_t* o_anchors, int32_t* o_src /*[M]*/,
-                            int32_t* o_vol /*[M] or NULL: anchors[:,0] of the survivors as a unit-stride array*/);
+                            int32_t* o_vol /*[M] or NULL: anchors[:,0] of the survivors as a unit-stride array*/,
+                            const int32_t* ray_val /*[R] or NULL*/,
+                            int32_t* o_ray_val /*[M] or NULL: ray_val of each survivor's ray = f2n_scatter_idx on the new bounds*/);
 
 /* Compositing (Renderer.cpp:196-208): colors = sum w*c + T_last*bg, disparity = sum w/(t+.01),
  * depth = sum w*(t+.01) / (1 - T_last + 1e-4); weights [M] is also returned (RenderResult, Renderer.h:18-27).
@@ -312,7 +314,8 @@ int f2n_compact_samples_src(void* stream, int n_rays, const int32_t* old_start_e
  * stride 1 reads a compact density array (f2n_field_fwd*'s out_f0: a quarter of the cache lines). */
 int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride,
                       const float* dt, const float* t, const float* rgb /*[M,3]*/, const float* bg /*[R,3]*/,
-                      float* colors /*[R,3]*/, float* disparity /*[R]*/, float* depth /*[R]*/, float* weights /*[M]*/);
+                      float* colors /*[R,3]*/, float* disparity /*[R]*/, float* depth /*[R]*/, float* weights /*[M]*/,
+                      float* out_vars /*[R] or NULL: f2n_weight_var_fwd of the weights, same arithmetic, same launch*/);
 
 /* Backward of the above through TruncExp; gradient scaling (CustomOps.cu:68-80) is applied to dsigma and
  * drgb when grad_scaling_progress < 1.  Any of dcolors/ddisparity/ddepth/dweights may be NULL (= zero).
@@ -321,7 +324,10 @@ int f2n_composite_fwd(void* stream, int n_rays, const int32_t* pts_start_end, co
 int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride,
                       const float* dt, const float* t, const float* rgb, const float* bg, const float* dcolors,
                       const float* ddisparity, const float* ddepth, const float* dweights,
-                      float grad_scaling_progress, float* drgb, float* df0, int df0_stride);
+                      float grad_scaling_progress, float* drgb, float* df0, int df0_stride,
+                      const float* var_weights /*[M] or NULL*/, const float* dvars /*[R] or NULL*/);
+/* var_weights + dvars (both or neither): the gradient f2n_weight_var_bwd would produce from them is added to dweights
+ * inside this launch (same arithmetic), so a training step needs neither the extra launch nor the [M] buffer. */
 
 /* WeightVarLoss forward/backward (CustomOps.cu:12-66). */
 int f2n_weight_var_fwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, float* out_vars);

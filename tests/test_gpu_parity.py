@@ -752,6 +752,14 @@ def test_early_stop_and_compaction(hip):
     for got, e in zip(o2, exp):
         assert_same(N(got), e, "compaction (+src)")
     assert_same(N(src)[:m], np.nonzero(N(mask))[0].astype(np.int32), "source rows")
+    # ScatterIdx of the survivors riding along: equals f2n_scatter_idx on the new bounds
+    ray_val = torch.from_numpy(rng.integers(0, 50, R).astype(np.int32)).to(DEV)
+    o3 = [torch.zeros_like(x) for x in o]
+    got_rv = torch.full((max(m, 1),), -7, dtype=torch.int32, device=DEV)
+    hip.compact_samples_src(R, T(se), new_se, mask, T(pts), T(dirs), T(dt), T(t), T(anchors), *o3, src, None, ray_val, got_rv)
+    exp_rv = torch.full((max(m, 1),), -7, dtype=torch.int32, device=DEV)
+    hip.scatter_idx(R, new_se, ray_val, exp_rv)
+    assert_same(N(got_rv), N(exp_rv), "fused scatter_idx")
 
 
 @pytest.mark.parametrize("gs", [1.0, 0.3])
@@ -793,6 +801,21 @@ def test_composite_forward_backward(hip, gs):
     hip.composite_bwd(R, T(se), f0c, T(dt), T(t), T(rgb), T(bg), T(dcol), T(ddisp), T(ddep), T(dw), gs, drgb2, df0c, f0_stride=1,
                       df0_stride=1)
     assert_same(N(drgb2), N(drgb)); assert_same(N(df0c), N(dfeat)[:, 0].copy())
+    # WeightVarLoss folded into the two launches: bit-identical to the separate kernels
+    var_sep = torch.zeros(R, device=DEV); hip.weight_var_fwd(R, wts, T(se), var_sep)
+    col3 = torch.zeros((R, 3), device=DEV); disp3 = torch.zeros(R, device=DEV); dep3 = torch.zeros(R, device=DEV)
+    wts3 = torch.zeros(n, device=DEV); var_fused = torch.full((R,), -1.0, device=DEV)
+    hip.composite_fwd(R, T(se), f0c, T(dt), T(t), T(rgb), T(bg), col3, disp3, dep3, wts3, f0_stride=1, out_vars=var_fused)
+    assert_same(N(var_fused), N(var_sep), "fused weight variance"); assert_same(N(wts3), N(wts))
+    dvar = torch.from_numpy(rng.standard_normal(R).astype(F32) * F32(0.1)).to(DEV)
+    dw_sep = torch.zeros(n, device=DEV); hip.weight_var_bwd(R, wts, T(se), dvar, dw_sep)
+    drgb_a = torch.zeros((n, 3), device=DEV); df0_a = torch.zeros(n, device=DEV)
+    hip.composite_bwd(R, T(se), f0c, T(dt), T(t), T(rgb), T(bg), T(dcol), T(ddisp), None, dw_sep, gs, drgb_a, df0_a, f0_stride=1,
+                      df0_stride=1)
+    drgb_b = torch.zeros((n, 3), device=DEV); df0_b = torch.zeros(n, device=DEV)
+    hip.composite_bwd(R, T(se), f0c, T(dt), T(t), T(rgb), T(bg), T(dcol), T(ddisp), None, None, gs, drgb_b, df0_b, f0_stride=1,
+                      df0_stride=1, var_weights=wts, dvars=dvar)
+    assert_same(N(drgb_b), N(drgb_a), "fused weight-variance backward (drgb)"); assert_same(N(df0_b), N(df0_a), "... (d f0)")
     # empty batch and NULL gradient inputs are accepted
     hip.composite_bwd(R, T(se), T(feat), T(dt), T(t), T(rgb), T(bg), T(dcol), None, None, None, 1.0, drgb, dfeat)
     rdrgb2, _ = op.composite_bwd(ref["ctx"], dt, rgb, bg, se, dcol)
