@@ -150,6 +150,8 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   }
   FinishPendingStep();
   renderer_->ZeroGrad();
+  renderer_->after_octree_update_ = nullptr;  // (a previous call that threw must not leave its hook / half a prefetch behind)
+  renderer_->DropPendingSamples();
   deferred_dropped_ = false;
   if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
   if (prefetch) {
@@ -173,7 +175,8 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   stats.loss = out.losses.slice(0, 0, 1).squeeze(0);
   stats.mse = out.losses.slice(0, 5, 6).squeeze(0);
   bool applied = false;
-  if (out.has_samples) {
+  // (a data-parallel replica whose batch missed the scene still joins the gradient exchange, with its zero gradients)
+  if (out.has_samples || grad_sync_hook_ || grad_sync_begin_hook_) {
     if (pipelined) {
       if (grad_sync_begin_hook_) grad_sync_begin_hook_();  // asynchronous all-reduce; awaited in the next step (or Flush)
       pending_ = true;

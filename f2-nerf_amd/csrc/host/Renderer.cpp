@@ -293,6 +293,9 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   fr.bg_color = bg_color;
   if (n_all_pts <= 0) {  // Renderer.cpp:83-97
     if (train) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f;
+    // data-parallel replicas must all take part in the occupancy exchange, also the one whose batch missed the scene
+    if (train && static_cast<PersSampler*>(pts_sampler_.get())->occupancy_sync_hook_)
+      pts_sampler_->UpdateOctNodes(sample_result_, torch::empty({0}, DevF32()), torch::empty({0}, DevF32()));
     last_n_kept_pts_ = 0;
     fr.empty = true;
     octree_ready_ev_.record();

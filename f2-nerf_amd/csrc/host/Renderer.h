@@ -64,6 +64,12 @@ class Renderer : public Pipe {
   void PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, float fineness);
   void PreSampleFinish();
   bool PreSampleBegun() const { return pending_samples_.active; }
+  void DropPendingSamples() {
+    if (!pending_samples_.active) return;
+    pending_samples_.counts_ready.synchronize();  // its kernels may still be running: keep the buffers until they are done
+    pending_samples_ = PendingSamples();
+    pending_rays_o_ = pending_rays_d_ = Tensor();
+  }
   std::function<void()> after_octree_update_;  // one-shot: called in SampleAndFilter right after the occupancy update
   PendingSamples pending_samples_;
   Tensor pending_rays_o_, pending_rays_d_;

@@ -296,6 +296,15 @@ def test_data_parallel_hooks_on_one_gpu(rt, fox_state):
             losses = [float(runner.train_step(d[0], d[1], d[2], d[3], d[4], True, *nxt)["loss"]) for _ in range(5)]
             assert runner.iter_step == 5
             outs.append((losses, [t.clone() for t in runner.states()]))  # states() completes a pending overlapped step
+            if mode in ("blocking", "overlapped"):
+                # a replica whose batch misses the scene still takes part in all three exchanges (no hang, no throw)
+                far = d[0] + 1e4
+                s_empty = runner.train_step(far, d[1], d[2], d[3], d[4], True)
+                assert s_empty["n_samples"] == 0 and runner.iter_step == 6
+                runner.flush()
+                for t in runner.states():
+                    if t.dtype.is_floating_point:
+                        assert torch.isfinite(t).all()
     finally:
         dist.destroy_process_group()
     for other in outs[1:]:
