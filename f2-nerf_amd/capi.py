@@ -345,6 +345,31 @@ def adam_step(n, param, grad, grad_scale, grad_round_h16, exp_avg, exp_avg_sq, s
                             _f(wd), _p(param_h, "h16", True), _i(int(zero_grad)), _p(skip_flag, "i32", True)), "f2n_adam_step")
 
 
+class _AdamGroup(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("param_h", ctypes.c_void_p), ("n", ctypes.c_int), ("grad_scale", ctypes.c_float), ("weight_decay", ctypes.c_float),
+                ("grad_round_h16", ctypes.c_int), ("check_finite", ctypes.c_int)]
+
+
+def adam_small_groups(groups, step, lr, beta1, beta2, eps, zero_grad, flags=None, skip_flag=None):
+    """groups: list of dicts {param, grad, exp_avg, exp_avg_sq, param_h (or None), grad_scale, weight_decay, grad_round_h16,
+    check_finite}; one launch (f2n_adam_small_groups)."""
+    arr = (_AdamGroup * len(groups))()
+    for a, g in zip(arr, groups):
+        a.param = _p(g["param"], "f32").value
+        a.grad = _p(g["grad"], "f32").value
+        a.exp_avg = _p(g["exp_avg"], "f32").value
+        a.exp_avg_sq = _p(g["exp_avg_sq"], "f32").value
+        a.param_h = _p(g.get("param_h"), "h16", True).value
+        a.n = int(g["param"].numel())
+        a.grad_scale = float(g["grad_scale"])
+        a.weight_decay = float(g["weight_decay"])
+        a.grad_round_h16 = int(bool(g.get("grad_round_h16", False)))
+        a.check_finite = int(bool(g.get("check_finite", False)))
+    _ck(lib().f2n_adam_small_groups(_stream(), _i(len(groups)), arr, _i(step), _f(lr), _f(beta1), _f(beta2), _f(eps),
+                                    _i(int(zero_grad)), _p(flags, "i32", True), _p(skip_flag, "i32", True)), "f2n_adam_small_groups")
+
+
 def adam_step_h16grad(n, param, grad_h, grad_scale, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
                       zero_grad, skip_flag=None):
     _ck(lib().f2n_adam_step_h16grad(_stream(), _i(n), _p(param, "f32"), _p(grad_h, "h16"), _f(grad_scale),

@@ -100,27 +100,57 @@ int ExpRunner::CurBatchSize() const {  // ExpRunner.cpp:86
   return int(pts_batch_size_ / global_data_pool_->meaningful_sampled_pts_per_ray_) >> 4 << 4;
 }
 
-void ExpRunner::OptimStep(const int32_t* skip_flag) {
+// One optimiser step.  compute_flags (device int32[3], or NULL): the finiteness flags of the two MLP gradients are
+// computed inside the small-groups launch and every update of this step is predicated on them (flags[2]).
+void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
   optim_steps_ += 1;
   void* st = CurStream();
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
   torch::NoGradGuard no_grad;
+  // the small fp32 groups (field MLP, colour MLP, app_emb) in ONE launch, in the order the flag layout names them
+  F2nAdamGroup small[4];
+  int n_small = 0;
+  auto add_small = [&](size_t i, bool check) {
+    auto& g = groups_[i];
+    float scale = g.grad_scale;
+    if (scale < 0.f) scale = 1.f / (g.name == "color_mlp" ? shader->mlp_->loss_scale_ : field->mlp_->loss_scale_);
+    F2nAdamGroup d;
+    d.param = F32P(g.param);
+    d.grad = F32P(g.grad);
+    d.exp_avg = F32P(exp_avg_[i]);
+    d.exp_avg_sq = F32P(exp_avg_sq_[i]);
+    d.param_h = g.param_h.defined() ? VoidP(g.param_h) : nullptr;
+    d.n = (int) (g.active > 0 ? g.active : g.param.numel());
+    d.grad_scale = scale;
+    d.weight_decay = g.weight_decay;
+    d.grad_round_h16 = g.grad_round_h16 ? 1 : 0;
+    d.check_finite = check ? 1 : 0;
+    TORCH_CHECK(n_small < 4, "too many small parameter groups");
+    small[n_small++] = d;
+  };
+  const bool flags = compute_flags != nullptr;
+  for (size_t i = 0; i < groups_.size(); i++)
+    if (groups_[i].name == "field_mlp") add_small(i, flags);
+  for (size_t i = 0; i < groups_.size(); i++)
+    if (groups_[i].name == "color_mlp") add_small(i, flags);
+  TORCH_CHECK(!flags || n_small == 2, "finiteness flags need the field and colour MLP groups");
+  for (size_t i = 0; i < groups_.size(); i++)
+    if (!groups_[i].grad_is_h16 && groups_[i].name != "field_mlp" && groups_[i].name != "color_mlp") add_small(i, false);
+  if (n_small > 0)
+    F2N_TIMED_CALL("adam", f2n_adam_small_groups(st, n_small, small, optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, /*zero_grad=*/1,
+                                                 compute_flags, skip_flag));
+  const int32_t* table_skip = flags ? compute_flags + 2 : skip_flag;  // (callers pass one or the other)
   for (size_t i = 0; i < groups_.size(); i++) {
     auto& g = groups_[i];
+    if (!g.grad_is_h16) continue;
     const int64_t n = g.active > 0 ? g.active : g.param.numel();
     float scale = g.grad_scale;
     if (scale < 0.f) scale = 1.f / (g.name == "color_mlp" ? shader->mlp_->loss_scale_ : field->mlp_->loss_scale_);
-    if (g.grad_is_h16) {
-      F2N_TIMED_CALL("adam_table", f2n_adam_step_h16grad(st, (int) n, F32P(g.param), VoidP(g.grad), scale, F32P(exp_avg_[i]),
-                                     F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
-                                     VoidP(g.param_h), /*zero_grad=*/1, skip_flag));
-      if (g.name == "feat_pool") field->grad_clean_ = true;
-    } else {
-      F2N_TIMED_CALL("adam", f2n_adam_step(st, (int) n, F32P(g.param), F32P(g.grad), scale, g.grad_round_h16 ? 1 : 0, F32P(exp_avg_[i]),
-                             F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
-                             g.param_h.defined() ? VoidP(g.param_h) : nullptr, /*zero_grad=*/1, skip_flag));
-    }
+    F2N_TIMED_CALL("adam_table", f2n_adam_step_h16grad(st, (int) n, F32P(g.param), VoidP(g.grad), scale, F32P(exp_avg_[i]),
+                                   F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
+                                   VoidP(g.param_h), /*zero_grad=*/1, table_skip));
+    if (g.name == "feat_pool") field->grad_clean_ = true;
   }
   renderer_->small_grads_clean_ = true;  // every group's gradient was consumed and cleared (also on the skipped path)
 }
@@ -237,14 +267,13 @@ bool ExpRunner::ResolveDeferredFlags() {
 void ExpRunner::EnqueueApply(bool apply_optimizer) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
-  const int32_t* skip = nullptr;
-  if (check_nan_) {
-    if (!nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
+  if (check_nan_ && !nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
+  if (apply_optimizer) {  // the flags are computed by the small-groups launch itself; a no-op on the device when they say so
+    OptimStep(nullptr, check_nan_ ? I32P(nan_flags_) : nullptr);
+  } else if (check_nan_) {
     F2N_CALL(f2n_nonfinite_flags(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
                                  F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_)));
-    skip = I32P(nan_flags_) + 2;
   }
-  if (apply_optimizer) OptimStep(skip);  // a no-op on the device when the flags say so
 }
 
 // The iteration's only read-back besides the two sample counts.  Returns true when the gradients were not finite (loss

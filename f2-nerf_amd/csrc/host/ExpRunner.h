@@ -44,7 +44,8 @@ class ExpRunner {
   TrainStats last_train_stats_;
   void UpdateAdaParams();
   float FinenessAt(int iter) const;
-  void OptimStep(const int32_t* skip_flag = nullptr);  // skip_flag: device int, != 0 drops the update
+  // skip_flag: device int, != 0 drops the update; compute_flags: device int32[3], finiteness flags computed (and obeyed) in the step
+  void OptimStep(const int32_t* skip_flag = nullptr, int32_t* compute_flags = nullptr);
   void BuildOptimizer();
   Tensor FlattenSmallGrads();
   int CurBatchSize() const;

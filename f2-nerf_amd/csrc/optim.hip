@@ -188,6 +188,63 @@ __global__ __launch_bounds__(1024) void nonfinite_flags_kernel(int n_a, const fl
   }
 }
 
+// The small parameter groups of one iteration (field MLP, colour MLP, appearance embedding: ~11 k values) in ONE
+// single-block launch: finiteness flags of the checked groups (the layout of f2n_nonfinite_flags: group 0, group 1, either),
+// then Adam on every group, predicated on those flags (and on an optional external one).  Same per-element arithmetic as
+// adam_kernel; replaces four launches of a few microseconds each on the per-iteration floor.
+#define F2N_ADAM_MAX_GROUPS 4
+struct F2nAdamGroupDev {
+  float *param, *grad, *exp_avg, *exp_avg_sq;
+  half_t* param_h;
+  int n, grad_round_h16, check_finite;
+  F2nAdamCoef k;
+};
+struct F2nAdamGroupsDev {
+  F2nAdamGroupDev g[F2N_ADAM_MAX_GROUPS];
+};
+
+__global__ __launch_bounds__(1024) void adam_small_groups_kernel(F2nAdamGroupsDev gs, int n_groups, int zero_grad,
+                                                                 int32_t* __restrict__ flags, const int32_t* __restrict__ skip_in) {
+  bool bad[F2N_ADAM_MAX_GROUPS];
+#pragma unroll
+  for (int q = 0; q < F2N_ADAM_MAX_GROUPS; q++) {
+    bool b = false;
+    if (q < n_groups && gs.g[q].check_finite)
+      for (int i = threadIdx.x; i < gs.g[q].n; i += blockDim.x) b |= !isfinite(gs.g[q].grad[i]);
+    bad[q] = __syncthreads_or(b ? 1 : 0) != 0;  // block-wide: every thread knows the group's flag
+  }
+  bool any_bad = false;
+#pragma unroll
+  for (int q = 0; q < F2N_ADAM_MAX_GROUPS; q++) any_bad |= bad[q];
+  if (flags != nullptr && threadIdx.x == 0) {
+    flags[0] = bad[0] ? 1 : 0;
+    flags[1] = bad[1] ? 1 : 0;
+    flags[2] = any_bad ? 1 : 0;
+  }
+  const bool skip = any_bad || (skip_in != nullptr && *skip_in != 0);
+#pragma unroll
+  for (int q = 0; q < F2N_ADAM_MAX_GROUPS; q++) {
+    if (q >= n_groups) continue;
+    const F2nAdamGroupDev& G = gs.g[q];
+    for (int i = threadIdx.x; i < G.n; i += blockDim.x) {
+      if (skip) {  // dropped iteration (ExpRunner.cpp:131-134): parameters and moments stay, the gradient is consumed
+        if (zero_grad) G.grad[i] = 0.f;
+        continue;
+      }
+      float g = G.grad[i];
+      if (zero_grad) G.grad[i] = 0.f;
+      if (G.grad_round_h16) g = (float) (half_t) ((float) (half_t) g * G.k.grad_scale);
+      else g = g * G.k.grad_scale;
+      float m = G.exp_avg[i], v = G.exp_avg_sq[i];
+      const float p = f2n_adam_update(G.param[i], g, m, v, G.k);
+      G.param[i] = p;
+      G.exp_avg[i] = m;
+      G.exp_avg_sq[i] = v;
+      if (G.param_h != nullptr) G.param_h[i] = (half_t) p;
+    }
+  }
+}
+
 static F2nAdamCoef f2n_adam_coef(int step, float lr, float beta1, float beta2, float eps, float wd, float grad_scale) {
   const double bc1 = 1.0 - pow((double) beta1, (double) step);
   const double bc2 = 1.0 - pow((double) beta2, (double) step);
@@ -232,6 +289,29 @@ int f2n_adam_step_h16grad(void* stream, int n, float* param, void* grad_h, float
   return f2n_launch_status();
 }
 
+int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups, int step, float lr, float beta1, float beta2,
+                          float eps, int zero_grad, int32_t* flags, const int32_t* skip_flag) {
+  if (n_groups < 1 || n_groups > F2N_ADAM_MAX_GROUPS || groups == nullptr || step < 1) return F2N_ERR_INVALID_ARG;
+  F2nAdamGroupsDev gs = {};
+  for (int q = 0; q < n_groups; q++) {
+    const F2nAdamGroup& g = groups[q];
+    if (g.n < 0 || (g.n > 0 && (g.param == nullptr || g.grad == nullptr || g.exp_avg == nullptr || g.exp_avg_sq == nullptr)))
+      return F2N_ERR_INVALID_ARG;
+    if (g.check_finite && q > 1) return F2N_ERR_UNSUPPORTED;  // the flag layout names groups 0 and 1
+    gs.g[q].param = g.param;
+    gs.g[q].grad = g.grad;
+    gs.g[q].exp_avg = g.exp_avg;
+    gs.g[q].exp_avg_sq = g.exp_avg_sq;
+    gs.g[q].param_h = (half_t*) g.param_h;
+    gs.g[q].n = g.n;
+    gs.g[q].grad_round_h16 = g.grad_round_h16;
+    gs.g[q].check_finite = g.check_finite;
+    gs.g[q].k = f2n_adam_coef(step, lr, beta1, beta2, eps, g.weight_decay, g.grad_scale);
+  }
+  hipLaunchKernelGGL(adam_small_groups_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, gs, n_groups, zero_grad, flags, skip_flag);
+  return f2n_launch_status();
+}
+
 int f2n_train_loss(void* stream, int n_rays, const float* pred_colors, const float* gt_colors, const float* disparity,
                    const float* sampled_var, int n_edge, int feat_dim, const float* edge_feats, float var_w, float disp_w,
                    float tv_w, float* out_losses, float* dcolors, float* ddisparity, float* dvar, float* dedge_feats) {
@@ -252,7 +332,7 @@ int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const fl
   return f2n_launch_status();
 }
 
-int f2n_abi_version(void) { return 4; }
+int f2n_abi_version(void) { return 5; }
 const char* f2n_build_info(void) { return "f2n_hip gfx950 (hipcc, -ffp-contract=off), wave64, mfma_f32_16x16x32_f16"; }
 
 }  // extern "C"

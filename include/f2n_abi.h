@@ -368,6 +368,25 @@ int f2n_adam_step(void* stream, int n, float* param, float* grad, float grad_sca
                   float* exp_avg, float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
                   float weight_decay, void* param_h_or_null, int zero_grad /* clear grad after use (also when skipped) */,
                   const int32_t* skip_flag /*device, or NULL*/);
+/* The small parameter groups of an iteration in ONE launch: finiteness flags (TCNNWP.cpp:234-240; layout of
+ * f2n_nonfinite_flags: flags[0] = group 0 has a non-finite gradient, flags[1] = group 1, flags[2] = either; only groups
+ * 0 and 1 may ask for the check) followed by f2n_adam_step on every group, predicated on flags[2] and on *skip_flag.
+ * `groups` is a HOST array of 1..4 descriptors; element-wise arithmetic identical to f2n_adam_step. */
+typedef struct F2nAdamGroup {
+  float* param;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  void* param_h;      /* h16 working copy to refresh, or NULL */
+  int n;
+  float grad_scale;
+  float weight_decay;
+  int grad_round_h16;
+  int check_finite;
+} F2nAdamGroup;
+int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups, int step, float lr, float beta1,
+                          float beta2, float eps, int zero_grad, int32_t* flags /*device [3] or NULL*/,
+                          const int32_t* skip_flag /*device, or NULL*/);
 /* h16 gradient table produced by f2n_hash_bwd / f2n_field_bwd (true gradient = float(grad_h) * grad_scale,
  * grad_scale = 1/128): fuses the fp16->fp32 cast, the /128 (Hash3DAnchored.cu:232), Adam, the fp32->fp16
  * refresh of the table (Hash3DAnchored.cu:186) and the re-zeroing of the gradient (:222) in one pass. */

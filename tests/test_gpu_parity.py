@@ -915,6 +915,47 @@ def test_nonfinite_flags_and_skipped_adam(hip):
         assert (N(tg) == 0).all() and bool((N(tp) == before).all()) == bad
 
 
+def test_adam_small_groups_equals_separate_launches(hip):
+    """f2n_adam_small_groups = f2n_nonfinite_flags + one f2n_adam_step per group, bit for bit, on the applied and on the
+    dropped path."""
+    rng = np.random.default_rng(23)
+    sizes = (3072, 7168, 800)
+    for bad in (False, True):
+        base = []
+        for k, n in enumerate(sizes):
+            g = rng.standard_normal(n).astype(F32)
+            if bad and k == 1:
+                g[n // 2] = np.inf
+            base.append(dict(p=rng.standard_normal(n).astype(F32), g=g, m=rng.standard_normal(n).astype(F32) * F32(0.1),
+                             v=rng.random(n, dtype=F32) * F32(0.01)))
+        scales, wds, rounds = (1.0 / 128, 1.0 / 64, 1.0), (1e-6, 1e-6, 1e-6), (True, True, False)
+        # separate launches
+        sep = [{k: T(v) for k, v in b.items()} for b in base]
+        sep_h = [torch.zeros(n, dtype=torch.float16, device=DEV) for n in sizes]
+        flags_a = torch.full((3,), 9, dtype=torch.int32, device=DEV)
+        hip.nonfinite_flags(sizes[0], sep[0]["g"], sizes[1], sep[1]["g"], flags_a)
+        for k in range(3):
+            hip.adam_step(sizes[k], sep[k]["p"], sep[k]["g"], scales[k], rounds[k], sep[k]["m"], sep[k]["v"], 7, 3e-3, 0.9, 0.99, 1e-15,
+                          wds[k], sep_h[k] if k < 2 else None, flags_a[2:], zero_grad=True)
+        # one launch
+        fus = [{k: T(v) for k, v in b.items()} for b in base]
+        fus_h = [torch.zeros(n, dtype=torch.float16, device=DEV) for n in sizes]
+        flags_b = torch.full((3,), 9, dtype=torch.int32, device=DEV)
+        hip.adam_small_groups([dict(param=fus[k]["p"], grad=fus[k]["g"], exp_avg=fus[k]["m"], exp_avg_sq=fus[k]["v"],
+                                    param_h=fus_h[k] if k < 2 else None, grad_scale=scales[k], weight_decay=wds[k],
+                                    grad_round_h16=rounds[k], check_finite=k < 2) for k in range(3)],
+                              7, 3e-3, 0.9, 0.99, 1e-15, True, flags_b)
+        assert N(flags_a).tolist() == N(flags_b).tolist() == ([0, 1, 1] if bad else [0, 0, 0])
+        for k in range(3):
+            for key in ("p", "m", "v", "g"):
+                assert_same(N(fus[k][key]), N(sep[k][key]), "group %d %s" % (k, key))
+            assert (N(fus[k]["g"]) == 0).all()
+            if bad:
+                assert_same(N(fus[k]["p"]), base[k]["p"])
+            if k < 2:
+                assert_same(N(fus_h[k]).view(np.uint16), N(sep_h[k]).view(np.uint16))
+
+
 def test_img2world_rays_and_pixel_gather(hip, fox_state, fox_golden):
     """Dataset.cu:93-123 on the device: bit-exact against the oracle (itself pinned on the reference kernel), for the fox
     cameras, for strongly distorted synthetic cameras, and against the committed golden rays."""
