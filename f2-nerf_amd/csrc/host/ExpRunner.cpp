@@ -184,7 +184,9 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   renderer_->DropPendingSamples();
   deferred_dropped_ = false;
   if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
-  if (prefetch) {
+  if (prefetch && !pipelined) {
+    // (Pipelined data-parallel steps keep the sampling at the step boundary instead: there it runs underneath the gradient
+    // all-reduce, which has nothing else to hide under -- measured with a one-rank RCCL world: 1.40 vs 1.53 ms per step.)
     // The NEXT batch's sampling only depends on this step's octree update: its kernels are issued (on a side stream) from
     // inside SampleAndFilter, right behind that update, with the next iteration's fineness; the host comes back for its
     // counts after this step's backward has been queued (PreSampleFinish below).
@@ -228,11 +230,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     else renderer_->PreSampleAsync(next_rays_o, next_rays_d, next_bounds);  // (a batch without samples never reached the hook)
   }
   if (applied && check_nan_ && prefetch) {  // streaming: do not stall on this step's flags (see ExpRunner.h)
-    if (!nan_flags_host_.defined()) nan_flags_host_ = torch::empty({4}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-    nan_flags_host_.copy_(nan_flags_, /*non_blocking=*/true);
-    nan_flags_ev_.record();
-    flags_deferred_ = true;
-    deferred_apply_ = apply_optimizer;
+    DeferFlags(apply_optimizer);
   } else if (applied && ResolveFlags(apply_optimizer)) {
     stats.skipped_nan = true;  // iteration not advanced, like the `continue` at ExpRunner.cpp:133
     if (apply_optimizer) {
@@ -312,15 +310,23 @@ void ExpRunner::FinishPending() {
 void ExpRunner::FinishPendingStep() {
   if (!pending_) return;
   pending_ = false;
-  if (grad_sync_end_hook_) grad_sync_end_hook_();
+  if (grad_sync_end_hook_) grad_sync_end_hook_();  // the compute stream waits for the collective; the host does not
   const float lr_now = cur_lr_;
   cur_lr_ = pending_lr_;
-  const bool nan = ApplyGradients(true);
+  EnqueueApply(true);  // flags + Adam, predicated on the device
   cur_lr_ = lr_now;
-  if (nan) {
-    iter_step_ = std::max(0, iter_step_ - 1);
-    UpdateAdaParams();
-  }
+  // The host does not wait for the flags here either (it would idle the device between this Adam and the next step's first
+  // kernels): they travel to pinned memory and are read after the next sample-count read-back, or by FinishPending().
+  if (check_nan_) DeferFlags(true);
+}
+
+void ExpRunner::DeferFlags(bool apply_optimizer) {
+  if (flags_deferred_) ResolveDeferredFlags();  // (one set in flight at a time)
+  if (!nan_flags_host_.defined()) nan_flags_host_ = torch::empty({4}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+  nan_flags_host_.copy_(nan_flags_, /*non_blocking=*/true);
+  nan_flags_ev_.record();
+  flags_deferred_ = true;
+  deferred_apply_ = apply_optimizer;
 }
 
 // The same iteration on the autograd tape, op for op as the reference spells it (ExpRunner.cpp:82-143): Render(),

@@ -26,6 +26,7 @@ class ExpRunner {
   // still in flight, and the finiteness flags a prefetching TrainStep reads one step late.
   void FinishPending();
   void FinishPendingStep();     // the pipelined data-parallel part only
+  void DeferFlags(bool apply_optimizer);  // start the asynchronous read-back of nan_flags_
   bool ResolveDeferredFlags();  // true: the step they belong to was dropped (loss scales halved, counters taken back)
   // next_*: optionally the NEXT iteration's rays (already resident): their sampling is prefetched on a side stream
   TrainStats TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
