@@ -61,6 +61,80 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+class _StubRunner:
+    """The hook surface of the host ExpRunner that parallel.attach() wires (bindings.cpp), without a GPU."""
+
+    def __init__(self, rank, log2):
+        rng = np.random.default_rng(500 + rank)
+        self.table = torch.from_numpy(rng.standard_normal((32 << log2, 2)).astype(np.float16))  # allocated: 2x the active prefix
+        self.flat = torch.from_numpy(rng.standard_normal(3072 + 7168 + 800).astype(np.float32))
+        self.grad_sync = self.occ_sync = None
+
+    def flatten_small_grads(self):
+        return self.flat
+
+    def grad_buffers(self):
+        return [self.table, self.flat[:3072], self.flat[3072:10240], self.flat[10240:]]
+
+    def set_grad_sync_hook(self, f):
+        self.grad_sync = f
+
+    def set_pipelined_grad_sync(self, begin, end):
+        self.grad_sync = lambda: (begin(), end())
+
+    def set_occupancy_sync_hook(self, f):
+        self.occ_sync = f
+
+
+def _attach_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import parallel
+    log2 = 5
+    r = _StubRunner(rank, log2)
+    before_t, before_f = r.table.clone(), r.flat.clone()
+    parallel.attach(r, log2)  # gloo: the blocking variant (overlap defaults to the RCCL backend only)
+    assert r.grad_sync is not None and r.occ_sync is not None
+    # a replica whose batch missed the scene contributes zero gradients and no votes, and still calls both hooks
+    if rank == 1:
+        r.table.zero_(); r.flat.zero_()
+        before_t, before_f = r.table.clone(), r.flat.clone()
+    occ = torch.full((4, 37), -1, dtype=torch.int32)
+    if rank == 0:
+        occ[0, 3] = 512; occ[2, 3] = 1; occ[3, 3] = 9
+    r.occ_sync(occ)
+    r.grad_sync()
+    np.save(os.path.join(out_dir, "a_t_%d.npy" % rank), r.table.numpy())
+    np.save(os.path.join(out_dir, "a_f_%d.npy" % rank), r.flat.numpy())
+    np.save(os.path.join(out_dir, "a_tb_%d.npy" % rank), before_t.numpy())
+    np.save(os.path.join(out_dir, "a_fb_%d.npy" % rank), before_f.numpy())
+    np.save(os.path.join(out_dir, "a_occ_%d.npy" % rank), occ.numpy())
+    dist.destroy_process_group()
+
+
+def test_attach_wires_three_collectives_gloo(tmp_path):
+    """parallel.attach(): after one step's hooks every replica holds the mean gradient (active table prefix + ONE flat small
+    buffer) and the max-combined occupancy votes -- including when one replica had nothing to contribute."""
+    world = 2
+    mp.spawn(_attach_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ld = lambda n, r: np.load(tmp_path / (n % r))
+    active = 17 << 5
+    tb = [ld("a_tb_%d.npy", r).astype(np.float32).reshape(-1) for r in range(world)]
+    mean_t = ((tb[0] + tb[1]) / 2).astype(np.float16).astype(np.float32)
+    mean_f = (ld("a_fb_%d.npy", 0) + ld("a_fb_%d.npy", 1)) / 2
+    for r in range(world):
+        t = ld("a_t_%d.npy", r).astype(np.float32).reshape(-1)
+        np.testing.assert_array_equal(t[:active], mean_t[:active])
+        np.testing.assert_array_equal(t[active:], tb[r][active:])
+        np.testing.assert_allclose(ld("a_f_%d.npy", r), mean_f, rtol=0, atol=1e-7)
+    o0, o1 = ld("a_occ_%d.npy", 0), ld("a_occ_%d.npy", 1)
+    np.testing.assert_array_equal(o0, o1)
+    assert o0[0, 3] == 512 and o0[2, 3] == 1 and o0[3, 3] == 9 and (o0[1] == -1).all()
+
+
 def test_data_parallel_collectives_gloo(tmp_path, fox_state, fox_golden):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
