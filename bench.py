@@ -12,11 +12,19 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU): rays shard acro
 rays per rank); one RCCL all-reduce (AVG) of the gradient buffers per step + one all-reduce (MAX) of the octree
 occupancy votes so that every replica prunes identically.
 
+`--gpus N` without a torch.distributed environment re-executes itself under `torch.distributed.run` with N ranks on
+127.0.0.1 (the driver launches the N ranks itself; both ways end in the same code).
+
 Prints ONE JSON line on rank 0 (see the contract in the task description): metric/value/unit, ms_per_step, plus
   roofline     -- HBM-roofline fraction of the dominant kernel, its duration measured live with HIP events on
                   the launch stream during the timed region (algorithmic bytes per sample: DESIGN.md section 4)
   cpu_baseline -- the CPU oracle (port of the reference path; the reference has no CPU path) timed on this box's
                   host cores on a bounded sample (rank 0, N=1 only).
+  converged    -- (rank 0, N=1 only) SURVEY 8(d) config 2 state (ii): the same scene TRAINED for 20 000 iterations on the
+                  reference's fox photographs at dataset.factor 2 (ExpRunner::Train: adaptive ray batch, octree
+                  subdivision / pruning at the milestones), its test-view PSNR by the reference's definition, and then the
+                  same full train step timed in that state (pruned 1e5-node octree, trained table, rays of 5..400
+                  samples, rho > 1) with its own dominant-kernel line.
 """
 import argparse
 import json
@@ -49,20 +57,121 @@ HBM_PEAK_GBS = 8000.0
 # HBM fraction as roofline.request_ceiling.
 GATHER_REQ_PEAK = 263.0e9
 
+# Algorithmic HBM bytes per MARCHED sample of the kernels that can dominate a step:
+#   hash_gather  16 levels x 8 corners x 4 B + point 12 + warp index 4 + 64 B of f16 feature planes written
+#   ray_march    dt 4 + t 4 + (warp, node) 8 written into the ray's slot + 16 B per leaf-list entry read (~1 entry / 2 samples)
+ALGO_BYTES_CONVERGED = {"hash_gather": 592, "ray_march": 16 + 8, "field_bwd": 64 + 64 + 8 * 16 * 8, "oct_intersect": 16}
+
+
+def converged_leg(args, st, dev):
+    """SURVEY 8(d) config 2, state (ii).  Trains the scene for args.train_iters iterations on the fox photographs with the
+    reference's loop (ExpRunner::Train), reports the test PSNR (reference definition: 8-bit quantised prediction,
+    ExpRunner.cpp:360-369), then times full train steps on real training batches in that state."""
+    from f2_nerf_amd import runtime, fox_data
+    host = runtime.host()
+    t_load = time.perf_counter()
+    sc, images = fox_data.scene(args.factor)
+    ds = runtime.make_dataset(sc, images)
+    runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022, device=dev)
+    torch.manual_seed(2022)
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t_load
+    t0 = time.perf_counter()
+    s = runner.train(ds, args.train_iters, 1)
+    torch.cuda.synchronize()
+    train_wall = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    views = [float(v) for v in runner.test_images(ds)]
+    torch.cuda.synchronize()
+    test_wall = time.perf_counter() - t1
+    out = {"state": "after %d iterations of ExpRunner::Train on the ngp_fox photographs at dataset.factor %d (%dx%d), %s.yaml"
+                    % (runner.iter_step, args.factor, int(sc["image_hw"][0]), int(sc["image_hw"][1]), args.preset),
+           "train_wall_s": round(train_wall, 2), "train_iterations": int(s["iterations"]),
+           "train_ray_samples_per_s": s["total_meaningful"] / train_wall, "train_rays_per_s": s["total_rays"] / train_wall,
+           "psnr_test_mean": round(views[-1], 3), "psnr_test_per_view": [round(v, 2) for v in views[:-1]],
+           "psnr_definition": "reference (ExpRunner.cpp:360-369): prediction clipped and quantised to 8 bit, 20 log10(1/sqrt(mse)), "
+                              "test views = every 8th image", "test_views_wall_s": round(test_wall, 2),
+           "image_hw": [int(v) for v in sc["image_hw"]], "octree_nodes": runner.n_nodes(), "setup_s": round(t_load, 1)}
+    # ---- timed steps in the converged state: real training batches of the reference's adaptive size, resident before timing ----
+    R = max(16, runner.cur_batch_size())
+    n_batches = 16
+    batches = [ds.rand_rays_data(R, 1) for _ in range(n_batches)]
+
+    def step(i):
+        b, nb = batches[i % n_batches], batches[(i + 1) % n_batches]
+        return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+    for i in range(10):
+        step(i)
+    runner.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nm = na = 0
+    K = args.converged_steps
+    for i in range(K):
+        r = step(10 + i)
+        nm += r["n_meaningful"]
+        na += r["n_samples"]
+    runner.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out.update({"rays_per_batch": R, "steps": K, "ms_per_step": el / K * 1e3, "value": nm / el, "unit": "ray-samples/s",
+                "marched_samples_per_s": na / el, "rho_marched_over_meaningful": na / max(nm, 1),
+                "meaningful_samples_per_step": nm / K, "marched_samples_per_step": na / K, "rays_per_s": R * K / el})
+    # per-kernel HIP-event breakdown of 40 more steps (events on the launch streams; not part of the timed region above)
+    host.ExpRunner.enable_kernel_timing(["*"])
+    KB = 40
+    nab = 0
+    for i in range(KB):
+        nab += step(i)["n_samples"]
+    torch.cuda.synchronize()
+    t = host.ExpRunner.collect_kernel_timing()
+    host.ExpRunner.disable_kernel_timing()
+    per = {k: v[1] / KB for k, v in t.items()}
+    out["timed_calls_ms_per_step"] = {k: round(v, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])}
+    dom = max(per, key=per.get)
+    smp = runner.get_samples(batches[0][0], batches[0][1], batches[0][2])
+    per_ray = (smp["pts_idx_bounds"][:, 1] - smp["pts_idx_bounds"][:, 0]).cpu().numpy()
+    out["samples_per_ray"] = {"mean": round(float(per_ray.mean()), 1), "p50": int(np.percentile(per_ray, 50)),
+                              "p99": int(np.percentile(per_ray, 99)), "max": int(per_ray.max())}
+    roof = {"bound": "hbm", "kernel": dom, "avg_kernel_ms": round(per[dom], 4), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if dom in ALGO_BYTES_CONVERGED:
+        ach = nab / KB * ALGO_BYTES_CONVERGED[dom] / (per[dom] * 1e-3) / 1e9
+        roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "bytes_per_marched_sample": ALGO_BYTES_CONVERGED[dom]})
+    if dom == "ray_march":  # latency-bound: the launch lasts as long as its longest ray
+        roof["latency_model"] = {"longest_ray_steps": int(per_ray.max()), "us_per_step_of_longest_ray": round(per[dom] * 1e3 / max(int(per_ray.max()), 1), 3)}
+    out["roofline"] = roof
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=800)   # >= 1 s of timed region at ~1.2 ms per step
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=8192)
     ap.add_argument("--preset", default="wanjinyou")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-converged", action="store_true", help="skip the converged-state leg (train 20k iterations, PSNR, timed steps)")
+    ap.add_argument("--train-iters", type=int, default=20000, help="iterations of the converged leg's training run")
+    ap.add_argument("--converged-steps", type=int, default=600, help="timed steps in the converged state")
+    ap.add_argument("--factor", type=int, default=2, choices=[2, 8], help="image resolution of the converged leg (dataset.factor)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # stand-alone multi-GPU invocation: one process per GPU over RCCL, exactly as the driver launches it
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (os.environ.get("F2N_BENCH_FORCE_DP") == "1" and world == 1):
+        sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # F2N_BENCH_FORCE_DP=1 (under torch.distributed.run --nproc-per-node 1) exercises the collective path with one rank
@@ -169,18 +278,25 @@ def main():
                 cpu_baseline = json.loads(out.stdout.strip().splitlines()[-1])
             except Exception as e:  # the baseline is a reported extra, never the thing measured
                 cpu_baseline = {"error": str(e)[:200]}
+        converged = None
+        if world == 1 and not args.no_converged:
+            try:
+                converged = converged_leg(args, st, dev)
+            except Exception as e:  # reported next to the headline, never instead of it
+                import traceback
+                converged = {"error": (str(e) + " | " + traceback.format_exc()[-600:])[:900]}
         line = {
             "metric": "training ray-samples/s (ngp_fox)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ngp_fox %s.yaml, %d rays/batch/GPU, fresh-initialised 2^%d x16 table, fineness %.1f, "
-                                   "synthetic random-pose rays, full train step (fwd+bwd+Adam+octree update)"
-                                   % (args.preset, args.rays, log2, runner.fineness),
+            "config": {"workload": "ngp_fox %s.yaml, %d rays/batch/GPU, 2^%d x16 table, the first %d iterations of training from "
+                                   "the fresh-initialised table (fineness %.1f), synthetic random-pose rays, full train step "
+                                   "(fwd+bwd+Adam+octree update)" % (args.preset, args.rays, log2, args.warmup + args.steps, runner.fineness),
                        "rays_per_batch": args.rays, "parallelism": "ray-dp%d" % world,
                        "rays_per_s": args.rays * world * args.steps / elapsed,
                        "marched_samples_per_s": n_marched / elapsed, "rho_marched_over_meaningful": rho,
                        "meaningful_samples_per_step": n_meaningful / args.steps},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged,
         }
         print(json.dumps(line), flush=True)
 

@@ -206,6 +206,18 @@ def hash_gather_planes(n, n_volumes, table_h, prim_pool, local_idx, local_size, 
                                      _p(planes_h, "h16")), "f2n_hash_gather_planes")
 
 
+def hash_gather_planes_balanced(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale, pts,
+                                pts_are_warped, volume_idx, vol_stride, planes_h, step01, level_scale_host):
+    """level_scale_host: 16 floats on the HOST (numpy array / list); step01 <= 0 -> the plain one-pair-per-XCD gather."""
+    import ctypes
+    arr = (ctypes.c_float * 16)(*[float(v) for v in level_scale_host])
+    _ck(lib().f2n_hash_gather_planes_balanced(_stream(), _i(n), _i(n_volumes), _p(table_h, "h16"), _p(prim_pool, "i32"),
+                                              _p(local_idx, "i32"), _p(local_size, "i32"), _p(bias_pool, "f32"),
+                                              _p(level_scale, "f32"), _p(pts, "f32"), _i(int(pts_are_warped)),
+                                              _p(volume_idx, "i32"), _i(vol_stride), _p(planes_h, "h16"),
+                                              ctypes.c_float(step01), arr), "f2n_hash_gather_planes_balanced")
+
+
 def field_mlp_planes(n, planes_h, mlp_params_h, out_feat, out_f0, save_x_h):
     _ck(lib().f2n_field_mlp_planes(_stream(), _i(n), _p(planes_h, "h16"), _p(mlp_params_h, "h16"), _p(out_feat, "f32", True),
                                    _p(out_f0, "f32", True), _p(save_x_h, "h16", True)), "f2n_field_mlp_planes")

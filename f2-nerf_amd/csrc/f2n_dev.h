@@ -80,6 +80,7 @@ int f2n_reduce_partials(void* stream, int n, int n_blocks, const float* partials
 #define F2N_WS_LOSS 4
 #define F2N_WS_BIN_REC 5
 #define F2N_WS_BIN_CNT 6
+#define F2N_WS_GATHER_CTR 7
 #define F2N_PARTITION_MIN_N 8192  // below this the single fused gather+MLP launch wins (an unpartitioned gather runs at 91 G reads/s, a partitioned one at 250 G/s)
 
 // ---- reductions in the order Eigen's scalar fixed-size unrollers use (n/2 | n - n/2 recursive split) ----

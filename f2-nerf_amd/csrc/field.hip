@@ -3,6 +3,9 @@
 // (c = sample, g = lane >> 4) gathers the four levels {2g, 2g+1, 8+2g, 9+2g} of its sample, which are exactly
 // the K-slots of the MFMA fragment it has to supply (mlp_dev.h), so features go from the L2/Infinity-Cache
 // resident table straight into matrix-core operands: no LDS staging, no HBM round trip of the [n,32] features.
+#include <math.h>
+#include <string.h>
+
 #include "mlp_dev.h"
 
 struct F2nHashArgs {
@@ -70,49 +73,88 @@ __device__ __forceinline__ void f2n_hash_cell(const float* p01, float mul, const
 
 // XCD-aware level-partitioned gather.  The 8 XCDs of an MI355X have private 4 MiB L2s; a wave that gathers all 16
 // levels touches the whole 17 MiB of addressed table and runs at the chip's random-access rate out of the Infinity
-// Cache (~90 G 4-byte gathers/s measured, tools/xcd_probe.py).  Here block b serves level pair (2p, 2p+1), p = b % 8
-// -- the XCD the dispatcher is observed to place it on -- so each L2 only ever sees a 3 MiB slice (260 G gathers/s
-// measured).  Placement is a speed assumption only: any mapping gives the same result.  Features leave through
-// f16 "planes" [8][n][4] (8 B per sample and level pair, coalesced), from which the MLP kernel's lane (c,g) reads
-// exactly its K-slots: plane g (features 4g..4g+3) and plane 4+g (features 16+4g..).
+// Cache (~90 G 4-byte gathers/s measured, tools/xcd_probe.py).  Here the blocks of XCD x (x = blockIdx % 8, where the
+// dispatcher is observed to place them) serve ONE level pair (2p, 2p+1) at a time, so an L2 only ever sees a 3 MiB slice.
+// Placement is a speed assumption only: any mapping gives the same result.  Features leave through f16 "planes"
+// [8][n][4] (8 B per sample and level pair, coalesced), from which the MLP kernel's lane (c,g) reads exactly its
+// K-slots: plane g (features 4g..4g+3) and plane 4+g (features 16+4g..).
+//
+// What bounds it (tools/gather_ab.py experiments, profiles/r02_gather_experiments.txt): every one of the 128 reads of a
+// sample pulls a whole 128-byte line from the XCD's L2 into a CU's L1 -- 1.04e8 lines in 0.42 ms = 31.6 TB/s of the
+// ~34.5 TB/s the eight L2s deliver together (MI355X_MICROARCH.md).  The same kernel without its table reads takes
+// 0.054 ms, with the eight reads of a cell redirected into ONE line 0.128 ms.  So the only lever is fewer distinct lines:
+//
+// Run combining (COMBINE): consecutive samples of a ray that fall into the same cell of a level (same integer cell, same
+// warp) read the same eight entries; only the first lane of each such run inside the wave issues the reads, the others
+// take the values over the LDS crossbar (ds_bpermute) and blend with their own weights -- bit-identical features.  The
+// L1 already absorbs most of these repeats, so this alone buys little; what it makes visible is how unequal the level
+// pairs are: on a converged scene (march fineness 1) pair (0,1) needs ~10 % of the lines of pair (14,15).
+//
+// Balanced split: with one pair pinned to each XCD the kernel lasts as long as the finest pair while the coarse pairs'
+// XCDs idle.  The launcher therefore cuts the 8 x n_tiles (pair, 256-sample tile) units into 8 contiguous, equally
+// EXPENSIVE shares (cost model: expected fraction of run-heading lanes per level from the march step, f2n_gather_costs)
+// and hands XCD x share x as up to F2N_MAX_SEGS (pair, tile range) segments; its blocks walk the share's tiles
+// block-cyclically, re-staging the hash constants when they cross into the next pair.
 #define F2N_N_PARTS 8
-// STAGED: the per-(level, transform) hash constants of the block's two levels (prim_pool / bias_pool rows, 24 B each)
-// are copied into LDS once per block: 12 of the 32 vector-memory instructions a sample issues were those -- broadcast
-// loads that cost no bandwidth but a texture-address issue slot each, the resource this kernel is bound by.
-template <bool STAGED>
+#define F2N_MAX_SEGS 8
+struct F2nGatherPlan {
+  int32_t n_seg[F2N_N_PARTS];
+  int32_t pair[F2N_N_PARTS][F2N_MAX_SEGS];
+  int32_t t0[F2N_N_PARTS][F2N_MAX_SEGS];   // first tile of the segment
+  int32_t v0[F2N_N_PARTS][F2N_MAX_SEGS];   // position of that tile in the XCD's virtual tile sequence
+  int32_t n_virtual[F2N_N_PARTS];
+};
+
+// STAGED: the per-(level, transform) hash constants of the current level pair (prim_pool / bias_pool rows, 24 B each) are
+// copied into LDS: 12 of the 32 vector-memory instructions a sample issues were those -- broadcast loads that cost no
+// bandwidth but an address-path issue slot each.
+template <bool STAGED, bool COMBINE>
 __global__ __launch_bounds__(256) void hash_gather_planes_kernel(
     int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
     const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
-    const int32_t* __restrict__ volume_idx, int vol_stride, half_t* __restrict__ planes) {
+    const int32_t* __restrict__ volume_idx, int vol_stride, half_t* __restrict__ planes, F2nGatherPlan plan) {
   __shared__ F2nLevelTab lt;
   extern __shared__ uint32_t pb_lds[];  // STAGED: [2 levels][V][prim xyz, bias xyz]
-  const int part = blockIdx.x % F2N_N_PARTS;
-  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, threadIdx.x);
-  // Levels {2 part, 2 part + 1}: the block's two feature pairs are one 8-byte plane element.  (Pairing a coarse with a
-  // fine level per XCD, {part, 15 - part}, to even out L1 hit rates was measured 8 % SLOWER: the split 4-byte stores
-  // cost more than the balance gains.)
-  const int lv[2] = {2 * part, 2 * part + 1};
-  if (STAGED) {
-    for (int i = threadIdx.x; i < 2 * 3 * h.n_volumes; i += 256) {
-      const int j = i >= 3 * h.n_volumes, i1 = i - j * 3 * h.n_volumes;
-      const int r = i1 / 3, k = i1 - 3 * r;
-      const size_t src = 3 * (size_t) lv[j] * h.n_volumes + i1;
-      pb_lds[6 * (j * h.n_volumes + r) + k] = (uint32_t) h.prim_pool[src];
-      pb_lds[6 * (j * h.n_volumes + r) + 3 + k] = __float_as_uint(h.bias_pool[src]);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int xcd = blockIdx.x % F2N_N_PARTS, q = blockIdx.x / F2N_N_PARTS, nq = gridDim.x / F2N_N_PARTS;
+  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+  int seg = -1, staged_pair = -1;
+  for (int vt = q; vt < plan.n_virtual[xcd]; vt += nq) {
+    while (seg + 1 < plan.n_seg[xcd] && vt >= plan.v0[xcd][seg + 1]) seg++;  // block-uniform
+    const int part = plan.pair[xcd][seg];
+    const int tile = plan.t0[xcd][seg] + (vt - plan.v0[xcd][seg]);
+    // Levels {2 part, 2 part + 1}: the two feature pairs are one 8-byte plane element.  (Pairing a coarse with a fine
+    // level, {part, 15 - part}, to even out L1 hit rates was measured 8 % SLOWER with the fixed split: the split 4-byte
+    // stores cost more than the balance gained.)
+    const int lv[2] = {2 * part, 2 * part + 1};
+    if (part != staged_pair) {
+      __syncthreads();  // everyone is done with the previous pair's constants (and, the first time, lt is filled)
+      if (STAGED) {
+        for (int i = tid; i < 2 * 3 * h.n_volumes; i += 256) {
+          const int j = i >= 3 * h.n_volumes, i1 = i - j * 3 * h.n_volumes;
+          const int r = i1 / 3, k = i1 - 3 * r;
+          const size_t src = 3 * (size_t) lv[j] * h.n_volumes + i1;
+          pb_lds[6 * (j * h.n_volumes + r) + k] = (uint32_t) h.prim_pool[src];
+          pb_lds[6 * (j * h.n_volumes + r) + 3 + k] = __float_as_uint(h.bias_pool[src]);
+        }
+        __syncthreads();
+      }
+      staged_pair = part;
     }
-  }
-  __syncthreads();
-  const int q = blockIdx.x / F2N_N_PARTS, nq = gridDim.x / F2N_N_PARTS;
-  for (int s = q * 256 + (int) threadIdx.x; s < n; s += nq * 256) {
+    const int s = tile * 256 + tid;
+    const bool valid = s < n;
+    if (!COMBINE && !valid) continue;
+    const int sc = valid ? s : n - 1;  // COMBINE: every lane takes part (tail lanes extend the last sample's run)
     float p01[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const float p = pts[3 * (size_t) s + k];
+      const float p = pts[3 * (size_t) sc + k];
       p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
     }
-    const int vol = volume_idx[(size_t) s * vol_stride];
+    const int vol = volume_idx[(size_t) sc * vol_stride];
     F2nCell cell[2];
     half2_t v[2][8];
+    bool head[2] = {true, true};
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int l = lv[j];
@@ -125,9 +167,30 @@ __global__ __launch_bounds__(256) void hash_gather_planes_kernel(
         const int tf = l * h.n_volumes + vol;
         f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell[j]);
       }
+      if (COMBINE) {  // same cell as the previous lane of the wave?  (DPP wave_shr:1; lane 0 always starts a run)
+        const int q0 = __builtin_amdgcn_update_dpp(0, (int) cell[j].p[0], 0x138, 0xF, 0xF, false);
+        const int q1 = __builtin_amdgcn_update_dpp(0, (int) cell[j].p[1], 0x138, 0xF, 0xF, false);
+        const int q2 = __builtin_amdgcn_update_dpp(0, (int) cell[j].p[2], 0x138, 0xF, 0xF, false);
+        const int qv = __builtin_amdgcn_update_dpp(-1, vol, 0x138, 0xF, 0xF, false);
+        head[j] = !(lane > 0 && q0 == (int) cell[j].p[0] && q1 == (int) cell[j].p[1] && q2 == (int) cell[j].p[2] && qv == vol);
+      }
       const half2_t* base = (const half2_t*) (h.table + lt.base[l]);
+      if (head[j]) {
 #pragma unroll
-      for (int d = 0; d < 8; d++) v[j][d] = base[cell[j].pos[d]];
+        for (int d = 0; d < 8; d++) v[j][d] = base[cell[j].pos[d]];
+      }
+    }
+    if (COMBINE) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const unsigned long long hm = __ballot(head[j]);
+        if (hm != ~0ull) {  // wave-uniform: some lane rides on its run's first lane
+          const int src = 63 - __clzll(hm & ((2ull << lane) - 1ull));
+#pragma unroll
+          for (int d = 0; d < 8; d++)
+            v[j][d] = __builtin_bit_cast(half2_t, __shfl(__builtin_bit_cast(int, v[j][d]), src));
+        }
+      }
     }
     half4_t out;
 #pragma unroll
@@ -142,7 +205,65 @@ __global__ __launch_bounds__(256) void hash_gather_planes_kernel(
       out[2 * j] = (half_t) s0;
       out[2 * j + 1] = (half_t) s1;
     }
-    *(half4_t*) (planes + ((size_t) part * n + s) * 4) = out;
+    if (valid) *(half4_t*) (planes + ((size_t) part * n + s) * 4) = out;
+  }
+}
+
+// Expected relative cost of one tile of each level pair when consecutive samples are `step01` apart in the [0,1] hash
+// space: a lane heads a run (issues its 8 reads) when the step crossed a cell boundary of the level (probability
+// ~1 - exp(-1.7 * cells per step): three axes), the warp changed (~4 % of steps) or the wave starts (1/64); on top, the
+// part of a tile that does not depend on the reads (hashing, blending, streams: 0.13 of a full level).  Checked against
+// the measured head fractions of a converged fox batch (0.09 / 0.40 / 0.87 / 1.0 at levels 0 / 8 / 12 / 15).
+static void f2n_gather_costs(float step01, const float* level_scale_host, float* cost8) {
+  for (int p = 0; p < F2N_N_PARTS; p++) {
+    float c = 0.f;
+    for (int j = 0; j < 2; j++) {
+      const float cells = level_scale_host[2 * p + j] * step01;
+      c += 0.13f + (1.f - (1.f - 1.f / 64.f - 0.04f) * expf(-1.7f * cells));
+    }
+    cost8[p] = c;
+  }
+}
+
+// Cuts the (pair, tile) units into 8 contiguous shares of equal cost, finest pair first.
+static void f2n_gather_plan(int n_tiles, const float* cost8 /* NULL: one pair per XCD */, F2nGatherPlan& plan) {
+  memset(&plan, 0, sizeof(plan));
+  if (cost8 == nullptr) {
+    for (int x = 0; x < F2N_N_PARTS; x++) {
+      plan.n_seg[x] = 1;
+      plan.pair[x][0] = x;
+      plan.n_virtual[x] = n_tiles;
+    }
+    return;
+  }
+  double total = 0;
+  for (int p = 0; p < F2N_N_PARTS; p++) total += (double) cost8[p] * n_tiles;
+  const double share = total / F2N_N_PARTS;
+  int x = 0;
+  double room = share;
+  for (int p = F2N_N_PARTS - 1; p >= 0; p--) {
+    int t = 0;
+    while (t < n_tiles) {
+      int take = (x == F2N_N_PARTS - 1) ? n_tiles - t : (int) ceil(room / cost8[p] - 1e-9);
+      if (take > n_tiles - t) take = n_tiles - t;
+      if (take > 0 && plan.n_seg[x] < F2N_MAX_SEGS) {
+        const int k = plan.n_seg[x]++;
+        plan.pair[x][k] = p;
+        plan.t0[x][k] = t;
+        plan.v0[x][k] = plan.n_virtual[x];
+        plan.n_virtual[x] += take;
+        t += take;
+        room -= (double) take * cost8[p];
+      }
+      if (t < n_tiles || room <= 1e-9) {  // this XCD's share is full (or its segment list is): next XCD
+        if (x < F2N_N_PARTS - 1) {
+          x++;
+          room += share;
+        } else if (take <= 0) {
+          break;
+        }
+      }
+    }
   }
 }
 
@@ -876,23 +997,72 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
   return f2n_field_mlp_planes(stream, n, planes, mlp_params_h, out_feat_f32, out_f0, save_x_h);
 }
 
+int f2n_gather_plan_query(int n_tiles, float step01, const float* level_scale_host, int32_t* out, float* cost8_out) {
+  if (n_tiles < 0 || out == nullptr) return F2N_ERR_INVALID_ARG;
+  F2nGatherPlan plan;
+  float cost8[F2N_N_PARTS];
+  const bool balanced = step01 > 0.f && level_scale_host != nullptr;
+  if (balanced) f2n_gather_costs(step01, level_scale_host, cost8);
+  f2n_gather_plan(n_tiles, balanced ? cost8 : nullptr, plan);
+  for (int x = 0; x < F2N_N_PARTS; x++) {
+    int32_t* o = out + x * (1 + 3 * F2N_MAX_SEGS);
+    o[0] = plan.n_seg[x];
+    for (int k = 0; k < F2N_MAX_SEGS; k++) {
+      const bool live = k < plan.n_seg[x];
+      const int end_v = !live ? 0 : (k + 1 < plan.n_seg[x] ? plan.v0[x][k + 1] : plan.n_virtual[x]);
+      o[1 + 3 * k] = live ? plan.pair[x][k] : -1;
+      o[2 + 3 * k] = live ? plan.t0[x][k] : 0;
+      o[3 + 3 * k] = live ? end_v - plan.v0[x][k] : 0;  // tiles in the segment
+    }
+    if (cost8_out != nullptr) cost8_out[x] = balanced ? cost8[x] : 1.f;
+  }
+  return F2N_OK;
+}
+
 int f2n_hash_gather_planes(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
                            const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
                            const float* pts, int pts_are_warped, const int32_t* volume_idx, int vol_stride, void* planes_h) {
+  return f2n_hash_gather_planes_balanced(stream, n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale,
+                                         pts, pts_are_warped, volume_idx, vol_stride, planes_h, 0.f, nullptr);
+}
+
+int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                                    const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                                    const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
+                                    int vol_stride, void* planes_h, float step01, const float* level_scale_host) {
   if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
   long per_part = ((long) n + 255) / 256;
   if (per_part > 256) per_part = 256;  // 32 CUs per XCD x 8 resident 256-thread blocks
   const size_t stage_bytes = (size_t) 2 * n_volumes * 6 * sizeof(uint32_t);
-  if (stage_bytes <= 20000 && n >= 64 * 256)  // keeps 8 blocks per CU resident; not worth the copy for small batches
-    hipLaunchKernelGGL(hash_gather_planes_kernel<true>, dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), stage_bytes,
-                       (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride,
-                       (half_t*) planes_h);
-  else
-    hipLaunchKernelGGL(hash_gather_planes_kernel<false>, dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), 0,
-                       (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride,
-                       (half_t*) planes_h);
+  const bool staged = stage_bytes <= 20000 && n >= 64 * 256;  // keeps 8 blocks per CU resident; not worth the copy for small batches
+  bool balanced = step01 > 0.f && level_scale_host != nullptr;
+  F2nGatherPlan plan;
+  float cost8[F2N_N_PARTS];
+  if (balanced) {
+    // Run combining and pair switching cost ~10 % of a tile (more registers: 6 instead of 8 waves per SIMD; re-staging;
+    // an L2 refill per switch): worth it only when the balanced share is well below the costliest pair's load.  On a
+    // fresh scene (fineness 16) the model predicts 0.90 and the balanced kernel measured 5 % SLOWER; on a converged one
+    // 0.53 predicted, 0.57 measured (tools/gather_ab.py).
+    f2n_gather_costs(step01, level_scale_host, cost8);
+    float sum = 0.f, mx = 0.f;
+    for (int p = 0; p < F2N_N_PARTS; p++) {
+      sum += cost8[p];
+      mx = fmaxf(mx, cost8[p]);
+    }
+    balanced = sum / F2N_N_PARTS < 0.8f * mx;
+  }
+  f2n_gather_plan((n + 255) / 256, balanced ? cost8 : nullptr, plan);
+#define F2N_LAUNCH_GATHER(ST, CB)                                                                                              \
+  hipLaunchKernelGGL((hash_gather_planes_kernel<ST, CB>), dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256),                \
+                     ST ? stage_bytes : 0, (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, \
+                     volume_idx, vol_stride, (half_t*) planes_h, plan)
+  if (staged && balanced) F2N_LAUNCH_GATHER(true, true);
+  else if (staged) F2N_LAUNCH_GATHER(true, false);
+  else if (balanced) F2N_LAUNCH_GATHER(false, true);
+  else F2N_LAUNCH_GATHER(false, false);
+#undef F2N_LAUNCH_GATHER
   return f2n_launch_status();
 }
 

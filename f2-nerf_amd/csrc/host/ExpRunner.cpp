@@ -413,15 +413,83 @@ std::vector<Tensor> ExpRunner::RenderWholeImage(const Tensor& rays_o, const Tens
   return {pred_colors, first_oct_disp, pred_disp};
 }
 
-// The per-image body of ExpRunner::TestImages (ExpRunner.cpp:333-372): render camera idx of the data set, PSNR against
-// the resident ground truth (fp32, no 8-bit quantisation of the prediction).
+// The per-image body of ExpRunner::TestImages (ExpRunner.cpp:353-369): render camera idx of the data set, quantise the
+// prediction to 8 bit exactly as the reference does before it measures ((x.clip(0,1) * 255) -> uint8 -> / 255, :360-362),
+// PSNR = 20 log10(1 / sqrt(mse)) against the resident ground truth.  Everything stays on the device.
 float ExpRunner::TestImagePSNR(Dataset& dataset, int idx) {
   TORCH_CHECK(dataset.image_tensors_.defined(), "no ground-truth images resident");
   auto rays = dataset.RaysOfCamera(idx);
   auto out = RenderWholeImage(rays.origins, rays.dirs, rays.bounds);
+  Tensor pred = (out[0].clip(0.f, 1.f) * 255.f).to(torch::kUInt8).to(torch::kFloat32) / 255.f;
   Tensor gt = dataset.image_tensors_[idx].reshape({-1, 3});
-  const float mse = (out[0] - gt).square().mean().item<float>();
+  const float mse = (pred - gt).square().mean().item<float>();
   return 20.f * std::log10(1.f / std::sqrt(mse));
+}
+
+// ExpRunner::TestImages (ExpRunner.cpp:343-383) without the PNG / YAML output: per-view PSNR of the test set, mean last.
+std::vector<float> ExpRunner::TestImages(Dataset& dataset) {
+  FinishPending();
+  auto prev = global_data_pool_->mode_;
+  global_data_pool_->mode_ = RunningMode::VALIDATE;
+  std::vector<float> out;
+  float sum = 0.f;
+  for (int i : dataset.test_set_) {
+    out.push_back(TestImagePSNR(dataset, i));
+    sum += out.back();
+  }
+  out.push_back(out.empty() ? 0.f : sum / float(out.size()));
+  global_data_pool_->mode_ = prev;
+  return out;
+}
+
+// One frame of ExpRunner::RenderPath (ExpRunner.cpp:322-341): the view from `pose` at 1/res_level resolution as the image
+// the reference writes -- [H, 3W, 3]: colours | first-octree-hit disparity | disparity, side by side.
+Tensor ExpRunner::RenderPathFrame(Dataset& dataset, const Tensor& pose, int res_level) {
+  FinishPending();
+  auto prev = global_data_pool_->mode_;
+  global_data_pool_->mode_ = RunningMode::VALIDATE;
+  auto rays = dataset.RaysFromPose(pose, res_level);
+  auto out = RenderWholeImage(rays.origins, rays.dirs, rays.bounds);
+  const int H = dataset.height_ / res_level, W = dataset.width_ / res_level;
+  Tensor img = torch::cat({out[0].reshape({H, W, 3}), out[1].reshape({H, W, 1}).repeat({1, 1, 3}),
+                           out[2].reshape({H, W, 1}).repeat({1, 1, 3})}, 1);
+  global_data_pool_->mode_ = prev;
+  return img;
+}
+
+// ExpRunner::RenderPath: every pose of `render_poses` [P,3,4]; `sink(i, image)` receives the frames (the reference writes
+// novel_images/<iter>_<i>.png -- image encoding is outside the hot path and left to the caller).
+void ExpRunner::RenderPath(Dataset& dataset, const Tensor& render_poses, const std::function<void(int, const Tensor&)>& sink,
+                           int res_level) {
+  Tensor poses = render_poses.to(torch::kCPU).to(torch::kFloat32).contiguous();
+  TORCH_CHECK(poses.dim() == 3 && poses.size(1) == 3 && poses.size(2) == 4, "render_poses must be [P,3,4]");
+  for (int i = 0; i < poses.size(0); i++) sink(i, RenderPathFrame(dataset, poses[i], res_level));
+}
+
+// ExpRunner::SaveCheckpoint / LoadCheckpoint (ExpRunner.cpp:188-219): <dir>/renderer.pt = torch::save of the state vector
+// in the reference's order (Renderer::States: sampler [nodes, warps, visit counts, milestones], field [table, primes,
+// biases, n_volumes, MLP], shader [MLP], app_emb), <dir>/scalars.pt = float tensor [iter_step].  Same container format
+// (LibTorch's pickle archive of a tensor list), so the files are interchangeable with the reference's.
+void ExpRunner::SaveCheckpoint(const std::string& dir) {
+  std::vector<Tensor> states = States();
+  for (auto& t : states) t = t.detach().contiguous();
+  torch::save(states, dir + "/renderer.pt");
+  Tensor scalars = torch::empty({1}, CpuF32());
+  scalars.index_put_({0}, float(iter_step_));
+  torch::save(scalars, dir + "/scalars.pt");
+}
+
+void ExpRunner::LoadCheckpoint(const std::string& dir) {
+  FinishPending();
+  {
+    Tensor scalars;
+    torch::load(scalars, dir + "/scalars.pt");
+    iter_step_ = (int) std::round(scalars[0].item<float>());
+    UpdateAdaParams();
+  }
+  std::vector<Tensor> states;
+  torch::load(states, dir + "/renderer.pt");
+  LoadStates(states);
 }
 
 // The loop of ExpRunner::Train (ExpRunner.cpp:82-143) without its reporting / checkpoint branches: adaptive ray batch

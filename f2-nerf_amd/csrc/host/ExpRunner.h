@@ -39,7 +39,13 @@ class ExpRunner {
   float CurVarLossWeight() const;
   std::vector<Tensor> RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   std::vector<Tensor> RenderWholeImage(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
-  float TestImagePSNR(Dataset& dataset, int idx);
+  float TestImagePSNR(Dataset& dataset, int idx);       // 8-bit quantised prediction, as ExpRunner.cpp:360-369
+  std::vector<float> TestImages(Dataset& dataset);      // per-view PSNR of the test set, then the mean
+  Tensor RenderPathFrame(Dataset& dataset, const Tensor& pose, int res_level = 1);
+  void RenderPath(Dataset& dataset, const Tensor& render_poses, const std::function<void(int, const Tensor&)>& sink,
+                  int res_level = 1);
+  void SaveCheckpoint(const std::string& dir);          // <dir>/renderer.pt + <dir>/scalars.pt (ExpRunner.cpp:205-219)
+  void LoadCheckpoint(const std::string& dir);          // ExpRunner.cpp:188-203
   int Train(Dataset& dataset, int until_iter = -1, int sets = DATA_TRAIN_SET);
   int64_t last_train_meaningful_ = 0, last_train_marched_ = 0, last_train_rays_ = 0;  // totals of the last Train call
   TrainStats last_train_stats_;

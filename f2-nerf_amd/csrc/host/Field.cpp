@@ -136,6 +136,10 @@ Hash3DAnchored::Hash3DAnchored(GlobalDataPool* gdp) {  // Hash3DAnchored.cpp:19-
   for (int l = 0; l < N_LEVELS; l++)  // Hash3DAnchored.cu:28, evaluated once on the host
     scales[l] = exp2f((RES_FINE_POW_2 - RES_BASE_POW_2) * float(l) / float(N_LEVELS - 1) + RES_BASE_POW_2);
   level_scale_ = torch::from_blob(scales.data(), {N_LEVELS}, CpuF32()).to(torch::kCUDA).contiguous();
+  level_scale_host_ = scales;
+  march_step_warped_ = c.Has("pts_sampler.sample_l") ? c.Float("pts_sampler.sample_l") : 0.f;
+  if (c.Has("pts_sampler.scale_by_dis") && c.Bool("pts_sampler.scale_by_dis")) march_step_warped_ *= 1.25f;  // typical stretch
+  balance_gather_ = !(c.Has("field.balance_gather") && !c.Bool("field.balance_gather"));
   // level l addresses halves [l*local, l*local + 2*local): the union is [0, (N_LEVELS+1)*local)
   active_halves_ = std::min<int64_t>(int64_t(N_LEVELS + 1) * local_size, int64_t(pool_size_) * N_CHANNELS);
   mlp_ = std::make_unique<FusedMLP>(gdp, N_LEVELS * N_CHANNELS, mlp_out_dim_, mlp_hidden_dim_, n_hidden_layers_);
@@ -252,9 +256,12 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
   prepass_x_ = keep_features ? torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16()) : Tensor();
   if (n >= 32768) {  // the two kernels of the large-batch path, issued (and timed) separately
     Tensor planes = torch::empty({8, n, 4}, DevF16());
-    F2N_TIMED_CALL("hash_gather", f2n_hash_gather_planes(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),
+    // consecutive samples of a ray are one march step apart: sample_l * fineness in warped space (PersSampler.cu:262-270,
+    // stretched by the distance scaling where it is on), half of that in the [0,1] space the grid hashes (:91)
+    const float step01 = march_step_warped_ * global_data_pool_->ray_march_fineness_ * .5f;
+    F2N_TIMED_CALL("hash_gather", f2n_hash_gather_planes_balanced(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),
                            I32P(feat_local_idx_), I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), 1,
-                           I32P(av.t), av.stride, VoidP(planes)));
+                           I32P(av.t), av.stride, VoidP(planes), balance_gather_ ? step01 : 0.f, level_scale_host_.data()));
     F2N_TIMED_CALL("field_mlp_prepass", f2n_field_mlp_planes(CurStream(), n, VoidP(planes), VoidP(mlp_->params_h_), nullptr, F32P(f0),
                            keep_features ? VoidP(prepass_x_) : nullptr));
   } else {

@@ -47,6 +47,9 @@ class Hash3DAnchored : public Field {
   Tensor prepass_x_;       // h16 [n,32] features of the last QueryDensityPreAct(keep_features = true), or undefined
   std::unique_ptr<FusedMLP> mlp_;
   int n_volumes_;
+  std::vector<float> level_scale_host_;  // the 16 level scales again, for the gather's cost model (host side)
+  float march_step_warped_ = 0.f;        // sample_l (x typical distance stretch): warped-space step at fineness 1
+  bool balance_gather_ = true;           // field.balance_gather=false: one level pair per XCD (A/B measurements)
   int64_t active_halves_;  // halves [0, active) are the only ones any level can address (level-overlap quirk)
 };
 

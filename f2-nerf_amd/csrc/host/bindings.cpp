@@ -118,6 +118,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("render_rays", &ExpRunner::RenderRays)
       .def("render_whole_image", &ExpRunner::RenderWholeImage)
       .def("test_image_psnr", &ExpRunner::TestImagePSNR)
+      .def("test_images", &ExpRunner::TestImages)
+      .def("render_path_frame", &ExpRunner::RenderPathFrame, py::arg("dataset"), py::arg("pose"), py::arg("res_level") = 1)
+      .def("render_path",
+           [](ExpRunner& r, Dataset& ds, const Tensor& poses, py::function sink, int res_level) {
+             r.RenderPath(ds, poses, [sink](int i, const Tensor& img) { sink(i, img); }, res_level);
+           },
+           py::arg("dataset"), py::arg("render_poses"), py::arg("sink"), py::arg("res_level") = 1)
+      .def("save_checkpoint", &ExpRunner::SaveCheckpoint)
+      .def("load_checkpoint", &ExpRunner::LoadCheckpoint)
       .def("train",
            [](ExpRunner& r, Dataset& ds, int until_iter, int sets) {
              int n;

@@ -41,7 +41,10 @@ __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const f
 // MODE 2: single pass into fixed-stride per-ray segments [ray*max_hits, ray*max_hits + cnt): no count pass, no scan.
 // ---------------------------------------------------------------------------------------------------
 #define F2N_COOP_RAYS_PER_BLOCK 32  // 256 threads
-#define F2N_COOP_STACK 56            // parked siblings per ray (7 per level of a path; deeper paths drop the farthest)
+// Parked siblings per ray.  A ray crosses at most 4 of a node's 8 children (three mid-planes), so behind the child that is
+// descended into at most 3 are parked per level of the current path: 72 entries cover paths of 24 levels, which is the
+// deepest tree the reference's own 48-int stack (2 ints per level, PersSampler.cu:7,70) can walk without overrunning it.
+#define F2N_COOP_STACK 72
 template <int MODE>
 __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     int n_rays, int max_hits, const uint8_t* __restrict__ search_order, const float* __restrict__ rays_o,
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
         // park every hit behind the first interior child, farthest first so that the nearest ends on top
         int rest = (m_int | m_leaf) & ~((2 << k_int) - 1);
         int n_rest = __popc(rest);
-        while (sp + n_rest >= F2N_COOP_STACK) {  // full (paths deeper than the reference's own 48-int stack): drop the farthest
+        while (sp + n_rest >= F2N_COOP_STACK) {  // unreachable for trees of <= 24 levels (see F2N_COOP_STACK); memory safety only
           rest &= ~(1 << (31 - __clz(rest)));
           n_rest--;
         }

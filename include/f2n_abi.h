@@ -231,6 +231,21 @@ int f2n_hash_gather_planes(void* stream, int n, int n_volumes, const void* table
                            const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
                            const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
                            int vol_stride, void* planes_h /*[8,n,4] h16*/);
+/* The same gather with run combining and a cost-balanced split (ABI v6).  step01 = typical distance of consecutive
+ * samples of a ray in the [0,1] hash space (the march's warped-space step / 2: sample_l * fineness / 2,
+ * PersSampler.cu:262-270 and Hash3DAnchored.cpp:91); level_scale_host = the 16 level scales as a HOST array.  Samples
+ * must be ray-ordered (as PersSampler::GetSamples emits them).  Consecutive samples in one cell of a level share their
+ * eight table reads; the level pairs, which then differ in cost by up to 10x, are spread over the XCDs by expected cost
+ * instead of one pair per XCD.  Bit-identical planes; step01 <= 0 or level_scale_host == NULL: exactly
+ * f2n_hash_gather_planes. */
+int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                                    const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                                    const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
+                                    int vol_stride, void* planes_h /*[8,n,4] h16*/, float step01, const float* level_scale_host);
+/* Introspection (host only, no device work): the split f2n_hash_gather_planes_balanced would use for n_tiles tiles of 256
+ * samples.  out [8][1 + 3*8] int32: per XCD the number of segments, then (level pair, first tile, tile count) per
+ * segment (-1, 0, 0 for unused slots); cost8_out [8] (may be NULL): the modelled cost of one tile of each level pair. */
+int f2n_gather_plan_query(int n_tiles, float step01, const float* level_scale_host, int32_t* out, float* cost8_out);
 int f2n_field_mlp_planes(void* stream, int n, const void* planes_h, const void* mlp_params_h, float* out_feat_f32,
                          float* out_f0, void* save_x_h);
 

@@ -99,7 +99,9 @@ def main(n_rays=256, log2_table=19, n_edge=8192, budget_s=12.0, max_iters=6, fin
     el = time.time() - t0
     print(json.dumps({"value": m_tot / el, "unit": "ray-samples/s", "cores": oc.num_threads(), "kind": "port",
                       "sample": "%d training iterations of %d rays (ngp_fox wanjinyou, log2_table %d, fineness %g): "
-                                "%d samples marched, %d meaningful, %.1f s" % (its, n_rays, log2_table, fineness, n_tot, m_tot, el),
+                                "%d samples marched, %d meaningful, %.1f s; OpenMP port of the reference path, most of its time in the "
+                                "reference-faithful DENSE per-iteration table passes (fp32->fp16 cast of 2^%d x16 entries, gradient "
+                                "zero-fill / widen / divide, dense Adam), not in per-sample work" % (its, n_rays, log2_table, fineness, n_tot, m_tot, el, log2_table),
                       "rays_per_s": its * n_rays / el, "marched_samples_per_s": n_tot / el}))
 
 

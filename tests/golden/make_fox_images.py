@@ -22,3 +22,12 @@ for f in files:
 arr = np.stack(imgs)
 np.savez_compressed(out, images=arr, factor_vs_state=np.float32(4.0))
 print(out, arr.shape, os.path.getsize(out) / 1e6, "MB")
+
+# ---- factor 2 (confs/wanjinyou.yaml: dataset.factor 2 -> 960x540): the reference's own images_2 JPEG files, byte for byte,
+# packed into one archive (decoded with PIL where they are used: f2-nerf_amd/fox_data.py).  9.6 MB of data, no source.
+out2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fox_images_f2_jpeg.npz")
+blobs = [np.frombuffer(open(f, "rb").read(), np.uint8) for f in files]
+offsets = np.cumsum([0] + [len(b) for b in blobs]).astype(np.int64)
+np.savez(out2, jpeg=np.concatenate(blobs), offsets=offsets, names=np.array([os.path.basename(f) for f in files]),
+         factor_vs_state=np.float32(1.0))
+print(out2, len(blobs), os.path.getsize(out2) / 1e6, "MB")

@@ -1,0 +1,417 @@
+"""GPU parity where the numbers are quoted (run with `-m gpu`): BASELINE config 2 at full size (8192 rays, 2^19 x 16
+table), the converged 148k-node octree, a synthetic 23-level tree that fills the DFS work stack, and a multi-iteration
+training trajectory across a subdivision milestone and a compaction -- all against the CPU oracle (pinned to the
+reference's own kernels, tests/test_oracle_vs_ref.py) on identical state and identical explicit random draws.
+Contract (north star): bit-exact sample indices; rendered RGB / PSNR within 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capi as oc  # noqa: E402
+from oracle import pipeline as op  # noqa: E402
+from oracle import octree_construct as octc  # noqa: E402
+from test_gpu_e2e import fox_batch, oracle_train_iteration, rel_err  # noqa: E402
+
+F32 = np.float32
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def rt():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    runtime.host()
+    return runtime
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import capi
+    capi.lib()
+    return capi
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype == np.float32:
+        return bool((a.view(np.uint32) == b.view(np.uint32)).all())
+    return bool((a == b).all())
+
+
+def single_pass_sample(hip, tree_nodes, pers_trans, search_order, rays_o, rays_d, noise, sample_l, scale_by_dis, near=0.01,
+                       max_hits=1024):
+    """The production sampler chain (child blocks -> single-pass DFS into strided slots -> single-pass march -> scan ->
+    pack), straight through the C-ABI."""
+    n = rays_o.shape[0]
+    tn, tr, so = T(tree_nodes), T(pers_trans), T(search_order)
+    ro, rd, nz = T(rays_o), T(rays_d), T(noise)
+    n_nodes = tree_nodes.size // 64
+    cb = torch.zeros(n_nodes * 8 * 32, dtype=torch.uint8, device=DEV)
+    hip.oct_build_child_blocks(n_nodes, tn, cb)
+    se = torch.zeros((n, 2), dtype=torch.int32, device=DEV)
+    oi = torch.zeros(n * max_hits, dtype=torch.int32, device=DEV)
+    nf = torch.zeros((n * max_hits, 2), device=DEV)
+    otr = torch.zeros(n * max_hits, dtype=torch.int32, device=DEV)
+    tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.oct_intersect_strided(n, max_hits, so, ro, rd, near, 1e8, tn, se, oi, nf, tot, otr, cb)
+    cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+    S = 1024
+    s_dt = torch.zeros(n * S, device=DEV); s_t = torch.zeros(n * S, device=DEV)
+    s_an = torch.zeros((n * S, 2), dtype=torch.int32, device=DEV); fod = torch.zeros(n, device=DEV)
+    hip.ray_march_strided(n, sample_l, scale_by_dis, ro, rd, nz, se, oi, nf, tn, tr, cnt, None, s_dt, s_t, s_an, fod, otr)
+    pse = torch.zeros((n, 2), dtype=torch.int32, device=DEV)
+    tot2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.segment_scan(n, cnt, pse, tot2)
+    m = int(tot2.item()); mm = max(m, 1)
+    out = dict(pts=torch.zeros((mm, 3), device=DEV), dirs=torch.zeros((mm, 3), device=DEV), dt=torch.zeros(mm, device=DEV),
+               t=torch.zeros(mm, device=DEV), anchors=torch.zeros((mm, 3), dtype=torch.int32, device=DEV))
+    hip.pack_samples(n, pse, ro, rd, tr, None, s_dt, s_t, s_an, out["pts"], out["dirs"], out["dt"], out["t"], out["anchors"])
+    torch.cuda.synchronize()
+    res = {k: N(v)[:m] for k, v in out.items()}
+    res["pts_idx_bounds"] = N(pse)
+    res["first_oct_dis"] = N(fod).reshape(n, 1)
+    hits = (N(se), N(oi), N(nf), int(tot.item()))
+    return hits, res
+
+
+def check_strided_hits(hits, ref_hits, max_hits):
+    se, oi, nf, total = hits
+    rse, ridx, rnf = ref_hits
+    n = len(rse)
+    assert total == len(ridx)
+    cnt = se[:, 1] - se[:, 0]
+    assert (se[:, 0] == np.arange(n) * max_hits).all() and (cnt == rse[:, 1] - rse[:, 0]).all()
+    # gather the filled prefixes of all slots into the oracle's ray-ordered compact layout
+    ray = np.repeat(np.arange(n), cnt)
+    pos = np.arange(len(ray)) - np.repeat(rse[:, 0], cnt)
+    flat = ray * max_hits + pos
+    assert same_bits(oi[flat], ridx), "leaf indices"
+    assert same_bits(nf[flat], rnf), "near / far"
+
+
+# ---------------------------------------------------------------------------------------------------
+# sampler on deep trees
+# ---------------------------------------------------------------------------------------------------
+def test_sampler_on_converged_octree(hip):
+    """The octree of a finished fox training (148 k nodes after five subdivisions and 20 compactions; dumped by
+    tools/train_fox.py --dump-sampler) with a real training batch of 13056 rays: leaf lists and every sample, bit for bit."""
+    z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
+    n = z["rays_o"].shape[0]
+    rd = oc.normalize_dirs(z["rays_d"])
+    rng = np.random.default_rng(0)
+    noise = (((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(float(z["fineness"]))).astype(F32)
+    hits, got = single_pass_sample(hip, z["tree_nodes"], z["pers_trans"], z["search_order"], z["rays_o"], rd, noise, 1. / 256., True)
+    ref_hits = oc.oct_intersect(z["search_order"], z["rays_o"], rd, 0.01, 1e8, z["tree_nodes"], 1024)
+    check_strided_hits(hits, ref_hits, 1024)
+    ref = oc.ray_march(z["rays_o"], rd, noise, 1. / 256., True, *ref_hits, z["tree_nodes"], z["pers_trans"])
+    per_ray = ref["pts_idx_bounds"][:, 1] - ref["pts_idx_bounds"][:, 0]
+    assert per_ray.max() > 150 and per_ray.mean() < 80  # the converged regime: a long tail next to short rays
+    for k in ref:
+        assert same_bits(got[k], ref[k]), k
+
+
+def deep_corner_tree(depth, trans_idx=0):
+    """A `depth`-level tree whose (-,-,-) child is subdivided at every level, all other children valid leaves: a ray that
+    leaves the corner along a near-diagonal crosses 4 children of EVERY node on the path, so the front-to-back walk has 3
+    parked siblings per level on its work stack at the bottom of the path."""
+    nodes = np.zeros(1 + 8 * depth, octc.NODE_DT)
+    nodes["parent"] = -1
+    nodes["childs"] = -1
+    nodes["trans_idx"] = -1
+    nodes["is_leaf_node"] = 1
+    side = F32(1024.)
+    nodes[0]["center"] = (side * F32(.5),) * 3
+    nodes[0]["side_len"] = side
+    cur, nxt = 0, 1
+    for _ in range(depth):
+        pc, ps = nodes[cur]["center"].copy(), nodes[cur]["side_len"]
+        nodes[cur]["is_leaf_node"] = 0
+        nodes[cur]["trans_idx"] = -1
+        for st in range(8):
+            off = np.array([((st >> 2) & 1) - .5, ((st >> 1) & 1) - .5, (st & 1) - .5], F32)
+            v = nxt + st
+            nodes[v]["center"] = (pc + ps * F32(.5) * off).astype(F32)
+            nodes[v]["side_len"] = ps * F32(.5)
+            nodes[v]["parent"] = cur
+            nodes[v]["trans_idx"] = trans_idx
+            nodes[cur]["childs"][st] = v
+        cur, nxt = nxt, nxt + 8  # slot 0 = (-,-,-)
+    return nodes
+
+
+@pytest.mark.parametrize("depth", [19, 23])
+def test_deep_tree_fills_the_dfs_stack(hip, fox_state, depth):
+    """Paths of 19+ levels with 3 parked siblings per level need more than 56 work-stack entries (the size the first
+    version of the cooperative DFS had, with a lossy overflow branch); 23 levels is the deepest path the reference's own
+    48-int stack can walk (PersSampler.cu:7,70).  The leaf lists must equal the one-thread DFS of the reference."""
+    st = fox_state
+    nodes = deep_corner_tree(depth)
+    blob = nodes.view(np.uint8).reshape(-1)
+    rng = np.random.default_rng(depth)
+    n = 257
+    smallest = 1024. / 2 ** depth
+    o = (rng.random((n, 3)) * smallest * 0.5).astype(F32)  # inside the deepest cell, next to the corner
+    d = (np.array([1., 1.1, 1.2]) + rng.random((n, 3)) * 0.3)
+    d[n // 2:] *= -1.0  # the other half looks away from the tree's bulk: short lists
+    o[n // 2:] = (rng.random((n - n // 2, 3)) * 900 + 50).astype(F32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F32)
+    noise = (((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(64.)).astype(F32)
+    tr = np.zeros(1, octc.TRANS_DT)  # one benign warp for every leaf: affine projections (z' = 1), finite Jacobians
+    tr["w2xz"][0, :, 0, :3] = rng.standard_normal((12, 3)) * 0.01
+    tr["w2xz"][0, :, 1, 3] = 1.0
+    tr["weight"][0] = rng.standard_normal((3, 12))
+    tr["center"][0] = 512.
+    tr["dis_summary"][0] = 1000.
+    trans = tr.view(np.uint8).reshape(-1)
+    hits, got = single_pass_sample(hip, blob, trans, st["search_order"], o, d, noise, 1. / 256., False, near=0.0)
+    ref_hits = oc.oct_intersect(st["search_order"], o, d, 0.0, 1e8, blob, 1024)
+    per_ray = ref_hits[0][:, 1] - ref_hits[0][:, 0]
+    assert per_ray[:n // 2].min() >= 3 * depth  # every level contributes its three far siblings
+    check_strided_hits(hits, ref_hits, 1024)
+    ref = oc.ray_march(o, d, noise, 1. / 256., False, *ref_hits, blob, trans)
+    for k in ("pts_idx_bounds", "anchors", "t", "dt", "pts"):
+        assert same_bits(got[k], ref[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE config 2, one full iteration at the benched size
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("table_init", ["reference", 0.3])
+def test_config2_full_iteration_parity(rt, fox_state, table_init):
+    """8192 rays, wanjinyou.yaml, 2^19 x 16 table, 8192 edge samples, fineness 16 -- exactly what bench.py times (the
+    partitioned plane gather, the cached-feature field forward, the owner-binned scatter), once on the fresh table of the
+    bench (nothing is stopped early) and once on a table with trained-looking magnitudes (early stop, compaction)."""
+    st = fox_state
+    rng = np.random.default_rng(2022)
+    R, NE = 8192, 8192
+    runner, cfg, arrays = rt.make_runner(st, "wanjinyou", seed=7, table_init=table_init)
+    assert int(cfg["field"]["log2_table_size"]) == 19
+    runner.iter_step = 1
+    runner.update_ada_params()
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    gt = rng.random((R, 3), dtype=F32)
+    noise = (((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(float(runner.fineness))).astype(F32)
+    bg = rng.random((R, 3), dtype=F32)
+    eidx = rng.integers(0, st["edge_pool"].size // 64, NE).astype(np.int32)
+    ecoord = (rng.random((NE, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32)
+    d = rt.to_dev(ro, rd, bounds, gt, cam, noise, bg, eidx, ecoord)
+    runner.set_forced_randoms(d[5], d[6], d[7], d[8])
+    ref = oracle_train_iteration(st, cfg, arrays, ro, rd, cam, gt, noise, bg, eidx, ecoord, iter_step=1)
+
+    s = runner.get_samples(d[0], d[1], d[2])
+    for k in ("pts_idx_bounds", "anchors", "t", "dt", "pts", "dirs"):
+        assert same_bits(N(s[k]), ref["smp"][k]), k
+    del s
+    runner.zero_grad()
+    stats = runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
+    assert stats["n_samples"] == len(ref["smp"]["t"])
+    # early-stop threshold (T > 1e-4) against 1-ulp expf differences: a handful of samples out of ~8e5 may flip
+    assert abs(stats["n_meaningful"] - ref["n_kept"]) <= 8, (stats["n_meaningful"], ref["n_kept"])
+    assert abs(float(stats["loss"]) - ref["loss"]) <= 1e-3 * max(1.0, abs(ref["loss"]))
+    g = {k: N(v) for k, v in runner.grads().items()}
+    rg = ref["grads"]
+    for k in ("color_mlp", "field_mlp", "app_emb"):
+        assert rel_err(g[k], rg[k]) <= 3e-2, (k, rel_err(g[k], rg[k]))
+    a, b = g["feat_pool"].reshape(-1).astype(np.float64), rg["feat_pool"].reshape(-1).astype(np.float64)
+    cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+    assert cos > 0.999, cos
+    assert rel_err(g["feat_pool"].reshape(-1), rg["feat_pool"].reshape(-1)) <= 5e-2
+    assert abs(int((a != 0).sum()) - int((b != 0).sum())) <= 2e-3 * (b != 0).sum() + 64  # same entries touched (fp16 flush aside)
+
+    out = runner.render_train(d[0], d[1], d[2], d[4])
+    colors = N(out["colors"])
+    assert np.abs(colors - ref["colors"]).max() <= 1e-3, np.abs(colors - ref["colors"]).max()
+    mse_g, mse_r = float(((colors - gt) ** 2).mean()), float(((ref["colors"] - gt) ** 2).mean())
+    assert abs(10 * np.log10(1 / mse_g) - 10 * np.log10(1 / mse_r)) <= 1e-3
+    assert np.abs(N(out["disparity"]) - ref["disparity"]).max() <= 1e-3 * max(1.0, np.abs(ref["disparity"]).max())
+    if stats["n_meaningful"] == ref["n_kept"]:
+        assert (N(out["idx_start_end"]) == ref["new_se"]).all()
+        assert np.abs(N(out["weights"]) - ref["weights"]).max() <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# a training trajectory across a subdivision milestone and a compaction
+# ---------------------------------------------------------------------------------------------------
+class OracleTrainer:
+    """ExpRunner::Train (ExpRunner.cpp:82-143) + PersSampler::UpdateOctNodes (PersSampler.cu:536-615) on the oracle."""
+
+    def __init__(self, st, cfg, arrays, n_images):
+        self.st, self.cfg = st, cfg
+        tn, tr, visit, _ms, table, prim, bias, nvol, p_field, p_color, app_emb = [np.array(a) for a in arrays]
+        self.nodes = tn.view(octc.NODE_DT).copy()
+        self.tr = tr
+        n = len(self.nodes)
+        self.w_stats = np.full(n, 1000, np.int32)
+        self.a_stats = np.full(n, 1000, np.int32)
+        self.visit = visit.astype(np.int32).copy()
+        self.milestones = sorted(int(v) for v in cfg["pts_sampler"]["sub_div_milestones"])
+        self.grid = op.HashGrid(table, prim, bias, int(nvol[0]), int(cfg["field"]["log2_table_size"]))
+        self.p_field, self.p_color, self.app_emb = p_field.copy(), p_color.copy(), app_emb.copy()
+        self.adam = {k: [np.zeros_like(v.reshape(-1)), np.zeros_like(v.reshape(-1))] for k, v in
+                     (("table", self.grid.table_f32), ("field", self.p_field), ("color", self.p_color), ("emb", self.app_emb))}
+        self.iter_step = 0
+        self.optim_steps = 0
+        ts = st["train_set"]
+        self.w2c, self.intri, self.bounds = st["w2c"][ts], st["intri"][ts], st["bounds"][ts]
+
+    def lr(self):
+        t = self.cfg["train"]
+        warm, end = int(t["learning_rate_warm_up_end_iter"]), int(t["end_iter"])
+        if self.iter_step >= warm:
+            p = F32(self.iter_step - warm) / F32(end - warm)
+            f = (F32(1.) - F32(t["learning_rate_alpha"])) * (np.cos(p * F32(np.pi), dtype=F32) * F32(.5) + F32(.5)) + F32(t["learning_rate_alpha"])
+        else:
+            f = F32(self.iter_step) / F32(warm)
+        return float(F32(t["learning_rate"]) * F32(f))
+
+    def fineness(self):
+        t = self.cfg["train"]
+        end = int(t["ray_march_fineness_decay_end_iter"])
+        if self.iter_step >= end:
+            return 1.0
+        p = F32(self.iter_step) / F32(end)
+        return float(np.exp(np.log(F32(1.)) * p + np.log(F32(t["ray_march_init_fineness"])) * (F32(1.) - p), dtype=F32))
+
+    def tree_blob(self):
+        return self.nodes.view(np.uint8).reshape(-1)
+
+    def proc(self, compact, subdivide, brute):
+        self.nodes, self.w_stats, self.a_stats = octc.proc_octree(self.nodes, self.w_stats, self.a_stats, self.visit, compact,
+                                                                  subdivide, brute)
+        self.visit = np.zeros(len(self.nodes), np.int32)
+
+    def step(self, rays_o, rays_d_raw, cam, gt, noise, bg, eidx, ecoord):
+        st, cfg = self.st, self.cfg
+        arrays = [self.tree_blob(), self.tr, None, None, self.grid.table_f32, self.grid.prim_pool, self.grid.bias_pool,
+                  np.array([self.grid.n_volumes]), self.p_field, self.p_color, self.app_emb]
+        # (the table gradient as the reference forms it: fp16 addends, fp16 running sums)
+        ref = oracle_train_iteration(st, cfg, arrays, rays_o, rays_d_raw, cam, gt, noise, bg, eidx, ecoord, self.iter_step,
+                                     fp32_accumulate=False)
+        # occupancy update with the pre-pass weights / alphas of ALL marched samples (Renderer.cpp:140-149)
+        smp = ref["smp"]
+        w_add, a_add, mark, self.visit = oc.mark_visit(len(self.nodes), smp["pts_idx_bounds"], smp["anchors"][:, 1],
+                                                       ref["w_pre"], ref["a_pre"], self.visit)
+        self.w_stats, self.a_stats, blob = oc.update_node_stats(w_add, a_add, mark, self.w_stats, self.a_stats, self.tree_blob())
+        self.nodes = blob.view(octc.NODE_DT).copy()
+        while self.milestones and self.milestones[0] <= self.iter_step:  # PersSampler.cu:605-610
+            self.proc(True, True, self.milestones[0] <= 0)
+            self.nodes = oc.mark_invisible(self.tree_blob(), self.intri, self.w2c, self.bounds).view(octc.NODE_DT).copy()
+            self.proc(True, False, False)
+            self.milestones.pop(0)
+        if self.iter_step % int(cfg["pts_sampler"]["compact_freq"]) == 0:
+            self.proc(True, False, False)
+        # Adam (the optimiser groups of Hash3DAnchored.cpp:124-150, SHShader.cpp:44-56, Renderer.cpp:238-258)
+        self.optim_steps += 1
+        lr = self.lr()
+        g = ref["grads"]
+        for key, p, grad, wd in (("table", self.grid.table_f32, g["feat_pool"], 0.0), ("field", self.p_field, g["field_mlp"], 1e-6),
+                                 ("color", self.p_color, g["color_mlp"], 1e-6), ("emb", self.app_emb, g["app_emb"], 1e-6)):
+            newp, self.adam[key][0], self.adam[key][1] = op.adam_step(p.reshape(-1), np.asarray(grad, F32).reshape(-1), self.adam[key][0],
+                                                                      self.adam[key][1], self.optim_steps, lr, 0.9, 0.99, 1e-15, wd)
+            p.reshape(-1)[...] = newp
+        self.iter_step += 1
+        return ref
+
+
+def test_training_trajectory_across_milestone_and_compaction(rt, fox_state):
+    """36 iterations on both sides from the same state with explicit draws: subdivision + MarkInvisible + compaction at the
+    milestone (iteration 12), compactions every 8 iterations, nodes dying in between (the occupancy statistics start at 2
+    instead of 1000, so unvisited / empty leaves are pruned within the run).  Compared after EVERY iteration: the node
+    array, the visit counts and the sample counts exactly; the occupancy statistics exactly up to a bounded number of
+    borderline votes; the loss within 2e-3; every sixth iteration the rendered batch colours (1e-3, later 3e-3)."""
+    st = fox_state
+    R, NE, ITERS = 256, 512, 36
+    overrides = ["field.log2_table_size=14", "pts_sampler.sub_div_milestones=[12]", "pts_sampler.compact_freq=8",
+                 "train.learning_rate_warm_up_end_iter=20"]
+    runner, cfg, arrays = rt.make_runner(st, "wanjinyou", overrides, seed=5, table_init=0.3)
+    runner.n_edge_pts = NE
+    for t in runner.occupancy_buffers()[:2]:
+        t.fill_(2)
+    orc = OracleTrainer(st, cfg, arrays, len(st["poses"]))
+    import copy
+    cfg_noemb = copy.deepcopy(cfg)
+    cfg_noemb["renderer"]["use_app_emb"] = False
+    orc.w_stats[:] = 2
+    orc.a_stats[:] = 2
+    rng = np.random.default_rng(99)
+    n_nodes_seen = set()
+    vote_flips = 0
+    worst_rgb = 0.0
+    for it in range(ITERS):
+        assert runner.iter_step == orc.iter_step == it
+        ro, rd, bounds, cam = fox_batch(st, rng, R)
+        gt = rng.random((R, 3), dtype=F32)
+        fin = float(runner.fineness)
+        assert abs(fin - orc.fineness()) <= 1e-5 * fin
+        noise = (((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(fin)).astype(F32)
+        bg = rng.random((R, 3), dtype=F32)
+        n_edges = st["edge_pool"].size // 64
+        eidx = rng.integers(0, n_edges, NE).astype(np.int32)
+        ecoord = (rng.random((NE, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32)
+        d = rt.to_dev(ro, rd, bounds, gt, cam, noise, bg, eidx, ecoord)
+        runner.set_forced_randoms(d[5], d[6], d[7], d[8])
+        ref = orc.step(ro, rd, cam, gt, noise, bg, eidx, ecoord)
+        stats = runner.train_step(d[0], d[1], d[2], d[3], d[4], True)
+        assert not stats["skipped_nan"]
+        assert stats["n_samples"] == len(ref["smp"]["t"]), it
+        assert abs(stats["n_meaningful"] - ref["n_kept"]) <= 2, (it, stats["n_meaningful"], ref["n_kept"])
+        assert abs(float(stats["loss"]) - ref["loss"]) <= 2e-3 * max(1.0, abs(ref["loss"])), (it, float(stats["loss"]), ref["loss"])
+        got_nodes = N(runner.tree_nodes()).view(octc.NODE_DT)
+        assert len(got_nodes) == len(orc.nodes), (it, len(got_nodes), len(orc.nodes))
+        for f in ("center", "side_len", "parent", "childs", "is_leaf_node"):
+            assert (got_nodes[f] == orc.nodes[f]).all(), (it, f)
+        wst, ast, vcnt = [N(t) for t in runner.occupancy_buffers()]
+        assert (vcnt == orc.visit).all(), it
+        # A vote compares a sample's weight / alpha with a threshold (PersSampler.cu:497-520); where the two sides' MLP outputs
+        # differ by an f16 ulp a borderline vote can fall differently.  Such nodes are counted, bounded, and the oracle's
+        # statistics are re-aligned so that one borderline vote does not fork the rest of the trajectory.
+        bad = (wst != orc.w_stats) | (ast != orc.a_stats) | (got_nodes["trans_idx"] != orc.nodes["trans_idx"])
+        if bad.any():
+            vote_flips += int(bad.sum())
+            assert bad.sum() <= 2, (it, int(bad.sum()))
+            assert (np.abs(wst - orc.w_stats)[bad] <= 513).all() and (np.abs(ast - orc.a_stats)[bad] <= 33).all()  # one vote each
+            orc.w_stats, orc.a_stats = wst.copy(), ast.copy()
+            orc.nodes["trans_idx"] = got_nodes["trans_idx"]
+        n_nodes_seen.add(len(got_nodes))
+        # every few iterations both sides render this batch with the UPDATED state (VALIDATE mode: no occupancy votes, no
+        # appearance embedding; the explicit noise / background draws stay in force)
+        if it % 6 == 5 or it == ITERS - 1:
+            got = N(runner.render_rays(d[0], d[1], d[2])[0])
+            arrays_now = [orc.tree_blob(), orc.tr, None, None, orc.grid.table_f32, orc.grid.prim_pool, orc.grid.bias_pool,
+                          np.array([orc.grid.n_volumes]), orc.p_field, orc.p_color, orc.app_emb]
+            ref2 = oracle_train_iteration(st, cfg_noemb, arrays_now, ro, rd, cam, gt, noise, bg, eidx, ecoord, orc.iter_step)
+            err = float(np.abs(got - ref2["colors"]).max())
+            worst_rgb = max(worst_rgb, err)
+            # identical weights render within 1e-3 (test_config2_full_iteration_parity); here the weights themselves come out of
+            # two optimiser trajectories, and Adam (eps 1e-15) turns one-ulp differences of f16 gradients into full-size steps
+            # of the affected entries: the renderings stay within 1e-3 for the first two dozen updates, 3e-3 after three dozen
+            assert err <= (1e-3 if it < 24 else 3e-3), (it, err)
+    assert len(n_nodes_seen) >= 3, n_nodes_seen  # the tree really changed (subdivision, pruning)
+    assert vote_flips <= 6, vote_flips       # of ~1e5 node-iterations
+    # final parameters: the tables of both sides took the same trajectory
+    states = [N(t) for t in runner.states()]
+    tab = states[4].reshape(-1)
+    ref_tab = orc.grid.table_f32.reshape(-1)
+    cos = float((tab.astype(np.float64) * ref_tab).sum() / (np.linalg.norm(tab) * np.linalg.norm(ref_tab)))
+    assert cos > 0.9999, cos
+    assert np.abs(states[8] - orc.p_field).max() <= 5e-3 and np.abs(states[9] - orc.p_color).max() <= 5e-3
