@@ -103,17 +103,17 @@ def converged_leg(args, st, dev):
     for i in range(10):
         step(i)
     runner.flush()
+    c0 = runner.counters()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nm = na = 0
     K = args.converged_steps
     for i in range(K):
-        r = step(10 + i)
-        nm += r["n_meaningful"]
-        na += r["n_samples"]
+        step(10 + i)
     runner.flush()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    c1 = runner.counters()
+    nm, na = c1["total_meaningful"] - c0["total_meaningful"], c1["total_marched"] - c0["total_marched"]
     out.update({"rays_per_batch": R, "steps": K, "ms_per_step": el / K * 1e3, "value": nm / el, "unit": "ray-samples/s",
                 "marched_samples_per_s": na / el, "rho_marched_over_meaningful": na / max(nm, 1),
                 "meaningful_samples_per_step": nm / K, "marched_samples_per_step": na / K, "rays_per_s": R * K / el})
@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--converged-steps", type=int, default=600, help="timed steps in the converged state")
     ap.add_argument("--factor", type=int, default=2, choices=[2, 8], help="image resolution of the converged leg (dataset.factor)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
+    ap.add_argument("--marker-pause", action="store_true", help="sleep 0.3 s before the timed region (marker for profiles/timeline_rocpd.py)")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
@@ -221,16 +222,19 @@ def main():
     if rank == 0:
         host.ExpRunner.enable_kernel_timing([DOMINANT, "field_mlp_prepass", "field_fwd_cached", "field_fwd", "field_bwd",
                                              "shade_fwd", "shade_bwd"])
+    c0 = runner.counters()  # (flushes)
     barrier()
+    if args.marker_pause:
+        time.sleep(0.3)
     t0 = time.perf_counter()
-    n_marched = n_meaningful = 0
     for i in range(args.steps):
-        s = step(args.warmup + i)
-        n_marched += s["n_samples"]
-        n_meaningful += s["n_meaningful"]
-    runner.flush()  # pipelined data-parallel mode: the last step's all-reduce + Adam belong to the timed region
+        step(args.warmup + i)
+    runner.flush()  # the last step's survivor count / flags (and, data-parallel, its all-reduce + Adam) belong to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    c1 = runner.counters()
+    n_marched = c1["total_marched"] - c0["total_marched"]
+    n_meaningful = c1["total_meaningful"] - c0["total_meaningful"]
     timing = host.ExpRunner.collect_kernel_timing() if rank == 0 else {}
     host.ExpRunner.disable_kernel_timing()
 

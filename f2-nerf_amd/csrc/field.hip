@@ -408,7 +408,12 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
                                                        int pts_are_warped, const int32_t* __restrict__ volume_idx, int vol_stride,
                                                        const half_t* __restrict__ gx, long gx_sample_stride,
                                                        long gx_pair_stride, const uint16_t* __restrict__ nz_mask,
-                                                       F2nBinQueues q, half_t* __restrict__ grad_table) {
+                                                       F2nBinQueues q, half_t* __restrict__ grad_table,
+                                                       const int32_t* __restrict__ n_dev, int n_off) {
+  if (n_dev != nullptr) {  // the row count is still on the device: split what there really is over the producer blocks
+    n = min(n, *n_dev + n_off);
+    chunk = min(chunk, (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255);
+  }
   __shared__ F2nLevelTab lt;
   __shared__ int s_cnt[F2N_BIN_MAX_BINS];
   __shared__ uint16_t s_idx[F2N_BIN_MAX_CHUNK];  // offsets (inside the chunk) of the samples with a non-zero gradient
@@ -628,9 +633,11 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
     const int32_t* __restrict__ volume_idx, int vol_stride, const float* __restrict__ x_f32,
     const half_t* __restrict__ params, float* __restrict__ out_feat_f32, half_t* __restrict__ out_feat_h,
     float* __restrict__ out_f0, half_t* __restrict__ save_x, const half_t* __restrict__ x_planes,
-    const half_t* __restrict__ x_cache, const int32_t* __restrict__ src_rows) {
+    const half_t* __restrict__ x_cache, const int32_t* __restrict__ src_rows, const int32_t* __restrict__ n_dev) {
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int n_alloc = n;  // the plane stride stays the allocated row count
+  if (n_dev != nullptr) n = min(n, *n_dev);  // the sample count is still on the device (f2n_field_fwd_cached_dyn)
   if (DO_HASH) {
     f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
     __syncthreads();
@@ -651,8 +658,8 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
       const int vol = volume_idx[(size_t) sc * vol_stride];
       xf = f2n_gather_frag(h, lt, p01, vol, g, valid);
     } else if (x_planes != nullptr) {  // features gathered by hash_gather_planes_kernel
-      xf = f2n_cat(*(const half4_t*) (x_planes + ((size_t) g * n + sc) * 4),
-                   *(const half4_t*) (x_planes + ((size_t) (4 + g) * n + sc) * 4));
+      xf = f2n_cat(*(const half4_t*) (x_planes + ((size_t) g * n_alloc + sc) * 4),
+                   *(const half4_t*) (x_planes + ((size_t) (4 + g) * n_alloc + sc) * 4));
       if (!valid) xf = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
     } else if (x_cache != nullptr) {  // h16 feature rows of an earlier query of the same table (f2n_field_fwd_cached)
       xf = f2n_load_xfrag_h(x_cache, src_rows != nullptr ? src_rows[sc] : sc, g, valid);
@@ -701,7 +708,9 @@ __global__ __launch_bounds__(F2N_BWD_THREADS, BPC) void field_bwd_kernel(
     const int32_t* __restrict__ volume_idx, int vol_stride, const half_t* __restrict__ params,
     const half_t* __restrict__ x_h, const float* __restrict__ x_f32, const float* __restrict__ dy, float loss_scale,
     float* __restrict__ dparams, float* __restrict__ dx_f32, half_t* __restrict__ grad_table, half_t* __restrict__ dx_planes,
-    uint16_t* __restrict__ nz_mask) {
+    uint16_t* __restrict__ nz_mask, const int32_t* __restrict__ n_dev, int n_off) {
+  const int n_alloc = n;  // plane stride / mask words: the allocated row count
+  if (n_dev != nullptr) n = min(n, *n_dev + n_off);  // the row count is still on the device (f2n_field_bwd_dyn)
   __shared__ F2nBwdSmem<NH> sm;
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -766,8 +775,8 @@ __global__ __launch_bounds__(F2N_BWD_THREADS, BPC) void field_bwd_kernel(
           for (int e = 0; e < 8; e++) nz |= (float) gx[e] != 0.f;
           const unsigned long long bal = __ballot(nz && valid);  // bit 16g + c: lane (c, g) of this tile
           if (valid) {
-            *(half4_t*) (dx_planes + ((size_t) g * n + s) * 4) = __builtin_shufflevector(gx, gx, 0, 1, 2, 3);
-            *(half4_t*) (dx_planes + ((size_t) (4 + g) * n + s) * 4) = __builtin_shufflevector(gx, gx, 4, 5, 6, 7);
+            *(half4_t*) (dx_planes + ((size_t) g * n_alloc + s) * 4) = __builtin_shufflevector(gx, gx, 0, 1, 2, 3);
+            *(half4_t*) (dx_planes + ((size_t) (4 + g) * n_alloc + s) * 4) = __builtin_shufflevector(gx, gx, 4, 5, 6, 7);
           }
           if (lane == 0)  // one 16-bit word per tile: sample c has a non-zero gradient
             nz_mask[tile] = (uint16_t) ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull);
@@ -863,7 +872,8 @@ static inline bool f2n_mlp_shape_ok(int d_in, int d_hidden, int n_hidden) {
 // Owner-binned scatter of f16 gradients gx (pair (l, ch) of sample s at gx[s*ss + (l>>1)*ps + 2*(l&1) + ch]).
 static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const int32_t* local_idx, const int32_t* local_size,
                               const float* level_scale, const float* pts, int warped, const int32_t* volume_idx, int vol_stride,
-                              const half_t* gx, long ss, long ps, const uint16_t* nz_mask, half_t* grad_table, int level_entries) {
+                              const half_t* gx, long ss, long ps, const uint16_t* nz_mask, half_t* grad_table, int level_entries,
+                              const int32_t* n_dev = nullptr, int n_off = 0) {
   F2nBinQueues q;
   q.n_bins = level_entries >> F2N_BIN_SHIFT;
   const int chunk = (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255;
@@ -873,7 +883,7 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   q.cnt = (int32_t*) f2n_ws_get(F2N_WS_BIN_CNT, n_seg * sizeof(int32_t));
   if (q.rec == nullptr || q.cnt == nullptr) return F2N_ERR_INVALID_ARG;
   hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
-                     level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table);
+                     level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table, n_dev, n_off);
   const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels
   hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS + 1) * H), dim3(256), 0, st, q, H, grad_table);
   return f2n_launch_status();
@@ -917,7 +927,7 @@ int f2n_hash_fwd(void* stream, int n, int n_volumes, const void* table_h, const 
   F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
   hipLaunchKernelGGL((field_fwd_kernel<1, true, false>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                      (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx,
-                     vol_stride, nullptr, nullptr, nullptr, nullptr, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr);
+                     vol_stride, nullptr, nullptr, nullptr, nullptr, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -945,10 +955,10 @@ int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const
   const dim3 grid(f2n_wave_grid((n + 15) / 16, 4)), block(F2N_FWD_THREADS);
   if (n_hidden == 1)
     hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
-                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   else
     hipLaunchKernelGGL((field_fwd_kernel<2, false, true>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr,
-                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       nullptr, 0, nullptr, 1, x, (const half_t*) params_h, nullptr, (half_t*) out_h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -965,10 +975,10 @@ int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_hidden == 1)
     hipLaunchKernelGGL((field_bwd_kernel<1, 0, 3>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr);
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr, nullptr, 0);
   else
     hipLaunchKernelGGL((field_bwd_kernel<2, 0, 2>), grid, block, 0, (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr,
-                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr);
+                       0, nullptr, 1, (const half_t*) params_h, nullptr, x, dy, loss_scale, partials, dx_f32, nullptr, nullptr, nullptr, nullptr, 0);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   return f2n_reduce_partials(stream, n_params, (int) grid.x, partials, dparams_f32_scaled);
@@ -984,7 +994,7 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
   if (n < F2N_PARTITION_MIN_N) {  // small batches: one launch, features stay in registers between gather and MFMA
     hipLaunchKernelGGL((field_fwd_kernel<1, true, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                        (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                       nullptr, (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr, nullptr, nullptr);
+                       nullptr, (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr, nullptr, nullptr, nullptr);
     return f2n_launch_status();
   }
   // large batches: XCD-aware level-partitioned gather into f16 planes (64 B/sample of internal workspace), then the
@@ -1074,19 +1084,25 @@ int f2n_field_mlp_planes(void* stream, int n, const void* planes_h, const void* 
   hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                      (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr,
                      (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, (const half_t*) planes_h,
-                     nullptr, nullptr);
+                     nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
 int f2n_field_fwd_cached(void* stream, int n, int n_cache, const int32_t* src_rows, const void* x_cache_h,
                          const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h) {
+  return f2n_field_fwd_cached_dyn(stream, n, nullptr, n_cache, src_rows, x_cache_h, mlp_params_h, out_feat_f32, out_f0, save_x_h);
+}
+
+int f2n_field_fwd_cached_dyn(void* stream, int n_max, const int32_t* n_dev, int n_cache, const int32_t* src_rows,
+                             const void* x_cache_h, const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h) {
+  const int n = n_max;
   if (n < 0 || n_cache < 0 || (n > 0 && x_cache_h == nullptr) || (src_rows == nullptr && n > n_cache)) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
   hipLaunchKernelGGL((field_fwd_kernel<1, false, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
                      (hipStream_t) stream, n, h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr,
                      (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr,
-                     (const half_t*) x_cache_h, src_rows);
+                     (const half_t*) x_cache_h, src_rows, n_dev);
   return f2n_launch_status();
 }
 
@@ -1094,6 +1110,17 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
                   const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts_warped,
                   const int32_t* volume_idx, int vol_stride, const void* mlp_params_h, const void* saved_x_h,
                   const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h, int level_entries) {
+  return f2n_field_bwd_dyn(stream, n, nullptr, 0, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped,
+                           volume_idx, vol_stride, mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_f32_scaled, grad_table_h,
+                           level_entries);
+}
+
+int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, int n_volumes, const int32_t* prim_pool,
+                      const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                      const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
+                      const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h,
+                      int level_entries) {
+  const int n = n_max;
   if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f) || level_entries < 0 || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
@@ -1115,7 +1142,7 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
   hipLaunchKernelGGL((field_bwd_kernel<1, HASH, BPC>), dim3(blocks), dim3(F2N_BWD_THREADS), 0, (hipStream_t) stream, n, h,  \
                      local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, (const half_t*) mlp_params_h, \
                      (const half_t*) saved_x_h, nullptr, dfeat, loss_scale, partials, nullptr, (half_t*) grad_table_h,       \
-                     dx_planes, nz_mask)
+                     dx_planes, nz_mask, n_dev, n_off)
   if (!bins) F2N_LAUNCH_FIELD_BWD(1, 2);
   else F2N_LAUNCH_FIELD_BWD(2, 3);
 #undef F2N_LAUNCH_FIELD_BWD
@@ -1123,7 +1150,7 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
   if (rc != F2N_OK) return rc;
   if (dx_planes != nullptr) {  // planes [8][n][4]: pair (l, ch) at (l>>1)*4n + 4*s + 2*(l&1) + ch
     rc = f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                            dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries);
+                            dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries, n_dev, n_off);
     if (rc != F2N_OK) return rc;
   }
   return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);

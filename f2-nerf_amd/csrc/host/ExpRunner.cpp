@@ -195,15 +195,20 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
       renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, fin);
     };
   }
+  // A streaming step (it was handed the next batch) does not wait for the survivor count either: it stays on the device
+  // (f2n_*_dyn entry points), the host queues the whole iteration without a device round trip and learns the count -- for
+  // the meaningful-samples EMA and the counters -- at the start of the next step (Renderer::ResolvePendingCount).
+  renderer_->async_count_ = (prefetch && async_counts_ == 1) || async_counts_ == 2;
   TrainOutputs out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(),
                                                      disp_loss_weight_, tv_loss_weight_);
+  renderer_->async_count_ = false;
   renderer_->after_octree_update_ = nullptr;
   ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)
   TrainStats stats;
   stats.skipped_nan = deferred_dropped_;  // the PREVIOUS iteration was dropped: reported one step late when prefetching
   stats.n_rays = rays_o.size(0);
   stats.n_samples = renderer_->last_n_all_pts_;
-  stats.n_meaningful = renderer_->last_n_kept_pts_;
+  stats.n_meaningful = renderer_->count_pending_ ? -1 : renderer_->last_n_kept_pts_;  // -1: still on the device (see counters())
   stats.loss = out.losses.slice(0, 0, 1).squeeze(0);
   stats.mse = out.losses.slice(0, 5, 6).squeeze(0);
   bool applied = false;
@@ -304,6 +309,7 @@ bool ExpRunner::ApplyGradients(bool apply_optimizer) {
 // deviation from the unpipelined order, and only on that rare path).
 void ExpRunner::FinishPending() {
   FinishPendingStep();
+  renderer_->ResolvePendingCount();
   ResolveDeferredFlags();
 }
 
@@ -502,6 +508,8 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   auto draw = [&]() { return dataset.RandRaysData(std::max(16, CurBatchSize()), sets); };
   auto next = draw();
   last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;
+  FinishPending();
+  const int64_t kept0 = renderer_->total_kept_pts_;
   const int give_up = 4 * (target + 16);  // every iteration non-finite: stop instead of spinning
   while (true) {
   while (iter_step_ < target) {
@@ -512,7 +520,6 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
     Tensor gt = std::get<1>(cur);
     TORCH_CHECK(gt.defined(), "Train needs resident ground-truth images in the Dataset");
     TrainStats s = TrainStep(r.origins, r.dirs, r.bounds, gt, std::get<2>(cur), true, nr.origins, nr.dirs, nr.bounds);
-    last_train_meaningful_ += s.n_meaningful;
     last_train_marched_ += s.n_samples;
     last_train_rays_ += s.n_rays;
     last_train_stats_ = s;

@@ -67,6 +67,7 @@ class ExpRunner {
   float gradient_scaling_start_, gradient_scaling_end_;
   float cur_lr_ = 0.f;
   bool check_nan_ = true;
+  int async_counts_ = 1;  // 1: streaming steps keep the survivor count on the device; 0: always read it back (as Render does); 2: never read it back in TrainStep (tests)
   int optim_steps_ = 0;
   std::function<void()> grad_sync_hook_;
   // pipelined variant: begin = launch the asynchronous all-reduce right after backward; end = make the compute stream

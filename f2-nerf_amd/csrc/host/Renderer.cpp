@@ -244,6 +244,10 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
 void Renderer::PreSampleFinish() {
   TORCH_CHECK(pending_samples_.active, "PreSampleFinish without PreSampleBegin");
   {
+    if (side_must_wait_consumed_) {  // the pack's outputs may be handed the memory of the samples this step has just consumed
+      samples_consumed_ev_.block(*side_stream_);
+      side_must_wait_consumed_ = false;
+    }
     c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
     presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pending_samples_);
     presample_done_ev_.record(*side_stream_);
@@ -256,19 +260,38 @@ void Renderer::PreSampleFinish() {
   pending_rays_d_ = Tensor();
 }
 
-RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx) {
+void Renderer::ResolvePendingCount() {
+  if (!count_pending_) return;
+  count_pending_ = false;
+  n_kept_ev_.synchronize();  // long since recorded: this is the previous step's count
+  const int n_kept = n_kept_host_.data_ptr<int32_t>()[0];
+  last_n_kept_pts_ = n_kept;
+  total_kept_pts_ += n_kept;
   auto* gdp = global_data_pool_;
+  gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(pending_count_rays_)) * 0.1f;
+  // (the previous step's finiteness flags are NOT read here: they are written by that step's last kernel, and waiting for
+  // them at the top of a step would stop the host from queueing ahead -- ExpRunner::TrainStep reads them once this step's
+  // forward and backward are queued)
+}
+
+RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,
+                                      bool async_count) {
+  auto* gdp = global_data_pool_;
+  ResolvePendingCount();
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
   if (train && PresampleMatches(rays_o, rays_d)) {  // PreSample[Async]() already marched these rays
     sample_result_ = std::move(presampled_);
-    if (presample_async_) {  // produced on the side stream: order it before this stream, and tell the allocator
+    if (presample_async_) {
+      // Produced on the side stream, out of the side stream's memory pool: order it before this stream.  The allocator is
+      // NOT told (record_stream on the seven tensors cost ~45 us of host time when they are released in the middle of the
+      // step, right where the device is waiting for the next launch): instead samples_consumed_ev_ is recorded on this
+      // stream once the last kernel that reads them has been queued, and the side stream waits for it before the next
+      // kernels that could be handed this memory again (PreSampleFinish).
       auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
       presample_done_ev_.block(cur);
-      for (Tensor* t : {&sample_result_.pts, &sample_result_.dirs, &sample_result_.dt, &sample_result_.t, &sample_result_.anchors,
-                        &sample_result_.pts_idx_bounds, &sample_result_.first_oct_dis})
-        if (t->defined()) t->record_stream(cur);
+      consumed_side_samples_ = true;
     }
     presampled_ = SampleResultFlex();
     has_presample_ = false;
@@ -281,6 +304,8 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   }
   int n_all_pts = sample_result_.pts.size(0);
   last_n_all_pts_ = n_all_pts;
+  if (train) total_all_pts_ += n_all_pts;
+  async_count = async_count && train;
   if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;
 
   Tensor bg_color;  // Renderer.cpp:67-81
@@ -298,6 +323,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       pts_sampler_->UpdateOctNodes(sample_result_, torch::empty({0}, DevF32()), torch::empty({0}, DevF32()));
     last_n_kept_pts_ = 0;
     fr.empty = true;
+    consumed_side_samples_ = false;  // (nothing was read from the side stream's buffers)
     octree_ready_ev_.record();
     return fr;
   }
@@ -342,13 +368,25 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
         f();
       }
     }
-    n_kept_ev_.synchronize();
-    n_kept = n_kept_host_.data_ptr<int32_t>()[0];
-    if (train && after_count_readback_) after_count_readback_();  // everything queued before this point has finished
-    last_n_kept_pts_ = n_kept;
+    if (async_count) {
+      // streaming step: the count stays on the device; n_kept is the capacity every buffer below is sized for
+      n_kept = n_all_pts;
+      count_pending_ = true;
+      pending_count_rays_ = n_rays;
+      fr.dyn = true;
+      fr.n_kept_dev = total;
+    } else {
+      n_kept_ev_.synchronize();
+      n_kept = n_kept_host_.data_ptr<int32_t>()[0];
+      if (train && after_count_readback_) after_count_readback_();  // everything queued before this point has finished
+      last_n_kept_pts_ = n_kept;
+      if (train) total_kept_pts_ += n_kept;
+    }
+    const int64_t so = fr.dyn ? 2 * (int64_t) n_edge : 0;   // first survivor row of pts_all / vol_all
+    const int64_t eo = fr.dyn ? 0 : n_kept;                 // first edge-sample row
     pts_all = torch::empty({n_kept + 2 * n_edge, 3}, DevF32());
     vol_all = torch::empty({n_kept + 2 * n_edge}, DevI32());
-    es.pts = pts_all.slice(0, 0, n_kept);
+    es.pts = pts_all.slice(0, so, so + n_kept);
     es.dirs = torch::empty({n_kept, 3}, DevF32());
     es.dt = torch::empty({n_kept}, DevF32());
     es.t = torch::empty({n_kept}, DevF32());
@@ -366,15 +404,16 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     }
     F2N_TIMED_CALL("compact_samples", f2n_compact_samples_src(st, n_rays, I32P(sample_result_.pts_idx_bounds), I32P(new_se), I32P(mask),
                                  F32P(sample_result_.pts), F32P(sample_result_.dirs), F32P(sample_result_.dt),
-                                 F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all), F32P(es.dirs),
-                                 F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows), I32P(vol_all),
+                                 F32P(sample_result_.t), I32P(sample_result_.anchors), F32P(pts_all) + 3 * so, F32P(es.dirs),
+                                 F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows), I32P(vol_all) + so,
                                  want_emb ? I32P(emb_contig) : nullptr, want_emb ? I32P(fr.sample_emb_idx) : nullptr));
     if (train) {
-      gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(n_rays)) * 0.1f;
-      // edge samples for the TV loss go straight behind the surviving samples (Renderer.cpp:159-166)
+      if (!fr.dyn)
+        gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(n_rays)) * 0.1f;
+      // edge samples for the TV loss share the field's point array with the surviving samples (Renderer.cpp:159-166)
       auto& oct = *ps->pers_octree_;
       F2N_CALL(f2n_edge_samples(st, n_edge, VoidP(oct.edge_pool_gpu_), VoidP(oct.pers_trans_gpu_), I32P(edge_idx),
-                                F32P(edge_coord), F32P(pts_all) + 3 * (int64_t) n_kept, I32P(vol_all) + n_kept));
+                                F32P(edge_coord), F32P(pts_all) + 3 * eo, I32P(vol_all) + eo));
     }
   }
 
@@ -383,6 +422,11 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   fr.emb = train && use_app_emb_ && emb_idx.defined();
   if (!fr.emb) fr.sample_emb_idx = torch::empty({0}, DevI32());  // autograd::Function inputs must be defined tensors
   sample_result_ = SampleResultFlex();  // drop the pre-early-stop buffers
+  if (consumed_side_samples_) {         // (see above: every reader of the side stream's sample buffers has been queued)
+    samples_consumed_ev_.record();
+    consumed_side_samples_ = false;
+    side_must_wait_consumed_ = true;
+  }
   octree_ready_ev_.record();            // everything the NEXT step's ray sampling depends on has been issued
   return fr;
 }
@@ -427,7 +471,7 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   Tensor gt = gt_colors.contiguous();
   CheckDev(gt, torch::kFloat32, "gt_colors");
   TORCH_CHECK(gt.numel() == (int64_t) n_rays * 3, "gt_colors must be [n_rays,3]");
-  RenderFront fr = SampleAndFilter(rays_o, rays_d, bounds, emb_idx);
+  RenderFront fr = SampleAndFilter(rays_o, rays_d, bounds, emb_idx, async_count_);
   void* st = CurStream();
   TrainOutputs out;
   out.losses = torch::empty({8}, DevF32());
@@ -441,18 +485,35 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   const int n_kept = fr.n_kept, n_edge = fr.n_edge, n = n_kept + 2 * n_edge;
   TORCH_CHECK(shader->degree_ == 4 && shader->n_hiddens_ == 2, "fused shading needs SH4 + 2 hidden layers");
 
+  // Row layout of the field's arrays: [survivors | edge samples], or -- when the survivor count is still on the device
+  // (fr.dyn: n_kept is then the capacity) -- [edge samples | survivors] so that every offset is known on the host.
+  const int64_t so = fr.dyn ? 2 * (int64_t) n_edge : 0, eo = fr.dyn ? 0 : n_kept;
+  const int32_t* n_dev = fr.dyn ? I32P(fr.n_kept_dev) : nullptr;
   // ---- forward ----
   Tensor feat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32()), field_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
   // the density pre-activations of the surviving samples also leave as a compact array: compositing then reads 4 B per
   // sample instead of one 64-byte line of `feat` per sample, and its backward writes a compact d f0 that the colour
   // backward merges into the dfeat rows it writes anyway (column 0 written in place was a read-modify-write of every line)
   Tensor f0c = torch::empty({std::max(n_kept, 1)}, DevF32()), df0c = torch::empty({std::max(n_kept, 1)}, DevF32());
-  field->ForwardRaw(fr.pts_all, fr.vol_all, 1, fr.src_rows, n_kept, feat, field_x, &f0c);
+  if (fr.dyn) {
+    TORCH_CHECK(field->prepass_x_.defined(), "no pre-pass feature cache for this query");
+    F2N_TIMED_CALL("field_fwd_cached", f2n_field_fwd_cached_dyn(st, n_kept, n_dev, (int) field->prepass_x_.size(0), I32P(fr.src_rows),
+                           VoidP(field->prepass_x_), VoidP(field->mlp_->params_h_), F32P(feat) + F2N_MLP_OUT_PAD * so, F32P(f0c),
+                           static_cast<void*>(field_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * so)));
+    if (n_edge > 0)
+      F2N_TIMED_CALL("field_fwd", f2n_field_fwd(st, 2 * n_edge, field->n_volumes_, VoidP(field->feat_pool_h_), I32P(field->prim_pool_),
+                             I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
+                             F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
+                             F32P(feat), nullptr, VoidP(field_x)));
+  } else {
+    field->ForwardRaw(fr.pts_all, fr.vol_all, 1, fr.src_rows, n_kept, feat, field_x, &f0c);
+  }
   field->prepass_x_ = Tensor();
   Tensor rgb = torch::empty({std::max(n_kept, 1), 3}, DevF32()), shade_x = torch::empty({std::max(n_kept, 1), 32}, DevF16());
   Tensor app = fr.emb ? app_emb_ : Tensor();
-  F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(st, n_kept, F32P(feat), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
-                         fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(rgb), VoidP(shade_x)));
+  F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd_dyn(st, n_kept, n_dev, F32P(feat) + F2N_MLP_OUT_PAD * so, F32P(es.dirs),
+                         fr.emb ? F32P(app) : nullptr, fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_),
+                         F32P(rgb), VoidP(shade_x)));
   Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
   Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({std::max(n_kept, 1)}, DevF32());
   Tensor bg = fr.bg_color.contiguous();
@@ -464,19 +525,28 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   Tensor dfeat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
   Tensor dcolors = torch::empty({n_rays, 3}, DevF32()), ddisp = torch::empty({n_rays}, DevF32()), dvar = torch::empty({n_rays}, DevF32());
   F2N_TIMED_CALL("train_loss", f2n_train_loss(st, n_rays, F32P(colors), F32P(gt), F32P(disparity), F32P(var), n_edge, F2N_MLP_OUT_PAD,
-                          F32P(feat) + (int64_t) F2N_MLP_OUT_PAD * n_kept, var_w, disp_w, tv_w, F32P(out.losses), F32P(dcolors),
-                          F32P(ddisp), F32P(dvar), F32P(dfeat) + (int64_t) F2N_MLP_OUT_PAD * n_kept));
+                          F32P(feat) + F2N_MLP_OUT_PAD * eo, var_w, disp_w, tv_w, F32P(out.losses), F32P(dcolors),
+                          F32P(ddisp), F32P(dvar), F32P(dfeat) + F2N_MLP_OUT_PAD * eo));
 
   // ---- backward ----
   Tensor drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());  // (WeightVarLoss backward rides inside composite_bwd)
   F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb), F32P(bg),
                              F32P(dcolors), F32P(ddisp), nullptr, nullptr, gdp->gradient_scaling_progress_, F32P(drgb),
                              F32P(df0c), 1, F32P(weights), F32P(dvar)));
-  F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd(st, n_kept, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
-                         VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat),
+  F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd_dyn(st, n_kept, n_dev, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
+                         VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat) + F2N_MLP_OUT_PAD * so,
                          F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,
                          fr.emb ? (int) app_emb_grad_.size(0) : 0, F32P(df0c)));
-  field->BackwardRaw(fr.pts_all, fr.vol_all, 1, field_x, dfeat);
+  if (fr.dyn) {
+    field->grad_clean_ = false;
+    F2N_TIMED_CALL("field_bwd", f2n_field_bwd_dyn(st, n, n_dev, 2 * n_edge, field->n_volumes_, I32P(field->prim_pool_),
+                           I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
+                           F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
+                           VoidP(field_x), F32P(dfeat), field->mlp_->loss_scale_, F32P(field->mlp_->grad_scaled_),
+                           VoidP(field->grad_h_), field->pool_size_ / N_LEVELS));
+  } else {
+    field->BackwardRaw(fr.pts_all, fr.vol_all, 1, field_x, dfeat);
+  }
   out.colors = colors;
   out.has_samples = true;
   return out;

@@ -42,6 +42,11 @@ struct RenderFront {
   Tensor bg_color, sample_emb_idx;
   int n_kept = 0, n_edge = 0;
   bool emb = false;
+  // Streaming training steps do not wait for the survivor count: n_kept is then an UPPER BOUND (the marched count, which
+  // sizes every buffer), the true count stays on the device (n_kept_dev, consumed by the f2n_*_dyn entry points) and the edge
+  // samples come FIRST in pts_all / vol_all so that every row offset is known without it.
+  bool dyn = false;
+  Tensor n_kept_dev;
 };
 
 struct TrainOutputs {
@@ -73,7 +78,15 @@ class Renderer : public Pipe {
   std::function<void()> after_octree_update_;  // one-shot: called in SampleAndFilter right after the occupancy update
   PendingSamples pending_samples_;
   Tensor pending_rays_o_, pending_rays_d_;
-  RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
+  RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,
+                              bool async_count = false);
+  // The survivor count of an async SampleAndFilter arrives in pinned memory; the host-side bookkeeping that depends on it
+  // (meaningful-samples EMA, counters) is applied here: at the start of the next step, or by ExpRunner::FinishPending.
+  void ResolvePendingCount();
+  bool async_count_ = false;        // set by ExpRunner::TrainStep for streaming steps
+  bool count_pending_ = false;
+  int pending_count_rays_ = 0;
+  int64_t total_kept_pts_ = 0, total_all_pts_ = 0;  // running totals over training-mode calls (resolved counts only)
   // forward + ExpRunner::Train's loss + backward into the gradient buffers, without the autograd tape
   TrainOutputs TrainForwardBackward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                     const Tensor& emb_idx, float var_w, float disp_w, float tv_w);
@@ -96,7 +109,8 @@ class Renderer : public Pipe {
   bool has_presample_ = false, presample_async_ = false;
   Tensor presample_rays_o_, presample_rays_d_;  // the rays the presample belongs to (held: see PresampleMatches)
   bool PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) const;
-  at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_, n_kept_ev_;
+  at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_, n_kept_ev_, samples_consumed_ev_;
+  bool consumed_side_samples_ = false, side_must_wait_consumed_ = false;
   bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
   Tensor n_kept_host_;  // pinned int32[1]: the surviving-sample count, read back through n_kept_ev_

@@ -228,6 +228,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("cur_batch_size", &ExpRunner::CurBatchSize)
       .def_readwrite("iter_step", &ExpRunner::iter_step_)
       .def_readwrite("check_nan", &ExpRunner::check_nan_)
+      .def_readwrite("async_counts", &ExpRunner::async_counts_)
+      .def("counters",  // running totals over training-mode steps; flushes (the last streaming step's count is still in flight)
+           [](ExpRunner& r) {
+             r.FinishPending();
+             py::dict d;
+             d["total_meaningful"] = r.renderer_->total_kept_pts_;
+             d["total_marched"] = r.renderer_->total_all_pts_;
+             return d;
+           })
       .def_readonly("cur_lr", &ExpRunner::cur_lr_)
       .def_property("n_edge_pts", [](ExpRunner& r) { return r.renderer_->n_edge_pts_; }, [](ExpRunner& r, int n) { r.renderer_->n_edge_pts_ = n; })
       .def_property_readonly("fineness", [](ExpRunner& r) { return r.global_data_pool_->ray_march_fineness_; })

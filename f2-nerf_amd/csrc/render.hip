@@ -40,6 +40,11 @@ __device__ __forceinline__ float f2n_row_exclusive(float incl, float carry, int 
   return c == 0 ? carry : prev;
 }
 
+// Every walk below keeps the NEXT 16-sample chunk's loads in flight while the current chunk goes through its exp /
+// division / scan chain: with 4 rays per wave and the kernel's tail being its longest ray (400 samples on a converged
+// scene = 25 chunks per walk), a load issued where its value is used exposed a full HBM round trip per chunk and walk --
+// that, not arithmetic, was ~80 % of the compositing kernels' time (converged scene: backward 0.16 ms for 2.6e5 samples).
+
 // Renderer.cpp:115-126
 __global__ __launch_bounds__(256) void early_stop_kernel(int n_rays, const int32_t* __restrict__ se, const float* __restrict__ f0,
                                                          int f0_stride, const float* __restrict__ dt, float* __restrict__ weights,
@@ -51,11 +56,23 @@ __global__ __launch_bounds__(256) void early_stop_kernel(int n_rays, const int32
   const int s = se[2 * ray], e = se[2 * ray + 1];
   float acc = 0.f;
   int cnt = 0;
+  float n_f0 = 0.f, n_dt = 0.f;
+  if (s < e) {
+    const int i = min(s + c, e - 1);
+    n_f0 = f0[(size_t) i * f0_stride];
+    n_dt = dt[i];
+  }
   for (int base = s; base < e; base += 16) {
     const int i = base + c;
     const bool in = i < e;
+    const float c_f0 = n_f0, c_dt = n_dt;
+    if (base + 16 < e) {
+      const int j = min(i + 16, e - 1);
+      n_f0 = f0[(size_t) j * f0_stride];
+      n_dt = dt[j];
+    }
     float sec = 0.f;
-    if (in) sec = expf(f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT) * dt[i];
+    if (in) sec = expf(c_f0 - F2N_DENSITY_SHIFT) * c_dt;
     const float alpha = 1.f - expf(-sec);
     const float incl = f2n_row_seq_scan(sec, acc, c);
     const float trans = expf(-f2n_row_exclusive(incl, acc, c));  // exclusive cumulative density
@@ -137,15 +154,34 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const in
   if (ray >= n_rays) return;
   const int s = se[2 * ray], e = se[2 * ray + 1];
   float acc = 0.f, col[3] = {0.f, 0.f, 0.f}, disp = 0.f, dep = 0.f;
+  // WeightVarLoss forward statistics (f2n_wv_stats) ride along in the same walk: same terms, same order
+  const bool with_var = out_vars != nullptr;
+  float wv_m = 0.f, wv_ws = 1e-6f;
+  struct In {
+    float f0, dt, t, c0, c1, c2;
+  };
+  auto fetch = [&](int i) {
+    In r;
+    r.f0 = f0[(size_t) i * f0_stride];
+    r.dt = dt[i];
+    r.t = t[i];
+    r.c0 = rgb[3 * (size_t) i];
+    r.c1 = rgb[3 * (size_t) i + 1];
+    r.c2 = rgb[3 * (size_t) i + 2];
+    return r;
+  };
+  In nxt = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (s < e) nxt = fetch(min(s + c, e - 1));
   for (int base = s; base < e; base += 16) {
     const int i = base + c;
     const bool in = i < e;
+    const In cur = nxt;
+    if (base + 16 < e) nxt = fetch(min(i + 16, e - 1));
     float sec = 0.f, tt = 1.f, cr[3] = {0.f, 0.f, 0.f};
     if (in) {
-      sec = expf(f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT) * dt[i];
-      tt = t[i] + F2N_T_BIAS;
-#pragma unroll
-      for (int k = 0; k < 3; k++) cr[k] = rgb[3 * (size_t) i + k];
+      sec = expf(cur.f0 - F2N_DENSITY_SHIFT) * cur.dt;
+      tt = cur.t + F2N_T_BIAS;
+      cr[0] = cur.c0; cr[1] = cur.c1; cr[2] = cur.c2;
     }
     const float alpha = 1.f - expf(-sec);
     const float incl = f2n_row_seq_scan(sec, acc, c);
@@ -157,6 +193,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const in
     for (int k = 0; k < 3; k++) col[k] = f2n_row_last(f2n_row_seq_scan(w * cr[k], col[k], c));
     disp = f2n_row_last(f2n_row_seq_scan(w / tt, disp, c));
     dep = f2n_row_last(f2n_row_seq_scan(w * tt, dep, c));
+    if (with_var) {
+      wv_m = f2n_row_last(f2n_row_seq_scan(w * ((float) (i - s) / 16.f), wv_m, c));
+      wv_ws = f2n_row_last(f2n_row_seq_scan(w, wv_ws, c));
+    }
   }
   if (c == 0) {
     const float last_trans = expf(-acc);
@@ -165,15 +205,17 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const in
     disparity[ray] = disp;
     depth[ray] = dep / (1.f - last_trans + 1e-4f);
   }
-  if (out_vars != nullptr) {  // WeightVarLoss forward (weight_var_fwd_kernel) on the weights this row has just written
+  if (with_var) {  // WeightVarLoss forward (weight_var_fwd_kernel): second walk over the weights this row has just written
     float var = 0.f;
     if (s < e) {
-      float mean, ws;
-      f2n_wv_stats(weights + s, e - s, c, mean, ws);
+      const float mean = wv_m / wv_ws;
+      float n_w = weights[min(s + c, e - 1)];
       for (int base = 0; base + s < e; base += 16) {
         const int i = base + c;
+        const float c_w = n_w;
+        if (base + 16 + s < e) n_w = weights[min(i + 16 + s, e - 1)];
         const float b = (float) i / 16.f - mean;
-        const float wi = i + s < e ? weights[i + s] : 0.f;
+        const float wi = i + s < e ? c_w : 0.f;
         var = f2n_row_last(f2n_row_seq_scan(wi * b * b, var, c));
       }
     }
@@ -201,20 +243,42 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
   if (dcolors != nullptr) { dC[0] = dcolors[3 * ray]; dC[1] = dcolors[3 * ray + 1]; dC[2] = dcolors[3 * ray + 2]; }
   const float dDisp = ddisparity != nullptr ? ddisparity[ray] : 0.f;
   const float dDep = ddepth != nullptr ? ddepth[ray] : 0.f;
-  // walk 1: totals
-  float acc = 0.f, dep_sum = 0.f;
-  for (int base = s; base < e; base += 16) {
-    const int i = base + c;
-    const bool in = i < e;
-    float sec = 0.f, tt = 1.f;
-    if (in) {
-      sec = expf(f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT) * dt[i];
-      tt = t[i] + F2N_T_BIAS;
+  const bool with_var = var_weights != nullptr && dvars != nullptr;
+  // walk 1: totals (cumulative density, depth numerator) and, in the same walk, the WeightVarLoss statistics (f2n_wv_stats)
+  float acc = 0.f, dep_sum = 0.f, wv_m = 0.f, wv_ws = 1e-6f;
+  {
+    struct In {
+      float f0, dt, t, vw;
+    };
+    auto fetch = [&](int i) {
+      In r;
+      r.f0 = f0[(size_t) i * f0_stride];
+      r.dt = dt[i];
+      r.t = t[i];
+      r.vw = with_var ? var_weights[i] : 0.f;
+      return r;
+    };
+    In nxt = fetch(min(s + c, e - 1));
+    for (int base = s; base < e; base += 16) {
+      const int i = base + c;
+      const bool in = i < e;
+      const In cur = nxt;
+      if (base + 16 < e) nxt = fetch(min(i + 16, e - 1));
+      float sec = 0.f, tt = 1.f;
+      if (in) {
+        sec = expf(cur.f0 - F2N_DENSITY_SHIFT) * cur.dt;
+        tt = cur.t + F2N_T_BIAS;
+      }
+      const float incl = f2n_row_seq_scan(sec, acc, c);
+      const float w = in ? expf(-f2n_row_exclusive(incl, acc, c)) * (1.f - expf(-sec)) : 0.f;
+      acc = f2n_row_last(incl);
+      dep_sum = f2n_row_last(f2n_row_seq_scan(w * tt, dep_sum, c));
+      if (with_var) {
+        const float wi = in ? cur.vw : 0.f;
+        wv_m = f2n_row_last(f2n_row_seq_scan(wi * ((float) (i - s) / 16.f), wv_m, c));
+        wv_ws = f2n_row_last(f2n_row_seq_scan(wi, wv_ws, c));
+      }
     }
-    const float incl = f2n_row_seq_scan(sec, acc, c);
-    const float w = in ? expf(-f2n_row_exclusive(incl, acc, c)) * (1.f - expf(-sec)) : 0.f;
-    acc = f2n_row_last(incl);
-    dep_sum = f2n_row_last(f2n_row_seq_scan(w * tt, dep_sum, c));
   }
   const float total = acc;
   const float last_trans = expf(-total);
@@ -225,31 +289,50 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
   const float d_total = -last_trans * d_last;  // last_trans = exp(-sum sec): every sec_i receives this
   const float dDepW = dDep / denom;
   // WeightVarLoss backward (weight_var_bwd_kernel) folded in: d var / d w_i = dv * (b_i^2 - tmp * (i/16) / ws)
-  float wv_mean = 0.f, wv_ws = 1.f, wv_tmp = 0.f, wv_dv = 0.f;
-  const bool with_var = var_weights != nullptr && dvars != nullptr;
+  float wv_mean = 0.f, wv_tmp = 0.f, wv_dv = 0.f;
   if (with_var) {
-    f2n_wv_stats(var_weights + s, e - s, c, wv_mean, wv_ws);
+    wv_mean = wv_m / wv_ws;
+    float n_w = var_weights[min(s + c, e - 1)];
     for (int base = 0; base + s < e; base += 16) {
       const int i = base + c;
+      const float c_w = n_w;
+      if (base + 16 + s < e) n_w = var_weights[min(i + 16 + s, e - 1)];
       const float b = (float) i / 16.f - wv_mean;
-      const float wi = i + s < e ? var_weights[i + s] : 0.f;
+      const float wi = i + s < e ? c_w : 0.f;
       wv_tmp = f2n_row_last(f2n_row_seq_scan(wi * 2.f * b, wv_tmp, c));
     }
     wv_dv = dvars[ray];
   }
   // walk 2: reverse, suffix carries sum_{j>i} d(acc_j)
+  struct RIn {
+    float f0, dt, t, c0, c1, c2, dw;
+  };
+  auto rfetch = [&](int i) {
+    RIn r;
+    r.f0 = f0[(size_t) i * f0_stride];
+    r.dt = dt[i];
+    r.t = t[i];
+    r.c0 = rgb[3 * (size_t) i];
+    r.c1 = rgb[3 * (size_t) i + 1];
+    r.c2 = rgb[3 * (size_t) i + 2];
+    r.dw = dweights != nullptr ? dweights[i] : 0.f;
+    return r;
+  };
   float suffix = 0.f;
+  RIn rn = rfetch(max(e - 1 - c, s));
   for (int hi = e; hi > s; hi -= 16) {
     const int i = hi - 1 - c;
     const bool in = i >= s;
+    const RIn rc = rn;
+    if (hi - 16 > s) rn = rfetch(max(i - 16, s));
     float x = 0.f, dti = 0.f, sigma = 0.f, tt = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dwi = 0.f;
     if (in) {
-      x = f0[(size_t) i * f0_stride] - F2N_DENSITY_SHIFT;
+      x = rc.f0 - F2N_DENSITY_SHIFT;
       sigma = expf(x);
-      dti = dt[i];
-      tt = t[i] + F2N_T_BIAS;
-      c0 = rgb[3 * (size_t) i]; c1 = rgb[3 * (size_t) i + 1]; c2 = rgb[3 * (size_t) i + 2];
-      if (dweights != nullptr) dwi = dweights[i];
+      dti = rc.dt;
+      tt = rc.t + F2N_T_BIAS;
+      c0 = rc.c0; c1 = rc.c1; c2 = rc.c2;
+      dwi = rc.dw;
     }
     const float sec = in ? sigma * dti : 0.f;
     // acc -= sec, rebuilt backwards: the exclusive cumulative density of sample i

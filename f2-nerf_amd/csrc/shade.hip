@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(int n, const float* __re
                                                         const float* __restrict__ app_emb,
                                                         const int32_t* __restrict__ sample_emb_idx,
                                                         const half_t* __restrict__ params, float* __restrict__ rgb,
-                                                        half_t* __restrict__ save_x) {
+                                                        half_t* __restrict__ save_x, const int32_t* __restrict__ n_dev) {
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  if (n_dev != nullptr) n = min(n, *n_dev);  // the sample count is still on the device (see f2n_shade_fwd_dyn)
   F2nMlpFwdW<2> w;
   w.load(params, c, g);
   const int n_blocks = (n + 15) / 16;
@@ -114,7 +115,9 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
                                                         const half_t* __restrict__ params, const half_t* __restrict__ x_h,
                                                         float loss_scale, float* __restrict__ dfeat,
                                                         float* __restrict__ dparams, int n_emb,
-                                                        float* __restrict__ emb_partials, const float* __restrict__ df0) {
+                                                        float* __restrict__ emb_partials, const float* __restrict__ df0,
+                                                        const int32_t* __restrict__ n_dev) {
+  if (n_dev != nullptr) n = min(n, *n_dev);
   __shared__ F2nShadeSmem sm;
   extern __shared__ float s_emb[];  // [n_emb * 16] per-block appearance-embedding gradient (ds_add_f32)
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -268,16 +271,30 @@ int f2n_scatter_idx(void* stream, int n_rays, const int32_t* start_end, const in
 
 int f2n_shade_fwd(void* stream, int n, const float* feat, const float* dirs, const float* app_emb,
                   const int32_t* sample_emb_idx, const void* mlp_params_h, float* rgb, void* save_x_h) {
+  return f2n_shade_fwd_dyn(stream, n, nullptr, feat, dirs, app_emb, sample_emb_idx, mlp_params_h, rgb, save_x_h);
+}
+
+int f2n_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* feat, const float* dirs, const float* app_emb,
+                      const int32_t* sample_emb_idx, const void* mlp_params_h, float* rgb, void* save_x_h) {
+  const int n = n_max;
   if (n < 0 || (app_emb != nullptr && sample_emb_idx == nullptr)) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
   hipLaunchKernelGGL(shade_fwd_kernel, dim3(f2n_shade_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, feat,
-                     dirs, app_emb, sample_emb_idx, (const half_t*) mlp_params_h, rgb, (half_t*) save_x_h);
+                     dirs, app_emb, sample_emb_idx, (const half_t*) mlp_params_h, rgb, (half_t*) save_x_h, n_dev);
   return f2n_launch_status();
 }
 
 int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
                   const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled, float* dapp_emb,
                   int n_emb, const float* df0) {
+  return f2n_shade_bwd_dyn(stream, n, nullptr, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_f32_scaled,
+                           dapp_emb, n_emb, df0);
+}
+
+int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* drgb, const int32_t* sample_emb_idx,
+                      const void* mlp_params_h, const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled,
+                      float* dapp_emb, int n_emb, const float* df0) {
+  const int n = n_max;
   if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1)) || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
   if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 57 KB of weights / reduction images
@@ -303,7 +320,8 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
     }
   }
   hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(256), dyn_lds, (hipStream_t) stream, n, drgb, sample_emb_idx,
-                     (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat, partials, n_emb, emb_partials, df0);
+                     (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat, partials, n_emb, emb_partials, df0,
+                     n_dev);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   rc = f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);

@@ -294,6 +294,27 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
                   float* dapp_emb /*[n_emb,16] or NULL*/, int n_emb, const float* df0 /*[n] or NULL*/);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Device-side sample counts (ABI v6).  Renderer::Render learns the number of samples that survive the early stop from a
+ * blocking read-back (Renderer.cpp:128-135: boolean-mask indexing) and only then launches the grad pass.  The _dyn entry
+ * points take the count where it is produced: n_dev points at a DEVICE int32 (the `total` of f2n_segment_scan); the kernels
+ * process min(n_max, *n_dev + n_off) rows, n_max sizes grids / workspaces / plane strides (buffers must hold n_max rows).
+ * The host can therefore queue a whole training step without waiting for the device.  n_dev == NULL: exactly the plain
+ * entry point with n = n_max.  Results for the rows processed are identical to the plain calls.
+ * ------------------------------------------------------------------------------------------------- */
+int f2n_field_fwd_cached_dyn(void* stream, int n_max, const int32_t* n_dev, int n_cache, const int32_t* src_rows,
+                             const void* x_cache_h, const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h);
+int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, int n_volumes, const int32_t* prim_pool,
+                      const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                      const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
+                      const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h,
+                      int level_entries);
+int f2n_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* feat, const float* dirs, const float* app_emb,
+                      const int32_t* sample_emb_idx, const void* mlp_params_h, float* rgb, void* save_x_h);
+int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* drgb, const int32_t* sample_emb_idx,
+                      const void* mlp_params_h, const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled,
+                      float* dapp_emb, int n_emb, const float* df0);
+
+/* ---------------------------------------------------------------------------------------------------
  * Renderer -- replaces the per-ray glue of Renderer::Render (Renderer/Renderer.cpp:105-208), i.e.
  * TruncExp (CustomOps.cpp:9-18), FlexOps::Sum/AccumulateSum (FlexOps.cu:5-93), CountValidPts /
  * FilterIdxBounds (Renderer.cu:8-50), GradientScaling (CustomOps.cu:68-80).  One sequential left-to-right

@@ -340,10 +340,52 @@ def test_data_parallel_hooks_on_one_gpu(rt, fox_state):
         for a, b in zip(outs[0][1], other[1]):
             assert a.shape == b.shape
             if a.dtype.is_floating_point:
-                # the hash table's fp64 LDS accumulation order is not deterministic: compare closely instead of bitwise
-                assert float((a.float() - b.float()).abs().max()) <= 1e-4 * max(float(a.float().abs().max()), 1e-6)
+                # The hash table's fp64 LDS accumulation order is not deterministic, and a streaming step lays its rows out
+                # differently (edge samples first), which shifts the 16-sample rows the scatter combines runs in: individual
+                # f16 records round differently, and for entries whose gradient sits at the f16 underflow boundary Adam (eps
+                # 1e-15) turns "zero or not" into a full lr-sized step.  Compare closely instead of bitwise.
+                d = (a.float() - b.float()).abs()
+                assert float(d.max()) <= 2e-3 * max(float(a.float().abs().max()), 1e-6)
+                assert float(d.mean()) <= 2e-6 * max(float(a.float().abs().max()), 1e-6)
             else:
                 assert (a == b).all()
+
+
+def test_streaming_step_equals_synchronous_step(rt, fox_state):
+    """A streaming training step keeps the survivor count on the device (f2n_*_dyn entry points: buffers sized for the
+    marched count, edge samples first, no host read-back in the middle of the iteration).  Same state, same explicit
+    draws: loss, colours and gradients must equal those of the synchronous step (the reference's order of operations)."""
+    st = fox_state
+    rng = np.random.default_rng(61)
+    R, NE = 1024, 512
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    gt = rng.random((R, 3), dtype=F32)
+    noise = (((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(8.)).astype(F32)
+    bg = rng.random((R, 3), dtype=F32)
+    eidx = rng.integers(0, st["edge_pool"].size // 64, NE).astype(np.int32)
+    ecoord = (rng.random((NE, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32)
+    d = rt.to_dev(ro, rd, bounds, gt, cam, noise, bg, eidx, ecoord)
+    res = []
+    for mode in (0, 2):  # 0: read the count back (as Render does); 2: never
+        runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=16"], seed=21, table_init=2.0)
+        runner.n_edge_pts = NE
+        runner.async_counts = mode
+        runner.iter_step = 1
+        runner.update_ada_params()
+        runner.set_forced_randoms(d[5], d[6], d[7], d[8])
+        runner.zero_grad()
+        stats = runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
+        g = {k: v.cpu().numpy().copy() for k, v in runner.grads().items()}
+        c = runner.counters()
+        res.append((float(stats["loss"]), stats["n_samples"], c["total_meaningful"], g))
+    (l0, n0, m0, g0), (l1, n1, m1, g1) = res
+    assert n0 == n1 and m0 == m1 and n0 > m0 > 32768  # early stop did something; the binned scatter is in play
+    assert l0 == l1
+    for k in ("color_mlp", "field_mlp", "app_emb"):
+        assert rel_err(g1[k], g0[k]) <= 2e-3, (k, rel_err(g1[k], g0[k]))  # (per-block partial sums see the rows in another order)
+    a, b = g0["feat_pool"].reshape(-1).astype(np.float64), g1["feat_pool"].reshape(-1).astype(np.float64)
+    assert float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999999
+    assert np.abs(a - b).max() <= 2.0 ** -9 * np.abs(a).max()
 
 
 def test_prefetched_sampling_is_not_used_by_a_render(rt, fox_state):

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Brings the fox scene to its converged state (ExpRunner::Train for --iters iterations on the committed photographs) and
+then runs --steps more training steps on pre-drawn batches after a 0.3 s pause -- the pause is the marker by which
+profiles/timeline_rocpd.py finds those steps inside a rocprofv3 --kernel-trace of this script.  Measurement aid."""
+import argparse, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import f2_nerf_amd  # noqa: F401
+from f2_nerf_amd import runtime, fox_data
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=20000)
+ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--factor", type=int, default=2)
+ap.add_argument("--overrides", nargs="*", default=[])
+args = ap.parse_args()
+st = fox_data.load_state()
+sc, images = fox_data.scene(args.factor)
+ds = runtime.make_dataset(sc, images)
+runner, cfg, _ = runtime.make_runner(st, "wanjinyou", ["train.end_iter=%d" % max(args.iters, 1)] + args.overrides, seed=2022)
+torch.manual_seed(2022)
+if args.iters > 0:
+    runner.train(ds, args.iters, 1)
+R = max(16, runner.cur_batch_size())
+batches = [ds.rand_rays_data(R, 1) for _ in range(8)]
+def step(i):
+    b, nb = batches[i % 8], batches[(i + 1) % 8]
+    return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+for i in range(6):
+    step(i)
+c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)
+t0 = time.perf_counter()
+for i in range(args.steps):
+    s = step(6 + i)
+runner.flush(); torch.cuda.synchronize()
+el = time.perf_counter() - t0
+c1 = runner.counters()
+print("rays %d  %.3f ms/step  marched/step %d meaningful/step %d nodes %d" % (R, el / args.steps * 1e3, (c1["total_marched"] - c0["total_marched"]) // args.steps,
+      (c1["total_meaningful"] - c0["total_meaningful"]) // args.steps, runner.n_nodes()))
