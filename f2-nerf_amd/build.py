@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libf2n_hip.so")
 OBJ = os.path.join(HERE, "build")
 
-HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip", "workspace.hip", "dataset.hip"]
+HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip", "workspace.hip", "dataset.hip", "octree.hip"]
 HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", os.path.join(INCLUDE, "f2n_abi.h")]
 # (-mllvm -amdgpu-mfma-vgpr-form=1 was tried: a third fewer instructions in the MLP backward kernels -- no
 # v_accvgpr_read of every MFMA result -- but 15 % SLOWER: those kernels are bound by dependency latency, not issue.)

@@ -1,5 +1,5 @@
 // PersSampler host logic: orchestration of the sampler kernels through the C-ABI, occupancy bookkeeping and
-// the host-side octree maintenance.  Behaviour follows src/PtsSampler/PersSampler.cu:317-615 and
+// the octree maintenance (on the device: csrc/octree.hip).  Behaviour follows src/PtsSampler/PersSampler.cu:317-615 and
 // src/PtsSampler/PersSampler.cpp:120-330,664-733 of the reference (cited inline); the control flow does not:
 // leaf-hit storage is a persistent worst-case workspace, segments are laid out in ray order by a device-side
 // scan, and the only host read-back of a GetSamples call is the pair (K, N) at its very end.
@@ -44,14 +44,8 @@ PersSampler::PersSampler(GlobalDataPool* global_data_pool) {
   pers_octree_->node_search_order_ = BuildSearchOrder();
 }
 
-void PersOctree::UploadNodes() {
-  tree_nodes_gpu_ = torch::from_blob(tree_nodes_.data(), {int64_t(tree_nodes_.size() * sizeof(TreeNode))}, CpuU8())
-                        .to(torch::kCUDA).contiguous();
-  RebuildChildBlocks();
-}
-
 void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of the tree (f2n_oct_build_child_blocks)
-  const int n = (int) tree_nodes_.size();
+  const int n = n_nodes_;
   child_blocks_gpu_ = torch::empty({int64_t(n) * 8 * 32}, torch::TensorOptions().dtype(torch::kUInt8).device(torch::kCUDA));
   F2N_CALL(f2n_oct_build_child_blocks(CurStream(), n, VoidP(tree_nodes_gpu_), VoidP(child_blocks_gpu_)));
 }
@@ -173,7 +167,7 @@ std::tuple<Tensor, Tensor> PersSampler::GetEdgeSamples(int n_pts) {
 void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weight,
                                  const Tensor& sampled_alpha) {
   auto& oct = *pers_octree_;
-  const int n_nodes = oct.tree_nodes_.size();
+  const int n_nodes = oct.n_nodes_;
   const int n_rays = sample_result.pts_idx_bounds.size(0);
   CheckDev(sampled_weight, torch::kFloat32, "sampled_weight");
   CheckDev(sampled_alpha, torch::kFloat32, "sampled_alpha");
@@ -213,140 +207,52 @@ void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Te
 
 void PersOctree::MarkInvisibleNodes() {  // PersSampler.cu:663-680
   TORCH_CHECK(w2c_.defined(), "training cameras not set: call SetTrainCameras");
-  F2N_CALL(f2n_oct_mark_invisible(CurStream(), (int) tree_nodes_.size(), (int) intri_.size(0), VoidP(tree_nodes_gpu_),
+  F2N_CALL(f2n_oct_mark_invisible(CurStream(), n_nodes_, (int) intri_.size(0), VoidP(tree_nodes_gpu_),
                                   F32P(intri_), F32P(w2c_), F32P(bound_)));
   RebuildChildBlocks();  // trans_idx of invisible leaves changed on the device
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ProcOctree, PersSampler.cpp:120-330: compaction of dead leaves, path compression, subdivision of visited
-// leaves.  Host code over a D2H copy of the node array, as in the reference.
+// ProcOctree, PersSampler.cpp:120-330: pruning of dead leaves, path compression, renumbering, subdivision of visited
+// leaves -- on the device (csrc/octree.hip), where the reference copies the node array to the host and back.  The only
+// host involvement left is reading the two new node counts (to size the new arrays).
 // ---------------------------------------------------------------------------------------------------------
 void PersOctree::ProcOctree(bool compact, bool subdivide, bool brute_force) {
-  Tensor nodes_cpu = tree_nodes_gpu_.to(torch::kCPU).contiguous();
-  Tensor w_cpu = tree_weight_stats_.to(torch::kCPU).contiguous();
-  Tensor a_cpu = tree_alpha_stats_.to(torch::kCPU).contiguous();
-  Tensor v_cpu = tree_visit_cnt_.to(torch::kCPU).contiguous();
-  const int n_before = (int) tree_nodes_.size();
-  std::vector<TreeNode> nb(n_before);
-  std::memcpy((void*) nb.data(), nodes_cpu.data_ptr(), size_t(n_before) * sizeof(TreeNode));
-  const int* w_before = w_cpu.data_ptr<int>();
-  const int* a_before = a_cpu.data_ptr<int>();
-  const int* visit_cnt = v_cpu.data_ptr<int>();
-
-  while (compact) {
-    for (int u = 0; u < n_before; u++) {
-      if (!nb[u].is_leaf_node) continue;
-      if (nb[u].trans_idx < 0 && nb[u].parent >= 0) {
-        int v = nb[u].parent;
-        for (int st = 0; st < 8; st++)
-          if (nb[v].childs[st] == u) nb[v].childs[st] = -1;
-      }
-    }
-    bool update_flag = false;
-    for (int u = 1; u < n_before; u++) {  // the root can not become a leaf
-      bool has_valid = false;
-      for (int st = 0; st < 8; st++)
-        if (nb[u].childs[st] >= 0) { has_valid = true; break; }
-      if (!has_valid) {
-        if (!nb[u].is_leaf_node) update_flag = true;
-        nb[u].is_leaf_node = true;
-      }
-    }
-    if (!update_flag) break;
+  TORCH_CHECK(compact, "ProcOctree without compaction is not used by the sampler (PersSampler.cu:605-614)");
+  torch::NoGradGuard no_grad;
+  void* st = CurStream();
+  const int n = n_nodes_;
+  auto u8 = [](int64_t bytes) { return torch::empty({bytes}, DevU8()); };
+  auto i32 = [](int64_t k) { return torch::empty({k}, DevI32()); };
+  Tensor w = tree_weight_stats_.contiguous(), a = tree_alpha_stats_.contiguous(), v = tree_visit_cnt_.contiguous();
+  Tensor work = u8(int64_t(n) * sizeof(TreeNode)), edited = u8(int64_t(n) * sizeof(TreeNode));
+  Tensor alive = i32(n), n_child = i32(n), keep = i32(n), new_pos = torch::empty({n, 2}, DevI32()), total = i32(1);
+  F2N_CALL(f2n_oct_prune_compress(st, n, VoidP(tree_nodes_gpu_), VoidP(work), VoidP(edited), I32P(alive), I32P(n_child), I32P(keep)));
+  F2N_CALL(f2n_segment_scan(st, n, I32P(keep), I32P(new_pos), I32P(total)));
+  const int m = total.item<int>();
+  TORCH_CHECK(m >= 1, "octree root was removed");
+  Tensor k_nodes = u8(int64_t(m) * sizeof(TreeNode)), k_w = i32(m), k_a = i32(m), k_v = i32(m);
+  F2N_CALL(f2n_oct_gather_kept(st, n, VoidP(edited), I32P(keep), I32P(new_pos), I32P(w), I32P(a), I32P(v), VoidP(k_nodes), I32P(k_w),
+                               I32P(k_a), I32P(k_v)));
+  if (!subdivide) {
+    tree_nodes_gpu_ = k_nodes;
+    tree_weight_stats_ = k_w;
+    tree_alpha_stats_ = k_a;
+    n_nodes_ = m;
+  } else {
+    Tensor depth = i32(m), size = i32(m), new_idx = i32(m);
+    F2N_CALL(f2n_oct_subtree_sizes(st, m, VoidP(k_nodes), I32P(k_v), brute_force ? 1 : 0, I32P(depth), I32P(size)));
+    const int m2 = size.slice(0, 0, 1).item<int>();
+    Tensor d_nodes = u8(int64_t(m2) * sizeof(TreeNode)), d_w = i32(m2), d_a = i32(m2);
+    F2N_CALL(f2n_oct_subdivide(st, m, VoidP(k_nodes), I32P(k_v), brute_force ? 1 : 0, I32P(size), I32P(k_w), I32P(k_a), I32P(new_idx),
+                               VoidP(d_nodes), I32P(d_w), I32P(d_a)));
+    tree_nodes_gpu_ = d_nodes;
+    tree_weight_stats_ = d_w;
+    tree_alpha_stats_ = d_a;
+    n_nodes_ = m2;
   }
-  if (compact) {  // splice out chains of single-child interior nodes
-    auto single_child = [&nb](int u) {
-      int cnt = 0, ret = -1;
-      for (int i = 0; i < 8; i++)
-        if (nb[u].childs[i] >= 0) { ret = i; cnt++; }
-      return cnt == 1 ? ret : -1;
-    };
-    for (int u = 0; u < n_before; u++) {
-      if (nb[u].is_leaf_node && nb[u].trans_idx < 0) continue;
-      int v = nb[u].parent;
-      while (v >= 0 && nb[v].parent >= 0 && single_child(v) >= 0) {
-        int vv = nb[v].parent;
-        for (int i = 0; i < 8; i++)
-          if (nb[vv].childs[i] == v) nb[vv].childs[i] = u;
-        nb[u].parent = vv;
-        nb[v].trans_idx = -1;
-        nb[v].is_leaf_node = true;  // flagged for removal
-        v = vv;
-      }
-    }
-  }
-  std::vector<int> new_idx(n_before, -1), inv_idx;
-  int n_kept = 0;
-  for (int u = 0; u < n_before; u++) {
-    if (!nb[u].is_leaf_node || nb[u].trans_idx >= 0) {
-      new_idx[u] = n_kept++;
-      inv_idx.push_back(u);
-    }
-  }
-  TORCH_CHECK(new_idx[0] == 0, "octree root was removed");
-  std::vector<TreeNode> new_nodes;
-  std::vector<int> new_w, new_a;
-  for (int u = 0; u < n_before; u++) {
-    if (new_idx[u] < 0) continue;
-    TreeNode node = nb[u];
-    if (node.parent >= 0) node.parent = new_idx[node.parent];
-    for (int st = 0; st < 8; st++)
-      if (node.childs[st] >= 0) node.childs[st] = new_idx[node.childs[st]];
-    new_nodes.push_back(node);
-    new_w.push_back(w_before[u]);
-    new_a.push_back(a_before[u]);
-  }
-  if (subdivide) {
-    std::vector<TreeNode> wp = std::move(new_nodes);
-    std::vector<int> wwp = std::move(new_w), awp = std::move(new_a);
-    new_nodes.clear(); new_w.clear(); new_a.clear();
-    std::function<int(int, int)> rec = [&](int u, int pa) -> int {
-      int new_u = (int) new_nodes.size();
-      new_nodes.push_back(wp[u]);
-      new_w.push_back(wwp[u]);
-      new_a.push_back(awp[u]);
-      new_nodes[new_u].parent = pa;
-      if (wp[u].is_leaf_node) {
-        if (!brute_force && visit_cnt[inv_idx[u]] <= 4) return new_u;
-        for (int st = 0; st < 8; st++) {
-          const float off[3] = {float((st >> 2) & 1) - .5f, float((st >> 1) & 1) - .5f, float(st & 1) - .5f};
-          int v = (int) new_nodes.size();
-          new_nodes.emplace_back();
-          TreeNode& ch = new_nodes[v];
-          TreeNode& pr = new_nodes[new_u];
-          pr.childs[st] = v;
-          for (int k = 0; k < 3; k++) ch.center[k] = pr.center[k] + pr.side_len * .5f * off[k];
-          ch.side_len = pr.side_len * .5f;
-          ch.parent = new_u;
-          for (int k = 0; k < 8; k++) ch.childs[k] = -1;
-          ch.is_leaf_node = true;
-          ch.trans_idx = pr.trans_idx;  // children inherit the parent's warp
-          new_w.push_back(new_w[new_u]);
-          new_a.push_back(new_a[new_u]);
-        }
-        new_nodes[new_u].is_leaf_node = false;
-        new_nodes[new_u].trans_idx = -1;
-        new_w[new_u] = INIT_NODE_STAT;
-        new_a[new_u] = INIT_NODE_STAT;
-      } else {
-        for (int st = 0; st < 8; st++) {
-          if (new_nodes[new_u].childs[st] >= 0) {
-            int v = rec(new_nodes[new_u].childs[st], new_u);
-            new_nodes[new_u].childs[st] = v;
-          }
-        }
-      }
-      return new_u;
-    };
-    rec(0, -1);
-  }
-  tree_nodes_ = std::move(new_nodes);
-  UploadNodes();
-  const int64_t n = (int64_t) tree_nodes_.size();
-  tree_weight_stats_ = torch::from_blob(new_w.data(), {n}, CpuI32()).to(torch::kCUDA).contiguous();
-  tree_alpha_stats_ = torch::from_blob(new_a.data(), {n}, CpuI32()).to(torch::kCUDA).contiguous();
-  tree_visit_cnt_ = torch::zeros({n}, DevI32());
+  tree_visit_cnt_ = torch::zeros({n_nodes_}, DevI32());
+  RebuildChildBlocks();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -369,12 +275,10 @@ int PersSampler::LoadStates(const std::vector<Tensor>& states, int idx) {
   Tensor milestones = states[idx++].clone().to(torch::kCPU).to(torch::kInt32).contiguous();
   TORCH_CHECK(oct.tree_nodes_gpu_.numel() % sizeof(TreeNode) == 0 && oct.pers_trans_gpu_.numel() % sizeof(TransInfo) == 0,
               "state blobs do not match the TreeNode/TransInfo layout");
-  Tensor nodes_cpu = oct.tree_nodes_gpu_.to(torch::kCPU);
-  oct.tree_nodes_.resize(nodes_cpu.numel() / sizeof(TreeNode));
-  std::memcpy((void*) oct.tree_nodes_.data(), nodes_cpu.data_ptr(), nodes_cpu.numel());
+  oct.n_nodes_ = int(oct.tree_nodes_gpu_.numel() / sizeof(TreeNode));
   sub_div_milestones_.resize(milestones.numel());
   std::memcpy(sub_div_milestones_.data(), milestones.data_ptr(), milestones.numel() * sizeof(int));
-  const int64_t n = (int64_t) oct.tree_nodes_.size();
+  const int64_t n = oct.n_nodes_;
   TORCH_CHECK(oct.tree_visit_cnt_.numel() == n, "visit_cnt size mismatch");
   oct.tree_weight_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());  // stats are NOT checkpointed (:721-722)
   oct.tree_alpha_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());
@@ -389,15 +293,14 @@ void PersSampler::InstallOctree(const Tensor& tree_nodes_bytes, const Tensor& pe
   auto& oct = *pers_octree_;
   TORCH_CHECK(tree_nodes_bytes.numel() % sizeof(TreeNode) == 0 && pers_trans_bytes.numel() % sizeof(TransInfo) == 0,
               "blobs do not match the TreeNode/TransInfo layout");
-  Tensor nodes_cpu = tree_nodes_bytes.to(torch::kCPU).to(torch::kUInt8).contiguous();
-  oct.tree_nodes_.resize(nodes_cpu.numel() / sizeof(TreeNode));
-  std::memcpy((void*) oct.tree_nodes_.data(), nodes_cpu.data_ptr(), nodes_cpu.numel());
+  oct.tree_nodes_gpu_ = tree_nodes_bytes.clone().to(torch::kCUDA).to(torch::kUInt8).contiguous();
+  oct.n_nodes_ = int(oct.tree_nodes_gpu_.numel() / sizeof(TreeNode));
   oct.pers_trans_gpu_ = pers_trans_bytes.clone().to(torch::kCUDA).to(torch::kUInt8).contiguous();
-  const int64_t n = (int64_t) oct.tree_nodes_.size();
+  const int64_t n = oct.n_nodes_;
   oct.tree_visit_cnt_ = torch::zeros({n}, DevI32());
   oct.tree_weight_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());
   oct.tree_alpha_stats_ = torch::full({n}, INIT_NODE_STAT, DevI32());
-  oct.UploadNodes();
+  oct.RebuildChildBlocks();
   TORCH_CHECK(global_data_pool_->n_volumes_ == int(oct.pers_trans_gpu_.numel() / sizeof(TransInfo)),
               "the octree has ", oct.pers_trans_gpu_.numel() / sizeof(TransInfo), " warps but the field was built for ",
               global_data_pool_->n_volumes_, " (runtime.n_volumes)");

@@ -1,6 +1,6 @@
-// PersSampler / PersOctree host side (mirrors src/PtsSampler/PersSampler.h).  Kernels: csrc/sampler.hip via
-// the C-ABI.  The octree is created from a serialised state (the reference's checkpoint byte layout); the
-// per-milestone maintenance (ProcOctree) is host code as in the reference.
+// PersSampler / PersOctree host side (mirrors src/PtsSampler/PersSampler.h).  Kernels: csrc/sampler.hip and
+// csrc/octree.hip via the C-ABI.  The octree is created from a serialised state (the reference's checkpoint byte layout)
+// or built from the cameras (OctreeBuilder.cpp); the per-milestone maintenance (ProcOctree) runs on the device.
 #pragma once
 #include <functional>
 
@@ -46,12 +46,11 @@ class PersOctree {
  public:
   void ProcOctree(bool compact, bool subdivide, bool brute_force);
   void MarkInvisibleNodes();
-  void UploadNodes();
   void RebuildChildBlocks();
 
   Tensor w2c_, intri_, bound_;  // training cameras, for MarkInvisibleNodes
-  std::vector<TreeNode> tree_nodes_;
-  Tensor tree_nodes_gpu_;
+  int n_nodes_ = 0;
+  Tensor tree_nodes_gpu_;  // TreeNode[n_nodes_], the reference's checkpoint bytes; lives (and is maintained) on the device
   Tensor child_blocks_gpu_;  // [n_nodes][8] x 32 B, derived from tree_nodes_gpu_ (f2n_oct_build_child_blocks)
   Tensor tree_weight_stats_, tree_alpha_stats_, tree_visit_cnt_;
   Tensor occ_;  // [4, n_nodes] weight votes, alpha votes, visited marks, visit counts (tree_visit_cnt_ is its last row)

@@ -222,7 +222,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              SamplerOf(r)->forced_noise_ = Tensor(); r.renderer_->forced_bg_ = Tensor();
              SamplerOf(r)->forced_edge_idx_ = Tensor(); SamplerOf(r)->forced_edge_coords_ = Tensor();
            })
-      .def("n_nodes", [](ExpRunner& r) { return (int) SamplerOf(r)->pers_octree_->tree_nodes_.size(); })
+      .def("n_nodes", [](ExpRunner& r) { return SamplerOf(r)->pers_octree_->n_nodes_; })
       .def("proc_octree", [](ExpRunner& r, bool compact, bool subdivide, bool brute) { SamplerOf(r)->pers_octree_->ProcOctree(compact, subdivide, brute); })
       .def("tree_nodes", [](ExpRunner& r) { return SamplerOf(r)->pers_octree_->tree_nodes_gpu_; })
       .def("cur_batch_size", &ExpRunner::CurBatchSize)

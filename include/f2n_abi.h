@@ -294,6 +294,29 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
                   float* dapp_emb /*[n_emb,16] or NULL*/, int n_emb, const float* df0 /*[n] or NULL*/);
 
 /* ---------------------------------------------------------------------------------------------------
+ * PersOctree::ProcOctree on the device (PtsSampler/PersSampler.cpp:120-330; ABI v6): the reference copies the node array
+ * to the host, edits it with index-ordered loops and copies it back; these four calls produce the same arrays without
+ * leaving HBM.  All buffers are caller-allocated; node arrays are TreeNode[] (64 B).
+ *   f2n_oct_prune_compress  compact loop + path compression (:139-215) on a copy: out_nodes [n] = edited nodes in the OLD
+ *                           numbering, keep [n] = 1 for the nodes that survive (:219-224).  work_nodes [n], alive [n],
+ *                           n_child [n] are scratch.
+ *   f2n_oct_gather_kept     renumbering (:226-252): new_pos = f2n_segment_scan(keep) start_end layout [n,2]; gathers nodes
+ *                           (parent / child indices rewritten), both statistics and the visit counts.
+ *   f2n_oct_subtree_sizes + f2n_oct_subdivide   subdivision (:255-318): leaves with visit_cnt > 4 (or all: brute_force)
+ *                           split into 8 children that inherit warp and statistics, the whole tree renumbered depth-first;
+ *                           size[0] after the first call is the new node count (read it to allocate dst_*).
+ * ------------------------------------------------------------------------------------------------- */
+int f2n_oct_prune_compress(void* stream, int n_nodes, const void* tree_nodes, void* work_nodes, void* out_nodes, int32_t* alive,
+                           int32_t* n_child, int32_t* keep);
+int f2n_oct_gather_kept(void* stream, int n_nodes, const void* nodes, const int32_t* keep, const int32_t* new_pos,
+                        const int32_t* w_stats, const int32_t* a_stats, const int32_t* visit_cnt, void* dst_nodes, int32_t* dst_w,
+                        int32_t* dst_a, int32_t* dst_visit);
+int f2n_oct_subtree_sizes(void* stream, int n_nodes, const void* nodes, const int32_t* visit_cnt, int brute_force, int32_t* depth,
+                          int32_t* size);
+int f2n_oct_subdivide(void* stream, int n_nodes, const void* nodes, const int32_t* visit_cnt, int brute_force, const int32_t* size,
+                      const int32_t* w_stats, const int32_t* a_stats, int32_t* new_idx, void* dst_nodes, int32_t* dst_w, int32_t* dst_a);
+
+/* ---------------------------------------------------------------------------------------------------
  * Device-side sample counts (ABI v6).  Renderer::Render learns the number of samples that survive the early stop from a
  * blocking read-back (Renderer.cpp:128-135: boolean-mask indexing) and only then launches the grad pass.  The _dyn entry
  * points take the count where it is produced: n_dev points at a DEVICE int32 (the `total` of f2n_segment_scan); the kernels

