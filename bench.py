@@ -149,7 +149,9 @@ def main():
     ap.add_argument("--steps", type=int, default=800)   # >= 1 s of timed region at ~1.2 ms per step
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=8192)
-    ap.add_argument("--preset", default="wanjinyou")
+    ap.add_argument("--preset", default="wanjinyou", help="wanjinyou (BASELINE config 2, the headline) | wanjinyou_big | free: the fox scene; "
+                    "llff | nerf-360: synthetic forward-facing / inward-ring rigs (f2-nerf_amd/rigs.py), octree built on the device")
+    ap.add_argument("--log2", type=int, default=0, help="override field.log2_table_size (e.g. 22 for BASELINE config 5's stress point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converged", action="store_true", help="skip the converged-state leg (train 20k iterations, PSNR, timed steps)")
     ap.add_argument("--train-iters", type=int, default=20000, help="iterations of the converged leg's training run")
@@ -188,8 +190,16 @@ def main():
 
     import f2_nerf_amd  # noqa: F401
     from f2_nerf_amd import runtime
-    st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
-    runner, cfg, _ = runtime.make_runner(st, args.preset, seed=2022, device=dev)   # identical replica on every rank
+    overrides = ["field.log2_table_size=%d" % args.log2] if args.log2 > 0 else []
+    from f2_nerf_amd import rigs
+    if args.preset in rigs.PRESET_RIG:   # synthetic rig: same seed on every rank -> identical scene, octree and replica
+        runner, cfg, st = rigs.build_runner(args.preset, overrides, seed=2022, device=dev)
+        scene_name = "synthetic %s rig (%d cameras, %d octree nodes built on the device)" % (
+            rigs.PRESET_RIG[args.preset], len(st["poses"]), runner.n_nodes())
+    else:
+        st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
+        runner, cfg, _ = runtime.make_runner(st, args.preset, overrides, seed=2022, device=dev)   # identical replica on every rank
+        scene_name = "ngp_fox"
     log2 = int(cfg["field"]["log2_table_size"])
     if args.diag_no_nan_check:
         runner.check_nan = False
@@ -283,19 +293,19 @@ def main():
             except Exception as e:  # the baseline is a reported extra, never the thing measured
                 cpu_baseline = {"error": str(e)[:200]}
         converged = None
-        if world == 1 and not args.no_converged:
+        if world == 1 and not args.no_converged and scene_name == "ngp_fox":
             try:
                 converged = converged_leg(args, st, dev)
             except Exception as e:  # reported next to the headline, never instead of it
                 import traceback
                 converged = {"error": (str(e) + " | " + traceback.format_exc()[-600:])[:900]}
         line = {
-            "metric": "training ray-samples/s (ngp_fox)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+            "metric": "training ray-samples/s (%s)" % ("ngp_fox" if scene_name == "ngp_fox" else args.preset), "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ngp_fox %s.yaml, %d rays/batch/GPU, 2^%d x16 table, the first %d iterations of training from "
+            "config": {"workload": "%s %s.yaml, %d rays/batch/GPU, 2^%d x16 table, the first %d iterations of training from "
                                    "the fresh-initialised table (fineness %.1f), synthetic random-pose rays, full train step "
-                                   "(fwd+bwd+Adam+octree update)" % (args.preset, args.rays, log2, args.warmup + args.steps, runner.fineness),
+                                   "(fwd+bwd+Adam+octree update)" % (scene_name, args.preset, args.rays, log2, args.warmup + args.steps, runner.fineness),
                        "rays_per_batch": args.rays, "parallelism": "ray-dp%d" % world,
                        "rays_per_s": args.rays * world * args.steps / elapsed,
                        "marched_samples_per_s": n_marched / elapsed, "rho_marched_over_meaningful": rho,
