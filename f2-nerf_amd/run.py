@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Launcher of the hot path: what scripts/run.py (hydra composition, image list, runtime_config.yaml) + main.cpp
+(torch::manual_seed(2022), ExpRunner(conf).Execute()) + ExpRunner::Execute (ExpRunner.cpp:385-399) do in the reference.
+
+    python -m f2_nerf_amd.run --config-name=wanjinyou dataset_name=example case_name=ngp_fox mode=train +work_dir=$(pwd)
+    python -m f2_nerf_amd.run --config-name=wanjinyou ... mode=render_path is_continue=true
+
+  * config: `--config-name NAME` composes NAME.yaml of a hydra-style directory (`--config-dir`, e.g. the reference's confs/)
+    or, without a directory, the built-in copy of the shipped experiment files (config.PRESETS); `key=value` / `+key=value`
+    are hydra-style overrides.  The composed config is written to <exp>/record/runtime_config.yaml like the reference does.
+  * data: <work_dir>/data/<dataset_name>/<case_name>/{cams_meta.npy, images[_<factor>]/*.jpg|png, (poses_render.npy),
+    (split.npy)} -- the reference's layout (Dataset.cpp:16-146); NormalizeScene, bounds relaxation and the 8th-image test split
+    are applied as there; images are decoded with PIL and kept resident in HBM.
+  * modes (ExpRunner::Execute): train (ExpRunner::Train with checkpoints every save_freq and the final TestImages),
+    test (TestImages of the latest checkpoint), render_path (RenderPath over poses_render.npy).  Image files are written with
+    PIL; everything per-ray runs in the C++/HIP host (there is no Python in the training loop: ExpRunner::Train).
+File IO and the command line are outside the hot path proper; this module exists so that a user of the
+reference finds the same entry point."""
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def parse_args(argv):
+    name, conf_dir, overrides = "wanjinyou", None, []
+    for a in argv:
+        if a.startswith("--config-name"):
+            name = a.split("=", 1)[1] if "=" in a else None
+        elif a.startswith("--config-dir"):
+            conf_dir = a.split("=", 1)[1] if "=" in a else None
+        elif "=" in a:
+            overrides.append(a.lstrip("+"))
+        elif name is None:
+            name = a
+        elif conf_dir is None and os.path.isdir(a):
+            conf_dir = a
+    return name, conf_dir, overrides
+
+
+def image_list(data_path, factor):
+    """scripts/run.py:22-36."""
+    pats = ["*.jpg", "*.png", "*.JPG", "*.jpeg"]
+    dirs = ["images", "images_1"] if 0.999 < factor < 1.001 else ["images_%d" % int(np.round(factor))]
+    files = []
+    for d in dirs:
+        for p in pats:
+            files += glob.glob(os.path.join(data_path, d, p))
+    if not files:
+        raise FileNotFoundError("No image found under %s (%s)" % (data_path, dirs))
+    return sorted(files)
+
+
+def load_dataset(cfg, data_path):
+    """Dataset::Dataset (Dataset.cpp:16-146) up to the tensors the host Dataset keeps resident."""
+    import torch
+    from PIL import Image
+    from . import rigs, runtime
+    factor = float(cfg["dataset"]["factor"])
+    meta = np.load(os.path.join(data_path, "cams_meta.npy"))
+    files = image_list(data_path, factor)
+    first = np.asarray(Image.open(files[0]).convert("RGB"))
+    sc = rigs.prepare_scene(meta, first.shape[:2], factor, tuple(float(v) for v in cfg["dataset"]["bounds_factor"]),
+                            intrinsics_already_scaled=False)
+    n = len(sc["poses"])
+    if len(files) != n:
+        raise ValueError("%d images for %d cameras" % (len(files), n))
+    images = np.stack([np.asarray(Image.open(f).convert("RGB"), np.uint8) for f in files])
+    sp = os.path.join(data_path, "split.npy")
+    if os.path.exists(sp):  # Dataset.cpp:92-104
+        st = np.load(sp).astype(np.uint8)
+        sc["train_set"] = np.nonzero(st & 1)[0].astype(np.int32)
+        sc["test_set"] = np.nonzero(st & 2)[0].astype(np.int32)
+    rp = os.path.join(data_path, "poses_render.npy")
+    if os.path.exists(rp):  # Dataset.cpp:55-70
+        poses = np.load(rp).astype(np.float32).reshape(-1, 3, 4)
+        poses[:, :3, 3] = (poses[:, :3, 3] - sc["center"][None]) / sc["radius"]
+        sc["render_poses"] = poses
+    ds = runtime.make_dataset(sc, torch.from_numpy(images.astype(np.float32) / np.float32(255.)))
+    return sc, ds
+
+
+def save_png(path, img):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    a = (img.detach().clamp(0, 1) * 255.).to("cpu").numpy().astype(np.uint8)
+    Image.fromarray(a).save(path)
+
+
+def main(argv=None):
+    import torch
+    from . import config, runtime
+    name, conf_dir, overrides = parse_args(sys.argv[1:] if argv is None else argv)
+    cfg = config.compose_yaml(conf_dir, name, overrides) if conf_dir else config.preset(name, overrides)
+    base_dir = cfg.get("work_dir", os.getcwd())
+    data_path = os.path.join(base_dir, "data", str(cfg.get("dataset_name", "example")), str(cfg["case_name"]))
+    exp_dir = os.path.join(base_dir, "exp", str(cfg["case_name"]), str(cfg["exp_name"]))
+    os.makedirs(os.path.join(exp_dir, "record"), exist_ok=True)
+    cfg.setdefault("dataset", {})["data_path"] = data_path
+    cfg["base_dir"], cfg["base_exp_dir"] = base_dir, exp_dir
+    import yaml
+    with open(os.path.join(exp_dir, "record", "runtime_config.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    print("Working directory is", base_dir)
+    torch.manual_seed(2022)  # main.cpp:9
+    sc, ds = load_dataset(cfg, data_path)
+    runner, cfg, built = runtime.make_runner_from_cameras(sc["poses"], sc["intri"], sc["bounds"], sc["train_set"], cfg=cfg)
+    ck_latest = os.path.join(exp_dir, "checkpoints", "latest")
+    if bool(cfg.get("is_continue", False)):  # ExpRunner.cpp:56-58
+        runner.load_checkpoint(ck_latest)
+    mode = str(cfg.get("mode", "train"))
+
+    def save_checkpoint():  # ExpRunner.cpp:205-219
+        d = os.path.join(exp_dir, "checkpoints", "%08d" % runner.iter_step)
+        os.makedirs(d, exist_ok=True)
+        runner.save_checkpoint(d)
+        os.makedirs(ck_latest, exist_ok=True)
+        for f in ("renderer.pt", "scalars.pt"):
+            link = os.path.join(ck_latest, f)
+            if os.path.lexists(link):
+                os.remove(link)
+            os.symlink(os.path.join(d, f), link)
+
+    def test_images():  # ExpRunner.cpp:343-383
+        views = [float(v) for v in runner.test_images(ds)]
+        out = {str(int(i)): p for i, p in zip(sc["test_set"], views[:-1])}
+        out["mean_psnr"] = views[-1]
+        os.makedirs(os.path.join(exp_dir, "test_images"), exist_ok=True)
+        with open(os.path.join(exp_dir, "test_images", "info.yaml"), "w") as f:
+            yaml.safe_dump(out, f)
+        print("Mean psnr: %s" % views[-1])
+        return out
+
+    if mode == "train":
+        t = cfg["train"]
+        end, save_freq, report = int(t["end_iter"]), int(t["save_freq"]), int(t["report_freq"])
+        t0 = time.time()
+        while runner.iter_step < end:
+            nxt = min(end, (runner.iter_step // save_freq + 1) * save_freq)
+            s = runner.train(ds, nxt, 1)
+            torch.cuda.synchronize()
+            mse = max(float(s["mse"]), 1e-12)
+            print("Iter: %6d PSNR: %.2f NRays: %5d OctSamples: %.1f Samples: %.1f MeaningfulSamples: %.1f IPS: %.1f LR: %.4f" % (
+                runner.iter_step, 10 * np.log10(1 / mse), s["n_rays"], runner.oct_per_ray, runner.sampled_per_ray,
+                runner.meaningful_per_ray, runner.iter_step / max(time.time() - t0, 1e-9), runner.cur_lr), flush=True)
+            if runner.iter_step % save_freq == 0:
+                save_checkpoint()
+        with open(os.path.join(exp_dir, "train_info.txt"), "w") as f:
+            f.write("%f\n" % (time.time() - t0))
+        print("Train done, test.")
+        test_images()
+    elif mode == "test":
+        test_images()
+    elif mode == "render_path":
+        if "render_poses" not in sc:
+            raise FileNotFoundError("poses_render.npy not found under " + data_path)
+        runner.render_path(ds, torch.from_numpy(sc["render_poses"]),
+                           lambda i, img: save_png(os.path.join(exp_dir, "novel_images", "%d_%03d.png" % (runner.iter_step, i)), img), 1)
+    else:
+        raise ValueError("unknown mode: %s" % mode)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -80,14 +80,14 @@ def make_runner(state, preset="wanjinyou", overrides=None, seed=2022, table_init
     return runner, cfg, arrays
 
 
-def make_runner_from_cameras(poses, intri, bounds, train_set, preset="wanjinyou", overrides=None, device="cuda:0"):
+def make_runner_from_cameras(poses, intri, bounds, train_set, preset="wanjinyou", overrides=None, device="cuda:0", cfg=None):
     """A fresh ExpRunner for a NEW scene: octree, perspective warps and edge pool are constructed from the training
     cameras on the device (host().build_octree), table / primes / biases / MLPs are initialised as the
     reference's constructors do.  poses [C,3,4] normalised c2w, intri [C,3,3], bounds [C,2] (already relaxed)."""
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device: the hot path has no CPU implementation")
     torch.cuda.set_device(device)
-    cfg = config.preset(preset, overrides)
+    cfg = cfg if cfg is not None else config.preset(preset, overrides)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32))
     ts = np.asarray(train_set)
     ps = cfg["pts_sampler"]

@@ -2,6 +2,8 @@
 Hash3DAnchored / SHShader over the C-ABI) against the CPU oracle pipeline on BASELINE config 1 (ngp_fox,
 wanjinyou.yaml, 256 rays), identical state and identical explicit random draws on both sides.
 Contract (north star): bit-exact sample indices; rendered RGB within 1e-3."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -367,7 +369,10 @@ def test_streaming_step_equals_synchronous_step(rt, fox_state):
     d = rt.to_dev(ro, rd, bounds, gt, cam, noise, bg, eidx, ecoord)
     res = []
     for mode in (0, 2):  # 0: read the count back (as Render does); 2: never
-        runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=16"], seed=21, table_init=2.0)
+        runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=16"], seed=21, table_init=0.5)
+        states = [t.cpu().clone() for t in runner.states()]
+        states[8][-16 * 64:-15 * 64] *= 16.0  # the density row of the field MLP's output layer: opaque stretches -> early stop
+        runner.load_states(states)
         runner.n_edge_pts = NE
         runner.async_counts = mode
         runner.iter_step = 1
@@ -379,7 +384,7 @@ def test_streaming_step_equals_synchronous_step(rt, fox_state):
         c = runner.counters()
         res.append((float(stats["loss"]), stats["n_samples"], c["total_meaningful"], g))
     (l0, n0, m0, g0), (l1, n1, m1, g1) = res
-    assert n0 == n1 and m0 == m1 and n0 > m0 > 32768  # early stop did something; the binned scatter is in play
+    assert n0 == n1 and m0 == m1 and 0.99 * n0 > m0 > 32768, (n0, m0)  # early stop did something; the binned scatter is in play
     assert l0 == l1
     for k in ("color_mlp", "field_mlp", "app_emb"):
         assert rel_err(g1[k], g0[k]) <= 2e-3, (k, rel_err(g1[k], g0[k]))  # (per-block partial sums see the rows in another order)
@@ -533,3 +538,39 @@ def test_octree_construction_from_cameras(rt, fox_state):
     d = rt.to_dev(ro, rd, bounds, gt, cam)
     mse = [float(runner.train_step(d[0], d[1], d[2], d[3], d[4], True)["mse"]) for _ in range(40)]
     assert np.isfinite(mse).all() and mse[-1] < 0.7 * mse[0], (mse[0], mse[-1])
+
+
+def test_launcher_train_test_render_path(rt, tmp_path):
+    """f2_nerf_amd.run == scripts/run.py + main.cpp + ExpRunner::Execute of the reference, on a data directory in the
+    reference's layout (cams_meta.npy, images_4/*.png, poses_render.npy) written from a small synthetic forward-facing rig:
+    mode=train leaves checkpoints (renderer.pt + scalars.pt, `latest` links), train_info.txt and test_images/info.yaml;
+    mode=test with is_continue reproduces the PSNR from the checkpoint; mode=render_path writes the novel views."""
+    import yaml
+    from PIL import Image
+    from f2_nerf_amd import rigs, run
+    rng = np.random.default_rng(2)
+    meta, hw = rigs.forward_facing(rng, n_side=(5, 4), hw=(48, 64), focal=56.0)
+    meta[:, 12:14] *= 4.0; meta[:, 14] *= 4.0; meta[:, 16:18] *= 4.0  # intrinsics on disk refer to the factor-1 images (Dataset.cpp:49)
+    data = tmp_path / "data" / "synth" / "rig"
+    (data / "images_4").mkdir(parents=True)
+    np.save(data / "cams_meta.npy", meta)
+    for i in range(len(meta)):
+        Image.fromarray(rng.integers(0, 255, (48, 64, 3), dtype=np.uint8)).save(data / "images_4" / ("%03d.png" % i))
+    np.save(data / "poses_render.npy", meta[:3, :12].reshape(3, 3, 4))
+    common = ["--config-name=llff", "dataset_name=synth", "case_name=rig", "exp_name=t", "+work_dir=%s" % tmp_path,
+              "field.log2_table_size=14", "train.end_iter=60", "train.save_freq=30", "train.learning_rate_warm_up_end_iter=10",
+              "pts_sampler.sub_div_milestones=[20]", "pts_sampler.compact_freq=25", "train.pts_batch_size=32768"]
+    assert run.main(common + ["mode=train"]) == 0
+    exp = tmp_path / "exp" / "rig" / "t"
+    assert (exp / "checkpoints" / "00000030" / "renderer.pt").exists() and (exp / "checkpoints" / "00000060" / "scalars.pt").exists()
+    assert os.path.realpath(exp / "checkpoints" / "latest" / "renderer.pt") == str(exp / "checkpoints" / "00000060" / "renderer.pt")
+    assert (exp / "train_info.txt").exists() and (exp / "record" / "runtime_config.yaml").exists()
+    info = yaml.safe_load(open(exp / "test_images" / "info.yaml"))
+    assert set(info) == {"0", "8", "16", "mean_psnr"} and np.isfinite(info["mean_psnr"])
+    assert run.main(common + ["mode=test", "is_continue=true"]) == 0
+    info2 = yaml.safe_load(open(exp / "test_images" / "info.yaml"))
+    assert abs(info2["mean_psnr"] - info["mean_psnr"]) < 1e-3  # same weights, same octree, deterministic evaluation
+    assert run.main(common + ["mode=render_path", "is_continue=true"]) == 0
+    frames = sorted(os.listdir(exp / "novel_images"))
+    assert frames == ["60_000.png", "60_001.png", "60_002.png"]
+    assert Image.open(exp / "novel_images" / frames[0]).size == (3 * 64, 48)

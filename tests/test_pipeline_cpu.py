@@ -1,7 +1,10 @@
 """CPU: self-consistency of the oracle's host-pipeline restatement (oracle/pipeline.py): its hand-written
 backward chains are checked against float64 torch autograd of the same formulas, and the MLP restatement
 against a plain fp32 network."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import capi as oc
@@ -127,3 +130,34 @@ def test_early_stop_prefix_and_adam():
         opt.step()
         p, m, v = op.adam_step(p, g, m, v, step, 1e-2, 0.9, 0.99, 1e-15, 1e-6)
         np.testing.assert_allclose(p, pt.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/confs"), reason="needs the reference's confs/ directory")
+@pytest.mark.parametrize("name", ["wanjinyou", "wanjinyou_big", "llff", "nerf-360", "free"])
+def test_presets_equal_the_reference_config_files(name):
+    """config.PRESETS / GROUP_DEFAULTS are data copied by hand from the reference's confs/ so that the GPU box (which has no
+    /root/reference) can run them: here they are tied to the files themselves, composed hydra-style from confs/ in place."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import config
+    want = config.compose_yaml("/root/reference/confs", name)
+    got = config.preset(name)
+    def norm(flat):  # (PyYAML reads `1e-1` as a string; the C++ host parses the strings, so compare the values)
+        out = {}
+        for k, v in flat.items():
+            parts = []
+            for item in v.split(","):
+                try:
+                    parts.append(float(item))
+                except ValueError:
+                    parts.append(item)
+            out[k] = parts
+        return out
+    for group in ("train", "dataset", "renderer", "pts_sampler", "field", "shader"):
+        assert norm(config.flatten({group: want[group]})) == norm(config.flatten({group: got[group]})), (name, group)
+    assert want["mode"] == got["mode"] == "train" and want["is_continue"] == got["is_continue"]
+    # the launcher's argument handling (scripts/run.py's hydra overrides)
+    from f2_nerf_amd import run
+    n, d, ov = run.parse_args(["--config-name=%s" % name, "--config-dir=/root/reference/confs", "case_name=ngp_fox", "+work_dir=/tmp/x",
+                               "train.end_iter=100"])
+    cfg = config.compose_yaml(d, n, ov)
+    assert cfg["case_name"] == "ngp_fox" and cfg["work_dir"] == "/tmp/x" and cfg["train"]["end_iter"] == 100
