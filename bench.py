@@ -208,7 +208,8 @@ def main():
         from f2_nerf_amd import parallel
         # per step: all-reduce(AVG) of the 17*2^log2-half active prefix of the fp16 hash-gradient table + MLP/app_emb
         # gradients, and all-reduce(MAX) of the octree occupancy votes (f2-nerf_amd/parallel.py)
-        parallel.attach(runner, log2)
+        ov = os.environ.get("F2N_DP_OVERLAP")  # (measurement knob: 1 / 0 force the pipelined / blocking exchange)
+        parallel.attach(runner, log2, overlap=None if ov is None else ov == "1")
 
     # synthetic random-pose batches, resident in HBM before the timed region (per-rank RNG stream)
     rng = np.random.default_rng(1000 + rank)

@@ -105,7 +105,7 @@ def build_host(force=False, verbose=False):
     if force or jobs or not os.path.exists(out):
         libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
         link = ["g++", "-shared"] + objs + ["-o", out, "-L" + libdir, "-L" + HERE, "-Wl,-rpath," + libdir,
-                                            "-Wl,-rpath,$ORIGIN", "-lf2n_hip", "-lc10", "-ltorch_cpu", "-ltorch",
+                                            "-Wl,-rpath,$ORIGIN", "-lf2n_hip", "-lrccl", "-lc10", "-ltorch_cpu", "-ltorch",
                                             "-ltorch_python", "-lc10_hip", "-ltorch_hip"]
         run(link)
     return out

@@ -1,0 +1,109 @@
+#include "DataParallel.h"
+
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+
+namespace f2n {
+
+#define F2N_NCCL(expr)                                                                                  \
+  do {                                                                                                  \
+    ncclResult_t r_ = (expr);                                                                           \
+    TORCH_CHECK(r_ == ncclSuccess, #expr, " failed: ", ncclGetErrorString(r_));                        \
+  } while (0)
+
+std::vector<uint8_t> DataParallel::NewUniqueId() {
+  ncclUniqueId id;
+  F2N_NCCL(ncclGetUniqueId(&id));
+  return std::vector<uint8_t>(reinterpret_cast<uint8_t*>(&id), reinterpret_cast<uint8_t*>(&id) + sizeof(id));
+}
+
+DataParallel::~DataParallel() {
+  if (comm_ != nullptr) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
+}
+
+void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vector<uint8_t>& unique_id, bool overlap) {
+  TORCH_CHECK(unique_id.size() == sizeof(ncclUniqueId), "unique id must be ", sizeof(ncclUniqueId), " bytes");
+  TORCH_CHECK(world >= 1 && rank >= 0 && rank < world, "bad rank / world size");
+  runner_ = runner;
+  rank_ = rank;
+  world_ = world;
+  runner->renderer_->dp_world_ = world;
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id.data(), sizeof(id));
+  ncclComm_t comm;
+  F2N_NCCL(ncclCommInitRank(&comm, world, id, rank));
+  comm_ = reinterpret_cast<ncclComm*>(comm);
+  comm_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA(/*high priority*/ true));
+  // Replicas must start from identical parameters, hash primes / biases and octree: whatever seeds the ranks were
+  // constructed with, rank 0's state wins (per-rank RNG streams are for ray / noise / background draws only).
+  BroadcastStates();
+  // A one-rank world has nothing to exchange: the hooks are only installed when asked for (F2N_DP_FORCE=1: tests and
+  // overhead measurements drive the RCCL calls with one rank; each costs a ~50-100 us kernel even then).
+  const char* force = getenv("F2N_DP_FORCE");
+  if (world == 1 && !(force != nullptr && force[0] == '1')) return;
+  auto* field = static_cast<Hash3DAnchored*>(runner->renderer_->scene_field_.get());
+  flat_ = runner->FlattenSmallGrads();
+  table_prefix_ = field->grad_h_.view({-1}).narrow(0, 0, field->active_halves_);
+  if (overlap) {
+    runner->grad_sync_begin_hook_ = [this]() { GradSyncBegin(); };
+    runner->grad_sync_end_hook_ = [this]() { GradSyncEnd(); };
+    runner->pipelined_sync_ = true;
+  } else {
+    runner->grad_sync_hook_ = [this]() {
+      GradSyncBegin();
+      GradSyncEnd();
+    };
+  }
+  static_cast<PersSampler*>(runner->renderer_->pts_sampler_.get())->occupancy_sync_hook_ = [this](Tensor occ) { OccupancySync(occ); };
+}
+
+void DataParallel::BroadcastStates() {
+  auto comm = reinterpret_cast<ncclComm_t>(comm_);
+  std::vector<Tensor> states = runner_->States();
+  hipStream_t st = (hipStream_t) CurStream();
+  std::vector<Tensor> dev;
+  for (auto& t : states) {
+    // sizes first: a replica built with another seed may hold another number of octree nodes
+    Tensor n = torch::full({1}, (int64_t) t.numel(), torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA));
+    F2N_NCCL(ncclBroadcast(n.data_ptr(), n.data_ptr(), 1, ncclInt64, 0, comm, st));
+    const int64_t want = n.item<int64_t>();
+    Tensor d = t.to(torch::kCUDA).contiguous();
+    if (d.numel() != want) d = torch::empty({want}, d.options());
+    F2N_NCCL(ncclBroadcast(d.data_ptr(), d.data_ptr(), (size_t) d.numel() * d.element_size(), ncclChar, 0, comm, st));
+    dev.push_back(d);
+  }
+  // shapes as the checkpoint format has them (LoadStates reshapes what it needs)
+  runner_->LoadStates(dev);
+}
+
+void DataParallel::GradSyncBegin() {
+  auto comm = reinterpret_cast<ncclComm_t>(comm_);
+  grads_ready_ev_.record();  // backward has been queued on the compute stream
+  grads_ready_ev_.block(*comm_stream_);
+  hipStream_t cs = comm_stream_->stream();
+  F2N_NCCL(ncclGroupStart());
+  F2N_NCCL(ncclAllReduce(table_prefix_.data_ptr(), table_prefix_.data_ptr(), (size_t) table_prefix_.numel(), ncclHalf, ncclAvg, comm, cs));
+  F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, cs));
+  F2N_NCCL(ncclGroupEnd());
+  reduced_ev_.record(*comm_stream_);
+}
+
+void DataParallel::GradSyncEnd() {
+  reduced_ev_.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());  // the compute stream waits; the host does not
+}
+
+void DataParallel::OccupancySync(Tensor occ) {
+  auto comm = reinterpret_cast<ncclComm_t>(comm_);
+  hipStream_t st = (hipStream_t) CurStream();
+  Tensor o = occ.contiguous();
+  TORCH_CHECK(o.data_ptr() == occ.data_ptr(), "occupancy buffer must be contiguous");
+  F2N_NCCL(ncclGroupStart());
+  F2N_NCCL(ncclAllReduce(o.data_ptr(), o.data_ptr(), (size_t) o.numel(), ncclInt32, ncclMax, comm, st));
+  // the survivor count behind the meaningful-samples EMA: every rank must size its next batch from the same number
+  Tensor& cnt = runner_->renderer_->dp_count_;
+  if (cnt.defined() && world_ > 1) F2N_NCCL(ncclAllReduce(cnt.data_ptr(), cnt.data_ptr(), (size_t) cnt.numel(), ncclInt32, ncclSum, comm, st));
+  F2N_NCCL(ncclGroupEnd());
+}
+
+}  // namespace f2n

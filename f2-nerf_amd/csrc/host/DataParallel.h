@@ -1,0 +1,48 @@
+// Ray-data-parallel replicas over RCCL, driven from the C++ host (no Python in the training step).
+//
+// The reference is single-GPU.  Rays are independent given a replicated model + octree: each rank renders
+// its own ray batch and the replicas exchange, per iteration,
+//   (1) gradients  -- ONE ncclGroup: all-reduce(AVG) of the active prefix of the f16 (x128) hash-gradient table
+//                     (17 * 2^log2 halves) + all-reduce(AVG) of the flat fp32 buffer holding field-MLP, colour-MLP and
+//                     app_emb gradients (ExpRunner::FlattenSmallGrads).  Issued on the communicator's own stream right
+//                     after backward; the compute stream only waits for it in the NEXT step, after that step's ray
+//                     sampling has been queued (ExpRunner's pipelined hooks), so the 17 MiB reduction over xGMI runs
+//                     underneath ~0.3 ms of sampler kernels;
+//   (2) occupancy  -- all-reduce(MAX) of the [4, n_nodes] vote / mark / visit-count buffer between MarkVisit and the
+//                     stat update (PersSampler.cu:555-603) on the compute stream, together with all-reduce(SUM) of the
+//                     survivor count (the meaningful-samples EMA that sizes the next ray batch, ExpRunner.cpp:86, must be
+//                     the same on every rank or the replicas draw different batch sizes).
+// Gradients are identical on all ranks after (1), so the device-side finiteness flags and the predicated Adam agree
+// everywhere.  The communicator is created with ncclCommInitRank from a unique id that rank 0 generates and the launcher
+// distributes (f2-nerf_amd/parallel.py: through the torch.distributed store; a file or an environment variable work too).
+#pragma once
+#include "ExpRunner.h"
+
+struct ncclComm;
+
+namespace f2n {
+
+class DataParallel {
+ public:
+  ~DataParallel();
+  static std::vector<uint8_t> NewUniqueId();  // rank 0
+  // Creates the communicator (collective: every rank must call), replicates rank 0's state on every rank and wires the
+  // exchanges into the runner.  overlap = pipelined gradient exchange (see above); false: in front of the optimiser.
+  void Attach(ExpRunner* runner, int rank, int world, const std::vector<uint8_t>& unique_id, bool overlap = true);
+  void BroadcastStates();           // rank 0's checkpoint vector -> every rank (collective)
+  int rank() const { return rank_; }
+  int world() const { return world_; }
+
+ private:
+  void GradSyncBegin();
+  void GradSyncEnd();
+  void OccupancySync(Tensor occ);
+  ExpRunner* runner_ = nullptr;
+  ncclComm* comm_ = nullptr;
+  int rank_ = 0, world_ = 1;
+  Tensor table_prefix_, flat_;
+  std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> comm_stream_;
+  at::cuda::CUDAEvent grads_ready_ev_, reduced_ev_;
+};
+
+}  // namespace f2n

@@ -135,8 +135,13 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
   for (size_t i = 0; i < groups_.size(); i++)
     if (groups_[i].name == "color_mlp") add_small(i, flags);
   TORCH_CHECK(!flags || n_small == 2, "finiteness flags need the field and colour MLP groups");
+  // torch::optim::Adam skips parameters whose gradient is undefined: without the appearance embedding in use nothing ever
+  // writes app_emb's gradient, and stepping it with weight decay alone (g = wd * p through Adam's normalisation) would walk
+  // the embedding to zero at lr per step
   for (size_t i = 0; i < groups_.size(); i++)
-    if (!groups_[i].grad_is_h16 && groups_[i].name != "field_mlp" && groups_[i].name != "color_mlp") add_small(i, false);
+    if (!groups_[i].grad_is_h16 && groups_[i].name != "field_mlp" && groups_[i].name != "color_mlp" &&
+        (groups_[i].name != "app_emb" || renderer_->use_app_emb_))
+      add_small(i, false);
   if (n_small > 0)
     F2N_TIMED_CALL("adam", f2n_adam_small_groups(st, n_small, small, optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, /*zero_grad=*/1,
                                                  compute_flags, skip_flag));

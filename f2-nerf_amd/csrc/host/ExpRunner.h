@@ -88,6 +88,7 @@ class ExpRunner {
   std::unique_ptr<Renderer> renderer_;
   std::vector<ParamGroup> groups_;
   std::vector<Tensor> exp_avg_, exp_avg_sq_;
+  std::shared_ptr<void> data_parallel_;  // DataParallel (DataParallel.h), when attached: released before the renderer
 };
 
 }  // namespace f2n

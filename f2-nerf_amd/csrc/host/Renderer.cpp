@@ -260,6 +260,12 @@ void Renderer::PreSampleFinish() {
   pending_rays_d_ = Tensor();
 }
 
+float Renderer::KeptPerRayForEma(int n_kept_local, int n_rays) {
+  if (dp_world_ <= 1 || !dp_count_host_.defined()) return float(n_kept_local) / float(n_rays);
+  dp_count_ev_.synchronize();  // recorded right behind the occupancy exchange of the same step
+  return float(dp_count_host_.data_ptr<int32_t>()[0]) / (float(n_rays) * float(dp_world_));
+}
+
 void Renderer::ResolvePendingCount() {
   if (!count_pending_) return;
   count_pending_ = false;
@@ -268,7 +274,7 @@ void Renderer::ResolvePendingCount() {
   last_n_kept_pts_ = n_kept;
   total_kept_pts_ += n_kept;
   auto* gdp = global_data_pool_;
-  gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(pending_count_rays_)) * 0.1f;
+  gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(n_kept, pending_count_rays_) * 0.1f;
   // (the previous step's finiteness flags are NOT read here: they are written by that step's last kernel, and waiting for
   // them at the top of a step would stop the host from queueing ahead -- ExpRunner::TrainStep reads them once this step's
   // forward and backward are queued)
@@ -317,10 +323,16 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   RenderFront fr;
   fr.bg_color = bg_color;
   if (n_all_pts <= 0) {  // Renderer.cpp:83-97
-    if (train) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f;
     // data-parallel replicas must all take part in the occupancy exchange, also the one whose batch missed the scene
+    if (train && dp_world_ > 1) dp_count_ = torch::zeros({1}, DevI32());
     if (train && static_cast<PersSampler*>(pts_sampler_.get())->occupancy_sync_hook_)
       pts_sampler_->UpdateOctNodes(sample_result_, torch::empty({0}, DevF32()), torch::empty({0}, DevF32()));
+    if (train && dp_world_ > 1) {
+      if (!dp_count_host_.defined()) dp_count_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+      dp_count_host_.copy_(dp_count_, /*non_blocking=*/true);
+      dp_count_ev_.record();
+    }
+    if (train) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(0, n_rays) * 0.1f;
     last_n_kept_pts_ = 0;
     fr.empty = true;
     consumed_side_samples_ = false;  // (nothing was read from the side stream's buffers)
@@ -350,7 +362,13 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     if (!n_kept_host_.defined()) n_kept_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
     n_kept_host_.copy_(total, /*non_blocking=*/true);
     n_kept_ev_.record();
+    if (train && dp_world_ > 1) dp_count_ = total.clone();  // summed over the ranks inside the occupancy exchange
     if (train) pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);  // Renderer.cpp:140-149
+    if (train && dp_world_ > 1) {
+      if (!dp_count_host_.defined()) dp_count_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+      dp_count_host_.copy_(dp_count_, /*non_blocking=*/true);
+      dp_count_ev_.record();
+    }
     Tensor edge_idx, edge_coord;
     auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
     if (train) {  // Renderer.cpp:159-166 / PersSampler.cu:454-473: the draws of GetEdgeSamples
@@ -409,7 +427,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
                                  want_emb ? I32P(emb_contig) : nullptr, want_emb ? I32P(fr.sample_emb_idx) : nullptr));
     if (train) {
       if (!fr.dyn)
-        gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + (float(n_kept) / float(n_rays)) * 0.1f;
+        gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(n_kept, n_rays) * 0.1f;
       // edge samples for the TV loss share the field's point array with the surviving samples (Renderer.cpp:159-166)
       auto& oct = *ps->pers_octree_;
       F2N_CALL(f2n_edge_samples(st, n_edge, VoidP(oct.edge_pool_gpu_), VoidP(oct.pers_trans_gpu_), I32P(edge_idx),

@@ -83,6 +83,12 @@ class Renderer : public Pipe {
   // The survivor count of an async SampleAndFilter arrives in pinned memory; the host-side bookkeeping that depends on it
   // (meaningful-samples EMA, counters) is applied here: at the start of the next step, or by ExpRunner::FinishPending.
   void ResolvePendingCount();
+  // data-parallel runs (DataParallel.cpp): the survivor count behind the meaningful-samples EMA is summed over the ranks in
+  // the occupancy exchange, so that every replica sizes its next ray batch from the same number
+  int dp_world_ = 1;
+  Tensor dp_count_, dp_count_host_;
+  at::cuda::CUDAEvent dp_count_ev_;
+  float KeptPerRayForEma(int n_kept_local, int n_rays);
   bool async_count_ = false;        // set by ExpRunner::TrainStep for streaming steps
   bool count_pending_ = false;
   int pending_count_rays_ = 0;

@@ -2,6 +2,7 @@
 // end-to-end tests).  Thin: object lifetime + tensor hand-over only.
 #include <torch/extension.h>
 
+#include "DataParallel.h"
 #include "ExpRunner.h"
 
 using namespace f2n;
@@ -87,6 +88,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_readonly("n_images", &Dataset::n_images_)
       .def_readonly("height", &Dataset::height_)
       .def_readonly("width", &Dataset::width_);
+  m.def("dp_new_unique_id", []() {  // rank 0: the id every rank passes to attach_data_parallel
+    auto id = DataParallel::NewUniqueId();
+    return py::bytes(reinterpret_cast<const char*>(id.data()), id.size());
+  });
   py::class_<ExpRunner>(m, "ExpRunner")
       .def(py::init<const std::map<std::string, std::string>&, int>(), py::arg("flat_config"), py::arg("n_images"))
       .def("load_states", &ExpRunner::LoadStates)
@@ -192,6 +197,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              r.pipelined_sync_ = true;
            })
       .def("flush", [](ExpRunner& r) { py::gil_scoped_release no_gil; r.FinishPending(); })
+      .def("attach_data_parallel",  // native RCCL exchanges, issued from C++ inside TrainStep (DataParallel.h); collective
+           [](ExpRunner& r, int rank, int world, const py::bytes& unique_id, bool overlap) {
+             std::string s = unique_id;
+             auto dp = std::make_shared<DataParallel>();
+             {
+               py::gil_scoped_release no_gil;
+               dp->Attach(&r, rank, world, std::vector<uint8_t>(s.begin(), s.end()), overlap);
+             }
+             r.data_parallel_ = dp;
+           },
+           py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("overlap") = true)
       .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically
            [](ExpRunner& r, py::function f) {
              SamplerOf(r)->occupancy_sync_hook_ = [f](Tensor occ) {

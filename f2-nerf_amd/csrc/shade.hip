@@ -116,14 +116,18 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
                                                         float loss_scale, float* __restrict__ dfeat,
                                                         float* __restrict__ dparams, int n_emb,
                                                         float* __restrict__ emb_partials, const float* __restrict__ df0,
-                                                        const int32_t* __restrict__ n_dev) {
+                                                        const int32_t* __restrict__ n_dev, float* __restrict__ emb_global) {
+  // emb_partials: per-block LDS image of the appearance-embedding gradient, flushed as a partial (n_emb <= 480);
+  // emb_global: more images than fit into LDS -- row sums go straight to the gradient with global atomics, as the
+  // reference's ScatterAddFuncBackward does (Scatter.cu:20-40)
   if (n_dev != nullptr) n = min(n, *n_dev);
   __shared__ F2nShadeSmem sm;
   extern __shared__ float s_emb[];  // [n_emb * 16] per-block appearance-embedding gradient (ds_add_f32)
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   f2n_mlp_lds_fill<2>(sm.w, params, tid, 256);
-  const bool do_emb = emb_partials != nullptr;
-  if (do_emb)
+  const bool do_emb = emb_partials != nullptr || emb_global != nullptr;
+  const bool emb_lds = emb_partials != nullptr;
+  if (emb_lds)
     for (int i = tid; i < n_emb * 16; i += 256) s_emb[i] = 0.f;
   __syncthreads();
   const half8_t idf[2] = {f2n_identity_frag(0, c, g), f2n_identity_frag(1, c, g)};
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
       if (do_emb) {
         // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples, accumulated in LDS.  The 16 samples
         // of a tile usually share a ray, hence an image: reduce across the 16 sample lanes first.
-        const int img = valid ? cur.img : -1;
+        const int img = (valid && cur.img >= 0 && cur.img < n_emb) ? cur.img : -1;  // an index outside the table adds nothing
+        float* acc_emb = emb_lds ? s_emb : emb_global;
         // sample 0's image, without an LDS round trip: every row of 16 lanes holds the same 16 samples
         const int img0 = __builtin_amdgcn_readfirstlane(img);
         const bool uniform = __all(img == img0);
@@ -224,12 +229,12 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               const float v = f2n_row16_allsum(dsf[r]);
-              if (c == 0) atomicAdd(&s_emb[img0 * 16 + 4 * g + r], v);
+              if (c == 0) atomicAdd(&acc_emb[img0 * 16 + 4 * g + r], v);
             }
           }
-        } else if (valid) {
+        } else if (img >= 0) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) atomicAdd(&s_emb[img * 16 + 4 * g + r], dsf[r]);
+          for (int r = 0; r < 4; r++) atomicAdd(&acc_emb[img * 16 + 4 * g + r], dsf[r]);
         }
       }
       f2n_mlp_accumulate_dw_half<2>(hb, acc);
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
   }
   __syncthreads();
   f2n_mlp_flush_dw<2>(acc, sm.acc, dparams, c, g, tid, 256);
-  if (do_emb) {  // s_emb is complete since the __syncthreads() above
+  if (emb_lds) {  // s_emb is complete since the __syncthreads() above
     float* dst = emb_partials + (size_t) blockIdx.x * n_emb * 16;
     for (int i = tid; i < n_emb * 16; i += 256) dst[i] = s_emb[i];
   }
@@ -297,7 +302,7 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
   const int n = n_max;
   if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1)) || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
-  if (dapp_emb != nullptr && n_emb > 480) return F2N_ERR_UNSUPPORTED;  // per-block LDS accumulator: 64 B per image next to 57 KB of weights / reduction images
+  const bool emb_in_lds = dapp_emb != nullptr && n_emb <= 480;  // per-block LDS accumulator: 64 B per image next to 57 KB of weights / reduction images
   if (n == 0) return F2N_OK;
   unsigned blocks = f2n_shade_grid((n + 31) / 32, 4);
   if (blocks > 512) blocks = 512;  // two resident blocks per CU (254 registers per lane)
@@ -305,7 +310,7 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
   float* partials = (float*) f2n_ws_get(F2N_WS_SHADE_DW, sizeof(float) * (size_t) blocks * n_params);
   float* emb_partials = nullptr;
   size_t dyn_lds = 0;
-  if (dapp_emb != nullptr) {
+  if (emb_in_lds) {
     emb_partials = (float*) f2n_ws_get(F2N_WS_SHADE_EMB, sizeof(float) * (size_t) blocks * n_emb * 16);
     dyn_lds = sizeof(float) * (size_t) n_emb * 16;
     if (emb_partials == nullptr) return F2N_ERR_INVALID_ARG;
@@ -321,11 +326,11 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
   }
   hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(256), dyn_lds, (hipStream_t) stream, n, drgb, sample_emb_idx,
                      (const half_t*) mlp_params_h, (const half_t*) saved_x_h, loss_scale, dfeat, partials, n_emb, emb_partials, df0,
-                     n_dev);
+                     n_dev, (dapp_emb != nullptr && !emb_in_lds) ? dapp_emb : nullptr);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   rc = f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
-  if (rc != F2N_OK || dapp_emb == nullptr) return rc;
+  if (rc != F2N_OK || !emb_in_lds) return rc;
   return f2n_reduce_partials(stream, n_emb * 16, (int) blocks, emb_partials, dapp_emb);
 }
 

@@ -58,14 +58,55 @@ def occupancy_sync(occ, group=None):
     dist.all_reduce(occ, op=dist.ReduceOp.MAX, group=group)
 
 
-def attach(runner, log2_table_size, group=None, overlap=None):
-    """Wire both collectives into an ExpRunner (csrc/host/ExpRunner.cpp hooks): 3 collectives per training step.
+def broadcast_states(runner, group=None):
+    """Replicas must start from identical parameters, hash primes / biases and octree.  runtime.make_runner_from_cameras draws
+    them from the torch RNG, the very generator that has to DIFFER per rank for distinct ray batches: whatever the ranks were
+    constructed with, rank 0's checkpoint vector is loaded everywhere (sizes first -- another seed may have built another
+    number of octree nodes)."""
+    states = runner.states()
+    backend = dist.get_backend(group)
+    out = []
+    for t in states:
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
+        dist.broadcast(n, src=0, group=group)
+        b = t.to(dev).contiguous()
+        if b.numel() != int(n.item()):
+            b = torch.empty(int(n.item()), dtype=b.dtype, device=dev)
+        dist.broadcast(b, src=0, group=group)
+        out.append(b)
+    runner.load_states(out)
+
+
+def attach(runner, log2_table_size, group=None, overlap=None, native=None):
+    """Wire the exchanges into an ExpRunner.
+
+    native (default: on for the nccl/RCCL backend): the C++ host creates its own RCCL communicator (ncclCommInitRank; the
+    unique id travels through this process group once) and issues the collectives itself from inside TrainStep
+    (csrc/host/DataParallel.cpp) -- one ncclGroup for the two gradient buffers on the communicator's stream, the occupancy
+    MAX + survivor-count SUM on the compute stream; no Python, no GIL, no dispatcher on the step's critical path.  Rank 0's
+    state is broadcast to every rank.  native=False keeps the torch.distributed hooks below (what the gloo tests run):
+
+    3 collectives per training step through Python callbacks.
 
     overlap (default: on for the nccl/RCCL backend): the two gradient all-reduces are launched asynchronously right
     after backward and only awaited in the NEXT train_step, after its ray sampling (which reads neither parameters nor
     gradients) has been issued -- the 17 MiB table reduction over xGMI then runs under ~0.3 ms of sampler kernels
     instead of in front of the optimiser.  Call runner.flush() before reading parameters outside train_step /
     render_rays / states() (those flush themselves)."""
+    if native is None:
+        native = dist.get_backend(group) == "nccl" and hasattr(runner, "attach_data_parallel")
+    if native:
+        from . import runtime
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ids = [runtime.host().dp_new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, group=group, device=torch.device("cuda", torch.cuda.current_device()))
+        # overlap: the gradient exchange runs underneath the next step's ray sampling, which therefore moves from "under this
+        # step's backward" to the step boundary -- worth it as soon as there is an exchange to hide (world > 1)
+        runner.attach_data_parallel(rank, world, ids[0], (world > 1) if overlap is None else bool(overlap))
+        return
+    if hasattr(runner, "states") and hasattr(runner, "load_states"):
+        broadcast_states(runner, group)
     flat = runner.flatten_small_grads()
     table = runner.grad_buffers()[0].view(-1)[:active_table_halves(log2_table_size)]
     if overlap is None:

@@ -8,7 +8,16 @@
  *
  * Conventions
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call only ENQUEUES work on
- *     that stream; nothing here synchronises, allocates or frees caller-visible memory.
+ *     that stream; nothing here allocates or frees caller-visible memory.
+ *   - Internal scratch: the backward / loss / large-batch field entry points (f2n_field_fwd for n >= 8192, f2n_field_bwd*,
+ *     f2n_mlp_bwd, f2n_shade_bwd*, f2n_hash_bwd with level_entries > 0, f2n_train_loss) keep per-block partial sums, feature
+ *     planes and scatter queues in ONE library-owned workspace per device and slot.  Consequences: (a) calls that share a
+ *     slot must be issued on ONE stream per device (or be ordered by the caller) -- two streams running f2n_field_bwd at
+ *     the same time would share partials; the host layer issues all of them on the compute stream and only sampler kernels
+ *     (which use no workspace) on its side stream; (b) the first calls, and a call that needs more scratch than any before
+ *     it, grow the workspace: that path drains the device (hipDeviceSynchronize) before the old buffer is released,
+ *     because queued kernels may still hold it.  Sizes settle after the first iterations; steady-state calls never
+ *     synchronise.
  *   - All pointers are DEVICE pointers to contiguous buffers in exactly the layouts named below, unless
  *     the parameter is documented as host data.  TreeNode = 64 B, TransInfo = 544 B, EdgePool = 64 B as in
  *     PtsSampler/PersSampler.h:15-37.  "h16" = IEEE binary16.
@@ -288,7 +297,10 @@ int f2n_shade_fwd(void* stream, int n, const float* feat /*[n,16]*/, const float
 /* drgb [n,3] -> dfeat[:,1:16] written; column 0 belongs to the density path: left untouched when df0 is NULL, or
  * filled from the compact array df0 [n] (f2n_composite_bwd with df0_stride 1) so that every dfeat row is written once,
  * as whole cache lines.  dparams accumulated (scaled domain), dapp_emb [n_img,16] accumulated UNSCALED or NULL.
- * The network output needed for the sigmoid derivative is recomputed from saved_x_h on the matrix cores. */
+ * The network output needed for the sigmoid derivative is recomputed from saved_x_h on the matrix cores.
+ * n_emb <= 480: the embedding gradient is accumulated per block in LDS and reduced (no same-address global atomics);
+ * larger image counts fall back to global atomics like the reference's ScatterAddFuncBackward (Scatter.cu:20-40).
+ * sample_emb_idx values outside [0, n_emb) contribute nothing (f2n_shade_fwd trusts its indices: it has no n_emb). */
 int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_emb_idx, const void* mlp_params_h,
                   const void* saved_x_h, float loss_scale, float* dfeat /*[n,16]*/, float* dparams_f32_scaled,
                   float* dapp_emb /*[n_emb,16] or NULL*/, int n_emb, const float* df0 /*[n] or NULL*/);

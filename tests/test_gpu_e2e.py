@@ -315,18 +315,24 @@ def test_data_parallel_hooks_on_one_gpu(rt, fox_state):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        for mode in ("none", "blocking", "overlapped", "prefetch", "overlapped+prefetch"):
+        for mode in ("none", "blocking", "overlapped", "prefetch", "overlapped+prefetch", "native", "native-blocking+prefetch"):
             runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=14"], seed=11, table_init=0.3)
             runner.n_edge_pts = 256
             runner.set_forced_randoms(noise, bg, eidx, ecoord)
             if mode in ("blocking", "overlapped", "overlapped+prefetch"):
-                parallel.attach(runner, 14, overlap=mode.startswith("overlapped"))
+                parallel.attach(runner, 14, overlap=mode.startswith("overlapped"), native=False)  # torch.distributed hooks
+            if mode.startswith("native"):  # the C++ host's own RCCL communicator (DataParallel.cpp), one-rank world
+                os.environ["F2N_DP_FORCE"] = "1"  # (a one-rank world would otherwise skip its exchanges)
+                try:
+                    parallel.attach(runner, 14, overlap=(mode == "native"), native=True)
+                finally:
+                    del os.environ["F2N_DP_FORCE"]
             # "prefetch": the next iteration's rays (here: the same batch) are sampled on a side stream during this one
             nxt = (d[0], d[1], d[2]) if "prefetch" in mode else (None, None, None)
             losses = [float(runner.train_step(d[0], d[1], d[2], d[3], d[4], True, *nxt)["loss"]) for _ in range(5)]
             assert runner.iter_step == 5
             outs.append((losses, [t.clone() for t in runner.states()]))  # states() completes a pending overlapped step
-            if mode in ("blocking", "overlapped"):
+            if mode in ("blocking", "overlapped", "native"):
                 # a replica whose batch misses the scene still takes part in all three exchanges (no hang, no throw)
                 far = d[0] + 1e4
                 s_empty = runner.train_step(far, d[1], d[2], d[3], d[4], True)

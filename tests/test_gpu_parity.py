@@ -621,7 +621,7 @@ def test_field_forward_from_prepass_cache(hip, fox_state, fox_golden):
         hip.field_fwd_cached(n + 1, n, None, cache, ph, torch.zeros((n + 1, 16), device=DEV), None, None)
 
 
-@pytest.mark.parametrize("n_emb", [0, 50, 480])  # 480: the largest per-block LDS image the backward accepts (> 64 KB of LDS)
+@pytest.mark.parametrize("n_emb", [0, 50, 480, 1500])  # 480: the largest per-block LDS image (> 64 KB of LDS); above: global atomics
 def test_shade_fused_forward_backward(hip, fox_golden, n_emb):
     use_emb = n_emb > 0
     g = fox_golden
