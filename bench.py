@@ -49,13 +49,15 @@ ALGO_BYTES = {"hash_gather": 512 + 12 + 4 + 64}
 # HBM-side bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate counter passes,
 # profiles/run_profiles.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), recorded per round in
 # profiles/<tag>_traffic.json; null when that file is absent.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
+TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r02_traffic.json"), os.path.join(ROOT, "profiles", "r01_traffic.json"))
+                     if os.path.exists(p)), "")
 HBM_PEAK_GBS = 8000.0
 # What actually bounds that kernel: 128 independent 4-byte reads per sample from an L2-resident table slice.  The chip
 # serves at most ~263 G such lane-requests/s whatever the cache policy or access width (tools/gather_policy_probe.py,
 # profiles/r01_gather_policy_probe.txt: each request moves a whole line from L2 into a CU's L1) -- reported next to the
 # HBM fraction as roofline.request_ceiling.
 GATHER_REQ_PEAK = 263.0e9
+L2_PEAK_TBS = 34.5  # aggregate L2 bandwidth of the eight XCDs (MI355X_MICROARCH.md, L2 section)
 
 # Algorithmic HBM bytes per MARCHED sample of the kernels that can dominate a step:
 #   hash_gather  16 levels x 8 corners x 4 B + point 12 + warp index 4 + 64 B of f16 feature planes written
@@ -269,7 +271,7 @@ def main():
             samples_per_launch = n_marched / world / args.steps
             achieved = samples_per_launch * ALGO_BYTES[DOMINANT] / (avg_ms * 1e-3) / 1e9
             traffic = None
-            if os.path.exists(TRAFFIC_FILE):
+            if TRAFFIC_FILE and os.path.exists(TRAFFIC_FILE):
                 with open(TRAFFIC_FILE) as f:
                     traffic = json.load(f).get("hash_gather_planes_kernel", {}).get("hbm_bytes_per_launch")
             roofline = {"bound": "hbm", "kernel": "hash_gather_planes_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -279,6 +281,11 @@ def main():
                         "request_ceiling": {"achieved": round(samples_per_launch * 128 / (avg_ms * 1e-3) / 1e9, 1),
                                             "peak": GATHER_REQ_PEAK / 1e9, "unit": "G 4-byte gathers/s",
                                             "frac": round(samples_per_launch * 128 / (avg_ms * 1e-3) / GATHER_REQ_PEAK, 4)},
+                        # what physically bounds it: each of the 128 hashed reads of a sample pulls one 128-byte line out of
+                        # an XCD's L2 into a CU's L1 (the primes are random on all three axes: no two corners share a line)
+                        "l2_line_bandwidth": {"achieved": round(samples_per_launch * 128 * 128 / (avg_ms * 1e-3) / 1e12, 2),
+                                              "peak": L2_PEAK_TBS, "unit": "TB/s (128-byte lines, L2 -> L1, all 8 XCDs)",
+                                              "frac": round(samples_per_launch * 128 * 128 / (avg_ms * 1e-3) / 1e12 / L2_PEAK_TBS, 4)},
                         # whole-path fractions from the same run -- table bytes 512*(rho+2) per meaningful sample
                         # against 8 TB/s, MLP flops (61440 + 6144 rho) against the 2.5 PFLOP/s dense f16 peak
                         "whole_path": {"gather_scatter_frac_of_hbm": round(value / max(world, 1) * 512 * (rho + 2) / 8.0e12, 5),

@@ -7,12 +7,12 @@
 #   3. --pmc SQ_*             : issue / wait breakdown         -> profiles/<tag>_pmc_sq.csv
 # Counter passes never share a run with tracing (gpurun refuses that combination).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-converged"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write.err
