@@ -254,6 +254,15 @@ def shade_fwd(n, feat, dirs, app_emb, sample_emb_idx, mlp_params_h, rgb, save_x_
                             _p(save_x_h, "h16", True)), "f2n_shade_fwd")
 
 
+def field_shade_fwd(n, src_rows, x_cache_h, field_params_h, dirs, app_emb, sample_emb_idx, color_params_h, out_f0, save_field_x_h,
+                    save_shade_x_h, rgb, n_dev=None):
+    _ck(lib().f2n_field_shade_fwd_dyn(_stream(), _i(n), _p(n_dev, "i32", True), _p(src_rows, "i32", True), _p(x_cache_h, "h16"),
+                                      _p(field_params_h, "h16"), _p(dirs, "f32"), _p(app_emb, "f32", True),
+                                      _p(sample_emb_idx, "i32", True), _p(color_params_h, "h16"), _p(out_f0, "f32", True),
+                                      _p(save_field_x_h, "h16", True), _p(save_shade_x_h, "h16", True), _p(rgb, "f32")),
+        "f2n_field_shade_fwd_dyn")
+
+
 def shade_bwd(n, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_scaled, dapp_emb, df0=None):
     _ck(lib().f2n_shade_bwd(_stream(), _i(n), _p(drgb, "f32"), _p(sample_emb_idx, "i32", True), _p(mlp_params_h, "h16"),
                             _p(saved_x_h, "h16"), _f(loss_scale), _p(dfeat, "f32"), _p(dparams_scaled, "f32"),

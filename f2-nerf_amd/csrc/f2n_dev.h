@@ -52,6 +52,13 @@ static_assert(sizeof(F2nChildInfo) == 32, "layout");
 static_assert(sizeof(F2nTreeNode) == 64 && sizeof(F2nTransInfo) == 544 && sizeof(F2nEdgePool) == 64, "layout");
 
 #if defined(__HIPCC__)
+// Wave issue priority of the compute-stream kernels.  The next batch's ray march runs on a second queue underneath the
+// backward; it is VALU-bound (two waves per SIMD issuing back to back) and, at equal priority, takes every other issue slot
+// from the MLP / compositing / scatter kernels it overlaps -- which are the step's critical path, while the march has slack.
+// Measured (profiles/r02_notes: s_setprio(2) on the compute-stream kernels): fresh scene unchanged (1.287 vs 1.28 ms), converged
+// scene WORSE (0.962 vs 0.93 ms: there the sampler's queue is as long as the compute queue, and the march slowed from 0.35 to
+// 0.38 ms) -- left at the default priority.
+#define F2N_RAISE_PRIO() ((void) 0)
 // Sum over the 16 lanes of a DPP row, result in every lane (quad butterflies, row_half_mirror, row_mirror): four VALU
 // instructions, no LDS round trip (a __shfl_xor ladder is four dependent ds_bpermute, ~100 cycles each for a lone wave).
 __device__ __forceinline__ float f2n_row16_allsum(float v) {

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
                                                        long gx_pair_stride, const uint16_t* __restrict__ nz_mask,
                                                        F2nBinQueues q, half_t* __restrict__ grad_table,
                                                        const int32_t* __restrict__ n_dev, int n_off) {
+  F2N_RAISE_PRIO();
   if (n_dev != nullptr) {  // the row count is still on the device: split what there really is over the producer blocks
     n = min(n, *n_dev + n_off);
     chunk = min(chunk, (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255);
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
 
 __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
                                                                   half_t* __restrict__ grad_table) {
+  F2N_RAISE_PRIO();
   __shared__ double s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp64 image of this block's table slice
   __shared__ int s_total;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(F2N_FWD_THREADS) void field_fwd_kernel(
     const half_t* __restrict__ params, float* __restrict__ out_feat_f32, half_t* __restrict__ out_feat_h,
     float* __restrict__ out_f0, half_t* __restrict__ save_x, const half_t* __restrict__ x_planes,
     const half_t* __restrict__ x_cache, const int32_t* __restrict__ src_rows, const int32_t* __restrict__ n_dev) {
+  F2N_RAISE_PRIO();
   __shared__ F2nLevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int n_alloc = n;  // the plane stride stays the allocated row count
@@ -709,6 +712,7 @@ __global__ __launch_bounds__(F2N_BWD_THREADS, BPC) void field_bwd_kernel(
     const half_t* __restrict__ x_h, const float* __restrict__ x_f32, const float* __restrict__ dy, float loss_scale,
     float* __restrict__ dparams, float* __restrict__ dx_f32, half_t* __restrict__ grad_table, half_t* __restrict__ dx_planes,
     uint16_t* __restrict__ nz_mask, const int32_t* __restrict__ n_dev, int n_off) {
+  F2N_RAISE_PRIO();
   const int n_alloc = n;  // plane stride / mask words: the allocated row count
   if (n_dev != nullptr) n = min(n, *n_dev + n_off);  // the row count is still on the device (f2n_field_bwd_dyn)
   __shared__ F2nBwdSmem<NH> sm;

@@ -23,7 +23,7 @@ SHShader::SHShader(GlobalDataPool* gdp) {  // SHShader.cpp:9-20
   degree_ = c.Int("shader.degree");
   d_hidden_ = c.Int("shader.d_hidden");
   n_hiddens_ = c.Int("shader.n_hiddens");
-  TORCH_CHECK(degree_ >= 1 && degree_ <= 4, "SH degree ", degree_, " is not supported (1..4)");
+  TORCH_CHECK(degree_ >= 1 && degree_ <= 8, "SH degree ", degree_, " is not supported (1..8; the fused colour path needs degree 4: 16 + 16 inputs)");
   mlp_ = std::make_unique<FusedMLP>(gdp, d_in_, d_out_, d_hidden_, n_hiddens_);
 }
 
@@ -508,30 +508,36 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   const int64_t so = fr.dyn ? 2 * (int64_t) n_edge : 0, eo = fr.dyn ? 0 : n_kept;
   const int32_t* n_dev = fr.dyn ? I32P(fr.n_kept_dev) : nullptr;
   // ---- forward ----
-  Tensor feat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32()), field_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
+  Tensor feat = torch::empty({fr.dyn ? std::max(2 * n_edge, 1) : n, F2N_MLP_OUT_PAD}, DevF32());
+  Tensor field_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
   // the density pre-activations of the surviving samples also leave as a compact array: compositing then reads 4 B per
   // sample instead of one 64-byte line of `feat` per sample, and its backward writes a compact d f0 that the colour
   // backward merges into the dfeat rows it writes anyway (column 0 written in place was a read-modify-write of every line)
   Tensor f0c = torch::empty({std::max(n_kept, 1)}, DevF32()), df0c = torch::empty({std::max(n_kept, 1)}, DevF32());
+  Tensor rgb = torch::empty({std::max(n_kept, 1), 3}, DevF32()), shade_x = torch::empty({std::max(n_kept, 1), 32}, DevF16());
+  Tensor app = fr.emb ? app_emb_ : Tensor();
   if (fr.dyn) {
+    // streaming step: field MLP (cached hash features) and colour path of the survivors in one launch -- their `feat` rows
+    // are never written (only the 2E edge rows of `feat` exist: the TV loss reads them); the synchronous path below keeps
+    // the two separate kernels and is what tests compare this with
     TORCH_CHECK(field->prepass_x_.defined(), "no pre-pass feature cache for this query");
-    F2N_TIMED_CALL("field_fwd_cached", f2n_field_fwd_cached_dyn(st, n_kept, n_dev, (int) field->prepass_x_.size(0), I32P(fr.src_rows),
-                           VoidP(field->prepass_x_), VoidP(field->mlp_->params_h_), F32P(feat) + F2N_MLP_OUT_PAD * so, F32P(f0c),
-                           static_cast<void*>(field_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * so)));
     if (n_edge > 0)
       F2N_TIMED_CALL("field_fwd", f2n_field_fwd(st, 2 * n_edge, field->n_volumes_, VoidP(field->feat_pool_h_), I32P(field->prim_pool_),
                              I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
                              F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
                              F32P(feat), nullptr, VoidP(field_x)));
+    F2N_TIMED_CALL("field_shade_fwd", f2n_field_shade_fwd_dyn(st, n_kept, n_dev, I32P(fr.src_rows), VoidP(field->prepass_x_),
+                           VoidP(field->mlp_->params_h_), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
+                           fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(f0c),
+                           static_cast<void*>(field_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * so), VoidP(shade_x),
+                           F32P(rgb)));
+    field->prepass_x_ = Tensor();
   } else {
     field->ForwardRaw(fr.pts_all, fr.vol_all, 1, fr.src_rows, n_kept, feat, field_x, &f0c);
+    field->prepass_x_ = Tensor();
+    F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(st, n_kept, F32P(feat), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
+                           fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(rgb), VoidP(shade_x)));
   }
-  field->prepass_x_ = Tensor();
-  Tensor rgb = torch::empty({std::max(n_kept, 1), 3}, DevF32()), shade_x = torch::empty({std::max(n_kept, 1), 32}, DevF16());
-  Tensor app = fr.emb ? app_emb_ : Tensor();
-  F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd_dyn(st, n_kept, n_dev, F32P(feat) + F2N_MLP_OUT_PAD * so, F32P(es.dirs),
-                         fr.emb ? F32P(app) : nullptr, fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_),
-                         F32P(rgb), VoidP(shade_x)));
   Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
   Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({std::max(n_kept, 1)}, DevF32());
   Tensor bg = fr.bg_color.contiguous();

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void early_stop_kernel(int n_rays, const int32
                                                          int f0_stride, const float* __restrict__ dt, float* __restrict__ weights,
                                                          float* __restrict__ alphas, int32_t* __restrict__ mask,
                                                          int32_t* __restrict__ kept) {
+  F2N_RAISE_PRIO();
   const int c = threadIdx.x & 15;
   const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int n_rays, const in
                                                             float* __restrict__ colors, float* __restrict__ disparity,
                                                             float* __restrict__ depth, float* __restrict__ weights,
                                                             float* __restrict__ out_vars) {
+  F2N_RAISE_PRIO();
   const int c = threadIdx.x & 15;
   const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
                                                             const float* __restrict__ ddepth, const float* __restrict__ dweights,
                                                             float gs_progress, float* __restrict__ drgb, float* __restrict__ df0, int df0_stride,
                                                             const float* __restrict__ var_weights, const float* __restrict__ dvars) {
+  F2N_RAISE_PRIO();
   const int c = threadIdx.x & 15;
   const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + (threadIdx.x >> 4);
   if (ray >= n_rays) return;

@@ -24,11 +24,73 @@ __device__ __forceinline__ void f2n_sh16(float x, float y, float z, float* o) {
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
+// Degrees 5..8 (SHShader.cu:51-102): only the stand-alone encoding seam offers them -- the fused colour path is built for
+// the 16 + 16 inputs every shipped config uses.  Same polynomial forms and operation order as the reference.
+__device__ __forceinline__ void f2n_sh_high(int degree, float x, float y, float z, float* o) {
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
+  const float x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;
+  if (degree <= 4) return;
+  o[16] = 2.5033429417967046f*xy*(x2 - y2);
+  o[17] = 1.7701307697799304f*yz*(-3.0f*x2 + y2);
+  o[18] = 0.94617469575756008f*xy*(7.0f*z2 - 1.0f);
+  o[19] = 0.66904654355728921f*yz*(3.0f - 7.0f*z2);
+  o[20] = -3.1735664074561294f*z2 + 3.7024941420321507f*z4 + 0.31735664074561293f;
+  o[21] = 0.66904654355728921f*xz*(3.0f - 7.0f*z2);
+  o[22] = 0.47308734787878004f*(x2 - y2)*(7.0f*z2 - 1.0f);
+  o[23] = 1.7701307697799304f*xz*(-x2 + 3.0f*y2);
+  o[24] = -3.7550144126950569f*x2*y2 + 0.62583573544917614f*x4 + 0.62583573544917614f*y4;
+  if (degree <= 5) return;
+  o[25] = 0.65638205684017015f*y*(10.0f*x2*y2 - 5.0f*x4 - y4);
+  o[26] = 8.3026492595241645f*xy*z*(x2 - y2);
+  o[27] = -0.48923829943525038f*y*(3.0f*x2 - y2)*(9.0f*z2 - 1.0f);
+  o[28] = 4.7935367849733241f*xy*z*(3.0f*z2 - 1.0f);
+  o[29] = 0.45294665119569694f*y*(14.0f*z2 - 21.0f*z4 - 1.0f);
+  o[30] = 0.1169503224534236f*z*(-70.0f*z2 + 63.0f*z4 + 15.0f);
+  o[31] = 0.45294665119569694f*x*(14.0f*z2 - 21.0f*z4 - 1.0f);
+  o[32] = 2.3967683924866621f*z*(x2 - y2)*(3.0f*z2 - 1.0f);
+  o[33] = -0.48923829943525038f*x*(x2 - 3.0f*y2)*(9.0f*z2 - 1.0f);
+  o[34] = 2.0756623148810411f*z*(-6.0f*x2*y2 + x4 + y4);
+  o[35] = 0.65638205684017015f*x*(10.0f*x2*y2 - x4 - 5.0f*y4);
+  if (degree <= 6) return;
+  o[36] = 1.3663682103838286f*xy*(-10.0f*x2*y2 + 3.0f*x4 + 3.0f*y4);
+  o[37] = 2.3666191622317521f*yz*(10.0f*x2*y2 - 5.0f*x4 - y4);
+  o[38] = 2.0182596029148963f*xy*(x2 - y2)*(11.0f*z2 - 1.0f);
+  o[39] = -0.92120525951492349f*yz*(3.0f*x2 - y2)*(11.0f*z2 - 3.0f);
+  o[40] = 0.92120525951492349f*xy*(-18.0f*z2 + 33.0f*z4 + 1.0f);
+  o[41] = 0.58262136251873131f*yz*(30.0f*z2 - 33.0f*z4 - 5.0f);
+  o[42] = 6.6747662381009842f*z2 - 20.024298714302954f*z4 + 14.684485723822165f*z6 - 0.31784601133814211f;
+  o[43] = 0.58262136251873131f*xz*(30.0f*z2 - 33.0f*z4 - 5.0f);
+  o[44] = 0.46060262975746175f*(x2 - y2)*(11.0f*z2*(3.0f*z2 - 1.0f) - 7.0f*z2 + 1.0f);
+  o[45] = -0.92120525951492349f*xz*(x2 - 3.0f*y2)*(11.0f*z2 - 3.0f);
+  o[46] = 0.50456490072872406f*(11.0f*z2 - 1.0f)*(-6.0f*x2*y2 + x4 + y4);
+  o[47] = 2.3666191622317521f*xz*(10.0f*x2*y2 - x4 - 5.0f*y4);
+  o[48] = 10.247761577878714f*x2*y4 - 10.247761577878714f*x4*y2 + 0.6831841051919143f*x6 - 0.6831841051919143f*y6;
+  if (degree <= 7) return;
+  o[49] = 0.70716273252459627f*y*(-21.0f*x2*y4 + 35.0f*x4*y2 - 7.0f*x6 + y6);
+  o[50] = 5.2919213236038001f*xy*z*(-10.0f*x2*y2 + 3.0f*x4 + 3.0f*y4);
+  o[51] = -0.51891557872026028f*y*(13.0f*z2 - 1.0f)*(-10.0f*x2*y2 + 5.0f*x4 + y4);
+  o[52] = 4.1513246297620823f*xy*z*(x2 - y2)*(13.0f*z2 - 3.0f);
+  o[53] = -0.15645893386229404f*y*(3.0f*x2 - y2)*(13.0f*z2*(11.0f*z2 - 3.0f) - 27.0f*z2 + 3.0f);
+  o[54] = 0.44253269244498261f*xy*z*(-110.0f*z2 + 143.0f*z4 + 15.0f);
+  o[55] = 0.090331607582517306f*y*(-135.0f*z2 + 495.0f*z4 - 429.0f*z6 + 5.0f);
+  o[56] = 0.068284276912004949f*z*(315.0f*z2 - 693.0f*z4 + 429.0f*z6 - 35.0f);
+  o[57] = 0.090331607582517306f*x*(-135.0f*z2 + 495.0f*z4 - 429.0f*z6 + 5.0f);
+  o[58] = 0.07375544874083044f*z*(x2 - y2)*(143.0f*z2*(3.0f*z2 - 1.0f) - 187.0f*z2 + 45.0f);
+  o[59] = -0.15645893386229404f*x*(x2 - 3.0f*y2)*(13.0f*z2*(11.0f*z2 - 3.0f) - 27.0f*z2 + 3.0f);
+  o[60] = 1.0378311574405206f*z*(13.0f*z2 - 3.0f)*(-6.0f*x2*y2 + x4 + y4);
+  o[61] = -0.51891557872026028f*x*(13.0f*z2 - 1.0f)*(-10.0f*x2*y2 + x4 + 5.0f*y4);
+  o[62] = 2.6459606618019f*z*(15.0f*x2*y4 - 15.0f*x4*y2 + x6 - y6);
+  o[63] = 0.70716273252459627f*x*(-35.0f*x2*y4 + 21.0f*x4*y2 - x6 + 7.0f*y6);
+}
+
 __global__ void sh_encode_kernel(int n, int degree, const float* __restrict__ dirs, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float sh[16];
-  f2n_sh16(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], sh);
+  float sh[64];
+  const float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
+  f2n_sh16(x, y, z, sh);
+  if (degree > 4) f2n_sh_high(degree, x, y, z, sh);
   const int w = degree * degree;
   for (int k = 0; k < w; k++) out[(size_t) i * w + k] = sh[k];
 }
@@ -79,6 +141,7 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(int n, const float* __re
                                                         const int32_t* __restrict__ sample_emb_idx,
                                                         const half_t* __restrict__ params, float* __restrict__ rgb,
                                                         half_t* __restrict__ save_x, const int32_t* __restrict__ n_dev) {
+  F2N_RAISE_PRIO();
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   if (n_dev != nullptr) n = min(n, *n_dev);  // the sample count is still on the device (see f2n_shade_fwd_dyn)
   F2nMlpFwdW<2> w;
@@ -105,6 +168,107 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(int n, const float* __re
   }
 }
 
+// Field MLP + colour path of the grad pass in ONE kernel (Renderer.cpp:152-189 for the surviving samples): the density
+// network's D tiles -- lane (c = sample, g) holds outputs 4g..4g+3 -- ARE the K-slots 4g..4g+3 of the colour network's input
+// fragment, so `feat` [M,16] never exists in memory: x_cache rows (h16 hash features of the pre-pass, through src_rows) ->
+// field MLP -> f16 rounding -> [1 | feat[1:]] + app_emb -> | SH4(dir) -> colour MLP -> sigmoid.  Written: the compact density
+// pre-activation f0 [M] (compositing), the two networks' h16 inputs (their backward passes recompute everything else) and
+// rgb.  Bit-identical to f2n_field_fwd_cached followed by f2n_shade_fwd (same fragments, same MFMA chains, same roundings).
+// Inputs of the next tile are in flight while the current one goes through its 20 MFMAs.
+__global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32_t* __restrict__ n_dev, const int32_t* __restrict__ src_rows,
+                                                              const half_t* __restrict__ x_cache, const half_t* __restrict__ field_params,
+                                                              const float* __restrict__ dirs, const float* __restrict__ app_emb,
+                                                              const int32_t* __restrict__ sample_emb_idx,
+                                                              const half_t* __restrict__ color_params, float* __restrict__ out_f0,
+                                                              half_t* __restrict__ save_field_x, half_t* __restrict__ save_shade_x,
+                                                              float* __restrict__ rgb) {
+  F2N_RAISE_PRIO();
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  if (n_dev != nullptr) n = min(n, *n_dev);
+  F2nMlpFwdW<1> wf;
+  wf.load(field_params, c, g);
+  F2nMlpFwdW<2> wc;
+  wc.load(color_params, c, g);
+  const int n_tiles = (n + 15) / 16;
+  const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
+  struct In {
+    half8_t xf;
+    float4_t e;
+    float d[3];
+  };
+  struct Idx {
+    int row, img;
+  };
+  const bool emb = app_emb != nullptr;
+  auto fetch_idx = [&](int tile) {
+    const int s = min(tile * 16 + c, n - 1);
+    Idx r;
+    r.row = src_rows != nullptr ? src_rows[s] : s;
+    r.img = emb ? sample_emb_idx[s] : 0;
+    return r;
+  };
+  auto fetch = [&](int tile, const Idx& ix) {
+    const int s = min(tile * 16 + c, n - 1);
+    In r;
+    r.xf = f2n_rowfrag(x_cache, F2N_D_IN, ix.row, 0, g);
+    r.e = emb ? *(const float4_t*) (app_emb + (size_t) ix.img * 16 + 4 * g) : float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; k++) r.d[k] = dirs[3 * (size_t) s + k];
+    return r;
+  };
+  if (wave_global >= n_tiles) return;
+  Idx ix_next = fetch_idx(wave_global);
+  In cur = fetch(wave_global, ix_next);
+  ix_next = fetch_idx(min(wave_global + wave_stride, n_tiles - 1));
+  for (int tile = wave_global; tile < n_tiles; tile += wave_stride) {
+    const int t1 = min(tile + wave_stride, n_tiles - 1), t2 = min(tile + 2 * wave_stride, n_tiles - 1);
+    const In nxt = fetch(t1, ix_next);  // (past the end: a harmless re-read of the last tile)
+    ix_next = fetch_idx(t2);
+    __builtin_amdgcn_sched_barrier(0);
+    const int s = tile * 16 + c;
+    const bool valid = s < n;
+    const half8_t xf = valid ? cur.xf : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    if (save_field_x != nullptr && valid) {
+      half_t* p = save_field_x + (size_t) s * F2N_D_IN + 4 * g;
+      *(half4_t*) p = __builtin_shufflevector(xf, xf, 0, 1, 2, 3);
+      *(half4_t*) (p + 16) = __builtin_shufflevector(xf, xf, 4, 5, 6, 7);
+    }
+    const float4_t o = wf.forward(xf);  // lane (c = sample, g): field outputs 4g..4g+3
+    float4_t f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) f[r] = (float) (half_t) o[r];  // f16 output precision (TCNNWP.cpp:143-144), widened (:112)
+    if (valid && g == 0 && out_f0 != nullptr) out_f0[s] = f[0];
+    if (g == 0) f[0] = 1.f;  // Renderer.cpp:181-182
+    if (emb) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) f[r] = f[r] + cur.e[r];  // Scatter.cu:10-18
+    }
+    float sh[16];
+    f2n_sh16(cur.d[0], cur.d[1], cur.d[2], sh);
+    half8_t xs;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      xs[r] = valid ? (half_t) f[r] : (half_t) 0.f;
+      const float v = (g == 0) ? sh[r] : (g == 1) ? sh[4 + r] : (g == 2) ? sh[8 + r] : sh[12 + r];
+      xs[4 + r] = valid ? (half_t) v : (half_t) 0.f;
+    }
+    if (save_shade_x != nullptr && valid) {
+      half_t* p = save_shade_x + (size_t) s * F2N_D_IN + 4 * g;
+      *(half4_t*) p = __builtin_shufflevector(xs, xs, 0, 1, 2, 3);
+      *(half4_t*) (p + 16) = __builtin_shufflevector(xs, xs, 4, 5, 6, 7);
+    }
+    const float4_t oc = wc.forward(xs);
+    if (valid && g == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float ov = (float) (half_t) oc[r];
+        rgb[3 * (size_t) s + r] = (1.f + 2.f * F2N_SHADE_EPS) / (1.f + expf(-ov)) - F2N_SHADE_EPS;
+      }
+    }
+    cur = nxt;
+  }
+}
+
 union F2nShadeSmem {
   F2nMlpLds<2> w;
   float acc[2 * (F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID)];  // two images, see f2n_mlp_flush_dw
@@ -117,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
                                                         float* __restrict__ dparams, int n_emb,
                                                         float* __restrict__ emb_partials, const float* __restrict__ df0,
                                                         const int32_t* __restrict__ n_dev, float* __restrict__ emb_global) {
+  F2N_RAISE_PRIO();
   // emb_partials: per-block LDS image of the appearance-embedding gradient, flushed as a partial (n_emb <= 480);
   // emb_global: more images than fit into LDS -- row sums go straight to the gradient with global atomics, as the
   // reference's ScatterAddFuncBackward does (Scatter.cu:20-40)
@@ -260,7 +425,7 @@ extern "C" {
 
 int f2n_sh_encode(void* stream, int n, int degree, const float* dirs, float* out) {
   if (n < 0) return F2N_ERR_INVALID_ARG;
-  if (degree < 1 || degree > 4) return F2N_ERR_UNSUPPORTED;
+  if (degree < 1 || degree > 8) return F2N_ERR_UNSUPPORTED;
   if (n == 0) return F2N_OK;
   hipLaunchKernelGGL(sh_encode_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n, degree, dirs, out);
   return f2n_launch_status();
@@ -286,6 +451,19 @@ int f2n_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
   if (n == 0) return F2N_OK;
   hipLaunchKernelGGL(shade_fwd_kernel, dim3(f2n_shade_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, feat,
                      dirs, app_emb, sample_emb_idx, (const half_t*) mlp_params_h, rgb, (half_t*) save_x_h, n_dev);
+  return f2n_launch_status();
+}
+
+int f2n_field_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const int32_t* src_rows, const void* x_cache_h,
+                            const void* field_params_h, const float* dirs, const float* app_emb, const int32_t* sample_emb_idx,
+                            const void* color_params_h, float* out_f0, void* save_field_x_h, void* save_shade_x_h, float* rgb) {
+  const int n = n_max;
+  if (n < 0 || (n > 0 && (x_cache_h == nullptr || rgb == nullptr)) || (app_emb != nullptr && sample_emb_idx == nullptr))
+    return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(field_shade_fwd_kernel, dim3(f2n_shade_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, n_dev,
+                     src_rows, (const half_t*) x_cache_h, (const half_t*) field_params_h, dirs, app_emb, sample_emb_idx,
+                     (const half_t*) color_params_h, out_f0, (half_t*) save_field_x_h, (half_t*) save_shade_x_h, rgb);
   return f2n_launch_status();
 }
 

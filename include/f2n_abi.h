@@ -280,7 +280,7 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
 /* ---------------------------------------------------------------------------------------------------
  * Shader -- replaces SHShader::Query (Shader/SHShader.cpp:23-29) and SHKenerl (Shader/SHShader.cu:10-118).
  * ------------------------------------------------------------------------------------------------- */
-int f2n_sh_encode(void* stream, int n, int degree /*1..4*/, const float* dirs /*[n,3]*/, float* out /*[n,degree^2]*/);
+int f2n_sh_encode(void* stream, int n, int degree /*1..8*/, const float* dirs /*[n,3]*/, float* out /*[n,degree^2]*/);
 
 /* ScatterIdxKernal (Utils/CustomOps/Scatter.cu:110-120): out[i] = ray_val[r] for every sample i of ray r. */
 int f2n_scatter_idx(void* stream, int n_rays, const int32_t* start_end, const int32_t* ray_val, int32_t* out /*[n]*/);
@@ -345,6 +345,14 @@ int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, 
                       int level_entries);
 int f2n_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* feat, const float* dirs, const float* app_emb,
                       const int32_t* sample_emb_idx, const void* mlp_params_h, float* rgb, void* save_x_h);
+/* f2n_field_fwd_cached + f2n_shade_fwd in one launch for the surviving samples of the grad pass (Renderer.cpp:152-189): the
+ * field network's outputs go straight into the colour network's input fragment, `feat` [n,16] is never written.  Outputs:
+ * out_f0 [n] (density pre-activation, for compositing), save_field_x_h / save_shade_x_h [n,32] (h16 inputs of the two
+ * networks, for f2n_field_bwd / f2n_shade_bwd; either may be NULL), rgb [n,3].  Bit-identical to the two separate calls.
+ * src_rows NULL: row i of x_cache_h.  n_dev as above (may be NULL). */
+int f2n_field_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const int32_t* src_rows, const void* x_cache_h,
+                            const void* field_params_h, const float* dirs, const float* app_emb, const int32_t* sample_emb_idx,
+                            const void* color_params_h, float* out_f0, void* save_field_x_h, void* save_shade_x_h, float* rgb);
 int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* drgb, const int32_t* sample_emb_idx,
                       const void* mlp_params_h, const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled,
                       float* dapp_emb, int n_emb, const float* df0);

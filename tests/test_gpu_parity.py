@@ -621,6 +621,47 @@ def test_field_forward_from_prepass_cache(hip, fox_state, fox_golden):
         hip.field_fwd_cached(n + 1, n, None, cache, ph, torch.zeros((n + 1, 16), device=DEV), None, None)
 
 
+@pytest.mark.parametrize("use_emb,use_ndev", [(True, False), (False, True)])
+def test_field_and_shade_forward_in_one_launch(hip, fox_state, fox_golden, use_emb, use_ndev):
+    """f2n_field_shade_fwd_dyn (field MLP on cached hash features -> colour path, `feat` never in memory) must equal
+    f2n_field_fwd_cached followed by f2n_shade_fwd bit for bit: rgb, f0, both saved network inputs.  With a device-side
+    count only the first *n_dev rows are produced."""
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(29)
+    grid = make_grid(st, rng, 14, scale=0.5)
+    pf, pc = rand_params(rng, 1), rand_params(rng, 2)
+    pts, anchors, dirs, se = g["march_pts"], g["march_anchors"], g["march_dirs"], g["march_pts_idx_bounds"]
+    n = len(pts)
+    gd = grid_dev(grid)
+    phf, phc = T(oc.f2h(pf).view(np.float16)), T(oc.f2h(pc).view(np.float16))
+    cache = torch.zeros((n, 32), dtype=torch.float16, device=DEV)
+    hip.field_fwd(n, grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts),
+                  T(anchors), 3, phf, None, torch.zeros(n, device=DEV), cache)
+    rows = np.sort(rng.choice(n, size=n // 2 + 7, replace=False)).astype(np.int32)
+    m = len(rows)
+    emb = T((rng.standard_normal((50, 16)) * 0.1).astype(F32)) if use_emb else None
+    sidx = T(oc.scatter_idx(n, se, g["cam"])[rows]) if use_emb else None
+    d_rows, d_dirs = T(rows), T(dirs[rows])
+    # separate kernels
+    feat = torch.zeros((m, 16), device=DEV); f0 = torch.zeros(m, device=DEV)
+    fx = torch.zeros((m, 32), dtype=torch.float16, device=DEV); sx = torch.zeros((m, 32), dtype=torch.float16, device=DEV)
+    rgb = torch.zeros((m, 3), device=DEV)
+    hip.field_fwd_cached(m, n, d_rows, cache, phf, feat, f0, fx)
+    hip.shade_fwd(m, feat, d_dirs, emb, sidx, phc, rgb, sx)
+    # one launch
+    m_dyn = m - 1000 if use_ndev else m
+    n_dev = torch.tensor([m_dyn], dtype=torch.int32, device=DEV) if use_ndev else None
+    f0b = torch.full((m,), -7.0, device=DEV); rgbb = torch.full((m, 3), -7.0, device=DEV)
+    fxb = torch.zeros((m, 32), dtype=torch.float16, device=DEV); sxb = torch.zeros((m, 32), dtype=torch.float16, device=DEV)
+    hip.field_shade_fwd(m, d_rows, cache, phf, d_dirs, emb, sidx, phc, f0b, fxb, sxb, rgbb, n_dev=n_dev)
+    assert_same(N(rgbb)[:m_dyn], N(rgb)[:m_dyn], "rgb")
+    assert_same(N(f0b)[:m_dyn], N(f0)[:m_dyn], "f0")
+    assert_same(N(fxb).view(np.uint16)[:m_dyn], N(fx).view(np.uint16)[:m_dyn], "field input rows")
+    assert_same(N(sxb).view(np.uint16)[:m_dyn], N(sx).view(np.uint16)[:m_dyn], "colour input rows")
+    if use_ndev:  # rows past the device-side count are untouched
+        assert (N(rgbb)[m_dyn:] == -7.0).all() and (N(f0b)[m_dyn:] == -7.0).all()
+
+
 @pytest.mark.parametrize("n_emb", [0, 50, 480, 1500])  # 480: the largest per-block LDS image (> 64 KB of LDS); above: global atomics
 def test_shade_fused_forward_backward(hip, fox_golden, n_emb):
     use_emb = n_emb > 0
@@ -676,8 +717,12 @@ def test_sh_encode(hip, fox_golden):
     out = torch.zeros((len(d3), 9), device=DEV)
     hip.sh_encode(len(d3), 3, T(d3), out)
     assert_same(N(out), fox_golden["sh3"], "sh3")
+    for deg in (5, 6, 7, 8):  # SHShader.cu:51-102: the oracle is pinned to the reference kernel for every degree
+        out = torch.zeros((len(d3), deg * deg), device=DEV)
+        hip.sh_encode(len(d3), deg, T(d3), out)
+        assert_same(N(out), oc.sh_encode(d3, deg), "sh%d" % deg)
     with pytest.raises(Exception):
-        hip.sh_encode(4, 5, T(d[:4]), torch.zeros((4, 25), device=DEV))  # unsupported degree fails loudly
+        hip.sh_encode(4, 9, T(d[:4]), torch.zeros((4, 81), device=DEV))  # unsupported degree fails loudly
 
 
 # ---------------------------------------------------------------------------------------------------

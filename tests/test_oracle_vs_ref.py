@@ -125,7 +125,7 @@ def test_small_ops_random():
     same(ref.count_valid(se, mask), capi.count_valid(se, mask))
     dirs = rng.standard_normal((500, 3)).astype(np.float32)
     dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
-    for deg in (1, 2, 3, 4):
+    for deg in (1, 2, 3, 4, 5, 6, 7, 8):  # SHShader.cu:32-102, every degree the reference kernel offers
         same(ref.sh_encode(dirs, deg), capi.sh_encode(dirs, deg))
     emb = rng.standard_normal((43, 16)).astype(np.float32)
     eidx = rng.integers(0, 43, R).astype(np.int32)
