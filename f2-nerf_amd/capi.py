@@ -391,6 +391,32 @@ def adam_small_groups(groups, step, lr, beta1, beta2, eps, zero_grad, flags=None
                                     _i(int(zero_grad)), _p(flags, "i32", True), _p(skip_flag, "i32", True)), "f2n_adam_small_groups")
 
 
+def adam_fused(groups, table, step, lr, beta1, beta2, eps, zero_grad, skip_flag=None):
+    """groups as in adam_small_groups (check_finite ignored); table: dict {param, grad_h, exp_avg, exp_avg_sq, param_h, grad_scale, n}
+    or None; ONE launch (f2n_adam_fused)."""
+    arr = (_AdamGroup * max(len(groups), 1))()
+    for a, g in zip(arr, groups):
+        a.param = _p(g["param"], "f32").value
+        a.grad = _p(g["grad"], "f32").value
+        a.exp_avg = _p(g["exp_avg"], "f32").value
+        a.exp_avg_sq = _p(g["exp_avg_sq"], "f32").value
+        a.param_h = _p(g.get("param_h"), "h16", True).value
+        a.n = int(g["param"].numel())
+        a.grad_scale = float(g["grad_scale"])
+        a.weight_decay = float(g["weight_decay"])
+        a.grad_round_h16 = int(bool(g.get("grad_round_h16", False)))
+        a.check_finite = 0
+    t = table or {}
+    _ck(lib().f2n_adam_fused(_stream(), _i(len(groups)), arr, _i(int(t.get("n", 0))), _p(t.get("param"), "f32", True),
+                             _p(t.get("grad_h"), "h16", True), _f(float(t.get("grad_scale", 1.0))), _p(t.get("exp_avg"), "f32", True),
+                             _p(t.get("exp_avg_sq"), "f32", True), _p(t.get("param_h"), "h16", True), _i(step), _f(lr), _f(beta1),
+                             _f(beta2), _f(eps), _i(int(zero_grad)), _p(skip_flag, "i32", True)), "f2n_adam_fused")
+
+
+def reduce_deferred():
+    _ck(lib().f2n_reduce_deferred(_stream()), "f2n_reduce_deferred")
+
+
 def adam_step_h16grad(n, param, grad_h, grad_scale, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
                       zero_grad, skip_flag=None):
     _ck(lib().f2n_adam_step_h16grad(_stream(), _i(n), _p(param, "f32"), _p(grad_h, "h16"), _f(grad_scale),

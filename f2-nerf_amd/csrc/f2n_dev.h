@@ -80,6 +80,7 @@ static inline unsigned f2n_div_up(long a, long b) { return (unsigned) ((a + b - 
 // workspace.hip: internal per-device scratch + the partial-sum reduction used by the backward kernels
 void* f2n_ws_get(int slot, size_t bytes);
 int f2n_reduce_partials(void* stream, int n, int n_blocks, const float* partials, float* out);
+int f2n_defer_reduction(int n, int n_blocks, const float* partials, float* out);  // folded later by f2n_reduce_deferred
 #define F2N_WS_FIELD_DW 0
 #define F2N_WS_SHADE_DW 1
 #define F2N_WS_SHADE_EMB 2

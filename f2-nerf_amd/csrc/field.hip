@@ -1116,14 +1116,14 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
                   const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h, int level_entries) {
   return f2n_field_bwd_dyn(stream, n, nullptr, 0, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped,
                            volume_idx, vol_stride, mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_f32_scaled, grad_table_h,
-                           level_entries);
+                           level_entries, 0);
 }
 
 int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, int n_volumes, const int32_t* prim_pool,
                       const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
                       const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
                       const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h,
-                      int level_entries) {
+                      int level_entries, int defer_reduce) {
   const int n = n_max;
   if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f) || level_entries < 0 || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
@@ -1157,6 +1157,7 @@ int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, 
                             dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries, n_dev, n_off);
     if (rc != F2N_OK) return rc;
   }
+  if (defer_reduce) return f2n_defer_reduction(n_params, (int) blocks, partials, dparams_f32_scaled);
   return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
 }
 

@@ -108,10 +108,10 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
   torch::NoGradGuard no_grad;
-  // the small fp32 groups (field MLP, colour MLP, app_emb) in ONE launch, in the order the flag layout names them
+  // the small fp32 groups (field MLP, colour MLP, app_emb), in the order the flag layout names them
   F2nAdamGroup small[4];
   int n_small = 0;
-  auto add_small = [&](size_t i, bool check) {
+  auto add_small = [&](size_t i) {
     auto& g = groups_[i];
     float scale = g.grad_scale;
     if (scale < 0.f) scale = 1.f / (g.name == "color_mlp" ? shader->mlp_->loss_scale_ : field->mlp_->loss_scale_);
@@ -125,38 +125,46 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
     d.grad_scale = scale;
     d.weight_decay = g.weight_decay;
     d.grad_round_h16 = g.grad_round_h16 ? 1 : 0;
-    d.check_finite = check ? 1 : 0;
+    d.check_finite = 0;
     TORCH_CHECK(n_small < 4, "too many small parameter groups");
     small[n_small++] = d;
   };
-  const bool flags = compute_flags != nullptr;
   for (size_t i = 0; i < groups_.size(); i++)
-    if (groups_[i].name == "field_mlp") add_small(i, flags);
+    if (groups_[i].name == "field_mlp") add_small(i);
   for (size_t i = 0; i < groups_.size(); i++)
-    if (groups_[i].name == "color_mlp") add_small(i, flags);
-  TORCH_CHECK(!flags || n_small == 2, "finiteness flags need the field and colour MLP groups");
+    if (groups_[i].name == "color_mlp") add_small(i);
   // torch::optim::Adam skips parameters whose gradient is undefined: without the appearance embedding in use nothing ever
   // writes app_emb's gradient, and stepping it with weight decay alone (g = wd * p through Adam's normalisation) would walk
   // the embedding to zero at lr per step
   for (size_t i = 0; i < groups_.size(); i++)
     if (!groups_[i].grad_is_h16 && groups_[i].name != "field_mlp" && groups_[i].name != "color_mlp" &&
         (groups_[i].name != "app_emb" || renderer_->use_app_emb_))
-      add_small(i, false);
-  if (n_small > 0)
-    F2N_TIMED_CALL("adam", f2n_adam_small_groups(st, n_small, small, optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, /*zero_grad=*/1,
-                                                 compute_flags, skip_flag));
-  const int32_t* table_skip = flags ? compute_flags + 2 : skip_flag;  // (callers pass one or the other)
+      add_small(i);
+  // TCNNWP.cpp:234-240 on the device: flags = {field MLP gradient non-finite, colour MLP gradient non-finite, either}; every
+  // update of this step is predicated on flags[2] -- computed by its own small launch so that the ONE launch that steps all
+  // groups (f2n_adam_fused) has no block-wide dependency in it
+  const int32_t* skip = skip_flag;
+  if (compute_flags != nullptr) {
+    F2N_TIMED_CALL("adam", f2n_nonfinite_flags(st, field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
+                                               F32P(shader->mlp_->grad_scaled_), compute_flags));
+    skip = compute_flags + 2;
+  }
+  int n_table = 0;
+  float *tp = nullptr, *tm = nullptr, *tv = nullptr;
+  void *tg = nullptr, *th = nullptr;
+  float tscale = 1.f;
   for (size_t i = 0; i < groups_.size(); i++) {
     auto& g = groups_[i];
     if (!g.grad_is_h16) continue;
-    const int64_t n = g.active > 0 ? g.active : g.param.numel();
-    float scale = g.grad_scale;
-    if (scale < 0.f) scale = 1.f / (g.name == "color_mlp" ? shader->mlp_->loss_scale_ : field->mlp_->loss_scale_);
-    F2N_TIMED_CALL("adam_table", f2n_adam_step_h16grad(st, (int) n, F32P(g.param), VoidP(g.grad), scale, F32P(exp_avg_[i]),
-                                   F32P(exp_avg_sq_[i]), optim_steps_, cur_lr_, 0.9f, 0.99f, 1e-15f, g.weight_decay,
-                                   VoidP(g.param_h), /*zero_grad=*/1, table_skip));
+    TORCH_CHECK(n_table == 0, "one h16-gradient table group expected");
+    n_table = (int) (g.active > 0 ? g.active : g.param.numel());
+    tp = F32P(g.param); tg = VoidP(g.grad); tm = F32P(exp_avg_[i]); tv = F32P(exp_avg_sq_[i]); th = VoidP(g.param_h);
+    tscale = g.grad_scale;
+    TORCH_CHECK(g.weight_decay == 0.f, "the table group has no weight decay (Hash3DAnchored.cpp:124-150)");
     if (g.name == "feat_pool") field->grad_clean_ = true;
   }
+  F2N_TIMED_CALL("adam_table", f2n_adam_fused(st, n_small, small, n_table, tp, tg, tscale, tm, tv, th, optim_steps_, cur_lr_, 0.9f, 0.99f,
+                                              1e-15f, /*zero_grad=*/1, skip));
   renderer_->small_grads_clean_ = true;  // every group's gradient was consumed and cleared (also on the skipped path)
 }
 

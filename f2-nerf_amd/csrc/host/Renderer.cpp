@@ -560,14 +560,16 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd_dyn(st, n_kept, n_dev, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
                          VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat) + F2N_MLP_OUT_PAD * so,
                          F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,
-                         fr.emb ? (int) app_emb_grad_.size(0) : 0, F32P(df0c)));
+                         fr.emb ? (int) app_emb_grad_.size(0) : 0, F32P(df0c), /*defer_reduce=*/fr.dyn ? 1 : 0));
   if (fr.dyn) {
     field->grad_clean_ = false;
     F2N_TIMED_CALL("field_bwd", f2n_field_bwd_dyn(st, n, n_dev, 2 * n_edge, field->n_volumes_, I32P(field->prim_pool_),
                            I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
                            F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
                            VoidP(field_x), F32P(dfeat), field->mlp_->loss_scale_, F32P(field->mlp_->grad_scaled_),
-                           VoidP(field->grad_h_), field->pool_size_ / N_LEVELS));
+                           VoidP(field->grad_h_), field->pool_size_ / N_LEVELS, /*defer_reduce=*/1));
+    // the three partial-sum reductions (colour-MLP weights, appearance embedding, field-MLP weights) in one launch
+    F2N_TIMED_CALL("reduce_partials", f2n_reduce_deferred(st));
   } else {
     field->BackwardRaw(fr.pts_all, fr.vol_all, 1, field_x, dfeat);
   }

@@ -245,6 +245,68 @@ __global__ __launch_bounds__(1024) void adam_small_groups_kernel(F2nAdamGroupsDe
   }
 }
 
+// Every parameter group of an iteration in ONE launch: the first `small_blocks` blocks step the small fp32 groups (flat index
+// over the concatenated groups), the others the hash table (the adam_h16grad_kernel body).  All of it is predicated on a flag
+// that a previous launch computed (f2n_nonfinite_flags: flags[2]), so nothing here waits for anything block-wide -- the
+// single-block flags-then-step launch this replaces took 21 us in front of the 41 us table pass, on the step's tail.
+__global__ __launch_bounds__(256) void adam_fused_kernel(F2nAdamGroupsDev gs, int n_groups, int small_blocks, int n4,
+                                                         float4_t* __restrict__ param, half4_t* __restrict__ grad,
+                                                         float4_t* __restrict__ exp_avg, float4_t* __restrict__ exp_avg_sq,
+                                                         F2nAdamCoef k, half4_t* __restrict__ param_h, int zero_grad,
+                                                         const int32_t* __restrict__ skip_flag) {
+  const bool skip = skip_flag != nullptr && *skip_flag != 0;
+  if ((int) blockIdx.x < small_blocks) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < F2N_ADAM_MAX_GROUPS; q++) {
+      if (q >= n_groups) break;
+      const F2nAdamGroupDev& G = gs.g[q];
+      if (i < G.n) {
+        float g = G.grad[i];
+        if (zero_grad) G.grad[i] = 0.f;
+        if (!skip) {
+          if (G.grad_round_h16) g = (float) (half_t) ((float) (half_t) g * G.k.grad_scale);
+          else g = g * G.k.grad_scale;
+          float m = G.exp_avg[i], v = G.exp_avg_sq[i];
+          const float p = f2n_adam_update(G.param[i], g, m, v, G.k);
+          G.param[i] = p;
+          G.exp_avg[i] = m;
+          G.exp_avg_sq[i] = v;
+          if (G.param_h != nullptr) G.param_h[i] = (half_t) p;
+        }
+        return;
+      }
+      i -= G.n;
+    }
+    return;
+  }
+  const int stride = (gridDim.x - small_blocks) * blockDim.x;
+  const int first = (blockIdx.x - small_blocks) * blockDim.x + threadIdx.x;
+  if (skip) {  // dropped iteration: leave parameters and moments, only clear the gradient
+    if (zero_grad)
+      for (int i = first; i < n4; i += stride) grad[i] = half4_t{0, 0, 0, 0};
+    return;
+  }
+  for (int i = first; i < n4; i += stride) {
+    const half4_t gh = grad[i];
+    float4_t p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+    half4_t ph;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float mm = m[c], vv = v[c];
+      p[c] = f2n_adam_update(p[c], (float) gh[c] * k.grad_scale, mm, vv, k);
+      m[c] = mm;
+      v[c] = vv;
+      ph[c] = (half_t) p[c];
+    }
+    param[i] = p;
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    param_h[i] = ph;
+    if (zero_grad) grad[i] = half4_t{0, 0, 0, 0};
+  }
+}
+
 static F2nAdamCoef f2n_adam_coef(int step, float lr, float beta1, float beta2, float eps, float wd, float grad_scale) {
   const double bc1 = 1.0 - pow((double) beta1, (double) step);
   const double bc2 = 1.0 - pow((double) beta2, (double) step);
@@ -309,6 +371,41 @@ int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups
     gs.g[q].k = f2n_adam_coef(step, lr, beta1, beta2, eps, g.weight_decay, g.grad_scale);
   }
   hipLaunchKernelGGL(adam_small_groups_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, gs, n_groups, zero_grad, flags, skip_flag);
+  return f2n_launch_status();
+}
+
+int f2n_adam_fused(void* stream, int n_groups, const F2nAdamGroup* groups, int n_table, float* table_param, void* table_grad_h,
+                   float table_grad_scale, float* table_exp_avg, float* table_exp_avg_sq, void* table_param_h, int step, float lr,
+                   float beta1, float beta2, float eps, int zero_grad, const int32_t* skip_flag) {
+  if (n_groups < 0 || n_groups > F2N_ADAM_MAX_GROUPS || (n_groups > 0 && groups == nullptr) || step < 1 || n_table < 0 ||
+      (n_table & 3) != 0 || (n_table > 0 && (table_param == nullptr || table_grad_h == nullptr || table_param_h == nullptr)))
+    return F2N_ERR_INVALID_ARG;
+  F2nAdamGroupsDev gs = {};
+  long n_small = 0;
+  for (int q = 0; q < n_groups; q++) {
+    const F2nAdamGroup& g = groups[q];
+    if (g.n < 0 || (g.n > 0 && (g.param == nullptr || g.grad == nullptr || g.exp_avg == nullptr || g.exp_avg_sq == nullptr)))
+      return F2N_ERR_INVALID_ARG;
+    gs.g[q].param = g.param;
+    gs.g[q].grad = g.grad;
+    gs.g[q].exp_avg = g.exp_avg;
+    gs.g[q].exp_avg_sq = g.exp_avg_sq;
+    gs.g[q].param_h = (half_t*) g.param_h;
+    gs.g[q].n = g.n;
+    gs.g[q].grad_round_h16 = g.grad_round_h16;
+    gs.g[q].check_finite = 0;
+    gs.g[q].k = f2n_adam_coef(step, lr, beta1, beta2, eps, g.weight_decay, g.grad_scale);
+    n_small += g.n;
+  }
+  const int small_blocks = (int) ((n_small + 255) / 256);
+  const int n4 = n_table / 4;
+  unsigned table_blocks = n4 > 0 ? f2n_div_up(n4, 256) : 0;
+  if (table_blocks > 8192) table_blocks = 8192;
+  if (small_blocks + table_blocks == 0) return F2N_OK;
+  const F2nAdamCoef k = f2n_adam_coef(step, lr, beta1, beta2, eps, 0.f, table_grad_scale);
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(small_blocks + table_blocks), dim3(256), 0, (hipStream_t) stream, gs, n_groups, small_blocks,
+                     n4, (float4_t*) table_param, (half4_t*) table_grad_h, (float4_t*) table_exp_avg, (float4_t*) table_exp_avg_sq, k,
+                     (half4_t*) table_param_h, zero_grad, skip_flag);
   return f2n_launch_status();
 }
 

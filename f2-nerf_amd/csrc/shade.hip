@@ -471,12 +471,12 @@ int f2n_shade_bwd(void* stream, int n, const float* drgb, const int32_t* sample_
                   const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled, float* dapp_emb,
                   int n_emb, const float* df0) {
   return f2n_shade_bwd_dyn(stream, n, nullptr, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_f32_scaled,
-                           dapp_emb, n_emb, df0);
+                           dapp_emb, n_emb, df0, 0);
 }
 
 int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* drgb, const int32_t* sample_emb_idx,
                       const void* mlp_params_h, const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled,
-                      float* dapp_emb, int n_emb, const float* df0) {
+                      float* dapp_emb, int n_emb, const float* df0, int defer_reduce) {
   const int n = n_max;
   if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1)) || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
@@ -507,6 +507,11 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
                      n_dev, (dapp_emb != nullptr && !emb_in_lds) ? dapp_emb : nullptr);
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
+  if (defer_reduce) {  // folded into their destinations by f2n_reduce_deferred, together with the field network's
+    rc = f2n_defer_reduction(n_params, (int) blocks, partials, dparams_f32_scaled);
+    if (rc != F2N_OK || !emb_in_lds) return rc;
+    return f2n_defer_reduction(n_emb * 16, (int) blocks, emb_partials, dapp_emb);
+  }
   rc = f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
   if (rc != F2N_OK || !emb_in_lds) return rc;
   return f2n_reduce_partials(stream, n_emb * 16, (int) blocks, emb_partials, dapp_emb);

@@ -9,6 +9,8 @@
 
 #include <mutex>
 
+#define F2N_RED_GROUPS 16  // source-block groups per reduction block (see f2n_reduce_partials_kernel)
+
 namespace {
 struct Slot {
   void* ptr = nullptr;
@@ -45,7 +47,6 @@ void* f2n_ws_get(int slot, size_t bytes) {
 // thread keeps 8 independent loads in flight (the sequential one-thread-per-parameter loop was a 256-deep chain of
 // dependent ~0.25 us reads: 60 us per call, three calls per training step; 4 groups: 14 us; 16 groups: two load rounds
 // for 256 source blocks).  The summation order is fixed: the result does not depend on scheduling.
-#define F2N_RED_GROUPS 16
 __global__ __launch_bounds__(64 * F2N_RED_GROUPS) void f2n_reduce_partials_kernel(int n, int n_blocks, const float* __restrict__ partials,
                                                                                    float* __restrict__ out) {
   __shared__ float s_part[F2N_RED_GROUPS][64];
@@ -68,6 +69,80 @@ __global__ __launch_bounds__(64 * F2N_RED_GROUPS) void f2n_reduce_partials_kerne
     for (int k = 0; k < F2N_RED_GROUPS; k += 4) t += (s_part[k][lane] + s_part[k + 1][lane]) + (s_part[k + 2][lane] + s_part[k + 3][lane]);
     out[i] += t;
   }
+}
+
+// Deferred reductions: the backward entry points called with defer_reduce leave their per-block partials in the workspace
+// and register them here; f2n_reduce_deferred folds all of them into their destinations with ONE launch (three dependent
+// launches of a few microseconds each -- colour-MLP weights, appearance embedding, field-MLP weights -- sat on the step's
+// critical path, each with the dispatcher's ~4 us hand-over).  Same per-element summation order as the single reduction.
+struct Deferred {
+  const float* partials;
+  float* out;
+  int n, n_blocks;
+};
+static Deferred g_deferred[16][4];
+static int g_n_deferred[16];
+
+int f2n_defer_reduction(int n, int n_blocks, const float* partials, float* out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_n_deferred[dev] >= 4) return F2N_ERR_UNSUPPORTED;
+  g_deferred[dev][g_n_deferred[dev]++] = Deferred{partials, out, n, n_blocks};
+  return F2N_OK;
+}
+
+struct F2nDeferredArgs {
+  Deferred d[4];
+  int first_block[5];
+};
+
+__global__ __launch_bounds__(64 * F2N_RED_GROUPS) void f2n_reduce_deferred_kernel(F2nDeferredArgs a, int n_seg) {
+  __shared__ float s_part[F2N_RED_GROUPS][64];
+  int seg = 0;
+  while (seg + 1 < n_seg && (int) blockIdx.x >= a.first_block[seg + 1]) seg++;
+  const Deferred d = a.d[seg];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = (blockIdx.x - a.first_block[seg]) * 64 + lane;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < d.n) {
+    int b = grp;
+    for (; b + 7 * F2N_RED_GROUPS < d.n_blocks; b += 8 * F2N_RED_GROUPS) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += d.partials[(size_t) (b + F2N_RED_GROUPS * u) * d.n + i];
+    }
+    for (; b < d.n_blocks; b += F2N_RED_GROUPS) acc[0] += d.partials[(size_t) b * d.n + i];
+  }
+  s_part[grp][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (grp == 0 && i < d.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < F2N_RED_GROUPS; k += 4) t += (s_part[k][lane] + s_part[k + 1][lane]) + (s_part[k + 2][lane] + s_part[k + 3][lane]);
+    d.out[i] += t;
+  }
+}
+
+extern "C" int f2n_reduce_deferred(void* stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
+  F2nDeferredArgs a = {};
+  int n_seg = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    n_seg = g_n_deferred[dev];
+    int block = 0;
+    for (int k = 0; k < n_seg; k++) {
+      a.d[k] = g_deferred[dev][k];
+      a.first_block[k] = block;
+      block += (int) f2n_div_up(a.d[k].n, 64);
+    }
+    a.first_block[n_seg] = block;
+    g_n_deferred[dev] = 0;
+  }
+  if (n_seg == 0 || a.first_block[n_seg] == 0) return F2N_OK;
+  hipLaunchKernelGGL(f2n_reduce_deferred_kernel, dim3(a.first_block[n_seg]), dim3(64 * F2N_RED_GROUPS), 0, (hipStream_t) stream, a, n_seg);
+  return f2n_launch_status();
 }
 
 int f2n_reduce_partials(void* stream, int n, int n_blocks, const float* partials, float* out) {

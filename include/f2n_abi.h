@@ -342,7 +342,7 @@ int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, 
                       const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
                       const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
                       const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h,
-                      int level_entries);
+                      int level_entries, int defer_reduce);
 int f2n_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* feat, const float* dirs, const float* app_emb,
                       const int32_t* sample_emb_idx, const void* mlp_params_h, float* rgb, void* save_x_h);
 /* f2n_field_fwd_cached + f2n_shade_fwd in one launch for the surviving samples of the grad pass (Renderer.cpp:152-189): the
@@ -355,7 +355,12 @@ int f2n_field_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const
                             const void* color_params_h, float* out_f0, void* save_field_x_h, void* save_shade_x_h, float* rgb);
 int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* drgb, const int32_t* sample_emb_idx,
                       const void* mlp_params_h, const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled,
-                      float* dapp_emb, int n_emb, const float* df0);
+                      float* dapp_emb, int n_emb, const float* df0, int defer_reduce);
+/* defer_reduce != 0 (f2n_shade_bwd_dyn, f2n_field_bwd_dyn): the per-block partial sums of the parameter gradients (and of the
+ * appearance-embedding gradient) stay in the library's workspace; ONE later f2n_reduce_deferred(stream) folds everything
+ * that was deferred on this device into the destinations named at the time (at most four pending reductions; same stream
+ * rule as the workspace itself).  Saves two dependent launches per training step. */
+int f2n_reduce_deferred(void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Renderer -- replaces the per-ray glue of Renderer::Render (Renderer/Renderer.cpp:105-208), i.e.
@@ -466,6 +471,13 @@ typedef struct F2nAdamGroup {
 int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups, int step, float lr, float beta1,
                           float beta2, float eps, int zero_grad, int32_t* flags /*device [3] or NULL*/,
                           const int32_t* skip_flag /*device, or NULL*/);
+/* Every group of an iteration in one launch: `groups` (HOST array of 0..4 descriptors; check_finite is ignored) as in
+ * f2n_adam_small_groups and the h16-gradient table as in f2n_adam_step_h16grad, all predicated on *skip_flag (device, or
+ * NULL) -- typically flags + 2 of a preceding f2n_nonfinite_flags.  Element-wise arithmetic identical to the separate
+ * steps; no block-wide dependency inside (the flags-then-step single-block launch took 21 us in front of the table pass). */
+int f2n_adam_fused(void* stream, int n_groups, const F2nAdamGroup* groups, int n_table, float* table_param, void* table_grad_h,
+                   float table_grad_scale, float* table_exp_avg, float* table_exp_avg_sq, void* table_param_h, int step, float lr,
+                   float beta1, float beta2, float eps, int zero_grad, const int32_t* skip_flag /*device, or NULL*/);
 /* h16 gradient table produced by f2n_hash_bwd / f2n_field_bwd (true gradient = float(grad_h) * grad_scale,
  * grad_scale = 1/128): fuses the fp16->fp32 cast, the /128 (Hash3DAnchored.cu:232), Adam, the fp32->fp16
  * refresh of the table (Hash3DAnchored.cu:186) and the re-zeroing of the gradient (:222) in one pass. */

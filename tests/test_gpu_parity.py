@@ -1001,6 +1001,51 @@ def test_adam_small_groups_equals_separate_launches(hip):
                 assert_same(N(fus_h[k]).view(np.uint16), N(sep_h[k]).view(np.uint16))
 
 
+def test_adam_fused_equals_separate_launches(hip):
+    """f2n_adam_fused (every small group + the h16-gradient table in ONE launch, predicated on a flag computed before) =
+    one f2n_adam_step per group + f2n_adam_step_h16grad, bit for bit, on the applied and on the dropped path."""
+    rng = np.random.default_rng(29)
+    sizes = (3072, 7168, 800)
+    n_tab = 17 << 12
+    for bad in (False, True):
+        base = [dict(p=rng.standard_normal(n).astype(F32), g=rng.standard_normal(n).astype(F32), m=rng.standard_normal(n).astype(F32) * F32(0.1),
+                     v=rng.random(n, dtype=F32) * F32(0.01)) for n in sizes]
+        tab = dict(p=rng.standard_normal(n_tab).astype(F32), g=(rng.standard_normal(n_tab) * 3).astype(np.float16),
+                   m=rng.standard_normal(n_tab).astype(F32) * F32(0.1), v=rng.random(n_tab, dtype=F32) * F32(0.01))
+        scales, wds, rounds = (1.0 / 128, 1.0 / 64, 1.0), (1e-6, 1e-6, 1e-6), (True, True, False)
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device=DEV)
+        out = []
+        for fused in (False, True):
+            grp = [{k: T(v) for k, v in b.items()} for b in base]
+            hs = [torch.zeros(n, dtype=torch.float16, device=DEV) for n in sizes]
+            tb = {k: T(v) for k, v in tab.items()}
+            th = torch.zeros(n_tab, dtype=torch.float16, device=DEV)
+            if fused:
+                hip.adam_fused([dict(param=grp[k]["p"], grad=grp[k]["g"], exp_avg=grp[k]["m"], exp_avg_sq=grp[k]["v"],
+                                     param_h=hs[k] if k < 2 else None, grad_scale=scales[k], weight_decay=wds[k], grad_round_h16=rounds[k])
+                                for k in range(3)],
+                               dict(param=tb["p"], grad_h=tb["g"], exp_avg=tb["m"], exp_avg_sq=tb["v"], param_h=th, grad_scale=1.0 / 128, n=n_tab),
+                               7, 3e-3, 0.9, 0.99, 1e-15, True, flag)
+            else:
+                for k in range(3):
+                    hip.adam_step(sizes[k], grp[k]["p"], grp[k]["g"], scales[k], rounds[k], grp[k]["m"], grp[k]["v"], 7, 3e-3, 0.9, 0.99, 1e-15,
+                                  wds[k], hs[k] if k < 2 else None, flag, zero_grad=True)
+                hip.adam_step_h16grad(n_tab, tb["p"], tb["g"], 1.0 / 128, tb["m"], tb["v"], 7, 3e-3, 0.9, 0.99, 1e-15, 0.0, th, True, flag)
+            out.append((grp, hs, tb, th))
+        (ga, ha, ta, tha), (gb, hb, tb2, thb) = out
+        for k in range(3):
+            for key in ("p", "m", "v", "g"):
+                assert_same(N(ga[k][key]), N(gb[k][key]), "group %d %s" % (k, key))
+            if k < 2:
+                assert_same(N(ha[k]).view(np.uint16), N(hb[k]).view(np.uint16))
+        for key in ("p", "m", "v"):
+            assert_same(N(ta[key]), N(tb2[key]), "table " + key)
+        assert (N(tb2["g"]).view(np.uint16) == 0).all() and (N(ta["g"]).view(np.uint16) == 0).all()
+        assert_same(N(tha).view(np.uint16), N(thb).view(np.uint16))
+        if bad:
+            assert_same(N(tb2["p"]), tab["p"])
+
+
 def test_img2world_rays_and_pixel_gather(hip, fox_state, fox_golden):
     """Dataset.cu:93-123 on the device: bit-exact against the oracle (itself pinned on the reference kernel), for the fox
     cameras, for strongly distorted synthetic cameras, and against the committed golden rays."""
