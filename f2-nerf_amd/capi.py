@@ -67,6 +67,20 @@ def normalize_dirs(n, dirs, out):
     _ck(lib().f2n_normalize_dirs(_stream(), _i(n), _p(dirs, "f32"), _p(out, "f32")), "f2n_normalize_dirs")
 
 
+def sampler_prologue(n, dirs, out, zero=None, u=None, fineness=0.0, noise_out=None):
+    _ck(lib().f2n_sampler_prologue(_stream(), _i(n), _p(dirs, "f32"), _p(out, "f32"), _p(zero, "i32", True),
+                                   _i(0 if zero is None else zero.numel()), _i(0 if u is None else u.numel()), _p(u, "f32", True),
+                                   _f(fineness), _p(noise_out, "f32", True)), "f2n_sampler_prologue")
+
+
+def edge_samples_ex(n, edge_pool, n_edges, transes, edge_idx, edge_coords, u01, out_pts, out_idx, idx_stride, out_pts2=None,
+                    out_idx2=None, idx_stride2=1):
+    _ck(lib().f2n_edge_samples_ex(_stream(), _i(n), _p(edge_pool, "u8"), _i(n_edges), _p(transes, "u8"), _p(edge_idx, "i32", True),
+                                  _p(edge_coords, "f32", True), _p(u01, "f32", True), _p(out_pts, "f32"), _p(out_idx, "i32"),
+                                  _i(idx_stride), _p(out_pts2, "f32", True), _p(out_idx2, "i32", True), _i(idx_stride2)),
+        "f2n_edge_samples_ex")
+
+
 def oct_intersect_count(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, hit_counts, child_blocks=None):
     _ck(lib().f2n_oct_intersect_count(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
                                       _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(hit_counts, "i32"),

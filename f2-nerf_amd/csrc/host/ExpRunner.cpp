@@ -194,7 +194,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   FinishPendingStep();
   renderer_->ZeroGrad();
   renderer_->after_octree_update_ = nullptr;  // (a previous call that threw must not leave its hook / half a prefetch behind)
-  renderer_->DropPendingSamples();
+  if (!renderer_->PendingMatches(rays_o, rays_d)) renderer_->DropPendingSamples();
   deferred_dropped_ = false;
   if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
   if (prefetch && !pipelined) {
@@ -241,12 +241,11 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     iter_step_++;
     UpdateAdaParams();
   }
-  // Prefetch, second half: the NEXT batch's march has been running on the side stream since this step's octree update;
-  // now that everything of this step is queued the host waits for its sample counts and issues the pack.
-  if (prefetch) {
-    if (renderer_->PreSampleBegun()) renderer_->PreSampleFinish();
-    else renderer_->PreSampleAsync(next_rays_o, next_rays_d, next_bounds);  // (a batch without samples never reached the hook)
-  }
+  // The NEXT batch's sampling has been running on the side stream since this step's octree update.  The host does not wait
+  // for its sample count here: the next step does, right before it needs it (Renderer::SampleAndFilter), so that whatever
+  // the caller does between two steps overlaps the march instead of following it.
+  if (prefetch && !renderer_->PreSampleBegun())  // (a batch without samples never reached the hook)
+    renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, global_data_pool_->ray_march_fineness_);
   if (applied && check_nan_ && prefetch) {  // streaming: do not stall on this step's flags (see ExpRunner.h)
     DeferFlags(apply_optimizer);
   } else if (applied && ResolveFlags(apply_optimizer)) {

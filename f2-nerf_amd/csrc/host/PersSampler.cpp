@@ -68,12 +68,26 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   auto& oct = *pers_octree_;
   void* st = CurStream();
   Tensor rays_d = torch::empty_like(rays_d_in);  // :319, with a fixed (oracle-restatable) summation order
-  F2N_CALL(f2n_normalize_dirs(st, n_rays, F32P(rays_d_in), F32P(rays_d)));
+  Tensor totals = torch::empty({2}, DevI32());   // [K, N]
+  Tensor rays_noise;                             // :372-381
+  const int n_noise = F2N_MAX_SAMPLE_PER_RAY + n_rays + 10;
+  bool map_noise = false;
+  if (forced_noise_.defined()) {
+    rays_noise = forced_noise_.contiguous();
+    TORCH_CHECK(rays_noise.numel() >= n_noise, "forced noise too short");
+  } else if (global_data_pool_->mode_ == RunningMode::VALIDATE) {
+    rays_noise = torch::full({n_noise}, fineness, DevF32());  // ones * fineness (:376-377)
+  } else {
+    rays_noise = torch::rand({n_noise}, DevF32());
+    map_noise = true;
+  }
+  // unit directions, zeroed totals and the noise map: one launch
+  F2N_CALL(f2n_sampler_prologue(st, n_rays, F32P(rays_d_in), F32P(rays_d), I32P(totals), 2, map_noise ? n_noise : 0,
+                                map_noise ? F32P(rays_noise) : nullptr, fineness, map_noise ? F32P(rays_noise) : nullptr));
   const float far = 1e8f;  // the `bounds` argument is ignored by the reference too (:322-323)
 
   Tensor counts = torch::empty({n_rays}, DevI32());
   Tensor oct_se = torch::empty({n_rays, 2}, DevI32());
-  Tensor totals = torch::zeros({2}, DevI32());  // [K, N]
   // Leaf hits go into fixed-stride per-ray slots of a worst-case workspace (n_rays * max_oct_intersect_per_ray
   // entries of 12 B: ~100 MB at 8192 rays, nothing next to 288 GB of HBM): ONE DFS pass instead of the reference's
   // count pass + host sync + fill pass (PersSampler.cu:342-366).
@@ -85,18 +99,6 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
                                   oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
                                   VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
                                   VoidP(oct.child_blocks_gpu_)));
-
-  Tensor rays_noise;  // :372-381
-  if (forced_noise_.defined()) {
-    rays_noise = forced_noise_.contiguous();
-    TORCH_CHECK(rays_noise.numel() >= F2N_MAX_SAMPLE_PER_RAY + n_rays + 10, "forced noise too short");
-  } else if (global_data_pool_->mode_ == RunningMode::VALIDATE) {
-    rays_noise = torch::ones({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32());
-    rays_noise.mul_(fineness);
-  } else {
-    rays_noise = torch::rand({F2N_MAX_SAMPLE_PER_RAY + n_rays + 10}, DevF32());
-    F2N_CALL(f2n_march_noise(st, (int) rays_noise.numel(), F32P(rays_noise), fineness, F32P(rays_noise)));
-  }
 
   // ONE march into fixed-stride per-ray slots (28 B x 1024 per ray of scratch, of which only the filled prefixes are
   // touched) + the per-ray counts; the reference marches twice (count pass, host sync, fill pass: :383-423).
@@ -114,6 +116,23 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
   totals_host.copy_(totals, /*non_blocking=*/true);
   p.counts_ready.record();
+  // The pack does not wait for the host to learn N: its outputs are sized for the worst case (every ray's slots full; pages
+  // beyond the N rows actually written are never touched) and it is queued right behind the scan.  With the host in the
+  // loop (count -> allocate -> launch) the pack of a prefetched batch started ~30 us after the count landed and the density
+  // pre-pass of the step behind it ~100 us later than it could: both sat on the step's critical path once the sampler
+  // chain was as long as the step it runs under (converged scenes).
+  // (extra_rows: spare rows IN FRONT of the packed samples, see SampleResultFlex)
+  const int extra = global_data_pool_->mode_ == RunningMode::TRAIN ? std::max(extra_sample_rows_, 0) : 0;
+  const int64_t cap = slots + extra;
+  p.extra_rows = extra;
+  p.o_pts = torch::empty({cap, 3}, DevF32());
+  p.o_dirs = torch::empty({slots, 3}, DevF32());
+  p.o_dt = torch::empty({slots}, DevF32());
+  p.o_t = torch::empty({slots}, DevF32());
+  p.o_anchors = torch::empty({cap, 3}, DevI32());
+  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(pts_se), F32P(rays_o), F32P(rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
+                                    F32P(s_dt), F32P(s_t), I32P(s_anchors), F32P(p.o_pts) + 3 * (int64_t) extra, F32P(p.o_dirs),
+                                    F32P(p.o_dt), F32P(p.o_t), I32P(p.o_anchors) + 3 * (int64_t) extra));
   p.active = true;
   p.n_rays = n_rays;
   p.rays_o = rays_o; p.rays_d = rays_d; p.counts = counts; p.oct_se = oct_se; p.totals = totals; p.totals_host = totals_host;
@@ -123,8 +142,6 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
 
 SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
   TORCH_CHECK(p.active, "FinishSamples without BeginSamples");
-  auto& oct = *pers_octree_;
-  void* st = CurStream();
   const int n_rays = p.n_rays;
   p.counts_ready.synchronize();
   const int n_all_oct = p.totals_host.data_ptr<int32_t>()[0];
@@ -133,18 +150,18 @@ SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
     float per_ray = float(n_all_oct) / float(n_rays);
     global_data_pool_->sampled_oct_per_ray_ = global_data_pool_->sampled_oct_per_ray_ * .9f + per_ray * .1f;
   }
-  SampleResultFlex res;
+  SampleResultFlex res;  // views of the first N rows of the arrays the pack is filling (or has filled)
   res.first_oct_dis = p.first_oct_dis;
-  res.pts = torch::empty({n_all_pts, 3}, DevF32());
-  res.dirs = torch::empty({n_all_pts, 3}, DevF32());
-  res.dt = torch::empty({n_all_pts}, DevF32());
-  res.t = torch::empty({n_all_pts}, DevF32());
-  res.anchors = torch::empty({n_all_pts, 3}, DevI32());
+  res.extra_rows = p.extra_rows;
+  res.pts = p.o_pts.narrow(0, p.extra_rows, n_all_pts);
+  res.dirs = p.o_dirs.narrow(0, 0, n_all_pts);
+  res.dt = p.o_dt.narrow(0, 0, n_all_pts);
+  res.t = p.o_t.narrow(0, 0, n_all_pts);
+  res.anchors = p.o_anchors.narrow(0, p.extra_rows, n_all_pts);
   res.pts_idx_bounds = p.pts_se;
-  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
-                                    F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(res.pts), F32P(res.dirs), F32P(res.dt), F32P(res.t),
-                                    I32P(res.anchors)));
-  p = PendingSamples();  // the scratch goes back to the allocator (of the stream it was allocated on)
+  // the scratch goes back to the allocator of the stream it was allocated on (and the pack runs on): whoever is handed
+  // it next is ordered behind the pack
+  p = PendingSamples();
   return res;
 }
 

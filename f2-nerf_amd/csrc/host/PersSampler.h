@@ -70,6 +70,8 @@ struct PendingSamples {
   int n_rays = 0;
   Tensor rays_o, rays_d, counts, oct_se, totals, totals_host, oct_idx, oct_nf, oct_tr, noise, pts_se, s_dt, s_t, s_anchors,
       first_oct_dis;
+  Tensor o_pts, o_dirs, o_dt, o_t, o_anchors;  // packed outputs, sized for the worst case (+ extra_rows), already being filled
+  int extra_rows = 0;
   at::cuda::CUDAEvent counts_ready;
 };
 
@@ -101,6 +103,7 @@ class PersSampler : public PtsSampler {
   std::function<void(Tensor)> occupancy_sync_hook_;  // gets the [4, n_nodes] vote / mark / visit-count buffer
   // explicit random draws for parity tests (empty = draw from torch's generator like the reference)
   Tensor forced_noise_, forced_edge_idx_, forced_edge_coords_;
+  int extra_sample_rows_ = 0;  // SampleResultFlex::extra_rows of the training samples (set by the Renderer: 2 * n_edge_pts)
 };
 
 }  // namespace f2n

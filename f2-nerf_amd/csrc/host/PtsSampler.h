@@ -13,6 +13,10 @@ struct SampleResultFlex {
   Tensor anchors;         // [ n_all_pts, 3 ]  (trans_idx, leaf node idx, 0)
   Tensor pts_idx_bounds;  // [ n_rays, 2 ]     start, end
   Tensor first_oct_dis;   // [ n_rays, 1 ]
+  // rows allocated (not filled) IN FRONT of pts and anchors (which are views starting extra_rows rows into their storage): a
+  // training step parks its 2E edge samples there so that the density pre-pass gathers their hash features in the same
+  // launches -- in front, because that offset is known before the sample count is
+  int extra_rows = 0;
 };
 
 class PtsSampler : public Pipe {

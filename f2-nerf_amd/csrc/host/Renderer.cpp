@@ -215,6 +215,11 @@ bool Renderer::PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) cons
 
 void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
   if (PresampleMatches(rays_o, rays_d)) return;  // already marched (asynchronously) for these rays
+  if (PendingMatches(rays_o, rays_d)) {          // ... or being marched
+    PreSampleFinish();
+    return;
+  }
+  static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
   presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   has_presample_ = true;
   presample_async_ = false;
@@ -234,24 +239,23 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
   if (!side_stream_)
     side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
   octree_ready_ev_.block(*side_stream_);  // the only dependency on this step: its occupancy update / ProcOctree
+  if (side_must_wait_consumed_) {  // the sampler's buffers may be handed the memory of samples the main stream is still reading
+    samples_consumed_ev_.block(*side_stream_);
+    side_must_wait_consumed_ = false;
+  }
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
-  static_cast<PersSampler*>(pts_sampler_.get())->BeginSamples(rays_o, rays_d, fineness, pending_samples_);
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+  ps->extra_sample_rows_ = 2 * n_edge_pts_;
+  ps->BeginSamples(rays_o, rays_d, fineness, pending_samples_);  // ... up to and including the pack
+  presample_done_ev_.record(*side_stream_);
   pending_rays_o_ = rays_o;
   pending_rays_d_ = rays_d;
 }
 
-// Second half: wait for the counts (by now the march has usually finished), allocate, pack.
+// Second half: wait for the counts (by now the march has usually finished) and take views of the packed rows.  No launch.
 void Renderer::PreSampleFinish() {
   TORCH_CHECK(pending_samples_.active, "PreSampleFinish without PreSampleBegin");
-  {
-    if (side_must_wait_consumed_) {  // the pack's outputs may be handed the memory of the samples this step has just consumed
-      samples_consumed_ev_.block(*side_stream_);
-      side_must_wait_consumed_ = false;
-    }
-    c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
-    presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pending_samples_);
-    presample_done_ev_.record(*side_stream_);
-  }
+  presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pending_samples_);
   has_presample_ = true;
   presample_async_ = true;
   presample_rays_o_ = pending_rays_o_;
@@ -287,6 +291,41 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
+  // Random draws of the step (Renderer.cpp:67-81 background, PersSampler.cu:456-457 edge samples): ONE uniform launch for both
+  // unless a test pinned either (the edge kernel maps three uniforms to an edge index and two coordinates in [-1,1)).
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+  const int n_edge = train ? n_edge_pts_ : 0;
+  const bool draw_bg = !forced_bg_.defined() && bg_color_type_ == BGColorType::rand_noise && train;
+  const bool draw_edge = n_edge > 0 && !ps->forced_edge_idx_.defined() && !ps->forced_edge_coords_.defined();
+  Tensor bg_color, edge_u, edge_idx, edge_coord;
+  if (draw_bg || draw_edge) {
+    const int64_t nb = draw_bg ? (int64_t) n_rays * 3 : 0, ne = draw_edge ? (int64_t) n_edge * 3 : 0;
+    Tensor u = torch::rand({nb + ne}, DevF32());
+    if (draw_bg) bg_color = u.narrow(0, 0, nb).view({n_rays, 3});
+    if (draw_edge) edge_u = u.narrow(0, nb, ne);
+  }
+  if (n_edge > 0 && !draw_edge) {
+    auto& oct = *ps->pers_octree_;
+    edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
+                                              : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
+    edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
+                                                   : torch::empty({n_edge, 2}, DevF32()).uniform_(-1.f, 1.f);
+  }
+  if (draw_bg) {}
+  else if (forced_bg_.defined()) bg_color = forced_bg_.contiguous();
+  else if (bg_color_type_ == BGColorType::white) bg_color = torch::ones({n_rays, 3}, DevF32());
+  else if (bg_color_type_ == BGColorType::rand_noise) bg_color = torch::ones({n_rays, 3}, DevF32()) * .5f;
+  else bg_color = torch::zeros({n_rays, 3}, DevF32());
+
+  // A prefetch whose kernels were queued by the previous step: only now does the host wait for its count (everything between
+  // the end of that step and this point -- the caller's loop, this step's bookkeeping, the draws above -- overlaps the march).
+  if (train && PendingMatches(rays_o, rays_d)) PreSampleFinish();
+  else DropPendingSamples();
+  bool wait_for_pack = false;
+  auto pack_done = [&]() {
+    if (wait_for_pack) presample_done_ev_.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    wait_for_pack = false;
+  };
   if (train && PresampleMatches(rays_o, rays_d)) {  // PreSample[Async]() already marched these rays
     sample_result_ = std::move(presampled_);
     if (presample_async_) {
@@ -295,8 +334,8 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       // step, right where the device is waiting for the next launch): instead samples_consumed_ev_ is recorded on this
       // stream once the last kernel that reads them has been queued, and the side stream waits for it before the next
       // kernels that could be handed this memory again (PreSampleFinish).
-      auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
-      presample_done_ev_.block(cur);
+      // (the wait itself is issued further down, right before the first kernel that reads the packed samples)
+      wait_for_pack = true;
       consumed_side_samples_ = true;
     }
     presampled_ = SampleResultFlex();
@@ -306,6 +345,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     presampled_ = SampleResultFlex();  // a presample for other rays (or made for training, in a render) is of no use
     has_presample_ = false;
     presample_rays_o_ = presample_rays_d_ = Tensor();
+    static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
     sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   }
   int n_all_pts = sample_result_.pts.size(0);
@@ -314,15 +354,10 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   async_count = async_count && train;
   if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;
 
-  Tensor bg_color;  // Renderer.cpp:67-81
-  if (forced_bg_.defined()) bg_color = forced_bg_.contiguous();
-  else if (bg_color_type_ == BGColorType::white) bg_color = torch::ones({n_rays, 3}, DevF32());
-  else if (bg_color_type_ == BGColorType::rand_noise) bg_color = train ? torch::rand({n_rays, 3}, DevF32()) : torch::ones({n_rays, 3}, DevF32()) * .5f;
-  else bg_color = torch::zeros({n_rays, 3}, DevF32());
-
   RenderFront fr;
   fr.bg_color = bg_color;
   if (n_all_pts <= 0) {  // Renderer.cpp:83-97
+    pack_done();
     // data-parallel replicas must all take part in the occupancy exchange, also the one whose batch missed the scene
     if (train && dp_world_ > 1) dp_count_ = torch::zeros({1}, DevI32());
     if (train && static_cast<PersSampler*>(pts_sampler_.get())->occupancy_sync_hook_)
@@ -345,15 +380,62 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   SampleResultFlex& es = fr.es;
   Tensor &pts_all = fr.pts_all, &vol_all = fr.vol_all, &src_rows = fr.src_rows;
   int n_kept = 0;
-  const int n_edge = train ? n_edge_pts_ : 0;
+  // Streaming step: the 2E edge samples ride through the density pre-pass IN FRONT of the ray samples (their hash features
+  // are then in the cache the grad pass reads; a separate gather + MLP for 2% of the rows cost three launches on the
+  // critical path).  They are generated into the spare front rows of the sampler's arrays and into the head of pts_all /
+  // vol_all -- by a launch that does not wait for the pack of the ray samples, which is usually still running.
+  const int64_t front = 2 * (int64_t) n_edge;
+  const bool edges_cached = async_count && n_edge > 0 && sample_result_.extra_rows >= front &&
+                            sample_result_.pts.storage_offset() >= 3 * front && sample_result_.anchors.storage_offset() >= 3 * front;
+  auto edge_samples_to = [&](float* pts1, int32_t* idx1, int stride1, float* pts2, int32_t* idx2) {
+    auto& oct = *ps->pers_octree_;
+    F2N_CALL(f2n_edge_samples_ex(st, n_edge, VoidP(oct.edge_pool_gpu_), oct.n_edges_, VoidP(oct.pers_trans_gpu_),
+                                 edge_idx.defined() ? I32P(edge_idx) : nullptr, edge_coord.defined() ? F32P(edge_coord) : nullptr,
+                                 edge_u.defined() ? F32P(edge_u) : nullptr, pts1, idx1, stride1, pts2, idx2, 1));
+  };
   {
     torch::NoGradGuard no_grad;
-    // the pre-pass keeps the hash features it gathers: the grad pass below reuses them for the surviving samples
-    Tensor f0 = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors, /*keep_features=*/true);
+    Tensor f0_full;
+    const float* f0p = nullptr;
+    if (edges_cached) {
+      const int64_t n_rows = (int64_t) n_all_pts + front;
+      Tensor pts_full = sample_result_.pts.as_strided({n_rows, 3}, {3, 1}, sample_result_.pts.storage_offset() - 3 * front);
+      Tensor anchors_full = sample_result_.anchors.as_strided({n_rows, 3}, {3, 1}, sample_result_.anchors.storage_offset() - 3 * front);
+      pts_all = torch::empty({n_rows, 3}, DevF32());
+      vol_all = torch::empty({n_rows}, DevI32());
+      edge_samples_to(F32P(pts_full), I32P(anchors_full), 3, F32P(pts_all), I32P(vol_all));
+      pack_done();
+      f0_full = field->QueryDensityPreAct(pts_full, anchors_full, /*keep_features=*/true);
+      f0p = F32P(f0_full) + front;
+      fr.edge_cache_row = 0;
+      fr.sample_cache_row = front;
+    } else {
+      // the pre-pass keeps the hash features it gathers: the grad pass below reuses them for the surviving samples
+      pack_done();
+      f0_full = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors, /*keep_features=*/true);
+      f0p = F32P(f0_full);
+    }
     Tensor weights = torch::empty({n_all_pts}, DevF32()), alphas = torch::empty({n_all_pts}, DevF32());
     Tensor mask = torch::empty({n_all_pts}, DevI32()), kept = torch::empty({n_rays}, DevI32());
-    F2N_TIMED_CALL("early_stop", f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), F32P(f0), 1, F32P(sample_result_.dt),
+    F2N_TIMED_CALL("early_stop", f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), f0p, 1, F32P(sample_result_.dt),
                             F32P(weights), F32P(alphas), I32P(mask), I32P(kept)));
+    // The occupancy update (Renderer.cpp:140-149) is all the NEXT batch's sampling waits for, and that sampling is the longer
+    // of the two chains of a converged step: a streaming step issues the update -- and, behind it, the prefetch on the side
+    // stream -- before the survivor scan, whose result nothing waits for.  (Data-parallel: the survivor count rides in the
+    // occupancy exchange, so the scan stays first; synchronous steps: the host is about to wait for the count.)
+    const bool octree_first = train && async_count && dp_world_ <= 1;
+    auto octree_update_issued = [&]() {
+      octree_ready_ev_.record();  // everything the NEXT step's ray sampling depends on has been issued ...
+      if (after_octree_update_) {  // ... so a prefetching TrainStep starts that sampling now (draw order: bg + edge, noise)
+        auto f = std::move(after_octree_update_);
+        after_octree_update_ = nullptr;
+        f();
+      }
+    };
+    if (octree_first) {
+      pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);
+      octree_update_issued();
+    }
     Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::empty({1}, DevI32());
     F2N_CALL(f2n_segment_scan(st, n_rays, I32P(kept), I32P(new_se), I32P(total)));  // FilterIdxBounds, Renderer.cu:20-50
     // Second (and last) host read-back of a Render call: M, the number of surviving samples.  It goes through pinned
@@ -363,29 +445,13 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     n_kept_host_.copy_(total, /*non_blocking=*/true);
     n_kept_ev_.record();
     if (train && dp_world_ > 1) dp_count_ = total.clone();  // summed over the ranks inside the occupancy exchange
-    if (train) pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);  // Renderer.cpp:140-149
+    if (train && !octree_first) pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);  // Renderer.cpp:140-149
     if (train && dp_world_ > 1) {
       if (!dp_count_host_.defined()) dp_count_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
       dp_count_host_.copy_(dp_count_, /*non_blocking=*/true);
       dp_count_ev_.record();
     }
-    Tensor edge_idx, edge_coord;
-    auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
-    if (train) {  // Renderer.cpp:159-166 / PersSampler.cu:454-473: the draws of GetEdgeSamples
-      auto& oct = *ps->pers_octree_;
-      edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
-                                                : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
-      edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
-                                                     : torch::empty({n_edge, 2}, DevF32()).uniform_(-1.f, 1.f);  // one launch (rand*2-1: three)
-    }
-    if (train) {
-      octree_ready_ev_.record();  // everything the NEXT step's ray sampling depends on has been issued ...
-      if (after_octree_update_) {  // ... so a prefetching TrainStep starts that sampling now (draw order: bg, edge, noise)
-        auto f = std::move(after_octree_update_);
-        after_octree_update_ = nullptr;
-        f();
-      }
-    }
+    if (train && !octree_first) octree_update_issued();
     if (async_count) {
       // streaming step: the count stays on the device; n_kept is the capacity every buffer below is sized for
       n_kept = n_all_pts;
@@ -402,8 +468,10 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     }
     const int64_t so = fr.dyn ? 2 * (int64_t) n_edge : 0;   // first survivor row of pts_all / vol_all
     const int64_t eo = fr.dyn ? 0 : n_kept;                 // first edge-sample row
-    pts_all = torch::empty({n_kept + 2 * n_edge, 3}, DevF32());
-    vol_all = torch::empty({n_kept + 2 * n_edge}, DevI32());
+    if (!edges_cached) {
+      pts_all = torch::empty({n_kept + 2 * n_edge, 3}, DevF32());
+      vol_all = torch::empty({n_kept + 2 * n_edge}, DevI32());
+    }
     es.pts = pts_all.slice(0, so, so + n_kept);
     es.dirs = torch::empty({n_kept, 3}, DevF32());
     es.dt = torch::empty({n_kept}, DevF32());
@@ -429,9 +497,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       if (!fr.dyn)
         gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(n_kept, n_rays) * 0.1f;
       // edge samples for the TV loss share the field's point array with the surviving samples (Renderer.cpp:159-166)
-      auto& oct = *ps->pers_octree_;
-      F2N_CALL(f2n_edge_samples(st, n_edge, VoidP(oct.edge_pool_gpu_), VoidP(oct.pers_trans_gpu_), I32P(edge_idx),
-                                F32P(edge_coord), F32P(pts_all) + 3 * eo, I32P(vol_all) + eo));
+      if (!edges_cached && n_edge > 0) edge_samples_to(F32P(pts_all) + 3 * eo, I32P(vol_all) + eo, 1, nullptr, nullptr);
     }
   }
 
@@ -521,12 +587,17 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
     // are never written (only the 2E edge rows of `feat` exist: the TV loss reads them); the synchronous path below keeps
     // the two separate kernels and is what tests compare this with
     TORCH_CHECK(field->prepass_x_.defined(), "no pre-pass feature cache for this query");
-    if (n_edge > 0)
+    if (n_edge > 0 && fr.edge_cache_row >= 0)  // field MLP of the edge samples on the rows the pre-pass cached for them
+      F2N_TIMED_CALL("field_fwd", f2n_field_fwd_cached(st, 2 * n_edge, 2 * n_edge, nullptr,
+                             static_cast<const void*>(field->prepass_x_.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * fr.edge_cache_row),
+                             VoidP(field->mlp_->params_h_), F32P(feat), nullptr, VoidP(field_x)));
+    else if (n_edge > 0)
       F2N_TIMED_CALL("field_fwd", f2n_field_fwd(st, 2 * n_edge, field->n_volumes_, VoidP(field->feat_pool_h_), I32P(field->prim_pool_),
                              I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
                              F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
                              F32P(feat), nullptr, VoidP(field_x)));
-    F2N_TIMED_CALL("field_shade_fwd", f2n_field_shade_fwd_dyn(st, n_kept, n_dev, I32P(fr.src_rows), VoidP(field->prepass_x_),
+    F2N_TIMED_CALL("field_shade_fwd", f2n_field_shade_fwd_dyn(st, n_kept, n_dev, I32P(fr.src_rows),
+                           static_cast<const void*>(field->prepass_x_.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * fr.sample_cache_row),
                            VoidP(field->mlp_->params_h_), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
                            fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(f0c),
                            static_cast<void*>(field_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * so), VoidP(shade_x),

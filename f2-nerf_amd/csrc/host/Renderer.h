@@ -47,6 +47,9 @@ struct RenderFront {
   // samples come FIRST in pts_all / vol_all so that every row offset is known without it.
   bool dyn = false;
   Tensor n_kept_dev;
+  // >= 0: the edge samples went through the density pre-pass; their hash features are rows [edge_cache_row, +2E) of its cache
+  int64_t edge_cache_row = -1;
+  int64_t sample_cache_row = 0;  // cache row of ray sample 0 (src_rows count from there)
 };
 
 struct TrainOutputs {
@@ -69,6 +72,11 @@ class Renderer : public Pipe {
   void PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, float fineness);
   void PreSampleFinish();
   bool PreSampleBegun() const { return pending_samples_.active; }
+  bool PendingMatches(const Tensor& rays_o, const Tensor& rays_d) const {
+    return pending_samples_.active && pending_rays_o_.defined() && pending_rays_d_.defined() &&
+           rays_o.data_ptr() == pending_rays_o_.data_ptr() && rays_d.data_ptr() == pending_rays_d_.data_ptr() &&
+           rays_o.sizes() == pending_rays_o_.sizes();
+  }
   void DropPendingSamples() {
     if (!pending_samples_.active) return;
     pending_samples_.counts_ready.synchronize();  // its kernels may still be running: keep the buffers until they are done

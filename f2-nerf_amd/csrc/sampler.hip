@@ -532,18 +532,50 @@ __global__ void normalize_dirs_kernel(int n, const float* __restrict__ in, float
   out[3 * i + 2] = z / nrm;
 }
 
-// GetEdgeSamplesKernel, PersSampler.cu:436-452.
-__global__ void edge_samples_kernel(int n_pts, const F2nEdgePool* __restrict__ edge_pool,
+// The three ray-count-sized preparations of a GetSamples call in one launch: unit directions (above), the zeroed hit / sample
+// totals the intersection and the scan add into, and the affine map of the march noise (PersSampler.cu:372-381).  They were
+// three dependent launches at the head of the sampler chain, which is the longer chain of a converged training step.
+__global__ void sampler_prologue_kernel(int n_rays, const float* __restrict__ in, float* __restrict__ out, int32_t* __restrict__ zero,
+                                        int n_zero, int n_noise, const float* u, float fineness, float* noise_out /*may be u*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_zero) zero[i] = 0;
+  if (i < n_noise) noise_out[i] = ((u[i] - .5f) + 1.f) * fineness;
+  if (i >= n_rays) return;
+  const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+  const float nrm = sqrtf((x * x + y * y) + z * z);
+  out[3 * i] = x / nrm;
+  out[3 * i + 1] = y / nrm;
+  out[3 * i + 2] = z / nrm;
+}
+
+// GetEdgeSamplesKernel, PersSampler.cu:436-452.  The draws either come as the reference makes them (edge_idx from randint,
+// edge_coords uniform in [-1,1)) or as three uniforms in [0,1) per point (u01: idx = floor(u0 * n_edges), coords = 2u - 1 --
+// one random launch instead of two).  The two warped points / transform indices of every edge point go to out_pts / out_idx
+// (index i at out_idx[(2i) * idx_stride]) and, when given, to a second destination with its own index stride: a streaming
+// training step appends them to the sampler's point array for the density pre-pass AND needs them at the head of the grad
+// pass's point array.
+__global__ void edge_samples_kernel(int n_pts, const F2nEdgePool* __restrict__ edge_pool, int n_edges,
                                     const F2nTransInfo* __restrict__ transes, const int32_t* __restrict__ edge_idx,
-                                    const float* __restrict__ edge_coords, float* __restrict__ out_pts,
-                                    int32_t* __restrict__ out_idx) {
+                                    const float* __restrict__ edge_coords, const float* __restrict__ u01,
+                                    float* __restrict__ out_pts, int32_t* __restrict__ out_idx, int idx_stride,
+                                    float* __restrict__ out_pts2, int32_t* __restrict__ out_idx2, int idx_stride2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pts) return;
-  const F2nEdgePool* e = edge_pool + edge_idx[i];
+  int ei;
+  float c0, c1;
+  if (u01 != nullptr) {
+    ei = min((int) (u01[3 * i] * (float) n_edges), n_edges - 1);
+    c0 = u01[3 * i + 1] * 2.f - 1.f;
+    c1 = u01[3 * i + 2] * 2.f - 1.f;
+  } else {
+    ei = edge_idx[i];
+    c0 = edge_coords[2 * i];
+    c1 = edge_coords[2 * i + 1];
+  }
+  const F2nEdgePool* e = edge_pool + ei;
   float w[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++)
-    w[c] = (e->center[c] + e->dir_0[c] * edge_coords[2 * i]) + e->dir_1[c] * edge_coords[2 * i + 1];
+  for (int c = 0; c < 3; c++) w[c] = (e->center[c] + e->dir_0[c] * c0) + e->dir_1[c] * c1;
   float a[3], b[3];
   f2n_warp(transes + e->t_idx_a, w, a);
   f2n_warp(transes + e->t_idx_b, w, b);
@@ -552,8 +584,17 @@ __global__ void edge_samples_kernel(int n_pts, const F2nEdgePool* __restrict__ e
     out_pts[6 * i + c] = a[c];
     out_pts[6 * i + 3 + c] = b[c];
   }
-  out_idx[2 * i] = e->t_idx_a;
-  out_idx[2 * i + 1] = e->t_idx_b;
+  out_idx[(size_t) (2 * i) * idx_stride] = e->t_idx_a;
+  out_idx[(size_t) (2 * i + 1) * idx_stride] = e->t_idx_b;
+  if (out_pts2 != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      out_pts2[6 * i + c] = a[c];
+      out_pts2[6 * i + 3 + c] = b[c];
+    }
+    out_idx2[(size_t) (2 * i) * idx_stride2] = e->t_idx_a;
+    out_idx2[(size_t) (2 * i + 1) * idx_stride2] = e->t_idx_b;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -836,6 +877,17 @@ int f2n_normalize_dirs(void* stream, int n, const float* dirs, float* out) {
   return f2n_launch_status();
 }
 
+int f2n_sampler_prologue(void* stream, int n_rays, const float* dirs, float* out, int32_t* zero, int n_zero, int n_noise,
+                         const float* u, float fineness, float* noise_out) {
+  if (n_rays < 0 || n_zero < 0 || n_noise < 0 || (n_zero > 0 && zero == nullptr) || (n_noise > 0 && (u == nullptr || noise_out == nullptr)))
+    return F2N_ERR_INVALID_ARG;
+  const int n = n_rays > n_noise ? (n_rays > n_zero ? n_rays : n_zero) : (n_noise > n_zero ? n_noise : n_zero);
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(sampler_prologue_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n_rays, dirs, out, zero,
+                     n_zero, n_noise, u, fineness, noise_out);
+  return f2n_launch_status();
+}
+
 int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                             const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* hit_counts,
                             const void* child_blocks) {
@@ -931,11 +983,20 @@ int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, con
 
 int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,
                      const float* edge_coords, float* out_pts, int32_t* out_idx) {
-  if (n_pts < 0) return F2N_ERR_INVALID_ARG;
+  return f2n_edge_samples_ex(stream, n_pts, edge_pool, 0, transes, edge_idx, edge_coords, nullptr, out_pts, out_idx, 1, nullptr,
+                             nullptr, 1);
+}
+
+int f2n_edge_samples_ex(void* stream, int n_pts, const void* edge_pool, int n_edges, const void* transes, const int32_t* edge_idx,
+                        const float* edge_coords, const float* u01, float* out_pts, int32_t* out_idx, int idx_stride,
+                        float* out_pts2, int32_t* out_idx2, int idx_stride2) {
+  if (n_pts < 0 || idx_stride < 1 || idx_stride2 < 1 || (u01 != nullptr && n_edges < 1) || (out_pts2 != nullptr) != (out_idx2 != nullptr))
+    return F2N_ERR_INVALID_ARG;
   if (n_pts == 0) return F2N_OK;
+  if (u01 == nullptr && (edge_idx == nullptr || edge_coords == nullptr)) return F2N_ERR_INVALID_ARG;
   hipLaunchKernelGGL(edge_samples_kernel, dim3(f2n_div_up(n_pts, 64)), dim3(64), 0, (hipStream_t) stream, n_pts,
-                     (const F2nEdgePool*) edge_pool, (const F2nTransInfo*) transes, edge_idx, edge_coords, out_pts,
-                     out_idx);
+                     (const F2nEdgePool*) edge_pool, n_edges, (const F2nTransInfo*) transes, edge_idx, edge_coords, u01, out_pts,
+                     out_idx, idx_stride, out_pts2, out_idx2, idx_stride2);
   return f2n_launch_status();
 }
 

@@ -56,6 +56,10 @@ const char* f2n_build_info(void);
 /* rays_d / ||rays_d|| (PersSampler.cu:319, torch::linalg_norm there).  Fixed fp32 order: sqrt((x*x + y*y) + z*z),
  * IEEE division, so that the CPU oracle restates it bit for bit.  out may alias dirs. */
 int f2n_normalize_dirs(void* stream, int n, const float* dirs /*[n,3]*/, float* out /*[n,3]*/);
+/* f2n_normalize_dirs + zero[0..n_zero) = 0 (the hit / sample totals of f2n_oct_intersect_strided / f2n_segment_scan) +
+ * f2n_march_noise (u -> noise_out, n_noise values; 0: none) in ONE launch: the head of a GetSamples call. */
+int f2n_sampler_prologue(void* stream, int n_rays, const float* dirs, float* out, int32_t* zero, int n_zero, int n_noise,
+                         const float* u, float fineness, float* noise_out);
 
 /* FindRayOctreeIntersectionKernel<false> (PersSampler.cu:53-152, launched :342-351).
  * rays_d must already be unit length (GetSamples normalises at :319); [near, far] is the global bound the
@@ -148,6 +152,14 @@ int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end /*[R
 /* GetEdgeSamplesKernel (PersSampler.cu:436-452).  edge_idx/edge_coords are the random draws of :456-457. */
 int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,
                      const float* edge_coords /*[n,2]*/, float* out_pts /*[n,2,3]*/, int32_t* out_idx /*[n,2]*/);
+/* The same with (a) the draws optionally given as u01 [n,3] uniform in [0,1) -- idx = min(floor(u0 * n_edges), n_edges - 1),
+ * coords = 2 u - 1: one random launch for :456-457 instead of two (edge_idx / edge_coords are then ignored, may be NULL) --,
+ * (b) a stride for the index output (3: the transform column of an anchors array [.,3]) and (c) an optional second
+ * destination (out_pts2 / out_idx2 both NULL or both given): a streaming training step appends the edge samples to the
+ * sampler's arrays so that the density pre-pass gathers their hash features too, and heads the grad pass's arrays with them. */
+int f2n_edge_samples_ex(void* stream, int n_pts, const void* edge_pool, int n_edges, const void* transes, const int32_t* edge_idx,
+                        const float* edge_coords, const float* u01, float* out_pts, int32_t* out_idx, int idx_stride,
+                        float* out_pts2, int32_t* out_idx2, int idx_stride2);
 
 /* MarkVistNodeKernel (PersSampler.cu:475-526).  oct node index of sample i = anchors[i*anchor_stride + 1].
  * w_adder/a_adder must be pre-filled with -1, mark with 0 (:555-557); visit_cnt is persistent state. */

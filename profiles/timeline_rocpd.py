@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the last training steps in a rocprofv3 --kernel-trace (rocpd SQLite) of tools/converged_steps.py: every
 dispatch after the last idle gap >= 100 ms, with its queue, start (relative, us) and duration; then per-step spans (a step
-ends with adam_h16grad_kernel) and, per kernel, mean duration and how much of it ran while the OTHER queue was busy too.
+ends with the Adam kernel: adam_fused_kernel, or adam_h16grad_kernel in older traces) and, per kernel, mean duration and how much of it ran while the OTHER queue was busy too.
 Usage: timeline_rocpd.py <db> [n_steps_to_print]"""
 import collections, sqlite3, sys
 
@@ -22,7 +22,7 @@ short = lambda n: n.split("(")[0].replace("void ", "").split("<")[0][-34:]
 steps, cur_step = [], []
 for r in rows:
     cur_step.append(r)
-    if "adam_h16grad" in r[0]:
+    if "adam_fused" in r[0] or "adam_h16grad" in r[0]:
         steps.append(cur_step); cur_step = []
 print("dispatches after the marker: %d, steps: %d, columns: %s" % (len(rows), len(steps), cols))
 spans = [(s[-1][2] - s[0][1]) / 1e3 for s in steps]

@@ -279,6 +279,39 @@ def test_edge_samples_and_occupancy(hip, fox_state, fox_golden):
     assert_same(N(tn2).view(NODE_DT)["trans_idx"].copy(), g["invisible_trans_idx"], "invisible")
 
 
+def test_edge_samples_from_uniforms_and_sampler_prologue(hip, fox_state, fox_golden):
+    """f2n_edge_samples_ex: three uniforms per point instead of (randint, uniform(-1,1)) draws -- idx = floor(u0 * n_edges),
+    coords = 2u - 1 --, the index output at the stride of an anchors array and a second destination: all equal to the
+    reference kernel (pinned golden / oracle) on the draws they imply.  f2n_sampler_prologue = normalize_dirs + zero fill +
+    noise map in one launch, bit for bit."""
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(12)
+    n_edges = st["edge_pool"].size // 64
+    n = 1000
+    u = rng.random((n, 3), dtype=F32)
+    u[0, 0] = F32(1.) - F32(2.) ** -24  # the largest float below one: the index clamp
+    eidx = np.minimum((u[:, 0] * F32(n_edges)).astype(np.int32), n_edges - 1)
+    ecoord = (u[:, 1:] * F32(2.) - F32(1.)).astype(F32)
+    ref_pts = torch.empty((n, 2, 3), device=DEV); ref_idx = torch.empty((n, 2), dtype=torch.int32, device=DEV)
+    hip.edge_samples(n, T(st["edge_pool"]), T(st["pers_trans"]), T(eidx), T(ecoord), ref_pts, ref_idx)
+    epts, eoidx = oc.edge_samples(st["edge_pool"], st["pers_trans"], eidx, ecoord)
+    assert_same(N(ref_pts), epts.reshape(n, 2, 3), "edge pts vs oracle"); assert_same(N(ref_idx), eoidx.reshape(n, 2), "edge idx vs oracle")
+    pts1 = torch.zeros((n, 2, 3), device=DEV); anc = torch.full((2 * n, 3), -9, dtype=torch.int32, device=DEV)
+    pts2 = torch.zeros((n, 2, 3), device=DEV); idx2 = torch.zeros((n, 2), dtype=torch.int32, device=DEV)
+    hip.edge_samples_ex(n, T(st["edge_pool"]), n_edges, T(st["pers_trans"]), None, None, T(u), pts1, anc, 3, pts2, idx2, 1)
+    assert_same(N(pts1), N(ref_pts)); assert_same(N(pts2), N(ref_pts)); assert_same(N(idx2), N(ref_idx))
+    a = N(anc)
+    assert_same(a[:, 0].reshape(n, 2), N(ref_idx)); assert (a[:, 1:] == -9).all()
+    # prologue
+    R = 777
+    dirs = rng.normal(size=(R, 3)).astype(F32) * F32(3.)
+    uu = rng.random(1024 + R + 10, dtype=F32)
+    out = torch.zeros((R, 3), device=DEV); zero = torch.full((2,), 5, dtype=torch.int32, device=DEV); nz = T(uu.copy())
+    hip.sampler_prologue(R, T(dirs), out, zero, nz, 3.5, nz)  # in place, as the host does
+    assert_same(N(out), oc.normalize_dirs(dirs)); assert (N(zero) == 0).all()
+    assert_same(N(nz), ((uu - F32(.5)) + F32(1.)) * F32(3.5))
+
+
 # ---------------------------------------------------------------------------------------------------
 # hash grid
 # ---------------------------------------------------------------------------------------------------

@@ -13,6 +13,8 @@ ap.add_argument("--iters", type=int, default=20000)
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--factor", type=int, default=2)
 ap.add_argument("--overrides", nargs="*", default=[])
+ap.add_argument("--kernel-timing", action="store_true")
+ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob")
 args = ap.parse_args()
 st = fox_data.load_state()
 sc, images = fox_data.scene(args.factor)
@@ -26,14 +28,30 @@ batches = [ds.rand_rays_data(R, 1) for _ in range(8)]
 def step(i):
     b, nb = batches[i % 8], batches[(i + 1) % 8]
     return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
-for i in range(6):
-    step(i)
-c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)
-t0 = time.perf_counter()
-for i in range(args.steps):
-    s = step(6 + i)
-runner.flush(); torch.cuda.synchronize()
-el = time.perf_counter() - t0
-c1 = runner.counters()
-print("rays %d  %.3f ms/step  marched/step %d meaningful/step %d nodes %d" % (R, el / args.steps * 1e3, (c1["total_marched"] - c0["total_marched"]) // args.steps,
-      (c1["total_meaningful"] - c0["total_meaningful"]) // args.steps, runner.n_nodes()))
+def timed(tag=""):
+    for i in range(6):
+        step(i)
+    c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)
+    if args.kernel_timing:
+        runtime.host().ExpRunner.enable_kernel_timing(["ray_march", "oct_intersect", "field_bwd", "hash_gather", "shade_bwd"])
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(6 + i)
+    runner.flush(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    c1 = runner.counters()
+    print("%srays %d  %.3f ms/step  marched/step %d meaningful/step %d nodes %d" % (tag, R, el / args.steps * 1e3,
+          (c1["total_marched"] - c0["total_marched"]) // args.steps, (c1["total_meaningful"] - c0["total_meaningful"]) // args.steps,
+          runner.n_nodes()), flush=True)
+    if args.kernel_timing:
+        tm = runtime.host().ExpRunner.collect_kernel_timing()
+        runtime.host().ExpRunner.disable_kernel_timing()
+        print("    " + "  ".join("%s %.1f us" % (k, v[1] / max(v[0], 1) * 1e3) for k, v in sorted(tm.items())), flush=True)
+if args.env_sweep:
+    name, vals = args.env_sweep.split("=")
+    for rep in range(2):
+        for v in vals.split(","):
+            os.environ[name] = v
+            timed("%s=%s: " % (name, v))
+else:
+    timed()
