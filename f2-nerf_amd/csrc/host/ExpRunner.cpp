@@ -404,20 +404,22 @@ std::vector<Tensor> ExpRunner::RenderRays(const Tensor& rays_o, const Tensor& ra
   torch::NoGradGuard no_grad;
   auto prev = global_data_pool_->mode_;
   global_data_pool_->mode_ = RunningMode::VALIDATE;
-  auto rr = renderer_->Render(rays_o, rays_d, bounds, Tensor());
+  auto rr = forward_render_ ? renderer_->RenderForward(rays_o, rays_d, bounds) : renderer_->Render(rays_o, rays_d, bounds, Tensor());
   global_data_pool_->mode_ = prev;
   return {rr.colors, rr.disparity, rr.first_oct_dis, rr.depth};
 }
 
-// ExpRunner::RenderWholeImage (ExpRunner.cpp:255-292): all rays of a view in 8192-ray chunks, VALIDATE mode.  The
-// reference bounces every chunk through the CPU; here rays and results stay in HBM.
+// ExpRunner::RenderWholeImage (ExpRunner.cpp:255-292): all rays of a view in chunks, VALIDATE mode.  The reference bounces
+// every 8192-ray chunk through the CPU; here rays and results stay in HBM and a chunk is 65536 rays on
+// the forward-only path (one host round trip -- the sample count -- per chunk; rays are independent and VALIDATE noise is a
+// constant, so the chunking does not change a bit of the image; sampler scratch: ~5 GB of the 288).
 std::vector<Tensor> ExpRunner::RenderWholeImage(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
   torch::NoGradGuard no_grad;
   const int n_rays = rays_d.size(0);
   Tensor pred_colors = torch::zeros({n_rays, 3}, DevF32());
   Tensor first_oct_disp = torch::full({n_rays, 1}, 1.f, DevF32());
   Tensor pred_disp = torch::zeros({n_rays, 1}, DevF32());
-  const int ray_batch_size = 8192;
+  const int ray_batch_size = forward_render_ ? render_chunk_rays_ : 8192;
   for (int i = 0; i < n_rays; i += ray_batch_size) {
     const int hi = std::min(i + ray_batch_size, n_rays);
     auto out = RenderRays(rays_o.index({Slc(i, hi)}).contiguous(), rays_d.index({Slc(i, hi)}).contiguous(),

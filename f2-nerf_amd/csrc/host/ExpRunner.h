@@ -37,6 +37,8 @@ class ExpRunner {
   TrainStats TrainStepAutograd(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                const Tensor& emb_idx, bool apply_optimizer = true);
   float CurVarLossWeight() const;
+  bool forward_render_ = true;      // inference through Renderer::RenderForward (false: the taped Render(), as a comparator)
+  int render_chunk_rays_ = 65536;   // rays per chunk of RenderWholeImage on that path
   std::vector<Tensor> RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   std::vector<Tensor> RenderWholeImage(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   float TestImagePSNR(Dataset& dataset, int idx);       // 8-bit quantised prediction, as ExpRunner.cpp:360-369

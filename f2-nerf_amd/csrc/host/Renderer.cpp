@@ -351,7 +351,6 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   int n_all_pts = sample_result_.pts.size(0);
   last_n_all_pts_ = n_all_pts;
   if (train) total_all_pts_ += n_all_pts;
-  async_count = async_count && train;
   if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;
 
   RenderFront fr;
@@ -455,8 +454,10 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     if (async_count) {
       // streaming step: the count stays on the device; n_kept is the capacity every buffer below is sized for
       n_kept = n_all_pts;
-      count_pending_ = true;
-      pending_count_rays_ = n_rays;
+      if (train) {  // (bookkeeping of the training counters / EMA: Renderer::ResolvePendingCount)
+        count_pending_ = true;
+        pending_count_rays_ = n_rays;
+      }
       fr.dyn = true;
       fr.n_kept_dev = total;
     } else {
@@ -538,6 +539,41 @@ RenderResult Renderer::Render(const Tensor& rays_o, const Tensor& rays_d, const 
   auto out = CompositeFunction::apply(scene_feat, sampled_colors, es.dt, es.t, fr.bg_color, es.pts_idx_bounds,
                                       (double) gdp->gradient_scaling_progress_);
   return {out[0], es.first_oct_dis, out[1], edge_feat, out[2], out[3], es.pts_idx_bounds};
+}
+
+// Forward-only rendering (ExpRunner::RenderWholeImage's chunk body, TestImages, RenderPath): the kernels of the streaming
+// training step without anything a backward would need -- the survivor count stays on the device (no second host round trip
+// per chunk), field MLP on the cached hash features + SH + colour MLP in ONE launch whose only outputs are the density
+// pre-activation and the colour of every surviving sample (no `feat`, no saved MLP inputs), then compositing.  No autograd
+// nodes, no occupancy update.  Bit-identical to Render() in VALIDATE mode (tests/test_gpu_e2e.py).
+RenderResult Renderer::RenderForward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
+  auto* gdp = global_data_pool_;
+  auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
+  auto* shader = static_cast<SHShader*>(shader_.get());
+  TORCH_CHECK(gdp->mode_ != RunningMode::TRAIN, "RenderForward is the inference path");
+  if (!(shader->degree_ == 4 && shader->n_hiddens_ == 2)) return Render(rays_o, rays_d, bounds, Tensor());  // (unfused colour path)
+  torch::NoGradGuard no_grad;
+  const int n_rays = rays_o.size(0);
+  RenderFront fr = SampleAndFilter(rays_o, rays_d, bounds, Tensor(), /*async_count=*/true);
+  if (fr.empty)
+    return {fr.bg_color, torch::zeros({n_rays, 1}, DevF32()), torch::zeros({n_rays}, DevF32()), Tensor(),
+            torch::full({n_rays}, 512.f, DevF32()), Tensor(), Tensor()};
+  void* st = CurStream();
+  SampleResultFlex& es = fr.es;
+  const int n_cap = std::max(fr.n_kept, 1);
+  TORCH_CHECK(field->prepass_x_.defined(), "no pre-pass feature cache for this query");
+  Tensor f0c = torch::empty({n_cap}, DevF32()), rgb = torch::empty({n_cap, 3}, DevF32());
+  F2N_TIMED_CALL("field_shade_fwd", f2n_field_shade_fwd_dyn(st, fr.n_kept, I32P(fr.n_kept_dev), I32P(fr.src_rows),
+                         static_cast<const void*>(field->prepass_x_.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * fr.sample_cache_row),
+                         VoidP(field->mlp_->params_h_), F32P(es.dirs), nullptr, nullptr, VoidP(shader->mlp_->params_h_), F32P(f0c),
+                         nullptr, nullptr, F32P(rgb)));
+  field->prepass_x_ = Tensor();
+  Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
+  Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({n_cap}, DevF32());
+  Tensor bg = fr.bg_color.contiguous();
+  F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
+                             F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights), nullptr));
+  return {colors, es.first_oct_dis, disparity, Tensor(), depth, weights, es.pts_idx_bounds};
 }
 
 // One training iteration's forward AND backward without the autograd tape: the same kernels as Render() + the loss

@@ -64,6 +64,7 @@ class Renderer : public Pipe {
  public:
   Renderer(GlobalDataPool* global_data_pool, int n_images);
   RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
+  RenderResult RenderForward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);  // inference: no tape, no count read-back
   // issues the ray sampling of the next SampleAndFilter / TrainForwardBackward call ahead of time (same rays!)
   void PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   // The same on a SIDE stream that only waits for this step's octree update: the sampler kernels (latency-bound: few

@@ -263,6 +263,21 @@ def test_dataset_rays_and_whole_image_render(rt, fox_state):
     img, first_oct, disp = runner.render_whole_image(co, cd, cb)
     chunks = [runner.render_rays(co[i:i + 8192], cd[i:i + 8192], cb[i:i + 8192])[0] for i in range(0, co.shape[0], 8192)]
     assert (torch.cat(chunks) == img).all() and float(disp.max()) == 1.0 and torch.isfinite(first_oct).all()
+    # the forward-only inference path (one fused field + colour launch on device-side counts, 65536-ray chunks) is the default;
+    # the taped Render() in 8192-ray chunks -- the reference's structure -- must give the same image, bit for bit
+    assert runner.forward_render
+    runner.forward_render = False
+    img_t, first_t, disp_t = runner.render_whole_image(co, cd, cb)
+    four = runner.render_rays(co[:3000], cd[:3000], cb[:3000])
+    runner.forward_render = True
+    runner.render_chunk_rays = 3000  # (several chunks, a ragged last one)
+    img_c, _, disp_c = runner.render_whole_image(co, cd, cb)
+    four_f = runner.render_rays(co[:3000], cd[:3000], cb[:3000])
+    runner.render_chunk_rays = 65536
+    assert (img_t == img).all() and (first_t == first_oct).all() and (disp_t == disp).all()
+    assert (img_c == img).all() and (disp_c == disp).all()
+    for a, b in zip(four, four_f):  # colours, disparity, first_oct_dis, depth
+        assert (a == b).all()
     psnr = runner.test_image_psnr(ds, int(st["test_set"][0]))
     # the reference's definition (ExpRunner.cpp:360-369): the prediction is quantised to 8 bit before the error is measured
     quant = (img.cpu().clip(0, 1) * 255.).to(torch.uint8).to(torch.float32) / 255.
