@@ -120,6 +120,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            },
            py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
            py::arg("apply_optimizer") = true)
+      .def_readwrite("end_iter", &ExpRunner::end_iter_)
       .def_readwrite("forward_render", &ExpRunner::forward_render_)
       .def_readwrite("render_chunk_rays", &ExpRunner::render_chunk_rays_)
       .def("render_rays", &ExpRunner::RenderRays)

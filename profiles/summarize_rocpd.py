@@ -7,7 +7,8 @@ import sys
 
 
 def short(name):
-    for k in ("field_fwd_kernel", "field_bwd_kernel", "shade_bwd_kernel", "shade_fwd_kernel", "hash_bwd_kernel",
+    for k in ("field_shade_fwd_kernel", "field_fwd_kernel", "field_bwd_kernel", "shade_bwd_kernel", "shade_fwd_kernel",
+              "hash_bwd_kernel", "hash_gather_planes_kernel", "hash_bin_accumulate_kernel", "hash_bin_kernel", "adam_fused_kernel",
               "adam_h16grad_kernel", "adam_kernel"):
         if k in name:
             tmpl = ""
@@ -19,6 +20,12 @@ def short(name):
                 tmpl = "<NH=1,atomics>"
             elif "field_bwd_kernelILi2" in name:
                 tmpl = "<NH=2>"
+            elif "hash_gather_planes_kernelILb1ELb1" in name:
+                tmpl = "<staged,run-combining>"
+            elif "hash_gather_planes_kernelILb1ELb0" in name:
+                tmpl = "<staged>"
+            elif "hash_gather_planes_kernelILb0" in name:
+                tmpl = "<unstaged>"
             return k + tmpl
     return name.split("(")[0].replace("void ", "")[:70]
 
@@ -69,8 +76,8 @@ def traffic(fetch_csv, write_csv, out_json):
         with open(path) as f:
             for r in csv.DictReader(f):
                 name = r["kernel"].split("(")[0]
-                for tag in ("hash_gather_planes_kernel", "hash_bin_kernel", "hash_bin_accumulate_kernel", "field_bwd_kernel",
-                            "shade_bwd_kernel", "shade_fwd_kernel", "ray_march_kernel<true>", "ray_march_kernel<false>"):
+                for tag in ("hash_gather_planes_kernel", "hash_bin_accumulate_kernel", "hash_bin_kernel", "field_bwd_kernel",
+                            "shade_bwd_kernel", "field_shade_fwd_kernel", "shade_fwd_kernel", "ray_march_kernel<true>", "ray_march_kernel<false>"):
                     if tag in name:
                         name = tag
                 if name not in best or float(r["avg_duration_ns"]) > float(best[name]["avg_duration_ns"]):
