@@ -143,6 +143,7 @@ Tensor Dataset::PixelGrid(int H_out, int W_out) {  // linspace(0, H-1, H_out) x 
   return torch::stack({g[0].reshape({-1}), g[1].reshape({-1})}, -1).contiguous();
 }
 
+// (reso_level is accepted and ignored, as in the reference: Dataset.cpp:177-179 renders H = height_, W = width_)
 BoundedRays Dataset::RaysOfCamera(int idx, int /*reso_level*/) {
   TORCH_CHECK(idx >= 0 && idx < n_images_, "camera index out of range");
   Tensor ij = PixelGrid(height_, width_);

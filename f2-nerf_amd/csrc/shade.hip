@@ -136,6 +136,14 @@ __device__ __forceinline__ half8_t f2n_load_xfrag(const half_t* __restrict__ x, 
 
 #define F2N_SHADE_EPS 1e-3f
 
+// The colour network's three outputs of sample c sit in lane (c, g = 0) as o[0..2].  The scaled sigmoid behind them
+// (SHShader.cpp:28: expf + an IEEE division, ~25 instructions) is evaluated ONCE per wave instead of three times: lane
+// (c, g) takes channel g from lane c and stores its own result (g < 3).  Same arithmetic per value, so the same bits.
+__device__ __forceinline__ float f2n_channel_of_group(const float4_t& o, int c, int g) {
+  const float v1 = __shfl(o[1], c), v2 = __shfl(o[2], c);
+  return g == 0 ? o[0] : g == 1 ? v1 : v2;
+}
+
 __global__ __launch_bounds__(256) void shade_fwd_kernel(int n, const float* __restrict__ feat, const float* __restrict__ dirs,
                                                         const float* __restrict__ app_emb,
                                                         const int32_t* __restrict__ sample_emb_idx,
@@ -158,13 +166,9 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(int n, const float* __re
       *(half4_t*) (p + 16) = __builtin_shufflevector(xf, xf, 4, 5, 6, 7);
     }
     const float4_t o = w.forward(xf);
-    if (valid && g == 0) {
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const float ov = (float) (half_t) o[r];  // f16 output precision, then fp32 torch ops (SHShader.cpp:28)
-        rgb[3 * (size_t) s + r] = (1.f + 2.f * F2N_SHADE_EPS) / (1.f + expf(-ov)) - F2N_SHADE_EPS;
-      }
-    }
+    const float ov = (float) (half_t) f2n_channel_of_group(o, c, g);  // f16 output precision, then fp32 torch ops (SHShader.cpp:28)
+    const float col = (1.f + 2.f * F2N_SHADE_EPS) / (1.f + expf(-ov)) - F2N_SHADE_EPS;
+    if (valid && g < 3) rgb[3 * (size_t) s + g] = col;
   }
 }
 
@@ -258,13 +262,9 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
       *(half4_t*) (p + 16) = __builtin_shufflevector(xs, xs, 4, 5, 6, 7);
     }
     const float4_t oc = wc.forward(xs);
-    if (valid && g == 0) {
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const float ov = (float) (half_t) oc[r];
-        rgb[3 * (size_t) s + r] = (1.f + 2.f * F2N_SHADE_EPS) / (1.f + expf(-ov)) - F2N_SHADE_EPS;
-      }
-    }
+    const float ov = (float) (half_t) f2n_channel_of_group(oc, c, g);
+    const float col = (1.f + 2.f * F2N_SHADE_EPS) / (1.f + expf(-ov)) - F2N_SHADE_EPS;
+    if (valid && g < 3) rgb[3 * (size_t) s + g] = col;
     cur = nxt;
   }
 }
@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
       auto dy_fn = [&](half8_t h0, half8_t h1) {
         float4_t o = f2n_mfma(wo[0], h0, z);
         o = f2n_mfma(wo[1], h1, o);
+        // (evaluating the three channels on three lane groups with shuffles, as the forward kernels do, was measured
+        // SLOWER here -- shade_bwd 0.102 -> 0.122 ms: four LDS round trips on the dependent chain between two MFMA stages,
+        // with two waves per SIMD to hide them)
         half8_t dyf = {0, 0, 0, 0, 0, 0, 0, 0};
         const float dv[3] = {d0, d1, d2};
 #pragma unroll
