@@ -290,7 +290,11 @@ def main():
                         # an XCD's L2 into a CU's L1 (the primes are random on all three axes: no two corners share a line)
                         "l2_line_bandwidth": {"achieved": round(samples_per_launch * 128 * 128 / (avg_ms * 1e-3) / 1e12, 2),
                                               "peak": L2_PEAK_TBS, "unit": "TB/s (128-byte lines, L2 -> L1, all 8 XCDs)",
-                                              "frac": round(samples_per_launch * 128 * 128 / (avg_ms * 1e-3) / 1e12 / L2_PEAK_TBS, 4)},
+                                              "frac": round(samples_per_launch * 128 * 128 / (avg_ms * 1e-3) / 1e12 / L2_PEAK_TBS, 4),
+                                              "model": "128 lines per sample = no line shared between samples: exact for the fox scene at "
+                                                       "fineness 16; an upper bound (frac may exceed 1) where consecutive samples of a ray share "
+                                                       "cells -- short march steps: llff / nerf-360 presets, converged scenes -- and the "
+                                                       "run-combining kernel reads a shared cell once"},
                         # whole-path fractions from the same run -- table bytes 512*(rho+2) per meaningful sample
                         # against 8 TB/s, MLP flops (61440 + 6144 rho) against the 2.5 PFLOP/s dense f16 peak
                         "whole_path": {"gather_scatter_frac_of_hbm": round(value / max(world, 1) * 512 * (rho + 2) / 8.0e12, 5),
