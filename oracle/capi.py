@@ -332,6 +332,23 @@ def mlp_n_params(d_in, d_hidden, n_hidden):
     return lib().oracle_mlp_n_params(ctypes.c_int(d_in), ctypes.c_int(d_hidden), ctypes.c_int(n_hidden))
 
 
+class mlp_accumulator:
+    """Context manager: the accumulator model of the MLP forward (0 = fp32 in k order, the parity comparator; 1 = a binary16
+    accumulator rounded after every 16-wide k-block, the other plausible reading of a WMMA fully-fused kernel)."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = lib().oracle_get_mlp_accumulator()
+        lib().oracle_set_mlp_accumulator(ctypes.c_int(self.mode))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_mlp_accumulator(ctypes.c_int(self.prev))
+        return False
+
+
 def mlp_fwd(params, x, d_hidden, n_hidden, want_acts=False):
     x = _f32(x)
     n, d_in = x.shape

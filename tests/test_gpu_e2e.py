@@ -125,6 +125,11 @@ def test_config1_end_to_end_parity(rt, fox_state):
     out = runner.render_train(d[0], d[1], d[2], d[4])
     colors = out["colors"].detach().cpu().numpy()
     assert np.abs(colors - ref["colors"]).max() <= 1e-3, np.abs(colors - ref["colors"]).max()  # north-star RGB tolerance
+    # ... and the same against the oracle's OTHER reading of the unpinned MLP contract (binary16 accumulator fragments,
+    # oracle/f2n_oracle.c: oracle_set_mlp_accumulator): the tolerance covers the accumulator nobody can pin
+    with oc.mlp_accumulator(1):
+        ref_h = oracle_train_iteration(st, cfg, arrays, ro, rd, cam, gt, noise, bg, eidx, ecoord, iter_step=1)
+    assert np.abs(colors - ref_h["colors"]).max() <= 1e-3, np.abs(colors - ref_h["colors"]).max()
     mse_g, mse_r = float(((colors - gt) ** 2).mean()), float(((ref["colors"] - gt) ** 2).mean())
     assert abs(10 * np.log10(1 / mse_g) - 10 * np.log10(1 / mse_r)) <= 1e-3  # PSNR within 1e-3 dB
     assert np.abs(out["disparity"].detach().cpu().numpy() - ref["disparity"]).max() <= 1e-3 * max(1.0, np.abs(ref["disparity"]).max())

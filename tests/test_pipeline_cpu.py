@@ -112,6 +112,34 @@ def test_shade_and_field_pipeline_shapes(fox_state, fox_golden):
     assert dp.shape == (7168,) and (dfeat[:, 0] == 0).all() and demb is None
 
 
+def test_mlp_accumulator_readings_are_closer_than_the_parity_tolerance(fox_state, fox_golden):
+    """The MLP rows of the oracle are "parity unpinned" (tiny-cuda-nn is not in the reference tree); what the published
+    FullyFusedMLP contract leaves open in the FORWARD arithmetic is the accumulator of the matrix products.  The oracle's
+    default is fp32 in k order; `mlp_accumulator(1)` is the other plausible reading of a WMMA kernel (binary16 accumulator
+    fragment, rounded after every 16-wide k-block).  This measures how far the two are apart through density MLP -> colour
+    MLP -> compositing on the golden march with trained-looking weights: well inside the 1e-3 RGB tolerance the GPU path is
+    held to against the default reading, so that tolerance also covers the reading nobody can pin."""
+    rng = np.random.default_rng(3)
+    st, g = fox_state, fox_golden
+    log2 = 14
+    grid = op.HashGrid((rng.standard_normal((16 << log2, 2)) * 0.3).astype(F32), st["prim_pool"], st["bias_pool"],
+                       int(st["n_volumes"]), log2)
+    p1, p2 = _params(rng, 1), _params(rng, 2)
+    se = g["march_pts_idx_bounds"]
+    bg = np.zeros((len(se), 3), F32)
+    out = {}
+    for mode in (0, 1):
+        with oc.mlp_accumulator(mode):
+            feat = op.field_fwd(grid, p1, g["march_pts"], g["march_anchors"][:, 0])
+            rgb = op.shade_fwd(p2, feat, g["march_dirs"])
+            comp = op.composite_fwd(feat, g["march_dt"], g["march_t"], rgb, bg, se)
+        out[mode] = (feat, rgb, comp["colors"])
+    d_feat, d_rgb, d_col = (float(np.abs(out[0][k] - out[1][k]).max()) for k in range(3))
+    assert 0.0 < d_feat <= 2e-3, d_feat   # the readings do differ (a few f16 ulps of the 16 field outputs) ...
+    assert d_rgb <= 5e-4, d_rgb           # ... by < 2e-4 in a sample's colour (measured 1.8e-4)
+    assert d_col <= 1e-4, d_col           # ... and by ~5e-6 in a composited ray colour
+
+
 def test_early_stop_prefix_and_adam():
     rng = np.random.default_rng(4)
     se, n = ragged(rng, 200, 80)
