@@ -201,8 +201,8 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     // (Pipelined data-parallel steps keep the sampling at the step boundary instead: there it runs underneath the gradient
     // all-reduce, which has nothing else to hide under -- measured with a one-rank RCCL world: 1.40 vs 1.53 ms per step.)
     // The NEXT batch's sampling only depends on this step's octree update: its kernels are issued (on a side stream) from
-    // inside SampleAndFilter, right behind that update, with the next iteration's fineness; the host comes back for its
-    // counts after this step's backward has been queued (PreSampleFinish below).
+    // inside SampleAndFilter, right behind that update, with the next iteration's fineness -- up to and including the pack;
+    // the host comes back for its counts at the top of the next step (Renderer::SampleAndFilter -> PreSampleFinish).
     const float fin = FinenessAt(iter_step_ + 1);
     renderer_->after_octree_update_ = [this, fin, &next_rays_o, &next_rays_d, &next_bounds]() {
       renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, fin);

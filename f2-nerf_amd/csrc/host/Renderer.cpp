@@ -311,11 +311,12 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
                                                    : torch::empty({n_edge, 2}, DevF32()).uniform_(-1.f, 1.f);
   }
-  if (draw_bg) {}
-  else if (forced_bg_.defined()) bg_color = forced_bg_.contiguous();
-  else if (bg_color_type_ == BGColorType::white) bg_color = torch::ones({n_rays, 3}, DevF32());
-  else if (bg_color_type_ == BGColorType::rand_noise) bg_color = torch::ones({n_rays, 3}, DevF32()) * .5f;
-  else bg_color = torch::zeros({n_rays, 3}, DevF32());
+  if (!draw_bg) {  // Renderer.cpp:67-81
+    if (forced_bg_.defined()) bg_color = forced_bg_.contiguous();
+    else if (bg_color_type_ == BGColorType::white) bg_color = torch::ones({n_rays, 3}, DevF32());
+    else if (bg_color_type_ == BGColorType::rand_noise) bg_color = torch::full({n_rays, 3}, .5f, DevF32());  // (not training)
+    else bg_color = torch::zeros({n_rays, 3}, DevF32());
+  }
 
   // A prefetch whose kernels were queued by the previous step: only now does the host wait for its count (everything between
   // the end of that step and this point -- the caller's loop, this step's bookkeeping, the draws above -- overlaps the march).
@@ -333,7 +334,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       // NOT told (record_stream on the seven tensors cost ~45 us of host time when they are released in the middle of the
       // step, right where the device is waiting for the next launch): instead samples_consumed_ev_ is recorded on this
       // stream once the last kernel that reads them has been queued, and the side stream waits for it before the next
-      // kernels that could be handed this memory again (PreSampleFinish).
+      // kernels that could be handed this memory again (PreSampleBegin).
       // (the wait itself is issued further down, right before the first kernel that reads the packed samples)
       wait_for_pack = true;
       consumed_side_samples_ = true;
