@@ -328,6 +328,10 @@ def main():
                        "marched_samples_per_s": n_marched / elapsed, "rho_marched_over_meaningful": rho,
                        "meaningful_samples_per_step": n_meaningful / args.steps},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged,
+            # buffers are sized for the worst case on purpose (1024 sample slots per ray, scatter queues): what that costs of 288 GB
+            "peak_hbm_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                             "reserved_by_allocator": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2),
+                             "note": "torch allocator only; the C-ABI library's own workspaces (scatter queues, planes) add ~1.3 GiB"},
         }
         print(json.dumps(line), flush=True)
 

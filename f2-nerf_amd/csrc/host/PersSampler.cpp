@@ -91,7 +91,11 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   // Leaf hits go into fixed-stride per-ray slots of a worst-case workspace (n_rays * max_oct_intersect_per_ray
   // entries of 12 B: ~100 MB at 8192 rays, nothing next to 288 GB of HBM): ONE DFS pass instead of the reference's
   // count pass + host sync + fill pass (PersSampler.cu:342-366).
-  const int64_t k_cap = int64_t(n_rays) * max_oct_intersect_per_ray_;
+  // (worst-case buffers are sized for the ray count rounded up to 2048: the adaptive batch of ExpRunner::Train changes its ray
+  // count every iteration, and a new size every iteration means a new hipMalloc every iteration -- the caching allocator had
+  // reserved 48 GiB by the end of a 20 000-iteration run)
+  const int64_t cap_rays = (int64_t(n_rays) + 2047) / 2048 * 2048;
+  const int64_t k_cap = cap_rays * max_oct_intersect_per_ray_;
   Tensor oct_idx = torch::empty({k_cap}, DevI32());
   Tensor oct_nf = torch::empty({k_cap, 2}, DevF32());
   Tensor oct_tr = torch::empty({k_cap}, DevI32());  // trans_idx of every listed leaf (the march would re-read the node)
@@ -103,7 +107,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   // ONE march into fixed-stride per-ray slots (28 B x 1024 per ray of scratch, of which only the filled prefixes are
   // touched) + the per-ray counts; the reference marches twice (count pass, host sync, fill pass: :383-423).
   Tensor pts_se = torch::empty({n_rays, 2}, DevI32());
-  const int64_t slots = int64_t(n_rays) * F2N_MAX_SAMPLE_PER_RAY;
+  const int64_t slots = cap_rays * F2N_MAX_SAMPLE_PER_RAY;
   Tensor s_dt = torch::empty({slots}, DevF32()), s_t = torch::empty({slots}, DevF32());  // warped points: computed by pack
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
   Tensor first_oct_dis = torch::empty({n_rays, 1}, DevF32());

@@ -21,4 +21,5 @@ for k in range(20):
     print("iters %5d..%5d  %.3f s  %.3f ms/iter  rays/iter %6.0f  marched/iter %7.0f  meaningful/iter %7.0f  nodes %6d  fineness %.2f" % (
         k * 1000, (k + 1) * 1000, el, el / n * 1e3, s["total_rays"] / n, (c1["total_marched"] - c0["total_marched"]) / n,
         (c1["total_meaningful"] - c0["total_meaningful"]) / n, runner.n_nodes(), float(runner.fineness)), flush=True)
-print("total %.2f s" % (time.perf_counter() - t_all))
+print("total %.2f s   peak HBM allocated %.2f GiB, reserved by the allocator %.2f GiB" % (
+    time.perf_counter() - t_all, torch.cuda.max_memory_allocated() / 2 ** 30, torch.cuda.max_memory_reserved() / 2 ** 30))
