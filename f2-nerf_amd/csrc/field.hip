@@ -392,7 +392,13 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 // ---------------------------------------------------------------------------------------------------
 #define F2N_BIN_SHIFT 12
 #define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
-#define F2N_BIN_NB 128        // sample chunks (producer blocks) per level
+#define F2N_BIN_NB 128        // sample chunks (producer blocks) per level: the launch shape, and the layout for large batches
+// How many of them are USED is decided on the device from the true sample count (it may still be a device-side value when
+// the kernels are launched): an owner block visits 2 x nb queue segments, each a dependent fabric round trip however few
+// records it holds, so with the ~2.6e5 samples of an ExpRunner::Train batch 128 chunks left the owners latency-bound on
+// mostly empty segments (0.09 ms, the same as for 8e5 samples).  Fewer, fuller segments: the queue memory of a (level,
+// slice) is split into nb segments of capacity cap * 128 / nb; producer blocks with B >= nb exit at once.
+__device__ __forceinline__ int f2n_bin_nb(int n_true) { return n_true > 393216 ? 128 : n_true > 131072 ? 64 : 32; }
 #define F2N_BIN_MAX_BINS 1024  // tables up to 2^22 entries per level (BASELINE config 5)
 #define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
@@ -411,10 +417,12 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
                                                        F2nBinQueues q, half_t* __restrict__ grad_table,
                                                        const int32_t* __restrict__ n_dev, int n_off) {
   F2N_RAISE_PRIO();
-  if (n_dev != nullptr) {  // the row count is still on the device: split what there really is over the producer blocks
-    n = min(n, *n_dev + n_off);
-    chunk = min(chunk, (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255);
-  }
+  if (n_dev != nullptr) n = min(n, *n_dev + n_off);  // the row count is still on the device
+  const int l = blockIdx.x % F2N_N_LEVELS, B = blockIdx.x / F2N_N_LEVELS;
+  const int nb = f2n_bin_nb(n);
+  if (B >= nb) return;  // (block-uniform, before any barrier)
+  chunk = (((n + nb - 1) / nb) + 255) & ~255;  // split what there really is over the producer blocks in use
+  const int cap_nb = q.cap * (F2N_BIN_NB / nb);
   __shared__ F2nLevelTab lt;
   __shared__ int s_cnt[F2N_BIN_MAX_BINS];
   __shared__ uint16_t s_idx[F2N_BIN_MAX_CHUNK];  // offsets (inside the chunk) of the samples with a non-zero gradient
@@ -423,12 +431,11 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
   for (int i = tid; i < q.n_bins; i += 256) s_cnt[i] = 0;
   __syncthreads();
-  const int l = blockIdx.x % F2N_N_LEVELS, B = blockIdx.x / F2N_N_LEVELS;
   const int s_begin = B * chunk, s_end = min(n, s_begin + chunk);
   const half_t* gl = gx + (size_t) (l >> 1) * gx_pair_stride + 2 * (l & 1);
   half2_t* tab = (half2_t*) (grad_table + lt.base[l]);
-  uint2* my_rec = q.rec + ((size_t) l * q.n_bins * F2N_BIN_NB + B) * q.cap;  // segment (l, bin, B) = my_rec + bin * bin_stride
-  const size_t bin_stride = (size_t) F2N_BIN_NB * q.cap;
+  uint2* my_rec = q.rec + ((size_t) l * q.n_bins * nb + B) * cap_nb;  // segment (l, bin, B) = my_rec + bin * bin_stride
+  const size_t bin_stride = (size_t) nb * cap_nb;
   // Samples whose whole f16 gradient is zero (most of them while the loss-scaled gradients sit at the f16 underflow
   // boundary) are dropped up front: nz_mask has one bit per sample (16-sample words, written by the MLP backward).
   // Order is preserved, so runs of equal cells stay adjacent.
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
             const uint32_t pos = cell.pos[d];
             const int bin = (int) (pos >> F2N_BIN_SHIFT);
             const int slot = atomicAdd(&s_cnt[bin], 1);
-            if (slot < q.cap) {
+            if (slot < cap_nb) {
               uint2 r;
               r.x = pos & (F2N_BIN_ENTRIES - 1);
               r.y = bits;
@@ -518,11 +525,12 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
     cur = nxt;
   }
   __syncthreads();
-  for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) l * q.n_bins + i) * F2N_BIN_NB + B] = min(s_cnt[i], q.cap);
+  for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) l * q.n_bins + i) * nb + B] = min(s_cnt[i], cap_nb);
 }
 
 __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
-                                                                  half_t* __restrict__ grad_table) {
+                                                                  half_t* __restrict__ grad_table, int n,
+                                                                  const int32_t* __restrict__ n_dev, int n_off) {
   F2N_RAISE_PRIO();
   __shared__ double s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp64 image of this block's table slice
   __shared__ int s_total;
@@ -530,12 +538,14 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   // table slice g <- (level l1 = g / H, local slice g - l1*H) and (level l1 - 1, local slice g - l1*H + H)
   const int H = slices_per_half_level, g = blockIdx.x;
   const int l1 = g / H, b1 = g - l1 * H;
-  // 2 sources x F2N_BIN_NB segments; wave w owns segments w, w+4, ...: lane j keeps the length of segment w + 4j
-  const int seg = wave + 4 * lane;                       // 0 .. 2*NB-1
-  const int src = seg / F2N_BIN_NB, B = seg % F2N_BIN_NB;
+  if (n_dev != nullptr) n = min(n, *n_dev + n_off);
+  const int nb = f2n_bin_nb(n), cap_nb = q.cap * (F2N_BIN_NB / nb);  // the producers' choice (same function of the same count)
+  // 2 sources x nb segments; wave w owns segments w, w+4, ...: lane j keeps the length of segment w + 4j
+  const int seg = wave + 4 * lane;                       // 0 .. 255, of which 0 .. 2*nb-1 exist
+  const int src = seg / nb, B = seg % nb;
   const int l = l1 - src, bl = b1 + src * H;
-  const bool live = l >= 0 && l < F2N_N_LEVELS && bl < q.n_bins;
-  const size_t my_seg = ((size_t) (live ? l : 0) * q.n_bins + (live ? bl : 0)) * F2N_BIN_NB + B;
+  const bool live = seg < 2 * nb && l >= 0 && l < F2N_N_LEVELS && bl < q.n_bins;
+  const size_t my_seg = ((size_t) (live ? l : 0) * q.n_bins + (live ? bl : 0)) * nb + (live ? B : 0);
   const int my_cnt = live ? q.cnt[my_seg] : 0;
   if (tid == 0) s_total = 0;
   __syncthreads();
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
       atomicAdd(&s_acc[2 * rec.x + 1], (double) val[1]);
     }
   };
-  for (int sg = 0; sg < 64; sg += 8) {  // eight segments at a time: up to sixteen independent loads in flight per lane
+  for (int sg = 0; sg < nb / 2; sg += 8) {  // eight segments at a time: up to sixteen independent loads in flight per lane
     uint2 rec[16];
     int cnt[8];
     const uint2* r[8];
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
     for (int u = 0; u < 8; u++) {
       cnt[u] = __shfl(my_cnt, sg + u);
       const unsigned long long sidx = __shfl((unsigned long long) my_seg, sg + u);
-      r[u] = q.rec + sidx * q.cap;
+      r[u] = q.rec + sidx * cap_nb;
       rec[2 * u] = lane < cnt[u] ? r[u][lane] : uint2{0u, 0u};
       rec[2 * u + 1] = lane + 64 < cnt[u] ? r[u][lane + 64] : uint2{0u, 0u};
     }
@@ -889,7 +899,7 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
                      level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table, n_dev, n_off);
   const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels
-  hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS + 1) * H), dim3(256), 0, st, q, H, grad_table);
+  hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS + 1) * H), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off);
   return f2n_launch_status();
 }
 
