@@ -82,6 +82,8 @@ def converged_leg(args, st, dev):
     s = runner.train(ds, args.train_iters, 1)
     torch.cuda.synchronize()
     train_wall = time.perf_counter() - t0
+    runner.test_image_psnr(ds, int(sc["test_set"][0]))  # untimed: the first render allocates its (larger) chunk buffers
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
     views = [float(v) for v in runner.test_images(ds)]
     torch.cuda.synchronize()
