@@ -48,3 +48,38 @@ def test_no_cpu_fallback_in_python_binding():
         capi._p(torch.zeros(4), "f32")
     src = open(os.path.join(ROOT, "f2-nerf_amd", "capi.py")).read() + open(os.path.join(ROOT, "f2-nerf_amd", "__init__.py")).read()
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_gather_plan_covers_every_tile_once_and_balances_the_xcds(lib):
+    """f2n_gather_plan_query (host only): the cost-balanced XCD split of the pre-pass gather.  Whatever the march step, every
+    (level pair, 256-sample tile) unit is served by exactly one XCD segment; without a step (fresh scenes) XCD x serves pair x
+    alone; with a short step (converged scenes: coarse pairs are ~10x cheaper per tile than the finest) the modelled cost per
+    XCD is within one tile of the mean."""
+    import numpy as np
+    seg_words = 1 + 3 * 8  # include/f2n_abi.h: out [8][1 + 3*8]
+    scales = np.array([16.0 * (4096.0 / 16.0) ** (l / 15.0) for l in range(16)], np.float32)  # per-level grid resolutions, 16 .. 4096
+    for n_tiles, step in ((3223, 0.0), (2110, 1.0 / 512), (2110, 1.0 / 64), (7, 1.0 / 512), (1, 0.0), (0, 1.0 / 512)):
+        out = np.full(8 * seg_words + 64, -7, np.int32)
+        cost = np.zeros(8, np.float32)
+        rc = lib.f2n_gather_plan_query(ctypes.c_int(n_tiles), ctypes.c_float(step), scales.ctypes.data_as(ctypes.c_void_p),
+                                       out.ctypes.data_as(ctypes.c_void_p), cost.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0 and (out[8 * seg_words:] == -7).all()
+        plan = out[:8 * seg_words].reshape(8, seg_words)
+        covered = np.zeros((8, max(n_tiles, 1)), np.int32)
+        load = np.zeros(8)
+        for x in range(8):
+            n_seg = int(plan[x, 0])
+            assert 0 <= n_seg <= (seg_words - 1) // 3
+            for k in range(n_seg):
+                pair, t0, cnt = (int(v) for v in plan[x, 1 + 3 * k:4 + 3 * k])
+                assert 0 <= pair < 8 and t0 >= 0 and cnt >= 0 and t0 + cnt <= n_tiles
+                covered[pair, t0:t0 + cnt] += 1
+                load[x] += cnt * float(cost[pair])
+        assert (covered[:, :n_tiles] == 1).all(), (n_tiles, step)
+        if step == 0.0:
+            for x in range(8):  # the plain split: XCD x owns level pair x
+                assert int(plan[x, 0]) == (1 if n_tiles > 0 else int(plan[x, 0])) and (n_tiles == 0 or int(plan[x, 1]) == x)
+            assert (cost == 1.0).all()
+        elif n_tiles >= 64:
+            assert cost[0] < cost[7]  # coarse pairs are cheaper per tile (consecutive samples share their cells) ...
+            assert load.max() - load.min() <= 2.0 * cost.max() + 1e-3 * load.mean(), (load, cost)  # ... and the XCDs end up even
