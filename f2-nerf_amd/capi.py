@@ -143,6 +143,14 @@ def edge_samples(n, edge_pool, transes, edge_idx, edge_coords, out_pts, out_idx)
                                _p(edge_coords, "f32"), _p(out_pts, "f32"), _p(out_idx, "i32")), "f2n_edge_samples")
 
 
+def early_stop_votes(n_rays, pts_se, f0, f0_stride, dt, weights, alphas, mask, kept, anchors, anchor_stride, w_adder, a_adder, mark,
+                     visit_cnt):
+    _ck(lib().f2n_early_stop_votes(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(f0, "f32"), _i(f0_stride), _p(dt, "f32"),
+                                   _p(weights, "f32"), _p(alphas, "f32"), _p(mask, "i32"), _p(kept, "i32"), _i(w_adder.numel()),
+                                   _p(anchors, "i32"), _i(anchor_stride), _p(w_adder, "i32"), _p(a_adder, "i32"), _p(mark, "i32"),
+                                   _p(visit_cnt, "i32")), "f2n_early_stop_votes")
+
+
 def oct_mark_visit(n_rays, pts_se, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt):
     _ck(lib().f2n_oct_mark_visit(_stream(), _i(n_rays), _i(w_adder.numel()), _p(pts_se, "i32"), _p(anchors, "i32"), _i(anchor_stride),
                                  _p(weights, "f32"), _p(alphas, "f32"), _p(w_adder, "i32"), _p(a_adder, "i32"),

@@ -184,19 +184,14 @@ std::tuple<Tensor, Tensor> PersSampler::GetEdgeSamples(int n_pts) {
   return {out_pts, out_idx};
 }
 
-// PersSampler.cu:536-615
-void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weight,
-                                 const Tensor& sampled_alpha) {
+// one [4, n_nodes] buffer: weight votes, alpha votes (init -1, :555-556), visited marks (0), running visit counts -- a
+// data-parallel run max-combines it across ranks with ONE collective.
+// The buffer persists between iterations: the visit counts stay where they are and the stat update re-arms the vote rows,
+// so an iteration issues no fill / copy here.  It is rebuilt whenever the node array or the visit counts were replaced
+// behind its back (ProcOctree, LoadStates, InstallOctree).
+Tensor& PersSampler::VoteBuffer() {
   auto& oct = *pers_octree_;
   const int n_nodes = oct.n_nodes_;
-  const int n_rays = sample_result.pts_idx_bounds.size(0);
-  CheckDev(sampled_weight, torch::kFloat32, "sampled_weight");
-  CheckDev(sampled_alpha, torch::kFloat32, "sampled_alpha");
-  // one [4, n_nodes] buffer: weight votes, alpha votes (init -1, :555-556), visited marks (0), running visit counts -- a
-  // data-parallel run max-combines it across ranks with ONE collective
-  // The buffer persists between iterations: the visit counts stay where they are and the stat update below re-arms the
-  // vote rows, so an iteration issues no fill / copy here.  It is rebuilt whenever the node array or the visit counts were
-  // replaced behind its back (ProcOctree, LoadStates, InstallOctree).
   Tensor& occ = oct.occ_;
   if (!occ.defined() || occ.size(1) != n_nodes || oct.tree_visit_cnt_.data_ptr() != (void*) (occ.data_ptr<int32_t>() + 3 * (int64_t) n_nodes)) {
     occ = torch::empty({4, n_nodes}, DevI32());
@@ -205,10 +200,42 @@ void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Te
     occ.select(0, 3).copy_(oct.tree_visit_cnt_);
     oct.tree_visit_cnt_ = occ.select(0, 3);
   }
-  void* st = CurStream();
-  F2N_TIMED_CALL("oct_mark_visit", f2n_oct_mark_visit(st, n_rays, n_nodes, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
+  return occ;
+}
+
+// PersSampler.cu:536-615
+void PersSampler::UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weight,
+                                 const Tensor& sampled_alpha) {
+  const int n_nodes = pers_octree_->n_nodes_;
+  const int n_rays = sample_result.pts_idx_bounds.size(0);
+  CheckDev(sampled_weight, torch::kFloat32, "sampled_weight");
+  CheckDev(sampled_alpha, torch::kFloat32, "sampled_alpha");
+  Tensor& occ = VoteBuffer();
+  F2N_TIMED_CALL("oct_mark_visit", f2n_oct_mark_visit(CurStream(), n_rays, n_nodes, I32P(sample_result.pts_idx_bounds), I32P(sample_result.anchors), 3,
                               F32P(sampled_weight), F32P(sampled_alpha), I32P(occ), I32P(occ) + n_nodes,
                               I32P(occ) + 2 * (int64_t) n_nodes, I32P(occ) + 3 * (int64_t) n_nodes));
+  FinishOctUpdate();
+}
+
+// The early stop of the density pre-pass (Renderer.cpp:115-126) and the votes of UpdateOctNodes in one launch (training steps:
+// the votes are cast over the weights / alphas the early stop produces); FinishOctUpdate() must follow.
+void PersSampler::EarlyStopAndVote(const SampleResultFlex& sample_result, const float* f0, Tensor& weights, Tensor& alphas, Tensor& mask,
+                                   Tensor& kept) {
+  const int n_nodes = pers_octree_->n_nodes_;
+  const int n_rays = sample_result.pts_idx_bounds.size(0);
+  Tensor& occ = VoteBuffer();
+  F2N_TIMED_CALL("early_stop", f2n_early_stop_votes(CurStream(), n_rays, I32P(sample_result.pts_idx_bounds), f0, 1, F32P(sample_result.dt),
+                              F32P(weights), F32P(alphas), I32P(mask), I32P(kept), n_nodes, I32P(sample_result.anchors), 3, I32P(occ),
+                              I32P(occ) + n_nodes, I32P(occ) + 2 * (int64_t) n_nodes, I32P(occ) + 3 * (int64_t) n_nodes));
+}
+
+// Everything of UpdateOctNodes behind the votes: the data-parallel exchange, the stat update (:579-593, MarkInvalidNodes
+// :528-534) and the octree maintenance that is due (:605-614).
+void PersSampler::FinishOctUpdate() {
+  auto& oct = *pers_octree_;
+  const int n_nodes = oct.n_nodes_;
+  Tensor& occ = oct.occ_;
+  void* st = CurStream();
   if (occupancy_sync_hook_) occupancy_sync_hook_(occ);
   Tensor adders = occ.slice(0, 0, 2), visit_mark = occ.select(0, 2);
   F2N_TIMED_CALL("oct_update_stats",f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),

@@ -84,6 +84,11 @@ class PersSampler : public PtsSampler {
   std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;
   void UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weights,
                       const Tensor& sampled_alpha) override;
+  // UpdateOctNodes split for the training step: early stop + votes in one launch, then the rest (exchange, stats, maintenance)
+  void EarlyStopAndVote(const SampleResultFlex& sample_result, const float* f0, Tensor& weights, Tensor& alphas, Tensor& mask,
+                        Tensor& kept);
+  void FinishOctUpdate();
+  Tensor& VoteBuffer();
   std::vector<Tensor> States() override;
   int LoadStates(const std::vector<Tensor>& states, int idx) override;
 

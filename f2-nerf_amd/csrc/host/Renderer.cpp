@@ -417,7 +417,9 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     }
     Tensor weights = torch::empty({n_all_pts}, DevF32()), alphas = torch::empty({n_all_pts}, DevF32());
     Tensor mask = torch::empty({n_all_pts}, DevI32()), kept = torch::empty({n_rays}, DevI32());
-    F2N_TIMED_CALL("early_stop", f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), f0p, 1, F32P(sample_result_.dt),
+    // training: the occupancy votes (first half of UpdateOctNodes, Renderer.cpp:140-149) ride in the early-stop launch
+    if (train) ps->EarlyStopAndVote(sample_result_, f0p, weights, alphas, mask, kept);
+    else F2N_TIMED_CALL("early_stop", f2n_early_stop(st, n_rays, I32P(sample_result_.pts_idx_bounds), f0p, 1, F32P(sample_result_.dt),
                             F32P(weights), F32P(alphas), I32P(mask), I32P(kept)));
     // The occupancy update (Renderer.cpp:140-149) is all the NEXT batch's sampling waits for, and that sampling is the longer
     // of the two chains of a converged step: a streaming step issues the update -- and, behind it, the prefetch on the side
@@ -433,7 +435,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       }
     };
     if (octree_first) {
-      pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);
+      ps->FinishOctUpdate();
       octree_update_issued();
     }
     Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::empty({1}, DevI32());
@@ -445,7 +447,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     n_kept_host_.copy_(total, /*non_blocking=*/true);
     n_kept_ev_.record();
     if (train && dp_world_ > 1) dp_count_ = total.clone();  // summed over the ranks inside the occupancy exchange
-    if (train && !octree_first) pts_sampler_->UpdateOctNodes(sample_result_, weights, alphas);  // Renderer.cpp:140-149
+    if (train && !octree_first) ps->FinishOctUpdate();  // Renderer.cpp:140-149 (the votes were cast above)
     if (train && dp_world_ > 1) {
       if (!dp_count_host_.defined()) dp_count_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
       dp_count_host_.copy_(dp_count_, /*non_blocking=*/true);

@@ -2,7 +2,7 @@
 // occupancy bookkeeping.  Semantics follow PtsSampler/PersSampler.cu:21-680 of the reference (cited per
 // kernel); the structure does not: two-phase count / device-side scan / fill with ray-ordered segments
 // and no host read-back, wave64 blocks, LDS-resident DFS stacks.
-#include "f2n_dev.h"
+#include "rows_dev.h"
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -611,6 +611,80 @@ __device__ __forceinline__ void f2n_vote(int32_t* w_adder, int32_t* a_adder, int
 // USE_LDS: the votes of a block's rays are first max-combined in LDS (ds_max_i32) and flushed once per block.
 // A few hundred leaves receive tens of thousands of votes per batch; as global atomics those are long
 // same-address dependent chains (~1 us each at the memory-side atomic unit).
+// The votes of one ray (its 16-lane row): thresholds from the ray's maxima (:12-17), then one vote per run of equal leaves,
+// cast by the run's last sample, which learns the run's maxima and start from a segmented max-scan over DPP row shifts.
+__device__ __forceinline__ void f2n_ray_votes(int s, int e, int c, float mw, float ma, const int32_t* __restrict__ anchors,
+                                              int anchor_stride, const float* weights, const float* alphas, int32_t* w_adder,
+                                              int32_t* a_adder, int32_t* mark, int32_t* cnt) {
+  // 0.1 / 0.01 / 0.02 are double literals in the reference (:12-17): float*double, then narrowed by fminf
+  const float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
+  const float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
+  float carry_w = 0.f, carry_a = 0.f;
+  int carry_start = s;
+  for (int base = s; base < e; base += 16) {
+    const int i = base + c;
+    const bool in = i < e;
+    const int ic = in ? i : e - 1;
+    const int node = anchors[(size_t) ic * anchor_stride + 1];
+    const int prev = ic > s ? anchors[(size_t) (ic - 1) * anchor_stride + 1] : -1;
+    const int next = ic + 1 < e ? anchors[(size_t) (ic + 1) * anchor_stride + 1] : -1;
+    const bool head = node != prev;
+    float cw = fmaxf(0.f, weights[ic]), ca = fmaxf(0.f, alphas[ic]);  // the reference's running maxima start at 0
+    int start = head ? ic : (int) 0x80000000;
+    if (c == 0 && !head) {  // the run continues from the previous chunk
+      cw = fmaxf(cw, carry_w);
+      ca = fmaxf(ca, carry_a);
+      start = carry_start;
+    }
+    int f = head ? 1 : 0;
+#define F2N_SEGMAX_STEP(K)                                                                     \
+  {                                                                                            \
+    const float tw = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cw), 0x110 + K, 0xF, 0xF, false)); \
+    const float ta = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ca), 0x110 + K, 0xF, 0xF, false)); \
+    const int ts = __builtin_amdgcn_update_dpp((int) 0x80000000, start, 0x110 + K, 0xF, 0xF, false);              \
+    const int tf = __builtin_amdgcn_update_dpp(1, f, 0x110 + K, 0xF, 0xF, false);                                 \
+    if (c >= K && f == 0) {                                                                    \
+      cw = fmaxf(cw, tw);                                                                      \
+      ca = fmaxf(ca, ta);                                                                      \
+      start = max(start, ts);                                                                  \
+    }                                                                                          \
+    if (c >= K) f |= tf;                                                                       \
+  }
+    F2N_SEGMAX_STEP(1)
+    F2N_SEGMAX_STEP(2)
+    F2N_SEGMAX_STEP(4)
+    F2N_SEGMAX_STEP(8)
+#undef F2N_SEGMAX_STEP
+    if (in && node != next) f2n_vote(w_adder, a_adder, mark, cnt, node, cw, ca, w_thres, a_thres, ic - start + 1);
+    carry_w = __shfl(cw, 15, 16);
+    carry_a = __shfl(ca, 15, 16);
+    carry_start = __shfl(start, 15, 16);
+  }
+}
+
+// USE_LDS: block-local vote images (see mark_visit_kernel) -- set up / flushed by these two.
+__device__ __forceinline__ void f2n_votes_lds_init(int32_t* s_votes, int n_nodes) {
+  for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
+    s_votes[i] = -2;
+    s_votes[n_nodes + i] = -2;
+    s_votes[2 * n_nodes + i] = 0;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void f2n_votes_lds_flush(const int32_t* s_votes, int n_nodes, int32_t* g_w_adder, int32_t* g_a_adder,
+                                                    int32_t* g_mark, int32_t* g_cnt) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
+    const int visits = s_votes[2 * n_nodes + i];
+    if (visits > 0) {
+      atomicMax(g_w_adder + i, s_votes[i]);
+      atomicMax(g_a_adder + i, s_votes[n_nodes + i]);
+      atomicMax(g_cnt + i, visits);
+      g_mark[i] = 1;
+    }
+  }
+}
+
 template <bool USE_LDS>
 __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __restrict__ pts_start_end,
                                   const int32_t* __restrict__ anchors, int anchor_stride, const float* __restrict__ weights,
@@ -621,16 +695,8 @@ __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __rest
   int32_t* a_adder = USE_LDS ? s_votes + n_nodes : g_a_adder;
   int32_t* cnt = USE_LDS ? s_votes + 2 * n_nodes : g_cnt;
   int32_t* mark = USE_LDS ? nullptr : g_mark;  // LDS path: "visited" <=> block-local visit count >= 1
-  if (USE_LDS) {
-    for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
-      s_votes[i] = -2;
-      s_votes[n_nodes + i] = -2;
-      s_votes[2 * n_nodes + i] = 0;
-    }
-    __syncthreads();
-  }
-  // one 16-lane row per ray (the votes are integer maxima: order-free); a vote is cast by the last sample of each
-  // run of equal leaves, which learns the run's maxima and start from a segmented max-scan over DPP row shifts
+  if (USE_LDS) f2n_votes_lds_init(s_votes, n_nodes);
+  // one 16-lane row per ray (the votes are integer maxima: order-free)
   const int c = threadIdx.x & 15;
   const int ray = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
   int s = 0, e = 0;
@@ -649,63 +715,81 @@ __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __rest
       mw = fmaxf(mw, __shfl_xor(mw, off, 16));
       ma = fmaxf(ma, __shfl_xor(ma, off, 16));
     }
-    // 0.1 / 0.01 / 0.02 are double literals in the reference (:12-17): float*double, then narrowed by fminf
-    const float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
-    const float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
-    float carry_w = 0.f, carry_a = 0.f;
-    int carry_start = s;
-    for (int base = s; base < e; base += 16) {
-      const int i = base + c;
-      const bool in = i < e;
-      const int ic = in ? i : e - 1;
-      const int node = anchors[(size_t) ic * anchor_stride + 1];
-      const int prev = ic > s ? anchors[(size_t) (ic - 1) * anchor_stride + 1] : -1;
-      const int next = ic + 1 < e ? anchors[(size_t) (ic + 1) * anchor_stride + 1] : -1;
-      const bool head = node != prev;
-      float cw = fmaxf(0.f, weights[ic]), ca = fmaxf(0.f, alphas[ic]);  // the reference's running maxima start at 0
-      int start = head ? ic : (int) 0x80000000;
-      if (c == 0 && !head) {  // the run continues from the previous chunk
-        cw = fmaxf(cw, carry_w);
-        ca = fmaxf(ca, carry_a);
-        start = carry_start;
-      }
-      int f = head ? 1 : 0;
-#define F2N_SEGMAX_STEP(K)                                                                     \
-  {                                                                                            \
-    const float tw = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cw), 0x110 + K, 0xF, 0xF, false)); \
-    const float ta = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ca), 0x110 + K, 0xF, 0xF, false)); \
-    const int ts = __builtin_amdgcn_update_dpp((int) 0x80000000, start, 0x110 + K, 0xF, 0xF, false);              \
-    const int tf = __builtin_amdgcn_update_dpp(1, f, 0x110 + K, 0xF, 0xF, false);                                 \
-    if (c >= K && f == 0) {                                                                    \
-      cw = fmaxf(cw, tw);                                                                      \
-      ca = fmaxf(ca, ta);                                                                      \
-      start = max(start, ts);                                                                  \
-    }                                                                                          \
-    if (c >= K) f |= tf;                                                                       \
+    f2n_ray_votes(s, e, c, mw, ma, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, cnt);
   }
-      F2N_SEGMAX_STEP(1)
-      F2N_SEGMAX_STEP(2)
-      F2N_SEGMAX_STEP(4)
-      F2N_SEGMAX_STEP(8)
-#undef F2N_SEGMAX_STEP
-      if (in && node != next) f2n_vote(w_adder, a_adder, mark, cnt, node, cw, ca, w_thres, a_thres, ic - start + 1);
-      carry_w = __shfl(cw, 15, 16);
-      carry_a = __shfl(ca, 15, 16);
-      carry_start = __shfl(start, 15, 16);
+  if (USE_LDS) f2n_votes_lds_flush(s_votes, n_nodes, g_w_adder, g_a_adder, g_mark, g_cnt);
+}
+
+// f2n_early_stop (Renderer.cpp:115-126) and f2n_oct_mark_visit (PersSampler.cu:475-526) in one launch: the pre-pass of a
+// training step walks every ray twice in a row -- transmittance / weights / mask, then the occupancy votes over those very
+// weights -- with the same row-per-ray mapping, and the second walk was a dependent launch on the chain the NEXT batch's
+// sampling waits for (pre-pass -> votes -> stat update).  The row keeps the ray's maxima while it writes weights and alphas and
+// re-reads its own writes for the votes (same lane, same address: no fence needed).  Arithmetic and outputs are those of the
+// two kernels, bit for bit.
+template <bool USE_LDS>
+__global__ void early_stop_votes_kernel(int n_rays, int n_nodes, const int32_t* __restrict__ se, const float* __restrict__ f0,
+                                        int f0_stride, const float* __restrict__ dt, float* weights, float* alphas,
+                                        int32_t* __restrict__ mask, int32_t* __restrict__ kept,
+                                        const int32_t* __restrict__ anchors, int anchor_stride, int32_t* g_w_adder,
+                                        int32_t* g_a_adder, int32_t* g_mark, int32_t* g_cnt) {
+  extern __shared__ int32_t s_votes[];
+  int32_t* w_adder = USE_LDS ? s_votes : g_w_adder;
+  int32_t* a_adder = USE_LDS ? s_votes + n_nodes : g_a_adder;
+  int32_t* cnt_v = USE_LDS ? s_votes + 2 * n_nodes : g_cnt;
+  int32_t* mark = USE_LDS ? nullptr : g_mark;
+  if (USE_LDS) f2n_votes_lds_init(s_votes, n_nodes);
+  const int c = threadIdx.x & 15;
+  const int ray = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+  int s = 0, e = 0;
+  if (ray < n_rays) {
+    s = se[2 * ray];
+    e = se[2 * ray + 1];
+  }
+  // ---- early stop: the walk of early_stop_kernel ----
+  float acc = 0.f, mw = 0.f, ma = 0.f;
+  int cnt = 0;
+  float n_f0 = 0.f, n_dt = 0.f;
+  if (s < e) {
+    const int i = min(s + c, e - 1);
+    n_f0 = f0[(size_t) i * f0_stride];
+    n_dt = dt[i];
+  }
+  for (int base = s; base < e; base += 16) {
+    const int i = base + c;
+    const bool in = i < e;
+    const float c_f0 = n_f0, c_dt = n_dt;
+    if (base + 16 < e) {
+      const int j = min(i + 16, e - 1);
+      n_f0 = f0[(size_t) j * f0_stride];
+      n_dt = dt[j];
     }
-  }
-  if (USE_LDS) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
-      const int visits = s_votes[2 * n_nodes + i];
-      if (visits > 0) {
-        atomicMax(g_w_adder + i, s_votes[i]);
-        atomicMax(g_a_adder + i, s_votes[n_nodes + i]);
-        atomicMax(g_cnt + i, visits);
-        g_mark[i] = 1;
-      }
+    float sec = 0.f;
+    if (in) sec = expf(c_f0 - F2N_DENSITY_SHIFT) * c_dt;
+    const float alpha = 1.f - expf(-sec);
+    const float incl = f2n_row_seq_scan(sec, acc, c);
+    const float trans = expf(-f2n_row_exclusive(incl, acc, c));  // exclusive cumulative density
+    acc = f2n_row_last(incl);
+    const int m = (in && trans > F2N_T_EPS) ? 1 : 0;
+    if (in) {
+      const float w = trans * alpha;
+      weights[i] = w;
+      alphas[i] = alpha;
+      mask[i] = m;
+      mw = fmaxf(mw, w);
+      ma = fmaxf(ma, alpha);
     }
+    cnt += m;
   }
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    cnt += __shfl_xor(cnt, off, 16);
+    mw = fmaxf(mw, __shfl_xor(mw, off, 16));
+    ma = fmaxf(ma, __shfl_xor(ma, off, 16));
+  }
+  if (ray < n_rays && c == 0) kept[ray] = cnt;
+  // ---- votes: the walk of mark_visit_kernel over what this row has just written ----
+  if (s < e) f2n_ray_votes(s, e, c, mw, ma, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, cnt_v);
+  if (USE_LDS) f2n_votes_lds_flush(s_votes, n_nodes, g_w_adder, g_a_adder, g_mark, g_cnt);
 }
 
 // PersSampler.cu:579-593 (torch integer ops) + MarkInvalidNodes (:528-534), one node per lane.
@@ -1012,6 +1096,24 @@ int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts
   } else {
     hipLaunchKernelGGL(mark_visit_kernel<false>, dim3(f2n_div_up(n_rays, 16)), dim3(256), 0, (hipStream_t) stream, n_rays,
                        n_nodes, pts_start_end, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, visit_cnt);
+  }
+  return f2n_launch_status();
+}
+
+int f2n_early_stop_votes(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
+                         float* weights, float* alphas, int32_t* mask, int32_t* kept, int n_nodes, const int32_t* anchors,
+                         int anchor_stride, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* visit_cnt) {
+  if (n_rays < 0 || n_nodes < 1 || anchor_stride < 2 || f0_stride < 1) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  const size_t lds = sizeof(int32_t) * 3 * (size_t) n_nodes;
+  if (lds <= 60 * 1024) {
+    hipLaunchKernelGGL(early_stop_votes_kernel<true>, dim3(f2n_div_up(n_rays, 64)), dim3(1024), lds, (hipStream_t) stream, n_rays,
+                       n_nodes, pts_start_end, f0, f0_stride, dt, weights, alphas, mask, kept, anchors, anchor_stride, w_adder,
+                       a_adder, mark, visit_cnt);
+  } else {
+    hipLaunchKernelGGL(early_stop_votes_kernel<false>, dim3(f2n_div_up(n_rays, 16)), dim3(256), 0, (hipStream_t) stream, n_rays,
+                       n_nodes, pts_start_end, f0, f0_stride, dt, weights, alphas, mask, kept, anchors, anchor_stride, w_adder,
+                       a_adder, mark, visit_cnt);
   }
   return f2n_launch_status();
 }

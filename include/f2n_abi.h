@@ -387,6 +387,12 @@ int f2n_reduce_deferred(void* stream);
 int f2n_early_stop(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride,
                    const float* dt, float* weights /*[N]*/, float* alphas /*[N]*/, int32_t* mask /*[N]*/,
                    int32_t* kept /*[R]*/);
+/* f2n_early_stop followed by f2n_oct_mark_visit (the occupancy votes of PersSampler.cu:475-526 over the weights / alphas the
+ * early stop has just produced) in ONE launch: same outputs, bit for bit.  anchors: node index of sample i at
+ * anchors[i*anchor_stride + 1]; vote buffers as f2n_oct_mark_visit expects them. */
+int f2n_early_stop_votes(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
+                         float* weights, float* alphas, int32_t* mask, int32_t* kept, int n_nodes, const int32_t* anchors,
+                         int anchor_stride, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* visit_cnt);
 
 /* Compaction of the surviving samples (Renderer.cpp:128-135: the five index-gathers).  Sample order is
  * preserved; new_start_end comes from f2n_segment_scan(kept). */

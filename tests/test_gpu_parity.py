@@ -279,6 +279,37 @@ def test_edge_samples_and_occupancy(hip, fox_state, fox_golden):
     assert_same(N(tn2).view(NODE_DT)["trans_idx"].copy(), g["invisible_trans_idx"], "invisible")
 
 
+@pytest.mark.parametrize("n_nodes", [897, 200000])  # block-local vote images in LDS / global atomics (more nodes than fit)
+def test_early_stop_and_votes_in_one_launch(hip, fox_golden, n_nodes):
+    """f2n_early_stop_votes = f2n_early_stop + f2n_oct_mark_visit: weights, alphas, mask, kept counts and all four vote /
+    mark / visit-count arrays equal those of the two separate launches, bit for bit, in both vote modes; ragged and empty
+    rays included."""
+    g = fox_golden
+    rng = np.random.default_rng(8)
+    se, anchors, dt = g["march_pts_idx_bounds"].copy(), g["march_anchors"].copy(), g["march_dt"]
+    n, R = len(dt), len(se)
+    se[3] = (se[3, 0], se[3, 0])  # an empty ray (its samples are simply not referenced)
+    if n_nodes > 897:  # spread the leaves over a big node array so that runs of equal leaves stay runs
+        anchors[:, 1] = (anchors[:, 1].astype(np.int64) * 211) % n_nodes
+    f0 = (rng.standard_normal(n) * 2.0 + 1.0).astype(F32)  # dense enough for the early stop to bite
+    d_se, d_f0, d_dt, d_an = T(se), T(f0), T(dt), T(anchors)
+
+    def buffers():
+        return dict(w=torch.full((n,), -5., device=DEV), a=torch.full((n,), -5., device=DEV),
+                    m=torch.full((n,), -5, dtype=torch.int32, device=DEV), k=torch.full((R,), -5, dtype=torch.int32, device=DEV),
+                    wa=torch.full((n_nodes,), -1, dtype=torch.int32, device=DEV), aa=torch.full((n_nodes,), -1, dtype=torch.int32, device=DEV),
+                    mk=torch.zeros(n_nodes, dtype=torch.int32, device=DEV),
+                    vc=torch.from_numpy(rng.integers(0, 3, n_nodes).astype(np.int32)).to(DEV))
+    rng = np.random.default_rng(9); a = buffers()
+    rng = np.random.default_rng(9); b = buffers()
+    hip.early_stop(R, d_se, d_f0, 1, d_dt, a["w"], a["a"], a["m"], a["k"])
+    hip.oct_mark_visit(R, d_se, d_an, 3, a["w"], a["a"], a["wa"], a["aa"], a["mk"], a["vc"])
+    hip.early_stop_votes(R, d_se, d_f0, 1, d_dt, b["w"], b["a"], b["m"], b["k"], d_an, 3, b["wa"], b["aa"], b["mk"], b["vc"])
+    for key in a:
+        assert_same(N(a[key]), N(b[key]), key)
+    assert int(N(a["k"])[3]) == 0 and 0 < int(N(a["k"]).sum()) < n and int(N(a["mk"]).sum()) > 10
+
+
 def test_edge_samples_from_uniforms_and_sampler_prologue(hip, fox_state, fox_golden):
     """f2n_edge_samples_ex: three uniforms per point instead of (randint, uniform(-1,1)) draws -- idx = floor(u0 * n_edges),
     coords = 2u - 1 --, the index output at the stride of an anchors array and a second destination: all equal to the
