@@ -277,12 +277,14 @@ def shade_fwd(n, feat, dirs, app_emb, sample_emb_idx, mlp_params_h, rgb, save_x_
 
 
 def field_shade_fwd(n, src_rows, x_cache_h, field_params_h, dirs, app_emb, sample_emb_idx, color_params_h, out_f0, save_field_x_h,
-                    save_shade_x_h, rgb, n_dev=None):
-    _ck(lib().f2n_field_shade_fwd_dyn(_stream(), _i(n), _p(n_dev, "i32", True), _p(src_rows, "i32", True), _p(x_cache_h, "h16"),
-                                      _p(field_params_h, "h16"), _p(dirs, "f32"), _p(app_emb, "f32", True),
-                                      _p(sample_emb_idx, "i32", True), _p(color_params_h, "h16"), _p(out_f0, "f32", True),
-                                      _p(save_field_x_h, "h16", True), _p(save_shade_x_h, "h16", True), _p(rgb, "f32")),
-        "f2n_field_shade_fwd_dyn")
+                    save_shade_x_h, rgb, n_dev=None, x_extra_h=None, feat_extra=None, save_x_extra_h=None):
+    n_extra = 0 if x_extra_h is None else x_extra_h.shape[0]
+    _ck(lib().f2n_field_shade_fwd_extra(_stream(), _i(n), _p(n_dev, "i32", True), _p(src_rows, "i32", True), _p(x_cache_h, "h16"),
+                                        _p(field_params_h, "h16"), _p(dirs, "f32"), _p(app_emb, "f32", True),
+                                        _p(sample_emb_idx, "i32", True), _p(color_params_h, "h16"), _p(out_f0, "f32", True),
+                                        _p(save_field_x_h, "h16", True), _p(save_shade_x_h, "h16", True), _p(rgb, "f32"), _i(n_extra),
+                                        _p(x_extra_h, "h16", True), _p(feat_extra, "f32", True), _p(save_x_extra_h, "h16", True)),
+        "f2n_field_shade_fwd_extra")
 
 
 def shade_bwd(n, drgb, sample_emb_idx, mlp_params_h, saved_x_h, loss_scale, dfeat, dparams_scaled, dapp_emb, df0=None):

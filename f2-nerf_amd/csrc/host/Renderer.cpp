@@ -626,21 +626,21 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
     // are never written (only the 2E edge rows of `feat` exist: the TV loss reads them); the synchronous path below keeps
     // the two separate kernels and is what tests compare this with
     TORCH_CHECK(field->prepass_x_.defined(), "no pre-pass feature cache for this query");
-    if (n_edge > 0 && fr.edge_cache_row >= 0)  // field MLP of the edge samples on the rows the pre-pass cached for them
-      F2N_TIMED_CALL("field_fwd", f2n_field_fwd_cached(st, 2 * n_edge, 2 * n_edge, nullptr,
-                             static_cast<const void*>(field->prepass_x_.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * fr.edge_cache_row),
-                             VoidP(field->mlp_->params_h_), F32P(feat), nullptr, VoidP(field_x)));
-    else if (n_edge > 0)
+    const bool edges_ride = n_edge > 0 && fr.edge_cache_row >= 0;  // their hash features are in the pre-pass cache too
+    if (n_edge > 0 && !edges_ride)
       F2N_TIMED_CALL("field_fwd", f2n_field_fwd(st, 2 * n_edge, field->n_volumes_, VoidP(field->feat_pool_h_), I32P(field->prim_pool_),
                              I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
                              F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
                              F32P(feat), nullptr, VoidP(field_x)));
-    F2N_TIMED_CALL("field_shade_fwd", f2n_field_shade_fwd_dyn(st, n_kept, n_dev, I32P(fr.src_rows),
-                           static_cast<const void*>(field->prepass_x_.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * fr.sample_cache_row),
-                           VoidP(field->mlp_->params_h_), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
-                           fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(f0c),
-                           static_cast<void*>(field_x.data_ptr<at::Half>() + (int64_t) N_LEVELS * N_CHANNELS * so), VoidP(shade_x),
-                           F32P(rgb)));
+    const at::Half* cache = field->prepass_x_.data_ptr<at::Half>();
+    const int64_t row = (int64_t) N_LEVELS * N_CHANNELS;
+    // survivors: field MLP -> colour path; edge samples (when cached): field MLP only, fp32 rows for the TV loss -- one launch
+    F2N_TIMED_CALL("field_shade_fwd", f2n_field_shade_fwd_extra(st, n_kept, n_dev, I32P(fr.src_rows),
+                           static_cast<const void*>(cache + row * fr.sample_cache_row), VoidP(field->mlp_->params_h_), F32P(es.dirs),
+                           fr.emb ? F32P(app) : nullptr, fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_),
+                           F32P(f0c), static_cast<void*>(field_x.data_ptr<at::Half>() + row * so), VoidP(shade_x), F32P(rgb),
+                           edges_ride ? 2 * n_edge : 0, edges_ride ? static_cast<const void*>(cache + row * fr.edge_cache_row) : nullptr,
+                           edges_ride ? F32P(feat) : nullptr, edges_ride ? VoidP(field_x) : nullptr));
     field->prepass_x_ = Tensor();
   } else {
     field->ForwardRaw(fr.pts_all, fr.vol_all, 1, fr.src_rows, n_kept, feat, field_x, &f0c);

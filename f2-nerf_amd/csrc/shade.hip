@@ -185,16 +185,41 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
                                                               const int32_t* __restrict__ sample_emb_idx,
                                                               const half_t* __restrict__ color_params, float* __restrict__ out_f0,
                                                               half_t* __restrict__ save_field_x, half_t* __restrict__ save_shade_x,
-                                                              float* __restrict__ rgb) {
+                                                              float* __restrict__ rgb, int n_extra,
+                                                              const half_t* __restrict__ x_extra, float* __restrict__ feat_extra,
+                                                              half_t* __restrict__ save_x_extra) {
   F2N_RAISE_PRIO();
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   if (n_dev != nullptr) n = min(n, *n_dev);
   F2nMlpFwdW<1> wf;
   wf.load(field_params, c, g);
+  const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
+  // "extra" rows (the 2E edge samples of the TV loss, Renderer.cpp:159-166): field MLP only, on their own cached rows; their
+  // 16 outputs are wanted as fp32 rows (the loss reads them).  Exactly f2n_field_fwd_cached's arithmetic; riding here saves
+  // that launch.  The LAST waves of the grid take them, the first ones start on the survivors' tiles at once.
+  {
+    const int n_etiles = (n_extra + 15) / 16;
+    for (int tile = wave_stride - 1 - wave_global; tile < n_etiles; tile += wave_stride) {
+      const int s = tile * 16 + c;
+      const bool valid = s < n_extra;
+      const half8_t xf = valid ? f2n_rowfrag(x_extra, F2N_D_IN, s, 0, g) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (save_x_extra != nullptr && valid) {
+        half_t* p = save_x_extra + (size_t) s * F2N_D_IN + 4 * g;
+        *(half4_t*) p = __builtin_shufflevector(xf, xf, 0, 1, 2, 3);
+        *(half4_t*) (p + 16) = __builtin_shufflevector(xf, xf, 4, 5, 6, 7);
+      }
+      const float4_t o = wf.forward(xf);
+      if (valid) {
+        float4_t of;
+#pragma unroll
+        for (int r = 0; r < 4; r++) of[r] = (float) (half_t) o[r];  // output precision is f16 (TCNNWP.cpp:143-144)
+        *(float4_t*) (feat_extra + (size_t) s * F2N_D_OUT + 4 * g) = of;
+      }
+    }
+  }
   F2nMlpFwdW<2> wc;
   wc.load(color_params, c, g);
   const int n_tiles = (n + 15) / 16;
-  const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
   struct In {
     half8_t xf;
     float4_t e;
@@ -460,13 +485,24 @@ int f2n_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
 int f2n_field_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const int32_t* src_rows, const void* x_cache_h,
                             const void* field_params_h, const float* dirs, const float* app_emb, const int32_t* sample_emb_idx,
                             const void* color_params_h, float* out_f0, void* save_field_x_h, void* save_shade_x_h, float* rgb) {
+  return f2n_field_shade_fwd_extra(stream, n_max, n_dev, src_rows, x_cache_h, field_params_h, dirs, app_emb, sample_emb_idx,
+                                   color_params_h, out_f0, save_field_x_h, save_shade_x_h, rgb, 0, nullptr, nullptr, nullptr);
+}
+
+int f2n_field_shade_fwd_extra(void* stream, int n_max, const int32_t* n_dev, const int32_t* src_rows, const void* x_cache_h,
+                              const void* field_params_h, const float* dirs, const float* app_emb, const int32_t* sample_emb_idx,
+                              const void* color_params_h, float* out_f0, void* save_field_x_h, void* save_shade_x_h, float* rgb,
+                              int n_extra, const void* x_extra_h, float* feat_extra, void* save_x_extra_h) {
   const int n = n_max;
-  if (n < 0 || (n > 0 && (x_cache_h == nullptr || rgb == nullptr)) || (app_emb != nullptr && sample_emb_idx == nullptr))
+  if (n < 0 || n_extra < 0 || (n > 0 && (x_cache_h == nullptr || rgb == nullptr)) || (app_emb != nullptr && sample_emb_idx == nullptr) ||
+      (n_extra > 0 && (x_extra_h == nullptr || feat_extra == nullptr)))
     return F2N_ERR_INVALID_ARG;
-  if (n == 0) return F2N_OK;
-  hipLaunchKernelGGL(field_shade_fwd_kernel, dim3(f2n_shade_grid((n + 15) / 16, 4)), dim3(256), 0, (hipStream_t) stream, n, n_dev,
+  if (n == 0 && n_extra == 0) return F2N_OK;
+  const int tiles = (n + 15) / 16 + (n_extra + 15) / 16;
+  hipLaunchKernelGGL(field_shade_fwd_kernel, dim3(f2n_shade_grid(tiles, 4)), dim3(256), 0, (hipStream_t) stream, n, n_dev,
                      src_rows, (const half_t*) x_cache_h, (const half_t*) field_params_h, dirs, app_emb, sample_emb_idx,
-                     (const half_t*) color_params_h, out_f0, (half_t*) save_field_x_h, (half_t*) save_shade_x_h, rgb);
+                     (const half_t*) color_params_h, out_f0, (half_t*) save_field_x_h, (half_t*) save_shade_x_h, rgb, n_extra,
+                     (const half_t*) x_extra_h, feat_extra, (half_t*) save_x_extra_h);
   return f2n_launch_status();
 }
 

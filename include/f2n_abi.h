@@ -365,6 +365,13 @@ int f2n_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
 int f2n_field_shade_fwd_dyn(void* stream, int n_max, const int32_t* n_dev, const int32_t* src_rows, const void* x_cache_h,
                             const void* field_params_h, const float* dirs, const float* app_emb, const int32_t* sample_emb_idx,
                             const void* color_params_h, float* out_f0, void* save_field_x_h, void* save_shade_x_h, float* rgb);
+/* ... plus n_extra rows that only go through the field MLP (x_extra_h [n_extra,32] -> feat_extra fp32 [n_extra,16], inputs
+ * saved to save_x_extra_h or NULL): f2n_field_fwd_cached for the edge (TV) samples of Renderer.cpp:159-166 riding in the same
+ * launch. */
+int f2n_field_shade_fwd_extra(void* stream, int n_max, const int32_t* n_dev, const int32_t* src_rows, const void* x_cache_h,
+                              const void* field_params_h, const float* dirs, const float* app_emb, const int32_t* sample_emb_idx,
+                              const void* color_params_h, float* out_f0, void* save_field_x_h, void* save_shade_x_h, float* rgb,
+                              int n_extra, const void* x_extra_h, float* feat_extra, void* save_x_extra_h);
 int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float* drgb, const int32_t* sample_emb_idx,
                       const void* mlp_params_h, const void* saved_x_h, float loss_scale, float* dfeat, float* dparams_f32_scaled,
                       float* dapp_emb, int n_emb, const float* df0, int defer_reduce);

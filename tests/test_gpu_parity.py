@@ -724,6 +724,20 @@ def test_field_and_shade_forward_in_one_launch(hip, fox_state, fox_golden, use_e
     assert_same(N(sxb).view(np.uint16)[:m_dyn], N(sx).view(np.uint16)[:m_dyn], "colour input rows")
     if use_ndev:  # rows past the device-side count are untouched
         assert (N(rgbb)[m_dyn:] == -7.0).all() and (N(f0b)[m_dyn:] == -7.0).all()
+    # ... and with "extra" rows riding along (the edge samples of the TV loss: field MLP only, fp32 feature rows out):
+    # the survivors' outputs do not change, the extra rows equal f2n_field_fwd_cached on them
+    n_ex = 1000 + 5
+    ex_cache = cache[n - n_ex:].contiguous()
+    feat_ex = torch.zeros((n_ex, 16), device=DEV); fx_ex = torch.zeros((n_ex, 32), dtype=torch.float16, device=DEV)
+    hip.field_fwd_cached(n_ex, n_ex, None, ex_cache, phf, feat_ex, torch.zeros(n_ex, device=DEV), fx_ex)
+    f0c_ = torch.full((m,), -7.0, device=DEV); rgbc = torch.full((m, 3), -7.0, device=DEV)
+    fxc = torch.zeros((m, 32), dtype=torch.float16, device=DEV); sxc = torch.zeros((m, 32), dtype=torch.float16, device=DEV)
+    feat_ex2 = torch.full((n_ex, 16), -7.0, device=DEV); fx_ex2 = torch.zeros((n_ex, 32), dtype=torch.float16, device=DEV)
+    hip.field_shade_fwd(m, d_rows, cache, phf, d_dirs, emb, sidx, phc, f0c_, fxc, sxc, rgbc, n_dev=n_dev, x_extra_h=ex_cache,
+                        feat_extra=feat_ex2, save_x_extra_h=fx_ex2)
+    assert_same(N(rgbc), N(rgbb), "rgb with extra rows"); assert_same(N(f0c_), N(f0b), "f0 with extra rows")
+    assert_same(N(feat_ex2), N(feat_ex), "extra feature rows")
+    assert_same(N(fx_ex2).view(np.uint16), N(fx_ex).view(np.uint16), "extra input rows")
 
 
 @pytest.mark.parametrize("n_emb", [0, 50, 480, 1500])  # 480: the largest per-block LDS image (> 64 KB of LDS); above: global atomics
