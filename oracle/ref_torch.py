@@ -1,0 +1,60 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/_ref/libf2n_ref_torch.so: the reference's own host code for
+perspective-warp construction (DistanceSummary, GetVisiCams, PCA, PersOctree::ConstructTrans) compiled against this image's
+libtorch on the CPU by oracle/build_ref_torch.py.  Import torch before the first call (the library resolves its libtorch
+symbols against the copy the Python process has loaded, and draws from the same global generator as torch.randint)."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "_ref", "libf2n_ref_torch.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (libtorch first)
+        _lib = ctypes.CDLL(SO)
+        _lib.ref_distance_summary.restype = ctypes.c_float
+    return _lib
+
+
+def _p(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def check_failures():
+    return int(lib().ref_torch_check_failures())
+
+
+def distance_summary(dis):
+    dis = _f32(dis).reshape(-1)
+    return float(lib().ref_distance_summary(ctypes.c_int(len(dis)), _p(dis)))
+
+
+def get_visi_cams(side_len, center, c2w, intri, bound):
+    c2w, intri, bound, center = _f32(c2w), _f32(intri), _f32(bound), _f32(center)
+    n = c2w.shape[0]
+    out = np.zeros(n, np.int32)
+    k = lib().ref_get_visi_cams(ctypes.c_float(side_len), _p(center), ctypes.c_int(n), _p(c2w), _p(intri), _p(bound), _p(out))
+    return out[:k].tolist()
+
+
+def construct_trans(rand_pts, c2w, intri33, center):
+    """One TransInfo (544 raw bytes).  Draws its first camera with torch::randint on the process-wide CPU generator."""
+    rand_pts, c2w, intri33, center = _f32(rand_pts), _f32(c2w), _f32(intri33), _f32(center)
+    out = np.zeros(544, np.uint8)
+    lib().ref_construct_trans(ctypes.c_int(rand_pts.shape[0]), _p(rand_pts), ctypes.c_int(c2w.shape[0]), _p(c2w), _p(intri33),
+                              _p(center), _p(out))
+    return out

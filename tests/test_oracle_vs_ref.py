@@ -199,3 +199,55 @@ def test_octree_maintenance_and_edge_pool_pinned(fox_state):
         assert (want_w == got_w).all() and (want_a == got_a).all(), rnd
         nodes = got_nodes.copy()
         assert len(nodes) > 1
+
+
+def test_warp_construction_pinned_against_the_reference_host_code(fox_state):
+    """the comparators the device-side octree / warp builder is tested against
+    (oracle/octree_construct.py: distance_summary, get_visi_cams, construct_trans) against the reference's OWN
+    DistanceSummary / GetVisiCams / PCA / PersOctree::ConstructTrans (PersSampler.cpp:16-66, 423-612), compiled in place against
+    this image's libtorch on the CPU (oracle/build_ref_torch.py).  Visible-camera lists exactly; the 544-byte TransInfo -- twelve
+    2x4 projection frames, the 3x12 PCA weight matrix, centre, distance summary -- to rounding (both sides run the same
+    libtorch ops; the angle-axis rotation is Eigen on one side, numpy on the other).  The first camera of the farthest-point
+    selection is a random draw in the reference: both sides are given the same one through the process-wide generator."""
+    import torch
+    from oracle import ref_torch, octree_construct as octc
+    if not ref_torch.available():
+        pytest.skip("oracle/_ref/libf2n_ref_torch.so not built (needs /root/reference)")
+    st = fox_state
+    ts = st["train_set"]
+    c2w = torch.from_numpy(st["poses"][ts].astype(np.float32))
+    K = torch.from_numpy(st["intri"][ts].astype(np.float32))
+    bnd = torch.from_numpy(st["bounds"][ts].astype(np.float32))
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 43, 500):  # DistanceSummary: lower-quartile log mean
+        d = (rng.random(n) * 3 + 0.05).astype(np.float32)
+        a, e = ref_torch.distance_summary(d), octc.distance_summary(torch.from_numpy(d))
+        assert abs(a - e) <= 2e-7 * abs(e), (n, a, e)
+    ctx = octc._VisiCtx(c2w, K, bnd)
+    # boxes: real leaves of the fox octree (the ones the reference built a warp for) plus a few that see few or no cameras
+    nodes = st["tree_nodes"].view(octc.NODE_DT)
+    leaves = np.nonzero(nodes["trans_idx"] >= 0)[0]
+    picks = leaves[rng.choice(len(leaves), 8, replace=False)]
+    boxes = [(float(nodes["side_len"][u]), [float(v) for v in nodes["center"][u]]) for u in picks]
+    boxes += [(0.25, [1.0, 0.5, -0.5]), (8.0, [0., 0., 0.]), (0.05, [30., 0., 0.])]
+    n_warps = 0
+    for trial, (side, center) in enumerate(boxes):
+        cen = torch.tensor(center, dtype=torch.float32)
+        visi = octc.get_visi_cams(ctx, side, cen)
+        assert visi == ref_torch.get_visi_cams(side, np.array(center, np.float32), c2w.numpy(), K.numpy(), bnd.numpy()), trial
+        if trial >= len(picks) or len(visi) < 6:
+            continue
+        vc = c2w[visi].contiguous()
+        pts = ((torch.from_numpy(rng.random((4096, 3)).astype(np.float32)) - .5) * side + cen).contiguous()
+        torch.manual_seed(100 + trial)
+        raw = ref_torch.construct_trans(pts.numpy(), vc.numpy(), K[0].numpy(), cen.numpy())
+        torch.manual_seed(100 + trial)
+        first = int(torch.randint(len(visi), (1,), dtype=torch.int32))
+        got = octc.construct_trans(pts, vc, K[0], cen, None, first_cam=first)
+        want = raw.view(octc.TRANS_DT)[0]
+        # (the PCA eigenvectors amplify the rounding-level differences of the frames by the inverse eigenvalue gaps: 1e-5 .. 1e-4)
+        for f, tol in (("w2xz", 5e-6), ("weight", 5e-4), ("center", 0.0), ("dis_summary", 2e-7)):
+            x, y = np.asarray(want[f], np.float64), np.asarray(got[f], np.float64)
+            assert np.abs(x - y).max() <= tol * max(np.abs(x).max(), 1e-30), (trial, f, np.abs(x - y).max())
+        n_warps += 1
+    assert n_warps >= 6 and ref_torch.check_failures() == 0
