@@ -44,6 +44,7 @@ def build(reference="/root/reference", keep_tu=False, verbose=True):
     h = _read(os.path.join(src, "PtsSampler/PersSampler.h"))
     tu += extract_between(h, r"^#define INIT_NODE_STAT", r"^#define TransWetType")
     tu += extract_between(h, r"^struct alignas\(32\) TransInfo", r"^};")
+    tu += extract_between(h, r"^struct alignas\(32\) TreeNode", r"^};")
     cpp = _read(os.path.join(src, "PtsSampler/PersSampler.cpp"))
     host = []
     host += extract_function(cpp, r"^float DistanceSummary\(")
@@ -55,6 +56,14 @@ def build(reference="/root/reference", keep_tu=False, verbose=True):
     body = extract_function(cpp, r"^TransInfo PersOctree::ConstructTrans\(")
     body[0] = body[0].replace("TransInfo PersOctree::ConstructTrans(", "static TransInfo ref_construct_trans_body(")
     host += body
+    # PersOctree::ConstructTreeNode (:359-421) as a free function over file-scope copies of the members it uses
+    host += ["", "#define ConstructTrans ref_construct_trans_body",
+             "static std::vector<TreeNode> tree_nodes_;", "static std::vector<TransInfo> pers_trans_;",
+             "static Tensor c2w_, intri_, bound_;", "static int max_depth_ = 0;", "static float split_dist_thres_ = 0.f;",
+             "static void ConstructTreeNode(int u, int depth, Wec3f center, float side_len);"]
+    node = extract_function(cpp, r"^void PersOctree::ConstructTreeNode\(")
+    node[0] = node[0].replace("void PersOctree::ConstructTreeNode(", "static void ConstructTreeNode(")
+    host += node
     text = "\n".join(host).replace("torch::kCUDA", "torch::kCPU")
     tu += text.split("\n")
     tu += ["", r'''
@@ -75,6 +84,28 @@ int ref_get_visi_cams(float side_len, const float* center3, int n_cams, const fl
   return (int) v.size();
 }
 // out: one TransInfo (544 bytes)
+// PersOctree::PersOctree up to ConstructEdgePool (:70-82): returns the node count; counts = {n_nodes, n_trans}
+int ref_build_octree(int max_depth, float bbox_side_len, float split_dist_thres, int n_cams, const float* c2w34, const float* intri33,
+                     const float* bound2, void* out_nodes, int cap_nodes, void* out_trans, int cap_trans, int* counts) {
+  max_depth_ = max_depth;
+  split_dist_thres_ = split_dist_thres;
+  c2w_ = torch::from_blob(const_cast<float*>(c2w34), {n_cams, 3, 4}, CPUFloat).clone();
+  intri_ = torch::from_blob(const_cast<float*>(intri33), {n_cams, 3, 3}, CPUFloat).clone();
+  bound_ = torch::from_blob(const_cast<float*>(bound2), {n_cams, 2}, CPUFloat).clone();
+  tree_nodes_.clear();
+  pers_trans_.clear();
+  TreeNode root;
+  root.parent = -1;
+  tree_nodes_.push_back(root);
+  ConstructTreeNode(0, 0, Wec3f::Zero(), bbox_side_len);
+  counts[0] = (int) tree_nodes_.size();
+  counts[1] = (int) pers_trans_.size();
+  static_assert(sizeof(TreeNode) == 64, "TreeNode layout");
+  if ((int) tree_nodes_.size() > cap_nodes || (int) pers_trans_.size() > cap_trans) return -1;
+  std::memcpy(out_nodes, tree_nodes_.data(), tree_nodes_.size() * sizeof(TreeNode));
+  std::memcpy(out_trans, pers_trans_.data(), pers_trans_.size() * sizeof(TransInfo));
+  return (int) tree_nodes_.size();
+}
 void ref_construct_trans(int n_pts, const float* rand_pts, int n_cams, const float* c2w34, const float* intri33, const float* center3,
                          void* out) {
   Tensor pts = torch::from_blob(const_cast<float*>(rand_pts), {n_pts, 3}, CPUFloat).clone();

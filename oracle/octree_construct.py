@@ -223,7 +223,12 @@ def construct_trans(rand_pts, c2w, intri, center, gen, first_cam=None):
 # ------------------------------------------------------------------------------------------------
 class PersOctreeBuilder:
     def __init__(self, max_depth, bbox_side_len, split_dist_thres, c2w, w2c, intri, bound, seed=2022,
-                 n_rand_pts=32 * 32 * 32, verbose=False):
+                 n_rand_pts=32 * 32 * 32, verbose=False, draws_like_reference=False):
+        # draws_like_reference: the reference draws the 32^3 random points of a node BEFORE it knows whether the node becomes a
+        # leaf with a warp (PersSampler.cpp:377), i.e. for every visited node; by default only the leaves that need them draw
+        # (same trees, fewer draws).  With the flag the generator is consumed exactly as the reference consumes it, which is what
+        # the pin against the reference's own code needs (tests/test_oracle_vs_ref.py).
+        self.draws_like_reference = draws_like_reference
         self.max_depth, self.split_dist_thres = max_depth, split_dist_thres
         self.c2w, self.w2c, self.intri, self.bound = c2w, w2c, intri, bound
         self.gen = torch.Generator().manual_seed(seed)
@@ -250,6 +255,9 @@ class PersOctreeBuilder:
             nd["is_leaf_node"] = 1
             return
         center_ts = torch.from_numpy(np.asarray(center, np.float32))
+        rand_pts = None
+        if self.draws_like_reference:
+            rand_pts = (torch.rand(self.n_rand_pts, 3, generator=self.gen) - .5) * float(side_len) + center_ts[None]
         visi = get_visi_cams(self.ctx, float(side_len), center_ts)
         cam_dis = torch.linalg.norm(self.c2w[:, :3, 3] - center_ts[None], 2, -1)
         dsum = distance_summary(cam_dis[visi]) if len(visi) else 1e8
@@ -268,7 +276,8 @@ class PersOctreeBuilder:
         else:
             nd["is_leaf_node"] = 1
             nd["trans_idx"] = len(self.trans)
-            rand_pts = (torch.rand(self.n_rand_pts, 3, generator=self.gen) - .5) * float(side_len) + center_ts[None]
+            if rand_pts is None:
+                rand_pts = (torch.rand(self.n_rand_pts, 3, generator=self.gen) - .5) * float(side_len) + center_ts[None]
             self.trans.append(construct_trans(rand_pts, self.c2w[visi], self.intri[0], center_ts, self.gen))
             if self.verbose and len(self.trans) % 50 == 0:
                 print("  leaves with warps:", len(self.trans), "nodes:", len(self.nodes), flush=True)

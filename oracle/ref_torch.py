@@ -58,3 +58,17 @@ def construct_trans(rand_pts, c2w, intri33, center):
     lib().ref_construct_trans(ctypes.c_int(rand_pts.shape[0]), _p(rand_pts), ctypes.c_int(c2w.shape[0]), _p(c2w), _p(intri33),
                               _p(center), _p(out))
     return out
+
+
+def build_octree(max_depth, bbox_side_len, split_dist_thres, c2w, intri, bound, cap_nodes=1 << 16, cap_trans=1 << 14):
+    """PersOctree::PersOctree's node / warp construction (PersSampler.cpp:70-82, 359-612) -> (TreeNode bytes, TransInfo bytes).
+    Draws (rand points of every visited node, first camera of every warp) come from the process-wide CPU generator."""
+    c2w, intri, bound = _f32(c2w), _f32(intri), _f32(bound)
+    nodes = np.zeros(cap_nodes * 64, np.uint8)
+    trans = np.zeros(cap_trans * 544, np.uint8)
+    counts = np.zeros(2, np.int32)
+    rc = lib().ref_build_octree(ctypes.c_int(max_depth), ctypes.c_float(bbox_side_len), ctypes.c_float(split_dist_thres),
+                                ctypes.c_int(c2w.shape[0]), _p(c2w), _p(intri), _p(bound), _p(nodes), ctypes.c_int(cap_nodes),
+                                _p(trans), ctypes.c_int(cap_trans), _p(counts))
+    assert rc >= 0, "capacity"
+    return nodes[:int(counts[0]) * 64].copy(), trans[:int(counts[1]) * 544].copy()

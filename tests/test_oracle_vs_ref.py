@@ -251,3 +251,38 @@ def test_warp_construction_pinned_against_the_reference_host_code(fox_state):
             assert np.abs(x - y).max() <= tol * max(np.abs(x).max(), 1e-30), (trial, f, np.abs(x - y).max())
         n_warps += 1
     assert n_warps >= 6 and ref_torch.check_failures() == 0
+
+
+def test_whole_octree_construction_pinned_against_the_reference_host_code(fox_state):
+    """PersOctree::PersOctree's node / warp construction for the fox cameras (PersSampler.cpp:70-82: ConstructTreeNode's
+    recursion :359-421 around GetVisiCams, DistanceSummary and ConstructTrans), run by the reference's own code (compiled in
+    place against libtorch, CPU) and by the restatement the device builder is compared with, from the same generator state and
+    with the reference's draw order: every field of every node equal; every warp's projection frames to 1e-5, its PCA weights
+    to rounding in the median (a leaf whose covariance has two nearly equal eigenvalues may rotate them: bounded at 5e-2)."""
+    import torch
+    from oracle import ref_torch, octree_construct as octc
+    if not ref_torch.available():
+        pytest.skip("oracle/_ref/libf2n_ref_torch.so not built (needs /root/reference)")
+    st = fox_state
+    ts = st["train_set"]
+    c2w = torch.from_numpy(st["poses"][ts].astype(np.float32))
+    K = torch.from_numpy(st["intri"][ts].astype(np.float32))
+    bnd = torch.from_numpy(st["bounds"][ts].astype(np.float32))
+    w2c = torch.from_numpy(st["w2c"][ts].astype(np.float32))
+    max_depth, bbox, thres = 16, 512.0, 1.5  # wanjinyou.yaml: max_level 16, bbox_levels 10 (side 2^9), split_dist_thres 1.5
+    torch.manual_seed(7)
+    rn, rtr = ref_torch.build_octree(max_depth, bbox, thres, c2w.numpy(), K.numpy(), bnd.numpy())
+    got_nodes, got_trans, _ = octc.PersOctreeBuilder(max_depth, bbox, thres, c2w, w2c, K, bnd, seed=7, draws_like_reference=True).arrays()
+    want_nodes, want_trans = rn.view(octc.NODE_DT), rtr.view(octc.TRANS_DT)
+    assert len(want_nodes) == len(got_nodes) > 500 and len(want_trans) == len(got_trans) > 200
+    assert len(want_nodes) == st["tree_nodes"].size // 64  # (the committed fixture is this tree)
+    for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"):
+        assert (want_nodes[f] == got_nodes[f]).all(), f
+
+    def rel(f):
+        x, y = np.asarray(want_trans[f], np.float64), np.asarray(got_trans[f], np.float64)
+        return np.abs(x - y).reshape(len(x), -1).max(1) / np.abs(x).reshape(len(x), -1).max(1)
+    assert rel("w2xz").max() <= 1e-5
+    assert np.median(rel("weight")) <= 1e-5 and rel("weight").max() <= 5e-2
+    assert (np.asarray(want_trans["center"]) == np.asarray(got_trans["center"])).all() and rel("dis_summary").max() <= 1e-6
+    assert ref_torch.check_failures() == 0
