@@ -70,29 +70,48 @@ void ExpRunner::LoadStates(const std::vector<Tensor>& states) {
   BuildOptimizer();  // parameter tensors may have been re-created (primes, nodes): re-bind the groups
 }
 
-// ExpRunner.cpp:221-254
-float ExpRunner::FinenessAt(int iter) const {  // ExpRunner.cpp:221-231
-  if (iter >= ray_march_fineness_decay_end_iter_) return 1.f;
-  float progress = float(iter) / float(ray_march_fineness_decay_end_iter_);
-  return std::exp(std::log(1.f) * progress + std::log(ray_march_init_fineness_) * (1.f - progress));
+// ExpRunner.cpp:108-114 (variance-loss ramp) and :221-254 (UpdateAdaParams), spelled as the reference spells them
+ExpRunner::ScheduleValues ExpRunner::ScheduleAt(const ScheduleParams& p, int iter) {
+  ScheduleValues v;
+  if (iter >= p.ray_march_fineness_decay_end_iter) {
+    v.fineness = 1.f;
+  } else {
+    float progress = float(iter) / float(p.ray_march_fineness_decay_end_iter);
+    v.fineness = std::exp(std::log(1.f) * progress + std::log(p.ray_march_init_fineness) * (1.f - progress));
+  }
+  float lr_factor;
+  if (iter >= p.learning_rate_warm_up_end_iter) {
+    float progress = float(iter - p.learning_rate_warm_up_end_iter) / float(p.end_iter - p.learning_rate_warm_up_end_iter);
+    lr_factor = (1.f - p.learning_rate_alpha) * (std::cos(progress * float(M_PI)) * .5f + .5f) + p.learning_rate_alpha;
+  } else {
+    lr_factor = float(iter) / float(p.learning_rate_warm_up_end_iter);
+  }
+  v.lr = p.learning_rate * lr_factor;
+  float progress = 1.f;
+  if (iter < p.gradient_scaling_end) {
+    progress = std::max(0.f, (float(iter) - p.gradient_scaling_start) / (p.gradient_scaling_end - p.gradient_scaling_start + 1e-9f));
+  }
+  v.gradient_scaling_progress = progress;
+  v.var_loss_weight = 0.f;
+  if (iter > p.var_loss_end) v.var_loss_weight = p.var_loss_weight;
+  else if (iter > p.var_loss_start) v.var_loss_weight = float(iter - p.var_loss_start) / float(p.var_loss_end - p.var_loss_start) * p.var_loss_weight;
+  return v;
 }
+
+ExpRunner::ScheduleParams ExpRunner::Schedule() const {
+  return {ray_march_init_fineness_, ray_march_fineness_decay_end_iter_, learning_rate_, learning_rate_alpha_,
+          learning_rate_warm_up_end_iter_, end_iter_, gradient_scaling_start_, gradient_scaling_end_, var_loss_weight_,
+          var_loss_start_, var_loss_end_};
+}
+
+float ExpRunner::FinenessAt(int iter) const { return ScheduleAt(Schedule(), iter).fineness; }
 
 void ExpRunner::UpdateAdaParams() {
   auto* gdp = global_data_pool_.get();
-  gdp->ray_march_fineness_ = FinenessAt(iter_step_);
-  float lr_factor;
-  if (iter_step_ >= learning_rate_warm_up_end_iter_) {
-    float progress = float(iter_step_ - learning_rate_warm_up_end_iter_) / float(end_iter_ - learning_rate_warm_up_end_iter_);
-    lr_factor = (1.f - learning_rate_alpha_) * (std::cos(progress * float(M_PI)) * .5f + .5f) + learning_rate_alpha_;
-  } else {
-    lr_factor = float(iter_step_) / float(learning_rate_warm_up_end_iter_);
-  }
-  cur_lr_ = learning_rate_ * lr_factor;
-  float progress = 1.f;
-  if (iter_step_ < gradient_scaling_end_) {
-    progress = std::max(0.f, (float(iter_step_) - gradient_scaling_start_) / (gradient_scaling_end_ - gradient_scaling_start_ + 1e-9f));
-  }
-  gdp->gradient_scaling_progress_ = progress;
+  const ScheduleValues v = ScheduleAt(Schedule(), iter_step_);
+  gdp->ray_march_fineness_ = v.fineness;
+  cur_lr_ = v.lr;
+  gdp->gradient_scaling_progress_ = v.gradient_scaling_progress;
   gdp->iter_step_ = iter_step_;
 }
 
@@ -169,11 +188,7 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
 }
 
 // Loss weights of the current iteration (ExpRunner.cpp:108-114).
-float ExpRunner::CurVarLossWeight() const {
-  if (iter_step_ > var_loss_end_) return var_loss_weight_;
-  if (iter_step_ > var_loss_start_) return float(iter_step_ - var_loss_start_) / float(var_loss_end_ - var_loss_start_) * var_loss_weight_;
-  return 0.f;
-}
+float ExpRunner::CurVarLossWeight() const { return ScheduleAt(Schedule(), iter_step_).var_loss_weight; }
 
 // One iteration of ExpRunner::Train (ExpRunner.cpp:82-143) for a given ray batch: untaped forward + loss + backward
 // (Renderer::TrainForwardBackward), device-side finiteness flags, Adam predicated on them, ONE flag read-back.

@@ -37,6 +37,22 @@ class ExpRunner {
   TrainStats TrainStepAutograd(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                const Tensor& emb_idx, bool apply_optimizer = true);
   float CurVarLossWeight() const;
+  // The iteration-dependent scalars of ExpRunner::Train / UpdateAdaParams (ExpRunner.cpp:108-114, 221-254) as a pure function
+  // of the configuration: what the members below feed, and what tests pin against the reference's own code without a GPU.
+  struct ScheduleParams {
+    float ray_march_init_fineness;
+    int ray_march_fineness_decay_end_iter;
+    float learning_rate, learning_rate_alpha, learning_rate_warm_up_end_iter;
+    int end_iter;
+    float gradient_scaling_start, gradient_scaling_end;
+    float var_loss_weight;
+    int var_loss_start, var_loss_end;
+  };
+  struct ScheduleValues {
+    float fineness, lr, gradient_scaling_progress, var_loss_weight;
+  };
+  static ScheduleValues ScheduleAt(const ScheduleParams& p, int iter);
+  ScheduleParams Schedule() const;
   bool forward_render_ = true;      // inference through Renderer::RenderForward (false: the taped Render(), as a comparator)
   int render_chunk_rays_ = 65536;   // rays per chunk of RenderWholeImage on that path
   std::vector<Tensor> RenderRays(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);

@@ -92,6 +92,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     auto id = DataParallel::NewUniqueId();
     return py::bytes(reinterpret_cast<const char*>(id.data()), id.size());
   });
+  // the schedules of ExpRunner::Train as a pure function (no device needed): tests pin them against the reference's own code
+  m.def("schedule_at", [](float init_fineness, int fineness_decay_end, float lr, float lr_alpha, float lr_warm_up_end, int end_iter,
+                          float gs_start, float gs_end, float var_w, int var_start, int var_end, int iter) {
+    ExpRunner::ScheduleParams p{init_fineness, fineness_decay_end, lr, lr_alpha, lr_warm_up_end, end_iter, gs_start, gs_end, var_w,
+                                var_start, var_end};
+    auto v = ExpRunner::ScheduleAt(p, iter);
+    return std::vector<float>{v.fineness, v.lr, v.gradient_scaling_progress, v.var_loss_weight};
+  });
   py::class_<ExpRunner>(m, "ExpRunner")
       .def(py::init<const std::map<std::string, std::string>&, int>(), py::arg("flat_config"), py::arg("n_images"))
       .def("load_states", &ExpRunner::LoadStates)

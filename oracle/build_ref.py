@@ -146,6 +146,25 @@ def build(reference="/root/reference", keep_tu=False, verbose=True):
     add(["static void ref_construct_edge_pool_body(const std::vector<TreeNode>& tree_nodes_, std::vector<EdgePool>& edge_pool_) {"]
         + body + ["}", ""])
 
+    # ---- training schedules: the body of ExpRunner::UpdateAdaParams (ExpRunner.cpp:222-253) and the variance-loss ramp of
+    # ExpRunner::Train (:108-114), pasted into a function whose locals carry the member names and types of ExpRunner.h:34-45 ----
+    ex = _read(os.path.join(src, "ExpRunner.cpp"))
+    ada = extract_between(ex, r"^void ExpRunner::UpdateAdaParams\(\) \{", r"^\}", include_end=False)[1:]
+    ramp = extract_between(ex, r"^\s*float var_loss_weight = 0.f;", r"^\s*Tensor loss = color_loss", include_end=False)
+    add(["struct RefGdp { float ray_march_fineness_ = 0.f, gradient_scaling_progress_ = 0.f; };",
+         "struct RefOptGroup { float* lr; RefOptGroup& options() { return *this; } void set_lr(float v) { *lr = v; } };",
+         "struct RefOpt { std::vector<RefOptGroup> g; std::vector<RefOptGroup>& param_groups() { return g; } };",
+         "static void ref_schedules_body(unsigned iter_step_, unsigned end_iter_, float ray_march_init_fineness_,",
+         "                               int ray_march_fineness_decay_end_iter_, int var_loss_start_, int var_loss_end_,",
+         "                               int gradient_scaling_start_, int gradient_scaling_end_, float learning_rate_,",
+         "                               float learning_rate_alpha_, float learning_rate_warm_up_end_iter_, float var_loss_weight_,",
+         "                               float* out4) {",
+         "  RefGdp gdp_obj; RefGdp* global_data_pool_ = &gdp_obj;",
+         "  float lr_seen = 0.f; RefOpt opt_obj; opt_obj.g.push_back(RefOptGroup{&lr_seen}); RefOpt* optimizer_ = &opt_obj;"]
+        + ada + ramp +
+        ["  out4[0] = gdp_obj.ray_march_fineness_; out4[1] = lr_seen; out4[2] = gdp_obj.gradient_scaling_progress_; out4[3] = var_loss_weight;",
+         "}", ""])
+
     add(["", '#include "%s"' % os.path.join(HERE, "ref_driver.inc"), ""])
 
     tmp = tempfile.mkdtemp(prefix="f2n_ref_")

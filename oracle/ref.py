@@ -286,3 +286,15 @@ def construct_edge_pool(tree_nodes):
         if m >= 0:
             return out[:m * 64].copy()
         cap = -m
+
+
+def schedules(iter_step, end_iter, init_fineness, fineness_decay_end, var_start, var_end, gs_start, gs_end, lr, lr_alpha,
+              lr_warm_up_end, var_w):
+    """ExpRunner::UpdateAdaParams (ExpRunner.cpp:221-254) + the variance-loss ramp (:108-114): (fineness, lr,
+    gradient_scaling_progress, var_loss_weight) at iter_step, by the reference's own statements."""
+    out = np.zeros(4, np.float32)
+    lib().ref_schedules(ctypes.c_uint(iter_step), ctypes.c_uint(end_iter), ctypes.c_float(init_fineness),
+                        ctypes.c_int(fineness_decay_end), ctypes.c_int(var_start), ctypes.c_int(var_end), ctypes.c_int(gs_start),
+                        ctypes.c_int(gs_end), ctypes.c_float(lr), ctypes.c_float(lr_alpha), ctypes.c_float(lr_warm_up_end),
+                        ctypes.c_float(var_w), _p(out))
+    return out

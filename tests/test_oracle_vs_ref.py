@@ -286,3 +286,35 @@ def test_whole_octree_construction_pinned_against_the_reference_host_code(fox_st
     assert np.median(rel("weight")) <= 1e-5 and rel("weight").max() <= 5e-2
     assert (np.asarray(want_trans["center"]) == np.asarray(got_trans["center"])).all() and rel("dis_summary").max() <= 1e-6
     assert ref_torch.check_failures() == 0
+
+
+def test_training_schedules_of_the_host_equal_the_reference_statements():
+    """SURVEY 8(a) a18, the schedule part: march fineness, learning rate (warm-up + cosine), gradient-scaling progress and the
+    variance-loss ramp as the C++ host computes them (ExpRunner::ScheduleAt, the pure function behind UpdateAdaParams /
+    CurVarLossWeight; bound as host.schedule_at, no device needed) against the reference's own statements
+    (ExpRunner.cpp:108-114, 221-254, compiled in place by oracle/build_ref.py) for every iteration of the shipped
+    configurations and some adversarial ones: equal floats, bit for bit."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import config, runtime
+    host = runtime.host()
+    cases = []
+    for name in ("wanjinyou", "wanjinyou_big", "llff", "nerf-360", "free"):
+        c = config.preset(name)
+        t = c["train"]
+        cases.append((int(t["end_iter"]), float(t["ray_march_init_fineness"]), int(t["ray_march_fineness_decay_end_iter"]),
+                      int(t["var_loss_start"]), int(t["var_loss_end"]), int(t["gradient_scaling_start"]), int(t["gradient_scaling_end"]),
+                      float(t["learning_rate"]), float(t["learning_rate_alpha"]), float(t["learning_rate_warm_up_end_iter"]),
+                      float(t["var_loss_weight"])))
+    cases += [(300, 16.0, 100, 10, 20, 5, 50, 1e-2, 0.1, 17.0, 1e-2), (1000, 3.7, 999, 0, 1, 0, 1, 5e-3, 0.0, 1.0, 0.3),
+              (64, 1.0, 1, 70, 80, 100, 200, 1e-1, 1.0, 30.0, 0.0)]
+    checked = 0
+    for (end, fin0, fin_end, vs, ve, gs, ge, lr, alpha, warm, vw) in cases:
+        iters = sorted(set(list(range(0, min(end, 2200))) + list(range(max(0, end - 1200), end + 3)) + [fin_end - 1, fin_end, vs, vs + 1, ve, ve + 1]))
+        for it in iters:
+            if it < 0:
+                continue
+            want = ref.schedules(it, end, fin0, fin_end, vs, ve, gs, ge, lr, alpha, warm, vw)
+            got = np.array(host.schedule_at(fin0, fin_end, lr, alpha, warm, end, float(gs), float(ge), vw, vs, ve, it), np.float32)
+            assert (want.view(np.uint32) == got.view(np.uint32)).all(), (it, end, want, got)
+            checked += 1
+    assert checked > 10000
