@@ -69,6 +69,7 @@ def prepare_scene(cams_meta, hw, factor=1.0, bounds_factor=(0.5, 4.0), intrinsic
     """The reference's Dataset constructor on a cams_meta array (Dataset.cpp:35-146) -> the dict layout of
     tests/golden/fox_state.npz minus the octree (poses, intri, dist_params, bounds, w2c, center, radius, splits, image_hw).
     `hw` is the image size the intrinsics refer to (the rigs above emit intrinsics at the final resolution)."""
+    import torch
     cam = np.asarray(cams_meta, np.float64).astype(F32).reshape(-1, 27)
     n = len(cam)
     poses = cam[:, 0:12].reshape(n, 3, 4).copy()
@@ -77,15 +78,24 @@ def prepare_scene(cams_meta, hw, factor=1.0, bounds_factor=(0.5, 4.0), intrinsic
         intri[:, 0:2, 0:3] /= F32(factor)
     dist = cam[:, 21:25].copy()
     bounds = cam[:, 25:27].copy()
-    cam_pos = poses[:, :3, 3].copy()
-    center = cam_pos.mean(0, dtype=F32)
-    radius = F32(np.linalg.norm(cam_pos - center[None], axis=-1).max())
-    poses[:, :3, 3] = (cam_pos - center[None]) / radius
-    c2w4 = np.concatenate([poses, np.tile(np.array([[[0, 0, 0, 1]]], F32), (n, 1, 1))], 1)
-    w2c = np.linalg.inv(c2w4)[:, :3, :].astype(F32)
-    bounds = bounds / radius
-    bounds = np.stack([bounds[:, 0] * F32(bounds_factor[0]), bounds[:, 1] * F32(bounds_factor[1])], -1)
-    bounds = np.clip(bounds, F32(1e-2), F32(1e9)).astype(F32)
+    # NormalizeScene (Dataset.cpp:127-146) with the very ATen ops the reference calls (mean / linalg_norm / linalg_inv on
+    # float32 tensors): numpy's pairwise float32 mean lands one ulp away from ATen's, and the scene centre moves every pose.
+    # Pinned against the reference's own function: tests/test_oracle_vs_ref.py.
+    with torch.no_grad():
+        tp = torch.from_numpy(poses)
+        cam_pos = tp[:, :3, 3].clone()
+        center_t = cam_pos.mean(0, False)
+        radius_t = torch.linalg.norm(cam_pos - center_t.unsqueeze(0), 2, -1, False).max()
+        radius = F32(radius_t.item())
+        tp[:, :3, 3] = (cam_pos - center_t.unsqueeze(0)) / float(radius)
+        w2c4 = torch.eye(4, dtype=torch.float32).unsqueeze(0).repeat(n, 1, 1).contiguous()
+        w2c4[:, :3, :] = tp.clone()
+        w2c = torch.linalg.inv(w2c4)[:, :3, :].contiguous().numpy()
+        tb = (torch.from_numpy(bounds) / float(radius)).contiguous()
+        tb = torch.stack([tb[..., 0] * float(bounds_factor[0]), tb[..., 1] * float(bounds_factor[1])], -1).contiguous()  # :73-75
+        tb.clamp_(1e-2, 1e9)
+        bounds = tb.numpy().astype(F32)
+        center = center_t.numpy().astype(F32)
     test = np.array([i for i in range(n) if i % 8 == 0], np.int32)
     train = np.array([i for i in range(n) if i % 8 != 0], np.int32)
     return dict(poses=poses.astype(F32), intri=intri.astype(F32), dist_params=dist.astype(F32), bounds=bounds, w2c=w2c,

@@ -64,6 +64,16 @@ def build(reference="/root/reference", keep_tu=False, verbose=True):
     node = extract_function(cpp, r"^void PersOctree::ConstructTreeNode\(")
     node[0] = node[0].replace("void PersOctree::ConstructTreeNode(", "static void ConstructTreeNode(")
     host += node
+    # Dataset::NormalizeScene (Dataset/Dataset.cpp:127-146) over file-scope copies of the members it touches
+    ds = _read(os.path.join(src, "Dataset/Dataset.cpp"))
+    norm = extract_function(ds, r"^void Dataset::NormalizeScene\(\)")
+    norm[0] = norm[0].replace("void Dataset::NormalizeScene()", "static void NormalizeScene()")
+    host += ["", "namespace Utils { static void TensorExportPCD(const std::string&, const Tensor&) {} }",
+             "struct RefCfgNode { RefCfgNode operator[](const char*) const { return RefCfgNode(); } };",
+             "struct RefDsGdp { RefCfgNode config_; std::string base_exp_dir_; };",
+             "static RefDsGdp ref_ds_gdp; static RefDsGdp* global_data_pool_ = &ref_ds_gdp;",
+             "static Tensor poses_, w2c_, bounds_, center_; static float radius_ = 0.f; static int n_images_ = 0;"]
+    host += norm
     text = "\n".join(host).replace("torch::kCUDA", "torch::kCPU")
     tu += text.split("\n")
     tu += ["", r'''
@@ -105,6 +115,21 @@ int ref_build_octree(int max_depth, float bbox_side_len, float split_dist_thres,
   std::memcpy(out_nodes, tree_nodes_.data(), tree_nodes_.size() * sizeof(TreeNode));
   std::memcpy(out_trans, pers_trans_.data(), pers_trans_.size() * sizeof(TransInfo));
   return (int) tree_nodes_.size();
+}
+// Dataset::NormalizeScene + the bounds relaxation of the constructor (Dataset.cpp:73-76): poses [n,3,4] and bounds [n,2] in place;
+// w2c [n,3,4], center [3], radius out
+void ref_normalize_scene(int n, float* poses34, float* bounds2, float f0, float f1, float* w2c34, float* center3, float* radius) {
+  poses_ = torch::from_blob(poses34, {n, 3, 4}, CPUFloat).clone();
+  bounds_ = torch::from_blob(bounds2, {n, 2}, CPUFloat).clone();
+  n_images_ = n;
+  NormalizeScene();
+  bounds_ = torch::stack({bounds_.index({"...", 0}) * f0, bounds_.index({"...", 1}) * f1}, -1).contiguous();  // :73-75, as spelled there
+  bounds_.clamp_(1e-2f, 1e9f);
+  std::memcpy(poses34, poses_.contiguous().data_ptr(), sizeof(float) * n * 12);
+  std::memcpy(bounds2, bounds_.contiguous().data_ptr(), sizeof(float) * n * 2);
+  std::memcpy(w2c34, w2c_.contiguous().data_ptr(), sizeof(float) * n * 12);
+  std::memcpy(center3, center_.contiguous().data_ptr(), sizeof(float) * 3);
+  *radius = radius_;
 }
 void ref_construct_trans(int n_pts, const float* rand_pts, int n_cams, const float* c2w34, const float* intri33, const float* center3,
                          void* out) {

@@ -72,3 +72,15 @@ def build_octree(max_depth, bbox_side_len, split_dist_thres, c2w, intri, bound, 
                                 _p(trans), ctypes.c_int(cap_trans), _p(counts))
     assert rc >= 0, "capacity"
     return nodes[:int(counts[0]) * 64].copy(), trans[:int(counts[1]) * 544].copy()
+
+
+def normalize_scene(poses, bounds, bounds_factor):
+    """Dataset::NormalizeScene (Dataset.cpp:127-146) + bounds relaxation / clamp (:73-76) -> dict like rigs.prepare_scene's."""
+    poses, bounds = _f32(poses).copy(), _f32(bounds).copy()
+    n = poses.shape[0]
+    w2c = np.zeros((n, 3, 4), np.float32)
+    center = np.zeros(3, np.float32)
+    radius = np.zeros(1, np.float32)
+    lib().ref_normalize_scene(ctypes.c_int(n), _p(poses), _p(bounds), ctypes.c_float(bounds_factor[0]), ctypes.c_float(bounds_factor[1]),
+                              _p(w2c), _p(center), _p(radius))
+    return dict(poses=poses, bounds=bounds, w2c=w2c, center=center, radius=np.float32(radius[0]))

@@ -318,3 +318,23 @@ def test_training_schedules_of_the_host_equal_the_reference_statements():
             assert (want.view(np.uint32) == got.view(np.uint32)).all(), (it, end, want, got)
             checked += 1
     assert checked > 10000
+
+
+def test_scene_preparation_of_the_launcher_equals_the_reference_function():
+    """The launcher's scene preparation (f2-nerf_amd/rigs.py::prepare_scene: scene centre / radius, normalised poses, w2c,
+    relaxed and clamped bounds) against the reference's own Dataset::NormalizeScene + bounds relaxation
+    (Dataset.cpp:73-76, 127-146, compiled in place against libtorch on the CPU) on a forward-facing and an inward-ring rig:
+    every output equal, bit for bit."""
+    from oracle import ref_torch
+    if not ref_torch.available():
+        pytest.skip("oracle/_ref/libf2n_ref_torch.so not built (needs /root/reference)")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import rigs
+    rng = np.random.default_rng(3)
+    for meta, hw in (rigs.forward_facing(rng), rigs.inward_ring(rng)):
+        cam = np.asarray(meta, np.float64).astype(np.float32).reshape(-1, 27)
+        for bf in ((0.5, 4.0), (0.1, 128.0)):
+            want = ref_torch.normalize_scene(cam[:, :12].reshape(-1, 3, 4), cam[:, 25:27], bf)
+            got = rigs.prepare_scene(meta, hw, 1.0, bf)
+            for k in ("poses", "bounds", "w2c", "center", "radius"):
+                same(np.asarray(want[k], np.float32), np.asarray(got[k], np.float32))
