@@ -74,6 +74,9 @@ def build(reference="/root/reference", keep_tu=False, verbose=True):
              "static RefDsGdp ref_ds_gdp; static RefDsGdp* global_data_pool_ = &ref_ds_gdp;",
              "static Tensor poses_, w2c_, bounds_, center_; static float radius_ = 0.f; static int n_images_ = 0;"]
     host += norm
+    # PoseInterpolate (Utils/CameraUtils.cpp:11-44): Eigen quaternion slerp between two camera poses
+    cu = _read(os.path.join(src, "Utils/CameraUtils.cpp"))
+    host += [""] + extract_function(cu, r"^Tensor PoseInterpolate\(")
     text = "\n".join(host).replace("torch::kCUDA", "torch::kCPU")
     tu += text.split("\n")
     tu += ["", r'''
@@ -130,6 +133,12 @@ void ref_normalize_scene(int n, float* poses34, float* bounds2, float f0, float 
   std::memcpy(w2c34, w2c_.contiguous().data_ptr(), sizeof(float) * n * 12);
   std::memcpy(center3, center_.contiguous().data_ptr(), sizeof(float) * 3);
   *radius = radius_;
+}
+void ref_pose_interpolate(const float* a34, const float* b34, float alpha, float* out34) {
+  Tensor a = torch::from_blob(const_cast<float*>(a34), {3, 4}, CPUFloat).clone();
+  Tensor b = torch::from_blob(const_cast<float*>(b34), {3, 4}, CPUFloat).clone();
+  Tensor r = PoseInterpolate(a, b, alpha).contiguous();
+  std::memcpy(out34, r.data_ptr(), sizeof(float) * 12);
 }
 void ref_construct_trans(int n_pts, const float* rand_pts, int n_cams, const float* c2w34, const float* intri33, const float* center3,
                          void* out) {

@@ -84,3 +84,11 @@ def normalize_scene(poses, bounds, bounds_factor):
     lib().ref_normalize_scene(ctypes.c_int(n), _p(poses), _p(bounds), ctypes.c_float(bounds_factor[0]), ctypes.c_float(bounds_factor[1]),
                               _p(w2c), _p(center), _p(radius))
     return dict(poses=poses, bounds=bounds, w2c=w2c, center=center, radius=np.float32(radius[0]))
+
+
+def pose_interpolate(a, b, alpha):
+    """PoseInterpolate (Utils/CameraUtils.cpp:11-44) on two [3,4] poses."""
+    a, b = _f32(a), _f32(b)
+    out = np.zeros((3, 4), np.float32)
+    lib().ref_pose_interpolate(_p(a), _p(b), ctypes.c_float(alpha), _p(out))
+    return out

@@ -338,3 +338,35 @@ def test_scene_preparation_of_the_launcher_equals_the_reference_function():
             got = rigs.prepare_scene(meta, hw, 1.0, bf)
             for k in ("poses", "bounds", "w2c", "center", "radius"):
                 same(np.asarray(want[k], np.float32), np.asarray(got[k], np.float32))
+
+
+def test_pose_interpolation_of_the_host_against_the_reference_function():
+    """PoseInterpolate (Utils/CameraUtils.cpp:11-44: Eigen rotation-matrix -> quaternion, slerp, back; translation lerp), used
+    by RenderPath / RandRaysWholeSpace: the host's Eigen-free spelling (csrc/host/Dataset.cpp, bound without a device) against
+    the reference's function compiled in place, on random pose pairs incl. equal rotations and the end points: within a few
+    float32 ulps (5e-7 absolute on unit-scale entries) -- not bit-exact: Eigen's slerp / normalisation round differently."""
+    import torch
+    from oracle import ref_torch
+    if not ref_torch.available():
+        pytest.skip("oracle/_ref/libf2n_ref_torch.so not built (needs /root/reference)")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    host = runtime.host()
+    rng = np.random.default_rng(0)
+
+    def rand_rot():
+        q = rng.standard_normal(4)
+        w, x, y, z = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    worst = 0.0
+    for t in range(300):
+        A = np.concatenate([rand_rot(), rng.standard_normal((3, 1))], 1).astype(np.float32)
+        B = np.concatenate([A[:, :3] if t % 5 == 0 else rand_rot(), rng.standard_normal((3, 1))], 1).astype(np.float32)
+        for al in (0.0, 0.25, 0.5, 0.9, 1.0):
+            want = ref_torch.pose_interpolate(A, B, al)
+            got = host.Dataset.pose_interpolate(torch.from_numpy(A), torch.from_numpy(B), al).numpy()
+            worst = max(worst, float(np.abs(want[:, :3] - got[:, :3]).max()))
+            assert np.abs(want[:, 3] - got[:, 3]).max() <= 1e-6 * max(1.0, float(np.abs(want[:, 3]).max()))
+    assert worst <= 1e-6, worst
