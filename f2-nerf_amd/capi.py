@@ -441,6 +441,10 @@ def reduce_deferred():
     _ck(lib().f2n_reduce_deferred(_stream()), "f2n_reduce_deferred")
 
 
+def deferred_reset():
+    _ck(lib().f2n_deferred_reset(), "f2n_deferred_reset")
+
+
 def adam_step_h16grad(n, param, grad_h, grad_scale, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
                       zero_grad, skip_flag=None):
     _ck(lib().f2n_adam_step_h16grad(_stream(), _i(n), _p(param, "f32"), _p(grad_h, "h16"), _f(grad_scale),

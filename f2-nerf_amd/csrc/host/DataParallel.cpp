@@ -60,21 +60,26 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
 
 void DataParallel::BroadcastStates() {
   auto comm = reinterpret_cast<ncclComm_t>(comm_);
-  std::vector<Tensor> states = runner_->States();
   hipStream_t st = (hipStream_t) CurStream();
-  std::vector<Tensor> dev;
-  for (auto& t : states) {
-    // sizes first: a replica built with another seed may hold another number of octree nodes
-    Tensor n = torch::full({1}, (int64_t) t.numel(), torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA));
-    F2N_NCCL(ncclBroadcast(n.data_ptr(), n.data_ptr(), 1, ncclInt64, 0, comm, st));
-    const int64_t want = n.item<int64_t>();
-    Tensor d = t.to(torch::kCUDA).contiguous();
-    if (d.numel() != want) d = torch::empty({want}, d.options());
-    F2N_NCCL(ncclBroadcast(d.data_ptr(), d.data_ptr(), (size_t) d.numel() * d.element_size(), ncclChar, 0, comm, st));
-    dev.push_back(d);
-  }
+  auto bcast = [&](const std::vector<Tensor>& states) {
+    std::vector<Tensor> dev;
+    for (auto& t : states) {
+      // sizes first: a replica built with another seed may hold another number of octree nodes / warps / edges
+      Tensor n = torch::full({1}, (int64_t) t.numel(), torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA));
+      F2N_NCCL(ncclBroadcast(n.data_ptr(), n.data_ptr(), 1, ncclInt64, 0, comm, st));
+      const int64_t want = n.item<int64_t>();
+      Tensor d = t.to(torch::kCUDA).contiguous();
+      if (d.numel() != want) d = torch::empty({want}, d.options());
+      if (want > 0) F2N_NCCL(ncclBroadcast(d.data_ptr(), d.data_ptr(), (size_t) d.numel() * d.element_size(), ncclChar, 0, comm, st));
+      dev.push_back(d);
+    }
+    return dev;
+  };
   // shapes as the checkpoint format has them (LoadStates reshapes what it needs)
-  runner_->LoadStates(dev);
+  runner_->LoadStates(bcast(runner_->States()));
+  // ... and what the checkpoint does not hold but a replica of ANOTHER construction would get wrong: the edge pool indexes
+  // rank 0's warps (a rank that kept its own pool would anchor the TV loss to the wrong volumes, or read out of bounds)
+  runner_->LoadAuxStates(bcast(runner_->AuxStates()));
 }
 
 void DataParallel::GradSyncBegin() {

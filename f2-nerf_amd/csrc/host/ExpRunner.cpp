@@ -70,6 +70,19 @@ void ExpRunner::LoadStates(const std::vector<Tensor>& states) {
   BuildOptimizer();  // parameter tensors may have been re-created (primes, nodes): re-bind the groups
 }
 
+std::vector<Tensor> ExpRunner::AuxStates() {
+  auto& oct = *static_cast<PersSampler*>(renderer_->pts_sampler_.get())->pers_octree_;
+  auto or_empty = [](const Tensor& t, torch::TensorOptions o) { return t.defined() ? t : torch::empty({0}, o); };
+  return {or_empty(oct.edge_pool_gpu_, DevU8()), or_empty(oct.w2c_, DevF32()), or_empty(oct.intri_, DevF32()), or_empty(oct.bound_, DevF32())};
+}
+
+void ExpRunner::LoadAuxStates(const std::vector<Tensor>& aux) {
+  TORCH_CHECK(aux.size() == 4, "aux states: edge pool, w2c, intri, bounds");
+  auto* ps = static_cast<PersSampler*>(renderer_->pts_sampler_.get());
+  if (aux[0].numel() > 0) ps->SetEdgePool(aux[0].reshape({-1}));
+  if (aux[1].numel() > 0) ps->SetTrainCameras(aux[1].reshape({-1, 3, 4}), aux[2].reshape({-1, 3, 3}), aux[3].reshape({-1, 2}));
+}
+
 // ExpRunner.cpp:108-114 (variance-loss ramp) and :221-254 (UpdateAdaParams), spelled as the reference spells them
 ExpRunner::ScheduleValues ExpRunner::ScheduleAt(const ScheduleParams& p, int iter) {
   ScheduleValues v;
@@ -506,6 +519,7 @@ void ExpRunner::RenderPath(Dataset& dataset, const Tensor& render_poses, const s
 // biases, n_volumes, MLP], shader [MLP], app_emb), <dir>/scalars.pt = float tensor [iter_step].  Same container format
 // (LibTorch's pickle archive of a tensor list), so the files are interchangeable with the reference's.
 void ExpRunner::SaveCheckpoint(const std::string& dir) {
+  FinishPending();  // a pipelined step's Adam / a deferred NaN flag may still change parameters and iter_step_
   std::vector<Tensor> states = States();
   for (auto& t : states) t = t.detach().contiguous();
   torch::save(states, dir + "/renderer.pt");
@@ -558,6 +572,9 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   FinishPending();  // may take the last iteration back (its finiteness flags are read one step late)
   if (iter_step_ >= target || executed > give_up) break;
   }
+  // (streaming steps resolve their survivor counts one step late: the total is the renderer's running counter, complete
+  // after the flush above)
+  last_train_meaningful_ = renderer_->total_kept_pts_ - kept0;
   return executed;
 }
 

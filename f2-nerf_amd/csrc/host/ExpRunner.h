@@ -21,6 +21,11 @@ class ExpRunner {
     FinishPending();
     return renderer_->States();
   }
+  // What a replica needs besides the checkpoint vector to be a copy of another one: the edge pool (built once from the
+  // construction-time tree, PersSampler.cpp:615-659; its t_idx_a/b index the warps) and the training cameras MarkInvisibleNodes
+  // projects into.  The reference's checkpoint does not hold them (its constructor rebuilds them from the data set).
+  std::vector<Tensor> AuxStates();
+  void LoadAuxStates(const std::vector<Tensor>& aux);
   bool ApplyGradients(bool apply_optimizer);
   // Flush: completes whatever a streaming TrainStep left open -- the pipelined data-parallel step whose all-reduce is
   // still in flight, and the finiteness flags a prefetching TrainStep reads one step late.

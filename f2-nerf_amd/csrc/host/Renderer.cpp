@@ -187,6 +187,7 @@ Renderer::Renderer(GlobalDataPool* gdp, int n_images) {  // Renderer.cpp:22-49
 
 void Renderer::ZeroGrad() {
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
+  F2N_CALL(f2n_deferred_reset());  // (a step that threw between its deferring launches and f2n_reduce_deferred leaves nothing behind)
   if (small_grads_clean_) {  // the fused Adam step cleared everything it consumed: no fill kernels this iteration
     small_grads_clean_ = false;
     if (!field->grad_clean_) field->grad_h_.zero_();

@@ -104,6 +104,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(py::init<const std::map<std::string, std::string>&, int>(), py::arg("flat_config"), py::arg("n_images"))
       .def("load_states", &ExpRunner::LoadStates)
       .def("states", &ExpRunner::States)
+      .def("aux_states", &ExpRunner::AuxStates)
+      .def("load_aux_states", &ExpRunner::LoadAuxStates)
       .def("train_step",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply,
               const std::optional<Tensor>& nro, const std::optional<Tensor>& nrd, const std::optional<Tensor>& nb) {

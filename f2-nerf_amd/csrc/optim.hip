@@ -429,7 +429,7 @@ int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const fl
   return f2n_launch_status();
 }
 
-int f2n_abi_version(void) { return 7; }
+int f2n_abi_version(void) { return 8; }
 const char* f2n_build_info(void) { return "f2n_hip gfx950 (hipcc, -ffp-contract=off), wave64, mfma_f32_16x16x32_f16"; }
 
 }  // extern "C"

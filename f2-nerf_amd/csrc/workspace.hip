@@ -123,6 +123,16 @@ __global__ __launch_bounds__(64 * F2N_RED_GROUPS) void f2n_reduce_deferred_kerne
   }
 }
 
+// Forgets whatever was registered and not yet folded (a caller whose backward threw between its deferring launches and
+// f2n_reduce_deferred must not have those stale entries folded into the NEXT step's gradients).
+extern "C" int f2n_deferred_reset(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_n_deferred[dev] = 0;
+  return F2N_OK;
+}
+
 extern "C" int f2n_reduce_deferred(void* stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;

@@ -63,19 +63,25 @@ def broadcast_states(runner, group=None):
     them from the torch RNG, the very generator that has to DIFFER per rank for distinct ray batches: whatever the ranks were
     constructed with, rank 0's checkpoint vector is loaded everywhere (sizes first -- another seed may have built another
     number of octree nodes)."""
-    states = runner.states()
     backend = dist.get_backend(group)
-    out = []
-    for t in states:
-        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
-        dist.broadcast(n, src=0, group=group)
-        b = t.to(dev).contiguous()
-        if b.numel() != int(n.item()):
-            b = torch.empty(int(n.item()), dtype=b.dtype, device=dev)
-        dist.broadcast(b, src=0, group=group)
-        out.append(b)
-    runner.load_states(out)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+    def bcast(states):
+        out = []
+        for t in states:
+            n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
+            dist.broadcast(n, src=0, group=group)
+            b = t.to(dev).contiguous()
+            if b.numel() != int(n.item()):
+                b = torch.empty(int(n.item()), dtype=b.dtype, device=dev)
+            if b.numel() > 0:
+                dist.broadcast(b, src=0, group=group)
+            out.append(b)
+        return out
+    runner.load_states(bcast(runner.states()))
+    # the edge pool (its t_idx_a/b index rank 0's warps) and the training cameras are not part of the checkpoint vector
+    if hasattr(runner, "aux_states"):
+        runner.load_aux_states(bcast(runner.aux_states()))
 
 
 def attach(runner, log2_table_size, group=None, overlap=None, native=None):

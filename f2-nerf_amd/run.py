@@ -138,14 +138,21 @@ def main(argv=None):
         t = cfg["train"]
         end, save_freq, report = int(t["end_iter"]), int(t["save_freq"]), int(t["report_freq"])
         t0 = time.time()
+        psnr_smooth = -1.0
         while runner.iter_step < end:
-            nxt = min(end, (runner.iter_step // save_freq + 1) * save_freq)
+            # the native loop runs up to the next report / checkpoint boundary (ExpRunner.cpp:157-172); the reference smooths
+            # the PSNR over every iteration (one host read-back each: :120-122) -- here the loss stays on the device inside
+            # the loop, so the same 0.9 / 0.1 smoothing is applied over the report boundaries' batches instead
+            nxt = min(end, (runner.iter_step // report + 1) * report, (runner.iter_step // save_freq + 1) * save_freq)
             s = runner.train(ds, nxt, 1)
-            torch.cuda.synchronize()
-            mse = max(float(s["mse"]), 1e-12)
-            print("Iter: %6d PSNR: %.2f NRays: %5d OctSamples: %.1f Samples: %.1f MeaningfulSamples: %.1f IPS: %.1f LR: %.4f" % (
-                runner.iter_step, 10 * np.log10(1 / mse), s["n_rays"], runner.oct_per_ray, runner.sampled_per_ray,
-                runner.meaningful_per_ray, runner.iter_step / max(time.time() - t0, 1e-9), runner.cur_lr), flush=True)
+            if runner.iter_step % report == 0 or runner.iter_step >= end:
+                torch.cuda.synchronize()
+                mse = max(float(s["mse"]), 1e-12)
+                psnr = 20 * np.log10(1 / np.sqrt(mse))
+                psnr_smooth = psnr if psnr_smooth < 0 else psnr * .1 + psnr_smooth * .9
+                print("Iter: %6d PSNR: %.2f NRays: %5d OctSamples: %.1f Samples: %.1f MeaningfulSamples: %.1f IPS: %.1f LR: %.4f" % (
+                    runner.iter_step, psnr_smooth, s["n_rays"], runner.oct_per_ray, runner.sampled_per_ray,
+                    runner.meaningful_per_ray, runner.iter_step / max(time.time() - t0, 1e-9), runner.cur_lr), flush=True)
             if runner.iter_step % save_freq == 0:
                 save_checkpoint()
         with open(os.path.join(exp_dir, "train_info.txt"), "w") as f:

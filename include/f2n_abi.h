@@ -380,6 +380,10 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
  * that was deferred on this device into the destinations named at the time (at most four pending reductions; same stream
  * rule as the workspace itself).  Saves two dependent launches per training step. */
 int f2n_reduce_deferred(void* stream);
+/* Drops every reduction registered on this device and not yet folded: call it at the start of a backward pass (the host's
+ * ZeroGrad does), so that a step that failed between a deferring launch and f2n_reduce_deferred cannot leak its partial sums
+ * into the next step's gradients.  No launch. */
+int f2n_deferred_reset(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * Renderer -- replaces the per-ray glue of Renderer::Render (Renderer/Renderer.cpp:105-208), i.e.

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_host_only_queries(lib):
-    assert lib.f2n_abi_version() == 7
+    assert lib.f2n_abi_version() == 8
     lib.f2n_build_info.restype = ctypes.c_char_p
     assert b"gfx950" in lib.f2n_build_info()
     assert lib.f2n_mlp_n_params(32, 64, 1) == 3072      # field MLP, SURVEY 8(a) a12
