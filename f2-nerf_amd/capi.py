@@ -240,6 +240,16 @@ def hash_gather_planes_balanced(n, n_volumes, table_h, prim_pool, local_idx, loc
                                               ctypes.c_float(step01), arr), "f2n_hash_gather_planes_balanced")
 
 
+def hash_gather_variant(n, n_volumes, step01, level_scale_host):
+    """bit 0: staged hash constants, bit 1: run combining + balanced split (what f2n_hash_gather_planes_balanced would launch)."""
+    import ctypes
+    arr = (ctypes.c_float * 16)(*[float(v) for v in level_scale_host])
+    rc = lib().f2n_hash_gather_variant(_i(n), _i(n_volumes), ctypes.c_float(step01), arr)
+    if rc < 0:
+        _ck(rc, "f2n_hash_gather_variant")
+    return rc
+
+
 def field_mlp_planes(n, planes_h, mlp_params_h, out_feat, out_f0, save_x_h):
     _ck(lib().f2n_field_mlp_planes(_stream(), _i(n), _p(planes_h, "h16"), _p(mlp_params_h, "h16"), _p(out_feat, "f32", True),
                                    _p(out_f0, "f32", True), _p(save_x_h, "h16", True)), "f2n_field_mlp_planes")

@@ -1050,20 +1050,11 @@ int f2n_hash_gather_planes(void* stream, int n, int n_volumes, const void* table
                                          pts, pts_are_warped, volume_idx, vol_stride, planes_h, 0.f, nullptr);
 }
 
-int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
-                                    const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
-                                    const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
-                                    int vol_stride, void* planes_h, float step01, const float* level_scale_host) {
-  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
-  if (n == 0) return F2N_OK;
-  F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
-  long per_part = ((long) n + 255) / 256;
-  if (per_part > 256) per_part = 256;  // 32 CUs per XCD x 8 resident 256-thread blocks
+// The launcher's choice of kernel variant: bit 0 = hash constants staged in LDS, bit 1 = run combining + cost-balanced split.
+static int f2n_gather_variant(int n, int n_volumes, float step01, const float* level_scale_host, float* cost8) {
   const size_t stage_bytes = (size_t) 2 * n_volumes * 6 * sizeof(uint32_t);
   const bool staged = stage_bytes <= 20000 && n >= 64 * 256;  // keeps 8 blocks per CU resident; not worth the copy for small batches
   bool balanced = step01 > 0.f && level_scale_host != nullptr;
-  F2nGatherPlan plan;
-  float cost8[F2N_N_PARTS];
   if (balanced) {
     // Run combining and pair switching cost ~10 % of a tile (more registers: 6 instead of 8 waves per SIMD; re-staging;
     // an L2 refill per switch): worth it only when the balanced share is well below the costliest pair's load.  On a
@@ -1077,6 +1068,29 @@ int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const vo
     }
     balanced = sum / F2N_N_PARTS < 0.8f * mx;
   }
+  return (staged ? 1 : 0) | (balanced ? 2 : 0);
+}
+
+int f2n_hash_gather_variant(int n, int n_volumes, float step01, const float* level_scale_host) {
+  if (n < 0 || n_volumes <= 0) return F2N_ERR_INVALID_ARG;
+  float cost8[F2N_N_PARTS];
+  return f2n_gather_variant(n, n_volumes, step01, level_scale_host, cost8);
+}
+
+int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                                    const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                                    const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
+                                    int vol_stride, void* planes_h, float step01, const float* level_scale_host) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
+  long per_part = ((long) n + 255) / 256;
+  if (per_part > 256) per_part = 256;  // 32 CUs per XCD x 8 resident 256-thread blocks
+  const size_t stage_bytes = (size_t) 2 * n_volumes * 6 * sizeof(uint32_t);
+  F2nGatherPlan plan;
+  float cost8[F2N_N_PARTS];
+  const int variant = f2n_gather_variant(n, n_volumes, step01, level_scale_host, cost8);
+  const bool staged = (variant & 1) != 0, balanced = (variant & 2) != 0;
   f2n_gather_plan((n + 255) / 256, balanced ? cost8 : nullptr, plan);
 #define F2N_LAUNCH_GATHER(ST, CB)                                                                                              \
   hipLaunchKernelGGL((hash_gather_planes_kernel<ST, CB>), dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256),                \

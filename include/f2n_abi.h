@@ -267,6 +267,11 @@ int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const vo
  * samples.  out [8][1 + 3*8] int32: per XCD the number of segments, then (level pair, first tile, tile count) per
  * segment (-1, 0, 0 for unused slots); cost8_out [8] (may be NULL): the modelled cost of one tile of each level pair. */
 int f2n_gather_plan_query(int n_tiles, float step01, const float* level_scale_host, int32_t* out, float* cost8_out);
+/* ... and the kernel variant it would launch for these sizes (host only, ABI v8): bit 0 = hash constants staged in LDS
+ * (2 * n_volumes * 24 B <= 20000 and n >= 16384), bit 1 = run combining + balanced split (the cost model predicts a balanced
+ * share below 0.8 x the costliest level pair).  Negative = error.  What the parity tests assert before they claim to have
+ * exercised a variant. */
+int f2n_hash_gather_variant(int n, int n_volumes, float step01, const float* level_scale_host);
 int f2n_field_mlp_planes(void* stream, int n, const void* planes_h, const void* mlp_params_h, float* out_feat_f32,
                          float* out_f0, void* save_x_h);
 

@@ -333,30 +333,26 @@ class OracleTrainer:
         return ref
 
 
-def test_training_trajectory_across_milestone_and_compaction(rt, fox_state):
-    """36 iterations on both sides from the same state with explicit draws: subdivision + MarkInvisible + compaction at the
-    milestone (iteration 12), compactions every 8 iterations, nodes dying in between (the occupancy statistics start at 2
-    instead of 1000, so unvisited / empty leaves are pruned within the run).  Compared after EVERY iteration: the node
-    array, the visit counts and the sample counts exactly; the occupancy statistics exactly up to a bounded number of
-    borderline votes; the loss within 2e-3; every sixth iteration the rendered batch colours (1e-3, later 1e-2)."""
-    st = fox_state
-    R, NE, ITERS = 256, 512, 36
-    overrides = ["field.log2_table_size=14", "pts_sampler.sub_div_milestones=[12]", "pts_sampler.compact_freq=8",
-                 "train.learning_rate_warm_up_end_iter=20"]
+def run_trajectory(rt, st, R, NE, ITERS, overrides, realign, render_at, seed, init_stat=2, tag="TRAJ"):
+    """ITERS iterations of ExpRunner::TrainStep on the device and of OracleTrainer on the CPU from the same state with explicit
+    draws.  Until the two sides FORK (a borderline occupancy vote falls differently: the MLP outputs differ by an f16 ulp,
+    PersSampler.cu:497-520) everything integer is compared exactly after every iteration.  realign=True copies the device's
+    statistics into the oracle at a fork, so that the exact comparison carries on; realign=False lets the fork stand: from
+    then on the comparison is statistical (node / sample counts, loss, colours) and the divergence it causes is reported."""
     runner, cfg, arrays = rt.make_runner(st, "wanjinyou", overrides, seed=5, table_init=0.3)
     runner.n_edge_pts = NE
     for t in runner.occupancy_buffers()[:2]:
-        t.fill_(2)
+        t.fill_(init_stat)
     orc = OracleTrainer(st, cfg, arrays, len(st["poses"]))
     import copy
     cfg_noemb = copy.deepcopy(cfg)
     cfg_noemb["renderer"]["use_app_emb"] = False
-    orc.w_stats[:] = 2
-    orc.a_stats[:] = 2
-    rng = np.random.default_rng(99)
-    n_nodes_seen = set()
-    vote_flips = 0
-    worst_rgb = 0.0
+    orc.w_stats[:] = init_stat
+    orc.a_stats[:] = init_stat
+    rng = np.random.default_rng(seed)
+    m = dict(n_nodes_seen=set(), vote_flips=0, worst_rgb=0.0, worst_rgb_mean=0.0, fork_iter=None, forked_nodes=0, worst_loss=0.0,
+             worst_sample_diff=0.0, worst_node_diff=0)
+    forked = False
     for it in range(ITERS):
         assert runner.iter_step == orc.iter_step == it
         ro, rd, bounds, cam = fox_batch(st, rng, R)
@@ -373,58 +369,120 @@ def test_training_trajectory_across_milestone_and_compaction(rt, fox_state):
         ref = orc.step(ro, rd, cam, gt, noise, bg, eidx, ecoord)
         stats = runner.train_step(d[0], d[1], d[2], d[3], d[4], True)
         assert not stats["skipped_nan"]
-        assert stats["n_samples"] == len(ref["smp"]["t"]), it
-        assert abs(stats["n_meaningful"] - ref["n_kept"]) <= 2, (it, stats["n_meaningful"], ref["n_kept"])
-        assert abs(float(stats["loss"]) - ref["loss"]) <= 2e-3 * max(1.0, abs(ref["loss"])), (it, float(stats["loss"]), ref["loss"])
+        n_ref = len(ref["smp"]["t"])
+        dl = abs(float(stats["loss"]) - ref["loss"]) / max(1.0, abs(ref["loss"]))
+        m["worst_loss"] = max(m["worst_loss"], dl)
         got_nodes = N(runner.tree_nodes()).view(octc.NODE_DT)
-        assert len(got_nodes) == len(orc.nodes), (it, len(got_nodes), len(orc.nodes))
-        for f in ("center", "side_len", "parent", "childs", "is_leaf_node"):
-            assert (got_nodes[f] == orc.nodes[f]).all(), (it, f)
         wst, ast, vcnt = [N(t) for t in runner.occupancy_buffers()]
-        assert (vcnt == orc.visit).all(), it
-        # A vote compares a sample's weight / alpha with a threshold (PersSampler.cu:497-520); where the two sides' MLP outputs
-        # differ by an f16 ulp a borderline vote can fall differently.  Such nodes are counted, bounded, and the oracle's
-        # statistics are re-aligned so that one borderline vote does not fork the rest of the trajectory.
-        bad = (wst != orc.w_stats) | (ast != orc.a_stats) | (got_nodes["trans_idx"] != orc.nodes["trans_idx"])
-        if bad.any():
-            vote_flips += int(bad.sum())
-            assert bad.sum() <= 8, (it, int(bad.sum()))
-            assert (np.abs(wst - orc.w_stats)[bad] <= 513).all() and (np.abs(ast - orc.a_stats)[bad] <= 33).all()  # one vote each
-            orc.w_stats, orc.a_stats = wst.copy(), ast.copy()
-            orc.nodes["trans_idx"] = got_nodes["trans_idx"]
-        n_nodes_seen.add(len(got_nodes))
-        # every few iterations both sides render this batch with the UPDATED state (VALIDATE mode: no occupancy votes, no
+        m["n_nodes_seen"].add(len(got_nodes))
+        if not forked:
+            assert stats["n_samples"] == n_ref, it
+            assert abs(stats["n_meaningful"] - ref["n_kept"]) <= max(2, R // 1024), (it, stats["n_meaningful"], ref["n_kept"])
+            assert dl <= 2e-3, (it, float(stats["loss"]), ref["loss"])
+            assert len(got_nodes) == len(orc.nodes), (it, len(got_nodes), len(orc.nodes))
+            for f in ("center", "side_len", "parent", "childs", "is_leaf_node"):
+                assert (got_nodes[f] == orc.nodes[f]).all(), (it, f)
+            assert (vcnt == orc.visit).all(), it
+            # A vote compares a sample's weight / alpha with a threshold (PersSampler.cu:497-520); where the two sides' MLP outputs
+            # differ by an f16 ulp a borderline vote can fall differently.  Such nodes are counted and bounded.
+            bad = (wst != orc.w_stats) | (ast != orc.a_stats) | (got_nodes["trans_idx"] != orc.nodes["trans_idx"])
+            if bad.any():
+                m["vote_flips"] += int(bad.sum())
+                assert bad.sum() <= max(8, R // 256), (it, int(bad.sum()))
+                assert (np.abs(wst - orc.w_stats)[bad] <= 513).all() and (np.abs(ast - orc.a_stats)[bad] <= 33).all()  # one vote each
+                if realign:  # ... and the oracle's statistics re-aligned so that one borderline vote does not fork the rest
+                    orc.w_stats, orc.a_stats = wst.copy(), ast.copy()
+                    orc.nodes["trans_idx"] = got_nodes["trans_idx"]
+                else:
+                    forked = True
+                    m["fork_iter"] = it
+                    m["forked_nodes"] = int(bad.sum())
+        else:
+            # the two sides carry different occupancy statistics for a few nodes: leaves may die (and be compacted away, or be
+            # subdivided at the milestone) an iteration apart.  What must hold is that this stays a perturbation.
+            sd = abs(stats["n_samples"] - n_ref) / max(n_ref, 1)
+            nd = abs(len(got_nodes) - len(orc.nodes))
+            m["worst_sample_diff"] = max(m["worst_sample_diff"], sd)
+            m["worst_node_diff"] = max(m["worst_node_diff"], nd)
+            assert sd <= 0.03, (it, stats["n_samples"], n_ref)
+            assert nd <= 0.02 * len(orc.nodes) + 16, (it, len(got_nodes), len(orc.nodes))
+            assert dl <= 1e-2, (it, float(stats["loss"]), ref["loss"])
+        # at the listed iterations both sides render this batch with the UPDATED state (VALIDATE mode: no occupancy votes, no
         # appearance embedding; the explicit noise / background draws stay in force)
-        if it % 6 == 5 or it == ITERS - 1:
+        if it in render_at:
             got = N(runner.render_rays(d[0], d[1], d[2])[0])
             arrays_now = [orc.tree_blob(), orc.tr, None, None, orc.grid.table_f32, orc.grid.prim_pool, orc.grid.bias_pool,
                           np.array([orc.grid.n_volumes]), orc.p_field, orc.p_color, orc.app_emb]
             ref2 = oracle_train_iteration(st, cfg_noemb, arrays_now, ro, rd, cam, gt, noise, bg, eidx, ecoord, orc.iter_step)
-            err = float(np.abs(got - ref2["colors"]).max())
-            worst_rgb = max(worst_rgb, err)
-            # identical weights render within 1e-3 (test_config2_full_iteration_parity); here the weights themselves come out of
-            # two optimiser trajectories, and Adam (eps 1e-15) turns one-ulp differences of f16 gradients into full-size steps
-            # of the affected entries.  The device side is not bit-reproducible either (scatter order), so the late bound is
-            # set from the spread of repeated runs: within 1e-3 for the first two dozen updates in every run; at updates 30 /
-            # 36 between 1.5e-3 and 4.3e-3 over 14 runs of the same test
-            assert err <= (1e-3 if it < 24 else 1e-2), (it, err)
+            e = np.abs(got - ref2["colors"])
+            err, mean = float(e.max()), float(e.mean())
+            m["worst_rgb"] = max(m["worst_rgb"], err)
+            m["worst_rgb_mean"] = max(m["worst_rgb_mean"], mean)
+            if not forked:
+                # identical weights render within 1e-3 (test_config2_full_iteration_parity); here the weights themselves come out
+                # of two optimiser trajectories, and Adam (eps 1e-15) turns one-ulp differences of f16 gradients into full-size
+                # steps of the affected entries.  The device side is not bit-reproducible either (scatter order), so the late
+                # bound is set from the spread of repeated runs: within 1e-3 for the first two dozen updates in every run; at
+                # updates 30 / 36 between 1.5e-3 and 4.3e-3 over 14 runs of the same test
+                assert err <= (1e-3 if it < 24 else 1e-2), (it, err)
+            else:
+                # a leaf that one side has pruned and the other has not was borderline EMPTY on both: colours move by little
+                assert mean <= 2e-3 and float(np.percentile(e, 99.9)) <= 3e-2, (it, mean, err)
     states = [N(t) for t in runner.states()]
     dl_f, dl_c = np.abs(states[8] - orc.p_field), np.abs(states[9] - orc.p_color)
-    print("TRAJ_METRICS flips %d worst_rgb %.2e field mean %.2e p99 %.2e max %.2e colour mean %.2e p99 %.2e max %.2e" % (
-        vote_flips, worst_rgb, dl_f.mean(), np.percentile(dl_f, 99), dl_f.max(), dl_c.mean(), np.percentile(dl_c, 99), dl_c.max()))
-    assert len(n_nodes_seen) >= 2 and 897 not in n_nodes_seen, n_nodes_seen  # pruned at iteration 0, subdivided at the milestone
-    assert vote_flips <= 24, vote_flips      # of ~1e5 node-iterations, clustered at the end as the weights drift apart (4..8 over 14 runs)
-    # final parameters: the tables of both sides took the same trajectory
-    states = [N(t) for t in runner.states()]
     tab = states[4].reshape(-1)
     ref_tab = orc.grid.table_f32.reshape(-1)
-    cos = float((tab.astype(np.float64) * ref_tab).sum() / (np.linalg.norm(tab) * np.linalg.norm(ref_tab)))
-    assert cos > 0.9999, cos
+    m["table_cos"] = float((tab.astype(np.float64) * ref_tab).sum() / (np.linalg.norm(tab) * np.linalg.norm(ref_tab)))
+    m["field_dl"], m["color_dl"] = dl_f, dl_c
+    print("%s_METRICS rays %d iters %d realign %d flips %d fork_iter %s forked_nodes %d worst_rgb %.2e (mean %.2e) worst_loss %.2e "
+          "sample_diff %.2e node_diff %d table_cos %.6f field mean %.2e p99 %.2e max %.2e colour mean %.2e p99 %.2e max %.2e" % (
+              tag, R, ITERS, int(realign), m["vote_flips"], m["fork_iter"], m["forked_nodes"], m["worst_rgb"], m["worst_rgb_mean"],
+              m["worst_loss"], m["worst_sample_diff"], m["worst_node_diff"], m["table_cos"], dl_f.mean(), np.percentile(dl_f, 99),
+              dl_f.max(), dl_c.mean(), np.percentile(dl_c, 99), dl_c.max()))
+    return m
+
+
+TRAJ_OVERRIDES = ["field.log2_table_size=14", "pts_sampler.sub_div_milestones=[12]", "pts_sampler.compact_freq=8",
+                  "train.learning_rate_warm_up_end_iter=20"]
+
+
+@pytest.mark.parametrize("realign", [True, False])
+def test_training_trajectory_across_milestone_and_compaction(rt, fox_state, realign):
+    """36 iterations on both sides from the same state with explicit draws: subdivision + MarkInvisible + compaction at the
+    milestone (iteration 12), compactions every 8 iterations, nodes dying in between (the occupancy statistics start at 2
+    instead of 1000, so unvisited / empty leaves are pruned within the run).  Compared after EVERY iteration: the node
+    array, the visit counts and the sample counts exactly; the occupancy statistics exactly up to a bounded number of
+    borderline votes; the loss within 2e-3; every sixth iteration the rendered batch colours (1e-3, later 1e-2).
+    realign=False (round-2 verdict): the oracle is NOT re-aligned when a borderline vote falls differently -- the two sides
+    fork, and the test asserts how far (it reports the iteration of the fork and the divergence that follows)."""
+    ITERS = 36
+    m = run_trajectory(rt, fox_state, 256, 512, ITERS, TRAJ_OVERRIDES, realign, {it for it in range(ITERS) if it % 6 == 5 or it == ITERS - 1},
+                       seed=99, tag="TRAJ")
+    assert len(m["n_nodes_seen"]) >= 2 and 897 not in m["n_nodes_seen"], m["n_nodes_seen"]  # pruned at iteration 0, subdivided at the milestone
+    if realign:
+        assert m["vote_flips"] <= 24, m["vote_flips"]  # of ~1e5 node-iterations, clustered at the end as the weights drift apart (4..8 over 14 runs)
+    else:
+        assert m["fork_iter"] is None or m["fork_iter"] >= 6, m["fork_iter"]  # (the first iterations are exact in every run)
+        assert m["forked_nodes"] <= 8
+    # final parameters: the tables of both sides took the same trajectory
+    assert m["table_cos"] > (0.9999 if realign or m["fork_iter"] is None else 0.999), m["table_cos"]
     # (Adam turns "tiny gradient or exactly zero" into a full lr-sized step per iteration: individual weights may sit a few
     # learning rates apart after 36 updates; the networks as a whole took the same path)
-    for got_p, ref_p in ((states[8], orc.p_field), (states[9], orc.p_color)):
-        dlt = np.abs(got_p - ref_p)
+    for dlt in (m["field_dl"], m["color_dl"]):
         # (over 14 runs: field MLP mean 2.6..3.0e-4, p99 1.4..1.6e-3; colour MLP mean 5.2..6.5e-4, p99 4.2..6.7e-3, max 4e-2)
+        assert dlt.mean() <= 2e-3 and np.percentile(dlt, 99) <= 3e-2, (float(dlt.mean()), float(np.percentile(dlt, 99)), float(dlt.max()))
+
+
+def test_training_trajectory_at_the_benched_size(rt, fox_state):
+    """12 iterations at BASELINE config 2's size -- 8192 rays, 2^19 x 16 table, 8192 edge samples, ~7e5 samples per iteration
+    (the partitioned gather, the owner-binned scatter, the table Adam over 17 * 2^19 halves) -- across a subdivision milestone
+    (iteration 6) and compactions (every 4), oracle not re-aligned."""
+    ITERS = 12
+    overrides = ["pts_sampler.sub_div_milestones=[6]", "pts_sampler.compact_freq=4", "train.learning_rate_warm_up_end_iter=20"]
+    m = run_trajectory(rt, fox_state, 8192, 8192, ITERS, overrides, False, {5, 11}, seed=123, tag="TRAJ_BENCH_SIZE")
+    assert len(m["n_nodes_seen"]) >= 2 and 897 not in m["n_nodes_seen"], m["n_nodes_seen"]
+    assert m["table_cos"] > 0.999, m["table_cos"]
+    for dlt in (m["field_dl"], m["color_dl"]):
         assert dlt.mean() <= 2e-3 and np.percentile(dlt, 99) <= 3e-2, (float(dlt.mean()), float(np.percentile(dlt, 99)), float(dlt.max()))
 
 
