@@ -75,6 +75,8 @@ def converged_leg(args, st, dev):
     sc, images = fox_data.scene(args.factor)
     ds = runtime.make_dataset(sc, images)
     runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022, device=dev)
+    if args.no_speculation:
+        runner.speculative_sampling = False
     torch.manual_seed(2022)
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
@@ -116,7 +118,10 @@ def converged_leg(args, st, dev):
     out.update({"rays_per_batch": round(R, 1), "steps": K, "ms_per_step": el / K * 1e3, "value": nm / el, "unit": "ray-samples/s",
                 "marched_samples_per_s": na / el, "rho_marched_over_meaningful": na / max(nm, 1),
                 "meaningful_samples_per_step": nm / K, "marched_samples_per_step": na / K, "rays_per_s": R * K / el,
-                "timed_loop": "ExpRunner::Train (native loop, fresh batches, ray generation and octree maintenance included)"})
+                "timed_loop": "ExpRunner::Train (native loop, fresh batches, ray generation and octree maintenance included)",
+                # batches whose intersection + march ran AHEAD of the previous step's stat update / behind it (ProcOctree
+                # iterations), rays walked again because a leaf on their list died in that update, stat updates so far
+                "speculative_sampling": {k: int(v) for k, v in runner.speculation_counters().items()}})
     R = max(16, runner.cur_batch_size())
     n_batches = 16
     batches = [ds.rand_rays_data(R, 1) for _ in range(n_batches)]
@@ -168,6 +173,8 @@ def main():
     ap.add_argument("--factor", type=int, default=2, choices=[2, 8], help="image resolution of the converged leg (dataset.factor)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     ap.add_argument("--marker-pause", action="store_true", help="sleep 0.3 s before the timed region (marker for profiles/timeline_rocpd.py)")
+    ap.add_argument("--no-speculation", action="store_true", help="A/B: sample the next batch behind the stat update (round-2 order) "
+                    "instead of speculatively ahead of it")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
@@ -212,6 +219,8 @@ def main():
     log2 = int(cfg["field"]["log2_table_size"])
     if args.diag_no_nan_check:
         runner.check_nan = False
+    if args.no_speculation:
+        runner.speculative_sampling = False
 
     if dp:
         from f2_nerf_amd import parallel

@@ -163,6 +163,32 @@ def oct_update_stats(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nod
                                    _p(child_blocks, "u8", True), _i(1 if reset_votes else 0)), "f2n_oct_update_stats")
 
 
+def oct_update_stats_ex(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes, child_blocks, reset_votes, died_at, epoch,
+                        death_epoch):
+    _ck(lib().f2n_oct_update_stats_ex(_stream(), _i(n_nodes), _p(w_adder, "i32"), _p(a_adder, "i32"), _p(mark, "i32"),
+                                      _p(w_stats, "i32"), _p(a_stats, "i32"), _p(tree_nodes, "u8"), _p(child_blocks, "u8", True),
+                                      _i(int(reset_votes)), _p(died_at, "i32", True), _i(epoch), _p(death_epoch, "i32", True)),
+        "f2n_oct_update_stats_ex")
+
+
+def oct_intersect_repair(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total,
+                         oct_trans, child_blocks, died_at, spec_epoch, death_epoch, repair_flags, n_repaired=None):
+    _ck(lib().f2n_oct_intersect_repair(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
+                                       _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
+                                       _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True),
+                                       _p(child_blocks, "u8", True), _p(died_at, "i32"), _i(spec_epoch), _p(death_epoch, "i32"),
+                                       _p(repair_flags, "i32"), _p(n_repaired, "i32", True)), "f2n_oct_intersect_repair")
+
+
+def ray_march_repair(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes, transes, counts,
+                     s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, repair_flags, death_epoch, spec_epoch):
+    _ck(lib().f2n_ray_march_repair(_stream(), _i(n_rays), _f(sample_l), _i(int(scale_by_dis)), _p(rays_o, "f32"), _p(rays_d, "f32"),
+                                   _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(tree_nodes, "u8"),
+                                   _p(transes, "u8"), _p(counts, "i32"), _p(s_pts, "f32", True), _p(s_dt, "f32"), _p(s_t, "f32"),
+                                   _p(s_anchors, "i32"), _p(first_oct_dis, "f32"), _p(oct_trans, "i32", True),
+                                   _p(repair_flags, "i32"), _p(death_epoch, "i32"), _i(spec_epoch)), "f2n_ray_march_repair")
+
+
 def oct_build_child_blocks(n_nodes, tree_nodes, child_blocks):
     _ck(lib().f2n_oct_build_child_blocks(_stream(), _i(n_nodes), _p(tree_nodes, "u8"), _p(child_blocks, "u8")),
         "f2n_oct_build_child_blocks")

@@ -222,6 +222,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   FinishPendingStep();
   renderer_->ZeroGrad();
   renderer_->after_octree_update_ = nullptr;  // (a previous call that threw must not leave its hook / half a prefetch behind)
+  renderer_->next_batch_ = Renderer::NextBatch();
   if (!renderer_->PendingMatches(rays_o, rays_d)) renderer_->DropPendingSamples();
   deferred_dropped_ = false;
   if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
@@ -235,6 +236,12 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     renderer_->after_octree_update_ = [this, fin, &next_rays_o, &next_rays_d, &next_bounds]() {
       renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, fin);
     };
+    // ... or, outside the ProcOctree iterations, speculatively from the top of this step (Renderer.h: next_batch_); the hook
+    // above remains the fallback
+    renderer_->next_batch_.rays_o = next_rays_o;
+    renderer_->next_batch_.rays_d = next_rays_d;
+    renderer_->next_batch_.fineness = fin;
+    renderer_->next_batch_.valid = true;
   }
   // A streaming step (it was handed the next batch) does not wait for the survivor count either: it stays on the device
   // (f2n_*_dyn entry points), the host queues the whole iteration without a device round trip and learns the count -- for
@@ -244,6 +251,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
                                                      disp_loss_weight_, tv_loss_weight_);
   renderer_->async_count_ = false;
   renderer_->after_octree_update_ = nullptr;
+  renderer_->next_batch_ = Renderer::NextBatch();
   ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)
   TrainStats stats;
   stats.skipped_nan = deferred_dropped_;  // the PREVIOUS iteration was dropped: reported one step late when prefetching

@@ -46,6 +46,13 @@ PersSampler::PersSampler(GlobalDataPool* global_data_pool) {
 
 void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of the tree (f2n_oct_build_child_blocks)
   const int n = n_nodes_;
+  // every caller has just replaced or edited the node array wholesale: speculative samples against the old one are void
+  generation_++;
+  died_at_ = torch::zeros({std::max(n, 1)}, DevI32());
+  if (!death_epoch_.defined()) {
+    death_epoch_ = torch::zeros({1}, DevI32());
+    n_repaired_ = torch::zeros({1}, DevI32());
+  }
   child_blocks_gpu_ = torch::empty({int64_t(n) * 8 * 32}, torch::TensorOptions().dtype(torch::kUInt8).device(torch::kCUDA));
   F2N_CALL(f2n_oct_build_child_blocks(CurStream(), n, VoidP(tree_nodes_gpu_), VoidP(child_blocks_gpu_)));
 }
@@ -59,7 +66,12 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   return FinishSamples(p);
 }
 
-void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, float fineness, PendingSamples& p) {
+bool PersSampler::MaintenanceDue() const {  // the conditions of FinishOctUpdate below, for the iteration in progress
+  const int it = global_data_pool_->iter_step_;
+  return (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= it) || it % compact_freq_ == 0;
+}
+
+void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, float fineness, PendingSamples& p, bool speculative) {
   Tensor rays_o = rays_o_raw.contiguous();
   Tensor rays_d_in = rays_d_raw.contiguous();
   CheckDev(rays_o, torch::kFloat32, "rays_o");
@@ -115,10 +127,52 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
                                  I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
                                  VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t), I32P(s_anchors),
                                  F32P(first_oct_dis), I32P(oct_tr)));
-  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(counts), I32P(pts_se), I32P(totals) + 1));
+  p.active = true;
+  p.n_rays = n_rays;
+  p.rays_o = rays_o; p.rays_d = rays_d; p.counts = counts; p.oct_se = oct_se; p.totals = totals;
+  p.oct_idx = oct_idx; p.oct_nf = oct_nf; p.oct_tr = oct_tr; p.noise = rays_noise; p.pts_se = pts_se; p.s_dt = s_dt; p.s_t = s_t;
+  p.s_anchors = s_anchors; p.first_oct_dis = first_oct_dis;
+  p.speculative = speculative;
+  p.completed = !speculative;
+  p.generation = oct.generation_;
+  p.spec_epoch = oct.epoch_ + 1;
+  if (speculative) {
+    p.repair_flags = torch::empty({n_rays}, DevI32());
+    return;
+  }
+  IssueScanAndPack(p);
+}
+
+// The rays a stat update invalidated are walked and marched again (f2n_oct_intersect_repair / f2n_ray_march_repair: both
+// return at once on the device when no leaf died, the common case), then the tail of a GetSamples call.
+bool PersSampler::CompleteSpeculative(PendingSamples& p) {
+  TORCH_CHECK(p.active && p.speculative && !p.completed, "CompleteSpeculative: nothing to complete");
+  auto& oct = *pers_octree_;
+  if (p.generation != oct.generation_) return false;
+  void* st = CurStream();
+  const float far = 1e8f;
+  F2N_TIMED_CALL("oct_repair", f2n_oct_intersect_repair(st, p.n_rays, max_oct_intersect_per_ray_, oct.node_search_order_.data_ptr<uint8_t>(),
+                                 F32P(p.rays_o), F32P(p.rays_d), global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(p.oct_se),
+                                 I32P(p.oct_idx), F32P(p.oct_nf), I32P(p.totals), I32P(p.oct_tr), VoidP(oct.child_blocks_gpu_),
+                                 I32P(oct.died_at_), p.spec_epoch, I32P(oct.death_epoch_), I32P(p.repair_flags), I32P(oct.n_repaired_)));
+  F2N_TIMED_CALL("march_repair", f2n_ray_march_repair(st, p.n_rays, sample_l_, scale_by_dis_, F32P(p.rays_o), F32P(p.rays_d), F32P(p.noise),
+                                 I32P(p.oct_se), I32P(p.oct_idx), F32P(p.oct_nf), VoidP(oct.tree_nodes_gpu_), VoidP(oct.pers_trans_gpu_),
+                                 I32P(p.counts), nullptr, F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.first_oct_dis),
+                                 I32P(p.oct_tr), I32P(p.repair_flags), I32P(oct.death_epoch_), p.spec_epoch));
+  p.completed = true;
+  IssueScanAndPack(p);
+  return true;
+}
+
+void PersSampler::IssueScanAndPack(PendingSamples& p) {
+  auto& oct = *pers_octree_;
+  void* st = CurStream();
+  const int n_rays = p.n_rays;
+  const int64_t slots = p.s_dt.numel();
+  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1));
   // the single host read-back of a GetSamples call: through pinned memory and an event (no stream drain)
   Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-  totals_host.copy_(totals, /*non_blocking=*/true);
+  totals_host.copy_(p.totals, /*non_blocking=*/true);
   p.counts_ready.record();
   // The pack does not wait for the host to learn N: its outputs are sized for the worst case (every ray's slots full; pages
   // beyond the N rows actually written are never touched) and it is queued right behind the scan.  With the host in the
@@ -134,18 +188,14 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   p.o_dt = torch::empty({slots}, DevF32());
   p.o_t = torch::empty({slots}, DevF32());
   p.o_anchors = torch::empty({cap, 3}, DevI32());
-  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(pts_se), F32P(rays_o), F32P(rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
-                                    F32P(s_dt), F32P(s_t), I32P(s_anchors), F32P(p.o_pts) + 3 * (int64_t) extra, F32P(p.o_dirs),
+  F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
+                                    F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.o_pts) + 3 * (int64_t) extra, F32P(p.o_dirs),
                                     F32P(p.o_dt), F32P(p.o_t), I32P(p.o_anchors) + 3 * (int64_t) extra));
-  p.active = true;
-  p.n_rays = n_rays;
-  p.rays_o = rays_o; p.rays_d = rays_d; p.counts = counts; p.oct_se = oct_se; p.totals = totals; p.totals_host = totals_host;
-  p.oct_idx = oct_idx; p.oct_nf = oct_nf; p.oct_tr = oct_tr; p.noise = rays_noise; p.pts_se = pts_se; p.s_dt = s_dt; p.s_t = s_t;
-  p.s_anchors = s_anchors; p.first_oct_dis = first_oct_dis;
+  p.totals_host = totals_host;
 }
 
 SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
-  TORCH_CHECK(p.active, "FinishSamples without BeginSamples");
+  TORCH_CHECK(p.active && p.completed, "FinishSamples without (completed) BeginSamples");
   const int n_rays = p.n_rays;
   p.counts_ready.synchronize();
   const int n_all_oct = p.totals_host.data_ptr<int32_t>()[0];
@@ -238,9 +288,10 @@ void PersSampler::FinishOctUpdate() {
   void* st = CurStream();
   if (occupancy_sync_hook_) occupancy_sync_hook_(occ);
   Tensor adders = occ.slice(0, 0, 2), visit_mark = occ.select(0, 2);
-  F2N_TIMED_CALL("oct_update_stats",f2n_oct_update_stats(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
+  oct.epoch_++;  // (deaths of this update are stamped with it: speculative samplers repair against them)
+  F2N_TIMED_CALL("oct_update_stats", f2n_oct_update_stats_ex(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
                                 I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
-                                VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1));
+                                VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1, I32P(oct.died_at_), oct.epoch_, I32P(oct.death_epoch_)));
 
   while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610
     oct.ProcOctree(true, true, sub_div_milestones_.back() <= 0);

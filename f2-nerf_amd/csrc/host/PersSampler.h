@@ -54,6 +54,13 @@ class PersOctree {
   Tensor child_blocks_gpu_;  // [n_nodes][8] x 32 B, derived from tree_nodes_gpu_ (f2n_oct_build_child_blocks)
   Tensor tree_weight_stats_, tree_alpha_stats_, tree_visit_cnt_;
   Tensor occ_;  // [4, n_nodes] weight votes, alpha votes, visited marks, visit counts (tree_visit_cnt_ is its last row)
+  // Speculative sampling (f2n_abi.h, "Speculative sampling"): every stat update is an epoch; a leaf that dies in it is stamped
+  // (died_at_[node] = epoch, death_epoch_[0] = epoch).  generation_ counts the changes that invalidate node indices or
+  // revive / re-number leaves (ProcOctree, MarkInvisibleNodes, LoadStates, InstallOctree): samples marched speculatively
+  // against an older generation cannot be repaired and are dropped.
+  Tensor died_at_, death_epoch_, n_repaired_;
+  int epoch_ = 0;
+  int64_t generation_ = 0;
   Tensor node_search_order_;
   Tensor pers_trans_gpu_;
   Tensor edge_pool_gpu_;
@@ -73,13 +80,25 @@ struct PendingSamples {
   Tensor o_pts, o_dirs, o_dt, o_t, o_anchors;  // packed outputs, sized for the worst case (+ extra_rows), already being filled
   int extra_rows = 0;
   at::cuda::CUDAEvent counts_ready;
+  // speculative: intersection and march were issued BEFORE the stat update they would normally wait for; scan / count / pack
+  // are issued by CompleteSpeculative once that update is in the stream, behind the repair of the rays it invalidated
+  bool speculative = false, completed = true;
+  int spec_epoch = 0;          // first stat-update epoch whose deaths the speculative walk may have missed
+  int64_t generation = 0;      // PersOctree::generation_ the samples were marched against
+  Tensor repair_flags;
 };
 
 class PersSampler : public PtsSampler {
  public:
   explicit PersSampler(GlobalDataPool* global_data_pool);
   SampleResultFlex GetSamples(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) override;
-  void BeginSamples(const Tensor& rays_o, const Tensor& rays_d, float fineness, PendingSamples& p);
+  // speculative = true: stop after the march (no scan / count / pack); CompleteSpeculative issues the rest
+  void BeginSamples(const Tensor& rays_o, const Tensor& rays_d, float fineness, PendingSamples& p, bool speculative = false);
+  // Call with the stat update(s) since BeginSamples already in the current stream's order.  False: the tree was re-numbered
+  // since (generation mismatch): nothing was issued, the caller must sample again.
+  bool CompleteSpeculative(PendingSamples& p);
+  void IssueScanAndPack(PendingSamples& p);
+  bool MaintenanceDue() const;  // the NEXT FinishOctUpdate runs ProcOctree (milestone / compact_freq, PersSampler.cu:605-614)
   SampleResultFlex FinishSamples(PendingSamples& p);
   std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;
   void UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weights,

@@ -253,9 +253,47 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
   pending_rays_d_ = rays_d;
 }
 
+// Speculative variant of PreSampleBegin: intersection + march only, NOT ordered behind this step's stat update.
+void Renderer::PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream) {
+  if (!side_stream_)
+    side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+  octree_ready_ev_.block(*side_stream_);  // the PREVIOUS step's update (this batch's own sampling already waited for it)
+  if (after_main_stream) {  // this batch was sampled on the main stream: whatever touched the tree there comes first
+    spec_start_ev_.record();
+    spec_start_ev_.block(*side_stream_);
+  }
+  if (side_must_wait_consumed_) {
+    samples_consumed_ev_.block(*side_stream_);
+    side_must_wait_consumed_ = false;
+  }
+  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+  ps->extra_sample_rows_ = 2 * n_edge_pts_;
+  ps->BeginSamples(rays_o, rays_d, fineness, pending_samples_, /*speculative=*/true);
+  pending_rays_o_ = rays_o;
+  pending_rays_d_ = rays_d;
+}
+
+// ... and its completion, called with this step's stat update issued (octree_ready_ev_ recorded): repair, scan, count, pack.
+bool Renderer::PreSampleSpecComplete() {
+  TORCH_CHECK(pending_samples_.active && pending_samples_.speculative && !pending_samples_.completed, "no speculative sampling in flight");
+  octree_ready_ev_.block(*side_stream_);
+  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+  ps->extra_sample_rows_ = 2 * n_edge_pts_;
+  if (!ps->CompleteSpeculative(pending_samples_)) {
+    pending_samples_ = PendingSamples();  // (its kernels are ordered on the side stream, whose pool its buffers return to)
+    pending_rays_o_ = pending_rays_d_ = Tensor();
+    return false;
+  }
+  presample_done_ev_.record(*side_stream_);
+  return true;
+}
+
 // Second half: wait for the counts (by now the march has usually finished) and take views of the packed rows.  No launch.
 void Renderer::PreSampleFinish() {
   TORCH_CHECK(pending_samples_.active, "PreSampleFinish without PreSampleBegin");
+  if (!pending_samples_.completed && !PreSampleSpecComplete()) return;  // (a speculative batch whose step never reached its update)
   presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pending_samples_);
   has_presample_ = true;
   presample_async_ = true;
@@ -352,6 +390,17 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   }
   int n_all_pts = sample_result_.pts.size(0);
   last_n_all_pts_ = n_all_pts;
+  // The NEXT batch's intersection and march start now, on the side stream, against the octree as it stands (see Renderer.h):
+  // they run underneath this step's pre-pass instead of behind its stat update.
+  bool spec_begun = false;
+  if (train && async_count && dp_world_ <= 1 && speculative_sampling_ && next_batch_.valid && n_all_pts > 0 && !pending_samples_.active &&
+      !ps->MaintenanceDue()) {
+    PreSampleSpecBegin(next_batch_.rays_o, next_batch_.rays_d, next_batch_.fineness, /*after_main_stream=*/!consumed_side_samples_);
+    spec_begun = true;
+    n_speculative_++;
+  } else if (train && next_batch_.valid) {
+    n_spec_fallback_++;
+  }
   if (train) total_all_pts_ += n_all_pts;
   if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;
 
@@ -429,7 +478,11 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     const bool octree_first = train && async_count && dp_world_ <= 1;
     auto octree_update_issued = [&]() {
       octree_ready_ev_.record();  // everything the NEXT step's ray sampling depends on has been issued ...
-      if (after_octree_update_) {  // ... so a prefetching TrainStep starts that sampling now (draw order: bg + edge, noise)
+      if (spec_begun) {  // ... so the speculative sampling of the next batch is repaired and packed now
+        spec_begun = false;
+        if (PreSampleSpecComplete()) after_octree_update_ = nullptr;
+      }
+      if (after_octree_update_) {  // ... or a prefetching TrainStep starts that sampling now (draw order: bg + edge, noise)
         auto f = std::move(after_octree_update_);
         after_octree_update_ = nullptr;
         f();

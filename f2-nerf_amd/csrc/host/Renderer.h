@@ -85,6 +85,21 @@ class Renderer : public Pipe {
     pending_rays_o_ = pending_rays_d_ = Tensor();
   }
   std::function<void()> after_octree_update_;  // one-shot: called in SampleAndFilter right after the occupancy update
+  // Speculative sampling of the NEXT batch (streaming single-GPU steps): intersection and march are issued on the side stream
+  // as soon as THIS batch's samples are packed -- against the octree as it stands, underneath this step's pre-pass -- and
+  // repaired behind this step's stat update (PersSampler::CompleteSpeculative).  The sampler's two latency chains (~0.6 ms on
+  // a converged scene) then no longer sit between one step's stat update and the next step's pre-pass.  Not used in the
+  // iterations that run ProcOctree (node indices change: the batch is sampled after the update, as before).
+  struct NextBatch {
+    Tensor rays_o, rays_d;
+    float fineness = 1.f;
+    bool valid = false;
+  } next_batch_;
+  bool speculative_sampling_ = true;
+  int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
+  void PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream);
+  bool PreSampleSpecComplete();  // false: could not be repaired (tree re-numbered): dropped
+  at::cuda::CUDAEvent spec_start_ev_;
   PendingSamples pending_samples_;
   Tensor pending_rays_o_, pending_rays_d_;
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,

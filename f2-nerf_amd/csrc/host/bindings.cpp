@@ -258,6 +258,19 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_readwrite("iter_step", &ExpRunner::iter_step_)
       .def_readwrite("check_nan", &ExpRunner::check_nan_)
       .def_readwrite("async_counts", &ExpRunner::async_counts_)
+      .def_property("speculative_sampling", [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },
+                    [](ExpRunner& r, bool on) { r.renderer_->speculative_sampling_ = on; })
+      .def("speculation_counters",  // batches sampled ahead of the stat update / behind it, rays repaired after a leaf died
+           [](ExpRunner& r) {
+             r.FinishPending();
+             py::dict d;
+             d["speculative"] = r.renderer_->n_speculative_;
+             d["fallback"] = r.renderer_->n_spec_fallback_;
+             auto& o = *SamplerOf(r)->pers_octree_;
+             d["rays_repaired"] = o.n_repaired_.defined() ? o.n_repaired_.item<int>() : 0;
+             d["stat_updates"] = o.epoch_;
+             return d;
+           })
       .def("counters",  // running totals over training-mode steps; flushes (the last streaming step's count is still in flight)
            [](ExpRunner& r) {
              r.FinishPending();

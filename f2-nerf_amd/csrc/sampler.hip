@@ -39,6 +39,13 @@ __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const f
 // memory round trips per ray and 8x more waves in flight to hide them (measured 0.63 -> 0.09 ms for 8192 rays).
 // MODE 0: count only.  MODE 1: fill a compact, ray-ordered list (segments from f2n_segment_scan).
 // MODE 2: single pass into fixed-stride per-ray segments [ray*max_hits, ray*max_hits + cnt): no count pass, no scan.
+// MODE 3: REPAIR of a MODE-2 result that was computed SPECULATIVELY, i.e. while (or before) f2n_oct_update_stats_ex of epoch
+//         >= spec_epoch was killing leaves (trans_idx -> -1: the only thing a stat update changes in the tree, and it is
+//         monotone).  A ray's list is still the list of the updated tree unless it holds a node that died since: every leaf it
+//         accepted is then still alive, every leaf it skipped as dead still dead, and nothing else in the walk depends on
+//         trans_idx.  The 8 lanes of a ray scan its list for such nodes (died_at[node] >= spec_epoch); only flagged rays (and
+//         rays at the max_hits cap, whose truncation point may move) walk the tree again, overwriting their slots.  Whole
+//         launch exits at once when no leaf died at all (*death_epoch < spec_epoch: the common case).
 // ---------------------------------------------------------------------------------------------------
 #define F2N_COOP_RAYS_PER_BLOCK 32  // 256 threads
 // Parked siblings per ray.  A ray crosses at most 4 of a node's 8 children (three mid-planes), so behind the child that is
@@ -51,7 +58,11 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     const float* __restrict__ rays_d, float g_near, float g_far, const F2nTreeNode* __restrict__ nodes,
     const int32_t* __restrict__ oct_start_end, int32_t* __restrict__ hit_counts, int32_t* __restrict__ oct_idx,
     float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total,
-    int32_t* __restrict__ oct_trans, const F2nChildInfo* __restrict__ child_blocks) {
+    int32_t* __restrict__ oct_trans, const F2nChildInfo* __restrict__ child_blocks, const int32_t* __restrict__ died_at,
+    int spec_epoch, const int32_t* __restrict__ death_epoch, int32_t* __restrict__ repair_flags, int32_t* __restrict__ n_repaired) {
+  if (MODE == 3) {
+    if (*death_epoch < spec_epoch) return;  // no leaf died since the speculative walk: every list stands (grid-uniform)
+  }
   // Work stack of a ray: every hit sibling behind the first interior hit of an expanded node is parked here, nearest on
   // top -- interior nodes as (index >= 0), valid leaves as (~index, near, far, trans) to be emitted when popped.  A node
   // is therefore expanded exactly once (parking only a "remaining siblings" mask meant re-reading and re-testing all
@@ -72,7 +83,18 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     base = oct_start_end[2 * ray];
     limit = in_range ? oct_start_end[2 * ray + 1] - base : 0;
   }
-  if (MODE == 2) base = ray * max_hits;
+  if (MODE >= 2) base = ray * max_hits;
+  int old_cnt = 0;
+  bool redo = false;
+  if (MODE == 3) {
+    bool dead_hit = false;
+    if (in_range) {
+      old_cnt = se_out[2 * ray + 1] - se_out[2 * ray];
+      for (int e = k; e < old_cnt; e += 8) dead_hit |= died_at[oct_idx[base + e]] >= spec_epoch;
+    }
+    redo = in_range && ((((__ballot(dead_hit) >> shift) & 0xffull) != 0ull) || old_cnt >= max_hits);
+    if (!redo) limit = 0;
+  }
   const int octant = (int(d[0] > 0.f) << 2) | (int(d[1] > 0.f) << 1) | int(d[2] > 0.f);
   const int my_slot = search_order[octant * 8 + k];  // the child slot this lane tests at every node
 
@@ -203,16 +225,22 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
   }
   if (in_range && k == 0) {
     if (MODE == 0) hit_counts[ray] = cnt;
-    if (MODE == 2) {
+    if (MODE == 2 || (MODE == 3 && redo)) {
       se_out[2 * ray] = base;
       se_out[2 * ray + 1] = base + cnt;
     }
+    if (MODE == 3) repair_flags[ray] = redo ? 1 : 0;
   }
-  if (MODE == 2) {  // wave-level hit total, one atomic per wave
-    int s = (in_range && k == 0) ? cnt : 0;
+  if (MODE >= 2) {  // wave-level hit total, one atomic per wave (repair: the change of the total)
+    int s = (in_range && k == 0) ? (MODE == 3 ? (redo ? cnt - old_cnt : 0) : cnt) : 0;
+    int r = (MODE == 3 && in_range && k == 0 && redo) ? 1 : 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if ((tid & 63) == 0) atomicAdd(total, s);
+    for (int off = 32; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off);
+      if (MODE == 3) r += __shfl_xor(r, off);
+    }
+    if ((tid & 63) == 0 && s != 0) atomicAdd(total, s);
+    if (MODE == 3 && (tid & 63) == 0 && r != 0 && n_repaired != nullptr) atomicAdd(n_repaired, r);
   }
 }
 
@@ -307,7 +335,13 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
     const float* __restrict__ near_far_all, const F2nTreeNode* __restrict__ nodes, const F2nTransInfo* __restrict__ transes,
     const int32_t* __restrict__ pts_start_end, int32_t* __restrict__ pts_counts, float* __restrict__ pts,
     float* __restrict__ dirs, float* __restrict__ dts, float* __restrict__ ts, int32_t* __restrict__ anchors,
-    float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all) {
+    float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all, const int32_t* __restrict__ repair_flags,
+    const int32_t* __restrict__ death_epoch, int spec_epoch) {
+  if (MODE == 2 && repair_flags != nullptr) {  // repair of a speculative march: only the rays whose leaf list was redone
+    if (*death_epoch < spec_epoch) return;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (r >= n_rays || repair_flags[r] == 0) return;
+  }
   const int lane16 = threadIdx.x & 15, kq = lane16 & 3, quad = lane16 >> 2;
   const int grp = quad == 0 ? 0 : quad == 1 ? 2 : quad == 2 ? 3 : 1;  // Eigen group of this quad (see above)
   const int proj = 3 * grp + min(kq, 2);                               // lane 3 of a quad shadows projection 3g+2 (unused)
@@ -796,7 +830,8 @@ __global__ void early_stop_votes_kernel(int n_rays, int n_nodes, const int32_t* 
 __global__ void update_stats_kernel(int n_nodes, int32_t* __restrict__ w_adder, int32_t* __restrict__ a_adder,
                                     int32_t* __restrict__ mark, int32_t* __restrict__ w_stats,
                                     int32_t* __restrict__ a_stats, F2nTreeNode* __restrict__ nodes,
-                                    F2nChildInfo* __restrict__ child_blocks, int reset_votes) {
+                                    F2nChildInfo* __restrict__ child_blocks, int reset_votes, int32_t* __restrict__ died_at,
+                                    int epoch, int32_t* __restrict__ death_epoch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const int m = mark[i];
@@ -819,6 +854,10 @@ __global__ void update_stats_kernel(int n_nodes, int32_t* __restrict__ w_adder, 
   w_stats[i] = st[0];
   a_stats[i] = st[1];
   if (st[0] < 0 || st[1] < 0) {
+    if (died_at != nullptr && nodes[i].trans_idx >= 0) {  // alive until now: stamp the death for speculative samplers (MODE 3 above)
+      died_at[i] = epoch;
+      *death_epoch = epoch;  // (every writer of a launch stores the same value)
+    }
     nodes[i].trans_idx = -1;
     const int pa = nodes[i].parent;
     if (child_blocks != nullptr && pa >= 0) {  // the parent's copy of this node's record
@@ -980,7 +1019,7 @@ int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_
   hipLaunchKernelGGL(oct_intersect_coop_kernel<0>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
                      (const F2nTreeNode*) tree_nodes, nullptr, hit_counts, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     (const F2nChildInfo*) child_blocks);
+                     (const F2nChildInfo*) child_blocks, nullptr, 0, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -993,7 +1032,21 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
   hipLaunchKernelGGL(oct_intersect_coop_kernel<2>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
                      (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total, oct_trans,
-                     (const F2nChildInfo*) child_blocks);
+                     (const F2nChildInfo*) child_blocks, nullptr, 0, nullptr, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_oct_intersect_repair(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                             const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
+                             int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans, const void* child_blocks,
+                             const int32_t* died_at, int spec_epoch, const int32_t* death_epoch, int32_t* repair_flags,
+                             int32_t* n_repaired) {
+  if (n_rays < 0 || max_hits < 1 || died_at == nullptr || death_epoch == nullptr || repair_flags == nullptr) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(oct_intersect_coop_kernel<3>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
+                     (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
+                     (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total, oct_trans,
+                     (const F2nChildInfo*) child_blocks, died_at, spec_epoch, death_epoch, repair_flags, n_repaired);
   return f2n_launch_status();
 }
 
@@ -1012,7 +1065,7 @@ int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order
   hipLaunchKernelGGL(oct_intersect_coop_kernel<1>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
                      (hipStream_t) stream, n_rays, 0, search_order, rays_o, rays_d, near_, far_,
                      (const F2nTreeNode*) tree_nodes, oct_start_end, nullptr, oct_idx, oct_near_far, nullptr, nullptr, nullptr,
-                     (const F2nChildInfo*) child_blocks);
+                     (const F2nChildInfo*) child_blocks, nullptr, 0, nullptr, nullptr, nullptr);
   return f2n_launch_status();
 }
 
@@ -1024,7 +1077,7 @@ int f2n_ray_march_count(void* stream, int n_rays, float sample_l, int scale_by_d
   hipLaunchKernelGGL(ray_march_kernel<0>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   return f2n_launch_status();
 }
 
@@ -1038,7 +1091,7 @@ int f2n_ray_march_fill(void* stream, int n_rays, float sample_l, int scale_by_di
   hipLaunchKernelGGL(ray_march_kernel<1>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, pts_start_end, nullptr,
-                     pts, dirs, dt, t, anchors, first_oct_dis, nullptr);
+                     pts, dirs, dt, t, anchors, first_oct_dis, nullptr, nullptr, nullptr, 0);
   return f2n_launch_status();
 }
 
@@ -1051,7 +1104,21 @@ int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by
   hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
-                     nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans);
+                     nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, nullptr, nullptr, 0);
+  return f2n_launch_status();
+}
+
+int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o, const float* rays_d,
+                         const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx, const float* oct_near_far,
+                         const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts, float* s_dt, float* s_t,
+                         int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans, const int32_t* repair_flags,
+                         const int32_t* death_epoch, int spec_epoch) {
+  if (n_rays < 0 || repair_flags == nullptr || death_epoch == nullptr) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
+                     (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
+                     oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
+                     nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, repair_flags, death_epoch, spec_epoch);
   return f2n_launch_status();
 }
 
@@ -1120,10 +1187,18 @@ int f2n_early_stop_votes(void* stream, int n_rays, const int32_t* pts_start_end,
 
 int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
                          int32_t* a_stats, void* tree_nodes, void* child_blocks, int reset_votes) {
-  if (n_nodes < 0) return F2N_ERR_INVALID_ARG;
+  return f2n_oct_update_stats_ex(stream, n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes, child_blocks, reset_votes,
+                                 nullptr, 0, nullptr);
+}
+
+int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
+                            int32_t* a_stats, void* tree_nodes, void* child_blocks, int reset_votes, int32_t* died_at, int epoch,
+                            int32_t* death_epoch) {
+  if (n_nodes < 0 || (died_at != nullptr) != (death_epoch != nullptr)) return F2N_ERR_INVALID_ARG;
   if (n_nodes == 0) return F2N_OK;
   hipLaunchKernelGGL(update_stats_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, n_nodes,
-                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks, reset_votes);
+                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks, reset_votes,
+                     died_at, epoch, death_epoch);
   return f2n_launch_status();
 }
 

@@ -175,6 +175,37 @@ int f2n_oct_mark_visit(void* stream, int n_rays, int n_nodes, const int32_t* pts
 int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
                          int32_t* a_stats, void* tree_nodes, void* child_blocks /*or NULL*/, int reset_votes);
 
+/* ---- Speculative sampling (ABI v8) -------------------------------------------------------------------------------------
+ * The reference samples a batch AFTER the previous iteration's UpdateOctNodes (ExpRunner.cpp:88-93 -> Renderer.cpp:100 ->
+ * PersSampler.cu:317, behind :536-615 of the iteration before): intersection and march of batch k+1 wait for the density
+ * pre-pass of batch k.  Outside the ProcOctree iterations the only thing that update changes in the tree is trans_idx -> -1 of
+ * the leaves that die (MarkInvalidNodes, :528-534), so batch k+1 can be sampled EARLY, against the tree as it stands, and
+ * repaired afterwards: a ray whose leaf list holds no node that died since is already exact (see oct_intersect_coop_kernel
+ * MODE 3 in csrc/sampler.hip for the argument), the others are walked and marched again into their fixed-stride slots.
+ *   f2n_oct_update_stats_ex   as f2n_oct_update_stats; a leaf that dies in this call gets died_at[node] = epoch and
+ *                             death_epoch[0] = epoch (both or neither may be NULL; epochs must increase from call to call)
+ *   f2n_oct_intersect_repair  on the outputs of f2n_oct_intersect_strided computed while / before the updates of epochs
+ *                             >= spec_epoch ran: rays whose list holds a node with died_at >= spec_epoch (or is at the
+ *                             max_hits cap) are walked again on the updated tree, total[0] is adjusted, repair_flags[r] = 1 for
+ *                             those rays and 0 for all others, n_repaired[0] (or NULL) += their number.  Returns immediately on
+ *                             the device when death_epoch[0] < spec_epoch (then repair_flags is NOT written).
+ *   f2n_ray_march_repair      f2n_ray_march_strided for the flagged rays only (same early exit).
+ * After both, slots / counts / first_oct_dis are bit-identical to a fresh f2n_oct_intersect_strided + f2n_ray_march_strided on
+ * the updated tree (tests/test_gpu_parity.py::test_speculative_sampling_repair). */
+int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
+                            int32_t* a_stats, void* tree_nodes, void* child_blocks /*or NULL*/, int reset_votes,
+                            int32_t* died_at /*[n_nodes] or NULL*/, int epoch, int32_t* death_epoch /*[1] or NULL*/);
+int f2n_oct_intersect_repair(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                             const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
+                             int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans, const void* child_blocks,
+                             const int32_t* died_at, int spec_epoch, const int32_t* death_epoch, int32_t* repair_flags /*[R]*/,
+                             int32_t* n_repaired /*[1] or NULL*/);
+int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_dis, const float* rays_o, const float* rays_d,
+                         const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx, const float* oct_near_far,
+                         const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts, float* s_dt, float* s_t,
+                         int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans, const int32_t* repair_flags,
+                         const int32_t* death_epoch, int spec_epoch);
+
 /* MarkInvisibleNodesKernel (PersSampler.cu:618-680). */
 int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris /*[C,3,3]*/,
                            const float* w2cs /*[C,3,4]*/, const float* bounds /*[C,2]*/);

@@ -98,7 +98,7 @@ def test_balanced_gather_is_bit_identical_on_the_converged_batch(hip, fox_state,
     st = fox_state
     pts, anchors = converged_march[fineness]
     n = len(pts)
-    assert n > 2e5 and n % 256 != 0  # a ragged last tile
+    assert n > 1e5 and n % 256 != 0  # a ragged last tile (5.5e5 samples at fineness 1, 1.3e5 at fineness 4)
     rng = np.random.default_rng(19)
     grid = op.HashGrid(rng.standard_normal((16 << 19, 2)).astype(F32) * F32(0.3), st["prim_pool"], st["bias_pool"], int(st["n_volumes"]), 19)
     step01 = (1. / 256.) * 1.25 * fineness * .5  # what Hash3DAnchored::QueryDensityPreAct hands the launcher
@@ -178,7 +178,9 @@ def _check_iteration(runner, rt, d, ref, gt, R, streaming, rgb_tol=1e-3, grad_to
     for k in ("color_mlp", "field_mlp", "app_emb"):
         if rg[k] is None:
             continue
-        assert rel_err(g[k], rg[k]) <= grad_tol, (k, rel_err(g[k], rg[k]))
+        # (both sides deliver the gradient as the reference's autograd does: rounded to f16 AFTER the division by the loss scale --
+        # where a whole batch's gradient is ~1e-6, as on the 360 rig, one f16 subnormal step, 2^-24, is 5 % of the largest entry)
+        assert np.abs(g[k] - rg[k]).max() <= grad_tol * np.abs(rg[k]).max() + 1.01 * 2.0 ** -24, (k, rel_err(g[k], rg[k]))
     a, b = g["feat_pool"].reshape(-1).astype(np.float64), rg["feat_pool"].reshape(-1).astype(np.float64)
     cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
     assert cos > 0.999, cos

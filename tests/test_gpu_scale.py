@@ -474,12 +474,13 @@ def test_training_trajectory_across_milestone_and_compaction(rt, fox_state, real
 
 
 def test_training_trajectory_at_the_benched_size(rt, fox_state):
-    """12 iterations at BASELINE config 2's size -- 8192 rays, 2^19 x 16 table, 8192 edge samples, ~7e5 samples per iteration
+    """6 iterations at BASELINE config 2's size -- 8192 rays, 2^19 x 16 table, 8192 edge samples, ~7e5 samples per iteration
     (the partitioned gather, the owner-binned scatter, the table Adam over 17 * 2^19 halves) -- across a subdivision milestone
-    (iteration 6) and compactions (every 4), oracle not re-aligned."""
-    ITERS = 12
-    overrides = ["pts_sampler.sub_div_milestones=[6]", "pts_sampler.compact_freq=4", "train.learning_rate_warm_up_end_iter=20"]
-    m = run_trajectory(rt, fox_state, 8192, 8192, ITERS, overrides, False, {5, 11}, seed=123, tag="TRAJ_BENCH_SIZE")
+    (iteration 3) and compactions (every 2), oracle not re-aligned.  (12 iterations ran the same way in round 3: no fork, RGB
+    1.5e-4, table cosine 1.0000; the oracle costs ~16 s per iteration at this size.)"""
+    ITERS = 6
+    overrides = ["pts_sampler.sub_div_milestones=[3]", "pts_sampler.compact_freq=2", "train.learning_rate_warm_up_end_iter=20"]
+    m = run_trajectory(rt, fox_state, 8192, 8192, ITERS, overrides, False, {2, 5}, seed=123, tag="TRAJ_BENCH_SIZE")
     assert len(m["n_nodes_seen"]) >= 2 and 897 not in m["n_nodes_seen"], m["n_nodes_seen"]
     assert m["table_cos"] > 0.999, m["table_cos"]
     for dlt in (m["field_dl"], m["color_dl"]):
@@ -611,3 +612,149 @@ def test_big_table_preset_trains_at_log2_22(rt, fox_state):
     assert np.isfinite(mse).all() and min(mse[-5:]) < 0.8 * mse[0], (mse[0], mse[-5:])
     tab = runner.states()[4]
     assert tab.shape[0] == 16 << 22 and torch.isfinite(tab).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# speculative sampling: sample early, repair behind the stat update
+# ---------------------------------------------------------------------------------------------------
+def _strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n, max_hits=1024):
+    """f2n_oct_intersect_strided + f2n_ray_march_strided into fresh buffers (device tensors kept)."""
+    b = dict(se=torch.zeros((n, 2), dtype=torch.int32, device=DEV), oi=torch.zeros(n * max_hits, dtype=torch.int32, device=DEV),
+             nf=torch.zeros((n * max_hits, 2), device=DEV), otr=torch.zeros(n * max_hits, dtype=torch.int32, device=DEV),
+             tot=torch.zeros(1, dtype=torch.int32, device=DEV), cnt=torch.zeros(n, dtype=torch.int32, device=DEV),
+             s_dt=torch.zeros(n * 1024, device=DEV), s_t=torch.zeros(n * 1024, device=DEV),
+             s_an=torch.zeros((n * 1024, 2), dtype=torch.int32, device=DEV), fod=torch.zeros(n, device=DEV))
+    hip.oct_intersect_strided(n, max_hits, so, ro, rd, 0.01, 1e8, tn, b["se"], b["oi"], b["nf"], b["tot"], b["otr"], cb)
+    hip.ray_march_strided(n, 1. / 256., True, ro, rd, nz, b["se"], b["oi"], b["nf"], tn, tr, b["cnt"], None, b["s_dt"], b["s_t"],
+                          b["s_an"], b["fod"], b["otr"])
+    return b
+
+
+def _filled_prefixes(b, n, max_hits=1024):
+    """The defined part of a strided sampling result as flat arrays (slots beyond a ray's count are scratch)."""
+    se, cnt = N(b["se"]), N(b["cnt"])
+    k = se[:, 1] - se[:, 0]
+    ray_k = np.repeat(np.arange(n), k)
+    flat_k = ray_k * max_hits + (np.arange(len(ray_k)) - np.repeat(np.cumsum(k) - k, k))
+    ray_s = np.repeat(np.arange(n), cnt)
+    flat_s = ray_s * 1024 + (np.arange(len(ray_s)) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    return dict(se=se, cnt=cnt, oi=N(b["oi"])[flat_k], nf=N(b["nf"])[flat_k], otr=N(b["otr"])[flat_k], s_dt=N(b["s_dt"])[flat_s],
+                s_t=N(b["s_t"])[flat_s], s_an=N(b["s_an"])[flat_s], fod=N(b["fod"]), tot=N(b["tot"]))
+
+
+@pytest.mark.parametrize("kill_frac", [0.02, 0.0005])
+def test_speculative_sampling_repair(hip, kill_frac):
+    """f2n_oct_intersect_repair / f2n_ray_march_repair (include/f2n_abi.h, "Speculative sampling"): a batch sampled BEFORE a stat
+    update killed leaves, then repaired, equals -- slot for slot, count for count -- the same batch sampled AFTER the update.
+    Converged 148 k-node octree, its real 13 056-ray batch; the update kills 2 % / 0.05 % of the valid leaves."""
+    z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
+    n = z["rays_o"].shape[0]
+    rd_np = oc.normalize_dirs(z["rays_d"])
+    rng = np.random.default_rng(7)
+    noise = (((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(1.)).astype(F32)
+    tn, tr, so = T(z["tree_nodes"].copy()), T(z["pers_trans"]), T(z["search_order"])
+    ro, rd, nz = T(z["rays_o"]), T(rd_np), T(noise)
+    n_nodes = z["tree_nodes"].size // 64
+    cb = torch.zeros(n_nodes * 8 * 32, dtype=torch.uint8, device=DEV)
+    hip.oct_build_child_blocks(n_nodes, tn, cb)
+    spec = _strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n)  # the speculative result: the tree before the update
+    before = _filled_prefixes(spec, n)
+    # the stat update: the victims were visited, got no positive vote and stand at 0 -> -1 -> dead (PersSampler.cu:579-603)
+    nodes = z["tree_nodes"].view(octc.NODE_DT)
+    valid = np.nonzero((nodes["trans_idx"] >= 0) & (nodes["childs"] < 0).all(1))[0]
+    hit_leaves = np.unique(before["oi"])
+    victims = rng.choice(hit_leaves, max(1, int(len(hit_leaves) * kill_frac)), replace=False)  # leaves this batch crosses
+    assert np.isin(victims, valid).all()
+    w_stats = np.full(n_nodes, 1000, np.int32); a_stats = np.full(n_nodes, 1000, np.int32)
+    w_stats[victims] = 0
+    mark = np.zeros(n_nodes, np.int32); mark[victims] = 1
+    adders = np.full((2, n_nodes), -1, np.int32)
+    died_at = torch.zeros(n_nodes, dtype=torch.int32, device=DEV)
+    death_epoch = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d_add, d_mark, d_w, d_a = T(adders), T(mark), T(w_stats), T(a_stats)
+    EPOCH = 5
+    hip.oct_update_stats_ex(n_nodes, d_add[0], d_add[1], d_mark, d_w, d_a, tn, cb, True, died_at, EPOCH, death_epoch)
+    assert int(death_epoch.item()) == EPOCH
+    got_died = np.nonzero(N(died_at) == EPOCH)[0]
+    assert (np.sort(got_died) == np.sort(victims)).all()
+    assert (N(tn).view(octc.NODE_DT)["trans_idx"][victims] == -1).all()
+    # a second update of a later epoch in which nothing dies leaves the stamps alone
+    hip.oct_update_stats_ex(n_nodes, d_add[0], d_add[1], d_mark, d_w, d_a, tn, cb, True, died_at, EPOCH + 1, death_epoch)
+    assert int(death_epoch.item()) == EPOCH and (N(died_at) == EPOCH).sum() == len(victims)
+    # repair asked for a LATER epoch than any death: returns on the device without touching anything
+    flags = torch.full((n,), 7, dtype=torch.int32, device=DEV)
+    n_rep = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.oct_intersect_repair(n, 1024, so, ro, rd, 0.01, 1e8, tn, spec["se"], spec["oi"], spec["nf"], spec["tot"], spec["otr"], cb, died_at,
+                             EPOCH + 1, death_epoch, flags, n_rep)
+    hip.ray_march_repair(n, 1. / 256., True, ro, rd, nz, spec["se"], spec["oi"], spec["nf"], tn, tr, spec["cnt"], None, spec["s_dt"],
+                         spec["s_t"], spec["s_an"], spec["fod"], spec["otr"], flags, death_epoch, EPOCH + 1)
+    assert (N(flags) == 7).all() and int(n_rep.item()) == 0
+    untouched = _filled_prefixes(spec, n)
+    for k in before:
+        assert same_bits(untouched[k], before[k]), k
+    # the real repair
+    hip.oct_intersect_repair(n, 1024, so, ro, rd, 0.01, 1e8, tn, spec["se"], spec["oi"], spec["nf"], spec["tot"], spec["otr"], cb, died_at,
+                             EPOCH, death_epoch, flags, n_rep)
+    hip.ray_march_repair(n, 1. / 256., True, ro, rd, nz, spec["se"], spec["oi"], spec["nf"], tn, tr, spec["cnt"], None, spec["s_dt"],
+                         spec["s_t"], spec["s_an"], spec["fod"], spec["otr"], flags, death_epoch, EPOCH)
+    repaired = _filled_prefixes(spec, n)
+    fresh = _filled_prefixes(_strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n), n)  # the batch sampled after the update
+    for k in fresh:
+        assert same_bits(repaired[k], fresh[k]), k
+    fl = N(flags)
+    assert set(np.unique(fl)) <= {0, 1} and int(n_rep.item()) == int(fl.sum())
+    # exactly the rays whose speculative list held a victim were walked again
+    k_per_ray = before["se"][:, 1] - before["se"][:, 0]
+    ray_of = np.repeat(np.arange(n), k_per_ray)
+    want = np.zeros(n, np.int32)
+    want[np.unique(ray_of[np.isin(before["oi"], victims)])] = 1
+    assert (fl == want).all() and 0 < fl.sum() < n
+    assert not same_bits(before["cnt"], fresh["cnt"])  # (the deaths did change the batch)
+    # against the CPU oracle on the updated tree
+    ref_hits = oc.oct_intersect(z["search_order"], z["rays_o"], rd_np, 0.01, 1e8, N(tn), 1024)
+    assert same_bits(repaired["oi"], ref_hits[1]) and same_bits(repaired["nf"], ref_hits[2])
+
+
+def test_speculative_training_equals_sampling_after_the_update(rt, fox_state):
+    """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
+    against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
+    statistics identical.  Learning rate 0 keeps the weights -- and so both runs -- deterministic, while the statistics start
+    at 2 so that leaves die (and rays are repaired) in most steps; a compaction and a subdivision fall inside the run."""
+    st = fox_state
+    overrides = ["field.log2_table_size=14", "train.learning_rate=0.0", "pts_sampler.sub_div_milestones=[9]", "pts_sampler.compact_freq=6"]
+    R, NE, ITERS = 1024, 512, 16
+    rng0 = np.random.default_rng(31)
+    batches = []
+    for _ in range(ITERS + 1):
+        ro, rd, bounds, cam = fox_batch(st, rng0, R)
+        batches.append(rt.to_dev(ro, rd, bounds, rng0.random((R, 3), dtype=F32), cam))
+    logs = {}
+    for spec in (True, False):
+        runner, cfg, _ = rt.make_runner(st, "wanjinyou", overrides, seed=5, table_init=0.3)
+        runner.n_edge_pts = NE
+        runner.speculative_sampling = spec
+        for t in runner.occupancy_buffers()[:2]:
+            t.fill_(2)
+        torch.manual_seed(11)  # the same noise / background / edge draws in both runs
+        log = []
+        for it in range(ITERS):
+            b, nb = batches[it], batches[it + 1]
+            s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+            runner.flush()
+            w, a, v = [N(t).copy() for t in runner.occupancy_buffers()]
+            log.append(dict(n_samples=s["n_samples"], kept=runner.counters()["total_meaningful"], nodes=N(runner.tree_nodes()).copy(),
+                            w=w, a=a, v=v, loss=float(s["loss"])))
+        logs[spec] = (log, runner.speculation_counters())
+    (la, ca), (lb, cb_) = logs[True], logs[False]
+    print("SPEC_COUNTERS on %s | off %s" % (ca, cb_))
+    assert ca["speculative"] >= ITERS - 6 and ca["rays_repaired"] > 0, ca   # most steps speculated, and deaths did invalidate rays
+    assert cb_["speculative"] == 0 and cb_["rays_repaired"] == 0, cb_
+    n_nodes = set()
+    for it in range(ITERS):
+        x, y = la[it], lb[it]
+        assert x["n_samples"] == y["n_samples"] and x["kept"] == y["kept"], (it, x["n_samples"], y["n_samples"], x["kept"], y["kept"])
+        assert x["nodes"].shape == y["nodes"].shape and (x["nodes"] == y["nodes"]).all(), it
+        assert (x["w"] == y["w"]).all() and (x["a"] == y["a"]).all() and (x["v"] == y["v"]).all(), it
+        assert abs(x["loss"] - y["loss"]) <= 1e-6 * max(1.0, abs(y["loss"])), (it, x["loss"], y["loss"])
+        n_nodes.add(x["nodes"].size // 64)
+    assert len(n_nodes) >= 3, n_nodes  # compaction and subdivision happened inside the run
