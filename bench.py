@@ -75,8 +75,8 @@ def converged_leg(args, st, dev):
     sc, images = fox_data.scene(args.factor)
     ds = runtime.make_dataset(sc, images)
     runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022, device=dev)
-    if args.no_speculation:
-        runner.speculative_sampling = False
+    if args.speculation:
+        runner.speculative_sampling = True
     torch.manual_seed(2022)
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
@@ -173,8 +173,9 @@ def main():
     ap.add_argument("--factor", type=int, default=2, choices=[2, 8], help="image resolution of the converged leg (dataset.factor)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     ap.add_argument("--marker-pause", action="store_true", help="sleep 0.3 s before the timed region (marker for profiles/timeline_rocpd.py)")
-    ap.add_argument("--no-speculation", action="store_true", help="A/B: sample the next batch behind the stat update (round-2 order) "
-                    "instead of speculatively ahead of it")
+    ap.add_argument("--speculation", action="store_true", help="A/B: sample the next batch speculatively AHEAD of the stat update and "
+                    "repair it behind it (Renderer::PreSampleSpecBegin; measured slower in the converged regime: "
+                    "profiles/r03_speculation_experiments.txt) instead of behind the update")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
@@ -219,8 +220,8 @@ def main():
     log2 = int(cfg["field"]["log2_table_size"])
     if args.diag_no_nan_check:
         runner.check_nan = False
-    if args.no_speculation:
-        runner.speculative_sampling = False
+    if args.speculation:
+        runner.speculative_sampling = True
 
     if dp:
         from f2_nerf_amd import parallel

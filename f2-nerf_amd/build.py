@@ -15,8 +15,22 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-LIB = os.path.join(HERE, "libf2n_hip.so")
 OBJ = os.path.join(HERE, "build")
+
+# Two builds of the same sources (include/f2n_abi.h: f2n_numerics_mode):
+#   ""        the product: libf2n_hip.so + _f2n_host*.so
+#   "refnum"  -DF2N_REFERENCE_NUMERICS=1: libf2n_hip_refnum.so + _f2n_host_refnum*.so -- the reference's per-addend f16 hash
+#             gradient atomics and an f16 MLP forward accumulator, for A/B trainings (bench.py psnr_numerics_ab).  A process
+#             picks it with F2N_REFERENCE_NUMERICS=1 in its environment BEFORE the package is imported (one numerics per process).
+VARIANT = "refnum" if os.environ.get("F2N_REFERENCE_NUMERICS", "0") not in ("", "0") else ""
+
+
+def lib_path(variant=None):
+    v = VARIANT if variant is None else variant
+    return os.path.join(HERE, "libf2n_hip%s.so" % ("_" + v if v else ""))
+
+
+LIB = lib_path()
 
 HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip", "workspace.hip", "dataset.hip", "octree.hip"]
 HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", "rows_dev.h", os.path.join(INCLUDE, "f2n_abi.h")]
@@ -37,17 +51,20 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, variant=None):
+    variant = VARIANT if variant is None else variant
+    lib = lib_path(variant)
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
     jobs = []
     objs = []
+    defs = ["-DF2N_REFERENCE_NUMERICS=1"] if variant == "refnum" else []
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, src.replace(".hip", (".%s.o" % variant) if variant else ".o"))
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([_hipcc()] + HIPCC_FLAGS + ["-c", s, "-o", o])
+            jobs.append([_hipcc()] + HIPCC_FLAGS + defs + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -61,17 +78,18 @@ def build_hip(force=False, verbose=False):
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn[-3000:])
-    if force or jobs or not os.path.exists(LIB):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
-    return LIB
+    if force or jobs or _newer(lib, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
 
 
-def host_module_path():
+def host_module_path(variant=None):
     import sysconfig
-    return os.path.join(HERE, "_f2n_host" + sysconfig.get_config_var("EXT_SUFFIX"))
+    v = VARIANT if variant is None else variant
+    return os.path.join(HERE, "_f2n_host" + ("_" + v if v else "") + sysconfig.get_config_var("EXT_SUFFIX"))
 
 
-def build_host(force=False, verbose=False):
+def build_host(force=False, verbose=False, variant=None):
     """C++/LibTorch host layer as a pybind11 extension, compiled with g++ against the pip wheel's headers."""
     import sysconfig
     import torch
@@ -79,7 +97,8 @@ def build_host(force=False, verbose=False):
     host_dir = os.path.join(CSRC, "host")
     srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp"))
     hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")] + [os.path.join(INCLUDE, "f2n_abi.h")]
-    out = host_module_path()
+    variant = VARIANT if variant is None else variant
+    out = host_module_path(variant)  # (the same objects; only the kernel library it is linked against differs)
     os.makedirs(OBJ, exist_ok=True)
     inc = ["-I" + p for p in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I" + INCLUDE,
                                                       "-I/opt/rocm/include"]
@@ -102,21 +121,25 @@ def build_host(force=False, verbose=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or not os.path.exists(out):
+    if force or jobs or _newer(out, objs + [lib_path(variant)]):
         libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
         link = ["g++", "-shared"] + objs + ["-o", out, "-L" + libdir, "-L" + HERE, "-Wl,-rpath," + libdir,
-                                            "-Wl,-rpath,$ORIGIN", "-lf2n_hip", "-lrccl", "-lc10", "-ltorch_cpu", "-ltorch",
+                                            "-Wl,-rpath,$ORIGIN", "-lf2n_hip" + ("_" + variant if variant else ""), "-lrccl", "-lc10", "-ltorch_cpu", "-ltorch",
                                             "-ltorch_python", "-lc10_hip", "-ltorch_hip"]
         run(link)
     return out
 
 
-def build_all(force=False, verbose=False):
-    lib = build_hip(force, verbose)
-    host = None
-    if os.path.isdir(os.path.join(CSRC, "host")):
-        host = build_host(force, verbose)
-    return lib, host
+def build_all(force=False, verbose=False, variants=("", "refnum")):
+    """Builds every variant; returns the paths of the one this process uses (VARIANT)."""
+    out = {}
+    for v in variants:
+        lib = build_hip(force, verbose, v)
+        host = None
+        if os.path.isdir(os.path.join(CSRC, "host")):
+            host = build_host(force, verbose, v)
+        out[v] = (lib, host)
+    return out.get(VARIANT, out[variants[0]])
 
 
 if __name__ == "__main__":

@@ -364,7 +364,19 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
     F2nCell cell;
     f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
     float v[16];
+#if F2N_REFERENCE_NUMERICS
+    // The reference's arithmetic, addend by addend (Hash3DAnchored.cu:145-153): every (sample, corner) product is rounded to
+    // f16 on its own and added by its own packed-f16 atomic, i.e. the running sums are f16 and their order is the order of
+    // arrival.  (The product build sums runs of equal cells in fp32 first: fewer roundings, no order dependence.)
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      v[2 * d] = g0 * cell.w[d];
+      v[2 * d + 1] = g1 * cell.w[d];
+    }
+    if (g0 != 0.f || g1 != 0.f) {
+#else
     if (f2n_combine_runs(cell, vol, c, g0, g1, v)) {
+#endif
       half2_t* base = (half2_t*) (grad_table + lt.base[l]);
 #pragma unroll
       for (int d = 0; d < 8; d++) {
@@ -906,6 +918,7 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
 // The binned path needs the reference's table layout -- local_idx[l] = l * E halves, local_size[l] = E entries with E a
 // power of two -- and whole 4096-entry slices per half level.
 static inline bool f2n_use_bins(int n, int level_entries) {
+  if (F2N_REFERENCE_NUMERICS) return false;  // per-addend f16 atomics in arrival order, as the reference (f2n_scatter_frag)
   return n >= F2N_BIN_MIN_N && n <= F2N_BIN_NB * (F2N_BIN_MAX_CHUNK - 256) && level_entries >= 2 * F2N_BIN_ENTRIES && (level_entries & (level_entries - 1)) == 0 &&
          (level_entries >> F2N_BIN_SHIFT) <= F2N_BIN_MAX_BINS;
 }

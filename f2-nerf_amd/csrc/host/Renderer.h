@@ -90,12 +90,17 @@ class Renderer : public Pipe {
   // repaired behind this step's stat update (PersSampler::CompleteSpeculative).  The sampler's two latency chains (~0.6 ms on
   // a converged scene) then no longer sit between one step's stat update and the next step's pre-pass.  Not used in the
   // iterations that run ProcOctree (node indices change: the batch is sampled after the update, as before).
+  // MEASURED (profiles/r03_speculation_experiments.txt): it takes the chains off the cycle, and the step does not get shorter --
+  // fresh scene 1.262 -> 1.247 ms, converged scene 0.903 -> 0.934 ms, 20 000 iterations 17.8 -> 19.6 s.  The compute queue is as
+  // long as the cycle was (both ~0.9 ms under mutual contention), and the repair -- whose duration is the re-walk and re-march
+  // of the LONGEST invalidated ray, ~85 us per converged step in which a leaf died, i.e. most of them -- now sits on the
+  // cycle instead.  Hence OFF by default; kept (and parity-tested) as an option.
   struct NextBatch {
     Tensor rays_o, rays_d;
     float fineness = 1.f;
     bool valid = false;
   } next_batch_;
-  bool speculative_sampling_ = true;
+  bool speculative_sampling_ = false;
   int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
   void PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream);
   bool PreSampleSpecComplete();  // false: could not be repaired (tree re-numbered): dropped

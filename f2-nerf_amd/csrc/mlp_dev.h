@@ -34,6 +34,42 @@ __device__ __forceinline__ float4_t f2n_mfma(half8_t a, half8_t b, float4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// ---- the accumulator of the forward contractions --------------------------------------------------------------------------
+// tiny-cuda-nn is not in the reference tree, so the accumulator type of its FullyFusedMLP forward cannot be pinned (DESIGN.md
+// section 6).  The product build accumulates in fp32 (what the MFMA does).  A build with -DF2N_REFERENCE_NUMERICS=1 (the
+// `refnum` variant of f2-nerf_amd/build.py: libf2n_hip_refnum.so) takes the OTHER plausible reading, the oracle's accumulator
+// mode 1 (oracle/f2n_oracle.c: or_mlp_dot): a binary16 accumulator fragment of m16n16k16 tiles -- the 16 products of a k-block
+// are summed in fp32 (one v_mfma_f32_16x16x16_f16 into a zero accumulator) and the running sum is rounded to f16 after every
+// block.  It exists to A/B whole trainings (bench.py: psnr_numerics_ab), not to be fast.
+#ifndef F2N_REFERENCE_NUMERICS
+#define F2N_REFERENCE_NUMERICS 0
+#endif
+__device__ __forceinline__ float4_t f2n_round_h4(float4_t v) {
+  float4_t r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r[i] = (float) (half_t) v[i];
+  return r;
+}
+// acc + sum over the 32-wide K-block the two fragments hold (forward / activation-recompute contractions only)
+__device__ __forceinline__ float4_t f2n_mfma_fwd(half8_t a, half8_t b, float4_t acc) {
+#if F2N_REFERENCE_NUMERICS
+  const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  // slots e = 0..3 of a fragment are k = 4g..4g+3 of the block's first 16 columns, e = 4..7 those of its second 16
+  const half4_t a0 = __builtin_shufflevector(a, a, 0, 1, 2, 3), a1 = __builtin_shufflevector(a, a, 4, 5, 6, 7);
+  const half4_t b0 = __builtin_shufflevector(b, b, 0, 1, 2, 3), b1 = __builtin_shufflevector(b, b, 4, 5, 6, 7);
+  float4_t blk = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, z, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; i++) acc[i] = acc[i] + blk[i];
+  acc = f2n_round_h4(acc);
+  blk = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, z, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; i++) acc[i] = acc[i] + blk[i];
+  return f2n_round_h4(acc);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ half8_t f2n_cat(half4_t lo, half4_t hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -117,19 +153,19 @@ struct F2nMlpFwdW {
     const float4_t z = {0.f, 0.f, 0.f, 0.f};
     float4_t t[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = f2n_mfma(w0[i], xf, z);
+    for (int i = 0; i < 4; i++) t[i] = f2n_mfma_fwd(w0[i], xf, z);
     half8_t h0 = f2n_pack<true>(t[0], t[1]), h1 = f2n_pack<true>(t[2], t[3]);
     if (NH == 2) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        t[i] = f2n_mfma(w1[i * 2], h0, z);
-        t[i] = f2n_mfma(w1[i * 2 + 1], h1, t[i]);
+        t[i] = f2n_mfma_fwd(w1[i * 2], h0, z);
+        t[i] = f2n_mfma_fwd(w1[i * 2 + 1], h1, t[i]);
       }
       h0 = f2n_pack<true>(t[0], t[1]);
       h1 = f2n_pack<true>(t[2], t[3]);
     }
-    float4_t o = f2n_mfma(wo[0], h0, z);
-    return f2n_mfma(wo[1], h1, o);
+    float4_t o = f2n_mfma_fwd(wo[0], h0, z);
+    return f2n_mfma_fwd(wo[1], h1, o);
   }
 };
 
@@ -231,13 +267,13 @@ __device__ __forceinline__ void f2n_mlp_half_bwd(const F2nMlpLds<NH>& s, half8_t
   // ---- sample-column orientation: recompute pre-activations, then the hidden-gradient chain ----
   float4_t t0[4], t1[4];
 #pragma unroll
-  for (int t = 0; t < 4; t++) t0[t] = f2n_mfma(f2n_rowfrag(s.w0, F2N_LD32, 16 * t + c, 0, g), xf, z);
+  for (int t = 0; t < 4; t++) t0[t] = f2n_mfma_fwd(f2n_rowfrag(s.w0, F2N_LD32, 16 * t + c, 0, g), xf, z);
   half8_t h0f[2] = {f2n_pack<true>(t0[0], t0[1]), f2n_pack<true>(t0[2], t0[3])};
   if (NH == 2) {
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      t1[t] = f2n_mfma(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 0, g), h0f[0], z);
-      t1[t] = f2n_mfma(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 32, g), h0f[1], t1[t]);
+      t1[t] = f2n_mfma_fwd(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 0, g), h0f[0], z);
+      t1[t] = f2n_mfma_fwd(f2n_rowfrag(s.w1, F2N_LD64, 16 * t + c, 32, g), h0f[1], t1[t]);
     }
   }
   half8_t hlf[2] = {h0f[0], h0f[1]};  // post-ReLU activations of the LAST hidden layer, as row fragments

@@ -430,6 +430,16 @@ int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const fl
 }
 
 int f2n_abi_version(void) { return 8; }
-const char* f2n_build_info(void) { return "f2n_hip gfx950 (hipcc, -ffp-contract=off), wave64, mfma_f32_16x16x32_f16"; }
+#ifndef F2N_REFERENCE_NUMERICS
+#define F2N_REFERENCE_NUMERICS 0
+#endif
+const char* f2n_build_info(void) {
+  return F2N_REFERENCE_NUMERICS
+             ? "f2n_hip gfx950 (hipcc, -ffp-contract=off), wave64, REFERENCE-NUMERICS build: f16 MLP forward accumulator (k-blocks "
+               "of 16), hash gradient by per-addend packed-f16 atomics"
+             : "f2n_hip gfx950 (hipcc, -ffp-contract=off), wave64, mfma_f32_16x16x32_f16";
+}
+/* 0: product numerics (fp32 MFMA accumulation, owner-binned fp32/fp64 hash-gradient sums); 1: the reference-numerics build */
+int f2n_numerics_mode(void) { return F2N_REFERENCE_NUMERICS; }
 
 }  // extern "C"

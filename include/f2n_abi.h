@@ -47,6 +47,12 @@ extern "C" {
 
 /* Library / device introspection (host-only). */
 int f2n_abi_version(void);
+/* 0 = product numerics; 1 = the reference-numerics build of this library (libf2n_hip_refnum.so, -DF2N_REFERENCE_NUMERICS=1):
+ * the two places where the product deviates from the reference's arithmetic ON PURPOSE are switched back -- the hash
+ * gradient is accumulated by per-addend packed-f16 atomics in arrival order (Hash3DAnchored.cu:145-153) instead of fp32 /
+ * fp64 owner sums rounded once, and the MLP forward products use an f16 accumulator fragment (the other plausible reading
+ * of tcnn's FullyFusedMLP).  Same ABI; used to A/B whole trainings (bench.py "psnr_numerics_ab"). */
+int f2n_numerics_mode(void);
 const char* f2n_build_info(void);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -719,7 +719,8 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state):
     """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
     against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
     statistics identical.  Learning rate 0 keeps the weights -- and so both runs -- deterministic, while the statistics start
-    at 2 so that leaves die (and rays are repaired) in most steps; a compaction and a subdivision fall inside the run."""
+    at 0 so that every visited leaf without a positive vote dies at once (and rays are repaired) in most steps; a compaction
+    and a subdivision fall inside the run."""
     st = fox_state
     overrides = ["field.log2_table_size=14", "train.learning_rate=0.0", "pts_sampler.sub_div_milestones=[9]", "pts_sampler.compact_freq=6"]
     R, NE, ITERS = 1024, 512, 16
@@ -734,7 +735,7 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state):
         runner.n_edge_pts = NE
         runner.speculative_sampling = spec
         for t in runner.occupancy_buffers()[:2]:
-            t.fill_(2)
+            t.fill_(0)
         torch.manual_seed(11)  # the same noise / background / edge draws in both runs
         log = []
         for it in range(ITERS):
