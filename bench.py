@@ -49,8 +49,8 @@ ALGO_BYTES = {"hash_gather": 512 + 12 + 4 + 64}
 # HBM-side bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate counter passes,
 # profiles/run_profiles.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), recorded per round in
 # profiles/<tag>_traffic.json; null when that file is absent.
-TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r02_traffic.json"), os.path.join(ROOT, "profiles", "r01_traffic.json"))
-                     if os.path.exists(p)), "")
+TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json"),
+                                 os.path.join(ROOT, "profiles", "r01_traffic.json")) if os.path.exists(p)), "")
 HBM_PEAK_GBS = 8000.0
 # What actually bounds that kernel: 128 independent 4-byte reads per sample from an L2-resident table slice.  The chip
 # serves at most ~263 G such lane-requests/s whatever the cache policy or access width (tools/gather_policy_probe.py,
@@ -63,6 +63,106 @@ L2_PEAK_TBS = 34.5  # aggregate L2 bandwidth of the eight XCDs (MI355X_MICROARCH
 #   hash_gather  16 levels x 8 corners x 4 B + point 12 + warp index 4 + 64 B of f16 feature planes written
 #   ray_march    dt 4 + t 4 + (warp, node) 8 written into the ray's slot + 16 B per leaf-list entry read (~1 entry / 2 samples)
 ALGO_BYTES_CONVERGED = {"hash_gather": 592, "ray_march": 16 + 8, "field_bwd": 64 + 64 + 8 * 16 * 8, "oct_intersect": 16}
+
+
+NODE_DT = np.dtype({"names": ["center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"],
+                    "formats": [("<f4", 3), "<f4", "<i4", ("<i4", 8), "u1", "<i4"], "offsets": [0, 12, 16, 20, 52, 56], "itemsize": 64})
+
+
+def psnr_runs(args, n_runs):
+    """n_runs complete trainings (ExpRunner::Train, args.train_iters iterations, fox photographs) from ONE seed in this process
+    and with this process's numerics (f2n_numerics_mode: the product build, or the reference-numerics build when the
+    environment says F2N_REFERENCE_NUMERICS=1).  Per run: test PSNR by the reference's definition (mean and per view), training
+    wall time, order-free checksums of the parameters after 1 / 10 / 100 / 1000 iterations (where do two runs from one seed
+    part?), and the set of surviving leaves (which leaves a run pruned)."""
+    from f2_nerf_amd import runtime, fox_data, capi
+    st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
+    sc, images = fox_data.scene(args.factor)
+    ds = runtime.make_dataset(sc, images)
+    runs, leaf_sets = [], []
+    for r in range(n_runs):
+        runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022)
+        torch.manual_seed(2022)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sums = {}
+        for stop in (1, 10, 100, 1000):
+            if stop < args.train_iters:
+                runner.train(ds, stop, 1)
+                stt = runner.states()  # [4] table, [8] field MLP, [9] colour MLP (fp32): integer sums of the bit patterns
+                sums[str(stop)] = [int(stt[i].contiguous().view(torch.int32).to(torch.int64).sum().item()) for i in (4, 8, 9)]
+        runner.train(ds, args.train_iters, 1)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        views = [float(v) for v in runner.test_images(ds)]
+        nodes = runner.tree_nodes().cpu().numpy().view(NODE_DT)
+        leaf = (nodes["trans_idx"] >= 0) & (nodes["childs"] < 0).all(1)
+        key = np.ascontiguousarray(np.concatenate([nodes["center"][leaf], nodes["side_len"][leaf, None]], 1), np.float32).view(np.uint64)
+        with np.errstate(over="ignore"):
+            leaf_sets.append(np.unique(key[:, 0] * np.uint64(0x9E3779B97F4A7C15) ^ key[:, 1]))
+        runs.append({"psnr_test_mean": round(views[-1], 3), "psnr_test_per_view": [round(v, 2) for v in views[:-1]],
+                     "train_wall_s": round(wall, 2), "octree_nodes": int(len(nodes)), "valid_leaves": int(leaf.sum()),
+                     "param_checksums_at_iter": sums})
+        del runner
+    jac = []
+    for i in range(n_runs):
+        for j in range(i + 1, n_runs):
+            inter = len(np.intersect1d(leaf_sets[i], leaf_sets[j], assume_unique=True))
+            jac.append(inter / max(len(leaf_sets[i]) + len(leaf_sets[j]) - inter, 1))
+    first_diff = None
+    for stop in ("1", "10", "100", "1000"):
+        vals = [tuple(r["param_checksums_at_iter"].get(stop, ())) for r in runs]
+        if len(set(vals)) > 1:
+            first_diff = int(stop)
+            break
+    m = np.array([r["psnr_test_mean"] for r in runs])
+    pv = np.array([r["psnr_test_per_view"] for r in runs])
+    out = {"numerics": capi.build_info(), "numerics_mode": int(capi.lib().f2n_numerics_mode()), "runs": n_runs,
+           "psnr_mean": round(float(m.mean()), 3), "psnr_std": round(float(m.std(ddof=1)) if n_runs > 1 else 0.0, 3),
+           "psnr_min": round(float(m.min()), 3), "psnr_max": round(float(m.max()), 3), "psnr_per_run": [float(v) for v in m],
+           "per_view_mean": [round(float(v), 2) for v in pv.mean(0)],
+           "per_view_std": [round(float(v), 2) for v in (pv.std(0, ddof=1) if n_runs > 1 else np.zeros(pv.shape[1]))],
+           "train_wall_s": [r["train_wall_s"] for r in runs], "valid_leaves": [r["valid_leaves"] for r in runs],
+           "surviving_leaf_sets_jaccard": {"min": round(min(jac), 4), "mean": round(float(np.mean(jac)), 4)} if jac else None,
+           # one seed, same draws: the first checkpoint (of iterations 1 / 10 / 100 / 1000) at which two runs' parameters differ
+           "runs_part_at_checkpoint": first_diff,
+           "corr_psnr_vs_valid_leaves": round(float(np.corrcoef(m, [r["valid_leaves"] for r in runs])[0, 1]), 3) if n_runs > 2 else None}
+    return out
+
+
+def psnr_numerics_ab(args):
+    """PSNR@20k as a distribution, and as an A/B of the two numerics (round-2 verdict, "make the PSNR claim testable"): two
+    worker processes of this script (one per build of the kernel library: include/f2n_abi.h f2n_numerics_mode) train the fox
+    scene args.psnr_runs / args.psnr_ref_runs times from one seed, side by side on the one GPU."""
+    procs = {}
+    for tag, n, envv in (("product", args.psnr_runs, "0"), ("reference_numerics", args.psnr_ref_runs, "1")):
+        if n <= 0:
+            continue
+        env = dict(os.environ, F2N_REFERENCE_NUMERICS=envv)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--psnr-worker", str(n), "--train-iters", str(args.train_iters),
+               "--factor", str(args.factor), "--preset", args.preset]
+        procs[tag] = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    out = {}
+    for tag, p in procs.items():
+        so = se = ""
+        try:
+            so, se = p.communicate(timeout=1500)
+            out[tag] = json.loads(so.strip().splitlines()[-1])
+        except Exception as e:
+            p.kill()
+            out[tag] = {"error": (str(e) + " | " + (se or "")[-400:])[:600]}
+    a, b = out.get("product", {}), out.get("reference_numerics", {})
+    if "psnr_mean" in a and "psnr_mean" in b:
+        out["delta_mean_db_reference_minus_product"] = round(b["psnr_mean"] - a["psnr_mean"], 3)
+        out["ranges_overlap"] = bool(a["psnr_min"] <= b["psnr_max"] and b["psnr_min"] <= a["psnr_max"])
+        out["within_0p1_db"] = bool(abs(b["psnr_mean"] - a["psnr_mean"]) <= 0.1)
+    out["note"] = ("same seed, same explicit schedule; the two workers share the GPU, so their train_wall_s are NOT timings. "
+                   "reference_numerics = libf2n_hip_refnum.so: hash gradient by per-addend packed-f16 atomics in arrival order "
+                   "(Hash3DAnchored.cu:145-153) and an f16 accumulator in the MLP forward products; product = fp32 MFMA accumulation, "
+                   "owner-binned hash-gradient sums rounded to f16 once")
+    return out
 
 
 def converged_leg(args, st, dev):
@@ -171,6 +271,9 @@ def main():
     ap.add_argument("--train-iters", type=int, default=20000, help="iterations of the converged leg's training run")
     ap.add_argument("--converged-steps", type=int, default=600, help="timed steps in the converged state")
     ap.add_argument("--factor", type=int, default=2, choices=[2, 8], help="image resolution of the converged leg (dataset.factor)")
+    ap.add_argument("--psnr-runs", type=int, default=4, help="trainings of the PSNR distribution with the product numerics (0: skip)")
+    ap.add_argument("--psnr-ref-runs", type=int, default=3, help="... with the reference-numerics build of the kernel library (0: skip)")
+    ap.add_argument("--psnr-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: run N trainings, print their summary
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     ap.add_argument("--marker-pause", action="store_true", help="sleep 0.3 s before the timed region (marker for profiles/timeline_rocpd.py)")
     ap.add_argument("--speculation", action="store_true", help="A/B: sample the next batch speculatively AHEAD of the stat update and "
@@ -179,6 +282,13 @@ def main():
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
+    if args.psnr_worker > 0:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs an MI355X")
+        torch.cuda.set_device(0)
+        import f2_nerf_amd  # noqa: F401
+        print(json.dumps(psnr_runs(args, args.psnr_worker)), flush=True)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         # stand-alone multi-GPU invocation: one process per GPU over RCCL, exactly as the driver launches it
         import socket
@@ -328,6 +438,11 @@ def main():
             except Exception as e:  # reported next to the headline, never instead of it
                 import traceback
                 converged = {"error": (str(e) + " | " + traceback.format_exc()[-600:])[:900]}
+            if args.psnr_runs > 0 or args.psnr_ref_runs > 0:  # (after every timed region: the workers share the GPU)
+                try:
+                    converged["psnr_numerics_ab"] = psnr_numerics_ab(args)
+                except Exception as e:
+                    converged["psnr_numerics_ab"] = {"error": str(e)[:300]}
         line = {
             "metric": "training ray-samples/s (%s)" % ("ngp_fox" if scene_name == "ngp_fox" else args.preset), "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,

