@@ -379,6 +379,18 @@ def main():
     host.ExpRunner.disable_kernel_timing()
 
     counts = torch.tensor([elapsed, float(n_meaningful), float(n_marched)], dtype=torch.float64, device=dev)
+    replicas = None
+    if dp:
+        # replicas must be bit-identical after the timed steps (same reduced gradients, same octree decisions on every rank):
+        # order-free integer checksums of table / MLPs / octree, gathered on rank 0
+        stt = runner.states()
+        mine = torch.tensor([int(stt[i].contiguous().view(torch.int32).to(torch.int64).sum().item()) for i in (4, 8, 9)] +
+                            [int(stt[0].to(torch.int64).sum().item()), runner.n_nodes()], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        sums = [[int(v) for v in t.tolist()] for t in allc]
+        replicas = {"identical": all(s_ == sums[0] for s_ in sums), "checksums_table_fieldmlp_colormlp_nodes_nnodes": sums,
+                    "rccl_comm_ranks": int(runner.dp_comm_ranks()), "torch_distributed_world": world}
     if dp:
         tmax = counts[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -454,7 +466,7 @@ def main():
                        "rays_per_s": args.rays * world * args.steps / elapsed,
                        "marched_samples_per_s": n_marched / elapsed, "rho_marched_over_meaningful": rho,
                        "meaningful_samples_per_step": n_meaningful / args.steps},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged, "replicas": replicas,
             # buffers are sized for the worst case on purpose (1024 sample slots per ray, scatter queues): what that costs of 288 GB
             "peak_hbm_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                              "reserved_by_allocator": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2),

@@ -18,6 +18,12 @@ std::vector<uint8_t> DataParallel::NewUniqueId() {
   return std::vector<uint8_t>(reinterpret_cast<uint8_t*>(&id), reinterpret_cast<uint8_t*>(&id) + sizeof(id));
 }
 
+int DataParallel::CommRanks() const {
+  int n = 0;
+  if (comm_ != nullptr) F2N_NCCL(ncclCommCount(reinterpret_cast<ncclComm_t>(comm_), &n));
+  return n;
+}
+
 DataParallel::~DataParallel() {
   if (comm_ != nullptr) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
 }
@@ -46,11 +52,11 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
   flat_ = runner->FlattenSmallGrads();
   table_prefix_ = field->grad_h_.view({-1}).narrow(0, 0, field->active_halves_);
   if (overlap) {
-    runner->grad_sync_begin_hook_ = [this]() { GradSyncBegin(); };
-    runner->grad_sync_end_hook_ = [this]() { GradSyncEnd(); };
-    runner->pipelined_sync_ = true;
+    runner->sync_.begin = [this]() { GradSyncBegin(); };
+    runner->sync_.end = [this]() { GradSyncEnd(); };
+    runner->sync_.pipelined = true;
   } else {
-    runner->grad_sync_hook_ = [this]() {
+    runner->sync_.blocking = [this]() {
       GradSyncBegin();
       GradSyncEnd();
     };

@@ -32,6 +32,7 @@ class DataParallel {
   void BroadcastStates();           // rank 0's checkpoint vector -> every rank (collective)
   int rank() const { return rank_; }
   int world() const { return world_; }
+  int CommRanks() const;            // what RCCL itself reports for the communicator (ncclCommCount)
 
  private:
   void GradSyncBegin();

@@ -2,7 +2,7 @@
 // loss terms, NaN-skip, LR / fineness / gradient-scaling schedules, checkpoint state order).  Dataset handling
 // (image loading, ray generation) is outside the hot path: rays and ground-truth colours are inputs here.
 // The optimiser is the fused Adam of csrc/optim.hip driven over the modules' parameter groups; multi-GPU data
-// parallelism hooks in through `grad_sync_hook_` (called after backward, before the step).
+// parallelism hooks in through `sync_` (GradSyncPipeline.h: in front of the optimiser, or pipelined under the next step's sampling).
 #include "ExpRunner.h"
 
 namespace f2n {
@@ -30,6 +30,17 @@ ExpRunner::ExpRunner(const std::map<std::string, std::string>& flat_config, int 
   BuildOptimizer();
   FlattenSmallGrads();
   UpdateAdaParams();
+  sync_.apply = [this](bool apply_optimizer, float lr) {  // (a pending step is applied with ITS learning rate)
+    const float lr_now = cur_lr_;
+    cur_lr_ = lr;
+    EnqueueApply(apply_optimizer);
+    cur_lr_ = lr_now;
+  };
+  // The host does not wait for the flags of a pipelined step (it would idle the device between this Adam and the next step's
+  // first kernels): they travel to pinned memory and are read after the next sample-count read-back, or by FinishPending().
+  sync_.defer_flags = [this]() {
+    if (check_nan_) DeferFlags(true);
+  };
 }
 
 void ExpRunner::BuildOptimizer() {
@@ -211,15 +222,12 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   auto* gdp = global_data_pool_.get();
   gdp->mode_ = RunningMode::TRAIN;
   gdp->backward_nan_ = false;
-  const bool pipelined = pipelined_sync_ && apply_optimizer;
+  const bool pipelined = sync_.pipelined && apply_optimizer;
   const bool prefetch = apply_optimizer && next_rays_o.defined() && next_rays_d.defined();
-  if (pipelined) {
-    // The previous step's gradient all-reduce is still in flight on RCCL's stream.  Ray sampling reads neither the
-    // parameters nor the gradients, so it is issued first (unless the previous step already prefetched it) and runs
-    // under the collective; only then is the collective awaited and the previous step's (flag-predicated) Adam applied.
-    renderer_->PreSample(rays_o, rays_d, bounds);
-  }
-  FinishPendingStep();
+  // Pipelined: the previous step's gradient all-reduce is still in flight on RCCL's stream.  Ray sampling reads neither the
+  // parameters nor the gradients, so it is issued first (unless the previous step already prefetched it) and runs
+  // under the collective; only then is the collective awaited and the previous step's (flag-predicated) Adam applied.
+  sync_.BeginStep(apply_optimizer, [&]() { renderer_->PreSample(rays_o, rays_d, bounds); });
   renderer_->ZeroGrad();
   renderer_->after_octree_update_ = nullptr;  // (a previous call that threw must not leave its hook / half a prefetch behind)
   renderer_->next_batch_ = Renderer::NextBatch();
@@ -262,16 +270,10 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   stats.mse = out.losses.slice(0, 5, 6).squeeze(0);
   bool applied = false;
   // (a data-parallel replica whose batch missed the scene still joins the gradient exchange, with its zero gradients)
-  if (out.has_samples || grad_sync_hook_ || grad_sync_begin_hook_) {
-    if (pipelined) {
-      if (grad_sync_begin_hook_) grad_sync_begin_hook_();  // asynchronous all-reduce; awaited in the next step (or Flush)
-      pending_ = true;
-      pending_lr_ = cur_lr_;
-    } else {
-      if (grad_sync_hook_) grad_sync_hook_();  // data-parallel all-reduce of the gradient buffers (RCCL)
-      EnqueueApply(apply_optimizer);           // finiteness flags + predicated Adam, with this iteration's learning rate
-      applied = true;
-    }
+  if (out.has_samples || sync_.Installed()) {
+    // pipelined: asynchronous all-reduce, awaited in the next step (or Flush); else: all-reduce of the gradient buffers
+    // (RCCL), then finiteness flags + predicated Adam with this iteration's learning rate
+    applied = sync_.GradientsReady(apply_optimizer, cur_lr_);
   }
   if (apply_optimizer) {
     iter_step_++;
@@ -361,18 +363,7 @@ void ExpRunner::FinishPending() {
   ResolveDeferredFlags();
 }
 
-void ExpRunner::FinishPendingStep() {
-  if (!pending_) return;
-  pending_ = false;
-  if (grad_sync_end_hook_) grad_sync_end_hook_();  // the compute stream waits for the collective; the host does not
-  const float lr_now = cur_lr_;
-  cur_lr_ = pending_lr_;
-  EnqueueApply(true);  // flags + Adam, predicated on the device
-  cur_lr_ = lr_now;
-  // The host does not wait for the flags here either (it would idle the device between this Adam and the next step's first
-  // kernels): they travel to pinned memory and are read after the next sample-count read-back, or by FinishPending().
-  if (check_nan_) DeferFlags(true);
-}
+void ExpRunner::FinishPendingStep() { sync_.FinishPendingStep(); }
 
 void ExpRunner::DeferFlags(bool apply_optimizer) {
   if (flags_deferred_) ResolveDeferredFlags();  // (one set in flight at a time)
@@ -413,7 +404,7 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
   if (loss.requires_grad()) {
     renderer_->ZeroGrad();
     loss.backward();
-    if (grad_sync_hook_) grad_sync_hook_();  // data-parallel all-reduce of the gradient buffers (RCCL)
+    if (sync_.blocking) sync_.blocking();  // data-parallel all-reduce of the gradient buffers (RCCL)
     if (check_nan_) {  // TCNNWP.cpp:234-240 + ExpRunner.cpp:131-134
       auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
       auto* shader = static_cast<SHShader*>(renderer_->shader_.get());

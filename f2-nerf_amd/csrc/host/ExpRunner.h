@@ -3,6 +3,7 @@
 #include <functional>
 
 #include "Dataset.h"
+#include "GradSyncPipeline.h"
 #include "Renderer.h"
 
 namespace f2n {
@@ -92,12 +93,10 @@ class ExpRunner {
   bool check_nan_ = true;
   int async_counts_ = 1;  // 1: streaming steps keep the survivor count on the device; 0: always read it back (as Render does); 2: never read it back in TrainStep (tests)
   int optim_steps_ = 0;
-  std::function<void()> grad_sync_hook_;
-  // pipelined variant: begin = launch the asynchronous all-reduce right after backward; end = make the compute stream
-  // wait for it -- called in the NEXT TrainStep after ray sampling has been issued (or by FinishPending / Flush)
-  std::function<void()> grad_sync_begin_hook_, grad_sync_end_hook_;
-  bool pipelined_sync_ = false, pending_ = false;
-  float pending_lr_ = 0.f;
+  // The data-parallel gradient exchange and its place in the step (GradSyncPipeline.h): sync_.blocking = all-reduce in front
+  // of the optimiser; sync_.begin / sync_.end + sync_.pipelined = launch the asynchronous all-reduce right after backward,
+  // make the compute stream wait for it in the NEXT TrainStep after ray sampling has been issued (or in FinishPending).
+  GradSyncPipeline sync_;
   Tensor nan_flags_;  // device int32 [4]: field MLP, colour MLP, either
   // A TrainStep that is handed the next batch (streaming use) does not wait for its own flags: they are copied to pinned
   // memory and read after the NEXT step's sample-count read-back, when they are certain to have arrived.  The update

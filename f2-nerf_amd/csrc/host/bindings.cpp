@@ -100,6 +100,19 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     auto v = ExpRunner::ScheduleAt(p, iter);
     return std::vector<float>{v.fineness, v.lr, v.gradient_scaling_progress, v.var_loss_weight};
   });
+  // the step / exchange interleaving of ExpRunner::TrainStep on its own (no device): tests drive it with recording callbacks
+  py::class_<GradSyncPipeline>(m, "GradSyncPipeline")
+      .def(py::init<>())
+      .def_readwrite("pipelined", &GradSyncPipeline::pipelined)
+      .def("set_blocking", [](GradSyncPipeline& p, py::function f) { p.blocking = [f]() { f(); }; })
+      .def("set_begin_end", [](GradSyncPipeline& p, py::function b, py::function e) { p.begin = [b]() { b(); }; p.end = [e]() { e(); }; })
+      .def("set_apply", [](GradSyncPipeline& p, py::function f) { p.apply = [f](bool a, float lr) { f(a, lr); }; })
+      .def("set_defer_flags", [](GradSyncPipeline& p, py::function f) { p.defer_flags = [f]() { f(); }; })
+      .def("installed", &GradSyncPipeline::Installed)
+      .def("pending", &GradSyncPipeline::Pending)
+      .def("begin_step", [](GradSyncPipeline& p, bool apply_optimizer, py::function presample) { p.BeginStep(apply_optimizer, [presample]() { presample(); }); })
+      .def("gradients_ready", &GradSyncPipeline::GradientsReady)
+      .def("finish_pending_step", &GradSyncPipeline::FinishPendingStep);
   py::class_<ExpRunner>(m, "ExpRunner")
       .def(py::init<const std::map<std::string, std::string>&, int>(), py::arg("flat_config"), py::arg("n_images"))
       .def("load_states", &ExpRunner::LoadStates)
@@ -202,12 +215,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              auto& o = *SamplerOf(r)->pers_octree_;
              return std::vector<Tensor>{o.tree_weight_stats_, o.tree_alpha_stats_, o.tree_visit_cnt_};
            })
-      .def("set_grad_sync_hook", [](ExpRunner& r, py::function f) { r.grad_sync_hook_ = [f]() { py::gil_scoped_acquire g; f(); }; })
+      .def("set_grad_sync_hook", [](ExpRunner& r, py::function f) { r.sync_.blocking = [f]() { py::gil_scoped_acquire g; f(); }; })
       .def("set_pipelined_grad_sync",
            [](ExpRunner& r, py::function begin, py::function end) {
-             r.grad_sync_begin_hook_ = [begin]() { py::gil_scoped_acquire g; begin(); };
-             r.grad_sync_end_hook_ = [end]() { py::gil_scoped_acquire g; end(); };
-             r.pipelined_sync_ = true;
+             r.sync_.begin = [begin]() { py::gil_scoped_acquire g; begin(); };
+             r.sync_.end = [end]() { py::gil_scoped_acquire g; end(); };
+             r.sync_.pipelined = true;
            })
       .def("flush", [](ExpRunner& r) { py::gil_scoped_release no_gil; r.FinishPending(); })
       .def("attach_data_parallel",  // native RCCL exchanges, issued from C++ inside TrainStep (DataParallel.h); collective
@@ -221,6 +234,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              r.data_parallel_ = dp;
            },
            py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("overlap") = true)
+      .def("dp_comm_ranks",  // ranks of the native RCCL communicator as RCCL reports them (0: none attached)
+           [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->CommRanks() : 0; })
       .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically
            [](ExpRunner& r, py::function f) {
              SamplerOf(r)->occupancy_sync_hook_ = [f](Tensor occ) {

@@ -189,3 +189,60 @@ def test_presets_equal_the_reference_config_files(name):
                                "train.end_iter=100"])
     cfg = config.compose_yaml(d, n, ov)
     assert cfg["case_name"] == "ngp_fox" and cfg["work_dir"] == "/tmp/x" and cfg["train"]["end_iter"] == 100
+
+
+def test_step_and_gradient_exchange_interleave_in_the_documented_order():
+    """GradSyncPipeline (csrc/host/GradSyncPipeline.h) is the piece of ExpRunner::TrainStep that decides WHEN the data-parallel
+    exchange, the optimiser and the next step's ray sampling run relative to each other.  It touches no device, so the host
+    extension's own object is driven here with recording callbacks: blocking exchange, pipelined exchange (begin after
+    backward, end + the PREVIOUS step's Adam with ITS learning rate behind the next step's sampling), the non-optimising step
+    in pipelined mode, and flush."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    host = runtime.host()
+    log = []
+
+    def make(pipelined, blocking):
+        p = host.GradSyncPipeline()
+        p.set_apply(lambda a, lr: log.append("adam(apply=%d, lr=%.3f)" % (a, lr)))
+        p.set_defer_flags(lambda: log.append("defer_flags"))
+        if blocking:
+            p.set_blocking(lambda: log.append("allreduce"))
+        if pipelined:
+            p.set_begin_end(lambda: log.append("begin"), lambda: log.append("end"))
+            p.pipelined = True
+        return p
+
+    def step(p, lr, apply=True):
+        p.begin_step(apply, lambda: log.append("sample"))
+        log.append("fwd_bwd")
+        return p.gradients_ready(apply, lr)
+
+    # no exchange at all (one GPU): nothing but the optimiser, nothing pending
+    p = make(False, False)
+    assert not p.installed() and step(p, 0.01) and not p.pending()
+    assert log == ["fwd_bwd", "adam(apply=1, lr=0.010)"]
+    # blocking exchange: in front of the optimiser, same step
+    del log[:]
+    p = make(False, True)
+    assert p.installed() and step(p, 0.01) and step(p, 0.02, apply=False)
+    assert log == ["fwd_bwd", "allreduce", "adam(apply=1, lr=0.010)", "fwd_bwd", "allreduce", "adam(apply=0, lr=0.020)"]
+    # pipelined exchange
+    del log[:]
+    p = make(True, False)
+    assert step(p, 0.01) is False and p.pending()
+    assert log == ["sample", "fwd_bwd", "begin"]  # (the first step has nothing to wait for)
+    del log[:]
+    assert step(p, 0.02) is False
+    # the next step's sampling is queued BEFORE the wait; the previous step is applied with the previous learning rate
+    assert log == ["sample", "end", "adam(apply=1, lr=0.010)", "defer_flags", "fwd_bwd", "begin"]
+    del log[:]
+    p.finish_pending_step()  # flush (FinishPending / states() / render)
+    p.finish_pending_step()
+    assert log == ["end", "adam(apply=1, lr=0.020)", "defer_flags"] and not p.pending()
+    # a step that does not apply the optimiser (tests, gradient inspection) never leaves an exchange in flight, and first
+    # completes the one that is
+    del log[:]
+    assert step(p, 0.03) is False
+    assert step(p, 0.04, apply=False) is True and not p.pending()
+    assert log == ["sample", "fwd_bwd", "begin", "end", "adam(apply=1, lr=0.030)", "defer_flags", "fwd_bwd", "adam(apply=0, lr=0.040)"]
