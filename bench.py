@@ -410,8 +410,14 @@ def main():
             samples_per_launch = n_marched / world / args.steps
             achieved = samples_per_launch * ALGO_BYTES[DOMINANT] / (avg_ms * 1e-3) / 1e9
             traffic = None
-            if TRAFFIC_FILE and os.path.exists(TRAFFIC_FILE):
-                with open(TRAFFIC_FILE) as f:
+            # per-workload counter files (profiles/run_profiles.sh): the headline workload, or the big-table stress points
+            tfile = TRAFFIC_FILE
+            if args.preset == "wanjinyou_big":
+                tfile = os.path.join(ROOT, "profiles", "r03_big%d_traffic.json" % log2)
+            elif args.preset != "wanjinyou" or args.log2 not in (0, 19) or args.rays != 8192:
+                tfile = ""  # (no counters were collected for this workload)
+            if tfile and os.path.exists(tfile):
+                with open(tfile) as f:
                     traffic = json.load(f).get("hash_gather_planes_kernel", {}).get("hbm_bytes_per_launch")
             roofline = {"bound": "hbm", "kernel": "hash_gather_planes_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -434,6 +440,12 @@ def main():
                         "whole_path": {"gather_scatter_frac_of_hbm": round(value / max(world, 1) * 512 * (rho + 2) / 8.0e12, 5),
                                        "mlp_frac_of_mfma": round(value / max(world, 1) * (61440 + 6144 * rho) / 2.5e15, 5)},
                         "timed_calls_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in timing.items()}}
+            if traffic:  # counter traffic against the same launch's duration: what the memory side actually moved per second
+                roofline["traffic_rate"] = {"achieved": round(traffic / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "note": "FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch / launch duration: far below 1 with an L2-"
+                                                    "resident table (2^19: the reads never leave the XCD), ~0.75 where every 4-byte read "
+                                                    "pulls a 128-byte line across the fabric (2^22: profiles/r03_big22_pmc_tcc.csv)"}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -254,14 +254,16 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
 }
 
 // Speculative variant of PreSampleBegin: intersection + march only, NOT ordered behind this step's stat update.
-void Renderer::PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream) {
+void Renderer::PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool /*after_main_stream*/) {
   if (!side_stream_)
     side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
-  octree_ready_ev_.block(*side_stream_);  // the PREVIOUS step's update (this batch's own sampling already waited for it)
-  if (after_main_stream) {  // this batch was sampled on the main stream: whatever touched the tree there comes first
-    spec_start_ev_.record();
-    spec_start_ev_.block(*side_stream_);
-  }
+  // Everything the main stream has been handed so far comes first: the kernels that DRAW the next batch's rays
+  // (Dataset::RandRaysData, queued by ExpRunner::Train right before this step) and whatever touched the tree there -- i.e. the
+  // speculative sampling starts when this step's own kernels start, not before.  (Waiting only for the previous step's octree
+  // update -- as a first version did -- let the side stream read ray buffers that were still to be written whenever the host
+  // ran ahead of the device: PSNR fell and octrees blew up at random, worst with a second process on the GPU.)
+  spec_start_ev_.record();
+  spec_start_ev_.block(*side_stream_);
   if (side_must_wait_consumed_) {
     samples_consumed_ev_.block(*side_stream_);
     side_must_wait_consumed_ = false;

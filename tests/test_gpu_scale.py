@@ -718,28 +718,35 @@ def test_speculative_sampling_repair(hip, kill_frac):
 def test_speculative_training_equals_sampling_after_the_update(rt, fox_state):
     """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
     against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
-    statistics identical.  Learning rate 0 keeps the weights -- and so both runs -- deterministic, while the statistics start
-    at 0 so that every visited leaf without a positive vote dies at once (and rays are repaired) in most steps; a compaction
-    and a subdivision fall inside the run."""
+    statistics identical.  Learning rate 0 keeps the weights -- and so both runs -- deterministic, while the statistics are
+    re-armed at 0 before every step so that every visited leaf without a positive vote in THAT batch dies at once (and rays
+    of the next, already marched batch are repaired) in most steps; a compaction and a subdivision fall inside the run.
+    The batches are drawn on the device right before each step, as ExpRunner::Train does (the speculative sampling must be
+    ordered behind the kernels that write its rays)."""
     st = fox_state
     overrides = ["field.log2_table_size=14", "train.learning_rate=0.0", "pts_sampler.sub_div_milestones=[9]", "pts_sampler.compact_freq=6"]
     R, NE, ITERS = 1024, 512, 16
     rng0 = np.random.default_rng(31)
-    batches = []
+    host_batches = []
     for _ in range(ITERS + 1):
         ro, rd, bounds, cam = fox_batch(st, rng0, R)
-        batches.append(rt.to_dev(ro, rd, bounds, rng0.random((R, 3), dtype=F32), cam))
+        host_batches.append([torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in (ro, rd, bounds, rng0.random((R, 3), dtype=F32), cam)])
+    busy = torch.randn(4096, 4096, device=DEV)
     logs = {}
     for spec in (True, False):
         runner, cfg, _ = rt.make_runner(st, "wanjinyou", overrides, seed=5, table_init=0.3)
         runner.n_edge_pts = NE
         runner.speculative_sampling = spec
-        for t in runner.occupancy_buffers()[:2]:
-            t.fill_(0)
         torch.manual_seed(11)  # the same noise / background / edge draws in both runs
         log = []
+        nb = [t.to(DEV, non_blocking=True) for t in host_batches[0]]
         for it in range(ITERS):
-            b, nb = batches[it], batches[it + 1]
+            for t in runner.occupancy_buffers()[:2]:
+                t.fill_(0)
+            b = nb
+            for _ in range(8):  # the device is kept behind the host: the next batch's rays are still to be written when ...
+                busy = (busy @ busy).clamp_(-1.0, 1.0)
+            nb = [t.to(DEV, non_blocking=True) for t in host_batches[it + 1]]  # ... its (speculative) sampling is queued
             s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
             runner.flush()
             w, a, v = [N(t).copy() for t in runner.occupancy_buffers()]
