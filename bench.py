@@ -175,8 +175,7 @@ def converged_leg(args, st, dev):
     sc, images = fox_data.scene(args.factor)
     ds = runtime.make_dataset(sc, images)
     runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022, device=dev)
-    if args.speculation:
-        runner.speculative_sampling = True
+    runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
     torch.manual_seed(2022)
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
@@ -276,9 +275,9 @@ def main():
     ap.add_argument("--psnr-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: run N trainings, print their summary
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     ap.add_argument("--marker-pause", action="store_true", help="sleep 0.3 s before the timed region (marker for profiles/timeline_rocpd.py)")
-    ap.add_argument("--speculation", action="store_true", help="A/B: sample the next batch speculatively AHEAD of the stat update and "
-                    "repair it behind it (Renderer::PreSampleSpecBegin; measured slower in the converged regime: "
-                    "profiles/r03_speculation_experiments.txt) instead of behind the update")
+    ap.add_argument("--speculation", choices=["auto", "on", "off"], default="auto", help="sampling of the next batch AHEAD of the stat "
+                    "update with repair behind it (Renderer::PreSampleSpecBegin): auto = while no leaf has died lately (the "
+                    "default of the host), on / off = A/B (profiles/r03_speculation_experiments.txt)")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
@@ -330,8 +329,7 @@ def main():
     log2 = int(cfg["field"]["log2_table_size"])
     if args.diag_no_nan_check:
         runner.check_nan = False
-    if args.speculation:
-        runner.speculative_sampling = True
+    runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
 
     if dp:
         from f2_nerf_amd import parallel

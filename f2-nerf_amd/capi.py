@@ -167,8 +167,8 @@ def oct_update_stats_ex(n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_
                         death_epoch):
     _ck(lib().f2n_oct_update_stats_ex(_stream(), _i(n_nodes), _p(w_adder, "i32"), _p(a_adder, "i32"), _p(mark, "i32"),
                                       _p(w_stats, "i32"), _p(a_stats, "i32"), _p(tree_nodes, "u8"), _p(child_blocks, "u8", True),
-                                      _i(int(reset_votes)), _p(died_at, "i32", True), _i(epoch), _p(death_epoch, "i32", True)),
-        "f2n_oct_update_stats_ex")
+                                      _i(int(reset_votes)), _p(died_at, "i32", True), _i(epoch), _p(death_epoch, "i32", True),
+                                      ctypes.c_void_p(0)), "f2n_oct_update_stats_ex")
 
 
 def oct_intersect_repair(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total,

@@ -89,6 +89,15 @@ int f2n_defer_reduction(int n, int n_blocks, const float* partials, float* out);
 #define F2N_WS_BIN_REC 5
 #define F2N_WS_BIN_CNT 6
 #define F2N_WS_GATHER_CTR 7
+#define F2N_WS_MLPG_W 8     // mlp_generic.hip: padded / transposed weights of the call
+#define F2N_WS_MLPG_ACTS 9  // ... saved activations and hidden gradients (tile-transposed f16)
+#define F2N_WS_MLPG_DW 10   // ... per-block partial weight gradients
+#define F2N_WS_SLOTS 12
+// mlp_generic.hip: the tcnn FullyFusedMLP shapes the two specialised kernels do not cover
+bool f2n_mlpg_shape_ok(int d_in, int d_hidden, int n_hidden);
+int f2n_mlpg_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const void* params_h, const float* x, void* out_h);
+int f2n_mlpg_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float loss_scale, const void* params_h, const float* x,
+                 const float* dy, float* dparams_f32_scaled, float* dx_f32);
 #define F2N_PARTITION_MIN_N 8192  // below this the single fused gather+MLP launch wins (an unpartitioned gather runs at 91 G reads/s, a partitioned one at 250 G/s)
 
 // ---- reductions in the order Eigen's scalar fixed-size unrollers use (n/2 | n - n/2 recursive split) ----

@@ -976,7 +976,10 @@ int f2n_hash_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, c
 
 int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const void* params_h, const float* x, void* out_h) {
   if (n < 0) return F2N_ERR_INVALID_ARG;
-  if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
+  if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) {  // not one of the two shipped networks: the general kernels (mlp_generic.hip)
+    if (!f2n_mlpg_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
+    return n == 0 ? F2N_OK : f2n_mlpg_fwd(stream, n, d_in, d_hidden, n_hidden, params_h, x, out_h);
+  }
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
   const dim3 grid(f2n_wave_grid((n + 15) / 16, 4)), block(F2N_FWD_THREADS);
@@ -992,7 +995,10 @@ int f2n_mlp_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const
 int f2n_mlp_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float loss_scale, const void* params_h,
                 const float* x, const float* dy, float* dparams_f32_scaled, float* dx_f32) {
   if (n < 0 || !(loss_scale > 0.f) || ((uintptr_t) params_h & 15)) return F2N_ERR_INVALID_ARG;  // 16-byte loads of the weights
-  if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
+  if (!f2n_mlp_shape_ok(d_in, d_hidden, n_hidden)) {
+    if (!f2n_mlpg_shape_ok(d_in, d_hidden, n_hidden)) return F2N_ERR_UNSUPPORTED;
+    return n == 0 ? F2N_OK : f2n_mlpg_bwd(stream, n, d_in, d_hidden, n_hidden, loss_scale, params_h, x, dy, dparams_f32_scaled, dx_f32);
+  }
   if (n == 0) return F2N_OK;
   F2nHashArgs h = {nullptr, nullptr, nullptr, 1};
   // resident blocks per CU by register budget: the one-hidden-layer kernel needs ~150 registers (3), the two-layer one 244 (2)

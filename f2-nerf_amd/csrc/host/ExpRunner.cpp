@@ -219,6 +219,9 @@ float ExpRunner::CurVarLossWeight() const { return ScheduleAt(Schedule(), iter_s
 TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                 const Tensor& emb_idx, bool apply_optimizer, const Tensor& next_rays_o,
                                 const Tensor& next_rays_d, const Tensor& next_bounds) {
+  // Network shapes without fused kernels (any tcnn FullyFusedMLP a YAML can ask for: csrc/mlp_generic.hip, unfused field /
+  // shader paths) train through the taped iteration: same losses, same optimiser, no streaming.
+  if (!renderer_->FusedPathOk()) return TrainStepAutograd(rays_o, rays_d, bounds, gt_colors, emb_idx, apply_optimizer);
   auto* gdp = global_data_pool_.get();
   gdp->mode_ = RunningMode::TRAIN;
   gdp->backward_nan_ = false;
@@ -404,6 +407,11 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
   if (loss.requires_grad()) {
     renderer_->ZeroGrad();
     loss.backward();
+    if (renderer_->app_emb_.grad().defined()) {  // (the unfused shader path delivers this gradient through autograd)
+      torch::NoGradGuard ng;
+      renderer_->app_emb_grad_.add_(renderer_->app_emb_.grad());
+      renderer_->app_emb_.mutable_grad() = Tensor();
+    }
     if (sync_.blocking) sync_.blocking();  // data-parallel all-reduce of the gradient buffers (RCCL)
     if (check_nan_) {  // TCNNWP.cpp:234-240 + ExpRunner.cpp:131-134
       auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());

@@ -143,6 +143,7 @@ Hash3DAnchored::Hash3DAnchored(GlobalDataPool* gdp) {  // Hash3DAnchored.cpp:19-
   // level l addresses halves [l*local, l*local + 2*local): the union is [0, (N_LEVELS+1)*local)
   active_halves_ = std::min<int64_t>(int64_t(N_LEVELS + 1) * local_size, int64_t(pool_size_) * N_CHANNELS);
   mlp_ = std::make_unique<FusedMLP>(gdp, N_LEVELS * N_CHANNELS, mlp_out_dim_, mlp_hidden_dim_, n_hidden_layers_);
+  fused_ok_ = mlp_hidden_dim_ == 64 && n_hidden_layers_ == 1;
   SyncHalf();
 }
 
@@ -199,6 +200,44 @@ struct FieldFunction : public torch::autograd::Function<FieldFunction> {
 
 }  // namespace
 
+namespace {
+
+// Hash3DAnchoredFunction of the reference (Hash3DAnchored.cu:160-233) as its own autograd node, for the unfused field path.
+struct HashEncodeFunction : public torch::autograd::Function<HashEncodeFunction> {
+  static variable_list forward(AutogradContext* ctx, Tensor feat_pool, Tensor points, Tensor anchors, int64_t field_ptr) {
+    auto* f = reinterpret_cast<Hash3DAnchored*>(field_ptr);
+    AnchorView av = ViewAnchors(anchors);
+    const int n = points.size(0);
+    Tensor out_h = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
+    F2N_TIMED_CALL("hash_fwd", f2n_hash_fwd(CurStream(), n, f->n_volumes_, VoidP(f->feat_pool_h_), I32P(f->prim_pool_), I32P(f->feat_local_idx_),
+                          I32P(f->feat_local_size_), F32P(f->bias_pool_), F32P(f->level_scale_), F32P(points), /*warped=*/1,
+                          I32P(av.t), av.stride, VoidP(out_h)));
+    ctx->saved_data["field"] = field_ptr;
+    ctx->saved_data["stride"] = (int64_t) av.stride;
+    ctx->save_for_backward({points, av.t});
+    return {out_h.to(torch::kFloat32)};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_output) {
+    auto* f = reinterpret_cast<Hash3DAnchored*>(ctx->saved_data["field"].toInt());
+    auto saved = ctx->get_saved_variables();
+    const int n = saved[0].size(0);
+    Tensor gin = (grad_output[0] * 128.f).to(torch::kFloat16).contiguous();  // Hash3DAnchored.cu:220
+    f->grad_clean_ = false;
+    F2N_TIMED_CALL("hash_bwd", f2n_hash_bwd(CurStream(), n, f->n_volumes_, I32P(f->prim_pool_), I32P(f->feat_local_idx_), I32P(f->feat_local_size_),
+                          F32P(f->bias_pool_), F32P(f->level_scale_), F32P(saved[0]), /*warped=*/1, I32P(saved[1]),
+                          (int) ctx->saved_data["stride"].toInt(), VoidP(gin), VoidP(f->grad_h_), f->pool_size_ / N_LEVELS));
+    return {Tensor(), Tensor(), Tensor(), Tensor()};  // the table gradient lives in f->grad_h_ (fp16, x128)
+  }
+};
+
+}  // namespace
+
+Tensor Hash3DAnchored::HashEncode(const Tensor& points, const Tensor& anchors) {
+  Tensor pts = points.contiguous();
+  CheckDev(pts, torch::kFloat32, "points");
+  return HashEncodeFunction::apply(feat_pool_, pts, anchors, reinterpret_cast<int64_t>(this))[0];
+}
+
 void Hash3DAnchored::ForwardRaw(const Tensor& points, const Tensor& anchors, int stride, const Tensor& src_rows, int n_reuse,
                                 Tensor& feat, Tensor& saved_x, Tensor* f0_cached) {
   const int n = points.size(0);
@@ -229,6 +268,7 @@ void Hash3DAnchored::BackwardRaw(const Tensor& points, const Tensor& anchors, in
 Tensor Hash3DAnchored::AnchoredQuery(const Tensor& points, const Tensor& anchors) {  // Hash3DAnchored.cpp:84-99
   Tensor pts = points.contiguous();
   CheckDev(pts, torch::kFloat32, "points");
+  if (!fused_ok_) return mlp_->Query(HashEncode(pts, anchors));  // hash -> fp32 -> tcnn MLP, as the reference spells it (:91-98)
   Tensor feat = FieldFunction::apply(feat_pool_, mlp_->params_, pts, anchors, torch::empty({0}, DevI32()), (int64_t) 0,
                                      reinterpret_cast<int64_t>(this))[0];
   return mlp_out_dim_ == F2N_MLP_OUT_PAD ? feat : feat.index({Slc(), Slc(0, mlp_out_dim_)}).contiguous();
@@ -240,6 +280,10 @@ Tensor Hash3DAnchored::AnchoredQueryReuse(const Tensor& points, const Tensor& an
   Tensor rows = src_rows.contiguous();
   CheckDev(rows, torch::kInt32, "src_rows");
   TORCH_CHECK(n_reuse >= 0 && n_reuse <= pts.size(0) && rows.numel() >= n_reuse, "bad reuse range");
+  if (!fused_ok_) {  // (no feature cache on the unfused path)
+    prepass_x_ = Tensor();
+    return AnchoredQuery(pts, anchors);
+  }
   Tensor feat = FieldFunction::apply(feat_pool_, mlp_->params_, pts, anchors, rows.slice(0, 0, n_reuse), (int64_t) n_reuse,
                                      reinterpret_cast<int64_t>(this))[0];
   prepass_x_ = Tensor();  // one consumer per pre-pass; the table may change after this step
@@ -252,6 +296,10 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
   CheckDev(pts, torch::kFloat32, "points");
   AnchorView av = ViewAnchors(anchors);
   const int n = pts.size(0);
+  if (!fused_ok_) {
+    prepass_x_ = Tensor();
+    return mlp_->Query(HashEncode(pts, anchors)).select(1, 0).contiguous();
+  }
   Tensor f0 = torch::empty({n}, DevF32());
   prepass_x_ = keep_features ? torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16()) : Tensor();
   if (n >= 32768) {  // the two kernels of the large-batch path, issued (and timed) separately

@@ -33,6 +33,11 @@ class Hash3DAnchored : public Field {
   void Reset() override;
   void SyncHalf();
   void ZeroGrad();
+  // The fused gather + MLP kernels exist for the field network of the shipped configs (32 -> 64 -> 16).  Any other
+  // field.mlp_hidden_dim / field.n_hidden_layers (TCNNWP.cpp:86-92) runs unfused: f2n_hash_fwd -> the general MLP kernels
+  // (csrc/mlp_generic.hip through FusedMLP::Query) -> f2n_hash_bwd, on the autograd tape (no feature cache, no streaming step).
+  bool fused_ok_ = true;
+  Tensor HashEncode(const Tensor& points, const Tensor& anchors);  // [n,32] fp32 features, differentiable w.r.t. the table
   Tensor TableGradUnscaled();  // fp32 [pool,2] = grad_h / 128 (Hash3DAnchored.cu:232)
 
   int pool_size_;

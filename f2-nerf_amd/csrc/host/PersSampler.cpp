@@ -52,6 +52,7 @@ void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of 
   if (!death_epoch_.defined()) {
     death_epoch_ = torch::zeros({1}, DevI32());
     n_repaired_ = torch::zeros({1}, DevI32());
+    death_epoch_host_ = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
   }
   child_blocks_gpu_ = torch::empty({int64_t(n) * 8 * 32}, torch::TensorOptions().dtype(torch::kUInt8).device(torch::kCUDA));
   F2N_CALL(f2n_oct_build_child_blocks(CurStream(), n, VoidP(tree_nodes_gpu_), VoidP(child_blocks_gpu_)));
@@ -64,6 +65,12 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   PendingSamples p;
   BeginSamples(rays_o_raw, rays_d_raw, global_data_pool_->ray_march_fineness_, p);
   return FinishSamples(p);
+}
+
+int PersOctree::QuietEpochs() const {
+  if (!death_epoch_host_.defined()) return 0;
+  const int last = *reinterpret_cast<volatile const int32_t*>(death_epoch_host_.data_ptr<int32_t>());  // (may lag: a hint)
+  return epoch_ - last;
 }
 
 bool PersSampler::MaintenanceDue() const {  // the conditions of FinishOctUpdate below, for the iteration in progress
@@ -291,7 +298,8 @@ void PersSampler::FinishOctUpdate() {
   oct.epoch_++;  // (deaths of this update are stamped with it: speculative samplers repair against them)
   F2N_TIMED_CALL("oct_update_stats", f2n_oct_update_stats_ex(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
                                 I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
-                                VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1, I32P(oct.died_at_), oct.epoch_, I32P(oct.death_epoch_)));
+                                VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1, I32P(oct.died_at_), oct.epoch_, I32P(oct.death_epoch_),
+                                I32P(oct.death_epoch_host_)));
 
   while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610
     oct.ProcOctree(true, true, sub_div_milestones_.back() <= 0);

@@ -59,6 +59,8 @@ class PersOctree {
   // revive / re-number leaves (ProcOctree, MarkInvisibleNodes, LoadStates, InstallOctree): samples marched speculatively
   // against an older generation cannot be repaired and are dropped.
   Tensor died_at_, death_epoch_, n_repaired_;
+  Tensor death_epoch_host_;  // pinned int32[1]: the last epoch in which a leaf died, written by the stat update itself
+  int QuietEpochs() const;   // stat updates since a leaf last died, as far as the host can tell without synchronising
   int epoch_ = 0;
   int64_t generation_ = 0;
   Tensor node_search_order_;

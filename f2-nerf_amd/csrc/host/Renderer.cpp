@@ -23,8 +23,10 @@ SHShader::SHShader(GlobalDataPool* gdp) {  // SHShader.cpp:9-20
   degree_ = c.Int("shader.degree");
   d_hidden_ = c.Int("shader.d_hidden");
   n_hiddens_ = c.Int("shader.n_hiddens");
-  TORCH_CHECK(degree_ >= 1 && degree_ <= 8, "SH degree ", degree_, " is not supported (1..8; the fused colour path needs degree 4: 16 + 16 inputs)");
+  TORCH_CHECK(degree_ >= 1 && degree_ <= 8, "SH degree ", degree_, " is not supported (1..8, SHShader.cu:51-102)");
+  TORCH_CHECK(d_in_ == 16 + degree_ * degree_, "shader.d_in must be 16 shading features + degree^2 SH coefficients (SHShader.cpp:24-25)");
   mlp_ = std::make_unique<FusedMLP>(gdp, d_in_, d_out_, d_hidden_, n_hiddens_);
+  fused_ok_ = degree_ == 4 && d_hidden_ == 64 && n_hiddens_ == 2;
 }
 
 Tensor SHShader::SHEncode(const Tensor& dirs) {  // SHShader.cu:108-118
@@ -135,6 +137,15 @@ Tensor CustomOps::WeightVar(Tensor weights, Tensor idx_start_end) {
 
 Tensor SHShader::QueryFromField(const Tensor& field_feats, const Tensor& dirs, const Tensor& app_emb,
                                 const Tensor& sample_emb_idx, Tensor* app_emb_grad) {
+  if (!fused_ok_) {
+    // op by op, as the reference: shading_feat = [1 | feat[1:]] (+ app_emb[img], CustomOps::ScatterAdd) -> SHShader::Query
+    // (Renderer.cpp:181-188).  The appearance embedding's gradient arrives through autograd here (app_emb.grad): the caller
+    // moves it into the optimiser's buffer (ExpRunner::TrainStepAutograd).
+    Tensor shading = torch::cat({torch::ones_like(field_feats.index({Slc(), Slc(0, 1)})), field_feats.index({Slc(), Slc(1, 16)})}, 1);
+    const bool emb = app_emb.defined() && sample_emb_idx.defined() && app_emb.numel() > 0 && sample_emb_idx.numel() > 0;
+    if (emb) shading = shading + app_emb.index_select(0, sample_emb_idx.to(torch::kInt64));
+    return Query(shading, dirs.contiguous());
+  }
   return ShadeFunction::apply(field_feats, mlp_->params_, app_emb, dirs.contiguous(), sample_emb_idx,
                               reinterpret_cast<int64_t>(this), reinterpret_cast<int64_t>(app_emb_grad))[0];
 }
@@ -183,6 +194,10 @@ Renderer::Renderer(GlobalDataPool* gdp, int n_images) {  // Renderer.cpp:22-49
   app_emb_grad_ = torch::zeros({n_images, 16}, DevF32());
   const std::string bg = gdp->config_.Str("renderer.bg_color");
   bg_color_type_ = bg == "white" ? BGColorType::white : (bg == "black" ? BGColorType::black : BGColorType::rand_noise);
+}
+
+bool Renderer::FusedPathOk() const {
+  return static_cast<Hash3DAnchored*>(scene_field_.get())->fused_ok_ && static_cast<SHShader*>(shader_.get())->fused_ok_;
 }
 
 void Renderer::ZeroGrad() {
@@ -395,7 +410,8 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   // The NEXT batch's intersection and march start now, on the side stream, against the octree as it stands (see Renderer.h):
   // they run underneath this step's pre-pass instead of behind its stat update.
   bool spec_begun = false;
-  if (train && async_count && dp_world_ <= 1 && speculative_sampling_ && next_batch_.valid && n_all_pts > 0 && !pending_samples_.active &&
+  const bool spec_now = speculative_sampling_ == 1 || (speculative_sampling_ == 2 && ps->pers_octree_->QuietEpochs() >= kSpecQuietEpochs);
+  if (train && async_count && dp_world_ <= 1 && spec_now && next_batch_.valid && n_all_pts > 0 && !pending_samples_.active &&
       !ps->MaintenanceDue()) {
     PreSampleSpecBegin(next_batch_.rays_o, next_batch_.rays_d, next_batch_.fineness, /*after_main_stream=*/!consumed_side_samples_);
     spec_begun = true;
@@ -610,7 +626,7 @@ RenderResult Renderer::RenderForward(const Tensor& rays_o, const Tensor& rays_d,
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   auto* shader = static_cast<SHShader*>(shader_.get());
   TORCH_CHECK(gdp->mode_ != RunningMode::TRAIN, "RenderForward is the inference path");
-  if (!(shader->degree_ == 4 && shader->n_hiddens_ == 2)) return Render(rays_o, rays_d, bounds, Tensor());  // (unfused colour path)
+  if (!FusedPathOk()) return Render(rays_o, rays_d, bounds, Tensor());  // (network shapes without fused kernels: op by op)
   torch::NoGradGuard no_grad;
   const int n_rays = rays_o.size(0);
   RenderFront fr = SampleAndFilter(rays_o, rays_d, bounds, Tensor(), /*async_count=*/true);
@@ -662,7 +678,7 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   }
   SampleResultFlex& es = fr.es;
   const int n_kept = fr.n_kept, n_edge = fr.n_edge, n = n_kept + 2 * n_edge;
-  TORCH_CHECK(shader->degree_ == 4 && shader->n_hiddens_ == 2, "fused shading needs SH4 + 2 hidden layers");
+  TORCH_CHECK(FusedPathOk(), "the untaped training step needs the shipped network shapes (ExpRunner::TrainStep takes the taped path otherwise)");
 
   // Row layout of the field's arrays: [survivors | edge samples], or -- when the survivor count is still on the device
   // (fr.dyn: n_kept is then the capacity) -- [edge samples | survivors] so that every offset is known on the host.

@@ -21,6 +21,9 @@ class SHShader : public Shader {
 
   std::unique_ptr<FusedMLP> mlp_;
   int d_hidden_, n_hiddens_, degree_;
+  // the fused SH + colour-MLP kernels exist for the shipped shader (SH degree 4, 32 -> 64 -> 64 -> 3); any other
+  // shader.degree / d_hidden / n_hiddens (confs/shader/sh_shader.yaml, SHShader.cu:51-102) runs op by op as SHShader.cpp:23-29
+  bool fused_ok_ = true;
 };
 
 struct RenderResult {  // Renderer.h:18-27 of the reference
@@ -90,17 +93,13 @@ class Renderer : public Pipe {
   // repaired behind this step's stat update (PersSampler::CompleteSpeculative).  The sampler's two latency chains (~0.6 ms on
   // a converged scene) then no longer sit between one step's stat update and the next step's pre-pass.  Not used in the
   // iterations that run ProcOctree (node indices change: the batch is sampled after the update, as before).
-  // MEASURED (profiles/r03_speculation_experiments.txt): it takes the chains off the cycle, and the step does not get shorter --
-  // fresh scene 1.262 -> 1.247 ms, converged scene 0.903 -> 0.934 ms, 20 000 iterations 17.8 -> 19.6 s.  The compute queue is as
-  // long as the cycle was (both ~0.9 ms under mutual contention), and the repair -- whose duration is the re-walk and re-march
-  // of the LONGEST invalidated ray, ~85 us per converged step in which a leaf died, i.e. most of them -- now sits on the
-  // cycle instead.  Hence OFF by default; kept (and parity-tested) as an option.
-  struct NextBatch {
-    Tensor rays_o, rays_d;
-    float fineness = 1.f;
-    bool valid = false;
-  } next_batch_;
-  bool speculative_sampling_ = false;
+  // MEASURED (profiles/r03_speculation_experiments.txt): it pays while no leaf dies -- fresh scene 1.254 -> 1.171 ms per step --
+  // and costs where leaves die in most steps -- converged scene 0.917 -> 0.959 ms, 20 000 iterations 17.9 -> 19.7 s: the
+  // repair's duration is the re-walk and re-march of the LONGEST invalidated ray (~85 us), and it sits on the cycle the
+  // sampler left.  Hence mode 2 (the default): speculate only when no leaf has died for kSpecQuietEpochs stat updates, as far
+  // as the host can tell from a pinned word the update kernel writes (a timing decision only: samples are identical).
+  int speculative_sampling_ = 2;  // 0 never, 1 always (outside ProcOctree iterations), 2 while the octree is quiet
+  static constexpr int kSpecQuietEpochs = 8;
   int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
   void PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream);
   bool PreSampleSpecComplete();  // false: could not be repaired (tree re-numbered): dropped
@@ -130,6 +129,8 @@ class Renderer : public Pipe {
   std::vector<Tensor> States() override;
   std::vector<ParamGroup> OptimParamGroups() override;
   void ZeroGrad();
+  // both networks have the shapes the fused (untaped, streaming) training step and the forward-only render are built for
+  bool FusedPathOk() const;
 
   GlobalDataPool* global_data_pool_;
   std::unique_ptr<PtsSampler> pts_sampler_;

@@ -273,8 +273,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_readwrite("iter_step", &ExpRunner::iter_step_)
       .def_readwrite("check_nan", &ExpRunner::check_nan_)
       .def_readwrite("async_counts", &ExpRunner::async_counts_)
-      .def_property("speculative_sampling", [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },
-                    [](ExpRunner& r, bool on) { r.renderer_->speculative_sampling_ = on; })
+      .def_property("speculative_sampling",  // 0 / False never, 1 / True always, 2 while no leaf has died lately (default)
+                    [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },
+                    [](ExpRunner& r, int mode) { r.renderer_->speculative_sampling_ = mode; })
       .def("speculation_counters",  // batches sampled ahead of the stat update / behind it, rays repaired after a leaf died
            [](ExpRunner& r) {
              r.FinishPending();

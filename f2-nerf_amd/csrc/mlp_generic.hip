@@ -1,0 +1,336 @@
+// Fully-fused MLP for the network shapes the two register-resident kernels of mlp_dev.h do not cover: any tcnn
+// "FullyFusedMLP" a reference YAML can ask for (Field/TCNNWP.cpp:86-92: n_neurons in {16, 32, 64, 128}, n_hidden_layers >= 1,
+// ReLU, no bias, no output activation; confs/field/hash3d_anchored.yaml:4-6, confs/shader/sh_shader.yaml:2-6) with any input
+// width up to 128 (the colour network's input is 16 + degree^2: 17 ... 80 for SH degrees 1 ... 8, SHShader.cu:108-118).
+// The shipped configs (32 -> 64 (-> 64) -> 16) keep their specialised kernels; this file is what makes the others run
+// instead of returning F2N_ERR_UNSUPPORTED.
+//
+// Same arithmetic contract as mlp_dev.h (f16 weights and inter-layer activations, fp32 accumulation, outputs padded to 16),
+// built on v_mfma_f32_16x16x16_f16 so that ONE tiling serves every width that is a multiple of 16:
+//
+//   mfma16(A, B): D[i][j] = sum_k A[i][k] B[k][j], k < 16;  lane (c = l & 15, g = l >> 4)
+//     A: lane holds A[c][4g .. 4g+3]     B: lane holds B[4g .. 4g+3][c]     D: lane holds D[4g .. 4g+3][c]
+//
+//   forward, sample-column orientation: T[neuron 16t+i][sample j] = sum over k-blocks q of mfma16(W[16t+c][16q+4g..],
+//   X^T[16q+4g..][sample c]).  The D tile of neuron tile t -- lane (c = sample, g) holds neurons 16t+4g .. +3 -- IS the B
+//   operand of k-block t of the next layer after ReLU + f16 rounding: the layer chain stays in registers, for any depth.
+//
+// The backward follows tcnn's own structure (saved activations, gradient chain, one GEMM per weight matrix) rather than the
+// recompute-in-registers scheme of the specialised kernels -- a 128 x 128 weight gradient does not fit a wave's registers:
+//   1. the forward stores x and every hidden activation as f16 in a TILE-TRANSPOSED layout [tile][feature][16 samples],
+//   2. the gradient chain G_l = (W_{l+1}^T G_{l+1}) * relu'(H_l) runs in the same orientation against transposed weights
+//      and stores G_l (and dY) in the same layout,
+//   3. dW_l = G_l^T H_{l-1} contracts over SAMPLES: in the tile-transposed layout both operands of mfma16 are 8-byte
+//      contiguous reads; blocks own sample chunks, write per-block partial sums, f2n_reduce_partials folds them.
+#include "mlp_dev.h"
+
+#define F2N_MLPG_MAX_W 128
+
+__device__ __forceinline__ float4_t f2n_mfma16_fwd(half4_t a, half4_t b, float4_t acc) {
+#if F2N_REFERENCE_NUMERICS
+  const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  const float4_t blk = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, z, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; i++) acc[i] = acc[i] + blk[i];
+  return f2n_round_h4(acc);  // the f16 accumulator fragment of the reference-numerics build (mlp_dev.h)
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
+#endif
+}
+
+// Parameter block prepared per call (a few 10 KB: one tiny launch): input layer padded to d_in_pad columns with zeros, and
+// every matrix transposed for the gradient chain.
+struct F2nMlpgPrep {
+  const half_t* w0p;   // [DH][d_in_pad]
+  const half_t* wl;    // [n_hidden - 1][DH][DH]
+  const half_t* wo;    // [16][DH]
+  const half_t* w0pT;  // [d_in_pad][DH]
+  const half_t* wlT;   // [n_hidden - 1][DH][DH]   (each transposed)
+  const half_t* woT;   // [DH][16]
+};
+
+__global__ void mlpg_prep_kernel(int d_in, int d_in_pad, int dh, int n_hidden, const half_t* __restrict__ params, half_t* __restrict__ out,
+                                 int with_transposes) {
+  const int n0 = dh * d_in_pad, n1 = (n_hidden - 1) * dh * dh, no = 16 * dh, fwd = n0 + n1 + no;
+  const int total = with_transposes ? 2 * fwd : fwd;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i < fwd ? i : i - fwd;
+    const bool tr = i >= fwd;
+    half_t v;
+    if (j < n0) {  // W0: [dh][d_in] -> padded (transposed: [d_in_pad][dh])
+      const int r = tr ? j % dh : j / d_in_pad, k = tr ? j / dh : j % d_in_pad;
+      v = k < d_in ? params[(size_t) r * d_in + k] : (half_t) 0.f;
+    } else if (j < n0 + n1) {
+      const int jj = j - n0, l = jj / (dh * dh), e = jj % (dh * dh);
+      const int r = tr ? e % dh : e / dh, k = tr ? e / dh : e % dh;
+      v = params[(size_t) dh * d_in + (size_t) l * dh * dh + r * dh + k];
+    } else {
+      const int e = j - n0 - n1;  // Wo: [16][dh]  (transposed: [dh][16])
+      const int r = tr ? e % 16 : e / dh, k = tr ? e / 16 : e % dh;
+      v = params[(size_t) dh * d_in + (size_t) (n_hidden - 1) * dh * dh + r * dh + k];
+    }
+    out[i] = v;
+  }
+}
+
+// lane (c, g): element (feature 16t + 4g + r, sample c) of tile `tile` in a [tile][n_feat][16] array
+#define F2N_TT(base, tile, n_feat, feat) ((base) + ((size_t) (tile) * (n_feat) + (feat)) * 16)
+
+template <int DH, bool SAVE>
+__global__ __launch_bounds__(256) void mlpg_fwd_kernel(int n, int d_in, int d_in_pad, int n_hidden, F2nMlpgPrep w,
+                                                       const float* __restrict__ x, half_t* __restrict__ out_h,
+                                                       half_t* __restrict__ xT, half_t* __restrict__ hT /*[n_hidden][tiles][DH][16]*/) {
+  constexpr int NT = DH / 16;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int n_tiles = (n + 15) / 16;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  for (int tile = wave; tile < n_tiles; tile += n_waves) {
+    const int s = tile * 16 + c;
+    const bool valid = s < n;
+    float4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = z;
+    for (int q = 0; q < d_in_pad / 16; q++) {  // input layer: the x fragment of a k-block is formed once and used by every tile
+      half4_t xf;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int k = 16 * q + 4 * g + i;
+        xf[i] = (valid && k < d_in) ? (half_t) x[(size_t) s * d_in + k] : (half_t) 0.f;
+        if (SAVE) F2N_TT(xT, tile, d_in_pad, k)[c] = xf[i];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        acc[t] = f2n_mfma16_fwd(*(const half4_t*) (w.w0p + (size_t) (16 * t + c) * d_in_pad + 16 * q + 4 * g), xf, acc[t]);
+    }
+    half4_t h[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) h[t] = f2n_cvt4<true>(acc[t]);
+    for (int l = 0; l < n_hidden; l++) {
+      if (SAVE) {
+        half_t* dst = hT + (size_t) l * n_tiles * DH * 16;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) F2N_TT(dst, tile, DH, 16 * t + 4 * g + r)[c] = h[t][r];
+      }
+      if (l == n_hidden - 1) break;
+      const half_t* wl = w.wl + (size_t) l * DH * DH;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        acc[t] = z;
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+          acc[t] = f2n_mfma16_fwd(*(const half4_t*) (wl + (size_t) (16 * t + c) * DH + 16 * q + 4 * g), h[q], acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++) h[t] = f2n_cvt4<true>(acc[t]);
+    }
+    float4_t o = z;
+#pragma unroll
+    for (int q = 0; q < NT; q++) o = f2n_mfma16_fwd(*(const half4_t*) (w.wo + (size_t) c * DH + 16 * q + 4 * g), h[q], o);
+    if (valid && out_h != nullptr) *(half4_t*) (out_h + (size_t) s * 16 + 4 * g) = f2n_cvt4<false>(o);  // outputs 4g..4g+3 of sample c
+  }
+}
+
+// Gradient chain.  dy fp32 [n,16] is rounded to f16, multiplied by the loss scale and rounded again (TCNNWP.cpp:112,174).
+template <int DH>
+__global__ __launch_bounds__(256) void mlpg_bwd_chain_kernel(int n, int d_in, int d_in_pad, int n_hidden, F2nMlpgPrep w,
+                                                             const float* __restrict__ dy, float loss_scale,
+                                                             const half_t* __restrict__ hT, half_t* __restrict__ gT,
+                                                             half_t* __restrict__ dyT, float* __restrict__ dx) {
+  constexpr int NT = DH / 16;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int n_tiles = (n + 15) / 16;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  for (int tile = wave; tile < n_tiles; tile += n_waves) {
+    const int s = tile * 16 + c;
+    const bool valid = s < n;
+    half4_t dyf;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      dyf[i] = valid ? (half_t) ((float) (half_t) dy[(size_t) s * 16 + 4 * g + i] * loss_scale) : (half_t) 0.f;
+      F2N_TT(dyT, tile, 16, 4 * g + i)[c] = dyf[i];
+    }
+    half4_t gv[NT], gp[NT];
+    {  // last hidden layer: G = (Wo^T dY) * relu'(H_last)
+      const half_t* hl = hT + (size_t) (n_hidden - 1) * n_tiles * DH * 16;
+      half_t* gl = gT + (size_t) (n_hidden - 1) * n_tiles * DH * 16;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const float4_t a = __builtin_amdgcn_mfma_f32_16x16x16f16(*(const half4_t*) (w.woT + (size_t) (16 * t + c) * 16 + 4 * g), dyf, z, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const bool on = (float) F2N_TT(hl, tile, DH, 16 * t + 4 * g + r)[c] > 0.f;
+          gv[t][r] = on ? (half_t) a[r] : (half_t) 0.f;
+          F2N_TT(gl, tile, DH, 16 * t + 4 * g + r)[c] = gv[t][r];
+        }
+      }
+    }
+    for (int l = n_hidden - 1; l >= 1; l--) {  // G_{l-1} = (W_l^T G_l) * relu'(H_{l-1})
+      const half_t* wt = w.wlT + (size_t) (l - 1) * DH * DH;
+      const half_t* hl = hT + (size_t) (l - 1) * n_tiles * DH * 16;
+      half_t* gl = gT + (size_t) (l - 1) * n_tiles * DH * 16;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        float4_t a = z;
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+          a = __builtin_amdgcn_mfma_f32_16x16x16f16(*(const half4_t*) (wt + (size_t) (16 * t + c) * DH + 16 * q + 4 * g), gv[q], a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const bool on = (float) F2N_TT(hl, tile, DH, 16 * t + 4 * g + r)[c] > 0.f;
+          gp[t][r] = on ? (half_t) a[r] : (half_t) 0.f;
+          F2N_TT(gl, tile, DH, 16 * t + 4 * g + r)[c] = gp[t][r];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++) gv[t] = gp[t];
+    }
+    if (dx != nullptr) {  // dL/dx = W0^T G_0, delivered unscaled in fp32 (TCNNWP.cpp:231)
+      for (int t = 0; t < d_in_pad / 16; t++) {
+        float4_t a = z;
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+          a = __builtin_amdgcn_mfma_f32_16x16x16f16(*(const half4_t*) (w.w0pT + (size_t) (16 * t + c) * DH + 16 * q + 4 * g), gv[q], a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int k = 16 * t + 4 * g + r;
+          if (valid && k < d_in) dx[(size_t) s * d_in + k] = a[r] / loss_scale;
+        }
+      }
+    }
+  }
+}
+
+// Weight gradients: blockIdx.y = matrix (0: input layer, 1 .. n_hidden-1: hidden layers, n_hidden: output layer), blockIdx.x =
+// sample chunk.  The four waves of a block split the matrix's 16 x 16 tiles round-robin (at most 16 accumulators per wave for
+// 128 x 128); every block writes its matrix's section of partials[blockIdx.x][n_params] (zeros if its chunk is empty).
+__global__ __launch_bounds__(256) void mlpg_dw_kernel(int n_tiles, int d_in, int d_in_pad, int dh, int n_hidden,
+                                                      const half_t* __restrict__ xT, const half_t* __restrict__ hT,
+                                                      const half_t* __restrict__ gT, const half_t* __restrict__ dyT,
+                                                      float* __restrict__ partials, int n_params) {
+  const int m = blockIdx.y;
+  const int rows = m == n_hidden ? 16 : dh, cols = m == 0 ? d_in_pad : dh, true_cols = m == 0 ? d_in : dh;
+  const size_t hl = (size_t) n_tiles * dh * 16;
+  const half_t* A = m == n_hidden ? dyT : gT + (size_t) m * hl;            // [tile][rows][16]
+  const half_t* B = m == 0 ? xT : hT + (size_t) (m - 1) * hl;              // [tile][cols][16]
+  const size_t off = m == 0 ? 0 : (size_t) dh * d_in + (size_t) (m - 1) * dh * dh;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int rt_n = rows / 16, ct_n = cols / 16, n_mt = rt_n * ct_n;
+  const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
+  const float4_t z = {0.f, 0.f, 0.f, 0.f};
+  float4_t acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) acc[u] = z;
+  for (int tile = t0; tile < t1; tile++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int idx = wv + 4 * u;
+      if (idx < n_mt) {
+        const int rt = idx / ct_n, ct = idx - rt * ct_n;
+        const half4_t a = *(const half4_t*) (F2N_TT(A, tile, rows, 16 * rt + c) + 4 * g);
+        const half4_t b = *(const half4_t*) (F2N_TT(B, tile, cols, 16 * ct + c) + 4 * g);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc[u], 0, 0, 0);
+      }
+    }
+  }
+  float* dst = partials + (size_t) blockIdx.x * n_params + off;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int idx = wv + 4 * u;
+    if (idx < n_mt) {
+      const int rt = idx / ct_n, ct = idx - rt * ct_n;
+      const int col = 16 * ct + c;
+      if (col < true_cols) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(size_t) (16 * rt + 4 * g + r) * true_cols + col] = acc[u][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side (called by f2n_mlp_fwd / f2n_mlp_bwd in field.hip for the shapes the specialised kernels do not cover)
+// ---------------------------------------------------------------------------------------------------
+bool f2n_mlpg_shape_ok(int d_in, int d_hidden, int n_hidden) {
+  return d_in >= 1 && d_in <= F2N_MLPG_MAX_W && (d_hidden == 16 || d_hidden == 32 || d_hidden == 64 || d_hidden == 128) && n_hidden >= 1 &&
+         n_hidden <= 8;
+}
+
+static size_t mlpg_prep_halves(int d_in_pad, int dh, int n_hidden) { return (size_t) dh * d_in_pad + (size_t) (n_hidden - 1) * dh * dh + 16 * (size_t) dh; }
+
+static int mlpg_prepare(hipStream_t st, int d_in, int dh, int n_hidden, const half_t* params_h, bool with_transposes, F2nMlpgPrep& w) {
+  const int d_in_pad = (d_in + 15) / 16 * 16;
+  const size_t fwd = mlpg_prep_halves(d_in_pad, dh, n_hidden);
+  half_t* buf = (half_t*) f2n_ws_get(F2N_WS_MLPG_W, sizeof(half_t) * 2 * fwd);
+  if (buf == nullptr) return F2N_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(mlpg_prep_kernel, dim3(64), dim3(256), 0, st, d_in, d_in_pad, dh, n_hidden, params_h, buf, with_transposes ? 1 : 0);
+  w.w0p = buf;
+  w.wl = buf + (size_t) dh * d_in_pad;
+  w.wo = w.wl + (size_t) (n_hidden - 1) * dh * dh;
+  w.w0pT = buf + fwd;
+  w.wlT = w.w0pT + (size_t) dh * d_in_pad;
+  w.woT = w.wlT + (size_t) (n_hidden - 1) * dh * dh;
+  return f2n_launch_status();
+}
+
+template <bool SAVE>
+static void mlpg_launch_fwd(hipStream_t st, int dh, unsigned grid, int n, int d_in, int d_in_pad, int n_hidden, const F2nMlpgPrep& w,
+                            const float* x, half_t* out_h, half_t* xT, half_t* hT) {
+#define F2N_MLPG_FWD(W) hipLaunchKernelGGL((mlpg_fwd_kernel<W, SAVE>), dim3(grid), dim3(256), 0, st, n, d_in, d_in_pad, n_hidden, w, x, out_h, xT, hT)
+  if (dh == 16) F2N_MLPG_FWD(16);
+  else if (dh == 32) F2N_MLPG_FWD(32);
+  else if (dh == 64) F2N_MLPG_FWD(64);
+  else F2N_MLPG_FWD(128);
+#undef F2N_MLPG_FWD
+}
+
+int f2n_mlpg_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const void* params_h, const float* x, void* out_h) {
+  hipStream_t st = (hipStream_t) stream;
+  F2nMlpgPrep w;
+  int rc = mlpg_prepare(st, d_in, d_hidden, n_hidden, (const half_t*) params_h, false, w);
+  if (rc != F2N_OK) return rc;
+  const int d_in_pad = (d_in + 15) / 16 * 16, n_tiles = (n + 15) / 16;
+  const unsigned grid = (unsigned) min(2048, (n_tiles + 3) / 4);
+  mlpg_launch_fwd<false>(st, d_hidden, grid, n, d_in, d_in_pad, n_hidden, w, x, (half_t*) out_h, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+int f2n_mlpg_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, float loss_scale, const void* params_h, const float* x,
+                 const float* dy, float* dparams_f32_scaled, float* dx_f32) {
+  hipStream_t st = (hipStream_t) stream;
+  F2nMlpgPrep w;
+  int rc = mlpg_prepare(st, d_in, d_hidden, n_hidden, (const half_t*) params_h, true, w);
+  if (rc != F2N_OK) return rc;
+  const int dh = d_hidden, d_in_pad = (d_in + 15) / 16 * 16, n_tiles = (n + 15) / 16;
+  const size_t hl = (size_t) n_tiles * dh * 16;
+  const size_t halves = (size_t) n_tiles * d_in_pad * 16 + 2 * (size_t) n_hidden * hl + (size_t) n_tiles * 16 * 16;
+  half_t* acts = (half_t*) f2n_ws_get(F2N_WS_MLPG_ACTS, sizeof(half_t) * halves);
+  if (acts == nullptr) return F2N_ERR_INVALID_ARG;
+  half_t* xT = acts;
+  half_t* hT = xT + (size_t) n_tiles * d_in_pad * 16;
+  half_t* gT = hT + (size_t) n_hidden * hl;
+  half_t* dyT = gT + (size_t) n_hidden * hl;
+  const unsigned grid = (unsigned) min(2048, (n_tiles + 3) / 4);
+  mlpg_launch_fwd<true>(st, dh, grid, n, d_in, d_in_pad, n_hidden, w, x, nullptr, xT, hT);
+#define F2N_MLPG_BWD(W) hipLaunchKernelGGL((mlpg_bwd_chain_kernel<W>), dim3(grid), dim3(256), 0, st, n, d_in, d_in_pad, n_hidden, w, dy, loss_scale, hT, gT, dyT, dx_f32)
+  if (dh == 16) F2N_MLPG_BWD(16);
+  else if (dh == 32) F2N_MLPG_BWD(32);
+  else if (dh == 64) F2N_MLPG_BWD(64);
+  else F2N_MLPG_BWD(128);
+#undef F2N_MLPG_BWD
+  rc = f2n_launch_status();
+  if (rc != F2N_OK) return rc;
+  const int n_params = d_hidden * d_in + (n_hidden - 1) * d_hidden * d_hidden + 16 * d_hidden;
+  const int nb = n_tiles < 128 ? (n_tiles < 1 ? 1 : n_tiles) : 128;
+  float* partials = (float*) f2n_ws_get(F2N_WS_MLPG_DW, sizeof(float) * (size_t) nb * n_params);
+  if (partials == nullptr) return F2N_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(mlpg_dw_kernel, dim3(nb, n_hidden + 1), dim3(256), 0, st, n_tiles, d_in, d_in_pad, dh, n_hidden, xT, hT, gT, dyT,
+                     partials, n_params);
+  rc = f2n_launch_status();
+  if (rc != F2N_OK) return rc;
+  return f2n_reduce_partials(stream, n_params, nb, partials, dparams_f32_scaled);
+}

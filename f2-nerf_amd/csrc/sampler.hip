@@ -831,7 +831,7 @@ __global__ void update_stats_kernel(int n_nodes, int32_t* __restrict__ w_adder, 
                                     int32_t* __restrict__ mark, int32_t* __restrict__ w_stats,
                                     int32_t* __restrict__ a_stats, F2nTreeNode* __restrict__ nodes,
                                     F2nChildInfo* __restrict__ child_blocks, int reset_votes, int32_t* __restrict__ died_at,
-                                    int epoch, int32_t* __restrict__ death_epoch) {
+                                    int epoch, int32_t* __restrict__ death_epoch, int32_t* __restrict__ death_epoch_host) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const int m = mark[i];
@@ -857,6 +857,7 @@ __global__ void update_stats_kernel(int n_nodes, int32_t* __restrict__ w_adder, 
     if (died_at != nullptr && nodes[i].trans_idx >= 0) {  // alive until now: stamp the death for speculative samplers (MODE 3 above)
       died_at[i] = epoch;
       *death_epoch = epoch;  // (every writer of a launch stores the same value)
+      if (death_epoch_host != nullptr) *death_epoch_host = epoch;  // pinned host word: the host's "did a leaf die lately" hint
     }
     nodes[i].trans_idx = -1;
     const int pa = nodes[i].parent;
@@ -1188,17 +1189,17 @@ int f2n_early_stop_votes(void* stream, int n_rays, const int32_t* pts_start_end,
 int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
                          int32_t* a_stats, void* tree_nodes, void* child_blocks, int reset_votes) {
   return f2n_oct_update_stats_ex(stream, n_nodes, w_adder, a_adder, mark, w_stats, a_stats, tree_nodes, child_blocks, reset_votes,
-                                 nullptr, 0, nullptr);
+                                 nullptr, 0, nullptr, nullptr);
 }
 
 int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
                             int32_t* a_stats, void* tree_nodes, void* child_blocks, int reset_votes, int32_t* died_at, int epoch,
-                            int32_t* death_epoch) {
+                            int32_t* death_epoch, int32_t* death_epoch_host) {
   if (n_nodes < 0 || (died_at != nullptr) != (death_epoch != nullptr)) return F2N_ERR_INVALID_ARG;
   if (n_nodes == 0) return F2N_OK;
   hipLaunchKernelGGL(update_stats_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, n_nodes,
                      w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks, reset_votes,
-                     died_at, epoch, death_epoch);
+                     died_at, epoch, death_epoch, death_epoch_host);
   return f2n_launch_status();
 }
 

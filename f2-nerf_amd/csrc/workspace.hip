@@ -16,13 +16,13 @@ struct Slot {
   void* ptr = nullptr;
   size_t bytes = 0;
 };
-Slot g_slots[16][8];
+Slot g_slots[16][F2N_WS_SLOTS];
 std::mutex g_mu;
 }  // namespace
 
 void* f2n_ws_get(int slot, size_t bytes) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 8) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= F2N_WS_SLOTS) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   Slot& s = g_slots[dev][slot];
   if (s.bytes < bytes) {

@@ -30,11 +30,11 @@ def host():
     return _host
 
 
-def xavier_mlp_params(rng, n_hidden):
+def xavier_mlp_params(rng, n_hidden, d_in=32, d_hidden=64):
     """Flat fp32 parameter vector in the exchange layout (layers first->last, each [out,in] row-major, last layer
     padded to 16 rows).  tcnn's pcg32 init stream cannot be reproduced, weights are exchanged as arrays."""
     parts = []
-    for rows, cols in [(64, 32)] + [(64, 64)] * (n_hidden - 1) + [(16, 64)]:
+    for rows, cols in [(d_hidden, d_in)] + [(d_hidden, d_hidden)] * (n_hidden - 1) + [(16, d_hidden)]:
         s = np.sqrt(6.0 / (rows + cols))
         parts.append(rng.uniform(-s, s, rows * cols).astype(np.float32))
     return np.concatenate(parts)
@@ -56,7 +56,8 @@ def initial_states(state, cfg, seed=2022, table_init="reference", n_images=None)
     milestones = np.array(list(reversed(cfg["pts_sampler"]["sub_div_milestones"])), np.int32)
     arrays = [state["tree_nodes"], state["pers_trans"], np.zeros(n_nodes, np.int32), milestones,
               table, state["prim_pool"], state["bias_pool"], np.array([int(state["n_volumes"])], np.int32),
-              xavier_mlp_params(rng, int(cfg["field"]["n_hidden_layers"])), xavier_mlp_params(rng, int(cfg["shader"]["n_hiddens"])),
+              xavier_mlp_params(rng, int(cfg["field"]["n_hidden_layers"]), 32, int(cfg["field"]["mlp_hidden_dim"])),
+              xavier_mlp_params(rng, int(cfg["shader"]["n_hiddens"]), int(cfg["shader"]["d_in"]), int(cfg["shader"]["d_hidden"])),
               (rng.standard_normal((n_images, 16)) * 0.1).astype(np.float32)]
     return arrays
 

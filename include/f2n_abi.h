@@ -200,7 +200,9 @@ int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a
  * the updated tree (tests/test_gpu_parity.py::test_speculative_sampling_repair). */
 int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
                             int32_t* a_stats, void* tree_nodes, void* child_blocks /*or NULL*/, int reset_votes,
-                            int32_t* died_at /*[n_nodes] or NULL*/, int epoch, int32_t* death_epoch /*[1] or NULL*/);
+                            int32_t* died_at /*[n_nodes] or NULL*/, int epoch, int32_t* death_epoch /*[1] or NULL*/,
+                            int32_t* death_epoch_host /*[1] device-accessible HOST word or NULL: also receives the epoch of a
+                            death -- a hint the host may read without synchronising (whether speculating pays right now)*/);
 int f2n_oct_intersect_repair(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                              const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
                              int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans, const void* child_blocks,

@@ -902,8 +902,8 @@ void oracle_scatter_add_bwd(int n_emb, int n_all, int c, const int32_t* idx, con
  *           kept in fp16; dL/dW is accumulated in fp32 over the batch then rounded to fp16 (param
  *           precision, :214-215) before the /loss_scale (:232); dL/dx is fp32 /loss_scale (:231).
  * ---------------------------------------------------------------------------------------------- */
-#define OR_MLP_MAX_W 64
-#define OR_MLP_MAX_L 4
+#define OR_MLP_MAX_W 128
+#define OR_MLP_MAX_L 9
 
 static void or_mlp_dims(int d_in, int d_hidden, int n_hidden, int* n_layers, int* rows, int* cols) {
   int L = n_hidden + 1;

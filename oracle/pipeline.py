@@ -38,23 +38,24 @@ class HashGrid:
         return capi.f2h(self.table_f32.reshape(-1))
 
 
-def field_fwd(grid, mlp_params, pts_warped, volume_idx, want_ctx=False):
-    """AnchoredQuery: (p+1)/2 -> hash -> fp32 -> tcnn MLP (32->64->16) -> fp32 [n,16]."""
+def field_fwd(grid, mlp_params, pts_warped, volume_idx, want_ctx=False, d_hidden=64, n_hidden=1):
+    """AnchoredQuery: (p+1)/2 -> hash -> fp32 -> tcnn MLP (32->64->16 in the shipped configs) -> fp32 [n,16]."""
     q01 = ((np.asarray(pts_warped, F32) + F32(1.)) * F32(.5)).astype(F32)
     x_h = capi.hash_fwd(grid.table_h, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q01,
                         volume_idx, grid.n_volumes, grid.scales)
     x = capi.h2f(x_h)
-    out_h, acts = capi.mlp_fwd(mlp_params, x, 64, 1, want_acts=True)
+    out_h, acts = capi.mlp_fwd(mlp_params, x, d_hidden, n_hidden, want_acts=True)
     feat = capi.h2f(out_h)
     if want_ctx:
-        return feat, dict(q01=q01, x=x, x_h=x_h, acts=acts, vol=np.ascontiguousarray(volume_idx, np.int32))
+        return feat, dict(q01=q01, x=x, x_h=x_h, acts=acts, vol=np.ascontiguousarray(volume_idx, np.int32), shape=(d_hidden, n_hidden))
     return feat
 
 
 def field_bwd(grid, mlp_params, ctx, dfeat, loss_scale=128.0, fp32_accumulate=True):
     """Returns (dparams fp32 unscaled, grad_table in the table's addressing: fp32 if fp32_accumulate else the
     order-dependent fp16 accumulation), both as TRUE (unscaled) gradients."""
-    dparams, _dx, dx_scaled_h = capi.mlp_bwd(mlp_params, ctx["x"], ctx["acts"], dfeat, 64, 1, loss_scale)
+    d_hidden, n_hidden = ctx.get("shape", (64, 1))
+    dparams, _dx, dx_scaled_h = capi.mlp_bwd(mlp_params, ctx["x"], ctx["acts"], dfeat, d_hidden, n_hidden, loss_scale)
     pool_halves = grid.table_f32.size
     g = capi.hash_bwd(pool_halves, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, ctx["q01"],
                       ctx["vol"], grid.n_volumes, dx_scaled_h, grid.scales, fp32_accumulate=fp32_accumulate)
@@ -66,21 +67,21 @@ def field_bwd(grid, mlp_params, ctx, dfeat, loss_scale=128.0, fp32_accumulate=Tr
 # ---------------------------------------------------------------------------------------------------
 # Shader
 # ---------------------------------------------------------------------------------------------------
-def shade_input(feat, dirs, app_emb=None, sample_emb_idx=None):
+def shade_input(feat, dirs, app_emb=None, sample_emb_idx=None, degree=4):
     feat = np.asarray(feat, F32)
     shading = np.concatenate([np.ones_like(feat[:, :1]), feat[:, 1:]], 1)          # Renderer.cpp:181-182
     if app_emb is not None:
         shading = capi.scatter_add(app_emb, sample_emb_idx, shading)                # Scatter.cu:10-18
-    return np.concatenate([shading, capi.sh_encode(dirs, 4)], -1).astype(F32)      # SHShader.cpp:24-25
+    return np.concatenate([shading, capi.sh_encode(dirs, degree)], -1).astype(F32)  # SHShader.cpp:24-25
 
 
-def shade_fwd(color_params, feat, dirs, app_emb=None, sample_emb_idx=None, want_ctx=False):
-    x = shade_input(feat, dirs, app_emb, sample_emb_idx)
-    out_h, acts = capi.mlp_fwd(color_params, x, 64, 2, want_acts=True)
+def shade_fwd(color_params, feat, dirs, app_emb=None, sample_emb_idx=None, want_ctx=False, d_hidden=64, n_hidden=2, degree=4):
+    x = shade_input(feat, dirs, app_emb, sample_emb_idx, degree)
+    out_h, acts = capi.mlp_fwd(color_params, x, d_hidden, n_hidden, want_acts=True)
     o = capi.h2f(out_h)[:, :3]
     rgb = ((F32(1.) + F32(2.) * EPS_RGB) / (F32(1.) + _exp(-o)) - EPS_RGB).astype(F32)  # SHShader.cpp:27-28
     if want_ctx:
-        return rgb, dict(x=x, acts=acts, o=o)
+        return rgb, dict(x=x, acts=acts, o=o, shape=(d_hidden, n_hidden))
     return rgb
 
 
@@ -90,7 +91,8 @@ def shade_bwd(color_params, ctx, drgb, n_emb=0, sample_emb_idx=None, loss_scale=
     do = (np.asarray(drgb, F32) * ((F32(1.) + F32(2.) * EPS_RGB) * e / ((F32(1.) + e) * (F32(1.) + e)))).astype(F32)
     dy = np.zeros((o.shape[0], 16), F32)
     dy[:, :3] = do
-    dparams, dx, _ = capi.mlp_bwd(color_params, ctx["x"], ctx["acts"], dy, 64, 2, loss_scale)
+    d_hidden, n_hidden = ctx.get("shape", (64, 2))
+    dparams, dx, _ = capi.mlp_bwd(color_params, ctx["x"], ctx["acts"], dy, d_hidden, n_hidden, loss_scale)
     dshading = np.ascontiguousarray(dx[:, :16])
     dfeat = dshading.copy()
     dfeat[:, 0] = 0                                       # the constant-1 column has no gradient to feat

@@ -49,18 +49,20 @@ def oracle_train_iteration(st, cfg, arrays, rays_o, rays_d_raw, emb_idx, gt, noi
     ps = cfg["pts_sampler"]
     hits = oc.oct_intersect(st["search_order"], rays_o, rays_d, float(ps["near"]), 1e8, tn, int(ps["max_oct_intersect_per_ray"]))
     smp = oc.ray_march(rays_o, rays_d, noise, float(ps["sample_l"]), bool(ps["scale_by_dis"]), *hits, tn, tr)
-    feat_all = op.field_fwd(grid, p_field, smp["pts"], smp["anchors"][:, 0])
+    fsh = dict(d_hidden=int(cfg["field"]["mlp_hidden_dim"]), n_hidden=int(cfg["field"]["n_hidden_layers"]))
+    ssh = dict(d_hidden=int(cfg["shader"]["d_hidden"]), n_hidden=int(cfg["shader"]["n_hiddens"]), degree=int(cfg["shader"]["degree"]))
+    feat_all = op.field_fwd(grid, p_field, smp["pts"], smp["anchors"][:, 0], **fsh)
     w_pre, a_pre, mask, new_se = op.early_stop(feat_all[:, 0], smp["dt"], smp["pts_idx_bounds"])
     pts, dirs, dt, t, anchors = op.compact(mask, smp["pts"], smp["dirs"], smp["dt"], smp["t"], smp["anchors"])
     m = len(pts)
     e_pts, e_idx = oc.edge_samples(st["edge_pool"], tr, edge_idx, edge_coords)
     q_pts = np.concatenate([pts, e_pts.reshape(-1, 3)], 0)
     q_vol = np.concatenate([anchors[:, 0], e_idx.reshape(-1)], 0).astype(np.int32)
-    feat, fctx = op.field_fwd(grid, p_field, q_pts, q_vol, want_ctx=True)
+    feat, fctx = op.field_fwd(grid, p_field, q_pts, q_vol, want_ctx=True, **fsh)
     scene_feat, edge_feat = feat[:m], feat[m:].reshape(len(edge_idx), 2, 16)
     use_emb = bool(cfg["renderer"]["use_app_emb"])
     sidx = oc.scatter_idx(m, new_se, emb_idx) if use_emb else None
-    rgb, sctx = op.shade_fwd(p_color, scene_feat, dirs, app_emb if use_emb else None, sidx, want_ctx=True)
+    rgb, sctx = op.shade_fwd(p_color, scene_feat, dirs, app_emb if use_emb else None, sidx, want_ctx=True, **ssh)
     comp = op.composite_fwd(scene_feat, dt, t, rgb, bg, new_se, want_ctx=True)
     tcfg = cfg["train"]
     var_w = 0.0

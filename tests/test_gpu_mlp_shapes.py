@@ -1,0 +1,151 @@
+"""GPU (run with `-m gpu`): the tcnn FullyFusedMLP shapes a reference YAML can ask for beyond the two shipped networks
+(Field/TCNNWP.cpp:86-92: n_neurons 16 / 32 / 64 / 128, any n_hidden_layers; colour-network inputs of 16 + degree^2 for SH degrees
+1..8) -- csrc/mlp_generic.hip through f2n_mlp_fwd / f2n_mlp_bwd -- against the oracle's MLP restatement, and one whole
+iteration + a short training run with a non-default field network, a non-default colour network and SH degree 3 through
+the host's unfused path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capi as oc  # noqa: E402
+from test_gpu_e2e import fox_batch, oracle_train_iteration, rel_err  # noqa: E402
+
+F32 = np.float32
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import capi
+    capi.lib()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def rt():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    runtime.host()
+    return runtime
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def rand_params(rng, d_in, d_hidden, n_hidden):
+    parts = []
+    for rows, cols in [(d_hidden, d_in)] + [(d_hidden, d_hidden)] * (n_hidden - 1) + [(16, d_hidden)]:
+        s = np.sqrt(6.0 / (rows + cols))
+        parts.append(rng.uniform(-s, s, rows * cols).astype(F32))
+    return np.concatenate(parts)
+
+
+SHAPES = [(32, 16, 1), (32, 32, 2), (32, 128, 4), (32, 64, 3), (17, 64, 2), (25, 128, 3), (80, 128, 2), (48, 16, 5), (32, 128, 1)]
+
+
+@pytest.mark.parametrize("d_in,d_hidden,n_hidden", SHAPES)
+@pytest.mark.parametrize("n", [4099, 31])
+def test_general_mlp_forward_and_backward(hip, d_in, d_hidden, n_hidden, n):
+    """f2n_mlp_fwd / f2n_mlp_bwd for network shapes outside the two specialised kernels: outputs within one f16 ulp of the
+    oracle (fp32 accumulation in another order), dL/dx and dL/dparams within the tolerances of the shipped shapes' tests."""
+    rng = np.random.default_rng(d_in * 1000 + d_hidden * 10 + n_hidden)
+    assert hip.lib().f2n_mlp_n_params(d_in, d_hidden, n_hidden) == oc.mlp_n_params(d_in, d_hidden, n_hidden)
+    params = rand_params(rng, d_in, d_hidden, n_hidden)
+    assert params.size == oc.mlp_n_params(d_in, d_hidden, n_hidden)
+    x = rng.standard_normal((n, d_in)).astype(F32)
+    ph = T(oc.f2h(params).view(np.float16))
+    out = torch.zeros((n, 16), dtype=torch.float16, device=DEV)
+    hip.mlp_fwd(n, d_in, d_hidden, n_hidden, ph, T(x), out)
+    ref_h, acts = oc.mlp_fwd(params, x, d_hidden, n_hidden, want_acts=True)
+    got, ref = N(out).astype(F32), oc.h2f(ref_h)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() <= 4 * 2.0 ** -11 * scale, (np.abs(got - ref).max(), scale)
+    assert (got == ref).mean() > 0.9, (got == ref).mean()
+    # backward
+    dy = (rng.standard_normal((n, 16)) * 1e-2).astype(F32)
+    dparams = torch.zeros(params.size, device=DEV)
+    dx = torch.full((n, d_in), 7.0, device=DEV)
+    hip.mlp_bwd(n, d_in, d_hidden, n_hidden, 128.0, ph, T(x), T(dy), dparams, dx)
+    rdp, rdx, _ = oc.mlp_bwd(params, x, acts, dy, d_hidden, n_hidden, 128.0)
+    gdx, gdp = N(dx), N(dparams) / F32(128.)
+    assert np.abs(gdx - rdx).max() <= 6e-3 * np.abs(rdx).max() + 1e-7, (np.abs(gdx - rdx).max(), np.abs(rdx).max())
+    # the oracle rounds dparams to fp16 twice (reference behaviour); compare at that resolution
+    assert np.abs(gdp - rdp).max() <= 6e-3 * np.abs(rdp).max() + 1e-7, (np.abs(gdp - rdp).max(), np.abs(rdp).max())
+    # a second call ACCUMULATES into dparams (TCNNWP.cpp:232 semantics of the shipped shapes' entry point)
+    hip.mlp_bwd(n, d_in, d_hidden, n_hidden, 128.0, ph, T(x), T(dy), dparams, dx)
+    assert np.abs(N(dparams) / F32(256.) - gdp).max() <= 1e-3 * np.abs(gdp).max() + 1e-7
+
+
+def test_unsupported_shapes_still_say_so(hip):
+    for d_in, d_hidden, n_hidden in ((32, 48, 1), (32, 256, 1), (200, 64, 1), (32, 64, 0), (32, 64, 9)):
+        x = torch.zeros((16, max(d_in, 1)), device=DEV)
+        out = torch.zeros((16, 16), dtype=torch.float16, device=DEV)
+        ph = torch.zeros(1 << 18, dtype=torch.float16, device=DEV)
+        with pytest.raises(hip.F2nError):
+            hip.mlp_fwd(16, d_in, d_hidden, n_hidden, ph, x, out)
+
+
+def test_nondefault_networks_train_through_the_host(rt, fox_state):
+    """field.mlp_hidden_dim 32 / n_hidden_layers 2, shader SH degree 3 (d_in 25), d_hidden 128, n_hiddens 3: the host routes the
+    field through f2n_hash_fwd -> general MLP -> f2n_hash_bwd and the shader through f2n_sh_encode -> general MLP, on the tape.
+    One iteration against the oracle pipeline with the same shapes (samples exact, RGB 1e-3, gradients), then training."""
+    st = fox_state
+    rng = np.random.default_rng(8)
+    overrides = ["field.log2_table_size=14", "field.mlp_hidden_dim=32", "field.n_hidden_layers=2", "shader.degree=3", "shader.d_in=25",
+                 "shader.d_hidden=128", "shader.n_hiddens=3", "train.learning_rate_warm_up_end_iter=20"]
+    runner, cfg, arrays = rt.make_runner(st, "wanjinyou", overrides, seed=7, table_init=0.3)
+    R, NE = 512, 512
+    runner.n_edge_pts = NE
+    runner.iter_step = 1
+    runner.update_ada_params()
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    gt = rng.random((R, 3), dtype=F32)
+    noise = (((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(float(runner.fineness))).astype(F32)
+    bg = rng.random((R, 3), dtype=F32)
+    eidx = rng.integers(0, st["edge_pool"].size // 64, NE).astype(np.int32)
+    ecoord = (rng.random((NE, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32)
+    d = rt.to_dev(ro, rd, bounds, gt, cam, noise, bg, eidx, ecoord)
+    runner.set_forced_randoms(d[5], d[6], d[7], d[8])
+    ref = oracle_train_iteration(st, cfg, arrays, ro, rd, cam, gt, noise, bg, eidx, ecoord, iter_step=1)
+    s = runner.get_samples(d[0], d[1], d[2])
+    for k in ("pts_idx_bounds", "anchors", "t"):
+        assert (N(s[k]) == ref["smp"][k]).all(), k
+    runner.zero_grad()
+    stats = runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
+    assert stats["n_samples"] == len(ref["smp"]["t"]) and abs(stats["n_meaningful"] - ref["n_kept"]) <= 2
+    assert abs(float(stats["loss"]) - ref["loss"]) <= 1e-3 * max(1.0, abs(ref["loss"])), (float(stats["loss"]), ref["loss"])
+    g = {k: N(v) for k, v in runner.grads().items()}
+    rg = ref["grads"]
+    for k in ("color_mlp", "field_mlp", "app_emb"):
+        assert g[k].shape == np.asarray(rg[k]).shape, (k, g[k].shape, np.asarray(rg[k]).shape)
+        assert np.abs(g[k] - rg[k]).max() <= 3e-2 * np.abs(rg[k]).max() + 1.01 * 2.0 ** -24, (k, rel_err(g[k], rg[k]))
+    a, b = g["feat_pool"].reshape(-1).astype(np.float64), rg["feat_pool"].reshape(-1).astype(np.float64)
+    assert float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999
+    out = runner.render_train(d[0], d[1], d[2], d[4])
+    assert np.abs(N(out["colors"]) - ref["colors"]).max() <= 1e-3
+    # forward-only rendering takes the same unfused path
+    img = N(runner.render_rays(d[0], d[1], d[2])[0])
+    assert img.shape == (R, 3) and np.isfinite(img).all()
+    # ... and the configuration trains
+    runner.clear_forced_randoms()
+    gtc = np.tile(np.array([[0.7, 0.4, 0.1]], F32), (R, 1))
+    dg = rt.to_dev(gtc)[0]
+    mse = [float(runner.train_step(d[0], d[1], d[2], dg, d[4], True)["mse"]) for _ in range(60)]
+    assert runner.iter_step == 61
+    assert np.isfinite(mse).all() and min(mse[-5:]) < 0.5 * mse[0], (mse[0], mse[-5:])
+    # checkpoint vector round trip with these shapes
+    states = [t.cpu().clone() for t in runner.states()]
+    assert states[8].numel() == 32 * 32 + 32 * 32 + 16 * 32 and states[9].numel() == 128 * 25 + 2 * 128 * 128 + 16 * 128
+    runner.load_states(states)
