@@ -5,6 +5,8 @@
 // scan, and the only host read-back of a GetSamples call is the pair (K, N) at its very end.
 #include "PersSampler.h"
 
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
 #include <cstring>
 #include <functional>
@@ -52,7 +54,16 @@ void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of 
   if (!death_epoch_.defined()) {
     death_epoch_ = torch::zeros({1}, DevI32());
     n_repaired_ = torch::zeros({1}, DevI32());
-    death_epoch_host_ = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, sizeof(int32_t), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+      death_epoch_host_ = static_cast<int32_t*>(h);
+      death_epoch_host_dev_ = static_cast<int32_t*>(d);
+      *death_epoch_host_ = 0;
+    } else {  // no hint then: mode "auto" of the speculative sampling never speculates
+      if (h != nullptr) (void) hipHostFree(h);
+      (void) hipGetLastError();
+    }
   }
   child_blocks_gpu_ = torch::empty({int64_t(n) * 8 * 32}, torch::TensorOptions().dtype(torch::kUInt8).device(torch::kCUDA));
   F2N_CALL(f2n_oct_build_child_blocks(CurStream(), n, VoidP(tree_nodes_gpu_), VoidP(child_blocks_gpu_)));
@@ -67,9 +78,13 @@ SampleResultFlex PersSampler::GetSamples(const Tensor& rays_o_raw, const Tensor&
   return FinishSamples(p);
 }
 
+PersOctree::~PersOctree() {
+  if (death_epoch_host_ != nullptr) (void) hipHostFree(death_epoch_host_);
+}
+
 int PersOctree::QuietEpochs() const {
-  if (!death_epoch_host_.defined()) return 0;
-  const int last = *reinterpret_cast<volatile const int32_t*>(death_epoch_host_.data_ptr<int32_t>());  // (may lag: a hint)
+  if (death_epoch_host_ == nullptr) return 0;
+  const int last = *reinterpret_cast<volatile const int32_t*>(death_epoch_host_);  // (may lag behind the device: a hint)
   return epoch_ - last;
 }
 
@@ -299,7 +314,7 @@ void PersSampler::FinishOctUpdate() {
   F2N_TIMED_CALL("oct_update_stats", f2n_oct_update_stats_ex(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
                                 I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
                                 VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1, I32P(oct.died_at_), oct.epoch_, I32P(oct.death_epoch_),
-                                I32P(oct.death_epoch_host_)));
+                                oct.death_epoch_host_dev_));
 
   while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610
     oct.ProcOctree(true, true, sub_div_milestones_.back() <= 0);

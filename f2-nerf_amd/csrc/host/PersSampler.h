@@ -59,7 +59,11 @@ class PersOctree {
   // revive / re-number leaves (ProcOctree, MarkInvisibleNodes, LoadStates, InstallOctree): samples marched speculatively
   // against an older generation cannot be repaired and are dropped.
   Tensor died_at_, death_epoch_, n_repaired_;
-  Tensor death_epoch_host_;  // pinned int32[1]: the last epoch in which a leaf died, written by the stat update itself
+  // host word (hipHostMalloc, mapped) + its device address: the last epoch in which a leaf died, written by the stat update
+  // kernel itself (a torch pinned tensor's host address is NOT a device address here: the first version faulted on the first death)
+  int32_t* death_epoch_host_ = nullptr;
+  int32_t* death_epoch_host_dev_ = nullptr;
+  ~PersOctree();
   int QuietEpochs() const;   // stat updates since a leaf last died, as far as the host can tell without synchronising
   int epoch_ = 0;
   int64_t generation_ = 0;

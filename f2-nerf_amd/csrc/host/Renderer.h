@@ -100,6 +100,11 @@ class Renderer : public Pipe {
   // as the host can tell from a pinned word the update kernel writes (a timing decision only: samples are identical).
   int speculative_sampling_ = 2;  // 0 never, 1 always (outside ProcOctree iterations), 2 while the octree is quiet
   static constexpr int kSpecQuietEpochs = 8;
+  struct NextBatch {
+    Tensor rays_o, rays_d;
+    float fineness = 1.f;
+    bool valid = false;
+  } next_batch_;
   int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
   void PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream);
   bool PreSampleSpecComplete();  // false: could not be repaired (tree re-numbered): dropped
