@@ -1219,7 +1219,7 @@ def test_empty_and_ragged_inputs(hip, fox_state):
 
 def test_errors_are_loud(hip):
     x = torch.zeros((4, 32), device=DEV)
-    with pytest.raises(Exception):
-        hip.mlp_fwd(4, 16, 64, 1, torch.zeros(10, dtype=torch.float16, device=DEV), x, torch.zeros((4, 16), dtype=torch.float16, device=DEV))
+    with pytest.raises(Exception):  # a width no tcnn FullyFusedMLP has (16 / 32 / 64 / 128 run: tests/test_gpu_mlp_shapes.py)
+        hip.mlp_fwd(4, 32, 48, 1, torch.zeros(1 << 14, dtype=torch.float16, device=DEV), x, torch.zeros((4, 16), dtype=torch.float16, device=DEV))
     with pytest.raises(Exception):
         hip.mlp_fwd(4, 32, 64, 1, torch.zeros(3072, dtype=torch.float16), x, torch.zeros((4, 16), dtype=torch.float16, device=DEV))  # CPU tensor
