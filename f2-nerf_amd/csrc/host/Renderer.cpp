@@ -43,7 +43,11 @@ Tensor SHShader::Query(const Tensor& feats, const Tensor& dirs) {  // SHShader.c
   Tensor input = torch::cat({feats, enc}, -1);
   Tensor output = mlp_->Query(input);
   const float eps = 1e-3f;
-  return (1.f + 2.f * eps) / (1.f + torch::exp(-output)) - eps;
+  // (the reference's expression, SHShader.cpp:27-28, on an output clamped at -80: below ~-88.7 exp(-output) is +inf in fp32 and
+  // ATen's backward of 1 / (1 + e) * e forms 0 * inf = NaN -- the gradient's true limit there is 0, which the clamp delivers;
+  // values are unchanged for every output >= -80.  Without it a wide colour network at the reference's learning rate 1e-2 ran
+  // into a permanent "Nan!" skip after ~20 iterations (tools/debug_generic.py).)
+  return (1.f + 2.f * eps) / (1.f + torch::exp(-output.clamp_min(-80.f))) - eps;
 }
 
 namespace {

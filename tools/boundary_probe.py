@@ -11,7 +11,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 lib = ctypes.CDLL(so)
 N = 32
 print("chain of %d dependent kernels, 1024 blocks x 256 threads each; times in us" % N)
-print("%-28s %10s %10s %10s %14s %14s" % ("bytes moved per kernel", "eager", "graph", "1 kernel", "eager/boundary", "graph/boundary"))
+print("%-28s %12s %12s %16s %16s" % ("bytes moved per kernel", "eager chain", "graph chain", "eager per kernel", "graph per kernel"))
 for mb in (0, 1, 8, 32, 128):
     out = (ctypes.c_float * 4)()
     rc = lib.boundary_probe(ctypes.c_size_t(mb << 20), N, 1024, out)
@@ -19,4 +19,4 @@ for mb in (0, 1, 8, 32, 128):
         print("probe failed", rc)
         continue
     e, g, k1 = out[0] * 1e3, out[1] * 1e3, out[2] * 1e3
-    print("%-28s %10.1f %10.1f %10.2f %14.2f %14.2f" % ("%d MiB" % mb, e, g, k1, (e - N * k1) / N, (g - N * k1) / N), flush=True)
+    print("%-28s %12.1f %12.1f %16.2f %16.2f" % ("%d MiB" % mb, e, g, e / N, g / N), flush=True)
