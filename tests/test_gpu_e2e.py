@@ -625,3 +625,56 @@ def test_two_rank_bench_when_two_gpus_are_visible():
     assert rep["rccl_comm_ranks"] == 2 and rep["torch_distributed_world"] == 2, rep
     assert rep["identical"], rep
     assert line["value"] > 0 and line["ms_per_step"] > 0
+
+
+def test_aux_states_and_deferred_reset(rt, fox_state):
+    """Round-2 advisor items on the device: (1) what a data-parallel attach replicates besides the checkpoint vector -- the
+    edge pool and the training cameras -- round-trips through aux_states / load_aux_states (a replica that kept its own edge
+    pool would index rank 0's warps); (2) partial sums a failed backward left registered are dropped by the next ZeroGrad
+    (f2n_deferred_reset) instead of being folded into the next step's gradients."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import capi
+    st = fox_state
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=14"], seed=3, table_init=0.3)
+    aux = [t.clone() for t in runner.aux_states()]
+    assert aux[0].numel() == st["edge_pool"].size and (aux[0].cpu().numpy() == st["edge_pool"]).all()
+    assert aux[1].shape[0] == len(st["train_set"]) and aux[2].shape == (len(st["train_set"]), 3, 3)
+    other, _, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=14"], seed=4, table_init=0.3)
+    other.set_edge_pool(torch.from_numpy(st["edge_pool"][:64 * 10].copy()))  # a replica with another (shorter) edge pool
+    assert other.aux_states()[0].numel() == 640
+    other.load_states(runner.states())
+    other.load_aux_states(aux)
+    for a, b in zip(other.aux_states(), aux):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # (2) a stale deferred reduction must not survive a ZeroGrad
+    rng = np.random.default_rng(2)
+    R = 256
+    ro, rd, bounds, cam = fox_batch(st, rng, R)
+    d = rt.to_dev(ro, rd, bounds, rng.random((R, 3), dtype=F32), cam)
+    runner.n_edge_pts = 256
+    runner.zero_grad()
+    runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
+    g0 = {k: v.clone() for k, v in runner.grads().items()}
+    poison = torch.full((7168,), 1e6, device="cuda")
+    lib = capi.lib()
+    import ctypes
+    # a deferring backward whose step "threw" before f2n_reduce_deferred: emulate by calling the deferring entry point directly
+    n = 64
+    x = torch.zeros((n, 32), dtype=torch.float16, device="cuda")
+    drgb = torch.ones((n, 3), device="cuda")
+    dfeat = torch.zeros((n, 16), device="cuda")
+    ph = torch.zeros(7168, dtype=torch.float16, device="cuda")
+    rc = lib.f2n_shade_bwd_dyn(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), n, ctypes.c_void_p(0), ctypes.c_void_p(drgb.data_ptr()),
+                               ctypes.c_void_p(0), ctypes.c_void_p(ph.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_float(128.0),
+                               ctypes.c_void_p(dfeat.data_ptr()), ctypes.c_void_p(poison.data_ptr()), ctypes.c_void_p(0), 0, ctypes.c_void_p(0), 1)
+    assert rc == 0
+    runner.zero_grad()   # -> f2n_deferred_reset
+    runner.async_counts = 2  # a streaming step: its backward defers its reductions and folds "everything registered" in one launch
+    runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
+    runner.async_counts = 1
+    runner.flush()
+    torch.cuda.synchronize()
+    assert float(poison.max()) == 1e6 and float(poison.min()) == 1e6  # the stale registration was never folded
+    g1 = runner.grads()
+    for k in ("color_mlp", "field_mlp"):
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-3 * float(g0[k].abs().max()) + 1e-9, k
