@@ -165,6 +165,30 @@ def psnr_numerics_ab(args):
     return out
 
 
+def other_configs(args):
+    """BASELINE configs 3-5 as short runs of this script in their own processes (one at a time: they are timed), so that the
+    default bench line carries a number for each: the llff and nerf-360 presets on the synthetic rigs, wanjinyou_big at the
+    file's log2 20 and at the 2^22 BASELINE.json names.  Counters for the big-table points: profiles/r03_big{20,22}_*."""
+    out = {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for tag, extra in (("llff", ["--preset", "llff"]), ("nerf-360", ["--preset", "nerf-360"]),
+                       ("wanjinyou_big_log2_20", ["--preset", "wanjinyou_big", "--log2", "20"]),
+                       ("wanjinyou_big_log2_22", ["--preset", "wanjinyou_big", "--log2", "22"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.other_steps), "--warmup", "10", "--no-cpu-baseline",
+               "--no-converged", "--other-configs", "0"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            ln = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+            rf = ln.get("roofline") or {}
+            out[tag] = {"value": ln["value"], "unit": ln["unit"], "ms_per_step": round(ln["ms_per_step"], 4), "steps": ln["steps"],
+                        "workload": ln["config"]["workload"], "meaningful_samples_per_step": round(ln["config"]["meaningful_samples_per_step"]),
+                        "dominant_kernel_ms": rf.get("avg_kernel_ms"), "hbm_frac_algorithmic": rf.get("frac"),
+                        "traffic_bytes_per_launch": rf.get("traffic"), "traffic_rate": (rf.get("traffic_rate") or {}).get("frac")}
+        except Exception as e:
+            out[tag] = {"error": str(e)[:200]}
+    return out
+
+
 def converged_leg(args, st, dev):
     """SURVEY 8(d) config 2, state (ii).  Trains the scene for args.train_iters iterations on the fox photographs with the
     reference's loop (ExpRunner::Train), reports the test PSNR (reference definition: 8-bit quantised prediction,
@@ -273,6 +297,9 @@ def main():
     ap.add_argument("--psnr-runs", type=int, default=4, help="trainings of the PSNR distribution with the product numerics (0: skip)")
     ap.add_argument("--psnr-ref-runs", type=int, default=3, help="... with the reference-numerics build of the kernel library (0: skip)")
     ap.add_argument("--psnr-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: run N trainings, print their summary
+    ap.add_argument("--other-configs", type=int, default=1, help="1: also run BASELINE configs 3-5 briefly (own processes) and report "
+                    "them in the line (N=1, default preset only); 0: skip")
+    ap.add_argument("--other-steps", type=int, default=60, help="timed steps of each of those runs")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     ap.add_argument("--marker-pause", action="store_true", help="sleep 0.3 s before the timed region (marker for profiles/timeline_rocpd.py)")
     ap.add_argument("--speculation", choices=["auto", "on", "off"], default="auto", help="sampling of the next batch AHEAD of the stat "
@@ -465,6 +492,13 @@ def main():
                     converged["psnr_numerics_ab"] = psnr_numerics_ab(args)
                 except Exception as e:
                     converged["psnr_numerics_ab"] = {"error": str(e)[:300]}
+        others = None
+        if world == 1 and args.other_configs and args.preset == "wanjinyou" and args.log2 in (0, 19) and not args.no_converged:
+            try:
+                torch.cuda.empty_cache()
+                others = other_configs(args)
+            except Exception as e:
+                others = {"error": str(e)[:300]}
         line = {
             "metric": "training ray-samples/s (%s)" % ("ngp_fox" if scene_name == "ngp_fox" else args.preset), "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -477,6 +511,7 @@ def main():
                        "marched_samples_per_s": n_marched / elapsed, "rho_marched_over_meaningful": rho,
                        "meaningful_samples_per_step": n_meaningful / args.steps},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged, "replicas": replicas,
+            "other_configs": others,
             # buffers are sized for the worst case on purpose (1024 sample slots per ray, scatter queues): what that costs of 288 GB
             "peak_hbm_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                              "reserved_by_allocator": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2),
