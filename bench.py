@@ -155,9 +155,15 @@ def psnr_numerics_ab(args):
             out[tag] = {"error": (str(e) + " | " + (se or "")[-400:])[:600]}
     a, b = out.get("product", {}), out.get("reference_numerics", {})
     if "psnr_mean" in a and "psnr_mean" in b:
-        out["delta_mean_db_reference_minus_product"] = round(b["psnr_mean"] - a["psnr_mean"], 3)
+        delta = b["psnr_mean"] - a["psnr_mean"]
+        # standard error of the difference of the two means (run-to-run spread of each numerics / sqrt of its run count)
+        se = float(np.sqrt(a["psnr_std"] ** 2 / max(a["runs"], 1) + b["psnr_std"] ** 2 / max(b["runs"], 1)))
+        out["delta_mean_db_reference_minus_product"] = round(delta, 3)
+        out["delta_standard_error_db"] = round(se, 3)
         out["ranges_overlap"] = bool(a["psnr_min"] <= b["psnr_max"] and b["psnr_min"] <= a["psnr_max"])
-        out["within_0p1_db"] = bool(abs(b["psnr_mean"] - a["psnr_mean"]) <= 0.1)
+        out["within_0p1_db"] = bool(abs(delta) <= 0.1)
+        out["delta_within_2_standard_errors_of_zero"] = bool(abs(delta) <= 2 * se)
+        out["pooled_evidence"] = "profiles/r03_psnr_study.json: 16 + 14 runs over four invocations"
     out["note"] = ("same seed, same explicit schedule; the two workers share the GPU, so their train_wall_s are NOT timings. "
                    "reference_numerics = libf2n_hip_refnum.so: hash gradient by per-addend packed-f16 atomics in arrival order "
                    "(Hash3DAnchored.cu:145-153) and an f16 accumulator in the MLP forward products; product = fp32 MFMA accumulation, "

@@ -652,6 +652,10 @@ def test_aux_states_and_deferred_reset(rt, fox_state):
     ro, rd, bounds, cam = fox_batch(st, rng, R)
     d = rt.to_dev(ro, rd, bounds, rng.random((R, 3), dtype=F32), cam)
     runner.n_edge_pts = 256
+    fr = rt.to_dev((((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(float(runner.fineness))).astype(F32),
+                   rng.random((R, 3), dtype=F32), rng.integers(0, st["edge_pool"].size // 64, 256).astype(np.int32),
+                   (rng.random((256, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32))
+    runner.set_forced_randoms(*fr)  # (the same draws in both steps below)
     runner.zero_grad()
     runner.train_step(d[0], d[1], d[2], d[3], d[4], False)
     g0 = {k: v.clone() for k, v in runner.grads().items()}
