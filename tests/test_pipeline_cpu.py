@@ -246,3 +246,19 @@ def test_step_and_gradient_exchange_interleave_in_the_documented_order():
     assert step(p, 0.03) is False
     assert step(p, 0.04, apply=False) is True and not p.pending()
     assert log == ["sample", "fwd_bwd", "begin", "end", "adam(apply=1, lr=0.030)", "defer_flags", "fwd_bwd", "adam(apply=0, lr=0.040)"]
+
+
+def test_bench_reads_the_node_layout_of_the_checkpoint():
+    """bench.py's PSNR study identifies surviving leaves from the raw TreeNode bytes with its own numpy dtype (it may not import the
+    oracle): field offsets and size must be those of the 64-byte checkpoint layout (PersSampler.h:22-29)."""
+    import importlib.util
+    import os
+    from oracle import octree_construct as octc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.NODE_DT.itemsize == octc.NODE_DT.itemsize == 64
+    for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"):
+        assert bench.NODE_DT.fields[f][1] == octc.NODE_DT.fields[f][1], f
+        assert bench.NODE_DT.fields[f][0].itemsize == octc.NODE_DT.fields[f][0].itemsize, f
