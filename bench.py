@@ -163,7 +163,7 @@ def psnr_numerics_ab(args):
         out["ranges_overlap"] = bool(a["psnr_min"] <= b["psnr_max"] and b["psnr_min"] <= a["psnr_max"])
         out["within_0p1_db"] = bool(abs(delta) <= 0.1)
         out["delta_within_2_standard_errors_of_zero"] = bool(abs(delta) <= 2 * se)
-        out["pooled_evidence"] = "profiles/r03_psnr_study.json: 16 + 14 runs over four invocations"
+        out["pooled_evidence"] = "profiles/r03_psnr_study.json: 16 + 14 runs over three invocations"
     out["note"] = ("same seed, same explicit schedule; the two workers share the GPU, so their train_wall_s are NOT timings. "
                    "reference_numerics = libf2n_hip_refnum.so: hash gradient by per-addend packed-f16 atomics in arrival order "
                    "(Hash3DAnchored.cu:145-153) and an f16 accumulator in the MLP forward products; product = fp32 MFMA accumulation, "
