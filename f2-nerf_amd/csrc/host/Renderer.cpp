@@ -314,6 +314,12 @@ bool Renderer::PreSampleSpecComplete() {
 // Second half: wait for the counts (by now the march has usually finished) and take views of the packed rows.  No launch.
 void Renderer::PreSampleFinish() {
   TORCH_CHECK(pending_samples_.active, "PreSampleFinish without PreSampleBegin");
+  // samples marched against a tree that has since been replaced or re-numbered (LoadStates / InstallOctree / ProcOctree between
+  // the prefetch and its use) are void, whichever way they were prefetched: the caller samples again
+  if (pending_samples_.generation != static_cast<PersSampler*>(pts_sampler_.get())->pers_octree_->generation_) {
+    DropPendingSamples();
+    return;
+  }
   if (!pending_samples_.completed && !PreSampleSpecComplete()) return;  // (a speculative batch whose step never reached its update)
   presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pending_samples_);
   has_presample_ = true;

@@ -682,3 +682,37 @@ def test_aux_states_and_deferred_reset(rt, fox_state):
     g1 = runner.grads()
     for k in ("color_mlp", "field_mlp"):
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-3 * float(g0[k].abs().max()) + 1e-9, k
+
+
+def test_prefetched_samples_do_not_survive_a_state_load(rt, fox_state):
+    """A streaming step prefetches the NEXT batch's samples against the octree of the moment.  If the octree is replaced before
+    that batch is trained on (load_states / install_octree between two steps), the prefetched samples belong to node indices
+    that no longer exist: the renderer must notice (PersOctree::generation_) and sample again."""
+    st = fox_state
+    rng = np.random.default_rng(12)
+    R = 512
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=14"], seed=2, table_init=0.3)
+    runner.n_edge_pts = 256
+    fr = rt.to_dev((((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(float(runner.fineness))).astype(F32),
+                   rng.random((R, 3), dtype=F32), rng.integers(0, st["edge_pool"].size // 64, 256).astype(np.int32),
+                   (rng.random((256, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32))
+    runner.set_forced_randoms(*fr)
+    b = []
+    for _ in range(2):
+        ro, rd, bounds, cam = fox_batch(st, rng, R)
+        b.append(rt.to_dev(ro, rd, bounds, rng.random((R, 3), dtype=F32), cam))
+    for mode in (1, 0):  # speculative prefetch / prefetch behind the update
+        runner.speculative_sampling = mode
+        runner.train_step(b[0][0], b[0][1], b[0][2], b[0][3], b[0][4], True, b[1][0], b[1][1], b[1][2])  # prefetches batch 1
+        n_old = int(runner.get_samples(b[1][0], b[1][1], b[1][2])["t"].shape[0])
+        z = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "data", "converged_sampler.npz")))
+        states = [t.cpu().clone() for t in runner.states()]
+        saved = [t.clone() for t in states]
+        states[0] = torch.from_numpy(z["tree_nodes"].copy())                       # the 148 k-node tree of a finished training
+        states[2] = torch.zeros(z["tree_nodes"].size // 64, dtype=torch.int32)
+        runner.load_states(states)
+        n_new = int(runner.get_samples(b[1][0], b[1][1], b[1][2])["t"].shape[0])
+        assert n_new != n_old
+        s = runner.train_step(b[1][0], b[1][1], b[1][2], b[1][3], b[1][4], False)
+        assert s["n_samples"] == n_new, (mode, s["n_samples"], n_new, n_old)
+        runner.load_states(saved)
