@@ -703,6 +703,8 @@ def test_prefetched_samples_do_not_survive_a_state_load(rt, fox_state):
         b.append(rt.to_dev(ro, rd, bounds, rng.random((R, 3), dtype=F32), cam))
     for mode in (1, 0):  # speculative prefetch / prefetch behind the update
         runner.speculative_sampling = mode
+        runner.iter_step = 1  # (iteration 0 compacts the octree: no speculation in that one)
+        runner.update_ada_params()
         runner.train_step(b[0][0], b[0][1], b[0][2], b[0][3], b[0][4], True, b[1][0], b[1][1], b[1][2])  # prefetches batch 1
         n_old = int(runner.get_samples(b[1][0], b[1][1], b[1][2])["t"].shape[0])
         z = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "data", "converged_sampler.npz")))
