@@ -4,6 +4,8 @@
 // and no host read-back, wave64 blocks, LDS-resident DFS stacks.
 #include "rows_dev.h"
 
+#include <stdlib.h>
+
 
 // ---------------------------------------------------------------------------------------------------
 // Slab test, PersSampler.cu:21-51.
@@ -974,6 +976,17 @@ __global__ void march_noise_kernel(int n, const float* __restrict__ u, float fin
   if (i < n) out[i] = ((u[i] - .5f) + 1.f) * fineness;
 }
 
+// Dynamic LDS handed to every (one-wave) block of the march kernel although it uses none: it caps how many march waves a CU keeps
+// resident (160 KB / this), i.e. how many wave slots and registers the latency-bound march takes from the MLP / scatter
+// kernels it runs underneath.  0 = no cap.  F2N_MARCH_LDS (bytes) overrides the default for experiments.
+static size_t f2n_march_lds() {
+  static int cached = -1;
+  const char* e = getenv("F2N_MARCH_LDS");
+  if (e != nullptr) return (size_t) atoi(e);
+  if (cached < 0) cached = 0;
+  return (size_t) cached;
+}
+
 extern "C" {
 
 int f2n_oct_visible_cams(void* stream, int n_boxes, int n_cams, const float* boxes, const float* c2w, const float* bounds, float fx,
@@ -1102,7 +1115,7 @@ int f2n_ray_march_strided(void* stream, int n_rays, float sample_l, int scale_by
                           int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans) {
   if (n_rays < 0) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
+  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, 4)), dim3(64), f2n_march_lds(),
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
                      nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, nullptr, nullptr, 0);
@@ -1116,7 +1129,7 @@ int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_
                          const int32_t* death_epoch, int spec_epoch) {
   if (n_rays < 0 || repair_flags == nullptr || death_epoch == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, 4)), dim3(64), 0,
+  hipLaunchKernelGGL(ray_march_kernel<2>, dim3(f2n_div_up(n_rays, 4)), dim3(64), f2n_march_lds(),
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
                      nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, repair_flags, death_epoch, spec_epoch);

@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--factor", type=int, default=2)
 ap.add_argument("--overrides", nargs="*", default=[])
 ap.add_argument("--kernel-timing", action="store_true")
+ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 auto (default: the host's default)")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob")
 args = ap.parse_args()
 st = fox_data.load_state()
@@ -23,6 +24,8 @@ runner, cfg, _ = runtime.make_runner(st, "wanjinyou", ["train.end_iter=%d" % max
 torch.manual_seed(2022)
 if args.iters > 0:
     runner.train(ds, args.iters, 1)
+if args.speculation >= 0:
+    runner.speculative_sampling = args.speculation
 R = max(16, runner.cur_batch_size())
 batches = [ds.rand_rays_data(R, 1) for _ in range(8)]
 def step(i):
@@ -33,7 +36,8 @@ def timed(tag=""):
         step(i)
     c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)
     if args.kernel_timing:
-        runtime.host().ExpRunner.enable_kernel_timing(["ray_march", "oct_intersect", "field_bwd", "hash_gather", "shade_bwd"])
+        runtime.host().ExpRunner.enable_kernel_timing(["ray_march", "oct_intersect", "field_bwd", "hash_gather", "shade_bwd", "oct_repair", "march_repair",
+                                                       "field_shade_fwd", "pack_samples", "early_stop"])
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(6 + i)
