@@ -80,19 +80,20 @@ __device__ __forceinline__ half8_t f2n_rowfrag(const half_t* M, int ld, int row,
   return f2n_cat(*(const half4_t*) p, *(const half4_t*) (p + 16));
 }
 
-// Two fp32 D tiles -> f16 row fragment of the next contraction (optionally through ReLU).
+// Two fp32 D tiles -> f16 row fragment of the next contraction (optionally through ReLU).  The ReLU is applied AFTER the
+// rounding, on packed halves (v_pk_max_f16: one instruction per two values instead of one v_max_f32 each; rounding to nearest
+// is monotone and keeps the sign, and max(-0, +0) = +0 on this ISA, so relu(round(x)) has the bits of round(relu(x))).
 template <bool RELU>
 __device__ __forceinline__ half8_t f2n_pack(float4_t a, float4_t b) {
   half8_t r;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    float x = a[i], y = b[i];
-    if (RELU) {
-      x = x > 0.f ? x : 0.f;
-      y = y > 0.f ? y : 0.f;
-    }
-    r[i] = (half_t) x;
-    r[4 + i] = (half_t) y;
+    r[i] = (half_t) a[i];
+    r[4 + i] = (half_t) b[i];
+  }
+  if (RELU) {
+    const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    r = __builtin_elementwise_max(r, z);
   }
   return r;
 }
@@ -101,7 +102,11 @@ template <bool RELU>
 __device__ __forceinline__ half4_t f2n_cvt4(float4_t a) {
   half4_t r;
 #pragma unroll
-  for (int i = 0; i < 4; i++) r[i] = (half_t) ((RELU && !(a[i] > 0.f)) ? 0.f : a[i]);
+  for (int i = 0; i < 4; i++) r[i] = (half_t) a[i];
+  if (RELU) {
+    const half4_t z = {0, 0, 0, 0};
+    r = __builtin_elementwise_max(r, z);
+  }
   return r;
 }
 
