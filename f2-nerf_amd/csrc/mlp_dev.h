@@ -174,6 +174,46 @@ struct F2nMlpFwdW {
   }
 };
 
+// The same forward chain with the weight fragments in LDS instead of registers: [fragment][lane] x 16 bytes, so a fragment
+// is one conflict-free ds_read_b128 per lane right before the MFMA that consumes it.  The two networks' fragments cost 80
+// VGPRs in the register-resident form (152 registers, three waves per SIMD in the fused field + colour forward); here they
+// cost 20 KB of LDS per block and the kernel keeps twice the waves resident to hide its tile's dependency chain.  `w` must
+// already include the lane offset and be opaque to the optimiser (else the reads are hoisted back into registers).
+template <int NH>
+struct F2nMlpFwdWLds {
+  static constexpr int N_FRAG = 4 + (NH == 2 ? 8 : 0) + 2;
+  static __device__ __forceinline__ void fill(half8_t* dst /*[N_FRAG][64]*/, const half_t* __restrict__ params, int lane) {
+    F2nMlpFwdW<NH> w;
+    w.load(params, lane & 15, lane >> 4);
+#pragma unroll
+    for (int t = 0; t < 4; t++) dst[t * 64 + lane] = w.w0[t];
+    if (NH == 2) {
+#pragma unroll
+      for (int t = 0; t < 8; t++) dst[(4 + t) * 64 + lane] = w.w1[t];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) dst[(N_FRAG - 2 + q) * 64 + lane] = w.wo[q];
+  }
+  static __device__ __forceinline__ float4_t forward(const half8_t* w, half8_t xf) {
+    const float4_t z = {0.f, 0.f, 0.f, 0.f};
+    float4_t t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = f2n_mfma_fwd(w[i * 64], xf, z);
+    half8_t h0 = f2n_pack<true>(t[0], t[1]), h1 = f2n_pack<true>(t[2], t[3]);
+    if (NH == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        t[i] = f2n_mfma_fwd(w[(4 + i * 2) * 64], h0, z);
+        t[i] = f2n_mfma_fwd(w[(4 + i * 2 + 1) * 64], h1, t[i]);
+      }
+      h0 = f2n_pack<true>(t[0], t[1]);
+      h1 = f2n_pack<true>(t[2], t[3]);
+    }
+    float4_t o = f2n_mfma_fwd(w[(N_FRAG - 2) * 64], h0, z);
+    return f2n_mfma_fwd(w[(N_FRAG - 1) * 64], h1, o);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // Backward: weights and their transposes live in LDS (padded rows: +4 halves keeps ds_read_b64 fragment
 // reads conflict-free), weight-gradient accumulators live in registers for the whole kernel.

@@ -191,8 +191,16 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
   F2N_RAISE_PRIO();
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   if (n_dev != nullptr) n = min(n, *n_dev);
-  F2nMlpFwdW<1> wf;
-  wf.load(field_params, c, g);
+  // both networks' weight fragments live in LDS (F2nMlpFwdWLds: 152 -> ~80 registers, twice the resident waves)
+  __shared__ half8_t s_wf[F2nMlpFwdWLds<1>::N_FRAG * 64];
+  __shared__ half8_t s_wc[F2nMlpFwdWLds<2>::N_FRAG * 64];
+  if ((tid >> 6) == 0) F2nMlpFwdWLds<1>::fill(s_wf, field_params, lane);
+  if ((tid >> 6) == 1) F2nMlpFwdWLds<2>::fill(s_wc, color_params, lane);
+  __syncthreads();
+  int w_off = lane;
+  asm volatile("" : "+v"(w_off));  // opaque: the fragment reads stay at their point of use
+  const half8_t* wf = s_wf + w_off;
+  const half8_t* wc = s_wc + w_off;
   const int wave_global = blockIdx.x * 4 + (tid >> 6), wave_stride = gridDim.x * 4;
   // "extra" rows (the 2E edge samples of the TV loss, Renderer.cpp:159-166): field MLP only, on their own cached rows; their
   // 16 outputs are wanted as fp32 rows (the loss reads them).  Exactly f2n_field_fwd_cached's arithmetic; riding here saves
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
         *(half4_t*) p = __builtin_shufflevector(xf, xf, 0, 1, 2, 3);
         *(half4_t*) (p + 16) = __builtin_shufflevector(xf, xf, 4, 5, 6, 7);
       }
-      const float4_t o = wf.forward(xf);
+      const float4_t o = F2nMlpFwdWLds<1>::forward(wf, xf);
       if (valid) {
         float4_t of;
 #pragma unroll
@@ -217,8 +225,6 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
       }
     }
   }
-  F2nMlpFwdW<2> wc;
-  wc.load(color_params, c, g);
   const int n_tiles = (n + 15) / 16;
   struct In {
     half8_t xf;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
       *(half4_t*) p = __builtin_shufflevector(xf, xf, 0, 1, 2, 3);
       *(half4_t*) (p + 16) = __builtin_shufflevector(xf, xf, 4, 5, 6, 7);
     }
-    const float4_t o = wf.forward(xf);  // lane (c = sample, g): field outputs 4g..4g+3
+    const float4_t o = F2nMlpFwdWLds<1>::forward(wf, xf);  // lane (c = sample, g): field outputs 4g..4g+3
     float4_t f;
 #pragma unroll
     for (int r = 0; r < 4; r++) f[r] = (float) (half_t) o[r];  // f16 output precision (TCNNWP.cpp:143-144), widened (:112)
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
       *(half4_t*) p = __builtin_shufflevector(xs, xs, 0, 1, 2, 3);
       *(half4_t*) (p + 16) = __builtin_shufflevector(xs, xs, 4, 5, 6, 7);
     }
-    const float4_t oc = wc.forward(xs);
+    const float4_t oc = F2nMlpFwdWLds<2>::forward(wc, xs);
     const float ov = (float) (half_t) f2n_channel_of_group(oc, c, g);
     const float col = (1.f + 2.f * F2N_SHADE_EPS) / (1.f + expf(-ov)) - F2N_SHADE_EPS;
     if (valid && g < 3) rgb[3 * (size_t) s + g] = col;
