@@ -11,6 +11,7 @@ import torch
 from . import build
 
 _lib = None
+ABI_VERSION = 8  # include/f2n_abi.h
 
 
 class F2nError(RuntimeError):
@@ -25,6 +26,9 @@ def lib():
                            "(there is no CPU fallback)" % build.LIB)
         _lib = ctypes.CDLL(build.LIB)
         _lib.f2n_build_info.restype = ctypes.c_char_p
+        if _lib.f2n_abi_version() != ABI_VERSION:  # a stale library next to a newer binding: argument lists would not match
+            raise F2nError("%s reports ABI version %d, this binding is written for %d: rebuild (__graft_entry__.build())"
+                           % (build.LIB, _lib.f2n_abi_version(), ABI_VERSION))
     return _lib
 
 

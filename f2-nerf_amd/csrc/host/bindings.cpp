@@ -26,8 +26,15 @@ py::dict StatsToDict(const TrainStats& s) {
 
 }  // namespace
 
+// the ABI version this host layer was compiled against (include/f2n_abi.h); a kernel library of another version next to it
+// means one of the two was not rebuilt -- calls would pass the wrong argument lists (observed once: a memory fault)
+#define F2N_HOST_EXPECTS_ABI 8
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "f2-nerf hot path: C++/LibTorch host layer over libf2n_hip.so";
+  TORCH_CHECK(f2n_abi_version() == F2N_HOST_EXPECTS_ABI, "libf2n_hip reports ABI version ", f2n_abi_version(), ", this host extension was built for ",
+              F2N_HOST_EXPECTS_ABI, ": rebuild both (python -c 'import __graft_entry__ as g; g.build()')");
+  m.attr("abi_version") = F2N_HOST_EXPECTS_ABI;
   auto bounded = [](const BoundedRays& r) { return std::vector<Tensor>{r.origins, r.dirs, r.bounds}; };
   auto ray_data = [](const std::tuple<BoundedRays, Tensor, Tensor>& t) {
     const auto& r = std::get<0>(t);

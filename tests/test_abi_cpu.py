@@ -98,3 +98,11 @@ def test_gather_plan_covers_every_tile_once_and_balances_the_xcds(lib):
         elif n_tiles >= 64:
             assert cost[0] < cost[7]  # coarse pairs are cheaper per tile (consecutive samples share their cells) ...
             assert load.max() - load.min() <= 2.0 * cost.max() + 1e-3 * load.mean(), (load, cost)  # ... and the XCDs end up even
+
+
+def test_binding_and_host_extension_refuse_a_library_of_another_abi_version():
+    """A stale libf2n_hip.so next to a newer host extension (or ctypes binding) would be called with the wrong argument lists:
+    both check f2n_abi_version() when they load."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import capi, runtime
+    assert capi.ABI_VERSION == capi.lib().f2n_abi_version() == runtime.host().abi_version == 8
