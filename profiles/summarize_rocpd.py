@@ -36,17 +36,25 @@ def stats(db, out):
     average over both shapes says nothing about either."""
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    shapes = {}
+    shapes, calls = {}, {}
     try:
         for n, g, c, tot in cur.execute("select name, grid_x, count(*), sum(duration) from kernels group by name, grid_x"):
             shapes.setdefault(n, []).append((int(g), int(c), float(tot)))
+        for n, d in cur.execute("select name, duration from kernels order by name, start"):
+            calls.setdefault(n, []).append(float(d))
     except sqlite3.Error:
-        shapes = {}
+        shapes, calls = {}, {}
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+        # first_us / median_us: a kernel's first launch of a process can be several times its steady duration (cold
+        # instruction cache and TLBs, clocks still ramping); the average over a handful of calls then says little
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent", "first_us", "median_us", "min_us", "max_us"])
         for n, c, t, a, p in rows:
-            w.writerow([short(n), c, "%.1f" % float(t), "%.2f" % float(a), "%.2f" % float(p)])
+            d = calls.get(n, [])
+            unit1 = float(t) / max(sum(d), 1e-9) if d else 0.0
+            extra = ["%.2f" % (d[0] * unit1), "%.2f" % (sorted(d)[len(d) // 2] * unit1), "%.2f" % (min(d) * unit1),
+                     "%.2f" % (max(d) * unit1)] if d else ["", "", "", ""]
+            w.writerow([short(n), c, "%.1f" % float(t), "%.2f" % float(a), "%.2f" % float(p)] + extra)
             sh = shapes.get(n, [])
             if len(sh) > 1:
                 unit = float(t) / max(sum(x[2] for x in sh), 1e-9)  # kernels.duration -> the unit top_kernels reports in
