@@ -206,6 +206,8 @@ def converged_leg(args, st, dev):
     ds = runtime.make_dataset(sc, images)
     runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022, device=dev)
     runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
+    if args.speculation_order >= 0:
+        runner.speculation_order = args.speculation_order
     torch.manual_seed(2022)
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
@@ -311,6 +313,8 @@ def main():
     ap.add_argument("--speculation", choices=["auto", "on", "off"], default="auto", help="sampling of the next batch AHEAD of the stat "
                     "update with repair behind it (Renderer::PreSampleSpecBegin): auto = while no leaf has died lately (the "
                     "default of the host), on / off = A/B (profiles/r03_speculation_experiments.txt)")
+    ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
+                    "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
@@ -363,6 +367,8 @@ def main():
     if args.diag_no_nan_check:
         runner.check_nan = False
     runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
+    if args.speculation_order >= 0:
+        runner.speculation_order = args.speculation_order
 
     if dp:
         from f2_nerf_amd import parallel

@@ -281,7 +281,8 @@ void Renderer::PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, fl
   // speculative sampling starts when this step's own kernels start, not before.  (Waiting only for the previous step's octree
   // update -- as a first version did -- let the side stream read ray buffers that were still to be written whenever the host
   // ran ahead of the device: PSNR fell and octrees blew up at random, worst with a second process on the GPU.)
-  spec_start_ev_.record();
+  if (!spec_start_recorded_) spec_start_ev_.record();  // (else: recorded at the top of this step, ahead of its random draws)
+  spec_start_recorded_ = false;
   spec_start_ev_.block(*side_stream_);
   if (side_must_wait_consumed_) {
     samples_consumed_ev_.block(*side_stream_);
@@ -357,6 +358,19 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
+  // The side stream of the next batch's speculative sampling (started further down, once this batch's samples are in hand) is
+  // ordered behind the point the main stream has reached NOW (spec_order_), not behind the draws and the edge samples that
+  // follow: the next batch's intersection then starts as soon as the previous step's Adam has finished and has the otherwise
+  // idle device to itself while the main queue hands over the flag copy, the draws and the edge samples (~40 us); under the
+  // gather that follows, each of its dependent node reads queues behind the gather's L2 traffic (0.06 ms alone, 0.36 ms
+  // underneath it).  Measured: fresh step 1.143-1.156 -> 1.128-1.129 ms.  (The draws keep their place in the generator's
+  // sequence -- background / edge samples of this step, then the next batch's march noise -- whichever way the next batch is
+  // sampled; only the event moves.)
+  spec_start_recorded_ = false;
+  if (spec_order_ == 1 && train && async_count && next_batch_.valid && dp_world_ <= 1 && speculative_sampling_ != 0) {
+    spec_start_ev_.record();
+    spec_start_recorded_ = true;
+  }
   // Random draws of the step (Renderer.cpp:67-81 background, PersSampler.cu:456-457 edge samples): ONE uniform launch for both
   // unless a test pinned either (the edge kernel maps three uniforms to an edge index and two coordinates in [-1,1)).
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
@@ -431,6 +445,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   } else if (train && next_batch_.valid) {
     n_spec_fallback_++;
   }
+  spec_start_recorded_ = false;
   if (train) total_all_pts_ += n_all_pts;
   if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;
 

@@ -109,6 +109,10 @@ class Renderer : public Pipe {
   void PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream);
   bool PreSampleSpecComplete();  // false: could not be repaired (tree re-numbered): dropped
   at::cuda::CUDAEvent spec_start_ev_;
+  // 1: the side stream of a speculative sampling is ordered behind the point the main stream had reached when the step BEGAN,
+  // not behind the step's random draws / edge samples (SampleAndFilter); 0: behind the draws (A/B: bench.py --speculation-order)
+  int spec_order_ = 1;
+  bool spec_start_recorded_ = false;
   PendingSamples pending_samples_;
   Tensor pending_rays_o_, pending_rays_d_;
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,

@@ -283,6 +283,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("speculative_sampling",  // 0 / False never, 1 / True always, 2 while no leaf has died lately (default)
                     [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },
                     [](ExpRunner& r, int mode) { r.renderer_->speculative_sampling_ = mode; })
+      .def_property("speculation_order",  // 1: the speculative sampler starts where the step begins, 0: behind its draws (Renderer.h)
+                    [](ExpRunner& r) { return r.renderer_->spec_order_; },
+                    [](ExpRunner& r, int bits) { r.renderer_->spec_order_ = bits; })
       .def("speculation_counters",  // batches sampled ahead of the stat update / behind it, rays repaired after a leaf died
            [](ExpRunner& r) {
              r.FinishPending();
