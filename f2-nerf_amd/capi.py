@@ -11,7 +11,7 @@ import torch
 from . import build
 
 _lib = None
-ABI_VERSION = 8  # include/f2n_abi.h
+ABI_VERSION = 9  # include/f2n_abi.h
 
 
 class F2nError(RuntimeError):
@@ -97,6 +97,20 @@ def oct_intersect_strided(n_rays, max_hits, search_order, rays_o, rays_d, near, 
                                         _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
                                         _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True),
                                         _p(child_blocks, "u8", True)), "f2n_oct_intersect_strided")
+
+
+def oct_lds_max_interior():
+    return int(lib().f2n_oct_lds_max_interior())
+
+
+def oct_intersect_strided_lds(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total,
+                              oct_trans, child_blocks, interior_nodes, rank_of):
+    """The walk of oct_intersect_strided out of LDS-resident child records (trees with few interior nodes)."""
+    _ck(lib().f2n_oct_intersect_strided_lds(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
+                                            _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
+                                            _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True),
+                                            _p(child_blocks, "u8"), _p(interior_nodes, "i32"), _p(rank_of, "i32"),
+                                            _i(int(interior_nodes.numel()))), "f2n_oct_intersect_strided_lds")
 
 
 def segment_scan(n, counts, start_end, total):

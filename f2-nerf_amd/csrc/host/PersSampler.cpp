@@ -67,6 +67,17 @@ void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of 
   }
   child_blocks_gpu_ = torch::empty({int64_t(n) * 8 * 32}, torch::TensorOptions().dtype(torch::kUInt8).device(torch::kCUDA));
   F2N_CALL(f2n_oct_build_child_blocks(CurStream(), n, VoidP(tree_nodes_gpu_), VoidP(child_blocks_gpu_)));
+  // which nodes have a child (TreeNode::childs = int32 words 5..12 of the 64-byte node).  (nonzero synchronises: this runs
+  // where the tree is replaced or re-numbered -- construction, state loads, ProcOctree -- not in an ordinary iteration.)
+  interior_nodes_ = interior_rank_ = Tensor();
+  n_interior_ = 0;
+  if (n > 0) {
+    Tensor words = tree_nodes_gpu_.view(torch::kInt32).view({n, 16});
+    Tensor is_interior = words.slice(1, 5, 13).ge(0).any(1);
+    interior_nodes_ = torch::nonzero(is_interior).squeeze(1).to(torch::kInt32).contiguous();
+    interior_rank_ = (torch::cumsum(is_interior.to(torch::kInt32), 0) - 1).to(torch::kInt32).contiguous();
+    n_interior_ = (int) interior_nodes_.size(0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -133,10 +144,19 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor oct_idx = torch::empty({k_cap}, DevI32());
   Tensor oct_nf = torch::empty({k_cap, 2}, DevF32());
   Tensor oct_tr = torch::empty({k_cap}, DevI32());  // trans_idx of every listed leaf (the march would re-read the node)
-  F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided(st, n_rays, max_oct_intersect_per_ray_,
-                                  oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
-                                  VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
-                                  VoidP(oct.child_blocks_gpu_)));
+  // (a tree whose interior nodes fit into a CU's LDS is walked out of LDS: the walk is a chain of dependent record reads, and
+  // it is prefetched underneath the previous step's hash gather, behind whose L2 traffic each of those reads would queue)
+  if (lds_octree_ && oct.n_interior_ >= 1 && oct.n_interior_ <= f2n_oct_lds_max_interior()) {
+    F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided_lds(st, n_rays, max_oct_intersect_per_ray_,
+                                    oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
+                                    VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
+                                    VoidP(oct.child_blocks_gpu_), I32P(oct.interior_nodes_), I32P(oct.interior_rank_), oct.n_interior_));
+  } else {
+    F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided(st, n_rays, max_oct_intersect_per_ray_,
+                                    oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
+                                    VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
+                                    VoidP(oct.child_blocks_gpu_)));
+  }
 
   // ONE march into fixed-stride per-ray slots (28 B x 1024 per ray of scratch, of which only the filled prefixes are
   // touched) + the per-ray counts; the reference marches twice (count pass, host sync, fill pass: :383-423).

@@ -52,6 +52,10 @@ class PersOctree {
   int n_nodes_ = 0;
   Tensor tree_nodes_gpu_;  // TreeNode[n_nodes_], the reference's checkpoint bytes; lives (and is maintained) on the device
   Tensor child_blocks_gpu_;  // [n_nodes][8] x 32 B, derived from tree_nodes_gpu_ (f2n_oct_build_child_blocks)
+  // The nodes a walk can expand (those with a child), for the walk that keeps their records in LDS
+  // (f2n_oct_intersect_strided_lds): interior_nodes_[r] = node index, interior_rank_[node] = r.  Rebuilt with the child blocks.
+  Tensor interior_nodes_, interior_rank_;
+  int n_interior_ = 0;
   Tensor tree_weight_stats_, tree_alpha_stats_, tree_visit_cnt_;
   Tensor occ_;  // [4, n_nodes] weight votes, alpha votes, visited marks, visit counts (tree_visit_cnt_ is its last row)
   // Speculative sampling (f2n_abi.h, "Speculative sampling"): every stat update is an epoch; a leaf that dies in it is stamped
@@ -104,6 +108,7 @@ class PersSampler : public PtsSampler {
   // since (generation mismatch): nothing was issued, the caller must sample again.
   bool CompleteSpeculative(PendingSamples& p);
   void IssueScanAndPack(PendingSamples& p);
+  bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
   bool MaintenanceDue() const;  // the NEXT FinishOctUpdate runs ProcOctree (milestone / compact_freq, PersSampler.cu:605-614)
   SampleResultFlex FinishSamples(PendingSamples& p);
   std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;

@@ -429,7 +429,7 @@ int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const fl
   return f2n_launch_status();
 }
 
-int f2n_abi_version(void) { return 8; }
+int f2n_abi_version(void) { return 9; }
 #ifndef F2N_REFERENCE_NUMERICS
 #define F2N_REFERENCE_NUMERICS 0
 #endif

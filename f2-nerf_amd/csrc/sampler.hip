@@ -54,16 +54,40 @@ __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const f
 // descended into at most 3 are parked per level of the current path: 72 entries cover paths of 24 levels, which is the
 // deepest tree the reference's own 48-int stack (2 ints per level, PersSampler.cu:7,70) can walk without overrunning it.
 #define F2N_COOP_STACK 72
-template <int MODE>
+// LDSREC (MODE 2 only): the child records of every INTERIOR node -- the only ones a walk ever expands -- are copied into LDS
+// when the block starts (interior_nodes[r] = node index of the r-th interior node, rank_of[node] = its r; both change only
+// when the tree is rebuilt) and the walk then never leaves the CU: `cur` and the parked interior entries hold RANKS instead of
+// node indices (an interior node is never emitted, so its index is not needed).  Why: a walk is a chain of ~30-40 dependent
+// record reads per ray with one wave per SIMD -- 0.06 ms for 8192 rays alone, but 0.36 ms underneath the hash gather of the
+// step it is prefetched under, where every one of those reads queues behind the gather's L2 traffic
+// (profiles/r03_fresh_timeline.txt).  The bulk copy is bandwidth-bound (256 B per interior node and block, all loads
+// independent) and barely notices.  Same records, same order of tests: the output is bit-identical to the global-memory walk.
+template <int MODE, bool LDSREC = false>
 __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     int n_rays, int max_hits, const uint8_t* __restrict__ search_order, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, float g_near, float g_far, const F2nTreeNode* __restrict__ nodes,
     const int32_t* __restrict__ oct_start_end, int32_t* __restrict__ hit_counts, int32_t* __restrict__ oct_idx,
     float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total,
     int32_t* __restrict__ oct_trans, const F2nChildInfo* __restrict__ child_blocks, const int32_t* __restrict__ died_at,
-    int spec_epoch, const int32_t* __restrict__ death_epoch, int32_t* __restrict__ repair_flags, int32_t* __restrict__ n_repaired) {
+    int spec_epoch, const int32_t* __restrict__ death_epoch, int32_t* __restrict__ repair_flags, int32_t* __restrict__ n_repaired,
+    const int32_t* __restrict__ interior_nodes = nullptr, const int32_t* __restrict__ rank_of = nullptr, int n_interior = 0) {
+  static_assert(!LDSREC || MODE == 2, "the LDS-resident walk exists for the single-pass variant");
   if (MODE == 3) {
     if (*death_epoch < spec_epoch) return;  // no leaf died since the speculative walk: every list stands (grid-uniform)
+  }
+  extern __shared__ float4_t s_rec[];  // LDSREC: [n_interior][8 slots][2] = the F2nChildInfo records, pad = rank of an interior child
+  if (LDSREC) {
+    for (int i = threadIdx.x; i < n_interior * 8; i += 256) {
+      const int u = interior_nodes[i >> 3];
+      const float4_t* rec = (const float4_t*) (child_blocks + (size_t) u * 8 + (i & 7));
+      const float4_t cs = rec[0];
+      float4_t meta = rec[1];
+      const int ch = __float_as_int(meta[0]);
+      if (ch >= 0 && __float_as_int(meta[2]) != 0) meta[3] = __int_as_float(rank_of[ch]);
+      s_rec[2 * i] = cs;
+      s_rec[2 * i + 1] = meta;
+    }
+    __syncthreads();
   }
   // Work stack of a ray: every hit sibling behind the first interior hit of an expanded node is parked here, nearest on
   // top -- interior nodes as (index >= 0), valid leaves as (~index, near, far, trans) to be emitted when popped.  A node
@@ -151,13 +175,20 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     // ---- test this lane's child of `cur` ----
     bool hit = false, interior = false, valid_leaf = false;
     int child = -1, child_trans = -1;
+    int child_rank = -1;  // LDSREC: what stands for an interior child on the stack and in `cur`
     float near_ = g_near, far_ = g_far;
     const bool expanding = active && cur >= 0;
     if (expanding) {
-      if (child_blocks != nullptr) {  // one 32-byte record per child slot: no dependent second read
-        const float4_t* rec = (const float4_t*) (child_blocks + (size_t) cur * 8 + my_slot);
-        const float4_t cs = rec[0];
-        const float4_t meta = rec[1];
+      if (LDSREC || child_blocks != nullptr) {  // one 32-byte record per child slot: no dependent second read
+        float4_t cs, meta;
+        if (LDSREC) {
+          cs = s_rec[2 * (cur * 8 + my_slot)];
+          meta = s_rec[2 * (cur * 8 + my_slot) + 1];
+        } else {
+          const float4_t* rec = (const float4_t*) (child_blocks + (size_t) cur * 8 + my_slot);
+          cs = rec[0];
+          meta = rec[1];
+        }
         child = __float_as_int(meta[0]);
         if (child >= 0) {
           const float cc[3] = {cs[0], cs[1], cs[2]};
@@ -167,6 +198,7 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
             child_trans = __float_as_int(meta[1]);
             interior = __float_as_int(meta[2]) != 0;
             valid_leaf = !interior && child_trans >= 0;
+            if (LDSREC) child_rank = __float_as_int(meta[3]);
           }
         }
       } else {
@@ -213,13 +245,13 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
         }
         if ((rest >> k) & 1) {
           const int pos = sp + 1 + __popc(rest >> (k + 1));
-          s_node[pos][grp] = interior ? child : ~child;
+          s_node[pos][grp] = interior ? (LDSREC ? child_rank : child) : ~child;
           s_near[pos][grp] = near_;
           s_far[pos][grp] = far_;
           s_tr[pos][grp] = child_trans;
         }
         sp += n_rest;
-        cur = __shfl(child, (tid & 56) + k_int);                // the interior child's node index (lane k_int)
+        cur = __shfl(LDSREC ? child_rank : child, (tid & 56) + k_int);  // the interior child's node index / rank (lane k_int)
       } else {
         cur = -1;
       }
@@ -1047,6 +1079,35 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
                      (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
                      (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total, oct_trans,
                      (const F2nChildInfo*) child_blocks, nullptr, 0, nullptr, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
+// Interior nodes whose records fit next to the walk's stacks (36 KB) in a CU's 160 KB of LDS; at one 256-thread block per 32
+// rays a batch of 8192 rays puts one block on every CU, so the rest of the LDS stays free for the kernels it runs underneath.
+#define F2N_LDS_OCT_MAX_INTERIOR 448
+int f2n_oct_lds_max_interior(void) { return F2N_LDS_OCT_MAX_INTERIOR; }
+
+int f2n_oct_intersect_strided_lds(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                                  const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
+                                  int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans,
+                                  const void* child_blocks, const int32_t* interior_nodes, const int32_t* rank_of, int n_interior) {
+  if (n_rays < 0 || max_hits < 1 || child_blocks == nullptr || interior_nodes == nullptr || rank_of == nullptr) return F2N_ERR_INVALID_ARG;
+  if (n_interior < 1 || n_interior > F2N_LDS_OCT_MAX_INTERIOR) return F2N_ERR_UNSUPPORTED;
+  if (n_rays == 0) return F2N_OK;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
+  if (!attr_set[dev]) {  // more than the default 64 KB of LDS (static stacks + dynamic records) per block
+    if (hipFuncSetAttribute((const void*) oct_intersect_coop_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            F2N_LDS_OCT_MAX_INTERIOR * 8 * (int) sizeof(F2nChildInfo)) != hipSuccess)
+      return F2N_ERR_UNSUPPORTED;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((oct_intersect_coop_kernel<2, true>), dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256),
+                     (size_t) n_interior * 8 * sizeof(F2nChildInfo), (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d,
+                     near_, far_, (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total,
+                     oct_trans, (const F2nChildInfo*) child_blocks, nullptr, 0, nullptr, nullptr, nullptr, interior_nodes, rank_of,
+                     n_interior);
   return f2n_launch_status();
 }
 

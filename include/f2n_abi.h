@@ -97,6 +97,22 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
                               float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/,
                               int32_t* oct_trans /*[R*max_hits] or NULL: trans_idx of every listed leaf*/,
                               const void* child_blocks /*or NULL*/);
+/* The same walk with the records of every node that HAS a child (the only ones a walk expands) copied into LDS when a block
+ * starts: interior_nodes[r] = index of the r-th such node in index order, rank_of[node] = its r (both derived from the node
+ * array; they change only when child indices do, i.e. with f2n_oct_build_child_blocks).  For trees of up to
+ * f2n_oct_lds_max_interior() such nodes (F2N_ERR_UNSUPPORTED beyond).  Output bit-identical to f2n_oct_intersect_strided; the
+ * point is latency: the reference's one-thread-per-ray DFS (PersSampler.cu:53-152) and the walk above are chains of dependent
+ * reads, which take ~6x longer when the kernel runs underneath a kernel that saturates the L2s (as the prefetched sampling of
+ * the next batch does, under the hash gather). */
+int f2n_oct_lds_max_interior(void);
+int f2n_oct_intersect_strided_lds(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                                  const float* rays_d, float near_, float far_, const void* tree_nodes,
+                                  int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[R*max_hits]*/,
+                                  float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/,
+                                  int32_t* oct_trans /*[R*max_hits] or NULL*/, const void* child_blocks,
+                                  const int32_t* interior_nodes /*[n_interior]*/, const int32_t* rank_of /*[n_nodes]*/,
+                                  int n_interior);
+
 
 /* Optional acceleration structure for the three intersection entry points: child_blocks [n_nodes][8] x 32 B, entry
  * [u][c] = {center xyz, side_len, child index (-1: none), child's trans_idx, child has children, pad} of child slot c of
