@@ -156,6 +156,15 @@ def pack_samples(n_rays, pts_se, rays_o, rays_d, transes, s_pts, s_dt, s_t, s_an
                                _p(anchors, "i32")), "f2n_pack_samples")
 
 
+def pack_samples_repair(n_rays, pts_se, rays_o, rays_d, transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors, death_epoch,
+                        spec_epoch):
+    """pack_samples again, on the device only if a leaf died in an epoch >= spec_epoch (see f2n_abi.h, speculative sampling)."""
+    _ck(lib().f2n_pack_samples_repair(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(rays_o, "f32", True), _p(rays_d, "f32"),
+                                      _p(transes, "u8", True), _p(s_pts, "f32", True), _p(s_dt, "f32"), _p(s_t, "f32"),
+                                      _p(s_anchors, "i32"), _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"),
+                                      _p(anchors, "i32"), _p(death_epoch, "i32"), _i(spec_epoch)), "f2n_pack_samples_repair")
+
+
 def edge_samples(n, edge_pool, transes, edge_idx, edge_coords, out_pts, out_idx):
     _ck(lib().f2n_edge_samples(_stream(), _i(n), _p(edge_pool, "u8"), _p(transes, "u8"), _p(edge_idx, "i32"),
                                _p(edge_coords, "f32"), _p(out_pts, "f32"), _p(out_idx, "i32")), "f2n_edge_samples")

@@ -178,11 +178,14 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   p.completed = !speculative;
   p.generation = oct.generation_;
   p.spec_epoch = oct.epoch_ + 1;
-  if (speculative) {
-    p.repair_flags = torch::empty({n_rays}, DevI32());
-    return;
-  }
+  if (speculative) p.repair_flags = torch::empty({n_rays}, DevI32());
+  // Scan, count and pack follow the march at once -- also for a speculative batch (optimistic_pack_): its pack then runs in the
+  // stretch of the step the march ends in (underneath the hash gather, when the walk ran out of LDS) instead of behind the
+  // stat update, where it lands on field_shade_fwd, which is as memory-bound as the pack is (115 us against 59 alone:
+  // profiles/r03_speculation_experiments.txt).  CompleteSpeculative scans again and packs again only if a leaf died since.
+  if (speculative && !optimistic_pack_) return;
   IssueScanAndPack(p);
+  p.packed_once = speculative;
 }
 
 // The rays a stat update invalidated are walked and marched again (f2n_oct_intersect_repair / f2n_ray_march_repair: both
@@ -202,8 +205,28 @@ bool PersSampler::CompleteSpeculative(PendingSamples& p) {
                                  I32P(p.counts), nullptr, F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.first_oct_dis),
                                  I32P(p.oct_tr), I32P(p.repair_flags), I32P(oct.death_epoch_), p.spec_epoch));
   p.completed = true;
-  IssueScanAndPack(p);
+  if (!p.packed_once) {
+    IssueScanAndPack(p);
+    return true;
+  }
+  // packed optimistically right behind the march: the counts are taken again (the repaired rays' may have changed; the host
+  // reads THIS copy), and the pack runs again on the device only if a leaf died since -- into the same worst-case-sized arrays
+  IssueScan(p);
+  F2N_TIMED_CALL("pack_repair", f2n_pack_samples_repair(st, p.n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_),
+                                  nullptr, F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.o_pts) + 3 * (int64_t) p.extra_rows,
+                                  F32P(p.o_dirs), F32P(p.o_dt), F32P(p.o_t), I32P(p.o_anchors) + 3 * (int64_t) p.extra_rows,
+                                  I32P(oct.death_epoch_), p.spec_epoch));
   return true;
+}
+
+void PersSampler::IssueScan(PendingSamples& p) {
+  void* st = CurStream();
+  F2N_CALL(f2n_segment_scan(st, p.n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1));
+  // the single host read-back of a GetSamples call: through pinned memory and an event (no stream drain)
+  Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+  totals_host.copy_(p.totals, /*non_blocking=*/true);
+  p.counts_ready.record();
+  p.totals_host = totals_host;
 }
 
 void PersSampler::IssueScanAndPack(PendingSamples& p) {
@@ -211,11 +234,7 @@ void PersSampler::IssueScanAndPack(PendingSamples& p) {
   void* st = CurStream();
   const int n_rays = p.n_rays;
   const int64_t slots = p.s_dt.numel();
-  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1));
-  // the single host read-back of a GetSamples call: through pinned memory and an event (no stream drain)
-  Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-  totals_host.copy_(p.totals, /*non_blocking=*/true);
-  p.counts_ready.record();
+  IssueScan(p);
   // The pack does not wait for the host to learn N: its outputs are sized for the worst case (every ray's slots full; pages
   // beyond the N rows actually written are never touched) and it is queued right behind the scan.  With the host in the
   // loop (count -> allocate -> launch) the pack of a prefetched batch started ~30 us after the count landed and the density
@@ -233,7 +252,6 @@ void PersSampler::IssueScanAndPack(PendingSamples& p) {
   F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
                                     F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.o_pts) + 3 * (int64_t) extra, F32P(p.o_dirs),
                                     F32P(p.o_dt), F32P(p.o_t), I32P(p.o_anchors) + 3 * (int64_t) extra));
-  p.totals_host = totals_host;
 }
 
 SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {

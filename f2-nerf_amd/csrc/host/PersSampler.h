@@ -93,6 +93,7 @@ struct PendingSamples {
   // speculative: intersection and march were issued BEFORE the stat update they would normally wait for; scan / count / pack
   // are issued by CompleteSpeculative once that update is in the stream, behind the repair of the rays it invalidated
   bool speculative = false, completed = true;
+  bool packed_once = false;    // speculative and already scanned + packed behind its march (PersSampler::optimistic_pack_)
   int spec_epoch = 0;          // first stat-update epoch whose deaths the speculative walk may have missed
   int64_t generation = 0;      // PersOctree::generation_ the samples were marched against
   Tensor repair_flags;
@@ -108,6 +109,8 @@ class PersSampler : public PtsSampler {
   // since (generation mismatch): nothing was issued, the caller must sample again.
   bool CompleteSpeculative(PendingSamples& p);
   void IssueScanAndPack(PendingSamples& p);
+  void IssueScan(PendingSamples& p);  // segment scan + count read-back
+  bool optimistic_pack_ = true;  // speculative batches are packed right behind their march, again only if a leaf died (A/B knob)
   bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
   bool MaintenanceDue() const;  // the NEXT FinishOctUpdate runs ProcOctree (milestone / compact_freq, PersSampler.cu:605-614)
   SampleResultFlex FinishSamples(PendingSamples& p);

@@ -283,6 +283,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("speculative_sampling",  // 0 / False never, 1 / True always, 2 while no leaf has died lately (default)
                     [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },
                     [](ExpRunner& r, int mode) { r.renderer_->speculative_sampling_ = mode; })
+      .def_property("optimistic_pack",  // speculative batches packed right behind their march, again only if a leaf died (A/B knob)
+                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_; },
+                    [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_ = on; })
       .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })

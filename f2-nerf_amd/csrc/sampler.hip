@@ -559,7 +559,11 @@ __global__ __launch_bounds__(256) void pack_samples_kernel(int n_rays, const int
                                                            const float* __restrict__ s_dt, const float* __restrict__ s_t,
                                                            const int32_t* __restrict__ s_anchors, float* __restrict__ pts,
                                                            float* __restrict__ dirs, float* __restrict__ dt, float* __restrict__ t,
-                                                           int32_t* __restrict__ anchors) {
+                                                           int32_t* __restrict__ anchors, const int32_t* __restrict__ death_epoch,
+                                                           int spec_epoch) {
+  // (re-pack of a speculatively sampled batch that was already packed before the stat update: nothing to do unless a leaf
+  // died since -- the same grid-uniform test as the two repair kernels)
+  if (death_epoch != nullptr && *death_epoch < spec_epoch) return;
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
@@ -1197,14 +1201,23 @@ int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_
   return f2n_launch_status();
 }
 
-int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
-                     const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
-                     float* pts, float* dirs, float* dt, float* t, int32_t* anchors) {
+int f2n_pack_samples_repair(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
+                            const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
+                            float* pts, float* dirs, float* dt, float* t, int32_t* anchors, const int32_t* death_epoch,
+                            int spec_epoch) {
   if (n_rays < 0 || (s_pts == nullptr && (rays_o == nullptr || transes == nullptr))) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(pack_samples_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, pts_start_end,
-                     rays_o, rays_d, (const F2nTransInfo*) transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors);
+                     rays_o, rays_d, (const F2nTransInfo*) transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors,
+                     death_epoch, spec_epoch);
   return f2n_launch_status();
+}
+
+int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
+                     const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
+                     float* pts, float* dirs, float* dt, float* t, int32_t* anchors) {
+  return f2n_pack_samples_repair(stream, n_rays, pts_start_end, rays_o, rays_d, transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t,
+                                 anchors, nullptr, 0);
 }
 
 int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,

@@ -212,6 +212,10 @@ int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a
  *                             those rays and 0 for all others, n_repaired[0] (or NULL) += their number.  Returns immediately on
  *                             the device when death_epoch[0] < spec_epoch (then repair_flags is NOT written).
  *   f2n_ray_march_repair      f2n_ray_march_strided for the flagged rays only (same early exit).
+ *   f2n_pack_samples_repair   f2n_pack_samples once more over the whole batch, but only when a leaf died since (same early exit):
+ *                             a batch may be scanned and packed OPTIMISTICALLY right behind its speculative march -- long before
+ *                             the stat update, in a stretch of the step where the memory system has room -- and is scanned again
+ *                             and conditionally packed again behind the two repair calls.
  * After both, slots / counts / first_oct_dis are bit-identical to a fresh f2n_oct_intersect_strided + f2n_ray_march_strided on
  * the updated tree (tests/test_gpu_parity.py::test_speculative_sampling_repair). */
 int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
@@ -229,6 +233,10 @@ int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_
                          const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts, float* s_dt, float* s_t,
                          int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans, const int32_t* repair_flags,
                          const int32_t* death_epoch, int spec_epoch);
+int f2n_pack_samples_repair(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
+                            const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
+                            float* pts, float* dirs, float* dt, float* t, int32_t* anchors, const int32_t* death_epoch /*[1]*/,
+                            int spec_epoch);
 
 /* MarkInvisibleNodesKernel (PersSampler.cu:618-680). */
 int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris /*[C,3,3]*/,
