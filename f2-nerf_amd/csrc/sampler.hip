@@ -77,15 +77,39 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
   }
   extern __shared__ float4_t s_rec[];  // LDSREC: [n_interior][8 slots][2] = the F2nChildInfo records, pad = rank of an interior child
   if (LDSREC) {
-    for (int i = threadIdx.x; i < n_interior * 8; i += 256) {
-      const int u = interior_nodes[i >> 3];
-      const float4_t* rec = (const float4_t*) (child_blocks + (size_t) u * 8 + (i & 7));
-      const float4_t cs = rec[0];
-      float4_t meta = rec[1];
-      const int ch = __float_as_int(meta[0]);
-      if (ch >= 0 && __float_as_int(meta[2]) != 0) meta[3] = __int_as_float(rank_of[ch]);
-      s_rec[2 * i] = cs;
-      s_rec[2 * i + 1] = meta;
+    // four records per thread and round: node index, record, rank of an interior child are three DEPENDENT reads -- issued
+    // for all four before any is waited for, so a round costs three round trips (each several microseconds underneath the
+    // gather), not twelve
+    const int n_rec = n_interior * 8;
+    for (int base = 0; base < n_rec; base += 4 * 256) {
+      int u[4], rk[4];
+      float4_t cs[4], meta[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = base + q * 256 + (int) threadIdx.x;
+        u[q] = interior_nodes[min(i, n_rec - 1) >> 3];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = min(base + q * 256 + (int) threadIdx.x, n_rec - 1);
+        const float4_t* rec = (const float4_t*) (child_blocks + (size_t) u[q] * 8 + (i & 7));
+        cs[q] = rec[0];
+        meta[q] = rec[1];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int ch = __float_as_int(meta[q][0]);
+        rk[q] = (ch >= 0 && __float_as_int(meta[q][2]) != 0) ? rank_of[ch] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = base + q * 256 + (int) threadIdx.x;
+        if (i < n_rec) {
+          meta[q][3] = __int_as_float(rk[q]);
+          s_rec[2 * i] = cs[q];
+          s_rec[2 * i + 1] = meta[q];
+        }
+      }
     }
     __syncthreads();
   }
