@@ -114,14 +114,14 @@ Hash3DAnchored::Hash3DAnchored(GlobalDataPool* gdp) {  // Hash3DAnchored.cpp:19-
     chosen.reserve(need);
     while ((int64_t) chosen.size() < need) {
       Tensor cand = torch::randint(1 << 28, 1 << 30, {std::max<int64_t>(4096, 24 * (need - (int64_t) chosen.size()))}, CpuI32());
-      const int* c = cand.data_ptr<int>();
+      const int* cd = cand.data_ptr<int>();
       for (int64_t k = 0; k < cand.numel() && (int64_t) chosen.size() < need; k++) {
         bool prime = true;
         for (int p : small) {
-          if ((int64_t) p * p > c[k]) break;
-          if (c[k] % p == 0) { prime = false; break; }
+          if ((int64_t) p * p > cd[k]) break;
+          if (cd[k] % p == 0) { prime = false; break; }
         }
-        if (prime) chosen.push_back(c[k]);
+        if (prime) chosen.push_back(cd[k]);
       }
     }
     prim_pool_ = torch::from_blob(chosen.data(), {N_LEVELS, n_volumes_, 3}, CpuI32()).clone().to(torch::kCUDA).contiguous();

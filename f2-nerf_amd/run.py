@@ -17,7 +17,6 @@
 File IO and the command line are outside the hot path proper; this module exists so that a user of the
 reference finds the same entry point."""
 import glob
-import json
 import os
 import sys
 import time

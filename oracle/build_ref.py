@@ -20,7 +20,6 @@ import os
 import re
 import shutil
 import subprocess
-import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -12,7 +12,6 @@ What this cannot pin: LibTorch 1.13's CUDA kernels for linalg_inv / linalg_eigh 
 on the GPU); both sides here run the same ops of the same libtorch on the CPU, so the comparison is about the ALGORITHM
 (camera selection, frame construction, PCA weights, step normalisation), not about LAPACK-vs-cuSOLVER ulps."""
 import os
-import re
 import shutil
 import subprocess
 import sys
