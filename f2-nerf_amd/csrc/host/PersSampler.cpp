@@ -191,10 +191,13 @@ void PersSampler::IssueScanAndPack(PendingSamples& p) {
   void* st = CurStream();
   const int n_rays = p.n_rays;
   const int64_t slots = p.s_dt.numel();
-  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1));
-  // the single host read-back of a GetSamples call: through pinned memory and an event (no stream drain)
-  Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-  totals_host.copy_(p.totals, /*non_blocking=*/true);
+  // the single host read-back of a GetSamples call: [K, N] go to mapped host memory from the scan kernel itself, read after an
+  // event (no stream drain, and no copy launch between the scan and the pack)
+  totals_words_.Ensure(16);
+  p.totals_slot = next_totals_slot_;
+  next_totals_slot_ = (next_totals_slot_ + 1) & 7;
+  F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1, totals_words_.Dev(2 * p.totals_slot),
+                               I32P(p.totals), 1));
   p.counts_ready.record();
   // The pack does not wait for the host to learn N: its outputs are sized for the worst case (every ray's slots full; pages
   // beyond the N rows actually written are never touched) and it is queued right behind the scan.  With the host in the
@@ -213,15 +216,14 @@ void PersSampler::IssueScanAndPack(PendingSamples& p) {
   F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
                                     F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.o_pts) + 3 * (int64_t) extra, F32P(p.o_dirs),
                                     F32P(p.o_dt), F32P(p.o_t), I32P(p.o_anchors) + 3 * (int64_t) extra));
-  p.totals_host = totals_host;
 }
 
 SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
   TORCH_CHECK(p.active && p.completed, "FinishSamples without (completed) BeginSamples");
   const int n_rays = p.n_rays;
   p.counts_ready.synchronize();
-  const int n_all_oct = p.totals_host.data_ptr<int32_t>()[0];
-  const int n_all_pts = p.totals_host.data_ptr<int32_t>()[1];
+  const int n_all_oct = totals_words_.Read(2 * p.totals_slot);
+  const int n_all_pts = totals_words_.Read(2 * p.totals_slot + 1);
   if (global_data_pool_->mode_ == RunningMode::TRAIN) {
     float per_ray = float(n_all_oct) / float(n_rays);
     global_data_pool_->sampled_oct_per_ray_ = global_data_pool_->sampled_oct_per_ray_ * .9f + per_ray * .1f;
