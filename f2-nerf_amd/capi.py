@@ -118,6 +118,23 @@ def segment_scan(n, counts, start_end, total):
         "f2n_segment_scan")
 
 
+def _mapped(host_tensor):
+    """Device address of a PINNED host int32 tensor (hipHostMalloc memory is mapped into the device's address space at the
+    same address), or NULL."""
+    if host_tensor is None:
+        return ctypes.c_void_p(0)
+    if host_tensor.is_cuda or not host_tensor.is_pinned() or host_tensor.dtype != _DT["i32"] or not host_tensor.is_contiguous():
+        raise F2nError("mirror must be a contiguous pinned host int32 tensor")
+    return ctypes.c_void_p(host_tensor.data_ptr())
+
+
+def segment_scan_ex(n, counts, start_end, total, mirror=None, also=None):
+    """mirror: pinned host int32 tensor of len(also) + 1 words that the scan kernel itself fills (read it after a sync)."""
+    n_also = 0 if also is None else int(also.numel())
+    _ck(lib().f2n_segment_scan_ex(_stream(), _i(n), _p(counts, "i32"), _p(start_end, "i32"), _p(total, "i32"), _mapped(mirror),
+                                  _p(also, "i32", True), _i(n_also)), "f2n_segment_scan_ex")
+
+
 def oct_intersect_fill(n_rays, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, child_blocks=None):
     _ck(lib().f2n_oct_intersect_fill(_stream(), _i(n_rays), _p(search_order, "u8"), _p(rays_o, "f32"), _p(rays_d, "f32"),
                                      _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"), _p(oct_idx, "i32"),
@@ -524,6 +541,6 @@ def train_loss(n_rays, pred, gt, disparity, sampled_var, n_edge, feat_dim, edge_
                              _p(dvar, "f32", True), _p(dedge_feats, "f32", True)), "f2n_train_loss")
 
 
-def nonfinite_flags(n_a, a, n_b, b, flags):
-    _ck(lib().f2n_nonfinite_flags(_stream(), _i(n_a), _p(a, "f32", True), _i(n_b), _p(b, "f32", True), _p(flags, "i32")),
-        "f2n_nonfinite_flags")
+def nonfinite_flags(n_a, a, n_b, b, flags, mirror=None):
+    _ck(lib().f2n_nonfinite_flags_ex(_stream(), _i(n_a), _p(a, "f32", True), _i(n_b), _p(b, "f32", True), _p(flags, "i32"),
+                                     _mapped(mirror)), "f2n_nonfinite_flags_ex")

@@ -221,12 +221,17 @@ bool PersSampler::CompleteSpeculative(PendingSamples& p) {
 
 void PersSampler::IssueScan(PendingSamples& p) {
   void* st = CurStream();
-  F2N_CALL(f2n_segment_scan(st, p.n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1));
-  // the single host read-back of a GetSamples call: through pinned memory and an event (no stream drain)
-  Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-  totals_host.copy_(p.totals, /*non_blocking=*/true);
+  // the single host read-back of a GetSamples call: [K, N] go to mapped host memory from the scan kernel itself, read after an
+  // event (no stream drain, and no copy launch between the scan and the pack); a batch that is scanned a second time
+  // (CompleteSpeculative) keeps its slot -- the host reads it only behind the last scan's event
+  totals_words_.Ensure(16);
+  if (p.totals_slot < 0) {
+    p.totals_slot = next_totals_slot_;
+    next_totals_slot_ = (next_totals_slot_ + 1) & 7;
+  }
+  F2N_CALL(f2n_segment_scan_ex(st, p.n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1, totals_words_.Dev(2 * p.totals_slot),
+                               I32P(p.totals), 1));
   p.counts_ready.record();
-  p.totals_host = totals_host;
 }
 
 void PersSampler::IssueScanAndPack(PendingSamples& p) {
@@ -258,8 +263,8 @@ SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
   TORCH_CHECK(p.active && p.completed, "FinishSamples without (completed) BeginSamples");
   const int n_rays = p.n_rays;
   p.counts_ready.synchronize();
-  const int n_all_oct = p.totals_host.data_ptr<int32_t>()[0];
-  const int n_all_pts = p.totals_host.data_ptr<int32_t>()[1];
+  const int n_all_oct = totals_words_.Read(2 * p.totals_slot);
+  const int n_all_pts = totals_words_.Read(2 * p.totals_slot + 1);
   if (global_data_pool_->mode_ == RunningMode::TRAIN) {
     float per_ray = float(n_all_oct) / float(n_rays);
     global_data_pool_->sampled_oct_per_ray_ = global_data_pool_->sampled_oct_per_ray_ * .9f + per_ray * .1f;

@@ -4,6 +4,7 @@
 #pragma once
 #include <functional>
 
+#include "MappedHost.h"
 #include "PtsSampler.h"
 
 namespace f2n {
@@ -85,10 +86,11 @@ class PersOctree {
 struct PendingSamples {
   bool active = false;
   int n_rays = 0;
-  Tensor rays_o, rays_d, counts, oct_se, totals, totals_host, oct_idx, oct_nf, oct_tr, noise, pts_se, s_dt, s_t, s_anchors,
+  Tensor rays_o, rays_d, counts, oct_se, totals, oct_idx, oct_nf, oct_tr, noise, pts_se, s_dt, s_t, s_anchors,
       first_oct_dis;
   Tensor o_pts, o_dirs, o_dt, o_t, o_anchors;  // packed outputs, sized for the worst case (+ extra_rows), already being filled
   int extra_rows = 0;
+  int totals_slot = -1;  // which pair of PersSampler::totals_words_ the scan writes [K, N] to (read after counts_ready)
   at::cuda::CUDAEvent counts_ready;
   // speculative: intersection and march were issued BEFORE the stat update they would normally wait for; scan / count / pack
   // are issued by CompleteSpeculative once that update is in the stream, behind the repair of the rays it invalidated
@@ -122,6 +124,10 @@ class PersSampler : public PtsSampler {
                         Tensor& kept);
   void FinishOctUpdate();
   Tensor& VoteBuffer();
+  // [K, N] of the sampling calls in flight, written by the scan kernel itself (MappedHost.h); eight rotating pairs -- at most
+  // two calls are in flight (a prefetched batch and a synchronous GetSamples), dropped ones finish within the next few
+  MappedWords totals_words_;
+  int next_totals_slot_ = 0;
   std::vector<Tensor> States() override;
   int LoadStates(const std::vector<Tensor>& states, int idx) override;
 

@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
 #define F2N_SCAN_ITEMS 4
 __global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, const int32_t* __restrict__ counts,
                                                                         int32_t* __restrict__ start_end,
-                                                                        int32_t* __restrict__ total) {
+                                                                        int32_t* __restrict__ total, int32_t* __restrict__ mirror,
+                                                                        const int32_t* __restrict__ also, int n_also) {
   __shared__ int s_wave[F2N_SCAN_THREADS / F2N_WAVE];
   __shared__ int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -348,7 +349,15 @@ __global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, c
     if (tid == F2N_SCAN_THREADS - 1) s_carry = run;  // last thread holds the chunk's inclusive total
     __syncthreads();
   }
-  if (tid == 0) total[0] = s_carry;
+  if (tid == 0) {
+    total[0] = s_carry;
+    // the host's copy of the count(s), written where the count is produced: `mirror` is mapped host memory (a separate
+    // device-to-host copy launch cost one ~5 us dependent boundary on the queue of every scan)
+    if (mirror != nullptr) {
+      for (int k = 0; k < n_also; k++) mirror[k] = also[k];
+      mirror[n_also] = s_carry;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1153,11 +1162,16 @@ int f2n_oct_intersect_repair(void* stream, int n_rays, int max_hits, const uint8
   return f2n_launch_status();
 }
 
-int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end, int32_t* total) {
-  if (n < 0) return F2N_ERR_INVALID_ARG;
+int f2n_segment_scan_ex(void* stream, int n, const int32_t* counts, int32_t* start_end, int32_t* total, int32_t* mirror,
+                        const int32_t* also, int n_also) {
+  if (n < 0 || n_also < 0 || n_also > 4 || (n_also > 0 && (also == nullptr || mirror == nullptr))) return F2N_ERR_INVALID_ARG;
   hipLaunchKernelGGL(segment_scan_kernel, dim3(1), dim3(F2N_SCAN_THREADS), 0, (hipStream_t) stream, n, counts,
-                     start_end, total);
+                     start_end, total, mirror, also, n_also);
   return f2n_launch_status();
+}
+
+int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end, int32_t* total) {
+  return f2n_segment_scan_ex(stream, n, counts, start_end, total, nullptr, nullptr, 0);
 }
 
 int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order, const float* rays_o,

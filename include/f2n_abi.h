@@ -79,6 +79,15 @@ int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_
  * total[0] = sum.  Replaces the racing atomicAdd allocator (PersSampler.cu:144) and the
  * torch::cumsum + .item() host sync (:395-397); also FilterIdxBounds' cumsum (Renderer/Renderer.cu:44-48). */
 int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end /*[n,2]*/, int32_t* total /*[1]*/);
+/* The same, and the host's copy of the result from the same launch: `mirror` (or NULL) is a DEVICE pointer to MAPPED HOST
+ * memory (hipHostMallocMapped + hipHostGetDevicePointer) that receives also[0..n_also) followed by the total -- e.g. the hit
+ * total of f2n_oct_intersect_strided next to the sample total, the pair the reference reads back with two .item() calls
+ * (PersSampler.cu:353,397).  The host reads it after an event recorded behind this call; no device-to-host copy is queued
+ * (on an in-order queue that copy is one more dependent launch between the scan and the kernel that consumes it).
+ * n_also <= 4. */
+int f2n_segment_scan_ex(void* stream, int n, const int32_t* counts, int32_t* start_end /*[n,2]*/, int32_t* total /*[1]*/,
+                        int32_t* mirror /*mapped host [n_also+1] or NULL*/, const int32_t* also /*device [n_also] or NULL*/,
+                        int n_also);
 
 /* FindRayOctreeIntersectionKernel<true> (PersSampler.cu:357-366): fills each ray's segment with
  * (leaf node index, t_near, t_far), front to back. */
@@ -602,6 +611,11 @@ int f2n_train_loss(void* stream, int n_rays, const float* pred_colors /*[R,3]*/,
 /* Gradient finiteness check of the two MLPs (Field/TCNNWP.cpp:234-240), device side:
  * flags[0] = a has a non-finite value, flags[1] = b has one, flags[2] = either (the optimiser's skip_flag). */
 int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags /*[3]*/);
+/* The same, with the three flags also written to `mirror` (DEVICE pointer to MAPPED HOST memory, or NULL): the host-side
+ * reaction of TCNNWP.cpp:236-240 (halve the loss scale, drop the iteration) reads them there behind an event, without a copy
+ * launch behind the optimiser. */
+int f2n_nonfinite_flags_ex(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags /*[3]*/,
+                           int32_t* mirror /*mapped host [3] or NULL*/);
 
 #ifdef __cplusplus
 }

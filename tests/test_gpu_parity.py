@@ -259,6 +259,33 @@ def test_segment_scan(hip):
     assert int(tot.item()) == 0  # empty input
 
 
+def test_segment_scan_and_flags_write_their_host_mirror(hip):
+    """f2n_segment_scan_ex / f2n_nonfinite_flags_ex: the launch that produces a count (or the finiteness flags) also writes
+    the host's copy into mapped host memory -- what the host reads behind an event instead of queueing a copy."""
+    rng = np.random.default_rng(3)
+    for n in (1, 4097, 100003):
+        c = rng.integers(0, 1000, n).astype(np.int32)
+        se = torch.empty((n, 2), dtype=torch.int32, device=DEV)
+        tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+        also = torch.tensor([41, 42], dtype=torch.int32, device=DEV)
+        mirror = torch.full((3,), -1, dtype=torch.int32).pin_memory()
+        hip.segment_scan_ex(n, T(c), se, tot, mirror, also)
+        torch.cuda.synchronize()
+        assert mirror.tolist() == [41, 42, int(c.sum())] and int(tot.item()) == int(c.sum())
+        assert_same(N(se)[:, 1], np.cumsum(c).astype(np.int32))
+        mirror1 = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+        hip.segment_scan_ex(n, T(c), se, tot, mirror1)
+        torch.cuda.synchronize()
+        assert mirror1.tolist() == [int(c.sum())]
+    a = rng.standard_normal(3072).astype(F32); b = rng.standard_normal(7168).astype(F32)
+    b[17] = np.inf
+    flags = torch.full((3,), 7, dtype=torch.int32, device=DEV)
+    mirror = torch.full((4,), 9, dtype=torch.int32).pin_memory()
+    hip.nonfinite_flags(a.size, T(a), b.size, T(b), flags, mirror)
+    torch.cuda.synchronize()
+    assert N(flags).tolist() == [0, 1, 1] and mirror.tolist() == [0, 1, 1, 9]
+
+
 def test_edge_samples_and_occupancy(hip, fox_state, fox_golden):
     st, g = fox_state, fox_golden
     n = len(g["edge_idx"])
