@@ -315,6 +315,10 @@ def main():
                     "default of the host), on / off = A/B (profiles/r03_speculation_experiments.txt)")
     ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
                     "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
+    ap.add_argument("--lds-octree", type=int, default=-1, help="A/B: 0 walks the octree through the L2s even when its interior nodes "
+                    "fit into LDS, 1 out of LDS; -1 = host default")
+    ap.add_argument("--optimistic-pack", type=int, default=-1, help="A/B: 1 packs a speculatively sampled batch right behind its march "
+                    "(and again only if a leaf died), 0 behind the stat update; -1 = host default")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
 
@@ -369,6 +373,10 @@ def main():
     runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
     if args.speculation_order >= 0:
         runner.speculation_order = args.speculation_order
+    if args.lds_octree >= 0:
+        runner.lds_octree = bool(args.lds_octree)
+    if args.optimistic_pack >= 0:
+        runner.optimistic_pack = bool(args.optimistic_pack)
 
     if dp:
         from f2_nerf_amd import parallel

@@ -11,7 +11,7 @@ import torch
 from . import build
 
 _lib = None
-ABI_VERSION = 8  # include/f2n_abi.h
+ABI_VERSION = 9  # include/f2n_abi.h
 
 
 class F2nError(RuntimeError):
@@ -99,9 +99,40 @@ def oct_intersect_strided(n_rays, max_hits, search_order, rays_o, rays_d, near, 
                                         _p(child_blocks, "u8", True)), "f2n_oct_intersect_strided")
 
 
+def oct_lds_max_interior():
+    return int(lib().f2n_oct_lds_max_interior())
+
+
+def oct_intersect_strided_lds(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total,
+                              oct_trans, child_blocks, interior_nodes, rank_of):
+    """The walk of oct_intersect_strided out of LDS-resident child records (trees with few interior nodes)."""
+    _ck(lib().f2n_oct_intersect_strided_lds(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
+                                            _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
+                                            _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True),
+                                            _p(child_blocks, "u8"), _p(interior_nodes, "i32"), _p(rank_of, "i32"),
+                                            _i(int(interior_nodes.numel()))), "f2n_oct_intersect_strided_lds")
+
+
 def segment_scan(n, counts, start_end, total):
     _ck(lib().f2n_segment_scan(_stream(), _i(n), _p(counts, "i32"), _p(start_end, "i32"), _p(total, "i32")),
         "f2n_segment_scan")
+
+
+def _mapped(host_tensor):
+    """Device address of a PINNED host int32 tensor (hipHostMalloc memory is mapped into the device's address space at the
+    same address), or NULL."""
+    if host_tensor is None:
+        return ctypes.c_void_p(0)
+    if host_tensor.is_cuda or not host_tensor.is_pinned() or host_tensor.dtype != _DT["i32"] or not host_tensor.is_contiguous():
+        raise F2nError("mirror must be a contiguous pinned host int32 tensor")
+    return ctypes.c_void_p(host_tensor.data_ptr())
+
+
+def segment_scan_ex(n, counts, start_end, total, mirror=None, also=None):
+    """mirror: pinned host int32 tensor of len(also) + 1 words that the scan kernel itself fills (read it after a sync)."""
+    n_also = 0 if also is None else int(also.numel())
+    _ck(lib().f2n_segment_scan_ex(_stream(), _i(n), _p(counts, "i32"), _p(start_end, "i32"), _p(total, "i32"), _mapped(mirror),
+                                  _p(also, "i32", True), _i(n_also)), "f2n_segment_scan_ex")
 
 
 def oct_intersect_fill(n_rays, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, child_blocks=None):
@@ -140,6 +171,15 @@ def pack_samples(n_rays, pts_se, rays_o, rays_d, transes, s_pts, s_dt, s_t, s_an
                                _p(transes, "u8", True), _p(s_pts, "f32", True), _p(s_dt, "f32"),
                                _p(s_t, "f32"), _p(s_anchors, "i32"), _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"),
                                _p(anchors, "i32")), "f2n_pack_samples")
+
+
+def pack_samples_repair(n_rays, pts_se, rays_o, rays_d, transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors, death_epoch,
+                        spec_epoch):
+    """pack_samples again, on the device only if a leaf died in an epoch >= spec_epoch (see f2n_abi.h, speculative sampling)."""
+    _ck(lib().f2n_pack_samples_repair(_stream(), _i(n_rays), _p(pts_se, "i32"), _p(rays_o, "f32", True), _p(rays_d, "f32"),
+                                      _p(transes, "u8", True), _p(s_pts, "f32", True), _p(s_dt, "f32"), _p(s_t, "f32"),
+                                      _p(s_anchors, "i32"), _p(pts, "f32"), _p(dirs, "f32"), _p(dt, "f32"), _p(t, "f32"),
+                                      _p(anchors, "i32"), _p(death_epoch, "i32"), _i(spec_epoch)), "f2n_pack_samples_repair")
 
 
 def edge_samples(n, edge_pool, transes, edge_idx, edge_coords, out_pts, out_idx):
@@ -501,6 +541,6 @@ def train_loss(n_rays, pred, gt, disparity, sampled_var, n_edge, feat_dim, edge_
                              _p(dvar, "f32", True), _p(dedge_feats, "f32", True)), "f2n_train_loss")
 
 
-def nonfinite_flags(n_a, a, n_b, b, flags):
-    _ck(lib().f2n_nonfinite_flags(_stream(), _i(n_a), _p(a, "f32", True), _i(n_b), _p(b, "f32", True), _p(flags, "i32")),
-        "f2n_nonfinite_flags")
+def nonfinite_flags(n_a, a, n_b, b, flags, mirror=None):
+    _ck(lib().f2n_nonfinite_flags_ex(_stream(), _i(n_a), _p(a, "f32", True), _i(n_b), _p(b, "f32", True), _p(flags, "i32"),
+                                     _mapped(mirror)), "f2n_nonfinite_flags_ex")

@@ -188,8 +188,8 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
   // groups (f2n_adam_fused) has no block-wide dependency in it
   const int32_t* skip = skip_flag;
   if (compute_flags != nullptr) {
-    F2N_TIMED_CALL("adam", f2n_nonfinite_flags(st, field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
-                                               F32P(shader->mlp_->grad_scaled_), compute_flags));
+    F2N_TIMED_CALL("adam", f2n_nonfinite_flags_ex(st, field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
+                                                  F32P(shader->mlp_->grad_scaled_), compute_flags, NextFlagMirror()));
     skip = compute_flags + 2;
   }
   int n_table = 0;
@@ -305,7 +305,8 @@ bool ExpRunner::ResolveDeferredFlags() {
   nan_flags_ev_.synchronize();
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
-  const int32_t* f = nan_flags_host_.data_ptr<int32_t>();
+  const int32_t f[3] = {flag_words_.Read(4 * deferred_flag_slot_), flag_words_.Read(4 * deferred_flag_slot_ + 1),
+                        flag_words_.Read(4 * deferred_flag_slot_ + 2)};
   if (f[0]) field->mlp_->loss_scale_ = std::max(field->mlp_->loss_scale_ / 2.f, 1.f);
   if (f[1]) shader->mlp_->loss_scale_ = std::max(shader->mlp_->loss_scale_ / 2.f, 1.f);
   if (!f[2]) return false;
@@ -319,6 +320,14 @@ bool ExpRunner::ResolveDeferredFlags() {
   return true;
 }
 
+// The host-visible slot the next flag kernel writes besides the device flags (see ExpRunner.h).
+int32_t* ExpRunner::NextFlagMirror() {
+  flag_words_.Ensure(8);
+  last_flag_slot_ = next_flag_slot_;
+  next_flag_slot_ ^= 1;
+  return flag_words_.Dev(4 * last_flag_slot_);
+}
+
 // Finiteness flags (TCNNWP.cpp:234-240, on the device) and Adam predicated on them: enqueue only.
 void ExpRunner::EnqueueApply(bool apply_optimizer) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
@@ -327,8 +336,8 @@ void ExpRunner::EnqueueApply(bool apply_optimizer) {
   if (apply_optimizer) {  // the flags are computed by the small-groups launch itself; a no-op on the device when they say so
     OptimStep(nullptr, check_nan_ ? I32P(nan_flags_) : nullptr);
   } else if (check_nan_) {
-    F2N_CALL(f2n_nonfinite_flags(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
-                                 F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_)));
+    F2N_CALL(f2n_nonfinite_flags_ex(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
+                                    F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_), NextFlagMirror()));
   }
 }
 
@@ -370,8 +379,7 @@ void ExpRunner::FinishPendingStep() { sync_.FinishPendingStep(); }
 
 void ExpRunner::DeferFlags(bool apply_optimizer) {
   if (flags_deferred_) ResolveDeferredFlags();  // (one set in flight at a time)
-  if (!nan_flags_host_.defined()) nan_flags_host_ = torch::empty({4}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-  nan_flags_host_.copy_(nan_flags_, /*non_blocking=*/true);
+  deferred_flag_slot_ = last_flag_slot_;  // (written by the flag kernel EnqueueApply has just queued)
   nan_flags_ev_.record();
   flags_deferred_ = true;
   deferred_apply_ = apply_optimizer;

@@ -39,6 +39,7 @@ class ExpRunner {
                        const Tensor& emb_idx, bool apply_optimizer = true, const Tensor& next_rays_o = Tensor(),
                        const Tensor& next_rays_d = Tensor(), const Tensor& next_bounds = Tensor());
   void EnqueueApply(bool apply_optimizer);
+  int32_t* NextFlagMirror();
   bool ResolveFlags(bool apply_optimizer);
   TrainStats TrainStepAutograd(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                const Tensor& emb_idx, bool apply_optimizer = true);
@@ -98,11 +99,13 @@ class ExpRunner {
   // make the compute stream wait for it in the NEXT TrainStep after ray sampling has been issued (or in FinishPending).
   GradSyncPipeline sync_;
   Tensor nan_flags_;  // device int32 [4]: field MLP, colour MLP, either
-  // A TrainStep that is handed the next batch (streaming use) does not wait for its own flags: they are copied to pinned
-  // memory and read after the NEXT step's sample-count read-back, when they are certain to have arrived.  The update
+  // A TrainStep that is handed the next batch (streaming use) does not wait for its own flags: the kernel that computes
+  // them also writes them to mapped host memory (MappedHost.h; two slots of four words, alternating -- the next step's kernel
+  // is queued before this step's slot is read), and the host reads them in the NEXT step, behind an event.  The update
   // itself is predicated on the device either way; only the host-side reaction (halved loss scale, iteration counter)
   // lags by one step, on the rare non-finite path.
-  Tensor nan_flags_host_;
+  MappedWords flag_words_;
+  int next_flag_slot_ = 0, last_flag_slot_ = 0, deferred_flag_slot_ = 0;
   at::cuda::CUDAEvent nan_flags_ev_;
   bool flags_deferred_ = false, deferred_apply_ = false, deferred_dropped_ = false;
 

@@ -67,6 +67,17 @@ void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of 
   }
   child_blocks_gpu_ = torch::empty({int64_t(n) * 8 * 32}, torch::TensorOptions().dtype(torch::kUInt8).device(torch::kCUDA));
   F2N_CALL(f2n_oct_build_child_blocks(CurStream(), n, VoidP(tree_nodes_gpu_), VoidP(child_blocks_gpu_)));
+  // which nodes have a child (TreeNode::childs = int32 words 5..12 of the 64-byte node).  (nonzero synchronises: this runs
+  // where the tree is replaced or re-numbered -- construction, state loads, ProcOctree -- not in an ordinary iteration.)
+  interior_nodes_ = interior_rank_ = Tensor();
+  n_interior_ = 0;
+  if (n > 0) {
+    Tensor words = tree_nodes_gpu_.view(torch::kInt32).view({n, 16});
+    Tensor is_interior = words.slice(1, 5, 13).ge(0).any(1);
+    interior_nodes_ = torch::nonzero(is_interior).squeeze(1).to(torch::kInt32).contiguous();
+    interior_rank_ = (torch::cumsum(is_interior.to(torch::kInt32), 0) - 1).to(torch::kInt32).contiguous();
+    n_interior_ = (int) interior_nodes_.size(0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -133,10 +144,19 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor oct_idx = torch::empty({k_cap}, DevI32());
   Tensor oct_nf = torch::empty({k_cap, 2}, DevF32());
   Tensor oct_tr = torch::empty({k_cap}, DevI32());  // trans_idx of every listed leaf (the march would re-read the node)
-  F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided(st, n_rays, max_oct_intersect_per_ray_,
-                                  oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
-                                  VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
-                                  VoidP(oct.child_blocks_gpu_)));
+  // (a tree whose interior nodes fit into a CU's LDS is walked out of LDS: the walk is a chain of dependent record reads, and
+  // it is prefetched underneath the previous step's hash gather, behind whose L2 traffic each of those reads would queue)
+  if (lds_octree_ && oct.n_interior_ >= 1 && oct.n_interior_ <= f2n_oct_lds_max_interior()) {
+    F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided_lds(st, n_rays, max_oct_intersect_per_ray_,
+                                    oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
+                                    VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
+                                    VoidP(oct.child_blocks_gpu_), I32P(oct.interior_nodes_), I32P(oct.interior_rank_), oct.n_interior_));
+  } else {
+    F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided(st, n_rays, max_oct_intersect_per_ray_,
+                                    oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
+                                    VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
+                                    VoidP(oct.child_blocks_gpu_)));
+  }
 
   // ONE march into fixed-stride per-ray slots (28 B x 1024 per ray of scratch, of which only the filled prefixes are
   // touched) + the per-ray counts; the reference marches twice (count pass, host sync, fill pass: :383-423).
@@ -158,11 +178,14 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   p.completed = !speculative;
   p.generation = oct.generation_;
   p.spec_epoch = oct.epoch_ + 1;
-  if (speculative) {
-    p.repair_flags = torch::empty({n_rays}, DevI32());
-    return;
-  }
+  if (speculative) p.repair_flags = torch::empty({n_rays}, DevI32());
+  // Scan, count and pack follow the march at once -- also for a speculative batch (optimistic_pack_): its pack then runs in the
+  // stretch of the step the march ends in (underneath the hash gather, when the walk ran out of LDS) instead of behind the
+  // stat update, where it lands on field_shade_fwd, which is as memory-bound as the pack is (115 us against 59 alone:
+  // profiles/r03_speculation_experiments.txt).  CompleteSpeculative scans again and packs again only if a leaf died since.
+  if (speculative && !optimistic_pack_) return;
   IssueScanAndPack(p);
+  p.packed_once = speculative;
 }
 
 // The rays a stat update invalidated are walked and marched again (f2n_oct_intersect_repair / f2n_ray_march_repair: both
@@ -182,8 +205,33 @@ bool PersSampler::CompleteSpeculative(PendingSamples& p) {
                                  I32P(p.counts), nullptr, F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.first_oct_dis),
                                  I32P(p.oct_tr), I32P(p.repair_flags), I32P(oct.death_epoch_), p.spec_epoch));
   p.completed = true;
-  IssueScanAndPack(p);
+  if (!p.packed_once) {
+    IssueScanAndPack(p);
+    return true;
+  }
+  // packed optimistically right behind the march: the counts are taken again (the repaired rays' may have changed; the host
+  // reads THIS copy), and the pack runs again on the device only if a leaf died since -- into the same worst-case-sized arrays
+  IssueScan(p);
+  F2N_TIMED_CALL("pack_repair", f2n_pack_samples_repair(st, p.n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_),
+                                  nullptr, F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.o_pts) + 3 * (int64_t) p.extra_rows,
+                                  F32P(p.o_dirs), F32P(p.o_dt), F32P(p.o_t), I32P(p.o_anchors) + 3 * (int64_t) p.extra_rows,
+                                  I32P(oct.death_epoch_), p.spec_epoch));
   return true;
+}
+
+void PersSampler::IssueScan(PendingSamples& p) {
+  void* st = CurStream();
+  // the single host read-back of a GetSamples call: [K, N] go to mapped host memory from the scan kernel itself, read after an
+  // event (no stream drain, and no copy launch between the scan and the pack); a batch that is scanned a second time
+  // (CompleteSpeculative) keeps its slot -- the host reads it only behind the last scan's event
+  totals_words_.Ensure(16);
+  if (p.totals_slot < 0) {
+    p.totals_slot = next_totals_slot_;
+    next_totals_slot_ = (next_totals_slot_ + 1) & 7;
+  }
+  F2N_CALL(f2n_segment_scan_ex(st, p.n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1, totals_words_.Dev(2 * p.totals_slot),
+                               I32P(p.totals), 1));
+  p.counts_ready.record();
 }
 
 void PersSampler::IssueScanAndPack(PendingSamples& p) {
@@ -191,11 +239,7 @@ void PersSampler::IssueScanAndPack(PendingSamples& p) {
   void* st = CurStream();
   const int n_rays = p.n_rays;
   const int64_t slots = p.s_dt.numel();
-  F2N_CALL(f2n_segment_scan(st, n_rays, I32P(p.counts), I32P(p.pts_se), I32P(p.totals) + 1));
-  // the single host read-back of a GetSamples call: through pinned memory and an event (no stream drain)
-  Tensor totals_host = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-  totals_host.copy_(p.totals, /*non_blocking=*/true);
-  p.counts_ready.record();
+  IssueScan(p);
   // The pack does not wait for the host to learn N: its outputs are sized for the worst case (every ray's slots full; pages
   // beyond the N rows actually written are never touched) and it is queued right behind the scan.  With the host in the
   // loop (count -> allocate -> launch) the pack of a prefetched batch started ~30 us after the count landed and the density
@@ -213,15 +257,14 @@ void PersSampler::IssueScanAndPack(PendingSamples& p) {
   F2N_TIMED_CALL("pack_samples", f2n_pack_samples(st, n_rays, I32P(p.pts_se), F32P(p.rays_o), F32P(p.rays_d), VoidP(oct.pers_trans_gpu_), nullptr,
                                     F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.o_pts) + 3 * (int64_t) extra, F32P(p.o_dirs),
                                     F32P(p.o_dt), F32P(p.o_t), I32P(p.o_anchors) + 3 * (int64_t) extra));
-  p.totals_host = totals_host;
 }
 
 SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
   TORCH_CHECK(p.active && p.completed, "FinishSamples without (completed) BeginSamples");
   const int n_rays = p.n_rays;
   p.counts_ready.synchronize();
-  const int n_all_oct = p.totals_host.data_ptr<int32_t>()[0];
-  const int n_all_pts = p.totals_host.data_ptr<int32_t>()[1];
+  const int n_all_oct = totals_words_.Read(2 * p.totals_slot);
+  const int n_all_pts = totals_words_.Read(2 * p.totals_slot + 1);
   if (global_data_pool_->mode_ == RunningMode::TRAIN) {
     float per_ray = float(n_all_oct) / float(n_rays);
     global_data_pool_->sampled_oct_per_ray_ = global_data_pool_->sampled_oct_per_ray_ * .9f + per_ray * .1f;

@@ -4,6 +4,7 @@
 #pragma once
 #include <functional>
 
+#include "MappedHost.h"
 #include "PtsSampler.h"
 
 namespace f2n {
@@ -52,6 +53,10 @@ class PersOctree {
   int n_nodes_ = 0;
   Tensor tree_nodes_gpu_;  // TreeNode[n_nodes_], the reference's checkpoint bytes; lives (and is maintained) on the device
   Tensor child_blocks_gpu_;  // [n_nodes][8] x 32 B, derived from tree_nodes_gpu_ (f2n_oct_build_child_blocks)
+  // The nodes a walk can expand (those with a child), for the walk that keeps their records in LDS
+  // (f2n_oct_intersect_strided_lds): interior_nodes_[r] = node index, interior_rank_[node] = r.  Rebuilt with the child blocks.
+  Tensor interior_nodes_, interior_rank_;
+  int n_interior_ = 0;
   Tensor tree_weight_stats_, tree_alpha_stats_, tree_visit_cnt_;
   Tensor occ_;  // [4, n_nodes] weight votes, alpha votes, visited marks, visit counts (tree_visit_cnt_ is its last row)
   // Speculative sampling (f2n_abi.h, "Speculative sampling"): every stat update is an epoch; a leaf that dies in it is stamped
@@ -81,14 +86,16 @@ class PersOctree {
 struct PendingSamples {
   bool active = false;
   int n_rays = 0;
-  Tensor rays_o, rays_d, counts, oct_se, totals, totals_host, oct_idx, oct_nf, oct_tr, noise, pts_se, s_dt, s_t, s_anchors,
+  Tensor rays_o, rays_d, counts, oct_se, totals, oct_idx, oct_nf, oct_tr, noise, pts_se, s_dt, s_t, s_anchors,
       first_oct_dis;
   Tensor o_pts, o_dirs, o_dt, o_t, o_anchors;  // packed outputs, sized for the worst case (+ extra_rows), already being filled
   int extra_rows = 0;
+  int totals_slot = -1;  // which pair of PersSampler::totals_words_ the scan writes [K, N] to (read after counts_ready)
   at::cuda::CUDAEvent counts_ready;
   // speculative: intersection and march were issued BEFORE the stat update they would normally wait for; scan / count / pack
   // are issued by CompleteSpeculative once that update is in the stream, behind the repair of the rays it invalidated
   bool speculative = false, completed = true;
+  bool packed_once = false;    // speculative and already scanned + packed behind its march (PersSampler::optimistic_pack_)
   int spec_epoch = 0;          // first stat-update epoch whose deaths the speculative walk may have missed
   int64_t generation = 0;      // PersOctree::generation_ the samples were marched against
   Tensor repair_flags;
@@ -104,6 +111,9 @@ class PersSampler : public PtsSampler {
   // since (generation mismatch): nothing was issued, the caller must sample again.
   bool CompleteSpeculative(PendingSamples& p);
   void IssueScanAndPack(PendingSamples& p);
+  void IssueScan(PendingSamples& p);  // segment scan + count read-back
+  bool optimistic_pack_ = true;  // speculative batches are packed right behind their march, again only if a leaf died (A/B knob)
+  bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
   bool MaintenanceDue() const;  // the NEXT FinishOctUpdate runs ProcOctree (milestone / compact_freq, PersSampler.cu:605-614)
   SampleResultFlex FinishSamples(PendingSamples& p);
   std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;
@@ -114,6 +124,10 @@ class PersSampler : public PtsSampler {
                         Tensor& kept);
   void FinishOctUpdate();
   Tensor& VoteBuffer();
+  // [K, N] of the sampling calls in flight, written by the scan kernel itself (MappedHost.h); eight rotating pairs -- at most
+  // two calls are in flight (a prefetched batch and a synchronous GetSamples), dropped ones finish within the next few
+  MappedWords totals_words_;
+  int next_totals_slot_ = 0;
   std::vector<Tensor> States() override;
   int LoadStates(const std::vector<Tensor>& states, int idx) override;
 

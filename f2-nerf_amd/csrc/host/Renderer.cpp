@@ -341,7 +341,7 @@ void Renderer::ResolvePendingCount() {
   if (!count_pending_) return;
   count_pending_ = false;
   n_kept_ev_.synchronize();  // long since recorded: this is the previous step's count
-  const int n_kept = n_kept_host_.data_ptr<int32_t>()[0];
+  const int n_kept = n_kept_words_.Read(0);
   last_n_kept_pts_ = n_kept;
   total_kept_pts_ += n_kept;
   auto* gdp = global_data_pool_;
@@ -538,12 +538,12 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       octree_update_issued();
     }
     Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::empty({1}, DevI32());
-    F2N_CALL(f2n_segment_scan(st, n_rays, I32P(kept), I32P(new_se), I32P(total)));  // FilterIdxBounds, Renderer.cu:20-50
-    // Second (and last) host read-back of a Render call: M, the number of surviving samples.  It goes through pinned
-    // memory and an event, not a stream drain, so that the work below that does not depend on M (the occupancy update,
-    // the random draws of the edge samples) is already queued behind the copy and runs while the host wakes up.
-    if (!n_kept_host_.defined()) n_kept_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-    n_kept_host_.copy_(total, /*non_blocking=*/true);
+    // Second (and last) host read-back of a Render call: M, the number of surviving samples.  The scan writes it to mapped
+    // host memory as well (FilterIdxBounds, Renderer.cu:20-50); the host reads it behind an event, not a stream drain, so that
+    // the work below that does not depend on M (the occupancy update, the edge samples) is already queued and runs while the
+    // host wakes up -- and no copy launch sits between the scan and the compaction.
+    n_kept_words_.Ensure(1);
+    F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(kept), I32P(new_se), I32P(total), n_kept_words_.Dev(0), nullptr, 0));
     n_kept_ev_.record();
     if (train && dp_world_ > 1) dp_count_ = total.clone();  // summed over the ranks inside the occupancy exchange
     if (train && !octree_first) ps->FinishOctUpdate();  // Renderer.cpp:140-149 (the votes were cast above)
@@ -564,7 +564,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       fr.n_kept_dev = total;
     } else {
       n_kept_ev_.synchronize();
-      n_kept = n_kept_host_.data_ptr<int32_t>()[0];
+      n_kept = n_kept_words_.Read(0);
       if (train && after_count_readback_) after_count_readback_();  // everything queued before this point has finished
       last_n_kept_pts_ = n_kept;
       if (train) total_kept_pts_ += n_kept;

@@ -158,7 +158,7 @@ class Renderer : public Pipe {
   bool consumed_side_samples_ = false, side_must_wait_consumed_ = false;
   bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
-  Tensor n_kept_host_;  // pinned int32[1]: the surviving-sample count, read back through n_kept_ev_
+  MappedWords n_kept_words_;  // [1]: the surviving-sample count, written by the survivor scan itself, read behind n_kept_ev_
   std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;
   Tensor forced_bg_;  // explicit background colours for parity tests (undefined = as the reference)
   int n_edge_pts_ = 8192;

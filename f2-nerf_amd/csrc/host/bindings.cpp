@@ -28,7 +28,7 @@ py::dict StatsToDict(const TrainStats& s) {
 
 // the ABI version this host layer was compiled against (include/f2n_abi.h); a kernel library of another version next to it
 // means one of the two was not rebuilt -- calls would pass the wrong argument lists (observed once: a memory fault)
-#define F2N_HOST_EXPECTS_ABI 8
+#define F2N_HOST_EXPECTS_ABI 9
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "f2-nerf hot path: C++/LibTorch host layer over libf2n_hip.so";
@@ -283,6 +283,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("speculative_sampling",  // 0 / False never, 1 / True always, 2 while no leaf has died lately (default)
                     [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },
                     [](ExpRunner& r, int mode) { r.renderer_->speculative_sampling_ = mode; })
+      .def_property("optimistic_pack",  // speculative batches packed right behind their march, again only if a leaf died (A/B knob)
+                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_; },
+                    [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_ = on; })
+      .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
+                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
+                    [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })
       .def_property("speculation_order",  // 1: the speculative sampler starts where the step begins, 0: behind its draws (Renderer.h)
                     [](ExpRunner& r) { return r.renderer_->spec_order_; },
                     [](ExpRunner& r, int bits) { r.renderer_->spec_order_ = bits; })

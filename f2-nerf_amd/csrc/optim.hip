@@ -91,7 +91,12 @@ struct F2nLossArgs {
   float *dcolors, *ddisp, *dvar, *dedge;
 };
 
-__global__ __launch_bounds__(256) void train_loss_kernel(F2nLossArgs a, float* __restrict__ partials) {
+// The last block to arrive adds the blocks' partial sums up (one wave, lane b owns block b's partial, fixed butterfly order:
+// the result does not depend on which block that is) and writes the eight outputs -- the second launch this used to be cost a
+// dependent boundary on the step's critical queue for a microsecond of work.  `arrived` lives behind the partials in the
+// workspace, is zero when the workspace is created and wraps back to zero with the last arrival (atomicInc).
+__global__ __launch_bounds__(256) void train_loss_kernel(F2nLossArgs a, float* __restrict__ partials, unsigned* __restrict__ arrived,
+                                                         float* __restrict__ out) {
   __shared__ float s_red[F2N_LOSS_TERMS][256];
   float acc[F2N_LOSS_TERMS] = {0.f, 0.f, 0.f, 0.f, 0.f};
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
@@ -141,29 +146,34 @@ __global__ __launch_bounds__(256) void train_loss_kernel(F2nLossArgs a, float* _
     __syncthreads();
   }
   if (threadIdx.x < F2N_LOSS_TERMS) partials[blockIdx.x * F2N_LOSS_TERMS + threadIdx.x] = s_red[threadIdx.x][0];
-}
-
-__global__ __launch_bounds__(64) void train_loss_finalize_kernel(F2nLossArgs a, int n_blocks, const float* __restrict__ partials,
-                                                                 float* __restrict__ out) {
+  __shared__ int s_last;
+  __threadfence();  // this block's partials are visible device-wide before its arrival is
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicInc(arrived, gridDim.x - 1) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  __threadfence();
+  const int n_blocks = gridDim.x;
   float t[F2N_LOSS_TERMS];
 #pragma unroll
   for (int k = 0; k < F2N_LOSS_TERMS; k++) {  // one wave: lane b owns block b's partial, fixed butterfly order
     float s = 0.f;
-    for (int b = threadIdx.x; b < n_blocks; b += 64) s += partials[b * F2N_LOSS_TERMS + k];
+    for (int b = threadIdx.x; b < n_blocks; b += 64)  // (device-scope loads: the other blocks' stores, not this CU's L1)
+      s += __hip_atomic_load(partials + b * F2N_LOSS_TERMS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     t[k] = s;
   }
   if (threadIdx.x != 0) return;
-  const float n_col = (float) max(3 * a.n_rays, 1), n_ray = (float) max(a.n_rays, 1), n_tv = (float) max(a.n_edge * a.feat_dim, 1);
-  const float color = t[0] / n_col, var = a.var != nullptr ? t[1] / n_ray : 0.f, disp = a.disp != nullptr ? t[2] / n_ray : 0.f;
-  const float tv = a.edge != nullptr ? t[3] / n_tv : 0.f;
+  const float f_col = (float) max(3 * a.n_rays, 1), f_ray = (float) max(a.n_rays, 1), f_tv = (float) max(a.n_edge * a.feat_dim, 1);
+  const float color = t[0] / f_col, var = a.var != nullptr ? t[1] / f_ray : 0.f, disp = a.disp != nullptr ? t[2] / f_ray : 0.f;
+  const float tv = a.edge != nullptr ? t[3] / f_tv : 0.f;
   out[0] = color + var * a.var_w + disp * a.disp_w + tv * a.tv_w;
   out[1] = color;
   out[2] = var;
   out[3] = disp;
   out[4] = tv;
-  out[5] = t[4] / n_col;
+  out[5] = t[4] / f_col;
   out[6] = 0.f;
   out[7] = 0.f;
 }
@@ -171,7 +181,8 @@ __global__ __launch_bounds__(64) void train_loss_finalize_kernel(F2nLossArgs a, 
 // TCNNWP.cpp:234-240: are the (loss-scaled) parameter gradients of the two MLPs finite?  One block, no atomics, no
 // pre-zeroing: flags = {a has a non-finite value, b has one, either}.
 __global__ __launch_bounds__(1024) void nonfinite_flags_kernel(int n_a, const float* __restrict__ a, int n_b,
-                                                               const float* __restrict__ b, int32_t* __restrict__ flags) {
+                                                               const float* __restrict__ b, int32_t* __restrict__ flags,
+                                                               int32_t* __restrict__ mirror) {
   __shared__ int s_bad[2];
   if (threadIdx.x < 2) s_bad[threadIdx.x] = 0;
   __syncthreads();
@@ -185,6 +196,11 @@ __global__ __launch_bounds__(1024) void nonfinite_flags_kernel(int n_a, const fl
     flags[0] = s_bad[0];
     flags[1] = s_bad[1];
     flags[2] = s_bad[0] | s_bad[1];
+    if (mirror != nullptr) {  // mapped host memory: the host's copy without a copy launch behind the optimiser
+      mirror[0] = s_bad[0];
+      mirror[1] = s_bad[1];
+      mirror[2] = s_bad[0] | s_bad[1];
+    }
   }
 }
 
@@ -414,22 +430,26 @@ int f2n_train_loss(void* stream, int n_rays, const float* pred_colors, const flo
                    float tv_w, float* out_losses, float* dcolors, float* ddisparity, float* dvar, float* dedge_feats) {
   if (n_rays < 0 || n_edge < 0 || feat_dim < 0 || out_losses == nullptr) return F2N_ERR_INVALID_ARG;
   if (n_rays > 0 && (pred_colors == nullptr || gt_colors == nullptr)) return F2N_ERR_INVALID_ARG;
-  float* partials = (float*) f2n_ws_get(F2N_WS_LOSS, sizeof(float) * F2N_LOSS_BLOCKS * F2N_LOSS_TERMS);
+  float* partials = (float*) f2n_ws_get(F2N_WS_LOSS, sizeof(float) * (F2N_LOSS_BLOCKS * F2N_LOSS_TERMS + 1));  // (+ arrival counter)
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   F2nLossArgs a = {n_rays, n_edge, feat_dim, pred_colors, gt_colors, disparity, sampled_var,
                    (n_edge > 0 && feat_dim > 0) ? edge_feats : nullptr, var_w, disp_w, tv_w, dcolors, ddisparity, dvar, dedge_feats};
-  hipLaunchKernelGGL(train_loss_kernel, dim3(F2N_LOSS_BLOCKS), dim3(256), 0, (hipStream_t) stream, a, partials);
-  hipLaunchKernelGGL(train_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, a, F2N_LOSS_BLOCKS, partials, out_losses);
+  hipLaunchKernelGGL(train_loss_kernel, dim3(F2N_LOSS_BLOCKS), dim3(256), 0, (hipStream_t) stream, a, partials,
+                     (unsigned*) (partials + F2N_LOSS_BLOCKS * F2N_LOSS_TERMS), out_losses);
+  return f2n_launch_status();
+}
+
+int f2n_nonfinite_flags_ex(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags, int32_t* mirror) {
+  if (n_a < 0 || n_b < 0 || flags == nullptr) return F2N_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(nonfinite_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, n_a, a, n_b, b, flags, mirror);
   return f2n_launch_status();
 }
 
 int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags) {
-  if (n_a < 0 || n_b < 0 || flags == nullptr) return F2N_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(nonfinite_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, n_a, a, n_b, b, flags);
-  return f2n_launch_status();
+  return f2n_nonfinite_flags_ex(stream, n_a, a, n_b, b, flags, nullptr);
 }
 
-int f2n_abi_version(void) { return 8; }
+int f2n_abi_version(void) { return 9; }
 #ifndef F2N_REFERENCE_NUMERICS
 #define F2N_REFERENCE_NUMERICS 0
 #endif

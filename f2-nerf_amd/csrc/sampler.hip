@@ -54,16 +54,64 @@ __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const f
 // descended into at most 3 are parked per level of the current path: 72 entries cover paths of 24 levels, which is the
 // deepest tree the reference's own 48-int stack (2 ints per level, PersSampler.cu:7,70) can walk without overrunning it.
 #define F2N_COOP_STACK 72
-template <int MODE>
+// LDSREC (MODE 2 only): the child records of every INTERIOR node -- the only ones a walk ever expands -- are copied into LDS
+// when the block starts (interior_nodes[r] = node index of the r-th interior node, rank_of[node] = its r; both change only
+// when the tree is rebuilt) and the walk then never leaves the CU: `cur` and the parked interior entries hold RANKS instead of
+// node indices (an interior node is never emitted, so its index is not needed).  Why: a walk is a chain of ~30-40 dependent
+// record reads per ray with one wave per SIMD -- 0.06 ms for 8192 rays alone, but 0.36 ms underneath the hash gather of the
+// step it is prefetched under, where every one of those reads queues behind the gather's L2 traffic
+// (profiles/r03_fresh_timeline.txt).  The bulk copy is bandwidth-bound (256 B per interior node and block, all loads
+// independent) and barely notices.  Same records, same order of tests: the output is bit-identical to the global-memory walk.
+template <int MODE, bool LDSREC = false>
 __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     int n_rays, int max_hits, const uint8_t* __restrict__ search_order, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, float g_near, float g_far, const F2nTreeNode* __restrict__ nodes,
     const int32_t* __restrict__ oct_start_end, int32_t* __restrict__ hit_counts, int32_t* __restrict__ oct_idx,
     float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total,
     int32_t* __restrict__ oct_trans, const F2nChildInfo* __restrict__ child_blocks, const int32_t* __restrict__ died_at,
-    int spec_epoch, const int32_t* __restrict__ death_epoch, int32_t* __restrict__ repair_flags, int32_t* __restrict__ n_repaired) {
+    int spec_epoch, const int32_t* __restrict__ death_epoch, int32_t* __restrict__ repair_flags, int32_t* __restrict__ n_repaired,
+    const int32_t* __restrict__ interior_nodes = nullptr, const int32_t* __restrict__ rank_of = nullptr, int n_interior = 0) {
+  static_assert(!LDSREC || MODE == 2, "the LDS-resident walk exists for the single-pass variant");
   if (MODE == 3) {
     if (*death_epoch < spec_epoch) return;  // no leaf died since the speculative walk: every list stands (grid-uniform)
+  }
+  extern __shared__ float4_t s_rec[];  // LDSREC: [n_interior][8 slots][2] = the F2nChildInfo records, pad = rank of an interior child
+  if (LDSREC) {
+    // four records per thread and round: node index, record, rank of an interior child are three DEPENDENT reads -- issued
+    // for all four before any is waited for, so a round costs three round trips (each several microseconds underneath the
+    // gather), not twelve
+    const int n_rec = n_interior * 8;
+    for (int base = 0; base < n_rec; base += 4 * 256) {
+      int u[4], rk[4];
+      float4_t cs[4], meta[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = base + q * 256 + (int) threadIdx.x;
+        u[q] = interior_nodes[min(i, n_rec - 1) >> 3];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = min(base + q * 256 + (int) threadIdx.x, n_rec - 1);
+        const float4_t* rec = (const float4_t*) (child_blocks + (size_t) u[q] * 8 + (i & 7));
+        cs[q] = rec[0];
+        meta[q] = rec[1];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int ch = __float_as_int(meta[q][0]);
+        rk[q] = (ch >= 0 && __float_as_int(meta[q][2]) != 0) ? rank_of[ch] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = base + q * 256 + (int) threadIdx.x;
+        if (i < n_rec) {
+          meta[q][3] = __int_as_float(rk[q]);
+          s_rec[2 * i] = cs[q];
+          s_rec[2 * i + 1] = meta[q];
+        }
+      }
+    }
+    __syncthreads();
   }
   // Work stack of a ray: every hit sibling behind the first interior hit of an expanded node is parked here, nearest on
   // top -- interior nodes as (index >= 0), valid leaves as (~index, near, far, trans) to be emitted when popped.  A node
@@ -151,13 +199,20 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     // ---- test this lane's child of `cur` ----
     bool hit = false, interior = false, valid_leaf = false;
     int child = -1, child_trans = -1;
+    int child_rank = -1;  // LDSREC: what stands for an interior child on the stack and in `cur`
     float near_ = g_near, far_ = g_far;
     const bool expanding = active && cur >= 0;
     if (expanding) {
-      if (child_blocks != nullptr) {  // one 32-byte record per child slot: no dependent second read
-        const float4_t* rec = (const float4_t*) (child_blocks + (size_t) cur * 8 + my_slot);
-        const float4_t cs = rec[0];
-        const float4_t meta = rec[1];
+      if (LDSREC || child_blocks != nullptr) {  // one 32-byte record per child slot: no dependent second read
+        float4_t cs, meta;
+        if (LDSREC) {
+          cs = s_rec[2 * (cur * 8 + my_slot)];
+          meta = s_rec[2 * (cur * 8 + my_slot) + 1];
+        } else {
+          const float4_t* rec = (const float4_t*) (child_blocks + (size_t) cur * 8 + my_slot);
+          cs = rec[0];
+          meta = rec[1];
+        }
         child = __float_as_int(meta[0]);
         if (child >= 0) {
           const float cc[3] = {cs[0], cs[1], cs[2]};
@@ -167,6 +222,7 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
             child_trans = __float_as_int(meta[1]);
             interior = __float_as_int(meta[2]) != 0;
             valid_leaf = !interior && child_trans >= 0;
+            if (LDSREC) child_rank = __float_as_int(meta[3]);
           }
         }
       } else {
@@ -213,13 +269,13 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
         }
         if ((rest >> k) & 1) {
           const int pos = sp + 1 + __popc(rest >> (k + 1));
-          s_node[pos][grp] = interior ? child : ~child;
+          s_node[pos][grp] = interior ? (LDSREC ? child_rank : child) : ~child;
           s_near[pos][grp] = near_;
           s_far[pos][grp] = far_;
           s_tr[pos][grp] = child_trans;
         }
         sp += n_rest;
-        cur = __shfl(child, (tid & 56) + k_int);                // the interior child's node index (lane k_int)
+        cur = __shfl(LDSREC ? child_rank : child, (tid & 56) + k_int);  // the interior child's node index / rank (lane k_int)
       } else {
         cur = -1;
       }
@@ -254,7 +310,8 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
 #define F2N_SCAN_ITEMS 4
 __global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, const int32_t* __restrict__ counts,
                                                                         int32_t* __restrict__ start_end,
-                                                                        int32_t* __restrict__ total) {
+                                                                        int32_t* __restrict__ total, int32_t* __restrict__ mirror,
+                                                                        const int32_t* __restrict__ also, int n_also) {
   __shared__ int s_wave[F2N_SCAN_THREADS / F2N_WAVE];
   __shared__ int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -292,7 +349,15 @@ __global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, c
     if (tid == F2N_SCAN_THREADS - 1) s_carry = run;  // last thread holds the chunk's inclusive total
     __syncthreads();
   }
-  if (tid == 0) total[0] = s_carry;
+  if (tid == 0) {
+    total[0] = s_carry;
+    // the host's copy of the count(s), written where the count is produced: `mirror` is mapped host memory (a separate
+    // device-to-host copy launch cost one ~5 us dependent boundary on the queue of every scan)
+    if (mirror != nullptr) {
+      for (int k = 0; k < n_also; k++) mirror[k] = also[k];
+      mirror[n_also] = s_carry;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -527,7 +592,11 @@ __global__ __launch_bounds__(256) void pack_samples_kernel(int n_rays, const int
                                                            const float* __restrict__ s_dt, const float* __restrict__ s_t,
                                                            const int32_t* __restrict__ s_anchors, float* __restrict__ pts,
                                                            float* __restrict__ dirs, float* __restrict__ dt, float* __restrict__ t,
-                                                           int32_t* __restrict__ anchors) {
+                                                           int32_t* __restrict__ anchors, const int32_t* __restrict__ death_epoch,
+                                                           int spec_epoch) {
+  // (re-pack of a speculatively sampled batch that was already packed before the stat update: nothing to do unless a leaf
+  // died since -- the same grid-uniform test as the two repair kernels)
+  if (death_epoch != nullptr && *death_epoch < spec_epoch) return;
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
@@ -1050,6 +1119,35 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
   return f2n_launch_status();
 }
 
+// Interior nodes whose records fit next to the walk's stacks (36 KB) in a CU's 160 KB of LDS; at one 256-thread block per 32
+// rays a batch of 8192 rays puts one block on every CU, so the rest of the LDS stays free for the kernels it runs underneath.
+#define F2N_LDS_OCT_MAX_INTERIOR 448
+int f2n_oct_lds_max_interior(void) { return F2N_LDS_OCT_MAX_INTERIOR; }
+
+int f2n_oct_intersect_strided_lds(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                                  const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
+                                  int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans,
+                                  const void* child_blocks, const int32_t* interior_nodes, const int32_t* rank_of, int n_interior) {
+  if (n_rays < 0 || max_hits < 1 || child_blocks == nullptr || interior_nodes == nullptr || rank_of == nullptr) return F2N_ERR_INVALID_ARG;
+  if (n_interior < 1 || n_interior > F2N_LDS_OCT_MAX_INTERIOR) return F2N_ERR_UNSUPPORTED;
+  if (n_rays == 0) return F2N_OK;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
+  if (!attr_set[dev]) {  // more than the default 64 KB of LDS (static stacks + dynamic records) per block
+    if (hipFuncSetAttribute((const void*) oct_intersect_coop_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            F2N_LDS_OCT_MAX_INTERIOR * 8 * (int) sizeof(F2nChildInfo)) != hipSuccess)
+      return F2N_ERR_UNSUPPORTED;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((oct_intersect_coop_kernel<2, true>), dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256),
+                     (size_t) n_interior * 8 * sizeof(F2nChildInfo), (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d,
+                     near_, far_, (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total,
+                     oct_trans, (const F2nChildInfo*) child_blocks, nullptr, 0, nullptr, nullptr, nullptr, interior_nodes, rank_of,
+                     n_interior);
+  return f2n_launch_status();
+}
+
 int f2n_oct_intersect_repair(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                              const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
                              int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans, const void* child_blocks,
@@ -1064,11 +1162,16 @@ int f2n_oct_intersect_repair(void* stream, int n_rays, int max_hits, const uint8
   return f2n_launch_status();
 }
 
-int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end, int32_t* total) {
-  if (n < 0) return F2N_ERR_INVALID_ARG;
+int f2n_segment_scan_ex(void* stream, int n, const int32_t* counts, int32_t* start_end, int32_t* total, int32_t* mirror,
+                        const int32_t* also, int n_also) {
+  if (n < 0 || n_also < 0 || n_also > 4 || (n_also > 0 && (also == nullptr || mirror == nullptr))) return F2N_ERR_INVALID_ARG;
   hipLaunchKernelGGL(segment_scan_kernel, dim3(1), dim3(F2N_SCAN_THREADS), 0, (hipStream_t) stream, n, counts,
-                     start_end, total);
+                     start_end, total, mirror, also, n_also);
   return f2n_launch_status();
+}
+
+int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end, int32_t* total) {
+  return f2n_segment_scan_ex(stream, n, counts, start_end, total, nullptr, nullptr, 0);
 }
 
 int f2n_oct_intersect_fill(void* stream, int n_rays, const uint8_t* search_order, const float* rays_o,
@@ -1136,14 +1239,23 @@ int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_
   return f2n_launch_status();
 }
 
-int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
-                     const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
-                     float* pts, float* dirs, float* dt, float* t, int32_t* anchors) {
+int f2n_pack_samples_repair(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
+                            const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
+                            float* pts, float* dirs, float* dt, float* t, int32_t* anchors, const int32_t* death_epoch,
+                            int spec_epoch) {
   if (n_rays < 0 || (s_pts == nullptr && (rays_o == nullptr || transes == nullptr))) return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(pack_samples_kernel, dim3(f2n_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t) stream, n_rays, pts_start_end,
-                     rays_o, rays_d, (const F2nTransInfo*) transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors);
+                     rays_o, rays_d, (const F2nTransInfo*) transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t, anchors,
+                     death_epoch, spec_epoch);
   return f2n_launch_status();
+}
+
+int f2n_pack_samples(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
+                     const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
+                     float* pts, float* dirs, float* dt, float* t, int32_t* anchors) {
+  return f2n_pack_samples_repair(stream, n_rays, pts_start_end, rays_o, rays_d, transes, s_pts, s_dt, s_t, s_anchors, pts, dirs, dt, t,
+                                 anchors, nullptr, 0);
 }
 
 int f2n_edge_samples(void* stream, int n_pts, const void* edge_pool, const void* transes, const int32_t* edge_idx,

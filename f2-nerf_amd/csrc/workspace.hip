@@ -38,6 +38,13 @@ void* f2n_ws_get(int slot, size_t bytes) {
     s.bytes = 0;
     size_t want = bytes + bytes / 4;
     if (hipMalloc(&s.ptr, want) != hipSuccess) return nullptr;
+    // a workspace starts out zeroed (arrival counters of last-block reductions live in some of them and return to zero by
+    // themselves afterwards); the callers' streams do not synchronise with the null stream, hence the drain
+    if (hipMemset(s.ptr, 0, want) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void) hipFree(s.ptr);
+      s.ptr = nullptr;
+      return nullptr;
+    }
     s.bytes = want;
   }
   return s.ptr;

@@ -79,6 +79,15 @@ int f2n_oct_intersect_count(void* stream, int n_rays, int max_hits, const uint8_
  * total[0] = sum.  Replaces the racing atomicAdd allocator (PersSampler.cu:144) and the
  * torch::cumsum + .item() host sync (:395-397); also FilterIdxBounds' cumsum (Renderer/Renderer.cu:44-48). */
 int f2n_segment_scan(void* stream, int n, const int32_t* counts, int32_t* start_end /*[n,2]*/, int32_t* total /*[1]*/);
+/* The same, and the host's copy of the result from the same launch: `mirror` (or NULL) is a DEVICE pointer to MAPPED HOST
+ * memory (hipHostMallocMapped + hipHostGetDevicePointer) that receives also[0..n_also) followed by the total -- e.g. the hit
+ * total of f2n_oct_intersect_strided next to the sample total, the pair the reference reads back with two .item() calls
+ * (PersSampler.cu:353,397).  The host reads it after an event recorded behind this call; no device-to-host copy is queued
+ * (on an in-order queue that copy is one more dependent launch between the scan and the kernel that consumes it).
+ * n_also <= 4. */
+int f2n_segment_scan_ex(void* stream, int n, const int32_t* counts, int32_t* start_end /*[n,2]*/, int32_t* total /*[1]*/,
+                        int32_t* mirror /*mapped host [n_also+1] or NULL*/, const int32_t* also /*device [n_also] or NULL*/,
+                        int n_also);
 
 /* FindRayOctreeIntersectionKernel<true> (PersSampler.cu:357-366): fills each ray's segment with
  * (leaf node index, t_near, t_far), front to back. */
@@ -97,6 +106,22 @@ int f2n_oct_intersect_strided(void* stream, int n_rays, int max_hits, const uint
                               float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/,
                               int32_t* oct_trans /*[R*max_hits] or NULL: trans_idx of every listed leaf*/,
                               const void* child_blocks /*or NULL*/);
+/* The same walk with the records of every node that HAS a child (the only ones a walk expands) copied into LDS when a block
+ * starts: interior_nodes[r] = index of the r-th such node in index order, rank_of[node] = its r (both derived from the node
+ * array; they change only when child indices do, i.e. with f2n_oct_build_child_blocks).  For trees of up to
+ * f2n_oct_lds_max_interior() such nodes (F2N_ERR_UNSUPPORTED beyond).  Output bit-identical to f2n_oct_intersect_strided; the
+ * point is latency: the reference's one-thread-per-ray DFS (PersSampler.cu:53-152) and the walk above are chains of dependent
+ * reads, which take ~6x longer when the kernel runs underneath a kernel that saturates the L2s (as the prefetched sampling of
+ * the next batch does, under the hash gather). */
+int f2n_oct_lds_max_interior(void);
+int f2n_oct_intersect_strided_lds(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                                  const float* rays_d, float near_, float far_, const void* tree_nodes,
+                                  int32_t* oct_start_end /*[R,2]*/, int32_t* oct_idx /*[R*max_hits]*/,
+                                  float* oct_near_far /*[R*max_hits,2]*/, int32_t* total /*[1]*/,
+                                  int32_t* oct_trans /*[R*max_hits] or NULL*/, const void* child_blocks,
+                                  const int32_t* interior_nodes /*[n_interior]*/, const int32_t* rank_of /*[n_nodes]*/,
+                                  int n_interior);
+
 
 /* Optional acceleration structure for the three intersection entry points: child_blocks [n_nodes][8] x 32 B, entry
  * [u][c] = {center xyz, side_len, child index (-1: none), child's trans_idx, child has children, pad} of child slot c of
@@ -196,6 +221,10 @@ int f2n_oct_update_stats(void* stream, int n_nodes, int32_t* w_adder, int32_t* a
  *                             those rays and 0 for all others, n_repaired[0] (or NULL) += their number.  Returns immediately on
  *                             the device when death_epoch[0] < spec_epoch (then repair_flags is NOT written).
  *   f2n_ray_march_repair      f2n_ray_march_strided for the flagged rays only (same early exit).
+ *   f2n_pack_samples_repair   f2n_pack_samples once more over the whole batch, but only when a leaf died since (same early exit):
+ *                             a batch may be scanned and packed OPTIMISTICALLY right behind its speculative march -- long before
+ *                             the stat update, in a stretch of the step where the memory system has room -- and is scanned again
+ *                             and conditionally packed again behind the two repair calls.
  * After both, slots / counts / first_oct_dis are bit-identical to a fresh f2n_oct_intersect_strided + f2n_ray_march_strided on
  * the updated tree (tests/test_gpu_parity.py::test_speculative_sampling_repair). */
 int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
@@ -213,6 +242,10 @@ int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_
                          const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts, float* s_dt, float* s_t,
                          int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans, const int32_t* repair_flags,
                          const int32_t* death_epoch, int spec_epoch);
+int f2n_pack_samples_repair(void* stream, int n_rays, const int32_t* pts_start_end, const float* rays_o, const float* rays_d,
+                            const void* transes, const float* s_pts, const float* s_dt, const float* s_t, const int32_t* s_anchors,
+                            float* pts, float* dirs, float* dt, float* t, int32_t* anchors, const int32_t* death_epoch /*[1]*/,
+                            int spec_epoch);
 
 /* MarkInvisibleNodesKernel (PersSampler.cu:618-680). */
 int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris /*[C,3,3]*/,
@@ -578,6 +611,11 @@ int f2n_train_loss(void* stream, int n_rays, const float* pred_colors /*[R,3]*/,
 /* Gradient finiteness check of the two MLPs (Field/TCNNWP.cpp:234-240), device side:
  * flags[0] = a has a non-finite value, flags[1] = b has one, flags[2] = either (the optimiser's skip_flag). */
 int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags /*[3]*/);
+/* The same, with the three flags also written to `mirror` (DEVICE pointer to MAPPED HOST memory, or NULL): the host-side
+ * reaction of TCNNWP.cpp:236-240 (halve the loss scale, drop the iteration) reads them there behind an event, without a copy
+ * launch behind the optimiser. */
+int f2n_nonfinite_flags_ex(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags /*[3]*/,
+                           int32_t* mirror /*mapped host [3] or NULL*/);
 
 #ifdef __cplusplus
 }

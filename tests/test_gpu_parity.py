@@ -136,6 +136,23 @@ def test_sampler_vs_oracle(hip, fox_state, seed, fineness, scale_by_dis, max_hit
         assert_same(nf2n[r * max_hits:r * max_hits + c], ref_hits[2][rse[r, 0]:rse[r, 1]], "strided near/far")
         node_trans = st["tree_nodes"].view(np.int32).reshape(-1, 16)[:, 14]  # TreeNode.trans_idx @56
         assert_same(N(tr2)[r * max_hits:r * max_hits + c], node_trans[oi2n[r * max_hits:r * max_hits + c]], "strided trans idx")
+    # the same walk out of LDS-resident child records (interior nodes only): every output word identical
+    words = st["tree_nodes"].view(np.int32).reshape(-1, 16)
+    is_interior = (words[:, 5:13] >= 0).any(1)
+    assert 1 <= int(is_interior.sum()) <= hip.oct_lds_max_interior()
+    interior_nodes = np.nonzero(is_interior)[0].astype(np.int32)
+    rank_of = (np.cumsum(is_interior) - 1).astype(np.int32)
+    se3 = torch.zeros_like(se2); oi3 = torch.zeros_like(oi2); nf3 = torch.zeros_like(nf2); tr3 = torch.full_like(tr2, -9)
+    tot3 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.oct_intersect_strided_lds(n, max_hits, so, T(o), T(d), 0.01, 1e8, tn, se3, oi3, nf3, tot3, tr3, cb, T(interior_nodes), T(rank_of))
+    assert int(tot3.item()) == int(tot.item())
+    assert_same(N(se3), se2n, "LDS walk: segments")
+    used = np.zeros(n * max_hits, dtype=bool)
+    for r in range(n):
+        used[r * max_hits:r * max_hits + (se2n[r, 1] - se2n[r, 0])] = True
+    assert_same(N(oi3)[used], oi2n[used], "LDS walk: leaf lists")
+    assert_same(N(nf3)[used], nf2n[used], "LDS walk: near / far")
+    assert_same(N(tr3)[used], N(tr2)[used], "LDS walk: trans idx")
     pcnt = torch.zeros(n, dtype=torch.int32, device=DEV)
     hip.ray_march_count(n, 1. / 256., scale_by_dis, T(o), T(d), T(noise), se2, oi2, nf2, tn, tr, pcnt)
     assert_same(N(pcnt), (ref["pts_idx_bounds"][:, 1] - ref["pts_idx_bounds"][:, 0]).astype(np.int32), "march count on strided hits")
@@ -240,6 +257,33 @@ def test_segment_scan(hip):
     tot = torch.full((1,), 5, dtype=torch.int32, device=DEV)
     hip.segment_scan(0, torch.empty(1, dtype=torch.int32, device=DEV), torch.empty((1, 2), dtype=torch.int32, device=DEV), tot)
     assert int(tot.item()) == 0  # empty input
+
+
+def test_segment_scan_and_flags_write_their_host_mirror(hip):
+    """f2n_segment_scan_ex / f2n_nonfinite_flags_ex: the launch that produces a count (or the finiteness flags) also writes
+    the host's copy into mapped host memory -- what the host reads behind an event instead of queueing a copy."""
+    rng = np.random.default_rng(3)
+    for n in (1, 4097, 100003):
+        c = rng.integers(0, 1000, n).astype(np.int32)
+        se = torch.empty((n, 2), dtype=torch.int32, device=DEV)
+        tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+        also = torch.tensor([41, 42], dtype=torch.int32, device=DEV)
+        mirror = torch.full((3,), -1, dtype=torch.int32).pin_memory()
+        hip.segment_scan_ex(n, T(c), se, tot, mirror, also)
+        torch.cuda.synchronize()
+        assert mirror.tolist() == [41, 42, int(c.sum())] and int(tot.item()) == int(c.sum())
+        assert_same(N(se)[:, 1], np.cumsum(c).astype(np.int32))
+        mirror1 = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+        hip.segment_scan_ex(n, T(c), se, tot, mirror1)
+        torch.cuda.synchronize()
+        assert mirror1.tolist() == [int(c.sum())]
+    a = rng.standard_normal(3072).astype(F32); b = rng.standard_normal(7168).astype(F32)
+    b[17] = np.inf
+    flags = torch.full((3,), 7, dtype=torch.int32, device=DEV)
+    mirror = torch.full((4,), 9, dtype=torch.int32).pin_memory()
+    hip.nonfinite_flags(a.size, T(a), b.size, T(b), flags, mirror)
+    torch.cuda.synchronize()
+    assert N(flags).tolist() == [0, 1, 1] and mirror.tolist() == [0, 1, 1, 9]
 
 
 def test_edge_samples_and_occupancy(hip, fox_state, fox_golden):

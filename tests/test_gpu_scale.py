@@ -713,6 +713,24 @@ def test_speculative_sampling_repair(hip, kill_frac):
     # against the CPU oracle on the updated tree
     ref_hits = oc.oct_intersect(z["search_order"], z["rays_o"], rd_np, 0.01, 1e8, N(tn), 1024)
     assert same_bits(repaired["oi"], ref_hits[1]) and same_bits(repaired["nf"], ref_hits[2])
+    # f2n_pack_samples_repair: the pack of a batch that was packed optimistically before the update runs again only if a leaf
+    # died in an epoch >= spec_epoch, and then equals the pack of the repaired slots
+    pse = torch.zeros((n, 2), dtype=torch.int32, device=DEV); tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.segment_scan(n, spec["cnt"], pse, tot)
+    m = max(int(tot.item()), 1)
+
+    def packed(fill):
+        return dict(pts=torch.full((m, 3), fill, device=DEV), dirs=torch.full((m, 3), fill, device=DEV), dt=torch.full((m,), fill, device=DEV),
+                    t=torch.full((m,), fill, device=DEV), anchors=torch.full((m, 3), -7, dtype=torch.int32, device=DEV))
+    want_p, got_p, kept_p = packed(0.0), packed(3.0), packed(3.0)
+    hip.pack_samples(n, pse, ro, rd, tr, None, spec["s_dt"], spec["s_t"], spec["s_an"], *[want_p[k] for k in ("pts", "dirs", "dt", "t", "anchors")])
+    hip.pack_samples_repair(n, pse, ro, rd, tr, None, spec["s_dt"], spec["s_t"], spec["s_an"],
+                            *[got_p[k] for k in ("pts", "dirs", "dt", "t", "anchors")], death_epoch, EPOCH)
+    hip.pack_samples_repair(n, pse, ro, rd, tr, None, spec["s_dt"], spec["s_t"], spec["s_an"],
+                            *[kept_p[k] for k in ("pts", "dirs", "dt", "t", "anchors")], death_epoch, EPOCH + 1)
+    for k in want_p:
+        assert same_bits(N(got_p[k]), N(want_p[k])), k
+        assert (N(kept_p[k]) == (-7 if k == "anchors" else 3.0)).all(), k  # (no leaf died since EPOCH + 1: not touched)
 
 
 def test_speculative_training_equals_sampling_after_the_update(rt, fox_state):
