@@ -57,6 +57,7 @@ HBM_PEAK_GBS = 8000.0
 # profiles/r01_gather_policy_probe.txt: each request moves a whole line from L2 into a CU's L1) -- reported next to the
 # HBM fraction as roofline.request_ceiling.
 GATHER_REQ_PEAK = 263.0e9
+STEADY_STEPS = 300  # length of the steady-state region reported next to a shorter timed region
 L2_PEAK_TBS = 34.5  # aggregate L2 bandwidth of the eight XCDs (MI355X_MICROARCH.md, L2 section)
 
 # Algorithmic HBM bytes per MARCHED sample of the kernels that can dominate a step:
@@ -161,7 +162,10 @@ def psnr_numerics_ab(args):
         out["delta_mean_db_reference_minus_product"] = round(delta, 3)
         out["delta_standard_error_db"] = round(se, 3)
         out["ranges_overlap"] = bool(a["psnr_min"] <= b["psnr_max"] and b["psnr_min"] <= a["psnr_max"])
-        out["within_0p1_db"] = bool(abs(delta) <= 0.1)
+        # the 0.1 dB question can only be answered by a comparison that RESOLVES 0.1 dB: standard error of the difference < 0.1
+        out["within_0p1_db"] = (bool(abs(delta) <= 0.1) if se < 0.1 else "inconclusive")
+        out["resolution_note"] = ("standard error of the difference %.3f dB %s 0.1 dB" % (se, "<" if se < 0.1 else ">=")) + \
+                                 ("" if se < 0.1 else ": this invocation cannot answer the 0.1 dB question; see pooled_evidence")
         out["delta_within_2_standard_errors_of_zero"] = bool(abs(delta) <= 2 * se)
         out["pooled_evidence"] = "profiles/r03_psnr_study.json: 16 + 14 runs over three invocations"
     out["note"] = ("same seed, same explicit schedule; the two workers share the GPU, so their train_wall_s are NOT timings. "
@@ -181,7 +185,7 @@ def other_configs(args):
                        ("wanjinyou_big_log2_20", ["--preset", "wanjinyou_big", "--log2", "20"]),
                        ("wanjinyou_big_log2_22", ["--preset", "wanjinyou_big", "--log2", "22"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.other_steps), "--warmup", "10", "--no-cpu-baseline",
-               "--no-converged", "--other-configs", "0"] + extra
+               "--no-converged", "--no-steady", "--other-configs", "0"] + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
             ln = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
@@ -225,7 +229,8 @@ def converged_leg(args, st, dev):
                     % (runner.iter_step, args.factor, int(sc["image_hw"][0]), int(sc["image_hw"][1]), args.preset),
            "train_wall_s": round(train_wall, 2), "train_iterations": int(s["iterations"]),
            "train_ray_samples_per_s": s["total_meaningful"] / train_wall, "train_rays_per_s": s["total_rays"] / train_wall,
-           "psnr_test_mean": round(views[-1], 3), "psnr_test_per_view": [round(v, 2) for v in views[:-1]],
+           "psnr_test_mean": round(views[-1], 3), "psnr_test_runs": 1, "psnr_test_per_view": [round(v, 2) for v in views[:-1]],
+           "psnr_test_note": "ONE training run; the run-to-run distribution of this number is psnr_numerics_ab.product",
            "psnr_definition": "reference (ExpRunner.cpp:360-369): prediction clipped and quantised to 8 bit, 20 log10(1/sqrt(mse)), "
                               "test views = every 8th image", "test_views_wall_s": round(test_wall, 2),
            "image_hw": [int(v) for v in sc["image_hw"]], "octree_nodes": runner.n_nodes(), "setup_s": round(t_load, 1)}
@@ -298,6 +303,7 @@ def main():
                     "llff | nerf-360: synthetic forward-facing / inward-ring rigs (f2-nerf_amd/rigs.py), octree built on the device")
     ap.add_argument("--log2", type=int, default=0, help="override field.log2_table_size (e.g. 22 for BASELINE config 5's stress point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the %d-step steady-state region that follows a shorter timed region" % STEADY_STEPS)
     ap.add_argument("--no-converged", action="store_true", help="skip the converged-state leg (train 20k iterations, PSNR, timed steps)")
     ap.add_argument("--train-iters", type=int, default=20000, help="iterations of the converged leg's training run")
     ap.add_argument("--converged-steps", type=int, default=600, help="timed steps in the converged state")
@@ -423,6 +429,24 @@ def main():
     timing = host.ExpRunner.collect_kernel_timing() if rank == 0 else {}
     host.ExpRunner.disable_kernel_timing()
 
+    # A short timed region (the driver's 20 steps = 22 ms) sits on the first iterations of a fresh scene; the steady state of
+    # this workload is reported next to it: STEADY_STEPS more steps, no kernel timers inside, same barrier bracket (every rank).
+    steady = None
+    if args.steps < STEADY_STEPS and not args.no_steady:
+        cs0 = runner.counters()
+        barrier()
+        ts0 = time.perf_counter()
+        for i in range(STEADY_STEPS):
+            step(args.warmup + args.steps + i)
+        runner.flush()
+        barrier()
+        tse = time.perf_counter() - ts0
+        cs1 = runner.counters()
+        steady = {"steps": STEADY_STEPS, "ms_per_step": tse / STEADY_STEPS * 1e3,
+                  "value_this_rank": (cs1["total_meaningful"] - cs0["total_meaningful"]) / tse, "unit": "ray-samples/s",
+                  "note": "follows the timed region; no HIP-event kernel timers inside; the early stop starts to remove samples "
+                          "as the scene trains, so meaningful samples per step fall slowly along it"}
+
     counts = torch.tensor([elapsed, float(n_meaningful), float(n_marched)], dtype=torch.float64, device=dev)
     replicas = None
     if dp:
@@ -461,11 +485,15 @@ def main():
                 tfile = os.path.join(ROOT, "profiles", "r03_big%d_traffic.json" % log2)
             elif args.preset != "wanjinyou" or args.log2 not in (0, 19) or args.rays != 8192:
                 tfile = ""  # (no counters were collected for this workload)
+            traffic_source = None
             if tfile and os.path.exists(tfile):
                 with open(tfile) as f:
                     traffic = json.load(f).get("hash_gather_planes_kernel", {}).get("hbm_bytes_per_launch")
+                # (PMC counters cannot ride in a timed run: the figure is READ from the committed counter pass of this workload)
+                traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/run_profiles.sh; not measured in this run)" % os.path.relpath(tfile, ROOT)
             roofline = {"bound": "hbm", "kernel": "hash_gather_planes_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": traffic_source,
                         "avg_kernel_ms": round(avg_ms, 4), "launches": launches, "bytes_per_sample": ALGO_BYTES[DOMINANT],
                         "samples_per_launch": int(samples_per_launch),
                         "request_ceiling": {"achieved": round(samples_per_launch * 128 / (avg_ms * 1e-3) / 1e9, 1),
@@ -530,7 +558,7 @@ def main():
                        "rays_per_s": args.rays * world * args.steps / elapsed,
                        "marched_samples_per_s": n_marched / elapsed, "rho_marched_over_meaningful": rho,
                        "meaningful_samples_per_step": n_meaningful / args.steps},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged, "replicas": replicas,
+            "steady_state": steady, "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged, "replicas": replicas,
             "other_configs": others,
             # buffers are sized for the worst case on purpose (1024 sample slots per ray, scatter queues): what that costs of 288 GB
             "peak_hbm_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

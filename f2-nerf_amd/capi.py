@@ -66,6 +66,14 @@ def build_info():
     return lib().f2n_build_info().decode()
 
 
+def debug_counters(reset=False):
+    """Diagnostic event counters of the library (f2n_debug_counters): [0] = scatter records applied by the atomic fallback."""
+    out = (ctypes.c_int32 * 8)()
+    torch.cuda.synchronize()
+    _ck(lib().f2n_debug_counters(out, _i(1 if reset else 0)), "f2n_debug_counters")
+    return [int(v) for v in out]
+
+
 # ---------------------------------------------------------------- sampler
 def normalize_dirs(n, dirs, out):
     _ck(lib().f2n_normalize_dirs(_stream(), _i(n), _p(dirs, "f32"), _p(out, "f32")), "f2n_normalize_dirs")

@@ -414,6 +414,10 @@ __device__ __forceinline__ int f2n_bin_nb(int n_true) { return n_true > 393216 ?
 #define F2N_BIN_MAX_BINS 1024  // tables up to 2^22 entries per level (BASELINE config 5)
 #define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
+// Diagnostic counters (f2n_debug_counters): [0] scatter records that found their queue segment full and fell back to the
+// packed-f16 global atomic -- the one place where the owner-binned scatter's result depends on the order of arrival.
+__device__ int f2n_dbg_counters[8];
+
 struct F2nBinQueues {
   uint2* rec;      // [16 levels][n_bins][NB][cap]
   int32_t* cnt;    // [16 levels][n_bins][NB]
@@ -528,6 +532,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
               r.y = bits;
               my_rec[(size_t) bin * bin_stride + slot] = r;
             } else {
+              atomicAdd(&f2n_dbg_counters[0], 1);
               __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (tab + pos), val);
             }
           }
@@ -924,6 +929,16 @@ static inline bool f2n_use_bins(int n, int level_entries) {
 }
 
 extern "C" {
+
+int f2n_debug_counters(int32_t* out8_host, int reset) {
+  if (out8_host != nullptr && hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(f2n_dbg_counters), 8 * sizeof(int32_t)) != hipSuccess)
+    return F2N_ERR_INVALID_ARG;
+  if (reset) {
+    const int32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(f2n_dbg_counters), zero, sizeof(zero)) != hipSuccess) return F2N_ERR_INVALID_ARG;
+  }
+  return F2N_OK;
+}
 
 int f2n_mlp_n_params(int d_in, int d_hidden, int n_hidden) {
   if (d_in <= 0 || d_hidden <= 0 || n_hidden < 1) return F2N_ERR_INVALID_ARG;

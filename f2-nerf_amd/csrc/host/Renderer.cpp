@@ -6,6 +6,10 @@
 // loss and backward, untaped, for ExpRunner::TrainStep.
 #include "Renderer.h"
 
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+
 namespace f2n {
 
 using torch::autograd::AutogradContext;
@@ -247,6 +251,30 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
   presample_rays_d_ = rays_d;
 }
 
+// The sampler's side stream.  F2N_SIDE_CUS=<n> (experiment knob; or ExpRunner binding `side_cus`): the stream is created with a compute-unit mask
+// of n CUs (hipExtStreamCreateWithCUMask; the mask bits are dealt round-robin over the eight XCDs), so that the latency-bound
+// sampler chain -- a few long-lived waves per CU -- stops sharing SIMDs with the occupancy-bound kernels of the main queue.
+void Renderer::EnsureSideStream() {
+  if (side_stream_) return;
+  if (side_cus_ < 0) {
+    const char* e = std::getenv("F2N_SIDE_CUS");
+    side_cus_ = e != nullptr ? std::max(0, std::min(256, std::atoi(e))) : 0;
+  }
+  const int n_cus = side_cus_;
+  if (n_cus > 0) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_cus; i++) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t raw = nullptr;
+    if (hipExtStreamCreateWithCUMask(&raw, 8, mask) == hipSuccess && raw != nullptr) {
+      side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(
+          c10::hip::getStreamFromExternalMasqueradingAsCUDA(raw, c10::hip::current_device()));
+      return;
+    }
+    (void) hipGetLastError();
+  }
+  side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+}
+
 void Renderer::PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
   PreSampleBegin(rays_o, rays_d, bounds, global_data_pool_->ray_march_fineness_);
   PreSampleFinish();
@@ -256,8 +284,7 @@ void Renderer::PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const 
 // Called from inside SampleAndFilter as soon as this step's occupancy update (the only thing the next batch's sampling
 // depends on) has been issued; the kernels then run underneath this step's forward/backward.
 void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& /*bounds*/, float fineness) {
-  if (!side_stream_)
-    side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+  EnsureSideStream();
   octree_ready_ev_.block(*side_stream_);  // the only dependency on this step: its occupancy update / ProcOctree
   if (side_must_wait_consumed_) {  // the sampler's buffers may be handed the memory of samples the main stream is still reading
     samples_consumed_ev_.block(*side_stream_);
@@ -274,8 +301,7 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
 
 // Speculative variant of PreSampleBegin: intersection + march only, NOT ordered behind this step's stat update.
 void Renderer::PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool /*after_main_stream*/) {
-  if (!side_stream_)
-    side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+  EnsureSideStream();
   // Everything the main stream has been handed so far comes first: the kernels that DRAW the next batch's rays
   // (Dataset::RandRaysData, queued by ExpRunner::Train right before this step) and whatever touched the tree there -- i.e. the
   // speculative sampling starts when this step's own kernels start, not before.  (Waiting only for the previous step's octree

@@ -160,6 +160,8 @@ class Renderer : public Pipe {
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
   MappedWords n_kept_words_;  // [1]: the surviving-sample count, written by the survivor scan itself, read behind n_kept_ev_
   std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;
+  void EnsureSideStream();
+  int side_cus_ = -1;  // CUs the side stream may use (0: all; -1: take F2N_SIDE_CUS); changing it drops the stream (callers drain first)
   Tensor forced_bg_;  // explicit background colours for parity tests (undefined = as the reference)
   int n_edge_pts_ = 8192;
   int last_n_all_pts_ = 0, last_n_kept_pts_ = 0;

@@ -5,6 +5,8 @@
 #include "DataParallel.h"
 #include "ExpRunner.h"
 
+#include <hip/hip_runtime_api.h>
+
 using namespace f2n;
 
 namespace {
@@ -289,6 +291,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })
+      .def_property("side_cus",  // compute units the sampler's side stream is confined to (0: all); experiment knob
+                    [](ExpRunner& r) { return r.renderer_->side_cus_; },
+                    [](ExpRunner& r, int n) {
+                      r.FinishPending();
+                      r.renderer_->DropPendingSamples();
+                      (void) hipDeviceSynchronize();
+                      r.renderer_->side_cus_ = std::max(0, std::min(256, n));
+                      r.renderer_->side_stream_.reset();
+                    })
       .def_property("speculation_order",  // 1: the speculative sampler starts where the step begins, 0: behind its draws (Renderer.h)
                     [](ExpRunner& r) { return r.renderer_->spec_order_; },
                     [](ExpRunner& r, int bits) { r.renderer_->spec_order_ = bits; })

@@ -54,6 +54,10 @@ int f2n_abi_version(void);
  * of tcnn's FullyFusedMLP).  Same ABI; used to A/B whole trainings (bench.py "psnr_numerics_ab"). */
 int f2n_numerics_mode(void);
 const char* f2n_build_info(void);
+/* Diagnostics (host-only, synchronous; no reference counterpart): eight device-side event counters copied to host memory,
+ * optionally reset.  [0] = scatter records of f2n_hash_bwd's owner-binned path that found their queue segment full and were
+ * applied by a packed-f16 atomic instead (the only order-dependent addition of that path).  The rest are reserved (0). */
+int f2n_debug_counters(int32_t* out8_host /* or NULL */, int reset);
 
 /* ---------------------------------------------------------------------------------------------------
  * Sampler -- replaces PersSampler::GetSamples' kernels (PtsSampler/PersSampler.cu:21-434).

@@ -15,6 +15,7 @@ ap.add_argument("--factor", type=int, default=2)
 ap.add_argument("--overrides", nargs="*", default=[])
 ap.add_argument("--kernel-timing", action="store_true")
 ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 auto (default: the host's default)")
+ap.add_argument("--side-cus-sweep", default="", help="v1,v2,...: repeat the timed steps with the sampler's side stream confined to that many CUs (0: all)")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob")
 args = ap.parse_args()
 st = fox_data.load_state()
@@ -51,7 +52,12 @@ def timed(tag=""):
         tm = runtime.host().ExpRunner.collect_kernel_timing()
         runtime.host().ExpRunner.disable_kernel_timing()
         print("    " + "  ".join("%s %.1f us" % (k, v[1] / max(v[0], 1) * 1e3) for k, v in sorted(tm.items())), flush=True)
-if args.env_sweep:
+if args.side_cus_sweep:
+    for rep in range(2):
+        for v in args.side_cus_sweep.split(","):
+            runner.side_cus = int(v)
+            timed("side_cus=%s: " % v)
+elif args.env_sweep:
     name, vals = args.env_sweep.split("=")
     for rep in range(2):
         for v in vals.split(","):
