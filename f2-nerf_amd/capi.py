@@ -11,7 +11,7 @@ import torch
 from . import build
 
 _lib = None
-ABI_VERSION = 9  # include/f2n_abi.h
+ABI_VERSION = 10  # include/f2n_abi.h
 
 
 class F2nError(RuntimeError):
@@ -239,6 +239,45 @@ def ray_march_repair(n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_
                                    _p(transes, "u8"), _p(counts, "i32"), _p(s_pts, "f32", True), _p(s_dt, "f32"), _p(s_t, "f32"),
                                    _p(s_anchors, "i32"), _p(first_oct_dis, "f32"), _p(oct_trans, "i32", True),
                                    _p(repair_flags, "i32"), _p(death_epoch, "i32"), _i(spec_epoch)), "f2n_ray_march_repair")
+
+
+def ray_march_strided_rec(n_rays, max_hits, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes, transes,
+                          counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, leaf_state, reached):
+    """ray_march_strided that records resumable states per leaf-list entry (tail repair of speculative batches)."""
+    _ck(lib().f2n_ray_march_strided_rec(_stream(), _i(n_rays), _i(max_hits), _f(sample_l), _i(int(scale_by_dis)), _p(rays_o, "f32"),
+                                        _p(rays_d, "f32"), _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"), _p(oct_nf, "f32"),
+                                        _p(tree_nodes, "u8"), _p(transes, "u8"), _p(counts, "i32"), _p(s_pts, "f32", True),
+                                        _p(s_dt, "f32"), _p(s_t, "f32"), _p(s_anchors, "i32"), _p(first_oct_dis, "f32"),
+                                        _p(oct_trans, "i32", True), _p(leaf_state, "i32"), _p(reached, "i32")),
+        "f2n_ray_march_strided_rec")
+
+
+def oct_list_repair(n_rays, max_hits, oct_se, oct_idx, oct_nf, oct_trans, total, died_at, spec_epoch, death_epoch, reached, repair_from,
+                    n_repaired, n_full):
+    _ck(lib().f2n_oct_list_repair(_stream(), _i(n_rays), _i(max_hits), _p(oct_se, "i32"), _p(oct_idx, "i32"), _p(oct_nf, "f32"),
+                                  _p(oct_trans, "i32", True), _p(total, "i32"), _p(died_at, "i32"), _i(spec_epoch),
+                                  _p(death_epoch, "i32"), _p(reached, "i32"), _p(repair_from, "i32"), _p(n_repaired, "i32", True),
+                                  _p(n_full, "i32")), "f2n_oct_list_repair")
+
+
+def oct_intersect_repair_flagged(n_rays, max_hits, search_order, rays_o, rays_d, near, far, tree_nodes, oct_se, oct_idx, oct_nf, total,
+                                 oct_trans, child_blocks, death_epoch, spec_epoch, repair_from, n_full):
+    _ck(lib().f2n_oct_intersect_repair_flagged(_stream(), _i(n_rays), _i(max_hits), _p(search_order, "u8"), _p(rays_o, "f32"),
+                                               _p(rays_d, "f32"), _f(near), _f(far), _p(tree_nodes, "u8"), _p(oct_se, "i32"),
+                                               _p(oct_idx, "i32"), _p(oct_nf, "f32"), _p(total, "i32"), _p(oct_trans, "i32", True),
+                                               _p(child_blocks, "u8", True), _p(death_epoch, "i32"), _i(spec_epoch),
+                                               _p(repair_from, "i32"), _p(n_full, "i32")), "f2n_oct_intersect_repair_flagged")
+
+
+def ray_march_repair_tail(n_rays, max_hits, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes, transes,
+                          counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, leaf_state, reached, repair_from, death_epoch,
+                          spec_epoch):
+    _ck(lib().f2n_ray_march_repair_tail(_stream(), _i(n_rays), _i(max_hits), _f(sample_l), _i(int(scale_by_dis)), _p(rays_o, "f32"),
+                                        _p(rays_d, "f32"), _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"), _p(oct_nf, "f32"),
+                                        _p(tree_nodes, "u8"), _p(transes, "u8"), _p(counts, "i32"), _p(s_pts, "f32", True),
+                                        _p(s_dt, "f32"), _p(s_t, "f32"), _p(s_anchors, "i32"), _p(first_oct_dis, "f32"),
+                                        _p(oct_trans, "i32", True), _p(leaf_state, "i32"), _p(reached, "i32"), _p(repair_from, "i32"),
+                                        _p(death_epoch, "i32"), _i(spec_epoch)), "f2n_ray_march_repair_tail")
 
 
 def oct_build_child_blocks(n_nodes, tree_nodes, child_blocks):

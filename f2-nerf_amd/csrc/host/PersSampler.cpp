@@ -113,7 +113,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   auto& oct = *pers_octree_;
   void* st = CurStream();
   Tensor rays_d = torch::empty_like(rays_d_in);  // :319, with a fixed (oracle-restatable) summation order
-  Tensor totals = torch::empty({2}, DevI32());   // [K, N]
+  Tensor totals = torch::empty({3}, DevI32());   // [K, N, rays a tail repair hands back to the full walk]
   Tensor rays_noise;                             // :372-381
   const int n_noise = F2N_MAX_SAMPLE_PER_RAY + n_rays + 10;
   bool map_noise = false;
@@ -127,7 +127,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
     map_noise = true;
   }
   // unit directions, zeroed totals and the noise map: one launch
-  F2N_CALL(f2n_sampler_prologue(st, n_rays, F32P(rays_d_in), F32P(rays_d), I32P(totals), 2, map_noise ? n_noise : 0,
+  F2N_CALL(f2n_sampler_prologue(st, n_rays, F32P(rays_d_in), F32P(rays_d), I32P(totals), 3, map_noise ? n_noise : 0,
                                 map_noise ? F32P(rays_noise) : nullptr, fineness, map_noise ? F32P(rays_noise) : nullptr));
   const float far = 1e8f;  // the `bounds` argument is ignored by the reference too (:322-323)
 
@@ -165,10 +165,21 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor s_dt = torch::empty({slots}, DevF32()), s_t = torch::empty({slots}, DevF32());  // warped points: computed by pack
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
   Tensor first_oct_dis = torch::empty({n_rays, 1}, DevF32());
-  F2N_TIMED_CALL("ray_march", f2n_ray_march_strided(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
-                                 I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
-                                 VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t), I32P(s_anchors),
-                                 F32P(first_oct_dis), I32P(oct_tr)));
+  const bool tail = speculative && tail_repair_ && max_oct_intersect_per_ray_ <= 2048;
+  if (tail) {  // ... recording, per leaf-list entry, the state a repair can resume from (f2n_abi.h, "Tail repair")
+    p.leaf_state = torch::empty({k_cap, 2}, DevI32());
+    p.reached = torch::empty({n_rays}, DevI32());
+    F2N_TIMED_CALL("ray_march", f2n_ray_march_strided_rec(st, n_rays, max_oct_intersect_per_ray_, sample_l_, scale_by_dis_, F32P(rays_o),
+                                   F32P(rays_d), F32P(rays_noise), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
+                                   VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t), I32P(s_anchors),
+                                   F32P(first_oct_dis), I32P(oct_tr), VoidP(p.leaf_state), I32P(p.reached)));
+  } else {
+    F2N_TIMED_CALL("ray_march", f2n_ray_march_strided(st, n_rays, sample_l_, scale_by_dis_, F32P(rays_o), F32P(rays_d), F32P(rays_noise),
+                                   I32P(oct_se), I32P(oct_idx), F32P(oct_nf), VoidP(oct.tree_nodes_gpu_),
+                                   VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t), I32P(s_anchors),
+                                   F32P(first_oct_dis), I32P(oct_tr)));
+  }
+  p.tail = tail;
   p.active = true;
   p.n_rays = n_rays;
   p.rays_o = rays_o; p.rays_d = rays_d; p.counts = counts; p.oct_se = oct_se; p.totals = totals;
@@ -196,6 +207,22 @@ bool PersSampler::CompleteSpeculative(PendingSamples& p) {
   if (p.generation != oct.generation_) return false;
   void* st = CurStream();
   const float far = 1e8f;
+  if (p.tail) {
+    // no second walk: dead entries leave the lists in place, the few lists that were cut at the cap are walked again, and the
+    // march resumes behind the first dead leaf of every ray it invalidated
+    F2N_TIMED_CALL("oct_repair", f2n_oct_list_repair(st, p.n_rays, max_oct_intersect_per_ray_, I32P(p.oct_se), I32P(p.oct_idx), F32P(p.oct_nf),
+                                   I32P(p.oct_tr), I32P(p.totals), I32P(oct.died_at_), p.spec_epoch, I32P(oct.death_epoch_), I32P(p.reached),
+                                   I32P(p.repair_flags), I32P(oct.n_repaired_), I32P(p.totals) + 2));
+    F2N_CALL(f2n_oct_intersect_repair_flagged(st, p.n_rays, max_oct_intersect_per_ray_, oct.node_search_order_.data_ptr<uint8_t>(),
+                                   F32P(p.rays_o), F32P(p.rays_d), global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(p.oct_se),
+                                   I32P(p.oct_idx), F32P(p.oct_nf), I32P(p.totals), I32P(p.oct_tr), VoidP(oct.child_blocks_gpu_),
+                                   I32P(oct.death_epoch_), p.spec_epoch, I32P(p.repair_flags), I32P(p.totals) + 2));
+    F2N_TIMED_CALL("march_repair", f2n_ray_march_repair_tail(st, p.n_rays, max_oct_intersect_per_ray_, sample_l_, scale_by_dis_, F32P(p.rays_o),
+                                   F32P(p.rays_d), F32P(p.noise), I32P(p.oct_se), I32P(p.oct_idx), F32P(p.oct_nf), VoidP(oct.tree_nodes_gpu_),
+                                   VoidP(oct.pers_trans_gpu_), I32P(p.counts), nullptr, F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors),
+                                   F32P(p.first_oct_dis), I32P(p.oct_tr), VoidP(p.leaf_state), I32P(p.reached), I32P(p.repair_flags),
+                                   I32P(oct.death_epoch_), p.spec_epoch));
+  } else {
   F2N_TIMED_CALL("oct_repair", f2n_oct_intersect_repair(st, p.n_rays, max_oct_intersect_per_ray_, oct.node_search_order_.data_ptr<uint8_t>(),
                                  F32P(p.rays_o), F32P(p.rays_d), global_near_, far, VoidP(oct.tree_nodes_gpu_), I32P(p.oct_se),
                                  I32P(p.oct_idx), F32P(p.oct_nf), I32P(p.totals), I32P(p.oct_tr), VoidP(oct.child_blocks_gpu_),
@@ -204,6 +231,7 @@ bool PersSampler::CompleteSpeculative(PendingSamples& p) {
                                  I32P(p.oct_se), I32P(p.oct_idx), F32P(p.oct_nf), VoidP(oct.tree_nodes_gpu_), VoidP(oct.pers_trans_gpu_),
                                  I32P(p.counts), nullptr, F32P(p.s_dt), F32P(p.s_t), I32P(p.s_anchors), F32P(p.first_oct_dis),
                                  I32P(p.oct_tr), I32P(p.repair_flags), I32P(oct.death_epoch_), p.spec_epoch));
+  }
   p.completed = true;
   if (!p.packed_once) {
     IssueScanAndPack(p);

@@ -98,7 +98,9 @@ struct PendingSamples {
   bool packed_once = false;    // speculative and already scanned + packed behind its march (PersSampler::optimistic_pack_)
   int spec_epoch = 0;          // first stat-update epoch whose deaths the speculative walk may have missed
   int64_t generation = 0;      // PersOctree::generation_ the samples were marched against
-  Tensor repair_flags;
+  Tensor repair_flags;         // (tail repair: repair_from, F2N_REPAIR_* or the list entry the march resumes from)
+  Tensor leaf_state, reached;  // tail repair: the march's resumable states per leaf-list entry / last entry looked at
+  bool tail = false;           // sampled with f2n_ray_march_strided_rec: repaired without a second walk
 };
 
 class PersSampler : public PtsSampler {
@@ -113,6 +115,9 @@ class PersSampler : public PtsSampler {
   void IssueScanAndPack(PendingSamples& p);
   void IssueScan(PendingSamples& p);  // segment scan + count read-back
   bool optimistic_pack_ = true;  // speculative batches are packed right behind their march, again only if a leaf died (A/B knob)
+  // speculative batches record resumable march states and are repaired by list compaction + a march of the tail behind the
+  // first dead leaf (f2n_oct_list_repair / f2n_ray_march_repair_tail) instead of a second walk and march from the origin
+  bool tail_repair_ = true;
   bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
   bool MaintenanceDue() const;  // the NEXT FinishOctUpdate runs ProcOctree (milestone / compact_freq, PersSampler.cu:605-614)
   SampleResultFlex FinishSamples(PendingSamples& p);

@@ -30,7 +30,7 @@ py::dict StatsToDict(const TrainStats& s) {
 
 // the ABI version this host layer was compiled against (include/f2n_abi.h); a kernel library of another version next to it
 // means one of the two was not rebuilt -- calls would pass the wrong argument lists (observed once: a memory fault)
-#define F2N_HOST_EXPECTS_ABI 9
+#define F2N_HOST_EXPECTS_ABI 10
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "f2-nerf hot path: C++/LibTorch host layer over libf2n_hip.so";
@@ -288,6 +288,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("optimistic_pack",  // speculative batches packed right behind their march, again only if a leaf died (A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_ = on; })
+      .def_property("tail_repair",  // speculative batches repaired by list compaction + a march of the tail behind the first dead leaf (A/B knob)
+                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_; },
+                    [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_ = on; })
       .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })

@@ -449,7 +449,7 @@ int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const fl
   return f2n_nonfinite_flags_ex(stream, n_a, a, n_b, b, flags, nullptr);
 }
 
-int f2n_abi_version(void) { return 9; }
+int f2n_abi_version(void) { return 10; }
 #ifndef F2N_REFERENCE_NUMERICS
 #define F2N_REFERENCE_NUMERICS 0
 #endif

@@ -54,6 +54,7 @@ __device__ __forceinline__ void f2n_slab(const float* o, const float* d, const f
 // descended into at most 3 are parked per level of the current path: 72 entries cover paths of 24 levels, which is the
 // deepest tree the reference's own 48-int stack (2 ints per level, PersSampler.cu:7,70) can walk without overrunning it.
 #define F2N_COOP_STACK 72
+// (repair_from values of the tail repair, F2N_REPAIR_NONE / F2N_REPAIR_FULL: include/f2n_abi.h)
 // LDSREC (MODE 2 only): the child records of every INTERIOR node -- the only ones a walk ever expands -- are copied into LDS
 // when the block starts (interior_nodes[r] = node index of the r-th interior node, rank_of[node] = its r; both change only
 // when the tree is rebuilt) and the walk then never leaves the CU: `cur` and the parked interior entries hold RANKS instead of
@@ -70,10 +71,13 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
     float* __restrict__ oct_near_far, int32_t* __restrict__ se_out, int32_t* __restrict__ total,
     int32_t* __restrict__ oct_trans, const F2nChildInfo* __restrict__ child_blocks, const int32_t* __restrict__ died_at,
     int spec_epoch, const int32_t* __restrict__ death_epoch, int32_t* __restrict__ repair_flags, int32_t* __restrict__ n_repaired,
-    const int32_t* __restrict__ interior_nodes = nullptr, const int32_t* __restrict__ rank_of = nullptr, int n_interior = 0) {
+    const int32_t* __restrict__ interior_nodes = nullptr, const int32_t* __restrict__ rank_of = nullptr, int n_interior = 0,
+    const int32_t* __restrict__ n_flagged = nullptr) {
   static_assert(!LDSREC || MODE == 2, "the LDS-resident walk exists for the single-pass variant");
   if (MODE == 3) {
     if (*death_epoch < spec_epoch) return;  // no leaf died since the speculative walk: every list stands (grid-uniform)
+    // flagged variant (behind f2n_oct_list_repair): only the rays it marked F2N_REPAIR_FULL in repair_flags are walked again
+    if (n_flagged != nullptr && *n_flagged == 0) return;
   }
   extern __shared__ float4_t s_rec[];  // LDSREC: [n_interior][8 slots][2] = the F2nChildInfo records, pad = rank of an interior child
   if (LDSREC) {
@@ -136,7 +140,11 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
   if (MODE >= 2) base = ray * max_hits;
   int old_cnt = 0;
   bool redo = false;
-  if (MODE == 3) {
+  if (MODE == 3 && n_flagged != nullptr) {
+    if (in_range) old_cnt = se_out[2 * ray + 1] - se_out[2 * ray];
+    redo = in_range && repair_flags[ray] == F2N_REPAIR_FULL;
+    if (!redo) limit = 0;
+  } else if (MODE == 3) {
     bool dead_hit = false;
     if (in_range) {
       old_cnt = se_out[2 * ray + 1] - se_out[2 * ray];
@@ -287,7 +295,10 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
       se_out[2 * ray] = base;
       se_out[2 * ray + 1] = base + cnt;
     }
-    if (MODE == 3) repair_flags[ray] = redo ? 1 : 0;
+    if (MODE == 3) {
+      if (n_flagged == nullptr) repair_flags[ray] = redo ? 1 : 0;
+      else if (redo) repair_flags[ray] = 0;  // (repair_from semantics: march this ray again from its origin)
+    }
   }
   if (MODE >= 2) {  // wave-level hit total, one atomic per wave (repair: the change of the total)
     int s = (in_range && k == 0) ? (MODE == 3 ? (redo ? cnt - old_cnt : 0) : cnt) : 0;
@@ -361,6 +372,73 @@ __global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, c
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Repair of speculatively walked leaf lists WITHOUT a second walk (speculative sampling, round 4).  A stat update changes
+// one thing in the tree -- trans_idx -> -1 of the leaves that die -- and the walk (PersSampler.cu:53-152) reads trans_idx only
+// to decide whether a leaf it has reached is listed: the list a fresh walk would produce is the old list minus its dead
+// entries, in the same order with the same near / far, PROVIDED the old list was not cut at max_hits (removing entries would
+// then make room for leaves the old walk never listed: those rays are flagged F2N_REPAIR_FULL and walked again).
+// One 16-lane row per ray: entries are tested 16 at a time (died_at[node] >= spec_epoch), survivors behind the first dead
+// entry slide forward in place.  repair_from[ray] = position of the first removed entry if the march got that far
+// (reached[ray], see ray_march_kernel<2, true>) -- the march then resumes from the state it recorded there -- else -1.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void oct_list_repair_kernel(int n_rays, int max_hits, int32_t* __restrict__ oct_start_end,
+                                                              int32_t* oct_idx, float* oct_near_far, int32_t* oct_trans,
+                                                              int32_t* __restrict__ total, const int32_t* __restrict__ died_at,
+                                                              int spec_epoch, const int32_t* __restrict__ death_epoch,
+                                                              const int32_t* __restrict__ reached, int32_t* __restrict__ repair_from,
+                                                              int32_t* __restrict__ n_repaired, int32_t* __restrict__ n_full) {
+  if (*death_epoch < spec_epoch) return;  // no leaf died since the speculative walk (grid-uniform; repair_from is not read then)
+  const int c = threadIdx.x & 15;
+  const int shift = (threadIdx.x & 48);  // position of this row's 16 bits inside a wave ballot
+  const int ray = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (ray >= n_rays) return;  // whole rows leave together
+  const size_t base = (size_t) ray * max_hits;
+  const int cnt = oct_start_end[2 * ray + 1] - oct_start_end[2 * ray];
+  int w = 0, p_min = -1;
+  const bool capped = cnt >= max_hits;
+  for (int e0 = 0; e0 < cnt; e0 += 16) {
+    const int e = e0 + c;
+    const bool in = e < cnt;
+    const int node = in ? oct_idx[base + e] : 0;
+    const bool dead = in && died_at[node] >= spec_epoch;
+    const bool keep = in && !dead;
+    const unsigned m_dead = (unsigned) ((__ballot(dead) >> shift) & 0xffffull);
+    const unsigned m_keep = (unsigned) ((__ballot(keep) >> shift) & 0xffffull);
+    if (p_min < 0 && m_dead != 0u) p_min = e0 + __ffs(m_dead) - 1;
+    if (capped) {
+      if (p_min >= 0) break;  // (row-uniform) a cut list that lost an entry: walked again
+      continue;
+    }
+    if (p_min >= 0 && keep) {
+      const int dst = w + __popc(m_keep & ((1u << c) - 1u));
+      if (dst != e) {  // every lane of the row has loaded before any stores: dst <= e, and slots >= e0 are read in this round
+        const float nr = oct_near_far[2 * (base + e)], fr = oct_near_far[2 * (base + e) + 1];
+        const int tr = oct_trans != nullptr ? oct_trans[base + e] : 0;
+        oct_idx[base + dst] = node;
+        oct_near_far[2 * (base + dst)] = nr;
+        oct_near_far[2 * (base + dst) + 1] = fr;
+        if (oct_trans != nullptr) oct_trans[base + dst] = tr;
+      }
+    }
+    w += __popc(m_keep);
+  }
+  if (c != 0) return;
+  int from = F2N_REPAIR_NONE;
+  if (p_min >= 0) {
+    if (capped) {
+      from = F2N_REPAIR_FULL;
+      atomicAdd(n_full, 1);
+    } else {
+      oct_start_end[2 * ray + 1] = oct_start_end[2 * ray] + w;
+      atomicAdd(total, w - cnt);
+      if (p_min <= reached[ray]) from = p_min;
+    }
+    if (from != F2N_REPAIR_NONE && n_repaired != nullptr) atomicAdd(n_repaired, 1);
+  }
+  repair_from[ray] = from;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Perspective-warped ray marching (PersSampler.cu:189-314), sixteen lanes per ray.
 //
 // A march step is a strictly sequential chain (the step length comes from the warp Jacobian at the current point):
@@ -395,7 +473,15 @@ __device__ __forceinline__ float f2n_row12_sum(float e) {
 // the 12-term tree ((e0+(e1+e2)) + (e3+(e4+e5))) + ((e6+(e7+e8)) + (e9+(e10+e11))): the triple sum is two quad_perm
 // steps, row_mirror pairs quads (0,3) = groups (0,1) and (1,2) = groups (2,3), row_half_mirror pairs the two halves --
 // every lane ends with the full sum, added in exactly the reference's order (fp add commutes, association is kept).
-template <int MODE>
+//
+// TAIL (MODE 2 only; speculative sampling, see f2n_oct_list_repair): the walk also RECORDS, for every leaf-list entry it
+// crosses into (or past), the state it had at the start of that iteration -- (t, samples emitted, list position, first-point
+// flag), 8 bytes into leaf_state[ray * max_hits + entry] -- and the last list position it looked at (reached[ray]).  An
+// iteration reads list entries only through that crossing loop, so when entry p is later REMOVED from the list (its leaf died)
+// every iteration before the one that first reached p is untouched: a repair resumes from leaf_state[p] on the compacted list
+// instead of from the ray's origin (repair_from[ray] = p > 0; 0 = from the origin, < 0 = nothing to do) and produces, bit for
+// bit, what a fresh march over the new list produces.
+template <int MODE, bool TAIL = false>
 __global__ __launch_bounds__(64) void ray_march_kernel(
     int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ noise_all, const int32_t* __restrict__ oct_start_end, const int32_t* __restrict__ oct_idx_all,
@@ -403,11 +489,20 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
     const int32_t* __restrict__ pts_start_end, int32_t* __restrict__ pts_counts, float* __restrict__ pts,
     float* __restrict__ dirs, float* __restrict__ dts, float* __restrict__ ts, int32_t* __restrict__ anchors,
     float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all, const int32_t* __restrict__ repair_flags,
-    const int32_t* __restrict__ death_epoch, int spec_epoch) {
+    const int32_t* __restrict__ death_epoch, int spec_epoch, uint2* __restrict__ leaf_state = nullptr,
+    int32_t* __restrict__ reached = nullptr) {
+  static_assert(!TAIL || MODE == 2, "resumable walks exist for the single-pass variant");
+  int resume = 0;  // TAIL repair: the list entry whose recorded state the walk resumes from (0: from the ray's origin)
   if (MODE == 2 && repair_flags != nullptr) {  // repair of a speculative march: only the rays whose leaf list was redone
     if (*death_epoch < spec_epoch) return;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (r >= n_rays || repair_flags[r] == 0) return;
+    if (r >= n_rays) return;
+    if (TAIL) {
+      resume = repair_flags[r];  // (= repair_from of f2n_oct_list_repair)
+      if (resume < 0) return;
+    } else if (repair_flags[r] == 0) {
+      return;
+    }
   }
   const int lane16 = threadIdx.x & 15, kq = lane16 & 3, quad = lane16 >> 2;
   const int grp = quad == 0 ? 0 : quad == 1 ? 2 : quad == 2 ? 3 : 1;  // Eigen group of this quad (see above)
@@ -447,7 +542,7 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
   const uint32_t m_w0 = j == 0 ? ~0u : 0u, m_w1 = j == 1 ? ~0u : 0u, m_w2 = j == 2 ? ~0u : 0u, m_t = j == 3 ? ~0u : 0u;
   const uint32_t m_dt = j == 4 ? ~0u : 0u, m_tr = j == 5 ? ~0u : 0u, m_oct = j == 6 ? ~0u : 0u;
   const uint32_t out_fixed = j >= 7 ? out_const : 0u;
-  int n = 0;
+  int n = 0, oct_ptr_final = 0;
   if (n_oct > 0 && max_n > 0) {
     const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
     const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
@@ -473,22 +568,34 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
         w_tr[q] = oct_trans != nullptr ? oct_trans[e] : -2;
       }
     };
-    fill_window(0);
+    float resume_t = 0.f;
+    if (TAIL && resume > 0) {  // the state recorded when the walk first reached the (since removed) entry `resume`
+      const uint2 rec = leaf_state[(size_t) oct_s + resume];
+      resume_t = __uint_as_float(rec.x);
+      n = (int) (rec.y & 0x7ffu);
+      oct_ptr = (int) ((rec.y >> 11) & 0x7ffu);
+      first = ((rec.y >> 22) & 1u) != 0u;
+      win_base = oct_ptr;
+      if (out_ptr != nullptr) out_ptr += (size_t) n * out_stride;
+    }
+    fill_window(win_base);
     int cur_oct = w_idx[0];
     int tidx = w_tr[0] != -2 ? w_tr[0] : nodes[cur_oct].trans_idx, cached_tidx = -1;
-    float cur_t = w_near[0], cur_far = w_far[0];
+    float cur_t = (TAIL && resume > 0) ? resume_t : w_near[0], cur_far = w_far[0];
     float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
     float m[8], wg[3], radius_clip = 1.f;  // this lane's projection of the current TransInfo
     // noise[n] sits on the step's critical path (it scales the step length): four values at a time, the next four
     // already in flight.  The buffer has 1024 + n_rays + 10 floats, so ray + n + 7 stays inside it.
     float nz[4], nz_next[4];
-    int nz_base = 0;
+    int nz_base = TAIL ? (n & ~3) : 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      nz[q] = noise[q];
-      nz_next[q] = noise[4 + q];
+      nz[q] = noise[nz_base + q];
+      nz_next[q] = noise[nz_base + 4 + q];
     }
     while (n < max_n && oct_ptr < n_oct) {
+      // (TAIL) the state this iteration starts from: what a later repair resumes with
+      const uint32_t st_word = TAIL ? ((uint32_t) n | ((uint32_t) oct_ptr << 11) | (first ? (1u << 22) : 0u)) : 0u;
       if (n - nz_base >= 4) {
         nz_base += 4;
 #pragma unroll
@@ -559,6 +666,7 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
       while (cur_t + march > cur_far) {  // leaf crossing (:291-301)
         oct_ptr++;
         if (oct_ptr >= n_oct) break;
+        if (TAIL && leaf_state != nullptr && j == 7) leaf_state[(size_t) oct_s + oct_ptr] = make_uint2(__float_as_uint(cur_t), st_word);
         if (oct_ptr - win_base >= 4) {
           win_base = oct_ptr;
           fill_window(win_base);
@@ -578,8 +686,10 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
       for (int c = 0; c < 3; c++) xyz[c] = o[c] + d[c] * cur_t;
       first = false;
     }
+    oct_ptr_final = oct_ptr;
   }
   if (MODE != 1 && j == 0) pts_counts[ray] = n;
+  if (TAIL && reached != nullptr && j == 0) reached[ray] = n_oct > 0 ? oct_ptr_final : 0;
 }
 
 // Strided slots -> ray-ordered compact SampleResultFlex arrays (one wave per ray, coalesced copies).  When the march
@@ -1049,11 +1159,12 @@ __global__ void march_noise_kernel(int n, const float* __restrict__ u, float fin
 // resident (160 KB / this), i.e. how many wave slots and registers the latency-bound march takes from the MLP / scatter
 // kernels it runs underneath.  0 = no cap.  F2N_MARCH_LDS (bytes) overrides the default for experiments.
 static size_t f2n_march_lds() {
-  static int cached = -1;
-  const char* e = getenv("F2N_MARCH_LDS");
-  if (e != nullptr) return (size_t) atoi(e);
-  if (cached < 0) cached = 0;
-  return (size_t) cached;
+  static const size_t bytes = []() -> size_t {  // (read once: getenv is neither cheap nor safe against a concurrent setenv)
+    const char* e = getenv("F2N_MARCH_LDS");
+    const long v = e != nullptr ? atol(e) : 0;
+    return (size_t) (v < 0 ? 0 : (v > 160 * 1024 ? 160 * 1024 : v));
+  }();
+  return bytes;
 }
 
 extern "C" {
@@ -1236,6 +1347,66 @@ int f2n_ray_march_repair(void* stream, int n_rays, float sample_l, int scale_by_
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
                      nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, repair_flags, death_epoch, spec_epoch);
+  return f2n_launch_status();
+}
+
+int f2n_ray_march_strided_rec(void* stream, int n_rays, int max_hits, float sample_l, int scale_by_dis, const float* rays_o,
+                              const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                              const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
+                              float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
+                              void* leaf_state, int32_t* reached) {
+  if (n_rays < 0 || leaf_state == nullptr || reached == nullptr || max_hits < 1 || max_hits > 2048) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL((ray_march_kernel<2, true>), dim3(f2n_div_up(n_rays, 4)), dim3(64), f2n_march_lds(),
+                     (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
+                     oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
+                     nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, nullptr, nullptr, 0, (uint2*) leaf_state, reached);
+  return f2n_launch_status();
+}
+
+int f2n_ray_march_repair_tail(void* stream, int n_rays, int max_hits, float sample_l, int scale_by_dis, const float* rays_o,
+                              const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                              const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
+                              float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
+                              void* leaf_state, int32_t* reached, const int32_t* repair_from, const int32_t* death_epoch,
+                              int spec_epoch) {
+  if (n_rays < 0 || leaf_state == nullptr || reached == nullptr || repair_from == nullptr || death_epoch == nullptr || max_hits < 1 ||
+      max_hits > 2048)
+    return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL((ray_march_kernel<2, true>), dim3(f2n_div_up(n_rays, 4)), dim3(64), f2n_march_lds(),
+                     (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
+                     oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
+                     nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, repair_from, death_epoch, spec_epoch,
+                     (uint2*) leaf_state, reached);
+  return f2n_launch_status();
+}
+
+int f2n_oct_list_repair(void* stream, int n_rays, int max_hits, int32_t* oct_start_end, int32_t* oct_idx, float* oct_near_far,
+                        int32_t* oct_trans, int32_t* total, const int32_t* died_at, int spec_epoch, const int32_t* death_epoch,
+                        const int32_t* reached, int32_t* repair_from, int32_t* n_repaired, int32_t* n_full) {
+  if (n_rays < 0 || max_hits < 1 || died_at == nullptr || death_epoch == nullptr || reached == nullptr || repair_from == nullptr ||
+      n_full == nullptr || total == nullptr)
+    return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(oct_list_repair_kernel, dim3(f2n_div_up(n_rays, 16)), dim3(256), 0, (hipStream_t) stream, n_rays, max_hits,
+                     oct_start_end, oct_idx, oct_near_far, oct_trans, total, died_at, spec_epoch, death_epoch, reached, repair_from,
+                     n_repaired, n_full);
+  return f2n_launch_status();
+}
+
+int f2n_oct_intersect_repair_flagged(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                                     const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
+                                     int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans,
+                                     const void* child_blocks, const int32_t* death_epoch, int spec_epoch, int32_t* repair_from,
+                                     const int32_t* n_full) {
+  if (n_rays < 0 || max_hits < 1 || death_epoch == nullptr || repair_from == nullptr || n_full == nullptr) return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(oct_intersect_coop_kernel<3>, dim3(f2n_div_up(n_rays, F2N_COOP_RAYS_PER_BLOCK)), dim3(256), 0,
+                     (hipStream_t) stream, n_rays, max_hits, search_order, rays_o, rays_d, near_, far_,
+                     (const F2nTreeNode*) tree_nodes, nullptr, nullptr, oct_idx, oct_near_far, oct_start_end, total, oct_trans,
+                     (const F2nChildInfo*) child_blocks, nullptr, spec_epoch, death_epoch, repair_from, nullptr, nullptr, nullptr, 0,
+                     n_full);
   return f2n_launch_status();
 }
 

@@ -300,6 +300,15 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
   }
 }
 
+// Appearance-embedding gradient addends on a 2^-48 grid (order-free integer sums; see shade_bwd_kernel).  |v| is clamped to
+// 2^14: a larger addend only occurs next to non-finite MLP gradients, and that step is dropped by the finiteness flags.
+#define F2N_EMB_FIXED_SCALE 281474976710656.0          // 2^48
+#define F2N_EMB_FIXED_INV (1.0 / 281474976710656.0)
+__device__ __forceinline__ unsigned long long f2n_emb_fixed(float v) {
+  const float cl = v == v ? fminf(fmaxf(v, -16384.f), 16384.f) : 0.f;
+  return (unsigned long long) __double2ll_rn((double) cl * F2N_EMB_FIXED_SCALE);
+}
+
 union F2nShadeSmem {
   F2nMlpLds<2> w;
   float acc[2 * (F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID)];  // two images, see f2n_mlp_flush_dw
@@ -313,18 +322,21 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
                                                         float* __restrict__ emb_partials, const float* __restrict__ df0,
                                                         const int32_t* __restrict__ n_dev, float* __restrict__ emb_global) {
   F2N_RAISE_PRIO();
-  // emb_partials: per-block LDS image of the appearance-embedding gradient, flushed as a partial (n_emb <= 480);
+  // emb_partials: per-block LDS image of the appearance-embedding gradient, flushed as a partial (n_emb <= 240).  The image
+  // is 64-bit FIXED POINT (2^-48 units, ds_add_u64): every addend is rounded to the grid on its own and integer sums do not
+  // depend on the order in which the block's four waves arrive -- with ds_add_f32 two trainings from one seed parted at
+  // iteration 2, in this gradient (tools/determinism_probe.py, round 4);
   // emb_global: more images than fit into LDS -- row sums go straight to the gradient with global atomics, as the
   // reference's ScatterAddFuncBackward does (Scatter.cu:20-40)
   if (n_dev != nullptr) n = min(n, *n_dev);
   __shared__ F2nShadeSmem sm;
-  extern __shared__ float s_emb[];  // [n_emb * 16] per-block appearance-embedding gradient (ds_add_f32)
+  extern __shared__ unsigned long long s_emb[];  // [n_emb * 16] per-block appearance-embedding gradient, fixed point
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   f2n_mlp_lds_fill<2>(sm.w, params, tid, 256);
   const bool do_emb = emb_partials != nullptr || emb_global != nullptr;
   const bool emb_lds = emb_partials != nullptr;
   if (emb_lds)
-    for (int i = tid; i < n_emb * 16; i += 256) s_emb[i] = 0.f;
+    for (int i = tid; i < n_emb * 16; i += 256) s_emb[i] = 0ull;
   __syncthreads();
   const half8_t idf[2] = {f2n_identity_frag(0, c, g), f2n_identity_frag(1, c, g)};
   // forward output layer fragments (needed to recompute o for the sigmoid derivative)
@@ -419,21 +431,24 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
         // ScatterAdd backward (Scatter.cu:20-40): per-image sum over samples, accumulated in LDS.  The 16 samples
         // of a tile usually share a ray, hence an image: reduce across the 16 sample lanes first.
         const int img = (valid && cur.img >= 0 && cur.img < n_emb) ? cur.img : -1;  // an index outside the table adds nothing
-        float* acc_emb = emb_lds ? s_emb : emb_global;
         // sample 0's image, without an LDS round trip: every row of 16 lanes holds the same 16 samples
         const int img0 = __builtin_amdgcn_readfirstlane(img);
         const bool uniform = __all(img == img0);
+        auto add_emb = [&](int im, int col, float v) {
+          if (emb_lds) atomicAdd(&s_emb[im * 16 + col], f2n_emb_fixed(v));
+          else atomicAdd(&emb_global[im * 16 + col], v);
+        };
         if (uniform) {
           if (img0 >= 0) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               const float v = f2n_row16_allsum(dsf[r]);
-              if (c == 0) atomicAdd(&acc_emb[img0 * 16 + 4 * g + r], v);
+              if (c == 0) add_emb(img0, 4 * g + r, v);
             }
           }
         } else if (img >= 0) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) atomicAdd(&acc_emb[img * 16 + 4 * g + r], dsf[r]);
+          for (int r = 0; r < 4; r++) add_emb(img, 4 * g + r, dsf[r]);
         }
       }
       f2n_mlp_accumulate_dw_half<2>(hb, acc);
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
   f2n_mlp_flush_dw<2>(acc, sm.acc, dparams, c, g, tid, 256);
   if (emb_lds) {  // s_emb is complete since the __syncthreads() above
     float* dst = emb_partials + (size_t) blockIdx.x * n_emb * 16;
-    for (int i = tid; i < n_emb * 16; i += 256) dst[i] = s_emb[i];
+    for (int i = tid; i < n_emb * 16; i += 256) dst[i] = (float) ((double) (long long) s_emb[i] * F2N_EMB_FIXED_INV);
   }
 }
 
@@ -525,7 +540,7 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
   const int n = n_max;
   if (n < 0 || !(loss_scale > 0.f) || (dapp_emb != nullptr && (sample_emb_idx == nullptr || n_emb < 1)) || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
-  const bool emb_in_lds = dapp_emb != nullptr && n_emb <= 480;  // per-block LDS accumulator: 64 B per image next to 57 KB of weights / reduction images
+  const bool emb_in_lds = dapp_emb != nullptr && n_emb <= 240;  // per-block LDS accumulator: 128 B (16 x int64) per image next to 57 KB of weights / reduction images
   if (n == 0) return F2N_OK;
   unsigned blocks = f2n_shade_grid((n + 31) / 32, 4);
   if (blocks > 512) blocks = 512;  // two resident blocks per CU (254 registers per lane)
@@ -535,14 +550,14 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
   size_t dyn_lds = 0;
   if (emb_in_lds) {
     emb_partials = (float*) f2n_ws_get(F2N_WS_SHADE_EMB, sizeof(float) * (size_t) blocks * n_emb * 16);
-    dyn_lds = sizeof(float) * (size_t) n_emb * 16;
+    dyn_lds = sizeof(unsigned long long) * (size_t) n_emb * 16;
     if (emb_partials == nullptr) return F2N_ERR_INVALID_ARG;
   }
   if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   if (dyn_lds > 4096) {  // 57 KB of static LDS + the per-image accumulator can pass 64 KB (a gfx950 workgroup may own all 160 KB)
     static bool raised = false;
     if (!raised) {
-      if (hipFuncSetAttribute((const void*) shade_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 480 * 16 * (int) sizeof(float)) != hipSuccess)
+      if (hipFuncSetAttribute((const void*) shade_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 240 * 16 * (int) sizeof(unsigned long long)) != hipSuccess)
         return F2N_ERR_UNSUPPORTED;
       raised = true;
     }

@@ -251,6 +251,50 @@ int f2n_pack_samples_repair(void* stream, int n_rays, const int32_t* pts_start_e
                             float* pts, float* dirs, float* dt, float* t, int32_t* anchors, const int32_t* death_epoch /*[1]*/,
                             int spec_epoch);
 
+/* ---- Tail repair of a speculatively sampled batch (ABI v10) -------------------------------------------------------------
+ * The repair above walks and marches an invalidated ray again from its origin: as latency-bound as the sampler itself
+ * (the longest invalidated ray), and it sits on the step's critical cycle.  Neither is necessary.  (1) The walk reads trans_idx
+ * only to decide whether a leaf it has reached is listed, so the list a fresh walk produces is the old list minus its dead
+ * entries (unless the old list was cut at max_hits).  (2) A march iteration looks at list entries only when it crosses out of
+ * its current leaf, so every iteration before the one that first reached the first removed entry is untouched.
+ *   f2n_ray_march_strided_rec  f2n_ray_march_strided that also records, per list entry it crosses into or past, the state the
+ *                              iteration started from -- leaf_state[ray * max_hits + entry] = {bits of t, samples emitted |
+ *                              list position << 11 | first-point flag << 22} -- and reached[ray] = the last list position it
+ *                              looked at.  max_hits <= 2048.
+ *   f2n_oct_list_repair        removes the entries whose node has died_at >= spec_epoch from every list IN PLACE (order, near /
+ *                              far, trans kept), adjusts oct_start_end / total[0]; repair_from[ray] = position of the first
+ *                              removed entry if the march had reached it, F2N_REPAIR_NONE (-1) if the ray needs no new march,
+ *                              F2N_REPAIR_FULL (-2) if the list was cut at max_hits and lost an entry (n_full[0] += 1; the list is
+ *                              left as it was).  Same early exit as the calls above (repair_from is then NOT written).
+ *   f2n_oct_intersect_repair_flagged  walks the F2N_REPAIR_FULL rays again (returns at once when n_full[0] == 0) and sets their
+ *                              repair_from to 0.
+ *   f2n_ray_march_repair_tail  resumes the march of every ray with repair_from >= 0 from the state recorded at that entry (0: from
+ *                              the origin) on the repaired list, recording again.
+ * Result: bit-identical to a fresh f2n_oct_intersect_strided + f2n_ray_march_strided on the updated tree
+ * (tests/test_gpu_scale.py::test_speculative_tail_repair). */
+#define F2N_REPAIR_NONE (-1)
+#define F2N_REPAIR_FULL (-2)
+int f2n_ray_march_strided_rec(void* stream, int n_rays, int max_hits, float sample_l, int scale_by_dis, const float* rays_o,
+                              const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                              const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
+                              float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
+                              void* leaf_state /*[R * max_hits] 8-byte records*/, int32_t* reached /*[R]*/);
+int f2n_oct_list_repair(void* stream, int n_rays, int max_hits, int32_t* oct_start_end, int32_t* oct_idx, float* oct_near_far,
+                        int32_t* oct_trans /*or NULL*/, int32_t* total, const int32_t* died_at, int spec_epoch,
+                        const int32_t* death_epoch, const int32_t* reached, int32_t* repair_from /*[R]*/,
+                        int32_t* n_repaired /*[1] or NULL*/, int32_t* n_full /*[1], zeroed by the caller*/);
+int f2n_oct_intersect_repair_flagged(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
+                                     const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
+                                     int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans,
+                                     const void* child_blocks, const int32_t* death_epoch, int spec_epoch, int32_t* repair_from,
+                                     const int32_t* n_full);
+int f2n_ray_march_repair_tail(void* stream, int n_rays, int max_hits, float sample_l, int scale_by_dis, const float* rays_o,
+                              const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                              const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
+                              float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
+                              void* leaf_state, int32_t* reached, const int32_t* repair_from, const int32_t* death_epoch,
+                              int spec_epoch);
+
 /* MarkInvisibleNodesKernel (PersSampler.cu:618-680). */
 int f2n_oct_mark_invisible(void* stream, int n_nodes, int n_cams, void* tree_nodes, const float* intris /*[C,3,3]*/,
                            const float* w2cs /*[C,3,4]*/, const float* bounds /*[C,2]*/);

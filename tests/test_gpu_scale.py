@@ -733,7 +733,107 @@ def test_speculative_sampling_repair(hip, kill_frac):
         assert (N(kept_p[k]) == (-7 if k == "anchors" else 3.0)).all(), k  # (no leaf died since EPOCH + 1: not touched)
 
 
-def test_speculative_training_equals_sampling_after_the_update(rt, fox_state):
+@pytest.mark.parametrize("kill_frac,max_hits", [(0.02, 1024), (0.0005, 1024), (0.02, 24)])
+def test_speculative_tail_repair(hip, kill_frac, max_hits):
+    """Tail repair of a speculatively sampled batch (include/f2n_abi.h, ABI v10): the march records a resumable state per
+    leaf-list entry (f2n_ray_march_strided_rec); after a stat update killed leaves, f2n_oct_list_repair removes the dead
+    entries from the lists in place, f2n_oct_intersect_repair_flagged walks the lists that were cut at max_hits again, and
+    f2n_ray_march_repair_tail resumes every invalidated ray behind its first dead leaf.  The result equals -- slot for slot --
+    the batch sampled after the update, and the recording march equals the plain one.  max_hits = 24 cuts most lists of the
+    converged scene, so that the F2N_REPAIR_FULL path runs too."""
+    z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
+    n = z["rays_o"].shape[0]
+    rd_np = oc.normalize_dirs(z["rays_d"])
+    rng = np.random.default_rng(11)
+    noise = (((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(1.)).astype(F32)
+    tn, tr, so = T(z["tree_nodes"].copy()), T(z["pers_trans"]), T(z["search_order"])
+    ro, rd, nz = T(z["rays_o"]), T(rd_np), T(noise)
+    n_nodes = z["tree_nodes"].size // 64
+    cb = torch.zeros(n_nodes * 8 * 32, dtype=torch.uint8, device=DEV)
+    hip.oct_build_child_blocks(n_nodes, tn, cb)
+    plain = _strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n, max_hits)
+
+    def rec_sample():
+        b = dict(se=torch.zeros((n, 2), dtype=torch.int32, device=DEV), oi=torch.zeros(n * max_hits, dtype=torch.int32, device=DEV),
+                 nf=torch.zeros((n * max_hits, 2), device=DEV), otr=torch.zeros(n * max_hits, dtype=torch.int32, device=DEV),
+                 tot=torch.zeros(1, dtype=torch.int32, device=DEV), cnt=torch.zeros(n, dtype=torch.int32, device=DEV),
+                 s_dt=torch.zeros(n * 1024, device=DEV), s_t=torch.zeros(n * 1024, device=DEV),
+                 s_an=torch.zeros((n * 1024, 2), dtype=torch.int32, device=DEV), fod=torch.zeros(n, device=DEV),
+                 ls=torch.full((n * max_hits, 2), -1, dtype=torch.int32, device=DEV), reached=torch.full((n,), -9, dtype=torch.int32, device=DEV))
+        hip.oct_intersect_strided(n, max_hits, so, ro, rd, 0.01, 1e8, tn, b["se"], b["oi"], b["nf"], b["tot"], b["otr"], cb)
+        hip.ray_march_strided_rec(n, max_hits, 1. / 256., True, ro, rd, nz, b["se"], b["oi"], b["nf"], tn, tr, b["cnt"], None, b["s_dt"],
+                                  b["s_t"], b["s_an"], b["fod"], b["otr"], b["ls"], b["reached"])
+        return b
+    spec = rec_sample()
+    before = _filled_prefixes(spec, n, max_hits)
+    want0 = _filled_prefixes(plain, n, max_hits)
+    for k in want0:
+        assert same_bits(before[k], want0[k]), k  # recording changes nothing
+    k_per_ray = before["se"][:, 1] - before["se"][:, 0]
+    reached = N(spec["reached"])
+    assert ((reached >= 0) & (reached <= k_per_ray)).all()
+    # the stat update
+    nodes = z["tree_nodes"].view(octc.NODE_DT)
+    hit_leaves = np.unique(before["oi"])
+    victims = rng.choice(hit_leaves, max(1, int(len(hit_leaves) * kill_frac)), replace=False)
+    w_stats = np.full(n_nodes, 1000, np.int32); a_stats = np.full(n_nodes, 1000, np.int32)
+    w_stats[victims] = 0
+    mark = np.zeros(n_nodes, np.int32); mark[victims] = 1
+    adders = np.full((2, n_nodes), -1, np.int32)
+    died_at = torch.zeros(n_nodes, dtype=torch.int32, device=DEV)
+    death_epoch = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d_add, d_mark, d_w, d_a = T(adders), T(mark), T(w_stats), T(a_stats)
+    EPOCH = 3
+    hip.oct_update_stats_ex(n_nodes, d_add[0], d_add[1], d_mark, d_w, d_a, tn, cb, True, died_at, EPOCH, death_epoch)
+    assert int(death_epoch.item()) == EPOCH
+    frm = torch.full((n,), 7, dtype=torch.int32, device=DEV)
+    n_rep = torch.zeros(1, dtype=torch.int32, device=DEV); n_full = torch.zeros(1, dtype=torch.int32, device=DEV)
+
+    def repair(epoch):
+        hip.oct_list_repair(n, max_hits, spec["se"], spec["oi"], spec["nf"], spec["otr"], spec["tot"], died_at, epoch, death_epoch,
+                            spec["reached"], frm, n_rep, n_full)
+        hip.oct_intersect_repair_flagged(n, max_hits, so, ro, rd, 0.01, 1e8, tn, spec["se"], spec["oi"], spec["nf"], spec["tot"], spec["otr"],
+                                         cb, death_epoch, epoch, frm, n_full)
+        hip.ray_march_repair_tail(n, max_hits, 1. / 256., True, ro, rd, nz, spec["se"], spec["oi"], spec["nf"], tn, tr, spec["cnt"], None,
+                                  spec["s_dt"], spec["s_t"], spec["s_an"], spec["fod"], spec["otr"], spec["ls"], spec["reached"], frm,
+                                  death_epoch, epoch)
+    repair(EPOCH + 1)  # asked for a later epoch than any death: returns on the device without touching anything
+    assert (N(frm) == 7).all() and int(n_rep.item()) == 0 and int(n_full.item()) == 0
+    untouched = _filled_prefixes(spec, n, max_hits)
+    for k in before:
+        assert same_bits(untouched[k], before[k]), k
+    repair(EPOCH)
+    repaired = _filled_prefixes(spec, n, max_hits)
+    fresh = _filled_prefixes(_strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n, max_hits), n, max_hits)
+    for k in fresh:
+        assert same_bits(repaired[k], fresh[k]), k
+    assert not same_bits(before["cnt"], fresh["cnt"])  # (the deaths did change the batch)
+    fr = N(frm)
+    ray_of = np.repeat(np.arange(n), k_per_ray)
+    holds_victim = np.zeros(n, bool)
+    holds_victim[np.unique(ray_of[np.isin(before["oi"], victims)])] = True
+    assert (fr[~holds_victim] == -1).all()                      # rays without a dead leaf: nothing to do
+    cut = k_per_ray >= max_hits
+    if max_hits == 1024:
+        assert int(n_full.item()) == 0 and (fr >= -1).all()
+        # a ray resumes at its first dead entry -- unless its march never got that far
+        pos_in_ray = np.arange(len(ray_of)) - np.repeat(np.cumsum(k_per_ray) - k_per_ray, k_per_ray)
+        first_dead = np.full(n, 1 << 30)
+        dead_e = np.isin(before["oi"], victims)
+        np.minimum.at(first_dead, ray_of[dead_e], pos_in_ray[dead_e])
+        want = np.where(holds_victim & (first_dead <= reached), first_dead, -1)
+        assert (fr == want).all()
+        assert 0 < (fr >= 0).sum() and (fr > 0).sum() > 0       # tails were resumed, not only whole rays
+    else:
+        assert int(n_full.item()) == int((cut & holds_victim).sum()) > 0   # cut lists that lost an entry were walked again ...
+        assert (fr[cut & holds_victim] == 0).all()                          # ... and are marched from their origin
+    assert int(n_rep.item()) == int((fr >= 0).sum())
+    ref_hits = oc.oct_intersect(z["search_order"], z["rays_o"], rd_np, 0.01, 1e8, N(tn), max_hits)
+    assert same_bits(repaired["oi"], ref_hits[1]) and same_bits(repaired["nf"], ref_hits[2])
+
+
+@pytest.mark.parametrize("tail", [True, False])
+def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, tail):
     """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
     against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
     statistics identical.  Learning rate 0 keeps the weights -- and so both runs -- deterministic, while the statistics are
@@ -760,6 +860,7 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state):
         runner.load_states(states)
         runner.n_edge_pts = NE
         runner.speculative_sampling = spec
+        runner.tail_repair = tail  # (repair by list compaction + tail march, or by a second walk + march from the origin)
         torch.manual_seed(11)  # the same noise / background / edge draws in both runs
         log = []
         nb = [t.to(DEV, non_blocking=True) for t in host_batches[0]]
