@@ -212,6 +212,8 @@ def converged_leg(args, st, dev):
     runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
     if args.speculation_order >= 0:
         runner.speculation_order = args.speculation_order
+    if args.speculation_depth >= 1:
+        runner.speculation_depth = args.speculation_depth
     torch.manual_seed(2022)
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
@@ -263,7 +265,9 @@ def converged_leg(args, st, dev):
     batches = [ds.rand_rays_data(R, 1) for _ in range(n_batches)]
 
     def step(i):
-        b, nb = batches[i % n_batches], batches[(i + 1) % n_batches]
+        b, nb, nb2 = batches[i % n_batches], batches[(i + 1) % n_batches], batches[(i + 2) % n_batches]
+        if runner.speculation_depth >= 2:
+            return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2], nb2[0], nb2[1])
         return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
     for i in range(4):
         step(i)
@@ -319,6 +323,8 @@ def main():
     ap.add_argument("--speculation", choices=["auto", "on", "off"], default="auto", help="sampling of the next batch AHEAD of the stat "
                     "update with repair behind it (Renderer::PreSampleSpecBegin): auto = while no leaf has died lately (the "
                     "default of the host), on / off = A/B (profiles/r03_speculation_experiments.txt)")
+    ap.add_argument("--speculation-depth", type=int, default=-1, help="A/B: batches sampled ahead of their step (1 or 2: Renderer.h "
+                    "spec_depth_); -1 = host default")
     ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
                     "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
     ap.add_argument("--lds-octree", type=int, default=-1, help="A/B: 0 walks the octree through the L2s even when its interior nodes "
@@ -379,6 +385,8 @@ def main():
     runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
     if args.speculation_order >= 0:
         runner.speculation_order = args.speculation_order
+    if args.speculation_depth >= 1:
+        runner.speculation_depth = args.speculation_depth
     if args.lds_octree >= 0:
         runner.lds_octree = bool(args.lds_octree)
     if args.optimistic_pack >= 0:
@@ -404,7 +412,10 @@ def main():
     def step(i):
         # the next batch's rays are handed over as well: their sampling is prefetched on a side stream underneath this
         # step's backward kernels (the reference draws its rays at the top of every iteration, ExpRunner.cpp:88-91)
-        b, nb = batches[i % n_batches], batches[(i + 1) % n_batches]
+        # (two-deep sampling pipeline: the batch after next as well -- it is walked and marched two steps ahead of its use)
+        b, nb, nb2 = batches[i % n_batches], batches[(i + 1) % n_batches], batches[(i + 2) % n_batches]
+        if runner.speculation_depth >= 2 and not dp:
+            return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2], nb2[0], nb2[1])
         return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
 
     for i in range(args.warmup):

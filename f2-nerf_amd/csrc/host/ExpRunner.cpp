@@ -5,6 +5,8 @@
 // parallelism hooks in through `sync_` (GradSyncPipeline.h: in front of the optimiser, or pipelined under the next step's sampling).
 #include "ExpRunner.h"
 
+#include <deque>
+
 namespace f2n {
 
 ExpRunner::ExpRunner(const std::map<std::string, std::string>& flat_config, int n_images) {
@@ -218,7 +220,8 @@ float ExpRunner::CurVarLossWeight() const { return ScheduleAt(Schedule(), iter_s
 // (Renderer::TrainForwardBackward), device-side finiteness flags, Adam predicated on them, ONE flag read-back.
 TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                                 const Tensor& emb_idx, bool apply_optimizer, const Tensor& next_rays_o,
-                                const Tensor& next_rays_d, const Tensor& next_bounds) {
+                                const Tensor& next_rays_d, const Tensor& next_bounds, const Tensor& next2_rays_o,
+                                const Tensor& next2_rays_d) {
   // Network shapes without fused kernels (any tcnn FullyFusedMLP a YAML can ask for: csrc/mlp_generic.hip, unfused field /
   // shader paths) train through the taped iteration: same losses, same optimiser, no streaming.
   if (!renderer_->FusedPathOk()) return TrainStepAutograd(rays_o, rays_d, bounds, gt_colors, emb_idx, apply_optimizer);
@@ -233,8 +236,9 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   sync_.BeginStep(apply_optimizer, [&]() { renderer_->PreSample(rays_o, rays_d, bounds); });
   renderer_->ZeroGrad();
   renderer_->after_octree_update_ = nullptr;  // (a previous call that threw must not leave its hook / half a prefetch behind)
-  renderer_->next_batch_ = Renderer::NextBatch();
-  if (!renderer_->PendingMatches(rays_o, rays_d)) renderer_->DropPendingSamples();
+  renderer_->next_batch_ = renderer_->next2_batch_ = Renderer::NextBatch();
+  renderer_->KeepOnlyPending(rays_o, rays_d, prefetch ? next_rays_o : Tensor(), prefetch ? next_rays_d : Tensor(),
+                             prefetch ? next2_rays_o : Tensor(), prefetch ? next2_rays_d : Tensor());
   deferred_dropped_ = false;
   if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
   if (prefetch && !pipelined) {
@@ -253,6 +257,12 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     renderer_->next_batch_.rays_d = next_rays_d;
     renderer_->next_batch_.fineness = fin;
     renderer_->next_batch_.valid = true;
+    if (next2_rays_o.defined() && next2_rays_d.defined()) {  // two-deep pipeline: the batch behind it is walked and marched now
+      renderer_->next2_batch_.rays_o = next2_rays_o;
+      renderer_->next2_batch_.rays_d = next2_rays_d;
+      renderer_->next2_batch_.fineness = FinenessAt(iter_step_ + 2);
+      renderer_->next2_batch_.valid = true;
+    }
   }
   // A streaming step (it was handed the next batch) does not wait for the survivor count either: it stays on the device
   // (f2n_*_dyn entry points), the host queues the whole iteration without a device round trip and learns the count -- for
@@ -262,7 +272,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
                                                      disp_loss_weight_, tv_loss_weight_);
   renderer_->async_count_ = false;
   renderer_->after_octree_update_ = nullptr;
-  renderer_->next_batch_ = Renderer::NextBatch();
+  renderer_->next_batch_ = renderer_->next2_batch_ = Renderer::NextBatch();
   ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)
   TrainStats stats;
   stats.skipped_nan = deferred_dropped_;  // the PREVIOUS iteration was dropped: reported one step late when prefetching
@@ -285,7 +295,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   // The NEXT batch's sampling has been running on the side stream since this step's octree update.  The host does not wait
   // for its sample count here: the next step does, right before it needs it (Renderer::SampleAndFilter), so that whatever
   // the caller does between two steps overlaps the march instead of following it.
-  if (prefetch && !renderer_->PreSampleBegun())  // (a batch without samples never reached the hook)
+  if (prefetch && !renderer_->PendingMatches(next_rays_o, next_rays_d))  // (a batch without samples never reached the hook)
     renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, global_data_pool_->ray_march_fineness_);
   if (applied && check_nan_ && prefetch) {  // streaming: do not stall on this step's flags (see ExpRunner.h)
     DeferFlags(apply_optimizer);
@@ -564,20 +574,29 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   const int target = until_iter > 0 ? std::min(until_iter, end_iter_) : end_iter_;
   int executed = 0;
   auto draw = [&]() { return dataset.RandRaysData(std::max(16, CurBatchSize()), sets); };
-  auto next = draw();
+  // The batches of the next iteration AND (two-deep sampling pipeline, Renderer::next2_batch_) of the one after it are drawn
+  // ahead: one draw per iteration, right before the step, as before -- but the adaptive ray count of a batch now comes from the
+  // meaningful-samples average as it stood TWO steps before the batch is used (one step with spec_depth_ 1; the reference:
+  // none, ExpRunner.cpp:86), because that is when its rays have to exist.
+  const bool two_deep = renderer_->spec_depth_ >= 2 && !sync_.Installed();
+  std::deque<decltype(draw())> ahead;
+  ahead.push_back(draw());
   last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;
   FinishPending();
   const int64_t kept0 = renderer_->total_kept_pts_;
   const int give_up = 4 * (target + 16);  // every iteration non-finite: stop instead of spinning
   while (true) {
   while (iter_step_ < target) {
-    auto cur = std::move(next);
-    next = draw();
+    while (ahead.size() < (two_deep ? 3u : 2u)) ahead.push_back(draw());
+    auto& cur = ahead[0];
     const BoundedRays& r = std::get<0>(cur);
-    const BoundedRays& nr = std::get<0>(next);
+    const BoundedRays& nr = std::get<0>(ahead[1]);
     Tensor gt = std::get<1>(cur);
     TORCH_CHECK(gt.defined(), "Train needs resident ground-truth images in the Dataset");
-    TrainStats s = TrainStep(r.origins, r.dirs, r.bounds, gt, std::get<2>(cur), true, nr.origins, nr.dirs, nr.bounds);
+    TrainStats s = two_deep ? TrainStep(r.origins, r.dirs, r.bounds, gt, std::get<2>(cur), true, nr.origins, nr.dirs, nr.bounds,
+                                        std::get<0>(ahead[2]).origins, std::get<0>(ahead[2]).dirs)
+                            : TrainStep(r.origins, r.dirs, r.bounds, gt, std::get<2>(cur), true, nr.origins, nr.dirs, nr.bounds);
+    ahead.pop_front();
     last_train_marched_ += s.n_samples;
     last_train_rays_ += s.n_rays;
     last_train_stats_ = s;

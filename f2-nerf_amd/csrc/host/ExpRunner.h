@@ -34,10 +34,12 @@ class ExpRunner {
   void FinishPendingStep();     // the pipelined data-parallel part only
   void DeferFlags(bool apply_optimizer);  // start the asynchronous read-back of nan_flags_
   bool ResolveDeferredFlags();  // true: the step they belong to was dropped (loss scales halved, counters taken back)
-  // next_*: optionally the NEXT iteration's rays (already resident): their sampling is prefetched on a side stream
+  // next_*: optionally the NEXT iteration's rays (already resident): their sampling is prefetched on a side stream;
+  // next2_*: and those of the iteration after it (two-deep sampling pipeline, Renderer::next2_batch_)
   TrainStats TrainStep(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& gt_colors,
                        const Tensor& emb_idx, bool apply_optimizer = true, const Tensor& next_rays_o = Tensor(),
-                       const Tensor& next_rays_d = Tensor(), const Tensor& next_bounds = Tensor());
+                       const Tensor& next_rays_d = Tensor(), const Tensor& next_bounds = Tensor(),
+                       const Tensor& next2_rays_o = Tensor(), const Tensor& next2_rays_d = Tensor());
   void EnqueueApply(bool apply_optimizer);
   int32_t* NextFlagMirror();
   bool ResolveFlags(bool apply_optimizer);

@@ -5,6 +5,7 @@
 // scan, and the only host read-back of a GetSamples call is the pair (K, N) at its very end.
 #include "PersSampler.h"
 
+#include <ATen/hip/HIPGeneratorImpl.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -48,7 +49,11 @@ PersSampler::PersSampler(GlobalDataPool* global_data_pool) {
 
 void PersOctree::RebuildChildBlocks() {  // the DFS's one-read-per-node view of the tree (f2n_oct_build_child_blocks)
   const int n = n_nodes_;
-  // every caller has just replaced or edited the node array wholesale: speculative samples against the old one are void
+  // every caller has just replaced or edited the node array wholesale: speculative samples against the old one are void --
+  // and their kernels, on the sampler's side streams, may still be READING the arrays that are released below (the allocator
+  // would hand the blocks to this stream's next allocation): the device is drained first.  Rare: construction, state loads,
+  // ProcOctree iterations.
+  (void) hipDeviceSynchronize();
   generation_++;
   died_at_ = torch::zeros({std::max(n, 1)}, DevI32());
   if (!death_epoch_.defined()) {
@@ -99,9 +104,12 @@ int PersOctree::QuietEpochs() const {
   return epoch_ - last;
 }
 
-bool PersSampler::MaintenanceDue() const {  // the conditions of FinishOctUpdate below, for the iteration in progress
-  const int it = global_data_pool_->iter_step_;
-  return (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= it) || it % compact_freq_ == 0;
+bool PersSampler::MaintenanceDue(int ahead) const {  // the conditions of FinishOctUpdate below, for the iteration in progress ... + ahead
+  for (int d = 0; d <= ahead; d++) {
+    const int it = global_data_pool_->iter_step_ + d;
+    if ((!sub_div_milestones_.empty() && sub_div_milestones_.back() <= it) || it % compact_freq_ == 0) return true;
+  }
+  return false;
 }
 
 void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, float fineness, PendingSamples& p, bool speculative) {
@@ -123,7 +131,17 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   } else if (global_data_pool_->mode_ == RunningMode::VALIDATE) {
     rays_noise = torch::full({n_noise}, fineness, DevF32());  // ones * fineness (:376-377)
   } else {
-    rays_noise = torch::rand({n_noise}, DevF32());
+    // The march noise has its own generator, re-seeded from the default generator's seed whenever that changes
+    // (torch::manual_seed): the noise of batch k is then the k-th draw of ITS sequence whatever else is drawn in between --
+    // background colours, edge samples, ray batches -- i.e. however far ahead of its step a batch is sampled (one or two steps,
+    // speculatively or behind the stat update: Renderer.h), the same batch gets the same noise.
+    const uint64_t seed = at::cuda::detail::getDefaultCUDAGenerator(rays_o.get_device()).current_seed();
+    if (!noise_gen_.defined() || seed != noise_gen_seed_ || noise_gen_.device() != rays_o.device()) {
+      noise_gen_ = at::cuda::detail::createCUDAGenerator(rays_o.get_device());
+      noise_gen_.set_current_seed(seed ^ 0x9E3779B97F4A7C15ull);
+      noise_gen_seed_ = seed;
+    }
+    rays_noise = torch::rand({n_noise}, noise_gen_, DevF32());
     map_noise = true;
   }
   // unit directions, zeroed totals and the noise map: one launch

@@ -119,7 +119,9 @@ class PersSampler : public PtsSampler {
   // first dead leaf (f2n_oct_list_repair / f2n_ray_march_repair_tail) instead of a second walk and march from the origin
   bool tail_repair_ = true;
   bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
-  bool MaintenanceDue() const;  // the NEXT FinishOctUpdate runs ProcOctree (milestone / compact_freq, PersSampler.cu:605-614)
+  // a FinishOctUpdate of the iteration in progress or of one of the `ahead` iterations behind it runs ProcOctree
+  // (milestone / compact_freq, PersSampler.cu:605-614)
+  bool MaintenanceDue(int ahead = 0) const;
   SampleResultFlex FinishSamples(PendingSamples& p);
   std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;
   void UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weights,
@@ -152,6 +154,8 @@ class PersSampler : public PtsSampler {
   std::function<void(Tensor)> occupancy_sync_hook_;  // gets the [4, n_nodes] vote / mark / visit-count buffer
   // explicit random draws for parity tests (empty = draw from torch's generator like the reference)
   Tensor forced_noise_, forced_edge_idx_, forced_edge_coords_;
+  at::Generator noise_gen_;  // the march noise's own random sequence (BeginSamples)
+  uint64_t noise_gen_seed_ = 0;
   int extra_sample_rows_ = 0;  // SampleResultFlex::extra_rows of the training samples (set by the Renderer: 2 * n_edge_pts)
 };
 

@@ -239,9 +239,10 @@ bool Renderer::PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) cons
 
 void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
   if (PresampleMatches(rays_o, rays_d)) return;  // already marched (asynchronously) for these rays
-  if (PendingMatches(rays_o, rays_d)) {          // ... or being marched
-    PreSampleFinish();
-    return;
+  const int slot = FindPending(rays_o, rays_d);
+  if (slot >= 0) {          // ... or being marched
+    PreSampleFinish(slot);
+    if (PresampleMatches(rays_o, rays_d)) return;
   }
   static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
   presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
@@ -251,110 +252,104 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
   presample_rays_d_ = rays_d;
 }
 
-// The sampler's side stream.  F2N_SIDE_CUS=<n> (experiment knob; or ExpRunner binding `side_cus`): the stream is created with a compute-unit mask
-// of n CUs (hipExtStreamCreateWithCUMask; the mask bits are dealt round-robin over the eight XCDs), so that the latency-bound
-// sampler chain -- a few long-lived waves per CU -- stops sharing SIMDs with the occupancy-bound kernels of the main queue.
-void Renderer::EnsureSideStream() {
-  if (side_stream_) return;
-  if (side_cus_ < 0) {
-    const char* e = std::getenv("F2N_SIDE_CUS");
-    side_cus_ = e != nullptr ? std::max(0, std::min(256, std::atoi(e))) : 0;
-  }
-  const int n_cus = side_cus_;
-  if (n_cus > 0) {
-    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n_cus; i++) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t raw = nullptr;
-    if (hipExtStreamCreateWithCUMask(&raw, 8, mask) == hipSuccess && raw != nullptr) {
-      side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(
-          c10::hip::getStreamFromExternalMasqueradingAsCUDA(raw, c10::hip::current_device()));
-      return;
-    }
-    (void) hipGetLastError();
-  }
-  side_stream_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+void Renderer::EnsureSideStream(int slot) {
+  if (!side_[slot])
+    side_[slot] = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+}
+
+// A side stream's buffers may be handed the memory of samples the main stream is still reading: it waits for the last
+// recording of samples_consumed_ev_ it has not waited for yet.
+void Renderer::SideWaitConsumed(int slot) {
+  if (side_waited_seq_[slot] == consumed_seq_) return;
+  samples_consumed_ev_.block(*side_[slot]);
+  side_waited_seq_[slot] = consumed_seq_;
 }
 
 void Renderer::PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
   PreSampleBegin(rays_o, rays_d, bounds, global_data_pool_->ray_march_fineness_);
-  PreSampleFinish();
+  const int slot = FindPending(rays_o, rays_d);
+  if (slot >= 0) PreSampleFinish(slot);
 }
 
-// First half of the prefetch: everything up to the sample counts, issued on the side stream without blocking the host.
+// First half of the prefetch: everything up to the sample counts, issued on a side stream without blocking the host.
 // Called from inside SampleAndFilter as soon as this step's occupancy update (the only thing the next batch's sampling
 // depends on) has been issued; the kernels then run underneath this step's forward/backward.
 void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& /*bounds*/, float fineness) {
-  EnsureSideStream();
-  octree_ready_ev_.block(*side_stream_);  // the only dependency on this step: its occupancy update / ProcOctree
-  if (side_must_wait_consumed_) {  // the sampler's buffers may be handed the memory of samples the main stream is still reading
-    samples_consumed_ev_.block(*side_stream_);
-    side_must_wait_consumed_ = false;
+  if (FindPending(rays_o, rays_d) >= 0) return;  // (already in flight for these rays)
+  int slot = FreePendingSlot();
+  if (slot < 0) {  // both slots hold batches for other rays: the one begun last is the furthest ahead, and goes
+    slot = kPendingSlots - 1;
+    DropPendingSlot(slot);
   }
-  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
+  EnsureSideStream(slot);
+  octree_ready_ev_.block(*side_[slot]);  // the only dependency on this step: its occupancy update / ProcOctree
+  SideWaitConsumed(slot);
+  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  ps->BeginSamples(rays_o, rays_d, fineness, pending_samples_);  // ... up to and including the pack
-  presample_done_ev_.record(*side_stream_);
-  pending_rays_o_ = rays_o;
-  pending_rays_d_ = rays_d;
+  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s);  // ... up to and including the pack
+  presample_done_ev_[slot].record(*side_[slot]);
+  pend_[slot].rays_o = rays_o;
+  pend_[slot].rays_d = rays_d;
 }
 
 // Speculative variant of PreSampleBegin: intersection + march only, NOT ordered behind this step's stat update.
-void Renderer::PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool /*after_main_stream*/) {
-  EnsureSideStream();
+void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness) {
+  EnsureSideStream(slot);
   // Everything the main stream has been handed so far comes first: the kernels that DRAW the next batch's rays
   // (Dataset::RandRaysData, queued by ExpRunner::Train right before this step) and whatever touched the tree there -- i.e. the
   // speculative sampling starts when this step's own kernels start, not before.  (Waiting only for the previous step's octree
   // update -- as a first version did -- let the side stream read ray buffers that were still to be written whenever the host
   // ran ahead of the device: PSNR fell and octrees blew up at random, worst with a second process on the GPU.)
-  if (!spec_start_recorded_) spec_start_ev_.record();  // (else: recorded at the top of this step, ahead of its random draws)
-  spec_start_recorded_ = false;
-  spec_start_ev_.block(*side_stream_);
-  if (side_must_wait_consumed_) {
-    samples_consumed_ev_.block(*side_stream_);
-    side_must_wait_consumed_ = false;
+  if (!spec_start_recorded_) {  // (else: recorded at the top of this step, ahead of its random draws)
+    spec_start_ev_.record();
+    spec_start_recorded_ = true;  // (a second batch begun in the same step waits for the same point)
   }
-  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
+  spec_start_ev_.block(*side_[slot]);
+  SideWaitConsumed(slot);
+  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  ps->BeginSamples(rays_o, rays_d, fineness, pending_samples_, /*speculative=*/true);
-  pending_rays_o_ = rays_o;
-  pending_rays_d_ = rays_d;
+  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/true);
+  pend_[slot].rays_o = rays_o;
+  pend_[slot].rays_d = rays_d;
 }
 
 // ... and its completion, called with this step's stat update issued (octree_ready_ev_ recorded): repair, scan, count, pack.
-bool Renderer::PreSampleSpecComplete() {
-  TORCH_CHECK(pending_samples_.active && pending_samples_.speculative && !pending_samples_.completed, "no speculative sampling in flight");
-  octree_ready_ev_.block(*side_stream_);
-  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_stream_);
+bool Renderer::PreSampleSpecComplete(int slot) {
+  auto& pb = pend_[slot];
+  TORCH_CHECK(pb.s.active && pb.s.speculative && !pb.s.completed, "no speculative sampling in flight");
+  octree_ready_ev_.block(*side_[slot]);
+  SideWaitConsumed(slot);
+  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  if (!ps->CompleteSpeculative(pending_samples_)) {
-    pending_samples_ = PendingSamples();  // (its kernels are ordered on the side stream, whose pool its buffers return to)
-    pending_rays_o_ = pending_rays_d_ = Tensor();
+  if (!ps->CompleteSpeculative(pb.s)) {
+    pb = PendingBatch();  // (its kernels are ordered on the side stream, whose pool its buffers return to)
     return false;
   }
-  presample_done_ev_.record(*side_stream_);
+  presample_done_ev_[slot].record(*side_[slot]);
   return true;
 }
 
 // Second half: wait for the counts (by now the march has usually finished) and take views of the packed rows.  No launch.
-void Renderer::PreSampleFinish() {
-  TORCH_CHECK(pending_samples_.active, "PreSampleFinish without PreSampleBegin");
+void Renderer::PreSampleFinish(int slot) {
+  auto& pb = pend_[slot];
+  TORCH_CHECK(pb.s.active, "PreSampleFinish without PreSampleBegin");
   // samples marched against a tree that has since been replaced or re-numbered (LoadStates / InstallOctree / ProcOctree between
   // the prefetch and its use) are void, whichever way they were prefetched: the caller samples again
-  if (pending_samples_.generation != static_cast<PersSampler*>(pts_sampler_.get())->pers_octree_->generation_) {
-    DropPendingSamples();
+  if (pb.s.generation != static_cast<PersSampler*>(pts_sampler_.get())->pers_octree_->generation_) {
+    DropPendingSlot(slot);
     return;
   }
-  if (!pending_samples_.completed && !PreSampleSpecComplete()) return;  // (a speculative batch whose step never reached its update)
-  presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pending_samples_);
+  if (!pb.s.completed && !PreSampleSpecComplete(slot)) return;  // (a speculative batch whose step never reached its update)
+  presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pb.s);
   has_presample_ = true;
   presample_async_ = true;
-  presample_rays_o_ = pending_rays_o_;
-  presample_rays_d_ = pending_rays_d_;
-  pending_rays_o_ = Tensor();
-  pending_rays_d_ = Tensor();
+  presample_slot_ = slot;
+  presample_rays_o_ = pb.rays_o;
+  presample_rays_d_ = pb.rays_d;
+  pb = PendingBatch();
 }
 
 float Renderer::KeptPerRayForEma(int n_kept_local, int n_rays) {
@@ -393,7 +388,8 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   // sequence -- background / edge samples of this step, then the next batch's march noise -- whichever way the next batch is
   // sampled; only the event moves.)
   spec_start_recorded_ = false;
-  if (spec_order_ == 1 && train && async_count && next_batch_.valid && dp_world_ <= 1 && speculative_sampling_ != 0) {
+  if (spec_order_ == 1 && train && async_count && (next_batch_.valid || next2_batch_.valid) && dp_world_ <= 1 &&
+      speculative_sampling_ != 0) {
     spec_start_ev_.record();
     spec_start_recorded_ = true;
   }
@@ -426,23 +422,32 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
 
   // A prefetch whose kernels were queued by the previous step: only now does the host wait for its count (everything between
   // the end of that step and this point -- the caller's loop, this step's bookkeeping, the draws above -- overlaps the march).
-  if (train && PendingMatches(rays_o, rays_d)) PreSampleFinish();
-  else DropPendingSamples();
+  if (train) {
+    // (batches in flight for other rays than this step's, the next step's or the one after: void)
+    KeepOnlyPending(rays_o, rays_d, next_batch_.valid ? next_batch_.rays_o : Tensor(), next_batch_.valid ? next_batch_.rays_d : Tensor(),
+                    next2_batch_.valid ? next2_batch_.rays_o : Tensor(), next2_batch_.valid ? next2_batch_.rays_d : Tensor());
+    const int slot = FindPending(rays_o, rays_d);
+    if (slot >= 0) PreSampleFinish(slot);
+  } else {
+    DropPendingSamples();
+  }
   bool wait_for_pack = false;
+  int pack_slot = 0;
   auto pack_done = [&]() {
-    if (wait_for_pack) presample_done_ev_.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    if (wait_for_pack) presample_done_ev_[pack_slot].block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
     wait_for_pack = false;
   };
   if (train && PresampleMatches(rays_o, rays_d)) {  // PreSample[Async]() already marched these rays
     sample_result_ = std::move(presampled_);
     if (presample_async_) {
-      // Produced on the side stream, out of the side stream's memory pool: order it before this stream.  The allocator is
+      // Produced on a side stream, out of that stream's memory pool: order it before this stream.  The allocator is
       // NOT told (record_stream on the seven tensors cost ~45 us of host time when they are released in the middle of the
       // step, right where the device is waiting for the next launch): instead samples_consumed_ev_ is recorded on this
-      // stream once the last kernel that reads them has been queued, and the side stream waits for it before the next
-      // kernels that could be handed this memory again (PreSampleBegin).
+      // stream once the last kernel that reads them has been queued, and the side streams wait for it before the next
+      // kernels that could be handed this memory again (SideWaitConsumed).
       // (the wait itself is issued further down, right before the first kernel that reads the packed samples)
       wait_for_pack = true;
+      pack_slot = presample_slot_;
       consumed_side_samples_ = true;
     }
     presampled_ = SampleResultFlex();
@@ -461,15 +466,24 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   // they run underneath this step's GATHER -- the pairing is deliberate: the gather is bound by L2 line traffic and leaves the
   // vector ALUs idle, the march is a latency chain of vector instructions.  (Started behind the gather instead, so that it
   // would not share the L2s with it, the sampler lands on the VALU-bound MLP / scatter kernels: measured 1.178 -> 1.245 ms.)
-  bool spec_begun = false;
+  // Which batches: the next step's, unless it is in flight already (two-deep pipeline: it was begun one step ago), and the
+  // one behind it (next2_batch_, spec_depth_ >= 2).  A batch begun now is void if a ProcOctree runs before it is consumed --
+  // in this step's update for the next batch, in this or the next step's for the one behind it -- so it is not begun then.
   const bool spec_now = speculative_sampling_ == 1 || (speculative_sampling_ == 2 && ps->pers_octree_->QuietEpochs() >= kSpecQuietEpochs);
-  if (train && async_count && dp_world_ <= 1 && spec_now && next_batch_.valid && n_all_pts > 0 && !pending_samples_.active &&
-      !ps->MaintenanceDue()) {
-    PreSampleSpecBegin(next_batch_.rays_o, next_batch_.rays_d, next_batch_.fineness, /*after_main_stream=*/true);
-    spec_begun = true;
+  const bool spec_ok = train && async_count && dp_world_ <= 1 && spec_now && n_all_pts > 0;
+  auto spec_begin = [&](const NextBatch& nb, int ahead) {
+    if (!nb.valid || FindPending(nb.rays_o, nb.rays_d) >= 0) return;
+    const int slot = FreePendingSlot();
+    if (!spec_ok || slot < 0 || ps->MaintenanceDue(ahead)) {
+      n_spec_fallback_++;
+      return;
+    }
+    PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness);
     n_speculative_++;
-  } else if (train && next_batch_.valid) {
-    n_spec_fallback_++;
+  };
+  if (train) {
+    spec_begin(next_batch_, 0);
+    if (spec_depth_ >= 2) spec_begin(next2_batch_, 1);
   }
   spec_start_recorded_ = false;
   if (train) total_all_pts_ += n_all_pts;
@@ -549,10 +563,11 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     const bool octree_first = train && async_count && dp_world_ <= 1;
     auto octree_update_issued = [&]() {
       octree_ready_ev_.record();  // everything the NEXT step's ray sampling depends on has been issued ...
-      if (spec_begun) {  // ... so the speculative sampling of the next batch is repaired and packed now
-        spec_begun = false;
-        if (PreSampleSpecComplete()) after_octree_update_ = nullptr;
-      }
+      // ... so the speculatively sampled batch of the next step is repaired and packed now (a batch for the step after it
+      // stays as it is: it is repaired behind the NEXT stat update, against every death since it was walked)
+      const int nslot = next_batch_.valid ? FindPending(next_batch_.rays_o, next_batch_.rays_d) : -1;
+      if (nslot >= 0 && pend_[nslot].s.speculative && !pend_[nslot].s.completed && PreSampleSpecComplete(nslot)) after_octree_update_ = nullptr;
+      else if (nslot >= 0 && pend_[nslot].s.completed) after_octree_update_ = nullptr;  // (already prefetched the ordinary way)
       if (after_octree_update_) {  // ... or a prefetching TrainStep starts that sampling now (draw order: bg + edge, noise)
         auto f = std::move(after_octree_update_);
         after_octree_update_ = nullptr;
@@ -638,7 +653,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   if (consumed_side_samples_) {         // (see above: every reader of the side stream's sample buffers has been queued)
     samples_consumed_ev_.record();
     consumed_side_samples_ = false;
-    side_must_wait_consumed_ = true;
+    consumed_seq_++;
   }
   octree_ready_ev_.record();            // everything the NEXT step's ray sampling depends on has been issued
   return fr;

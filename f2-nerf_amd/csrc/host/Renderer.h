@@ -74,18 +74,47 @@ class Renderer : public Pipe {
   // waves, long dependent chains) then run underneath the remaining forward/backward kernels of the current step.
   void PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
   void PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, float fineness);
-  void PreSampleFinish();
-  bool PreSampleBegun() const { return pending_samples_.active; }
-  bool PendingMatches(const Tensor& rays_o, const Tensor& rays_d) const {
-    return pending_samples_.active && pending_rays_o_.defined() && pending_rays_d_.defined() &&
-           rays_o.data_ptr() == pending_rays_o_.data_ptr() && rays_d.data_ptr() == pending_rays_d_.data_ptr() &&
-           rays_o.sizes() == pending_rays_o_.sizes();
+  // Batches whose sampling is in flight on a side stream: at most kPendingSlots of them (round 4: the batch the NEXT step
+  // consumes, being repaired / packed, and the one behind it, being walked and marched -- see next2_batch_), each on its own
+  // stream.  A batch is identified by the ray tensors it was begun for (held: see PresampleMatches).
+  static constexpr int kPendingSlots = 2;
+  struct PendingBatch {
+    PendingSamples s;
+    Tensor rays_o, rays_d;
+  };
+  PendingBatch pend_[kPendingSlots];
+  int FindPending(const Tensor& rays_o, const Tensor& rays_d) const {
+    for (int i = 0; i < kPendingSlots; i++)
+      if (pend_[i].s.active && pend_[i].rays_o.defined() && pend_[i].rays_d.defined() && rays_o.defined() && rays_d.defined() &&
+          rays_o.data_ptr() == pend_[i].rays_o.data_ptr() && rays_d.data_ptr() == pend_[i].rays_d.data_ptr() &&
+          rays_o.sizes() == pend_[i].rays_o.sizes())
+        return i;
+    return -1;
+  }
+  int FreePendingSlot() const {
+    for (int i = 0; i < kPendingSlots; i++)
+      if (!pend_[i].s.active) return i;
+    return -1;
+  }
+  void PreSampleFinish(int slot);
+  bool PreSampleBegun() const { return pend_[0].s.active || pend_[1].s.active; }
+  bool PendingMatches(const Tensor& rays_o, const Tensor& rays_d) const { return FindPending(rays_o, rays_d) >= 0; }
+  void DropPendingSlot(int i) {
+    if (!pend_[i].s.active) return;
+    pend_[i].s.counts_ready.synchronize();  // its kernels may still be running: keep the buffers until they are done
+    if (!pend_[i].s.completed && side_[i]) side_[i]->synchronize();  // (a speculative batch has recorded no count event yet)
+    pend_[i] = PendingBatch();
   }
   void DropPendingSamples() {
-    if (!pending_samples_.active) return;
-    pending_samples_.counts_ready.synchronize();  // its kernels may still be running: keep the buffers until they are done
-    pending_samples_ = PendingSamples();
-    pending_rays_o_ = pending_rays_d_ = Tensor();
+    for (int i = 0; i < kPendingSlots; i++) DropPendingSlot(i);
+  }
+  // drops every pending batch that was not begun for one of these ray pairs (undefined tensors match nothing)
+  void KeepOnlyPending(const Tensor& o0, const Tensor& d0, const Tensor& o1, const Tensor& d1, const Tensor& o2, const Tensor& d2) {
+    for (int i = 0; i < kPendingSlots; i++) {
+      if (!pend_[i].s.active) continue;
+      const int a = FindPending(o0, d0), b = FindPending(o1, d1), c = FindPending(o2, d2);
+      if (i != a && i != b && i != c) DropPendingSlot(i);
+    }
   }
   std::function<void()> after_octree_update_;  // one-shot: called in SampleAndFilter right after the occupancy update
   // Speculative sampling of the NEXT batch (streaming single-GPU steps): intersection and march are issued on the side stream
@@ -104,17 +133,21 @@ class Renderer : public Pipe {
     Tensor rays_o, rays_d;
     float fineness = 1.f;
     bool valid = false;
-  } next_batch_;
+  } next_batch_, next2_batch_;  // the batch of the next step, and (two-deep pipeline) of the step after it
+  // Two-deep pipeline (round 4).  With ONE batch in flight the sampler chain of batch k+1 -- walk, march, repair, scan, pack:
+  // 0.65-0.75 ms of latency on a converged scene -- has exactly step k to finish in, and a converged step is no longer than that:
+  // the main queue waits for it.  With next2_batch_ handed over as well, batch k+2 is walked and marched during step k (on the
+  // other side stream) and repaired + packed behind step k+1's stat update against every death since: its chain has two steps,
+  // and the only sampler work between a stat update and the next step's pre-pass is the tail repair + pack of the batch in front.
+  int spec_depth_ = 2;
   int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
-  void PreSampleSpecBegin(const Tensor& rays_o, const Tensor& rays_d, float fineness, bool after_main_stream);
-  bool PreSampleSpecComplete();  // false: could not be repaired (tree re-numbered): dropped
+  void PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness);
+  bool PreSampleSpecComplete(int slot);  // false: could not be repaired (tree re-numbered): dropped
   at::cuda::CUDAEvent spec_start_ev_;
   // 1: the side stream of a speculative sampling is ordered behind the point the main stream had reached when the step BEGAN,
   // not behind the step's random draws / edge samples (SampleAndFilter); 0: behind the draws (A/B: bench.py --speculation-order)
   int spec_order_ = 1;
   bool spec_start_recorded_ = false;
-  PendingSamples pending_samples_;
-  Tensor pending_rays_o_, pending_rays_d_;
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,
                               bool async_count = false);
   // The survivor count of an async SampleAndFilter arrives in pinned memory; the host-side bookkeeping that depends on it
@@ -152,16 +185,20 @@ class Renderer : public Pipe {
   BGColorType bg_color_type_ = BGColorType::rand_noise;
   SampleResultFlex sample_result_, presampled_;
   bool has_presample_ = false, presample_async_ = false;
+  int presample_slot_ = 0;  // the side stream (pending slot) an asynchronous presample was produced on
   Tensor presample_rays_o_, presample_rays_d_;  // the rays the presample belongs to (held: see PresampleMatches)
   bool PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) const;
-  at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_, n_kept_ev_, samples_consumed_ev_;
-  bool consumed_side_samples_ = false, side_must_wait_consumed_ = false;
+  at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_[kPendingSlots], n_kept_ev_, samples_consumed_ev_;
+  // samples_consumed_ev_ (main stream: the last reader of a side stream's sample buffers has been queued) is awaited by a side
+  // stream before its next kernels, once per recording: consumed_seq_ counts the recordings, side_waited_seq_ what each waited for
+  bool consumed_side_samples_ = false;
+  uint64_t consumed_seq_ = 0, side_waited_seq_[kPendingSlots] = {0, 0};
+  void SideWaitConsumed(int slot);
   bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
   MappedWords n_kept_words_;  // [1]: the surviving-sample count, written by the survivor scan itself, read behind n_kept_ev_
-  std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;
-  void EnsureSideStream();
-  int side_cus_ = -1;  // CUs the side stream may use (0: all; -1: take F2N_SIDE_CUS); changing it drops the stream (callers drain first)
+  std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_[kPendingSlots];
+  void EnsureSideStream(int slot);
   Tensor forced_bg_;  // explicit background colours for parity tests (undefined = as the reference)
   int n_edge_pts_ = 8192;
   int last_n_all_pts_ = 0, last_n_kept_pts_ = 0;

@@ -130,17 +130,19 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("load_aux_states", &ExpRunner::LoadAuxStates)
       .def("train_step",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply,
-              const std::optional<Tensor>& nro, const std::optional<Tensor>& nrd, const std::optional<Tensor>& nb) {
+              const std::optional<Tensor>& nro, const std::optional<Tensor>& nrd, const std::optional<Tensor>& nb,
+              const std::optional<Tensor>& n2ro, const std::optional<Tensor>& n2rd) {
              TrainStats s;
              {
                py::gil_scoped_release no_gil;  // hooks re-acquire the GIL themselves
-               s = r.TrainStep(ro, rd, b, gt, emb, apply, nro.value_or(Tensor()), nrd.value_or(Tensor()), nb.value_or(Tensor()));
+               s = r.TrainStep(ro, rd, b, gt, emb, apply, nro.value_or(Tensor()), nrd.value_or(Tensor()), nb.value_or(Tensor()),
+                               n2ro.value_or(Tensor()), n2rd.value_or(Tensor()));
              }
              return StatsToDict(s);
            },
            py::arg("rays_o"), py::arg("rays_d"), py::arg("bounds"), py::arg("gt_colors"), py::arg("emb_idx"),
            py::arg("apply_optimizer") = true, py::arg("next_rays_o") = py::none(), py::arg("next_rays_d") = py::none(),
-           py::arg("next_bounds") = py::none())
+           py::arg("next_bounds") = py::none(), py::arg("next2_rays_o") = py::none(), py::arg("next2_rays_d") = py::none())
       .def("train_step_autograd",
            [](ExpRunner& r, const Tensor& ro, const Tensor& rd, const Tensor& b, const Tensor& gt, const Tensor& emb, bool apply) {
              TrainStats s;
@@ -294,15 +296,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })
-      .def_property("side_cus",  // compute units the sampler's side stream is confined to (0: all); experiment knob
-                    [](ExpRunner& r) { return r.renderer_->side_cus_; },
-                    [](ExpRunner& r, int n) {
-                      r.FinishPending();
-                      r.renderer_->DropPendingSamples();
-                      (void) hipDeviceSynchronize();
-                      r.renderer_->side_cus_ = std::max(0, std::min(256, n));
-                      r.renderer_->side_stream_.reset();
-                    })
+      .def_property("speculation_depth",  // 2: ExpRunner::Train hands the batch after next over as well (two-deep sampling pipeline); 1: one
+                    [](ExpRunner& r) { return r.renderer_->spec_depth_; },
+                    [](ExpRunner& r, int d) { r.FinishPending(); r.renderer_->DropPendingSamples(); r.renderer_->spec_depth_ = d >= 2 ? 2 : 1; })
       .def_property("speculation_order",  // 1: the speculative sampler starts where the step begins, 0: behind its draws (Renderer.h)
                     [](ExpRunner& r) { return r.renderer_->spec_order_; },
                     [](ExpRunner& r, int bits) { r.renderer_->spec_order_ = bits; })

@@ -832,8 +832,8 @@ def test_speculative_tail_repair(hip, kill_frac, max_hits):
     assert same_bits(repaired["oi"], ref_hits[1]) and same_bits(repaired["nf"], ref_hits[2])
 
 
-@pytest.mark.parametrize("tail", [True, False])
-def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, tail):
+@pytest.mark.parametrize("tail,depth", [(True, 2), (True, 1), (False, 1)])
+def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, tail, depth):
     """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
     against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
     statistics identical.  Learning rate 0 keeps the weights -- and so both runs -- deterministic, while the statistics are
@@ -846,7 +846,7 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, ta
     R, NE, ITERS = 1024, 512, 16
     rng0 = np.random.default_rng(31)
     host_batches = []
-    for _ in range(ITERS + 1):
+    for _ in range(ITERS + 2):
         ro, rd, bounds, cam = fox_batch(st, rng0, R)
         host_batches.append([torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in (ro, rd, bounds, rng0.random((R, 3), dtype=F32), cam)])
     busy = torch.randn(4096, 4096, device=DEV)
@@ -861,17 +861,22 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, ta
         runner.n_edge_pts = NE
         runner.speculative_sampling = spec
         runner.tail_repair = tail  # (repair by list compaction + tail march, or by a second walk + march from the origin)
+        runner.speculation_depth = depth  # (2: the batch after next is handed over too and walked two steps ahead of its use)
         torch.manual_seed(11)  # the same noise / background / edge draws in both runs
         log = []
         nb = [t.to(DEV, non_blocking=True) for t in host_batches[0]]
+        nb2 = [t.to(DEV, non_blocking=True) for t in host_batches[1]]
         for it in range(ITERS):
             for t in runner.occupancy_buffers()[:2]:
                 t.fill_(0)
-            b = nb
-            for _ in range(8):  # the device is kept behind the host: the next batch's rays are still to be written when ...
+            b, nb = nb, nb2
+            for _ in range(8):  # the device is kept behind the host: the next batches' rays are still to be written when ...
                 busy = (busy @ busy).clamp_(-1.0, 1.0)
-            nb = [t.to(DEV, non_blocking=True) for t in host_batches[it + 1]]  # ... its (speculative) sampling is queued
-            s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+            nb2 = [t.to(DEV, non_blocking=True) for t in host_batches[it + 2]]  # ... their (speculative) sampling is queued
+            if depth == 2:
+                s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2], nb2[0], nb2[1])
+            else:
+                s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
             runner.flush()
             w, a, v = [N(t).copy() for t in runner.occupancy_buffers()]
             log.append(dict(n_samples=s["n_samples"], kept=runner.counters()["total_meaningful"], nodes=N(runner.tree_nodes()).copy(),

@@ -15,7 +15,7 @@ ap.add_argument("--factor", type=int, default=2)
 ap.add_argument("--overrides", nargs="*", default=[])
 ap.add_argument("--kernel-timing", action="store_true")
 ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 auto (default: the host's default)")
-ap.add_argument("--side-cus-sweep", default="", help="v1,v2,...: repeat the timed steps with the sampler's side stream confined to that many CUs (0: all)")
+ap.add_argument("--depth", type=int, default=-1, help="sampling pipeline depth of the timed steps (1 / 2; default: the host's)")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob")
 args = ap.parse_args()
 st = fox_data.load_state()
@@ -29,8 +29,12 @@ if args.speculation >= 0:
     runner.speculative_sampling = args.speculation
 R = max(16, runner.cur_batch_size())
 batches = [ds.rand_rays_data(R, 1) for _ in range(8)]
+if args.depth >= 1:
+    runner.speculation_depth = args.depth
 def step(i):
-    b, nb = batches[i % 8], batches[(i + 1) % 8]
+    b, nb, nb2 = batches[i % 8], batches[(i + 1) % 8], batches[(i + 2) % 8]
+    if runner.speculation_depth >= 2:
+        return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2], nb2[0], nb2[1])
     return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
 def timed(tag=""):
     for i in range(6):
@@ -52,12 +56,7 @@ def timed(tag=""):
         tm = runtime.host().ExpRunner.collect_kernel_timing()
         runtime.host().ExpRunner.disable_kernel_timing()
         print("    " + "  ".join("%s %.1f us" % (k, v[1] / max(v[0], 1) * 1e3) for k, v in sorted(tm.items())), flush=True)
-if args.side_cus_sweep:
-    for rep in range(2):
-        for v in args.side_cus_sweep.split(","):
-            runner.side_cus = int(v)
-            timed("side_cus=%s: " % v)
-elif args.env_sweep:
+if args.env_sweep:
     name, vals = args.env_sweep.split("=")
     for rep in range(2):
         for v in vals.split(","):
