@@ -252,6 +252,17 @@ def ray_march_strided_rec(n_rays, max_hits, sample_l, scale_by_dis, rays_o, rays
         "f2n_ray_march_strided_rec")
 
 
+def ray_march_persistent(n_rays, max_hits, n_blocks, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes,
+                         transes, counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, leaf_state, reached, order, counter):
+    """The strided march on n_blocks persistent one-wave blocks, rays sorted by leaf count (see f2n_abi.h)."""
+    _ck(lib().f2n_ray_march_persistent(_stream(), _i(n_rays), _i(max_hits), _i(n_blocks), _f(sample_l), _i(int(scale_by_dis)),
+                                       _p(rays_o, "f32"), _p(rays_d, "f32"), _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"),
+                                       _p(oct_nf, "f32"), _p(tree_nodes, "u8"), _p(transes, "u8"), _p(counts, "i32"),
+                                       _p(s_pts, "f32", True), _p(s_dt, "f32"), _p(s_t, "f32"), _p(s_anchors, "i32"),
+                                       _p(first_oct_dis, "f32"), _p(oct_trans, "i32", True), _p(leaf_state, "i32", True),
+                                       _p(reached, "i32", True), _p(order, "i32"), _p(counter, "i32")), "f2n_ray_march_persistent")
+
+
 def oct_list_repair(n_rays, max_hits, oct_se, oct_idx, oct_nf, oct_trans, total, died_at, spec_epoch, death_epoch, reached, repair_from,
                     n_repaired, n_full):
     _ck(lib().f2n_oct_list_repair(_stream(), _i(n_rays), _i(max_hits), _p(oct_se, "i32"), _p(oct_idx, "i32"), _p(oct_nf, "f32"),

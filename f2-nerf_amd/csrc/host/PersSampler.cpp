@@ -184,7 +184,18 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
   Tensor first_oct_dis = torch::empty({n_rays, 1}, DevF32());
   const bool tail = speculative && tail_repair_ && max_oct_intersect_per_ray_ <= 2048;
-  if (tail) {  // ... recording, per leaf-list entry, the state a repair can resume from (f2n_abi.h, "Tail repair")
+  if (speculative && march_blocks_ > 0 && max_oct_intersect_per_ray_ <= 2048) {  // small persistent grid, rays sorted by leaf count
+    Tensor order = torch::empty({n_rays + 1}, DevI32());  // [R] ray order + the group counter
+    if (tail) {
+      p.leaf_state = torch::empty({k_cap, 2}, DevI32());
+      p.reached = torch::empty({n_rays}, DevI32());
+    }
+    F2N_TIMED_CALL("ray_march", f2n_ray_march_persistent(st, n_rays, max_oct_intersect_per_ray_, march_blocks_, sample_l_, scale_by_dis_,
+                                   F32P(rays_o), F32P(rays_d), F32P(rays_noise), I32P(oct_se), I32P(oct_idx), F32P(oct_nf),
+                                   VoidP(oct.tree_nodes_gpu_), VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t),
+                                   I32P(s_anchors), F32P(first_oct_dis), I32P(oct_tr), tail ? VoidP(p.leaf_state) : nullptr,
+                                   tail ? I32P(p.reached) : nullptr, I32P(order), I32P(order) + n_rays));
+  } else if (tail) {  // ... recording, per leaf-list entry, the state a repair can resume from (f2n_abi.h, "Tail repair")
     p.leaf_state = torch::empty({k_cap, 2}, DevI32());
     p.reached = torch::empty({n_rays}, DevI32());
     F2N_TIMED_CALL("ray_march", f2n_ray_march_strided_rec(st, n_rays, max_oct_intersect_per_ray_, sample_l_, scale_by_dis_, F32P(rays_o),

@@ -118,6 +118,9 @@ class PersSampler : public PtsSampler {
   // speculative batches record resumable march states and are repaired by list compaction + a march of the tail behind the
   // first dead leaf (f2n_oct_list_repair / f2n_ray_march_repair_tail) instead of a second walk and march from the origin
   bool tail_repair_ = true;
+  // > 0: speculative batches are marched by this many persistent one-wave blocks, rays sorted by leaf count
+  // (f2n_ray_march_persistent): a small footprint underneath the main queue's kernels, for batches that have two steps to finish
+  int march_blocks_ = 0;
   bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
   // a FinishOctUpdate of the iteration in progress or of one of the `ahead` iterations behind it runs ProcOctree
   // (milestone / compact_freq, PersSampler.cu:605-614)

@@ -293,6 +293,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("tail_repair",  // speculative batches repaired by list compaction + a march of the tail behind the first dead leaf (A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_ = on; })
+      .def_property("march_blocks",  // > 0: speculative batches marched on that many persistent one-wave blocks (0: one block per 4 rays)
+                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_; },
+                    [](ExpRunner& r, int n) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_ = std::max(0, n); })
       .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })

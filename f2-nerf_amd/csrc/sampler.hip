@@ -481,35 +481,21 @@ __device__ __forceinline__ float f2n_row12_sum(float e) {
 // every iteration before the one that first reached p is untouched: a repair resumes from leaf_state[p] on the compacted list
 // instead of from the ray's origin (repair_from[ray] = p > 0; 0 = from the origin, < 0 = nothing to do) and produces, bit for
 // bit, what a fresh march over the new list produces.
-template <int MODE, bool TAIL = false>
-__global__ __launch_bounds__(64) void ray_march_kernel(
-    int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+template <int MODE, bool TAIL>
+__device__ __forceinline__ void f2n_march_ray(
+    const int ray, const int resume, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ noise_all, const int32_t* __restrict__ oct_start_end, const int32_t* __restrict__ oct_idx_all,
     const float* __restrict__ near_far_all, const F2nTreeNode* __restrict__ nodes, const F2nTransInfo* __restrict__ transes,
     const int32_t* __restrict__ pts_start_end, int32_t* __restrict__ pts_counts, float* __restrict__ pts,
     float* __restrict__ dirs, float* __restrict__ dts, float* __restrict__ ts, int32_t* __restrict__ anchors,
-    float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all, const int32_t* __restrict__ repair_flags,
-    const int32_t* __restrict__ death_epoch, int spec_epoch, uint2* __restrict__ leaf_state = nullptr,
-    int32_t* __restrict__ reached = nullptr) {
-  static_assert(!TAIL || MODE == 2, "resumable walks exist for the single-pass variant");
-  int resume = 0;  // TAIL repair: the list entry whose recorded state the walk resumes from (0: from the ray's origin)
-  if (MODE == 2 && repair_flags != nullptr) {  // repair of a speculative march: only the rays whose leaf list was redone
-    if (*death_epoch < spec_epoch) return;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (r >= n_rays) return;
-    if (TAIL) {
-      resume = repair_flags[r];  // (= repair_from of f2n_oct_list_repair)
-      if (resume < 0) return;
-    } else if (repair_flags[r] == 0) {
-      return;
-    }
-  }
+    float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all, uint2* __restrict__ leaf_state,
+    int32_t* __restrict__ reached) {
+  // (`ray` is uniform over the 16-lane row; resume: TAIL repair -- the list entry whose recorded state the walk resumes from,
+  // 0 = from the ray's origin)
   const int lane16 = threadIdx.x & 15, kq = lane16 & 3, quad = lane16 >> 2;
   const int grp = quad == 0 ? 0 : quad == 1 ? 2 : quad == 2 ? 3 : 1;  // Eigen group of this quad (see above)
   const int proj = 3 * grp + min(kq, 2);                               // lane 3 of a quad shadows projection 3g+2 (unused)
   const int j = lane16;                                                // emission role
-  const int ray = blockIdx.x * 4 + (threadIdx.x >> 4);
-  if (ray >= n_rays) return;  // whole rows leave together
   const int oct_s = oct_start_end[2 * ray], n_oct = oct_start_end[2 * ray + 1] - oct_s;
   constexpr bool FILL = MODE != 0;
   int max_n = F2N_MAX_SAMPLE_PER_RAY;
@@ -690,6 +676,110 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
   }
   if (MODE != 1 && j == 0) pts_counts[ray] = n;
   if (TAIL && reached != nullptr && j == 0) reached[ray] = n_oct > 0 ? oct_ptr_final : 0;
+}
+
+template <int MODE, bool TAIL = false>
+__global__ __launch_bounds__(64) void ray_march_kernel(
+    int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ noise_all, const int32_t* __restrict__ oct_start_end, const int32_t* __restrict__ oct_idx_all,
+    const float* __restrict__ near_far_all, const F2nTreeNode* __restrict__ nodes, const F2nTransInfo* __restrict__ transes,
+    const int32_t* __restrict__ pts_start_end, int32_t* __restrict__ pts_counts, float* __restrict__ pts,
+    float* __restrict__ dirs, float* __restrict__ dts, float* __restrict__ ts, int32_t* __restrict__ anchors,
+    float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all, const int32_t* __restrict__ repair_flags,
+    const int32_t* __restrict__ death_epoch, int spec_epoch, uint2* __restrict__ leaf_state = nullptr,
+    int32_t* __restrict__ reached = nullptr) {
+  static_assert(!TAIL || MODE == 2, "resumable walks exist for the single-pass variant");
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 4);
+  int resume = 0;
+  if (MODE == 2 && repair_flags != nullptr) {  // repair of a speculative march: only the rays whose leaf list was redone
+    if (*death_epoch < spec_epoch) return;
+    if (ray >= n_rays) return;
+    if (TAIL) {
+      resume = repair_flags[ray];  // (= repair_from of f2n_oct_list_repair)
+      if (resume < 0) return;
+    } else if (repair_flags[ray] == 0) {
+      return;
+    }
+  }
+  if (ray >= n_rays) return;  // whole rows leave together
+  f2n_march_ray<MODE, TAIL>(ray, resume, sample_l, scale_by_dis, rays_o, rays_d, noise_all, oct_start_end, oct_idx_all, near_far_all,
+                            nodes, transes, pts_start_end, pts_counts, pts, dirs, dts, ts, anchors, first_oct_dis, oct_trans_all,
+                            leaf_state, reached);
+}
+
+// The same march on a SMALL, persistent grid (speculative batches of the two-deep pipeline, round 4): `gridDim.x` one-wave
+// blocks take groups of four rays off a counter -- in the order of `order` (rays sorted by leaf count, longest first: the four
+// rows of a wave then hold rays of similar length, and the longest chains start first) -- until the batch is done.  Why: the
+// ordinary launch puts ~3.4 march waves of 96 registers on every SIMD of the chip for the first ~100 us of a march, and the
+// occupancy-bound kernels of the main queue that run meanwhile (field_bwd: 23 us alone, 95 us underneath the march;
+// shade_bwd, field_shade_fwd, compositing) lose most of their resident waves to them.  A batch that is sampled two steps
+// ahead of its use has ~1.5 ms to finish: a few hundred waves do it, one per CU or two.  Same per-ray code, same bits.
+template <bool TAIL>
+__global__ __launch_bounds__(64) void ray_march_persistent_kernel(
+    int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ noise_all, const int32_t* __restrict__ oct_start_end, const int32_t* __restrict__ oct_idx_all,
+    const float* __restrict__ near_far_all, const F2nTreeNode* __restrict__ nodes, const F2nTransInfo* __restrict__ transes,
+    int32_t* __restrict__ pts_counts, float* __restrict__ pts, float* __restrict__ dts, float* __restrict__ ts,
+    int32_t* __restrict__ anchors, float* __restrict__ first_oct_dis, const int32_t* __restrict__ oct_trans_all,
+    uint2* __restrict__ leaf_state, int32_t* __restrict__ reached, const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
+  const int n_groups = (n_rays + 3) >> 2;
+  for (;;) {
+    int g = 0;
+    if ((threadIdx.x & 63) == 0) g = atomicAdd(counter, 1);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= n_groups) break;
+    const int slot = g * 4 + (threadIdx.x >> 4);
+    if (slot < n_rays) {
+      const int ray = order != nullptr ? order[slot] : slot;
+      f2n_march_ray<2, TAIL>(ray, 0, sample_l, scale_by_dis, rays_o, rays_d, noise_all, oct_start_end, oct_idx_all, near_far_all, nodes,
+                             transes, nullptr, pts_counts, pts, nullptr, dts, ts, anchors, first_oct_dis, oct_trans_all, leaf_state,
+                             reached);
+    }
+  }
+}
+
+// Rays ordered by leaf count, longest list first (counting sort, one block; the order among rays of equal count is whatever the
+// LDS counters hand out: it only decides which wave marches a ray, not what the march produces).
+__global__ __launch_bounds__(1024) void sort_rays_by_hits_kernel(int n_rays, int max_hits, const int32_t* __restrict__ oct_start_end,
+                                                                 int32_t* __restrict__ order, int32_t* __restrict__ counter) {
+  __shared__ int s_bin[2048 + 2];  // bin b = rays with max_hits - count == b (so that ascending bins are descending counts)
+  __shared__ int s_wave[16];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < 2048 + 2; b += 1024) s_bin[b] = 0;
+  if (tid == 0 && counter != nullptr) *counter = 0;  // (the persistent march's group counter)
+  __syncthreads();
+  for (int r = tid; r < n_rays; r += 1024) {
+    const int k = min(max(oct_start_end[2 * r + 1] - oct_start_end[2 * r], 0), max_hits);
+    atomicAdd(&s_bin[max_hits - k], 1);
+  }
+  __syncthreads();
+  {  // exclusive prefix over the 2050 bins: two bins per thread, wave scans, wave carries
+    const int a = s_bin[2 * tid], b = s_bin[2 * tid + 1];
+    int incl = a + b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if ((tid & 63) >= off) incl += up;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    int carry = 0;
+    for (int w = 0; w < (tid >> 6); w++) carry += s_wave[w];
+    const int excl = carry + incl - (a + b);
+    s_bin[2 * tid] = excl;
+    s_bin[2 * tid + 1] = excl + a;
+    if (tid == 1023) {  // the two bins behind the last pair (max_hits = 2048: bins 2048, 2049)
+      const int t0 = s_bin[2048], t1 = s_bin[2049];
+      s_bin[2048] = carry + incl;
+      s_bin[2049] = carry + incl + t0;
+      (void) t1;
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < n_rays; r += 1024) {
+    const int k = min(max(oct_start_end[2 * r + 1] - oct_start_end[2 * r], 0), max_hits);
+    order[atomicAdd(&s_bin[max_hits - k], 1)] = r;
+  }
 }
 
 // Strided slots -> ray-ordered compact SampleResultFlex arrays (one wave per ray, coalesced copies).  When the march
@@ -1361,6 +1451,32 @@ int f2n_ray_march_strided_rec(void* stream, int n_rays, int max_hits, float samp
                      (hipStream_t) stream, n_rays, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx,
                      oct_near_far, (const F2nTreeNode*) tree_nodes, (const F2nTransInfo*) transes, nullptr, pts_counts, s_pts,
                      nullptr, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, nullptr, nullptr, 0, (uint2*) leaf_state, reached);
+  return f2n_launch_status();
+}
+
+int f2n_ray_march_persistent(void* stream, int n_rays, int max_hits, int n_blocks, float sample_l, int scale_by_dis, const float* rays_o,
+                             const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                             const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
+                             float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
+                             void* leaf_state, int32_t* reached, int32_t* order, int32_t* counter) {
+  if (n_rays < 0 || n_blocks < 1 || max_hits < 1 || max_hits > 2048 || order == nullptr || counter == nullptr ||
+      (leaf_state == nullptr) != (reached == nullptr))
+    return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(sort_rays_by_hits_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, n_rays, max_hits, oct_start_end, order,
+                     counter);
+  const int blocks = min(n_blocks, f2n_div_up(n_rays, 4));
+  if (leaf_state != nullptr) {
+    hipLaunchKernelGGL(ray_march_persistent_kernel<true>, dim3(blocks), dim3(64), 0, (hipStream_t) stream, n_rays, sample_l,
+                       scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx, oct_near_far, (const F2nTreeNode*) tree_nodes,
+                       (const F2nTransInfo*) transes, pts_counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans,
+                       (uint2*) leaf_state, reached, order, counter);
+  } else {
+    hipLaunchKernelGGL(ray_march_persistent_kernel<false>, dim3(blocks), dim3(64), 0, (hipStream_t) stream, n_rays, sample_l,
+                       scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx, oct_near_far, (const F2nTreeNode*) tree_nodes,
+                       (const F2nTransInfo*) transes, pts_counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, nullptr,
+                       nullptr, order, counter);
+  }
   return f2n_launch_status();
 }
 

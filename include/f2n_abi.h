@@ -279,6 +279,16 @@ int f2n_ray_march_strided_rec(void* stream, int n_rays, int max_hits, float samp
                               const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
                               float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
                               void* leaf_state /*[R * max_hits] 8-byte records*/, int32_t* reached /*[R]*/);
+/* f2n_ray_march_strided[_rec] on a small persistent grid: n_blocks one-wave blocks take groups of four rays off counter[0], rays
+ * ordered by leaf count, longest first (order[R]: scratch, filled here; counter[1]: scratch, zeroed here).  For batches that are
+ * sampled well ahead of their use (two-deep pipeline): a few hundred resident waves instead of R / 4, so that the occupancy-bound
+ * kernels the march runs underneath keep their wave slots.  leaf_state / reached both NULL: no recording.  Same slots, same
+ * bits (tests/test_gpu_scale.py::test_persistent_march). */
+int f2n_ray_march_persistent(void* stream, int n_rays, int max_hits, int n_blocks, float sample_l, int scale_by_dis, const float* rays_o,
+                             const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
+                             const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
+                             float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
+                             void* leaf_state /*or NULL*/, int32_t* reached /*or NULL*/, int32_t* order /*[R]*/, int32_t* counter /*[1]*/);
 int f2n_oct_list_repair(void* stream, int n_rays, int max_hits, int32_t* oct_start_end, int32_t* oct_idx, float* oct_near_far,
                         int32_t* oct_trans /*or NULL*/, int32_t* total, const int32_t* died_at, int spec_epoch,
                         const int32_t* death_epoch, const int32_t* reached, int32_t* repair_from /*[R]*/,

@@ -833,6 +833,46 @@ def test_speculative_tail_repair(hip, kill_frac, max_hits):
 
 
 @pytest.mark.parametrize("tail,depth", [(True, 2), (True, 1), (False, 1)])
+@pytest.mark.parametrize("n_blocks,record", [(64, True), (512, False)])
+def test_persistent_march(hip, n_blocks, record):
+    """f2n_ray_march_persistent (a few persistent one-wave blocks, rays sorted by leaf count, groups of four off a counter) fills
+    the same slots, counts and -- when recording -- the same resumable states as one block per four rays."""
+    z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
+    n = z["rays_o"].shape[0]
+    rd_np = oc.normalize_dirs(z["rays_d"])
+    rng = np.random.default_rng(3)
+    noise = (((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(1.)).astype(F32)
+    tn, tr, so = T(z["tree_nodes"].copy()), T(z["pers_trans"]), T(z["search_order"])
+    ro, rd, nz = T(z["rays_o"]), T(rd_np), T(noise)
+    n_nodes = z["tree_nodes"].size // 64
+    cb = torch.zeros(n_nodes * 8 * 32, dtype=torch.uint8, device=DEV)
+    hip.oct_build_child_blocks(n_nodes, tn, cb)
+    want = _strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n)
+    ls_w = torch.full((n * 1024, 2), -1, dtype=torch.int32, device=DEV); re_w = torch.full((n,), -9, dtype=torch.int32, device=DEV)
+    if record:
+        hip.ray_march_strided_rec(n, 1024, 1. / 256., True, ro, rd, nz, want["se"], want["oi"], want["nf"], tn, tr, want["cnt"], None,
+                                  want["s_dt"], want["s_t"], want["s_an"], want["fod"], want["otr"], ls_w, re_w)
+    got = dict(want)
+    for k in ("cnt", "s_dt", "s_t", "s_an", "fod"):
+        got[k] = torch.zeros_like(want[k])
+    ls_g = torch.full((n * 1024, 2), -1, dtype=torch.int32, device=DEV); re_g = torch.full((n,), -9, dtype=torch.int32, device=DEV)
+    order = torch.zeros(n, dtype=torch.int32, device=DEV); counter = torch.full((1,), 12345, dtype=torch.int32, device=DEV)
+    hip.ray_march_persistent(n, 1024, n_blocks, 1. / 256., True, ro, rd, nz, got["se"], got["oi"], got["nf"], tn, tr, got["cnt"], None,
+                             got["s_dt"], got["s_t"], got["s_an"], got["fod"], got["otr"], ls_g if record else None,
+                             re_g if record else None, order, counter)
+    a, b = _filled_prefixes(want, n), _filled_prefixes(got, n)
+    for k in a:
+        assert same_bits(a[k], b[k]), k
+    o = N(order)
+    assert (np.sort(o) == np.arange(n)).all()                    # a permutation of the rays ...
+    k_per_ray = a["se"][:, 1] - a["se"][:, 0]
+    assert (np.diff(k_per_ray[o]) <= 0).all()                    # ... longest leaf list first
+    assert int(counter.item()) >= (n + 3) // 4                   # every group of four was handed out
+    if record:
+        assert (N(re_g) == N(re_w)).all()
+        assert (N(ls_g) == N(ls_w)).all()                        # (untouched entries keep the fill value on both sides)
+
+
 def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, tail, depth):
     """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
     against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
@@ -862,6 +902,7 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, ta
         runner.speculative_sampling = spec
         runner.tail_repair = tail  # (repair by list compaction + tail march, or by a second walk + march from the origin)
         runner.speculation_depth = depth  # (2: the batch after next is handed over too and walked two steps ahead of its use)
+        runner.march_blocks = 96 if depth == 2 else 0  # (... there on a small persistent grid)
         torch.manual_seed(11)  # the same noise / background / edge draws in both runs
         log = []
         nb = [t.to(DEV, non_blocking=True) for t in host_batches[0]]

@@ -15,6 +15,7 @@ ap.add_argument("--factor", type=int, default=2)
 ap.add_argument("--overrides", nargs="*", default=[])
 ap.add_argument("--kernel-timing", action="store_true")
 ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 auto (default: the host's default)")
+ap.add_argument("--march-blocks-sweep", default="", help="v1,v2,...: repeat the timed steps with the speculative march on that many persistent blocks (0: classic)")
 ap.add_argument("--depth", type=int, default=-1, help="sampling pipeline depth of the timed steps (1 / 2; default: the host's)")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob")
 args = ap.parse_args()
@@ -56,7 +57,12 @@ def timed(tag=""):
         tm = runtime.host().ExpRunner.collect_kernel_timing()
         runtime.host().ExpRunner.disable_kernel_timing()
         print("    " + "  ".join("%s %.1f us" % (k, v[1] / max(v[0], 1) * 1e3) for k, v in sorted(tm.items())), flush=True)
-if args.env_sweep:
+if args.march_blocks_sweep:
+    for rep in range(2):
+        for v in args.march_blocks_sweep.split(","):
+            runner.march_blocks = int(v)
+            timed("march_blocks=%s: " % v)
+elif args.env_sweep:
     name, vals = args.env_sweep.split("=")
     for rep in range(2):
         for v in vals.split(","):
