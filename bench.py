@@ -214,6 +214,8 @@ def converged_leg(args, st, dev):
         runner.speculation_order = args.speculation_order
     if args.speculation_depth >= 1:
         runner.speculation_depth = args.speculation_depth
+    if args.march_blocks >= 0:
+        runner.march_blocks = args.march_blocks
     torch.manual_seed(2022)
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
@@ -325,6 +327,8 @@ def main():
                     "default of the host), on / off = A/B (profiles/r03_speculation_experiments.txt)")
     ap.add_argument("--speculation-depth", type=int, default=-1, help="A/B: batches sampled ahead of their step (1 or 2: Renderer.h "
                     "spec_depth_); -1 = host default")
+    ap.add_argument("--march-blocks", type=int, default=-1, help="A/B: > 0 marches speculative batches on that many persistent one-wave "
+                    "blocks (rays sorted by leaf count), 0 on one block per four rays; -1 = host default")
     ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
                     "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
     ap.add_argument("--lds-octree", type=int, default=-1, help="A/B: 0 walks the octree through the L2s even when its interior nodes "
@@ -387,6 +391,8 @@ def main():
         runner.speculation_order = args.speculation_order
     if args.speculation_depth >= 1:
         runner.speculation_depth = args.speculation_depth
+    if args.march_blocks >= 0:
+        runner.march_blocks = args.march_blocks
     if args.lds_octree >= 0:
         runner.lds_octree = bool(args.lds_octree)
     if args.optimistic_pack >= 0:

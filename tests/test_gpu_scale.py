@@ -873,6 +873,7 @@ def test_persistent_march(hip, n_blocks, record):
         assert (N(ls_g) == N(ls_w)).all()                        # (untouched entries keep the fill value on both sides)
 
 
+@pytest.mark.parametrize("tail,depth", [(True, 2), (True, 1), (False, 1)])
 def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, tail, depth):
     """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
     against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
