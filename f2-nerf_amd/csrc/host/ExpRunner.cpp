@@ -576,9 +576,10 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   auto draw = [&]() { return dataset.RandRaysData(std::max(16, CurBatchSize()), sets); };
   // The batches of the next iteration AND (two-deep sampling pipeline, Renderer::next2_batch_) of the one after it are drawn
   // ahead: one draw per iteration, right before the step, as before -- but the adaptive ray count of a batch now comes from the
-  // meaningful-samples average as it stood TWO steps before the batch is used (one step with spec_depth_ 1; the reference:
-  // none, ExpRunner.cpp:86), because that is when its rays have to exist.
-  const bool two_deep = renderer_->spec_depth_ >= 2 && !sync_.Installed();
+  // meaningful-samples average as it stood TWO steps before the batch is used (the reference: none, ExpRunner.cpp:86), because
+  // that is when its rays have to exist.  Always two ahead, whatever the renderer then does with the second batch: the sequence
+  // of batches does not depend on a scheduling decision.
+  const bool two_deep = !sync_.Installed();  // (whether the batch after next is BEGUN two steps ahead is the renderer's decision)
   std::deque<decltype(draw())> ahead;
   ahead.push_back(draw());
   last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;

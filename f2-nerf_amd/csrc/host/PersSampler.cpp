@@ -184,7 +184,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
   Tensor first_oct_dis = torch::empty({n_rays, 1}, DevF32());
   const bool tail = speculative && tail_repair_ && max_oct_intersect_per_ray_ <= 2048;
-  if (speculative && march_blocks_ > 0 && max_oct_intersect_per_ray_ <= 2048) {  // small persistent grid, rays sorted by leaf count
+  if (speculative && persistent_march_ && march_blocks_ > 0 && max_oct_intersect_per_ray_ <= 2048) {  // small persistent grid, rays sorted by leaf count
     Tensor order = torch::empty({n_rays + 1}, DevI32());  // [R] ray order + the group counter
     if (tail) {
       p.leaf_state = torch::empty({k_cap, 2}, DevI32());

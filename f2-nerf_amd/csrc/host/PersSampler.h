@@ -120,7 +120,9 @@ class PersSampler : public PtsSampler {
   bool tail_repair_ = true;
   // > 0: speculative batches are marched by this many persistent one-wave blocks, rays sorted by leaf count
   // (f2n_ray_march_persistent): a small footprint underneath the main queue's kernels, for batches that have two steps to finish
-  int march_blocks_ = 0;
+  int march_blocks_ = 512;
+  bool persistent_march_ = false;  // set by the Renderer around the BeginSamples of a batch that is begun two steps ahead
+  int LdsWalkMaxInterior() const { return lds_octree_ ? f2n_oct_lds_max_interior() : 0; }
   bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
   // a FinishOctUpdate of the iteration in progress or of one of the `ahead` iterations behind it runs ProcOctree
   // (milestone / compact_freq, PersSampler.cu:605-614)

@@ -469,21 +469,31 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   // Which batches: the next step's, unless it is in flight already (two-deep pipeline: it was begun one step ago), and the
   // one behind it (next2_batch_, spec_depth_ >= 2).  A batch begun now is void if a ProcOctree runs before it is consumed --
   // in this step's update for the next batch, in this or the next step's for the one behind it -- so it is not begun then.
-  const bool spec_now = speculative_sampling_ == 1 || (speculative_sampling_ == 2 && ps->pers_octree_->QuietEpochs() >= kSpecQuietEpochs);
-  const bool spec_ok = train && async_count && dp_world_ <= 1 && spec_now && n_all_pts > 0;
+  // WHEN (measured, profiles/r04_pipeline_experiments.txt): a batch begun one step ahead pays while its chain fits underneath
+  // the step's gather -- a young scene: the walk runs out of LDS, rays are of one length -- and while no leaf dies (mode 2);
+  // a batch begun TWO steps ahead, marched by a small persistent grid, pays once the tree has outgrown the LDS walk (the
+  // chain is then as long as the step) and costs on a young scene (it spreads the march from underneath the L2-bound gather
+  // over the VALU-bound kernels of the whole step: fresh step 1.13 -> 1.17-1.24 ms).
+  const bool quiet = ps->pers_octree_->QuietEpochs() >= kSpecQuietEpochs;
+  const bool big_tree = ps->pers_octree_->n_interior_ > ps->LdsWalkMaxInterior();
+  const bool two_deep = spec_depth_ >= 3 || (spec_depth_ == 2 && big_tree);
+  const bool spec_base = train && async_count && dp_world_ <= 1 && speculative_sampling_ != 0 && n_all_pts > 0;
   auto spec_begin = [&](const NextBatch& nb, int ahead) {
     if (!nb.valid || FindPending(nb.rays_o, nb.rays_d) >= 0) return;
     const int slot = FreePendingSlot();
-    if (!spec_ok || slot < 0 || ps->MaintenanceDue(ahead)) {
+    const bool now = ahead >= 1 ? two_deep : (speculative_sampling_ == 1 || quiet || two_deep);
+    if (!spec_base || !now || slot < 0 || ps->MaintenanceDue(ahead)) {
       n_spec_fallback_++;
       return;
     }
+    ps->persistent_march_ = ahead >= 1;  // (two steps to finish in: a few hundred resident waves do it)
     PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness);
+    ps->persistent_march_ = false;
     n_speculative_++;
   };
   if (train) {
     spec_begin(next_batch_, 0);
-    if (spec_depth_ >= 2) spec_begin(next2_batch_, 1);
+    spec_begin(next2_batch_, 1);
   }
   spec_start_recorded_ = false;
   if (train) total_all_pts_ += n_all_pts;

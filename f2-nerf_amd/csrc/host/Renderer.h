@@ -139,6 +139,8 @@ class Renderer : public Pipe {
   // the main queue waits for it.  With next2_batch_ handed over as well, batch k+2 is walked and marched during step k (on the
   // other side stream) and repaired + packed behind step k+1's stat update against every death since: its chain has two steps,
   // and the only sampler work between a stat update and the next step's pre-pass is the tail repair + pack of the batch in front.
+  // 1: never; 2: once the octree has outgrown the LDS-resident walk (PersSampler::LdsWalkMaxInterior: the chain is then as long
+  // as a step); 3: always.
   int spec_depth_ = 2;
   int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
   void PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness);

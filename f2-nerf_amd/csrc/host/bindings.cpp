@@ -299,9 +299,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })
-      .def_property("speculation_depth",  // 2: ExpRunner::Train hands the batch after next over as well (two-deep sampling pipeline); 1: one
+      .def_property("speculation_depth",  // the batch after next is begun two steps ahead: 1 never, 2 once the octree has outgrown the LDS walk, 3 always
                     [](ExpRunner& r) { return r.renderer_->spec_depth_; },
-                    [](ExpRunner& r, int d) { r.FinishPending(); r.renderer_->DropPendingSamples(); r.renderer_->spec_depth_ = d >= 2 ? 2 : 1; })
+                    [](ExpRunner& r, int d) { r.FinishPending(); r.renderer_->DropPendingSamples(); r.renderer_->spec_depth_ = std::max(1, std::min(3, d)); })
       .def_property("speculation_order",  // 1: the speculative sampler starts where the step begins, 0: behind its draws (Renderer.h)
                     [](ExpRunner& r) { return r.renderer_->spec_order_; },
                     [](ExpRunner& r, int bits) { r.renderer_->spec_order_ = bits; })
