@@ -599,6 +599,16 @@ def train_loss(n_rays, pred, gt, disparity, sampled_var, n_edge, feat_dim, edge_
                              _p(dvar, "f32", True), _p(dedge_feats, "f32", True)), "f2n_train_loss")
 
 
+def composite_train(n_rays, se, f0, f0_stride, dt, t, rgb, bg, gt, var_w, disp_w, tv_w, gs_progress, n_edge, feat_dim, edge_feats,
+                    dedge_feats, colors, weights, drgb, df0, df0_stride, out_losses, defer_reduce=False):
+    """composite_fwd + train_loss + composite_bwd in one launch (include/f2n_abi.h)."""
+    _ck(lib().f2n_composite_train(_stream(), _i(n_rays), _p(se, "i32"), _p(f0, "f32"), _i(f0_stride), _p(dt, "f32"), _p(t, "f32"),
+                                  _p(rgb, "f32"), _p(bg, "f32"), _p(gt, "f32"), _f(var_w), _f(disp_w), _f(tv_w), _f(gs_progress),
+                                  _i(n_edge), _i(feat_dim), _p(edge_feats, "f32", True), _p(dedge_feats, "f32", True),
+                                  _p(colors, "f32"), _p(weights, "f32"), _p(drgb, "f32"), _p(df0, "f32"), _i(df0_stride),
+                                  _p(out_losses, "f32"), _i(1 if defer_reduce else 0)), "f2n_composite_train")
+
+
 def nonfinite_flags(n_a, a, n_b, b, flags, mirror=None):
     _ck(lib().f2n_nonfinite_flags_ex(_stream(), _i(n_a), _p(a, "f32", True), _i(n_b), _p(b, "f32", True), _p(flags, "i32"),
                                      _mapped(mirror)), "f2n_nonfinite_flags_ex")

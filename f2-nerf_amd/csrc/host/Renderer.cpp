@@ -798,25 +798,35 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
     F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(st, n_kept, F32P(feat), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
                            fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(rgb), VoidP(shade_x)));
   }
-  Tensor colors = torch::empty({n_rays, 3}, DevF32()), disparity = torch::empty({n_rays}, DevF32());
-  Tensor depth = torch::empty({n_rays}, DevF32()), weights = torch::empty({std::max(n_kept, 1)}, DevF32());
+  Tensor colors = torch::empty({n_rays, 3}, DevF32());
+  Tensor weights = torch::empty({std::max(n_kept, 1)}, DevF32());
   Tensor bg = fr.bg_color.contiguous();
-  Tensor var = torch::empty({n_rays}, DevF32());
-  F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
-                             F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights), F32P(var)));  // (+ WeightVarLoss fwd)
-
-  // ---- loss and its gradients; the TV gradient goes straight into the edge rows of dfeat ----
   Tensor dfeat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
-  Tensor dcolors = torch::empty({n_rays, 3}, DevF32()), ddisp = torch::empty({n_rays}, DevF32()), dvar = torch::empty({n_rays}, DevF32());
-  F2N_TIMED_CALL("train_loss", f2n_train_loss(st, n_rays, F32P(colors), F32P(gt), F32P(disparity), F32P(var), n_edge, F2N_MLP_OUT_PAD,
-                          F32P(feat) + F2N_MLP_OUT_PAD * eo, var_w, disp_w, tv_w, F32P(out.losses), F32P(dcolors),
-                          F32P(ddisp), F32P(dvar), F32P(dfeat) + F2N_MLP_OUT_PAD * eo));
+  Tensor drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());  // (WeightVarLoss backward rides inside the compositing backward)
+  if (fuse_composite_ && fr.dyn) {
+    // ---- compositing forward, loss, compositing backward: one launch (f2n_composite_train); the TV gradient goes straight
+    // into the edge rows of dfeat, the loss values are completed by the step's deferred reduction below ----
+    F2N_TIMED_CALL("composite_train", f2n_composite_train(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
+                                 F32P(bg), F32P(gt), var_w, disp_w, tv_w, gdp->gradient_scaling_progress_, n_edge, F2N_MLP_OUT_PAD,
+                                 n_edge > 0 ? F32P(feat) + F2N_MLP_OUT_PAD * eo : nullptr, n_edge > 0 ? F32P(dfeat) + F2N_MLP_OUT_PAD * eo : nullptr,
+                                 F32P(colors), F32P(weights), F32P(drgb), F32P(df0c), 1, F32P(out.losses), /*defer_reduce=*/1));
+  } else {
+    Tensor disparity = torch::empty({n_rays}, DevF32()), depth = torch::empty({n_rays}, DevF32());
+    Tensor var = torch::empty({n_rays}, DevF32());
+    F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
+                               F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights), F32P(var)));  // (+ WeightVarLoss fwd)
 
-  // ---- backward ----
-  Tensor drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());  // (WeightVarLoss backward rides inside composite_bwd)
-  F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb), F32P(bg),
-                             F32P(dcolors), F32P(ddisp), nullptr, nullptr, gdp->gradient_scaling_progress_, F32P(drgb),
-                             F32P(df0c), 1, F32P(weights), F32P(dvar)));
+    // ---- loss and its gradients; the TV gradient goes straight into the edge rows of dfeat ----
+    Tensor dcolors = torch::empty({n_rays, 3}, DevF32()), ddisp = torch::empty({n_rays}, DevF32()), dvar = torch::empty({n_rays}, DevF32());
+    F2N_TIMED_CALL("train_loss", f2n_train_loss(st, n_rays, F32P(colors), F32P(gt), F32P(disparity), F32P(var), n_edge, F2N_MLP_OUT_PAD,
+                            F32P(feat) + F2N_MLP_OUT_PAD * eo, var_w, disp_w, tv_w, F32P(out.losses), F32P(dcolors),
+                            F32P(ddisp), F32P(dvar), F32P(dfeat) + F2N_MLP_OUT_PAD * eo));
+
+    // ---- backward ----
+    F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb), F32P(bg),
+                               F32P(dcolors), F32P(ddisp), nullptr, nullptr, gdp->gradient_scaling_progress_, F32P(drgb),
+                               F32P(df0c), 1, F32P(weights), F32P(dvar)));
+  }
   F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd_dyn(st, n_kept, n_dev, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
                          VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat) + F2N_MLP_OUT_PAD * so,
                          F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,

@@ -162,6 +162,9 @@ class Renderer : public Pipe {
   at::cuda::CUDAEvent dp_count_ev_;
   float KeptPerRayForEma(int n_kept_local, int n_rays);
   bool async_count_ = false;        // set by ExpRunner::TrainStep for streaming steps
+  // streaming steps: compositing forward + loss + compositing backward as ONE launch (f2n_composite_train); false: the three
+  // launches it replaces (what tests compare it with)
+  bool fuse_composite_ = true;
   bool count_pending_ = false;
   int pending_count_rays_ = 0;
   int64_t total_kept_pts_ = 0, total_all_pts_ = 0;  // running totals over training-mode calls (resolved counts only)

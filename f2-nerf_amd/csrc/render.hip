@@ -341,6 +341,245 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int n_rays, const in
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Compositing forward + the loss of ExpRunner::Train + compositing backward in ONE launch (round 4; the streaming training
+// step).  Renderer.cpp:196-208 / FlexOps.cu:55-93 forward, ExpRunner.cpp:95-120, then the backward chain of composite_bwd_kernel.
+// Everything between a ray's colour and the gradient of its samples is per ray: d loss / d colour = (pred - gt) / sqrt(.) / 3R,
+// d / d disparity, d / d weight-variance are element-wise functions of that ray's own outputs (the means' denominators are
+// known on the host), so the row that has just walked a ray forward turns around and walks it backward -- with the totals the
+// backward's first walk used to rebuild (cumulative density, depth numerator, WeightVar statistics) still in its registers.
+// Replaces composite_fwd -> train_loss (+ its finalisation) -> composite_bwd: three dependent launches of the step's main
+// queue and one re-walk of every ray.  Arithmetic and order of every sum are those of the three kernels: colours, weights,
+// drgb, df0 are bit-identical (tests/test_gpu_parity.py::test_composite_train_equals_three_launches).
+// The loss VALUES (reported only) leave as per-block partial sums of pre-scaled terms, folded by the step's deferred
+// reduction (f2n_reduce_deferred) in a fixed order: out_losses = {loss, colour, var, disparity, tv, mse, 0, 0}.
+// Blocks behind the ray blocks (tv_blocks of them) take the TV term over the edge features (ExpRunner.cpp:101) and its gradient.
+// ---------------------------------------------------------------------------------------------------
+#define F2N_CT_TERMS 8
+__global__ __launch_bounds__(256) void composite_train_kernel(
+    int n_rays, const int32_t* __restrict__ se, const float* __restrict__ f0, int f0_stride, const float* __restrict__ dt,
+    const float* __restrict__ t, const float* __restrict__ rgb, const float* __restrict__ bg, const float* __restrict__ gt,
+    float var_w, float disp_w, float tv_w, float gs_progress, int n_edge, int feat_dim, const float* __restrict__ edge,
+    float* __restrict__ dedge, float* __restrict__ colors, float* __restrict__ weights, float* __restrict__ drgb,
+    float* __restrict__ df0, int df0_stride, float* __restrict__ partials, float* __restrict__ out_losses, int ray_blocks) {
+  F2N_RAISE_PRIO();
+  __shared__ float s_terms[F2N_ROW_RAYS_PER_BLOCK][4];
+  __shared__ float s_tv[256];
+  if (blockIdx.x == 0 && threadIdx.x < F2N_CT_TERMS) out_losses[threadIdx.x] = 0.f;  // (the deferred reduction ADDS the partial sums)
+  if ((int) blockIdx.x >= ray_blocks) {
+    // ---- TV term: mean (edge_feat[:,0,:] - edge_feat[:,1,:])^2 and its gradient, element-wise ----
+    const int n_tv = n_edge * feat_dim;
+    const float inv_tv = 1.f / (float) max(n_tv, 1);
+    const int tvb = gridDim.x - ray_blocks;
+    float acc = 0.f;
+    for (int i = (blockIdx.x - ray_blocks) * 256 + threadIdx.x; i < n_tv; i += tvb * 256) {
+      const int e = i / feat_dim, f = i - e * feat_dim;
+      const size_t i0 = ((size_t) 2 * e) * feat_dim + f, i1 = i0 + feat_dim;
+      const float d = edge[i0] - edge[i1];
+      acc += d * d;
+      if (dedge != nullptr) {
+        const float g = tv_w * 2.f * d * inv_tv;
+        dedge[i0] = g;
+        dedge[i1] = -g;
+      }
+    }
+    s_tv[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int) threadIdx.x < off) s_tv[threadIdx.x] += s_tv[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x < F2N_CT_TERMS) {
+      const float tv = s_tv[0] * inv_tv;
+      partials[(size_t) blockIdx.x * F2N_CT_TERMS + threadIdx.x] = threadIdx.x == 0 ? tv * tv_w : threadIdx.x == 4 ? tv : 0.f;
+    }
+    return;
+  }
+  const int c = threadIdx.x & 15, row = threadIdx.x >> 4;
+  const int ray = blockIdx.x * F2N_ROW_RAYS_PER_BLOCK + row;
+  const bool live = ray < n_rays;
+  int s = 0, e = 0;
+  if (live) {
+    s = se[2 * ray];
+    e = se[2 * ray + 1];
+  }
+  // ================= forward walk (composite_fwd_kernel, with the WeightVar statistics riding along) =================
+  float acc = 0.f, col[3] = {0.f, 0.f, 0.f}, disp = 0.f, dep = 0.f, wv_m = 0.f, wv_ws = 1e-6f;
+  {
+    struct In {
+      float f0, dt, t, c0, c1, c2;
+    };
+    auto fetch = [&](int i) {
+      In r;
+      r.f0 = f0[(size_t) i * f0_stride];
+      r.dt = dt[i];
+      r.t = t[i];
+      r.c0 = rgb[3 * (size_t) i];
+      r.c1 = rgb[3 * (size_t) i + 1];
+      r.c2 = rgb[3 * (size_t) i + 2];
+      return r;
+    };
+    In nxt = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (s < e) nxt = fetch(min(s + c, e - 1));
+    for (int base = s; base < e; base += 16) {
+      const int i = base + c;
+      const bool in = i < e;
+      const In cur = nxt;
+      if (base + 16 < e) nxt = fetch(min(i + 16, e - 1));
+      float sec = 0.f, tt = 1.f, cr[3] = {0.f, 0.f, 0.f};
+      if (in) {
+        sec = expf(cur.f0 - F2N_DENSITY_SHIFT) * cur.dt;
+        tt = cur.t + F2N_T_BIAS;
+        cr[0] = cur.c0; cr[1] = cur.c1; cr[2] = cur.c2;
+      }
+      const float alpha = 1.f - expf(-sec);
+      const float incl = f2n_row_seq_scan(sec, acc, c);
+      const float trans = expf(-f2n_row_exclusive(incl, acc, c));
+      acc = f2n_row_last(incl);
+      const float w = in ? trans * alpha : 0.f;
+      if (in) weights[i] = w;
+#pragma unroll
+      for (int k = 0; k < 3; k++) col[k] = f2n_row_last(f2n_row_seq_scan(w * cr[k], col[k], c));
+      disp = f2n_row_last(f2n_row_seq_scan(w / tt, disp, c));
+      dep = f2n_row_last(f2n_row_seq_scan(w * tt, dep, c));
+      wv_m = f2n_row_last(f2n_row_seq_scan(w * ((float) (i - s) / 16.f), wv_m, c));
+      wv_ws = f2n_row_last(f2n_row_seq_scan(w, wv_ws, c));
+    }
+  }
+  const float total = acc;
+  const float last_trans = expf(-total);
+  float bgc[3] = {0.f, 0.f, 0.f}, gtc[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      bgc[k] = bg[3 * ray + k];
+      gtc[k] = gt[3 * ray + k];
+    }
+  }
+  float pred[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pred[k] = col[k] + last_trans * bgc[k];
+  if (live && c < 3) colors[3 * ray + c] = c == 0 ? pred[0] : c == 1 ? pred[1] : pred[2];
+  // WeightVarLoss forward (weight_var_fwd_kernel) and the first half of its backward (wv_tmp of weight_var_bwd_kernel): one more
+  // walk over the weights this row has just written
+  float var = 0.f, wv_tmp = 0.f;
+  const float wv_mean = wv_m / wv_ws;
+  if (s < e) {
+    float n_w = weights[min(s + c, e - 1)];
+    for (int base = 0; base + s < e; base += 16) {
+      const int i = base + c;
+      const float c_w = n_w;
+      if (base + 16 + s < e) n_w = weights[min(i + 16 + s, e - 1)];
+      const float b = (float) i / 16.f - wv_mean;
+      const float wi = i + s < e ? c_w : 0.f;
+      var = f2n_row_last(f2n_row_seq_scan(wi * b * b, var, c));
+      wv_tmp = f2n_row_last(f2n_row_seq_scan(wi * 2.f * b, wv_tmp, c));
+    }
+  }
+  // ================= the loss of this ray and its gradients (train_loss_kernel, element-wise per ray) =================
+  const float inv_col = 1.f / (float) max(3 * n_rays, 1), inv_ray = 1.f / (float) max(n_rays, 1);
+  float dC[3], t_col = 0.f, t_mse = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float d = pred[k] - gtc[k];
+    const float r = sqrtf(d * d + 1e-4f);
+    t_col += r;
+    t_mse += d * d;
+    dC[k] = d / r * inv_col;
+  }
+  const float r_var = sqrtf(var + 1e-2f);
+  const float wv_dv = var_w * .5f / r_var * inv_ray;
+  const float dDisp = disp_w * 2.f * disp * inv_ray;
+  if (c == 0) {
+    s_terms[row][0] = live ? t_col * inv_col : 0.f;
+    s_terms[row][1] = live ? r_var * inv_ray : 0.f;
+    s_terms[row][2] = live ? disp * disp * inv_ray : 0.f;
+    s_terms[row][3] = live ? t_mse * inv_col : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < F2N_CT_TERMS) {  // this block's partial sums, rows in a fixed order
+    float sc = 0.f, sv = 0.f, sd = 0.f, sm = 0.f;
+    for (int r = 0; r < F2N_ROW_RAYS_PER_BLOCK; r++) {
+      sc += s_terms[r][0];
+      sv += s_terms[r][1];
+      sd += s_terms[r][2];
+      sm += s_terms[r][3];
+    }
+    const int k = threadIdx.x;
+    partials[(size_t) blockIdx.x * F2N_CT_TERMS + k] =
+        k == 0 ? sc + sv * var_w + sd * disp_w : k == 1 ? sc : k == 2 ? sv : k == 3 ? sd : k == 5 ? sm : 0.f;
+  }
+  if (s >= e) return;
+  // ================= backward walk (composite_bwd_kernel's second walk; its first walk's totals are in registers) =================
+  const float dep_sum = dep;
+  const float denom = 1.f - last_trans + 1e-4f;
+  const float dDep = 0.f;  // (the depth output carries no loss term)
+  const float d_last = (dC[0] * bgc[0] + dC[1] * bgc[1] + dC[2] * bgc[2]) + dDep * dep_sum / (denom * denom);
+  const float d_total = -last_trans * d_last;
+  const float dDepW = dDep / denom;
+  struct RIn {
+    float f0, dt, t, c0, c1, c2;
+  };
+  auto rfetch = [&](int i) {
+    RIn r;
+    r.f0 = f0[(size_t) i * f0_stride];
+    r.dt = dt[i];
+    r.t = t[i];
+    r.c0 = rgb[3 * (size_t) i];
+    r.c1 = rgb[3 * (size_t) i + 1];
+    r.c2 = rgb[3 * (size_t) i + 2];
+    return r;
+  };
+  float suffix = 0.f;
+  RIn rn = rfetch(max(e - 1 - c, s));
+  for (int hi = e; hi > s; hi -= 16) {
+    const int i = hi - 1 - c;
+    const bool in = i >= s;
+    const RIn rc = rn;
+    if (hi - 16 > s) rn = rfetch(max(i - 16, s));
+    float x = 0.f, dti = 0.f, sigma = 0.f, tt = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (in) {
+      x = rc.f0 - F2N_DENSITY_SHIFT;
+      sigma = expf(x);
+      dti = rc.dt;
+      tt = rc.t + F2N_T_BIAS;
+      c0 = rc.c0; c1 = rc.c1; c2 = rc.c2;
+    }
+    const float sec = in ? sigma * dti : 0.f;
+    const float acc_i = f2n_row_seq_scan(-sec, acc, c);
+    acc = f2n_row_last(acc_i);
+    const float trans = expf(-acc_i);
+    const float ems = expf(-sec);
+    const float alpha = 1.f - ems;
+    const float w = trans * alpha;
+    float dw = (dC[0] * c0 + dC[1] * c1 + dC[2] * c2) + dDisp / tt + dDepW * tt;
+    if (in) {
+      const float r = (float) (i - s) / 16.f, b = r - wv_mean;
+      dw += wv_dv * (b * b + wv_tmp * -r / wv_ws);
+    }
+    const float d_acc = in ? -dw * w : 0.f;
+    const float suf_incl = f2n_row_seq_scan(d_acc, suffix, c);
+    const float suf_i = f2n_row_exclusive(suf_incl, suffix, c);
+    suffix = f2n_row_last(suf_incl);
+    if (in) {
+      const float d_sec = dw * trans * ems + suf_i + d_total;
+      float d_sigma = d_sec * dti;
+      float g0 = dC[0] * w, g1 = dC[1] * w, g2 = dC[2] * w;
+      if (gs_progress < 1.f) {  // CustomOps.cu:68-80
+        const float a = ((float) (i - s) + .5f) / (float) (e - s);
+        const float sc = gs_progress + (1.f - gs_progress) * a * a;
+        d_sigma *= sc;
+        g0 *= sc; g1 *= sc; g2 *= sc;
+      }
+      drgb[3 * (size_t) i] = g0;
+      drgb[3 * (size_t) i + 1] = g1;
+      drgb[3 * (size_t) i + 2] = g2;
+      df0[(size_t) i * df0_stride] = d_sigma * expf(fminf(fmaxf(x, -100.f), 5.f));
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void weight_var_fwd_kernel(int n_rays, const float* __restrict__ weights,
                                                              const int32_t* __restrict__ se, float* __restrict__ out) {
   const int c = threadIdx.x & 15;
@@ -492,6 +731,28 @@ int f2n_composite_bwd(void* stream, int n_rays, const int32_t* pts_start_end, co
   if (f0_stride < 1 || df0_stride < 1 || ((var_weights == nullptr) != (dvars == nullptr))) return F2N_ERR_INVALID_ARG;
   F2N_ROW_LAUNCH(composite_bwd_kernel, n_rays, pts_start_end, f0, f0_stride, dt, t, rgb, bg, dcolors, ddisparity, ddepth, dweights,
                  grad_scaling_progress, drgb, df0, df0_stride, var_weights, dvars);
+}
+
+int f2n_composite_train(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
+                        const float* t, const float* rgb, const float* bg, const float* gt_colors, float var_w, float disp_w, float tv_w,
+                        float grad_scaling_progress, int n_edge, int feat_dim, const float* edge_feats, float* dedge_feats,
+                        float* colors, float* weights, float* drgb, float* df0, int df0_stride, float* out_losses, int defer_reduce) {
+  if (n_rays < 1 || f0_stride < 1 || df0_stride < 1 || n_edge < 0 || (n_edge > 0 && (edge_feats == nullptr || feat_dim < 1)) ||
+      out_losses == nullptr)
+    return F2N_ERR_INVALID_ARG;
+  const int ray_blocks = (int) f2n_div_up(n_rays, F2N_ROW_RAYS_PER_BLOCK);
+  const int tv_blocks = n_edge > 0 ? (int) min((long) 32, (long) f2n_div_up((long) n_edge * feat_dim, 256)) : 0;
+  const int blocks = ray_blocks + tv_blocks;
+  float* partials = (float*) f2n_ws_get(F2N_WS_LOSS, sizeof(float) * ((size_t) blocks * F2N_CT_TERMS + 64 * 8 + 16));
+  if (partials == nullptr) return F2N_ERR_INVALID_ARG;
+  partials += 64 * 8 + 16;  // (the head of this slot belongs to f2n_train_loss: its partials and arrival counter)
+  hipLaunchKernelGGL(composite_train_kernel, dim3(blocks), dim3(256), 0, (hipStream_t) stream, n_rays, pts_start_end, f0, f0_stride, dt, t,
+                     rgb, bg, gt_colors, var_w, disp_w, tv_w, grad_scaling_progress, n_edge, feat_dim, edge_feats, dedge_feats, colors,
+                     weights, drgb, df0, df0_stride, partials, out_losses, ray_blocks);
+  const int rc = f2n_launch_status();
+  if (rc != F2N_OK) return rc;
+  if (defer_reduce) return f2n_defer_reduction(F2N_CT_TERMS, blocks, partials, out_losses);
+  return f2n_reduce_partials(stream, F2N_CT_TERMS, blocks, partials, out_losses);
 }
 
 int f2n_weight_var_fwd(void* stream, int n_rays, const float* weights, const int32_t* pts_start_end, float* out_vars) {

@@ -666,6 +666,19 @@ int f2n_train_loss(void* stream, int n_rays, const float* pred_colors /*[R,3]*/,
                    const float* edge_feats /*[E,2,feat_dim]*/, float var_w, float disp_w, float tv_w,
                    float* out_losses /*[8]*/, float* dcolors, float* ddisparity, float* dvar, float* dedge_feats);
 
+/* f2n_composite_fwd -> f2n_train_loss -> f2n_composite_bwd in ONE launch (the streaming training step; round 4): every ray is
+ * walked forward, its loss terms and their gradients are formed in registers (they are element-wise per ray: ExpRunner.cpp:95-120),
+ * and the same row walks it backward with the totals still at hand.  Outputs as the three calls': colors [R,3], weights [M], drgb
+ * [M,3], df0 (stride df0_stride) -- bit-identical -- plus dedge_feats (TV gradient) and out_losses [8] = {loss, colour, var,
+ * disparity, tv, mse, 0, 0}: zeroed by the launch and completed by the reduction of its per-block partial sums -- at once
+ * (defer_reduce = 0) or by the step's f2n_reduce_deferred (defer_reduce = 1).  The reported loss VALUES sum pre-scaled terms
+ * (mean = sum of x / n instead of (sum of x) / n): equal to f2n_train_loss's to rounding, not bit for bit. */
+int f2n_composite_train(void* stream, int n_rays, const int32_t* pts_start_end, const float* f0, int f0_stride, const float* dt,
+                        const float* t, const float* rgb, const float* bg, const float* gt_colors, float var_w, float disp_w, float tv_w,
+                        float grad_scaling_progress, int n_edge, int feat_dim, const float* edge_feats /*[E,2,feat_dim] or NULL*/,
+                        float* dedge_feats /*or NULL*/, float* colors, float* weights, float* drgb, float* df0, int df0_stride,
+                        float* out_losses /*[8]*/, int defer_reduce);
+
 /* Gradient finiteness check of the two MLPs (Field/TCNNWP.cpp:234-240), device side:
  * flags[0] = a has a non-finite value, flags[1] = b has one, flags[2] = either (the optimiser's skip_flag). */
 int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags /*[3]*/);

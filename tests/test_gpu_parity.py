@@ -784,7 +784,7 @@ def test_field_and_shade_forward_in_one_launch(hip, fox_state, fox_golden, use_e
     assert_same(N(fx_ex2).view(np.uint16), N(fx_ex).view(np.uint16), "extra input rows")
 
 
-@pytest.mark.parametrize("n_emb", [0, 50, 480, 1500])  # 480: the largest per-block LDS image (> 64 KB of LDS); above: global atomics
+@pytest.mark.parametrize("n_emb", [0, 50, 240, 1500])  # 240: the largest per-block LDS image (64-bit fixed point); above: global atomics
 def test_shade_fused_forward_backward(hip, fox_golden, n_emb):
     use_emb = n_emb > 0
     g = fox_golden
@@ -987,6 +987,51 @@ def test_composite_forward_backward(hip, gs):
     hip.composite_bwd(R, T(se), T(feat), T(dt), T(t), T(rgb), T(bg), T(dcol), None, None, None, 1.0, drgb, dfeat)
     rdrgb2, _ = op.composite_bwd(ref["ctx"], dt, rgb, bg, se, dcol)
     assert np.abs(N(drgb) - rdrgb2).max() <= 1e-5 * max(1.0, np.abs(rdrgb2).max())
+
+
+@pytest.mark.parametrize("gs,var_w", [(1.0, 0.01), (0.3, 0.0)])
+def test_composite_train_equals_three_launches(hip, gs, var_w):
+    """f2n_composite_train (compositing forward + the loss of ExpRunner::Train + compositing backward in one launch) against
+    f2n_composite_fwd -> f2n_train_loss -> f2n_composite_bwd: colours, weights, d rgb, d f0 and the TV gradient bit for bit, the
+    reported loss values to rounding (they sum pre-scaled terms).  Ragged rays including empty ones and rays longer than a row."""
+    rng = np.random.default_rng(41)
+    R, E, D = 1000, 300, 16
+    se, n = ragged(rng, R, 90)
+    f0 = (rng.standard_normal(n) * 2 + 2).astype(F32)
+    dt = (rng.random(n, dtype=F32) * F32(0.03)).astype(F32)
+    t = np.sort(rng.random(n, dtype=F32) * 5)
+    rgb = rng.random((n, 3), dtype=F32); bg = rng.random((R, 3), dtype=F32); gt = rng.random((R, 3), dtype=F32)
+    edge = rng.standard_normal((E, 2, D)).astype(F32)
+    disp_w, tv_w = 0.0005, 0.1
+    d = dict(se=T(se), f0=T(f0), dt=T(dt), t=T(t), rgb=T(rgb), bg=T(bg), gt=T(gt), edge=T(edge))
+    # the three launches
+    col = torch.zeros((R, 3), device=DEV); disp = torch.zeros(R, device=DEV); dep = torch.zeros(R, device=DEV)
+    wts = torch.zeros(n, device=DEV); var = torch.zeros(R, device=DEV)
+    hip.composite_fwd(R, d["se"], d["f0"], d["dt"], d["t"], d["rgb"], d["bg"], col, disp, dep, wts, f0_stride=1, out_vars=var)
+    losses = torch.zeros(8, device=DEV)
+    dc = torch.zeros((R, 3), device=DEV); dd = torch.zeros(R, device=DEV); dv = torch.zeros(R, device=DEV)
+    de = torch.zeros((E, 2, D), device=DEV)
+    hip.train_loss(R, col, d["gt"], disp, var, E, D, d["edge"], var_w, disp_w, tv_w, losses, dc, dd, dv, de)
+    drgb = torch.zeros((n, 3), device=DEV); df0 = torch.zeros(n, device=DEV)
+    hip.composite_bwd(R, d["se"], d["f0"], d["dt"], d["t"], d["rgb"], d["bg"], dc, dd, None, None, gs, drgb, df0, f0_stride=1, df0_stride=1,
+                      var_weights=wts, dvars=dv)
+    # one launch
+    col2 = torch.full((R, 3), -7.0, device=DEV); wts2 = torch.full((n,), -7.0, device=DEV)
+    drgb2 = torch.full((n, 3), -7.0, device=DEV); df02 = torch.full((n,), -7.0, device=DEV)
+    de2 = torch.full((E, 2, D), -7.0, device=DEV); losses2 = torch.full((8,), 123.0, device=DEV)
+    hip.composite_train(R, d["se"], d["f0"], 1, d["dt"], d["t"], d["rgb"], d["bg"], d["gt"], var_w, disp_w, tv_w, gs, E, D, d["edge"], de2,
+                        col2, wts2, drgb2, df02, 1, losses2)
+    assert_same(N(col2), N(col), "colours"); assert_same(N(wts2), N(wts), "weights")
+    assert_same(N(de2), N(de), "TV gradient")
+    assert_same(N(drgb2), N(drgb), "d rgb"); assert_same(N(df02), N(df0), "d f0")
+    a, b = N(losses2), N(losses)
+    assert np.abs(a[:6] - b[:6]).max() <= 3e-6 * np.abs(b[:6]).max(), (a, b)
+    assert a[6] == 0.0 and a[7] == 0.0
+    # no edge samples: the TV terms vanish, the rest stands
+    losses3 = torch.zeros(8, device=DEV)
+    hip.composite_train(R, d["se"], d["f0"], 1, d["dt"], d["t"], d["rgb"], d["bg"], d["gt"], var_w, disp_w, tv_w, gs, 0, D, None, None,
+                        col2, wts2, drgb2, df02, 1, losses3)
+    assert_same(N(drgb2), N(drgb)); assert float(losses3[4]) == 0.0 and abs(float(losses3[1]) - float(losses[1])) <= 3e-6
 
 
 def test_adam(hip):

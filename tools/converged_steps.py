@@ -16,6 +16,7 @@ ap.add_argument("--overrides", nargs="*", default=[])
 ap.add_argument("--kernel-timing", action="store_true")
 ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 auto (default: the host's default)")
 ap.add_argument("--march-blocks-sweep", default="", help="v1,v2,...: repeat the timed steps with the speculative march on that many persistent blocks (0: classic)")
+ap.add_argument("--native", action="store_true", help="time ExpRunner::Train's own loop (fresh batches drawn on the device every iteration) instead of python-driven steps on resident batches")
 ap.add_argument("--depth", type=int, default=-1, help="sampling pipeline depth of the timed steps (1 / 2; default: the host's)")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob")
 args = ap.parse_args()
@@ -57,7 +58,18 @@ def timed(tag=""):
         tm = runtime.host().ExpRunner.collect_kernel_timing()
         runtime.host().ExpRunner.disable_kernel_timing()
         print("    " + "  ".join("%s %.1f us" % (k, v[1] / max(v[0], 1) * 1e3) for k, v in sorted(tm.items())), flush=True)
-if args.march_blocks_sweep:
+if args.native:
+    runner.end_iter = runner.iter_step + args.steps + 64
+    runner.train(ds, runner.iter_step + 16, 1); runner.flush()
+    c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)
+    t0 = time.perf_counter()
+    s2 = runner.train(ds, runner.iter_step + args.steps, 1); runner.flush(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    c1 = runner.counters()
+    print("native loop: %.3f ms/step  marched/step %d meaningful/step %d nodes %d  spec %s" % (
+        el / args.steps * 1e3, (c1["total_marched"] - c0["total_marched"]) // args.steps,
+        (c1["total_meaningful"] - c0["total_meaningful"]) // args.steps, runner.n_nodes(), dict(runner.speculation_counters())), flush=True)
+elif args.march_blocks_sweep:
     for rep in range(2):
         for v in args.march_blocks_sweep.split(","):
             runner.march_blocks = int(v)
