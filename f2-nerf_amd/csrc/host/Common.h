@@ -6,6 +6,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 
+#include <chrono>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -94,6 +95,33 @@ class KernelTimers {
   std::map<std::string, std::unique_ptr<at::cuda::CUDAEvent>> pending_;
   std::map<std::string, std::vector<std::pair<std::unique_ptr<at::cuda::CUDAEvent>, std::unique_ptr<at::cuda::CUDAEvent>>>> spans_;
 };
+
+// Host-side wall-clock accumulators per named region (where does the HOST thread spend an iteration: queueing, drawing batches,
+// waiting for which event?).  A few nanoseconds per region when disabled; measurement aid (ExpRunner.host_profile binding).
+class HostProf {
+ public:
+  static HostProf& Get() {
+    static HostProf inst;
+    return inst;
+  }
+  bool on = false;
+  std::map<std::string, std::pair<int64_t, double>> acc;  // name -> (entries, seconds)
+  struct Scope {
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    bool live;
+    explicit Scope(const char* n) : name(n), live(HostProf::Get().on) {
+      if (live) t0 = std::chrono::steady_clock::now();
+    }
+    ~Scope() {
+      if (!live) return;
+      auto& a = HostProf::Get().acc[name];
+      a.first += 1;
+      a.second += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  };
+};
+#define F2N_HOST_SCOPE(name) HostProf::Scope f2n_host_scope_##__LINE__(name)
 
 #define F2N_TIMED_CALL(name, expr)      \
   do {                                  \

@@ -202,14 +202,22 @@ std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysDataOfCamera(int idx, i
 }
 
 std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysData(int batch_size, int sets) {
-  std::vector<int> img_idx;
-  if ((sets & DATA_TRAIN_SET) != 0) img_idx.insert(img_idx.end(), train_set_.begin(), train_set_.end());
-  if ((sets & DATA_VAL_SET) != 0) img_idx.insert(img_idx.end(), val_set_.begin(), val_set_.end());
-  if ((sets & DATA_TEST_SET) != 0) img_idx.insert(img_idx.end(), test_set_.begin(), test_set_.end());
-  TORCH_CHECK(!img_idx.empty(), "empty image set");
-  Tensor cur_set = torch::from_blob(img_idx.data(), {(int64_t) img_idx.size()}, CpuI32()).to(torch::kCUDA);
+  // The image list of a set lives on the device, uploaded once per `sets` value: the upload of a pageable host array is a
+  // SYNCHRONOUS copy -- issued every iteration (as a first version did) it made the host wait for the whole previous training
+  // step before it could queue the next one: ~0.2 ms of idle device at the head of every step of ExpRunner::Train
+  // (profiles/r04_native_loop_timeline.txt).
+  auto it = set_on_device_.find(sets);
+  if (it == set_on_device_.end()) {
+    std::vector<int> img_idx;
+    if ((sets & DATA_TRAIN_SET) != 0) img_idx.insert(img_idx.end(), train_set_.begin(), train_set_.end());
+    if ((sets & DATA_VAL_SET) != 0) img_idx.insert(img_idx.end(), val_set_.begin(), val_set_.end());
+    if ((sets & DATA_TEST_SET) != 0) img_idx.insert(img_idx.end(), test_set_.begin(), test_set_.end());
+    TORCH_CHECK(!img_idx.empty(), "empty image set");
+    it = set_on_device_.emplace(sets, torch::from_blob(img_idx.data(), {(int64_t) img_idx.size()}, CpuI32()).to(torch::kCUDA)).first;
+  }
+  const Tensor& cur_set = it->second;
   // every draw on the device: uniform image of the set, uniform pixel (Dataset.cpp:286-291)
-  Tensor cam = cur_set.index({torch::randint((int64_t) img_idx.size(), {batch_size}, DevI32().dtype(torch::kInt64))}).contiguous();
+  Tensor cam = cur_set.index({torch::randint(cur_set.size(0), {batch_size}, DevI32().dtype(torch::kInt64))}).contiguous();
   Tensor i = torch::randint(0, height_, {batch_size}, DevI32()), j = torch::randint(0, width_, {batch_size}, DevI32());
   Tensor ij = torch::stack({i, j}, -1).contiguous();
   last_cam_indices_ = cam;

@@ -4,6 +4,7 @@
 // iteration, Dataset.cpp:275-298).  File IO (cams_meta.npy, JPEG decoding, NormalizeScene) is out of scope: the
 // constructor takes the tensors the reference's constructor would have produced.
 #pragma once
+#include <map>
 #include <tuple>
 
 #include "GlobalDataPool.h"
@@ -49,6 +50,7 @@ class Dataset {
   Tensor poses_cpu_;                             // for the host-side pose blending of RandRaysWholeSpace
   Tensor image_tensors_;                         // device, [C,H,W,3] fp32
   std::vector<int> train_set_, test_set_, val_set_;
+  std::map<int, Tensor> set_on_device_;  // RandRaysData: the image indices of a `sets` combination, uploaded once
   Tensor last_cam_indices_, last_ij_;            // the draws behind the most recent Rand* batch (tests, logging)
 
  private:

@@ -241,9 +241,10 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
                              prefetch ? next2_rays_o : Tensor(), prefetch ? next2_rays_d : Tensor());
   deferred_dropped_ = false;
   if (!renderer_->after_count_readback_) renderer_->after_count_readback_ = [this]() { ResolveDeferredFlags(); };
-  if (prefetch && !pipelined) {
-    // (Pipelined data-parallel steps keep the sampling at the step boundary instead: there it runs underneath the gradient
-    // all-reduce, which has nothing else to hide under -- measured with a one-rank RCCL world: 1.40 vs 1.53 ms per step.)
+  if (prefetch) {
+    // (Pipelined data-parallel steps used to keep the sampling at the step boundary, underneath the gradient all-reduce; since
+    // round 4 they run the same program as a single GPU -- speculative, two-deep sampling on the side streams -- and
+    // BeginStep's PreSample finds the batch already in flight.)
     // The NEXT batch's sampling only depends on this step's octree update: its kernels are issued (on a side stream) from
     // inside SampleAndFilter, right behind that update, with the next iteration's fineness -- up to and including the pack;
     // the host comes back for its counts at the top of the next step (Renderer::SampleAndFilter -> PreSampleFinish).
@@ -268,8 +269,12 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   // (f2n_*_dyn entry points), the host queues the whole iteration without a device round trip and learns the count -- for
   // the meaningful-samples EMA and the counters -- at the start of the next step (Renderer::ResolvePendingCount).
   renderer_->async_count_ = (prefetch && async_counts_ == 1) || async_counts_ == 2;
-  TrainOutputs out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(),
-                                                     disp_loss_weight_, tv_loss_weight_);
+  TrainOutputs out;
+  {
+    F2N_HOST_SCOPE("step.fwd_bwd");
+    out = renderer_->TrainForwardBackward(rays_o, rays_d, bounds, gt_colors, emb_idx, CurVarLossWeight(), disp_loss_weight_,
+                                          tv_loss_weight_);
+  }
   renderer_->async_count_ = false;
   renderer_->after_octree_update_ = nullptr;
   renderer_->next_batch_ = renderer_->next2_batch_ = Renderer::NextBatch();
@@ -312,7 +317,10 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
 bool ExpRunner::ResolveDeferredFlags() {
   if (!flags_deferred_) return false;
   flags_deferred_ = false;
-  nan_flags_ev_.synchronize();
+  {
+    F2N_HOST_SCOPE("wait.flags");
+    nan_flags_ev_.synchronize();
+  }
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
   const int32_t f[3] = {flag_words_.Read(4 * deferred_flag_slot_), flag_words_.Read(4 * deferred_flag_slot_ + 1),
@@ -422,15 +430,25 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
   }
   stats.loss = loss.detach();
   stats.mse = (pred_colors.detach() - gt_colors).square().mean();
-  if (loss.requires_grad()) {
+  // (a data-parallel replica whose batch missed the scene still joins the gradient exchange, with its zero gradients: every
+  // rank must enter the collective, and the ranks that did see samples average over the whole world)
+  const bool has_grad = loss.requires_grad();
+  if (has_grad || sync_.Installed()) {
     renderer_->ZeroGrad();
-    loss.backward();
+    if (has_grad) loss.backward();
     if (renderer_->app_emb_.grad().defined()) {  // (the unfused shader path delivers this gradient through autograd)
       torch::NoGradGuard ng;
       renderer_->app_emb_grad_.add_(renderer_->app_emb_.grad());
       renderer_->app_emb_.mutable_grad() = Tensor();
     }
-    if (sync_.blocking) sync_.blocking();  // data-parallel all-reduce of the gradient buffers (RCCL)
+    // data-parallel all-reduce of the gradient buffers (RCCL), whichever way it was installed: the taped step has no next
+    // step's sampling to hide a pipelined exchange under, so begin / end run back to back
+    if (sync_.blocking) {
+      sync_.blocking();
+    } else if (sync_.begin) {
+      sync_.begin();
+      if (sync_.end) sync_.end();
+    }
     if (check_nan_) {  // TCNNWP.cpp:234-240 + ExpRunner.cpp:131-134
       auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
       auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
@@ -579,7 +597,7 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   // meaningful-samples average as it stood TWO steps before the batch is used (the reference: none, ExpRunner.cpp:86), because
   // that is when its rays have to exist.  Always two ahead, whatever the renderer then does with the second batch: the sequence
   // of batches does not depend on a scheduling decision.
-  const bool two_deep = !sync_.Installed();  // (whether the batch after next is BEGUN two steps ahead is the renderer's decision)
+  const bool two_deep = true;  // (whether the batch after next is BEGUN two steps ahead is the renderer's decision)
   std::deque<decltype(draw())> ahead;
   ahead.push_back(draw());
   last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;
@@ -588,7 +606,11 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   const int give_up = 4 * (target + 16);  // every iteration non-finite: stop instead of spinning
   while (true) {
   while (iter_step_ < target) {
-    while (ahead.size() < (two_deep ? 3u : 2u)) ahead.push_back(draw());
+    {
+      F2N_HOST_SCOPE("train.draw");
+      while (ahead.size() < (two_deep ? 3u : 2u)) ahead.push_back(draw());
+    }
+    F2N_HOST_SCOPE("train.step");
     auto& cur = ahead[0];
     const BoundedRays& r = std::get<0>(cur);
     const BoundedRays& nr = std::get<0>(ahead[1]);

@@ -113,6 +113,7 @@ bool PersSampler::MaintenanceDue(int ahead) const {  // the conditions of Finish
 }
 
 void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, float fineness, PendingSamples& p, bool speculative) {
+  F2N_HOST_SCOPE("sampler.begin");
   Tensor rays_o = rays_o_raw.contiguous();
   Tensor rays_d_in = rays_d_raw.contiguous();
   CheckDev(rays_o, torch::kFloat32, "rays_o");
@@ -223,7 +224,8 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   // stretch of the step the march ends in (underneath the hash gather, when the walk ran out of LDS) instead of behind the
   // stat update, where it lands on field_shade_fwd, which is as memory-bound as the pack is (115 us against 59 alone:
   // profiles/r03_speculation_experiments.txt).  CompleteSpeculative scans again and packs again only if a leaf died since.
-  if (speculative && !optimistic_pack_) return;
+  // (not for a batch that is begun two steps ahead: where that pays, leaves die in most steps and the pack would run twice)
+  if (speculative && (!optimistic_pack_ || persistent_march_)) return;
   IssueScanAndPack(p);
   p.packed_once = speculative;
 }
@@ -231,6 +233,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
 // The rays a stat update invalidated are walked and marched again (f2n_oct_intersect_repair / f2n_ray_march_repair: both
 // return at once on the device when no leaf died, the common case), then the tail of a GetSamples call.
 bool PersSampler::CompleteSpeculative(PendingSamples& p) {
+  F2N_HOST_SCOPE("sampler.complete");
   TORCH_CHECK(p.active && p.speculative && !p.completed, "CompleteSpeculative: nothing to complete");
   auto& oct = *pers_octree_;
   if (p.generation != oct.generation_) return false;
@@ -319,7 +322,10 @@ void PersSampler::IssueScanAndPack(PendingSamples& p) {
 SampleResultFlex PersSampler::FinishSamples(PendingSamples& p) {
   TORCH_CHECK(p.active && p.completed, "FinishSamples without (completed) BeginSamples");
   const int n_rays = p.n_rays;
-  p.counts_ready.synchronize();
+  {
+    F2N_HOST_SCOPE("wait.sample_counts");
+    p.counts_ready.synchronize();
+  }
   const int n_all_oct = totals_words_.Read(2 * p.totals_slot);
   const int n_all_pts = totals_words_.Read(2 * p.totals_slot + 1);
   if (global_data_pool_->mode_ == RunningMode::TRAIN) {

@@ -361,11 +361,27 @@ float Renderer::KeptPerRayForEma(int n_kept_local, int n_rays) {
 void Renderer::ResolvePendingCount() {
   if (!count_pending_) return;
   count_pending_ = false;
-  n_kept_ev_.synchronize();  // long since recorded: this is the previous step's count
-  const int n_kept = n_kept_words_.Read(0);
+  {
+    F2N_HOST_SCOPE("wait.kept");
+    n_kept_ev_.synchronize();  // long since recorded: this is the previous step's count
+  }
+  const int n_kept = n_kept_words_.Read(1);
   last_n_kept_pts_ = n_kept;
   total_kept_pts_ += n_kept;
   auto* gdp = global_data_pool_;
+  if (dp_world_ > 1) {
+    // Data-parallel streaming steps: every rank must size its next batch from the same number, the survivor count summed over
+    // the ranks.  The sum rides in the occupancy exchange (DataParallel::OccupancySync) -- which a streaming step issues BEFORE
+    // its survivor scan (octree-first, as on one GPU) -- so the exchange of step k carries the count of step k-1, and step k's
+    // scan drops the sum into the mapped word next to its own count: no launch, no wait of its own, one more step of lag in an
+    // average that only sizes batches.
+    if (dp_sum_mirrored_) {
+      const float per_ray = float(n_kept_words_.Read(0)) / (float(dp_sum_rays_) * float(dp_world_));
+      gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + per_ray * 0.1f;
+    }
+    dp_sum_mirrored_ = false;
+    return;
+  }
   gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(n_kept, pending_count_rays_) * 0.1f;
   // (the previous step's finiteness flags are NOT read here: they are written by that step's last kernel, and waiting for
   // them at the top of a step would stop the host from queueing ahead -- ExpRunner::TrainStep reads them once this step's
@@ -374,6 +390,7 @@ void Renderer::ResolvePendingCount() {
 
 RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,
                                       bool async_count) {
+  F2N_HOST_SCOPE("step.sample_and_filter");
   auto* gdp = global_data_pool_;
   ResolvePendingCount();
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
@@ -388,8 +405,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   // sequence -- background / edge samples of this step, then the next batch's march noise -- whichever way the next batch is
   // sampled; only the event moves.)
   spec_start_recorded_ = false;
-  if (spec_order_ == 1 && train && async_count && (next_batch_.valid || next2_batch_.valid) && dp_world_ <= 1 &&
-      speculative_sampling_ != 0) {
+  if (spec_order_ == 1 && train && async_count && (next_batch_.valid || next2_batch_.valid) && speculative_sampling_ != 0) {
     spec_start_ev_.record();
     spec_start_recorded_ = true;
   }
@@ -477,7 +493,9 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   const bool quiet = ps->pers_octree_->QuietEpochs() >= kSpecQuietEpochs;
   const bool big_tree = ps->pers_octree_->n_interior_ > ps->LdsWalkMaxInterior();
   const bool two_deep = spec_depth_ >= 3 || (spec_depth_ == 2 && big_tree);
-  const bool spec_base = train && async_count && dp_world_ <= 1 && speculative_sampling_ != 0 && n_all_pts > 0;
+  // (data-parallel replicas speculate like a single GPU: the deaths a repair looks for are stamped by the stat update, which
+  // runs behind the occupancy exchange and is therefore the same on every rank)
+  const bool spec_base = train && async_count && speculative_sampling_ != 0 && n_all_pts > 0;
   auto spec_begin = [&](const NextBatch& nb, int ahead) {
     if (!nb.valid || FindPending(nb.rays_o, nb.rays_d) >= 0) return;
     const int slot = FreePendingSlot();
@@ -504,15 +522,33 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   if (n_all_pts <= 0) {  // Renderer.cpp:83-97
     pack_done();
     // data-parallel replicas must all take part in the occupancy exchange, also the one whose batch missed the scene
-    if (train && dp_world_ > 1) dp_count_ = torch::zeros({1}, DevI32());
+    const bool dp_lagged = train && dp_world_ > 1 && async_count;  // (see ResolvePendingCount)
+    if (train && dp_world_ > 1 && !dp_lagged) dp_count_ = torch::zeros({1}, DevI32());
     if (train && static_cast<PersSampler*>(pts_sampler_.get())->occupancy_sync_hook_)
       pts_sampler_->UpdateOctNodes(sample_result_, torch::empty({0}, DevF32()), torch::empty({0}, DevF32()));
-    if (train && dp_world_ > 1) {
+    if (dp_lagged) {
+      // the exchange has just summed the PREVIOUS step's count over the ranks: a scan over no rays drops it (and this step's
+      // count, zero) into the mapped words, exactly as the survivor scan of a step with samples does
+      Tensor total = torch::empty({1}, DevI32());
+      n_kept_words_.Ensure(2);
+      if (dp_count_.defined()) {
+        F2N_CALL(f2n_segment_scan_ex(CurStream(), 0, nullptr, nullptr, I32P(total), n_kept_words_.Dev(0), I32P(dp_count_), 1));
+        dp_sum_mirrored_ = true;
+        dp_sum_rays_ = dp_count_rays_;
+      } else {
+        F2N_CALL(f2n_segment_scan_ex(CurStream(), 0, nullptr, nullptr, I32P(total), n_kept_words_.Dev(1), nullptr, 0));
+      }
+      n_kept_ev_.record();
+      dp_count_ = total;
+      dp_count_rays_ = n_rays;
+      count_pending_ = true;
+      pending_count_rays_ = n_rays;
+    } else if (train && dp_world_ > 1) {
       if (!dp_count_host_.defined()) dp_count_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
       dp_count_host_.copy_(dp_count_, /*non_blocking=*/true);
       dp_count_ev_.record();
     }
-    if (train) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(0, n_rays) * 0.1f;
+    if (train && !dp_lagged) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(0, n_rays) * 0.1f;
     last_n_kept_pts_ = 0;
     fr.empty = true;
     consumed_side_samples_ = false;  // (nothing was read from the side stream's buffers)
@@ -570,7 +606,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     // of the two chains of a converged step: a streaming step issues the update -- and, behind it, the prefetch on the side
     // stream -- before the survivor scan, whose result nothing waits for.  (Data-parallel: the survivor count rides in the
     // occupancy exchange, so the scan stays first; synchronous steps: the host is about to wait for the count.)
-    const bool octree_first = train && async_count && dp_world_ <= 1;
+    const bool octree_first = train && async_count;
     auto octree_update_issued = [&]() {
       octree_ready_ev_.record();  // everything the NEXT step's ray sampling depends on has been issued ...
       // ... so the speculatively sampled batch of the next step is repaired and packed now (a batch for the step after it
@@ -593,12 +629,25 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     // host memory as well (FilterIdxBounds, Renderer.cu:20-50); the host reads it behind an event, not a stream drain, so that
     // the work below that does not depend on M (the occupancy update, the edge samples) is already queued and runs while the
     // host wakes up -- and no copy launch sits between the scan and the compaction.
-    n_kept_words_.Ensure(1);
-    F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(kept), I32P(new_se), I32P(total), n_kept_words_.Dev(0), nullptr, 0));
+    n_kept_words_.Ensure(2);  // [0] data-parallel: the previous step's count summed over the ranks; [1] this step's count
+    const bool dp_lagged = train && dp_world_ > 1 && octree_first;
+    if (dp_lagged && dp_count_.defined()) {
+      // (dp_count_ went through this step's occupancy exchange a moment ago: it now holds the ranks' sum of the previous count)
+      F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(kept), I32P(new_se), I32P(total), n_kept_words_.Dev(0), I32P(dp_count_), 1));
+      dp_sum_mirrored_ = true;
+      dp_sum_rays_ = dp_count_rays_;
+    } else {
+      F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(kept), I32P(new_se), I32P(total), n_kept_words_.Dev(1), nullptr, 0));
+    }
     n_kept_ev_.record();
-    if (train && dp_world_ > 1) dp_count_ = total.clone();  // summed over the ranks inside the occupancy exchange
+    if (dp_lagged) {  // this step's count: summed over the ranks inside the NEXT step's occupancy exchange (in place)
+      dp_count_ = total;
+      dp_count_rays_ = n_rays;
+    } else if (train && dp_world_ > 1) {
+      dp_count_ = total.clone();  // synchronous steps: summed inside this step's exchange, read right away
+    }
     if (train && !octree_first) ps->FinishOctUpdate();  // Renderer.cpp:140-149 (the votes were cast above)
-    if (train && dp_world_ > 1) {
+    if (train && dp_world_ > 1 && !dp_lagged) {
       if (!dp_count_host_.defined()) dp_count_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
       dp_count_host_.copy_(dp_count_, /*non_blocking=*/true);
       dp_count_ev_.record();
@@ -615,7 +664,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       fr.n_kept_dev = total;
     } else {
       n_kept_ev_.synchronize();
-      n_kept = n_kept_words_.Read(0);
+      n_kept = n_kept_words_.Read(1);
       if (train && after_count_readback_) after_count_readback_();  // everything queued before this point has finished
       last_n_kept_pts_ = n_kept;
       if (train) total_kept_pts_ += n_kept;

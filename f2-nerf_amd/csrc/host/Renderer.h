@@ -159,6 +159,8 @@ class Renderer : public Pipe {
   // the occupancy exchange, so that every replica sizes its next ray batch from the same number
   int dp_world_ = 1;
   Tensor dp_count_, dp_count_host_;
+  int dp_count_rays_ = 0, dp_sum_rays_ = 0;  // rays behind dp_count_ / behind the sum a scan has mirrored to the host
+  bool dp_sum_mirrored_ = false;
   at::cuda::CUDAEvent dp_count_ev_;
   float KeptPerRayForEma(int n_kept_local, int n_rays);
   bool async_count_ = false;        // set by ExpRunner::TrainStep for streaming steps

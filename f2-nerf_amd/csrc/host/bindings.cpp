@@ -254,6 +254,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                f(occ);
              };
            })
+      .def_static("host_profile",  // on=True: start (cleared); on=False: stop and return {region: (entries, seconds)} of the host thread
+                  [](bool on) {
+                    auto& hp = HostProf::Get();
+                    py::dict d;
+                    for (auto& kv : hp.acc) d[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
+                    hp.acc.clear();
+                    hp.on = on;
+                    return d;
+                  })
       .def_static("enable_kernel_timing", [](const std::vector<std::string>& names) { KernelTimers::Get().Enable(names); })
       .def_static("disable_kernel_timing", []() { KernelTimers::Get().Disable(); })
       .def_static("collect_kernel_timing",

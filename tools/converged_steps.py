@@ -62,9 +62,12 @@ if args.native:
     runner.end_iter = runner.iter_step + args.steps + 64
     runner.train(ds, runner.iter_step + 16, 1); runner.flush()
     c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)
+    runtime.host().ExpRunner.host_profile(True)
     t0 = time.perf_counter()
     s2 = runner.train(ds, runner.iter_step + args.steps, 1); runner.flush(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    hp = runtime.host().ExpRunner.host_profile(False)
+    print("host thread, us per iteration: " + "  ".join("%s %.1f (x%.1f)" % (k, v[1] / args.steps * 1e6, v[0] / args.steps) for k, v in sorted(hp.items())))
     c1 = runner.counters()
     print("native loop: %.3f ms/step  marched/step %d meaningful/step %d nodes %d  spec %s" % (
         el / args.steps * 1e3, (c1["total_marched"] - c0["total_marched"]) // args.steps,
