@@ -366,7 +366,9 @@ def test_data_parallel_hooks_on_one_gpu(rt, fox_state):
     finally:
         dist.destroy_process_group()
     for other in outs[1:]:
-        assert outs[0][0] == other[0], (outs[0][0], other[0])
+        # (the REPORTED loss of a streaming step comes from f2n_composite_train's pre-scaled partial sums, that of a synchronous
+        # step from f2n_train_loss: equal to rounding; parameters and gradients -- below -- are compared exactly)
+        assert np.allclose(outs[0][0], other[0], rtol=2e-6, atol=0), (outs[0][0], other[0])
         for a, b in zip(outs[0][1], other[1]):
             assert a.shape == b.shape
             if a.dtype.is_floating_point:

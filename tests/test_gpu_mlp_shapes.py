@@ -146,6 +146,17 @@ def test_nondefault_networks_train_through_the_host(rt, fox_state):
     # (a step whose f16 gradients overflow is skipped and halves the loss scale, TCNNWP.cpp:234-240: allow a few)
     assert runner.iter_step >= 55, runner.iter_step
     assert np.isfinite(mse).all() and min(mse[-5:]) < 0.5 * mse[0], (mse[0], mse[-5:])
+    # data-parallel exchanges reach the taped step too, whichever way they were installed (round-3 advisor: with only the
+    # pipelined begin / end pair installed -- what parallel.attach does by default -- no gradient exchange ever ran here and
+    # replicas drifted apart silently); a batch that misses the scene still enters it (the other ranks would hang otherwise)
+    calls = {"begin": 0, "end": 0}
+    runner.set_pipelined_grad_sync(lambda: calls.__setitem__("begin", calls["begin"] + 1), lambda: calls.__setitem__("end", calls["end"] + 1))
+    for _ in range(3):
+        runner.train_step(d[0], d[1], d[2], dg, d[4], True)
+    assert calls == {"begin": 3, "end": 3}, calls
+    far = d[0] + 1e4
+    assert runner.train_step(far, d[1], d[2], dg, d[4], True)["n_samples"] == 0
+    assert calls == {"begin": 4, "end": 4}, calls
     # checkpoint vector round trip with these shapes
     states = [t.cpu().clone() for t in runner.states()]
     assert states[8].numel() == 32 * 32 + 32 * 32 + 16 * 32 and states[9].numel() == 128 * 25 + 2 * 128 * 128 + 16 * 128
