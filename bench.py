@@ -352,8 +352,12 @@ def main():
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
         sock.close()
-        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("F2N_BENCH_DRY_RUN") == "1":  # (tests/test_parallel_cpu.py: the launcher's command, not the run)
+            print(" ".join(cmd))
+            return
+        os.execvp(sys.executable, cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and not (os.environ.get("F2N_BENCH_FORCE_DP") == "1" and world == 1):

@@ -438,6 +438,14 @@ def img2world_rays(n, poses, intri, dist_params, cam_idx, ij, rays_o, rays_d):
                                  _p(ij, "i32"), _p(rays_o, "f32"), _p(rays_d, "f32")), "f2n_img2world_rays")
 
 
+def draw_ray_batch(n_rays, u01, image_set, height, width, poses, intri, dist_params, images, cam_bounds, cam_indices, ij, rays_o,
+                   rays_d, gt_colors, bounds):
+    _ck(lib().f2n_draw_ray_batch(_stream(), _i(n_rays), _p(u01, "f32"), _p(image_set, "i32"), _i(int(image_set.numel())), _i(height),
+                                 _i(width), _p(poses, "f32"), _p(intri, "f32"), _p(dist_params, "f32"), _p(images, "f32", True),
+                                 _p(cam_bounds, "f32"), _p(cam_indices, "i32"), _p(ij, "i32"), _p(rays_o, "f32"), _p(rays_d, "f32"),
+                                 _p(gt_colors, "f32", True), _p(bounds, "f32")), "f2n_draw_ray_batch")
+
+
 def gather_pixels(n, height, width, images, cam_bounds, cam_idx, ij, gt_colors, bounds):
     _ck(lib().f2n_gather_pixels(_stream(), _i(n), _i(height), _i(width), _p(images, "f32", True), _p(cam_bounds, "f32", True),
                                 _p(cam_idx, "i32"), _p(ij, "i32"), _p(gt_colors, "f32", True), _p(bounds, "f32", True)),

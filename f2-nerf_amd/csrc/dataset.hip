@@ -86,7 +86,60 @@ __global__ void gather_pixels_kernel(int n_rays, int height, int width, const fl
   }
 }
 
+// Dataset::RandRaysData (Dataset.cpp:275-298) in ONE launch: three uniforms per ray pick an image of the set and a pixel, the
+// ray is generated (img2world_kernel's arithmetic) and the ground-truth colour / bounds gathered.  The ATen spelling -- three
+// randint, an index, a stack, then the two kernels above -- was eight dependent launches on the training step's main queue,
+// once per iteration.
+__global__ void draw_ray_batch_kernel(int n_rays, const float* __restrict__ u01, const int32_t* __restrict__ image_set, int n_set,
+                                      int height, int width, const float* __restrict__ poses, const float* __restrict__ intri,
+                                      const float* __restrict__ dist, const float* __restrict__ images,
+                                      const float* __restrict__ cam_bounds, int32_t* __restrict__ cam_idx, int32_t* __restrict__ ij,
+                                      float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ colors,
+                                      float* __restrict__ bounds) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const int c = image_set[min((int) (u01[3 * (size_t) r] * (float) n_set), n_set - 1)];
+  const int pi = min((int) (u01[3 * (size_t) r + 1] * (float) height), height - 1);
+  const int pj = min((int) (u01[3 * (size_t) r + 2] * (float) width), width - 1);
+  cam_idx[r] = c;
+  ij[2 * r] = pi;
+  ij[2 * r + 1] = pj;
+  const float* K = intri + 9 * (size_t) c;
+  const float* P = poses + 12 * (size_t) c;
+  const float i = (float) pi + .5f, j = (float) pj + .5f;
+  const float cx = K[2], cy = K[5], fx = K[0], fy = K[4];
+  float u = (j - cx) / fx;
+  float v = (i - cy) / fy;
+  float k[4] = {dist[4 * (size_t) c], dist[4 * (size_t) c + 1], dist[4 * (size_t) c + 2], dist[4 * (size_t) c + 3]};
+  f2n_undistort(k, u, v);
+  const float dir[3] = {u, -v, -1.f};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    rays_d[3 * (size_t) r + a] = f2n_sum3(P[4 * a] * dir[0], P[4 * a + 1] * dir[1], P[4 * a + 2] * dir[2]);
+    rays_o[3 * (size_t) r + a] = P[4 * a + 3];
+  }
+  if (colors != nullptr) {
+    const size_t px = ((size_t) c * height + pi) * width + pj;
+#pragma unroll
+    for (int a = 0; a < 3; a++) colors[3 * (size_t) r + a] = images[3 * px + a];
+  }
+  bounds[2 * (size_t) r] = cam_bounds[2 * (size_t) c];
+  bounds[2 * (size_t) r + 1] = cam_bounds[2 * (size_t) c + 1];
+}
+
 extern "C" {
+
+int f2n_draw_ray_batch(void* stream, int n_rays, const float* u01, const int32_t* image_set, int n_set, int height, int width,
+                       const float* poses, const float* intri, const float* dist_params, const float* images, const float* cam_bounds,
+                       int32_t* cam_indices, int32_t* ij, float* rays_o, float* rays_d, float* gt_colors, float* bounds) {
+  if (n_rays < 0 || n_set < 1 || height <= 0 || width <= 0 || (gt_colors != nullptr && images == nullptr) || cam_bounds == nullptr)
+    return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(draw_ray_batch_kernel, dim3(f2n_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t) stream, n_rays, u01, image_set,
+                     n_set, height, width, poses, intri, dist_params, images, cam_bounds, cam_indices, ij, rays_o, rays_d, gt_colors,
+                     bounds);
+  return f2n_launch_status();
+}
 
 int f2n_img2world_rays(void* stream, int n_rays, const float* poses, const float* intri, const float* dist_params,
                        const int32_t* cam_indices, const int32_t* ij, float* rays_o, float* rays_d) {

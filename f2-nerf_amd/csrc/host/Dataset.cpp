@@ -216,17 +216,18 @@ std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysData(int batch_size, in
     it = set_on_device_.emplace(sets, torch::from_blob(img_idx.data(), {(int64_t) img_idx.size()}, CpuI32()).to(torch::kCUDA)).first;
   }
   const Tensor& cur_set = it->second;
-  // every draw on the device: uniform image of the set, uniform pixel (Dataset.cpp:286-291)
-  Tensor cam = cur_set.index({torch::randint(cur_set.size(0), {batch_size}, DevI32().dtype(torch::kInt64))}).contiguous();
-  Tensor i = torch::randint(0, height_, {batch_size}, DevI32()), j = torch::randint(0, width_, {batch_size}, DevI32());
-  Tensor ij = torch::stack({i, j}, -1).contiguous();
+  // every draw on the device: uniform image of the set, uniform pixel (Dataset.cpp:286-291) -- one uniform launch and ONE kernel
+  // that maps the draws, generates the rays and gathers colours and bounds (f2n_draw_ray_batch)
+  Tensor u = torch::rand({batch_size, 3}, DevF32());
+  Tensor cam = torch::empty({batch_size}, DevI32()), ij = torch::empty({batch_size, 2}, DevI32());
+  Tensor rays_o = torch::empty({batch_size, 3}, DevF32()), rays_d = torch::empty({batch_size, 3}, DevF32());
+  Tensor colors = torch::empty({batch_size, 3}, DevF32()), b = torch::empty({batch_size, 2}, DevF32());
+  F2N_CALL(f2n_draw_ray_batch(CurStream(), batch_size, F32P(u), I32P(cur_set), (int) cur_set.size(0), height_, width_, F32P(poses_),
+                              F32P(intri_), F32P(dist_params_), image_tensors_.defined() ? F32P(image_tensors_) : nullptr, F32P(bounds_),
+                              I32P(cam), I32P(ij), F32P(rays_o), F32P(rays_d), image_tensors_.defined() ? F32P(colors) : nullptr, F32P(b)));
   last_cam_indices_ = cam;
   last_ij_ = ij;
-  auto rays = Img2WorldRayFlex(cam, ij);
-  Tensor colors = torch::empty({batch_size, 3}, DevF32()), b = torch::empty({batch_size, 2}, DevF32());
-  F2N_CALL(f2n_gather_pixels(CurStream(), batch_size, height_, width_, image_tensors_.defined() ? F32P(image_tensors_) : nullptr,
-                             F32P(bounds_), I32P(cam), I32P(ij), image_tensors_.defined() ? F32P(colors) : nullptr, F32P(b)));
-  return {{rays.origins, rays.dirs, b}, image_tensors_.defined() ? colors : Tensor(), cam};
+  return {{rays_o, rays_d, b}, image_tensors_.defined() ? colors : Tensor(), cam};
 }
 
 }  // namespace f2n

@@ -602,6 +602,13 @@ int f2n_img2world_rays(void* stream, int n_rays, const float* poses, const float
  * ([C,2]); either output may be NULL. */
 int f2n_gather_pixels(void* stream, int n_rays, int height, int width, const float* images, const float* cam_bounds,
                       const int32_t* cam_indices, const int32_t* ij, float* gt_colors /*[n,3]*/, float* bounds /*[n,2]*/);
+/* Dataset::RandRaysData (Dataset/Dataset.cpp:275-298) in one launch: u01 [R,3] uniforms in [0,1) pick an image of image_set
+ * (n_set entries) and a pixel (i = floor(u1 * height), j = floor(u2 * width)); then f2n_img2world_rays and f2n_gather_pixels for
+ * those draws.  Outputs: cam_indices [R], ij [R,2], rays_o / rays_d [R,3], gt_colors [R,3] (or NULL), bounds [R,2]. */
+int f2n_draw_ray_batch(void* stream, int n_rays, const float* u01, const int32_t* image_set, int n_set, int height, int width,
+                       const float* poses, const float* intri, const float* dist_params, const float* images /*or NULL*/,
+                       const float* cam_bounds, int32_t* cam_indices, int32_t* ij, float* rays_o, float* rays_d,
+                       float* gt_colors /*or NULL*/, float* bounds);
 
 /* ---------------------------------------------------------------------------------------------------
  * Optimiser -- replaces torch::optim::Adam::step over the groups of Hash3DAnchored::OptimParamGroups

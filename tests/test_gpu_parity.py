@@ -1245,6 +1245,26 @@ def test_img2world_rays_and_pixel_gather(hip, fox_state, fox_golden):
     col = torch.zeros((3000, 3), device=DEV); bnd = torch.zeros((3000, 2), device=DEV)
     hip.gather_pixels(3000, h, w, T(images), T(cb), T(cam2), T(ij2), col, bnd)
     assert_same(N(col), images[cam2, ij2[:, 0], ij2[:, 1]], "pixels"); assert_same(N(bnd), cb[cam2], "bounds")
+    # Dataset::RandRaysData in one launch (f2n_draw_ray_batch): the draws it reports, pushed through the two kernels above, give
+    # the rays / colours / bounds it wrote; images come from the set only, pixels cover the whole image
+    nC = len(st["poses"])
+    imgs = rng.random((nC, 9, 11, 3), dtype=F32); cbn = rng.random((nC, 2), dtype=F32)
+    subset = np.array([i for i in range(nC) if i % 8 != 0], np.int32)
+    nb = 50000
+    u = rng.random((nb, 3), dtype=F32); u[0] = [0.0, 0.0, 0.0]; u[1] = np.nextafter(F32(1), F32(0))
+    cam3 = torch.zeros(nb, dtype=torch.int32, device=DEV); ij3 = torch.zeros((nb, 2), dtype=torch.int32, device=DEV)
+    o3 = torch.zeros((nb, 3), device=DEV); d3 = torch.zeros((nb, 3), device=DEV)
+    c3 = torch.zeros((nb, 3), device=DEV); b3 = torch.zeros((nb, 2), device=DEV)
+    hip.draw_ray_batch(nb, T(u), T(subset), 9, 11, T(st["poses"]), T(st["intri"]), T(st["dist_params"]), T(imgs), T(cbn), cam3, ij3, o3, d3,
+                       c3, b3)
+    cam_h, ij_h = N(cam3), N(ij3)
+    assert np.isin(cam_h, subset).all() and set(np.unique(cam_h)) == set(subset.tolist())
+    assert ij_h.min() == 0 and ij_h[:, 0].max() == 8 and ij_h[:, 1].max() == 10
+    assert cam_h[0] == subset[0] and (ij_h[0] == 0).all() and cam_h[1] == subset[-1] and (ij_h[1] == [8, 10]).all()
+    o4 = torch.zeros((nb, 3), device=DEV); d4 = torch.zeros((nb, 3), device=DEV)
+    hip.img2world_rays(nb, T(st["poses"]), T(st["intri"]), T(st["dist_params"]), cam3, ij3, o4, d4)
+    assert_same(N(o3), N(o4), "drawn origins"); assert_same(N(d3).view(np.uint32), N(d4).view(np.uint32), "drawn directions")
+    assert_same(N(c3), imgs[cam_h, ij_h[:, 0], ij_h[:, 1]], "drawn colours"); assert_same(N(b3), cbn[cam_h], "drawn bounds")
 
 
 def test_empty_and_ragged_inputs(hip, fox_state):

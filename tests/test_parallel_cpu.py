@@ -214,3 +214,76 @@ def test_broadcast_replicates_checkpoint_vector_and_edge_pool_gloo(tmp_path):
         for a, b in zip(got["st"] + got["aux"], want.st + want.aux):
             assert a.numel() == b.numel() and a.dtype == b.dtype
             assert torch.equal(a.reshape(-1), b.reshape(-1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the arithmetic of the gradient exchange at world size 8, and bench.py's multi-GPU launcher.
+# ---------------------------------------------------------------------------------------------------------------------
+def _avg8_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import parallel
+    t = torch.from_numpy(np.load(os.path.join(out_dir, "avg8_in.npy"))[rank].copy())
+    parallel._avg_(t)
+    np.save(os.path.join(out_dir, "avg8_out_%d.npy" % rank), t.numpy())
+    dist.destroy_process_group()
+
+
+def test_f16_gradient_average_over_eight_ranks_neither_overflows_nor_flushes(tmp_path):
+    """The hash-gradient table travels as x128 loss-scaled binary16 and is AVERAGED over the ranks (parallel._avg_ on gloo;
+    ncclAvg on the C++ host's communicator, DataParallel.cpp).  Eight ranks, adversarial columns: (a) every rank at the f16
+    maximum -- a sum-then-divide in f16 would be inf; (b) the smallest normal on one rank only -- its mean is a subnormal and
+    must survive; (c) the smallest subnormal x 8 on every rank; (d) mixed signs that cancel; (e) ordinary gradients.  Every
+    rank must end with round_f16(exact mean).  The same columns through the pre-multiply-then-sum arithmetic in f16 that
+    NCCL / RCCL document for ncclAvg (each contribution scaled by 1/8 first, partial sums in the buffer's type): no overflow
+    either, and within one f16 ulp of the largest contribution per hop of the exact mean."""
+    world = 8
+    rng = np.random.default_rng(2024)
+    n = 4096
+    x = (rng.standard_normal((world, n)) * 3.0).astype(np.float16)                   # (e)
+    x[:, 0] = np.float16(65504.0)                                                      # (a)
+    x[:, 1] = 0; x[3, 1] = np.float16(2.0 ** -14)                                      # (b)
+    x[:, 2] = np.float16(8 * 2.0 ** -24)                                               # (c)
+    x[:, 3] = np.float16(1000.0) * np.where(np.arange(world) % 2 == 0, 1, -1)          # (d)
+    x[:, 4] = np.float16(-65504.0)
+    np.save(tmp_path / "avg8_in.npy", x)
+    mp.spawn(_avg8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    exact = x.astype(np.float64).mean(0)
+    want = exact.astype(np.float16)
+    for r in range(world):
+        got = np.load(tmp_path / ("avg8_out_%d.npy" % r))
+        assert np.isfinite(got.astype(np.float32)).all()
+        assert (got.view(np.uint16) == want.view(np.uint16)).all(), r
+    assert want[0] == np.float16(65504.0) and want[4] == np.float16(-65504.0) and want[1] == np.float16(2.0 ** -17) and want[3] == 0
+    assert want[2] == np.float16(8 * 2.0 ** -24)
+    # ncclAvg as documented (PreMulSum with 1/nranks, arithmetic in the buffer's type): ring order 0..7
+    acc = (x[0].astype(np.float32) / 8).astype(np.float16)
+    for r in range(1, world):
+        acc = (acc.astype(np.float32) + (x[r].astype(np.float32) / 8).astype(np.float16).astype(np.float32)).astype(np.float16)
+    assert np.isfinite(acc.astype(np.float32)).all()
+    assert acc[0] == np.float16(65504.0)                       # no overflow at the maximum
+    assert acc[2] == np.float16(8 * 2.0 ** -24)                # subnormal contributions of 2^-24 each still add up
+    ulp = np.maximum(np.abs(x.astype(np.float64)).max(0), 2.0 ** -14) * 2.0 ** -10   # of the largest contribution of a column
+    assert (np.abs(acc.astype(np.float64) - exact) <= 8 * ulp).all()
+
+
+def test_bench_multi_gpu_launcher_dry_run():
+    """`python bench.py --gpus 8` outside a launcher re-executes itself under torch.distributed.run with eight ranks on
+    127.0.0.1 (what the driver does itself); the command is checked without running it (F2N_BENCH_DRY_RUN=1), and a rank
+    count that does not match WORLD_SIZE is refused."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["F2N_BENCH_DRY_RUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "3"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    cmd = r.stdout.strip().splitlines()[-1].split()
+    assert "torch.distributed.run" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "7", "--warmup", "3"] and cmd[-7].endswith("bench.py")
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=2" in (r2.stderr + r2.stdout)
