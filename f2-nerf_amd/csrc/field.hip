@@ -410,7 +410,9 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 // records it holds, so with the ~2.6e5 samples of an ExpRunner::Train batch 128 chunks left the owners latency-bound on
 // mostly empty segments (0.09 ms, the same as for 8e5 samples).  Fewer, fuller segments: the queue memory of a (level,
 // slice) is split into nb segments of capacity cap * 128 / nb; producer blocks with B >= nb exit at once.
-__device__ __forceinline__ int f2n_bin_nb(int n_true) { return n_true > 393216 ? 128 : n_true > 131072 ? 64 : 32; }
+__device__ __forceinline__ int f2n_bin_nb(int n_true, int force = 0) {
+  return force > 0 ? force : n_true > 393216 ? 128 : n_true > 131072 ? 64 : 32;
+}
 #define F2N_BIN_MAX_BINS 1024  // tables up to 2^22 entries per level (BASELINE config 5)
 #define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
@@ -422,6 +424,7 @@ struct F2nBinQueues {
   uint2* rec;      // [16 levels][n_bins][NB][cap]
   int32_t* cnt;    // [16 levels][n_bins][NB]
   int cap, n_bins;
+  int nb_force;  // 0, or the chunk count to use whatever the sample count (F2N_BIN_NB: measurement knob)
 };
 
 __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHashArgs h, const int32_t* __restrict__ local_idx,
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   F2N_RAISE_PRIO();
   if (n_dev != nullptr) n = min(n, *n_dev + n_off);  // the row count is still on the device
   const int l = blockIdx.x % F2N_N_LEVELS, B = blockIdx.x / F2N_N_LEVELS;
-  const int nb = f2n_bin_nb(n);
+  const int nb = f2n_bin_nb(n, q.nb_force);
   if (B >= nb) return;  // (block-uniform, before any barrier)
   chunk = (((n + nb - 1) / nb) + 255) & ~255;  // split what there really is over the producer blocks in use
   const int cap_nb = q.cap * (F2N_BIN_NB / nb);
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   const int H = slices_per_half_level, g = blockIdx.x;
   const int l1 = g / H, b1 = g - l1 * H;
   if (n_dev != nullptr) n = min(n, *n_dev + n_off);
-  const int nb = f2n_bin_nb(n), cap_nb = q.cap * (F2N_BIN_NB / nb);  // the producers' choice (same function of the same count)
+  const int nb = f2n_bin_nb(n, q.nb_force), cap_nb = q.cap * (F2N_BIN_NB / nb);  // the producers' choice (same function of the same count)
   // 2 sources x nb segments; wave w owns segments w, w+4, ...: lane j keeps the length of segment w + 4j
   const int seg = wave + 4 * lane;                       // 0 .. 255, of which 0 .. 2*nb-1 exist
   const int src = seg / nb, B = seg % nb;
@@ -583,8 +586,12 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
       atomicAdd(&s_acc[2 * rec.x + 1], (double) val[1]);
     }
   };
-  for (int sg = 0; sg < nb / 2; sg += 8) {  // eight segments at a time: up to sixteen independent loads in flight per lane
-    uint2 rec[16];
+  // Eight segments at a time, the first 256 records of each with FOUR coalesced 8-byte loads per lane, all 32 of them issued
+  // before any record is added: a segment holds ~150 records at the 2.6e5 samples of an ExpRunner::Train batch, and the
+  // "rest" loop below -- one dependent fabric round trip per segment and 64 records -- used to run for most segments (eight
+  // sequential round trips per batch behind the two prefetched ones: most of this kernel's 0.08 ms).
+  for (int sg = 0; sg < nb / 2; sg += 8) {
+    uint2 rec[32];
     int cnt[8];
     const uint2* r[8];
 #pragma unroll
@@ -592,14 +599,14 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
       cnt[u] = __shfl(my_cnt, sg + u);
       const unsigned long long sidx = __shfl((unsigned long long) my_seg, sg + u);
       r[u] = q.rec + sidx * cap_nb;
-      rec[2 * u] = lane < cnt[u] ? r[u][lane] : uint2{0u, 0u};
-      rec[2 * u + 1] = lane + 64 < cnt[u] ? r[u][lane + 64] : uint2{0u, 0u};
+#pragma unroll
+      for (int k = 0; k < 4; k++) rec[4 * u + k] = lane + 64 * k < cnt[u] ? r[u][lane + 64 * k] : uint2{0u, 0u};
     }
 #pragma unroll
-    for (int u = 0; u < 16; u++) add(rec[u]);
+    for (int u = 0; u < 32; u++) add(rec[u]);
 #pragma unroll
     for (int u = 0; u < 8; u++)  // long segments: the rest
-      for (int i = lane + 128; i < cnt[u]; i += 64) add(r[u][i]);
+      for (int i = lane + 256; i < cnt[u]; i += 64) add(r[u][i]);
   }
   __syncthreads();
   half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
@@ -906,6 +913,12 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
                               const half_t* gx, long ss, long ps, const uint16_t* nz_mask, half_t* grad_table, int level_entries,
                               const int32_t* n_dev = nullptr, int n_off = 0) {
   F2nBinQueues q;
+  static const int nb_force = []() {
+    const char* e = getenv("F2N_BIN_NB");
+    const int v = e != nullptr ? atoi(e) : 0;
+    return (v == 32 || v == 64 || v == 128) ? v : 0;
+  }();
+  q.nb_force = nb_force;
   q.n_bins = level_entries >> F2N_BIN_SHIFT;
   const int chunk = (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255;
   q.cap = (int) (1.25 * 8.0 * (double) chunk / (double) q.n_bins) + 64;
