@@ -548,6 +548,23 @@ Tensor ExpRunner::RenderPathFrame(Dataset& dataset, const Tensor& pose, int res_
   return img;
 }
 
+// ExpRunner::VisualizeImage (ExpRunner.cpp:301-321), the body of RenderAllImages (:295-299): training view idx rendered in
+// VALIDATE mode as the image the reference writes to images/<iter>_<idx>.png -- [H, 4W, 3]: ground truth | colours |
+// first-octree-hit disparity | disparity.
+Tensor ExpRunner::VisualizeImage(Dataset& dataset, int idx) {
+  TORCH_CHECK(dataset.image_tensors_.defined(), "no ground-truth images resident");
+  FinishPending();
+  auto prev = global_data_pool_->mode_;
+  global_data_pool_->mode_ = RunningMode::VALIDATE;
+  auto rays = dataset.RaysOfCamera(idx);
+  auto out = RenderWholeImage(rays.origins, rays.dirs, rays.bounds);
+  const int H = dataset.height_, W = dataset.width_;
+  Tensor img = torch::cat({dataset.image_tensors_[idx].reshape({H, W, 3}), out[0].reshape({H, W, 3}),
+                           out[1].reshape({H, W, 1}).repeat({1, 1, 3}), out[2].reshape({H, W, 1}).repeat({1, 1, 3})}, 1);
+  global_data_pool_->mode_ = prev;
+  return img;
+}
+
 // ExpRunner::RenderPath: every pose of `render_poses` [P,3,4]; `sink(i, image)` receives the frames (the reference writes
 // novel_images/<iter>_<i>.png -- image encoding is outside the hot path and left to the caller).
 void ExpRunner::RenderPath(Dataset& dataset, const Tensor& render_poses, const std::function<void(int, const Tensor&)>& sink,

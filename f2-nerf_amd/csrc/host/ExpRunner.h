@@ -69,6 +69,7 @@ class ExpRunner {
   float TestImagePSNR(Dataset& dataset, int idx);       // 8-bit quantised prediction, as ExpRunner.cpp:360-369
   std::vector<float> TestImages(Dataset& dataset);      // per-view PSNR of the test set, then the mean
   Tensor RenderPathFrame(Dataset& dataset, const Tensor& pose, int res_level = 1);
+  Tensor VisualizeImage(Dataset& dataset, int idx);     // [H, 4W, 3]: gt | colours | first-hit disparity | disparity (ExpRunner.cpp:301-321)
   void RenderPath(Dataset& dataset, const Tensor& render_poses, const std::function<void(int, const Tensor&)>& sink,
                   int res_level = 1);
   void SaveCheckpoint(const std::string& dir);          // <dir>/renderer.pt + <dir>/scalars.pt (ExpRunner.cpp:205-219)

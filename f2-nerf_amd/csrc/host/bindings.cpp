@@ -161,6 +161,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("render_whole_image", &ExpRunner::RenderWholeImage)
       .def("test_image_psnr", &ExpRunner::TestImagePSNR)
       .def("test_images", &ExpRunner::TestImages)
+      .def("visualize_image", &ExpRunner::VisualizeImage)
       .def("render_path_frame", &ExpRunner::RenderPathFrame, py::arg("dataset"), py::arg("pose"), py::arg("res_level") = 1)
       .def("render_path",
            [](ExpRunner& r, Dataset& ds, const Tensor& poses, py::function sink, int res_level) {

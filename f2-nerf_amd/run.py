@@ -165,6 +165,9 @@ def main(argv=None):
             raise FileNotFoundError("poses_render.npy not found under " + data_path)
         runner.render_path(ds, torch.from_numpy(sc["render_poses"]),
                            lambda i, img: save_png(os.path.join(exp_dir, "novel_images", "%d_%03d.png" % (runner.iter_step, i)), img), 1)
+    elif mode == "render_all":  # ExpRunner::RenderAllImages (ExpRunner.cpp:295-299): every image of the data set, as VisualizeImage writes it
+        for idx in range(int(ds.n_images)):
+            save_png(os.path.join(exp_dir, "images", "%d_%d.png" % (runner.iter_step, idx)), runner.visualize_image(ds, idx))
     else:
         raise ValueError("unknown mode: %s" % mode)
     return 0

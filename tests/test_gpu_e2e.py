@@ -574,7 +574,8 @@ def test_launcher_train_test_render_path(rt, tmp_path):
     """f2_nerf_amd.run == scripts/run.py + main.cpp + ExpRunner::Execute of the reference, on a data directory in the
     reference's layout (cams_meta.npy, images_4/*.png, poses_render.npy) written from a small synthetic forward-facing rig:
     mode=train leaves checkpoints (renderer.pt + scalars.pt, `latest` links), train_info.txt and test_images/info.yaml;
-    mode=test with is_continue reproduces the PSNR from the checkpoint; mode=render_path writes the novel views."""
+    mode=test with is_continue reproduces the PSNR from the checkpoint; mode=render_path writes the novel views; mode=render_all
+    the side-by-side images of every view."""
     import yaml
     from PIL import Image
     from f2_nerf_amd import rigs, run
@@ -604,6 +605,12 @@ def test_launcher_train_test_render_path(rt, tmp_path):
     frames = sorted(os.listdir(exp / "novel_images"))
     assert frames == ["60_000.png", "60_001.png", "60_002.png"]
     assert Image.open(exp / "novel_images" / frames[0]).size == (3 * 64, 48)
+    # mode=render_all (ExpRunner::RenderAllImages): every image of the data set as VisualizeImage writes it -- gt | colours |
+    # first-hit disparity | disparity side by side
+    assert run.main(common + ["mode=render_all", "is_continue=true"]) == 0
+    imgs = sorted(os.listdir(exp / "images"))
+    assert len(imgs) == len(meta) and all(f.startswith("60_") for f in imgs)
+    assert Image.open(exp / "images" / imgs[0]).size == (4 * 64, 48)
 
 
 def test_two_rank_bench_when_two_gpus_are_visible():
