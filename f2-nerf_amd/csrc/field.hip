@@ -1068,6 +1068,23 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
   return f2n_field_mlp_planes(stream, n, planes, mlp_params_h, out_feat_f32, out_f0, save_x_h);
 }
 
+// The one-kernel gather -> MLP of the small-batch path at ANY size (the north star's "features staged on-chip as the MFMA tile"):
+// a wave gathers all 16 levels of its 16 samples and feeds the matrix cores from registers, no planes in HBM.  What it gives
+// up is the XCD-aware level partition (every wave touches all 16 levels: each L2 sees the whole table).  Kept as the A/B
+// comparator of the partitioned pipeline (profiles/r04_fused_gather_ab.txt), not used by the host at n >= F2N_PARTITION_MIN_N.
+int f2n_field_fwd_fused(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool, const int32_t* local_idx,
+                        const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts_warped,
+                        const int32_t* volume_idx, int vol_stride, const void* mlp_params_h, float* out_feat_f32, float* out_f0,
+                        void* save_x_h) {
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1) return F2N_ERR_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
+  hipLaunchKernelGGL((field_fwd_kernel<1, true, true>), dim3(f2n_wave_grid((n + 15) / 16, 4)), dim3(F2N_FWD_THREADS), 0,
+                     (hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, nullptr,
+                     (const half_t*) mlp_params_h, out_feat_f32, nullptr, out_f0, (half_t*) save_x_h, nullptr, nullptr, nullptr, nullptr);
+  return f2n_launch_status();
+}
+
 int f2n_gather_plan_query(int n_tiles, float step01, const float* level_scale_host, int32_t* out, float* cost8_out) {
   if (n_tiles < 0 || out == nullptr) return F2N_ERR_INVALID_ARG;
   F2nGatherPlan plan;

@@ -1,6 +1,8 @@
 // FusedMLP + Hash3DAnchored host logic.
 #include "Hash3DAnchored.h"
 
+#include <cstdlib>
+
 namespace f2n {
 
 using torch::autograd::AutogradContext;
@@ -302,7 +304,15 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
   }
   Tensor f0 = torch::empty({n}, DevF32());
   prepass_x_ = keep_features ? torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16()) : Tensor();
-  if (n >= 32768) {  // the two kernels of the large-batch path, issued (and timed) separately
+  static const bool force_fused = []() {  // measurement knob: the one-kernel gather -> MLP at every size (profiles/r04_fused_gather_ab.txt)
+    const char* e = std::getenv("F2N_FUSED_GATHER");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (force_fused) {
+    F2N_TIMED_CALL("field_prepass_fused", f2n_field_fwd_fused(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),
+                           I32P(feat_local_idx_), I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), I32P(av.t),
+                           av.stride, VoidP(mlp_->params_h_), nullptr, F32P(f0), keep_features ? VoidP(prepass_x_) : nullptr));
+  } else if (n >= 32768) {  // the two kernels of the large-batch path, issued (and timed) separately
     Tensor planes = torch::empty({8, n, 4}, DevF16());
     // consecutive samples of a ray are one march step apart: sample_l * fineness in warped space (PersSampler.cu:262-270,
     // stretched by the distance scaling where it is on), half of that in the [0,1] space the grid hashes (:91)

@@ -17,6 +17,12 @@ struct SampleResultFlex {
   // training step parks its 2E edge samples there so that the density pre-pass gathers their hash features in the same
   // launches -- in front, because that offset is known before the sample count is
   int extra_rows = 0;
+  // Streaming training steps (Renderer::PreGenerateStepDraws): the step's background colours and its 2E edge samples, generated
+  // on the sampler's side stream right behind the pack -- the edge points already sit in the extra rows above and at the head of
+  // pts_all / vol_all (worst-case-sized homes of the grad pass's point / warp-index arrays) -- so that the step's main queue
+  // starts with the hash gather instead of a draw launch and an edge-sample launch.
+  bool step_draws_ready = false;
+  Tensor bg_color, pts_all, vol_all;
 };
 
 class PtsSampler : public Pipe {

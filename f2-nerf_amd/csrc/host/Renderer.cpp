@@ -6,6 +6,7 @@
 // loss and backward, untaped, for ExpRunner::TrainStep.
 #include "Renderer.h"
 
+#include <ATen/hip/HIPGeneratorImpl.h>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
@@ -288,6 +289,7 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
   ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s);  // ... up to and including the pack
+  if (global_data_pool_->mode_ == RunningMode::TRAIN) PreGenerateStepDraws(slot);
   presample_done_ev_[slot].record(*side_[slot]);
   pend_[slot].rays_o = rays_o;
   pend_[slot].rays_d = rays_d;
@@ -328,8 +330,44 @@ bool Renderer::PreSampleSpecComplete(int slot) {
     pb = PendingBatch();  // (its kernels are ordered on the side stream, whose pool its buffers return to)
     return false;
   }
+  if (global_data_pool_->mode_ == RunningMode::TRAIN) PreGenerateStepDraws(slot);
   presample_done_ev_[slot].record(*side_[slot]);
   return true;
+}
+
+Tensor Renderer::DrawStepUniforms(int64_t n) {
+  const int dev = c10::hip::current_device();
+  const uint64_t seed = at::cuda::detail::getDefaultCUDAGenerator(dev).current_seed();
+  if (!aux_gen_.defined() || seed != aux_gen_seed_ || aux_gen_.device().index() != dev) {
+    aux_gen_ = at::cuda::detail::createCUDAGenerator(dev);
+    aux_gen_.set_current_seed(seed ^ 0xD1B54A32D192ED03ull);
+    aux_gen_seed_ = seed;
+  }
+  return torch::rand({n}, aux_gen_, DevF32());
+}
+
+// The draws of the step that will consume pend_[slot] (random background, 2E edge samples) and the edge-sample launch itself,
+// queued on that slot's side stream right behind its pack: the packed arrays (front rows) and worst-case-sized pts_all / vol_all
+// are their homes.  Only when nothing is pinned by a test and the background is random (the training configuration).
+void Renderer::PreGenerateStepDraws(int slot) {
+  auto& pb = pend_[slot];
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+  const int n_edge = n_edge_pts_, n_rays = pb.s.n_rays;
+  const int64_t front = 2 * (int64_t) n_edge;
+  if (!pregen_draws_ || n_edge <= 0 || forced_bg_.defined() || bg_color_type_ != BGColorType::rand_noise || ps->forced_edge_idx_.defined() ||
+      ps->forced_edge_coords_.defined() || !pb.s.o_pts.defined() || pb.s.extra_rows < front || ps->pers_octree_->n_edges_ <= 0)
+    return;
+  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
+  const int64_t nb = (int64_t) n_rays * 3, ne = (int64_t) n_edge * 3;
+  Tensor u = DrawStepUniforms(nb + ne);
+  pb.bg_color = u.narrow(0, 0, nb).view({n_rays, 3});
+  const int64_t rows = pb.s.s_dt.numel() + front;  // every ray's slots full: the survivors can never be more
+  pb.pts_all = torch::empty({rows, 3}, DevF32());
+  pb.vol_all = torch::empty({rows}, DevI32());
+  auto& oct = *ps->pers_octree_;
+  F2N_CALL(f2n_edge_samples_ex(CurStream(), n_edge, VoidP(oct.edge_pool_gpu_), oct.n_edges_, VoidP(oct.pers_trans_gpu_), nullptr, nullptr,
+                               F32P(u) + nb, F32P(pb.s.o_pts), I32P(pb.s.o_anchors), 3, F32P(pb.pts_all), I32P(pb.vol_all), 1));
+  pb.step_draws_ready = true;
 }
 
 // Second half: wait for the counts (by now the march has usually finished) and take views of the packed rows.  No launch.
@@ -344,6 +382,10 @@ void Renderer::PreSampleFinish(int slot) {
   }
   if (!pb.s.completed && !PreSampleSpecComplete(slot)) return;  // (a speculative batch whose step never reached its update)
   presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pb.s);
+  presampled_.step_draws_ready = pb.step_draws_ready;
+  presampled_.bg_color = pb.bg_color;
+  presampled_.pts_all = pb.pts_all;
+  presampled_.vol_all = pb.vol_all;
   has_presample_ = true;
   presample_async_ = true;
   presample_slot_ = slot;
@@ -409,35 +451,9 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     spec_start_ev_.record();
     spec_start_recorded_ = true;
   }
-  // Random draws of the step (Renderer.cpp:67-81 background, PersSampler.cu:456-457 edge samples): ONE uniform launch for both
-  // unless a test pinned either (the edge kernel maps three uniforms to an edge index and two coordinates in [-1,1)).
-  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
-  const int n_edge = train ? n_edge_pts_ : 0;
-  const bool draw_bg = !forced_bg_.defined() && bg_color_type_ == BGColorType::rand_noise && train;
-  const bool draw_edge = n_edge > 0 && !ps->forced_edge_idx_.defined() && !ps->forced_edge_coords_.defined();
-  Tensor bg_color, edge_u, edge_idx, edge_coord;
-  if (draw_bg || draw_edge) {
-    const int64_t nb = draw_bg ? (int64_t) n_rays * 3 : 0, ne = draw_edge ? (int64_t) n_edge * 3 : 0;
-    Tensor u = torch::rand({nb + ne}, DevF32());
-    if (draw_bg) bg_color = u.narrow(0, 0, nb).view({n_rays, 3});
-    if (draw_edge) edge_u = u.narrow(0, nb, ne);
-  }
-  if (n_edge > 0 && !draw_edge) {
-    auto& oct = *ps->pers_octree_;
-    edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
-                                              : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
-    edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
-                                                   : torch::empty({n_edge, 2}, DevF32()).uniform_(-1.f, 1.f);
-  }
-  if (!draw_bg) {  // Renderer.cpp:67-81
-    if (forced_bg_.defined()) bg_color = forced_bg_.contiguous();
-    else if (bg_color_type_ == BGColorType::white) bg_color = torch::ones({n_rays, 3}, DevF32());
-    else if (bg_color_type_ == BGColorType::rand_noise) bg_color = torch::full({n_rays, 3}, .5f, DevF32());  // (not training)
-    else bg_color = torch::zeros({n_rays, 3}, DevF32());
-  }
-
   // A prefetch whose kernels were queued by the previous step: only now does the host wait for its count (everything between
-  // the end of that step and this point -- the caller's loop, this step's bookkeeping, the draws above -- overlaps the march).
+  // the end of that step and this point -- the caller's loop, this step's bookkeeping -- overlaps the march).
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   if (train) {
     // (batches in flight for other rays than this step's, the next step's or the one after: void)
     KeepOnlyPending(rays_o, rays_d, next_batch_.valid ? next_batch_.rays_o : Tensor(), next_batch_.valid ? next_batch_.rays_d : Tensor(),
@@ -476,6 +492,36 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
     sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   }
+  // Random draws of the step (Renderer.cpp:67-81 background, PersSampler.cu:456-457 edge samples): ONE uniform launch for both
+  // unless a test pinned either (the edge kernel maps three uniforms to an edge index and two coordinates in [-1,1)).
+  // A batch that was prefetched brings them along, drawn and turned into edge samples on its side stream behind its pack
+  // (PreGenerateStepDraws): the main queue of the step then starts with the hash gather.
+  const int n_edge = train ? n_edge_pts_ : 0;
+  const bool pregen = train && async_count && sample_result_.step_draws_ready && sample_result_.extra_rows >= 2 * (int64_t) n_edge;
+  const bool draw_bg = !pregen && !forced_bg_.defined() && bg_color_type_ == BGColorType::rand_noise && train;
+  const bool draw_edge = !pregen && n_edge > 0 && !ps->forced_edge_idx_.defined() && !ps->forced_edge_coords_.defined();
+  Tensor bg_color, edge_u, edge_idx, edge_coord;
+  if (pregen) bg_color = sample_result_.bg_color;
+  if (draw_bg || draw_edge) {
+    const int64_t nb = draw_bg ? (int64_t) n_rays * 3 : 0, ne = draw_edge ? (int64_t) n_edge * 3 : 0;
+    Tensor u = DrawStepUniforms(nb + ne);
+    if (draw_bg) bg_color = u.narrow(0, 0, nb).view({n_rays, 3});
+    if (draw_edge) edge_u = u.narrow(0, nb, ne);
+  }
+  if (n_edge > 0 && !draw_edge && !pregen) {
+    auto& oct = *ps->pers_octree_;
+    edge_idx = ps->forced_edge_idx_.defined() ? ps->forced_edge_idx_.contiguous()
+                                              : torch::randint(0, oct.n_edges_, {n_edge}, DevI32()).contiguous();
+    edge_coord = ps->forced_edge_coords_.defined() ? ps->forced_edge_coords_.contiguous()
+                                                   : torch::empty({n_edge, 2}, DevF32()).uniform_(-1.f, 1.f);
+  }
+  if (!draw_bg && !pregen) {  // Renderer.cpp:67-81
+    if (forced_bg_.defined()) bg_color = forced_bg_.contiguous();
+    else if (bg_color_type_ == BGColorType::white) bg_color = torch::ones({n_rays, 3}, DevF32());
+    else if (bg_color_type_ == BGColorType::rand_noise) bg_color = torch::full({n_rays, 3}, .5f, DevF32());  // (not training)
+    else bg_color = torch::zeros({n_rays, 3}, DevF32());
+  }
+
   int n_all_pts = sample_result_.pts.size(0);
   last_n_all_pts_ = n_all_pts;
   // The NEXT batch's intersection and march start now, on the side stream, against the octree as it stands (see Renderer.h):
@@ -582,9 +628,14 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       const int64_t n_rows = (int64_t) n_all_pts + front;
       Tensor pts_full = sample_result_.pts.as_strided({n_rows, 3}, {3, 1}, sample_result_.pts.storage_offset() - 3 * front);
       Tensor anchors_full = sample_result_.anchors.as_strided({n_rows, 3}, {3, 1}, sample_result_.anchors.storage_offset() - 3 * front);
-      pts_all = torch::empty({n_rows, 3}, DevF32());
-      vol_all = torch::empty({n_rows}, DevI32());
-      edge_samples_to(F32P(pts_full), I32P(anchors_full), 3, F32P(pts_all), I32P(vol_all));
+      if (pregen) {  // (already generated into the front rows and into these two arrays, on the batch's side stream)
+        pts_all = sample_result_.pts_all.narrow(0, 0, n_rows);
+        vol_all = sample_result_.vol_all.narrow(0, 0, n_rows);
+      } else {
+        pts_all = torch::empty({n_rows, 3}, DevF32());
+        vol_all = torch::empty({n_rows}, DevI32());
+        edge_samples_to(F32P(pts_full), I32P(anchors_full), 3, F32P(pts_all), I32P(vol_all));
+      }
       pack_done();
       f0_full = field->QueryDensityPreAct(pts_full, anchors_full, /*keep_features=*/true);
       f0p = F32P(f0_full) + front;

@@ -81,7 +81,18 @@ class Renderer : public Pipe {
   struct PendingBatch {
     PendingSamples s;
     Tensor rays_o, rays_d;
+    bool step_draws_ready = false;  // PreGenerateStepDraws ran behind this batch's pack
+    Tensor bg_color, pts_all, vol_all;
   };
+  // the background colours and edge samples of the step that will consume pend_[slot], on that slot's side stream (behind its pack)
+  void PreGenerateStepDraws(int slot);
+  // The random draws a training step makes for itself (background colours, edge samples: Renderer.cpp:67-81, PersSampler.cu:456-457)
+  // come from their own generator, re-seeded with the default generator's seed (as the march noise, PersSampler::BeginSamples):
+  // the k-th training step gets the k-th draw whether it is made at the top of that step or a step earlier on a side stream.
+  at::Generator aux_gen_;
+  uint64_t aux_gen_seed_ = 0;
+  Tensor DrawStepUniforms(int64_t n);
+  bool pregen_draws_ = true;
   PendingBatch pend_[kPendingSlots];
   int FindPending(const Tensor& rays_o, const Tensor& rays_d) const {
     for (int i = 0; i < kPendingSlots; i++)

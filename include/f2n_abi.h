@@ -371,6 +371,12 @@ int f2n_field_fwd(void* stream, int n, int n_volumes, const void* table_h, const
                   const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
                   const float* level_scale, const float* pts_warped, const int32_t* volume_idx, int vol_stride,
                   const void* mlp_params_h, float* out_feat_f32, float* out_f0, void* save_x_h);
+/* f2n_field_fwd's one-kernel path (hash gather -> MLP inside one wave, features never in HBM) at ANY batch size: the A/B
+ * comparator of the XCD-partitioned gather + plane-fed MLP that f2n_field_fwd uses for large batches.  Same results. */
+int f2n_field_fwd_fused(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool, const int32_t* local_idx,
+                        const int32_t* local_size, const float* bias_pool, const float* level_scale, const float* pts_warped,
+                        const int32_t* volume_idx, int vol_stride, const void* mlp_params_h, float* out_feat_f32 /*or NULL*/,
+                        float* out_f0 /*or NULL*/, void* save_x_h /*or NULL*/);
 
 /* The two halves of f2n_field_fwd's large-batch path, callable on their own.
  * f2n_hash_gather_planes: the 16-level gather with an XCD-aware partition -- workgroup b serves levels (2p, 2p+1),
