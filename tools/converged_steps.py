@@ -44,7 +44,7 @@ def timed(tag=""):
     c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)
     if args.kernel_timing:
         runtime.host().ExpRunner.enable_kernel_timing(["ray_march", "oct_intersect", "field_bwd", "hash_gather", "shade_bwd", "oct_repair", "march_repair",
-                                                       "field_shade_fwd", "pack_samples", "early_stop"])
+                                                       "field_shade_fwd", "pack_samples", "early_stop", "field_prepass_fused", "field_mlp_prepass", "composite_train"])
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(6 + i)
