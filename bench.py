@@ -329,6 +329,7 @@ def main():
                     "spec_depth_); -1 = host default")
     ap.add_argument("--march-blocks", type=int, default=-1, help="A/B: > 0 marches speculative batches on that many persistent one-wave "
                     "blocks (rays sorted by leaf count), 0 on one block per four rays; -1 = host default")
+    ap.add_argument("--march-blocks-near", type=int, default=-1, help="A/B: the same for batches begun ONE step ahead; -1 = host default")
     ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
                     "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
     ap.add_argument("--lds-octree", type=int, default=-1, help="A/B: 0 walks the octree through the L2s even when its interior nodes "
@@ -397,6 +398,8 @@ def main():
         runner.speculation_depth = args.speculation_depth
     if args.march_blocks >= 0:
         runner.march_blocks = args.march_blocks
+    if args.march_blocks_near >= 0:
+        runner.march_blocks_near = args.march_blocks_near
     if args.lds_octree >= 0:
         runner.lds_octree = bool(args.lds_octree)
     if args.optimistic_pack >= 0:

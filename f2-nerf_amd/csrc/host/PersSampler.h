@@ -121,6 +121,8 @@ class PersSampler : public PtsSampler {
   // > 0: speculative batches are marched by this many persistent one-wave blocks, rays sorted by leaf count
   // (f2n_ray_march_persistent): a small footprint underneath the main queue's kernels, for batches that have two steps to finish
   int march_blocks_ = 512;
+  int march_blocks_near_ = 0;       // the same for batches begun ONE step ahead (0: one block per four rays); measurement knob
+  bool persistent_near_ = false;
   bool persistent_march_ = false;  // set by the Renderer around the BeginSamples of a batch that is begun two steps ahead
   int LdsWalkMaxInterior() const { return lds_octree_ ? f2n_oct_lds_max_interior() : 0; }
   bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)

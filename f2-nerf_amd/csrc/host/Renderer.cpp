@@ -550,9 +550,10 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       n_spec_fallback_++;
       return;
     }
-    ps->persistent_march_ = ahead >= 1;  // (two steps to finish in: a few hundred resident waves do it)
+    ps->persistent_march_ = ahead >= 1 || ps->march_blocks_near_ > 0;  // (two steps to finish in: a few hundred resident waves do it)
+    ps->persistent_near_ = ahead < 1;
     PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness);
-    ps->persistent_march_ = false;
+    ps->persistent_march_ = ps->persistent_near_ = false;
     n_speculative_++;
   };
   if (train) {

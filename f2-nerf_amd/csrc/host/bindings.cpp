@@ -306,6 +306,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("march_blocks",  // > 0: speculative batches marched on that many persistent one-wave blocks (0: one block per 4 rays)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_; },
                     [](ExpRunner& r, int n) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_ = std::max(0, n); })
+      .def_property("march_blocks_near",  // the same for batches begun one step ahead (0: classic launch)
+                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_near_; },
+                    [](ExpRunner& r, int n) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_near_ = std::max(0, n); })
       .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })
