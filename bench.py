@@ -330,6 +330,8 @@ def main():
     ap.add_argument("--march-blocks", type=int, default=-1, help="A/B: > 0 marches speculative batches on that many persistent one-wave "
                     "blocks (rays sorted by leaf count), 0 on one block per four rays; -1 = host default")
     ap.add_argument("--march-blocks-near", type=int, default=-1, help="A/B: the same for batches begun ONE step ahead; -1 = host default")
+    ap.add_argument("--spec-at-step-end", type=int, default=-1, help="A/B: small trees: 1 begins the batch after next when a step's "
+                    "backward is queued, 0 at the top of the next step; -1 = host default")
     ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
                     "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
     ap.add_argument("--lds-octree", type=int, default=-1, help="A/B: 0 walks the octree through the L2s even when its interior nodes "
@@ -400,6 +402,8 @@ def main():
         runner.march_blocks = args.march_blocks
     if args.march_blocks_near >= 0:
         runner.march_blocks_near = args.march_blocks_near
+    if args.spec_at_step_end >= 0:
+        runner.spec_at_step_end = bool(args.spec_at_step_end)
     if args.lds_octree >= 0:
         runner.lds_octree = bool(args.lds_octree)
     if args.optimistic_pack >= 0:

@@ -104,6 +104,10 @@ int PersOctree::QuietEpochs() const {
   return epoch_ - last;
 }
 
+bool PersSampler::MaintenanceDueAt(int it) const {
+  return (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= it) || it % compact_freq_ == 0;
+}
+
 bool PersSampler::MaintenanceDue(int ahead) const {  // the conditions of FinishOctUpdate below, for the iteration in progress ... + ahead
   for (int d = 0; d <= ahead; d++) {
     const int it = global_data_pool_->iter_step_ + d;

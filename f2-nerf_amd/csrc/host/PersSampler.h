@@ -129,6 +129,7 @@ class PersSampler : public PtsSampler {
   // a FinishOctUpdate of the iteration in progress or of one of the `ahead` iterations behind it runs ProcOctree
   // (milestone / compact_freq, PersSampler.cu:605-614)
   bool MaintenanceDue(int ahead = 0) const;
+  bool MaintenanceDueAt(int iter) const;  // ... of iteration `iter`
   SampleResultFlex FinishSamples(PendingSamples& p);
   std::tuple<Tensor, Tensor> GetEdgeSamples(int n_pts) override;
   void UpdateOctNodes(const SampleResultFlex& sample_result, const Tensor& sampled_weights,

@@ -317,6 +317,22 @@ void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& 
   pend_[slot].rays_d = rays_d;
 }
 
+void Renderer::SpecBeginAtStepEnd() {
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+  auto* gdp = global_data_pool_;
+  const NextBatch& nb = next2_batch_;
+  if (!nb.valid || gdp->mode_ != RunningMode::TRAIN || speculative_sampling_ == 0 || FindPending(nb.rays_o, nb.rays_d) >= 0) return;
+  const bool big_tree = ps->pers_octree_->n_interior_ > ps->LdsWalkMaxInterior();
+  if (spec_depth_ >= 3 || (spec_depth_ == 2 && big_tree)) return;  // (two-deep regime: begun at the top of this step already)
+  const bool quiet = ps->pers_octree_->QuietEpochs() >= kSpecQuietEpochs;
+  const int slot = FreePendingSlot();
+  if (!(speculative_sampling_ == 1 || quiet) || slot < 0 || ps->MaintenanceDueAt(gdp->iter_step_ + 1)) return;
+  spec_start_recorded_ = false;  // (the side stream starts behind what this step has queued so far)
+  PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness);
+  spec_start_recorded_ = false;
+  n_speculative_++;
+}
+
 // ... and its completion, called with this step's stat update issued (octree_ready_ev_ recorded): repair, scan, count, pack.
 bool Renderer::PreSampleSpecComplete(int slot) {
   auto& pb = pend_[slot];

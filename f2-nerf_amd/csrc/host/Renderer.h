@@ -155,6 +155,13 @@ class Renderer : public Pipe {
   int spec_depth_ = 2;
   int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
   void PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness);
+  // Small trees (one-step-ahead regime): the batch after next is begun when THIS step's backward has been queued, not at the top
+  // of the next step -- its noise draw, prologue and LDS-resident walk then run underneath the step's Adam / reduction tail (an
+  // HBM stream: the vector units are idle) instead of colliding with the next step's gather, whose long-lived blocks keep a
+  // newly dispatched small kernel waiting for a wave slot (measured: 0.29 ms for the 9 k-element noise draw;
+  // profiles/r04_fresh_timeline.txt).  The step's own stat update is in the stream already, so the batch is repaired against the
+  // next one only, exactly like a batch begun at the top of the next step.
+  void SpecBeginAtStepEnd();
   bool PreSampleSpecComplete(int slot);  // false: could not be repaired (tree re-numbered): dropped
   at::cuda::CUDAEvent spec_start_ev_;
   // 1: the side stream of a speculative sampling is ordered behind the point the main stream had reached when the step BEGAN,

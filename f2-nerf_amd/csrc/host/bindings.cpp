@@ -293,6 +293,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("cur_batch_size", &ExpRunner::CurBatchSize)
       .def_readwrite("iter_step", &ExpRunner::iter_step_)
       .def_readwrite("check_nan", &ExpRunner::check_nan_)
+      .def_readwrite("spec_at_step_end", &ExpRunner::spec_at_step_end_)
       .def_readwrite("async_counts", &ExpRunner::async_counts_)
       .def_property("speculative_sampling",  // 0 / False never, 1 / True always, 2 while no leaf has died lately (default)
                     [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },

@@ -872,7 +872,7 @@ def test_persistent_march(hip, n_blocks, record):
         assert (N(ls_g) == N(ls_w)).all()                        # (untouched entries keep the fill value on both sides)
 
 
-@pytest.mark.parametrize("tail,depth", [(True, 2), (True, 1), (False, 1)])
+@pytest.mark.parametrize("tail,depth", [(True, 3), (True, 2), (True, 1), (False, 1)])
 def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, tail, depth):
     """ExpRunner::TrainStep with the next batch's sampling issued speculatively (Renderer::PreSampleSpecBegin / Complete)
     against the same steps with the sampling behind the stat update: per-step sample counts, node array and occupancy
@@ -901,8 +901,11 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, ta
         runner.n_edge_pts = NE
         runner.speculative_sampling = spec
         runner.tail_repair = tail  # (repair by list compaction + tail march, or by a second walk + march from the origin)
-        runner.speculation_depth = 3 if depth == 2 else 1  # (3: the batch after next is ALWAYS walked two steps ahead of its use,
-        runner.march_blocks = 96                           #  on a small persistent grid; the default does so for big octrees only)
+        # depth 3: the batch after next is ALWAYS walked two steps ahead of its use, on a small persistent grid; 2 (the default):
+        # only for big octrees -- on this small one it is begun when a step's backward has been queued (Renderer::SpecBeginAtStepEnd);
+        # 1: the next batch only, from the top of the step
+        runner.speculation_depth = depth
+        runner.march_blocks = 96
         torch.manual_seed(11)  # the same noise / background / edge draws in both runs
         log = []
         nb = [t.to(DEV, non_blocking=True) for t in host_batches[0]]
@@ -914,7 +917,7 @@ def test_speculative_training_equals_sampling_after_the_update(rt, fox_state, ta
             for _ in range(8):  # the device is kept behind the host: the next batches' rays are still to be written when ...
                 busy = (busy @ busy).clamp_(-1.0, 1.0)
             nb2 = [t.to(DEV, non_blocking=True) for t in host_batches[it + 2]]  # ... their (speculative) sampling is queued
-            if depth == 2:
+            if depth >= 2:
                 s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2], nb2[0], nb2[1])
             else:
                 s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
