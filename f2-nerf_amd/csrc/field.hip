@@ -316,6 +316,7 @@ __device__ __forceinline__ int f2n_row_shl1_i(int v, int fill) {  // lane c read
 // and only the last lane of each run owns a contribution: v[2d + ch] = run total for corner d, channel ch (the
 // reference rounds every addend to f16 and every partial sum; this is the same sum with fewer roundings).
 // Returns true on the last lane of a run.  EVERY lane of the wave must call this (lanes without a sample pass 0).
+__device__ int f2n_combine_min = 0;
 __device__ __forceinline__ bool f2n_combine_runs(const F2nCell& cell, int vol, int c, float g0, float g1, float* v) {
   const bool same_as_prev = c > 0 && f2n_row_shr_i<1>((int) cell.p[0], -1) == (int) cell.p[0] &&
                             f2n_row_shr_i<1>((int) cell.p[1], -1) == (int) cell.p[1] &&
@@ -327,7 +328,11 @@ __device__ __forceinline__ bool f2n_combine_runs(const F2nCell& cell, int vol, i
     v[2 * d] = g0 * cell.w[d];
     v[2 * d + 1] = g1 * cell.w[d];
   }
-  if (__ballot(same_as_prev) == 0ull) return tail;  // no run longer than one sample in this wave (the fine levels)
+  // no run longer than one sample in this wave (the fine levels) -- or so few (F2N_COMBINE_MIN, a measurement knob: 0 = any) that
+  // the segmented scan below (~200 instructions per tile) costs more than the records it saves
+  if (__popcll(__ballot(same_as_prev)) <= f2n_combine_min) {
+    return true;  // every lane is its own run: head and tail
+  }
   int f = head;
 #define F2N_SEG_STEP(K)                                   \
   {                                                       \
@@ -920,6 +925,12 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
     return (v == 32 || v == 64 || v == 128) ? v : 0;
   }();
   q.nb_force = nb_force;
+  static const bool combine_min_set = []() {
+    const char* e = getenv("F2N_COMBINE_MIN");
+    const int v = e != nullptr ? atoi(e) : 0;
+    return v == 0 || hipMemcpyToSymbol(HIP_SYMBOL(f2n_combine_min), &v, sizeof(int)) == hipSuccess;
+  }();
+  (void) combine_min_set;
   static const int acc_dbg = []() {
     const char* e = getenv("F2N_ACC_DBG");
     return e != nullptr ? atoi(e) : 0;
