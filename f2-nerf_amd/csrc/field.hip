@@ -316,7 +316,6 @@ __device__ __forceinline__ int f2n_row_shl1_i(int v, int fill) {  // lane c read
 // and only the last lane of each run owns a contribution: v[2d + ch] = run total for corner d, channel ch (the
 // reference rounds every addend to f16 and every partial sum; this is the same sum with fewer roundings).
 // Returns true on the last lane of a run.  EVERY lane of the wave must call this (lanes without a sample pass 0).
-__device__ int f2n_combine_min = 0;
 __device__ __forceinline__ bool f2n_combine_runs(const F2nCell& cell, int vol, int c, float g0, float g1, float* v) {
   const bool same_as_prev = c > 0 && f2n_row_shr_i<1>((int) cell.p[0], -1) == (int) cell.p[0] &&
                             f2n_row_shr_i<1>((int) cell.p[1], -1) == (int) cell.p[1] &&
@@ -328,11 +327,9 @@ __device__ __forceinline__ bool f2n_combine_runs(const F2nCell& cell, int vol, i
     v[2 * d] = g0 * cell.w[d];
     v[2 * d + 1] = g1 * cell.w[d];
   }
-  // no run longer than one sample in this wave (the fine levels) -- or so few (F2N_COMBINE_MIN, a measurement knob: 0 = any) that
-  // the segmented scan below (~200 instructions per tile) costs more than the records it saves
-  if (__popcll(__ballot(same_as_prev)) <= f2n_combine_min) {
-    return true;  // every lane is its own run: head and tail
-  }
+  // no run longer than one sample in this wave (the fine levels).  (Skipping the scan below also when only a few lanes continue a
+  // run -- up to 24 of 64 -- was measured and changes nothing: profiles/r04_pipeline_experiments.txt item 7.)
+  if (__ballot(same_as_prev) == 0ull) return tail;
   int f = head;
 #define F2N_SEG_STEP(K)                                   \
   {                                                       \
@@ -430,7 +427,6 @@ struct F2nBinQueues {
   int32_t* cnt;    // [16 levels][n_bins][NB]
   int cap, n_bins;
   int nb_force;  // 0, or the chunk count to use whatever the sample count (F2N_BIN_NB: measurement knob)
-  int dbg;       // measurement knob F2N_ACC_DBG (wrong results!): 1 owners skip the LDS adds, 2 skip the records, 4 skip the flush
 };
 
 __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHashArgs h, const int32_t* __restrict__ local_idx,
@@ -586,17 +582,18 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   // Segments in batches, the first 128 records of each with one coalesced 8-byte load per lane (the records were written
   // by other XCDs a moment ago -- every read is a fabric round trip, so as many as possible are kept in flight).
   auto add = [&](uint2 rec) {
-    if (rec.y != 0u && !(q.dbg & 1)) {  // a stored record is never (+0, +0); padding is
+    if (rec.y != 0u) {  // a stored record is never (+0, +0); padding is
       const half2_t val = __builtin_bit_cast(half2_t, rec.y);
       atomicAdd(&s_acc[2 * rec.x], (double) val[0]);
       atomicAdd(&s_acc[2 * rec.x + 1], (double) val[1]);
     }
   };
   // Eight segments at a time, the first 256 records of each with FOUR coalesced 8-byte loads per lane, all 32 of them issued
-  // before any record is added: a segment holds ~150 records at the 2.6e5 samples of an ExpRunner::Train batch, and the
-  // "rest" loop below -- one dependent fabric round trip per segment and 64 records -- used to run for most segments (eight
-  // sequential round trips per batch behind the two prefetched ones: most of this kernel's 0.08 ms).
-  for (int sg = 0; sg < ((q.dbg & 2) ? 0 : nb / 2); sg += 8) {
+  // before any record is added: a segment holds ~150 records at the 2.6e5 samples of an ExpRunner::Train batch, so two rounds left
+  // most segments to the "rest" loop below (one dependent fabric round trip per segment and 64 records).  (Measured: the kernel's
+  // time is the volume of these reads -- 76 us with them, 13 us without, the LDS adds hidden underneath -- not their scheduling:
+  // profiles/r04_pipeline_experiments.txt item 7.)
+  for (int sg = 0; sg < nb / 2; sg += 8) {
     uint2 rec[32];
     int cnt[8];
     const uint2* r[8];
@@ -616,7 +613,7 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   }
   __syncthreads();
   half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
-  for (int e0 = tid; e0 < ((q.dbg & 4) ? 0 : F2N_BIN_ENTRIES); e0 += 256 * 8) {  // eight independent table reads in flight per thread
+  for (int e0 = tid; e0 < F2N_BIN_ENTRIES; e0 += 256 * 8) {  // eight independent table reads in flight per thread
     half2_t old[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) old[u] = tab[e0 + 256 * u];
@@ -925,17 +922,8 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
     return (v == 32 || v == 64 || v == 128) ? v : 0;
   }();
   q.nb_force = nb_force;
-  static const bool combine_min_set = []() {
-    const char* e = getenv("F2N_COMBINE_MIN");
-    const int v = e != nullptr ? atoi(e) : 0;
-    return v == 0 || hipMemcpyToSymbol(HIP_SYMBOL(f2n_combine_min), &v, sizeof(int)) == hipSuccess;
-  }();
-  (void) combine_min_set;
-  static const int acc_dbg = []() {
-    const char* e = getenv("F2N_ACC_DBG");
-    return e != nullptr ? atoi(e) : 0;
-  }();
-  q.dbg = acc_dbg;
+
+
   q.n_bins = level_entries >> F2N_BIN_SHIFT;
   const int chunk = (((n + F2N_BIN_NB - 1) / F2N_BIN_NB) + 255) & ~255;
   q.cap = (int) (1.25 * 8.0 * (double) chunk / (double) q.n_bins) + 64;
