@@ -60,12 +60,14 @@ def build_hip(force=False, verbose=False, variant=None):
     jobs = []
     objs = []
     defs = ["-DF2N_REFERENCE_NUMERICS=1"] if variant == "refnum" else []
+    extra = os.environ.get("F2N_EXTRA_HIPCC", "")  # measurement knob: "file.hip:-flag -flag;other.hip:-flag"
+    extra_by_file = dict(kv.split(":", 1) for kv in extra.split(";") if ":" in kv)
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", (".%s.o" % variant) if variant else ".o"))
         objs.append(o)
-        if force or _newer(o, [s] + hdrs):
-            jobs.append([_hipcc()] + HIPCC_FLAGS + defs + ["-c", s, "-o", o])
+        if force or _newer(o, [s] + hdrs) or src in extra_by_file:
+            jobs.append([_hipcc()] + HIPCC_FLAGS + defs + extra_by_file.get(src, "").split() + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
