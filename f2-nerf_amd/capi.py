@@ -66,10 +66,6 @@ def build_info():
     return lib().f2n_build_info().decode()
 
 
-def field_bwd_scatter_deferred():
-    _ck(lib().f2n_field_bwd_scatter_deferred(_stream()), "f2n_field_bwd_scatter_deferred")
-
-
 def debug_counters(reset=False):
     """Diagnostic event counters of the library (f2n_debug_counters): [0] = scatter records applied by the atomic fallback."""
     out = (ctypes.c_int32 * 8)()

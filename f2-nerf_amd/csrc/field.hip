@@ -946,24 +946,6 @@ static inline bool f2n_use_bins(int n, int level_entries) {
          (level_entries >> F2N_BIN_SHIFT) <= F2N_BIN_MAX_BINS;
 }
 
-// The owner-binned scatter of an f2n_field_bwd_dyn call that was asked to leave it to the caller (defer_reduce bit 1).
-struct F2nPendingScatter {
-  bool pending;
-  int n;
-  F2nHashArgs h;
-  const int32_t *local_idx, *local_size;
-  const float *level_scale, *pts;
-  const int32_t* volume_idx;
-  int vol_stride;
-  half_t* dx_planes;
-  uint16_t* nz_mask;
-  half_t* grad_table;
-  int level_entries;
-  const int32_t* n_dev;
-  int n_off;
-};
-static F2nPendingScatter g_pending_scatter[16];
-
 extern "C" {
 
 int f2n_debug_counters(int32_t* out8_host, int reset) {
@@ -1264,31 +1246,12 @@ int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, 
   int rc = f2n_launch_status();
   if (rc != F2N_OK) return rc;
   if (dx_planes != nullptr) {  // planes [8][n][4]: pair (l, ch) at (l>>1)*4n + 4*s + 2*(l&1) + ch
-    if (defer_reduce & 2) {  // the caller issues the scatter itself (f2n_field_bwd_scatter_deferred), behind an event of its own
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
-      F2nPendingScatter& ps = g_pending_scatter[dev];
-      ps = F2nPendingScatter{true, n, h, local_idx, local_size, level_scale, pts_warped, volume_idx, vol_stride, dx_planes, nz_mask,
-                             (half_t*) grad_table_h, level_entries, n_dev, n_off};
-    } else {
-      rc = f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                              dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries, n_dev, n_off);
-      if (rc != F2N_OK) return rc;
-    }
+    rc = f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
+                            dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries, n_dev, n_off);
+    if (rc != F2N_OK) return rc;
   }
-  if (defer_reduce & 1) return f2n_defer_reduction(n_params, (int) blocks, partials, dparams_f32_scaled);
+  if (defer_reduce) return f2n_defer_reduction(n_params, (int) blocks, partials, dparams_f32_scaled);
   return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
-}
-
-int f2n_field_bwd_scatter_deferred(void* stream) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
-  F2nPendingScatter& ps = g_pending_scatter[dev];
-  if (!ps.pending) return F2N_OK;  // (the batch was small: the MLP backward scattered with atomics itself)
-  ps.pending = false;
-  return f2n_binned_scatter((hipStream_t) stream, ps.n, ps.h, ps.local_idx, ps.local_size, ps.level_scale, ps.pts, 1, ps.volume_idx,
-                            ps.vol_stride, ps.dx_planes, 4, 4 * (long) ps.n, ps.nz_mask, ps.grad_table, ps.level_entries, ps.n_dev,
-                            ps.n_off);
 }
 
 }  // extern "C"

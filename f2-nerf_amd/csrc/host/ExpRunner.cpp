@@ -190,18 +190,10 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
   // groups (f2n_adam_fused) has no block-wide dependency in it
   const int32_t* skip = skip_flag;
   if (compute_flags != nullptr) {
-    if (renderer_->reduce_on_aux_) {  // behind the reduction, on the auxiliary stream (Renderer.h: aux_reduce_)
-      c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*renderer_->aux_);
-      F2N_TIMED_CALL("adam", f2n_nonfinite_flags_ex(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
-                                                    F32P(shader->mlp_->grad_scaled_), compute_flags, NextFlagMirror()));
-      renderer_->aux_done_ev_.record(*renderer_->aux_);
-    } else {
-      F2N_TIMED_CALL("adam", f2n_nonfinite_flags_ex(st, field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
-                                                    F32P(shader->mlp_->grad_scaled_), compute_flags, NextFlagMirror()));
-    }
+    F2N_TIMED_CALL("adam", f2n_nonfinite_flags_ex(st, field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
+                                                  F32P(shader->mlp_->grad_scaled_), compute_flags, NextFlagMirror()));
     skip = compute_flags + 2;
   }
-  renderer_->JoinAux();  // (the reduced gradients, and the flags, are what the launch below reads)
   int n_table = 0;
   float *tp = nullptr, *tm = nullptr, *tv = nullptr;
   void *tg = nullptr, *th = nullptr;
@@ -277,7 +269,6 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   // (f2n_*_dyn entry points), the host queues the whole iteration without a device round trip and learns the count -- for
   // the meaningful-samples EMA and the counters -- at the start of the next step (Renderer::ResolvePendingCount).
   renderer_->async_count_ = (prefetch && async_counts_ == 1) || async_counts_ == 2;
-  renderer_->aux_reduce_allowed_ = !sync_.Installed();  // (with an exchange the flags must follow the all-reduce: main queue)
   TrainOutputs out;
   {
     F2N_HOST_SCOPE("step.fwd_bwd");
@@ -297,7 +288,6 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   stats.loss = out.losses.slice(0, 0, 1).squeeze(0);
   stats.mse = out.losses.slice(0, 5, 6).squeeze(0);
   bool applied = false;
-  if (!(out.has_samples || sync_.Installed())) renderer_->JoinAux();
   // (a data-parallel replica whose batch missed the scene still joins the gradient exchange, with its zero gradients)
   if (out.has_samples || sync_.Installed()) {
     // pipelined: asynchronous all-reduce, awaited in the next step (or Flush); else: all-reduce of the gradient buffers
@@ -365,11 +355,9 @@ void ExpRunner::EnqueueApply(bool apply_optimizer) {
   if (apply_optimizer) {  // the flags are computed by the small-groups launch itself; a no-op on the device when they say so
     OptimStep(nullptr, check_nan_ ? I32P(nan_flags_) : nullptr);
   } else if (check_nan_) {
-    renderer_->JoinAux();
     F2N_CALL(f2n_nonfinite_flags_ex(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
                                     F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_), NextFlagMirror()));
   }
-  renderer_->JoinAux();  // (no launch of this step may be left unordered behind the main queue)
 }
 
 // The iteration's only read-back besides the two sample counts.  Returns true when the gradients were not finite (loss

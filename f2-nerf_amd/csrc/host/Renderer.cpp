@@ -351,12 +351,6 @@ bool Renderer::PreSampleSpecComplete(int slot) {
   return true;
 }
 
-void Renderer::JoinAux() {
-  if (!reduce_on_aux_) return;
-  reduce_on_aux_ = false;
-  aux_done_ev_.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
-}
-
 Tensor Renderer::DrawStepUniforms(int64_t n) {
   const int dev = c10::hip::current_device();
   const uint64_t seed = at::cuda::detail::getDefaultCUDAGenerator(dev).current_seed();
@@ -956,27 +950,13 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
                          fr.emb ? (int) app_emb_grad_.size(0) : 0, F32P(df0c), /*defer_reduce=*/fr.dyn ? 1 : 0));
   if (fr.dyn) {
     field->grad_clean_ = false;
-    const bool on_aux = aux_reduce_ && aux_reduce_allowed_;
     F2N_TIMED_CALL("field_bwd", f2n_field_bwd_dyn(st, n, n_dev, 2 * n_edge, field->n_volumes_, I32P(field->prim_pool_),
                            I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
                            F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
                            VoidP(field_x), F32P(dfeat), field->mlp_->loss_scale_, F32P(field->mlp_->grad_scaled_),
-                           VoidP(field->grad_h_), field->pool_size_ / N_LEVELS, /*defer_reduce=*/on_aux ? 3 : 1));
-    // the partial-sum reductions (loss values, colour-MLP weights, appearance embedding, field-MLP weights) in one launch
-    if (on_aux) {  // ... on the auxiliary stream, behind the MLP backward kernel, while this stream goes on with the scatter
-      if (!aux_) aux_ = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
-      mlp_bwd_done_ev_.record();
-      mlp_bwd_done_ev_.block(*aux_);
-      {
-        c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*aux_);
-        F2N_TIMED_CALL("reduce_partials", f2n_reduce_deferred(CurStream()));
-        aux_done_ev_.record(*aux_);
-      }
-      reduce_on_aux_ = true;
-      F2N_TIMED_CALL("hash_scatter", f2n_field_bwd_scatter_deferred(st));
-    } else {
-      F2N_TIMED_CALL("reduce_partials", f2n_reduce_deferred(st));
-    }
+                           VoidP(field->grad_h_), field->pool_size_ / N_LEVELS, /*defer_reduce=*/1));
+    // the three partial-sum reductions (colour-MLP weights, appearance embedding, field-MLP weights) in one launch
+    F2N_TIMED_CALL("reduce_partials", f2n_reduce_deferred(st));
   } else {
     field->BackwardRaw(fr.pts_all, fr.vol_all, 1, field_x, dfeat);
   }

@@ -185,14 +185,6 @@ class Renderer : public Pipe {
   // streaming steps: compositing forward + loss + compositing backward as ONE launch (f2n_composite_train); false: the three
   // launches it replaces (what tests compare it with)
   bool fuse_composite_ = true;
-  // Streaming steps without a data-parallel exchange: the folding of the per-block gradient partials (f2n_reduce_deferred) and
-  // the finiteness flags run on an AUXILIARY stream, ordered behind the field-MLP backward kernel, while the main queue goes
-  // on with the hash scatter; the optimiser waits for them.  Two dependent launches (~23 us with their boundaries) leave the
-  // main queue.  (With an exchange installed the flags must follow the all-reduce: everything stays on the main queue.)
-  bool aux_reduce_ = true, aux_reduce_allowed_ = true, reduce_on_aux_ = false;
-  std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> aux_;
-  at::cuda::CUDAEvent mlp_bwd_done_ev_, aux_done_ev_;
-  void JoinAux();  // the main stream waits for whatever was queued on the auxiliary stream this step
   bool count_pending_ = false;
   int pending_count_rays_ = 0;
   int64_t total_kept_pts_ = 0, total_all_pts_ = 0;  // running totals over training-mode calls (resolved counts only)

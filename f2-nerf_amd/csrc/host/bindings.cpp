@@ -315,8 +315,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })
       .def_property("pregen_draws",  // a prefetched batch brings its step's background / edge draws and edge samples along (A/B knob)
                     [](ExpRunner& r) { return r.renderer_->pregen_draws_; }, [](ExpRunner& r, bool on) { r.renderer_->pregen_draws_ = on; })
-      .def_property("aux_reduce",  // reduction + finiteness flags on an auxiliary stream beside the hash scatter (A/B knob)
-                    [](ExpRunner& r) { return r.renderer_->aux_reduce_; }, [](ExpRunner& r, bool on) { r.FinishPending(); r.renderer_->aux_reduce_ = on; })
       .def_property("fuse_composite",  // streaming steps: compositing fwd + loss + bwd in one launch (A/B knob; same gradients)
                     [](ExpRunner& r) { return r.renderer_->fuse_composite_; }, [](ExpRunner& r, bool on) { r.renderer_->fuse_composite_ = on; })
       .def_property("speculation_depth",  // the batch after next is begun two steps ahead: 1 never, 2 once the octree has outgrown the LDS walk, 3 always

@@ -521,12 +521,6 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
  * that was deferred on this device into the destinations named at the time (at most four pending reductions; same stream
  * rule as the workspace itself).  Saves two dependent launches per training step. */
 int f2n_reduce_deferred(void* stream);
-/* defer_reduce bit 1 (value 2 or 3) of f2n_field_bwd_dyn: the call stops behind the MLP backward kernel and leaves the
- * owner-binned hash scatter (the Hash3DAnchoredBackwardKernel part, Hash3DAnchored.cu:81-155) to this call, which the caller
- * issues on the same stream.  Why: the parameter-gradient partials are complete once the MLP kernel has run, so a caller can
- * fold them (f2n_reduce_deferred) and compute the finiteness flags on ANOTHER stream, ordered by an event of its own, while the
- * scatter runs -- two dependent launches less between the scatter and the optimiser.  No-op when nothing is pending. */
-int f2n_field_bwd_scatter_deferred(void* stream);
 /* Drops every reduction registered on this device and not yet folded: call it at the start of a backward pass (the host's
  * ZeroGrad does), so that a step that failed between a deferring launch and f2n_reduce_deferred cannot leak its partial sums
  * into the next step's gradients.  No launch. */
