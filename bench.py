@@ -49,7 +49,7 @@ ALGO_BYTES = {"hash_gather": 512 + 12 + 4 + 64}
 # HBM-side bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate counter passes,
 # profiles/run_profiles.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), recorded per round in
 # profiles/<tag>_traffic.json; null when that file is absent.
-TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json"),
+TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r04_traffic.json"), os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json"),
                                  os.path.join(ROOT, "profiles", "r01_traffic.json")) if os.path.exists(p)), "")
 HBM_PEAK_GBS = 8000.0
 # What actually bounds that kernel: 128 independent 4-byte reads per sample from an L2-resident table slice.  The chip
@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--marker-pause", action="store_true", help="sleep 0.3 s before the timed region (marker for profiles/timeline_rocpd.py)")
     ap.add_argument("--speculation", choices=["auto", "on", "off"], default="auto", help="sampling of the next batch AHEAD of the stat "
                     "update with repair behind it (Renderer::PreSampleSpecBegin): auto = while no leaf has died lately (the "
-                    "default of the host), on / off = A/B (profiles/r03_speculation_experiments.txt)")
+                    "default of the host), on / off = A/B (profiles/r03_speculation_experiments.txt, r04_pipeline_experiments.txt)")
     ap.add_argument("--speculation-depth", type=int, default=-1, help="A/B: batches sampled ahead of their step (1 or 2: Renderer.h "
                     "spec_depth_); -1 = host default")
     ap.add_argument("--march-blocks", type=int, default=-1, help="A/B: > 0 marches speculative batches on that many persistent one-wave "

@@ -9,7 +9,7 @@
 # Counter passes never share a run with tracing (gpurun refuses that combination).
 # Environment: BENCH_EXTRA = extra bench.py arguments (e.g. "--preset wanjinyou_big --log2 22"), PASSES = which passes to run.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 BENCH_EXTRA=${BENCH_EXTRA:-}
 PASSES=${PASSES:-"stats fetch write sq"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
