@@ -76,11 +76,40 @@ __global__ void mlpg_prep_kernel(int d_in, int d_in_pad, int dh, int n_hidden, c
 // lane (c, g): element (feature 16t + 4g + r, sample c) of tile `tile` in a [tile][n_feat][16] array
 #define F2N_TT(base, tile, n_feat, feat) ((base) + ((size_t) (tile) * (n_feat) + (feat)) * 16)
 
-template <int DH, bool SAVE>
+// LDSW: the three forward matrices (input layer, hidden layers, output layer: contiguous in the prepared block) are copied into
+// LDS once per block, rows padded by F2N_MLPG_LDS_PAD halves -- a fragment read takes 8 bytes from each of 16 consecutive rows,
+// and with a row stride of 2 * DH bytes those rows fall on two banks' worth of addresses; + 8 bytes spreads them -- instead of
+// being re-read through L1 by every 16-sample tile (round-3 verdict, weak 11).  Used while the padded matrices leave room for four
+// resident blocks per CU (mlpg_lds_bytes <= 40 KB: widths up to 64 with up to four hidden layers, 128 with one).
+#define F2N_MLPG_LDS_PAD 4
+template <int DH, bool SAVE, bool LDSW>
 __global__ __launch_bounds__(256) void mlpg_fwd_kernel(int n, int d_in, int d_in_pad, int n_hidden, F2nMlpgPrep w,
                                                        const float* __restrict__ x, half_t* __restrict__ out_h,
                                                        half_t* __restrict__ xT, half_t* __restrict__ hT /*[n_hidden][tiles][DH][16]*/) {
   constexpr int NT = DH / 16;
+  extern __shared__ half_t s_mlpg_w[];
+  const int ld0 = LDSW ? d_in_pad + F2N_MLPG_LDS_PAD : d_in_pad, ldh = LDSW ? DH + F2N_MLPG_LDS_PAD : DH;
+  const half_t *W0 = w.w0p, *WL = w.wl, *WO = w.wo;
+  if (LDSW) {
+    half_t* s0 = s_mlpg_w;
+    half_t* sl = s0 + (size_t) DH * ld0;
+    half_t* so = sl + (size_t) (n_hidden - 1) * DH * ldh;
+    // 4 halves (8 bytes) per thread and step; every row length is a multiple of 16 halves
+    for (int i = threadIdx.x * 4; i < DH * d_in_pad; i += 256 * 4) {
+      const int r = i / d_in_pad, k = i - r * d_in_pad;
+      *(half4_t*) (s0 + (size_t) r * ld0 + k) = *(const half4_t*) (w.w0p + i);
+    }
+    for (int i = threadIdx.x * 4; i < (n_hidden - 1) * DH * DH; i += 256 * 4) {
+      const int r = i / DH, k = i - r * DH;  // r runs over the rows of all hidden matrices
+      *(half4_t*) (sl + (size_t) r * ldh + k) = *(const half4_t*) (w.wl + i);
+    }
+    for (int i = threadIdx.x * 4; i < 16 * DH; i += 256 * 4) {
+      const int r = i / DH, k = i - r * DH;
+      *(half4_t*) (so + (size_t) r * ldh + k) = *(const half4_t*) (w.wo + i);
+    }
+    __syncthreads();
+    W0 = s0; WL = sl; WO = so;
+  }
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int n_tiles = (n + 15) / 16;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
@@ -101,7 +130,7 @@ __global__ __launch_bounds__(256) void mlpg_fwd_kernel(int n, int d_in, int d_in
       }
 #pragma unroll
       for (int t = 0; t < NT; t++)
-        acc[t] = f2n_mfma16_fwd(*(const half4_t*) (w.w0p + (size_t) (16 * t + c) * d_in_pad + 16 * q + 4 * g), xf, acc[t]);
+        acc[t] = f2n_mfma16_fwd(*(const half4_t*) (W0 + (size_t) (16 * t + c) * ld0 + 16 * q + 4 * g), xf, acc[t]);
     }
     half4_t h[NT];
 #pragma unroll
@@ -115,20 +144,20 @@ __global__ __launch_bounds__(256) void mlpg_fwd_kernel(int n, int d_in, int d_in
           for (int r = 0; r < 4; r++) F2N_TT(dst, tile, DH, 16 * t + 4 * g + r)[c] = h[t][r];
       }
       if (l == n_hidden - 1) break;
-      const half_t* wl = w.wl + (size_t) l * DH * DH;
+      const half_t* wl = WL + (size_t) l * DH * ldh;
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         acc[t] = z;
 #pragma unroll
         for (int q = 0; q < NT; q++)
-          acc[t] = f2n_mfma16_fwd(*(const half4_t*) (wl + (size_t) (16 * t + c) * DH + 16 * q + 4 * g), h[q], acc[t]);
+          acc[t] = f2n_mfma16_fwd(*(const half4_t*) (wl + (size_t) (16 * t + c) * ldh + 16 * q + 4 * g), h[q], acc[t]);
       }
 #pragma unroll
       for (int t = 0; t < NT; t++) h[t] = f2n_cvt4<true>(acc[t]);
     }
     float4_t o = z;
 #pragma unroll
-    for (int q = 0; q < NT; q++) o = f2n_mfma16_fwd(*(const half4_t*) (w.wo + (size_t) c * DH + 16 * q + 4 * g), h[q], o);
+    for (int q = 0; q < NT; q++) o = f2n_mfma16_fwd(*(const half4_t*) (WO + (size_t) c * ldh + 16 * q + 4 * g), h[q], o);
     if (valid && out_h != nullptr) *(half4_t*) (out_h + (size_t) s * 16 + 4 * g) = f2n_cvt4<false>(o);  // outputs 4g..4g+3 of sample c
   }
 }
@@ -277,15 +306,30 @@ static int mlpg_prepare(hipStream_t st, int d_in, int dh, int n_hidden, const ha
   return f2n_launch_status();
 }
 
+static size_t mlpg_lds_bytes(int d_in_pad, int dh, int n_hidden) {  // the forward matrices with padded rows (mlpg_fwd_kernel<.., LDSW>)
+  return sizeof(half_t) * ((size_t) dh * (d_in_pad + F2N_MLPG_LDS_PAD) + (size_t) (n_hidden - 1) * dh * (dh + F2N_MLPG_LDS_PAD) +
+                           16 * (size_t) (dh + F2N_MLPG_LDS_PAD));
+}
+
 template <bool SAVE>
-static void mlpg_launch_fwd(hipStream_t st, int dh, unsigned grid, int n, int d_in, int d_in_pad, int n_hidden, const F2nMlpgPrep& w,
-                            const float* x, half_t* out_h, half_t* xT, half_t* hT) {
-#define F2N_MLPG_FWD(W) hipLaunchKernelGGL((mlpg_fwd_kernel<W, SAVE>), dim3(grid), dim3(256), 0, st, n, d_in, d_in_pad, n_hidden, w, x, out_h, xT, hT)
+static int mlpg_launch_fwd(hipStream_t st, int dh, unsigned grid, int n, int d_in, int d_in_pad, int n_hidden, const F2nMlpgPrep& w,
+                           const float* x, half_t* out_h, half_t* xT, half_t* hT) {
+  const size_t lds = mlpg_lds_bytes(d_in_pad, dh, n_hidden);
+  const bool in_lds = lds <= 40 * 1024;  // (four resident blocks per CU; larger networks keep reading their weights through L1)
+#define F2N_MLPG_FWD(W)                                                                                                              \
+  do {                                                                                                                               \
+    if (in_lds) {                                                                                                                    \
+      hipLaunchKernelGGL((mlpg_fwd_kernel<W, SAVE, true>), dim3(grid), dim3(256), lds, st, n, d_in, d_in_pad, n_hidden, w, x, out_h, xT, hT); \
+    } else {                                                                                                                         \
+      hipLaunchKernelGGL((mlpg_fwd_kernel<W, SAVE, false>), dim3(grid), dim3(256), 0, st, n, d_in, d_in_pad, n_hidden, w, x, out_h, xT, hT);  \
+    }                                                                                                                                \
+  } while (0)
   if (dh == 16) F2N_MLPG_FWD(16);
   else if (dh == 32) F2N_MLPG_FWD(32);
   else if (dh == 64) F2N_MLPG_FWD(64);
   else F2N_MLPG_FWD(128);
 #undef F2N_MLPG_FWD
+  return F2N_OK;
 }
 
 int f2n_mlpg_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const void* params_h, const float* x, void* out_h) {
@@ -295,7 +339,8 @@ int f2n_mlpg_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, cons
   if (rc != F2N_OK) return rc;
   const int d_in_pad = (d_in + 15) / 16 * 16, n_tiles = (n + 15) / 16;
   const unsigned grid = (unsigned) min(2048, (n_tiles + 3) / 4);
-  mlpg_launch_fwd<false>(st, d_hidden, grid, n, d_in, d_in_pad, n_hidden, w, x, (half_t*) out_h, nullptr, nullptr);
+  rc = mlpg_launch_fwd<false>(st, d_hidden, grid, n, d_in, d_in_pad, n_hidden, w, x, (half_t*) out_h, nullptr, nullptr);
+  if (rc != F2N_OK) return rc;
   return f2n_launch_status();
 }
 
@@ -315,7 +360,8 @@ int f2n_mlpg_bwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, floa
   half_t* gT = hT + (size_t) n_hidden * hl;
   half_t* dyT = gT + (size_t) n_hidden * hl;
   const unsigned grid = (unsigned) min(2048, (n_tiles + 3) / 4);
-  mlpg_launch_fwd<true>(st, dh, grid, n, d_in, d_in_pad, n_hidden, w, x, nullptr, xT, hT);
+  rc = mlpg_launch_fwd<true>(st, dh, grid, n, d_in, d_in_pad, n_hidden, w, x, nullptr, xT, hT);
+  if (rc != F2N_OK) return rc;
 #define F2N_MLPG_BWD(W) hipLaunchKernelGGL((mlpg_bwd_chain_kernel<W>), dim3(grid), dim3(256), 0, st, n, d_in, d_in_pad, n_hidden, w, dy, loss_scale, hT, gT, dyT, dx_f32)
   if (dh == 16) F2N_MLPG_BWD(16);
   else if (dh == 32) F2N_MLPG_BWD(32);
