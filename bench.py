@@ -350,6 +350,8 @@ def main():
     ap.add_argument("--march-blocks-near", type=int, default=-1, help="A/B: the same for batches begun ONE step ahead; -1 = host default")
     ap.add_argument("--spec-at-step-end", type=int, default=-1, help="A/B: small trees: 1 begins the batch after next when a step's "
                     "backward is queued, 0 at the top of the next step; -1 = host default")
+    ap.add_argument("--knob", action="append", default=[], help="A/B: NAME=VALUE sets an ExpRunner property (tail_repair, fuse_composite, "
+                    "pregen_draws, optimistic_pack, ...) on the headline runner; repeatable")
     ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
                     "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
     ap.add_argument("--lds-octree", type=int, default=-1, help="A/B: 0 walks the octree through the L2s even when its interior nodes "
@@ -422,6 +424,9 @@ def main():
         runner.march_blocks_near = args.march_blocks_near
     if args.spec_at_step_end >= 0:
         runner.spec_at_step_end = bool(args.spec_at_step_end)
+    for kv in args.knob:
+        k, v = kv.split("=")
+        setattr(runner, k, type(getattr(runner, k))(int(v)))
     if args.lds_octree >= 0:
         runner.lds_octree = bool(args.lds_octree)
     if args.optimistic_pack >= 0:
