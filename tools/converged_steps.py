@@ -26,7 +26,9 @@ ds = runtime.make_dataset(sc, images)
 runner, cfg, _ = runtime.make_runner(st, "wanjinyou", ["train.end_iter=%d" % max(args.iters, 1)] + args.overrides, seed=2022)
 torch.manual_seed(2022)
 if args.iters > 0:
+    torch.cuda.synchronize(); _t0 = time.perf_counter()
     runner.train(ds, args.iters, 1)
+    torch.cuda.synchronize(); print("trained %d iterations in %.2f s" % (args.iters, time.perf_counter() - _t0), flush=True)
 if args.speculation >= 0:
     runner.speculative_sampling = args.speculation
 R = max(16, runner.cur_batch_size())
