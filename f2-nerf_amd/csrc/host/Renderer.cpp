@@ -253,9 +253,18 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
   presample_rays_d_ = rays_d;
 }
 
+// The two side streams are per DEVICE, not per Renderer: a process that builds a second runner (bench.py: the headline runner, then
+// the converged leg's) would otherwise hold five streams -- main + 2 + 2 -- and HIP multiplexes streams onto four hardware queues
+// by default: the second runner's sampler then shared a queue with its own main stream (measured: 20 000 iterations 17.6 s
+// in bench.py against 15.2 s for the same loop in a process of its own; profiles/r04_pipeline_experiments.txt item 9).
 void Renderer::EnsureSideStream(int slot) {
-  if (!side_[slot])
-    side_[slot] = std::make_unique<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+  if (side_[slot]) return;
+  static std::shared_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> shared[16][kPendingSlots];
+  const int dev = c10::hip::current_device();
+  TORCH_CHECK(dev >= 0 && dev < 16, "device index out of range");
+  if (!shared[dev][slot])
+    shared[dev][slot] = std::make_shared<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+  side_[slot] = shared[dev][slot];
 }
 
 // A side stream's buffers may be handed the memory of samples the main stream is still reading: it waits for the last

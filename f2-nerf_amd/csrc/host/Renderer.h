@@ -222,7 +222,7 @@ class Renderer : public Pipe {
   bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
   MappedWords n_kept_words_;  // [1]: the surviving-sample count, written by the survivor scan itself, read behind n_kept_ev_
-  std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_[kPendingSlots];
+  std::shared_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_[kPendingSlots];  // (shared by every Renderer of the device)
   void EnsureSideStream(int slot);
   Tensor forced_bg_;  // explicit background colours for parity tests (undefined = as the reference)
   int n_edge_pts_ = 8192;
