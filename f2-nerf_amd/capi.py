@@ -356,6 +356,16 @@ def hash_gather_planes(n, n_volumes, table_h, prim_pool, local_idx, local_size, 
                                      _p(planes_h, "h16")), "f2n_hash_gather_planes")
 
 
+def hash_gather_planes_binned(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale, pts, pts_are_warped,
+                              volume_idx, vol_stride, planes_h, level_entries, first_binned_pair):
+    """hash_gather_planes for tables beyond the L2s: level pairs >= first_binned_pair through the slice-binned pipeline."""
+    _ck(lib().f2n_hash_gather_planes_binned(_stream(), _i(n), _i(n_volumes), _p(table_h, "h16"), _p(prim_pool, "i32"),
+                                            _p(local_idx, "i32"), _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"),
+                                            _p(pts, "f32"), _i(int(pts_are_warped)), _p(volume_idx, "i32"), _i(vol_stride),
+                                            _p(planes_h, "h16"), _i(level_entries), _i(first_binned_pair)),
+        "f2n_hash_gather_planes_binned")
+
+
 def hash_gather_planes_balanced(n, n_volumes, table_h, prim_pool, local_idx, local_size, bias_pool, level_scale, pts,
                                 pts_are_warped, volume_idx, vol_stride, planes_h, step01, level_scale_host):
     """level_scale_host: 16 floats on the HOST (numpy array / list); step01 <= 0 -> the plain one-pair-per-XCD gather."""

@@ -267,6 +267,191 @@ static void f2n_gather_plan(int n_tiles, const float* cost8 /* NULL: one pair pe
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Slice-binned gather for tables that have left the L2s (BASELINE config 5: 2^21 / 2^22 entries per level; round 4).
+// With a level slice far larger than an XCD's 4 MiB L2 every hashed read of a fine level is a miss that pulls a 128-byte line
+// across the fabric for 4 bytes of payload (8.35 GB per launch at 2^22: profiles/r03_big22_pmc_tcc.csv).  The mirror image of the
+// owner-binned scatter reads the table ONCE instead:
+//   (1) gather_request_kernel   block (level, sample chunk): hash, and for every corner append the 12-bit entry-in-slice to the
+//       request queue (level, 4096-entry slice, chunk); remember the slot it got (8 x u16 per sample and level, coalesced);
+//   (2) gather_serve_kernel     block (level, slice): the slice (16 KB) into LDS, then every request queue of the slice is answered
+//       IN PLACE ORDER -- result[slot] = slice[request[slot]] -- so both streams are coalesced;
+//   (3) gather_blend_kernel     per sample: hash again (cheaper than carrying cells through memory), pick its eight values out of
+//       its chunk's result queues (a few hundred KB per level and chunk: they stay in the L2 while the chunk's tiles pass), blend
+//       in the order of hash_gather_planes_kernel, write the f16 plane element.
+// A request that finds its queue full (slot 0xFFFF) is read from the table directly in (3).  Coarse level pairs, whose working set
+// fits the L2s whatever the table size, keep the partitioned gather.  Planes are bit-identical (tests/test_gpu_parity.py::
+// test_binned_gather_equals_partitioned_gather).
+// ---------------------------------------------------------------------------------------------------
+#define F2N_BIN_SHIFT 12  // (4096-entry table slices: shared with the owner-binned scatter below)
+#define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
+#define F2N_BIN_MAX_BINS 1024
+#define F2N_GB_NC 128  // sample chunks (request producers) per level
+struct F2nGatherBins {
+  uint16_t* req;    // [NL][n_bins][NC][cap]
+  uint32_t* res;    // same shape: the half2 bits of the requested entries
+  int32_t* cnt;     // [NL][n_bins][NC]
+  uint16_t* slots;  // [NL][n][8]
+  int cap, n_bins, l0, chunk;
+};
+
+__global__ __launch_bounds__(256) void gather_request_kernel(int n, F2nHashArgs h, const int32_t* __restrict__ local_idx,
+                                                             const int32_t* __restrict__ local_size, const float* __restrict__ level_scale,
+                                                             const float* __restrict__ pts, int pts_are_warped,
+                                                             const int32_t* __restrict__ volume_idx, int vol_stride, F2nGatherBins q) {
+  __shared__ F2nLevelTab lt;
+  __shared__ int s_cnt[F2N_BIN_MAX_BINS];
+  const int tid = threadIdx.x;
+  const int li = blockIdx.x / F2N_GB_NC, B = blockIdx.x % F2N_GB_NC, l = q.l0 + li;
+  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+  for (int i = tid; i < q.n_bins; i += 256) s_cnt[i] = 0;
+  __syncthreads();
+  const int s_begin = B * q.chunk, s_end = min(n, s_begin + q.chunk);
+  uint16_t* my_req = q.req + ((size_t) li * q.n_bins * F2N_GB_NC + B) * q.cap;  // segment (li, bin, B) = my_req + bin * bin_stride
+  const size_t bin_stride = (size_t) F2N_GB_NC * q.cap;
+  for (int s0 = s_begin; s0 < s_end; s0 += 256) {
+    const int s = s0 + tid;
+    if (s < s_end) {
+      float p01[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float p = pts[3 * (size_t) s + k];
+        p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
+      }
+      const int vol = volume_idx[(size_t) s * vol_stride];
+      const int tf = l * h.n_volumes + vol;
+      F2nCell cell;
+      f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
+      uint32_t packed[4];
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        const uint32_t pos = cell.pos[d];
+        const int bin = (int) (pos >> F2N_BIN_SHIFT);
+        int slot = atomicAdd(&s_cnt[bin], 1);
+        if (slot < q.cap) my_req[(size_t) bin * bin_stride + slot] = (uint16_t) (pos & (F2N_BIN_ENTRIES - 1));
+        else slot = 0xFFFF;
+        if (d & 1) packed[d >> 1] |= (uint32_t) slot << 16;
+        else packed[d >> 1] = (uint32_t) slot;
+      }
+      *(uint4*) (q.slots + ((size_t) li * n + s) * 8) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) li * q.n_bins + i) * F2N_GB_NC + B] = min(s_cnt[i], q.cap);
+}
+
+__global__ __launch_bounds__(256) void gather_serve_kernel(const half_t* __restrict__ table, const int32_t* __restrict__ local_idx,
+                                                           F2nGatherBins q) {
+  __shared__ uint32_t s_slice[F2N_BIN_ENTRIES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = blockIdx.x / q.n_bins, bin = blockIdx.x % q.n_bins, l = q.l0 + li;
+  const uint32_t* slice = (const uint32_t*) (table + local_idx[l]) + (size_t) bin * F2N_BIN_ENTRIES;
+  for (int i = tid; i < F2N_BIN_ENTRIES; i += 256) s_slice[i] = slice[i];
+  const size_t seg0 = ((size_t) li * q.n_bins + bin) * F2N_GB_NC;
+  // wave w answers chunks w, w + 4, ...: lane j keeps the length of chunk w + 4j (32 per wave)
+  const int my_cnt = lane < F2N_GB_NC / 4 ? q.cnt[seg0 + wave + 4 * lane] : 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < F2N_GB_NC / 4; k0 += 4) {  // four queues at a time, up to three rounds of 64 requests each in flight
+    uint16_t e[4][3];
+    int cnt[4];
+    size_t off[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      cnt[u] = __shfl(my_cnt, k0 + u);
+      off[u] = (seg0 + wave + 4 * (k0 + u)) * q.cap;
+#pragma unroll
+      for (int r = 0; r < 3; r++) e[u][r] = lane + 64 * r < cnt[u] ? q.req[off[u] + lane + 64 * r] : (uint16_t) 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        if (lane + 64 * r < cnt[u]) q.res[off[u] + lane + 64 * r] = s_slice[e[u][r]];
+      for (int i = lane + 192; i < cnt[u]; i += 64) q.res[off[u] + i] = s_slice[q.req[off[u] + i]];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_blend_kernel(int n, int n_tiles, F2nHashArgs h, const int32_t* __restrict__ local_idx,
+                                                           const int32_t* __restrict__ local_size, const float* __restrict__ level_scale,
+                                                           const float* __restrict__ pts, int pts_are_warped,
+                                                           const int32_t* __restrict__ volume_idx, int vol_stride,
+                                                           half_t* __restrict__ planes, F2nGatherBins q) {
+  __shared__ F2nLevelTab lt;
+  const int tid = threadIdx.x;
+  f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
+  __syncthreads();
+  // A chunk's tiles all run on XCD (chunk % 8) -- blockIdx round-robins over the XCDs -- so that a chunk's result queues are
+  // pulled into ONE L2 instead of eight.
+  const int tpc = q.chunk / 256, x = blockIdx.x % F2N_N_PARTS, k = blockIdx.x / F2N_N_PARTS;
+  const int chunk_id = x + F2N_N_PARTS * ((k / tpc) % (F2N_GB_NC / F2N_N_PARTS));
+  const int part = q.l0 / 2 + k / (tpc * (F2N_GB_NC / F2N_N_PARTS)), tile = chunk_id * tpc + k % tpc;
+  const int s = tile * 256 + tid;
+  if (s >= n) return;
+  float p01[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float p = pts[3 * (size_t) s + k];
+    p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
+  }
+  const int vol = volume_idx[(size_t) s * vol_stride];
+  const int B = s / q.chunk;
+  half4_t out;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int l = 2 * part + j, li = l - q.l0;
+    const int tf = l * h.n_volumes + vol;
+    F2nCell cell;
+    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
+    const uint4 sl = *(const uint4*) (q.slots + ((size_t) li * n + s) * 8);
+    const uint32_t packed[4] = {sl.x, sl.y, sl.z, sl.w};
+    const half2_t* base = (const half2_t*) (h.table + lt.base[l]);
+    half2_t v[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      const uint32_t slot = (d & 1) ? packed[d >> 1] >> 16 : packed[d >> 1] & 0xFFFFu;
+      const uint32_t pos = cell.pos[d];
+      if (slot != 0xFFFFu) {
+        const size_t seg = ((size_t) li * q.n_bins + (pos >> F2N_BIN_SHIFT)) * F2N_GB_NC + B;
+        v[d] = __builtin_bit_cast(half2_t, q.res[seg * q.cap + slot]);
+      } else {
+        v[d] = base[pos];  // its queue was full: read from the table directly
+      }
+    }
+    float s0 = cell.w[0] * (float) v[0][0];  // same fp32 summation order as hash_gather_planes_kernel / the oracle
+    float s1 = cell.w[0] * (float) v[0][1];
+#pragma unroll
+    for (int d = 1; d < 8; d++) {
+      s0 = s0 + cell.w[d] * (float) v[d][0];
+      s1 = s1 + cell.w[d] * (float) v[d][1];
+    }
+    out[2 * j] = (half_t) s0;
+    out[2 * j + 1] = (half_t) s1;
+  }
+  *(half4_t*) (planes + ((size_t) part * n + s) * 4) = out;
+}
+
+// (pair, tile) units of the pairs [0, n_pairs) dealt to the 8 XCD shares of the partitioned gather in pair-major order.
+static void f2n_gather_plan_coarse(int n_tiles, int n_pairs, F2nGatherPlan& plan) {
+  memset(&plan, 0, sizeof(plan));
+  const long units = (long) n_pairs * n_tiles, share = (units + F2N_N_PARTS - 1) / F2N_N_PARTS;
+  for (int x = 0; x < F2N_N_PARTS; x++) {
+    long u = (long) x * share;
+    const long u_end = u + share < units ? u + share : units;
+    while (u < u_end && plan.n_seg[x] < F2N_MAX_SEGS) {
+      const int p = (int) (u / n_tiles), t = (int) (u % n_tiles);
+      const long take = (u_end - u) < (n_tiles - t) ? (u_end - u) : (n_tiles - t);
+      const int k = plan.n_seg[x]++;
+      plan.pair[x][k] = p;
+      plan.t0[x][k] = t;
+      plan.v0[x][k] = plan.n_virtual[x];
+      plan.n_virtual[x] += (int) take;
+      u += take;
+    }
+  }
+}
+
 // Gathers this lane's four levels of one sample: returns the X row fragment (8 halves).
 __device__ __forceinline__ half8_t f2n_gather_frag(const F2nHashArgs& h, const F2nLevelTab& lt, const float* p01, int vol,
                                                    int g, bool valid) {
@@ -415,6 +600,7 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 __device__ __forceinline__ int f2n_bin_nb(int n_true, int force = 0) {
   return force > 0 ? force : n_true > 393216 ? 128 : n_true > 131072 ? 64 : 32;
 }
+#undef F2N_BIN_MAX_BINS
 #define F2N_BIN_MAX_BINS 1024  // tables up to 2^22 entries per level (BASELINE config 5)
 #define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
@@ -1170,6 +1356,53 @@ int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const vo
   else if (balanced) F2N_LAUNCH_GATHER(false, true);
   else F2N_LAUNCH_GATHER(false, false);
 #undef F2N_LAUNCH_GATHER
+  return f2n_launch_status();
+}
+
+int f2n_hash_gather_planes_binned(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                                  const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                                  const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
+                                  int vol_stride, void* planes_h, int level_entries, int first_binned_pair) {
+  const int p0 = first_binned_pair;
+  if (n < 0 || n_volumes <= 0 || vol_stride < 1 || p0 < 0 || p0 > F2N_N_PARTS) return F2N_ERR_INVALID_ARG;
+  if (level_entries < 2 * F2N_BIN_ENTRIES || (level_entries & (level_entries - 1)) != 0 || (level_entries >> F2N_BIN_SHIFT) > F2N_BIN_MAX_BINS)
+    return F2N_ERR_UNSUPPORTED;  // (the reference's table layout: local_size[l] = E, a power of two, whole 4096-entry slices)
+  if (n == 0) return F2N_OK;
+  hipStream_t st = (hipStream_t) stream;
+  F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
+  const int n_tiles = (n + 255) / 256;
+  if (p0 > 0) {  // the coarse pairs: the partitioned gather, its (pair, tile) units dealt to the eight XCD shares
+    long per_part = n_tiles;
+    if (per_part > 256) per_part = 256;
+    F2nGatherPlan plan;
+    f2n_gather_plan_coarse(n_tiles, p0, plan);
+    hipLaunchKernelGGL((hash_gather_planes_kernel<false, false>), dim3((unsigned) (F2N_N_PARTS * per_part)), dim3(256), 0, st, n, h,
+                       local_idx, local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride, (half_t*) planes_h, plan);
+    const int rc = f2n_launch_status();
+    if (rc != F2N_OK) return rc;
+  }
+  if (p0 == F2N_N_PARTS) return F2N_OK;
+  F2nGatherBins q;
+  q.l0 = 2 * p0;
+  const int nl = F2N_N_LEVELS - q.l0;
+  q.n_bins = level_entries >> F2N_BIN_SHIFT;
+  q.chunk = (((n + F2N_GB_NC - 1) / F2N_GB_NC) + 255) & ~255;
+  q.cap = ((int) (1.25 * 8.0 * (double) q.chunk / (double) q.n_bins) + 32 + 7) & ~7;
+  if (q.cap > 0xFFF0) return F2N_ERR_UNSUPPORTED;
+  const size_t n_seg = (size_t) nl * q.n_bins * F2N_GB_NC;
+  const size_t b_req = (n_seg * q.cap * sizeof(uint16_t) + 255) & ~(size_t) 255, b_res = n_seg * q.cap * sizeof(uint32_t);
+  const size_t b_cnt = (n_seg * sizeof(int32_t) + 255) & ~(size_t) 255, b_slots = (size_t) nl * n * 8 * sizeof(uint16_t);
+  char* ws = (char*) f2n_ws_get(F2N_WS_GATHER_BINS, b_res + b_req + b_cnt + b_slots);
+  if (ws == nullptr) return F2N_ERR_INVALID_ARG;
+  q.res = (uint32_t*) ws;
+  q.req = (uint16_t*) (ws + b_res);
+  q.cnt = (int32_t*) (ws + b_res + b_req);
+  q.slots = (uint16_t*) (ws + b_res + b_req + b_cnt);
+  hipLaunchKernelGGL(gather_request_kernel, dim3(nl * F2N_GB_NC), dim3(256), 0, st, n, h, local_idx, local_size, level_scale, pts,
+                     pts_are_warped, volume_idx, vol_stride, q);
+  hipLaunchKernelGGL(gather_serve_kernel, dim3(nl * q.n_bins), dim3(256), 0, st, (const half_t*) table_h, local_idx, q);
+  hipLaunchKernelGGL(gather_blend_kernel, dim3((unsigned) ((F2N_N_PARTS - p0) * F2N_GB_NC * (q.chunk / 256))), dim3(256), 0, st, n, n_tiles, h, local_idx,
+                     local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride, (half_t*) planes_h, q);
   return f2n_launch_status();
 }
 

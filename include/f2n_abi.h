@@ -403,6 +403,15 @@ int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const vo
  * samples.  out [8][1 + 3*8] int32: per XCD the number of segments, then (level pair, first tile, tile count) per
  * segment (-1, 0, 0 for unused slots); cost8_out [8] (may be NULL): the modelled cost of one tile of each level pair. */
 int f2n_gather_plan_query(int n_tiles, float step01, const float* level_scale_host, int32_t* out, float* cost8_out);
+/* f2n_hash_gather_planes for tables that have left the L2s (Field/Hash3DAnchored.cu:11-79 at confs/wanjinyou_big.yaml's sizes and
+ * beyond; level_entries = local_size[l] = a power of two, 2 * 4096 ... 2^22): level pairs >= first_binned_pair go through a
+ * slice-binned pipeline -- requests binned by 4096-entry table slice, every slice read once into LDS and its requests answered in
+ * queue order, values blended per sample -- instead of one 128-byte fabric line per 4-byte read; pairs below it keep the
+ * partitioned gather.  Planes bit-identical to f2n_hash_gather_planes.  Scratch: library workspace (~0.8 GB at 8e5 samples). */
+int f2n_hash_gather_planes_binned(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
+                                  const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                                  const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,
+                                  int vol_stride, void* planes_h, int level_entries, int first_binned_pair);
 /* ... and the kernel variant it would launch for these sizes (host only, ABI v8): bit 0 = hash constants staged in LDS
  * (2 * n_volumes * 24 B <= 20000 and n >= 16384), bit 1 = run combining + balanced split (the cost model predicts a balanced
  * share below 0.8 x the costliest level pair).  Negative = error.  What the parity tests assert before they claim to have
