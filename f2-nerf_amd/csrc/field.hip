@@ -272,164 +272,228 @@ static void f2n_gather_plan(int n_tiles, const float* cost8 /* NULL: one pair pe
 // Slice-binned gather for tables that have left the L2s (BASELINE config 5: 2^21 / 2^22 entries per level; round 4).
 // With a level slice far larger than an XCD's 4 MiB L2 every hashed read of a fine level is a miss that pulls a 128-byte line
 // across the fabric for 4 bytes of payload (8.35 GB per launch at 2^22: profiles/r03_big22_pmc_tcc.csv).  The mirror image of the
-// owner-binned scatter reads the table ONCE instead:
-//   (1) gather_request_kernel   block (level, sample chunk): hash, and for every corner append the 12-bit entry-in-slice to the
-//       request queue (level, 4096-entry slice, chunk); remember the slot it got (8 x u16 per sample and level, coalesced);
-//   (2) gather_serve_kernel     block (level, slice): the slice (16 KB) into LDS, then every request queue of the slice is answered
-//       IN PLACE ORDER -- result[slot] = slice[request[slot]] -- so both streams are coalesced;
-//   (3) gather_blend_kernel     per sample: hash again (cheaper than carrying cells through memory), pick its eight values out of
-//       its chunk's result queues (a few hundred KB per level and chunk: they stay in the L2 while the chunk's tiles pass), blend
-//       in the order of hash_gather_planes_kernel, write the f16 plane element.
-// A request that finds its queue full (slot 0xFFFF) is read from the table directly in (3).  Coarse level pairs, whose working set
-// fits the L2s whatever the table size, keep the partitioned gather.  Planes are bit-identical (tests/test_gpu_parity.py::
-// test_binned_gather_equals_partitioned_gather).
+// owner-binned scatter reads the table ONCE instead; every intermediate stream is dense and moves through LDS at both ends:
+//   (1) gather_request_kernel   block (level, chunk of 1536 samples): hash; an LDS counter per 4096-entry table slice hands every
+//       corner its slot; the 12-bit entries-in-slice are laid out slice-major in LDS (exclusive scan of the counters) and leave
+//       as ONE dense region of <= 12288 u16 per (level, chunk).  Side outputs: the slot of every corner (8 x u16 per sample and
+//       level), the slice offsets of the region for (3), and (offset, count) transposed to [slice][chunk] for (2);
+//   (2) gather_serve_kernel     block (level, slice): the slice (16 KB) into LDS; 16-lane groups walk the chunks and answer the
+//       slice's segment of each region in place: result[i] = slice[request[i]];
+//   (3) gather_blend_kernel     block (level pair, chunk): per level the chunk's result region (<= 48 KB, dense) and its slice
+//       offsets into LDS; every sample hashes again (cheaper than carrying cells through memory), picks its eight values
+//       from LDS by (slice offset + slot) and blends them in the order of hash_gather_planes_kernel; one 8-byte plane store.
+// Per sample and level: 16 B of requests, 32 B of results and 16 B of slots, each written once and read once (128 B against
+// 8 x 128 B of line fills).  Coarse level pairs, whose working set fits the L2s whatever the table size, keep the partitioned
+// gather.  Planes are bit-identical (tests/test_gpu_parity.py::test_binned_gather_equals_partitioned_gather).
 // ---------------------------------------------------------------------------------------------------
-#define F2N_BIN_SHIFT 12  // (4096-entry table slices: shared with the owner-binned scatter below)
-#define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
-#define F2N_BIN_MAX_BINS 1024
-#define F2N_GB_NC 128  // sample chunks (request producers) per level
+#define F2N_GB_SHIFT 13  // 8192-entry table slices (32 KB in the serving block's LDS; an entry-in-slice is a u16)
+#define F2N_GB_ENTRIES (1 << F2N_GB_SHIFT)
+#define F2N_GB_MAX_BINS 1024
+#define F2N_GB_SERVE_THREADS 512
+#define F2N_GB_THREADS 512
+#define F2N_GB_SPT 3                                   // samples per thread
+#define F2N_GB_CHUNK (F2N_GB_THREADS * F2N_GB_SPT)     // 1536 samples per chunk
+#define F2N_GB_REGION (F2N_GB_CHUNK * 8)               // requests of one (level, chunk)
+#define F2N_GB_MAX_CHUNKS 1024
 struct F2nGatherBins {
-  uint16_t* req;    // [NL][n_bins][NC][cap]
+  uint16_t* req;    // [NL][nc][REGION]: entry-in-slice, slice-major inside a region
   uint32_t* res;    // same shape: the half2 bits of the requested entries
-  int32_t* cnt;     // [NL][n_bins][NC]
+  uint32_t* meta;   // [NL][n_bins][nc]: offset << 16 | count of the slice's segment in chunk's region (the serving block's view)
+  uint16_t* offc;   // [NL][nc][n_bins]: the same offsets chunk-major (the blending block's view)
+  int32_t* total;   // [NL][nc]: requests in the region
   uint16_t* slots;  // [NL][n][8]
-  int cap, n_bins, l0, chunk;
+  int n_bins, l0, nc;
 };
 
-__global__ __launch_bounds__(256) void gather_request_kernel(int n, F2nHashArgs h, const int32_t* __restrict__ local_idx,
-                                                             const int32_t* __restrict__ local_size, const float* __restrict__ level_scale,
-                                                             const float* __restrict__ pts, int pts_are_warped,
-                                                             const int32_t* __restrict__ volume_idx, int vol_stride, F2nGatherBins q) {
+__global__ __launch_bounds__(F2N_GB_THREADS) void gather_request_kernel(
+    int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
+    const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
+    const int32_t* __restrict__ volume_idx, int vol_stride, F2nGatherBins q) {
   __shared__ F2nLevelTab lt;
-  __shared__ int s_cnt[F2N_BIN_MAX_BINS];
-  const int tid = threadIdx.x;
-  const int li = blockIdx.x / F2N_GB_NC, B = blockIdx.x % F2N_GB_NC, l = q.l0 + li;
+  __shared__ int s_cnt[F2N_GB_MAX_BINS];
+  __shared__ int s_off[F2N_GB_MAX_BINS];
+  __shared__ int s_wave[F2N_GB_THREADS / 64];
+  __shared__ uint16_t s_pay[F2N_GB_REGION];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = blockIdx.x / q.nc, B = blockIdx.x % q.nc, l = q.l0 + li;
   f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
-  for (int i = tid; i < q.n_bins; i += 256) s_cnt[i] = 0;
+  for (int i = tid; i < F2N_GB_MAX_BINS; i += F2N_GB_THREADS) s_cnt[i] = 0;
   __syncthreads();
-  const int s_begin = B * q.chunk, s_end = min(n, s_begin + q.chunk);
-  uint16_t* my_req = q.req + ((size_t) li * q.n_bins * F2N_GB_NC + B) * q.cap;  // segment (li, bin, B) = my_req + bin * bin_stride
-  const size_t bin_stride = (size_t) F2N_GB_NC * q.cap;
-  for (int s0 = s_begin; s0 < s_end; s0 += 256) {
-    const int s = s0 + tid;
-    if (s < s_end) {
+  uint32_t pos[F2N_GB_SPT][8], slot[F2N_GB_SPT][4];
+#pragma unroll
+  for (int u = 0; u < F2N_GB_SPT; u++) {
+    const int s = B * F2N_GB_CHUNK + u * F2N_GB_THREADS + tid;
+    if (s < n) {
       float p01[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const float p = pts[3 * (size_t) s + k];
         p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
       }
-      const int vol = volume_idx[(size_t) s * vol_stride];
-      const int tf = l * h.n_volumes + vol;
+      const int tf = l * h.n_volumes + volume_idx[(size_t) s * vol_stride];
       F2nCell cell;
       f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
-      uint32_t packed[4];
 #pragma unroll
       for (int d = 0; d < 8; d++) {
-        const uint32_t pos = cell.pos[d];
-        const int bin = (int) (pos >> F2N_BIN_SHIFT);
-        int slot = atomicAdd(&s_cnt[bin], 1);
-        if (slot < q.cap) my_req[(size_t) bin * bin_stride + slot] = (uint16_t) (pos & (F2N_BIN_ENTRIES - 1));
-        else slot = 0xFFFF;
-        if (d & 1) packed[d >> 1] |= (uint32_t) slot << 16;
-        else packed[d >> 1] = (uint32_t) slot;
+        pos[u][d] = cell.pos[d];
+        const uint32_t got = (uint32_t) atomicAdd(&s_cnt[cell.pos[d] >> F2N_GB_SHIFT], 1);
+        if (d & 1) slot[u][d >> 1] |= got << 16;
+        else slot[u][d >> 1] = got;
       }
-      *(uint4*) (q.slots + ((size_t) li * n + s) * 8) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+      *(uint4*) (q.slots + ((size_t) li * n + s) * 8) = make_uint4(slot[u][0], slot[u][1], slot[u][2], slot[u][3]);
     }
   }
   __syncthreads();
-  for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) li * q.n_bins + i) * F2N_GB_NC + B] = min(s_cnt[i], q.cap);
+  // exclusive scan of the slice counters: two per thread
+  const int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+  int incl = c0 + c1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int before = 0;
+#pragma unroll
+  for (int w = 0; w < F2N_GB_THREADS / 64; w++) before += w < wave ? s_wave[w] : 0;
+  const int excl = before + incl - (c0 + c1);
+  s_off[2 * tid] = excl;
+  s_off[2 * tid + 1] = excl + c0;
+  if (2 * tid < q.n_bins) {
+    uint32_t* meta = q.meta + (size_t) li * q.n_bins * q.nc + B;
+    meta[(size_t) (2 * tid) * q.nc] = (uint32_t) excl << 16 | (uint32_t) c0;
+    meta[(size_t) (2 * tid + 1) * q.nc] = (uint32_t) (excl + c0) << 16 | (uint32_t) c1;
+    ((uint32_t*) (q.offc + ((size_t) li * q.nc + B) * q.n_bins))[tid] = (uint32_t) excl | (uint32_t) (excl + c0) << 16;
+  }
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int w = 0; w < F2N_GB_THREADS / 64; w++) total += s_wave[w];
+  if (tid == 0) q.total[li * q.nc + B] = total;
+#pragma unroll
+  for (int u = 0; u < F2N_GB_SPT; u++) {
+    const int s = B * F2N_GB_CHUNK + u * F2N_GB_THREADS + tid;
+    if (s < n) {
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        const uint32_t got = (d & 1) ? slot[u][d >> 1] >> 16 : slot[u][d >> 1] & 0xFFFFu;
+        s_pay[s_off[pos[u][d] >> F2N_GB_SHIFT] + got] = (uint16_t) (pos[u][d] & (F2N_GB_ENTRIES - 1));
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t* dst = (uint32_t*) (q.req + ((size_t) li * q.nc + B) * F2N_GB_REGION);
+  const uint32_t* src = (const uint32_t*) s_pay;
+  for (int i = tid; i < (total + 1) / 2; i += F2N_GB_THREADS) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(256) void gather_serve_kernel(const half_t* __restrict__ table, const int32_t* __restrict__ local_idx,
-                                                           F2nGatherBins q) {
-  __shared__ uint32_t s_slice[F2N_BIN_ENTRIES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = blockIdx.x / q.n_bins, bin = blockIdx.x % q.n_bins, l = q.l0 + li;
-  const uint32_t* slice = (const uint32_t*) (table + local_idx[l]) + (size_t) bin * F2N_BIN_ENTRIES;
-  for (int i = tid; i < F2N_BIN_ENTRIES; i += 256) s_slice[i] = slice[i];
-  const size_t seg0 = ((size_t) li * q.n_bins + bin) * F2N_GB_NC;
-  // wave w answers chunks w, w + 4, ...: lane j keeps the length of chunk w + 4j (32 per wave)
-  const int my_cnt = lane < F2N_GB_NC / 4 ? q.cnt[seg0 + wave + 4 * lane] : 0;
+// G lanes per chunk segment (the launcher picks G by the mean segment length 12288 / n_bins), U segments of a group in flight:
+// the kernel is a stream of short dependent load -> LDS -> store chains over data other XCDs wrote a moment ago (fabric reads,
+// ~2 us each), so its rate is the bytes it keeps in flight.
+template <int G, int U>
+__global__ __launch_bounds__(F2N_GB_SERVE_THREADS) void gather_serve_kernel(const half_t* __restrict__ table,
+                                                                            const int32_t* __restrict__ local_idx, F2nGatherBins q) {
+  __shared__ uint32_t s_slice[F2N_GB_ENTRIES];
+  __shared__ uint32_t s_meta[F2N_GB_MAX_CHUNKS];
+  constexpr int NG = F2N_GB_SERVE_THREADS / G;
+  const int tid = threadIdx.x, sub = tid % G, grp = tid / G;
+  // Consecutive blocks go to consecutive XCDs: XCD x serves the slices [x, x + 1) * n_bins / 8 of a level in order, so that the
+  // segments of adjacent slices -- neighbours inside every chunk's region, a few dozen bytes each -- share their 128-byte lines
+  // in ONE L2 instead of being fetched by several.
+  const int li = blockIdx.x / q.n_bins, r = blockIdx.x % q.n_bins, l = q.l0 + li;
+  const int bin = (r % F2N_N_PARTS) * (q.n_bins / F2N_N_PARTS) + r / F2N_N_PARTS;
+  const uint32_t* slice = (const uint32_t*) (table + local_idx[l]) + (size_t) bin * F2N_GB_ENTRIES;
+  for (int i = tid; i < F2N_GB_ENTRIES / 4; i += F2N_GB_SERVE_THREADS) ((uint4*) s_slice)[i] = ((const uint4*) slice)[i];
+  const uint32_t* meta = q.meta + ((size_t) li * q.n_bins + bin) * q.nc;
+  for (int i = tid; i < q.nc; i += F2N_GB_SERVE_THREADS) s_meta[i] = meta[i];
   __syncthreads();
-  for (int k0 = 0; k0 < F2N_GB_NC / 4; k0 += 4) {  // four queues at a time, up to three rounds of 64 requests each in flight
-    uint16_t e[4][3];
-    int cnt[4];
-    size_t off[4];
+  const size_t region0 = (size_t) li * q.nc * F2N_GB_REGION;
+  for (int B0 = grp; B0 < q.nc; B0 += NG * U) {
+    uint16_t e[U];
+    size_t at[U];
+    int cnt[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      cnt[u] = __shfl(my_cnt, k0 + u);
-      off[u] = (seg0 + wave + 4 * (k0 + u)) * q.cap;
-#pragma unroll
-      for (int r = 0; r < 3; r++) e[u][r] = lane + 64 * r < cnt[u] ? q.req[off[u] + lane + 64 * r] : (uint16_t) 0;
+    for (int u = 0; u < U; u++) {
+      const int B = B0 + NG * u;
+      const uint32_t m = B < q.nc ? s_meta[B] : 0u;
+      cnt[u] = (int) (m & 0xFFFFu);
+      at[u] = region0 + (size_t) B * F2N_GB_REGION + (m >> 16);
+      e[u] = sub < cnt[u] ? q.req[at[u] + sub] : (uint16_t) 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-        if (lane + 64 * r < cnt[u]) q.res[off[u] + lane + 64 * r] = s_slice[e[u][r]];
-      for (int i = lane + 192; i < cnt[u]; i += 64) q.res[off[u] + i] = s_slice[q.req[off[u] + i]];
+    for (int u = 0; u < U; u++) {
+      if (sub < cnt[u]) q.res[at[u] + sub] = s_slice[e[u]];
+      for (int i = sub + G; i < cnt[u]; i += G) q.res[at[u] + i] = s_slice[q.req[at[u] + i]];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void gather_blend_kernel(int n, int n_tiles, F2nHashArgs h, const int32_t* __restrict__ local_idx,
-                                                           const int32_t* __restrict__ local_size, const float* __restrict__ level_scale,
-                                                           const float* __restrict__ pts, int pts_are_warped,
-                                                           const int32_t* __restrict__ volume_idx, int vol_stride,
-                                                           half_t* __restrict__ planes, F2nGatherBins q) {
+__global__ __launch_bounds__(F2N_GB_THREADS) void gather_blend_kernel(
+    int n, F2nHashArgs h, const int32_t* __restrict__ local_idx, const int32_t* __restrict__ local_size,
+    const float* __restrict__ level_scale, const float* __restrict__ pts, int pts_are_warped,
+    const int32_t* __restrict__ volume_idx, int vol_stride, half_t* __restrict__ planes, F2nGatherBins q) {
   __shared__ F2nLevelTab lt;
+  __shared__ uint32_t s_res[F2N_GB_REGION];
+  __shared__ uint16_t s_off[F2N_GB_MAX_BINS];
   const int tid = threadIdx.x;
+  const int pi = blockIdx.x / q.nc, B = blockIdx.x % q.nc, part = q.l0 / 2 + pi;
   f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
-  __syncthreads();
-  // A chunk's tiles all run on XCD (chunk % 8) -- blockIdx round-robins over the XCDs -- so that a chunk's result queues are
-  // pulled into ONE L2 instead of eight.
-  const int tpc = q.chunk / 256, x = blockIdx.x % F2N_N_PARTS, k = blockIdx.x / F2N_N_PARTS;
-  const int chunk_id = x + F2N_N_PARTS * ((k / tpc) % (F2N_GB_NC / F2N_N_PARTS));
-  const int part = q.l0 / 2 + k / (tpc * (F2N_GB_NC / F2N_N_PARTS)), tile = chunk_id * tpc + k % tpc;
-  const int s = tile * 256 + tid;
-  if (s >= n) return;
-  float p01[3];
+  float p01[F2N_GB_SPT][3];
+  int vol[F2N_GB_SPT];
+  half4_t out[F2N_GB_SPT];
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const float p = pts[3 * (size_t) s + k];
-    p01[k] = pts_are_warped ? (p + 1.f) * .5f : p;
+  for (int u = 0; u < F2N_GB_SPT; u++) {
+    const int s = B * F2N_GB_CHUNK + u * F2N_GB_THREADS + tid;
+    const int sc = s < n ? s : n - 1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float p = pts[3 * (size_t) sc + k];
+      p01[u][k] = pts_are_warped ? (p + 1.f) * .5f : p;
+    }
+    vol[u] = volume_idx[(size_t) sc * vol_stride];
   }
-  const int vol = volume_idx[(size_t) s * vol_stride];
-  const int B = s / q.chunk;
-  half4_t out;
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    const int l = 2 * part + j, li = l - q.l0;
-    const int tf = l * h.n_volumes + vol;
-    F2nCell cell;
-    f2n_hash_cell(p01, lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
-    const uint4 sl = *(const uint4*) (q.slots + ((size_t) li * n + s) * 8);
-    const uint32_t packed[4] = {sl.x, sl.y, sl.z, sl.w};
-    const half2_t* base = (const half2_t*) (h.table + lt.base[l]);
-    half2_t v[8];
+    const int li = 2 * pi + j, l = q.l0 + li;
+    __syncthreads();  // lt filled / the previous level's region is no longer read
+    const int total = q.total[li * q.nc + B];
+    const uint4* src = (const uint4*) (q.res + ((size_t) li * q.nc + B) * F2N_GB_REGION);
+    for (int i = tid; i < (total + 3) / 4; i += F2N_GB_THREADS) ((uint4*) s_res)[i] = src[i];
+    if (2 * tid < q.n_bins) ((uint32_t*) s_off)[tid] = ((const uint32_t*) (q.offc + ((size_t) li * q.nc + B) * q.n_bins))[tid];
+    __syncthreads();
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-      const uint32_t slot = (d & 1) ? packed[d >> 1] >> 16 : packed[d >> 1] & 0xFFFFu;
-      const uint32_t pos = cell.pos[d];
-      if (slot != 0xFFFFu) {
-        const size_t seg = ((size_t) li * q.n_bins + (pos >> F2N_BIN_SHIFT)) * F2N_GB_NC + B;
-        v[d] = __builtin_bit_cast(half2_t, q.res[seg * q.cap + slot]);
-      } else {
-        v[d] = base[pos];  // its queue was full: read from the table directly
+    for (int u = 0; u < F2N_GB_SPT; u++) {
+      const int s = B * F2N_GB_CHUNK + u * F2N_GB_THREADS + tid;
+      if (s < n) {
+        const int tf = l * h.n_volumes + vol[u];
+        F2nCell cell;
+        f2n_hash_cell(p01[u], lt.scale[l], h.prim_pool + 3 * tf, h.bias_pool + 3 * tf, lt.size[l], cell);
+        const uint4 sl = *(const uint4*) (q.slots + ((size_t) li * n + s) * 8);
+        const uint32_t packed[4] = {sl.x, sl.y, sl.z, sl.w};
+        half2_t v[8];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          const uint32_t got = (d & 1) ? packed[d >> 1] >> 16 : packed[d >> 1] & 0xFFFFu;
+          v[d] = __builtin_bit_cast(half2_t, s_res[s_off[cell.pos[d] >> F2N_GB_SHIFT] + got]);
+        }
+        float s0 = cell.w[0] * (float) v[0][0];  // same fp32 summation order as hash_gather_planes_kernel / the oracle
+        float s1 = cell.w[0] * (float) v[0][1];
+#pragma unroll
+        for (int d = 1; d < 8; d++) {
+          s0 = s0 + cell.w[d] * (float) v[d][0];
+          s1 = s1 + cell.w[d] * (float) v[d][1];
+        }
+        out[u][2 * j] = (half_t) s0;
+        out[u][2 * j + 1] = (half_t) s1;
       }
     }
-    float s0 = cell.w[0] * (float) v[0][0];  // same fp32 summation order as hash_gather_planes_kernel / the oracle
-    float s1 = cell.w[0] * (float) v[0][1];
-#pragma unroll
-    for (int d = 1; d < 8; d++) {
-      s0 = s0 + cell.w[d] * (float) v[d][0];
-      s1 = s1 + cell.w[d] * (float) v[d][1];
-    }
-    out[2 * j] = (half_t) s0;
-    out[2 * j + 1] = (half_t) s1;
   }
-  *(half4_t*) (planes + ((size_t) part * n + s) * 4) = out;
+#pragma unroll
+  for (int u = 0; u < F2N_GB_SPT; u++) {
+    const int s = B * F2N_GB_CHUNK + u * F2N_GB_THREADS + tid;
+    if (s < n) *(half4_t*) (planes + ((size_t) part * n + s) * 4) = out[u];
+  }
 }
 
 // (pair, tile) units of the pairs [0, n_pairs) dealt to the 8 XCD shares of the partitioned gather in pair-major order.
@@ -600,7 +664,6 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 __device__ __forceinline__ int f2n_bin_nb(int n_true, int force = 0) {
   return force > 0 ? force : n_true > 393216 ? 128 : n_true > 131072 ? 64 : 32;
 }
-#undef F2N_BIN_MAX_BINS
 #define F2N_BIN_MAX_BINS 1024  // tables up to 2^22 entries per level (BASELINE config 5)
 #define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
@@ -1365,8 +1428,8 @@ int f2n_hash_gather_planes_binned(void* stream, int n, int n_volumes, const void
                                   int vol_stride, void* planes_h, int level_entries, int first_binned_pair) {
   const int p0 = first_binned_pair;
   if (n < 0 || n_volumes <= 0 || vol_stride < 1 || p0 < 0 || p0 > F2N_N_PARTS) return F2N_ERR_INVALID_ARG;
-  if (level_entries < 2 * F2N_BIN_ENTRIES || (level_entries & (level_entries - 1)) != 0 || (level_entries >> F2N_BIN_SHIFT) > F2N_BIN_MAX_BINS)
-    return F2N_ERR_UNSUPPORTED;  // (the reference's table layout: local_size[l] = E, a power of two, whole 4096-entry slices)
+  if (level_entries < F2N_N_PARTS * F2N_GB_ENTRIES || (level_entries & (level_entries - 1)) != 0 || (level_entries >> F2N_GB_SHIFT) > F2N_GB_MAX_BINS)
+    return F2N_ERR_UNSUPPORTED;  // (the reference's table layout: local_size[l] = E, a power of two, whole 8192-entry slices)
   if (n == 0) return F2N_OK;
   hipStream_t st = (hipStream_t) stream;
   F2nHashArgs h = {(const half_t*) table_h, prim_pool, bias_pool, n_volumes};
@@ -1385,24 +1448,30 @@ int f2n_hash_gather_planes_binned(void* stream, int n, int n_volumes, const void
   F2nGatherBins q;
   q.l0 = 2 * p0;
   const int nl = F2N_N_LEVELS - q.l0;
-  q.n_bins = level_entries >> F2N_BIN_SHIFT;
-  q.chunk = (((n + F2N_GB_NC - 1) / F2N_GB_NC) + 255) & ~255;
-  q.cap = ((int) (1.25 * 8.0 * (double) q.chunk / (double) q.n_bins) + 32 + 7) & ~7;
-  if (q.cap > 0xFFF0) return F2N_ERR_UNSUPPORTED;
-  const size_t n_seg = (size_t) nl * q.n_bins * F2N_GB_NC;
-  const size_t b_req = (n_seg * q.cap * sizeof(uint16_t) + 255) & ~(size_t) 255, b_res = n_seg * q.cap * sizeof(uint32_t);
-  const size_t b_cnt = (n_seg * sizeof(int32_t) + 255) & ~(size_t) 255, b_slots = (size_t) nl * n * 8 * sizeof(uint16_t);
-  char* ws = (char*) f2n_ws_get(F2N_WS_GATHER_BINS, b_res + b_req + b_cnt + b_slots);
+  q.n_bins = level_entries >> F2N_GB_SHIFT;
+  q.nc = (n + F2N_GB_CHUNK - 1) / F2N_GB_CHUNK;
+  if (q.nc > F2N_GB_MAX_CHUNKS) return F2N_ERR_UNSUPPORTED;
+  const size_t n_regions = (size_t) nl * q.nc;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+  const size_t b_res = up(n_regions * F2N_GB_REGION * sizeof(uint32_t)), b_req = up(n_regions * F2N_GB_REGION * sizeof(uint16_t));
+  const size_t b_meta = up(n_regions * q.n_bins * sizeof(uint32_t)), b_offc = up(n_regions * q.n_bins * sizeof(uint16_t));
+  const size_t b_total = up(n_regions * sizeof(int32_t)), b_slots = up((size_t) nl * n * 8 * sizeof(uint16_t));
+  char* ws = (char*) f2n_ws_get(F2N_WS_GATHER_BINS, b_res + b_req + b_meta + b_offc + b_total + b_slots);
   if (ws == nullptr) return F2N_ERR_INVALID_ARG;
   q.res = (uint32_t*) ws;
   q.req = (uint16_t*) (ws + b_res);
-  q.cnt = (int32_t*) (ws + b_res + b_req);
-  q.slots = (uint16_t*) (ws + b_res + b_req + b_cnt);
-  hipLaunchKernelGGL(gather_request_kernel, dim3(nl * F2N_GB_NC), dim3(256), 0, st, n, h, local_idx, local_size, level_scale, pts,
-                     pts_are_warped, volume_idx, vol_stride, q);
-  hipLaunchKernelGGL(gather_serve_kernel, dim3(nl * q.n_bins), dim3(256), 0, st, (const half_t*) table_h, local_idx, q);
-  hipLaunchKernelGGL(gather_blend_kernel, dim3((unsigned) ((F2N_N_PARTS - p0) * F2N_GB_NC * (q.chunk / 256))), dim3(256), 0, st, n, n_tiles, h, local_idx,
-                     local_size, level_scale, pts, pts_are_warped, volume_idx, vol_stride, (half_t*) planes_h, q);
+  q.meta = (uint32_t*) (ws + b_res + b_req);
+  q.offc = (uint16_t*) (ws + b_res + b_req + b_meta);
+  q.total = (int32_t*) (ws + b_res + b_req + b_meta + b_offc);
+  q.slots = (uint16_t*) (ws + b_res + b_req + b_meta + b_offc + b_total);
+  hipLaunchKernelGGL(gather_request_kernel, dim3(nl * q.nc), dim3(F2N_GB_THREADS), 0, st, n, h, local_idx, local_size, level_scale,
+                     pts, pts_are_warped, volume_idx, vol_stride, q);
+  if (F2N_GB_REGION / q.n_bins > 40)  // mean segment length: 48 at 2^21 entries per level, 24 at 2^22
+    hipLaunchKernelGGL((gather_serve_kernel<64, 4>), dim3(nl * q.n_bins), dim3(F2N_GB_SERVE_THREADS), 0, st, (const half_t*) table_h, local_idx, q);
+  else
+    hipLaunchKernelGGL((gather_serve_kernel<32, 4>), dim3(nl * q.n_bins), dim3(F2N_GB_SERVE_THREADS), 0, st, (const half_t*) table_h, local_idx, q);
+  hipLaunchKernelGGL(gather_blend_kernel, dim3((F2N_N_PARTS - p0) * q.nc), dim3(F2N_GB_THREADS), 0, st, n, h, local_idx, local_size,
+                     level_scale, pts, pts_are_warped, volume_idx, vol_stride, (half_t*) planes_h, q);
   return f2n_launch_status();
 }
 

@@ -318,14 +318,18 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
     // stretched by the distance scaling where it is on), half of that in the [0,1] space the grid hashes (:91)
     const float step01 = march_step_warped_ * global_data_pool_->ray_march_fineness_ * .5f;
     // Tables that have left the L2s (2^21 entries per level and more: BASELINE config 5) take the slice-binned gather for the level
-    // pairs whose working set exceeds an L2 -- F2N_BINNED_GATHER_P0 (measurement knob): first binned pair, 8 = off, default 3
+    // pairs whose working set exceeds an L2 -- F2N_BINNED_GATHER_P0 (measurement knob): first binned pair, 8 = off, default 1
     static const int binned_p0 = []() {
       const char* e = std::getenv("F2N_BINNED_GATHER_P0");
-      const int v = e != nullptr ? std::atoi(e) : 3;
+      const int v = e != nullptr ? std::atoi(e) : 1;
       return v < 0 ? 0 : (v > 8 ? 8 : v);
     }();
+    static const int binned_min_log2 = []() {
+      const char* e = std::getenv("F2N_BINNED_GATHER_MIN_LOG2");
+      return e != nullptr ? std::atoi(e) : 21;
+    }();
     const int level_entries = (int) (pool_size_ / N_LEVELS);
-    if (binned_p0 < 8 && level_entries >= (1 << 21) && level_entries <= (1 << 22) && n >= 65536) {
+    if (binned_p0 < 8 && level_entries >= (1 << binned_min_log2) && level_entries <= (1 << 22) && n >= 65536 && n <= 1536 * 1024) {
       F2N_TIMED_CALL("hash_gather", f2n_hash_gather_planes_binned(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),
                              I32P(feat_local_idx_), I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), 1,
                              I32P(av.t), av.stride, VoidP(planes), level_entries, binned_p0));
