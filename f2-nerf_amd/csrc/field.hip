@@ -273,11 +273,11 @@ static void f2n_gather_plan(int n_tiles, const float* cost8 /* NULL: one pair pe
 // With a level slice far larger than an XCD's 4 MiB L2 every hashed read of a fine level is a miss that pulls a 128-byte line
 // across the fabric for 4 bytes of payload (8.35 GB per launch at 2^22: profiles/r03_big22_pmc_tcc.csv).  The mirror image of the
 // owner-binned scatter reads the table ONCE instead; every intermediate stream is dense and moves through LDS at both ends:
-//   (1) gather_request_kernel   block (level, chunk of 1536 samples): hash; an LDS counter per 4096-entry table slice hands every
-//       corner its slot; the 12-bit entries-in-slice are laid out slice-major in LDS (exclusive scan of the counters) and leave
+//   (1) gather_request_kernel   block (level, chunk of 1536 samples): hash; an LDS counter per 8192-entry table slice hands every
+//       corner its slot; the 13-bit entries-in-slice are laid out slice-major in LDS (exclusive scan of the counters) and leave
 //       as ONE dense region of <= 12288 u16 per (level, chunk).  Side outputs: the slot of every corner (8 x u16 per sample and
-//       level), the slice offsets of the region for (3), and (offset, count) transposed to [slice][chunk] for (2);
-//   (2) gather_serve_kernel     block (level, slice): the slice (16 KB) into LDS; 16-lane groups walk the chunks and answer the
+//       level) and the region's slice offsets;
+//   (2) gather_serve_kernel     block (level, slice): the slice (32 KB) into LDS; lane groups walk the chunks and answer the
 //       slice's segment of each region in place: result[i] = slice[request[i]];
 //   (3) gather_blend_kernel     block (level pair, chunk): per level the chunk's result region (<= 48 KB, dense) and its slice
 //       offsets into LDS; every sample hashes again (cheaper than carrying cells through memory), picks its eight values
@@ -298,8 +298,7 @@ static void f2n_gather_plan(int n_tiles, const float* cost8 /* NULL: one pair pe
 struct F2nGatherBins {
   uint16_t* req;    // [NL][nc][REGION]: entry-in-slice, slice-major inside a region
   uint32_t* res;    // same shape: the half2 bits of the requested entries
-  uint32_t* meta;   // [NL][n_bins][nc]: offset << 16 | count of the slice's segment in chunk's region (the serving block's view)
-  uint16_t* offc;   // [NL][nc][n_bins]: the same offsets chunk-major (the blending block's view)
+  uint16_t* offc;   // [NL][nc][n_bins]: where a slice's segment starts in the chunk's region
   int32_t* total;   // [NL][nc]: requests in the region
   uint16_t* slots;  // [NL][n][8]
   int n_bins, l0, nc;
@@ -361,9 +360,6 @@ __global__ __launch_bounds__(F2N_GB_THREADS) void gather_request_kernel(
   s_off[2 * tid] = excl;
   s_off[2 * tid + 1] = excl + c0;
   if (2 * tid < q.n_bins) {
-    uint32_t* meta = q.meta + (size_t) li * q.n_bins * q.nc + B;
-    meta[(size_t) (2 * tid) * q.nc] = (uint32_t) excl << 16 | (uint32_t) c0;
-    meta[(size_t) (2 * tid + 1) * q.nc] = (uint32_t) (excl + c0) << 16 | (uint32_t) c1;
     ((uint32_t*) (q.offc + ((size_t) li * q.nc + B) * q.n_bins))[tid] = (uint32_t) excl | (uint32_t) (excl + c0) << 16;
   }
   __syncthreads();
@@ -388,9 +384,23 @@ __global__ __launch_bounds__(F2N_GB_THREADS) void gather_request_kernel(
   for (int i = tid; i < (total + 1) / 2; i += F2N_GB_THREADS) dst[i] = src[i];
 }
 
-// G lanes per chunk segment (the launcher picks G by the mean segment length 12288 / n_bins), U segments of a group in flight:
-// the kernel is a stream of short dependent load -> LDS -> store chains over data other XCDs wrote a moment ago (fabric reads,
-// ~2 us each), so its rate is the bytes it keeps in flight.
+// A group of G lanes per chunk segment, FOUR requests per lane (one aligned 8-byte load, one 16-byte store; the launcher picks
+// G by the mean segment length 12288 / n_bins), U segments of a group in flight: the kernel is a stream of short dependent
+// load -> LDS -> store chains over data other XCDs wrote a moment ago, so its rate is the bytes it keeps in flight.
+__device__ __forceinline__ void f2n_serve4(const uint32_t* s_slice, uint2 ld, uint32_t* res, int idx, int first, int last) {
+  const uint32_t e[4] = {ld.x & 0xFFFFu, ld.x >> 16, ld.y & 0xFFFFu, ld.y >> 16};
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = s_slice[e[k] & (F2N_GB_ENTRIES - 1)];  // (neighbouring segments' entries at the edges)
+  if (idx >= first && idx + 4 <= last) {
+    *(uint4*) (res + idx) = make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (idx + k >= first && idx + k < last) res[idx + k] = v[k];
+  }
+}
+
 template <int G, int U>
 __global__ __launch_bounds__(F2N_GB_SERVE_THREADS) void gather_serve_kernel(const half_t* __restrict__ table,
                                                                             const int32_t* __restrict__ local_idx, F2nGatherBins q) {
@@ -405,26 +415,34 @@ __global__ __launch_bounds__(F2N_GB_SERVE_THREADS) void gather_serve_kernel(cons
   const int bin = (r % F2N_N_PARTS) * (q.n_bins / F2N_N_PARTS) + r / F2N_N_PARTS;
   const uint32_t* slice = (const uint32_t*) (table + local_idx[l]) + (size_t) bin * F2N_GB_ENTRIES;
   for (int i = tid; i < F2N_GB_ENTRIES / 4; i += F2N_GB_SERVE_THREADS) ((uint4*) s_slice)[i] = ((const uint4*) slice)[i];
-  const uint32_t* meta = q.meta + ((size_t) li * q.n_bins + bin) * q.nc;
-  for (int i = tid; i < q.nc; i += F2N_GB_SERVE_THREADS) s_meta[i] = meta[i];
+  // (offset, count) of this slice's segment in every chunk's region: two u16 out of the chunk's offset row -- rows are 2 n_bins
+  // bytes apart, but the blocks of adjacent slices run on this XCD at the same time and find the lines in its L2
+  for (int B = tid; B < q.nc; B += F2N_GB_SERVE_THREADS) {
+    const uint16_t* row = q.offc + ((size_t) li * q.nc + B) * q.n_bins;
+    const uint32_t off = row[bin], end = bin + 1 < q.n_bins ? (uint32_t) row[bin + 1] : (uint32_t) q.total[li * q.nc + B];
+    s_meta[B] = off << 16 | (end - off);
+  }
   __syncthreads();
   const size_t region0 = (size_t) li * q.nc * F2N_GB_REGION;
   for (int B0 = grp; B0 < q.nc; B0 += NG * U) {
-    uint16_t e[U];
-    size_t at[U];
-    int cnt[U];
+    uint2 ld[U];
+    size_t base[U];
+    int first[U], last[U], idx[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int B = B0 + NG * u;
       const uint32_t m = B < q.nc ? s_meta[B] : 0u;
-      cnt[u] = (int) (m & 0xFFFFu);
-      at[u] = region0 + (size_t) B * F2N_GB_REGION + (m >> 16);
-      e[u] = sub < cnt[u] ? q.req[at[u] + sub] : (uint16_t) 0;
+      first[u] = (int) (m >> 16);
+      last[u] = first[u] + (int) (m & 0xFFFFu);
+      base[u] = region0 + (size_t) B * F2N_GB_REGION;
+      idx[u] = (first[u] & ~3) + 4 * sub;
+      ld[u] = idx[u] < last[u] ? *(const uint2*) (q.req + base[u] + idx[u]) : make_uint2(0u, 0u);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (sub < cnt[u]) q.res[at[u] + sub] = s_slice[e[u]];
-      for (int i = sub + G; i < cnt[u]; i += G) q.res[at[u] + i] = s_slice[q.req[at[u] + i]];
+      if (idx[u] < last[u]) f2n_serve4(s_slice, ld[u], q.res + base[u], idx[u], first[u], last[u]);
+      for (int i = idx[u] + 4 * G; i < last[u]; i += 4 * G)
+        f2n_serve4(s_slice, *(const uint2*) (q.req + base[u] + i), q.res + base[u], i, first[u], last[u]);
     }
   }
 }
@@ -1454,22 +1472,21 @@ int f2n_hash_gather_planes_binned(void* stream, int n, int n_volumes, const void
   const size_t n_regions = (size_t) nl * q.nc;
   auto up = [](size_t b) { return (b + 255) & ~(size_t) 255; };
   const size_t b_res = up(n_regions * F2N_GB_REGION * sizeof(uint32_t)), b_req = up(n_regions * F2N_GB_REGION * sizeof(uint16_t));
-  const size_t b_meta = up(n_regions * q.n_bins * sizeof(uint32_t)), b_offc = up(n_regions * q.n_bins * sizeof(uint16_t));
+  const size_t b_offc = up(n_regions * q.n_bins * sizeof(uint16_t));
   const size_t b_total = up(n_regions * sizeof(int32_t)), b_slots = up((size_t) nl * n * 8 * sizeof(uint16_t));
-  char* ws = (char*) f2n_ws_get(F2N_WS_GATHER_BINS, b_res + b_req + b_meta + b_offc + b_total + b_slots);
+  char* ws = (char*) f2n_ws_get(F2N_WS_GATHER_BINS, b_res + b_req + b_offc + b_total + b_slots);
   if (ws == nullptr) return F2N_ERR_INVALID_ARG;
   q.res = (uint32_t*) ws;
   q.req = (uint16_t*) (ws + b_res);
-  q.meta = (uint32_t*) (ws + b_res + b_req);
-  q.offc = (uint16_t*) (ws + b_res + b_req + b_meta);
-  q.total = (int32_t*) (ws + b_res + b_req + b_meta + b_offc);
-  q.slots = (uint16_t*) (ws + b_res + b_req + b_meta + b_offc + b_total);
+  q.offc = (uint16_t*) (ws + b_res + b_req);
+  q.total = (int32_t*) (ws + b_res + b_req + b_offc);
+  q.slots = (uint16_t*) (ws + b_res + b_req + b_offc + b_total);
   hipLaunchKernelGGL(gather_request_kernel, dim3(nl * q.nc), dim3(F2N_GB_THREADS), 0, st, n, h, local_idx, local_size, level_scale,
                      pts, pts_are_warped, volume_idx, vol_stride, q);
   if (F2N_GB_REGION / q.n_bins > 40)  // mean segment length: 48 at 2^21 entries per level, 24 at 2^22
-    hipLaunchKernelGGL((gather_serve_kernel<64, 4>), dim3(nl * q.n_bins), dim3(F2N_GB_SERVE_THREADS), 0, st, (const half_t*) table_h, local_idx, q);
+    hipLaunchKernelGGL((gather_serve_kernel<16, 4>), dim3(nl * q.n_bins), dim3(F2N_GB_SERVE_THREADS), 0, st, (const half_t*) table_h, local_idx, q);
   else
-    hipLaunchKernelGGL((gather_serve_kernel<32, 4>), dim3(nl * q.n_bins), dim3(F2N_GB_SERVE_THREADS), 0, st, (const half_t*) table_h, local_idx, q);
+    hipLaunchKernelGGL((gather_serve_kernel<8, 4>), dim3(nl * q.n_bins), dim3(F2N_GB_SERVE_THREADS), 0, st, (const half_t*) table_h, local_idx, q);
   hipLaunchKernelGGL(gather_blend_kernel, dim3((F2N_N_PARTS - p0) * q.nc), dim3(F2N_GB_THREADS), 0, st, n, h, local_idx, local_size,
                      level_scale, pts, pts_are_warped, volume_idx, vol_stride, (half_t*) planes_h, q);
   return f2n_launch_status();
