@@ -143,8 +143,10 @@ def psnr_runs(args, n_runs):
 def psnr_numerics_ab(args):
     """PSNR@20k as a distribution, and as an A/B of the two numerics (round-2 verdict, "make the PSNR claim testable"): two
     worker processes of this script (one per build of the kernel library: include/f2n_abi.h f2n_numerics_mode) train the fox
-    scene args.psnr_runs / args.psnr_ref_runs times from one seed, side by side on the one GPU."""
-    procs = {}
+    scene args.psnr_runs / args.psnr_ref_runs times, ONE AFTER THE OTHER (until round 4 they shared the GPU: a training then
+    took three times as long, so nothing was gained, and a co-tenant is the one condition under which two product trainings
+    from one seed have been seen to part -- DESIGN.md section 7, "reproducibility")."""
+    out = {}
     for tag, n, envv in (("product", args.psnr_runs, "0"), ("reference_numerics", args.psnr_ref_runs, "1")):
         if n <= 0:
             continue
@@ -153,9 +155,7 @@ def psnr_numerics_ab(args):
             env.pop(k, None)
         cmd = [sys.executable, os.path.abspath(__file__), "--psnr-worker", str(n), "--train-iters", str(args.train_iters),
                "--factor", str(args.factor), "--preset", args.preset]
-        procs[tag] = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
-    out = {}
-    for tag, p in procs.items():
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
         so = se = ""
         try:
             so, se = p.communicate(timeout=1500)
@@ -184,8 +184,8 @@ def psnr_numerics_ab(args):
                                      "mean_db": round(float(dif.mean()), 3),
                                      "standard_error_db": round(float(dif.std(ddof=1) / np.sqrt(k)), 3)}
         out["pooled_evidence"] = "profiles/r03_psnr_study.json: 16 + 14 runs over three invocations (round 3: one seed, run-to-run spread)"
-    out["note"] = ("run r of either build trains from seed 2022 + r, same explicit schedule; the two workers share the GPU, so their "
-                   "train_wall_s are NOT timings. "
+    out["note"] = ("run r of either build trains from seed 2022 + r, same explicit schedule; the two workers run one after the other "
+                   "(their train_wall_s include the checkpoints' host round trips). "
                    "reference_numerics = libf2n_hip_refnum.so: hash gradient by per-addend packed-f16 atomics in arrival order "
                    "(Hash3DAnchored.cu:145-153) and an f16 accumulator in the MLP forward products; product = fp32 MFMA accumulation, "
                    "owner-binned hash-gradient sums rounded to f16 once")
@@ -532,14 +532,16 @@ def main():
             traffic = None
             # per-workload counter files (profiles/run_profiles.sh): the headline workload, or the big-table stress points
             tfile = TRAFFIC_FILE
-            if args.preset == "wanjinyou_big":
-                tfile = os.path.join(ROOT, "profiles", "r03_big%d_traffic.json" % log2)
+            if args.preset == "wanjinyou_big":  # (2^21 and up: the slice-binned gather of round 4, four kernels behind one call)
+                tfile = os.path.join(ROOT, "profiles", ("r04_big%d_traffic.json" if log2 >= 21 else "r03_big%d_traffic.json") % log2)
             elif args.preset != "wanjinyou" or args.log2 not in (0, 19) or args.rays != 8192:
                 tfile = ""  # (no counters were collected for this workload)
             traffic_source = None
             if tfile and os.path.exists(tfile):
                 with open(tfile) as f:
-                    traffic = json.load(f).get("hash_gather_planes_kernel", {}).get("hbm_bytes_per_launch")
+                    per_kernel = json.load(f)
+                traffic = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in per_kernel.items()
+                              if "hash_gather_planes_kernel" in k or "gather_request_kernel" in k or "gather_serve_kernel" in k or "gather_blend_kernel" in k) or None
                 # (PMC counters cannot ride in a timed run: the figure is READ from the committed counter pass of this workload)
                 traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/run_profiles.sh; not measured in this run)" % os.path.relpath(tfile, ROOT)
             roofline = {"bound": "hbm", "kernel": "hash_gather_planes_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -569,7 +571,8 @@ def main():
                                             "frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                             "note": "FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch / launch duration: far below 1 with an L2-"
                                                     "resident table (2^19: the reads never leave the XCD), ~0.75 where every 4-byte read "
-                                                    "pulls a 128-byte line across the fabric (2^22: profiles/r03_big22_pmc_tcc.csv)"}
+                                                    "pulls a 128-byte line across the fabric (2^20; 2^22 before round 4's slice-binned gather: "
+                                                    "profiles/r03_big22_pmc_tcc.csv, profiles/r04_binned_gather.txt)"}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -586,7 +589,7 @@ def main():
             except Exception as e:  # reported next to the headline, never instead of it
                 import traceback
                 converged = {"error": (str(e) + " | " + traceback.format_exc()[-600:])[:900]}
-            if args.psnr_runs > 0 or args.psnr_ref_runs > 0:  # (after every timed region: the workers share the GPU)
+            if args.psnr_runs > 0 or args.psnr_ref_runs > 0:  # (after every timed region)
                 try:
                     converged["psnr_numerics_ab"] = psnr_numerics_ab(args)
                 except Exception as e:

@@ -74,6 +74,11 @@ def debug_counters(reset=False):
     return [int(v) for v in out]
 
 
+def debug_spin(microseconds):
+    """One wave spinning for that long on the current stream (f2n_debug_spin)."""
+    _ck(lib().f2n_debug_spin(_stream(), _i(microseconds)), "f2n_debug_spin")
+
+
 # ---------------------------------------------------------------- sampler
 def normalize_dirs(n, dirs, out):
     _ck(lib().f2n_normalize_dirs(_stream(), _i(n), _p(dirs, "f32"), _p(out, "f32")), "f2n_normalize_dirs")

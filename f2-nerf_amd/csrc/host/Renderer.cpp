@@ -9,6 +9,7 @@
 #include <ATen/hip/HIPGeneratorImpl.h>
 #include <hip/hip_runtime_api.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace f2n {
@@ -253,6 +254,37 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
   presample_rays_d_ = rays_d;
 }
 
+// F2N_DEBUG_SIDE_DELAY="begin_us:complete_us:main_us:period" (debugging aid, off by default): every period-th speculative begin /
+// completion / step is preceded by a spin kernel of that many microseconds on its stream (f2n_debug_spin), which skews the sampler's
+// side streams against the main stream.  Results must not depend on it (tools/determinism_probe.py --side-delay).
+namespace {
+struct SideDelay {
+  int begin_us = 0, complete_us = 0, main_us = 0, period = 1;
+  uint64_t calls[3] = {0, 0, 0};
+  SideDelay() {
+    const char* e = std::getenv("F2N_DEBUG_SIDE_DELAY");
+    if (e != nullptr) std::sscanf(e, "%d:%d:%d:%d", &begin_us, &complete_us, &main_us, &period);
+    if (period < 1) period = 1;
+  }
+  void Apply(int which) {
+    const int us = which == 0 ? begin_us : which == 1 ? complete_us : main_us;
+    if (us > 0 && (calls[which]++ % (uint64_t) period) == 0) F2N_CALL(f2n_debug_spin(CurStream(), us));
+  }
+};
+SideDelay& DebugSideDelay() {
+  static SideDelay d;
+  return d;
+}
+}  // namespace
+
+void Renderer::SetDebugSideDelay(int begin_us, int complete_us, int main_us, int period) {
+  auto& d = DebugSideDelay();
+  d.begin_us = begin_us;
+  d.complete_us = complete_us;
+  d.main_us = main_us;
+  d.period = period < 1 ? 1 : period;
+}
+
 // The two side streams are per DEVICE, not per Renderer: a process that builds a second runner (bench.py: the headline runner, then
 // the converged leg's) would otherwise hold five streams -- main + 2 + 2 -- and HIP multiplexes streams onto four hardware queues
 // by default: the second runner's sampler then shared a queue with its own main stream (measured: 20 000 iterations 17.6 s
@@ -321,6 +353,7 @@ void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& 
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
+  DebugSideDelay().Apply(0);
   ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/true);
   pend_[slot].rays_o = rays_o;
   pend_[slot].rays_d = rays_d;
@@ -351,7 +384,9 @@ bool Renderer::PreSampleSpecComplete(int slot) {
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
+  DebugSideDelay().Apply(1);
   if (!ps->CompleteSpeculative(pb.s)) {
+    n_spec_dropped_++;
     pb = PendingBatch();  // (its kernels are ordered on the side stream, whose pool its buffers return to)
     return false;
   }
@@ -460,6 +495,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   F2N_HOST_SCOPE("step.sample_and_filter");
   auto* gdp = global_data_pool_;
   ResolvePendingCount();
+  if (gdp->mode_ == RunningMode::TRAIN) DebugSideDelay().Apply(2);
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);

@@ -66,6 +66,8 @@ class Renderer : public Pipe {
 
  public:
   Renderer(GlobalDataPool* global_data_pool, int n_images);
+  // debugging aid (see Renderer.cpp, F2N_DEBUG_SIDE_DELAY): spin kernels in front of every period-th speculative begin / completion / step
+  static void SetDebugSideDelay(int begin_us, int complete_us, int main_us, int period);
   RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
   RenderResult RenderForward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);  // inference: no tape, no count read-back
   // issues the ray sampling of the next SampleAndFilter / TrainForwardBackward call ahead of time (same rays!)
@@ -94,6 +96,7 @@ class Renderer : public Pipe {
   Tensor DrawStepUniforms(int64_t n);
   bool pregen_draws_ = true;
   PendingBatch pend_[kPendingSlots];
+  int64_t n_spec_dropped_ = 0;  // batches begun ahead and thrown away (other rays asked for, tree replaced)
   int FindPending(const Tensor& rays_o, const Tensor& rays_d) const {
     for (int i = 0; i < kPendingSlots; i++)
       if (pend_[i].s.active && pend_[i].rays_o.defined() && pend_[i].rays_d.defined() && rays_o.defined() && rays_d.defined() &&
@@ -112,6 +115,7 @@ class Renderer : public Pipe {
   bool PendingMatches(const Tensor& rays_o, const Tensor& rays_d) const { return FindPending(rays_o, rays_d) >= 0; }
   void DropPendingSlot(int i) {
     if (!pend_[i].s.active) return;
+    n_spec_dropped_++;
     pend_[i].s.counts_ready.synchronize();  // its kernels may still be running: keep the buffers until they are done
     if (!pend_[i].s.completed && side_[i]) side_[i]->synchronize();  // (a speculative batch has recorded no count event yet)
     pend_[i] = PendingBatch();

@@ -264,6 +264,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     hp.on = on;
                     return d;
                   })
+      .def_static("debug_side_delay",  // spin kernels (us) in front of every period-th speculative begin / completion / step: a race amplifier
+                  [](int begin_us, int complete_us, int main_us, int period) { Renderer::SetDebugSideDelay(begin_us, complete_us, main_us, period); })
       .def_static("enable_kernel_timing", [](const std::vector<std::string>& names) { KernelTimers::Get().Enable(names); })
       .def_static("disable_kernel_timing", []() { KernelTimers::Get().Disable(); })
       .def_static("collect_kernel_timing",
@@ -329,6 +331,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              py::dict d;
              d["speculative"] = r.renderer_->n_speculative_;
              d["fallback"] = r.renderer_->n_spec_fallback_;
+             d["dropped"] = r.renderer_->n_spec_dropped_;
              auto& o = *SamplerOf(r)->pers_octree_;
              d["rays_repaired"] = o.n_repaired_.defined() ? o.n_repaired_.item<int>() : 0;
              d["stat_updates"] = o.epoch_;

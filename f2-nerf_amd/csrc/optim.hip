@@ -339,6 +339,13 @@ static F2nAdamCoef f2n_adam_coef(int step, float lr, float beta1, float beta2, f
   return k;
 }
 
+// One wave that spins for `ticks` of the 100 MHz constant clock: a delay on a stream (f2n_debug_spin; the race amplifier of
+// Renderer's F2N_DEBUG_SIDE_DELAY).
+__global__ void debug_spin_kernel(long long ticks) {
+  const long long t0 = (long long) wall_clock64();
+  while ((long long) wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 extern "C" {
 
 int f2n_adam_step(void* stream, int n, float* param, float* grad, float grad_scale, int grad_round_h16, float* exp_avg,
@@ -447,6 +454,12 @@ int f2n_nonfinite_flags_ex(void* stream, int n_a, const float* a, int n_b, const
 
 int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags) {
   return f2n_nonfinite_flags_ex(stream, n_a, a, n_b, b, flags, nullptr);
+}
+
+int f2n_debug_spin(void* stream, int microseconds) {
+  if (microseconds <= 0) return F2N_OK;
+  hipLaunchKernelGGL(debug_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, (long long) microseconds * 100);
+  return f2n_launch_status();
 }
 
 int f2n_abi_version(void) { return 10; }

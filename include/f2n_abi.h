@@ -58,6 +58,10 @@ const char* f2n_build_info(void);
  * optionally reset.  [0] = scatter records of f2n_hash_bwd's owner-binned path that found their queue segment full and were
  * applied by a packed-f16 atomic instead (the only order-dependent addition of that path).  The rest are reserved (0). */
 int f2n_debug_counters(int32_t* out8_host /* or NULL */, int reset);
+/* ... and a delay on a stream: one wave that spins for that many microseconds.  Renderer's F2N_DEBUG_SIDE_DELAY puts it in front of
+ * the sampler's side-stream work to skew the streams against each other (a race that needs an unusual interleaving then shows in
+ * tools/determinism_probe.py within one run instead of once in tens of thousands of iterations). */
+int f2n_debug_spin(void* stream, int microseconds);
 
 /* ---------------------------------------------------------------------------------------------------
  * Sampler -- replaces PersSampler::GetSamples' kernels (PtsSampler/PersSampler.cu:21-434).
@@ -404,10 +408,12 @@ int f2n_hash_gather_planes_balanced(void* stream, int n, int n_volumes, const vo
  * segment (-1, 0, 0 for unused slots); cost8_out [8] (may be NULL): the modelled cost of one tile of each level pair. */
 int f2n_gather_plan_query(int n_tiles, float step01, const float* level_scale_host, int32_t* out, float* cost8_out);
 /* f2n_hash_gather_planes for tables that have left the L2s (Field/Hash3DAnchored.cu:11-79 at confs/wanjinyou_big.yaml's sizes and
- * beyond; level_entries = local_size[l] = a power of two, 2 * 4096 ... 2^22): level pairs >= first_binned_pair go through a
- * slice-binned pipeline -- requests binned by 4096-entry table slice, every slice read once into LDS and its requests answered in
- * queue order, values blended per sample -- instead of one 128-byte fabric line per 4-byte read; pairs below it keep the
- * partitioned gather.  Planes bit-identical to f2n_hash_gather_planes.  Scratch: library workspace (~0.8 GB at 8e5 samples). */
+ * beyond; level_entries = local_size[l] = a power of two, 8 * 8192 ... 2^23): level pairs >= first_binned_pair (0 ... 8) go through
+ * a slice-binned pipeline -- requests binned by 8192-entry table slice per 1536-sample chunk, every slice read once into LDS and
+ * its requests answered in place, values blended per sample in the reference's order -- instead of one 128-byte fabric line per
+ * 4-byte read; pairs below it keep the partitioned gather.  Planes bit-identical to f2n_hash_gather_planes.
+ * F2N_ERR_UNSUPPORTED: level_entries outside that range or n > 1536 * 1024.  Scratch: library workspace, 56 B per sample and
+ * binned level (~0.65 GB at 8e5 samples and 14 levels). */
 int f2n_hash_gather_planes_binned(void* stream, int n, int n_volumes, const void* table_h, const int32_t* prim_pool,
                                   const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
                                   const float* level_scale, const float* pts, int pts_are_warped, const int32_t* volume_idx,

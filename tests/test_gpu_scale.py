@@ -832,6 +832,66 @@ def test_speculative_tail_repair(hip, kill_frac, max_hits):
     assert same_bits(repaired["oi"], ref_hits[1]) and same_bits(repaired["nf"], ref_hits[2])
 
 
+@pytest.mark.parametrize("view", ["after_first_update", "nodes_new_child_blocks_old", "nodes_old_child_blocks_new"])
+@pytest.mark.parametrize("max_hits", [1024, 24])
+def test_speculative_walk_that_saw_a_later_tree(hip, view, max_hits):
+    """A batch begun ahead is walked on a side stream that is only ordered behind the updates issued BEFORE it was begun: when it
+    actually runs, later updates may be finished, or in flight.  Whatever mixture of old and new node records / child blocks the
+    walk and the march saw, the batch completed behind those updates (repair from spec_epoch) must equal the batch sampled on
+    the final tree.  Two updates (epochs 3 and 4); the walk runs after the first one -- seeing all of it, or only its node
+    records, or only its child blocks -- with spec_epoch = 3."""
+    z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
+    n = z["rays_o"].shape[0]
+    rd_np = oc.normalize_dirs(z["rays_d"])
+    rng = np.random.default_rng(23)
+    noise = (((rng.random(1024 + n + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(1.)).astype(F32)
+    tn, tr, so = T(z["tree_nodes"].copy()), T(z["pers_trans"]), T(z["search_order"])
+    ro, rd, nz = T(z["rays_o"]), T(rd_np), T(noise)
+    n_nodes = z["tree_nodes"].size // 64
+    cb = torch.zeros(n_nodes * 8 * 32, dtype=torch.uint8, device=DEV)
+    hip.oct_build_child_blocks(n_nodes, tn, cb)
+    first = _filled_prefixes(_strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n, max_hits), n, max_hits)
+    hit_leaves = np.unique(first["oi"])
+    victims = rng.choice(hit_leaves, max(2, int(len(hit_leaves) * 0.04)), replace=False)
+    v1, v2 = victims[: len(victims) // 2], victims[len(victims) // 2:]
+    died_at = torch.zeros(n_nodes, dtype=torch.int32, device=DEV)
+    death_epoch = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d_add = T(np.full((2, n_nodes), -1, np.int32))
+
+    def update(vs, epoch):
+        w_stats = np.full(n_nodes, 1000, np.int32); w_stats[vs] = 0
+        mark = np.zeros(n_nodes, np.int32); mark[vs] = 1
+        hip.oct_update_stats_ex(n_nodes, d_add[0], d_add[1], T(mark), T(w_stats), T(np.full(n_nodes, 1000, np.int32)), tn, cb, True, died_at,
+                                epoch, death_epoch)
+    tn_old, cb_old = tn.clone(), cb.clone()
+    update(v1, 3)
+    tn_seen = tn_old if view == "nodes_old_child_blocks_new" else tn
+    cb_seen = cb_old if view == "nodes_new_child_blocks_old" else cb
+    spec = dict(se=torch.zeros((n, 2), dtype=torch.int32, device=DEV), oi=torch.zeros(n * max_hits, dtype=torch.int32, device=DEV),
+                nf=torch.zeros((n * max_hits, 2), device=DEV), otr=torch.zeros(n * max_hits, dtype=torch.int32, device=DEV),
+                tot=torch.zeros(1, dtype=torch.int32, device=DEV), cnt=torch.zeros(n, dtype=torch.int32, device=DEV),
+                s_dt=torch.zeros(n * 1024, device=DEV), s_t=torch.zeros(n * 1024, device=DEV),
+                s_an=torch.zeros((n * 1024, 2), dtype=torch.int32, device=DEV), fod=torch.zeros(n, device=DEV),
+                ls=torch.full((n * max_hits, 2), -1, dtype=torch.int32, device=DEV), reached=torch.full((n,), -9, dtype=torch.int32, device=DEV))
+    hip.oct_intersect_strided(n, max_hits, so, ro, rd, 0.01, 1e8, tn_seen, spec["se"], spec["oi"], spec["nf"], spec["tot"], spec["otr"], cb_seen)
+    hip.ray_march_strided_rec(n, max_hits, 1. / 256., True, ro, rd, nz, spec["se"], spec["oi"], spec["nf"], tn_seen, tr, spec["cnt"], None,
+                              spec["s_dt"], spec["s_t"], spec["s_an"], spec["fod"], spec["otr"], spec["ls"], spec["reached"])
+    update(v2, 4)
+    frm = torch.full((n,), 7, dtype=torch.int32, device=DEV)
+    n_rep = torch.zeros(1, dtype=torch.int32, device=DEV); n_full = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.oct_list_repair(n, max_hits, spec["se"], spec["oi"], spec["nf"], spec["otr"], spec["tot"], died_at, 3, death_epoch, spec["reached"],
+                        frm, n_rep, n_full)
+    hip.oct_intersect_repair_flagged(n, max_hits, so, ro, rd, 0.01, 1e8, tn, spec["se"], spec["oi"], spec["nf"], spec["tot"], spec["otr"], cb,
+                                     death_epoch, 3, frm, n_full)
+    hip.ray_march_repair_tail(n, max_hits, 1. / 256., True, ro, rd, nz, spec["se"], spec["oi"], spec["nf"], tn, tr, spec["cnt"], None,
+                              spec["s_dt"], spec["s_t"], spec["s_an"], spec["fod"], spec["otr"], spec["ls"], spec["reached"], frm, death_epoch, 3)
+    repaired = _filled_prefixes(spec, n, max_hits)
+    fresh = _filled_prefixes(_strided_sample(hip, tn, cb, tr, so, ro, rd, nz, n, max_hits), n, max_hits)
+    for k in fresh:
+        assert same_bits(repaired[k], fresh[k]), k
+    assert not same_bits(first["cnt"], fresh["cnt"])
+
+
 @pytest.mark.parametrize("n_blocks,record", [(64, True), (512, False)])
 def test_persistent_march(hip, n_blocks, record):
     """f2n_ray_march_persistent (a few persistent one-wave blocks, rays sorted by leaf count, groups of four off a counter) fills

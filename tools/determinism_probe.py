@@ -16,9 +16,20 @@ ap.add_argument("--runs", type=int, default=2)
 ap.add_argument("--factor", type=int, default=2)
 ap.add_argument("--speculation", type=int, default=-1)
 ap.add_argument("--stride", type=int, default=1, help="iterations per Train call (checksums every `stride` iterations)")
+ap.add_argument("--dense-from", type=int, default=0, help="checksums after EVERY iteration in [dense-from, dense-to]")
+ap.add_argument("--dense-to", type=int, default=0)
+ap.add_argument("--poison", type=int, default=0, help="between runs: render the test views (1) and leave 0xFF-filled blocks of "
+                "every size class in the caching allocator (2: both) -- a run that reads memory it never wrote then parts from run 0")
+ap.add_argument("--set", nargs="*", default=[], help="runner properties, name=int (speculation_depth=1 tail_repair=0 march_blocks=0 ...)")
+ap.add_argument("--side-delay", nargs="*", default=[], help="one begin_us:complete_us:main_us:period per run AFTER run 0: "
+                "run 0 trains undisturbed, the others with their streams skewed -- they must not part")
 ap.add_argument("--overrides", nargs="*", default=[])
 args = ap.parse_args()
-NAMES = ["table", "field_mlp", "color_mlp", "app_emb", "nodes", "n_nodes", "batch", "marched", "meaningful"]
+NAMES = ["table", "field_mlp", "color_mlp", "app_emb", "nodes", "n_nodes", "batch", "marched", "meaningful", "speculative", "fallback", "dropped", "rays_repaired"]
+
+
+SCHEDULE = sorted(set(list(range(args.stride, args.iters + 1, args.stride)) +
+                      (list(range(args.dense_from, min(args.dense_to, args.iters) + 1)) if args.dense_to > 0 else [])))
 
 
 def csum(t):
@@ -32,20 +43,38 @@ def one_run():
     runner, cfg, _ = runtime.make_runner(st, "wanjinyou", ["train.end_iter=20000"] + args.overrides, seed=2022)
     if args.speculation >= 0:
         runner.speculative_sampling = args.speculation
+    for kv in args.set:
+        k, v = kv.split("=")
+        setattr(runner, k, int(v))
     torch.manual_seed(2022)
     rows = []
-    for it in range(args.stride, args.iters + 1, args.stride):
+    for it in SCHEDULE:
         runner.train(ds, it, 1)
         s = runner.states()  # [0] nodes [4] table [8] field MLP [9] colour MLP [10] app_emb
         c = runner.counters()
+        sp = runner.speculation_counters()
         rows.append([csum(s[4]), csum(s[8]), csum(s[9]), csum(s[-1]), csum(s[0].view(torch.int32)) if s[0].numel() % 4 == 0 else 0,
-                     runner.n_nodes(), runner.cur_batch_size(), c["total_marched"], c["total_meaningful"]])
+                     runner.n_nodes(), runner.cur_batch_size(), c["total_marched"], c["total_meaningful"]] +
+                    [int(sp[k]) for k in ("speculative", "fallback", "dropped", "rays_repaired")])
     dbg = capi.debug_counters() if hasattr(capi, "debug_counters") else None
+    if args.poison >= 1:
+        runner.test_images(ds)
+    del runner
+    if args.poison >= 2:
+        junk = []
+        for lg in range(9, 31):  # 512 B ... 1 GiB
+            for _ in range(6 if lg < 24 else 2):
+                junk.append(torch.full((1 << lg,), -1, dtype=torch.int8, device="cuda"))
+        torch.cuda.synchronize()
+        del junk
     return rows, dbg
 
 
 runs = []
 for r in range(args.runs):
+    if args.side_delay:
+        b, c, m, per = [int(v) for v in args.side_delay[(r - 1) % len(args.side_delay)].split(":")] if r > 0 else (0, 0, 0, 1)
+        runtime.host().ExpRunner.debug_side_delay(b, c, m, max(per, 1))
     rows, dbg = one_run()
     runs.append(rows)
     print("run %d: last row %s  debug counters %s" % (r, rows[-1], dbg), flush=True)
@@ -53,13 +82,13 @@ ref = runs[0]
 for r in range(1, args.runs):
     first = None
     for i, (a, b) in enumerate(zip(ref, runs[r])):
-        if a != b:
+        if a[:-1] != b[:-1]:  # (rays_repaired: how many rays a repair touched depends on what the side stream's walk happened to see)
             first = i
             break
     if first is None:
         print("run %d == run 0 over %d iterations (every checksum)" % (r, args.iters))
     else:
         diff = [NAMES[k] for k in range(len(NAMES)) if ref[first][k] != runs[r][first][k]]
-        print("run %d parts from run 0 at iteration %d in: %s" % (r, (first + 1) * args.stride, ", ".join(diff)))
+        print("run %d parts from run 0 at iteration %d in: %s" % (r, SCHEDULE[first], ", ".join(diff)))
         for i in range(max(0, first - 1), min(len(ref), first + 3)):
-            print("   it %4d  run0 %s\n            run%d %s" % ((i + 1) * args.stride, ref[i], r, runs[r][i]))
+            print("   it %4d  run0 %s\n            run%d %s" % (SCHEDULE[i], ref[i], r, runs[r][i]))
