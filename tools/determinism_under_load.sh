@@ -1,3 +1,6 @@
+#!/bin/bash
+# Two trainings from one seed with CO-TENANTS on the GPU: a reference-numerics worker of bench.py as background load and three
+# determinism probes (three runs each) side by side.  profiles/r04_determinism_20k.txt section 6, DESIGN.md section 7.8.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 # background load: the reference-numerics worker of bench.py's psnr_numerics_ab (the only co-tenant under which two product
 # trainings from one seed have been seen to part)
