@@ -74,6 +74,11 @@ def debug_counters(reset=False):
     return [int(v) for v in out]
 
 
+def debug_pollute(value):
+    """Garbage derived from `value` in 64 KB of LDS and ~100 vector registers of every CU, on the current stream (f2n_debug_pollute)."""
+    _ck(lib().f2n_debug_pollute(_stream(), ctypes.c_uint(int(value) & 0xFFFFFFFF)), "f2n_debug_pollute")
+
+
 def debug_spin(microseconds):
     """One wave spinning for that long on the current stream (f2n_debug_spin)."""
     _ck(lib().f2n_debug_spin(_stream(), _i(microseconds)), "f2n_debug_spin")

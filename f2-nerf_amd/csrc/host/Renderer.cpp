@@ -260,6 +260,7 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
 namespace {
 struct SideDelay {
   int begin_us = 0, complete_us = 0, main_us = 0, period = 1;
+  unsigned pollute = 0;  // != 0: every begin / completion / step is preceded by f2n_debug_pollute with a value derived from it
   uint64_t calls[3] = {0, 0, 0};
   SideDelay() {
     const char* e = std::getenv("F2N_DEBUG_SIDE_DELAY");
@@ -268,7 +269,15 @@ struct SideDelay {
   }
   void Apply(int which) {
     const int us = which == 0 ? begin_us : which == 1 ? complete_us : main_us;
-    if (us > 0 && (calls[which]++ % (uint64_t) period) == 0) F2N_CALL(f2n_debug_spin(CurStream(), us));
+    const uint64_t call = calls[which]++;
+    if (pollute != 0) {
+      F2N_CALL(f2n_debug_pollute(CurStream(), pollute * 2654435761u + (unsigned) call * 3u + (unsigned) which));
+      if (which == 2) {  // ... and a co-tenant's worth of them beside the step, on a stream nothing is ordered against
+        static c10::hip::HIPStreamMasqueradingAsCUDA other = c10::hip::getStreamFromPoolMasqueradingAsCUDA();
+        for (unsigned k = 0; k < 6; k++) F2N_CALL(f2n_debug_pollute((void*) other.stream(), pollute * 40503u + (unsigned) call * 7u + k));
+      }
+    }
+    if (us > 0 && (call % (uint64_t) period) == 0) F2N_CALL(f2n_debug_spin(CurStream(), us));
   }
 };
 SideDelay& DebugSideDelay() {
@@ -277,8 +286,9 @@ SideDelay& DebugSideDelay() {
 }
 }  // namespace
 
-void Renderer::SetDebugSideDelay(int begin_us, int complete_us, int main_us, int period) {
+void Renderer::SetDebugSideDelay(int begin_us, int complete_us, int main_us, int period, unsigned pollute) {
   auto& d = DebugSideDelay();
+  d.pollute = pollute;
   d.begin_us = begin_us;
   d.complete_us = complete_us;
   d.main_us = main_us;

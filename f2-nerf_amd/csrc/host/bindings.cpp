@@ -265,7 +265,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     return d;
                   })
       .def_static("debug_side_delay",  // spin kernels (us) in front of every period-th speculative begin / completion / step: a race amplifier
-                  [](int begin_us, int complete_us, int main_us, int period) { Renderer::SetDebugSideDelay(begin_us, complete_us, main_us, period); })
+                  [](int begin_us, int complete_us, int main_us, int period, unsigned pollute) {
+                    Renderer::SetDebugSideDelay(begin_us, complete_us, main_us, period, pollute);
+                  },
+                  py::arg("begin_us"), py::arg("complete_us"), py::arg("main_us"), py::arg("period"), py::arg("pollute") = 0u)
       .def_static("enable_kernel_timing", [](const std::vector<std::string>& names) { KernelTimers::Get().Enable(names); })
       .def_static("disable_kernel_timing", []() { KernelTimers::Get().Disable(); })
       .def_static("collect_kernel_timing",

@@ -339,6 +339,21 @@ static F2nAdamCoef f2n_adam_coef(int step, float lr, float beta1, float beta2, f
   return k;
 }
 
+// Leaves `value`-derived garbage in 64 KB of LDS and ~100 vector registers of every CU (f2n_debug_pollute): what a co-tenant's
+// kernels do to the state a kernel finds when it starts.  A kernel that reads LDS or registers it never wrote then depends on it.
+__global__ __launch_bounds__(256) void debug_pollute_kernel(unsigned value, unsigned* __restrict__ sink) {
+  extern __shared__ unsigned s_junk[];
+  unsigned r[96];
+#pragma unroll
+  for (int i = 0; i < 96; i++) r[i] = value * 2654435761u + (unsigned) i * 40503u + threadIdx.x;
+  for (int i = threadIdx.x; i < 16 * 1024; i += 256) s_junk[i] = value ^ (0x9E3779B9u * (unsigned) i);
+  __syncthreads();
+  unsigned acc = s_junk[(threadIdx.x * 61u) & (16 * 1024 - 1)];
+#pragma unroll
+  for (int i = 0; i < 96; i++) acc = acc * 31u + r[i];  // (keeps the registers live)
+  if (sink != nullptr && acc == 0x12345678u) sink[0] = acc;
+}
+
 // One wave that spins for `ticks` of the 100 MHz constant clock: a delay on a stream (f2n_debug_spin; the race amplifier of
 // Renderer's F2N_DEBUG_SIDE_DELAY).
 __global__ void debug_spin_kernel(long long ticks) {
@@ -454,6 +469,11 @@ int f2n_nonfinite_flags_ex(void* stream, int n_a, const float* a, int n_b, const
 
 int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const float* b, int32_t* flags) {
   return f2n_nonfinite_flags_ex(stream, n_a, a, n_b, b, flags, nullptr);
+}
+
+int f2n_debug_pollute(void* stream, unsigned value) {
+  hipLaunchKernelGGL(debug_pollute_kernel, dim3(1024), dim3(256), 64 * 1024, (hipStream_t) stream, value, (unsigned*) nullptr);
+  return f2n_launch_status();
 }
 
 int f2n_debug_spin(void* stream, int microseconds) {

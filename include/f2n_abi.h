@@ -62,6 +62,9 @@ int f2n_debug_counters(int32_t* out8_host /* or NULL */, int reset);
  * the sampler's side-stream work to skew the streams against each other (a race that needs an unusual interleaving then shows in
  * tools/determinism_probe.py within one run instead of once in tens of thousands of iterations). */
 int f2n_debug_spin(void* stream, int microseconds);
+/* ... and a launch that leaves value-derived garbage in 64 KB of LDS and ~100 vector registers of every CU: what a co-tenant's
+ * kernels do to the state a kernel finds when it starts (Renderer's debug_side_delay(..., pollute)). */
+int f2n_debug_pollute(void* stream, unsigned value);
 
 /* ---------------------------------------------------------------------------------------------------
  * Sampler -- replaces PersSampler::GetSamples' kernels (PtsSampler/PersSampler.cu:21-434).

@@ -23,6 +23,8 @@ ap.add_argument("--poison", type=int, default=0, help="between runs: render the 
 ap.add_argument("--set", nargs="*", default=[], help="runner properties, name=int (speculation_depth=1 tail_repair=0 march_blocks=0 ...)")
 ap.add_argument("--side-delay", nargs="*", default=[], help="one begin_us:complete_us:main_us:period per run AFTER run 0: "
                 "run 0 trains undisturbed, the others with their streams skewed -- they must not part")
+ap.add_argument("--pollute", action="store_true", help="run r > 0: garbage (different per run) left in the LDS and registers of every CU in front "
+                "of every step and every speculative begin / completion (f2n_debug_pollute): a kernel that reads state it never wrote parts")
 ap.add_argument("--overrides", nargs="*", default=[])
 args = ap.parse_args()
 NAMES = ["table", "field_mlp", "color_mlp", "app_emb", "nodes", "n_nodes", "batch", "marched", "meaningful", "speculative", "fallback", "dropped", "rays_repaired"]
@@ -72,9 +74,9 @@ def one_run():
 
 runs = []
 for r in range(args.runs):
-    if args.side_delay:
-        b, c, m, per = [int(v) for v in args.side_delay[(r - 1) % len(args.side_delay)].split(":")] if r > 0 else (0, 0, 0, 1)
-        runtime.host().ExpRunner.debug_side_delay(b, c, m, max(per, 1))
+    if args.side_delay or args.pollute:
+        b, c, m, per = [int(v) for v in args.side_delay[(r - 1) % len(args.side_delay)].split(":")] if (r > 0 and args.side_delay) else (0, 0, 0, 1)
+        runtime.host().ExpRunner.debug_side_delay(b, c, m, max(per, 1), (7919 * r) if args.pollute else 0)
     rows, dbg = one_run()
     runs.append(rows)
     print("run %d: last row %s  debug counters %s" % (r, rows[-1], dbg), flush=True)
