@@ -402,7 +402,10 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
         for (int r = 0; r < 3; r++) {
           const float ov = (float) (half_t) o[r];
           const float e = expf(-ov);
-          const float dsig = (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
+          // e = +inf (output below ~-88.7): the quotient is inf / inf = NaN where the derivative's limit is 0.  The reference lets
+          // the NaN through (ATen's backward of SHShader.cpp:27-28) and tcnn then drops the step; the product -- here, in the
+          // taped path (Renderer.cpp, ShadeSigmoid) and in the oracle -- takes the limit.  The reference-numerics build keeps the NaN.
+          const float dsig = (!F2N_REFERENCE_NUMERICS && e > 3.0e38f) ? 0.f : (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
           const half_t v = (half_t) ((float) (half_t) (dv[r] * dsig) * loss_scale);
           dyf[r] = (valid && g == 0) ? v : (half_t) 0.f;
         }

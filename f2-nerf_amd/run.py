@@ -149,7 +149,8 @@ def main(argv=None):
                 mse = max(float(s["mse"]), 1e-12)
                 psnr = 20 * np.log10(1 / np.sqrt(mse))
                 psnr_smooth = psnr if psnr_smooth < 0 else psnr * .1 + psnr_smooth * .9
-                print("Iter: %6d PSNR: %.2f NRays: %5d OctSamples: %.1f Samples: %.1f MeaningfulSamples: %.1f IPS: %.1f LR: %.4f" % (
+                # (labelled differently from the reference's per-iteration EMA, with which it is not comparable line by line)
+                print("Iter: %6d PSNR(report-batch EMA): %.2f NRays: %5d OctSamples: %.1f Samples: %.1f MeaningfulSamples: %.1f IPS: %.1f LR: %.4f" % (
                     runner.iter_step, psnr_smooth, s["n_rays"], runner.oct_per_ray, runner.sampled_per_ray,
                     runner.meaningful_per_ray, runner.iter_step / max(time.time() - t0, 1e-9), runner.cur_lr), flush=True)
             if runner.iter_step % save_freq == 0:

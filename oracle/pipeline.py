@@ -87,8 +87,13 @@ def shade_fwd(color_params, feat, dirs, app_emb=None, sample_emb_idx=None, want_
 
 def shade_bwd(color_params, ctx, drgb, n_emb=0, sample_emb_idx=None, loss_scale=128.0):
     o = ctx["o"]
-    e = _exp(-o)
-    do = (np.asarray(drgb, F32) * ((F32(1.) + F32(2.) * EPS_RGB) * e / ((F32(1.) + e) * (F32(1.) + e)))).astype(F32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        e = _exp(-o)
+        dsig = ((F32(1.) + F32(2.) * EPS_RGB) * e / ((F32(1.) + e) * (F32(1.) + e))).astype(F32)
+    # e = +inf (o below ~-88.7): inf / inf where the derivative's limit is 0.  The reference's autograd lets the NaN through and
+    # tcnn drops the step (TCNNWP.cpp:234-240); product, taped path and this restatement take the limit.
+    dsig = np.where(np.isinf(e), F32(0.), dsig).astype(F32)
+    do = (np.asarray(drgb, F32) * dsig).astype(F32)
     dy = np.zeros((o.shape[0], 16), F32)
     dy[:, :3] = do
     d_hidden, n_hidden = ctx.get("shape", (64, 2))
