@@ -625,18 +625,19 @@ def test_partitioned_gather_equals_fused_forward(hip, fox_state, fox_golden):
     assert_same(N(planes).view(np.uint16).transpose(1, 0, 2).reshape(n, 32), N(sx_a).view(np.uint16), "plane layout")
 
 
-@pytest.mark.parametrize("log2_t,n,p0,clump", [(21, 100003, 3, False), (21, 70001, 0, True), (22, 131072, 5, False)])
+@pytest.mark.parametrize("log2_t,n,p0,clump", [(21, 100003, 3, False), (21, 70001, 0, True), (22, 131072, 5, False), (21, 1, 0, False),
+                                                   (21, 1537, 1, True), (21, 0, 0, False)])
 def test_binned_gather_equals_partitioned_gather(hip, fox_state, log2_t, n, p0, clump):
     """The slice-binned gather of the big tables (requests binned by 4096-entry table slice, slices served from LDS) writes the
-    planes of the partitioned gather bit for bit -- also when a request queue overflows (clumped points: the overflowing
-    requests are read from the table directly) and whichever level pair the binned part starts at."""
+    planes of the partitioned gather bit for bit -- for clumped points (a few slices take most of a chunk's requests), for
+    batches of one sample, of one sample more than a chunk, of none, and whichever level pair the binned part starts at."""
     st = fox_state
     rng = np.random.default_rng(log2_t + p0)
     grid = make_grid(st, rng, log2_t, scale=0.5)
     gd = grid_dev(grid)
     pts = (rng.random((n, 3), dtype=F32) * F32(2) - F32(1))
     if clump:
-        pts[n // 3:] = pts[7]  # two thirds of the batch in one cell: every queue of that cell's slices overflows
+        pts[n // 3:] = pts[7]  # two thirds of the batch in one cell: a handful of slices take most of every chunk's requests
     anchors = np.zeros((n, 3), np.int32)
     anchors[:, 0] = rng.integers(0, grid.n_volumes, n)
     a = torch.zeros((8, n, 4), dtype=torch.float16, device=DEV)
