@@ -201,7 +201,7 @@ std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysDataOfCamera(int idx, i
   return {{rays.origins, rays.dirs, b}, image_tensors_.defined() ? colors : Tensor(), cam};
 }
 
-std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysData(int batch_size, int sets) {
+std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysData(int batch_size, int sets, int64_t seq) {
   // The image list of a set lives on the device, uploaded once per `sets` value: the upload of a pageable host array is a
   // SYNCHRONOUS copy -- issued every iteration (as a first version did) it made the host wait for the whole previous training
   // step before it could queue the next one: ~0.2 ms of idle device at the head of every step of ExpRunner::Train
@@ -218,7 +218,7 @@ std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysData(int batch_size, in
   const Tensor& cur_set = it->second;
   // every draw on the device: uniform image of the set, uniform pixel (Dataset.cpp:286-291) -- one uniform launch and ONE kernel
   // that maps the draws, generates the rays and gathers colours and bounds (f2n_draw_ray_batch)
-  Tensor u = torch::rand({batch_size, 3}, DevF32());
+  Tensor u = ray_draws_.Draw((int64_t) batch_size * 3, seq).view({batch_size, 3});
   Tensor cam = torch::empty({batch_size}, DevI32()), ij = torch::empty({batch_size, 2}, DevI32());
   Tensor rays_o = torch::empty({batch_size, 3}, DevF32()), rays_d = torch::empty({batch_size, 3}, DevF32());
   Tensor colors = torch::empty({batch_size, 3}, DevF32()), b = torch::empty({batch_size, 2}, DevF32());

@@ -8,6 +8,7 @@
 #include <tuple>
 
 #include "GlobalDataPool.h"
+#include "KeyedDraws.h"
 
 namespace f2n {
 
@@ -38,7 +39,9 @@ class Dataset {
   BoundedRays RaysInterpolate(int idx_0, int idx_1, float alpha, int reso_level = 1);
   BoundedRays RandRaysWholeSpace(int batch_size);                             // :245-255
   std::tuple<BoundedRays, Tensor, Tensor> RandRaysDataOfCamera(int idx, int batch_size);
-  std::tuple<BoundedRays, Tensor, Tensor> RandRaysData(int batch_size, int sets);  // :275-298
+  // seq >= 0: the batch's sequence number in a training run -- its three uniforms per ray are then draw `seq` of the ray purpose
+  // (KeyedDraws.h), whenever and however often the batch is drawn; seq < 0: the next draw of this data set's own sequence
+  std::tuple<BoundedRays, Tensor, Tensor> RandRaysData(int batch_size, int sets, int64_t seq = -1);  // :275-298
 
   Rays Img2WorldRay(int cam_idx, const Tensor& ij);
   Rays Img2WorldRay(const Tensor& pose, const Tensor& intri, const Tensor& dist_params, const Tensor& ij);
@@ -52,6 +55,7 @@ class Dataset {
   std::vector<int> train_set_, test_set_, val_set_;
   std::map<int, Tensor> set_on_device_;  // RandRaysData: the image indices of a `sets` combination, uploaded once
   Tensor last_cam_indices_, last_ij_;            // the draws behind the most recent Rand* batch (tests, logging)
+  KeyedUniforms ray_draws_{0xA0761D6478BD642Full};
 
  private:
   Tensor PixelGrid(int H_out, int W_out);  // all (row, col) of the full-resolution image sub-sampled to H_out x W_out

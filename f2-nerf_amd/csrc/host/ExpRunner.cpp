@@ -32,6 +32,7 @@ ExpRunner::ExpRunner(const std::map<std::string, std::string>& flat_config, int 
   BuildOptimizer();
   FlattenSmallGrads();
   UpdateAdaParams();
+  ema_base_value_ = global_data_pool_->meaningful_sampled_pts_per_ray_;
   sync_.apply = [this](bool apply_optimizer, float lr) {  // (a pending step is applied with ITS learning rate)
     const float lr_now = cur_lr_;
     cur_lr_ = lr;
@@ -145,6 +146,35 @@ int ExpRunner::CurBatchSize() const {  // ExpRunner.cpp:86
   return int(pts_batch_size_ / global_data_pool_->meaningful_sampled_pts_per_ray_) >> 4 << 4;
 }
 
+// The ray count of the batch with sequence number `seq` (ExpRunner.cpp:86 at a FIXED lag): pts_batch_size over the
+// meaningful-samples average as it stood after step seq - kBatchSizeLag.  The reference sizes a batch from the average of the
+// step before it; a streaming step learns its count one step late (two in a data-parallel run) and Train() draws two batches
+// ahead, so the lag a schedule can honour in every mode is 5 -- and using that one lag in every mode (synchronous steps included)
+// is what makes the sequence of batch sizes independent of the sampling schedule and of how Train() is chunked.
+int ExpRunner::BatchSizeFor(int64_t seq) {
+  const int64_t want = seq - kBatchSizeLag;
+  float ema = ema_base_value_;
+  if (want >= ema_base_seq_) {
+    // (a streaming step's count is resolved at the top of the next step; a Train() call that starts right behind one asks earlier)
+    if (renderer_->count_pending_ && renderer_->pending_count_seq_ <= want + 1) renderer_->ResolvePendingCount();
+    int64_t s = want;
+    while (s >= ema_base_seq_ && !renderer_->EmaAfter(s, &ema)) s--;  // (a step that recorded nothing: data-parallel first step)
+    if (s < ema_base_seq_) ema = ema_base_value_;
+  }
+  return int(pts_batch_size_ / ema) >> 4 << 4;
+}
+
+// The sequence numbers restart at `seq` (checkpoint load: seq = the iteration, so that a resumed run draws what the uninterrupted
+// run would have drawn at that iteration): batches up to seq + kBatchSizeLag are sized from the average as it stands now.
+void ExpRunner::ResetStepSequence(int64_t seq) {
+  FinishPending();
+  renderer_->DropPendingSamples();
+  step_seq_ = seq;
+  ema_base_seq_ = seq;
+  ema_base_value_ = global_data_pool_->meaningful_sampled_pts_per_ray_;
+  for (auto& m : renderer_->ema_ring_) m = Renderer::EmaMark();
+}
+
 // One optimiser step.  compute_flags (device int32[3], or NULL): the finiteness flags of the two MLP gradients are
 // computed inside the small-groups launch and every update of this step is predicated on them (flags[2]).
 void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
@@ -226,6 +256,13 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   // shader paths) train through the taped iteration: same losses, same optimiser, no streaming.
   if (!renderer_->FusedPathOk()) return TrainStepAutograd(rays_o, rays_d, bounds, gt_colors, emb_idx, apply_optimizer);
   auto* gdp = global_data_pool_.get();
+  // this step's batch, and the two behind it, by sequence number: what their random draws are keyed by (KeyedDraws.h)
+  const int64_t seq = step_seq_++;
+  renderer_->cur_seq_ = seq;
+  struct SeqReset {
+    Renderer* r;
+    ~SeqReset() { r->cur_seq_ = -1; }
+  } seq_reset{renderer_.get()};
   gdp->mode_ = RunningMode::TRAIN;
   gdp->backward_nan_ = false;
   const bool pipelined = sync_.pipelined && apply_optimizer;
@@ -249,19 +286,21 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     // inside SampleAndFilter, right behind that update, with the next iteration's fineness -- up to and including the pack;
     // the host comes back for its counts at the top of the next step (Renderer::SampleAndFilter -> PreSampleFinish).
     const float fin = FinenessAt(iter_step_ + 1);
-    renderer_->after_octree_update_ = [this, fin, &next_rays_o, &next_rays_d, &next_bounds]() {
-      renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, fin);
+    renderer_->after_octree_update_ = [this, fin, seq, &next_rays_o, &next_rays_d, &next_bounds]() {
+      renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, fin, seq + 1);
     };
     // ... or, outside the ProcOctree iterations, speculatively from the top of this step (Renderer.h: next_batch_); the hook
     // above remains the fallback
     renderer_->next_batch_.rays_o = next_rays_o;
     renderer_->next_batch_.rays_d = next_rays_d;
     renderer_->next_batch_.fineness = fin;
+    renderer_->next_batch_.seq = seq + 1;
     renderer_->next_batch_.valid = true;
     if (next2_rays_o.defined() && next2_rays_d.defined()) {  // two-deep pipeline: the batch behind it is walked and marched now
       renderer_->next2_batch_.rays_o = next2_rays_o;
       renderer_->next2_batch_.rays_d = next2_rays_d;
       renderer_->next2_batch_.fineness = FinenessAt(iter_step_ + 2);
+      renderer_->next2_batch_.seq = seq + 2;
       renderer_->next2_batch_.valid = true;
     }
   }
@@ -301,8 +340,13 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   // The NEXT batch's sampling has been running on the side stream since this step's octree update.  The host does not wait
   // for its sample count here: the next step does, right before it needs it (Renderer::SampleAndFilter), so that whatever
   // the caller does between two steps overlaps the march instead of following it.
+  if (digest_table_) {  // diagnostics: an order-free checksum of the f16 table as this step leaves it, kept on the device
+    auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+    if (!digest_table_sums_.defined()) digest_table_sums_ = torch::zeros({Renderer::kDigestRing}, torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA));
+    digest_table_sums_.select(0, seq % Renderer::kDigestRing).copy_(field->feat_pool_h_.view(torch::kInt16).sum(torch::kInt64));
+  }
   if (prefetch && !renderer_->PendingMatches(next_rays_o, next_rays_d))  // (a batch without samples never reached the hook)
-    renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, global_data_pool_->ray_march_fineness_);
+    renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, global_data_pool_->ray_march_fineness_, seq + 1);
   if (applied && check_nan_ && prefetch) {  // streaming: do not stall on this step's flags (see ExpRunner.h)
     DeferFlags(apply_optimizer);
   } else if (applied && ResolveFlags(apply_optimizer)) {
@@ -413,7 +457,9 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
   gdp->mode_ = RunningMode::TRAIN;
   gdp->backward_nan_ = false;
   const int batch = rays_o.size(0);
+  renderer_->cur_seq_ = step_seq_++;
   auto rr = renderer_->Render(rays_o, rays_d, bounds, emb_idx);
+  renderer_->cur_seq_ = -1;
   TrainStats stats;
   stats.n_rays = batch;
   stats.n_samples = renderer_->last_n_all_pts_;
@@ -597,6 +643,7 @@ void ExpRunner::LoadCheckpoint(const std::string& dir) {
     iter_step_ = (int) std::round(scalars[0].item<float>());
     UpdateAdaParams();
   }
+  ResetStepSequence(iter_step_);
   std::vector<Tensor> states;
   torch::load(states, dir + "/renderer.pt");
   LoadStates(states);
@@ -609,15 +656,16 @@ void ExpRunner::LoadCheckpoint(const std::string& dir) {
 int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   const int target = until_iter > 0 ? std::min(until_iter, end_iter_) : end_iter_;
   int executed = 0;
-  auto draw = [&]() { return dataset.RandRaysData(std::max(16, CurBatchSize()), sets); };
+  auto draw = [&](int64_t seq) { return dataset.RandRaysData(std::max(16, BatchSizeFor(seq)), sets, seq); };
   // The batches of the next iteration AND (two-deep sampling pipeline, Renderer::next2_batch_) of the one after it are drawn
   // ahead: one draw per iteration, right before the step, as before -- but the adaptive ray count of a batch now comes from the
-  // meaningful-samples average as it stood TWO steps before the batch is used (the reference: none, ExpRunner.cpp:86), because
-  // that is when its rays have to exist.  Always two ahead, whatever the renderer then does with the second batch: the sequence
-  // of batches does not depend on a scheduling decision.
+  // meaningful-samples average at a fixed lag (BatchSizeFor; the reference: the step before, ExpRunner.cpp:86), because its rays
+  // have to exist two steps before it is used.  Always two ahead, whatever the renderer then does with the second batch -- and
+  // every batch is keyed by its sequence number (rays, march noise, background, edge samples: KeyedDraws.h), so the batches a
+  // Train() call draws at its start are the ones the previous call had drawn ahead and dropped: the sequence of batches depends
+  // neither on a scheduling decision nor on how the iterations are split over Train() calls.
   const bool two_deep = true;  // (whether the batch after next is BEGUN two steps ahead is the renderer's decision)
-  std::deque<decltype(draw())> ahead;
-  ahead.push_back(draw());
+  std::deque<decltype(draw(0))> ahead;
   last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;
   FinishPending();
   const int64_t kept0 = renderer_->total_kept_pts_;
@@ -626,7 +674,7 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   while (iter_step_ < target) {
     {
       F2N_HOST_SCOPE("train.draw");
-      while (ahead.size() < (two_deep ? 3u : 2u)) ahead.push_back(draw());
+      while (ahead.size() < (two_deep ? 3u : 2u)) ahead.push_back(draw(step_seq_ + (int64_t) ahead.size()));
     }
     F2N_HOST_SCOPE("train.step");
     auto& cur = ahead[0];

@@ -84,6 +84,16 @@ class ExpRunner {
   void BuildOptimizer();
   Tensor FlattenSmallGrads();
   int CurBatchSize() const;
+  // Sequence numbers (KeyedDraws.h): step_seq_ counts the training steps taken (dropped non-finite ones included); the batch of
+  // step k, its march noise and its background / edge draws are draw k of their purposes.
+  int64_t step_seq_ = 0;
+  static constexpr int kBatchSizeLag = 5;
+  int64_t ema_base_seq_ = 0;       // steps before this one left no record: batches are sized from ema_base_value_ instead
+  float ema_base_value_ = 512.f;   // (GlobalDataPool's initial meaningful-samples average)
+  int BatchSizeFor(int64_t seq);
+  bool digest_table_ = false;   // per-step table checksums into the digest (Renderer::StepDigest; two small launches per step)
+  Tensor digest_table_sums_;
+  void ResetStepSequence(int64_t seq);
 
   int iter_step_ = 0, end_iter_;
   int pts_batch_size_;

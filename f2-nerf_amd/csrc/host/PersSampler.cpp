@@ -5,7 +5,6 @@
 // scan, and the only host read-back of a GetSamples call is the pair (K, N) at its very end.
 #include "PersSampler.h"
 
-#include <ATen/hip/HIPGeneratorImpl.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -121,7 +120,8 @@ bool PersSampler::MaintenanceDue(int ahead) const {  // the conditions of Finish
   return false;
 }
 
-void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, float fineness, PendingSamples& p, bool speculative) {
+void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_raw, float fineness, PendingSamples& p, bool speculative,
+                               int64_t seq) {
   F2N_HOST_SCOPE("sampler.begin");
   Tensor rays_o = rays_o_raw.contiguous();
   Tensor rays_d_in = rays_d_raw.contiguous();
@@ -135,23 +135,19 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor rays_noise;                             // :372-381
   const int n_noise = F2N_MAX_SAMPLE_PER_RAY + n_rays + 10;
   bool map_noise = false;
+  const int64_t keyed = keyed_seq_;
+  keyed_seq_ = -1;  // (one-shot, whichever branch runs)
   if (forced_noise_.defined()) {
     rays_noise = forced_noise_.contiguous();
     TORCH_CHECK(rays_noise.numel() >= n_noise, "forced noise too short");
   } else if (global_data_pool_->mode_ == RunningMode::VALIDATE) {
     rays_noise = torch::full({n_noise}, fineness, DevF32());  // ones * fineness (:376-377)
   } else {
-    // The march noise has its own generator, re-seeded from the default generator's seed whenever that changes
-    // (torch::manual_seed): the noise of batch k is then the k-th draw of ITS sequence whatever else is drawn in between --
-    // background colours, edge samples, ray batches -- i.e. however far ahead of its step a batch is sampled (one or two steps,
-    // speculatively or behind the stat update: Renderer.h), the same batch gets the same noise.
-    const uint64_t seed = at::cuda::detail::getDefaultCUDAGenerator(rays_o.get_device()).current_seed();
-    if (!noise_gen_.defined() || seed != noise_gen_seed_ || noise_gen_.device() != rays_o.device()) {
-      noise_gen_ = at::cuda::detail::createCUDAGenerator(rays_o.get_device());
-      noise_gen_.set_current_seed(seed ^ 0x9E3779B97F4A7C15ull);
-      noise_gen_seed_ = seed;
-    }
-    rays_noise = torch::rand({n_noise}, noise_gen_, DevF32());
+    // The march noise of a batch is keyed by the batch's sequence number (KeyedDraws.h): the same batch gets the same noise
+    // however far ahead of its step it is sampled (one or two steps, speculatively or behind the stat update: Renderer.h) and
+    // however often (a prefetched batch that is dropped and sampled again draws the SAME numbers, not the next ones).
+    if (seq < 0) seq = keyed;
+    rays_noise = noise_draws_.Draw(n_noise, seq);
     map_noise = true;
   }
   // unit directions, zeroed totals and the noise map: one launch
@@ -194,13 +190,14 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
   Tensor first_oct_dis = torch::empty({n_rays, 1}, DevF32());
   const bool tail = speculative && tail_repair_ && max_oct_intersect_per_ray_ <= 2048;
-  if (speculative && persistent_march_ && march_blocks_ > 0 && max_oct_intersect_per_ray_ <= 2048) {  // small persistent grid, rays sorted by leaf count
+  const int persistent_blocks = persistent_near_ ? march_blocks_near_ : march_blocks_;  // (the grid this batch would be marched on)
+  if (speculative && persistent_march_ && persistent_blocks > 0 && max_oct_intersect_per_ray_ <= 2048) {  // small persistent grid, rays sorted by leaf count
     Tensor order = torch::empty({n_rays + 1}, DevI32());  // [R] ray order + the group counter
     if (tail) {
       p.leaf_state = torch::empty({k_cap, 2}, DevI32());
       p.reached = torch::empty({n_rays}, DevI32());
     }
-    F2N_TIMED_CALL("ray_march", f2n_ray_march_persistent(st, n_rays, max_oct_intersect_per_ray_, persistent_near_ ? march_blocks_near_ : march_blocks_, sample_l_, scale_by_dis_,
+    F2N_TIMED_CALL("ray_march", f2n_ray_march_persistent(st, n_rays, max_oct_intersect_per_ray_, persistent_blocks, sample_l_, scale_by_dis_,
                                    F32P(rays_o), F32P(rays_d), F32P(rays_noise), I32P(oct_se), I32P(oct_idx), F32P(oct_nf),
                                    VoidP(oct.tree_nodes_gpu_), VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t),
                                    I32P(s_anchors), F32P(first_oct_dis), I32P(oct_tr), tail ? VoidP(p.leaf_state) : nullptr,

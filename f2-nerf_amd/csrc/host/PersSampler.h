@@ -4,6 +4,7 @@
 #pragma once
 #include <functional>
 
+#include "KeyedDraws.h"
 #include "MappedHost.h"
 #include "PtsSampler.h"
 
@@ -108,7 +109,11 @@ class PersSampler : public PtsSampler {
   explicit PersSampler(GlobalDataPool* global_data_pool);
   SampleResultFlex GetSamples(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) override;
   // speculative = true: stop after the march (no scan / count / pack); CompleteSpeculative issues the rest
-  void BeginSamples(const Tensor& rays_o, const Tensor& rays_d, float fineness, PendingSamples& p, bool speculative = false);
+  // seq: the batch's sequence number in the training run (its march noise is draw `seq` of the noise purpose, KeyedDraws.h);
+  // < 0: keyed_seq_ if the caller set it (GetSamples has the reference's signature), else the next draw of the sampler's own sequence
+  void BeginSamples(const Tensor& rays_o, const Tensor& rays_d, float fineness, PendingSamples& p, bool speculative = false,
+                    int64_t seq = -1);
+  int64_t keyed_seq_ = -1;  // one-shot: the sequence number of the batch the NEXT BeginSamples / GetSamples call samples
   // Call with the stat update(s) since BeginSamples already in the current stream's order.  False: the tree was re-numbered
   // since (generation mismatch): nothing was issued, the caller must sample again.
   bool CompleteSpeculative(PendingSamples& p);
@@ -139,8 +144,10 @@ class PersSampler : public PtsSampler {
                         Tensor& kept);
   void FinishOctUpdate();
   Tensor& VoteBuffer();
-  // [K, N] of the sampling calls in flight, written by the scan kernel itself (MappedHost.h); eight rotating pairs -- at most
-  // two calls are in flight (a prefetched batch and a synchronous GetSamples), dropped ones finish within the next few
+  // [K, N] of the sampling calls in flight, written by the scan kernel itself (MappedHost.h); eight rotating pairs: up to
+  // Renderer::kPendingSlots prefetched batches and one synchronous GetSamples hold a pair each, a dropped batch's kernels are
+  // waited for before its slot is released (Renderer::DropPendingSlot), so a pair comes round again only after five newer
+  // calls have taken theirs
   MappedWords totals_words_;
   int next_totals_slot_ = 0;
   std::vector<Tensor> States() override;
@@ -162,8 +169,7 @@ class PersSampler : public PtsSampler {
   std::function<void(Tensor)> occupancy_sync_hook_;  // gets the [4, n_nodes] vote / mark / visit-count buffer
   // explicit random draws for parity tests (empty = draw from torch's generator like the reference)
   Tensor forced_noise_, forced_edge_idx_, forced_edge_coords_;
-  at::Generator noise_gen_;  // the march noise's own random sequence (BeginSamples)
-  uint64_t noise_gen_seed_ = 0;
+  KeyedUniforms noise_draws_{0x9E3779B97F4A7C15ull};  // the march noise: draw k belongs to batch k (BeginSamples)
   int extra_sample_rows_ = 0;  // SampleResultFlex::extra_rows of the training samples (set by the Renderer: 2 * n_edge_pts)
 };
 

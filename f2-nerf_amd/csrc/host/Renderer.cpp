@@ -6,7 +6,6 @@
 // loss and backward, untaped, for ExpRunner::TrainStep.
 #include "Renderer.h"
 
-#include <ATen/hip/HIPGeneratorImpl.h>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
@@ -247,6 +246,7 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
     if (PresampleMatches(rays_o, rays_d)) return;
   }
   static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
+  static_cast<PersSampler*>(pts_sampler_.get())->keyed_seq_ = cur_seq_;
   presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   has_presample_ = true;
   presample_async_ = false;
@@ -326,7 +326,7 @@ void Renderer::PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const 
 // First half of the prefetch: everything up to the sample counts, issued on a side stream without blocking the host.
 // Called from inside SampleAndFilter as soon as this step's occupancy update (the only thing the next batch's sampling
 // depends on) has been issued; the kernels then run underneath this step's forward/backward.
-void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& /*bounds*/, float fineness) {
+void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& /*bounds*/, float fineness, int64_t seq) {
   if (FindPending(rays_o, rays_d) >= 0) return;  // (already in flight for these rays)
   int slot = FreePendingSlot();
   if (slot < 0) {  // both slots hold batches for other rays: the one begun last is the furthest ahead, and goes
@@ -339,7 +339,8 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s);  // ... up to and including the pack
+  pend_[slot].seq = seq;
+  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/false, seq);  // ... up to and including the pack
   if (global_data_pool_->mode_ == RunningMode::TRAIN) PreGenerateStepDraws(slot);
   presample_done_ev_[slot].record(*side_[slot]);
   pend_[slot].rays_o = rays_o;
@@ -347,7 +348,7 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
 }
 
 // Speculative variant of PreSampleBegin: intersection + march only, NOT ordered behind this step's stat update.
-void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness) {
+void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness, int64_t seq) {
   EnsureSideStream(slot);
   // Everything the main stream has been handed so far comes first: the kernels that DRAW the next batch's rays
   // (Dataset::RandRaysData, queued by ExpRunner::Train right before this step) and whatever touched the tree there -- i.e. the
@@ -364,7 +365,8 @@ void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& 
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
   DebugSideDelay().Apply(0);
-  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/true);
+  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/true, seq);
+  pend_[slot].seq = seq;
   pend_[slot].rays_o = rays_o;
   pend_[slot].rays_d = rays_d;
 }
@@ -380,7 +382,7 @@ void Renderer::SpecBeginAtStepEnd() {
   const int slot = FreePendingSlot();
   if (!(speculative_sampling_ == 1 || quiet) || slot < 0 || ps->MaintenanceDueAt(gdp->iter_step_ + 1)) return;
   spec_start_recorded_ = false;  // (the side stream starts behind what this step has queued so far)
-  PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness);
+  PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness, nb.seq);
   spec_start_recorded_ = false;
   n_speculative_++;
 }
@@ -405,17 +407,6 @@ bool Renderer::PreSampleSpecComplete(int slot) {
   return true;
 }
 
-Tensor Renderer::DrawStepUniforms(int64_t n) {
-  const int dev = c10::hip::current_device();
-  const uint64_t seed = at::cuda::detail::getDefaultCUDAGenerator(dev).current_seed();
-  if (!aux_gen_.defined() || seed != aux_gen_seed_ || aux_gen_.device().index() != dev) {
-    aux_gen_ = at::cuda::detail::createCUDAGenerator(dev);
-    aux_gen_.set_current_seed(seed ^ 0xD1B54A32D192ED03ull);
-    aux_gen_seed_ = seed;
-  }
-  return torch::rand({n}, aux_gen_, DevF32());
-}
-
 // The draws of the step that will consume pend_[slot] (random background, 2E edge samples) and the edge-sample launch itself,
 // queued on that slot's side stream right behind its pack: the packed arrays (front rows) and worst-case-sized pts_all / vol_all
 // are their homes.  Only when nothing is pinned by a test and the background is random (the training configuration).
@@ -429,7 +420,7 @@ void Renderer::PreGenerateStepDraws(int slot) {
     return;
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   const int64_t nb = (int64_t) n_rays * 3, ne = (int64_t) n_edge * 3;
-  Tensor u = DrawStepUniforms(nb + ne);
+  Tensor u = DrawStepUniforms(nb + ne, pb.seq);
   pb.bg_color = u.narrow(0, 0, nb).view({n_rays, 3});
   const int64_t rows = pb.s.s_dt.numel() + front;  // every ray's slots full: the survivors can never be more
   pb.pts_all = torch::empty({rows, 3}, DevF32());
@@ -480,6 +471,7 @@ void Renderer::ResolvePendingCount() {
   const int n_kept = n_kept_words_.Read(1);
   last_n_kept_pts_ = n_kept;
   total_kept_pts_ += n_kept;
+  DigestKept(pending_count_seq_, n_kept);
   auto* gdp = global_data_pool_;
   if (dp_world_ > 1) {
     // Data-parallel streaming steps: every rank must size its next batch from the same number, the survivor count summed over
@@ -490,11 +482,13 @@ void Renderer::ResolvePendingCount() {
     if (dp_sum_mirrored_) {
       const float per_ray = float(n_kept_words_.Read(0)) / (float(dp_sum_rays_) * float(dp_world_));
       gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + per_ray * 0.1f;
+      RecordEma(pending_count_seq_ - 1);  // (the sum that has just gone in is the count of the step before the pending one)
     }
     dp_sum_mirrored_ = false;
     return;
   }
   gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(n_kept, pending_count_rays_) * 0.1f;
+  RecordEma(pending_count_seq_);
   // (the previous step's finiteness flags are NOT read here: they are written by that step's last kernel, and waiting for
   // them at the top of a step would stop the host from queueing ahead -- ExpRunner::TrainStep reads them once this step's
   // forward and backward are queued)
@@ -561,6 +555,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     has_presample_ = false;
     presample_rays_o_ = presample_rays_d_ = Tensor();
     static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
+    static_cast<PersSampler*>(pts_sampler_.get())->keyed_seq_ = train ? cur_seq_ : -1;
     sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   }
   // Random draws of the step (Renderer.cpp:67-81 background, PersSampler.cu:456-457 edge samples): ONE uniform launch for both
@@ -575,7 +570,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   if (pregen) bg_color = sample_result_.bg_color;
   if (draw_bg || draw_edge) {
     const int64_t nb = draw_bg ? (int64_t) n_rays * 3 : 0, ne = draw_edge ? (int64_t) n_edge * 3 : 0;
-    Tensor u = DrawStepUniforms(nb + ne);
+    Tensor u = DrawStepUniforms(nb + ne, train ? cur_seq_ : -1);
     if (draw_bg) bg_color = u.narrow(0, 0, nb).view({n_rays, 3});
     if (draw_edge) edge_u = u.narrow(0, nb, ne);
   }
@@ -623,7 +618,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     }
     ps->persistent_march_ = ahead >= 1 || ps->march_blocks_near_ > 0;  // (two steps to finish in: a few hundred resident waves do it)
     ps->persistent_near_ = ahead < 1;
-    PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness);
+    PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness, nb.seq);
     ps->persistent_march_ = ps->persistent_near_ = false;
     n_speculative_++;
   };
@@ -633,6 +628,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   }
   spec_start_recorded_ = false;
   if (train) total_all_pts_ += n_all_pts;
+  if (train) DigestBegin(n_rays, n_all_pts);
   if (train) gdp->sampled_pts_per_ray_ = gdp->sampled_pts_per_ray_ * 0.9f + (float(n_all_pts) / float(n_rays)) * 0.1f;
 
   RenderFront fr;
@@ -661,12 +657,17 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       dp_count_rays_ = n_rays;
       count_pending_ = true;
       pending_count_rays_ = n_rays;
+      pending_count_seq_ = cur_seq_;
     } else if (train && dp_world_ > 1) {
       if (!dp_count_host_.defined()) dp_count_host_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
       dp_count_host_.copy_(dp_count_, /*non_blocking=*/true);
       dp_count_ev_.record();
     }
-    if (train && !dp_lagged) gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(0, n_rays) * 0.1f;
+    if (train && !dp_lagged) {
+      gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(0, n_rays) * 0.1f;
+      RecordEma(cur_seq_);
+      DigestKept(cur_seq_, 0);
+    }
     last_n_kept_pts_ = 0;
     fr.empty = true;
     consumed_side_samples_ = false;  // (nothing was read from the side stream's buffers)
@@ -782,6 +783,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       if (train) {  // (bookkeeping of the training counters / EMA: Renderer::ResolvePendingCount)
         count_pending_ = true;
         pending_count_rays_ = n_rays;
+        pending_count_seq_ = cur_seq_;
       }
       fr.dyn = true;
       fr.n_kept_dev = total;
@@ -820,8 +822,11 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
                                  F32P(es.dt), F32P(es.t), I32P(es.anchors), I32P(src_rows), I32P(vol_all) + so,
                                  want_emb ? I32P(emb_contig) : nullptr, want_emb ? I32P(fr.sample_emb_idx) : nullptr));
     if (train) {
-      if (!fr.dyn)
+      if (!fr.dyn) {
         gdp->meaningful_sampled_pts_per_ray_ = gdp->meaningful_sampled_pts_per_ray_ * 0.9f + KeptPerRayForEma(n_kept, n_rays) * 0.1f;
+        RecordEma(cur_seq_);
+        DigestKept(cur_seq_, n_kept);
+      }
       // edge samples for the TV loss share the field's point array with the surviving samples (Renderer.cpp:159-166)
       if (!edges_cached && n_edge > 0) edge_samples_to(F32P(pts_all) + 3 * eo, I32P(vol_all) + eo, 1, nullptr, nullptr);
     }

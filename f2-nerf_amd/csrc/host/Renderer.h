@@ -75,7 +75,8 @@ class Renderer : public Pipe {
   // The same on a SIDE stream that only waits for this step's octree update: the sampler kernels (latency-bound: few
   // waves, long dependent chains) then run underneath the remaining forward/backward kernels of the current step.
   void PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);
-  void PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, float fineness);
+  // seq: the batch's sequence number in the training run (KeyedDraws.h: keys its march noise and its step's draws); < 0: unkeyed
+  void PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, float fineness, int64_t seq = -1);
   // Batches whose sampling is in flight on a side stream: at most kPendingSlots of them (round 4: the batch the NEXT step
   // consumes, being repaired / packed, and the one behind it, being walked and marched -- see next2_batch_), each on its own
   // stream.  A batch is identified by the ray tensors it was begun for (held: see PresampleMatches).
@@ -83,17 +84,20 @@ class Renderer : public Pipe {
   struct PendingBatch {
     PendingSamples s;
     Tensor rays_o, rays_d;
+    int64_t seq = -1;               // the batch's sequence number (keys its noise and the draws of the step that consumes it)
     bool step_draws_ready = false;  // PreGenerateStepDraws ran behind this batch's pack
     Tensor bg_color, pts_all, vol_all;
   };
   // the background colours and edge samples of the step that will consume pend_[slot], on that slot's side stream (behind its pack)
   void PreGenerateStepDraws(int slot);
   // The random draws a training step makes for itself (background colours, edge samples: Renderer.cpp:67-81, PersSampler.cu:456-457)
-  // come from their own generator, re-seeded with the default generator's seed (as the march noise, PersSampler::BeginSamples):
-  // the k-th training step gets the k-th draw whether it is made at the top of that step or a step earlier on a side stream.
-  at::Generator aux_gen_;
-  uint64_t aux_gen_seed_ = 0;
-  Tensor DrawStepUniforms(int64_t n);
+  // are keyed by the step's sequence number (KeyedDraws.h, as the march noise: PersSampler::BeginSamples): step k gets draw k
+  // whether it is made at the top of that step or a step earlier on a side stream, once or -- after a dropped batch -- twice.
+  KeyedUniforms step_draws_{0xD1B54A32D192ED03ull};
+  Tensor DrawStepUniforms(int64_t n, int64_t seq) { return step_draws_.Draw(n, seq); }
+  // The sequence number of the batch the running / next training-mode SampleAndFilter consumes: set by ExpRunner around every
+  // step (its count of steps taken); -1: unkeyed (Render() called on its own: each call takes the next draw of every purpose).
+  int64_t cur_seq_ = -1;
   bool pregen_draws_ = true;
   PendingBatch pend_[kPendingSlots];
   int64_t n_spec_dropped_ = 0;  // batches begun ahead and thrown away (other rays asked for, tree replaced)
@@ -147,6 +151,7 @@ class Renderer : public Pipe {
   struct NextBatch {
     Tensor rays_o, rays_d;
     float fineness = 1.f;
+    int64_t seq = -1;
     bool valid = false;
   } next_batch_, next2_batch_;  // the batch of the next step, and (two-deep pipeline) of the step after it
   // Two-deep pipeline (round 4).  With ONE batch in flight the sampler chain of batch k+1 -- walk, march, repair, scan, pack:
@@ -158,7 +163,7 @@ class Renderer : public Pipe {
   // as a step); 3: always.
   int spec_depth_ = 2;
   int64_t n_speculative_ = 0, n_spec_fallback_ = 0;  // batches sampled speculatively / sampled after the update instead
-  void PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness);
+  void PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness, int64_t seq);
   // Small trees (one-step-ahead regime): the batch after next is begun when THIS step's backward has been queued, not at the top
   // of the next step -- its noise draw, prologue and LDS-resident walk then run underneath the step's Adam / reduction tail (an
   // HBM stream: the vector units are idle) instead of colliding with the next step's gather, whose long-lived blocks keep a
@@ -185,6 +190,40 @@ class Renderer : public Pipe {
   bool dp_sum_mirrored_ = false;
   at::cuda::CUDAEvent dp_count_ev_;
   float KeptPerRayForEma(int n_kept_local, int n_rays);
+  // The meaningful-samples average AFTER the count of step `seq` went into it, for the last kEmaRing steps: ExpRunner::Train
+  // sizes batch j from the average after step j - kBatchSizeLag in EVERY mode (synchronous steps know their count at once,
+  // streaming steps one step late, data-parallel streaming steps two: a fixed lag takes the schedule out of the batch sizes).
+  static constexpr int kEmaRing = 32;
+  struct EmaMark {
+    int64_t seq = -1;
+    float value = 0.f;
+  } ema_ring_[kEmaRing];
+  void RecordEma(int64_t seq) {
+    if (seq >= 0) ema_ring_[seq % kEmaRing] = {seq, global_data_pool_->meaningful_sampled_pts_per_ray_};
+  }
+  bool EmaAfter(int64_t seq, float* value) const {
+    if (seq < 0 || ema_ring_[seq % kEmaRing].seq != seq) return false;
+    *value = ema_ring_[seq % kEmaRing].value;
+    return true;
+  }
+  int64_t pending_count_seq_ = -1;  // the step the pending survivor count belongs to
+  // Per-step digest (diagnostics: WHERE do two trainings part?): rays, marched and surviving samples of the last kDigestRing
+  // training steps, by sequence number; table_sum (when ExpRunner::digest_table_ is on): an order-free integer checksum of the
+  // f16 table after the step's Adam, on the device until read.
+  static constexpr int kDigestRing = 4096;
+  struct StepDigest {
+    int64_t seq = -1;
+    int iter = 0, n_rays = 0, n_marched = 0, n_kept = -1;
+  };
+  std::vector<StepDigest> digest_;
+  void DigestBegin(int n_rays, int n_marched) {
+    if (cur_seq_ < 0) return;
+    if (digest_.empty()) digest_.resize(kDigestRing);
+    digest_[cur_seq_ % kDigestRing] = {cur_seq_, global_data_pool_->iter_step_, n_rays, n_marched, -1};
+  }
+  void DigestKept(int64_t seq, int n_kept) {
+    if (seq >= 0 && !digest_.empty() && digest_[seq % kDigestRing].seq == seq) digest_[seq % kDigestRing].n_kept = n_kept;
+  }
   bool async_count_ = false;        // set by ExpRunner::TrainStep for streaming steps
   // streaming steps: compositing forward + loss + compositing backward as ONE launch (f2n_composite_train); false: the three
   // launches it replaces (what tests compare it with)

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+
 using namespace f2n;
 
 namespace {
@@ -88,8 +90,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            py::arg("pose"), py::arg("reso_level") = 1)
       .def("rand_rays_from_pose", [bounded](Dataset& d, int n, const Tensor& pose) { return bounded(d.RandRaysFromPose(n, pose)); })
       .def("rand_rays_whole_space", [bounded](Dataset& d, int n) { return bounded(d.RandRaysWholeSpace(n)); })
-      .def("rand_rays_data", [ray_data](Dataset& d, int n, int sets) { return ray_data(d.RandRaysData(n, sets)); },
-           py::arg("batch_size"), py::arg("sets") = DATA_TRAIN_SET)
+      .def("rand_rays_data", [ray_data](Dataset& d, int n, int sets, int64_t seq) { return ray_data(d.RandRaysData(n, sets, seq)); },
+           py::arg("batch_size"), py::arg("sets") = DATA_TRAIN_SET, py::arg("seq") = -1)
       .def("rand_rays_data_of_camera", [ray_data](Dataset& d, int idx, int n) { return ray_data(d.RandRaysDataOfCamera(idx, n)); })
       .def_static("pose_interpolate", &PoseInterpolate)
       .def_readonly("last_cam_indices", &Dataset::last_cam_indices_)
@@ -296,6 +298,27 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("proc_octree", [](ExpRunner& r, bool compact, bool subdivide, bool brute) { SamplerOf(r)->pers_octree_->ProcOctree(compact, subdivide, brute); })
       .def("tree_nodes", [](ExpRunner& r) { return SamplerOf(r)->pers_octree_->tree_nodes_gpu_; })
       .def("cur_batch_size", &ExpRunner::CurBatchSize)
+      .def("batch_size_for", &ExpRunner::BatchSizeFor)  // ray count of the batch with that sequence number (fixed-lag average)
+      .def_property("step_seq",  // training steps taken = the sequence number the next step's draws are keyed by (KeyedDraws.h)
+                    [](ExpRunner& r) { return r.step_seq_; }, [](ExpRunner& r, int64_t s) { r.ResetStepSequence(s); })
+      .def_readwrite("digest_table", &ExpRunner::digest_table_)
+      .def("step_digest",  // the last steps' (seq, iter, rays, marched, kept[, table checksum]), oldest first (flushes)
+           [](ExpRunner& r) {
+             r.FinishPending();
+             py::list out;
+             auto& dg = r.renderer_->digest_;
+             Tensor sums = r.digest_table_sums_.defined() ? r.digest_table_sums_.cpu() : Tensor();
+             std::vector<Renderer::StepDigest> rows;
+             for (auto& d : dg) if (d.seq >= 0) rows.push_back(d);
+             std::sort(rows.begin(), rows.end(), [](const Renderer::StepDigest& a, const Renderer::StepDigest& b) { return a.seq < b.seq; });
+             for (auto& d : rows) {
+               py::list row;
+               row.append(d.seq); row.append(d.iter); row.append(d.n_rays); row.append(d.n_marched); row.append(d.n_kept);
+               if (sums.defined()) row.append(sums.data_ptr<int64_t>()[d.seq % Renderer::kDigestRing]);
+               out.append(row);
+             }
+             return out;
+           })
       .def_readwrite("iter_step", &ExpRunner::iter_step_)
       .def_readwrite("check_nan", &ExpRunner::check_nan_)
       .def_readwrite("spec_at_step_end", &ExpRunner::spec_at_step_end_)
