@@ -208,9 +208,9 @@ class Renderer : public Pipe {
   }
   int64_t pending_count_seq_ = -1;  // the step the pending survivor count belongs to
   // Per-step digest (diagnostics: WHERE do two trainings part?): rays, marched and surviving samples of the last kDigestRing
-  // training steps, by sequence number; table_sum (when ExpRunner::digest_table_ is on): an order-free integer checksum of the
+  // training steps (a whole 20 000-iteration run), by sequence number; table_sum (when ExpRunner::digest_table_ is on): an order-free integer checksum of the
   // f16 table after the step's Adam, on the device until read.
-  static constexpr int kDigestRing = 4096;
+  static constexpr int kDigestRing = 32768;
   struct StepDigest {
     int64_t seq = -1;
     int iter = 0, n_rays = 0, n_marched = 0, n_kept = -1;

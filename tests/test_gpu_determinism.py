@@ -71,7 +71,7 @@ def test_training_is_independent_of_the_sampling_schedule(fox_scene):
     assert ref["iter_step"] == ITERS and ref["step_seq"] >= ITERS
     assert ref["spec"]["speculative"] == 0
     # the modes did differ in what they DID: batches were begun ahead, rays repaired, batches dropped at the ProcOctree iterations
-    assert runs["always_two_ahead"]["spec"]["speculative"] > ITERS and runs["always_one_ahead"]["spec"]["speculative"] > ITERS // 2
+    assert runs["always_two_ahead"]["spec"]["speculative"] > ITERS // 2 and runs["always_one_ahead"]["spec"]["speculative"] > ITERS // 2
     assert runs["always_one_ahead"]["spec"]["rays_repaired"] > 0 or runs["always_two_ahead"]["spec"]["rays_repaired"] > 0
     n_nodes = ref["nodes"].size // 64
     assert n_nodes > 897, n_nodes  # the subdivision at iteration 2000 ran

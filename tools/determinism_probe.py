@@ -26,6 +26,8 @@ ap.add_argument("--side-delay", nargs="*", default=[], help="one begin_us:comple
 ap.add_argument("--pollute", action="store_true", help="run r > 0: garbage (different per run) left in the LDS and registers of every CU in front "
                 "of every step and every speculative begin / completion (f2n_debug_pollute): a kernel that reads state it never wrote parts")
 ap.add_argument("--overrides", nargs="*", default=[])
+ap.add_argument("--digest", action="store_true", help="per-STEP digest (ExpRunner.step_digest: seq, iter, rays, marched, kept, table checksum "
+                "after the step) of every run, compared step by step: names the first step and quantity in which two runs part")
 args = ap.parse_args()
 NAMES = ["table", "field_mlp", "color_mlp", "app_emb", "nodes", "n_nodes", "batch", "marched", "meaningful", "speculative", "fallback", "dropped", "rays_repaired"]
 
@@ -49,6 +51,7 @@ def one_run():
         k, v = kv.split("=")
         setattr(runner, k, int(v))
     torch.manual_seed(2022)
+    runner.digest_table = bool(args.digest)
     rows = []
     for it in SCHEDULE:
         runner.train(ds, it, 1)
@@ -59,6 +62,8 @@ def one_run():
                      runner.n_nodes(), runner.cur_batch_size(), c["total_marched"], c["total_meaningful"]] +
                     [int(sp[k]) for k in ("speculative", "fallback", "dropped", "rays_repaired")])
     dbg = capi.debug_counters() if hasattr(capi, "debug_counters") else None
+    if args.digest:
+        DIGESTS.append([tuple(int(v) for v in row) for row in runner.step_digest()])
     if args.poison >= 1:
         runner.test_images(ds)
     del runner
@@ -73,6 +78,7 @@ def one_run():
 
 
 runs = []
+DIGESTS = []
 for r in range(args.runs):
     if args.side_delay or args.pollute:
         b, c, m, per = [int(v) for v in args.side_delay[(r - 1) % len(args.side_delay)].split(":")] if (r > 0 and args.side_delay) else (0, 0, 0, 1)
@@ -94,3 +100,18 @@ for r in range(1, args.runs):
         print("run %d parts from run 0 at iteration %d in: %s" % (r, SCHEDULE[first], ", ".join(diff)))
         for i in range(max(0, first - 1), min(len(ref), first + 3)):
             print("   it %4d  run0 %s\n            run%d %s" % (SCHEDULE[i], ref[i], r, runs[r][i]))
+
+if args.digest:
+    DNAMES = ["seq", "iter", "rays", "marched", "kept", "table"]
+    for r in range(1, len(DIGESTS)):
+        a, b = DIGESTS[0], DIGESTS[r]
+        first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), None)
+        if first is None and len(a) == len(b):
+            print("digest: run %d == run 0 in every one of %d steps" % (r, len(a)))
+        elif first is None:
+            print("digest: run %d has %d steps, run 0 %d (equal where both exist)" % (r, len(b), len(a)))
+        else:
+            diff = [DNAMES[k] for k in range(len(a[first])) if a[first][k] != b[first][k]]
+            print("digest: run %d parts from run 0 at step seq %d (iteration %d) in: %s" % (r, a[first][0], a[first][1], ", ".join(diff)))
+            for i in range(max(0, first - 2), min(len(a), first + 3)):
+                print("   run0 %s\n   run%d %s" % (a[i], r, b[i]))
