@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
                                                                   const int32_t* __restrict__ n_dev, int n_off) {
   F2N_RAISE_PRIO();
   __shared__ double s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp64 image of this block's table slice
-  __shared__ int s_total;
+  int& s_total = *(int*) &s_acc[0];              // (the record total lives in the image's first word until the image is zeroed)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // table slice g <- (level l1 = g / H, local slice g - l1*H) and (level l1 - 1, local slice g - l1*H + H)
   const int H = slices_per_half_level, g = blockIdx.x;
@@ -843,7 +843,9 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off);
   if (lane == 0 && wsum > 0) atomicAdd(&s_total, wsum);
   __syncthreads();
-  if (s_total == 0) return;  // block-uniform: nothing landed in this slice
+  const int total = s_total;
+  if (total == 0) return;  // block-uniform: nothing landed in this slice
+  __syncthreads();         // (everyone has read the total before its word is zeroed with the image)
   for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.0;
   __syncthreads();
   // Segments in batches, the first 128 records of each with one coalesced 8-byte load per lane (the records were written

@@ -345,6 +345,14 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
     if (!digest_table_sums_.defined()) digest_table_sums_ = torch::zeros({Renderer::kDigestRing}, torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA));
     digest_table_sums_.select(0, seq % Renderer::kDigestRing).copy_(field->feat_pool_h_.view(torch::kInt16).sum(torch::kInt64));
   }
+  if (renderer_->digest_taps_ && applied) {  // (parameters as this step's Adam leaves them; Renderer::DigestTap)
+    auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+    auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+    renderer_->DigestTap(Renderer::TAP_TABLE, field->feat_pool_h_);
+    renderer_->DigestTap(Renderer::TAP_FIELD_MLP, field->mlp_->params_h_);
+    renderer_->DigestTap(Renderer::TAP_COLOR_MLP, shader->mlp_->params_h_);
+    renderer_->DigestTap(Renderer::TAP_APP_EMB, renderer_->app_emb_);
+  }
   if (prefetch && !renderer_->PendingMatches(next_rays_o, next_rays_d))  // (a batch without samples never reached the hook)
     renderer_->PreSampleBegin(next_rays_o, next_rays_d, next_bounds, global_data_pool_->ray_march_fineness_, seq + 1);
   if (applied && check_nan_ && prefetch) {  // streaming: do not stall on this step's flags (see ExpRunner.h)

@@ -455,6 +455,16 @@ void Renderer::PreSampleFinish(int slot) {
   pb = PendingBatch();
 }
 
+void Renderer::DigestTap(int tap, const Tensor& t) {
+  if (!digest_taps_ || cur_seq_ < 0 || !t.defined() || t.numel() == 0) return;
+  if (!digest_tap_sums_.defined())
+    digest_tap_sums_ = torch::zeros({kDigestRing, N_TAPS}, torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA));
+  Tensor flat = t.detach().contiguous().reshape({-1});
+  const int64_t bytes = flat.numel() * flat.element_size();
+  Tensor bits = bytes % 4 == 0 ? flat.view(torch::kInt32) : (bytes % 2 == 0 ? flat.view(torch::kInt16) : flat.view(torch::kInt8));
+  digest_tap_sums_.select(0, cur_seq_ % kDigestRing).select(0, tap).copy_(bits.sum(torch::kInt64));
+}
+
 float Renderer::KeptPerRayForEma(int n_kept_local, int n_rays) {
   if (dp_world_ <= 1 || !dp_count_host_.defined()) return float(n_kept_local) / float(n_rays);
   dp_count_ev_.synchronize();  // recorded right behind the occupancy exchange of the same step
@@ -712,6 +722,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       pack_done();
       f0_full = field->QueryDensityPreAct(pts_full, anchors_full, /*keep_features=*/true);
       f0p = F32P(f0_full) + front;
+      if (digest_taps_ && train) DigestTap(TAP_EDGE, pts_full.narrow(0, 0, front));
       fr.edge_cache_row = 0;
       fr.sample_cache_row = front;
     } else {
@@ -719,6 +730,13 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       pack_done();
       f0_full = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors, /*keep_features=*/true);
       f0p = F32P(f0_full);
+    }
+    if (digest_taps_ && train) {
+      DigestTap(TAP_PTS, sample_result_.pts);
+      DigestTap(TAP_DT, sample_result_.dt);
+      DigestTap(TAP_ANCHORS, sample_result_.anchors.select(1, 0));
+      DigestTap(TAP_F0, f0_full);
+      DigestTap(TAP_BG, bg_color);
     }
     Tensor weights = torch::empty({n_all_pts}, DevF32()), alphas = torch::empty({n_all_pts}, DevF32());
     Tensor mask = torch::empty({n_all_pts}, DevI32()), kept = torch::empty({n_rays}, DevI32());
@@ -764,6 +782,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(kept), I32P(new_se), I32P(total), n_kept_words_.Dev(1), nullptr, 0));
     }
     n_kept_ev_.record();
+    if (digest_taps_ && train) DigestTap(TAP_SURVIVORS, new_se);
     if (dp_lagged) {  // this step's count: summed over the ranks inside the NEXT step's occupancy exchange (in place)
       dp_count_ = total;
       dp_count_rays_ = n_rays;
@@ -1004,6 +1023,7 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
                                F32P(dcolors), F32P(ddisp), nullptr, nullptr, gdp->gradient_scaling_progress_, F32P(drgb),
                                F32P(df0c), 1, F32P(weights), F32P(dvar)));
   }
+  if (digest_taps_) DigestTap(TAP_GRAD_BEFORE, field->grad_h_);  // (must be all zeros: Adam's zero_grad / ZeroGrad)
   F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd_dyn(st, n_kept, n_dev, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
                          VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat) + F2N_MLP_OUT_PAD * so,
                          F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,
@@ -1019,6 +1039,22 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
     F2N_TIMED_CALL("reduce_partials", f2n_reduce_deferred(st));
   } else {
     field->BackwardRaw(fr.pts_all, fr.vol_all, 1, field_x, dfeat);
+  }
+  if (digest_taps_ && fr.dyn) {
+    // what the scatter has just read, as it stands AFTER the scatter: rows [0, 2E + survivors) of pts_all / vol_all and of the
+    // MLP backward's inputs (rows beyond the device-side count are never written: masked out)
+    const int64_t rows = fr.pts_all.size(0);
+    Tensor live = torch::arange(rows, DevI32()).lt(fr.n_kept_dev + (int) so).to(torch::kInt32);
+    DigestTap(TAP_PTS_ALL_AFTER, fr.pts_all.view(torch::kInt32).sum(1, false, torch::kInt64) * live);
+    DigestTap(TAP_VOL_ALL_AFTER, fr.vol_all.to(torch::kInt64) * live);
+    Tensor live_n = live.narrow(0, 0, n);
+    DigestTap(TAP_FIELD_X, field_x.view(torch::kInt32).sum(1, false, torch::kInt64) * live_n);
+    DigestTap(TAP_DFEAT, dfeat.view(torch::kInt32).sum(1, false, torch::kInt64) * live_n);
+  }
+  if (digest_taps_) {
+    DigestTap(TAP_COLORS, colors);
+    DigestTap(TAP_TABLE_GRAD, field->grad_h_);
+    DigestTap(TAP_SMALL_GRADS, small_grads_flat_);
   }
   out.colors = colors;
   out.has_samples = true;

@@ -224,6 +224,15 @@ class Renderer : public Pipe {
   void DigestKept(int64_t seq, int n_kept) {
     if (seq >= 0 && !digest_.empty() && digest_[seq % kDigestRing].seq == seq) digest_[seq % kDigestRing].n_kept = n_kept;
   }
+  // Debugging taps (ExpRunner::digest_taps): order-free integer checksums of a step's intermediate arrays -- sampler outputs,
+  // pre-pass densities, survivor bounds, background, edge samples, colours, gradient buffers, parameters after Adam -- one
+  // int64 per (step, tap), on the device until read (ExpRunner.step_digest).  Two trainings that part are bisected to the
+  // first array that differs.  One small reduction launch per tap and step: off unless asked for.
+  enum { TAP_PTS, TAP_DT, TAP_ANCHORS, TAP_F0, TAP_SURVIVORS, TAP_BG, TAP_EDGE, TAP_COLORS, TAP_TABLE_GRAD, TAP_SMALL_GRADS, TAP_TABLE,
+         TAP_FIELD_MLP, TAP_COLOR_MLP, TAP_APP_EMB, TAP_GRAD_BEFORE, TAP_PTS_ALL_AFTER, TAP_VOL_ALL_AFTER, TAP_FIELD_X, TAP_DFEAT, N_TAPS };
+  bool digest_taps_ = false;
+  Tensor digest_tap_sums_;  // int64 [kDigestRing, N_TAPS]
+  void DigestTap(int tap, const Tensor& t);
   bool async_count_ = false;        // set by ExpRunner::TrainStep for streaming steps
   // streaming steps: compositing forward + loss + compositing backward as ONE launch (f2n_composite_train); false: the three
   // launches it replaces (what tests compare it with)

@@ -302,6 +302,23 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("step_seq",  // training steps taken = the sequence number the next step's draws are keyed by (KeyedDraws.h)
                     [](ExpRunner& r) { return r.step_seq_; }, [](ExpRunner& r, int64_t s) { r.ResetStepSequence(s); })
       .def_readwrite("digest_table", &ExpRunner::digest_table_)
+      .def_property("digest_taps",  // per-step checksums of the step's intermediate arrays (Renderer::DigestTap; debugging)
+                    [](ExpRunner& r) { return r.renderer_->digest_taps_; }, [](ExpRunner& r, bool on) { r.renderer_->digest_taps_ = on; })
+      .def("step_taps",  // int64 [steps, 1 + N_TAPS]: seq, then the taps (pts, dt, anchors, f0, survivors, bg, edge, colours, table grad,
+           [](ExpRunner& r) {  // small grads, table, field MLP, colour MLP, app_emb), oldest first
+             r.FinishPending();
+             std::vector<int64_t> seqs;
+             for (auto& d : r.renderer_->digest_) if (d.seq >= 0) seqs.push_back(d.seq);
+             std::sort(seqs.begin(), seqs.end());
+             Tensor out = torch::zeros({(int64_t) seqs.size(), 1 + Renderer::N_TAPS}, torch::kInt64);
+             if (!r.renderer_->digest_tap_sums_.defined()) return out;
+             Tensor sums = r.renderer_->digest_tap_sums_.cpu();
+             for (size_t i = 0; i < seqs.size(); i++) {
+               out[i][0] = seqs[i];
+               out[i].narrow(0, 1, Renderer::N_TAPS).copy_(sums[seqs[i] % Renderer::kDigestRing]);
+             }
+             return out;
+           })
       .def("step_digest",  // the last steps' (seq, iter, rays, marched, kept[, table checksum]), oldest first (flushes)
            [](ExpRunner& r) {
              r.FinishPending();

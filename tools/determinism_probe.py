@@ -26,6 +26,9 @@ ap.add_argument("--side-delay", nargs="*", default=[], help="one begin_us:comple
 ap.add_argument("--pollute", action="store_true", help="run r > 0: garbage (different per run) left in the LDS and registers of every CU in front "
                 "of every step and every speculative begin / completion (f2n_debug_pollute): a kernel that reads state it never wrote parts")
 ap.add_argument("--overrides", nargs="*", default=[])
+ap.add_argument("--taps", action="store_true", help="with --digest: checksums of every step's intermediate arrays too (ExpRunner.step_taps): "
+                "the first ARRAY in which two runs part")
+ap.add_argument("--save-taps", default="", help="file prefix: every run's tap matrix is saved (comparison across processes)")
 ap.add_argument("--digest", action="store_true", help="per-STEP digest (ExpRunner.step_digest: seq, iter, rays, marched, kept, table checksum "
                 "after the step) of every run, compared step by step: names the first step and quantity in which two runs part")
 args = ap.parse_args()
@@ -52,6 +55,7 @@ def one_run():
         setattr(runner, k, int(v))
     torch.manual_seed(2022)
     runner.digest_table = bool(args.digest)
+    runner.digest_taps = bool(args.taps)
     rows = []
     for it in SCHEDULE:
         runner.train(ds, it, 1)
@@ -64,6 +68,10 @@ def one_run():
     dbg = capi.debug_counters() if hasattr(capi, "debug_counters") else None
     if args.digest:
         DIGESTS.append([tuple(int(v) for v in row) for row in runner.step_digest()])
+        if args.taps:
+            TAPS.append(runner.step_taps().numpy().copy())
+            if args.save_taps:
+                np.save("%s_run%d.npy" % (args.save_taps, len(TAPS) - 1), TAPS[-1])
     if args.poison >= 1:
         runner.test_images(ds)
     del runner
@@ -79,6 +87,8 @@ def one_run():
 
 runs = []
 DIGESTS = []
+TAPS = []
+TAP_NAMES = ["seq", "pts", "dt", "anchors", "f0", "survivors", "bg", "edge", "colors", "table_grad", "small_grads", "table", "field_mlp", "color_mlp", "app_emb", "grad_before", "pts_all_after", "vol_all_after", "field_x", "dfeat"]
 for r in range(args.runs):
     if args.side_delay or args.pollute:
         b, c, m, per = [int(v) for v in args.side_delay[(r - 1) % len(args.side_delay)].split(":")] if (r > 0 and args.side_delay) else (0, 0, 0, 1)
@@ -115,3 +125,17 @@ if args.digest:
             print("digest: run %d parts from run 0 at step seq %d (iteration %d) in: %s" % (r, a[first][0], a[first][1], ", ".join(diff)))
             for i in range(max(0, first - 2), min(len(a), first + 3)):
                 print("   run0 %s\n   run%d %s" % (a[i], r, b[i]))
+
+if args.taps:
+    for r in range(1, len(TAPS)):
+        a, b = TAPS[0], TAPS[r]
+        k = min(len(a), len(b))
+        bad = np.nonzero((a[:k] != b[:k]).any(1))[0]
+        if len(bad) == 0:
+            print("taps: run %d == run 0 in every tap of %d steps" % (r, k))
+        else:
+            i = int(bad[0])
+            cols = [TAP_NAMES[c] for c in range(a.shape[1]) if a[i, c] != b[i, c]]
+            print("taps: run %d parts from run 0 at step seq %d, first in (pipeline order): %s" % (r, int(a[i, 0]), ", ".join(cols)))
+            for j in range(max(0, i - 1), min(k, i + 2)):
+                print("   run0 %s\n   run%d %s" % (a[j].tolist(), r, b[j].tolist()))
