@@ -84,7 +84,9 @@ def psnr_runs(args, n_runs):
     sc, images = fox_data.scene(args.factor)
     ds = runtime.make_dataset(sc, images)
     runs, leaf_sets = [], []
-    seeds = [2022 + r for r in range(n_runs)] + ([2022] if n_runs > 0 else [])
+    rerun_seed = not getattr(args, "psnr_no_rerun", False)
+    seeds = [2022 + r for r in range(n_runs)] + ([2022] if (n_runs > 0 and rerun_seed) else [])
+    partial = getattr(args, "psnr_partial", "")
     for seed in seeds:
         runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022)
         torch.manual_seed(seed)
@@ -109,6 +111,12 @@ def psnr_runs(args, n_runs):
                      "train_wall_s": round(wall, 2), "octree_nodes": int(len(nodes)), "valid_leaves": int(leaf.sum()),
                      "param_checksums_at_iter": sums})
         del runner
+        if partial:  # (a study that is cut short keeps what it has: tools/psnr_study.sh)
+            with open(partial, "w") as f:
+                json.dump({"numerics_mode": int(capi.lib().f2n_numerics_mode()), "runs": runs}, f)
+    if not rerun_seed:
+        runs.append(dict(runs[0]))
+        leaf_sets.append(leaf_sets[0])
     rerun, rerun_leaves = runs.pop(), leaf_sets.pop()  # the repeated seed: compared with run 0 only
     first_diff = None
     for stop in ("1", "10", "100", "1000"):
@@ -118,7 +126,7 @@ def psnr_runs(args, n_runs):
     inter0 = len(np.intersect1d(leaf_sets[0], rerun_leaves, assume_unique=True))
     same_seed = {"seed": 2022, "psnr_run0": runs[0]["psnr_test_mean"], "psnr_rerun": rerun["psnr_test_mean"],
                  "checksums_part_at_checkpoint": first_diff,
-                 "identical": first_diff is None and runs[0]["psnr_test_mean"] == rerun["psnr_test_mean"],
+                 "identical": (first_diff is None and runs[0]["psnr_test_mean"] == rerun["psnr_test_mean"]) if rerun_seed else None,
                  "surviving_leaf_sets_jaccard": round(inter0 / max(len(leaf_sets[0]) + len(rerun_leaves) - inter0, 1), 4)}
     jac = []
     for i in range(n_runs):
@@ -335,6 +343,8 @@ def main():
     ap.add_argument("--psnr-runs", type=int, default=4, help="trainings of the PSNR distribution with the product numerics (0: skip)")
     ap.add_argument("--psnr-ref-runs", type=int, default=3, help="... with the reference-numerics build of the kernel library (0: skip)")
     ap.add_argument("--psnr-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: run N trainings, print their summary
+    ap.add_argument("--psnr-no-rerun", action="store_true", help=argparse.SUPPRESS)  # worker: no repeat of seed 2022 at the end
+    ap.add_argument("--psnr-partial", default="", help=argparse.SUPPRESS)  # worker: file that holds the runs finished so far
     ap.add_argument("--other-configs", type=int, default=1, help="1: also run BASELINE configs 3-5 briefly (own processes) and report "
                     "them in the line (N=1, default preset only); 0: skip")
     ap.add_argument("--other-steps", type=int, default=60, help="timed steps of each of those runs")
