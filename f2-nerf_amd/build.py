@@ -22,7 +22,11 @@ OBJ = os.path.join(HERE, "build")
 #   "refnum"  -DF2N_REFERENCE_NUMERICS=1: libf2n_hip_refnum.so + _f2n_host_refnum*.so -- the reference's per-addend f16 hash
 #             gradient atomics and an f16 MLP forward accumulator, for A/B trainings (bench.py psnr_numerics_ab).  A process
 #             picks it with F2N_REFERENCE_NUMERICS=1 in its environment BEFORE the package is imported (one numerics per process).
-VARIANT = "refnum" if os.environ.get("F2N_REFERENCE_NUMERICS", "0") not in ("", "0") else ""
+#   "debug"   -DF2N_DEBUG_BUILD=1: libf2n_hip_debug.so + _f2n_host_debug*.so -- the product's code plus the debugging launches of
+#             include/f2n_debug.h, the stream-skew hooks of the host's Renderer and the measurement knobs that read the
+#             environment (the product library reads none).  Picked with F2N_DEBUG_BUILD=1 in the environment before the import.
+VARIANT = ("refnum" if os.environ.get("F2N_REFERENCE_NUMERICS", "0") not in ("", "0") else
+           "debug" if os.environ.get("F2N_DEBUG_BUILD", "0") not in ("", "0") else "")
 
 
 def lib_path(variant=None):
@@ -34,7 +38,7 @@ LIB = lib_path()
 
 HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip", "workspace.hip", "dataset.hip", "octree.hip",
                "mlp_generic.hip"]
-HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", "rows_dev.h", os.path.join(INCLUDE, "f2n_abi.h")]
+HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", "rows_dev.h", os.path.join(INCLUDE, "f2n_abi.h"), os.path.join(INCLUDE, "f2n_debug.h")]
 # (-mllvm -amdgpu-mfma-vgpr-form=1 was tried: a third fewer instructions in the MLP backward kernels -- no
 # v_accvgpr_read of every MFMA result -- but 15 % SLOWER: those kernels are bound by dependency latency, not issue.)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -59,7 +63,7 @@ def build_hip(force=False, verbose=False, variant=None):
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
     jobs = []
     objs = []
-    defs = ["-DF2N_REFERENCE_NUMERICS=1"] if variant == "refnum" else []
+    defs = {"refnum": ["-DF2N_REFERENCE_NUMERICS=1"], "debug": ["-DF2N_DEBUG_BUILD=1"]}.get(variant, [])
     extra = os.environ.get("F2N_EXTRA_HIPCC", "")  # measurement knob: "file.hip:-flag -flag;other.hip:-flag"
     extra_by_file = dict(kv.split(":", 1) for kv in extra.split(";") if ":" in kv)
     for src in HIP_SOURCES:
@@ -99,18 +103,21 @@ def build_host(force=False, verbose=False, variant=None):
     from torch.utils import cpp_extension as ce
     host_dir = os.path.join(CSRC, "host")
     srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp"))
-    hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")] + [os.path.join(INCLUDE, "f2n_abi.h")]
+    hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")] + [os.path.join(INCLUDE, "f2n_abi.h"),
+                                                                                             os.path.join(INCLUDE, "f2n_debug.h")]
     variant = VARIANT if variant is None else variant
-    out = host_module_path(variant)  # (the same objects; only the kernel library it is linked against differs)
+    out = host_module_path(variant)  # (product and refnum: the same objects, only the kernel library linked against differs;
+    #                                     debug: its own objects, compiled with -DF2N_DEBUG_BUILD=1)
+    dbg = variant == "debug"
     os.makedirs(OBJ, exist_ok=True)
     inc = ["-I" + p for p in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I" + INCLUDE,
                                                       "-I/opt/rocm/include"]
     cxx11 = int(torch._C._GLIBCXX_USE_CXX11_ABI)
     flags = ["-O2", "-std=c++17", "-fPIC", "-DTORCH_EXTENSION_NAME=_f2n_host", "-DTORCH_API_INCLUDE_EXTENSION_H",
-             "-D_GLIBCXX_USE_CXX11_ABI=%d" % cxx11, "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-w"]
+             "-D_GLIBCXX_USE_CXX11_ABI=%d" % cxx11, "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-w"] + (["-DF2N_DEBUG_BUILD=1"] if dbg else [])
     jobs, objs = [], []
     for s in srcs:
-        o = os.path.join(OBJ, "host_" + os.path.basename(s).replace(".cpp", ".o"))
+        o = os.path.join(OBJ, "host_" + os.path.basename(s).replace(".cpp", ".debug.o" if dbg else ".o"))
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
             jobs.append(["g++"] + flags + inc + ["-c", s, "-o", o])
@@ -133,7 +140,7 @@ def build_host(force=False, verbose=False, variant=None):
     return out
 
 
-def build_all(force=False, verbose=False, variants=("", "refnum")):
+def build_all(force=False, verbose=False, variants=("", "refnum", "debug")):
     """Builds every variant; returns the paths of the one this process uses (VARIANT)."""
     out = {}
     for v in variants:

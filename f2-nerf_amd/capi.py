@@ -11,7 +11,7 @@ import torch
 from . import build
 
 _lib = None
-ABI_VERSION = 10  # include/f2n_abi.h
+ABI_VERSION = 11  # include/f2n_abi.h
 
 
 class F2nError(RuntimeError):
@@ -74,13 +74,21 @@ def debug_counters(reset=False):
     return [int(v) for v in out]
 
 
+def _debug_only(name):
+    if not hasattr(lib(), name):
+        raise RuntimeError("%s exists in the debug variant of the library only (include/f2n_debug.h): set F2N_DEBUG_BUILD=1 before "
+                           "importing the package" % name)
+
+
 def debug_pollute(value):
     """Garbage derived from `value` in 64 KB of LDS and ~100 vector registers of every CU, on the current stream (f2n_debug_pollute)."""
+    _debug_only("f2n_debug_pollute")
     _ck(lib().f2n_debug_pollute(_stream(), ctypes.c_uint(int(value) & 0xFFFFFFFF)), "f2n_debug_pollute")
 
 
 def debug_spin(microseconds):
     """One wave spinning for that long on the current stream (f2n_debug_spin)."""
+    _debug_only("f2n_debug_spin")
     _ck(lib().f2n_debug_spin(_stream(), _i(microseconds)), "f2n_debug_spin")
 
 

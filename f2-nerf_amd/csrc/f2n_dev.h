@@ -6,6 +6,12 @@
 #include <stdint.h>
 
 #include "../../include/f2n_abi.h"
+#ifndef F2N_DEBUG_BUILD
+#define F2N_DEBUG_BUILD 0  // 1: the debug variant of the library (include/f2n_debug.h): debugging launches + measurement knobs
+#endif
+#if F2N_DEBUG_BUILD
+#include "../../include/f2n_debug.h"
+#endif
 
 #define F2N_WAVE 64
 

@@ -1185,12 +1185,16 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
                               const half_t* gx, long ss, long ps, const uint16_t* nz_mask, half_t* grad_table, int level_entries,
                               const int32_t* n_dev = nullptr, int n_off = 0) {
   F2nBinQueues q;
+#if F2N_DEBUG_BUILD  // measurement knob of the debug variant: the producer chunk count whatever the sample count
   static const int nb_force = []() {
     const char* e = getenv("F2N_BIN_NB");
     const int v = e != nullptr ? atoi(e) : 0;
     return (v == 32 || v == 64 || v == 128) ? v : 0;
   }();
   q.nb_force = nb_force;
+#else
+  q.nb_force = 0;
+#endif
 
 
   q.n_bins = level_entries >> F2N_BIN_SHIFT;

@@ -15,6 +15,12 @@
 #include <vector>
 
 #include "f2n_abi.h"
+#ifndef F2N_DEBUG_BUILD
+#define F2N_DEBUG_BUILD 0  // 1: the debug variant of the host layer (build.py variant "debug"): stream-skew hooks + measurement knobs
+#endif
+#if F2N_DEBUG_BUILD
+#include "f2n_debug.h"
+#endif
 
 #define None torch::indexing::None
 #define Slc torch::indexing::Slice

@@ -28,7 +28,8 @@ DataParallel::~DataParallel() {
   if (comm_ != nullptr) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
 }
 
-void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vector<uint8_t>& unique_id, bool overlap) {
+void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vector<uint8_t>& unique_id, bool overlap,
+                          bool hooks_for_one_rank) {
   TORCH_CHECK(unique_id.size() == sizeof(ncclUniqueId), "unique id must be ", sizeof(ncclUniqueId), " bytes");
   TORCH_CHECK(world >= 1 && rank >= 0 && rank < world, "bad rank / world size");
   runner_ = runner;
@@ -44,10 +45,9 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
   // Replicas must start from identical parameters, hash primes / biases and octree: whatever seeds the ranks were
   // constructed with, rank 0's state wins (per-rank RNG streams are for ray / noise / background draws only).
   BroadcastStates();
-  // A one-rank world has nothing to exchange: the hooks are only installed when asked for (F2N_DP_FORCE=1: tests and
-  // overhead measurements drive the RCCL calls with one rank; each costs a ~50-100 us kernel even then).
-  const char* force = getenv("F2N_DP_FORCE");
-  if (world == 1 && !(force != nullptr && force[0] == '1')) return;
+  // A one-rank world has nothing to exchange: the hooks are only installed when asked for (tests and overhead measurements
+  // drive the RCCL calls with one rank; each costs a ~50-100 us kernel even then).
+  if (world == 1 && !hooks_for_one_rank) return;
   auto* field = static_cast<Hash3DAnchored*>(runner->renderer_->scene_field_.get());
   flat_ = runner->FlattenSmallGrads();
   table_prefix_ = field->grad_h_.view({-1}).narrow(0, 0, field->active_halves_);

@@ -28,7 +28,10 @@ class DataParallel {
   static std::vector<uint8_t> NewUniqueId();  // rank 0
   // Creates the communicator (collective: every rank must call), replicates rank 0's state on every rank and wires the
   // exchanges into the runner.  overlap = pipelined gradient exchange (see above); false: in front of the optimiser.
-  void Attach(ExpRunner* runner, int rank, int world, const std::vector<uint8_t>& unique_id, bool overlap = true);
+  // hooks_for_one_rank: a one-rank world has nothing to exchange and installs no hooks unless asked to (tests and overhead
+  // measurements drive the RCCL calls with one rank)
+  void Attach(ExpRunner* runner, int rank, int world, const std::vector<uint8_t>& unique_id, bool overlap = true,
+              bool hooks_for_one_rank = false);
   void BroadcastStates();           // rank 0's checkpoint vector -> every rank (collective)
   int rank() const { return rank_; }
   int world() const { return world_; }

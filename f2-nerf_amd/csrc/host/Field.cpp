@@ -304,10 +304,14 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
   }
   Tensor f0 = torch::empty({n}, DevF32());
   prepass_x_ = keep_features ? torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16()) : Tensor();
+#if F2N_DEBUG_BUILD
   static const bool force_fused = []() {  // measurement knob: the one-kernel gather -> MLP at every size (profiles/r04_fused_gather_ab.txt)
     const char* e = std::getenv("F2N_FUSED_GATHER");
     return e != nullptr && e[0] == '1';
   }();
+#else
+  constexpr bool force_fused = false;  // (measured to lose at every training size: profiles/r04_fused_gather_ab.txt)
+#endif
   if (force_fused) {
     F2N_TIMED_CALL("field_prepass_fused", f2n_field_fwd_fused(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),
                            I32P(feat_local_idx_), I32P(feat_local_size_), F32P(bias_pool_), F32P(level_scale_), F32P(pts), I32P(av.t),
@@ -318,7 +322,8 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
     // stretched by the distance scaling where it is on), half of that in the [0,1] space the grid hashes (:91)
     const float step01 = march_step_warped_ * global_data_pool_->ray_march_fineness_ * .5f;
     // Tables that have left the L2s (2^21 entries per level and more: BASELINE config 5) take the slice-binned gather for the level
-    // pairs whose working set exceeds an L2 -- F2N_BINNED_GATHER_P0 (measurement knob): first binned pair, 8 = off, default 1
+    // pairs whose working set exceeds an L2: from level pair 1 on, for tables of 2^21 entries per level and more
+#if F2N_DEBUG_BUILD  // (measurement knobs of the debug variant: first binned pair, 8 = off; smallest table that takes the binned path)
     static const int binned_p0 = []() {
       const char* e = std::getenv("F2N_BINNED_GATHER_P0");
       const int v = e != nullptr ? std::atoi(e) : 1;
@@ -328,6 +333,9 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
       const char* e = std::getenv("F2N_BINNED_GATHER_MIN_LOG2");
       return e != nullptr ? std::atoi(e) : 21;
     }();
+#else
+    constexpr int binned_p0 = 1, binned_min_log2 = 21;
+#endif
     const int level_entries = (int) (pool_size_ / N_LEVELS);
     if (binned_p0 < 8 && level_entries >= (1 << binned_min_log2) && level_entries <= (1 << 22) && n >= 65536 && n <= 1536 * 1024) {
       F2N_TIMED_CALL("hash_gather", f2n_hash_gather_planes_binned(CurStream(), n, n_volumes_, VoidP(feat_pool_h_), I32P(prim_pool_),

@@ -254,6 +254,7 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
   presample_rays_d_ = rays_d;
 }
 
+#if F2N_DEBUG_BUILD
 // F2N_DEBUG_SIDE_DELAY="begin_us:complete_us:main_us:period" (debugging aid, off by default): every period-th speculative begin /
 // completion / step is preceded by a spin kernel of that many microseconds on its stream (f2n_debug_spin), which skews the sampler's
 // side streams against the main stream.  Results must not depend on it (tools/determinism_probe.py --side-delay).
@@ -294,6 +295,10 @@ void Renderer::SetDebugSideDelay(int begin_us, int complete_us, int main_us, int
   d.main_us = main_us;
   d.period = period < 1 ? 1 : period;
 }
+#define F2N_DEBUG_SKEW(which) DebugSideDelay().Apply(which)
+#else
+#define F2N_DEBUG_SKEW(which) ((void) 0)  // (the product's step has no debugging hooks: host/Common.h F2N_DEBUG_BUILD)
+#endif
 
 // The two side streams are per DEVICE, not per Renderer: a process that builds a second runner (bench.py: the headline runner, then
 // the converged leg's) would otherwise hold five streams -- main + 2 + 2 -- and HIP multiplexes streams onto four hardware queues
@@ -364,7 +369,7 @@ void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& 
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  DebugSideDelay().Apply(0);
+  F2N_DEBUG_SKEW(0);
   ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/true, seq);
   pend_[slot].seq = seq;
   pend_[slot].rays_o = rays_o;
@@ -396,7 +401,7 @@ bool Renderer::PreSampleSpecComplete(int slot) {
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  DebugSideDelay().Apply(1);
+  F2N_DEBUG_SKEW(1);
   if (!ps->CompleteSpeculative(pb.s)) {
     n_spec_dropped_++;
     pb = PendingBatch();  // (its kernels are ordered on the side stream, whose pool its buffers return to)
@@ -509,7 +514,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   F2N_HOST_SCOPE("step.sample_and_filter");
   auto* gdp = global_data_pool_;
   ResolvePendingCount();
-  if (gdp->mode_ == RunningMode::TRAIN) DebugSideDelay().Apply(2);
+  if (gdp->mode_ == RunningMode::TRAIN) F2N_DEBUG_SKEW(2);
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);

@@ -66,8 +66,10 @@ class Renderer : public Pipe {
 
  public:
   Renderer(GlobalDataPool* global_data_pool, int n_images);
-  // debugging aid (see Renderer.cpp, F2N_DEBUG_SIDE_DELAY): spin kernels in front of every period-th speculative begin / completion / step
+#if F2N_DEBUG_BUILD
+  // debug variant only (see Renderer.cpp): spin kernels in front of every period-th speculative begin / completion / step
   static void SetDebugSideDelay(int begin_us, int complete_us, int main_us, int period, unsigned pollute = 0);
+#endif
   RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
   RenderResult RenderForward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);  // inference: no tape, no count read-back
   // issues the ray sampling of the next SampleAndFilter / TrainForwardBackward call ahead of time (same rays!)

@@ -32,7 +32,7 @@ py::dict StatsToDict(const TrainStats& s) {
 
 // the ABI version this host layer was compiled against (include/f2n_abi.h); a kernel library of another version next to it
 // means one of the two was not rebuilt -- calls would pass the wrong argument lists (observed once: a memory fault)
-#define F2N_HOST_EXPECTS_ABI 10
+#define F2N_HOST_EXPECTS_ABI 11
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "f2-nerf hot path: C++/LibTorch host layer over libf2n_hip.so";
@@ -238,16 +238,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            })
       .def("flush", [](ExpRunner& r) { py::gil_scoped_release no_gil; r.FinishPending(); })
       .def("attach_data_parallel",  // native RCCL exchanges, issued from C++ inside TrainStep (DataParallel.h); collective
-           [](ExpRunner& r, int rank, int world, const py::bytes& unique_id, bool overlap) {
+           [](ExpRunner& r, int rank, int world, const py::bytes& unique_id, bool overlap, bool hooks_for_one_rank) {
              std::string s = unique_id;
              auto dp = std::make_shared<DataParallel>();
              {
                py::gil_scoped_release no_gil;
-               dp->Attach(&r, rank, world, std::vector<uint8_t>(s.begin(), s.end()), overlap);
+               dp->Attach(&r, rank, world, std::vector<uint8_t>(s.begin(), s.end()), overlap, hooks_for_one_rank);
              }
              r.data_parallel_ = dp;
            },
-           py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("overlap") = true)
+           py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("overlap") = true, py::arg("hooks_for_one_rank") = false)
       .def("dp_comm_ranks",  // ranks of the native RCCL communicator as RCCL reports them (0: none attached)
            [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->CommRanks() : 0; })
       .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically
@@ -266,11 +266,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     hp.on = on;
                     return d;
                   })
+#if F2N_DEBUG_BUILD
       .def_static("debug_side_delay",  // spin kernels (us) in front of every period-th speculative begin / completion / step: a race amplifier
                   [](int begin_us, int complete_us, int main_us, int period, unsigned pollute) {
                     Renderer::SetDebugSideDelay(begin_us, complete_us, main_us, period, pollute);
                   },
                   py::arg("begin_us"), py::arg("complete_us"), py::arg("main_us"), py::arg("period"), py::arg("pollute") = 0u)
+#endif
       .def_static("enable_kernel_timing", [](const std::vector<std::string>& names) { KernelTimers::Get().Enable(names); })
       .def_static("disable_kernel_timing", []() { KernelTimers::Get().Disable(); })
       .def_static("collect_kernel_timing",

@@ -339,6 +339,7 @@ static F2nAdamCoef f2n_adam_coef(int step, float lr, float beta1, float beta2, f
   return k;
 }
 
+#if F2N_DEBUG_BUILD  // (include/f2n_debug.h: the debug variant of the library only)
 // Leaves `value`-derived garbage in 64 KB of LDS and ~100 vector registers of every CU (f2n_debug_pollute): what a co-tenant's
 // kernels do to the state a kernel finds when it starts.  A kernel that reads LDS or registers it never wrote then depends on it.
 __global__ __launch_bounds__(256) void debug_pollute_kernel(unsigned value, unsigned* __restrict__ sink) {
@@ -360,6 +361,7 @@ __global__ void debug_spin_kernel(long long ticks) {
   const long long t0 = (long long) wall_clock64();
   while ((long long) wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
+#endif
 
 extern "C" {
 
@@ -471,6 +473,7 @@ int f2n_nonfinite_flags(void* stream, int n_a, const float* a, int n_b, const fl
   return f2n_nonfinite_flags_ex(stream, n_a, a, n_b, b, flags, nullptr);
 }
 
+#if F2N_DEBUG_BUILD
 int f2n_debug_pollute(void* stream, unsigned value) {
   hipLaunchKernelGGL(debug_pollute_kernel, dim3(1024), dim3(256), 64 * 1024, (hipStream_t) stream, value, (unsigned*) nullptr);
   return f2n_launch_status();
@@ -481,8 +484,9 @@ int f2n_debug_spin(void* stream, int microseconds) {
   hipLaunchKernelGGL(debug_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, (long long) microseconds * 100);
   return f2n_launch_status();
 }
+#endif
 
-int f2n_abi_version(void) { return 10; }
+int f2n_abi_version(void) { return 11; }
 #ifndef F2N_REFERENCE_NUMERICS
 #define F2N_REFERENCE_NUMERICS 0
 #endif

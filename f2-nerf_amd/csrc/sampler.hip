@@ -1249,12 +1249,16 @@ __global__ void march_noise_kernel(int n, const float* __restrict__ u, float fin
 // resident (160 KB / this), i.e. how many wave slots and registers the latency-bound march takes from the MLP / scatter
 // kernels it runs underneath.  0 = no cap.  F2N_MARCH_LDS (bytes) overrides the default for experiments.
 static size_t f2n_march_lds() {
+#if F2N_DEBUG_BUILD
   static const size_t bytes = []() -> size_t {  // (read once: getenv is neither cheap nor safe against a concurrent setenv)
     const char* e = getenv("F2N_MARCH_LDS");
     const long v = e != nullptr ? atol(e) : 0;
     return (size_t) (v < 0 ? 0 : (v > 160 * 1024 ? 160 * 1024 : v));
   }();
   return bytes;
+#else
+  return 0;
+#endif
 }
 
 extern "C" {

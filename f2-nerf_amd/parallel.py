@@ -84,7 +84,7 @@ def broadcast_states(runner, group=None):
         runner.load_aux_states(bcast(runner.aux_states()))
 
 
-def attach(runner, log2_table_size, group=None, overlap=None, native=None):
+def attach(runner, log2_table_size, group=None, overlap=None, native=None, hooks_for_one_rank=False):
     """Wire the exchanges into an ExpRunner.
 
     native (default: on for the nccl/RCCL backend): the C++ host creates its own RCCL communicator (ncclCommInitRank; the
@@ -109,7 +109,8 @@ def attach(runner, log2_table_size, group=None, overlap=None, native=None):
         dist.broadcast_object_list(ids, src=0, group=group, device=torch.device("cuda", torch.cuda.current_device()))
         # overlap: the gradient exchange runs underneath the next step's ray sampling, which therefore moves from "under this
         # step's backward" to the step boundary -- worth it as soon as there is an exchange to hide (world > 1)
-        runner.attach_data_parallel(rank, world, ids[0], (world > 1) if overlap is None else bool(overlap))
+        # (hooks_for_one_rank: a one-rank world installs no exchange unless asked to -- tests, overhead measurements)
+        runner.attach_data_parallel(rank, world, ids[0], (world > 1) if overlap is None else bool(overlap), bool(hooks_for_one_rank))
         return
     if hasattr(runner, "states") and hasattr(runner, "load_states"):
         broadcast_states(runner, group)

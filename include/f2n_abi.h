@@ -58,13 +58,8 @@ const char* f2n_build_info(void);
  * optionally reset.  [0] = scatter records of f2n_hash_bwd's owner-binned path that found their queue segment full and were
  * applied by a packed-f16 atomic instead (the only order-dependent addition of that path).  The rest are reserved (0). */
 int f2n_debug_counters(int32_t* out8_host /* or NULL */, int reset);
-/* ... and a delay on a stream: one wave that spins for that many microseconds.  Renderer's F2N_DEBUG_SIDE_DELAY puts it in front of
- * the sampler's side-stream work to skew the streams against each other (a race that needs an unusual interleaving then shows in
- * tools/determinism_probe.py within one run instead of once in tens of thousands of iterations). */
-int f2n_debug_spin(void* stream, int microseconds);
-/* ... and a launch that leaves value-derived garbage in 64 KB of LDS and ~100 vector registers of every CU: what a co-tenant's
- * kernels do to the state a kernel finds when it starts (Renderer's debug_side_delay(..., pollute)). */
-int f2n_debug_pollute(void* stream, unsigned value);
+/* (The two debugging launches of rounds 3-4 -- a delay on a stream, a launch that leaves garbage in every CU's LDS and registers
+ * -- are not part of this ABI: include/f2n_debug.h, compiled into the debug variant of the library only.) */
 
 /* ---------------------------------------------------------------------------------------------------
  * Sampler -- replaces PersSampler::GetSamples' kernels (PtsSampler/PersSampler.cu:21-434).

@@ -38,15 +38,34 @@ def test_reference_numerics_variant_exports_the_same_abi():
     ref = ctypes.CDLL(build.build_hip(variant="refnum"))
     missing = [n for n in declared() if not hasattr(ref, n)]
     assert not missing, missing
-    assert ref.f2n_numerics_mode() == 1 and ref.f2n_abi_version() == 10
+    assert ref.f2n_numerics_mode() == 1 and ref.f2n_abi_version() == 11
     ref.f2n_build_info.restype = ctypes.c_char_p
     assert b"REFERENCE-NUMERICS" in ref.f2n_build_info()
     assert os.path.exists(build.host_module_path("refnum")) or True  # (built by __graft_entry__.build())
 
 
+def test_debug_variant_is_the_product_abi_plus_the_debugging_launches(lib):
+    """libf2n_hip_debug.so (-DF2N_DEBUG_BUILD=1) exports the product ABI plus include/f2n_debug.h; the product library exports none of
+    the debugging launches and contains no getenv call (round-4 verdict, weak 11: debug entry points and environment knobs in the
+    product)."""
+    import subprocess
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import build
+    dbg = ctypes.CDLL(build.build_hip(variant="debug"))
+    assert not [n for n in declared() if not hasattr(dbg, n)]
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "f2n_debug.h")).read(), flags=re.S)
+    extra = sorted(set(re.findall(r"\b(f2n_[a-z0-9_]+)\s*\(", txt)))
+    assert extra == ["f2n_debug_pollute", "f2n_debug_spin"]
+    for n in extra:
+        assert hasattr(dbg, n) and not hasattr(lib, n), n
+    syms = subprocess.run(["nm", "-D", "--undefined-only", build.lib_path("")], capture_output=True, text=True).stdout
+    assert "getenv" not in syms, "the product library reads the environment"
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", build.lib_path("debug")], capture_output=True, text=True).stdout
+
+
 def test_host_only_queries(lib):
     assert lib.f2n_numerics_mode() == 0
-    assert lib.f2n_abi_version() == 10
+    assert lib.f2n_abi_version() == 11
     lib.f2n_build_info.restype = ctypes.c_char_p
     assert b"gfx950" in lib.f2n_build_info()
     assert lib.f2n_mlp_n_params(32, 64, 1) == 3072      # field MLP, SURVEY 8(a) a12
@@ -105,4 +124,4 @@ def test_binding_and_host_extension_refuse_a_library_of_another_abi_version():
     both check f2n_abi_version() when they load."""
     import f2_nerf_amd  # noqa: F401
     from f2_nerf_amd import capi, runtime
-    assert capi.ABI_VERSION == capi.lib().f2n_abi_version() == runtime.host().abi_version == 10
+    assert capi.ABI_VERSION == capi.lib().f2n_abi_version() == runtime.host().abi_version == 11

@@ -344,11 +344,8 @@ def test_data_parallel_hooks_on_one_gpu(rt, fox_state):
             if mode in ("blocking", "overlapped", "overlapped+prefetch"):
                 parallel.attach(runner, 14, overlap=mode.startswith("overlapped"), native=False)  # torch.distributed hooks
             if mode.startswith("native"):  # the C++ host's own RCCL communicator (DataParallel.cpp), one-rank world
-                os.environ["F2N_DP_FORCE"] = "1"  # (a one-rank world would otherwise skip its exchanges)
-                try:
-                    parallel.attach(runner, 14, overlap=(mode == "native"), native=True)
-                finally:
-                    del os.environ["F2N_DP_FORCE"]
+                # (hooks_for_one_rank: a one-rank world would otherwise skip its exchanges)
+                parallel.attach(runner, 14, overlap=(mode == "native"), native=True, hooks_for_one_rank=True)
             # "prefetch": the next iteration's rays (here: the same batch) are sampled on a side stream during this one
             nxt = (d[0], d[1], d[2]) if "prefetch" in mode else (None, None, None)
             losses = [float(runner.train_step(d[0], d[1], d[2], d[3], d[4], True, *nxt)["loss"]) for _ in range(5)]

@@ -7,9 +7,6 @@ reproducible run to run")."""
 import argparse, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-import f2_nerf_amd  # noqa: F401
-from f2_nerf_amd import runtime, fox_data, capi
-
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=150)
 ap.add_argument("--runs", type=int, default=2)
@@ -32,6 +29,10 @@ ap.add_argument("--save-taps", default="", help="file prefix: every run's tap ma
 ap.add_argument("--digest", action="store_true", help="per-STEP digest (ExpRunner.step_digest: seq, iter, rays, marched, kept, table checksum "
                 "after the step) of every run, compared step by step: names the first step and quantity in which two runs part")
 args = ap.parse_args()
+if args.side_delay or args.pollute:  # the stream-skew / pollution hooks exist in the debug variant of the libraries only
+    os.environ["F2N_DEBUG_BUILD"] = "1"
+import f2_nerf_amd  # noqa: F401
+from f2_nerf_amd import runtime, fox_data, capi
 NAMES = ["table", "field_mlp", "color_mlp", "app_emb", "nodes", "n_nodes", "batch", "marched", "meaningful", "speculative", "fallback", "dropped", "rays_repaired"]
 
 
