@@ -859,26 +859,40 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   };
   // Eight segments at a time, the first 256 records of each with FOUR coalesced 8-byte loads per lane, all 32 of them issued
   // before any record is added: a segment holds ~150 records at the 2.6e5 samples of an ExpRunner::Train batch, so two rounds left
-  // most segments to the "rest" loop below (one dependent fabric round trip per segment and 64 records).  (Measured: the kernel's
-  // time is the volume of these reads -- 76 us with them, 13 us without, the LDS adds hidden underneath -- not their scheduling:
-  // profiles/r04_pipeline_experiments.txt item 7.)
-  for (int sg = 0; sg < nb / 2; sg += 8) {
+  // most segments to the "rest" loop below (one dependent fabric round trip per segment and 64 records).  Round 5: the rounds are
+  // software-pipelined -- the 32 loads of round k + 1 are in flight while the 64 LDS adds per lane of round k run (the kernel was a
+  // chain of load round trip -> adds -> load round trip: 96 us for 2.4e5 samples' records alone on the GPU against ~46 us of LDS
+  // atomic issue, profiles/r05_scatter.txt).  Sums are exact in fp64 whatever the order: the table is bit-identical.
+  struct Round {
     uint2 rec[32];
     int cnt[8];
     const uint2* r[8];
+  };
+  auto load_round = [&](int sg, Round& o) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      cnt[u] = __shfl(my_cnt, sg + u);
+      o.cnt[u] = __shfl(my_cnt, sg + u);
       const unsigned long long sidx = __shfl((unsigned long long) my_seg, sg + u);
-      r[u] = q.rec + sidx * cap_nb;
+      o.r[u] = q.rec + sidx * cap_nb;
 #pragma unroll
-      for (int k = 0; k < 4; k++) rec[4 * u + k] = lane + 64 * k < cnt[u] ? r[u][lane + 64 * k] : uint2{0u, 0u};
+      for (int k = 0; k < 4; k++) o.rec[4 * u + k] = lane + 64 * k < o.cnt[u] ? o.r[u][lane + 64 * k] : uint2{0u, 0u};
     }
+  };
+  auto add_round = [&](const Round& o) {
 #pragma unroll
-    for (int u = 0; u < 32; u++) add(rec[u]);
+    for (int u = 0; u < 32; u++) add(o.rec[u]);
 #pragma unroll
     for (int u = 0; u < 8; u++)  // long segments: the rest
-      for (int i = lane + 256; i < cnt[u]; i += 64) add(r[u][i]);
+      for (int i = lane + 256; i < o.cnt[u]; i += 64) add(o.r[u][i]);
+  };
+  const int n_rounds = nb / 16;  // nb / 2 segments per wave, eight per round: 2, 4 or 8 rounds
+  Round ra, rb;
+  load_round(0, ra);
+  for (int rd = 0; rd < n_rounds; rd += 2) {
+    load_round(8 * (rd + 1), rb);  // (n_rounds is even)
+    add_round(ra);
+    if (rd + 2 < n_rounds) load_round(8 * (rd + 2), ra);
+    add_round(rb);
   }
   __syncthreads();
   half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;

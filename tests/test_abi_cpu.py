@@ -55,7 +55,7 @@ def test_debug_variant_is_the_product_abi_plus_the_debugging_launches(lib):
     assert not [n for n in declared() if not hasattr(dbg, n)]
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "f2n_debug.h")).read(), flags=re.S)
     extra = sorted(set(re.findall(r"\b(f2n_[a-z0-9_]+)\s*\(", txt)))
-    assert extra == ["f2n_debug_pollute", "f2n_debug_spin"]
+    assert extra == ["f2n_debug_composite_train_colors_in", "f2n_debug_pollute", "f2n_debug_spin"]
     for n in extra:
         assert hasattr(dbg, n) and not hasattr(lib, n), n
     syms = subprocess.run(["nm", "-D", "--undefined-only", build.lib_path("")], capture_output=True, text=True).stdout
