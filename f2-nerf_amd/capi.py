@@ -103,6 +103,13 @@ def sampler_prologue(n, dirs, out, zero=None, u=None, fineness=0.0, noise_out=No
                                    _f(fineness), _p(noise_out, "f32", True)), "f2n_sampler_prologue")
 
 
+def sampler_prologue_keyed(n, dirs, out, zero, n_noise, key, seq, fineness, noise_out):
+    """f2n_sampler_prologue with the march noise drawn by the launch (Philox4x32-10 keyed by (key, seq): include/f2n_abi.h)."""
+    _ck(lib().f2n_sampler_prologue_keyed(_stream(), _i(n), _p(dirs, "f32"), _p(out, "f32"), _p(zero, "i32", True),
+                                         _i(0 if zero is None else zero.numel()), _i(n_noise), ctypes.c_uint64(int(key) & (2 ** 64 - 1)),
+                                         ctypes.c_uint64(int(seq) & (2 ** 64 - 1)), _f(fineness), _p(noise_out, "f32")), "f2n_sampler_prologue_keyed")
+
+
 def edge_samples_ex(n, edge_pool, n_edges, transes, edge_idx, edge_coords, u01, out_pts, out_idx, idx_stride, out_pts2=None,
                     out_idx2=None, idx_stride2=1):
     _ck(lib().f2n_edge_samples_ex(_stream(), _i(n), _p(edge_pool, "u8"), _i(n_edges), _p(transes, "u8"), _p(edge_idx, "i32", True),

@@ -90,7 +90,8 @@ __global__ void gather_pixels_kernel(int n_rays, int height, int width, const fl
 // ray is generated (img2world_kernel's arithmetic) and the ground-truth colour / bounds gathered.  The ATen spelling -- three
 // randint, an index, a stack, then the two kernels above -- was eight dependent launches on the training step's main queue,
 // once per iteration.
-__global__ void draw_ray_batch_kernel(int n_rays, const float* __restrict__ u01, const int32_t* __restrict__ image_set, int n_set,
+__global__ void draw_ray_batch_kernel(int n_rays, const float* __restrict__ u01, unsigned long long key, unsigned long long seq,
+                                      const int32_t* __restrict__ image_set, int n_set,
                                       int height, int width, const float* __restrict__ poses, const float* __restrict__ intri,
                                       const float* __restrict__ dist, const float* __restrict__ images,
                                       const float* __restrict__ cam_bounds, int32_t* __restrict__ cam_idx, int32_t* __restrict__ ij,
@@ -98,9 +99,17 @@ __global__ void draw_ray_batch_kernel(int n_rays, const float* __restrict__ u01,
                                       float* __restrict__ bounds) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rays) return;
-  const int c = image_set[min((int) (u01[3 * (size_t) r] * (float) n_set), n_set - 1)];
-  const int pi = min((int) (u01[3 * (size_t) r + 1] * (float) height), height - 1);
-  const int pj = min((int) (u01[3 * (size_t) r + 2] * (float) width), width - 1);
+  float u3[3];
+  if (u01 != nullptr) {
+    u3[0] = u01[3 * (size_t) r]; u3[1] = u01[3 * (size_t) r + 1]; u3[2] = u01[3 * (size_t) r + 2];
+  } else {  // keyed: ray r of batch `seq` draws its own three uniforms (no rand launch in front of this kernel)
+    uint32_t x[4];
+    f2n_philox4x32((uint32_t) r, 0u, (uint32_t) seq, (uint32_t) (seq >> 32), (uint32_t) key, (uint32_t) (key >> 32), x);
+    u3[0] = f2n_u01(x[0]); u3[1] = f2n_u01(x[1]); u3[2] = f2n_u01(x[2]);
+  }
+  const int c = image_set[min((int) (u3[0] * (float) n_set), n_set - 1)];
+  const int pi = min((int) (u3[1] * (float) height), height - 1);
+  const int pj = min((int) (u3[2] * (float) width), width - 1);
   cam_idx[r] = c;
   ij[2 * r] = pi;
   ij[2 * r + 1] = pj;
@@ -132,12 +141,24 @@ extern "C" {
 int f2n_draw_ray_batch(void* stream, int n_rays, const float* u01, const int32_t* image_set, int n_set, int height, int width,
                        const float* poses, const float* intri, const float* dist_params, const float* images, const float* cam_bounds,
                        int32_t* cam_indices, int32_t* ij, float* rays_o, float* rays_d, float* gt_colors, float* bounds) {
+  if (n_rays < 0 || n_set < 1 || height <= 0 || width <= 0 || (gt_colors != nullptr && images == nullptr) || cam_bounds == nullptr || u01 == nullptr)
+    return F2N_ERR_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  hipLaunchKernelGGL(draw_ray_batch_kernel, dim3(f2n_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t) stream, n_rays, u01, 0ull, 0ull, image_set,
+                     n_set, height, width, poses, intri, dist_params, images, cam_bounds, cam_indices, ij, rays_o, rays_d, gt_colors,
+                     bounds);
+  return f2n_launch_status();
+}
+
+int f2n_draw_ray_batch_keyed(void* stream, int n_rays, uint64_t key, uint64_t seq, const int32_t* image_set, int n_set, int height, int width,
+                             const float* poses, const float* intri, const float* dist_params, const float* images, const float* cam_bounds,
+                             int32_t* cam_indices, int32_t* ij, float* rays_o, float* rays_d, float* gt_colors, float* bounds) {
   if (n_rays < 0 || n_set < 1 || height <= 0 || width <= 0 || (gt_colors != nullptr && images == nullptr) || cam_bounds == nullptr)
     return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
-  hipLaunchKernelGGL(draw_ray_batch_kernel, dim3(f2n_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t) stream, n_rays, u01, image_set,
-                     n_set, height, width, poses, intri, dist_params, images, cam_bounds, cam_indices, ij, rays_o, rays_d, gt_colors,
-                     bounds);
+  hipLaunchKernelGGL(draw_ray_batch_kernel, dim3(f2n_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t) stream, n_rays, (const float*) nullptr,
+                     (unsigned long long) key, (unsigned long long) seq, image_set, n_set, height, width, poses, intri, dist_params, images,
+                     cam_bounds, cam_indices, ij, rays_o, rays_d, gt_colors, bounds);
   return f2n_launch_status();
 }
 

@@ -86,6 +86,23 @@ static inline unsigned f2n_div_up(long a, long b) { return (unsigned) ((a + b - 
 // workspace.hip: internal per-device scratch + the partial-sum reduction used by the backward kernels
 void* f2n_ws_get(int slot, size_t bytes);
 int f2n_reduce_partials(void* stream, int n, int n_blocks, const float* partials, float* out);
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11): the counter-based generator
+// behind the keyed draws of the host (host/KeyedDraws.h) where a kernel makes its own uniforms instead of reading a rand launch's
+// output: key = (seed ^ purpose), counter = (element / 4, 0, sequence number).
+__device__ __forceinline__ void f2n_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float f2n_u01(uint32_t x) { return (float) (x >> 8) * (1.f / 16777216.f); }  // 24 bits: [0, 1)
+
 int f2n_defer_reduction(int n, int n_blocks, const float* partials, float* out);  // folded later by f2n_reduce_deferred
 #define F2N_WS_FIELD_DW 0
 #define F2N_WS_SHADE_DW 1

@@ -218,11 +218,11 @@ std::tuple<BoundedRays, Tensor, Tensor> Dataset::RandRaysData(int batch_size, in
   const Tensor& cur_set = it->second;
   // every draw on the device: uniform image of the set, uniform pixel (Dataset.cpp:286-291) -- one uniform launch and ONE kernel
   // that maps the draws, generates the rays and gathers colours and bounds (f2n_draw_ray_batch)
-  Tensor u = ray_draws_.Draw((int64_t) batch_size * 3, seq).view({batch_size, 3});
   Tensor cam = torch::empty({batch_size}, DevI32()), ij = torch::empty({batch_size, 2}, DevI32());
   Tensor rays_o = torch::empty({batch_size, 3}, DevF32()), rays_d = torch::empty({batch_size, 3}, DevF32());
   Tensor colors = torch::empty({batch_size, 3}, DevF32()), b = torch::empty({batch_size, 2}, DevF32());
-  F2N_CALL(f2n_draw_ray_batch(CurStream(), batch_size, F32P(u), I32P(cur_set), (int) cur_set.size(0), height_, width_, F32P(poses_),
+  const auto key = ray_draws_.KeyFor(seq);  // (the kernel draws its own three uniforms per ray: no rand launch on the step's main queue)
+  F2N_CALL(f2n_draw_ray_batch_keyed(CurStream(), batch_size, key.key, key.seq, I32P(cur_set), (int) cur_set.size(0), height_, width_, F32P(poses_),
                               F32P(intri_), F32P(dist_params_), image_tensors_.defined() ? F32P(image_tensors_) : nullptr, F32P(bounds_),
                               I32P(cam), I32P(ij), F32P(rays_o), F32P(rays_d), image_tensors_.defined() ? F32P(colors) : nullptr, F32P(b)));
   last_cam_indices_ = cam;

@@ -36,12 +36,28 @@ class KeyedUniforms {
     gen_.set_offset(s * kStride);
     return torch::rand({n}, gen_, DevF32());
   }
+  // The same key without a draw: {seed ^ purpose, sequence number} for kernels that make their own uniforms (Philox4x32-10 in
+  // csrc/f2n_dev.h: f2n_draw_ray_batch_keyed, f2n_sampler_prologue_keyed) -- one launch less than rand + consumer.
+  struct Key {
+    uint64_t key, seq;
+  };
+  Key KeyFor(int64_t seq) {
+    const int dev = c10::hip::current_device();
+    const uint64_t seed = at::cuda::detail::getDefaultCUDAGenerator(dev).current_seed();
+    if (!keyed_ || seed != key_seed_) {
+      key_seed_ = seed;
+      keyed_ = true;
+      own_seq_ = 0;
+    }
+    return {seed ^ purpose_, seq >= 0 ? (uint64_t) seq : (uint64_t) (kOwnBase + own_seq_++)};
+  }
   void Rewind() { own_seq_ = 0; }
 
  private:
   uint64_t purpose_;
   at::Generator gen_;
-  uint64_t seed_ = 0;
+  uint64_t seed_ = 0, key_seed_ = 0;
+  bool keyed_ = false;
   int64_t own_seq_ = 0;
 };
 

@@ -147,12 +147,17 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
     // however far ahead of its step it is sampled (one or two steps, speculatively or behind the stat update: Renderer.h) and
     // however often (a prefetched batch that is dropped and sampled again draws the SAME numbers, not the next ones).
     if (seq < 0) seq = keyed;
-    rays_noise = noise_draws_.Draw(n_noise, seq);
+    rays_noise = torch::empty({n_noise}, DevF32());  // (drawn by the prologue launch itself: Philox keyed by (seed, purpose, seq))
     map_noise = true;
   }
-  // unit directions, zeroed totals and the noise map: one launch
-  F2N_CALL(f2n_sampler_prologue(st, n_rays, F32P(rays_d_in), F32P(rays_d), I32P(totals), 3, map_noise ? n_noise : 0,
-                                map_noise ? F32P(rays_noise) : nullptr, fineness, map_noise ? F32P(rays_noise) : nullptr));
+  // unit directions, zeroed totals and the march noise: one launch
+  if (map_noise) {
+    const auto key = noise_draws_.KeyFor(seq);
+    F2N_CALL(f2n_sampler_prologue_keyed(st, n_rays, F32P(rays_d_in), F32P(rays_d), I32P(totals), 3, n_noise, key.key, key.seq, fineness,
+                                        F32P(rays_noise)));
+  } else {
+    F2N_CALL(f2n_sampler_prologue(st, n_rays, F32P(rays_d_in), F32P(rays_d), I32P(totals), 3, 0, nullptr, fineness, nullptr));
+  }
   const float far = 1e8f;  // the `bounds` argument is ignored by the reference too (:322-323)
 
   Tensor counts = torch::empty({n_rays}, DevI32());
@@ -415,7 +420,7 @@ void PersSampler::EarlyStopAndVote(const SampleResultFlex& sample_result, const 
 
 // Everything of UpdateOctNodes behind the votes: the data-parallel exchange, the stat update (:579-593, MarkInvalidNodes
 // :528-534) and the octree maintenance that is due (:605-614).
-void PersSampler::FinishOctUpdate() {
+void PersSampler::FinishOctUpdate(const ScanArgs* scan) {
   auto& oct = *pers_octree_;
   const int n_nodes = oct.n_nodes_;
   Tensor& occ = oct.occ_;
@@ -423,10 +428,18 @@ void PersSampler::FinishOctUpdate() {
   if (occupancy_sync_hook_) occupancy_sync_hook_(occ);
   Tensor adders = occ.slice(0, 0, 2), visit_mark = occ.select(0, 2);
   oct.epoch_++;  // (deaths of this update are stamped with it: speculative samplers repair against them)
-  F2N_TIMED_CALL("oct_update_stats", f2n_oct_update_stats_ex(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
-                                I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
-                                VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1, I32P(oct.died_at_), oct.epoch_, I32P(oct.death_epoch_),
-                                oct.death_epoch_host_dev_));
+  if (scan != nullptr) {
+    F2N_TIMED_CALL("oct_update_stats", f2n_oct_update_stats_scan(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
+                                  I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
+                                  VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1, I32P(oct.died_at_), oct.epoch_, I32P(oct.death_epoch_),
+                                  oct.death_epoch_host_dev_, scan->n, scan->counts, scan->start_end, scan->total, scan->mirror, scan->also,
+                                  scan->n_also));
+  } else {
+    F2N_TIMED_CALL("oct_update_stats", f2n_oct_update_stats_ex(st, n_nodes, I32P(adders), I32P(adders) + n_nodes, I32P(visit_mark),
+                                  I32P(oct.tree_weight_stats_), I32P(oct.tree_alpha_stats_), VoidP(oct.tree_nodes_gpu_),
+                                  VoidP(oct.child_blocks_gpu_), /*reset_votes=*/1, I32P(oct.died_at_), oct.epoch_, I32P(oct.death_epoch_),
+                                  oct.death_epoch_host_dev_));
+  }
 
   while (!sub_div_milestones_.empty() && sub_div_milestones_.back() <= global_data_pool_->iter_step_) {  // :605-610
     oct.ProcOctree(true, true, sub_div_milestones_.back() <= 0);

@@ -142,7 +142,15 @@ class PersSampler : public PtsSampler {
   // UpdateOctNodes split for the training step: early stop + votes in one launch, then the rest (exchange, stats, maintenance)
   void EarlyStopAndVote(const SampleResultFlex& sample_result, const float* f0, Tensor& weights, Tensor& alphas, Tensor& mask,
                         Tensor& kept);
-  void FinishOctUpdate();
+  // scan (optional): the survivor scan of the same step rides in the stat update's launch (f2n_oct_update_stats_scan)
+  struct ScanArgs {
+    int n = 0;
+    const int32_t* counts = nullptr;
+    int32_t *start_end = nullptr, *total = nullptr, *mirror = nullptr;
+    const int32_t* also = nullptr;
+    int n_also = 0;
+  };
+  void FinishOctUpdate(const ScanArgs* scan = nullptr);
   Tensor& VoteBuffer();
   // [K, N] of the sampling calls in flight, written by the scan kernel itself (MappedHost.h); eight rotating pairs: up to
   // Renderer::kPendingSlots prefetched batches and one synchronous GetSamples hold a pair each, a dropped batch's kernels are

@@ -767,18 +767,32 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
         f();
       }
     };
+    Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::empty({1}, DevI32());
+    n_kept_words_.Ensure(2);  // [0] data-parallel: the previous step's count summed over the ranks; [1] this step's count
+    bool scan_issued = false;
     if (octree_first) {
-      ps->FinishOctUpdate();
+      // the survivor scan rides in the stat update's launch (f2n_oct_update_stats_scan: one dependent launch less on the main queue)
+      PersSampler::ScanArgs sa;
+      sa.n = n_rays; sa.counts = I32P(kept); sa.start_end = I32P(new_se); sa.total = I32P(total);
+      if (train && dp_world_ > 1 && dp_count_.defined()) {  // (see below: the ranks' sum of the previous count, dropped into word 0)
+        sa.mirror = n_kept_words_.Dev(0); sa.also = I32P(dp_count_); sa.n_also = 1;
+        dp_sum_mirrored_ = true;
+        dp_sum_rays_ = dp_count_rays_;
+      } else {
+        sa.mirror = n_kept_words_.Dev(1);
+      }
+      ps->FinishOctUpdate(&sa);
+      scan_issued = true;
       octree_update_issued();
     }
-    Tensor new_se = torch::empty({n_rays, 2}, DevI32()), total = torch::empty({1}, DevI32());
     // Second (and last) host read-back of a Render call: M, the number of surviving samples.  The scan writes it to mapped
     // host memory as well (FilterIdxBounds, Renderer.cu:20-50); the host reads it behind an event, not a stream drain, so that
     // the work below that does not depend on M (the occupancy update, the edge samples) is already queued and runs while the
     // host wakes up -- and no copy launch sits between the scan and the compaction.
-    n_kept_words_.Ensure(2);  // [0] data-parallel: the previous step's count summed over the ranks; [1] this step's count
     const bool dp_lagged = train && dp_world_ > 1 && octree_first;
-    if (dp_lagged && dp_count_.defined()) {
+    if (scan_issued) {
+      // (issued with the stat update above)
+    } else if (dp_lagged && dp_count_.defined()) {
       // (dp_count_ went through this step's occupancy exchange a moment ago: it now holds the ranks' sum of the previous count)
       F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(kept), I32P(new_se), I32P(total), n_kept_words_.Dev(0), I32P(dp_count_), 1));
       dp_sum_mirrored_ = true;

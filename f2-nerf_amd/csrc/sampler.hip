@@ -319,10 +319,9 @@ __global__ __launch_bounds__(256) void oct_intersect_coop_kernel(
 // ---------------------------------------------------------------------------------------------------
 #define F2N_SCAN_THREADS 1024
 #define F2N_SCAN_ITEMS 4
-__global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, const int32_t* __restrict__ counts,
-                                                                        int32_t* __restrict__ start_end,
-                                                                        int32_t* __restrict__ total, int32_t* __restrict__ mirror,
-                                                                        const int32_t* __restrict__ also, int n_also) {
+__device__ __forceinline__ void f2n_segment_scan_block(int n, const int32_t* __restrict__ counts, int32_t* __restrict__ start_end,
+                                                       int32_t* __restrict__ total, int32_t* __restrict__ mirror,
+                                                       const int32_t* __restrict__ also, int n_also) {
   __shared__ int s_wave[F2N_SCAN_THREADS / F2N_WAVE];
   __shared__ int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,6 +368,13 @@ __global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, c
       mirror[n_also] = s_carry;
     }
   }
+}
+
+__global__ __launch_bounds__(F2N_SCAN_THREADS) void segment_scan_kernel(int n, const int32_t* __restrict__ counts,
+                                                                        int32_t* __restrict__ start_end,
+                                                                        int32_t* __restrict__ total, int32_t* __restrict__ mirror,
+                                                                        const int32_t* __restrict__ also, int n_also) {
+  f2n_segment_scan_block(n, counts, start_end, total, mirror, also, n_also);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -841,10 +847,21 @@ __global__ void normalize_dirs_kernel(int n, const float* __restrict__ in, float
 // totals the intersection and the scan add into, and the affine map of the march noise (PersSampler.cu:372-381).  They were
 // three dependent launches at the head of the sampler chain, which is the longer chain of a converged training step.
 __global__ void sampler_prologue_kernel(int n_rays, const float* __restrict__ in, float* __restrict__ out, int32_t* __restrict__ zero,
-                                        int n_zero, int n_noise, const float* u, float fineness, float* noise_out /*may be u*/) {
+                                        int n_zero, int n_noise, const float* u, float fineness, float* noise_out /*may be u*/,
+                                        unsigned long long key, unsigned long long seq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_zero) zero[i] = 0;
-  if (i < n_noise) noise_out[i] = ((u[i] - .5f) + 1.f) * fineness;
+  if (i < n_noise) {
+    float ui;
+    if (u != nullptr) {
+      ui = u[i];
+    } else {  // keyed: element i of batch `seq`'s march noise, drawn here (no rand launch at the head of the sampler chain)
+      uint32_t x[4];
+      f2n_philox4x32((uint32_t) (i >> 2), 0u, (uint32_t) seq, (uint32_t) (seq >> 32), (uint32_t) key, (uint32_t) (key >> 32), x);
+      ui = f2n_u01(x[i & 3]);
+    }
+    noise_out[i] = ((ui - .5f) + 1.f) * fineness;
+  }
   if (i >= n_rays) return;
   const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
   const float nrm = sqrtf((x * x + y * y) + z * z);
@@ -1098,12 +1115,29 @@ __global__ void early_stop_votes_kernel(int n_rays, int n_nodes, const int32_t* 
 }
 
 // PersSampler.cu:579-593 (torch integer ops) + MarkInvalidNodes (:528-534), one node per lane.
-__global__ void update_stats_kernel(int n_nodes, int32_t* __restrict__ w_adder, int32_t* __restrict__ a_adder,
-                                    int32_t* __restrict__ mark, int32_t* __restrict__ w_stats,
-                                    int32_t* __restrict__ a_stats, F2nTreeNode* __restrict__ nodes,
-                                    F2nChildInfo* __restrict__ child_blocks, int reset_votes, int32_t* __restrict__ died_at,
-                                    int epoch, int32_t* __restrict__ death_epoch, int32_t* __restrict__ death_epoch_host) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+struct F2nStatsArgs {
+  int n_nodes;
+  int32_t *w_adder, *a_adder, *mark, *w_stats, *a_stats;
+  F2nTreeNode* nodes;
+  F2nChildInfo* child_blocks;
+  int reset_votes;
+  int32_t* died_at;
+  int epoch;
+  int32_t *death_epoch, *death_epoch_host;
+};
+
+__device__ __forceinline__ void f2n_update_stats_node(int i, const F2nStatsArgs& a) {
+  int32_t* __restrict__ w_adder = a.w_adder;
+  int32_t* __restrict__ a_adder = a.a_adder;
+  int32_t* __restrict__ mark = a.mark;
+  int32_t* __restrict__ w_stats = a.w_stats;
+  int32_t* __restrict__ a_stats = a.a_stats;
+  F2nTreeNode* __restrict__ nodes = a.nodes;
+  F2nChildInfo* __restrict__ child_blocks = a.child_blocks;
+  int32_t* __restrict__ died_at = a.died_at;
+  int32_t* __restrict__ death_epoch = a.death_epoch;
+  int32_t* __restrict__ death_epoch_host = a.death_epoch_host;
+  const int reset_votes = a.reset_votes, epoch = a.epoch, n_nodes = a.n_nodes;
   if (i >= n_nodes) return;
   const int m = mark[i];
   int st[2];
@@ -1138,6 +1172,19 @@ __global__ void update_stats_kernel(int n_nodes, int32_t* __restrict__ w_adder, 
         if (nodes[pa].childs[c] == i) child_blocks[(size_t) pa * 8 + c].trans_idx = -1;
     }
   }
+}
+
+__global__ void update_stats_kernel(F2nStatsArgs a) { f2n_update_stats_node(blockIdx.x * blockDim.x + threadIdx.x, a); }
+
+// The stat update and the survivor scan of a streaming training step in ONE launch (round 5, launch floor): they are independent --
+// one lane per node, and one block scanning the rays' kept counts -- and sat on the step's main queue as two dependent launches
+// behind the early stop.  Block 0 scans (FilterIdxBounds, Renderer.cu:20-50); the blocks behind it take 1024 nodes each.
+__global__ __launch_bounds__(F2N_SCAN_THREADS) void stats_and_scan_kernel(F2nStatsArgs a, int n, const int32_t* __restrict__ counts,
+                                                                          int32_t* __restrict__ start_end, int32_t* __restrict__ total,
+                                                                          int32_t* __restrict__ mirror, const int32_t* __restrict__ also,
+                                                                          int n_also) {
+  if (blockIdx.x == 0) f2n_segment_scan_block(n, counts, start_end, total, mirror, also, n_also);
+  else f2n_update_stats_node((blockIdx.x - 1) * F2N_SCAN_THREADS + threadIdx.x, a);
 }
 
 // child_blocks[u][c] <- what the DFS needs to know about child slot c of node u
@@ -1295,7 +1342,16 @@ int f2n_sampler_prologue(void* stream, int n_rays, const float* dirs, float* out
   const int n = n_rays > n_noise ? (n_rays > n_zero ? n_rays : n_zero) : (n_noise > n_zero ? n_noise : n_zero);
   if (n == 0) return F2N_OK;
   hipLaunchKernelGGL(sampler_prologue_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n_rays, dirs, out, zero,
-                     n_zero, n_noise, u, fineness, noise_out);
+                     n_zero, n_noise, u, fineness, noise_out, 0ull, 0ull);
+  return f2n_launch_status();
+}
+
+int f2n_sampler_prologue_keyed(void* stream, int n_rays, const float* dirs, float* out, int32_t* zero, int n_zero, int n_noise,
+                               uint64_t key, uint64_t seq, float fineness, float* noise_out) {
+  if (n_rays < 0 || n_zero < 0 || n_noise < 1 || (n_zero > 0 && zero == nullptr) || noise_out == nullptr) return F2N_ERR_INVALID_ARG;
+  const int n = n_rays > n_noise ? (n_rays > n_zero ? n_rays : n_zero) : (n_noise > n_zero ? n_noise : n_zero);
+  hipLaunchKernelGGL(sampler_prologue_kernel, dim3(f2n_div_up(n, 256)), dim3(256), 0, (hipStream_t) stream, n_rays, dirs, out, zero,
+                     n_zero, n_noise, (const float*) nullptr, fineness, noise_out, (unsigned long long) key, (unsigned long long) seq);
   return f2n_launch_status();
 }
 
@@ -1613,9 +1669,23 @@ int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t
                             int32_t* death_epoch, int32_t* death_epoch_host) {
   if (n_nodes < 0 || (died_at != nullptr) != (death_epoch != nullptr)) return F2N_ERR_INVALID_ARG;
   if (n_nodes == 0) return F2N_OK;
-  hipLaunchKernelGGL(update_stats_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, n_nodes,
-                     w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks, reset_votes,
-                     died_at, epoch, death_epoch, death_epoch_host);
+  const F2nStatsArgs a = {n_nodes, w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks, reset_votes,
+                          died_at, epoch, death_epoch, death_epoch_host};
+  hipLaunchKernelGGL(update_stats_kernel, dim3(f2n_div_up(n_nodes, 256)), dim3(256), 0, (hipStream_t) stream, a);
+  return f2n_launch_status();
+}
+
+int f2n_oct_update_stats_scan(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
+                              int32_t* a_stats, void* tree_nodes, void* child_blocks, int reset_votes, int32_t* died_at, int epoch,
+                              int32_t* death_epoch, int32_t* death_epoch_host, int n, const int32_t* counts, int32_t* start_end,
+                              int32_t* total, int32_t* mirror, const int32_t* also, int n_also) {
+  if (n_nodes < 0 || (died_at != nullptr) != (death_epoch != nullptr) || n < 0 || n_also < 0 || n_also > 4 ||
+      (n_also > 0 && (also == nullptr || mirror == nullptr)))
+    return F2N_ERR_INVALID_ARG;
+  const F2nStatsArgs a = {n_nodes, w_adder, a_adder, mark, w_stats, a_stats, (F2nTreeNode*) tree_nodes, (F2nChildInfo*) child_blocks, reset_votes,
+                          died_at, epoch, death_epoch, death_epoch_host};
+  hipLaunchKernelGGL(stats_and_scan_kernel, dim3(1 + f2n_div_up(n_nodes, F2N_SCAN_THREADS)), dim3(F2N_SCAN_THREADS), 0, (hipStream_t) stream, a,
+                     n, counts, start_end, total, mirror, also, n_also);
   return f2n_launch_status();
 }
 

@@ -72,6 +72,11 @@ int f2n_normalize_dirs(void* stream, int n, const float* dirs /*[n,3]*/, float* 
  * f2n_march_noise (u -> noise_out, n_noise values; 0: none) in ONE launch: the head of a GetSamples call. */
 int f2n_sampler_prologue(void* stream, int n_rays, const float* dirs, float* out, int32_t* zero, int n_zero, int n_noise,
                          const float* u, float fineness, float* noise_out);
+/* The same with the march noise DRAWN by the launch (round 5): element i of the noise is uniform number i of the batch with sequence
+ * number `seq` under `key` (Philox4x32-10, counter = (i / 4, 0, seq), key = seed ^ purpose: host/KeyedDraws.h) -- a function of what
+ * the draw is for, not of how many draws were made before it -- mapped like f2n_march_noise.  No rand launch in front of the chain. */
+int f2n_sampler_prologue_keyed(void* stream, int n_rays, const float* dirs, float* out, int32_t* zero, int n_zero, int n_noise,
+                               uint64_t key, uint64_t seq, float fineness, float* noise_out /*[n_noise]*/);
 
 /* FindRayOctreeIntersectionKernel<false> (PersSampler.cu:53-152, launched :342-351).
  * rays_d must already be unit length (GetSamples normalises at :319); [near, far] is the global bound the
@@ -238,6 +243,13 @@ int f2n_oct_update_stats_ex(void* stream, int n_nodes, int32_t* w_adder, int32_t
                             int32_t* died_at /*[n_nodes] or NULL*/, int epoch, int32_t* death_epoch /*[1] or NULL*/,
                             int32_t* death_epoch_host /*[1] device-accessible HOST word or NULL: also receives the epoch of a
                             death -- a hint the host may read without synchronising (whether speculating pays right now)*/);
+/* f2n_oct_update_stats_ex and f2n_segment_scan_ex in ONE launch (round 5): the stat update of a streaming training step
+ * (PersSampler.cu:579-593, :528-534) and the scan of the rays' surviving-sample counts (FilterIdxBounds, Renderer.cu:20-50) are
+ * independent and used to be two dependent launches of the step's main queue.  Same results as the two calls. */
+int f2n_oct_update_stats_scan(void* stream, int n_nodes, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* w_stats,
+                              int32_t* a_stats, void* tree_nodes, void* child_blocks, int reset_votes, int32_t* died_at, int epoch,
+                              int32_t* death_epoch, int32_t* death_epoch_host, int n, const int32_t* counts, int32_t* start_end /*[n,2]*/,
+                              int32_t* total /*[1]*/, int32_t* mirror, const int32_t* also, int n_also);
 int f2n_oct_intersect_repair(void* stream, int n_rays, int max_hits, const uint8_t* search_order, const float* rays_o,
                              const float* rays_d, float near_, float far_, const void* tree_nodes, int32_t* oct_start_end,
                              int32_t* oct_idx, float* oct_near_far, int32_t* total, int32_t* oct_trans, const void* child_blocks,
@@ -628,6 +640,12 @@ int f2n_draw_ray_batch(void* stream, int n_rays, const float* u01, const int32_t
                        const float* poses, const float* intri, const float* dist_params, const float* images /*or NULL*/,
                        const float* cam_bounds, int32_t* cam_indices, int32_t* ij, float* rays_o, float* rays_d,
                        float* gt_colors /*or NULL*/, float* bounds);
+/* The same with the three uniforms of ray r drawn by the launch itself: Philox4x32-10, counter = (r, 0, seq), key = seed ^ purpose
+ * (host/KeyedDraws.h): batch `seq` is the same batch whenever, however often and with whatever else in between it is drawn. */
+int f2n_draw_ray_batch_keyed(void* stream, int n_rays, uint64_t key, uint64_t seq, const int32_t* image_set, int n_set, int height,
+                             int width, const float* poses, const float* intri, const float* dist_params, const float* images /*or NULL*/,
+                             const float* cam_bounds, int32_t* cam_indices, int32_t* ij, float* rays_o, float* rays_d,
+                             float* gt_colors /*or NULL*/, float* bounds);
 
 /* ---------------------------------------------------------------------------------------------------
  * Optimiser -- replaces torch::optim::Adam::step over the groups of Hash3DAnchored::OptimParamGroups

@@ -114,3 +114,23 @@ def test_keyed_draws_do_not_depend_on_when_or_how_often_they_are_made(fox_scene)
     # unkeyed calls walk the object's own sequence: consecutive batches differ
     p, q = a.rand_rays_data(512), a.rand_rays_data(512)
     assert not torch.equal(p[1], q[1])
+
+
+def test_in_kernel_draws_are_philox_of_their_key():
+    """The march noise a prologue launch draws for itself is Philox4x32-10 of (key, seq, element) bit for bit (integer work: exact),
+    mapped like PersSampler.cu:372-381: ((u - .5) + 1) * fineness."""
+    from f2_nerf_amd import capi
+    n_rays, n_noise, key, seq, fin = 256, 1024 + 256 + 10, 0x1234567890ABCDEF, (1 << 40) + 7, np.float32(2.5)
+    dirs = torch.randn(n_rays, 3, device="cuda")
+    out, zero, noise = torch.empty_like(dirs), torch.ones(3, dtype=torch.int32, device="cuda"), torch.empty(n_noise, device="cuda")
+    capi.sampler_prologue_keyed(n_rays, dirs, out, zero, n_noise, key, seq, float(fin), noise)
+    i = np.arange(n_noise)
+    ctr = np.stack([i >> 2, np.zeros_like(i), np.full_like(i, seq & 0xFFFFFFFF), np.full_like(i, seq >> 32)], 1).astype(np.uint32)
+    from philox_ref import philox4x32_10
+    x = philox4x32_10(ctr, (key & 0xFFFFFFFF, key >> 32))[i, i & 3]
+    u = (x >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    want = ((u - np.float32(.5)) + np.float32(1.)) * fin
+    got = noise.cpu().numpy()
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    assert int(zero.sum()) == 0 and torch.allclose(out.norm(dim=1), torch.ones(n_rays, device="cuda"), atol=1e-5)
+    assert 0.45 < float(u.mean()) < 0.55 and u.min() >= 0 and u.max() < 1

@@ -262,3 +262,18 @@ def test_bench_reads_the_node_layout_of_the_checkpoint():
     for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"):
         assert bench.NODE_DT.fields[f][1] == octc.NODE_DT.fields[f][1], f
         assert bench.NODE_DT.fields[f][0].itemsize == octc.NODE_DT.fields[f][0].itemsize, f
+
+
+def test_philox_reference_matches_the_published_known_answers():
+    """tests/philox_ref.py (the checker of the kernels' keyed draws: tests/test_gpu_determinism.py) against the known-answer vectors of
+    Random123's Philox4x32-10 (kat_vectors: zero, all-ones and the pi-digit counter / key)."""
+    import numpy as np
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from philox_ref import philox4x32_10
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kats:
+        got = philox4x32_10(np.array([c], np.uint32), k)[0]
+        assert tuple(int(v) for v in got) == want
