@@ -819,13 +819,13 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
 
 __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
                                                                   half_t* __restrict__ grad_table, int n,
-                                                                  const int32_t* __restrict__ n_dev, int n_off) {
+                                                                  const int32_t* __restrict__ n_dev, int n_off, int first_slice) {
   F2N_RAISE_PRIO();
   __shared__ double s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp64 image of this block's table slice
   int& s_total = *(int*) &s_acc[0];              // (the record total lives in the image's first word until the image is zeroed)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // table slice g <- (level l1 = g / H, local slice g - l1*H) and (level l1 - 1, local slice g - l1*H + H)
-  const int H = slices_per_half_level, g = blockIdx.x;
+  const int H = slices_per_half_level, g = first_slice + (int) blockIdx.x;  // (a launch may cover a bucket of the table's slices)
   const int l1 = g / H, b1 = g - l1 * H;
   if (n_dev != nullptr) n = min(n, *n_dev + n_off);
   const int nb = f2n_bin_nb(n, q.nb_force), cap_nb = q.cap * (F2N_BIN_NB / nb);  // the producers' choice (same function of the same count)
@@ -859,40 +859,26 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   };
   // Eight segments at a time, the first 256 records of each with FOUR coalesced 8-byte loads per lane, all 32 of them issued
   // before any record is added: a segment holds ~150 records at the 2.6e5 samples of an ExpRunner::Train batch, so two rounds left
-  // most segments to the "rest" loop below (one dependent fabric round trip per segment and 64 records).  Round 5: the rounds are
-  // software-pipelined -- the 32 loads of round k + 1 are in flight while the 64 LDS adds per lane of round k run (the kernel was a
-  // chain of load round trip -> adds -> load round trip: 96 us for 2.4e5 samples' records alone on the GPU against ~46 us of LDS
-  // atomic issue, profiles/r05_scatter.txt).  Sums are exact in fp64 whatever the order: the table is bit-identical.
-  struct Round {
+  // most segments to the "rest" loop below (one dependent fabric round trip per segment and 64 records).  (Measured: the kernel's
+  // time is the volume of these reads -- 76 us with them, 13 us without, the LDS adds hidden underneath -- not their scheduling:
+  // profiles/r04_pipeline_experiments.txt item 7.)
+  for (int sg = 0; sg < nb / 2; sg += 8) {
     uint2 rec[32];
     int cnt[8];
     const uint2* r[8];
-  };
-  auto load_round = [&](int sg, Round& o) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      o.cnt[u] = __shfl(my_cnt, sg + u);
+      cnt[u] = __shfl(my_cnt, sg + u);
       const unsigned long long sidx = __shfl((unsigned long long) my_seg, sg + u);
-      o.r[u] = q.rec + sidx * cap_nb;
+      r[u] = q.rec + sidx * cap_nb;
 #pragma unroll
-      for (int k = 0; k < 4; k++) o.rec[4 * u + k] = lane + 64 * k < o.cnt[u] ? o.r[u][lane + 64 * k] : uint2{0u, 0u};
+      for (int k = 0; k < 4; k++) rec[4 * u + k] = lane + 64 * k < cnt[u] ? r[u][lane + 64 * k] : uint2{0u, 0u};
     }
-  };
-  auto add_round = [&](const Round& o) {
 #pragma unroll
-    for (int u = 0; u < 32; u++) add(o.rec[u]);
+    for (int u = 0; u < 32; u++) add(rec[u]);
 #pragma unroll
     for (int u = 0; u < 8; u++)  // long segments: the rest
-      for (int i = lane + 256; i < o.cnt[u]; i += 64) add(o.r[u][i]);
-  };
-  const int n_rounds = nb / 16;  // nb / 2 segments per wave, eight per round: 2, 4 or 8 rounds
-  Round ra, rb;
-  load_round(0, ra);
-  for (int rd = 0; rd < n_rounds; rd += 2) {
-    load_round(8 * (rd + 1), rb);  // (n_rounds is even)
-    add_round(ra);
-    if (rd + 2 < n_rounds) load_round(8 * (rd + 2), ra);
-    add_round(rb);
+      for (int i = lane + 256; i < cnt[u]; i += 64) add(r[u][i]);
   }
   __syncthreads();
   half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
@@ -1193,6 +1179,13 @@ static inline bool f2n_mlp_shape_ok(int d_in, int d_hidden, int n_hidden) {
 
 #define F2N_BIN_MIN_N 32768  // below this the direct atomics cost less than the two extra launches
 
+struct F2nBucketHook {
+  f2n_bucket_fn fn;
+  void* user;
+  int n;
+};
+static F2nBucketHook g_bucket_hook[16];
+
 // Owner-binned scatter of f16 gradients gx (pair (l, ch) of sample s at gx[s*ss + (l>>1)*ps + 2*(l&1) + ch]).
 static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const int32_t* local_idx, const int32_t* local_size,
                               const float* level_scale, const float* pts, int warped, const int32_t* volume_idx, int vol_stride,
@@ -1221,7 +1214,23 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
                      level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table, n_dev, n_off);
   const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels
-  hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3((F2N_N_LEVELS + 1) * H), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off);
+  // Data-parallel runs ask for the owner launch in BUCKETS of table slices (f2n_set_scatter_buckets): after each bucket's launch the
+  // host is called back and starts that range's all-reduce while the next bucket's owners still run.
+  const int S = (F2N_N_LEVELS + 1) * H;
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  const F2nBucketHook hook = (dev >= 0 && dev < 16) ? g_bucket_hook[dev] : F2nBucketHook{nullptr, nullptr, 0};
+  if (hook.fn != nullptr && hook.n > 1 && S >= hook.n) {
+    for (int b = 0; b < hook.n; b++) {
+      const int g0 = (int) ((long) b * S / hook.n), g1 = (int) ((long) (b + 1) * S / hook.n);
+      hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3(g1 - g0), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, g0);
+      const int rc = f2n_launch_status();
+      if (rc != F2N_OK) return rc;
+      hook.fn(hook.user, b, hook.n);
+    }
+    return F2N_OK;
+  }
+  hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3(S), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, 0);
   return f2n_launch_status();
 }
 
@@ -1234,6 +1243,13 @@ static inline bool f2n_use_bins(int n, int level_entries) {
 }
 
 extern "C" {
+
+int f2n_set_scatter_buckets(int n_buckets, f2n_bucket_fn fn, void* user) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || n_buckets < 0 || n_buckets > 64) return F2N_ERR_INVALID_ARG;
+  g_bucket_hook[dev] = F2nBucketHook{n_buckets > 1 ? fn : nullptr, user, n_buckets > 1 ? n_buckets : 0};
+  return F2N_OK;
+}
 
 int f2n_debug_counters(int32_t* out8_host, int reset) {
   if (out8_host != nullptr && hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(f2n_dbg_counters), 8 * sizeof(int32_t)) != hipSuccess)

@@ -25,7 +25,29 @@ int DataParallel::CommRanks() const {
 }
 
 DataParallel::~DataParallel() {
+  if (n_buckets_ > 1) (void) f2n_set_scatter_buckets(0, nullptr, nullptr);
   if (comm_ != nullptr) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
+}
+
+// Bucket b of n_buckets_: table slices [b * S / n, (b + 1) * S / n) of 4096 entries = 8192 halves each, S = slices of the active
+// prefix -- the rule of f2n_set_scatter_buckets (include/f2n_abi.h), restated here because the ranks must cut the prefix the same
+// way whether or not their scatter reported anything this step.
+std::pair<int64_t, int64_t> DataParallel::BucketRange(int b) const {
+  const int64_t halves = table_prefix_.numel();
+  if (n_buckets_ <= 1) return {0, halves};
+  const int64_t S = halves / 8192;
+  const int64_t g0 = (int64_t) b * S / n_buckets_, g1 = (int64_t) (b + 1) * S / n_buckets_;
+  return {g0 * 8192, (g1 - g0) * 8192};
+}
+
+void DataParallel::SendBucket(int b) {
+  auto comm = reinterpret_cast<ncclComm_t>(comm_);
+  auto& ev = bucket_ev_[b];
+  ev.record();  // the kernels that complete this range have been queued on the compute stream
+  ev.block(*comm_stream_);
+  const auto r = BucketRange(b);
+  at::Half* base = table_prefix_.data_ptr<at::Half>() + r.first;
+  F2N_NCCL(ncclAllReduce(base, base, (size_t) r.second, ncclHalf, ncclAvg, comm, comm_stream_->stream()));
 }
 
 void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vector<uint8_t>& unique_id, bool overlap,
@@ -51,6 +73,18 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
   auto* field = static_cast<Hash3DAnchored*>(runner->renderer_->scene_field_.get());
   flat_ = runner->FlattenSmallGrads();
   table_prefix_ = field->grad_h_.view({-1}).narrow(0, 0, field->active_halves_);
+  // The table exchange in level-group buckets (round-4 verdict, next 6): the scatter's owner launch is cut into kTableBuckets launches
+  // and reports each finished range (f2n_set_scatter_buckets -> GradSyncPipeline::BucketReady -> SendBucket): the first three
+  // quarters of the 17 MiB travel underneath the rest of the owner kernel instead of behind the step's last kernel.
+  n_buckets_ = (table_prefix_.numel() % 8192 == 0 && table_prefix_.numel() / 8192 >= kTableBuckets) ? kTableBuckets : 1;
+  bucket_ev_.resize(n_buckets_);
+  runner->sync_.bucket = [this](int b, int n) {
+    TORCH_CHECK(n == n_buckets_, "scatter reports ", n, " buckets, the exchange was set up for ", n_buckets_);
+    n_bucket_callbacks_++;
+    SendBucket(b);
+  };
+  if (n_buckets_ > 1)
+    F2N_CALL(f2n_set_scatter_buckets(n_buckets_, [](void* user, int b, int n) { static_cast<DataParallel*>(user)->runner_->sync_.BucketReady(b, n); }, this));
   if (overlap) {
     runner->sync_.begin = [this]() { GradSyncBegin(); };
     runner->sync_.end = [this]() { GradSyncEnd(); };
@@ -90,13 +124,12 @@ void DataParallel::BroadcastStates() {
 
 void DataParallel::GradSyncBegin() {
   auto comm = reinterpret_cast<ncclComm_t>(comm_);
+  // the table buckets the scatter did not report while it ran (all of them for a batch that took the small-batch path or had no
+  // samples): every rank issues n_buckets_ table all-reduces and one for the flat small-gradient buffer per step, in this order
+  for (int b = runner_->sync_.buckets_sent(); b < n_buckets_; b++) SendBucket(b);
   grads_ready_ev_.record();  // backward has been queued on the compute stream
   grads_ready_ev_.block(*comm_stream_);
-  hipStream_t cs = comm_stream_->stream();
-  F2N_NCCL(ncclGroupStart());
-  F2N_NCCL(ncclAllReduce(table_prefix_.data_ptr(), table_prefix_.data_ptr(), (size_t) table_prefix_.numel(), ncclHalf, ncclAvg, comm, cs));
-  F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, cs));
-  F2N_NCCL(ncclGroupEnd());
+  F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, comm_stream_->stream()));
   reduced_ev_.record(*comm_stream_);
 }
 

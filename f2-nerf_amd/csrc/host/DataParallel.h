@@ -38,6 +38,12 @@ class DataParallel {
   int CommRanks() const;            // what RCCL itself reports for the communicator (ncclCommCount)
 
  private:
+  // bucketed table exchange (GradSyncPipeline.h): range b of n of the active table prefix, in halves
+  static constexpr int kTableBuckets = 4;
+  int n_buckets_ = 1;
+  int64_t n_bucket_callbacks_ = 0;  // table ranges the scatter reported while it ran (the rest went with GradSyncBegin)
+  std::pair<int64_t, int64_t> BucketRange(int b) const;
+  void SendBucket(int b);
   void GradSyncBegin();
   void GradSyncEnd();
   void OccupancySync(Tensor occ);
@@ -47,6 +53,7 @@ class DataParallel {
   Tensor table_prefix_, flat_;
   std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> comm_stream_;
   at::cuda::CUDAEvent grads_ready_ev_, reduced_ev_;
+  std::vector<at::cuda::CUDAEvent> bucket_ev_;
 };
 
 }  // namespace f2n

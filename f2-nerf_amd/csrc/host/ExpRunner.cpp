@@ -504,6 +504,7 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
       sync_.begin();
       if (sync_.end) sync_.end();
     }
+    sync_.ResetBuckets();  // (table buckets the taped backward's scatter reported were sent; the rest went with the exchange above)
     if (check_nan_) {  // TCNNWP.cpp:234-240 + ExpRunner.cpp:131-134
       auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
       auto* shader = static_cast<SHShader*>(renderer_->shader_.get());

@@ -8,6 +8,7 @@
 // The reference is single-GPU; the exchanges themselves live in DataParallel.cpp / parallel.py.
 #pragma once
 #include <functional>
+#include <stdexcept>
 
 namespace f2n {
 
@@ -16,6 +17,18 @@ class GradSyncPipeline {
   // the exchange, installed by DataParallel::Attach or the Python hooks (either `blocking` or the `begin` / `end` pair)
   std::function<void()> blocking, begin, end;
   bool pipelined = false;
+  // Bucketed table exchange (round 5): while the backward's last kernels run, the scatter reports the ranges of the gradient table
+  // that are final (f2n_set_scatter_buckets); `bucket` starts range b's all-reduce at once.  Buckets arrive in order, at most once
+  // each, between BeginStep and GradientsReady; `begin` / `blocking` then send whatever was not sent (all of it when the scatter
+  // reported nothing: small batches) -- every rank issues the same sequence of collectives whatever path its scatter took.
+  std::function<void(int bucket, int n_buckets)> bucket;
+  int buckets_sent() const { return buckets_sent_; }
+  void BucketReady(int b, int n) {
+    if (!bucket) return;
+    if (b != buckets_sent_ || b >= n) throw std::logic_error("GradSyncPipeline: gradient bucket out of order");
+    bucket(b, n);
+    buckets_sent_ = b + 1;
+  }
   // what the runner does around it
   std::function<void(bool apply_optimizer, float lr)> apply;  // finiteness flags + predicated Adam: enqueue only
   std::function<void()> defer_flags;                          // start the asynchronous read-back of the flags
@@ -25,7 +38,9 @@ class GradSyncPipeline {
 
   // Top of a step.  `presample` (may be empty) issues this step's ray sampling, which reads neither parameters nor
   // gradients: in pipelined mode it goes first, so that it runs underneath the exchange that is still in flight.
+  void ResetBuckets() { buckets_sent_ = 0; }
   void BeginStep(bool apply_optimizer, const std::function<void()>& presample) {
+    buckets_sent_ = 0;  // (a step that threw behind a bucket must not leave its count behind)
     if (pipelined && apply_optimizer && presample) presample();
     FinishPendingStep();
   }
@@ -33,6 +48,10 @@ class GradSyncPipeline {
   // This step's gradients are in their buffers.  True: exchanged (if there is an exchange) and applied now.  False: the
   // exchange was started and the step is completed by the next BeginStep / FinishPendingStep.
   bool GradientsReady(bool apply_optimizer, float lr) {
+    struct Reset {
+      int& n;
+      ~Reset() { n = 0; }
+    } reset{buckets_sent_};  // (begin / blocking read buckets_sent(): what is left to send)
     if (pipelined && apply_optimizer) {
       if (begin) begin();
       pending_ = true;
@@ -57,6 +76,7 @@ class GradSyncPipeline {
  private:
   bool pending_ = false;
   float pending_lr_ = 0.f;
+  int buckets_sent_ = 0;
 };
 
 }  // namespace f2n

@@ -119,6 +119,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("set_begin_end", [](GradSyncPipeline& p, py::function b, py::function e) { p.begin = [b]() { b(); }; p.end = [e]() { e(); }; })
       .def("set_apply", [](GradSyncPipeline& p, py::function f) { p.apply = [f](bool a, float lr) { f(a, lr); }; })
       .def("set_defer_flags", [](GradSyncPipeline& p, py::function f) { p.defer_flags = [f]() { f(); }; })
+      .def("set_bucket", [](GradSyncPipeline& p, py::function f) { p.bucket = [f](int b, int n) { f(b, n); }; })
+      .def("bucket_ready", &GradSyncPipeline::BucketReady)
+      .def_property_readonly("buckets_sent", &GradSyncPipeline::buckets_sent)
       .def("installed", &GradSyncPipeline::Installed)
       .def("pending", &GradSyncPipeline::Pending)
       .def("begin_step", [](GradSyncPipeline& p, bool apply_optimizer, py::function presample) { p.BeginStep(apply_optimizer, [presample]() { presample(); }); })
@@ -248,6 +251,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              r.data_parallel_ = dp;
            },
            py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("overlap") = true, py::arg("hooks_for_one_rank") = false)
+      .def("dp_bucket_callbacks",  // table-gradient ranges the scatter reported while it ran (bucketed exchange, DataParallel.h)
+           [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->n_bucket_callbacks_ : (int64_t) 0; })
       .def("dp_comm_ranks",  // ranks of the native RCCL communicator as RCCL reports them (0: none attached)
            [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->CommRanks() : 0; })
       .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically

@@ -300,10 +300,15 @@ __global__ __launch_bounds__(256) void field_shade_fwd_kernel(int n, const int32
   }
 }
 
-// Appearance-embedding gradient addends on a 2^-48 grid (order-free integer sums; see shade_bwd_kernel).  |v| is clamped to
-// 2^14: a larger addend only occurs next to non-finite MLP gradients, and that step is dropped by the finiteness flags.
-#define F2N_EMB_FIXED_SCALE 281474976710656.0          // 2^48
-#define F2N_EMB_FIXED_INV (1.0 / 281474976710656.0)
+// Appearance-embedding gradient addends on a 2^-38 grid (order-free integer sums; see shade_bwd_kernel).  |v| is clamped to 2^14, so
+// an addend is at most 2^52 and a cell takes 1024 of them without wrapping -- a block adds one addend per 16-sample tile and image,
+// at most ~200 per cell at the largest batches (round-4 advisor: at 2^-48 two clamped addends wrapped).  A larger or non-finite addend
+// only occurs when the colour network's backward has produced non-finite values, i.e. next to non-finite MLP gradients: that step is
+// dropped by the finiteness flags over the two MLPs' gradients (the same rows feed the field MLP's backward), so the clamp / the zero
+// a NaN maps to is never applied.  Scenes with more than 240 images (the per-block LDS image is 128 B per image) take the global
+// path below, whose float atomics add in arrival order: "same seed, same bits" holds up to 240 images (the shipped scenes: 50-185).
+#define F2N_EMB_FIXED_SCALE 274877906944.0          // 2^38
+#define F2N_EMB_FIXED_INV (1.0 / 274877906944.0)
 __device__ __forceinline__ unsigned long long f2n_emb_fixed(float v) {
   const float cl = v == v ? fminf(fmaxf(v, -16384.f), 16384.f) : 0.f;
   return (unsigned long long) __double2ll_rn((double) cl * F2N_EMB_FIXED_SCALE);
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
                                                         const int32_t* __restrict__ n_dev, float* __restrict__ emb_global) {
   F2N_RAISE_PRIO();
   // emb_partials: per-block LDS image of the appearance-embedding gradient, flushed as a partial (n_emb <= 240).  The image
-  // is 64-bit FIXED POINT (2^-48 units, ds_add_u64): every addend is rounded to the grid on its own and integer sums do not
+  // is 64-bit FIXED POINT (2^-38 units, ds_add_u64): every addend is rounded to the grid on its own and integer sums do not
   // depend on the order in which the block's four waves arrive -- with ds_add_f32 two trainings from one seed parted at
   // iteration 2, in this gradient (tools/determinism_probe.py, round 4);
   // emb_global: more images than fit into LDS -- row sums go straight to the gradient with global atomics, as the
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void shade_bwd_kernel(int n, const float* _
           const float e = expf(-ov);
           // e = +inf (output below ~-88.7): the quotient is inf / inf = NaN where the derivative's limit is 0.  The reference lets
           // the NaN through (ATen's backward of SHShader.cpp:27-28) and tcnn then drops the step; the product -- here, in the
-          // taped path (Renderer.cpp, ShadeSigmoid) and in the oracle -- takes the limit.  The reference-numerics build keeps the NaN.
+          // taped path (SHShader::Query in host/Renderer.cpp: the clamp at -80) and in the oracle -- takes the limit.  The reference-numerics build keeps the NaN.
           const float dsig = (!F2N_REFERENCE_NUMERICS && e > 3.0e38f) ? 0.f : (1.f + 2.f * F2N_SHADE_EPS) * e / ((1.f + e) * (1.f + e));
           const half_t v = (half_t) ((float) (half_t) (dv[r] * dsig) * loss_scale);
           dyf[r] = (valid && g == 0) ? v : (half_t) 0.f;

@@ -54,6 +54,16 @@ int f2n_abi_version(void);
  * of tcnn's FullyFusedMLP).  Same ABI; used to A/B whole trainings (bench.py "psnr_numerics_ab"). */
 int f2n_numerics_mode(void);
 const char* f2n_build_info(void);
+/* Data-parallel runs (one all-reduce of the hash-table gradient per step): the owner launch of the binned scatter behind
+ * f2n_hash_bwd / f2n_field_bwd[_dyn] can be cut into n_buckets launches over contiguous ranges of table slices -- bucket b = slices
+ * [b * S / n, (b + 1) * S / n) of the S = 17 * (level_entries / 8192) slices of 4096 entries (8192 halves) that the active prefix of
+ * the table spans -- and fn(user, b, n) is called on the calling host thread right behind bucket b's launch: that range of the
+ * gradient table is final once the launch has run, so its all-reduce can start (on another stream, behind an event) while the
+ * later buckets' owners still run, instead of the whole 17 MiB waiting for the step's last kernel.  Per device; n_buckets <= 1 or
+ * fn == NULL removes the hook.  A scatter that does not take the binned path (small batches, tiny tables) calls nothing: the caller
+ * sends what is left when the backward returns (host/DataParallel.cpp). */
+typedef void (*f2n_bucket_fn)(void* user, int bucket, int n_buckets);
+int f2n_set_scatter_buckets(int n_buckets, f2n_bucket_fn fn, void* user);
 /* Diagnostics (host-only, synchronous; no reference counterpart): eight device-side event counters copied to host memory,
  * optionally reset.  [0] = scatter records of f2n_hash_bwd's owner-binned path that found their queue segment full and were
  * applied by a packed-f16 atomic instead (the only order-dependent addition of that path).  The rest are reserved (0). */

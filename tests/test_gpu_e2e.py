@@ -610,6 +610,41 @@ def test_launcher_train_test_render_path(rt, tmp_path):
     assert Image.open(exp / "images" / imgs[0]).size == (4 * 64, 48)
 
 
+def test_bucketed_table_exchange_on_one_gpu(rt, fox_state):
+    """The bucketed table exchange of a data-parallel step (host/DataParallel.cpp: the scatter's owner launch cut into four launches,
+    each range's all-reduce started from the library's callback while the next owners run) through RCCL with a one-rank world, at a
+    batch that takes the owner-binned scatter: parameters after three steps equal a hook-less run bit for bit (an average over one
+    rank is the identity), pipelined and blocking, and the callbacks did fire (3 steps x 4 buckets)."""
+    import socket
+    import torch.distributed as dist
+    from f2_nerf_amd import parallel, runtime
+    st = fox_state
+    rng = np.random.default_rng(5)
+    batches = [runtime.to_dev(*runtime.synthetic_ray_batch(st, 2048, rng)) for _ in range(4)]
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = {}
+        for mode in ("none", "native", "native-blocking"):
+            runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=15"], seed=3, table_init=0.3)
+            torch.manual_seed(9)
+            if mode != "none":
+                parallel.attach(runner, 15, overlap=(mode == "native"), native=True, hooks_for_one_rank=True)
+            for i in range(3):
+                b, nb = batches[i], batches[i + 1]
+                s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+                assert s["n_samples"] >= 32768, s["n_samples"]  # (the owner-binned scatter: F2N_BIN_MIN_N)
+            outs[mode] = ([t.clone() for t in runner.states()], runner.dp_bucket_callbacks())
+            del runner
+        for mode in ("native", "native-blocking"):
+            assert outs[mode][1] == 12, (mode, outs[mode][1])
+            for a, b in zip(outs["none"][0], outs[mode][0]):
+                assert torch.equal(a, b), mode
+        assert outs["none"][1] == 0
+    finally:
+        dist.destroy_process_group()
+
+
 def test_two_rank_bench_when_two_gpus_are_visible():
     """bench.py --gpus 2 through its own torch.distributed.run launch: two ranks over RCCL (the native communicator of
     csrc/host/DataParallel.cpp), replicas bit-identical after 20 pipelined steps.  Needs two devices: on a one-GPU lease

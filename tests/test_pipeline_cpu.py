@@ -248,6 +248,52 @@ def test_step_and_gradient_exchange_interleave_in_the_documented_order():
     assert log == ["sample", "fwd_bwd", "begin", "end", "adam(apply=1, lr=0.030)", "defer_flags", "fwd_bwd", "adam(apply=0, lr=0.040)"]
 
 
+def test_table_gradient_buckets_travel_in_order_and_the_exchange_sends_the_rest():
+    """Bucketed table exchange (GradSyncPipeline::BucketReady, round 5): the scatter reports the finished ranges of the gradient table
+    while the backward's last kernels run; range b's all-reduce starts at once, `begin` (or the blocking exchange) sends the buckets
+    that were not reported -- all of them for a batch that took the small-batch path -- and then the flat small-gradient buffer.  The
+    sequence of collectives a rank issues per step is therefore always b0 b1 b2 b3 flat, whatever its scatter did: pinned here with
+    the host extension's own object; out-of-order or repeated buckets throw."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    host = runtime.host()
+    log = []
+    N = 4
+    p = host.GradSyncPipeline()
+    p.set_apply(lambda a, lr: log.append("adam"))
+    p.set_defer_flags(lambda: None)
+    p.set_bucket(lambda b, n: log.append("allreduce(table bucket %d/%d)" % (b, n)))
+
+    def begin():
+        for b in range(p.buckets_sent, N):  # what DataParallel::GradSyncBegin does
+            log.append("allreduce(table bucket %d/%d)" % (b, N))
+        log.append("allreduce(flat)")
+    p.set_begin_end(begin, lambda: log.append("wait"))
+    p.pipelined = True
+    want = ["allreduce(table bucket %d/%d)" % (b, N) for b in range(N)] + ["allreduce(flat)"]
+    for reported in (4, 2, 0, 4):  # the scatter reported every bucket / two of them / none (small batch) / every one again
+        del log[:]
+        p.begin_step(True, lambda: None)
+        for b in range(reported):
+            p.bucket_ready(b, N)
+        assert p.buckets_sent == reported
+        p.gradients_ready(True, 0.01)
+        assert [x for x in log if x.startswith("allreduce")] == want, log
+        assert p.buckets_sent == 0
+    p.begin_step(True, lambda: None)
+    p.bucket_ready(0, N)
+    with pytest.raises(Exception):
+        p.bucket_ready(0, N)  # twice
+    with pytest.raises(Exception):
+        p.bucket_ready(2, N)  # skipping one
+    p.begin_step(True, lambda: None)  # a new step starts from bucket 0 again
+    p.bucket_ready(0, N)
+    # without a bucket callback (one GPU, or the torch.distributed hooks) the notifications are ignored
+    q = host.GradSyncPipeline()
+    q.bucket_ready(3, N)
+    assert q.buckets_sent == 0
+
+
 def test_bench_reads_the_node_layout_of_the_checkpoint():
     """bench.py's PSNR study identifies surviving leaves from the raw TreeNode bytes with its own numpy dtype (it may not import the
     oracle): field offsets and size must be those of the 64-byte checkpoint layout (PersSampler.h:22-29)."""
