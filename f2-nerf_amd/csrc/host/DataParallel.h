@@ -35,7 +35,8 @@ class DataParallel {
   void BroadcastStates();           // rank 0's checkpoint vector -> every rank (collective)
   int rank() const { return rank_; }
   int world() const { return world_; }
-  int CommRanks() const;            // what RCCL itself reports for the communicator (ncclCommCount)
+  int CommRanks() const;
+  int64_t BucketCallbacks() const { return n_bucket_callbacks_; }  // table ranges the scatter reported while it ran            // what RCCL itself reports for the communicator (ncclCommCount)
 
  private:
   // bucketed table exchange (GradSyncPipeline.h): range b of n of the active table prefix, in halves
