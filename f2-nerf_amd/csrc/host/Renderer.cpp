@@ -1,5 +1,5 @@
-// SHShader + Renderer host logic.  Behaviour follows src/Shader/SHShader.cpp and src/Renderer/Renderer.cpp:52-258
-// of the reference (cited inline).  Where the reference strings ~40 ATen ops and 6 FlexOps launches per Render
+// Renderer host logic (SHShader: SHShader.cpp; the sampling pipeline: RendererPrefetch.cpp; the untaped training iteration:
+// RendererTrain.cpp).  Behaviour follows src/Renderer/Renderer.cpp:52-258 of the reference (cited inline).  Where the reference strings ~40 ATen ops and 6 FlexOps launches per Render
 // call, this issues: field pre-pass -> early_stop -> scan -> compact -> (mark_visit, update_stats) -> edge
 // samples -> fused field -> scatter_idx -> fused shade -> composite, with two host read-backs in total (N, M).
 // Render() is the taped (autograd) plugin entry point of the reference; TrainForwardBackward() is the same chain plus
@@ -10,87 +10,14 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 namespace f2n {
 
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
-// ---------------------------------------------------------------------------------------------------------
-// SHShader
-// ---------------------------------------------------------------------------------------------------------
-SHShader::SHShader(GlobalDataPool* gdp) {  // SHShader.cpp:9-20
-  global_data_pool_ = gdp;
-  gdp->shader_ = this;
-  const auto& c = gdp->config_;
-  d_in_ = c.Int("shader.d_in");
-  d_out_ = c.Int("shader.d_out");
-  degree_ = c.Int("shader.degree");
-  d_hidden_ = c.Int("shader.d_hidden");
-  n_hiddens_ = c.Int("shader.n_hiddens");
-  TORCH_CHECK(degree_ >= 1 && degree_ <= 8, "SH degree ", degree_, " is not supported (1..8, SHShader.cu:51-102)");
-  TORCH_CHECK(d_in_ == 16 + degree_ * degree_, "shader.d_in must be 16 shading features + degree^2 SH coefficients (SHShader.cpp:24-25)");
-  mlp_ = std::make_unique<FusedMLP>(gdp, d_in_, d_out_, d_hidden_, n_hiddens_);
-  fused_ok_ = degree_ == 4 && d_hidden_ == 64 && n_hiddens_ == 2;
-}
-
-Tensor SHShader::SHEncode(const Tensor& dirs) {  // SHShader.cu:108-118
-  Tensor d = dirs.contiguous();
-  CheckDev(d, torch::kFloat32, "dirs");
-  const int n = d.size(0);
-  Tensor out = torch::empty({n, degree_ * degree_}, DevF32());
-  F2N_CALL(f2n_sh_encode(CurStream(), n, degree_, F32P(d), F32P(out)));
-  return out;
-}
-
-Tensor SHShader::Query(const Tensor& feats, const Tensor& dirs) {  // SHShader.cpp:23-29, op by op
-  Tensor enc = SHEncode(dirs);
-  Tensor input = torch::cat({feats, enc}, -1);
-  Tensor output = mlp_->Query(input);
-  const float eps = 1e-3f;
-  // (the reference's expression, SHShader.cpp:27-28, on an output clamped at -80: below ~-88.7 exp(-output) is +inf in fp32 and
-  // ATen's backward of 1 / (1 + e) * e forms 0 * inf = NaN -- the gradient's true limit there is 0, which the clamp delivers;
-  // values are unchanged for every output >= -80.  Without it a wide colour network at the reference's learning rate 1e-2 ran
-  // into a permanent "Nan!" skip after ~20 iterations (tools/debug_generic.py).)
-  return (1.f + 2.f * eps) / (1.f + torch::exp(-output.clamp_min(-80.f))) - eps;
-}
-
 namespace {
-
-struct ShadeFunction : public torch::autograd::Function<ShadeFunction> {
-  static variable_list forward(AutogradContext* ctx, Tensor field_feats, Tensor color_params, Tensor app_emb, Tensor dirs,
-                               Tensor sample_emb_idx, int64_t shader_ptr, int64_t emb_grad_ptr) {
-    auto* sh = reinterpret_cast<SHShader*>(shader_ptr);
-    Tensor feats = field_feats.contiguous();
-    CheckDev(feats, torch::kFloat32, "field feats");
-    TORCH_CHECK(feats.size(1) == 16 && sh->degree_ == 4 && sh->n_hiddens_ == 2, "fused shading needs 16 feats + SH4 + 2 hidden");
-    const int n = feats.size(0);
-    const bool emb = app_emb.defined() && sample_emb_idx.defined() && app_emb.numel() > 0 && sample_emb_idx.numel() > 0;
-    Tensor rgb = torch::empty({n, 3}, DevF32());
-    Tensor saved_x = torch::empty({n, 32}, DevF16());
-    F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(CurStream(), n, F32P(feats), F32P(dirs), emb ? F32P(app_emb) : nullptr,
-                           emb ? I32P(sample_emb_idx) : nullptr, VoidP(sh->mlp_->params_h_), F32P(rgb), VoidP(saved_x)));
-    ctx->saved_data["shader"] = shader_ptr;
-    ctx->saved_data["emb_grad"] = emb_grad_ptr;
-    ctx->saved_data["emb"] = emb;
-    ctx->save_for_backward({saved_x, sample_emb_idx});
-    return {rgb};
-  }
-  static variable_list backward(AutogradContext* ctx, variable_list grad_output) {
-    auto* sh = reinterpret_cast<SHShader*>(ctx->saved_data["shader"].toInt());
-    auto* emb_grad = reinterpret_cast<Tensor*>(ctx->saved_data["emb_grad"].toInt());
-    const bool emb = ctx->saved_data["emb"].toBool();
-    auto saved = ctx->get_saved_variables();
-    Tensor drgb = grad_output[0].contiguous();
-    const int n = saved[0].size(0);
-    Tensor dfeat = torch::zeros({n, 16}, DevF32());
-    F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd(CurStream(), n, F32P(drgb), emb ? I32P(saved[1]) : nullptr, VoidP(sh->mlp_->params_h_),
-                           VoidP(saved[0]), sh->mlp_->loss_scale_, F32P(dfeat), F32P(sh->mlp_->grad_scaled_),
-                           (emb && emb_grad != nullptr) ? F32P(*emb_grad) : nullptr,
-                           (emb && emb_grad != nullptr) ? (int) emb_grad->size(0) : 0, nullptr));
-    return {dfeat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
-  }
-};
 
 // Volume rendering (Renderer.cpp:190-208) as one autograd node.
 struct CompositeFunction : public torch::autograd::Function<CompositeFunction> {
@@ -144,47 +71,6 @@ Tensor CustomOps::WeightVar(Tensor weights, Tensor idx_start_end) {
   return WeightVarFunction::apply(weights.contiguous(), idx_start_end.contiguous())[0];
 }
 
-Tensor SHShader::QueryFromField(const Tensor& field_feats, const Tensor& dirs, const Tensor& app_emb,
-                                const Tensor& sample_emb_idx, Tensor* app_emb_grad) {
-  if (!fused_ok_) {
-    // op by op, as the reference: shading_feat = [1 | feat[1:]] (+ app_emb[img], CustomOps::ScatterAdd) -> SHShader::Query
-    // (Renderer.cpp:181-188).  The appearance embedding's gradient arrives through autograd here (app_emb.grad): the caller
-    // moves it into the optimiser's buffer (ExpRunner::TrainStepAutograd).
-    Tensor shading = torch::cat({torch::ones_like(field_feats.index({Slc(), Slc(0, 1)})), field_feats.index({Slc(), Slc(1, 16)})}, 1);
-    const bool emb = app_emb.defined() && sample_emb_idx.defined() && app_emb.numel() > 0 && sample_emb_idx.numel() > 0;
-    if (emb) shading = shading + app_emb.index_select(0, sample_emb_idx.to(torch::kInt64));
-    return Query(shading, dirs.contiguous());
-  }
-  return ShadeFunction::apply(field_feats, mlp_->params_, app_emb, dirs.contiguous(), sample_emb_idx,
-                              reinterpret_cast<int64_t>(this), reinterpret_cast<int64_t>(app_emb_grad))[0];
-}
-
-int SHShader::LoadStates(const std::vector<Tensor>& states, int idx) {
-  torch::NoGradGuard g;
-  mlp_->params_.copy_(states[idx++].to(torch::kCUDA).to(torch::kFloat32));
-  mlp_->SyncHalf();
-  return idx;
-}
-std::vector<Tensor> SHShader::States() { return {mlp_->params_.detach()}; }
-std::vector<ParamGroup> SHShader::OptimParamGroups() {  // SHShader.cpp:44-56
-  ParamGroup g;
-  g.name = "color_mlp";
-  g.param = mlp_->params_;
-  g.grad = mlp_->grad_scaled_;
-  g.param_h = mlp_->params_h_;
-  g.weight_decay = 1e-6f;
-  g.grad_round_h16 = true;
-  g.grad_scale = -1.f;
-  return {g};
-}
-void SHShader::Reset() { mlp_->InitParams(); }
-
-std::unique_ptr<Shader> ConstructShader(GlobalDataPool* gdp) {  // ShaderFactory.cpp:8-17
-  const std::string type = gdp->config_.Str("shader.type");
-  TORCH_CHECK(type == "SHShader", "unknown shader.type: ", type);
-  return std::make_unique<SHShader>(gdp);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Renderer
 // ---------------------------------------------------------------------------------------------------------
@@ -227,237 +113,6 @@ void Renderer::ZeroGrad() {
   field->ZeroGrad();
   static_cast<SHShader*>(shader_.get())->mlp_->ZeroGrad();
   app_emb_grad_.zero_();
-}
-
-// A prefetched sampling is identified by the ray tensors it was made for.  The renderer HOLDS those tensors: an address
-// alone can be recycled by the allocator for other rays (a test image rendered right after training picked up the
-// samples prefetched for the next training batch that way, once in ~10 runs).
-bool Renderer::PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) const {
-  return has_presample_ && presample_rays_o_.defined() && presample_rays_d_.defined() &&
-         rays_o.data_ptr() == presample_rays_o_.data_ptr() && rays_d.data_ptr() == presample_rays_d_.data_ptr() &&
-         rays_o.sizes() == presample_rays_o_.sizes();
-}
-
-void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
-  if (PresampleMatches(rays_o, rays_d)) return;  // already marched (asynchronously) for these rays
-  const int slot = FindPending(rays_o, rays_d);
-  if (slot >= 0) {          // ... or being marched
-    PreSampleFinish(slot);
-    if (PresampleMatches(rays_o, rays_d)) return;
-  }
-  static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
-  static_cast<PersSampler*>(pts_sampler_.get())->keyed_seq_ = cur_seq_;
-  presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
-  has_presample_ = true;
-  presample_async_ = false;
-  presample_rays_o_ = rays_o;
-  presample_rays_d_ = rays_d;
-}
-
-#if F2N_DEBUG_BUILD
-// F2N_DEBUG_SIDE_DELAY="begin_us:complete_us:main_us:period" (debugging aid, off by default): every period-th speculative begin /
-// completion / step is preceded by a spin kernel of that many microseconds on its stream (f2n_debug_spin), which skews the sampler's
-// side streams against the main stream.  Results must not depend on it (tools/determinism_probe.py --side-delay).
-namespace {
-struct SideDelay {
-  int begin_us = 0, complete_us = 0, main_us = 0, period = 1;
-  unsigned pollute = 0;  // != 0: every begin / completion / step is preceded by f2n_debug_pollute with a value derived from it
-  uint64_t calls[3] = {0, 0, 0};
-  SideDelay() {
-    const char* e = std::getenv("F2N_DEBUG_SIDE_DELAY");
-    if (e != nullptr) std::sscanf(e, "%d:%d:%d:%d", &begin_us, &complete_us, &main_us, &period);
-    if (period < 1) period = 1;
-  }
-  void Apply(int which) {
-    const int us = which == 0 ? begin_us : which == 1 ? complete_us : main_us;
-    const uint64_t call = calls[which]++;
-    if (pollute != 0) {
-      F2N_CALL(f2n_debug_pollute(CurStream(), pollute * 2654435761u + (unsigned) call * 3u + (unsigned) which));
-      if (which == 2) {  // ... and a co-tenant's worth of them beside the step, on a stream nothing is ordered against
-        static c10::hip::HIPStreamMasqueradingAsCUDA other = c10::hip::getStreamFromPoolMasqueradingAsCUDA();
-        for (unsigned k = 0; k < 6; k++) F2N_CALL(f2n_debug_pollute((void*) other.stream(), pollute * 40503u + (unsigned) call * 7u + k));
-      }
-    }
-    if (us > 0 && (call % (uint64_t) period) == 0) F2N_CALL(f2n_debug_spin(CurStream(), us));
-  }
-};
-SideDelay& DebugSideDelay() {
-  static SideDelay d;
-  return d;
-}
-}  // namespace
-
-void Renderer::SetDebugSideDelay(int begin_us, int complete_us, int main_us, int period, unsigned pollute) {
-  auto& d = DebugSideDelay();
-  d.pollute = pollute;
-  d.begin_us = begin_us;
-  d.complete_us = complete_us;
-  d.main_us = main_us;
-  d.period = period < 1 ? 1 : period;
-}
-#define F2N_DEBUG_SKEW(which) DebugSideDelay().Apply(which)
-#else
-#define F2N_DEBUG_SKEW(which) ((void) 0)  // (the product's step has no debugging hooks: host/Common.h F2N_DEBUG_BUILD)
-#endif
-
-// The two side streams are per DEVICE, not per Renderer: a process that builds a second runner (bench.py: the headline runner, then
-// the converged leg's) would otherwise hold five streams -- main + 2 + 2 -- and HIP multiplexes streams onto four hardware queues
-// by default: the second runner's sampler then shared a queue with its own main stream (measured: 20 000 iterations 17.6 s
-// in bench.py against 15.2 s for the same loop in a process of its own; profiles/r04_pipeline_experiments.txt item 9).
-void Renderer::EnsureSideStream(int slot) {
-  if (side_[slot]) return;
-  static std::shared_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> shared[16][kPendingSlots];
-  const int dev = c10::hip::current_device();
-  TORCH_CHECK(dev >= 0 && dev < 16, "device index out of range");
-  if (!shared[dev][slot])
-    shared[dev][slot] = std::make_shared<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
-  side_[slot] = shared[dev][slot];
-}
-
-// A side stream's buffers may be handed the memory of samples the main stream is still reading: it waits for the last
-// recording of samples_consumed_ev_ it has not waited for yet.
-void Renderer::SideWaitConsumed(int slot) {
-  if (side_waited_seq_[slot] == consumed_seq_) return;
-  samples_consumed_ev_.block(*side_[slot]);
-  side_waited_seq_[slot] = consumed_seq_;
-}
-
-void Renderer::PreSampleAsync(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds) {
-  PreSampleBegin(rays_o, rays_d, bounds, global_data_pool_->ray_march_fineness_);
-  const int slot = FindPending(rays_o, rays_d);
-  if (slot >= 0) PreSampleFinish(slot);
-}
-
-// First half of the prefetch: everything up to the sample counts, issued on a side stream without blocking the host.
-// Called from inside SampleAndFilter as soon as this step's occupancy update (the only thing the next batch's sampling
-// depends on) has been issued; the kernels then run underneath this step's forward/backward.
-void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const Tensor& /*bounds*/, float fineness, int64_t seq) {
-  if (FindPending(rays_o, rays_d) >= 0) return;  // (already in flight for these rays)
-  int slot = FreePendingSlot();
-  if (slot < 0) {  // both slots hold batches for other rays: the one begun last is the furthest ahead, and goes
-    slot = kPendingSlots - 1;
-    DropPendingSlot(slot);
-  }
-  EnsureSideStream(slot);
-  octree_ready_ev_.block(*side_[slot]);  // the only dependency on this step: its occupancy update / ProcOctree
-  SideWaitConsumed(slot);
-  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
-  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
-  ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  pend_[slot].seq = seq;
-  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/false, seq);  // ... up to and including the pack
-  if (global_data_pool_->mode_ == RunningMode::TRAIN) PreGenerateStepDraws(slot);
-  presample_done_ev_[slot].record(*side_[slot]);
-  pend_[slot].rays_o = rays_o;
-  pend_[slot].rays_d = rays_d;
-}
-
-// Speculative variant of PreSampleBegin: intersection + march only, NOT ordered behind this step's stat update.
-void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& rays_d, float fineness, int64_t seq) {
-  EnsureSideStream(slot);
-  // Everything the main stream has been handed so far comes first: the kernels that DRAW the next batch's rays
-  // (Dataset::RandRaysData, queued by ExpRunner::Train right before this step) and whatever touched the tree there -- i.e. the
-  // speculative sampling starts when this step's own kernels start, not before.  (Waiting only for the previous step's octree
-  // update -- as a first version did -- let the side stream read ray buffers that were still to be written whenever the host
-  // ran ahead of the device: PSNR fell and octrees blew up at random, worst with a second process on the GPU.)
-  if (!spec_start_recorded_) {  // (else: recorded at the top of this step, ahead of its random draws)
-    spec_start_ev_.record();
-    spec_start_recorded_ = true;  // (a second batch begun in the same step waits for the same point)
-  }
-  spec_start_ev_.block(*side_[slot]);
-  SideWaitConsumed(slot);
-  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
-  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
-  ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  F2N_DEBUG_SKEW(0);
-  ps->BeginSamples(rays_o, rays_d, fineness, pend_[slot].s, /*speculative=*/true, seq);
-  pend_[slot].seq = seq;
-  pend_[slot].rays_o = rays_o;
-  pend_[slot].rays_d = rays_d;
-}
-
-void Renderer::SpecBeginAtStepEnd() {
-  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
-  auto* gdp = global_data_pool_;
-  const NextBatch& nb = next2_batch_;
-  if (!nb.valid || gdp->mode_ != RunningMode::TRAIN || speculative_sampling_ == 0 || FindPending(nb.rays_o, nb.rays_d) >= 0) return;
-  const bool big_tree = ps->pers_octree_->n_interior_ > ps->LdsWalkMaxInterior();
-  if (spec_depth_ >= 3 || (spec_depth_ == 2 && big_tree)) return;  // (two-deep regime: begun at the top of this step already)
-  const bool quiet = ps->pers_octree_->QuietEpochs() >= kSpecQuietEpochs;
-  const int slot = FreePendingSlot();
-  if (!(speculative_sampling_ == 1 || quiet) || slot < 0 || ps->MaintenanceDueAt(gdp->iter_step_ + 1)) return;
-  spec_start_recorded_ = false;  // (the side stream starts behind what this step has queued so far)
-  PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness, nb.seq);
-  spec_start_recorded_ = false;
-  n_speculative_++;
-}
-
-// ... and its completion, called with this step's stat update issued (octree_ready_ev_ recorded): repair, scan, count, pack.
-bool Renderer::PreSampleSpecComplete(int slot) {
-  auto& pb = pend_[slot];
-  TORCH_CHECK(pb.s.active && pb.s.speculative && !pb.s.completed, "no speculative sampling in flight");
-  octree_ready_ev_.block(*side_[slot]);
-  SideWaitConsumed(slot);
-  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
-  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
-  ps->extra_sample_rows_ = 2 * n_edge_pts_;
-  F2N_DEBUG_SKEW(1);
-  if (!ps->CompleteSpeculative(pb.s)) {
-    n_spec_dropped_++;
-    pb = PendingBatch();  // (its kernels are ordered on the side stream, whose pool its buffers return to)
-    return false;
-  }
-  if (global_data_pool_->mode_ == RunningMode::TRAIN) PreGenerateStepDraws(slot);
-  presample_done_ev_[slot].record(*side_[slot]);
-  return true;
-}
-
-// The draws of the step that will consume pend_[slot] (random background, 2E edge samples) and the edge-sample launch itself,
-// queued on that slot's side stream right behind its pack: the packed arrays (front rows) and worst-case-sized pts_all / vol_all
-// are their homes.  Only when nothing is pinned by a test and the background is random (the training configuration).
-void Renderer::PreGenerateStepDraws(int slot) {
-  auto& pb = pend_[slot];
-  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
-  const int n_edge = n_edge_pts_, n_rays = pb.s.n_rays;
-  const int64_t front = 2 * (int64_t) n_edge;
-  if (!pregen_draws_ || n_edge <= 0 || forced_bg_.defined() || bg_color_type_ != BGColorType::rand_noise || ps->forced_edge_idx_.defined() ||
-      ps->forced_edge_coords_.defined() || !pb.s.o_pts.defined() || pb.s.extra_rows < front || ps->pers_octree_->n_edges_ <= 0)
-    return;
-  c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
-  const int64_t nb = (int64_t) n_rays * 3, ne = (int64_t) n_edge * 3;
-  Tensor u = DrawStepUniforms(nb + ne, pb.seq);
-  pb.bg_color = u.narrow(0, 0, nb).view({n_rays, 3});
-  const int64_t rows = pb.s.s_dt.numel() + front;  // every ray's slots full: the survivors can never be more
-  pb.pts_all = torch::empty({rows, 3}, DevF32());
-  pb.vol_all = torch::empty({rows}, DevI32());
-  auto& oct = *ps->pers_octree_;
-  F2N_CALL(f2n_edge_samples_ex(CurStream(), n_edge, VoidP(oct.edge_pool_gpu_), oct.n_edges_, VoidP(oct.pers_trans_gpu_), nullptr, nullptr,
-                               F32P(u) + nb, F32P(pb.s.o_pts), I32P(pb.s.o_anchors), 3, F32P(pb.pts_all), I32P(pb.vol_all), 1));
-  pb.step_draws_ready = true;
-}
-
-// Second half: wait for the counts (by now the march has usually finished) and take views of the packed rows.  No launch.
-void Renderer::PreSampleFinish(int slot) {
-  auto& pb = pend_[slot];
-  TORCH_CHECK(pb.s.active, "PreSampleFinish without PreSampleBegin");
-  // samples marched against a tree that has since been replaced or re-numbered (LoadStates / InstallOctree / ProcOctree between
-  // the prefetch and its use) are void, whichever way they were prefetched: the caller samples again
-  if (pb.s.generation != static_cast<PersSampler*>(pts_sampler_.get())->pers_octree_->generation_) {
-    DropPendingSlot(slot);
-    return;
-  }
-  if (!pb.s.completed && !PreSampleSpecComplete(slot)) return;  // (a speculative batch whose step never reached its update)
-  presampled_ = static_cast<PersSampler*>(pts_sampler_.get())->FinishSamples(pb.s);
-  presampled_.step_draws_ready = pb.step_draws_ready;
-  presampled_.bg_color = pb.bg_color;
-  presampled_.pts_all = pb.pts_all;
-  presampled_.vol_all = pb.vol_all;
-  has_presample_ = true;
-  presample_async_ = true;
-  presample_slot_ = slot;
-  presample_rays_o_ = pb.rays_o;
-  presample_rays_d_ = pb.rays_d;
-  pb = PendingBatch();
 }
 
 void Renderer::DigestTap(int tap, const Tensor& t) {
@@ -514,7 +169,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   F2N_HOST_SCOPE("step.sample_and_filter");
   auto* gdp = global_data_pool_;
   ResolvePendingCount();
-  if (gdp->mode_ == RunningMode::TRAIN) F2N_DEBUG_SKEW(2);
+  if (gdp->mode_ == RunningMode::TRAIN) DebugSkew(2);
   auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
@@ -554,7 +209,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     if (presample_async_) {
       // Produced on a side stream, out of that stream's memory pool: order it before this stream.  The allocator is
       // NOT told (record_stream on the seven tensors cost ~45 us of host time when they are released in the middle of the
-      // step, right where the device is waiting for the next launch): instead samples_consumed_ev_ is recorded on this
+      // step, right where the device is waiting for the next launch): instead the device's `consumed` event is recorded on this
       // stream once the last kernel that reads them has been queued, and the side streams wait for it before the next
       // kernels that could be handed this memory again (SideWaitConsumed).
       // (the wait itself is issued further down, right before the first kernel that reads the packed samples)
@@ -872,13 +527,14 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
 
   fr.n_kept = n_kept;
   fr.n_edge = n_edge;
+  fr.side_pool_buffers = pregen;
   fr.emb = train && use_app_emb_ && emb_idx.defined();
   if (!fr.emb) fr.sample_emb_idx = torch::empty({0}, DevI32());  // autograd::Function inputs must be defined tensors
   sample_result_ = SampleResultFlex();  // drop the pre-early-stop buffers
   if (consumed_side_samples_) {         // (see above: every reader of the side stream's sample buffers has been queued)
-    samples_consumed_ev_.record();
+    side_shared_->consumed.record();
     consumed_side_samples_ = false;
-    consumed_seq_++;
+    side_shared_->seq++;
   }
   octree_ready_ev_.record();            // everything the NEXT step's ray sampling depends on has been issued
   return fr;
@@ -942,142 +598,6 @@ RenderResult Renderer::RenderForward(const Tensor& rays_o, const Tensor& rays_d,
   F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
                              F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights), nullptr));
   return {colors, es.first_oct_dis, disparity, Tensor(), depth, weights, es.pts_idx_bounds};
-}
-
-// One training iteration's forward AND backward without the autograd tape: the same kernels as Render() + the loss
-// of ExpRunner::Train (ExpRunner.cpp:95-120) + the backward chain, issued back to back.  Every gradient buffer of the
-// chain is written exactly once by the kernel that owns it (composite_bwd: dfeat[:,0] and drgb; shade_bwd:
-// dfeat[:,1:16]; the loss kernel: the edge rows of dfeat), so there is no zero-fill, no gradient accumulation pass and
-// no slice/cat copy: ~100 ATen launches and ~0.5 GB of HBM traffic per step less than the taped version.
-TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds,
-                                            const Tensor& gt_colors, const Tensor& emb_idx, float var_w, float disp_w, float tv_w) {
-  auto* gdp = global_data_pool_;
-  auto* field = static_cast<Hash3DAnchored*>(scene_field_.get());
-  auto* shader = static_cast<SHShader*>(shader_.get());
-  torch::NoGradGuard no_grad;
-  const int n_rays = rays_o.size(0);
-  Tensor gt = gt_colors.contiguous();
-  CheckDev(gt, torch::kFloat32, "gt_colors");
-  TORCH_CHECK(gt.numel() == (int64_t) n_rays * 3, "gt_colors must be [n_rays,3]");
-  RenderFront fr = SampleAndFilter(rays_o, rays_d, bounds, emb_idx, async_count_);
-  void* st = CurStream();
-  TrainOutputs out;
-  out.losses = torch::empty({8}, DevF32());
-  if (fr.empty) {  // no samples at all: the colour is the background, nothing depends on the parameters (Renderer.cpp:83-97)
-    Tensor bg = fr.bg_color.contiguous();
-    F2N_CALL(f2n_train_loss(st, n_rays, F32P(bg), F32P(gt), nullptr, nullptr, 0, 0, nullptr, 0.f, 0.f, 0.f, F32P(out.losses),
-                            nullptr, nullptr, nullptr, nullptr));
-    return out;
-  }
-  SampleResultFlex& es = fr.es;
-  const int n_kept = fr.n_kept, n_edge = fr.n_edge, n = n_kept + 2 * n_edge;
-  TORCH_CHECK(FusedPathOk(), "the untaped training step needs the shipped network shapes (ExpRunner::TrainStep takes the taped path otherwise)");
-
-  // Row layout of the field's arrays: [survivors | edge samples], or -- when the survivor count is still on the device
-  // (fr.dyn: n_kept is then the capacity) -- [edge samples | survivors] so that every offset is known on the host.
-  const int64_t so = fr.dyn ? 2 * (int64_t) n_edge : 0, eo = fr.dyn ? 0 : n_kept;
-  const int32_t* n_dev = fr.dyn ? I32P(fr.n_kept_dev) : nullptr;
-  // ---- forward ----
-  Tensor feat = torch::empty({fr.dyn ? std::max(2 * n_edge, 1) : n, F2N_MLP_OUT_PAD}, DevF32());
-  Tensor field_x = torch::empty({n, N_LEVELS * N_CHANNELS}, DevF16());
-  // the density pre-activations of the surviving samples also leave as a compact array: compositing then reads 4 B per
-  // sample instead of one 64-byte line of `feat` per sample, and its backward writes a compact d f0 that the colour
-  // backward merges into the dfeat rows it writes anyway (column 0 written in place was a read-modify-write of every line)
-  Tensor f0c = torch::empty({std::max(n_kept, 1)}, DevF32()), df0c = torch::empty({std::max(n_kept, 1)}, DevF32());
-  Tensor rgb = torch::empty({std::max(n_kept, 1), 3}, DevF32()), shade_x = torch::empty({std::max(n_kept, 1), 32}, DevF16());
-  Tensor app = fr.emb ? app_emb_ : Tensor();
-  if (fr.dyn) {
-    // streaming step: field MLP (cached hash features) and colour path of the survivors in one launch -- their `feat` rows
-    // are never written (only the 2E edge rows of `feat` exist: the TV loss reads them); the synchronous path below keeps
-    // the two separate kernels and is what tests compare this with
-    TORCH_CHECK(field->prepass_x_.defined(), "no pre-pass feature cache for this query");
-    const bool edges_ride = n_edge > 0 && fr.edge_cache_row >= 0;  // their hash features are in the pre-pass cache too
-    if (n_edge > 0 && !edges_ride)
-      F2N_TIMED_CALL("field_fwd", f2n_field_fwd(st, 2 * n_edge, field->n_volumes_, VoidP(field->feat_pool_h_), I32P(field->prim_pool_),
-                             I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
-                             F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
-                             F32P(feat), nullptr, VoidP(field_x)));
-    const at::Half* cache = field->prepass_x_.data_ptr<at::Half>();
-    const int64_t row = (int64_t) N_LEVELS * N_CHANNELS;
-    // survivors: field MLP -> colour path; edge samples (when cached): field MLP only, fp32 rows for the TV loss -- one launch
-    F2N_TIMED_CALL("field_shade_fwd", f2n_field_shade_fwd_extra(st, n_kept, n_dev, I32P(fr.src_rows),
-                           static_cast<const void*>(cache + row * fr.sample_cache_row), VoidP(field->mlp_->params_h_), F32P(es.dirs),
-                           fr.emb ? F32P(app) : nullptr, fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_),
-                           F32P(f0c), static_cast<void*>(field_x.data_ptr<at::Half>() + row * so), VoidP(shade_x), F32P(rgb),
-                           edges_ride ? 2 * n_edge : 0, edges_ride ? static_cast<const void*>(cache + row * fr.edge_cache_row) : nullptr,
-                           edges_ride ? F32P(feat) : nullptr, edges_ride ? VoidP(field_x) : nullptr));
-    field->prepass_x_ = Tensor();
-  } else {
-    field->ForwardRaw(fr.pts_all, fr.vol_all, 1, fr.src_rows, n_kept, feat, field_x, &f0c);
-    field->prepass_x_ = Tensor();
-    F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(st, n_kept, F32P(feat), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
-                           fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(rgb), VoidP(shade_x)));
-  }
-  Tensor colors = torch::empty({n_rays, 3}, DevF32());
-  Tensor weights = torch::empty({std::max(n_kept, 1)}, DevF32());
-  Tensor bg = fr.bg_color.contiguous();
-  Tensor dfeat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
-  Tensor drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());  // (WeightVarLoss backward rides inside the compositing backward)
-  if (fuse_composite_ && fr.dyn) {
-    // ---- compositing forward, loss, compositing backward: one launch (f2n_composite_train); the TV gradient goes straight
-    // into the edge rows of dfeat, the loss values are completed by the step's deferred reduction below ----
-    F2N_TIMED_CALL("composite_train", f2n_composite_train(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
-                                 F32P(bg), F32P(gt), var_w, disp_w, tv_w, gdp->gradient_scaling_progress_, n_edge, F2N_MLP_OUT_PAD,
-                                 n_edge > 0 ? F32P(feat) + F2N_MLP_OUT_PAD * eo : nullptr, n_edge > 0 ? F32P(dfeat) + F2N_MLP_OUT_PAD * eo : nullptr,
-                                 F32P(colors), F32P(weights), F32P(drgb), F32P(df0c), 1, F32P(out.losses), /*defer_reduce=*/1));
-  } else {
-    Tensor disparity = torch::empty({n_rays}, DevF32()), depth = torch::empty({n_rays}, DevF32());
-    Tensor var = torch::empty({n_rays}, DevF32());
-    F2N_TIMED_CALL("composite_fwd", f2n_composite_fwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),
-                               F32P(bg), F32P(colors), F32P(disparity), F32P(depth), F32P(weights), F32P(var)));  // (+ WeightVarLoss fwd)
-
-    // ---- loss and its gradients; the TV gradient goes straight into the edge rows of dfeat ----
-    Tensor dcolors = torch::empty({n_rays, 3}, DevF32()), ddisp = torch::empty({n_rays}, DevF32()), dvar = torch::empty({n_rays}, DevF32());
-    F2N_TIMED_CALL("train_loss", f2n_train_loss(st, n_rays, F32P(colors), F32P(gt), F32P(disparity), F32P(var), n_edge, F2N_MLP_OUT_PAD,
-                            F32P(feat) + F2N_MLP_OUT_PAD * eo, var_w, disp_w, tv_w, F32P(out.losses), F32P(dcolors),
-                            F32P(ddisp), F32P(dvar), F32P(dfeat) + F2N_MLP_OUT_PAD * eo));
-
-    // ---- backward ----
-    F2N_TIMED_CALL("composite_bwd", f2n_composite_bwd(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb), F32P(bg),
-                               F32P(dcolors), F32P(ddisp), nullptr, nullptr, gdp->gradient_scaling_progress_, F32P(drgb),
-                               F32P(df0c), 1, F32P(weights), F32P(dvar)));
-  }
-  if (digest_taps_) DigestTap(TAP_GRAD_BEFORE, field->grad_h_);  // (must be all zeros: Adam's zero_grad / ZeroGrad)
-  F2N_TIMED_CALL("shade_bwd", f2n_shade_bwd_dyn(st, n_kept, n_dev, F32P(drgb), fr.emb ? I32P(fr.sample_emb_idx) : nullptr,
-                         VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat) + F2N_MLP_OUT_PAD * so,
-                         F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,
-                         fr.emb ? (int) app_emb_grad_.size(0) : 0, F32P(df0c), /*defer_reduce=*/fr.dyn ? 1 : 0));
-  if (fr.dyn) {
-    field->grad_clean_ = false;
-    F2N_TIMED_CALL("field_bwd", f2n_field_bwd_dyn(st, n, n_dev, 2 * n_edge, field->n_volumes_, I32P(field->prim_pool_),
-                           I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
-                           F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
-                           VoidP(field_x), F32P(dfeat), field->mlp_->loss_scale_, F32P(field->mlp_->grad_scaled_),
-                           VoidP(field->grad_h_), field->pool_size_ / N_LEVELS, /*defer_reduce=*/1));
-    // the three partial-sum reductions (colour-MLP weights, appearance embedding, field-MLP weights) in one launch
-    F2N_TIMED_CALL("reduce_partials", f2n_reduce_deferred(st));
-  } else {
-    field->BackwardRaw(fr.pts_all, fr.vol_all, 1, field_x, dfeat);
-  }
-  if (digest_taps_ && fr.dyn) {
-    // what the scatter has just read, as it stands AFTER the scatter: rows [0, 2E + survivors) of pts_all / vol_all and of the
-    // MLP backward's inputs (rows beyond the device-side count are never written: masked out)
-    const int64_t rows = fr.pts_all.size(0);
-    Tensor live = torch::arange(rows, DevI32()).lt(fr.n_kept_dev + (int) so).to(torch::kInt32);
-    DigestTap(TAP_PTS_ALL_AFTER, fr.pts_all.view(torch::kInt32).sum(1, false, torch::kInt64) * live);
-    DigestTap(TAP_VOL_ALL_AFTER, fr.vol_all.to(torch::kInt64) * live);
-    Tensor live_n = live.narrow(0, 0, n);
-    DigestTap(TAP_FIELD_X, field_x.view(torch::kInt32).sum(1, false, torch::kInt64) * live_n);
-    DigestTap(TAP_DFEAT, dfeat.view(torch::kInt32).sum(1, false, torch::kInt64) * live_n);
-  }
-  if (digest_taps_) {
-    DigestTap(TAP_COLORS, colors);
-    DigestTap(TAP_TABLE_GRAD, field->grad_h_);
-    DigestTap(TAP_SMALL_GRADS, small_grads_flat_);
-  }
-  out.colors = colors;
-  out.has_samples = true;
-  return out;
 }
 
 int Renderer::LoadStates(const std::vector<Tensor>& states, int idx) {  // Renderer.cpp:216-224

@@ -53,6 +53,9 @@ struct RenderFront {
   // >= 0: the edge samples went through the density pre-pass; their hash features are rows [edge_cache_row, +2E) of its cache
   int64_t edge_cache_row = -1;
   int64_t sample_cache_row = 0;  // cache row of ray sample 0 (src_rows count from there)
+  // pts_all / vol_all / bg_color came out of a side stream's allocator pool (Renderer::PreGenerateStepDraws) and are read by the
+  // step's LAST kernels (compositing, the scatter): the device's `consumed` event is recorded once more behind those
+  bool side_pool_buffers = false;
 };
 
 struct TrainOutputs {
@@ -67,9 +70,10 @@ class Renderer : public Pipe {
  public:
   Renderer(GlobalDataPool* global_data_pool, int n_images);
 #if F2N_DEBUG_BUILD
-  // debug variant only (see Renderer.cpp): spin kernels in front of every period-th speculative begin / completion / step
+  // debug variant only (see RendererPrefetch.cpp): spin kernels in front of every period-th speculative begin / completion / step
   static void SetDebugSideDelay(int begin_us, int complete_us, int main_us, int period, unsigned pollute = 0);
 #endif
+  static void DebugSkew(int which);  // 0 speculative begin, 1 completion, 2 step; a no-op in the product build
   RenderResult Render(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx);
   RenderResult RenderForward(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds);  // inference: no tape, no count read-back
   // issues the ray sampling of the next SampleAndFilter / TrainForwardBackward call ahead of time (same rays!)
@@ -267,11 +271,19 @@ class Renderer : public Pipe {
   int presample_slot_ = 0;  // the side stream (pending slot) an asynchronous presample was produced on
   Tensor presample_rays_o_, presample_rays_d_;  // the rays the presample belongs to (held: see PresampleMatches)
   bool PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) const;
-  at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_[kPendingSlots], n_kept_ev_, samples_consumed_ev_;
-  // samples_consumed_ev_ (main stream: the last reader of a side stream's sample buffers has been queued) is awaited by a side
-  // stream before its next kernels, once per recording: consumed_seq_ counts the recordings, side_waited_seq_ what each waited for
+  at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_[kPendingSlots], n_kept_ev_;
+  // The two side streams -- and so their allocator pools -- are per DEVICE (EnsureSideStream), and so is the protocol that stands in
+  // for record_stream on the sample buffers that cross from a side stream's pool to the main stream: `consumed` is recorded on the
+  // main stream once the last reader of such buffers has been queued and awaited by a side stream before its next kernels, once
+  // per recording (seq counts the recordings, waited[slot] what each stream has waited for).  One event per device, not per
+  // Renderer: memory one Renderer returns to a shared pool may be handed to another Renderer's side-stream kernels (round-4 advisor).
+  struct SideShared {
+    std::shared_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> stream[kPendingSlots];
+    at::cuda::CUDAEvent consumed;
+    uint64_t seq = 0, waited[kPendingSlots] = {0, 0};
+  };
+  std::shared_ptr<SideShared> side_shared_;
   bool consumed_side_samples_ = false;
-  uint64_t consumed_seq_ = 0, side_waited_seq_[kPendingSlots] = {0, 0};
   void SideWaitConsumed(int slot);
   bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
