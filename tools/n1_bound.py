@@ -62,7 +62,7 @@ def handed_in(o):
 
 handed_in(outs[1]); torch.cuda.synchronize()
 err = float((outs[0]["colors"] - outs[1]["colors"]).abs().max())
-same_grad = bool(torch.equal(outs[0]["df0"], outs[1]["df0"])) and float((outs[0]["drgb"] - outs[1]["drgb"]).abs().max()) < 1e-6
+grad_err = max(float((outs[0]["df0"] - outs[1]["df0"]).abs().max()), float((outs[0]["drgb"] - outs[1]["drgb"]).abs().max()))
 res = []
 for rep in range(5):
     a = timeit(lambda: plain(outs[0]), 50) * 1e3
@@ -70,4 +70,4 @@ for rep in range(5):
     res.append((a, b))
 a, b = np.median([r[0] for r in res]), np.median([r[1] for r in res])
 print("n1_bound: %d rays, %d surviving samples (longest ray %d) | composite_train %.1f us | with the colour sums handed in %.1f us | upper bound of the saving %.1f us "
-      "(median of 5 alternated pairs of 50 launches; colours agree to %.1e, sample gradients %s)" % (n_rays, m, int(keep.max()), a, b, a - b, err, "equal" if same_grad else "DIFFER"))
+      "(median of 5 alternated pairs of 50 launches; the handed-in sums are rebuilt from the first launch's colours: colours agree to %.1e, sample gradients to %.1e)" % (n_rays, m, int(keep.max()), a, b, a - b, err, grad_err))

@@ -51,5 +51,8 @@ for name, (pts, anchors) in sets.items():
     g[torch.rand(n, device=dev) < args.zero_frac] = 0
     table = torch.zeros(16 << (log2 + 1), dtype=torch.float16, device=dev)
     f = lambda: capi.hash_bwd(n, nvol, prim, lidx, lsize, bias, scale, pts, True, anchors, 3, g, table, 1 << log2)
+    capi.debug_counters(reset=True)
     ms = timeit(f, args.reps)
-    print("scatter_bench %-30s n %7d  %.4f ms per scatter (both kernels)  checksum %d" % (name, n, ms, int(table.view(torch.int32).to(torch.int64).sum())), flush=True)
+    table.zero_(); f()
+    print("scatter_bench %-30s n %7d  %.4f ms per scatter (both kernels)  checksum of one scatter %d  records that fell back to atomics %d" %
+          (name, n, ms, int(table.view(torch.int32).to(torch.int64).sum()), capi.debug_counters()[0]), flush=True)
