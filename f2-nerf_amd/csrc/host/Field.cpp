@@ -322,7 +322,8 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
     // stretched by the distance scaling where it is on), half of that in the [0,1] space the grid hashes (:91)
     const float step01 = march_step_warped_ * global_data_pool_->ray_march_fineness_ * .5f;
     // Tables that have left the L2s (2^21 entries per level and more: BASELINE config 5) take the slice-binned gather for the level
-    // pairs whose working set exceeds an L2: from level pair 1 on, for tables of 2^21 entries per level and more
+    // pairs whose working set exceeds an L2: from level pair 1 on, for tables of 2^20 entries per level and more (round 5: at 2^20,
+    // wanjinyou_big.yaml's own size, the binned pipeline takes the step from 1.37 to 1.31 ms -- profiles/r05_big20_binned_ab.txt)
 #if F2N_DEBUG_BUILD  // (measurement knobs of the debug variant: first binned pair, 8 = off; smallest table that takes the binned path)
     static const int binned_p0 = []() {
       const char* e = std::getenv("F2N_BINNED_GATHER_P0");
@@ -331,10 +332,10 @@ Tensor Hash3DAnchored::QueryDensityPreAct(const Tensor& points, const Tensor& an
     }();
     static const int binned_min_log2 = []() {
       const char* e = std::getenv("F2N_BINNED_GATHER_MIN_LOG2");
-      return e != nullptr ? std::atoi(e) : 21;
+      return e != nullptr ? std::atoi(e) : 20;
     }();
 #else
-    constexpr int binned_p0 = 1, binned_min_log2 = 21;
+    constexpr int binned_p0 = 1, binned_min_log2 = 20;
 #endif
     const int level_entries = (int) (pool_size_ / N_LEVELS);
     if (binned_p0 < 8 && level_entries >= (1 << binned_min_log2) && level_entries <= (1 << 22) && n >= 65536 && n <= 1536 * 1024) {

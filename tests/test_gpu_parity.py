@@ -626,7 +626,8 @@ def test_partitioned_gather_equals_fused_forward(hip, fox_state, fox_golden):
 
 
 @pytest.mark.parametrize("log2_t,n,p0,clump", [(21, 100003, 3, False), (21, 70001, 0, True), (22, 131072, 5, False), (21, 1, 0, False),
-                                                   (21, 1537, 1, True), (21, 0, 0, False)])
+                                                   (21, 1537, 1, True), (21, 0, 0, False),
+                                                   (20, 120001, 1, False), (20, 66000, 1, True)])  # 2^20: wanjinyou_big.yaml's own size (round 5)
 def test_binned_gather_equals_partitioned_gather(hip, fox_state, log2_t, n, p0, clump):
     """The slice-binned gather of the big tables (requests binned by 4096-entry table slice, slices served from LDS) writes the
     planes of the partitioned gather bit for bit -- for clumped points (a few slices take most of a chunk's requests), for
