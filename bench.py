@@ -581,7 +581,8 @@ def main():
             # per-workload counter files (profiles/run_profiles.sh): the headline workload, or the big-table stress points
             tfile = TRAFFIC_FILE
             if args.preset == "wanjinyou_big":  # (2^21 and up: the slice-binned gather of round 4, four kernels behind one call)
-                tfile = os.path.join(ROOT, "profiles", ("r04_big%d_traffic.json" if log2 >= 21 else "r03_big%d_traffic.json") % log2)
+                # (the newest counter pass of this table size: round 5 re-took 2^20 after the binned gather was extended to it)
+                tfile = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_big%d_traffic.json" % (r, log2)) for r in (5, 4, 3)) if os.path.exists(f)), "")
             elif args.preset != "wanjinyou" or args.log2 not in (0, 19) or args.rays != 8192:
                 tfile = ""  # (no counters were collected for this workload)
             traffic_source = None

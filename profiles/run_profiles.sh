@@ -6,10 +6,11 @@
 #       both -> profiles/<tag>_traffic.json (bytes per launch; FETCH_SIZE doubled, the gfx950 correction of the guide)
 #   3. --pmc SQ_*             : issue / wait breakdown         -> profiles/<tag>_pmc_sq.csv
 #   4. --pmc TCC_HIT_sum TCC_MISS_sum : L2 hit / miss requests -> profiles/<tag>_pmc_tcc.csv   (PASSES="... tcc")
-# Counter passes never share a run with tracing (gpurun refuses that combination).
+# Counter passes never share a run with tracing (gpurun refuses that combination).  Every pass runs under `timeout` (round 5: rocprofv3 was seen
+# to hang in its finalisation behind a finished workload; the results database is complete by then and is summarised all the same).
 # Environment: BENCH_EXTRA = extra bench.py arguments (e.g. "--preset wanjinyou_big --log2 22"), PASSES = which passes to run.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 BENCH_EXTRA=${BENCH_EXTRA:-}
 PASSES=${PASSES:-"stats fetch write sq"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -19,11 +20,11 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-converged $BENCH_EXTRA"
 for k in $PASSES; do
   case $k in
-    stats) rocprofv3 --kernel-trace --stats -d $OUT/stats -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err ;;
-    fetch) rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch.err ;;
-    write) rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write.err ;;
-    sq) rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $OUT/sq -- $BENCH > /dev/null 2> $OUT/sq.err ;;
-    tcc) rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/tcc -- $BENCH > /dev/null 2> $OUT/tcc.err ;;
+    stats) timeout ${PASS_TIMEOUT:-200} rocprofv3 --kernel-trace --stats -d $OUT/stats -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err ;;
+    fetch) timeout ${PASS_TIMEOUT:-200} rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch.err ;;
+    write) timeout ${PASS_TIMEOUT:-200} rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write.err ;;
+    sq) timeout ${PASS_TIMEOUT:-200} rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $OUT/sq -- $BENCH > /dev/null 2> $OUT/sq.err ;;
+    tcc) timeout ${PASS_TIMEOUT:-200} rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/tcc -- $BENCH > /dev/null 2> $OUT/tcc.err ;;
   esac
 done
 cd $ROOT
