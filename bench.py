@@ -404,6 +404,7 @@ def main():
                     "fit into LDS, 1 out of LDS; -1 = host default")
     ap.add_argument("--optimistic-pack", type=int, default=-1, help="A/B: 1 packs a speculatively sampled batch right behind its march "
                     "(and again only if a leaf died), 0 behind the stat update; -1 = host default")
+    ap.add_argument("--dp-buckets", type=int, default=0, help="data-parallel runs: table all-reduce in that many buckets (0 = the host's default, 4; 1 = one all-reduce)")
     ap.add_argument("--dp-overlap", type=int, default=-1, help="data-parallel runs: 1 pipelined / 0 blocking gradient exchange; -1 = default (pipelined)")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
     args = ap.parse_args()
@@ -483,6 +484,8 @@ def main():
         from f2_nerf_amd import parallel
         # per step: all-reduce(AVG) of the 17*2^log2-half active prefix of the fp16 hash-gradient table + MLP/app_emb
         # gradients, and all-reduce(MAX) of the octree occupancy votes (f2-nerf_amd/parallel.py)
+        if args.dp_buckets > 0:
+            runtime.host().dp_set_table_buckets(args.dp_buckets)
         # (--dp-overlap 1 / 0 force the pipelined / blocking exchange; a forced one-rank world installs its hooks too)
         parallel.attach(runner, log2, overlap=None if args.dp_overlap < 0 else args.dp_overlap == 1, hooks_for_one_rank=(world == 1))
 

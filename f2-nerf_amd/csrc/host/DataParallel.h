@@ -35,6 +35,8 @@ class DataParallel {
   void BroadcastStates();           // rank 0's checkpoint vector -> every rank (collective)
   int rank() const { return rank_; }
   int world() const { return world_; }
+  // table all-reduce buckets of the NEXT Attach (default kTableBuckets; 1 = the whole prefix in one all-reduce: A/B, bench.py --dp-buckets)
+  static int table_buckets;
   int CommRanks() const;
   int64_t BucketCallbacks() const { return n_bucket_callbacks_; }  // table ranges the scatter reported while it ran            // what RCCL itself reports for the communicator (ncclCommCount)
 

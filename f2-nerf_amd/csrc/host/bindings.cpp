@@ -99,6 +99,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_readonly("n_images", &Dataset::n_images_)
       .def_readonly("height", &Dataset::height_)
       .def_readonly("width", &Dataset::width_);
+  m.def("dp_set_table_buckets", [](int n) { DataParallel::table_buckets = n; });  // table all-reduce buckets of the next attach (A/B)
   m.def("dp_new_unique_id", []() {  // rank 0: the id every rank passes to attach_data_parallel
     auto id = DataParallel::NewUniqueId();
     return py::bytes(reinterpret_cast<const char*>(id.data()), id.size());
