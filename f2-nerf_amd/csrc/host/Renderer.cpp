@@ -380,6 +380,11 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
         edge_samples_to(F32P(pts_full), I32P(anchors_full), 3, F32P(pts_all), I32P(vol_all));
       }
       pack_done();
+      if (digest_taps_ && train) {
+        DigestTap(TAP_PTS_PRE, sample_result_.pts);
+        DigestTap(TAP_DT_PRE, sample_result_.dt);
+        DigestTap(TAP_ANCHORS_PRE, sample_result_.anchors.select(1, 0));
+      }
       f0_full = field->QueryDensityPreAct(pts_full, anchors_full, /*keep_features=*/true);
       f0p = F32P(f0_full) + front;
       if (digest_taps_ && train) DigestTap(TAP_EDGE, pts_full.narrow(0, 0, front));
@@ -388,6 +393,11 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     } else {
       // the pre-pass keeps the hash features it gathers: the grad pass below reuses them for the surviving samples
       pack_done();
+      if (digest_taps_ && train) {
+        DigestTap(TAP_PTS_PRE, sample_result_.pts);
+        DigestTap(TAP_DT_PRE, sample_result_.dt);
+        DigestTap(TAP_ANCHORS_PRE, sample_result_.anchors.select(1, 0));
+      }
       f0_full = field->QueryDensityPreAct(sample_result_.pts, sample_result_.anchors, /*keep_features=*/true);
       f0p = F32P(f0_full);
     }

@@ -235,7 +235,10 @@ class Renderer : public Pipe {
   // int64 per (step, tap), on the device until read (ExpRunner.step_digest).  Two trainings that part are bisected to the
   // first array that differs.  One small reduction launch per tap and step: off unless asked for.
   enum { TAP_PTS, TAP_DT, TAP_ANCHORS, TAP_F0, TAP_SURVIVORS, TAP_BG, TAP_EDGE, TAP_COLORS, TAP_TABLE_GRAD, TAP_SMALL_GRADS, TAP_TABLE,
-         TAP_FIELD_MLP, TAP_COLOR_MLP, TAP_APP_EMB, TAP_GRAD_BEFORE, TAP_PTS_ALL_AFTER, TAP_VOL_ALL_AFTER, TAP_FIELD_X, TAP_DFEAT, N_TAPS };
+         TAP_FIELD_MLP, TAP_COLOR_MLP, TAP_APP_EMB, TAP_GRAD_BEFORE, TAP_PTS_ALL_AFTER, TAP_VOL_ALL_AFTER, TAP_FIELD_X, TAP_DFEAT,
+         // the same arrays IN FRONT of the kernel that consumes them: a tap pair that differs inside one run is an array that changed while
+         // (or after) it was read -- a late write from another stream -- and needs no second run to compare with
+         TAP_PTS_PRE, TAP_DT_PRE, TAP_ANCHORS_PRE, TAP_PTS_ALL_PRE, TAP_VOL_ALL_PRE, N_TAPS };
   bool digest_taps_ = false;
   Tensor digest_tap_sums_;  // int64 [kDigestRing, N_TAPS]
   void DigestTap(int tap, const Tensor& t);

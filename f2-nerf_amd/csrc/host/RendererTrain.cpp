@@ -117,6 +117,12 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
                          VoidP(shader->mlp_->params_h_), VoidP(shade_x), shader->mlp_->loss_scale_, F32P(dfeat) + F2N_MLP_OUT_PAD * so,
                          F32P(shader->mlp_->grad_scaled_), fr.emb ? F32P(app_emb_grad_) : nullptr,
                          fr.emb ? (int) app_emb_grad_.size(0) : 0, F32P(df0c), /*defer_reduce=*/fr.dyn ? 1 : 0));
+  if (digest_taps_ && fr.dyn) {  // (the scatter's point / volume rows in FRONT of it: compared with the taps behind it, in the same run)
+    const int64_t rows = fr.pts_all.size(0);
+    Tensor live = torch::arange(rows, DevI32()).lt(fr.n_kept_dev + (int) so).to(torch::kInt32);
+    DigestTap(TAP_PTS_ALL_PRE, fr.pts_all.view(torch::kInt32).sum(1, false, torch::kInt64) * live);
+    DigestTap(TAP_VOL_ALL_PRE, fr.vol_all.to(torch::kInt64) * live);
+  }
   if (fr.dyn) {
     field->grad_clean_ = false;
     F2N_TIMED_CALL("field_bwd", f2n_field_bwd_dyn(st, n, n_dev, 2 * n_edge, field->n_volumes_, I32P(field->prim_pool_),

@@ -89,7 +89,8 @@ def one_run():
 runs = []
 DIGESTS = []
 TAPS = []
-TAP_NAMES = ["seq", "pts", "dt", "anchors", "f0", "survivors", "bg", "edge", "colors", "table_grad", "small_grads", "table", "field_mlp", "color_mlp", "app_emb", "grad_before", "pts_all_after", "vol_all_after", "field_x", "dfeat"]
+TAP_NAMES = ["seq", "pts", "dt", "anchors", "f0", "survivors", "bg", "edge", "colors", "table_grad", "small_grads", "table", "field_mlp", "color_mlp", "app_emb", "grad_before", "pts_all_after", "vol_all_after", "field_x", "dfeat",
+             "pts_pre", "dt_pre", "anchors_pre", "pts_all_pre", "vol_all_pre"]
 for r in range(args.runs):
     if args.side_delay or args.pollute:
         b, c, m, per = [int(v) for v in args.side_delay[(r - 1) % len(args.side_delay)].split(":")] if (r > 0 and args.side_delay) else (0, 0, 0, 1)
@@ -140,3 +141,13 @@ if args.taps:
             print("taps: run %d parts from run 0 at step seq %d, first in (pipeline order): %s" % (r, int(a[i, 0]), ", ".join(cols)))
             for j in range(max(0, i - 1), min(k, i + 2)):
                 print("   run0 %s\n   run%d %s" % (a[j].tolist(), r, b[j].tolist()))
+
+if args.taps:
+    # inside ONE run: an array whose checksum in front of its consumer differs from the one behind it changed in between
+    PAIRS = [("pts_pre", "pts"), ("dt_pre", "dt"), ("anchors_pre", "anchors"), ("pts_all_pre", "pts_all_after"), ("vol_all_pre", "vol_all_after")]
+    for r, a in enumerate(TAPS):
+        for pre, post in PAIRS:
+            i, j = TAP_NAMES.index(pre), TAP_NAMES.index(post)
+            bad = np.nonzero(a[:, i] != a[:, j])[0]
+            print("pre/post: run %d  %-12s vs %-14s  steps where the array changed around its consumer: %d%s" %
+                  (r, pre, post, len(bad), ("  first at seq %d" % int(a[bad[0], 0])) if len(bad) else ""))
