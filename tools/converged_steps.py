@@ -18,7 +18,7 @@ ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 au
 ap.add_argument("--march-blocks-sweep", default="", help="v1,v2,...: repeat the timed steps with the speculative march on that many persistent blocks (0: classic)")
 ap.add_argument("--native", action="store_true", help="time ExpRunner::Train's own loop (fresh batches drawn on the device every iteration) instead of python-driven steps on resident batches")
 ap.add_argument("--depth", type=int, default=-1, help="sampling pipeline depth of the timed steps (1 / 2; default: the host's)")
-ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob")
+ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob (knobs exist in the debug variant only: F2N_DEBUG_BUILD=1; most are read once per process)")
 args = ap.parse_args()
 st = fox_data.load_state()
 sc, images = fox_data.scene(args.factor)
