@@ -157,9 +157,12 @@ int ExpRunner::BatchSizeFor(int64_t seq) {
   if (want >= ema_base_seq_) {
     // (a streaming step's count is resolved at the top of the next step; a Train() call that starts right behind one asks earlier)
     if (renderer_->count_pending_ && renderer_->pending_count_seq_ <= want + 1) renderer_->ResolvePendingCount();
+    // (a step that recorded nothing -- the first step of a data-parallel run -- falls back on the step before it; the ring holds the
+    // last Renderer::kEmaRing steps, and the draw that asks is at most a handful of steps ahead of the newest record)
     int64_t s = want;
-    while (s >= ema_base_seq_ && !renderer_->EmaAfter(s, &ema)) s--;  // (a step that recorded nothing: data-parallel first step)
-    if (s < ema_base_seq_) ema = ema_base_value_;
+    const int64_t floor_seq = std::max(ema_base_seq_, want - Renderer::kEmaRing);
+    while (s >= floor_seq && !renderer_->EmaAfter(s, &ema)) s--;
+    if (s < floor_seq) ema = s < ema_base_seq_ ? ema_base_value_ : global_data_pool_->meaningful_sampled_pts_per_ray_;
   }
   return int(pts_batch_size_ / ema) >> 4 << 4;
 }
