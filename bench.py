@@ -255,8 +255,6 @@ def converged_leg(args, st, dev):
     ds = runtime.make_dataset(sc, images)
     runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022, device=dev)
     runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
-    if args.speculation_order >= 0:
-        runner.speculation_order = args.speculation_order
     if args.speculation_depth >= 1:
         runner.speculation_depth = args.speculation_depth
     if args.march_blocks >= 0:
@@ -393,17 +391,8 @@ def main():
                     "spec_depth_); -1 = host default")
     ap.add_argument("--march-blocks", type=int, default=-1, help="A/B: > 0 marches speculative batches on that many persistent one-wave "
                     "blocks (rays sorted by leaf count), 0 on one block per four rays; -1 = host default")
-    ap.add_argument("--march-blocks-near", type=int, default=-1, help="A/B: the same for batches begun ONE step ahead; -1 = host default")
-    ap.add_argument("--spec-at-step-end", type=int, default=-1, help="A/B: small trees: 1 begins the batch after next when a step's "
-                    "backward is queued, 0 at the top of the next step; -1 = host default")
-    ap.add_argument("--knob", action="append", default=[], help="A/B: NAME=VALUE sets an ExpRunner property (tail_repair, fuse_composite, "
-                    "pregen_draws, optimistic_pack, ...) on the headline runner; repeatable")
-    ap.add_argument("--speculation-order", type=int, default=-1, help="A/B of where the speculative sampling of the next batch "
-                    "starts (Renderer.h spec_order_: 1 where the step begins, 0 behind its random draws); -1 = host default")
-    ap.add_argument("--lds-octree", type=int, default=-1, help="A/B: 0 walks the octree through the L2s even when its interior nodes "
-                    "fit into LDS, 1 out of LDS; -1 = host default")
-    ap.add_argument("--optimistic-pack", type=int, default=-1, help="A/B: 1 packs a speculatively sampled batch right behind its march "
-                    "(and again only if a leaf died), 0 behind the stat update; -1 = host default")
+    ap.add_argument("--knob", action="append", default=[], help="A/B: NAME=VALUE sets an ExpRunner property (tail_repair, march_blocks, "
+                    "speculation_depth, ...) on the headline runner; repeatable")
     ap.add_argument("--dp-buckets", type=int, default=0, help="data-parallel runs: table all-reduce in that many buckets (0 = the host's default, 4; 1 = one all-reduce)")
     ap.add_argument("--dp-overlap", type=int, default=-1, help="data-parallel runs: 1 pipelined / 0 blocking gradient exchange; -1 = default (pipelined)")
     ap.add_argument("--diag-no-nan-check", action="store_true", help="diagnostic only: drop the per-step gradient finiteness check")
@@ -462,23 +451,13 @@ def main():
     if args.diag_no_nan_check:
         runner.check_nan = False
     runner.speculative_sampling = {"auto": 2, "on": 1, "off": 0}[args.speculation]
-    if args.speculation_order >= 0:
-        runner.speculation_order = args.speculation_order
     if args.speculation_depth >= 1:
         runner.speculation_depth = args.speculation_depth
     if args.march_blocks >= 0:
         runner.march_blocks = args.march_blocks
-    if args.march_blocks_near >= 0:
-        runner.march_blocks_near = args.march_blocks_near
-    if args.spec_at_step_end >= 0:
-        runner.spec_at_step_end = bool(args.spec_at_step_end)
     for kv in args.knob:
         k, v = kv.split("=")
         setattr(runner, k, type(getattr(runner, k))(int(v)))
-    if args.lds_octree >= 0:
-        runner.lds_octree = bool(args.lds_octree)
-    if args.optimistic_pack >= 0:
-        runner.optimistic_pack = bool(args.optimistic_pack)
 
     if dp:
         from f2_nerf_amd import parallel

@@ -319,7 +319,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   }
   renderer_->async_count_ = false;
   renderer_->after_octree_update_ = nullptr;
-  if (prefetch && out.has_samples && spec_at_step_end_) renderer_->SpecBeginAtStepEnd();  // (small trees: the batch after next, see Renderer.h)
+  if (prefetch && out.has_samples) renderer_->SpecBeginAtStepEnd();  // (small trees: the batch after next, see Renderer.h)
   renderer_->next_batch_ = renderer_->next2_batch_ = Renderer::NextBatch();
   ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)
   TrainStats stats;

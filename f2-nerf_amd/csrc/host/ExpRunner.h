@@ -105,7 +105,6 @@ class ExpRunner {
   float gradient_scaling_start_, gradient_scaling_end_;
   float cur_lr_ = 0.f;
   bool check_nan_ = true;
-  bool spec_at_step_end_ = true;  // small trees: begin the batch after next when this step's backward is queued (A/B knob)
   int async_counts_ = 1;  // 1: streaming steps keep the survivor count on the device; 0: always read it back (as Render does); 2: never read it back in TrainStep (tests)
   int optim_steps_ = 0;
   // The data-parallel gradient exchange and its place in the step (GradSyncPipeline.h): sync_.blocking = all-reduce in front

@@ -175,7 +175,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor oct_tr = torch::empty({k_cap}, DevI32());  // trans_idx of every listed leaf (the march would re-read the node)
   // (a tree whose interior nodes fit into a CU's LDS is walked out of LDS: the walk is a chain of dependent record reads, and
   // it is prefetched underneath the previous step's hash gather, behind whose L2 traffic each of those reads would queue)
-  if (lds_octree_ && oct.n_interior_ >= 1 && oct.n_interior_ <= f2n_oct_lds_max_interior()) {
+  if (oct.n_interior_ >= 1 && oct.n_interior_ <= f2n_oct_lds_max_interior()) {
     F2N_TIMED_CALL("oct_intersect", f2n_oct_intersect_strided_lds(st, n_rays, max_oct_intersect_per_ray_,
                                     oct.node_search_order_.data_ptr<uint8_t>(), F32P(rays_o), F32P(rays_d), global_near_, far,
                                     VoidP(oct.tree_nodes_gpu_), I32P(oct_se), I32P(oct_idx), F32P(oct_nf), I32P(totals), I32P(oct_tr),
@@ -195,7 +195,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   Tensor s_anchors = torch::empty({slots, 2}, DevI32());
   Tensor first_oct_dis = torch::empty({n_rays, 1}, DevF32());
   const bool tail = speculative && tail_repair_ && max_oct_intersect_per_ray_ <= 2048;
-  const int persistent_blocks = persistent_near_ ? march_blocks_near_ : march_blocks_;  // (the grid this batch would be marched on)
+  const int persistent_blocks = march_blocks_;  // (the grid a batch that is begun two steps ahead is marched on)
   if (speculative && persistent_march_ && persistent_blocks > 0 && max_oct_intersect_per_ray_ <= 2048) {  // small persistent grid, rays sorted by leaf count
     Tensor order = torch::empty({n_rays + 1}, DevI32());  // [R] ray order + the group counter
     if (tail) {
@@ -231,12 +231,12 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
   p.generation = oct.generation_;
   p.spec_epoch = oct.epoch_ + 1;
   if (speculative) p.repair_flags = torch::empty({n_rays}, DevI32());
-  // Scan, count and pack follow the march at once -- also for a speculative batch (optimistic_pack_): its pack then runs in the
+  // Scan, count and pack follow the march at once -- also for a speculative batch that is begun one step ahead: its pack then runs in the
   // stretch of the step the march ends in (underneath the hash gather, when the walk ran out of LDS) instead of behind the
   // stat update, where it lands on field_shade_fwd, which is as memory-bound as the pack is (115 us against 59 alone:
   // profiles/r03_speculation_experiments.txt).  CompleteSpeculative scans again and packs again only if a leaf died since.
   // (not for a batch that is begun two steps ahead: where that pays, leaves die in most steps and the pack would run twice)
-  if (speculative && (!optimistic_pack_ || persistent_march_)) return;
+  if (speculative && persistent_march_) return;
   IssueScanAndPack(p);
   p.packed_once = speculative;
 }

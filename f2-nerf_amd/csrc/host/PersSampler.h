@@ -96,7 +96,7 @@ struct PendingSamples {
   // speculative: intersection and march were issued BEFORE the stat update they would normally wait for; scan / count / pack
   // are issued by CompleteSpeculative once that update is in the stream, behind the repair of the rays it invalidated
   bool speculative = false, completed = true;
-  bool packed_once = false;    // speculative and already scanned + packed behind its march (PersSampler::optimistic_pack_)
+  bool packed_once = false;    // speculative and already scanned + packed behind its march (one-step-ahead batches: PersSampler::BeginSamples)
   int spec_epoch = 0;          // first stat-update epoch whose deaths the speculative walk may have missed
   int64_t generation = 0;      // PersOctree::generation_ the samples were marched against
   Tensor repair_flags;         // (tail repair: repair_from, F2N_REPAIR_* or the list entry the march resumes from)
@@ -119,18 +119,14 @@ class PersSampler : public PtsSampler {
   bool CompleteSpeculative(PendingSamples& p);
   void IssueScanAndPack(PendingSamples& p);
   void IssueScan(PendingSamples& p);  // segment scan + count read-back
-  bool optimistic_pack_ = true;  // speculative batches are packed right behind their march, again only if a leaf died (A/B knob)
   // speculative batches record resumable march states and are repaired by list compaction + a march of the tail behind the
   // first dead leaf (f2n_oct_list_repair / f2n_ray_march_repair_tail) instead of a second walk and march from the origin
   bool tail_repair_ = true;
   // > 0: speculative batches are marched by this many persistent one-wave blocks, rays sorted by leaf count
   // (f2n_ray_march_persistent): a small footprint underneath the main queue's kernels, for batches that have two steps to finish
   int march_blocks_ = 512;
-  int march_blocks_near_ = 0;       // the same for batches begun ONE step ahead (0: one block per four rays); measurement knob
-  bool persistent_near_ = false;
   bool persistent_march_ = false;  // set by the Renderer around the BeginSamples of a batch that is begun two steps ahead
-  int LdsWalkMaxInterior() const { return lds_octree_ ? f2n_oct_lds_max_interior() : 0; }
-  bool lds_octree_ = true;  // small trees: walk them out of LDS (A/B knob; same bits either way)
+  int LdsWalkMaxInterior() const { return f2n_oct_lds_max_interior(); }  // small trees are walked out of LDS (same bits either way)
   // a FinishOctUpdate of the iteration in progress or of one of the `ahead` iterations behind it runs ProcOctree
   // (milestone / compact_freq, PersSampler.cu:605-614)
   bool MaintenanceDue(int ahead = 0) const;

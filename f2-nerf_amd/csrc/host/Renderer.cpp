@@ -174,7 +174,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   const bool train = gdp->mode_ == RunningMode::TRAIN;
   const int n_rays = rays_o.size(0);
   // The side stream of the next batch's speculative sampling (started further down, once this batch's samples are in hand) is
-  // ordered behind the point the main stream has reached NOW (spec_order_), not behind the draws and the edge samples that
+  // ordered behind the point the main stream has reached NOW, not behind the draws and the edge samples that
   // follow: the next batch's intersection then starts as soon as the previous step's Adam has finished and has the otherwise
   // idle device to itself while the main queue hands over the flag copy, the draws and the edge samples (~40 us); under the
   // gather that follows, each of its dependent node reads queues behind the gather's L2 traffic (0.06 ms alone, 0.36 ms
@@ -182,7 +182,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   // sequence -- background / edge samples of this step, then the next batch's march noise -- whichever way the next batch is
   // sampled; only the event moves.)
   spec_start_recorded_ = false;
-  if (spec_order_ == 1 && train && async_count && (next_batch_.valid || next2_batch_.valid) && speculative_sampling_ != 0) {
+  if (train && async_count && (next_batch_.valid || next2_batch_.valid) && speculative_sampling_ != 0) {
     spec_start_ev_.record();
     spec_start_recorded_ = true;
   }
@@ -286,10 +286,9 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       n_spec_fallback_++;
       return;
     }
-    ps->persistent_march_ = ahead >= 1 || ps->march_blocks_near_ > 0;  // (two steps to finish in: a few hundred resident waves do it)
-    ps->persistent_near_ = ahead < 1;
+    ps->persistent_march_ = ahead >= 1;  // (two steps to finish in: a few hundred resident waves do it)
     PreSampleSpecBegin(slot, nb.rays_o, nb.rays_d, nb.fineness, nb.seq);
-    ps->persistent_march_ = ps->persistent_near_ = false;
+    ps->persistent_march_ = false;
     n_speculative_++;
   };
   if (train) {

@@ -104,7 +104,6 @@ class Renderer : public Pipe {
   // The sequence number of the batch the running / next training-mode SampleAndFilter consumes: set by ExpRunner around every
   // step (its count of steps taken); -1: unkeyed (Render() called on its own: each call takes the next draw of every purpose).
   int64_t cur_seq_ = -1;
-  bool pregen_draws_ = true;
   PendingBatch pend_[kPendingSlots];
   int64_t n_spec_dropped_ = 0;  // batches begun ahead and thrown away (other rays asked for, tree replaced)
   int FindPending(const Tensor& rays_o, const Tensor& rays_d) const {
@@ -179,9 +178,6 @@ class Renderer : public Pipe {
   void SpecBeginAtStepEnd();
   bool PreSampleSpecComplete(int slot);  // false: could not be repaired (tree re-numbered): dropped
   at::cuda::CUDAEvent spec_start_ev_;
-  // 1: the side stream of a speculative sampling is ordered behind the point the main stream had reached when the step BEGAN,
-  // not behind the step's random draws / edge samples (SampleAndFilter); 0: behind the draws (A/B: bench.py --speculation-order)
-  int spec_order_ = 1;
   bool spec_start_recorded_ = false;
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,
                               bool async_count = false);
@@ -243,9 +239,6 @@ class Renderer : public Pipe {
   Tensor digest_tap_sums_;  // int64 [kDigestRing, N_TAPS]
   void DigestTap(int tap, const Tensor& t);
   bool async_count_ = false;        // set by ExpRunner::TrainStep for streaming steps
-  // streaming steps: compositing forward + loss + compositing backward as ONE launch (f2n_composite_train); false: the three
-  // launches it replaces (what tests compare it with)
-  bool fuse_composite_ = true;
   bool count_pending_ = false;
   int pending_count_rays_ = 0;
   int64_t total_kept_pts_ = 0, total_all_pts_ = 0;  // running totals over training-mode calls (resolved counts only)

@@ -211,7 +211,7 @@ void Renderer::PreGenerateStepDraws(int slot) {
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   const int n_edge = n_edge_pts_, n_rays = pb.s.n_rays;
   const int64_t front = 2 * (int64_t) n_edge;
-  if (!pregen_draws_ || n_edge <= 0 || forced_bg_.defined() || bg_color_type_ != BGColorType::rand_noise || ps->forced_edge_idx_.defined() ||
+  if (n_edge <= 0 || forced_bg_.defined() || bg_color_type_ != BGColorType::rand_noise || ps->forced_edge_idx_.defined() ||
       ps->forced_edge_coords_.defined() || !pb.s.o_pts.defined() || pb.s.extra_rows < front || ps->pers_octree_->n_edges_ <= 0)
     return;
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);

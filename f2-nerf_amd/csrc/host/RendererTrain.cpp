@@ -88,7 +88,7 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
   Tensor bg = fr.bg_color.contiguous();
   Tensor dfeat = torch::empty({n, F2N_MLP_OUT_PAD}, DevF32());
   Tensor drgb = torch::empty({std::max(n_kept, 1), 3}, DevF32());  // (WeightVarLoss backward rides inside the compositing backward)
-  if (fuse_composite_ && fr.dyn) {
+  if (fr.dyn) {
     // ---- compositing forward, loss, compositing backward: one launch (f2n_composite_train); the TV gradient goes straight
     // into the edge rows of dfeat, the loss values are completed by the step's deferred reduction below ----
     F2N_TIMED_CALL("composite_train", f2n_composite_train(st, n_rays, I32P(es.pts_idx_bounds), F32P(f0c), 1, F32P(es.dt), F32P(es.t), F32P(rgb),

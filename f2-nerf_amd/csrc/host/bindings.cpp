@@ -346,36 +346,19 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            })
       .def_readwrite("iter_step", &ExpRunner::iter_step_)
       .def_readwrite("check_nan", &ExpRunner::check_nan_)
-      .def_readwrite("spec_at_step_end", &ExpRunner::spec_at_step_end_)
       .def_readwrite("async_counts", &ExpRunner::async_counts_)
       .def_property("speculative_sampling",  // 0 / False never, 1 / True always, 2 while no leaf has died lately (default)
                     [](ExpRunner& r) { return r.renderer_->speculative_sampling_; },
                     [](ExpRunner& r, int mode) { r.renderer_->speculative_sampling_ = mode; })
-      .def_property("optimistic_pack",  // speculative batches packed right behind their march, again only if a leaf died (A/B knob)
-                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_; },
-                    [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->optimistic_pack_ = on; })
       .def_property("tail_repair",  // speculative batches repaired by list compaction + a march of the tail behind the first dead leaf (A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_ = on; })
       .def_property("march_blocks",  // > 0: speculative batches marched on that many persistent one-wave blocks (0: one block per 4 rays)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_; },
                     [](ExpRunner& r, int n) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_ = std::max(0, n); })
-      .def_property("march_blocks_near",  // the same for batches begun one step ahead (0: classic launch)
-                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_near_; },
-                    [](ExpRunner& r, int n) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_blocks_near_ = std::max(0, n); })
-      .def_property("lds_octree",  // small trees are walked out of LDS-resident child records (same bits; A/B knob)
-                    [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_; },
-                    [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->lds_octree_ = on; })
-      .def_property("pregen_draws",  // a prefetched batch brings its step's background / edge draws and edge samples along (A/B knob)
-                    [](ExpRunner& r) { return r.renderer_->pregen_draws_; }, [](ExpRunner& r, bool on) { r.renderer_->pregen_draws_ = on; })
-      .def_property("fuse_composite",  // streaming steps: compositing fwd + loss + bwd in one launch (A/B knob; same gradients)
-                    [](ExpRunner& r) { return r.renderer_->fuse_composite_; }, [](ExpRunner& r, bool on) { r.renderer_->fuse_composite_ = on; })
       .def_property("speculation_depth",  // the batch after next is begun two steps ahead: 1 never, 2 once the octree has outgrown the LDS walk, 3 always
                     [](ExpRunner& r) { return r.renderer_->spec_depth_; },
                     [](ExpRunner& r, int d) { r.FinishPending(); r.renderer_->DropPendingSamples(); r.renderer_->spec_depth_ = std::max(1, std::min(3, d)); })
-      .def_property("speculation_order",  // 1: the speculative sampler starts where the step begins, 0: behind its draws (Renderer.h)
-                    [](ExpRunner& r) { return r.renderer_->spec_order_; },
-                    [](ExpRunner& r, int bits) { r.renderer_->spec_order_ = bits; })
       .def("speculation_counters",  // batches sampled ahead of the stat update / behind it, rays repaired after a leaf died
            [](ExpRunner& r) {
              r.FinishPending();
