@@ -29,6 +29,7 @@ int DataParallel::CommRanks() const {
 
 DataParallel::~DataParallel() {
   if (n_buckets_ > 1) (void) f2n_set_scatter_buckets(0, nullptr, nullptr);
+  if (world_ > 1) KeyedUniforms::SetReplica(0);
   if (comm_ != nullptr) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
 }
 
@@ -61,6 +62,7 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
   rank_ = rank;
   world_ = world;
   runner->renderer_->dp_world_ = world;
+  KeyedUniforms::SetReplica(world > 1 ? rank : 0);  // (rays, march noise, background and edge draws: a stream per rank, KeyedDraws.h)
   ncclUniqueId id;
   std::memcpy(&id, unique_id.data(), sizeof(id));
   ncclComm_t comm;

@@ -100,6 +100,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_readonly("height", &Dataset::height_)
       .def_readonly("width", &Dataset::width_);
   m.def("dp_set_table_buckets", [](int n) { DataParallel::table_buckets = n; });  // table all-reduce buckets of the next attach (A/B)
+  // data-parallel replicas draw stream `rank` of every keyed purpose (KeyedDraws.h; the native attach sets it itself)
+  m.def("dp_set_replica", [](int rank) { KeyedUniforms::SetReplica(rank); });
+  m.def("keyed_draw_key", [](uint64_t seed, uint64_t purpose, int rank) {  // the Philox key of a purpose on a rank (no device needed)
+    return KeyedUniforms::KeyOf(seed, purpose, KeyedUniforms::SaltOf(rank));
+  });
   m.def("dp_new_unique_id", []() {  // rank 0: the id every rank passes to attach_data_parallel
     auto id = DataParallel::NewUniqueId();
     return py::bytes(reinterpret_cast<const char*>(id.data()), id.size());

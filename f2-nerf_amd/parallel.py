@@ -114,6 +114,9 @@ def attach(runner, log2_table_size, group=None, overlap=None, native=None, hooks
         return
     if hasattr(runner, "states") and hasattr(runner, "load_states"):
         broadcast_states(runner, group)
+    if hasattr(runner, "attach_data_parallel") and dist.get_world_size(group) > 1:
+        from . import runtime
+        runtime.host().dp_set_replica(dist.get_rank(group))  # a draw stream per rank (csrc/host/KeyedDraws.h), as the native attach does
     flat = runner.flatten_small_grads()
     table = runner.grad_buffers()[0].view(-1)[:active_table_halves(log2_table_size)]
     if overlap is None:

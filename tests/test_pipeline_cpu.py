@@ -323,3 +323,21 @@ def test_philox_reference_matches_the_published_known_answers():
     for c, k, want in kats:
         got = philox4x32_10(np.array([c], np.uint32), k)[0]
         assert tuple(int(v) for v in got) == want
+
+
+def test_data_parallel_replicas_draw_their_own_streams():
+    """Keyed draws (csrc/host/KeyedDraws.h) take their Philox key from (seed, purpose) -- and, in a data-parallel run, from the rank:
+    with one seed on every rank (the replicas' parameters and octree come from it) the ranks would otherwise draw the same rays in
+    ExpRunner::Train, the same march noise, background colours and edge samples, and N GPUs would render one batch N times.  Rank 0
+    (and a single GPU) keeps the key of seed ^ purpose: the single-GPU bits do not change."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    host = runtime.host()
+    purposes = (0xA0761D6478BD642F, 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03)  # rays, march noise, step draws (Dataset.h, PersSampler.h, Renderer.h)
+    for seed in (2022, 67280421310721, 0):
+        keys = set()
+        for p in purposes:
+            assert host.keyed_draw_key(seed, p, 0) == seed ^ p
+            for rank in range(8):
+                keys.add(host.keyed_draw_key(seed, p, rank))
+        assert len(keys) == len(purposes) * 8  # every (purpose, rank) its own key
