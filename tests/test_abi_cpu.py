@@ -125,3 +125,28 @@ def test_binding_and_host_extension_refuse_a_library_of_another_abi_version():
     import f2_nerf_amd  # noqa: F401
     from f2_nerf_amd import capi, runtime
     assert capi.ABI_VERSION == capi.lib().f2n_abi_version() == runtime.host().abi_version == 11
+
+
+def test_no_kernel_of_the_product_spills_vector_registers_or_uses_scratch(lib):
+    """Static resources of every gfx950 kernel hipcc has just built (tools/kernel_resources.py reads the code objects' metadata; the
+    table is committed as profiles/r05_kernel_resources.txt).  A training step must not touch scratch memory: a private array that
+    falls out of registers turns into HBM traffic no roofline figure of DESIGN.md accounts for.  Known and off the training path:
+    `sh_encode_kernel`, the stand-alone SH seam for degrees 1-8, indexes a 64-float private array dynamically (272 B of scratch);
+    the persistent march keeps a few scalars in spare vector lanes (SGPR spills, no memory).  The occupancy the design argues from is
+    checked too: the register-resident backward kernels keep two blocks per CU, the gather all eight waves per SIMD."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.table("")
+    assert len(rows) >= 100
+    by = {r["kernel"]: r for r in rows}
+    assert [r["kernel"] for r in rows if r["vgpr_spill"]] == []
+    assert sorted(r["kernel"] for r in rows if r["scratch"]) == ["sh_encode_kernel"]
+    assert all(r["kernel"].startswith("ray_march_persistent_kernel") for r in rows if r["sgpr_spill"])
+    for k in ("hash_gather_planes_kernel<true, false>", "hash_gather_planes_kernel<true, true>", "adam_fused_kernel"):
+        assert by[k]["waves_per_simd"] == 8, (k, by[k])
+    for k in ("shade_bwd_kernel", "field_bwd_kernel<2, 0, 2>", "hash_bin_accumulate_kernel"):
+        assert by[k]["waves_per_simd"] >= 2 and by[k]["vgpr"] + by[k]["agpr"] <= 256, (k, by[k])
+    assert by["field_shade_fwd_kernel"]["waves_per_simd"] >= 5  # (weights in LDS: 152 -> 80 registers, DESIGN section 3)
+    assert by["hash_bin_kernel"]["waves_per_simd"] >= 4
