@@ -11,7 +11,7 @@ import torch
 from . import build
 
 _lib = None
-ABI_VERSION = 11  # include/f2n_abi.h
+ABI_VERSION = 12  # include/f2n_abi.h
 
 
 class F2nError(RuntimeError):
@@ -60,6 +60,7 @@ def _ck(rc, name):
 
 _i = ctypes.c_int
 _f = ctypes.c_float
+_d = ctypes.c_double  # (the Adam betas: doubles as in torch::optim::AdamOptions, include/f2n_abi.h)
 
 
 def build_info():
@@ -564,10 +565,19 @@ def flex_acc_bwd(n_rays, include_this, dsum, se, out):
 
 
 # ---------------------------------------------------------------- optimiser
+def adam_coefficients(step, lr, beta1=0.9, beta2=0.99, eps=1e-15, weight_decay=0.0, grad_scale=1.0):
+    """The nine float scalars the Adam kernels are launched with (host function, no device): [lr / (1 - beta1^step),
+    sqrt(1 - beta2^step), beta1, beta2, 1 - beta1, 1 - beta2, eps, weight_decay, grad_scale]."""
+    out = (ctypes.c_float * 9)()
+    _ck(lib().f2n_adam_coefficients(_i(step), _f(lr), _d(beta1), _d(beta2), _f(eps), _f(weight_decay), _f(grad_scale), out),
+        "f2n_adam_coefficients")
+    return [float(v) for v in out]
+
+
 def adam_step(n, param, grad, grad_scale, grad_round_h16, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
               skip_flag=None, zero_grad=False):
     _ck(lib().f2n_adam_step(_stream(), _i(n), _p(param, "f32"), _p(grad, "f32"), _f(grad_scale), _i(int(grad_round_h16)),
-                            _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _f(beta1), _f(beta2), _f(eps),
+                            _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _d(beta1), _d(beta2), _f(eps),
                             _f(wd), _p(param_h, "h16", True), _i(int(zero_grad)), _p(skip_flag, "i32", True)), "f2n_adam_step")
 
 
@@ -592,7 +602,7 @@ def adam_small_groups(groups, step, lr, beta1, beta2, eps, zero_grad, flags=None
         a.weight_decay = float(g["weight_decay"])
         a.grad_round_h16 = int(bool(g.get("grad_round_h16", False)))
         a.check_finite = int(bool(g.get("check_finite", False)))
-    _ck(lib().f2n_adam_small_groups(_stream(), _i(len(groups)), arr, _i(step), _f(lr), _f(beta1), _f(beta2), _f(eps),
+    _ck(lib().f2n_adam_small_groups(_stream(), _i(len(groups)), arr, _i(step), _f(lr), _d(beta1), _d(beta2), _f(eps),
                                     _i(int(zero_grad)), _p(flags, "i32", True), _p(skip_flag, "i32", True)), "f2n_adam_small_groups")
 
 
@@ -614,8 +624,8 @@ def adam_fused(groups, table, step, lr, beta1, beta2, eps, zero_grad, skip_flag=
     t = table or {}
     _ck(lib().f2n_adam_fused(_stream(), _i(len(groups)), arr, _i(int(t.get("n", 0))), _p(t.get("param"), "f32", True),
                              _p(t.get("grad_h"), "h16", True), _f(float(t.get("grad_scale", 1.0))), _p(t.get("exp_avg"), "f32", True),
-                             _p(t.get("exp_avg_sq"), "f32", True), _p(t.get("param_h"), "h16", True), _i(step), _f(lr), _f(beta1),
-                             _f(beta2), _f(eps), _i(int(zero_grad)), _p(skip_flag, "i32", True)), "f2n_adam_fused")
+                             _p(t.get("exp_avg_sq"), "f32", True), _p(t.get("param_h"), "h16", True), _i(step), _f(lr), _d(beta1),
+                             _d(beta2), _f(eps), _i(int(zero_grad)), _p(skip_flag, "i32", True)), "f2n_adam_fused")
 
 
 def reduce_deferred():
@@ -629,7 +639,7 @@ def deferred_reset():
 def adam_step_h16grad(n, param, grad_h, grad_scale, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd, param_h,
                       zero_grad, skip_flag=None):
     _ck(lib().f2n_adam_step_h16grad(_stream(), _i(n), _p(param, "f32"), _p(grad_h, "h16"), _f(grad_scale),
-                                    _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _f(beta1), _f(beta2),
+                                    _p(exp_avg, "f32"), _p(exp_avg_sq, "f32"), _i(step), _f(lr), _d(beta1), _d(beta2),
                                     _f(eps), _f(wd), _p(param_h, "h16"), _i(int(zero_grad)),
                                     _p(skip_flag, "i32", True)), "f2n_adam_step_h16grad")
 

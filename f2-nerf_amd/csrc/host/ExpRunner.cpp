@@ -241,7 +241,7 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
     TORCH_CHECK(g.weight_decay == 0.f, "the table group has no weight decay (Hash3DAnchored.cpp:124-150)");
     if (g.name == "feat_pool") field->grad_clean_ = true;
   }
-  F2N_TIMED_CALL("adam_table", f2n_adam_fused(st, n_small, small, n_table, tp, tg, tscale, tm, tv, th, optim_steps_, cur_lr_, 0.9f, 0.99f,
+  F2N_TIMED_CALL("adam_table", f2n_adam_fused(st, n_small, small, n_table, tp, tg, tscale, tm, tv, th, optim_steps_, cur_lr_, /*betas: doubles, as AdamOptions holds them*/ 0.9, 0.99,
                                               1e-15f, /*zero_grad=*/1, skip));
   renderer_->small_grads_clean_ = true;  // every group's gradient was consumed and cleared (also on the skipped path)
 }

@@ -323,16 +323,20 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(F2nAdamGroupsDev gs, in
   }
 }
 
-static F2nAdamCoef f2n_adam_coef(int step, float lr, float beta1, float beta2, float eps, float wd, float grad_scale) {
-  const double bc1 = 1.0 - pow((double) beta1, (double) step);
-  const double bc2 = 1.0 - pow((double) beta2, (double) step);
+// The scalars of torch::optim::Adam::step as LibTorch forms them (adam.cpp): betas are doubles (AdamOptions), `1 - beta` and the bias
+// corrections `1 - pow(beta, step)` are double expressions, step_size = lr / bias_correction1 as well; each is narrowed to float only
+// where it meets a float tensor (mul_(beta1), add_(grad, 1 - beta1), addcmul_(..., 1 - beta2), div by sqrt(bias_correction2),
+// addcdiv_(..., -step_size)).
+static F2nAdamCoef f2n_adam_coef(int step, float lr, double beta1, double beta2, float eps, float wd, float grad_scale) {
+  const double bc1 = 1.0 - pow(beta1, (double) step);
+  const double bc2 = 1.0 - pow(beta2, (double) step);
   F2nAdamCoef k;
   k.lr_over_bc1 = (float) ((double) lr / bc1);
   k.sqrt_bc2 = (float) sqrt(bc2);
-  k.beta1 = beta1;
-  k.beta2 = beta2;
-  k.one_m_beta1 = (float) (1.0 - (double) beta1);
-  k.one_m_beta2 = (float) (1.0 - (double) beta2);
+  k.beta1 = (float) beta1;
+  k.beta2 = (float) beta2;
+  k.one_m_beta1 = (float) (1.0 - beta1);
+  k.one_m_beta2 = (float) (1.0 - beta2);
   k.eps = eps;
   k.weight_decay = wd;
   k.grad_scale = grad_scale;
@@ -365,8 +369,16 @@ __global__ void debug_spin_kernel(long long ticks) {
 
 extern "C" {
 
+int f2n_adam_coefficients(int step, float lr, double beta1, double beta2, float eps, float weight_decay, float grad_scale, float* out9) {
+  if (step < 1 || out9 == nullptr) return F2N_ERR_INVALID_ARG;
+  const F2nAdamCoef k = f2n_adam_coef(step, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  const float v[9] = {k.lr_over_bc1, k.sqrt_bc2, k.beta1, k.beta2, k.one_m_beta1, k.one_m_beta2, k.eps, k.weight_decay, k.grad_scale};
+  for (int i = 0; i < 9; i++) out9[i] = v[i];
+  return F2N_OK;
+}
+
 int f2n_adam_step(void* stream, int n, float* param, float* grad, float grad_scale, int grad_round_h16, float* exp_avg,
-                  float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float* exp_avg_sq, int step, float lr, double beta1, double beta2, float eps, float weight_decay,
                   void* param_h_or_null, int zero_grad, const int32_t* skip_flag) {
   if (n < 0 || step < 1) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
@@ -377,7 +389,7 @@ int f2n_adam_step(void* stream, int n, float* param, float* grad, float grad_sca
 }
 
 int f2n_adam_step_h16grad(void* stream, int n, float* param, void* grad_h, float grad_scale, float* exp_avg, float* exp_avg_sq,
-                          int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* param_h,
+                          int step, float lr, double beta1, double beta2, float eps, float weight_decay, void* param_h,
                           int zero_grad, const int32_t* skip_flag) {
   if (n < 0 || step < 1 || (n & 3) != 0 || param_h == nullptr) return F2N_ERR_INVALID_ARG;
   if (n == 0) return F2N_OK;
@@ -391,7 +403,7 @@ int f2n_adam_step_h16grad(void* stream, int n, float* param, void* grad_h, float
   return f2n_launch_status();
 }
 
-int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups, int step, float lr, float beta1, float beta2,
+int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups, int step, float lr, double beta1, double beta2,
                           float eps, int zero_grad, int32_t* flags, const int32_t* skip_flag) {
   if (n_groups < 1 || n_groups > F2N_ADAM_MAX_GROUPS || groups == nullptr || step < 1) return F2N_ERR_INVALID_ARG;
   F2nAdamGroupsDev gs = {};
@@ -416,7 +428,7 @@ int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups
 
 int f2n_adam_fused(void* stream, int n_groups, const F2nAdamGroup* groups, int n_table, float* table_param, void* table_grad_h,
                    float table_grad_scale, float* table_exp_avg, float* table_exp_avg_sq, void* table_param_h, int step, float lr,
-                   float beta1, float beta2, float eps, int zero_grad, const int32_t* skip_flag) {
+                   double beta1, double beta2, float eps, int zero_grad, const int32_t* skip_flag) {
   if (n_groups < 0 || n_groups > F2N_ADAM_MAX_GROUPS || (n_groups > 0 && groups == nullptr) || step < 1 || n_table < 0 ||
       (n_table & 3) != 0 || (n_table > 0 && (table_param == nullptr || table_grad_h == nullptr || table_param_h == nullptr)))
     return F2N_ERR_INVALID_ARG;
@@ -486,7 +498,7 @@ int f2n_debug_spin(void* stream, int microseconds) {
 }
 #endif
 
-int f2n_abi_version(void) { return 11; }
+int f2n_abi_version(void) { return 12; }
 #ifndef F2N_REFERENCE_NUMERICS
 #define F2N_REFERENCE_NUMERICS 0
 #endif

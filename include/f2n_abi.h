@@ -661,13 +661,21 @@ int f2n_draw_ray_batch_keyed(void* stream, int n_rays, uint64_t key, uint64_t se
  * Optimiser -- replaces torch::optim::Adam::step over the groups of Hash3DAnchored::OptimParamGroups
  * (Field/Hash3DAnchored.cpp:124-150), SHShader (Shader/SHShader.cpp:44-56), Renderer (Renderer.cpp:238-258):
  * beta = (0.9, 0.99), eps = 1e-15, L2 weight decay added to the gradient (torch Adam semantics).
+ * beta1 / beta2 are DOUBLES, as in torch::optim::AdamOptions (`opt->betas() = {0.9, 0.99}`, Hash3DAnchored.cpp:131): LibTorch forms
+ * 1 - beta and the bias corrections 1 - beta^step in double and only then narrows them to the tensors' float, so (float)(1 - 0.9) =
+ * 0.1f -- a float beta would give 1 - 0.9f = 0.100000024 and a second-moment coefficient that is 9e-7 off (ABI v12; up to v11 the
+ * betas were floats).  f2n_adam_coefficients returns the nine scalars every Adam kernel of this library is launched with:
+ * out[0..8] = -step_size's magnitude lr / (1 - beta1^step), sqrt(1 - beta2^step), beta1, beta2, 1 - beta1, 1 - beta2, eps,
+ * weight_decay, grad_scale.  Host function, no device needed (tests pin it against LibTorch's own scalars).
  * ------------------------------------------------------------------------------------------------- */
+int f2n_adam_coefficients(int step, float lr, double beta1, double beta2, float eps, float weight_decay, float grad_scale,
+                          float* out9 /*host*/);
 /* fp32 gradient (grad * grad_scale is the true gradient); optionally refreshes an h16 working copy.
  * grad_round_h16 != 0 reproduces the two binary16 roundings the reference applies to MLP parameter gradients:
  * g = f16(f16(grad) * grad_scale) (tcnn param-precision output while loss-scaled, Field/TCNNWP.cpp:214-215, then
  * autograd's cast of the unscaled gradient to the f16 dtype of the Function input, :111,:242). */
 int f2n_adam_step(void* stream, int n, float* param, float* grad, float grad_scale, int grad_round_h16,
-                  float* exp_avg, float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
+                  float* exp_avg, float* exp_avg_sq, int step, float lr, double beta1, double beta2, float eps,
                   float weight_decay, void* param_h_or_null, int zero_grad /* clear grad after use (also when skipped) */,
                   const int32_t* skip_flag /*device, or NULL*/);
 /* The small parameter groups of an iteration in ONE launch: finiteness flags (TCNNWP.cpp:234-240; layout of
@@ -686,8 +694,8 @@ typedef struct F2nAdamGroup {
   int grad_round_h16;
   int check_finite;
 } F2nAdamGroup;
-int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups, int step, float lr, float beta1,
-                          float beta2, float eps, int zero_grad, int32_t* flags /*device [3] or NULL*/,
+int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups, int step, float lr, double beta1,
+                          double beta2, float eps, int zero_grad, int32_t* flags /*device [3] or NULL*/,
                           const int32_t* skip_flag /*device, or NULL*/);
 /* Every group of an iteration in one launch: `groups` (HOST array of 0..4 descriptors; check_finite is ignored) as in
  * f2n_adam_small_groups and the h16-gradient table as in f2n_adam_step_h16grad, all predicated on *skip_flag (device, or
@@ -695,12 +703,12 @@ int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups
  * steps; no block-wide dependency inside (the flags-then-step single-block launch took 21 us in front of the table pass). */
 int f2n_adam_fused(void* stream, int n_groups, const F2nAdamGroup* groups, int n_table, float* table_param, void* table_grad_h,
                    float table_grad_scale, float* table_exp_avg, float* table_exp_avg_sq, void* table_param_h, int step, float lr,
-                   float beta1, float beta2, float eps, int zero_grad, const int32_t* skip_flag /*device, or NULL*/);
+                   double beta1, double beta2, float eps, int zero_grad, const int32_t* skip_flag /*device, or NULL*/);
 /* h16 gradient table produced by f2n_hash_bwd / f2n_field_bwd (true gradient = float(grad_h) * grad_scale,
  * grad_scale = 1/128): fuses the fp16->fp32 cast, the /128 (Hash3DAnchored.cu:232), Adam, the fp32->fp16
  * refresh of the table (Hash3DAnchored.cu:186) and the re-zeroing of the gradient (:222) in one pass. */
 int f2n_adam_step_h16grad(void* stream, int n, float* param, void* grad_h, float grad_scale, float* exp_avg,
-                          float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
+                          float* exp_avg_sq, int step, float lr, double beta1, double beta2, float eps,
                           float weight_decay, void* param_h, int zero_grad, const int32_t* skip_flag /*device, or NULL*/);
 /* skip_flag (both steps): when *skip_flag != 0 on the device the update is dropped -- parameters and moments stay,
  * an h16 gradient table is still cleared when zero_grad is set.  This is the `continue` of ExpRunner.cpp:131-134

@@ -375,3 +375,34 @@ def mlp_bwd(params, x, acts, dy, d_hidden, n_hidden, loss_scale=128.0):
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+# ---------------------------------------------------------------- lane-local pieces on their own (tests/test_lane_code_cpu.py)
+def slab(o, d, c, side, near, far):
+    o, d, c, side = _f32(o), _f32(d), _f32(c), _f32(side)
+    nf = np.ascontiguousarray(np.stack([np.full(len(o), near, np.float32), np.full(len(o), far, np.float32)], -1))
+    lib().oracle_slab(ctypes.c_int(len(o)), _p(o), _p(d), _p(c), _p(side), _p(nf))
+    return nf
+
+
+def warp(transes, trans_idx, pts):
+    transes, trans_idx, pts = _u8(transes), _i32(trans_idx), _f32(pts)
+    out = np.empty((len(pts), 3), np.float32)
+    jac = np.empty((len(pts), 3, 3), np.float32)
+    lib().oracle_warp(ctypes.c_int(len(pts)), _p(transes), _p(trans_idx), _p(pts), _p(out), _p(jac))
+    return out, jac
+
+
+def hash_cell(pt01, mul, prim, bias, local_size):
+    pt01, mul, prim, bias = _f32(pt01), _f32(mul), _i32(prim), _f32(bias)
+    ls = np.ascontiguousarray(local_size, np.uint32)
+    pos = np.empty((len(pt01), 8), np.uint32)
+    w = np.empty((len(pt01), 8), np.float32)
+    lib().oracle_hash_cell(ctypes.c_int(len(pt01)), _p(pt01), _p(mul), _p(prim), _p(bias), _p(ls), _p(pos), _p(w))
+    return pos, w
+
+
+def undistort(k4, uv):
+    k4, uv = _f32(k4), _f32(uv).copy()
+    lib().oracle_undistort(ctypes.c_int(len(uv)), _p(k4), _p(uv))
+    return uv

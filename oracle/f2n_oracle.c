@@ -1047,6 +1047,35 @@ int oracle_mlp_bwd(int n, int d_in, int d_hidden, int n_hidden, float loss_scale
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Lane-local pieces on their own (tests/test_lane_code_cpu.py compares the PRODUCT's device functions, compiled for the
+ * host from their source text, with these): slab test, warp + Jacobian, hash cell, undistortion.
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_slab(int n, const float* o, const float* d, const float* c, const float* side, float* near_far) {
+  for (int i = 0; i < n; i++) or_slab(o + 3 * i, d + 3 * i, c + 3 * i, side[i], near_far + 2 * i, near_far + 2 * i + 1);
+}
+
+void oracle_warp(int n, const uint8_t* trans, const int32_t* trans_idx, const float* p, float* out, float* jac) {
+  const OrTransInfo* tr = (const OrTransInfo*) trans;
+  for (int i = 0; i < n; i++) {
+    or_warp(tr + trans_idx[i], p + 3 * i, out + 3 * i);
+    or_warp_jac(tr + trans_idx[i], p + 3 * i, (float (*)[3]) (jac + 9 * i));
+  }
+}
+
+void oracle_hash_cell(int n, const float* pt01, const float* mul, const int32_t* prim, const float* bias,
+                      const uint32_t* local_size, uint32_t* pos, float* w) {
+  for (int i = 0; i < n; i++) {
+    OrCell c;
+    or_hash_cell(pt01 + 3 * i, mul[i], prim + 3 * i, bias + 3 * i, local_size[i], &c);
+    for (int k = 0; k < 8; k++) { pos[8 * i + k] = c.pos[k]; w[8 * i + k] = c.w[k]; }
+  }
+}
+
+void oracle_undistort(int n, const float* k4, float* uv) {
+  for (int i = 0; i < n; i++) or_undistort(k4 + 4 * i, uv + 2 * i, uv + 2 * i + 1);
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

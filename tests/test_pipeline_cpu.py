@@ -341,3 +341,36 @@ def test_data_parallel_replicas_draw_their_own_streams():
             for rank in range(8):
                 keys.add(host.keyed_draw_key(seed, p, rank))
         assert len(keys) == len(purposes) * 8  # every (purpose, rank) its own key
+
+
+def test_adam_restatement_is_libtorch_op_sequence_up_to_fma_contraction():
+    """oracle.pipeline.adam_step (what the GPU tests hold f2n_adam_* against, and what tests/test_lane_code_cpu.py holds the kernels'
+    own update function against bit for bit) versus the op sequence of LibTorch's Adam::step (torch/csrc/api/src/optim/adam.cpp, the
+    optimiser of ExpRunner.cpp:136) run with ATen itself: exp_avg.mul_(b1).add_(g, 1 - b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2);
+    denom = (exp_avg_sq.sqrt() / sqrt(bc2)).add_(eps); p.addcdiv_(exp_avg, denom, -lr / bc1).  Same scalars (doubles narrowed where
+    they meet the float tensors); ATen's kernels fuse `a + alpha * b` into one FMA (as nvcc does by default in the reference's CUDA
+    build -- DESIGN section 6, 'not reproducible'), the restatement and the product (-ffp-contract=off) round the product first.
+    With the FMA emulated in float64 the moments agree in EVERY element; without it they agree to the last place or two."""
+    import math
+    rng = np.random.default_rng(8)
+    n = 100000
+    F64 = np.float64
+    p = rng.standard_normal(n).astype(F32); g = (rng.standard_normal(n) * 1e-3).astype(F32)
+    m = (rng.standard_normal(n) * 1e-3).astype(F32); v = (rng.random(n) * 1e-6).astype(F32)
+    b1, b2, eps = 0.9, 0.99, 1e-15
+    for step, lr in ((1, 1e-2), (10, 1e-2), (5000, 3e-3)):
+        lr = float(F32(lr))
+        rp, rm, rv = op.adam_step(p, g, m, v, step, lr, b1, b2, eps, 0.0)
+        tp, tg, tm, tv = [torch.from_numpy(a.copy()) for a in (p, g, m, v)]
+        tm.mul_(b1).add_(tg, alpha=1 - b1)
+        tv.mul_(b2).addcmul_(tg, tg, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = (tv.sqrt() / math.sqrt(bc2)).add_(eps)
+        tp.addcdiv_(tm, denom, value=-(lr / bc1))
+        # the moments with ATen's fused multiply-adds spelled out: one rounding of alpha * b + a
+        fm = (g.astype(F64) * F64(F32(1 - b1)) + (m * F32(b1)).astype(F32).astype(F64)).astype(F32)
+        fv = (((F32(1 - b2) * g).astype(F32)).astype(F64) * g.astype(F64) + (v * F32(b2)).astype(F32).astype(F64)).astype(F32)
+        assert (fm == tm.numpy()).all() and (fv == tv.numpy()).all(), step
+        # ... and the restatement's separately rounded form stays within rounding of them
+        assert np.abs(rm - tm.numpy()).max() <= 2.0 ** -22 * np.abs(rm).max() and np.abs(rv - tv.numpy()).max() <= 2.0 ** -22 * np.abs(rv).max()
+        assert np.abs(rp - tp.numpy()).max() <= 4e-7 * np.abs(rp).max(), step
