@@ -14,6 +14,12 @@
   * modes (ExpRunner::Execute): train (ExpRunner::Train with checkpoints every save_freq and the final TestImages),
     test (TestImages of the latest checkpoint), render_path (RenderPath over poses_render.npy).  Image files are written with
     PIL; everything per-ray runs in the C++/HIP host (there is no Python in the training loop: ExpRunner::Train).
+  * data-parallel training (the reference is single-GPU): launched as N ranks -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 -m f2_nerf_amd.run ...` -- every rank builds the same scene from the same seed, the
+    C++ host attaches its RCCL communicator (parallel.attach: rank 0's state is broadcast, gradients are averaged and occupancy
+    votes max-combined inside TrainStep) and draws its own rays / noise / background (host/KeyedDraws.h: a stream per rank), so one
+    iteration trains on N x pts_batch_size samples; rank 0 writes checkpoints, logs and test images.  NOT run on hardware in this
+    build (every lease had one GPU): the same exchange is what bench.py --gpus N times.
 File IO and the command line are outside the hot path proper; this module exists so that a user of the
 reference finds the same entry point."""
 import glob
@@ -104,15 +110,28 @@ def main(argv=None):
     with open(os.path.join(exp_dir, "record", "runtime_config.yaml"), "w") as f:
         yaml.safe_dump(cfg, f)
     print("Working directory is", base_dir)
-    torch.manual_seed(2022)  # main.cpp:9
+    # one process per GPU when launched by torch.distributed.run (see the module docstring); a plain launch is rank 0 of 1
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    torch.cuda.set_device(dev)
+    torch.manual_seed(2022)  # main.cpp:9 (the same on every rank: the replicas' octree and parameters come from it)
     sc, ds = load_dataset(cfg, data_path)
-    runner, cfg, built = runtime.make_runner_from_cameras(sc["poses"], sc["intri"], sc["bounds"], sc["train_set"], cfg=cfg)
+    runner, cfg, built = runtime.make_runner_from_cameras(sc["poses"], sc["intri"], sc["bounds"], sc["train_set"], cfg=cfg, device=dev)
+    if world > 1:
+        from . import parallel
+        parallel.attach(runner, int(cfg["field"]["log2_table_size"]))
     ck_latest = os.path.join(exp_dir, "checkpoints", "latest")
     if bool(cfg.get("is_continue", False)):  # ExpRunner.cpp:56-58
         runner.load_checkpoint(ck_latest)
     mode = str(cfg.get("mode", "train"))
 
     def save_checkpoint():  # ExpRunner.cpp:205-219
+        if rank != 0:  # (replicas are identical: one writer)
+            return
         d = os.path.join(exp_dir, "checkpoints", "%08d" % runner.iter_step)
         os.makedirs(d, exist_ok=True)
         runner.save_checkpoint(d)
@@ -124,6 +143,8 @@ def main(argv=None):
             os.symlink(os.path.join(d, f), link)
 
     def test_images():  # ExpRunner.cpp:343-383
+        if rank != 0:
+            return None
         views = [float(v) for v in runner.test_images(ds)]
         out = {str(int(i)): p for i, p in zip(sc["test_set"], views[:-1])}
         out["mean_psnr"] = views[-1]
@@ -133,7 +154,9 @@ def main(argv=None):
         print("Mean psnr: %s" % views[-1])
         return out
 
-    if mode == "train":
+    if rank != 0 and mode != "train":
+        pass  # (the rendering modes are one rank's work; the others wait at the barrier below)
+    elif mode == "train":
         t = cfg["train"]
         end, save_freq, report = int(t["end_iter"]), int(t["save_freq"]), int(t["report_freq"])
         t0 = time.time()
@@ -144,7 +167,7 @@ def main(argv=None):
             # the loop, so the same 0.9 / 0.1 smoothing is applied over the report boundaries' batches instead
             nxt = min(end, (runner.iter_step // report + 1) * report, (runner.iter_step // save_freq + 1) * save_freq)
             s = runner.train(ds, nxt, 1)
-            if runner.iter_step % report == 0 or runner.iter_step >= end:
+            if rank == 0 and (runner.iter_step % report == 0 or runner.iter_step >= end):
                 torch.cuda.synchronize()
                 mse = max(float(s["mse"]), 1e-12)
                 psnr = 20 * np.log10(1 / np.sqrt(mse))
@@ -155,9 +178,10 @@ def main(argv=None):
                     runner.meaningful_per_ray, runner.iter_step / max(time.time() - t0, 1e-9), runner.cur_lr), flush=True)
             if runner.iter_step % save_freq == 0:
                 save_checkpoint()
-        with open(os.path.join(exp_dir, "train_info.txt"), "w") as f:
-            f.write("%f\n" % (time.time() - t0))
-        print("Train done, test.")
+        if rank == 0:
+            with open(os.path.join(exp_dir, "train_info.txt"), "w") as f:
+                f.write("%f\n" % (time.time() - t0))
+            print("Train done, test.")
         test_images()
     elif mode == "test":
         test_images()
@@ -171,6 +195,10 @@ def main(argv=None):
             save_png(os.path.join(exp_dir, "images", "%d_%d.png" % (runner.iter_step, idx)), runner.visualize_image(ds, idx))
     else:
         raise ValueError("unknown mode: %s" % mode)
+    if world > 1:
+        runner.flush()
+        dist.barrier()  # (rank 0 may still be rendering its test images)
+        dist.destroy_process_group()
     return 0
 
 
