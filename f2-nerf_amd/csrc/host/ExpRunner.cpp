@@ -268,7 +268,6 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   } seq_reset{renderer_.get()};
   gdp->mode_ = RunningMode::TRAIN;
   gdp->backward_nan_ = false;
-  const bool pipelined = sync_.pipelined && apply_optimizer;
   const bool prefetch = apply_optimizer && next_rays_o.defined() && next_rays_d.defined();
   // Pipelined: the previous step's gradient all-reduce is still in flight on RCCL's stream.  Ray sampling reads neither the
   // parameters nor the gradients, so it is issued first (unless the previous step already prefetched it) and runs
