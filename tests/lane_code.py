@@ -116,12 +116,14 @@ def source():
 
 
 _lib = None
+_tmp = None  # (kept for the life of the process: the loaded library lives in it)
 
 
 def lib():
-    global _lib
+    global _lib, _tmp
     if _lib is None:
-        tmp = tempfile.mkdtemp(prefix="f2n_lane_")
+        _tmp = tempfile.TemporaryDirectory(prefix="f2n_lane_")
+        tmp = _tmp.name
         cpp, so = os.path.join(tmp, "lane_code.cpp"), os.path.join(tmp, "liblane_code.so")
         with open(cpp, "w") as f:
             f.write(source())
