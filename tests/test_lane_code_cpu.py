@@ -153,7 +153,8 @@ def test_adam_scalars_are_the_ones_libtorch_forms_and_the_update_equals_the_orac
     torch::optim::AdamOptions) against the scalars of torch's Adam::step -- 1 - beta and 1 - beta^step formed in double, narrowed to
     float where they meet the float tensors -- and the kernels' update function with those scalars against the oracle's Adam."""
     import f2_nerf_amd  # noqa: F401
-    from f2_nerf_amd import capi
+    from f2_nerf_amd import build, capi
+    build.build_hip()  # (a no-op when the library is up to date; the entry point is a host function: no GPU)
     rng = np.random.default_rng(8)
     n = 50000
     for step, lr, wd in ((1, 1e-2, 0.0), (2, 3.3e-3, 1e-6), (10, 1e-2, 1e-6), (137, 7.7e-4, 0.0), (20000, 1e-3, 1e-6)):
