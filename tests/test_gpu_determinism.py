@@ -116,6 +116,27 @@ def test_keyed_draws_do_not_depend_on_when_or_how_often_they_are_made(fox_scene)
     assert not torch.equal(p[1], q[1])
 
 
+def test_replicas_of_a_data_parallel_run_draw_their_own_streams(fox_scene):
+    """With one seed on every rank (the replicas' parameters and octree come from it), what makes rank r's batches its own is the
+    salt of the keyed draws (host/KeyedDraws.h: key = seed ^ purpose ^ salt(rank); DataParallel::Attach sets it): another replica
+    draws other rays for the same (seed, batch number), the same replica the same ones again, and rank 0 the single-GPU ones."""
+    from f2_nerf_amd import runtime
+    st, sc, images = fox_scene
+    torch.manual_seed(77)
+    host = runtime.host()
+    a = runtime.make_dataset(sc, images)
+    x0 = a.rand_rays_data(4096, 1, 5)
+    try:
+        host.dp_set_replica(3)
+        x3 = a.rand_rays_data(4096, 1, 5)
+        y3 = a.rand_rays_data(4096, 1, 5)
+    finally:
+        host.dp_set_replica(0)
+    z0 = a.rand_rays_data(4096, 1, 5)
+    assert not torch.equal(x0[1], x3[1])
+    assert torch.equal(x3[1], y3[1]) and torch.equal(x0[1], z0[1])
+
+
 def test_in_kernel_draws_are_philox_of_their_key():
     """The march noise a prologue launch draws for itself is Philox4x32-10 of (key, seq, element) bit for bit (integer work: exact),
     mapped like PersSampler.cu:372-381: ((u - .5) + 1) * fineness."""
