@@ -1,0 +1,92 @@
+"""Test infrastructure -- NOT part of the product.  Builds tests/wave_emul/_build/libf2n_emul.so: the product's kernel sources
+(f2-nerf_amd/csrc/*.hip, read in place) compiled for x86-64 by ROCm's clang++ against the wavefront emulation of
+tests/wave_emul/include/hip/hip_runtime.h.  The library exports the same C-ABI as libf2n_hip.so (include/f2n_abi.h), with host
+pointers where the product takes device pointers.
+
+The source text is compiled as it is, except for two spellings that only exist for the GPU target and are rewritten on the way
+(the rewritten copies live in _build/, never in the tree; REWRITES lists them and the build reports how often each fired):
+  * `extern __shared__ T name[];`      -> `T* name = (T*) wemu::dyn_lds();`   (dynamic LDS is the emulator's buffer)
+  * `asm volatile("" : "+v"(x));`      -> `asm volatile("" : "+r"(x));`        (an optimisation barrier on a VGPR)
+"""
+import concurrent.futures
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "f2-nerf_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libf2n_emul.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+SOURCES = ["sampler.hip", "render.hip", "dataset.hip", "octree.hip", "optim.hip", "workspace.hip", "field.hip", "shade.hip",
+           "mlp_generic.hip"]
+HEADERS = ["f2n_dev.h", "rows_dev.h", "mlp_dev.h"]
+REWRITES = [
+    (re.compile(r"extern\s+__shared__\s+([A-Za-z_][A-Za-z_0-9 ]*?)\s+([A-Za-z_][A-Za-z_0-9]*)\s*\[\s*\]\s*;"),
+     r"\1* \2 = (\1*) wemu::dyn_lds();"),
+    (re.compile(r'asm\s+volatile\(""\s*:\s*"\+v"\(([A-Za-z_0-9]+)\)\);'), r'asm volatile("" : "+r"(\1));'),
+]
+# -ffp-contract=off: as the product build (f2-nerf_amd/build.py); binary16 arithmetic rounded after every operation, as the GPU's
+# native f16 instructions do (clang's default for x86 keeps excess precision inside an expression)
+FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Xclang", "-ffloat16-excess-precision=none",
+         "-mf16c", "-w", "-I" + os.path.join(HERE, "include"), "-I" + OUT]
+
+
+def _rewrite(text):
+    fired = []
+    for rx, to in REWRITES:
+        text, n = rx.subn(to, text)
+        fired.append(n)
+    return text, fired
+
+
+def build(sources=None, verbose=False, force=False):
+    sources = SOURCES if sources is None else sources
+    os.makedirs(os.path.join(OUT, "csrc"), exist_ok=True)
+    report = {}
+    newest = 0.0
+    for name in HEADERS + sources:
+        src = os.path.join(CSRC, name)
+        newest = max(newest, os.path.getmtime(src))
+        with open(src) as f:
+            text, fired = _rewrite(f.read())
+        report[name] = fired
+        dst = os.path.join(OUT, "csrc", name)
+        if not os.path.exists(dst) or open(dst).read() != text:
+            with open(dst, "w") as f:
+                f.write(text)
+    for dep in (os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "wemu_rt.cpp"), os.path.join(ROOT, "include", "f2n_abi.h"),
+                os.path.abspath(__file__)):
+        newest = max(newest, os.path.getmtime(dep))
+    # (csrc/f2n_dev.h includes "../../include/f2n_abi.h": the copies sit two levels below a directory that holds include/)
+    inc = os.path.join(OUT, "..", "..", "include")
+    tag = os.path.join(OUT, "sources.txt")
+    want = " ".join(sources)
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest and os.path.exists(tag) and open(tag).read() == want:
+        return LIB, report
+    jobs = [[CLANG] + FLAGS + ["-c", os.path.join(OUT, "csrc", s), "-o", os.path.join(OUT, s + ".o")] for s in sources]
+    jobs.append([CLANG] + FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(OUT, "wemu_rt.o")])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("wave_emul build failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, jobs))
+    run([CLANG, "-shared", "-fPIC"] + [j[-1] for j in jobs] + ["-o", LIB, "-lm"])
+    with open(tag, "w") as f:
+        f.write(want)
+    return LIB, report
+
+
+if __name__ == "__main__":
+    import sys
+    lib, rep = build(sources=sys.argv[1:] or None, verbose=True, force=True)
+    print(lib)
+    for k, v in rep.items():
+        print("  %-18s dynamic-LDS declarations rewritten: %d, VGPR barriers rewritten: %d" % (k, v[0], v[1]))
