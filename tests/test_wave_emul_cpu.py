@@ -61,7 +61,9 @@ def hip(emul_lib, monkeypatch):
     monkeypatch.setattr(capi, "_lib", emul_lib)
     monkeypatch.setattr(capi, "_p", host_pointer)
     monkeypatch.setattr(capi, "_stream", lambda: ctypes.c_void_p(0))
+    monkeypatch.setattr(capi, "_mapped", lambda t: host_pointer(t, "i32", allow_none=True))  # (a "mapped" mirror is a host tensor)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)  # (mapped host memory is host memory)
     monkeypatch.setattr(gp, "DEV", "cpu")
     # (on the GPU T() and N() copy by crossing the bus; here they must copy explicitly, or a kernel would update the oracle's inputs)
     monkeypatch.setattr(gp, "T", lambda a: torch.from_numpy(np.array(a, copy=True, order="C")))
@@ -85,14 +87,45 @@ def _on_the_emulator(name, params=None):
     return test
 
 
-# every test of tests/test_gpu_parity.py by name; None = with the GPU run's own parameters
+# every test of tests/test_gpu_parity.py by name (but test_errors_are_loud, which is about the product binding refusing CPU tensors --
+# the very thing the fixture above replaces --, test_sampler_full_size_properties -- 8192 rays twice: three minutes here -- and
+# test_workspace_growth_with_queued_kernels -- about launches that are still queued, which the emulator's never are);
+# None = with the GPU run's own parameters, otherwise the same test at sizes the emulator finishes in seconds (a cross-lane operation
+# costs it ~3 us: the 2^20 / 2^22 tables and the 700- / 1500-ray batches stay with the GPU run)
 _TESTS = {
     "test_sampler_golden": None,
+    "test_sampler_vs_oracle": ("seed,fineness,scale_by_dis,max_hits,n", [(1, 8.0, True, 1024, 150), (2, 2.0, False, 1024, 60), (3, 16.0, True, 5, 513)]),
+    "test_sampler_sample_cap": None,
     "test_normalize_dirs": None,
     "test_segment_scan": None,
+    "test_segment_scan_and_flags_write_their_host_mirror": None,
+    "test_edge_samples_and_occupancy": None,
+    "test_early_stop_and_votes_in_one_launch": None,
+    "test_edge_samples_from_uniforms_and_sampler_prologue": None,
+    "test_hash_forward_bit_exact": None,
+    "test_hash_forward_golden_and_linearity": None,
+    "test_hash_backward": None,
+    "test_hash_backward_owner_binned": ("log2", [14]),
+    "test_mlp_forward": None,
+    "test_mlp_backward": None,
+    "test_partitioned_gather_equals_fused_forward": None,
+    "test_binned_gather_equals_partitioned_gather": ("log2_t,n,p0,clump", [(21, 1, 0, False), (21, 1537, 1, True), (21, 0, 0, False), (20, 66000, 1, True)]),
+    "test_field_fused_forward_backward": None,
+    "test_field_forward_from_prepass_cache": None,
+    "test_field_and_shade_forward_in_one_launch": None,
+    "test_shade_fused_forward_backward": None,
+    "test_sh_encode": None,
     "test_segmented_ops_bit_exact": None,
     "test_early_stop_and_compaction": None,
+    "test_composite_forward_backward": None,
+    "test_composite_train_equals_three_launches": None,
     "test_adam": None,
+    "test_train_loss_and_gradients": None,
+    "test_nonfinite_flags_and_skipped_adam": None,
+    "test_adam_small_groups_equals_separate_launches": None,
+    "test_adam_fused_equals_separate_launches": None,
+    "test_img2world_rays_and_pixel_gather": None,
+    "test_empty_and_ragged_inputs": None,
 }
 for _name, _params in _TESTS.items():
     globals()[_name] = _on_the_emulator(_name, _params)

@@ -35,6 +35,7 @@ void* g_sched_sp = nullptr;
 Body g_body;
 void* g_closure;
 long g_counters[8];
+size_t g_dyn_bytes = 0;
 
 // callee-saved registers of the SysV x86-64 ABI + the stack pointer; nothing else survives a call anyway
 extern "C" void wemu_switch(void** save_sp, void* new_sp);
@@ -159,7 +160,7 @@ void execute(Fibre* wave, uint64_t mask, int n_lanes) {
 void run_block(int n_threads) {
   const int n_waves = (n_threads + 63) / 64;
   for (int t = 0; t < n_threads; t++) fibre_init(g_fibres[t], t, g_bdim);
-  memset(g_dyn_lds, 0xCD, kDynLds);
+  memset(g_dyn_lds, 0xCD, g_dyn_bytes);
   for (;;) {
     for (int w = 0; w < n_waves; w++) {
       Fibre* wave = g_fibres + 64 * w;
@@ -169,22 +170,22 @@ void run_block(int n_threads) {
           if (wave[l].state == READY) run(wave[l]);
         // every lane of the wave is parked or done: the lanes parked at the lowest cross-lane site form the next EXEC mask
         const void* site = nullptr;
-        int groups = 0;
+        bool divergent = false;
         for (int l = 0; l < n_lanes; l++) {
-          if (wave[l].state != PARKED || wave[l].op->kind == BARRIER || wave[l].op->kind == BARRIER_OR) continue;
+          if (wave[l].state != PARKED || wave[l].op->kind >= BARRIER) continue;
           const void* s = wave[l].op->site;
-          bool seen = false;
-          for (int m = 0; m < l && !seen; m++)
-            seen = wave[m].state == PARKED && wave[m].op->kind != BARRIER && wave[m].op->kind != BARRIER_OR && wave[m].op->site == s;
-          if (!seen) groups++;
-          if (site == nullptr || s < site) site = s;
+          if (site == nullptr) site = s;
+          else if (s != site) {
+            divergent = true;
+            if (s < site) site = s;
+          }
         }
         if (site == nullptr) break;  // nothing but barriers and finished lanes
         uint64_t mask = 0;
         for (int l = 0; l < n_lanes; l++)
-          if (wave[l].state == PARKED && wave[l].op->kind != BARRIER && wave[l].op->kind != BARRIER_OR && wave[l].op->site == site) mask |= 1ull << l;
+          if (wave[l].state == PARKED && wave[l].op->kind < BARRIER && wave[l].op->site == site) mask |= 1ull << l;
+        if (divergent) g_counters[2]++;
         g_counters[1]++;
-        if (groups > 1) g_counters[2]++;
         execute(wave, mask, n_lanes);
         for (int l = 0; l < n_lanes; l++)
           if ((mask >> l) & 1) wave[l].state = READY;
@@ -231,6 +232,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closur
     for (int t = 0; t < kMaxThreads; t++) g_fibres[t].stack = g_stacks + kStack * t;
   }
   g_counters[0]++;
+  g_dyn_bytes = std::min(kDynLds, (dyn_lds_bytes + 4095) & ~(size_t) 4095);  // (a page of poison behind what was asked for)
   g_body = body;
   g_closure = closure;
   g_bdim = block;
