@@ -30,7 +30,7 @@ REWRITES = [
 ]
 # -ffp-contract=off: as the product build (f2-nerf_amd/build.py); binary16 arithmetic rounded after every operation, as the GPU's
 # native f16 instructions do (clang's default for x86 keeps excess precision inside an expression)
-FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Xclang", "-ffloat16-excess-precision=none",
+FLAGS = ["-x", "c++", "-std=c++17", "-O0", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Xclang", "-ffloat16-excess-precision=none",
          "-mf16c", "-w", "-I" + os.path.join(HERE, "include"), "-I" + OUT]
 
 
@@ -82,6 +82,25 @@ def build(sources=None, verbose=False, force=False):
     with open(tag, "w") as f:
         f.write(want)
     return LIB, report
+
+
+def build_selftest(force=False):
+    """libwemu_selftest.so: tests/wave_emul/selftest.hip (known-answer kernels for the emulation itself) + the runtime."""
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(HERE, "selftest.hip")
+    lib = os.path.join(OUT, "libwemu_selftest.so")
+    deps = [src, os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "wemu_rt.cpp"), os.path.abspath(__file__)]
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= max(os.path.getmtime(d) for d in deps):
+        return lib
+    with open(src) as f:
+        text, _ = _rewrite(f.read())
+    with open(os.path.join(OUT, "selftest.hip"), "w") as f:
+        f.write(text)
+    r = subprocess.run([CLANG] + FLAGS + ["-shared", os.path.join(OUT, "selftest.hip"), "-x", "c++", os.path.join(HERE, "wemu_rt.cpp"), "-o", lib, "-lm"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("wave_emul selftest build failed:\n" + r.stderr[-6000:])
+    return lib
 
 
 if __name__ == "__main__":

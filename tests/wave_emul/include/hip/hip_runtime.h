@@ -75,7 +75,7 @@ struct Op {
   void* d;
   uint64_t result;     // filled in by the scheduler
 };
-uint64_t park(Op& op);  // parks the running fibre at `op`, returns op.result once the operation has been carried out
+uint64_t park(Op& op) __attribute__((convergent));  // parks the running fibre at `op`, returns op.result once the operation has been carried out
 void* dyn_lds();        // the dynamic LDS of the running workgroup
 typedef void (*Body)(void* closure);
 void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure);
@@ -193,9 +193,8 @@ static inline wemu_half2 wemu_atomic_fadd_v2f16(void* p, wemu_half2 v) {
 static inline unsigned atomicInc(unsigned* p, unsigned lim) { unsigned o = *p; *p = o >= lim ? 0 : o + 1; return o; }
 
 // ------------------------------------------------------------------------------------------------- cross-lane operations
-#define WEMU_SITE __builtin_return_address(0)
 namespace wemu {
-static inline uint32_t permute(const void* site, uint32_t v, int src, uint32_t fallback) {
+static inline __attribute__((convergent)) uint32_t permute(const void* site, uint32_t v, int src, uint32_t fallback) {
   Op op{};
   op.kind = PERMUTE; op.site = site; op.val = v; op.src = src; op.fallback = fallback;
   return (uint32_t) park(op);
@@ -228,7 +227,7 @@ static inline int dpp_src(int lane, int ctrl) {
   if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));    // row_half_mirror
   abort();  // (row_bcast15 / row_bcast31 write lanes of OTHER rows: not used by these kernels)
 }
-static inline int update_dpp(const void* site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+static inline __attribute__((noinline, convergent, noduplicate)) int update_dpp(const void* site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   const int lane = g_lane;
   const bool enabled = ((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane & 15) >> 2)) & 1);
   // a lane whose row / bank is masked off keeps `old` but still takes part in the instruction (its register is a source)
@@ -245,49 +244,47 @@ static inline int update_dpp(const void* site, int old, int src, int ctrl, int r
 // would need its caller's frame; this is cheaper and survives inlining of the device helpers into their kernels).
 #define WEMU_HERE() ([]() __attribute__((noinline)) -> const void* { return __builtin_return_address(0); }())
 
-template <typename T> static inline __attribute__((noinline)) T __shfl(T v, int src_lane, int width = 64) {
-  return wemu::permute_any(WEMU_SITE, v, [=](int self) { return (src_lane & (width - 1)) + (self & ~(width - 1)); });
+// Every cross-lane operation carries its call site as DATA (WEMU_HERE() of the expansion) and is `convergent`: the compiler may then
+// neither merge the operations of two branches into one call (they would vote together) nor duplicate one operation into two
+// paths (its lanes would vote apart) -- the same attribute the GPU target puts on these builtins.
+#define WEMU_OP static inline __attribute__((noinline, convergent, noduplicate))
+template <typename T> WEMU_OP T wemu_shfl(const void* site, T v, int src_lane, int width = 64) {
+  return wemu::permute_any(site, v, [=](int self) { return (src_lane & (width - 1)) + (self & ~(width - 1)); });
 }
-template <typename T> static inline __attribute__((noinline)) T __shfl_up(T v, unsigned delta, int width = 64) {
-  return wemu::permute_any(WEMU_SITE, v, [=](int self) { const int i = self - (int) delta; return i < (self & ~(width - 1)) ? self : i; });
+template <typename T> WEMU_OP T wemu_shfl_up(const void* site, T v, unsigned delta, int width = 64) {
+  return wemu::permute_any(site, v, [=](int self) { const int i = self - (int) delta; return i < (self & ~(width - 1)) ? self : i; });
 }
-template <typename T> static inline __attribute__((noinline)) T __shfl_down(T v, unsigned delta, int width = 64) {
-  return wemu::permute_any(WEMU_SITE, v, [=](int self) { return (self & (width - 1)) + (int) delta >= width ? self : self + (int) delta; });
+template <typename T> WEMU_OP T wemu_shfl_down(const void* site, T v, unsigned delta, int width = 64) {
+  return wemu::permute_any(site, v, [=](int self) { return (self & (width - 1)) + (int) delta >= width ? self : self + (int) delta; });
 }
-template <typename T> static inline __attribute__((noinline)) T __shfl_xor(T v, int mask, int width = 64) {
-  return wemu::permute_any(WEMU_SITE, v, [=](int self) { const int i = self ^ mask; return i >= ((self + width) & ~(width - 1)) ? self : i; });
+template <typename T> WEMU_OP T wemu_shfl_xor(const void* site, T v, int mask, int width = 64) {
+  return wemu::permute_any(site, v, [=](int self) { const int i = self ^ mask; return i >= ((self + width) & ~(width - 1)) ? self : i; });
 }
-static inline __attribute__((noinline)) unsigned long long __ballot(int pred) {
+WEMU_OP unsigned long long wemu_ballot(const void* site, int pred) {
   wemu::Op op{};
-  op.kind = wemu::BALLOT; op.site = WEMU_SITE; op.val = pred != 0;
+  op.kind = wemu::BALLOT; op.site = site; op.val = pred != 0;
   return wemu::park(op);
 }
-static inline __attribute__((noinline)) int __any(int pred) {
+WEMU_OP int wemu_readfirstlane(const void* site, int v) {
   wemu::Op op{};
-  op.kind = wemu::BALLOT; op.site = WEMU_SITE; op.val = pred != 0;
-  return wemu::park(op) != 0;
-}
-static inline __attribute__((noinline)) int __all(int pred) {
-  wemu::Op op{};
-  op.kind = wemu::BALLOT; op.site = WEMU_SITE; op.val = pred == 0;  // (all <=> nobody in the mask has !pred)
-  return wemu::park(op) == 0;
-}
-static inline __attribute__((noinline)) int wemu_readfirstlane(int v) {
-  wemu::Op op{};
-  op.kind = wemu::FIRST; op.site = WEMU_SITE; op.val = (uint32_t) v;
+  op.kind = wemu::FIRST; op.site = site; op.val = (uint32_t) v;
   return (int) wemu::park(op);
 }
-#define __builtin_amdgcn_readfirstlane(v) wemu_readfirstlane(v)
-static inline __attribute__((noinline)) void __syncthreads() {
+WEMU_OP int wemu_barrier(int kind, int pred) {
   wemu::Op op{};
-  op.kind = wemu::BARRIER; op.site = WEMU_SITE;
-  wemu::park(op);
-}
-static inline __attribute__((noinline)) int __syncthreads_or(int pred) {
-  wemu::Op op{};
-  op.kind = wemu::BARRIER_OR; op.site = WEMU_SITE; op.val = pred != 0;
+  op.kind = kind; op.val = pred != 0;
   return (int) wemu::park(op);
 }
+#define __shfl(...) wemu_shfl(WEMU_HERE(), __VA_ARGS__)
+#define __shfl_up(...) wemu_shfl_up(WEMU_HERE(), __VA_ARGS__)
+#define __shfl_down(...) wemu_shfl_down(WEMU_HERE(), __VA_ARGS__)
+#define __shfl_xor(...) wemu_shfl_xor(WEMU_HERE(), __VA_ARGS__)
+#define __ballot(pred) wemu_ballot(WEMU_HERE(), (pred))
+#define __any(pred) (wemu_ballot(WEMU_HERE(), (pred)) != 0)
+#define __all(pred) (wemu_ballot(WEMU_HERE(), !(pred)) == 0)  // (all <=> nobody in the mask has !pred)
+#define __builtin_amdgcn_readfirstlane(v) wemu_readfirstlane(WEMU_HERE(), (v))
+#define __syncthreads() ((void) wemu_barrier(wemu::BARRIER, 0))
+#define __syncthreads_or(pred) wemu_barrier(wemu::BARRIER_OR, (pred))
 
 // ------------------------------------------------------------------------------------------------- matrix cores
 // v_mfma_f32_16x16x16_f16 / v_mfma_f32_16x16x32_f16 (CDNA3 / CDNA4 ISA): D[i][j] = C[i][j] + sum_k A[i][k] B[k][j], one wave.
@@ -298,19 +295,19 @@ static inline __attribute__((noinline)) int __syncthreads_or(int pred) {
 typedef _Float16 wemu_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 wemu_half8 __attribute__((ext_vector_type(8)));
 typedef float wemu_float4 __attribute__((ext_vector_type(4)));
-static inline __attribute__((noinline)) wemu_float4 wemu_mfma_16x16x16(wemu_half4 a, wemu_half4 b, wemu_float4 c) {
+WEMU_OP wemu_float4 wemu_mfma_16x16x16(const void* site, wemu_half4 a, wemu_half4 b, wemu_float4 c) {
   wemu_float4 d;
   wemu::Op op{};
-  op.kind = wemu::MFMA_16x16x16_F16; op.site = WEMU_SITE; op.a = &a; op.b = &b; op.c = &c; op.d = &d;
+  op.kind = wemu::MFMA_16x16x16_F16; op.site = site; op.a = &a; op.b = &b; op.c = &c; op.d = &d;
   wemu::park(op);
   return d;
 }
-static inline __attribute__((noinline)) wemu_float4 wemu_mfma_16x16x32(wemu_half8 a, wemu_half8 b, wemu_float4 c) {
+WEMU_OP wemu_float4 wemu_mfma_16x16x32(const void* site, wemu_half8 a, wemu_half8 b, wemu_float4 c) {
   wemu_float4 d;
   wemu::Op op{};
-  op.kind = wemu::MFMA_16x16x32_F16; op.site = WEMU_SITE; op.a = &a; op.b = &b; op.c = &c; op.d = &d;
+  op.kind = wemu::MFMA_16x16x32_F16; op.site = site; op.a = &a; op.b = &b; op.c = &c; op.d = &d;
   wemu::park(op);
   return d;
 }
-#define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, cbsz, abid, blgp) wemu_mfma_16x16x16((a), (b), (c))
-#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, cbsz, abid, blgp) wemu_mfma_16x16x32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, cbsz, abid, blgp) wemu_mfma_16x16x16(WEMU_HERE(), (a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, cbsz, abid, blgp) wemu_mfma_16x16x32(WEMU_HERE(), (a), (b), (c))
