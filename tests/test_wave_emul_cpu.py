@@ -25,7 +25,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "wave_emul"))
 
-import tests.test_gpu_parity as gp  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import test_gpu_converged as gconv  # noqa: E402
+import test_gpu_mlp_shapes as gmlp  # noqa: E402
+import test_gpu_parity as gp  # noqa: E402
+import test_gpu_scale as gscale  # noqa: E402
+
+_GPU_MODULES = (gp, gscale, gconv, gmlp)
 
 
 @pytest.fixture(scope="session")
@@ -64,17 +71,39 @@ def hip(emul_lib, monkeypatch):
     monkeypatch.setattr(capi, "_mapped", lambda t: host_pointer(t, "i32", allow_none=True))  # (a "mapped" mirror is a host tensor)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)  # (mapped host memory is host memory)
-    monkeypatch.setattr(gp, "DEV", "cpu")
-    # (on the GPU T() and N() copy by crossing the bus; here they must copy explicitly, or a kernel would update the oracle's inputs)
-    monkeypatch.setattr(gp, "T", lambda a: torch.from_numpy(np.array(a, copy=True, order="C")))
-    monkeypatch.setattr(gp, "N", lambda t: t.detach().numpy().copy())
+    for mod in _GPU_MODULES:
+        for name, value in (("DEV", "cpu"),
+                            # (on the GPU T() and N() copy by crossing the bus; here they must copy explicitly, or a kernel would
+                            # update the oracle's inputs in place)
+                            ("T", lambda a: torch.from_numpy(np.array(a, copy=True, order="C"))),
+                            ("N", lambda t: t.detach().numpy().copy())):
+            if hasattr(mod, name):
+                monkeypatch.setattr(mod, name, value)
+    monkeypatch.setattr(gscale, "np", _NumpyWithASmallConvergedBatch())
     return capi
 
 
-def _on_the_emulator(name, params=None):
+class _NumpyWithASmallConvergedBatch:
+    """numpy, except that the converged octree's 13 056-ray training batch (tools/data/converged_sampler.npz: what the kernel-level
+    tests of test_gpu_scale.py sample) comes back as every 97th ray: the same tree, the same kind of rays, 135 of them."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def load(path, *a, **k):
+        z = np.load(path, *a, **k)
+        if os.path.basename(str(path)) != "converged_sampler.npz":
+            return z
+        z = dict(z)
+        n = z["rays_o"].shape[0]
+        return {key: (v[::97].copy() if getattr(v, "shape", None) and v.shape[0] == n else v) for key, v in z.items()}
+
+
+def _on_the_emulator(name, params=None, module=gp):
     """The GPU test `name` as a test of this module; params = (argnames, values) replaces its own parametrisation where the GPU
     sizes would take the emulator minutes."""
-    fn = getattr(gp, name)
+    fn = getattr(module, name)
 
     @functools.wraps(fn)
     def test(*a, **k):
@@ -129,6 +158,19 @@ _TESTS = {
 }
 for _name, _params in _TESTS.items():
     globals()[_name] = _on_the_emulator(_name, _params)
+
+# kernel-level tests of the other GPU modules (the ones that go through the C-ABI alone; the host classes need a device)
+_MORE = [
+    (gscale, "test_deep_tree_fills_the_dfs_stack", None),
+    (gscale, "test_speculative_sampling_repair", None),
+    (gscale, "test_speculative_tail_repair", None),
+    (gscale, "test_speculative_walk_that_saw_a_later_tree", None),
+    (gscale, "test_persistent_march", None),
+    (gmlp, "test_general_mlp_forward_and_backward", None),
+    (gmlp, "test_unsupported_shapes_still_say_so", None),
+]
+for _mod, _name, _params in _MORE:
+    globals()[_name] = _on_the_emulator(_name, _params, _mod)
 
 
 def test_the_emulated_library_is_the_products_source_text(emul_lib):
@@ -216,3 +258,18 @@ def test_emulated_mfma_tiles(selftest_lib):
     Af, Bf = A.astype(np.float32), B.astype(np.float32)
     assert (D16 == Af[:, :16] @ Bf[:16] + C).all()   # (small integers: every sum is exact)
     assert (D32 == Af @ Bf + C).all()
+
+
+def test_emulated_wave_is_whole_again_at_the_top_of_a_loop(selftest_lib):
+    """Lanes that finish a trip's work early wait for the others at the end of the loop's body (the hardware reconverges there);
+    a scheduler that went by addresses alone would let them run ahead to the loop's head -- a lower address -- and vote alone."""
+    n_groups = 23
+    out = np.zeros((n_groups, 64), np.int32)
+    counter = np.zeros(1, np.int32)
+    assert selftest_lib.st_persistent(out.ctypes.data_as(ctypes.c_void_p), counter.ctypes.data_as(ctypes.c_void_p), n_groups, 3) == 0
+    lane = np.arange(64)
+    for g in range(n_groups):
+        trips = (g * 7 + (lane >> 4) * 5) % 11
+        acc = np.array([sum(i + (int(x) ^ 1) for i in range(int(t))) if t != 3 else 0 for x, t in zip(lane, trips)])
+        assert (out[g] == acc + 1).all(), (g, out[g], acc + 1)
+    assert counter[0] == n_groups + 3  # (every block's last fetch comes back empty)

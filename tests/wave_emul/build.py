@@ -34,6 +34,11 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O0", "-fPIC", "-ffp-contract=off", "-fno-f
          "-mf16c", "-w", "-I" + os.path.join(HERE, "include"), "-I" + OUT]
 
 
+RT_FLAGS = [f if f != "-O0" else "-O2" for f in FLAGS] + ["-fno-omit-frame-pointer", "-mno-omit-leaf-frame-pointer", "-fno-optimize-sibling-calls"]  # (the emulation's own runtime)
+# the kernels' basic blocks and function exits report to the runtime (wemu_rt.cpp: how it knows which lanes are behind)
+FLAGS += ["-fno-omit-frame-pointer", "-fsanitize-coverage=trace-pc,no-prune", "-finstrument-functions-after-inlining"]
+
+
 def _rewrite(text):
     fired = []
     for rx, to in REWRITES:
@@ -67,7 +72,7 @@ def build(sources=None, verbose=False, force=False):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest and os.path.exists(tag) and open(tag).read() == want:
         return LIB, report
     jobs = [[CLANG] + FLAGS + ["-c", os.path.join(OUT, "csrc", s), "-o", os.path.join(OUT, s + ".o")] for s in sources]
-    jobs.append([CLANG] + FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(OUT, "wemu_rt.o")])
+    jobs.append([CLANG] + RT_FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(OUT, "wemu_rt.o")])
 
     def run(cmd):
         if verbose:
@@ -96,10 +101,12 @@ def build_selftest(force=False):
         text, _ = _rewrite(f.read())
     with open(os.path.join(OUT, "selftest.hip"), "w") as f:
         f.write(text)
-    r = subprocess.run([CLANG] + FLAGS + ["-shared", os.path.join(OUT, "selftest.hip"), "-x", "c++", os.path.join(HERE, "wemu_rt.cpp"), "-o", lib, "-lm"],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("wave_emul selftest build failed:\n" + r.stderr[-6000:])
+    for cmd in ([CLANG] + FLAGS + ["-c", os.path.join(OUT, "selftest.hip"), "-o", os.path.join(OUT, "selftest.o")],
+                [CLANG] + RT_FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(OUT, "wemu_rt.selftest.o")],
+                [CLANG, "-shared", "-fPIC", os.path.join(OUT, "selftest.o"), os.path.join(OUT, "wemu_rt.selftest.o"), "-o", lib, "-lm"]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("wave_emul selftest build failed:\n" + r.stderr[-6000:])
     return lib
 
 

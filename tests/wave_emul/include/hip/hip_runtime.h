@@ -75,7 +75,7 @@ struct Op {
   void* d;
   uint64_t result;     // filled in by the scheduler
 };
-uint64_t park(Op& op) __attribute__((convergent));  // parks the running fibre at `op`, returns op.result once the operation has been carried out
+uint64_t park(Op& op);  // parks the running fibre at `op`, returns op.result once the operation has been carried out
 void* dyn_lds();        // the dynamic LDS of the running workgroup
 typedef void (*Body)(void* closure);
 void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure);
@@ -193,98 +193,48 @@ static inline wemu_half2 wemu_atomic_fadd_v2f16(void* p, wemu_half2 v) {
 static inline unsigned atomicInc(unsigned* p, unsigned lim) { unsigned o = *p; *p = o >= lim ? 0 : o + 1; return o; }
 
 // ------------------------------------------------------------------------------------------------- cross-lane operations
+// Every operation carries its call site as DATA: WEMU_HERE() is the return address of a marker call that is unique per expansion
+// (and per inlined copy of a device helper).  The kernels are compiled at -O0 -- an optimiser that merges the operations of two
+// branches into one call, or duplicates one operation into two paths, changes who votes with whom (the GPU target forbids both
+// through `convergent`; tests/wave_emul/selftest.hip holds the emulation to the answers the hardware gives) -- and the operations
+// themselves live in wemu_rt.cpp, compiled with optimisation.
+#define WEMU_HERE() ([]() __attribute__((noinline)) -> const void* { return __builtin_return_address(0); }())
 namespace wemu {
-static inline __attribute__((convergent)) uint32_t permute(const void* site, uint32_t v, int src, uint32_t fallback) {
-  Op op{};
-  op.kind = PERMUTE; op.site = site; op.val = v; op.src = src; op.fallback = fallback;
-  return (uint32_t) park(op);
-}
+enum { SHFL_IDX, SHFL_UP, SHFL_DOWN, SHFL_XOR };
+uint32_t xl_shfl(const void* site, uint32_t v, int mode, int arg, int width);
+int xl_dpp(const void* site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl);
+unsigned long long xl_ballot(const void* site, int pred);
+int xl_first(const void* site, int v);
+int xl_barrier(int kind, int pred);
+void xl_mfma(const void* site, int kind, const void* a, const void* b, const void* c, void* d);
 // any trivially copyable value of 4 or 8 bytes, 32 bits at a time (as HIP's own __shfl overloads do)
-template <typename T, typename SrcOf>
-static inline T permute_any(const void* site, T v, SrcOf src_of) {
+template <typename T>
+static inline T shfl_any(const void* site, T v, int mode, int arg, int width) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "shuffle of a 4- or 8-byte value");
   uint32_t w[sizeof(T) / 4];
   memcpy(w, &v, sizeof(T));
-  const int src = src_of(g_lane);
-  // (own value when the source falls outside the segment -- HIP's __shfl_up/down/xor; 0 when the source lane is inactive)
-  for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = permute((const char*) site + i, w[i], src, 0u);
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = xl_shfl((const char*) site + i, w[i], mode, arg, width);
   T r;
   memcpy(&r, w, sizeof(T));
   return r;
 }
-// DPP source lane of `lane` under dpp_ctrl (gfx9 encodings); -1: no valid source in the row
-static inline int dpp_src(int lane, int ctrl) {
-  const int row = lane & ~15, c = lane & 15;
-  if (ctrl >= 0x000 && ctrl <= 0x0FF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);                   // quad_perm
-  if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 15; return c + n <= 15 ? row + c + n : -1; }     // row_shl
-  if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 15; return c - n >= 0 ? row + c - n : -1; }      // row_shr
-  if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 15; return row + ((c - n) & 15); }               // row_ror
-  if (ctrl == 0x130) return lane + 1 <= 63 ? lane + 1 : -1;   // wave_shl:1
-  if (ctrl == 0x134) return (lane + 1) & 63;                   // wave_rol:1
-  if (ctrl == 0x138) return lane - 1 >= 0 ? lane - 1 : -1;    // wave_shr:1
-  if (ctrl == 0x13C) return (lane - 1) & 63;                   // wave_ror:1
-  if (ctrl == 0x140) return row + 15 - c;                      // row_mirror
-  if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));    // row_half_mirror
-  abort();  // (row_bcast15 / row_bcast31 write lanes of OTHER rows: not used by these kernels)
-}
-static inline __attribute__((noinline, convergent, noduplicate)) int update_dpp(const void* site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-  const int lane = g_lane;
-  const bool enabled = ((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane & 15) >> 2)) & 1);
-  // a lane whose row / bank is masked off keeps `old` but still takes part in the instruction (its register is a source)
-  const int s = enabled ? dpp_src(lane, ctrl) : lane;
-  const uint32_t fb = enabled ? (bound_ctrl ? 0u : (uint32_t) old) : (uint32_t) old;
-  const uint32_t r = permute(site, (uint32_t) src, enabled ? s : -1, fb);
-  return (int) r;
-}
 }  // namespace wemu
-
-#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) wemu::update_dpp(WEMU_HERE(), (old), (src), (ctrl), (rm), (bm), (bc))
-#define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) wemu::update_dpp(WEMU_HERE(), 0, (src), (ctrl), (rm), (bm), (bc))
-// The call site of a cross-lane operation: the address of a label-free marker that is unique per expansion (a noinline call
-// would need its caller's frame; this is cheaper and survives inlining of the device helpers into their kernels).
-#define WEMU_HERE() ([]() __attribute__((noinline)) -> const void* { return __builtin_return_address(0); }())
-
-// Every cross-lane operation carries its call site as DATA (WEMU_HERE() of the expansion) and is `convergent`: the compiler may then
-// neither merge the operations of two branches into one call (they would vote together) nor duplicate one operation into two
-// paths (its lanes would vote apart) -- the same attribute the GPU target puts on these builtins.
-#define WEMU_OP static inline __attribute__((noinline, convergent, noduplicate))
-template <typename T> WEMU_OP T wemu_shfl(const void* site, T v, int src_lane, int width = 64) {
-  return wemu::permute_any(site, v, [=](int self) { return (src_lane & (width - 1)) + (self & ~(width - 1)); });
-}
-template <typename T> WEMU_OP T wemu_shfl_up(const void* site, T v, unsigned delta, int width = 64) {
-  return wemu::permute_any(site, v, [=](int self) { const int i = self - (int) delta; return i < (self & ~(width - 1)) ? self : i; });
-}
-template <typename T> WEMU_OP T wemu_shfl_down(const void* site, T v, unsigned delta, int width = 64) {
-  return wemu::permute_any(site, v, [=](int self) { return (self & (width - 1)) + (int) delta >= width ? self : self + (int) delta; });
-}
-template <typename T> WEMU_OP T wemu_shfl_xor(const void* site, T v, int mask, int width = 64) {
-  return wemu::permute_any(site, v, [=](int self) { const int i = self ^ mask; return i >= ((self + width) & ~(width - 1)) ? self : i; });
-}
-WEMU_OP unsigned long long wemu_ballot(const void* site, int pred) {
-  wemu::Op op{};
-  op.kind = wemu::BALLOT; op.site = site; op.val = pred != 0;
-  return wemu::park(op);
-}
-WEMU_OP int wemu_readfirstlane(const void* site, int v) {
-  wemu::Op op{};
-  op.kind = wemu::FIRST; op.site = site; op.val = (uint32_t) v;
-  return (int) wemu::park(op);
-}
-WEMU_OP int wemu_barrier(int kind, int pred) {
-  wemu::Op op{};
-  op.kind = kind; op.val = pred != 0;
-  return (int) wemu::park(op);
-}
+template <typename T> static inline T wemu_shfl(const void* site, T v, int src_lane, int width = 64) { return wemu::shfl_any(site, v, wemu::SHFL_IDX, src_lane, width); }
+template <typename T> static inline T wemu_shfl_up(const void* site, T v, unsigned delta, int width = 64) { return wemu::shfl_any(site, v, wemu::SHFL_UP, (int) delta, width); }
+template <typename T> static inline T wemu_shfl_down(const void* site, T v, unsigned delta, int width = 64) { return wemu::shfl_any(site, v, wemu::SHFL_DOWN, (int) delta, width); }
+template <typename T> static inline T wemu_shfl_xor(const void* site, T v, int mask, int width = 64) { return wemu::shfl_any(site, v, wemu::SHFL_XOR, mask, width); }
 #define __shfl(...) wemu_shfl(WEMU_HERE(), __VA_ARGS__)
 #define __shfl_up(...) wemu_shfl_up(WEMU_HERE(), __VA_ARGS__)
 #define __shfl_down(...) wemu_shfl_down(WEMU_HERE(), __VA_ARGS__)
 #define __shfl_xor(...) wemu_shfl_xor(WEMU_HERE(), __VA_ARGS__)
-#define __ballot(pred) wemu_ballot(WEMU_HERE(), (pred))
-#define __any(pred) (wemu_ballot(WEMU_HERE(), (pred)) != 0)
-#define __all(pred) (wemu_ballot(WEMU_HERE(), !(pred)) == 0)  // (all <=> nobody in the mask has !pred)
-#define __builtin_amdgcn_readfirstlane(v) wemu_readfirstlane(WEMU_HERE(), (v))
-#define __syncthreads() ((void) wemu_barrier(wemu::BARRIER, 0))
-#define __syncthreads_or(pred) wemu_barrier(wemu::BARRIER_OR, (pred))
+#define __ballot(pred) wemu::xl_ballot(WEMU_HERE(), (pred))
+#define __any(pred) (wemu::xl_ballot(WEMU_HERE(), (pred)) != 0)
+#define __all(pred) (wemu::xl_ballot(WEMU_HERE(), !(pred)) == 0)  // (all <=> nobody in the mask has !pred)
+#define __builtin_amdgcn_readfirstlane(v) wemu::xl_first(WEMU_HERE(), (v))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) wemu::xl_dpp(WEMU_HERE(), (old), (src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) wemu::xl_dpp(WEMU_HERE(), 0, (src), (ctrl), (rm), (bm), (bc))
+#define __syncthreads() ((void) wemu::xl_barrier(wemu::BARRIER, 0))
+#define __syncthreads_or(pred) wemu::xl_barrier(wemu::BARRIER_OR, (pred))
 
 // ------------------------------------------------------------------------------------------------- matrix cores
 // v_mfma_f32_16x16x16_f16 / v_mfma_f32_16x16x32_f16 (CDNA3 / CDNA4 ISA): D[i][j] = C[i][j] + sum_k A[i][k] B[k][j], one wave.
@@ -295,18 +245,14 @@ WEMU_OP int wemu_barrier(int kind, int pred) {
 typedef _Float16 wemu_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 wemu_half8 __attribute__((ext_vector_type(8)));
 typedef float wemu_float4 __attribute__((ext_vector_type(4)));
-WEMU_OP wemu_float4 wemu_mfma_16x16x16(const void* site, wemu_half4 a, wemu_half4 b, wemu_float4 c) {
+static inline wemu_float4 wemu_mfma_16x16x16(const void* site, wemu_half4 a, wemu_half4 b, wemu_float4 c) {
   wemu_float4 d;
-  wemu::Op op{};
-  op.kind = wemu::MFMA_16x16x16_F16; op.site = site; op.a = &a; op.b = &b; op.c = &c; op.d = &d;
-  wemu::park(op);
+  wemu::xl_mfma(site, wemu::MFMA_16x16x16_F16, &a, &b, &c, &d);
   return d;
 }
-WEMU_OP wemu_float4 wemu_mfma_16x16x32(const void* site, wemu_half8 a, wemu_half8 b, wemu_float4 c) {
+static inline wemu_float4 wemu_mfma_16x16x32(const void* site, wemu_half8 a, wemu_half8 b, wemu_float4 c) {
   wemu_float4 d;
-  wemu::Op op{};
-  op.kind = wemu::MFMA_16x16x32_F16; op.site = site; op.a = &a; op.b = &b; op.c = &c; op.d = &d;
-  wemu::park(op);
+  wemu::xl_mfma(site, wemu::MFMA_16x16x32_F16, &a, &b, &c, &d);
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, cbsz, abid, blgp) wemu_mfma_16x16x16(WEMU_HERE(), (a), (b), (c))

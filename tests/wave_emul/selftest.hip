@@ -70,6 +70,23 @@ __global__ void st_block_kernel(int* __restrict__ out, int n) {
   if (t == 0) atomicAdd(out + n, 1);
 }
 
+// A persistent wave: groups of work off a counter; the four rows of the wave work for different lengths inside a trip, and the wave
+// must be whole again at the top of the next one (the lanes that finish early wait at the end of the body, not at the loop's head)
+__global__ void st_persistent_kernel(int* __restrict__ out, int* __restrict__ counter, int n_groups) {
+  for (;;) {
+    int g = 0;
+    if ((threadIdx.x & 63) == 0) g = atomicAdd(counter, 1);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= n_groups) break;
+    const int row = threadIdx.x >> 4;
+    const int trips = (g * 7 + row * 5) % 11;
+    int acc = 0;
+    if (trips != 3)  // (one row in some trips skips the work altogether)
+      for (int i = 0; i < trips; i++) acc += __shfl_xor(i + (int) threadIdx.x, 1, 16);
+    out[g * 64 + threadIdx.x] += acc + 1;
+  }
+}
+
 // D = A B + C with the fragment layouts of v_mfma_f32_16x16x16_f16 / v_mfma_f32_16x16x32_f16; A, B row-major f16 [16][K], [K][16]
 __global__ void st_mfma_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float* __restrict__ C,
                                float* __restrict__ D16, float* __restrict__ D32) {
@@ -105,6 +122,10 @@ int st_masks(unsigned long long* out) {
 }
 int st_block(int* out, int n_blocks) {
   hipLaunchKernelGGL(st_block_kernel, dim3(n_blocks), dim3(256), 256 * sizeof(int), (hipStream_t) 0, out, n_blocks * 256);
+  return (int) hipGetLastError();
+}
+int st_persistent(int* out, int* counter, int n_groups, int n_blocks) {
+  hipLaunchKernelGGL(st_persistent_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t) 0, out, counter, n_groups);
   return (int) hipGetLastError();
 }
 int st_mfma(const void* A, const void* B, const float* C, float* D16, float* D32) {

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <sys/mman.h>
 
+#include <unordered_map>
 #include <vector>
 
 namespace wemu {
@@ -14,6 +15,13 @@ int g_lane;
 namespace {
 
 enum State { READY, PARKED, DONE };
+// Where a fibre is in the program, beyond an address: the live function activations (frame pointer + the basic block it is in,
+// from the compiler's block instrumentation: __sanitizer_cov_trace_pc) and, per activation, the loops it is inside with the number
+// of back-edges it has taken.  A loop is learnt the first time any fibre jumps backwards inside an activation: [head, latch] are the
+// target and source blocks (at -O0 a loop's blocks are contiguous and its latch is the last of them).
+constexpr int kMaxFrames = 32, kMaxLoops = 32, kMaxLevels = 40;
+struct FrameRec { uintptr_t fp, block; };
+struct LoopRec { uintptr_t fp, head, latch; uint32_t iter; };
 struct Fibre {
   void* sp;      // saved stack pointer while the fibre is not running
   char* stack;
@@ -21,6 +29,12 @@ struct Fibre {
   Op* op;
   Idx tid;
   int lane;
+  int nf, nl;
+  FrameRec fr[kMaxFrames];
+  LoopRec lp[kMaxLoops];
+  // taken when it parks: the return addresses of its call chain, kernel side first, with the frame each lies in
+  int nlev;
+  uintptr_t ra[kMaxLevels], rfp[kMaxLevels];
 };
 
 constexpr size_t kStack = 256 << 10;  // per work-item (virtual; pages are touched on demand)
@@ -36,6 +50,8 @@ Body g_body;
 void* g_closure;
 long g_counters[8];
 size_t g_dyn_bytes = 0;
+int g_block_threads = 0;
+std::unordered_map<uintptr_t, uintptr_t> g_loops;  // head block -> latch block of every loop seen so far
 
 // callee-saved registers of the SysV x86-64 ABI + the stack pointer; nothing else survives a call anyway
 extern "C" void wemu_switch(void** save_sp, void* new_sp);
@@ -72,6 +88,7 @@ void fibre_main() {
 void fibre_init(Fibre& f, int linear, const dim3& b) {
   f.state = READY;
   f.op = nullptr;
+  f.nf = f.nl = f.nlev = 0;
   f.tid = {linear % b.x, (linear / b.x) % b.y, linear / (b.x * b.y)};
   f.lane = linear & 63;
   // top of stack: [fake return address of fibre_main][fibre_main as wemu_switch's return target][six registers]
@@ -157,7 +174,97 @@ void execute(Fibre* wave, uint64_t mask, int n_lanes) {
   }
 }
 
+const FrameRec* frame_of(const Fibre& f, uintptr_t fp) {
+  for (int i = f.nf - 1; i >= 0; i--)
+    if (f.fr[i].fp == fp) return &f.fr[i];
+  return nullptr;
+}
+
+// < 0: a is behind b in the program (a runs first), > 0: b is behind a, 0: cannot tell them apart.
+// Compared activation by activation from the kernel inwards: inside one activation first the loops (fewer back-edges taken =
+// behind; not in the loop at all = before it or past it, by its block), then the addresses (lower = behind: forward code).
+int behind(const Fibre& a, const Fibre& b) {
+  const int n = std::min(a.nlev, b.nlev);
+  for (int k = 0; k < n; k++) {
+    const uintptr_t fa = a.rfp[k], fb = b.rfp[k];
+    const FrameRec* ba = frame_of(a, fa);
+    const FrameRec* bb = frame_of(b, fb);
+    int i = 0, j = 0;
+    while (i < a.nl && a.lp[i].fp != fa) i++;
+    while (j < b.nl && b.lp[j].fp != fb) j++;
+    for (;;) {
+      const bool ha = i < a.nl && a.lp[i].fp == fa, hb = j < b.nl && b.lp[j].fp == fb;
+      if (!ha && !hb) break;
+      if (ha && hb && a.lp[i].head == b.lp[j].head) {
+        if (a.lp[i].iter != b.lp[j].iter) return a.lp[i].iter < b.lp[j].iter ? -1 : 1;
+        i++, j++;
+        continue;
+      }
+      // one of them is in a loop the other has no record of: the other is in front of it, in its first trip, or past it
+      const bool a_has = ha && (!hb || a.lp[i].head < b.lp[j].head);
+      const LoopRec& lr = a_has ? a.lp[i] : b.lp[j];
+      const FrameRec* other = a_has ? bb : ba;
+      const auto it = g_loops.find(lr.head);
+      const uintptr_t latch = std::max(lr.latch, it == g_loops.end() ? (uintptr_t) 0 : it->second);
+      const uintptr_t ob = other != nullptr ? other->block : 0;
+      const bool other_first = ob <= latch;  // before the loop or in its first trip: the other is behind; past it: the one in the loop is
+      return (a_has ? other_first : !other_first) ? 1 : -1;
+    }
+    if (a.ra[k] != b.ra[k]) return a.ra[k] < b.ra[k] ? -1 : 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// The compiler's basic-block instrumentation (-fsanitize-coverage=trace-pc on the kernel sources only): one call at the head of
+// every block.  Keeps the running fibre's activations and loops up to date.
+extern "C" void __sanitizer_cov_trace_pc() {
+  Fibre* f = g_cur;
+  if (f == nullptr) return;  // host code of the .hip files (launch wrappers)
+  const uintptr_t* me = static_cast<const uintptr_t*>(__builtin_frame_address(0));
+  const uintptr_t fp = me[0], pc = me[1];  // the instrumented function's frame and the block's address
+  if (f->nf > 0 && f->fr[f->nf - 1].fp == fp && pc > f->fr[f->nf - 1].block && (f->nl == 0 || f->lp[f->nl - 1].fp != fp || pc <= f->lp[f->nl - 1].latch)) {
+    f->fr[f->nf - 1].block = pc;  // (the common case: one block further in the same activation, inside the same loops)
+    return;
+  }
+  while (f->nf > 0 && f->fr[f->nf - 1].fp < fp) f->nf--;  // activations that have returned (deeper = lower)
+  while (f->nl > 0 && f->lp[f->nl - 1].fp < fp) f->nl--;
+  if (f->nf > 0 && f->fr[f->nf - 1].fp == fp) {
+    const uintptr_t last = f->fr[f->nf - 1].block;
+    while (f->nl > 0 && f->lp[f->nl - 1].fp == fp && (pc < f->lp[f->nl - 1].head || pc > f->lp[f->nl - 1].latch) && !(pc <= last && pc == f->lp[f->nl - 1].head))
+      f->nl--;  // left that loop
+    if (pc <= last) {  // a back-edge: from block `last` to block `pc`
+      if (f->nl > 0 && f->lp[f->nl - 1].fp == fp && f->lp[f->nl - 1].head == pc) {
+        f->lp[f->nl - 1].iter++;
+        f->lp[f->nl - 1].latch = std::max(f->lp[f->nl - 1].latch, last);
+      } else if (f->nl < kMaxLoops) {
+        f->lp[f->nl++] = {fp, pc, last, 1};
+      }
+      uintptr_t& g = g_loops[pc];
+      g = std::max(g, last);
+    }
+    f->fr[f->nf - 1].block = pc;
+  } else if (f->nf < kMaxFrames) {
+    f->fr[f->nf++] = {fp, pc};
+  }
+}
+// (-finstrument-functions-after-inlining: an activation that returns takes its records with it, so that the next activation at the
+// same stack address does not inherit them)
+extern "C" void __cyg_profile_func_enter(void*, void*) {}
+extern "C" void __cyg_profile_func_exit(void*, void*) {
+  Fibre* f = g_cur;
+  if (f == nullptr) return;
+  const uintptr_t* me = static_cast<const uintptr_t*>(__builtin_frame_address(0));
+  const uintptr_t fp = me[0];
+  while (f->nf > 0 && f->fr[f->nf - 1].fp <= fp) f->nf--;
+  while (f->nl > 0 && f->lp[f->nl - 1].fp <= fp) f->nl--;
+}
+
+namespace {
+
 void run_block(int n_threads) {
+  g_block_threads = n_threads;
   const int n_waves = (n_threads + 63) / 64;
   for (int t = 0; t < n_threads; t++) fibre_init(g_fibres[t], t, g_bdim);
   memset(g_dyn_lds, 0xCD, g_dyn_bytes);
@@ -168,19 +275,20 @@ void run_block(int n_threads) {
       for (;;) {
         for (int l = 0; l < n_lanes; l++)
           if (wave[l].state == READY) run(wave[l]);
-        // every lane of the wave is parked or done: the lanes parked at the lowest cross-lane site form the next EXEC mask
-        const void* site = nullptr;
+        // every lane of the wave is parked or done: the lanes that are furthest BEHIND in the program go next (with the lanes that
+        // share their site, they form the EXEC mask) -- the order in which the hardware's reconvergence lets them run
+        int best = -1;
         bool divergent = false;
         for (int l = 0; l < n_lanes; l++) {
           if (wave[l].state != PARKED || wave[l].op->kind >= BARRIER) continue;
-          const void* s = wave[l].op->site;
-          if (site == nullptr) site = s;
-          else if (s != site) {
+          if (best < 0) best = l;
+          else if (wave[l].op->site != wave[best].op->site) {
             divergent = true;
-            if (s < site) site = s;
+            if (behind(wave[l], wave[best]) < 0) best = l;
           }
         }
-        if (site == nullptr) break;  // nothing but barriers and finished lanes
+        if (best < 0) break;  // nothing but barriers and finished lanes
+        const void* site = wave[best].op->site;
         uint64_t mask = 0;
         for (int l = 0; l < n_lanes; l++)
           if (wave[l].state == PARKED && wave[l].op->kind < BARRIER && wave[l].op->site == site) mask |= 1ull << l;
@@ -214,8 +322,105 @@ uint64_t park(Op& op) {
   Fibre* f = g_cur;
   f->op = &op;
   f->state = PARKED;
+  {  // the call chain, innermost first on the stack, stored kernel side first (fibre_main's saved frame pointer is 0)
+    uintptr_t ra[kMaxLevels], rfp[kMaxLevels];
+    int n = 0;
+    for (const uintptr_t* fp = static_cast<const uintptr_t*>(__builtin_frame_address(0)); fp != nullptr && fp[0] != 0 && n < kMaxLevels;
+         fp = reinterpret_cast<const uintptr_t*>(fp[0])) {
+      ra[n] = fp[1];
+      rfp[n] = fp[0];
+      n++;
+    }
+    f->nlev = n;
+    for (int k = 0; k < n; k++) {
+      f->ra[k] = ra[n - 1 - k];
+      f->rfp[k] = rfp[n - 1 - k];
+    }
+  }
+  // straight on to the wave's next runnable lane, if there is one (the scheduler would pick exactly that one)
+  Fibre* wave = g_fibres + ((f - g_fibres) & ~63);
+  const int n_lanes = std::min(64, g_block_threads - (int) (wave - g_fibres));
+  for (int l = (int) (f - wave) + 1; l < n_lanes; l++)
+    if (wave[l].state == READY) {
+      Fibre& n = wave[l];
+      g_cur = &n;
+      g_tid = n.tid;
+      g_lane = n.lane;
+      wemu_switch(&f->sp, n.sp);
+      return op.result;
+    }
   wemu_switch(&f->sp, g_sched_sp);
   return op.result;
+}
+
+// DPP source lane of `lane` under dpp_ctrl (gfx9 encodings); -1: no valid source in the row
+static inline int dpp_src(int lane, int ctrl) {
+  const int row = lane & ~15, c = lane & 15;
+  if (ctrl >= 0x000 && ctrl <= 0x0FF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);                   // quad_perm
+  if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 15; return c + n <= 15 ? row + c + n : -1; }     // row_shl
+  if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 15; return c - n >= 0 ? row + c - n : -1; }      // row_shr
+  if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 15; return row + ((c - n) & 15); }               // row_ror
+  if (ctrl == 0x130) return lane + 1 <= 63 ? lane + 1 : -1;   // wave_shl:1
+  if (ctrl == 0x134) return (lane + 1) & 63;                   // wave_rol:1
+  if (ctrl == 0x138) return lane - 1 >= 0 ? lane - 1 : -1;    // wave_shr:1
+  if (ctrl == 0x13C) return (lane - 1) & 63;                   // wave_ror:1
+  if (ctrl == 0x140) return row + 15 - c;                      // row_mirror
+  if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));    // row_half_mirror
+  fprintf(stderr, "wave_emul: dpp_ctrl 0x%x\n", ctrl);        // (row_bcast15 / row_bcast31 write lanes of OTHER rows: not used here)
+  abort();
+}
+
+static inline uint32_t permute(const void* site, uint32_t v, int src, uint32_t fallback) {
+  Op op{};
+  op.kind = PERMUTE; op.site = site; op.val = v; op.src = src; op.fallback = fallback;
+  return (uint32_t) park(op);
+}
+
+// HIP's __shfl family (amd_warp_functions.h): a source outside the lane's segment of `width` reads the lane's own value
+// (up / down / xor); a source lane that is inactive reads 0 (ds_bpermute_b32)
+uint32_t xl_shfl(const void* site, uint32_t v, int mode, int arg, int width) {
+  const int self = g_lane;
+  int src = self;
+  switch (mode) {
+    case SHFL_IDX: src = (arg & (width - 1)) + (self & ~(width - 1)); break;
+    case SHFL_UP: { const int i = self - arg; src = i < (self & ~(width - 1)) ? self : i; break; }
+    case SHFL_DOWN: src = (self & (width - 1)) + arg >= width ? self : self + arg; break;
+    case SHFL_XOR: { const int i = self ^ arg; src = i >= ((self + width) & ~(width - 1)) ? self : i; break; }
+  }
+  return permute(site, v, src, 0u);
+}
+
+// v_mov_b32_dpp: a lane whose row / bank is masked off keeps `old` (it still takes part: its register is a source); a lane whose
+// source does not exist in the row or is inactive gets 0 under bound_ctrl, `old` otherwise
+int xl_dpp(const void* site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int lane = g_lane;
+  const bool enabled = ((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane & 15) >> 2)) & 1);
+  const uint32_t fb = enabled && bound_ctrl ? 0u : (uint32_t) old;
+  return (int) permute(site, (uint32_t) src, enabled ? dpp_src(lane, ctrl) : -1, fb);
+}
+
+unsigned long long xl_ballot(const void* site, int pred) {
+  Op op{};
+  op.kind = BALLOT; op.site = site; op.val = pred != 0;
+  return park(op);
+}
+
+int xl_first(const void* site, int v) {
+  Op op{};
+  op.kind = FIRST; op.site = site; op.val = (uint32_t) v;
+  return (int) park(op);
+}
+
+int xl_barrier(int kind, int pred) {
+  Op op{};
+  op.kind = kind; op.val = pred != 0;
+  return (int) park(op);
+}
+
+void xl_mfma(const void* site, int kind, const void* a, const void* b, const void* c, void* d) {
+  Op op{};
+  op.kind = kind; op.site = site; op.a = a; op.b = b; op.c = c; op.d = d;
+  park(op);
 }
 
 void* dyn_lds() { return g_dyn_lds; }
