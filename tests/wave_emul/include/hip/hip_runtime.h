@@ -1,6 +1,6 @@
 // Test infrastructure -- NOT part of the product.  A CPU stand-in for <hip/hip_runtime.h> under which the kernels of
 // f2-nerf_amd/csrc/*.hip compile for x86-64 (ROCm's clang++ as a plain host compiler) and run with the execution model they are
-// written for: 64-lane wavefronts, cross-lane operations, LDS, workgroup barriers.  tests/wave_emul/build.py builds
+// written for: 64-lane wavefronts, cross-lane operations, LDS, workgroup barriers.  tests/wave_emul/wemu_build.py builds
 // libf2n_emul.so from the product's own source text; tests/test_wave_emul_cpu.py runs the bodies of the -m gpu parity tests
 // against it, so that the cooperative part of every kernel (DPP chains, ballots, shuffles, LDS stacks, MFMA tiles) is held against
 // the oracle on every CPU run, not only on the GPU box.  Nothing here is measured or shipped; the product library is built by

@@ -35,8 +35,8 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O0", "-fPIC", "-ffp-contract=off", "-fno-f
 
 
 RT_FLAGS = [f if f != "-O0" else "-O2" for f in FLAGS] + ["-fno-omit-frame-pointer", "-mno-omit-leaf-frame-pointer", "-fno-optimize-sibling-calls"]  # (the emulation's own runtime)
-# the kernels' basic blocks and function exits report to the runtime (wemu_rt.cpp: how it knows which lanes are behind)
-FLAGS += ["-fno-omit-frame-pointer", "-fsanitize-coverage=trace-pc,no-prune", "-finstrument-functions-after-inlining"]
+# the kernels' basic blocks report to the runtime (wemu_rt.cpp: how it knows which lanes are behind)
+FLAGS += ["-fno-omit-frame-pointer", "-fsanitize-coverage=trace-pc,no-prune"]
 
 
 def _rewrite(text):
@@ -47,9 +47,13 @@ def _rewrite(text):
     return text, fired
 
 
-def build(sources=None, verbose=False, force=False):
+def build(sources=None, verbose=False, force=False, mutate=None, tag=""):
+    """mutate = [(file name, old text, new text)]: a deliberately broken variant (built into _build/<tag>/) for the tests that show
+    the emulated suite notices."""
     sources = SOURCES if sources is None else sources
-    os.makedirs(os.path.join(OUT, "csrc"), exist_ok=True)
+    out = os.path.join(OUT, tag) if tag else OUT
+    lib = os.path.join(out, "libf2n_emul.so")
+    os.makedirs(os.path.join(out, "csrc"), exist_ok=True)
     report = {}
     newest = 0.0
     for name in HEADERS + sources:
@@ -57,22 +61,27 @@ def build(sources=None, verbose=False, force=False):
         newest = max(newest, os.path.getmtime(src))
         with open(src) as f:
             text, fired = _rewrite(f.read())
+        for mname, old, new in mutate or []:
+            if mname == name:
+                assert text.count(old) == 1, (name, old, text.count(old))
+                text = text.replace(old, new)
         report[name] = fired
-        dst = os.path.join(OUT, "csrc", name)
+        dst = os.path.join(out, "csrc", name)
         if not os.path.exists(dst) or open(dst).read() != text:
             with open(dst, "w") as f:
                 f.write(text)
     for dep in (os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "wemu_rt.cpp"), os.path.join(ROOT, "include", "f2n_abi.h"),
                 os.path.abspath(__file__)):
         newest = max(newest, os.path.getmtime(dep))
-    # (csrc/f2n_dev.h includes "../../include/f2n_abi.h": the copies sit two levels below a directory that holds include/)
-    inc = os.path.join(OUT, "..", "..", "include")
-    tag = os.path.join(OUT, "sources.txt")
-    want = " ".join(sources)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest and os.path.exists(tag) and open(tag).read() == want:
-        return LIB, report
-    jobs = [[CLANG] + FLAGS + ["-c", os.path.join(OUT, "csrc", s), "-o", os.path.join(OUT, s + ".o")] for s in sources]
-    jobs.append([CLANG] + RT_FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(OUT, "wemu_rt.o")])
+    tagf = os.path.join(out, "sources.txt")
+    want = " ".join(sources) + " | " + repr(mutate)
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= newest and os.path.exists(tagf) and open(tagf).read() == want:
+        return lib, report
+    # (csrc/f2n_dev.h includes "../../include/f2n_abi.h": resolved against the copies' directory first, then against -I paths --
+    # tests/wave_emul/include/f2n_abi.h forwards to the repository's header)
+    flags = FLAGS + ["-I" + os.path.join(HERE, "include", "hip", "..", "..")]
+    jobs = [[CLANG] + flags + ["-c", os.path.join(out, "csrc", s), "-o", os.path.join(out, s + ".o")] for s in sources]
+    jobs.append([CLANG] + RT_FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(out, "wemu_rt.o")])
 
     def run(cmd):
         if verbose:
@@ -83,10 +92,10 @@ def build(sources=None, verbose=False, force=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
-    run([CLANG, "-shared", "-fPIC"] + [j[-1] for j in jobs] + ["-o", LIB, "-lm"])
-    with open(tag, "w") as f:
+    run([CLANG, "-shared", "-fPIC"] + [j[-1] for j in jobs] + ["-o", lib, "-lm"])
+    with open(tagf, "w") as f:
         f.write(want)
-    return LIB, report
+    return lib, report
 
 
 def build_selftest(force=False):

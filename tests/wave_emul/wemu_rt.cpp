@@ -30,10 +30,14 @@ struct Fibre {
   Idx tid;
   int lane;
   int nf, nl;
+  FrameRec* top;      // &fr[nf - 1], or &no_frame
+  uintptr_t top_hi;   // the latch of the innermost loop of that activation (blocks beyond it leave the loop)
+  FrameRec no_frame;
   FrameRec fr[kMaxFrames];
   LoopRec lp[kMaxLoops];
   // taken when it parks: the return addresses of its call chain, kernel side first, with the frame each lies in
-  int nlev;
+  int nlev;  // -1: not read yet
+  const uintptr_t* park_fp;
   uintptr_t ra[kMaxLevels], rfp[kMaxLevels];
 };
 
@@ -89,6 +93,9 @@ void fibre_init(Fibre& f, int linear, const dim3& b) {
   f.state = READY;
   f.op = nullptr;
   f.nf = f.nl = f.nlev = 0;
+  f.no_frame = {0, 0};
+  f.top = &f.no_frame;
+  f.top_hi = 0;
   f.tid = {linear % b.x, (linear / b.x) % b.y, linear / (b.x * b.y)};
   f.lane = linear & 63;
   // top of stack: [fake return address of fibre_main][fibre_main as wemu_switch's return target][six registers]
@@ -183,7 +190,24 @@ const FrameRec* frame_of(const Fibre& f, uintptr_t fp) {
 // < 0: a is behind b in the program (a runs first), > 0: b is behind a, 0: cannot tell them apart.
 // Compared activation by activation from the kernel inwards: inside one activation first the loops (fewer back-edges taken =
 // behind; not in the loop at all = before it or past it, by its block), then the addresses (lower = behind: forward code).
-int behind(const Fibre& a, const Fibre& b) {
+void read_chain(Fibre& f) {  // the parked fibre's stack is intact: frame pointers link its activations (fibre_main's saved one is 0)
+  uintptr_t ra[kMaxLevels], rfp[kMaxLevels];
+  int n = 0;
+  for (const uintptr_t* fp = f.park_fp; fp != nullptr && fp[0] != 0 && n < kMaxLevels; fp = reinterpret_cast<const uintptr_t*>(fp[0])) {
+    ra[n] = fp[1];
+    rfp[n] = fp[0];
+    n++;
+  }
+  f.nlev = n;
+  for (int k = 0; k < n; k++) {
+    f.ra[k] = ra[n - 1 - k];
+    f.rfp[k] = rfp[n - 1 - k];
+  }
+}
+
+int behind(Fibre& a, Fibre& b) {
+  if (a.nlev < 0) read_chain(a);
+  if (b.nlev < 0) read_chain(b);
   const int n = std::min(a.nlev, b.nlev);
   for (int k = 0; k < n; k++) {
     const uintptr_t fa = a.rfp[k], fb = b.rfp[k];
@@ -224,16 +248,19 @@ extern "C" void __sanitizer_cov_trace_pc() {
   if (f == nullptr) return;  // host code of the .hip files (launch wrappers)
   const uintptr_t* me = static_cast<const uintptr_t*>(__builtin_frame_address(0));
   const uintptr_t fp = me[0], pc = me[1];  // the instrumented function's frame and the block's address
-  if (f->nf > 0 && f->fr[f->nf - 1].fp == fp && pc > f->fr[f->nf - 1].block && (f->nl == 0 || f->lp[f->nl - 1].fp != fp || pc <= f->lp[f->nl - 1].latch)) {
-    f->fr[f->nf - 1].block = pc;  // (the common case: one block further in the same activation, inside the same loops)
+  FrameRec* top = f->top;
+  if (top->fp == fp && pc > top->block && pc <= f->top_hi) {
+    top->block = pc;  // (the common case: further on in the same activation, inside the same loops)
     return;
   }
   while (f->nf > 0 && f->fr[f->nf - 1].fp < fp) f->nf--;  // activations that have returned (deeper = lower)
   while (f->nl > 0 && f->lp[f->nl - 1].fp < fp) f->nl--;
   if (f->nf > 0 && f->fr[f->nf - 1].fp == fp) {
+    // (an activation of ANOTHER function at the same stack address -- one helper returned, the next was called -- lands here too:
+    // what it inherits is dropped at its first block, which lies outside the other function's loops, and a loop it seems to have
+    // taken is never compared with anything: two lanes in one helper at one call site have been told apart further out)
     const uintptr_t last = f->fr[f->nf - 1].block;
-    while (f->nl > 0 && f->lp[f->nl - 1].fp == fp && (pc < f->lp[f->nl - 1].head || pc > f->lp[f->nl - 1].latch) && !(pc <= last && pc == f->lp[f->nl - 1].head))
-      f->nl--;  // left that loop
+    while (f->nl > 0 && f->lp[f->nl - 1].fp == fp && (pc < f->lp[f->nl - 1].head || pc > f->lp[f->nl - 1].latch)) f->nl--;  // left that loop
     if (pc <= last) {  // a back-edge: from block `last` to block `pc`
       if (f->nl > 0 && f->lp[f->nl - 1].fp == fp && f->lp[f->nl - 1].head == pc) {
         f->lp[f->nl - 1].iter++;
@@ -248,17 +275,8 @@ extern "C" void __sanitizer_cov_trace_pc() {
   } else if (f->nf < kMaxFrames) {
     f->fr[f->nf++] = {fp, pc};
   }
-}
-// (-finstrument-functions-after-inlining: an activation that returns takes its records with it, so that the next activation at the
-// same stack address does not inherit them)
-extern "C" void __cyg_profile_func_enter(void*, void*) {}
-extern "C" void __cyg_profile_func_exit(void*, void*) {
-  Fibre* f = g_cur;
-  if (f == nullptr) return;
-  const uintptr_t* me = static_cast<const uintptr_t*>(__builtin_frame_address(0));
-  const uintptr_t fp = me[0];
-  while (f->nf > 0 && f->fr[f->nf - 1].fp <= fp) f->nf--;
-  while (f->nl > 0 && f->lp[f->nl - 1].fp <= fp) f->nl--;
+  f->top = f->nf > 0 ? &f->fr[f->nf - 1] : &f->no_frame;
+  f->top_hi = f->nl > 0 && f->lp[f->nl - 1].fp == fp ? f->lp[f->nl - 1].latch : ~(uintptr_t) 0;
 }
 
 namespace {
@@ -322,21 +340,8 @@ uint64_t park(Op& op) {
   Fibre* f = g_cur;
   f->op = &op;
   f->state = PARKED;
-  {  // the call chain, innermost first on the stack, stored kernel side first (fibre_main's saved frame pointer is 0)
-    uintptr_t ra[kMaxLevels], rfp[kMaxLevels];
-    int n = 0;
-    for (const uintptr_t* fp = static_cast<const uintptr_t*>(__builtin_frame_address(0)); fp != nullptr && fp[0] != 0 && n < kMaxLevels;
-         fp = reinterpret_cast<const uintptr_t*>(fp[0])) {
-      ra[n] = fp[1];
-      rfp[n] = fp[0];
-      n++;
-    }
-    f->nlev = n;
-    for (int k = 0; k < n; k++) {
-      f->ra[k] = ra[n - 1 - k];
-      f->rfp[k] = rfp[n - 1 - k];
-    }
-  }
+  f->park_fp = static_cast<const uintptr_t*>(__builtin_frame_address(0));  // (its call chain is read off the stack when it is needed)
+  f->nlev = -1;
   // straight on to the wave's next runnable lane, if there is one (the scheduler would pick exactly that one)
   Fibre* wave = g_fibres + ((f - g_fibres) & ~63);
   const int n_lanes = std::min(64, g_block_threads - (int) (wave - g_fibres));
