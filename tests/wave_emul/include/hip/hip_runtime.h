@@ -79,6 +79,7 @@ uint64_t park(Op& op);  // parks the running fibre at `op`, returns op.result on
 void* dyn_lds();        // the dynamic LDS of the running workgroup
 typedef void (*Body)(void* closure);
 void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure);
+extern "C" void wemu_set_schedule(int mode);  // the order workgroups and waves run in (a race detector: results must not depend on it)
 extern "C" long wemu_counter(int which);  // 0: launches, 1: cross-lane operations, 2: operations that found a wave in more than one
                                           // group (divergent), 3: barriers, 4: work-items run
 }  // namespace wemu

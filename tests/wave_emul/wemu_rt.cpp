@@ -55,6 +55,7 @@ void* g_closure;
 long g_counters[8];
 size_t g_dyn_bytes = 0;
 int g_block_threads = 0;
+int g_schedule = 0;  // 0: workgroups and waves in ascending order; 1: both descending; 2: waves rotate, workgroups interleave from both ends
 std::unordered_map<uintptr_t, uintptr_t> g_loops;  // head block -> latch block of every loop seen so far
 
 // callee-saved registers of the SysV x86-64 ABI + the stack pointer; nothing else survives a call anyway
@@ -286,8 +287,11 @@ void run_block(int n_threads) {
   const int n_waves = (n_threads + 63) / 64;
   for (int t = 0; t < n_threads; t++) fibre_init(g_fibres[t], t, g_bdim);
   memset(g_dyn_lds, 0xCD, g_dyn_bytes);
-  for (;;) {
-    for (int w = 0; w < n_waves; w++) {
+  for (int round = 0;; round++) {
+    for (int wi = 0; wi < n_waves; wi++) {
+      // (the order in which the waves of a workgroup get to run between two barriers is the hardware's business: a kernel whose
+      // results depend on it has a race, and shows it when the order is changed -- wemu_set_schedule)
+      const int w = g_schedule == 0 ? wi : g_schedule == 1 ? n_waves - 1 - wi : (wi + round + (int) g_bid.x) % n_waves;
       Fibre* wave = g_fibres + 64 * w;
       const int n_lanes = std::min(64, n_threads - 64 * w);
       for (;;) {
@@ -447,16 +451,17 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closur
   g_closure = closure;
   g_bdim = block;
   g_gdim = grid;
-  for (unsigned z = 0; z < grid.z; z++)
-    for (unsigned y = 0; y < grid.y; y++)
-      for (unsigned x = 0; x < grid.x; x++) {
-        g_bid = {x, y, z};
-        run_block((int) n_threads);
-        g_counters[4] += (long) n_threads;
-      }
+  const size_t n_blocks = (size_t) grid.x * grid.y * grid.z;
+  for (size_t i = 0; i < n_blocks; i++) {
+    const size_t b = g_schedule == 0 ? i : g_schedule == 1 ? n_blocks - 1 - i : ((i & 1) ? n_blocks - 1 - i / 2 : i / 2);
+    g_bid = {(unsigned) (b % grid.x), (unsigned) ((b / grid.x) % grid.y), (unsigned) (b / ((size_t) grid.x * grid.y))};
+    run_block((int) n_threads);
+    g_counters[4] += (long) n_threads;
+  }
   g_cur = nullptr;
 }
 
+extern "C" void wemu_set_schedule(int mode) { g_schedule = mode; }
 extern "C" long wemu_counter(int which) { return which >= 0 && which < 8 ? g_counters[which] : -1; }
 
 }  // namespace wemu
