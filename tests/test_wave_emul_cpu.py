@@ -162,6 +162,7 @@ for _name, _params in _TESTS.items():
 
 # kernel-level tests of the other GPU modules (the ones that go through the C-ABI alone; the host classes need a device)
 _MORE = [
+    (gscale, "test_sampler_on_converged_octree", None),
     (gscale, "test_deep_tree_fills_the_dfs_stack", None),
     (gscale, "test_speculative_sampling_repair", None),
     (gscale, "test_speculative_tail_repair", None),
@@ -169,9 +170,31 @@ _MORE = [
     (gscale, "test_persistent_march", None),
     (gmlp, "test_general_mlp_forward_and_backward", ("d_in,d_hidden,n_hidden,n", [sh + (31,) for sh in gmlp.SHAPES] + [(17, 64, 2, 4099), (48, 16, 5, 4099)])),
     (gmlp, "test_unsupported_shapes_still_say_so", None),
+    # the run-combining / cost-balanced gather (every training iteration from fineness ~4 down takes it)
+    (gconv, "test_balanced_gather_edge_sizes", None),
+    (gconv, "test_balanced_gather_unstaged_with_many_warps", ("fineness", [4.0])),
 ]
 for _mod, _name, _params in _MORE:
     globals()[_name] = _on_the_emulator(_name, _params, _mod)
+
+
+@pytest.fixture(scope="session")
+def converged_march():
+    """test_gpu_converged.py's fixture of the same name -- the converged octree's training batch marched at fineness 1 / 2 / 4 -- from
+    the ORACLE's sampler instead of the device's (the device sampler equals it bit for bit on this very scene:
+    test_gpu_scale.py::test_sampler_on_converged_octree; on the emulator: the tests above), and from every 8th ray: input for the gather
+    tests, 6.9e4 samples at fineness 1."""
+    z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
+    ro, rd = np.ascontiguousarray(z["rays_o"][::8]), gp.oc.normalize_dirs(np.ascontiguousarray(z["rays_d"][::8]))
+    n = len(ro)
+    hits = gp.oc.oct_intersect(z["search_order"], ro, rd, 0.01, 1e8, z["tree_nodes"], 1024)
+    out = {}
+    for fin in (1.0, 4.0):
+        rng = np.random.default_rng(int(fin))
+        noise = (((rng.random(1024 + n + 10, dtype=np.float32) - np.float32(.5)) + np.float32(1.)) * np.float32(fin)).astype(np.float32)
+        m = gp.oc.ray_march(ro, rd, noise, 1. / 256., True, *hits, z["tree_nodes"], z["pers_trans"])
+        out[fin] = (np.ascontiguousarray(m["pts"]), np.ascontiguousarray(m["anchors"]))
+    return out
 
 
 def test_the_emulated_library_is_the_products_source_text(emul_lib):
