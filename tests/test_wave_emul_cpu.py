@@ -354,3 +354,64 @@ def test_results_do_not_depend_on_the_order_waves_and_workgroups_run_in(hip, emu
             fn(**{k: (kw[k] if k in kw else args[k]) for k in inspect.signature(fn).parameters})
     finally:
         emul_lib.wemu_set_schedule(int(os.environ.get("WEMU_SCHEDULE", "0")))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# octree maintenance on the device: the GPU test drives it through the host class (PersOctree::ProcOctree,
+# csrc/host/PersSampler.cpp); here the same call sequence is issued from Python against the emulated kernels of csrc/octree.hip
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _proc_octree_on_the_emulator(L, nodes, w, a, visit, subdivide, brute):
+    """PersOctree::ProcOctree(compact = true, subdivide, brute) of csrc/host/PersSampler.cpp, call for call."""
+    octc = gscale.octc
+    n = len(nodes)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    i32 = lambda *shape: np.zeros(shape, np.int32)  # noqa: E731
+    src = np.ascontiguousarray(nodes).view(np.uint8).reshape(-1).copy()
+    work, edited = np.zeros_like(src), np.zeros_like(src)
+    alive, n_child, keep, new_pos, total = i32(n), i32(n), i32(n), i32(n, 2), i32(1)
+    assert L.f2n_oct_prune_compress(None, n, vp(src), vp(work), vp(edited), vp(alive), vp(n_child), vp(keep)) == 0
+    assert L.f2n_segment_scan(None, n, vp(keep), vp(new_pos), vp(total)) == 0
+    m = int(total[0])
+    assert m >= 1
+    k_nodes, k_w, k_a, k_v = np.zeros(m * 64, np.uint8), i32(m), i32(m), i32(m)
+    assert L.f2n_oct_gather_kept(None, n, vp(edited), vp(keep), vp(new_pos), vp(w), vp(a), vp(visit), vp(k_nodes), vp(k_w), vp(k_a), vp(k_v)) == 0
+    if not subdivide:
+        return k_nodes.view(octc.NODE_DT), k_w, k_a
+    depth, size, new_idx = i32(m), i32(m), i32(m)
+    assert L.f2n_oct_subtree_sizes(None, m, vp(k_nodes), vp(k_v), int(brute), vp(depth), vp(size)) == 0
+    m2 = int(size[0])
+    d_nodes, d_w, d_a = np.zeros(m2 * 64, np.uint8), i32(m2), i32(m2)
+    assert L.f2n_oct_subdivide(None, m, vp(k_nodes), vp(k_v), int(brute), vp(size), vp(k_w), vp(k_a), vp(new_idx), vp(d_nodes), vp(d_w), vp(d_a)) == 0
+    return d_nodes.view(octc.NODE_DT), d_w, d_a
+
+
+@pytest.mark.parametrize("scene", ["fox", "converged"])
+def test_device_proc_octree_chain_on_the_emulator(emul_lib, fox_state, scene):
+    """tests/test_gpu_scale.py::test_device_proc_octree_chain, kernel level: chains of prune / compress / subdivide rounds with
+    random leaf deaths and visit counts; node arrays field by field and both statistics equal to the reference's sequential
+    algorithm (oracle/_ref where it is built, else its pinned restatement)."""
+    rng = np.random.default_rng(4)
+    if scene == "converged":  # the 148 k-node tree of a finished training
+        z = np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz"))
+        nodes = z["tree_nodes"].view(gscale.octc.NODE_DT).copy()
+        rounds = [(False, False, 0.3), (True, False, 0.2), (False, False, 0.7)]
+    else:                     # the 897-node construction tree
+        nodes = fox_state["tree_nodes"].view(gscale.octc.NODE_DT).copy()
+        rounds = [(True, False, 0.3), (False, False, 0.2), (True, True, 0.0), (False, False, 0.6), (True, False, 0.5), (False, False, 0.95)]
+    sizes = [len(nodes)]
+    for rnd, (sub, brute, kill) in enumerate(rounds):
+        n = len(nodes)
+        valid = np.nonzero(nodes["trans_idx"] >= 0)[0]
+        nodes["trans_idx"][rng.choice(valid, int(len(valid) * kill), replace=False)] = -1
+        visit = rng.integers(0, 10, n).astype(np.int32)
+        w = rng.integers(-5, 2000, n).astype(np.int32)
+        a = rng.integers(-5, 2000, n).astype(np.int32)
+        want_nodes, want_w, want_a = gscale._ref_proc(nodes, w, a, visit, True, sub, brute)
+        got, gw, ga = _proc_octree_on_the_emulator(emul_lib, nodes, w, a, visit, sub, brute)
+        assert len(got) == len(want_nodes), (rnd, len(got), len(want_nodes))
+        for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx"):
+            assert (got[f] == want_nodes[f]).all(), (rnd, f)
+        assert (gw == want_w).all() and (ga == want_a).all(), rnd
+        nodes = got.copy()
+        sizes.append(len(nodes))
+    assert max(sizes) > sizes[0] and min(sizes) < sizes[0], sizes  # (the chain both grew and shrank the tree)
