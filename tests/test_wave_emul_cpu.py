@@ -415,3 +415,90 @@ def test_device_proc_octree_chain_on_the_emulator(emul_lib, fox_state, scene):
         nodes = got.copy()
         sizes.append(len(nodes))
     assert max(sizes) > sizes[0] and min(sizes) < sizes[0], sizes  # (the chain both grew and shrank the tree)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# entry points the GPU suite reaches through the host classes only: direct calls on the emulated library
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _vp(x):
+    return x.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_keyed_draws_of_the_kernels_on_the_emulator(emul_lib, fox_state):
+    """The march noise a prologue launch draws for itself and the three uniforms of every ray of a keyed batch draw are
+    Philox4x32-10 of (key, sequence number, element) bit for bit (tests/test_gpu_determinism.py::test_in_kernel_draws_are_philox_of_
+    their_key, and f2n_draw_ray_batch_keyed == f2n_draw_ray_batch on the uniforms the numpy restatement gives)."""
+    from philox_ref import philox4x32_10
+    F32 = np.float32
+    L, st = emul_lib, fox_state
+    key, seq, fin = 0x1234567890ABCDEF, (1 << 40) + 7, F32(2.5)
+    n_rays, n_noise = 256, 1024 + 256 + 10
+    rng = np.random.default_rng(1)
+    dirs = rng.standard_normal((n_rays, 3)).astype(F32)
+    out, zero, noise = np.zeros_like(dirs), np.ones(3, np.int32), np.zeros(n_noise, F32)
+    assert L.f2n_sampler_prologue_keyed(None, n_rays, _vp(dirs), _vp(out), _vp(zero), 3, n_noise, ctypes.c_uint64(key), ctypes.c_uint64(seq),
+                                        ctypes.c_float(fin), _vp(noise)) == 0
+    i = np.arange(n_noise)
+    ctr = np.stack([i >> 2, np.zeros_like(i), np.full_like(i, seq & 0xFFFFFFFF), np.full_like(i, seq >> 32)], 1).astype(np.uint32)
+    x = philox4x32_10(ctr, (key & 0xFFFFFFFF, key >> 32))[i, i & 3]
+    u = (x >> np.uint32(8)).astype(F32) * F32(1.0 / 16777216.0)
+    want = ((u - F32(.5)) + F32(1.)) * fin
+    assert (noise.view(np.uint32) == want.view(np.uint32)).all()
+    assert (zero == 0).all() and (out.view(np.uint32) == gp.oc.normalize_dirs(dirs).view(np.uint32)).all()
+    # a keyed ray batch: ray r draws Philox(counter = (r, 0, seq), key) and takes its first three words
+    ts = np.ascontiguousarray(st["train_set"].astype(np.int32))
+    C = len(st["poses"])
+    H, W, R = 24, 32, 1000
+    images = rng.random((C, H, W, 3)).astype(F32)
+    poses, intri = np.ascontiguousarray(st["poses"][:, :3, :4].astype(F32)), np.ascontiguousarray(st["intri"].astype(F32))
+    dist = (rng.standard_normal((C, 4)) * 0.01).astype(F32)
+    bounds = np.ascontiguousarray(st["bounds"].astype(F32))
+    r = np.arange(R)
+    ctr = np.stack([r, np.zeros_like(r), np.full_like(r, seq & 0xFFFFFFFF), np.full_like(r, seq >> 32)], 1).astype(np.uint32)
+    u01 = np.ascontiguousarray(((philox4x32_10(ctr, (key & 0xFFFFFFFF, key >> 32))[:, :3] >> np.uint32(8)).astype(F32) * F32(1.0 / 16777216.0)))
+
+    def outputs():
+        return [np.zeros(R, np.int32), np.zeros((R, 2), np.int32), np.zeros((R, 3), F32), np.zeros((R, 3), F32), np.zeros((R, 3), F32), np.zeros((R, 2), F32)]
+    a, b = outputs(), outputs()
+    common = (_vp(ts), len(ts), H, W, _vp(poses), _vp(intri), _vp(dist), _vp(images), _vp(bounds))
+    assert L.f2n_draw_ray_batch_keyed(None, R, ctypes.c_uint64(key), ctypes.c_uint64(seq), *common, *[_vp(t) for t in a]) == 0
+    assert L.f2n_draw_ray_batch(None, R, _vp(u01), *common, *[_vp(t) for t in b]) == 0
+    for x_, y_ in zip(a, b):
+        assert (x_.view(np.uint32) == y_.view(np.uint32)).all()
+    assert len(np.unique(a[0])) > 10 and a[1][:, 0].max() < H and a[1][:, 1].max() < W
+
+
+def test_stat_update_and_scan_in_one_launch_on_the_emulator(emul_lib, fox_state):
+    """f2n_oct_update_stats_scan (round 5: one launch) == f2n_oct_update_stats_ex + f2n_segment_scan_ex: statistics, node records,
+    child blocks, death stamps, scan, totals and the host mirror, on the fox octree with random votes."""
+    L, st = emul_lib, fox_state
+    rng = np.random.default_rng(8)
+    n_nodes = st["tree_nodes"].size // 64
+    n = 4097
+    counts = rng.integers(0, 300, n).astype(np.int32)
+    also = np.array([41, 42], np.int32)
+    cb0 = np.zeros(n_nodes * 8 * 32, np.uint8)
+    tn0 = st["tree_nodes"].copy()
+    assert L.f2n_oct_build_child_blocks(None, n_nodes, _vp(tn0), _vp(cb0)) == 0
+
+    def inputs():
+        g = np.random.default_rng(9)
+        return dict(wa=g.integers(-1, 3, n_nodes).astype(np.int32), aa=g.integers(-1, 3, n_nodes).astype(np.int32),
+                    mk=g.integers(0, 2, n_nodes).astype(np.int32), ws=g.integers(-2, 5, n_nodes).astype(np.int32),
+                    as_=g.integers(-2, 5, n_nodes).astype(np.int32), tn=tn0.copy(), cb=cb0.copy(), died=np.full(n_nodes, -1, np.int32),
+                    de=np.zeros(1, np.int32), deh=np.zeros(1, np.int32), se=np.zeros((n, 2), np.int32), tot=np.zeros(1, np.int32),
+                    mirror=np.full(3, -1, np.int32))
+    a, b = inputs(), inputs()
+    epoch = 5
+    assert L.f2n_oct_update_stats_ex(None, n_nodes, _vp(a["wa"]), _vp(a["aa"]), _vp(a["mk"]), _vp(a["ws"]), _vp(a["as_"]), _vp(a["tn"]), _vp(a["cb"]), 1,
+                                     _vp(a["died"]), epoch, _vp(a["de"]), _vp(a["deh"])) == 0
+    assert L.f2n_segment_scan_ex(None, n, _vp(counts), _vp(a["se"]), _vp(a["tot"]), _vp(a["mirror"]), _vp(also), 2) == 0
+    assert L.f2n_oct_update_stats_scan(None, n_nodes, _vp(b["wa"]), _vp(b["aa"]), _vp(b["mk"]), _vp(b["ws"]), _vp(b["as_"]), _vp(b["tn"]), _vp(b["cb"]), 1,
+                                       _vp(b["died"]), epoch, _vp(b["de"]), _vp(b["deh"]), n, _vp(counts), _vp(b["se"]), _vp(b["tot"]),
+                                       _vp(b["mirror"]), _vp(also), 2) == 0
+    for k in a:
+        assert (a[k] == b[k]).all(), k
+    assert int(a["tot"][0]) == int(counts.sum()) and list(a["mirror"]) == [41, 42, int(counts.sum())]
+    assert (a["died"] == epoch).any() and int(a["de"][0]) == epoch  # (leaves did die in this update)
+    ew, ea, enodes = gp.oc.update_node_stats(inputs()["wa"], inputs()["aa"], inputs()["mk"], inputs()["ws"], inputs()["as_"], tn0)
+    assert (a["ws"] == ew).all() and (a["as_"] == ea).all() and (a["tn"] == enodes).all()  # ... and the oracle agrees
