@@ -502,3 +502,49 @@ def test_stat_update_and_scan_in_one_launch_on_the_emulator(emul_lib, fox_state)
     assert (a["died"] == epoch).any() and int(a["de"][0]) == epoch  # (leaves did die in this update)
     ew, ea, enodes = gp.oc.update_node_stats(inputs()["wa"], inputs()["aa"], inputs()["mk"], inputs()["ws"], inputs()["as_"], tn0)
     assert (a["ws"] == ew).all() and (a["as_"] == ea).all() and (a["tn"] == enodes).all()  # ... and the oracle agrees
+
+
+def test_reference_numerics_build_on_the_emulator(hip, monkeypatch, fox_state, fox_golden):
+    """The kernel-level half of tests/test_gpu_refnum.py: the same sources with -DF2N_REFERENCE_NUMERICS=1 (libf2n_hip_refnum.so's
+    build) -- the MLP forward with a binary16 accumulator fragment is the oracle's accumulator reading 1, the hash backward adds
+    f16-rounded addends into f16 running sums (Hash3DAnchored.cu:145-153)."""
+    import wemu_build as wave_emul_build
+    lib, _ = wave_emul_build.build(tag="refnum", defines=("F2N_REFERENCE_NUMERICS=1",))
+    L = ctypes.CDLL(lib)
+    L.f2n_build_info.restype = ctypes.c_char_p
+    monkeypatch.setattr(hip, "_lib", L)
+    assert L.f2n_numerics_mode() == 1 and b"REFERENCE-NUMERICS" in L.f2n_build_info()
+    oc, op, T, N, F32 = gp.oc, gp.op, gp.T, gp.N, np.float32
+    rng = np.random.default_rng(3)
+    for n_hidden in (1, 2):
+        params = (rng.standard_normal(oc.mlp_n_params(32, 64, n_hidden)) * 0.25).astype(F32)
+        x = rng.standard_normal((1024, 32)).astype(F32)
+        out = torch.zeros((1024, 16), dtype=torch.float16)
+        hip.mlp_fwd(1024, 32, 64, n_hidden, T(oc.f2h(params).view(np.float16)), T(x), out)
+        got = N(out).astype(F32)
+        ref0 = oc.h2f(oc.mlp_fwd(params, x, 64, n_hidden))
+        with oc.mlp_accumulator(1):
+            ref1 = oc.h2f(oc.mlp_fwd(params, x, 64, n_hidden))
+        e0, e1 = np.abs(got - ref0), np.abs(got - ref1)
+        assert e1.max() <= 4 * 2.0 ** -11 * np.abs(ref1).max() and e1.mean() < 0.25 * e0.mean(), (e1.mean(), e0.mean())
+        assert (got == ref1).mean() > 0.97, (got == ref1).mean()
+    st, g, log2 = fox_state, fox_golden, 14
+    grid = op.HashGrid(np.zeros((16 << log2, 2), F32), st["prim_pool"], st["bias_pool"], int(st["n_volumes"]), log2)
+    reps = 3
+    pts = np.tile(g["march_pts"], (reps, 1))
+    vol = np.tile(np.ascontiguousarray(g["march_anchors"][:, 0]), reps)
+    n = len(pts)
+    gin_h = oc.f2h((rng.standard_normal((n, 32)) * 0.05).astype(F32))
+    gtab = torch.zeros(grid.table_f32.size, dtype=torch.float16)
+    hip.hash_bwd(n, grid.n_volumes, T(grid.prim_pool), T(grid.local_idx), T(grid.local_size), T(grid.bias_pool), T(grid.scales), T(pts), True,
+                 T(vol), 1, T(gin_h.view(np.float16)), gtab, 1 << log2)
+    q01 = ((pts + F32(1.)) * F32(.5)).astype(F32)
+    args = (grid.table_f32.size, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q01, vol, grid.n_volumes, gin_h, grid.scales)
+    ref32 = oc.hash_bwd(*args, fp32_accumulate=True)
+    ref16 = oc.h2f(oc.hash_bwd(*args, fp32_accumulate=False))
+    got = N(gtab).astype(F32)
+    d32, o16 = np.abs(got - ref32), np.abs(ref16 - ref32)
+    assert ((got != 0) == (ref16 != 0)).mean() > 0.999
+    # f16 running sums in SOME order: as far from the exact sums as the oracle's f16 accumulation in ITS order, not closer
+    assert 0.3 * o16.mean() <= d32.mean() <= 3.0 * o16.mean(), (d32.mean(), o16.mean())
+    assert d32.max() <= 0.05 * np.abs(ref32).max()
