@@ -222,81 +222,23 @@ def selftest_lib():
     return ctypes.CDLL(wave_emul_build.build_selftest())
 
 
-def test_emulated_permutes_know_the_isa(selftest_lib):
-    out = np.full((18, 64), 12345, np.int32)
-    assert selftest_lib.st_permutes(out.ctypes.data_as(ctypes.c_void_p)) == 0
-    l = np.arange(64)
-    row, c = l & ~15, l & 15
-    want = [
-        l ^ 1, l ^ 2,
-        np.where(c >= 1, l - 1, -7), np.where(c >= 3, l - 3, 0), np.where(c + 2 <= 15, l + 2, -7),
-        row + 15 - c, (l & ~7) | (7 - (l & 7)),
-        np.where(((l >> 4) & 1) == 0, l ^ 1, -7), np.where(c < 8, l ^ 1, -7), row + ((c - 1) & 15),
-        row + 15, np.full(64, 70 & 63), l ^ 32, l ^ 3, np.where(c >= 1, l - 1, l), np.where((l & 7) + 2 < 8, l + 2, l),
-        (((l & ~7) + 7) * 0.5).astype(np.int32), l ^ 1,
-    ]
-    for k, w in enumerate(want):
-        assert (out[k] == w).all(), (k, out[k], w)
+def _host_run(lib):
+    """known_answers.py's runner for a library whose launches take host pointers (the emulation)."""
+    def run(name, *args):
+        conv = [x.ctypes.data_as(ctypes.c_void_p) if isinstance(x, np.ndarray) else x for x in args]
+        assert getattr(lib, name)(*conv) == 0, name
+    return run
 
 
-def test_emulated_exec_masks_follow_the_control_flow(selftest_lib):
-    out = np.zeros((8, 64), np.uint64)
-    assert selftest_lib.st_masks(out.ctypes.data_as(ctypes.c_void_p)) == 0
-    l = np.arange(64)
-    mask = lambda pred: int(sum(1 << int(i) for i in l[pred]))  # noqa: E731
-    untouched = 0xDEAD
-    assert (out[0] == mask(l % 3 == 0)).all()
-    assert (out[1][l % 2 == 1] == mask((l % 2 == 1) & (l < 40))).all() and (out[1][l % 2 == 0] == untouched).all()
-    assert (out[2][l % 2 == 0] == mask((l % 2 == 0) & (l >= 60))).all() and (out[2][l % 2 == 1] == untouched).all()
-    assert (out[3][l >= 13] == 13).all() and (out[3][l < 13] == untouched).all()
-    assert (out[4][l != 5] == 0).all() and out[4][5] == untouched
-    want5 = np.where(l >= 2, np.where((l & 15) >= 1, l - 1, -7), 0).astype(np.int64)
-    want5[2] = -7  # (lane 1 is not in the mask)
-    assert (out[5][2:].astype(np.uint32) == want5[2:].astype(np.uint32)).all() and (out[5][:2] == untouched).all()
-    left = lambda i: 64 - 8 * (i + 1)  # noqa: E731  (lanes still in the loop at trip i)
-    assert (out[6] == np.array([sum(left(i) for i in range(int(x) >> 3)) for x in l])).all()
-    assert (out[7][:50] == (1 << 50) - 1).all() and (out[7][50:] == untouched).all()
-
-
-def test_emulated_workgroup_has_lds_barriers_and_their_vote(selftest_lib):
-    nb = 3
-    out = np.zeros(nb * 256 + 1, np.int32)
-    assert selftest_lib.st_block(out.ctypes.data_as(ctypes.c_void_p), nb) == 0
-    for b in range(nb):
-        t = np.arange(256)
-        a = b * 1000 + (255 - t)
-        got = out[b * 256:(b + 1) * 256]
-        assert (got[:64] == a[:64].sum()).all()
-        assert (got[64:] == (a + (255 - t) ** 2 + 1000000 * (b == 1))[64:]).all()
-    assert out[-1] == nb
-
-
-def test_emulated_mfma_tiles(selftest_lib):
-    rng = np.random.default_rng(5)
-    A = rng.integers(-8, 9, (16, 32)).astype(np.float16)
-    B = rng.integers(-8, 9, (32, 16)).astype(np.float16)
-    C = rng.integers(-100, 100, (16, 16)).astype(np.float32)
-    D16, D32 = np.zeros((16, 16), np.float32), np.zeros((16, 16), np.float32)
-    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-    assert selftest_lib.st_mfma(p(A), p(B), p(C), p(D16), p(D32)) == 0
-    Af, Bf = A.astype(np.float32), B.astype(np.float32)
-    assert (D16 == Af[:, :16] @ Bf[:16] + C).all()   # (small integers: every sum is exact)
-    assert (D32 == Af @ Bf + C).all()
-
-
-def test_emulated_wave_is_whole_again_at_the_top_of_a_loop(selftest_lib):
-    """Lanes that finish a trip's work early wait for the others at the end of the loop's body (the hardware reconverges there);
-    a scheduler that went by addresses alone would let them run ahead to the loop's head -- a lower address -- and vote alone."""
-    n_groups = 23
-    out = np.zeros((n_groups, 64), np.int32)
-    counter = np.zeros(1, np.int32)
-    assert selftest_lib.st_persistent(out.ctypes.data_as(ctypes.c_void_p), counter.ctypes.data_as(ctypes.c_void_p), n_groups, 3) == 0
-    lane = np.arange(64)
-    for g in range(n_groups):
-        trips = (g * 7 + (lane >> 4) * 5) % 11
-        acc = np.array([sum(i + (int(x) ^ 1) for i in range(int(t))) if t != 3 else 0 for x, t in zip(lane, trips)])
-        assert (out[g] == acc + 1).all(), (g, out[g], acc + 1)
-    assert counter[0] == n_groups + 3  # (every block's last fetch comes back empty)
+@pytest.mark.parametrize("case", ["permutes", "masks", "block", "mfma", "persistent"])
+def test_emulated_wave_knows_the_isa(selftest_lib, case):
+    """Every cross-lane operation under full and partial EXEC masks, divergent loop exits, LDS / barriers / the barrier's vote, the
+    two MFMA tiles against exact integer products, and a persistent wave whose rows work for different lengths (lanes that finish
+    a trip early wait at the end of the loop's body: a scheduler that went by addresses alone would let them run ahead to the
+    loop's head and vote alone).  Expected values: tests/wave_emul/known_answers.py -- the same file
+    tools/wave_selftest_on_gpu.py holds the HARDWARE to."""
+    import known_answers
+    getattr(known_answers, "check_" + case)(_host_run(selftest_lib))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
