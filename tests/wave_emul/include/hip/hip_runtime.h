@@ -78,9 +78,15 @@ struct Op {
 uint64_t park(Op& op);  // parks the running fibre at `op`, returns op.result once the operation has been carried out
 void* dyn_lds();        // the dynamic LDS of the running workgroup
 typedef void (*Body)(void* closure);
-void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure);
+void launch(const char* kernel, dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure);
 extern "C" void wemu_set_schedule(int mode);  // the order workgroups and waves run in (a race detector: results must not depend on it)
-extern "C" long wemu_counter(int which);  // 0: launches, 1: cross-lane operations, 2: operations that found a wave in more than one
+extern "C" long wemu_counter(int which);
+// the memory traffic of every launch since wemu_traffic_reset(), from the compiler's load / store instrumentation (only the
+// "traffic" build of wemu_build.py has it): out[0..7] = global bytes loaded, stored, distinct 128-byte lines loaded, stored,
+// LDS (dynamic buffer + the library's own statics) bytes loaded, stored, workgroups, work-items per workgroup
+extern "C" int wemu_traffic_launches(void);
+extern "C" int wemu_traffic_get(int i, char* name, int name_size, unsigned long long* out8);
+extern "C" void wemu_traffic_reset(void);  // 0: launches, 1: cross-lane operations, 2: operations that found a wave in more than one
                                           // group (divergent), 3: barriers, 4: work-items run
 }  // namespace wemu
 
@@ -91,12 +97,12 @@ extern "C" long wemu_counter(int which);  // 0: launches, 1: cross-lane operatio
 #define warpSize 64
 
 template <typename F>
-static inline void wemu_launch_(dim3 grid, dim3 block, size_t lds, F&& f) {
-  wemu::launch(grid, block, lds, [](void* c) { (*static_cast<std::remove_reference_t<F>*>(c))(); }, &f);
+static inline void wemu_launch_(const char* kernel, dim3 grid, dim3 block, size_t lds, F&& f) {
+  wemu::launch(kernel, grid, block, lds, [](void* c) { (*static_cast<std::remove_reference_t<F>*>(c))(); }, &f);
 }
 // (launches are synchronous: the stream argument is evaluated and dropped)
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  wemu_launch_(dim3(grid), dim3(block), (size_t) (lds), [&]() { (void) (stream); kernel(__VA_ARGS__); })
+  wemu_launch_(#kernel, dim3(grid), dim3(block), (size_t) (lds), [&]() { (void) (stream); kernel(__VA_ARGS__); })
 
 // ------------------------------------------------------------------------------------------------- host API subset
 typedef int hipError_t;

@@ -47,7 +47,7 @@ def _rewrite(text):
     return text, fired
 
 
-def build(sources=None, verbose=False, force=False, mutate=None, tag="", defines=()):
+def build(sources=None, verbose=False, force=False, mutate=None, tag="", defines=(), traffic=False):
     """mutate = [(file name, old text, new text)]: a deliberately broken variant (built into _build/<tag>/) for the tests that show
     the emulated suite notices.  defines: e.g. ("F2N_REFERENCE_NUMERICS=1",), the second build of the product (f2-nerf_amd/build.py)."""
     sources = SOURCES if sources is None else sources
@@ -74,12 +74,14 @@ def build(sources=None, verbose=False, force=False, mutate=None, tag="", defines
                 os.path.abspath(__file__)):
         newest = max(newest, os.path.getmtime(dep))
     tagf = os.path.join(out, "sources.txt")
-    want = " ".join(sources) + " | " + repr(mutate) + " | " + repr(tuple(defines))
+    want = " ".join(sources) + " | " + repr(mutate) + " | " + repr(tuple(defines)) + " | " + repr(traffic)
     if not force and os.path.exists(lib) and os.path.getmtime(lib) >= newest and os.path.exists(tagf) and open(tagf).read() == want:
         return lib, report
     # (csrc/f2n_dev.h includes "../../include/f2n_abi.h": resolved against the copies' directory first, then against -I paths --
     # tests/wave_emul/include/f2n_abi.h forwards to the repository's header)
     flags = FLAGS + ["-I" + os.path.join(HERE, "include", "hip", "..", "..")] + ["-D" + d for d in defines]
+    if traffic:  # (every load and store of the kernels reports to the runtime as well: tools/source_level_traffic.py)
+        flags = [f + ",trace-loads,trace-stores" if f.startswith("-fsanitize-coverage=") else f for f in flags]
     jobs = [[CLANG] + flags + ["-c", os.path.join(out, "csrc", s), "-o", os.path.join(out, s + ".o")] for s in sources]
     jobs.append([CLANG] + RT_FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(out, "wemu_rt.o")])
 

@@ -3,7 +3,12 @@
 #include <stdio.h>
 #include <sys/mman.h>
 
+#include <link.h>
+#include <pthread.h>
+
+#include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace wemu {
@@ -56,6 +61,17 @@ long g_counters[8];
 size_t g_dyn_bytes = 0;
 int g_block_threads = 0;
 int g_schedule = 0;  // 0: workgroups and waves in ascending order; 1: both descending; 2: waves rotate, workgroups interleave from both ends
+// ---- the memory traffic of a launch, as the source text performs it (load / store instrumentation of the "traffic" build) ----
+struct LaunchTraffic {
+  std::string kernel;
+  unsigned long long v[8];
+};
+std::vector<LaunchTraffic> g_traffic;
+std::unordered_set<uintptr_t> g_ld_lines, g_st_lines;
+unsigned long long g_tr[6];
+uintptr_t g_host_stack_lo = 0, g_host_stack_hi = 0;  // the launching thread's stack: kernel arguments (by-reference captures of the launch)
+uintptr_t g_image_lo = 0, g_image_hi = 0;  // this shared object: `__shared__` statics (and constant tables) live in it
+bool g_tracing = false;                     // a launch is running and the build is instrumented
 std::unordered_map<uintptr_t, uintptr_t> g_loops;  // head block -> latch block of every loop seen so far
 
 // callee-saved registers of the SysV x86-64 ABI + the stack pointer; nothing else survives a call anyway
@@ -434,7 +450,7 @@ void xl_mfma(const void* site, int kind, const void* a, const void* b, const voi
 
 void* dyn_lds() { return g_dyn_lds; }
 
-void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure) {
+void launch(const char* kernel, dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure) {
   const size_t n_threads = (size_t) block.x * block.y * block.z;
   if (n_threads == 0 || n_threads > (size_t) kMaxThreads || dyn_lds_bytes > kDynLds) {
     fprintf(stderr, "wave_emul: launch of %zu work-items per group / %zu bytes of dynamic LDS\n", n_threads, dyn_lds_bytes);
@@ -445,6 +461,38 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closur
     if (g_stacks == MAP_FAILED || posix_memalign(reinterpret_cast<void**>(&g_dyn_lds), 256, kDynLds) != 0) abort();
     for (int t = 0; t < kMaxThreads; t++) g_fibres[t].stack = g_stacks + kStack * t;
   }
+  if (g_image_hi == 0) {
+    dl_iterate_phdr([](dl_phdr_info* info, size_t, void*) {
+      const uintptr_t me = reinterpret_cast<uintptr_t>(&g_image_lo);
+      uintptr_t lo = ~(uintptr_t) 0, hi = 0;
+      for (int i = 0; i < info->dlpi_phnum; i++)
+        if (info->dlpi_phdr[i].p_type == PT_LOAD) {
+          lo = std::min(lo, (uintptr_t) (info->dlpi_addr + info->dlpi_phdr[i].p_vaddr));
+          hi = std::max(hi, (uintptr_t) (info->dlpi_addr + info->dlpi_phdr[i].p_vaddr + info->dlpi_phdr[i].p_memsz));
+        }
+      if (me >= lo && me < hi) {
+        g_image_lo = lo;
+        g_image_hi = hi;
+        return 1;
+      }
+      return 0;
+    }, nullptr);
+  }
+  {
+    pthread_attr_t at;
+    void* lo = nullptr;
+    size_t sz = 0;
+    if (pthread_getattr_np(pthread_self(), &at) == 0) {
+      pthread_attr_getstack(&at, &lo, &sz);
+      pthread_attr_destroy(&at);
+      g_host_stack_lo = (uintptr_t) lo;
+      g_host_stack_hi = (uintptr_t) lo + sz;
+    }
+  }
+  memset(g_tr, 0, sizeof(g_tr));
+  g_ld_lines.clear();
+  g_st_lines.clear();
+  g_tracing = true;
   g_counters[0]++;
   g_dyn_bytes = std::min(kDynLds, (dyn_lds_bytes + 4095) & ~(size_t) 4095);  // (a page of poison behind what was asked for)
   g_body = body;
@@ -459,7 +507,50 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closur
     g_counters[4] += (long) n_threads;
   }
   g_cur = nullptr;
+  g_tracing = false;
+  if (g_tr[0] | g_tr[1] | g_tr[4] | g_tr[5]) {
+    LaunchTraffic t;
+    t.kernel = kernel;
+    t.v[0] = g_tr[0]; t.v[1] = g_tr[1]; t.v[2] = g_ld_lines.size(); t.v[3] = g_st_lines.size(); t.v[4] = g_tr[4]; t.v[5] = g_tr[5];
+    t.v[6] = n_blocks; t.v[7] = n_threads;
+    g_traffic.push_back(t);
+  }
 }
+
+extern "C" int wemu_traffic_launches(void) { return (int) g_traffic.size(); }
+extern "C" void wemu_traffic_reset(void) { g_traffic.clear(); }
+extern "C" int wemu_traffic_get(int i, char* name, int name_size, unsigned long long* out8) {
+  if (i < 0 || i >= (int) g_traffic.size()) return -1;
+  snprintf(name, (size_t) name_size, "%s", g_traffic[i].kernel.c_str());
+  memcpy(out8, g_traffic[i].v, sizeof(g_traffic[i].v));
+  return 0;
+}
+
+namespace {
+inline void traffic(uintptr_t a, unsigned bytes, bool store) {
+  if (!g_tracing || g_cur == nullptr) return;
+  if (a >= (uintptr_t) g_stacks && a < (uintptr_t) g_stacks + kStack * kMaxThreads) return;  // registers / private memory
+  if (a >= g_host_stack_lo && a < g_host_stack_hi) return;                                     // kernel arguments
+  const bool lds = (a >= (uintptr_t) g_dyn_lds && a < (uintptr_t) g_dyn_lds + kDynLds) || (a >= g_image_lo && a < g_image_hi);
+  if (lds) {
+    g_tr[store ? 5 : 4] += bytes;
+    return;
+  }
+  g_tr[store ? 1 : 0] += bytes;
+  (store ? g_st_lines : g_ld_lines).insert(a >> 7);
+  if (((a + bytes - 1) >> 7) != (a >> 7)) (store ? g_st_lines : g_ld_lines).insert((a + bytes - 1) >> 7);
+}
+}  // namespace
+extern "C" void __sanitizer_cov_load1(void* p) { traffic((uintptr_t) p, 1, false); }
+extern "C" void __sanitizer_cov_load2(void* p) { traffic((uintptr_t) p, 2, false); }
+extern "C" void __sanitizer_cov_load4(void* p) { traffic((uintptr_t) p, 4, false); }
+extern "C" void __sanitizer_cov_load8(void* p) { traffic((uintptr_t) p, 8, false); }
+extern "C" void __sanitizer_cov_load16(void* p) { traffic((uintptr_t) p, 16, false); }
+extern "C" void __sanitizer_cov_store1(void* p) { traffic((uintptr_t) p, 1, true); }
+extern "C" void __sanitizer_cov_store2(void* p) { traffic((uintptr_t) p, 2, true); }
+extern "C" void __sanitizer_cov_store4(void* p) { traffic((uintptr_t) p, 4, true); }
+extern "C" void __sanitizer_cov_store8(void* p) { traffic((uintptr_t) p, 8, true); }
+extern "C" void __sanitizer_cov_store16(void* p) { traffic((uintptr_t) p, 16, true); }
 
 extern "C" void wemu_set_schedule(int mode) { g_schedule = mode; }
 extern "C" long wemu_counter(int which) { return which >= 0 && which < 8 ? g_counters[which] : -1; }
