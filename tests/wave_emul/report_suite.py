@@ -1,6 +1,6 @@
 """Runs tests/test_wave_emul_cpu.py (the GPU parity tests' bodies on the emulated wavefront: tests/wave_emul/) and writes one line
 per case: outcome, time, launches, work-items, cross-lane operations, how many of those found their wave in more than one group
-(divergent: the scheduler had to decide who is behind), barriers.  `python tools/emulated_suite_report.py > profiles/r05_emulated_suite.txt`
+(divergent: the scheduler had to decide who is behind), barriers.  `python tests/wave_emul/report_suite.py > profiles/r05_emulated_suite.txt`
 (no GPU needed; WEMU_SCHEDULE=1 / 2 in the environment runs the suite under the other workgroup / wave orders)."""
 import ctypes
 import os
@@ -9,7 +9,7 @@ import time
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "wave_emul"))
 

@@ -1,9 +1,9 @@
-"""What the kernels' SOURCE TEXT moves through memory, per unit of work -- the figures DESIGN.md section 4 prices the roofline with
+"""Test infrastructure (it builds its inputs with the oracle's hash-grid layout helpers, so it lives under tests/).  What the kernels' SOURCE TEXT moves through memory, per unit of work -- the figures DESIGN.md section 4 prices the roofline with
 (592 B per marched sample for the gather, 8-byte records for the scatter, 30 B per table entry for Adam), counted
 instead of argued.  The kernels are compiled for the emulated wavefront (tests/wave_emul/) with the compiler's load / store
 instrumentation on top; the runtime classifies every access of a launch (private stack = registers: dropped; the dynamic LDS buffer
 and the library's own statics = LDS; everything else = global memory) and counts bytes (aggregate copies the compiler expands into memcpy are not seen: noted where it matters).  No GPU needed:
-`python tools/source_level_traffic.py > profiles/r05_source_level_traffic.txt`.  What it cannot know: what the caches make of it
+`python tests/wave_emul/source_level_traffic.py > profiles/r05_source_level_traffic.txt`.  What it cannot know: what the caches make of it
 (that is what the FETCH_SIZE / WRITE_SIZE passes of profiles/run_profiles.sh measure on the hardware)."""
 import ctypes
 import os
@@ -13,7 +13,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "wave_emul"))

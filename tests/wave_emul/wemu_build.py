@@ -80,7 +80,7 @@ def build(sources=None, verbose=False, force=False, mutate=None, tag="", defines
     # (csrc/f2n_dev.h includes "../../include/f2n_abi.h": resolved against the copies' directory first, then against -I paths --
     # tests/wave_emul/include/f2n_abi.h forwards to the repository's header)
     flags = FLAGS + ["-I" + os.path.join(HERE, "include", "hip", "..", "..")] + ["-D" + d for d in defines]
-    if traffic:  # (every load and store of the kernels reports to the runtime as well: tools/source_level_traffic.py)
+    if traffic:  # (every load and store of the kernels reports to the runtime as well: tests/wave_emul/source_level_traffic.py)
         flags = [f + ",trace-loads,trace-stores" if f.startswith("-fsanitize-coverage=") else f for f in flags]
     jobs = [[CLANG] + flags + ["-c", os.path.join(out, "csrc", s), "-o", os.path.join(out, s + ".o")] for s in sources]
     jobs.append([CLANG] + RT_FLAGS + ["-c", os.path.join(HERE, "wemu_rt.cpp"), "-o", os.path.join(out, "wemu_rt.o")])
