@@ -490,3 +490,118 @@ def test_reference_numerics_build_on_the_emulator(hip, monkeypatch, fox_state, f
     # f16 running sums in SOME order: as far from the exact sums as the oracle's f16 accumulation in ITS order, not closer
     assert 0.3 * o16.mean() <= d32.mean() <= 3.0 * o16.mean(), (d32.mean(), o16.mean())
     assert d32.max() <= 0.05 * np.abs(ref32).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the drop-in boundary as a whole: ExpRunner::Train's iteration composed from the C-ABI's seam entry points, one call where the
+# reference has one, on the emulated kernels -- against the oracle's iteration (tests/test_gpu_e2e.py's helper)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_one_training_iteration_through_the_seams_on_the_emulator(hip, fox_state):
+    """BASELINE config 1 (256 rays, 2^14 x 16 table, 2048 edge samples): sampler (count / scan / fill) -> density pre-pass -> early
+    stop + FilterIdxBounds + compaction -> edge samples -> field (hash grid + MLP) -> ScatterIdx + SH + colour MLP -> compositing (+
+    WeightVar) -> loss -> compositing backward -> colour backward -> field backward (MLP + hash scatter) -- what a maintainer who binds
+    the reference's seams to include/f2n_abi.h one by one would run.  Bars: tests/test_gpu_e2e.py::test_config1_end_to_end_parity's."""
+    import test_gpu_e2e as e2e
+    from f2_nerf_amd import config
+    st, oc, op, T, N, F32 = fox_state, gp.oc, gp.op, gp.T, gp.N, np.float32
+    cfg = config.preset("wanjinyou", ["field.log2_table_size=14"])
+    rng = np.random.default_rng(42)
+    R, NE, log2, it = 256, e2e.N_EDGE, 14, 1
+    n_img = len(st["poses"])
+    table = (rng.standard_normal((16 << log2, 2)) * 0.3).astype(F32)
+    p_field, p_color = gp.rand_params(rng, 1), gp.rand_params(rng, 2)
+    app_emb = (rng.standard_normal((n_img, 16)) * 0.1).astype(F32)
+    arrays = (st["tree_nodes"], st["pers_trans"], None, None, table, st["prim_pool"], st["bias_pool"], np.array([int(st["n_volumes"])]), p_field, p_color, app_emb)
+    ro, rd, bounds, cam = e2e.fox_batch(st, rng, R)
+    gt = rng.random((R, 3), dtype=F32)
+    fineness = 16.0
+    noise = (((rng.random(1024 + R + 10, dtype=F32) - F32(.5)) + F32(1.)) * F32(fineness)).astype(F32)
+    bg = rng.random((R, 3), dtype=F32)
+    eidx = rng.integers(0, st["edge_pool"].size // 64, NE).astype(np.int32)
+    ecoord = (rng.random((NE, 2), dtype=F32) * F32(2.) - F32(1.)).astype(F32)
+    ref = e2e.oracle_train_iteration(st, cfg, arrays, ro, rd, cam, gt, noise, bg, eidx, ecoord, iter_step=it)
+
+    z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype)  # noqa: E731
+    i32 = torch.int32
+    # ---- PersSampler::GetSamples ----
+    rdn = z(R, 3)
+    hip.normalize_dirs(R, T(rd), rdn)
+    ps = cfg["pts_sampler"]
+    hits, smp = gp.gpu_sample(hip, st, ro, N(rdn), noise, float(ps["sample_l"]), bool(ps["scale_by_dis"]), near=float(ps["near"]),
+                              max_hits=int(ps["max_oct_intersect_per_ray"]))
+    for k in ("pts_idx_bounds", "anchors", "t", "dt", "pts", "dirs"):
+        a, b = smp[k], ref["smp"][k]
+        assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all(), k
+    n = len(smp["t"])
+    grid = op.HashGrid(table, st["prim_pool"], st["bias_pool"], int(st["n_volumes"]), log2)
+    gd = gp.grid_dev(grid)
+    ph_f, ph_c = T(oc.f2h(p_field).view(np.float16)), T(oc.f2h(p_color).view(np.float16))
+    gargs = (grid.n_volumes, gd["table_h"], gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"])
+    # ---- density pre-pass, early stop (Renderer.cpp:101-135), FilterIdxBounds, compaction ----
+    se, pts, dirs, dt, t, anc = T(smp["pts_idx_bounds"]), T(smp["pts"]), T(smp["dirs"]), T(smp["dt"]), T(smp["t"]), T(smp["anchors"])
+    f0_all = z(n)
+    hip.field_fwd(n, *gargs, pts, anc, 3, ph_f, None, f0_all, None)
+    w_pre, a_pre, mask, kept = z(n), z(n), z(n, dtype=i32), z(R, dtype=i32)
+    hip.early_stop(R, se, f0_all, 1, dt, w_pre, a_pre, mask, kept)
+    new_se, tot = z(R, 2, dtype=i32), z(1, dtype=i32)
+    hip.segment_scan(R, kept, new_se, tot)
+    m = int(tot.item())
+    assert abs(m - ref["n_kept"]) <= 2  # (early-stop threshold against 1-ulp expf differences)
+    k_pts, k_dirs, k_dt, k_t, k_anc = z(m, 3), z(m, 3), z(m), z(m), z(m, 3, dtype=i32)
+    hip.compact_samples(R, se, new_se, mask, pts, dirs, dt, t, anc, k_pts, k_dirs, k_dt, k_t, k_anc)
+    same_kept = m == ref["n_kept"] and (N(new_se) == ref["new_se"]).all()
+    # ---- edge samples, field over kept + edge points ----
+    e_pts, e_idx = z(NE, 2, 3), z(NE, 2, dtype=i32)
+    hip.edge_samples(NE, T(st["edge_pool"]), T(st["pers_trans"]), T(eidx), T(ecoord), e_pts, e_idx)
+    q_pts = torch.cat([k_pts, e_pts.reshape(-1, 3)], 0).contiguous()
+    q_vol = torch.cat([k_anc[:, 0], e_idx.reshape(-1)], 0).contiguous()
+    nq = m + 2 * NE
+    feat, f0, sx_f = z(nq, 16), z(nq), z(nq, 32, dtype=torch.float16)
+    hip.field_fwd(nq, *gargs, q_pts, q_vol, 1, ph_f, feat, f0, sx_f)
+    scene_feat, edge_feat = feat[:m].contiguous(), feat[m:].reshape(NE, 2, 16).contiguous()
+    # ---- ScatterIdx + SHShader::Query ----
+    sidx = z(m, dtype=i32)
+    hip.scatter_idx(R, new_se, T(cam), sidx)
+    rgb, sx_c = z(m, 3), z(m, 32, dtype=torch.float16)
+    hip.shade_fwd(m, scene_feat, k_dirs, T(app_emb), sidx, ph_c, rgb, sx_c)
+    # ---- compositing (+ WeightVar), loss ----
+    col, disp, dep, wts, var = z(R, 3), z(R), z(R), z(m), z(R)
+    hip.composite_fwd(R, new_se, scene_feat, k_dt, k_t, rgb, T(bg), col, disp, dep, wts, out_vars=var)
+    colors = N(col)
+    assert np.abs(colors - ref["colors"]).max() <= 1e-3, np.abs(colors - ref["colors"]).max()  # north-star RGB tolerance
+    mse_g, mse_r = float(((colors - gt) ** 2).mean()), float(((ref["colors"] - gt) ** 2).mean())
+    assert abs(10 * np.log10(1 / mse_g) - 10 * np.log10(1 / mse_r)) <= 1e-3  # PSNR within 1e-3 dB
+    assert np.abs(N(disp) - ref["disparity"]).max() <= 1e-3 * max(1.0, np.abs(ref["disparity"]).max())
+    if same_kept:
+        assert np.abs(N(wts) - ref["weights"]).max() <= 1e-3
+        assert np.abs(N(edge_feat) - ref["edge_feat"]).max() <= 4 * 2.0 ** -11 * max(1.0, np.abs(ref["edge_feat"]).max())
+    tc = cfg["train"]
+    var_w = 0.0 if it <= tc["var_loss_start"] else tc["var_loss_weight"] * min(1.0, (it - tc["var_loss_start"]) / (tc["var_loss_end"] - tc["var_loss_start"]))
+    gs0, gs1 = float(tc["gradient_scaling_start"]), float(tc["gradient_scaling_end"])
+    gs = 1.0 if it >= gs1 else max(0.0, (it - gs0) / (gs1 - gs0 + 1e-9))
+    losses, dc, dd, dv, de = z(8), z(R, 3), z(R), z(R), z(NE, 2, 16)
+    hip.train_loss(R, col, T(gt), disp, var, NE, 16, edge_feat, float(var_w), float(tc["disp_loss_weight"]), float(tc["tv_loss_weight"]), losses, dc, dd, dv, de)
+    assert abs(float(losses[0]) - ref["loss"]) <= 1e-3 * max(1.0, abs(ref["loss"]))
+    # ---- backward: compositing, colour path, field ----
+    drgb, df0 = z(m, 3), z(m)
+    hip.composite_bwd(R, new_se, f0[:m].contiguous(), k_dt, k_t, rgb, T(bg), dc, dd, None, None, gs, drgb, df0, f0_stride=1, df0_stride=1,
+                      var_weights=wts, dvars=dv)
+    dfeat = z(nq, 16)
+    dfeat_scene = z(m, 16)
+    dp_c, demb = z(p_color.size), z(n_img, 16)
+    hip.shade_bwd(m, drgb, sidx, ph_c, sx_c, 128.0, dfeat_scene, dp_c, demb, df0=df0)
+    dfeat[:m] = dfeat_scene
+    dfeat[m:] = de.reshape(-1, 16)
+    dp_f, gtab = z(p_field.size), z(grid.table_f32.size, dtype=torch.float16)
+    hip.field_bwd(nq, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], q_pts, q_vol, 1, ph_f, sx_f, dfeat, 128.0, dp_f, gtab,
+                  1 << log2)
+    if same_kept:  # (the gradients of another sample set are another sum)
+        rg = ref["grads"]
+        rel = e2e.rel_err
+        assert rel(N(dp_c) / F32(128.), rg["color_mlp"]) <= 3e-2, rel(N(dp_c) / F32(128.), rg["color_mlp"])
+        assert rel(N(dp_f) / F32(128.), rg["field_mlp"]) <= 3e-2, rel(N(dp_f) / F32(128.), rg["field_mlp"])
+        assert rel(N(demb), rg["app_emb"]) <= 3e-2, rel(N(demb), rg["app_emb"])
+        gt_tab, rt_tab = N(gtab).astype(F32).reshape(-1) / F32(128.), rg["feat_pool"].reshape(-1)
+        cos = float((gt_tab * rt_tab).sum() / (np.linalg.norm(gt_tab) * np.linalg.norm(rt_tab)))
+        assert cos > 0.999 and rel(gt_tab, rt_tab) <= 5e-2, (cos, rel(gt_tab, rt_tab))
+    assert same_kept  # (this seed's batch has no sample at the early-stop threshold: everything above was compared)
