@@ -605,3 +605,9 @@ def test_one_training_iteration_through_the_seams_on_the_emulator(hip, fox_state
         cos = float((gt_tab * rt_tab).sum() / (np.linalg.norm(gt_tab) * np.linalg.norm(rt_tab)))
         assert cos > 0.999 and rel(gt_tab, rt_tab) <= 5e-2, (cos, rel(gt_tab, rt_tab))
     assert same_kept  # (this seed's batch has no sample at the early-stop threshold: everything above was compared)
+
+
+def test_the_emulation_never_lost_track_of_a_fibre(emul_lib):
+    """(the last test of this module) no kernel nested activations or loops deeper than a fibre's record holds: whenever the lanes
+    of a wave had parted, who runs next was decided from their places in the program."""
+    assert emul_lib.wemu_counter(0) > 0 and emul_lib.wemu_counter(5) == 0

@@ -87,7 +87,7 @@ extern "C" long wemu_counter(int which);
 extern "C" int wemu_traffic_launches(void);
 extern "C" int wemu_traffic_get(int i, char* name, int name_size, unsigned long long* out8);
 extern "C" void wemu_traffic_reset(void);  // 0: launches, 1: cross-lane operations, 2: operations that found a wave in more than one
-                                          // group (divergent), 3: barriers, 4: work-items run
+                                          // group (divergent), 3: barriers, 4: work-items run, 5: activations / loops that did not fit a fibre's record (must stay 0)
 }  // namespace wemu
 
 #define threadIdx (wemu::g_tid)

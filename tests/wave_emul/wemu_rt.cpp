@@ -284,6 +284,8 @@ extern "C" void __sanitizer_cov_trace_pc() {
         f->lp[f->nl - 1].latch = std::max(f->lp[f->nl - 1].latch, last);
       } else if (f->nl < kMaxLoops) {
         f->lp[f->nl++] = {fp, pc, last, 1};
+      } else {
+        g_counters[5]++;  // (a loop nest deeper than the record: the ordering falls back on addresses there; tests assert it never happens)
       }
       uintptr_t& g = g_loops[pc];
       g = std::max(g, last);
@@ -291,6 +293,8 @@ extern "C" void __sanitizer_cov_trace_pc() {
     f->fr[f->nf - 1].block = pc;
   } else if (f->nf < kMaxFrames) {
     f->fr[f->nf++] = {fp, pc};
+  } else {
+    g_counters[5]++;
   }
   f->top = f->nf > 0 ? &f->fr[f->nf - 1] : &f->no_frame;
   f->top_hi = f->nl > 0 && f->lp[f->nl - 1].fp == fp ? f->lp[f->nl - 1].latch : ~(uintptr_t) 0;
@@ -459,7 +463,10 @@ void launch(const char* kernel, dim3 grid, dim3 block, size_t dyn_lds_bytes, Bod
   if (g_stacks == nullptr) {
     g_stacks = static_cast<char*>(mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
     if (g_stacks == MAP_FAILED || posix_memalign(reinterpret_cast<void**>(&g_dyn_lds), 256, kDynLds) != 0) abort();
-    for (int t = 0; t < kMaxThreads; t++) g_fibres[t].stack = g_stacks + kStack * t;
+    for (int t = 0; t < kMaxThreads; t++) {
+      g_fibres[t].stack = g_stacks + kStack * t;
+      mprotect(g_fibres[t].stack, 4096, PROT_NONE);  // a work-item that outgrows its stack faults instead of writing into its neighbour's
+    }
   }
   if (g_image_hi == 0) {
     dl_iterate_phdr([](dl_phdr_info* info, size_t, void*) {
