@@ -1,0 +1,98 @@
+// Test infrastructure -- NOT part of the product.  Forced in front of every file of f2-nerf_amd/csrc/host/ (-include) when the host
+// layer is built for the emulated wavefront (tests/wave_emul/wemu_build.py build_host): the C++/LibTorch plugin classes -- Renderer,
+// PersSampler, Hash3DAnchored, SHShader, ExpRunner, the octree builder, the dataset -- compile from their own source text, with the
+// handful of GPU-runtime names they use pointed at CPU stand-ins: tensors live on the CPU (torch::kCUDA reads torch::kCPU), streams
+// are one (launches of the emulated kernel library are synchronous), events are always reached, "mapped host memory" is host
+// memory, a CUDA generator is a CPU generator.  What the host DOES -- which kernels it calls with what, in which order, what it
+// prefetches, repairs, drops and resolves when -- is its own code, unchanged.
+#pragma once
+#include <torch/torch.h>
+#include <torch/extension.h>
+#include <ATen/hip/HIPEvent.h>
+#include <ATen/hip/HIPGeneratorImpl.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/CPUGeneratorImpl.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+namespace at { namespace cuda {
+struct EmuEvent {
+  EmuEvent(unsigned = 0) {}
+  void record() {}
+  template <typename S> void record(const S&) {}
+  template <typename S> void block(const S&) {}
+  bool query() const { return true; }
+  void synchronize() const {}
+  float elapsed_time(const EmuEvent&) const { return 0.f; }
+};
+namespace detail {
+// A CUDA generator is a Philox stream addressed by (seed, offset); host/KeyedDraws.h sets the offset to pick draw number `seq` of a
+// purpose.  The CPU stand-in keeps that addressing -- the same (seed, offset) gives the same uniforms, another offset others -- by
+// reseeding its mt19937 from the pair (the VALUES differ from the GPU's, as they do between any two generators: nothing compares
+// them across the two; the keyed draws the kernels make themselves are Philox on both sides).
+struct EmuGeneratorImpl : public at::CPUGeneratorImpl {
+  EmuGeneratorImpl() : at::CPUGeneratorImpl(0) { device_ = c10::Device(c10::DeviceType::CPU, 0); }
+  void set_current_seed(uint64_t s) override {
+    seed_ = s;
+    at::CPUGeneratorImpl::set_current_seed(s);
+  }
+  uint64_t current_seed() const override { return seed_; }
+  void set_offset(uint64_t o) override {
+    offset_ = o;
+    at::CPUGeneratorImpl::set_current_seed(seed_ * 0x9E3779B97F4A7C15ull + o * 0xD1B54A32D192ED03ull + 1);
+  }
+  uint64_t get_offset() const override { return offset_; }
+  EmuGeneratorImpl* clone_impl() const override {
+    auto* g = new EmuGeneratorImpl();
+    g->set_current_seed(seed_);
+    g->set_offset(offset_);
+    return g;
+  }
+  uint64_t seed_ = 0, offset_ = 0;
+};
+inline const at::Generator& getDefaultEmuGenerator(int = -1) { return at::detail::getDefaultCPUGenerator(); }
+inline at::Generator createEmuGenerator(int = -1) { return at::make_generator<EmuGeneratorImpl>(); }
+}  // namespace detail
+}  // namespace cuda
+}  // namespace at
+
+namespace c10 { namespace hip {
+struct EmuStream {
+  hipStream_t stream() const { return nullptr; }
+  void synchronize() const {}
+  bool operator==(const EmuStream&) const { return true; }
+  bool operator!=(const EmuStream&) const { return false; }
+  int device_index() const { return 0; }
+};
+inline EmuStream getStreamFromPoolEmu(bool = false, int = -1) { return EmuStream(); }
+inline EmuStream getCurrentEmuStream(int = -1) { return EmuStream(); }
+struct EmuStreamGuard {
+  explicit EmuStreamGuard(const EmuStream&) {}
+};
+inline int emu_current_device() { return 0; }
+}  // namespace hip
+}  // namespace c10
+
+static inline hipError_t emu_host_malloc(void** p, size_t n) { *p = calloc(1, n ? n : 4); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t emu_host_device_pointer(void** d, void* h) { *d = h; return hipSuccess; }
+static inline hipError_t emu_host_free(void* p) { free(p); return hipSuccess; }
+
+#define kCUDA kCPU
+#define is_cuda is_cpu
+#define CUDAEvent EmuEvent
+#define getDefaultCUDAGenerator getDefaultEmuGenerator
+#define createCUDAGenerator createEmuGenerator
+#define HIPStreamMasqueradingAsCUDA EmuStream
+#define getStreamFromPoolMasqueradingAsCUDA getStreamFromPoolEmu
+#define getCurrentHIPStreamMasqueradingAsCUDA getCurrentEmuStream
+#define getCurrentHIPStream getCurrentEmuStream
+#define HIPStreamGuardMasqueradingAsCUDA EmuStreamGuard
+#define current_device emu_current_device
+#define hipHostMalloc(p, n, flags) emu_host_malloc((void**) (p), (n))
+#define hipHostGetDevicePointer(d, h, flags) emu_host_device_pointer((void**) (d), (h))
+#define hipHostFree(p) emu_host_free(p)
+#define hipDeviceSynchronize() hipSuccess
+#define hipGetLastError() hipSuccess

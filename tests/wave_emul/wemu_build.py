@@ -121,6 +121,50 @@ def build_selftest(force=False):
     return lib
 
 
+def build_host(force=False, verbose=False):
+    """_build/_f2n_host_emul*.so: the C++/LibTorch host layer (f2-nerf_amd/csrc/host/*.cpp, read in place) compiled by g++ with
+    host_shim/host_shim.h forced in front of every file and linked against libf2n_emul.so -- the plugin classes on CPU tensors."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    lib, _ = build()
+    host_dir = os.path.join(CSRC, "host")
+    srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp"))
+    shim = os.path.join(HERE, "host_shim")
+    deps = srcs + [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")] + [
+        os.path.join(shim, "host_shim.h"), os.path.join(shim, "rccl", "rccl.h"), os.path.join(ROOT, "include", "f2n_abi.h"), os.path.abspath(__file__)]
+    out = os.path.join(OUT, "_f2n_host_emul" + sysconfig.get_config_var("EXT_SUFFIX"))
+    obj = os.path.join(OUT, "host")
+    os.makedirs(obj, exist_ok=True)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(max(os.path.getmtime(d) for d in deps), os.path.getmtime(lib)):
+        return out
+    inc = ["-I" + shim] + ["-I" + p for p in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(ROOT, "include"),
+                                                                  "-I/opt/rocm/include"]
+    flags = ["-O1", "-std=c++17", "-fPIC", "-DTORCH_EXTENSION_NAME=_f2n_host_emul", "-DTORCH_API_INCLUDE_EXTENSION_H",
+             "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-w",
+             "-include", os.path.join(shim, "host_shim.h")]
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(obj, os.path.basename(s).replace(".cpp", ".o"))
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(d) for d in deps):
+            jobs.append(["g++"] + flags + inc + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd[:6]), "...", cmd[-3], flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("wave_emul host build failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, jobs))
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    run(["g++", "-shared"] + objs + ["-o", out, "-L" + libdir, "-L" + OUT, "-Wl,-rpath," + libdir, "-Wl,-rpath," + OUT, "-lf2n_emul", "-lc10", "-ltorch_cpu",
+                                    "-ltorch", "-ltorch_python", "-lc10_hip", "-ltorch_hip"])
+    return out
+
+
 if __name__ == "__main__":
     import sys
     lib, rep = build(sources=sys.argv[1:] or None, verbose=True, force=True)
