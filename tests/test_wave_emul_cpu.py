@@ -611,3 +611,45 @@ def test_the_emulation_never_lost_track_of_a_fibre(emul_lib):
     """(the last test of this module) no kernel nested activations or loops deeper than a fibre's record holds: whenever the lanes
     of a wave had parted, who runs next was decided from their places in the program."""
     assert emul_lib.wemu_counter(0) > 0 and emul_lib.wemu_counter(5) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the HOST layer on the emulated wavefront: csrc/host/*.cpp -- ExpRunner, Renderer, PersSampler, Hash3DAnchored, SHShader, the
+# octree builder, the dataset -- compiled from its own text against CPU stand-ins for the GPU-runtime names it uses
+# (tests/wave_emul/host_shim/host_shim.h) and linked against libf2n_emul.so.  The GPU suite's host-level tests then run here:
+# which kernels the host calls with what, in which order, what it prefetches, repairs, drops and resolves when, is its own code.
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="session")
+def emul_host(emul_lib):
+    import importlib.util
+    import wemu_build as wave_emul_build
+    path = wave_emul_build.build_host()
+    ctypes.CDLL(wave_emul_build.LIB, mode=ctypes.RTLD_GLOBAL)
+    spec = importlib.util.spec_from_file_location("_f2n_host_emul", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture
+def rt(emul_host, hip, monkeypatch):
+    """The `rt` fixture of the GPU modules (f2_nerf_amd.runtime) with the emulated host module behind runtime.host() and the CPU
+    as "the device" (the `hip` fixture has pointed the ctypes binding at the emulated kernel library already)."""
+    import test_gpu_e2e as e2e
+    from f2_nerf_amd import runtime
+    monkeypatch.setattr(runtime, "_host", emul_host)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    to_dev = runtime.to_dev
+    monkeypatch.setattr(runtime, "to_dev", lambda *arrays, device="cpu": to_dev(*arrays, device="cpu"))
+    for mod in (e2e,) + _GPU_MODULES:
+        if hasattr(mod, "DEV"):
+            monkeypatch.setattr(mod, "DEV", "cpu")
+    return runtime
+
+
+_HOST_TESTS = [
+    ("test_gpu_e2e", "test_config1_end_to_end_parity", None),
+]
+for _modname, _name, _params in _HOST_TESTS:
+    globals()[_name] = _on_the_emulator(_name, _params, __import__(_modname))

@@ -80,6 +80,15 @@ static inline hipError_t emu_host_malloc(void** p, size_t n) { *p = calloc(1, n 
 static inline hipError_t emu_host_device_pointer(void** d, void* h) { *d = h; return hipSuccess; }
 static inline hipError_t emu_host_free(void* p) { free(p); return hipSuccess; }
 
+// `torch::from_blob(host array).to(torch::kCUDA)` is a COPY to the device in the product; with the CPU as the device `.to` would keep the
+// alias of an array that is about to go out of scope (Hash3DAnchored's level scales, the sampler's search order): every use of from_blob
+// in the host layer wraps a read-only source, so the stand-in copies at once.
+namespace torch {
+inline at::Tensor from_blob_copy(void* data, at::IntArrayRef sizes, const at::TensorOptions& options = at::TensorOptions()) {
+  return at::from_blob(data, sizes, options).clone();
+}
+}  // namespace torch
+#define from_blob from_blob_copy
 #define kCUDA kCPU
 #define is_cuda is_cpu
 #define CUDAEvent EmuEvent
