@@ -640,6 +640,7 @@ def rt(emul_host, hip, monkeypatch):
     monkeypatch.setattr(runtime, "_host", emul_host)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
     to_dev = runtime.to_dev
     monkeypatch.setattr(runtime, "to_dev", lambda *arrays, device="cpu": to_dev(*arrays, device="cpu"))
     for mod in (e2e,) + _GPU_MODULES:
@@ -650,6 +651,79 @@ def rt(emul_host, hip, monkeypatch):
 
 _HOST_TESTS = [
     ("test_gpu_e2e", "test_config1_end_to_end_parity", None),
+    ("test_gpu_e2e", "test_validate_render_and_training_sanity", None),
+    ("test_gpu_e2e", "test_proc_octree_matches_restatement", None),
+    ("test_gpu_e2e", "test_streaming_step_equals_synchronous_step", None),
+    ("test_gpu_e2e", "test_prefetched_sampling_is_not_used_by_a_render", None),
+    ("test_gpu_e2e", "test_deferred_finiteness_flags_when_prefetching", None),
+    ("test_gpu_e2e", "test_aux_states_and_deferred_reset", None),
+    ("test_gpu_e2e", "test_prefetched_samples_do_not_survive_a_state_load", None),
+    ("test_gpu_e2e", "test_octree_construction_from_cameras", None),
+    ("test_gpu_scale", "test_speculative_training_equals_sampling_after_the_update", None),
+    ("test_gpu_scale", "test_device_proc_octree_chain", None),
+    ("test_gpu_scale", "test_training_trajectory_across_milestone_and_compaction", None),
 ]
 for _modname, _name, _params in _HOST_TESTS:
     globals()[_name] = _on_the_emulator(_name, _params, __import__(_modname))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# tests/test_gpu_determinism.py at the emulator's size: ExpRunner::Train on the fox photographs under several sampling schedules
+# and chunkings of the loop -- every step's digest, every parameter checksum, the node array and the statistics identical.  (The
+# GPU run trains 2400 iterations per schedule at the shipped batch size; here 128-ray batches, a 2^12 table, a compaction every 4
+# iterations and a subdivision + MarkInvisibleNodes at iteration 6, so that batches begun ahead are dropped and begun again.)
+# ---------------------------------------------------------------------------------------------------------------------------------
+import test_gpu_determinism as gdet  # noqa: E402
+
+_SMALL_RUN = ["train.end_iter=20000", "field.log2_table_size=12", "train.pts_batch_size=4096", "pts_sampler.compact_freq=4",
+              "pts_sampler.sub_div_milestones=[6]"]
+
+
+@pytest.fixture(scope="session")
+def fox_scene_small():
+    from f2_nerf_amd import fox_data
+    st = fox_data.load_state()
+    sc, images = fox_data.scene(8)
+    return st, sc, images
+
+
+def _train_small(rt, fox_scene, spec, depth, tail, chunk, iters):
+    st, sc, images = fox_scene
+    ds = rt.make_dataset(sc, images)
+    runner, cfg, _ = rt.make_runner(st, "wanjinyou", _SMALL_RUN, seed=2022)
+    runner.speculative_sampling, runner.speculation_depth, runner.tail_repair, runner.digest_table = spec, depth, tail, True
+    torch.manual_seed(2022)
+    it = 0
+    while it < iters:
+        it = min(iters, it + chunk)
+        runner.train(ds, it, 1)
+    s, c = runner.states(), runner.counters()
+    return dict(table=gdet._csum(s[4]), field_mlp=gdet._csum(s[8]), color_mlp=gdet._csum(s[9]), app_emb=gdet._csum(s[-1]), nodes=s[0].numpy().copy(),
+                visit=s[2].numpy().copy(), stats=[t.numpy().copy() for t in runner.occupancy_buffers()[:2]], marched=c["total_marched"],
+                meaningful=c["total_meaningful"], iter_step=runner.iter_step, step_seq=runner.step_seq,
+                digest=[tuple(int(v) for v in row) for row in runner.step_digest()], spec=dict(runner.speculation_counters()))
+
+
+_SCHEDULES = {"after_the_update": (0, 1, True, 1000), "always_two_ahead_chunks_of_3": (1, 3, True, 3), "default": (2, 2, True, 1000),
+              "always_one_ahead_full_repair": (1, 1, False, 1000)}
+
+
+def _assert_same_training(ref, r, m):
+    tail = ref["digest"][-min(len(ref["digest"]), len(r["digest"])):]
+    tail_r = r["digest"][-len(tail):]
+    first = next((i for i, (a, b) in enumerate(zip(tail, tail_r)) if a != b), None)
+    assert first is None, "%s parts from sampling-after-the-update at step %s: %s vs %s" % (m, tail[first][0], tail[first], tail_r[first])
+    for k in ("table", "field_mlp", "color_mlp", "app_emb", "marched", "meaningful", "iter_step", "step_seq"):
+        assert r[k] == ref[k], (m, k, r[k], ref[k])
+    assert r["nodes"].shape == ref["nodes"].shape and (r["nodes"] == ref["nodes"]).all(), m
+    assert (r["visit"] == ref["visit"]).all() and all((a == b).all() for a, b in zip(r["stats"], ref["stats"])), m
+
+
+@pytest.mark.parametrize("other", [k for k in _SCHEDULES if k != "after_the_update"][:1 if os.environ.get("WEMU_FULL", "0") in ("", "0") else None])
+def test_training_is_independent_of_the_sampling_schedule_on_the_emulator(rt, fox_scene_small, other):
+    iters = 9
+    ref = _train_small(rt, fox_scene_small, *_SCHEDULES["after_the_update"], iters)
+    assert ref["iter_step"] == iters and ref["spec"]["speculative"] == 0 and ref["nodes"].size // 64 != 897  # (the subdivision ran)
+    r = _train_small(rt, fox_scene_small, *_SCHEDULES[other], iters)
+    assert r["spec"]["speculative"] > 0, r["spec"]  # (it did sample ahead)
+    _assert_same_training(ref, r, other)
