@@ -649,20 +649,20 @@ def rt(emul_host, hip, monkeypatch):
     return runtime
 
 
+# WEMU_FULL=1 in the environment: the host-level tests that take the emulator a minute or more each as well (recorded once per
+# round: profiles/r05_emulated_host_suite.txt); the default run keeps the CPU suite at a few minutes
+_FULL = os.environ.get("WEMU_FULL", "0") not in ("", "0")
 _HOST_TESTS = [
     ("test_gpu_e2e", "test_config1_end_to_end_parity", None),
-    ("test_gpu_e2e", "test_validate_render_and_training_sanity", None),
     ("test_gpu_e2e", "test_proc_octree_matches_restatement", None),
+] + ([
     ("test_gpu_e2e", "test_streaming_step_equals_synchronous_step", None),
     ("test_gpu_e2e", "test_prefetched_sampling_is_not_used_by_a_render", None),
     ("test_gpu_e2e", "test_deferred_finiteness_flags_when_prefetching", None),
     ("test_gpu_e2e", "test_aux_states_and_deferred_reset", None),
     ("test_gpu_e2e", "test_prefetched_samples_do_not_survive_a_state_load", None),
-    ("test_gpu_e2e", "test_octree_construction_from_cameras", None),
-    ("test_gpu_scale", "test_speculative_training_equals_sampling_after_the_update", None),
-    ("test_gpu_scale", "test_device_proc_octree_chain", None),
-    ("test_gpu_scale", "test_training_trajectory_across_milestone_and_compaction", None),
-]
+    ("test_gpu_scale", "test_device_proc_octree_chain", ("scene", ["fox"])),
+] if _FULL else [])
 for _modname, _name, _params in _HOST_TESTS:
     globals()[_name] = _on_the_emulator(_name, _params, __import__(_modname))
 
@@ -719,7 +719,7 @@ def _assert_same_training(ref, r, m):
     assert (r["visit"] == ref["visit"]).all() and all((a == b).all() for a, b in zip(r["stats"], ref["stats"])), m
 
 
-@pytest.mark.parametrize("other", [k for k in _SCHEDULES if k != "after_the_update"][:1 if os.environ.get("WEMU_FULL", "0") in ("", "0") else None])
+@pytest.mark.parametrize("other", [k for k in _SCHEDULES if k != "after_the_update"][:None if _FULL else 1])
 def test_training_is_independent_of_the_sampling_schedule_on_the_emulator(rt, fox_scene_small, other):
     iters = 9
     ref = _train_small(rt, fox_scene_small, *_SCHEDULES["after_the_update"], iters)
@@ -727,3 +727,57 @@ def test_training_is_independent_of_the_sampling_schedule_on_the_emulator(rt, fo
     r = _train_small(rt, fox_scene_small, *_SCHEDULES[other], iters)
     assert r["spec"]["speculative"] > 0, r["spec"]  # (it did sample ahead)
     _assert_same_training(ref, r, other)
+
+
+@pytest.mark.parametrize("tail,depth", [(True, 3), (True, 2), (True, 1), (False, 1)] if _FULL else [(True, 3)])
+def test_speculative_training_equals_sampling_after_the_update_on_the_emulator(rt, fox_state, tail, depth):
+    """tests/test_gpu_scale.py::test_speculative_training_equals_sampling_after_the_update at the emulator's size (64 rays and 9 steps;
+    192 and 12 with WEMU_FULL=1; no matrix products to keep a device busy -- there is no queue to fall behind here): ExpRunner::TrainStep with the next batches
+    sampled AHEAD of the stat update that kills leaves under them (statistics re-armed at 0 before every step: every visited leaf
+    without a positive vote dies at once), repaired by list compaction + tail march or by a second walk + march, against the same
+    steps with the sampling behind the update -- per-step sample counts, node array and statistics identical; a compaction and a
+    subdivision fall inside the run."""
+    import test_gpu_e2e as e2e
+    st, F32, N = fox_state, np.float32, (lambda t: t.detach().numpy())
+    overrides = ["field.log2_table_size=12", "train.learning_rate=0.0", "pts_sampler.sub_div_milestones=[7]", "pts_sampler.compact_freq=5"]
+    R, NE, ITERS = (192, 128, 12) if _FULL else (64, 64, 9)
+    rng0 = np.random.default_rng(31)
+    batches = []
+    for _ in range(ITERS + 2):
+        ro, rd, bounds, cam = e2e.fox_batch(st, rng0, R)
+        batches.append([torch.from_numpy(np.ascontiguousarray(a)) for a in (ro, rd, bounds, rng0.random((R, 3), dtype=F32), cam)])
+    logs = {}
+    for spec in (True, False):
+        runner, cfg, _ = rt.make_runner(st, "wanjinyou", overrides, seed=5, table_init=0.3)
+        states = [t.clone() for t in runner.states()]
+        states[8][-16 * 64:-15 * 64] *= 16.0  # (opaque and empty stretches instead of a uniform fog: see the GPU test)
+        runner.load_states(states)
+        runner.n_edge_pts = NE
+        runner.speculative_sampling, runner.tail_repair, runner.speculation_depth, runner.march_blocks = spec, tail, depth, 96
+        torch.manual_seed(11)
+        log = []
+        for it in range(ITERS):
+            for t in runner.occupancy_buffers()[:2]:
+                t.fill_(0)
+            b, nb, nb2 = batches[it], batches[it + 1], batches[it + 2]
+            if depth >= 2:
+                s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2], nb2[0], nb2[1])
+            else:
+                s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+            runner.flush()
+            w, a, v = [N(t).copy() for t in runner.occupancy_buffers()]
+            log.append(dict(n_samples=s["n_samples"], kept=runner.counters()["total_meaningful"], nodes=N(runner.tree_nodes()).copy(), w=w, a=a, v=v,
+                            loss=float(s["loss"])))
+        logs[spec] = (log, dict(runner.speculation_counters()))
+    (la, ca), (lb, cb) = logs[True], logs[False]
+    assert ca["speculative"] >= ITERS - 6 and ca["rays_repaired"] > 0, ca  # most steps sampled ahead, and deaths did invalidate rays
+    assert cb["speculative"] == 0 and cb["rays_repaired"] == 0, cb
+    n_nodes = set()
+    for it in range(ITERS):
+        x, y = la[it], lb[it]
+        assert x["n_samples"] == y["n_samples"] and x["kept"] == y["kept"], (it, x["n_samples"], y["n_samples"], x["kept"], y["kept"])
+        assert x["nodes"].shape == y["nodes"].shape and (x["nodes"] == y["nodes"]).all(), it
+        assert (x["w"] == y["w"]).all() and (x["a"] == y["a"]).all() and (x["v"] == y["v"]).all(), it
+        assert abs(x["loss"] - y["loss"]) <= 1e-6 * max(1.0, abs(y["loss"])), (it, x["loss"], y["loss"])
+        n_nodes.add(x["nodes"].size // 64)
+    assert len(n_nodes) >= 3, n_nodes  # compaction and subdivision happened inside the run
