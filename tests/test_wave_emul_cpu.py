@@ -641,6 +641,12 @@ def rt(emul_host, hip, monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    for name in ("rand", "randn", "zeros", "ones", "empty", "full", "tensor"):  # (a literal device="cuda" in a test body means "the device")
+        def factory(*a, _orig=getattr(torch, name), **k):
+            if str(k.get("device", "")).startswith("cuda"):
+                k["device"] = "cpu"
+            return _orig(*a, **k)
+        monkeypatch.setattr(torch, name, factory)
     to_dev = runtime.to_dev
     monkeypatch.setattr(runtime, "to_dev", lambda *arrays, device="cpu": to_dev(*arrays, device="cpu"))
     for mod in (e2e,) + _GPU_MODULES:
@@ -703,6 +709,19 @@ def _train_small(rt, fox_scene, spec, depth, tail, chunk, iters):
                 meaningful=c["total_meaningful"], iter_step=runner.iter_step, step_seq=runner.step_seq,
                 digest=[tuple(int(v) for v in row) for row in runner.step_digest()], spec=dict(runner.speculation_counters()))
 
+
+@pytest.fixture
+def fox_scene(rt, fox_scene_small):
+    """(tests/test_gpu_determinism.py's fixture: the fox scene with its photographs on "the device"; `rt` has put the emulated host
+    behind runtime.host())"""
+    return fox_scene_small
+
+
+# the keyed draws of the host (Dataset::RandRaysData through f2n_draw_ray_batch_keyed; the per-rank streams of data-parallel replicas)
+test_keyed_draws_do_not_depend_on_when_or_how_often_they_are_made = _on_the_emulator(
+    "test_keyed_draws_do_not_depend_on_when_or_how_often_they_are_made", None, gdet)
+test_replicas_of_a_data_parallel_run_draw_their_own_streams = _on_the_emulator(
+    "test_replicas_of_a_data_parallel_run_draw_their_own_streams", None, gdet)
 
 _SCHEDULES = {"after_the_update": (0, 1, True, 1000), "always_two_ahead_chunks_of_3": (1, 3, True, 3), "default": (2, 2, True, 1000),
               "always_one_ahead_full_repair": (1, 1, False, 1000)}
