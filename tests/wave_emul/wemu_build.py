@@ -142,6 +142,8 @@ def build_host(force=False, verbose=False):
                                                                   "-I/opt/rocm/include"]
     flags = ["-O1", "-std=c++17", "-fPIC", "-DTORCH_EXTENSION_NAME=_f2n_host_emul", "-DTORCH_API_INCLUDE_EXTENSION_H",
              "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-w",
+             # (its own pybind11 type registry: the product's host module may live in the same process and registers the same C++ classes)
+             '-DPYBIND11_COMPILER_TYPE="_wemu"',
              "-include", os.path.join(shim, "host_shim.h")]
     jobs, objs = [], []
     for s in srcs:
