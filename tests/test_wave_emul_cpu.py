@@ -802,3 +802,40 @@ def test_speculative_training_equals_sampling_after_the_update_on_the_emulator(r
         assert abs(x["loss"] - y["loss"]) <= 1e-6 * max(1.0, abs(y["loss"])), (it, x["loss"], y["loss"])
         n_nodes.add(x["nodes"].size // 64)
     assert len(n_nodes) >= 3, n_nodes  # compaction and subdivision happened inside the run
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# what the driver runs at the end of a round, on the emulated stack: __graft_entry__.smoke() as it stands, and bench.py's main path
+# (two warm-up and three timed steps of 64-ray batches on a 2^14 table; no converged leg, no CPU baseline, no other configs) -- the
+# JSON line's fields and arithmetic, the two-deep pipeline's arguments, the kernel timers' bookkeeping.  Not a measurement of anything.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_smoke_on_the_emulator(rt, monkeypatch, capsys):
+    import __graft_entry__ as entry
+    monkeypatch.setattr(torch.cuda, "get_device_name", lambda *a, **k: "emulated wavefront")
+    entry.smoke()
+    assert "smoke ok" in capsys.readouterr().out
+
+
+def test_bench_main_path_on_the_emulator(rt, monkeypatch, capsys):
+    import json
+    import bench
+    monkeypatch.setattr(torch.cuda, "max_memory_allocated", lambda *a, **k: 0)
+    monkeypatch.setattr(torch.cuda, "max_memory_reserved", lambda *a, **k: 0)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda *a, **k: None)
+    # (the dominant call -- the gather of the large-batch path, what `roofline` is about -- is issued from 32768 samples per step on:
+    # ~400 rays of the fresh fox scene, half a minute per step here: only with WEMU_FULL=1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--rays", "400" if _FULL else "64", "--log2", "14", "--no-converged",
+                                      "--no-cpu-baseline", "--no-steady", "--other-configs", "0"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    line = json.loads([x for x in capsys.readouterr().out.splitlines() if x.startswith("{")][-1])
+    assert line["metric"].startswith("training ray-samples/s") and line["unit"] == "ray-samples/s" and line["n_gpus"] == 1
+    assert line["steps"] == 3 and line["warmup"] == 2 and line["higher_is_better"] is True and line["scaling"] == "weak" and line["dtype"] == "f16"
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert line["value"] > 0 and abs(line["value"] - line["config"]["meaningful_samples_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    rf = line["roofline"]
+    assert (rf is not None) == _FULL
+    if rf is not None:
+        assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["launches"] == 3 and rf["bytes_per_sample"] == 592
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["traffic"] is None  # (no counter file for this table size)

@@ -26,7 +26,7 @@ struct EmuEvent {
   template <typename S> void block(const S&) {}
   bool query() const { return true; }
   void synchronize() const {}
-  float elapsed_time(const EmuEvent&) const { return 0.f; }
+  float elapsed_time(const EmuEvent&) const { return 1.f; }  // (a millisecond: whoever divides by a kernel's time can)
 };
 namespace detail {
 // A CUDA generator is a Philox stream addressed by (seed, offset); host/KeyedDraws.h sets the offset to pick draw number `seq` of a
