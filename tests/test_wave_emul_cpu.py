@@ -668,8 +668,6 @@ _HOST_TESTS = [
     ("test_gpu_e2e", "test_aux_states_and_deferred_reset", None),
     ("test_gpu_e2e", "test_prefetched_samples_do_not_survive_a_state_load", None),
     ("test_gpu_scale", "test_device_proc_octree_chain", ("scene", ["fox"])),
-    ("test_gpu_e2e", "test_octree_construction_from_cameras", None),
-    ("test_gpu_mlp_shapes", "test_nondefault_networks_train_through_the_host", None),
 ] if _FULL else [])
 for _modname, _name, _params in _HOST_TESTS:
     globals()[_name] = _on_the_emulator(_name, _params, __import__(_modname))
