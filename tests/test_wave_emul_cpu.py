@@ -837,3 +837,46 @@ def test_bench_main_path_on_the_emulator(rt, monkeypatch, capsys):
     if rf is not None:
         assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["launches"] == 3 and rf["bytes_per_sample"] == 592
         assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["traffic"] is None  # (no counter file for this table size)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SURVEY 8(e) without hardware: a data-parallel training of TWO ranks -- two processes, each the emulated host on the emulated
+# kernels, attached through DataParallel::Attach (csrc/host/DataParallel.cpp as it stands) over a shared-memory <rccl/rccl.h> -- the
+# program bench.py --gpus 2 runs: replicas built from different seeds, rank 0's state broadcast at the attach, per-rank ray batches,
+# two-deep sampling, the pipelined gradient exchange (table buckets + one flat buffer), the MAX of the occupancy votes and the SUM of
+# the survivor counts inside every step, compactions and a subdivision on every rank's own copy of the octree.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _run_ranks(world, steps, rays, overlap, uid_hex):
+    import json
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    worker = os.path.join(ROOT, "tests", "wave_emul", "dp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), uid_hex, str(steps), str(rays), str(overlap)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung: the ranks did not issue the same sequence of collectives")
+        assert p.returncode == 0, se[-3000:]
+        outs.append(json.loads([x for x in so.splitlines() if x.startswith("{")][-1]))
+    return outs
+
+
+@pytest.mark.parametrize("overlap", [1, 0] if _FULL else [1])
+def test_two_rank_data_parallel_training_on_the_emulator(emul_host, overlap):
+    uid = emul_host.dp_new_unique_id().hex()
+    steps, rays = 7, 64
+    a, b = _run_ranks(2, steps, rays, overlap, uid)
+    assert a["rank"] == 0 and b["rank"] == 1 and a["comm_ranks"] == 2 and b["comm_ranks"] == 2
+    assert a["table_before_attach"] != b["table_before_attach"]  # (they were built differently: the attach had something to do)
+    for k in ("table", "field_mlp", "color_mlp", "app_emb", "nodes", "n_nodes", "meaningful_per_ray"):
+        assert a[k] == b[k], (k, a[k], b[k])  # bit-identical replicas after the run: parameters, octree, the batch-sizing average
+    assert a["n_nodes"] != 897  # (the compaction / subdivision ran on both)
+    assert a["losses"] != b["losses"] and all(np.isfinite(a["losses"] + b["losses"]))  # (each rank trained on its own rays)
+    # one rank alone, same seed and rays as rank 0: another training (the exchange did change what rank 0 learnt)
+    solo = _run_ranks(1, steps, rays, -1, uid)[0]
+    assert solo["table_before_attach"] == a["table_before_attach"] and solo["table"] != a["table"]
