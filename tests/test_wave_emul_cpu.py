@@ -641,6 +641,7 @@ def rt(emul_host, hip, monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: type("TheOneStream", (), {"cuda_stream": 0})())
     for name in ("rand", "randn", "zeros", "ones", "empty", "full", "tensor"):  # (a literal device="cuda" in a test body means "the device")
         def factory(*a, _orig=getattr(torch, name), **k):
             if str(k.get("device", "")).startswith("cuda"):
