@@ -285,7 +285,7 @@ _ORDER_FREE = [
 ]
 
 
-@pytest.mark.parametrize("schedule", [1, 2])
+@pytest.mark.parametrize("schedule", [1, 2] if os.environ.get("WEMU_FULL", "0") not in ("", "0") else [2])
 def test_results_do_not_depend_on_the_order_waves_and_workgroups_run_in(hip, emul_lib, fox_state, fox_golden, schedule):
     import inspect
     args = {"hip": hip, "fox_state": fox_state, "fox_golden": fox_golden}
