@@ -881,3 +881,42 @@ def test_two_rank_data_parallel_training_on_the_emulator(emul_host, overlap):
     # one rank alone, same seed and rays as rank 0: another training (the exchange did change what rank 0 learnt)
     solo = _run_ranks(1, steps, rays, -1, uid)[0]
     assert solo["table_before_attach"] == a["table_before_attach"] and solo["table"] != a["table"]
+
+
+def test_bench_with_two_ranks_on_the_emulator(emul_host):
+    """`bench.py --gpus 2` as the driver launches it -- one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment -- on the
+    emulated stack (tests/wave_emul/bench_dp_worker.py): bench.main() as it stands, f2_nerf_amd.parallel's native attach, the barrier
+    bracket, the MAX of the ranks' times and the SUM of their samples, the replica checksums gathered on rank 0, ONE JSON line from
+    rank 0 and none from rank 1."""
+    import json
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    worker = os.path.join(ROOT, "tests", "wave_emul", "bench_dp_worker.py")
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--rays", "48", "--log2", "12", "--no-steady"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, worker] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank of bench.py --gpus 2 hung")
+        assert p.returncode == 0, se[-3000:]
+        outs.append([x for x in so.splitlines() if x.startswith("{")])
+    assert len(outs[0]) == 1 and len(outs[1]) == 0  # rank 0 prints the line, rank 1 nothing
+    line = json.loads(outs[0][0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "ray-dp2"
+    rep = line["replicas"]
+    assert rep["identical"] is True and rep["rccl_comm_ranks"] == 2 and rep["torch_distributed_world"] == 2 and len(rep["checksums_table_fieldmlp_colormlp_nodes_nnodes"]) == 2
+    assert line["value"] > 0 and line["cpu_baseline"] is None and line["converged"] is None and line["other_configs"] is None
+    # whole-job aggregate: the samples of BOTH ranks over the slower rank's time
+    assert abs(line["value"] - line["config"]["meaningful_samples_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    assert line["config"]["rays_per_s"] > 0 and abs(line["config"]["rays_per_s"] - 48 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["config"]["rays_per_s"]
