@@ -920,3 +920,47 @@ def test_bench_with_two_ranks_on_the_emulator(emul_host):
     # whole-job aggregate: the samples of BOTH ranks over the slower rank's time
     assert abs(line["value"] - line["config"]["meaningful_samples_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
     assert line["config"]["rays_per_s"] > 0 and abs(line["config"]["rays_per_s"] - 48 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["config"]["rays_per_s"]
+
+
+@pytest.mark.skipif(not _FULL, reason="a minute per case on the emulator: WEMU_FULL=1 (recorded in profiles/r05_emulated_host_suite.txt)")
+@pytest.mark.parametrize("world", [1, 2])
+def test_launcher_on_the_emulator(emul_host, tmp_path, world):
+    """`python -m f2_nerf_amd.run --config-name=llff ... mode=train` on the emulated stack (tests/wave_emul/launcher_worker.py: run.main()
+    as it stands) on a data directory in the reference's layout: the octree is built from the cameras on "the device", six iterations of
+    ExpRunner::Train with a subdivision and a compaction, checkpoints in the reference's container, the test views' PSNR.  world = 2: the
+    launcher's data-parallel training as torch.distributed.run would start it -- both ranks finish, rank 0 alone writes."""
+    import socket
+    import subprocess
+    from PIL import Image
+    from f2_nerf_amd import rigs
+    rng = np.random.default_rng(2)
+    meta, hw = rigs.forward_facing(rng, n_side=(4, 3), hw=(24, 32), focal=28.0)
+    meta[:, 12:14] *= 4.0; meta[:, 14] *= 4.0; meta[:, 16:18] *= 4.0  # (intrinsics on disk refer to the factor-1 images, Dataset.cpp:49)
+    data = tmp_path / "data" / "synth" / "rig"
+    (data / "images_4").mkdir(parents=True)
+    np.save(data / "cams_meta.npy", meta)
+    for i in range(len(meta)):
+        Image.fromarray(rng.integers(0, 255, (24, 32, 3), dtype=np.uint8)).save(data / "images_4" / ("%03d.png" % i))
+    args = ["--config-name=llff", "dataset_name=synth", "case_name=rig", "exp_name=t", "+work_dir=%s" % tmp_path, "field.log2_table_size=12",
+            "train.end_iter=6", "train.save_freq=3", "train.report_freq=2", "train.learning_rate_warm_up_end_iter=3", "pts_sampler.sub_div_milestones=[3]",
+            "pts_sampler.compact_freq=4", "train.pts_batch_size=2048", "mode=train"]
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        if world > 1:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "wave_emul", "launcher_worker.py")] + args, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=1200)
+        assert p.returncode == 0, se[-3000:]
+        outs.append(so)
+    exp = tmp_path / "exp" / "rig" / "t"
+    assert (exp / "checkpoints" / "00000003" / "renderer.pt").exists() and (exp / "checkpoints" / "00000006" / "scalars.pt").exists()
+    assert (exp / "train_info.txt").exists() and (exp / "test_images" / "info.yaml").exists()
+    assert "Mean psnr" in outs[0] and all("Mean psnr" not in o and "Iter:" not in o for o in outs[1:])  # one writer
