@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "wave_emul"))
 
 
-def main():
+def stand_ins():
+    """The emulated host module behind runtime.host(), the CPU as "the device", gloo under torch.distributed (reported as "nccl")."""
     import torch
     import torch.distributed as dist
     import wemu_build
@@ -48,6 +49,10 @@ def main():
     dist.get_backend = lambda group=None: "nccl"
     bol = dist.broadcast_object_list
     dist.broadcast_object_list = lambda objs, src=0, group=None, device=None: bol(objs, src=src, group=group)
+
+
+def main():
+    stand_ins()
     import bench
     bench.main()
 
