@@ -669,6 +669,9 @@ _HOST_TESTS = [
     ("test_gpu_e2e", "test_aux_states_and_deferred_reset", None),
     ("test_gpu_e2e", "test_prefetched_samples_do_not_survive_a_state_load", None),
     ("test_gpu_scale", "test_device_proc_octree_chain", ("scene", ["fox"])),
+    # 36 iterations of the host on the emulated kernels against 36 iterations of the ORACLE (nodes, visit counts, sample counts exact
+    # after every iteration): seven minutes here
+    ("test_gpu_scale", "test_training_trajectory_across_milestone_and_compaction", ("realign", [True])),
 ] if _FULL else [])
 for _modname, _name, _params in _HOST_TESTS:
     globals()[_name] = _on_the_emulator(_name, _params, __import__(_modname))
