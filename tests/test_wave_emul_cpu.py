@@ -970,3 +970,13 @@ def _launcher_on_the_emulator(emul_host, tmp_path, world):
 
 if _FULL:  # (a minute per case on the emulator: recorded in profiles/r05_emulated_host_suite.txt)
     test_launcher_on_the_emulator = _launcher_on_the_emulator
+
+
+def test_the_host_never_waited_on_an_event_that_was_not_recorded(emul_host):
+    """(after the host-level tests of this module) One ordering bug a stand-in without asynchrony can still see: a stream made to wait
+    on an event nobody has recorded -- on the GPU that wait returns at once, an ordering the code believes it has and has not.  The
+    stand-in for at::cuda::CUDAEvent counts them (tests/wave_emul/host_shim/host_shim.h)."""
+    import wemu_build as wave_emul_build
+    L = ctypes.CDLL(wave_emul_build.build_host())
+    L.wemu_host_unrecorded_waits.restype = ctypes.c_long
+    assert L.wemu_host_unrecorded_waits() == 0

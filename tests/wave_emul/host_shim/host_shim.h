@@ -19,11 +19,15 @@
 #include <cstdlib>
 
 namespace at { namespace cuda {
+// (one thing a stand-in without asynchrony can still see: a wait on an event that was never recorded.  On the GPU that wait returns at
+// once -- an ordering the code believes it has and has not.  Counted; tests read the count through wemu_host_unrecorded_waits.)
+inline long g_wemu_unrecorded_waits = 0;
 struct EmuEvent {
   EmuEvent(unsigned = 0) {}
-  void record() {}
-  template <typename S> void record(const S&) {}
-  template <typename S> void block(const S&) {}
+  bool recorded = false;
+  void record() { recorded = true; }
+  template <typename S> void record(const S&) { recorded = true; }
+  template <typename S> void block(const S&) { if (!recorded) g_wemu_unrecorded_waits++; }
   bool query() const { return true; }
   void synchronize() const {}
   float elapsed_time(const EmuEvent&) const { return 1.f; }  // (a millisecond: whoever divides by a kernel's time can)
@@ -75,6 +79,8 @@ struct EmuStreamGuard {
 inline int emu_current_device() { return 0; }
 }  // namespace hip
 }  // namespace c10
+
+extern "C" __attribute__((used, visibility("default"))) inline long wemu_host_unrecorded_waits() { return at::cuda::g_wemu_unrecorded_waits; }
 
 static inline hipError_t emu_host_malloc(void** p, size_t n) { *p = calloc(1, n ? n : 4); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t emu_host_device_pointer(void** d, void* h) { *d = h; return hipSuccess; }
