@@ -18,18 +18,34 @@
 
 #include <cstdlib>
 
+extern "C" {
+long wemu_hb_record(int stream);
+void wemu_hb_wait(int stream, long token);
+void wemu_hb_host_sync(long token);
+}
+namespace c10 { namespace hip {
+inline int& emu_cur_stream_id() { static thread_local int id = 0; return id; }
+}  // namespace hip
+}  // namespace c10
+
 namespace at { namespace cuda {
-// (one thing a stand-in without asynchrony can still see: a wait on an event that was never recorded.  On the GPU that wait returns at
-// once -- an ordering the code believes it has and has not.  Counted; tests read the count through wemu_host_unrecorded_waits.)
+// The stand-ins keep the ORDER the host asks for, even though nothing here runs concurrently: every record / wait / host-side
+// synchronisation is reported to the emulated kernel library (wemu_hb_*: vector clocks per stream), which checks the accesses of every
+// launch against it (tests/wave_emul/stream_races.py).  And they count waits on events that were never recorded: on the GPU such a wait
+// returns at once -- an ordering the code believes it has and has not (wemu_host_unrecorded_waits).
 inline long g_wemu_unrecorded_waits = 0;
 struct EmuEvent {
   EmuEvent(unsigned = 0) {}
   bool recorded = false;
-  void record() { recorded = true; }
-  template <typename S> void record(const S&) { recorded = true; }
-  template <typename S> void block(const S&) { if (!recorded) g_wemu_unrecorded_waits++; }
-  bool query() const { return true; }
-  void synchronize() const {}
+  long token = -1;
+  void record() { recorded = true; token = wemu_hb_record(c10::hip::emu_cur_stream_id()); }
+  template <typename S> void record(const S& s) { recorded = true; token = wemu_hb_record(s.id); }
+  template <typename S> void block(const S& s) {
+    if (!recorded) g_wemu_unrecorded_waits++;
+    wemu_hb_wait(s.id, token);
+  }
+  bool query() const { wemu_hb_host_sync(token); return true; }  // (always reached: the host goes on as if it had waited)
+  void synchronize() const { wemu_hb_host_sync(token); }
   float elapsed_time(const EmuEvent&) const { return 1.f; }  // (a millisecond: whoever divides by a kernel's time can)
 };
 namespace detail {
@@ -65,16 +81,29 @@ inline at::Generator createEmuGenerator(int = -1) { return at::make_generator<Em
 
 namespace c10 { namespace hip {
 struct EmuStream {
-  hipStream_t stream() const { return nullptr; }
-  void synchronize() const {}
-  bool operator==(const EmuStream&) const { return true; }
-  bool operator!=(const EmuStream&) const { return false; }
+  int id = 0;  // 0: the default ("main") stream; 1..7: streams from the pool
+  hipStream_t stream() const { return reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(id)); }
+  void synchronize() const { wemu_hb_host_sync(-1); }
+  bool operator==(const EmuStream& o) const { return id == o.id; }
+  bool operator!=(const EmuStream& o) const { return id != o.id; }
   int device_index() const { return 0; }
 };
-inline EmuStream getStreamFromPoolEmu(bool = false, int = -1) { return EmuStream(); }
-inline EmuStream getCurrentEmuStream(int = -1) { return EmuStream(); }
+inline EmuStream getStreamFromPoolEmu(bool = false, int = -1) {
+  static int next = 0;
+  EmuStream s;
+  s.id = 1 + (next++ % 7);
+  return s;
+}
+inline EmuStream getCurrentEmuStream(int = -1) {
+  EmuStream s;
+  s.id = emu_cur_stream_id();
+  return s;
+}
 struct EmuStreamGuard {
-  explicit EmuStreamGuard(const EmuStream&) {}
+  int prev;
+  explicit EmuStreamGuard(const EmuStream& s) : prev(emu_cur_stream_id()) { emu_cur_stream_id() = s.id; }
+  ~EmuStreamGuard() { emu_cur_stream_id() = prev; }
+  EmuStreamGuard(const EmuStreamGuard&) = delete;
 };
 inline int emu_current_device() { return 0; }
 }  // namespace hip
@@ -109,5 +138,5 @@ inline at::Tensor from_blob_copy(void* data, at::IntArrayRef sizes, const at::Te
 #define hipHostMalloc(p, n, flags) emu_host_malloc((void**) (p), (n))
 #define hipHostGetDevicePointer(d, h, flags) emu_host_device_pointer((void**) (d), (h))
 #define hipHostFree(p) emu_host_free(p)
-#define hipDeviceSynchronize() hipSuccess
+#define hipDeviceSynchronize() (wemu_hb_host_sync(-1), hipSuccess)
 #define hipGetLastError() hipSuccess

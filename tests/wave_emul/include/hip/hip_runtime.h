@@ -78,12 +78,18 @@ struct Op {
 uint64_t park(Op& op);  // parks the running fibre at `op`, returns op.result once the operation has been carried out
 void* dyn_lds();        // the dynamic LDS of the running workgroup
 typedef void (*Body)(void* closure);
-void launch(const char* kernel, dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure);
+void launch(const char* kernel, const void* stream, dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure);
 extern "C" void wemu_set_schedule(int mode);  // the order workgroups and waves run in (a race detector: results must not depend on it)
 extern "C" long wemu_counter(int which);
 // the memory traffic of every launch since wemu_traffic_reset(), from the compiler's load / store instrumentation (only the
 // "traffic" build of wemu_build.py has it): out[0..7] = global bytes loaded, stored, distinct 128-byte lines loaded, stored,
 // LDS (dynamic buffer + the library's own statics) bytes loaded, stored, workgroups, work-items per workgroup
+extern "C" void wemu_hb_enable(int on);          // happens-before bookkeeping + race check (the "traffic" build sees the accesses)
+extern "C" long wemu_hb_record(int stream);       // an event recorded on `stream` -> token
+extern "C" void wemu_hb_wait(int stream, long token);
+extern "C" void wemu_hb_host_sync(long token);    // the host waited for that event (token < 0: for the whole device)
+extern "C" int wemu_hb_races(void);
+extern "C" long wemu_hb_race(int i, char* first, char* second, char* kind, int size, unsigned long long* addr);
 extern "C" int wemu_traffic_launches(void);
 extern "C" int wemu_traffic_get(int i, char* name, int name_size, unsigned long long* out8);
 extern "C" void wemu_traffic_reset(void);  // 0: launches, 1: cross-lane operations, 2: operations that found a wave in more than one
@@ -97,12 +103,12 @@ extern "C" void wemu_traffic_reset(void);  // 0: launches, 1: cross-lane operati
 #define warpSize 64
 
 template <typename F>
-static inline void wemu_launch_(const char* kernel, dim3 grid, dim3 block, size_t lds, F&& f) {
-  wemu::launch(kernel, grid, block, lds, [](void* c) { (*static_cast<std::remove_reference_t<F>*>(c))(); }, &f);
+static inline void wemu_launch_(const char* kernel, const void* stream, dim3 grid, dim3 block, size_t lds, F&& f) {
+  wemu::launch(kernel, stream, grid, block, lds, [](void* c) { (*static_cast<std::remove_reference_t<F>*>(c))(); }, &f);
 }
-// (launches are synchronous: the stream argument is evaluated and dropped)
+// (launches are synchronous; the stream argument only names the stream for the race detector of wemu_rt.cpp)
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  wemu_launch_(#kernel, dim3(grid), dim3(block), (size_t) (lds), [&]() { (void) (stream); kernel(__VA_ARGS__); })
+  wemu_launch_(#kernel, (const void*) (stream), dim3(grid), dim3(block), (size_t) (lds), [&]() { kernel(__VA_ARGS__); })
 
 // ------------------------------------------------------------------------------------------------- host API subset
 typedef int hipError_t;

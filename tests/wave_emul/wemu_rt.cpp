@@ -72,6 +72,51 @@ unsigned long long g_tr[6];
 uintptr_t g_host_stack_lo = 0, g_host_stack_hi = 0;  // the launching thread's stack: kernel arguments (by-reference captures of the launch)
 uintptr_t g_image_lo = 0, g_image_hi = 0;  // this shared object: `__shared__` statics (and constant tables) live in it
 bool g_tracing = false;                     // a launch is running and the build is instrumented
+// ---- a race detector between streams (traffic build + WEMU happens-before hooks of the host stand-ins; tests/wave_emul/stream_races.py) ----
+// The host orders its streams with events.  The stand-ins report every record / wait / host-side synchronisation here (vector clocks,
+// one component per stream); every launch carries its stream; every global access of a launch is checked against the last write and the
+// last reads of its 4-byte word: an access that is not ordered behind a conflicting access of ANOTHER stream is a race the GPU is
+// free to lose.  (Torch operations of the host are not seen: they can hide a race, not invent one.  Freed memory must not be reused
+// while this runs -- the caching allocator of the GPU keeps a stream's blocks to that stream, malloc does not: LD_PRELOAD a free() that
+// does nothing.)
+constexpr int kStreams = 8;
+struct VC { int c[kStreams]; };
+bool g_hb_on = false;
+VC g_vc[kStreams], g_host_vc;
+std::vector<VC> g_tokens;
+int g_cur_stream = 0, g_cur_kernel = 0;
+std::vector<std::string> g_kernel_names;
+struct Shadow {
+  int w_stream = -1, w_epoch = 0, w_kernel = 0;
+  int r_epoch[kStreams] = {0}, r_kernel[kStreams] = {0};
+};
+std::unordered_map<uintptr_t, Shadow> g_shadow;
+struct Race { std::string first, second, kind; uintptr_t addr; long count; };
+std::vector<Race> g_races;
+void report_race(int k_first, int k_second, const char* kind, uintptr_t granule) {
+  for (auto& r : g_races)
+    if (r.first == g_kernel_names[k_first] && r.second == g_kernel_names[k_second] && r.kind == kind) {
+      r.count++;
+      return;
+    }
+  g_races.push_back({g_kernel_names[k_first], g_kernel_names[k_second], kind, granule << 2, 1});
+}
+inline void hb_access(uintptr_t a, bool store) {
+  const int s = g_cur_stream;
+  const VC& me = g_vc[s];
+  Shadow& sh = g_shadow[a >> 2];
+  if (sh.w_stream >= 0 && sh.w_stream != s && sh.w_epoch > me.c[sh.w_stream]) report_race(sh.w_kernel, g_cur_kernel, store ? "write after write" : "read after write", a >> 2);
+  if (store) {
+    for (int r = 0; r < kStreams; r++)
+      if (r != s && sh.r_epoch[r] > me.c[r]) report_race(sh.r_kernel[r], g_cur_kernel, "write after read", a >> 2);
+    sh.w_stream = s;
+    sh.w_epoch = me.c[s];
+    sh.w_kernel = g_cur_kernel;
+  } else {
+    sh.r_epoch[s] = me.c[s];
+    sh.r_kernel[s] = g_cur_kernel;
+  }
+}
 std::unordered_map<uintptr_t, uintptr_t> g_loops;  // head block -> latch block of every loop seen so far
 
 // callee-saved registers of the SysV x86-64 ABI + the stack pointer; nothing else survives a call anyway
@@ -454,7 +499,7 @@ void xl_mfma(const void* site, int kind, const void* a, const void* b, const voi
 
 void* dyn_lds() { return g_dyn_lds; }
 
-void launch(const char* kernel, dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure) {
+void launch(const char* kernel, const void* stream, dim3 grid, dim3 block, size_t dyn_lds_bytes, Body body, void* closure) {
   const size_t n_threads = (size_t) block.x * block.y * block.z;
   if (n_threads == 0 || n_threads > (size_t) kMaxThreads || dyn_lds_bytes > kDynLds) {
     fprintf(stderr, "wave_emul: launch of %zu work-items per group / %zu bytes of dynamic LDS\n", n_threads, dyn_lds_bytes);
@@ -496,6 +541,14 @@ void launch(const char* kernel, dim3 grid, dim3 block, size_t dyn_lds_bytes, Bod
       g_host_stack_hi = (uintptr_t) lo + sz;
     }
   }
+  if (g_hb_on) {
+    g_cur_stream = (int) (reinterpret_cast<uintptr_t>(stream) & (kStreams - 1));
+    VC& v = g_vc[g_cur_stream];
+    for (int i = 0; i < kStreams; i++) v.c[i] = std::max(v.c[i], g_host_vc.c[i]);  // (the host issued this launch after what it had waited for)
+    v.c[g_cur_stream]++;
+    g_kernel_names.push_back(std::string(kernel) + " [stream " + std::to_string(g_cur_stream) + "]");
+    g_cur_kernel = (int) g_kernel_names.size() - 1;
+  }
   memset(g_tr, 0, sizeof(g_tr));
   g_ld_lines.clear();
   g_st_lines.clear();
@@ -524,6 +577,46 @@ void launch(const char* kernel, dim3 grid, dim3 block, size_t dyn_lds_bytes, Bod
   }
 }
 
+extern "C" void wemu_hb_enable(int on) {
+  g_hb_on = on != 0;
+  memset(g_vc, 0, sizeof(g_vc));
+  memset(&g_host_vc, 0, sizeof(g_host_vc));
+  g_tokens.clear();
+  g_shadow.clear();
+  g_races.clear();
+  g_kernel_names.clear();
+}
+extern "C" long wemu_hb_record(int stream) {
+  if (!g_hb_on) return -1;
+  VC v = g_vc[stream & (kStreams - 1)];
+  for (int i = 0; i < kStreams; i++) v.c[i] = std::max(v.c[i], g_host_vc.c[i]);  // (recorded by the host after what it had waited for)
+  g_tokens.push_back(v);
+  return (long) g_tokens.size() - 1;
+}
+extern "C" void wemu_hb_wait(int stream, long token) {
+  static const bool ignore = getenv("WEMU_HB_IGNORE_WAITS") != nullptr;  // (the detector's positive control: a host that never waits)
+  if (!g_hb_on || token < 0 || ignore) return;
+  VC& v = g_vc[stream & (kStreams - 1)];
+  for (int i = 0; i < kStreams; i++) v.c[i] = std::max(v.c[i], g_tokens[token].c[i]);
+}
+extern "C" void wemu_hb_host_sync(long token) {  // the host waited for an event (token >= 0) or for the whole device (token < 0)
+  if (!g_hb_on) return;
+  if (token >= 0) {
+    for (int i = 0; i < kStreams; i++) g_host_vc.c[i] = std::max(g_host_vc.c[i], g_tokens[token].c[i]);
+  } else {
+    for (int st = 0; st < kStreams; st++)
+      for (int i = 0; i < kStreams; i++) g_host_vc.c[i] = std::max(g_host_vc.c[i], g_vc[st].c[i]);
+  }
+}
+extern "C" int wemu_hb_races(void) { return (int) g_races.size(); }
+extern "C" long wemu_hb_race(int i, char* first, char* second, char* kind, int size, unsigned long long* addr) {
+  if (i < 0 || i >= (int) g_races.size()) return -1;
+  snprintf(first, (size_t) size, "%s", g_races[i].first.c_str());
+  snprintf(second, (size_t) size, "%s", g_races[i].second.c_str());
+  snprintf(kind, (size_t) size, "%s", g_races[i].kind.c_str());
+  *addr = g_races[i].addr;
+  return g_races[i].count;
+}
 extern "C" int wemu_traffic_launches(void) { return (int) g_traffic.size(); }
 extern "C" void wemu_traffic_reset(void) { g_traffic.clear(); }
 extern "C" int wemu_traffic_get(int i, char* name, int name_size, unsigned long long* out8) {
@@ -544,6 +637,11 @@ inline void traffic(uintptr_t a, unsigned bytes, bool store) {
     return;
   }
   g_tr[store ? 1 : 0] += bytes;
+  if (g_hb_on) {
+    for (unsigned off = 0; off < bytes; off += 4) hb_access(a + off, store);  // (word by word: two kernels may share a line, not a word)
+    if (((a + bytes - 1) >> 2) != ((a + ((bytes - 1) & ~3u)) >> 2)) hb_access(a + bytes - 1, store);
+    return;
+  }
   (store ? g_st_lines : g_ld_lines).insert(a >> 7);
   if (((a + bytes - 1) >> 7) != (a >> 7)) (store ? g_st_lines : g_ld_lines).insert((a + bytes - 1) >> 7);
 }
