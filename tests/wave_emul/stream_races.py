@@ -18,6 +18,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "wave_emul"))
 
 
+def report(L, what):
+    n = L.wemu_hb_races()
+    L.wemu_hb_race.restype = ctypes.c_long
+    print("# %s; %d launches; %d distinct (kernel, kernel, kind) conflicts without an ordering" % (what, L.wemu_traffic_launches(), n))
+    a, b, k = ctypes.create_string_buffer(300), ctypes.create_string_buffer(300), ctypes.create_string_buffer(64)
+    addr = ctypes.c_ulonglong()
+    for i in range(n):
+        cnt = L.wemu_hb_race(i, a, b, k, 300, ctypes.byref(addr))
+        print("%-20s %8d words   %s   <-   %s" % (k.value.decode(), cnt, b.value.decode(), a.value.decode()))
+
+
 def main():
     import numpy as np
     import torch
@@ -36,6 +47,22 @@ def main():
     torch.cuda.set_device = lambda *a, **k: None
     torch.set_num_threads(1)
     st = dict(np.load(os.path.join(ROOT, "tests", "golden", "fox_state.npz")))
+    if len(sys.argv) > 1 and sys.argv[1] == "train":  # ExpRunner::Train itself: batches drawn on the device, the loop's own prefetching
+        from f2_nerf_amd import fox_data
+        depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+        sc, images = fox_data.scene(8)
+        ds = runtime.make_dataset(sc, images)
+        runner, cfg, _ = runtime.make_runner(st, "wanjinyou", ["train.end_iter=20000", "field.log2_table_size=12", "train.pts_batch_size=4096",
+                                                               "pts_sampler.compact_freq=4", "pts_sampler.sub_div_milestones=[6]"], seed=2022)
+        runner.speculative_sampling, runner.speculation_depth = 1, depth
+        torch.manual_seed(2022)
+        L.wemu_hb_enable(1)
+        runner.train(ds, 5, 1)
+        runner.train(ds, 10, 1)
+        runner.flush()
+        report(L, "ExpRunner::Train, 10 iterations in two calls on the fox photographs (128-ray batches, compactions at 0 / 4 / 8, a subdivision at 6), "
+                  "speculation depth %d; %s" % (depth, dict(runner.speculation_counters())))
+        return 0
     tail, depth, R, NE, ITERS = (sys.argv[1] != "full" if len(sys.argv) > 1 else True), int(sys.argv[2]) if len(sys.argv) > 2 else 3, 64, 64, 9
     overrides = ["field.log2_table_size=12", "train.learning_rate=0.0", "pts_sampler.sub_div_milestones=[7]", "pts_sampler.compact_freq=5"]
     rng0 = np.random.default_rng(31)
@@ -60,16 +87,7 @@ def main():
         else:
             runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
     runner.flush()
-    sc = dict(runner.speculation_counters())
-    n = L.wemu_hb_races()
-    L.wemu_hb_race.restype = ctypes.c_long
-    print("# %d steps, tail repair %s, speculation depth %d; %s; %d launches; %d distinct (kernel, kernel, kind) conflicts without an ordering" % (
-        ITERS, tail, depth, sc, L.wemu_traffic_launches(), n))
-    a, b, k = ctypes.create_string_buffer(300), ctypes.create_string_buffer(300), ctypes.create_string_buffer(64)
-    addr = ctypes.c_ulonglong()
-    for i in range(n):
-        cnt = L.wemu_hb_race(i, a, b, k, 300, ctypes.byref(addr))
-        print("%-20s %8d words   %s   <-   %s" % (k.value.decode(), cnt, b.value.decode(), a.value.decode()))
+    report(L, "%d steps, tail repair %s, speculation depth %d; %s" % (ITERS, tail, depth, dict(runner.speculation_counters())))
     return 0
 
 
