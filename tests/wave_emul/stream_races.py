@@ -27,6 +27,9 @@ def report(L, what):
     for i in range(n):
         cnt = L.wemu_hb_race(i, a, b, k, 300, ctypes.byref(addr))
         print("%-20s %8d words   %s   <-   %s" % (k.value.decode(), cnt, b.value.decode(), a.value.decode()))
+    buf = ctypes.create_string_buffer(8000)
+    L.wemu_hb_shared_words(buf, 8000)
+    print("#   " + buf.value.decode())
 
 
 def main():

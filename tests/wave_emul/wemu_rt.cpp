@@ -89,6 +89,7 @@ std::vector<std::string> g_kernel_names;
 struct Shadow {
   int w_stream = -1, w_epoch = 0, w_kernel = 0;
   int r_epoch[kStreams] = {0}, r_kernel[kStreams] = {0};
+  unsigned streams = 0;  // every stream that touched the word
 };
 std::unordered_map<uintptr_t, Shadow> g_shadow;
 struct Race { std::string first, second, kind; uintptr_t addr; long count; };
@@ -105,6 +106,7 @@ inline void hb_access(uintptr_t a, bool store) {
   const int s = g_cur_stream;
   const VC& me = g_vc[s];
   Shadow& sh = g_shadow[a >> 2];
+  sh.streams |= 1u << s;
   if (sh.w_stream >= 0 && sh.w_stream != s && sh.w_epoch > me.c[sh.w_stream]) report_race(sh.w_kernel, g_cur_kernel, store ? "write after write" : "read after write", a >> 2);
   if (store) {
     for (int r = 0; r < kStreams; r++)
@@ -609,6 +611,25 @@ extern "C" void wemu_hb_host_sync(long token) {  // the host waited for an event
   }
 }
 extern "C" int wemu_hb_races(void) { return (int) g_races.size(); }
+// words that more than one stream touched (ordered or not), by the kernel that wrote them last: which buffers cross streams at all
+extern "C" int wemu_hb_shared_words(char* out, int size) {
+  std::unordered_map<std::string, long> by_writer;
+  long total = 0, all = 0;
+  for (auto& kv : g_shadow) {
+    all++;
+    if (__builtin_popcount(kv.second.streams) < 2) continue;
+    total++;
+    std::string w = kv.second.w_stream >= 0 ? g_kernel_names[kv.second.w_kernel] : std::string("(never written by a kernel: inputs)");
+    by_writer[w.substr(0, w.find(" [stream"))]++;
+  }
+  std::vector<std::pair<long, std::string>> v;
+  for (auto& kv : by_writer) v.push_back({kv.second, kv.first});
+  std::sort(v.rbegin(), v.rend());
+  std::string txt = std::to_string(total) + " of " + std::to_string(all) + " words touched by kernels were touched from more than one stream; last written by:";
+  for (auto& e : v) txt += "\n#     " + std::to_string(e.first) + "  " + e.second;
+  snprintf(out, (size_t) size, "%s", txt.c_str());
+  return (int) v.size();
+}
 extern "C" long wemu_hb_race(int i, char* first, char* second, char* kind, int size, unsigned long long* addr) {
   if (i < 0 || i >= (int) g_races.size()) return -1;
   snprintf(first, (size_t) size, "%s", g_races[i].first.c_str());
