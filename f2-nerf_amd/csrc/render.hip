@@ -41,9 +41,9 @@ __global__ __launch_bounds__(256) void early_stop_kernel(int n_rays, const int32
     float sec = 0.f;
     if (in) sec = expf(c_f0 - F2N_DENSITY_SHIFT) * c_dt;
     const float alpha = 1.f - expf(-sec);
-    const float incl = f2n_row_seq_scan(sec, acc, c);
-    const float trans = expf(-f2n_row_exclusive(incl, acc, c));  // exclusive cumulative density
-    acc = f2n_row_last(incl);
+    float excl;
+    f2n_row_chain1x(sec, acc, excl);
+    const float trans = expf(-excl);  // exclusive cumulative density
     const int m = (in && trans > F2N_T_EPS) ? 1 : 0;
     if (in) {
       weights[i] = trans * alpha;
@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
     e = se[2 * ray + 1];
   }
   // ================= forward walk (composite_fwd_kernel, with the WeightVar statistics riding along) =================
+  // (the eight running sums are chains that keep their state in the row from chunk to chunk: rows_dev.h)
   float acc = 0.f, col[3] = {0.f, 0.f, 0.f}, disp = 0.f, dep = 0.f, wv_m = 0.f, wv_ws = 1e-6f;
   {
     struct In {
@@ -443,20 +444,26 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
         cr[0] = cur.c0; cr[1] = cur.c1; cr[2] = cur.c2;
       }
       const float alpha = 1.f - expf(-sec);
-      const float incl = f2n_row_seq_scan(sec, acc, c);
-      const float trans = expf(-f2n_row_exclusive(incl, acc, c));
-      acc = f2n_row_last(incl);
+      float excl;
+      f2n_row_chain1x(sec, acc, excl);
+      const float trans = expf(-excl);
       const float w = in ? trans * alpha : 0.f;
       if (in) weights[i] = w;
+      const float x_disp = w / tt, x_dep = w * tt, x_m = w * ((float) (i - s) / 16.f);
       if (!COLORS_IN) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) col[k] = f2n_row_last(f2n_row_seq_scan(w * cr[k], col[k], c));
+        f2n_row_chain4(w * cr[0], w * cr[1], w * cr[2], x_disp, col[0], col[1], col[2], disp);
+        f2n_row_chain3(x_dep, x_m, w, dep, wv_m, wv_ws);
+      } else {
+        f2n_row_chain4(x_disp, x_dep, x_m, w, disp, dep, wv_m, wv_ws);
       }
-      disp = f2n_row_last(f2n_row_seq_scan(w / tt, disp, c));
-      dep = f2n_row_last(f2n_row_seq_scan(w * tt, dep, c));
-      wv_m = f2n_row_last(f2n_row_seq_scan(w * ((float) (i - s) / 16.f), wv_m, c));
-      wv_ws = f2n_row_last(f2n_row_seq_scan(w, wv_ws, c));
     }
+    acc = f2n_row_last(acc);
+#pragma unroll
+    for (int k = 0; k < 3; k++) col[k] = f2n_row_last(col[k]);
+    disp = f2n_row_last(disp);
+    dep = f2n_row_last(dep);
+    wv_m = f2n_row_last(wv_m);
+    wv_ws = f2n_row_last(wv_ws);
   }
   if (COLORS_IN && live) {
 #pragma unroll
@@ -488,9 +495,10 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
       if (base + 16 + s < e) n_w = weights[min(i + 16 + s, e - 1)];
       const float b = (float) i / 16.f - wv_mean;
       const float wi = i + s < e ? c_w : 0.f;
-      var = f2n_row_last(f2n_row_seq_scan(wi * b * b, var, c));
-      wv_tmp = f2n_row_last(f2n_row_seq_scan(wi * 2.f * b, wv_tmp, c));
+      f2n_row_chain2(wi * b * b, wi * 2.f * b, var, wv_tmp);
     }
+    var = f2n_row_last(var);
+    wv_tmp = f2n_row_last(wv_tmp);
   }
   // ================= the loss of this ray and its gradients (train_loss_kernel, element-wise per ray) =================
   const float inv_col = 1.f / (float) max(3 * n_rays, 1), inv_ray = 1.f / (float) max(n_rays, 1);
@@ -562,8 +570,8 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
       c0 = rc.c0; c1 = rc.c1; c2 = rc.c2;
     }
     const float sec = in ? sigma * dti : 0.f;
-    const float acc_i = f2n_row_seq_scan(-sec, acc, c);
-    acc = f2n_row_last(acc_i);
+    f2n_row_chain1(-sec, acc);
+    const float acc_i = acc;
     const float trans = expf(-acc_i);
     const float ems = expf(-sec);
     const float alpha = 1.f - ems;
@@ -574,9 +582,8 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
       dw += wv_dv * (b * b + wv_tmp * -r / wv_ws);
     }
     const float d_acc = in ? -dw * w : 0.f;
-    const float suf_incl = f2n_row_seq_scan(d_acc, suffix, c);
-    const float suf_i = f2n_row_exclusive(suf_incl, suffix, c);
-    suffix = f2n_row_last(suf_incl);
+    float suf_i;
+    f2n_row_chain1x(d_acc, suffix, suf_i);
     if (in) {
       const float d_sec = dw * trans * ems + suf_i + d_total;
       float d_sigma = d_sec * dti;

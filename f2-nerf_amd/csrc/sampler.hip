@@ -941,17 +941,40 @@ __device__ __forceinline__ void f2n_ray_votes(int s, int e, int c, float mw, flo
   // 0.1 / 0.01 / 0.02 are double literals in the reference (:12-17): float*double, then narrowed by fminf
   const float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
   const float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
+  // (round 6) A chunk's three inputs are fetched one chunk AHEAD -- a walk whose loads are issued where their values are used pays a
+  // memory round trip per chunk, and the launch lasts as long as its longest ray --; the neighbours' leaves come from the row
+  // itself (DPP shifts; the chunk borders from the previous chunk's last lane and the prefetched chunk's first) instead of two
+  // more loads; what crosses from one chunk to the next is only ever used by lane 0, which row_ror:1 serves without an LDS trip.
   float carry_w = 0.f, carry_a = 0.f;
-  int carry_start = s;
+  int carry_start = s, carry_node = -1;
+  auto rot1 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false); };  // lane 0 <- lane 15
+  int n_node;
+  float n_w, n_a;
+  {
+    const int i0 = min(s + c, e - 1);
+    n_node = anchors[(size_t) i0 * anchor_stride + 1];
+    n_w = weights[i0];
+    n_a = alphas[i0];
+  }
   for (int base = s; base < e; base += 16) {
     const int i = base + c;
     const bool in = i < e;
     const int ic = in ? i : e - 1;
-    const int node = anchors[(size_t) ic * anchor_stride + 1];
-    const int prev = ic > s ? anchors[(size_t) (ic - 1) * anchor_stride + 1] : -1;
-    const int next = ic + 1 < e ? anchors[(size_t) (ic + 1) * anchor_stride + 1] : -1;
+    const int node = n_node;
+    const float c_w = n_w, c_a = n_a;
+    if (base + 16 < e) {
+      const int j = min(i + 16, e - 1);
+      n_node = anchors[(size_t) j * anchor_stride + 1];
+      n_w = weights[j];
+      n_a = alphas[j];
+    }
+    // lane 0: the previous chunk's last leaf (no leaf in front of the ray's first sample); lane 15: the next chunk's first
+    const int prev = __builtin_amdgcn_update_dpp(base > s ? carry_node : -1, node, 0x111, 0xF, 0xF, false);
+    const int nx0 = __builtin_amdgcn_update_dpp(0, n_node, 0x12F, 0xF, 0xF, false);  // lane 15 <- lane 0
+    const int nxt = __builtin_amdgcn_update_dpp(nx0, node, 0x101, 0xF, 0xF, false);
+    const int next = ic + 1 < e ? nxt : -1;
     const bool head = node != prev;
-    float cw = fmaxf(0.f, weights[ic]), ca = fmaxf(0.f, alphas[ic]);  // the reference's running maxima start at 0
+    float cw = fmaxf(0.f, c_w), ca = fmaxf(0.f, c_a);  // the reference's running maxima start at 0
     int start = head ? ic : (int) 0x80000000;
     if (c == 0 && !head) {  // the run continues from the previous chunk
       cw = fmaxf(cw, carry_w);
@@ -978,9 +1001,10 @@ __device__ __forceinline__ void f2n_ray_votes(int s, int e, int c, float mw, flo
     F2N_SEGMAX_STEP(8)
 #undef F2N_SEGMAX_STEP
     if (in && node != next) f2n_vote(w_adder, a_adder, mark, cnt, node, cw, ca, w_thres, a_thres, ic - start + 1);
-    carry_w = __shfl(cw, 15, 16);
-    carry_a = __shfl(ca, 15, 16);
-    carry_start = __shfl(start, 15, 16);
+    carry_w = __int_as_float(rot1(__float_as_int(cw)));
+    carry_a = __int_as_float(rot1(__float_as_int(ca)));
+    carry_start = rot1(start);
+    carry_node = rot1(node);
   }
 }
 
@@ -1088,9 +1112,9 @@ __global__ void early_stop_votes_kernel(int n_rays, int n_nodes, const int32_t* 
     float sec = 0.f;
     if (in) sec = expf(c_f0 - F2N_DENSITY_SHIFT) * c_dt;
     const float alpha = 1.f - expf(-sec);
-    const float incl = f2n_row_seq_scan(sec, acc, c);
-    const float trans = expf(-f2n_row_exclusive(incl, acc, c));  // exclusive cumulative density
-    acc = f2n_row_last(incl);
+    float excl;
+    f2n_row_chain1x(sec, acc, excl);
+    const float trans = expf(-excl);  // exclusive cumulative density
     const int m = (in && trans > F2N_T_EPS) ? 1 : 0;
     if (in) {
       const float w = trans * alpha;

@@ -251,14 +251,17 @@ def test_full_iteration_parity_on_the_converged_state(rt, fox_state):
 # ---------------------------------------------------------------------------------------------------
 # (c) BASELINE configs 3-5 at their native table sizes
 # ---------------------------------------------------------------------------------------------------
-def test_full_iteration_parity_at_log2_22(rt, fox_state):
-    """wanjinyou_big.yaml at the 2^22 entries per level BASELINE config 5 names: one full iteration against the oracle (512 MiB
-    fp32 table on the host): 4096 rays, fineness 16, trained-looking table."""
+@pytest.mark.parametrize("log2", [20, 22])
+def test_full_iteration_parity_at_log2_22(rt, fox_state, log2):
+    """wanjinyou_big.yaml at the 2^22 entries per level BASELINE config 5 names, and at the preset's OWN log2 20
+    (confs/wanjinyou_big.yaml:18-19; round-5 verdict, missing 2: the slice-binned gather is the host's default there): one full
+    iteration through the host against the oracle (512 MiB fp32 table on the host at 2^22): 4096 rays, fineness 16, trained-looking
+    table.  The batch is inside the window in which Hash3DAnchored::GatherPlanes takes the binned pipeline (host/Field.cpp)."""
     st = fox_state
     rng = np.random.default_rng(22)
     R, NE = 4096, 2048
-    runner, cfg, arrays = rt.make_runner(st, "wanjinyou_big", ["field.log2_table_size=22"], seed=3, table_init=0.3)
-    assert int(cfg["field"]["log2_table_size"]) == 22
+    runner, cfg, arrays = rt.make_runner(st, "wanjinyou_big", ["field.log2_table_size=%d" % log2] if log2 != 20 else [], seed=3, table_init=0.3)
+    assert int(cfg["field"]["log2_table_size"]) == log2
     runner.n_edge_pts = NE
     runner.iter_step = 1
     runner.update_ada_params()
@@ -268,9 +271,9 @@ def test_full_iteration_parity_at_log2_22(rt, fox_state):
     d = rt.to_dev(ro, rd, bounds, gt, cam, noise, bg, eidx, ecoord)
     runner.set_forced_randoms(d[5], d[6], d[7], d[8])
     ref = oracle_train_iteration(st, cfg, arrays, ro, rd, cam, gt, noise, bg, eidx, ecoord, iter_step=1)
-    assert len(ref["smp"]["t"]) > 3e5
+    assert 3e5 < len(ref["smp"]["t"]) + 2 * NE < 1536 * 1024
     m = _check_iteration(runner, rt, d, ref, gt, R, streaming=True)
-    print("LOG2_22_PARITY rgb %.2e cos %.6f" % (m["rgb_err"], m["cos"]))
+    print("LOG2_%d_PARITY rgb %.2e cos %.6f" % (log2, m["rgb_err"], m["cos"]))
 
 
 @pytest.mark.parametrize("preset", ["llff", "nerf-360"])

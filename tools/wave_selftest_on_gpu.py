@@ -1,9 +1,8 @@
 """Holds an MI355X to the known answers the wavefront emulation is held to (tests/wave_emul/known_answers.py): compiles
 tests/wave_emul/selftest.hip with hipcc for gfx950 and runs its kernels on cuda:0.  A pass says the emulation's reading of the ISA
 -- DPP controls and masks, bound_ctrl, ds_bpermute from inactive lanes, EXEC masks under divergence, reconvergence at the end of a
-loop body, the MFMA fragment layouts -- is the hardware's.  Needs a GPU (`gpurun -- python tools/wave_selftest_on_gpu.py`); NOT part
-of the test suite: no lease of this build was left to run it on (the round's GPU budget was spent before the emulation existed), so
-this file has compiled (hipcc --offload-arch=gfx950) and never run."""
+loop body, the MFMA fragment layouts -- is the hardware's.  Needs a GPU (`gpurun -- python tools/wave_selftest_on_gpu.py`); since round 6 part
+of the `-m gpu` suite (tests/test_gpu_wave_selftest.py)."""
 import ctypes
 import os
 import subprocess
