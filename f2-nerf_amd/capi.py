@@ -11,7 +11,7 @@ import torch
 from . import build
 
 _lib = None
-ABI_VERSION = 12  # include/f2n_abi.h
+ABI_VERSION = 13  # include/f2n_abi.h
 
 
 class F2nError(RuntimeError):

@@ -1183,6 +1183,7 @@ struct F2nBucketHook {
   f2n_bucket_fn fn;
   void* user;
   int n;
+  const void* table;  // the gradient table the hook is for (nullptr: any)
 };
 static F2nBucketHook g_bucket_hook[16];
 
@@ -1219,8 +1220,8 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   const int S = (F2N_N_LEVELS + 1) * H;
   int dev = 0;
   (void) hipGetDevice(&dev);
-  const F2nBucketHook hook = (dev >= 0 && dev < 16) ? g_bucket_hook[dev] : F2nBucketHook{nullptr, nullptr, 0};
-  if (hook.fn != nullptr && hook.n > 1 && S >= hook.n) {
+  const F2nBucketHook hook = (dev >= 0 && dev < 16) ? g_bucket_hook[dev] : F2nBucketHook{nullptr, nullptr, 0, nullptr};
+  if (hook.fn != nullptr && hook.n > 1 && S >= hook.n && (hook.table == nullptr || hook.table == (const void*) grad_table)) {
     for (int b = 0; b < hook.n; b++) {
       const int g0 = (int) ((long) b * S / hook.n), g1 = (int) ((long) (b + 1) * S / hook.n);
       hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3(g1 - g0), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, g0);
@@ -1244,10 +1245,12 @@ static inline bool f2n_use_bins(int n, int level_entries) {
 
 extern "C" {
 
-int f2n_set_scatter_buckets(int n_buckets, f2n_bucket_fn fn, void* user) {
+int f2n_set_scatter_buckets(int n_buckets, f2n_bucket_fn fn, void* user) { return f2n_set_scatter_buckets_for(n_buckets, fn, user, nullptr); }
+
+int f2n_set_scatter_buckets_for(int n_buckets, f2n_bucket_fn fn, void* user, const void* grad_table_h16) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || n_buckets < 0 || n_buckets > 64) return F2N_ERR_INVALID_ARG;
-  g_bucket_hook[dev] = F2nBucketHook{n_buckets > 1 ? fn : nullptr, user, n_buckets > 1 ? n_buckets : 0};
+  g_bucket_hook[dev] = F2nBucketHook{n_buckets > 1 ? fn : nullptr, user, n_buckets > 1 ? n_buckets : 0, grad_table_h16};
   return F2N_OK;
 }
 

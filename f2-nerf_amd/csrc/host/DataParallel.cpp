@@ -15,6 +15,17 @@ namespace f2n {
 
 int DataParallel::table_buckets = DataParallel::kTableBuckets;
 
+// the runner's own callbacks (apply / defer_flags) stay; what pointed into a DataParallel object goes
+static GradSyncPipeline GradSyncPipelineHooksRemoved(GradSyncPipeline p) {
+  p.blocking = nullptr;
+  p.begin = nullptr;
+  p.end = nullptr;
+  p.bucket = nullptr;
+  p.pipelined = false;
+  p.ResetBuckets();
+  return p;
+}
+
 std::vector<uint8_t> DataParallel::NewUniqueId() {
   ncclUniqueId id;
   F2N_NCCL(ncclGetUniqueId(&id));
@@ -28,7 +39,14 @@ int DataParallel::CommRanks() const {
 }
 
 DataParallel::~DataParallel() {
-  if (n_buckets_ > 1) (void) f2n_set_scatter_buckets(0, nullptr, nullptr);
+  if (n_buckets_ > 1 && device_ >= 0) {  // the hook is per device: remove it where Attach put it, whatever device is current now
+    c10::DeviceGuard guard(c10::Device(torch::kCUDA, (c10::DeviceIndex) device_));
+    (void) f2n_set_scatter_buckets_for(0, nullptr, nullptr, nullptr);
+  }
+  if (hooks_installed_ && !runner_alive_.expired()) {  // a runner that outlives this object must not call into it
+    runner_->sync_ = GradSyncPipelineHooksRemoved(runner_->sync_);
+    static_cast<PersSampler*>(runner_->renderer_->pts_sampler_.get())->occupancy_sync_hook_ = nullptr;
+  }
   if (world_ > 1) KeyedUniforms::SetReplica(0);
   if (comm_ != nullptr) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
 }
@@ -59,8 +77,10 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
   TORCH_CHECK(unique_id.size() == sizeof(ncclUniqueId), "unique id must be ", sizeof(ncclUniqueId), " bytes");
   TORCH_CHECK(world >= 1 && rank >= 0 && rank < world, "bad rank / world size");
   runner_ = runner;
+  runner_alive_ = runner->alive_;
   rank_ = rank;
   world_ = world;
+  device_ = (int) c10::hip::current_device();
   runner->renderer_->dp_world_ = world;
   KeyedUniforms::SetReplica(world > 1 ? rank : 0);  // (rays, march noise, background and edge draws: a stream per rank, KeyedDraws.h)
   ncclUniqueId id;
@@ -89,8 +109,10 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
     n_bucket_callbacks_++;
     SendBucket(b);
   };
-  if (n_buckets_ > 1)
-    F2N_CALL(f2n_set_scatter_buckets(n_buckets_, [](void* user, int b, int n) { static_cast<DataParallel*>(user)->runner_->sync_.BucketReady(b, n); }, this));
+  hooks_installed_ = true;
+  if (n_buckets_ > 1)  // (for THIS runner's gradient table only: another scatter on the device reports to nobody)
+    F2N_CALL(f2n_set_scatter_buckets_for(n_buckets_, [](void* user, int b, int n) { static_cast<DataParallel*>(user)->runner_->sync_.BucketReady(b, n); }, this,
+                                         table_prefix_.data_ptr()));
   if (overlap) {
     runner->sync_.begin = [this]() { GradSyncBegin(); };
     runner->sync_.end = [this]() { GradSyncEnd(); };

@@ -51,6 +51,9 @@ class DataParallel {
   void GradSyncEnd();
   void OccupancySync(Tensor occ);
   ExpRunner* runner_ = nullptr;
+  std::weak_ptr<int> runner_alive_;
+  bool hooks_installed_ = false;
+  int device_ = -1;  // the device current at Attach: where the scatter hook lives and where the destructor removes it
   ncclComm* comm_ = nullptr;
   int rank_ = 0, world_ = 1;
   Tensor table_prefix_, flat_;

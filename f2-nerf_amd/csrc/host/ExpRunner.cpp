@@ -468,6 +468,7 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
   gdp->backward_nan_ = false;
   const int batch = rays_o.size(0);
   renderer_->cur_seq_ = step_seq_++;
+  sync_.ArmBuckets();  // (the taped backward's scatter reports its table buckets to the exchange below)
   auto rr = renderer_->Render(rays_o, rays_d, bounds, emb_idx);
   renderer_->cur_seq_ = -1;
   TrainStats stats;

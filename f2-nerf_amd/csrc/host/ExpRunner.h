@@ -111,6 +111,8 @@ class ExpRunner {
   // of the optimiser; sync_.begin / sync_.end + sync_.pipelined = launch the asynchronous all-reduce right after backward,
   // make the compute stream wait for it in the NEXT TrainStep after ray sampling has been issued (or in FinishPending).
   GradSyncPipeline sync_;
+  // what a DataParallel object holds weakly: its destructor unhooks itself from a runner that is still there, and leaves a dead one alone
+  std::shared_ptr<int> alive_ = std::make_shared<int>(0);
   Tensor nan_flags_;  // device int32 [4]: field MLP, colour MLP, either
   // A TrainStep that is handed the next batch (streaming use) does not wait for its own flags: the kernel that computes
   // them also writes them to mapped host memory (MappedHost.h; two slots of four words, alternating -- the next step's kernel

@@ -21,10 +21,18 @@ class GradSyncPipeline {
   // that are final (f2n_set_scatter_buckets); `bucket` starts range b's all-reduce at once.  Buckets arrive in order, at most once
   // each, between BeginStep and GradientsReady; `begin` / `blocking` then send whatever was not sent (all of it when the scatter
   // reported nothing: small batches) -- every rank issues the same sequence of collectives whatever path its scatter took.
+  // A notification only counts INSIDE a step whose gradients will be exchanged (armed by BeginStep / ArmBuckets, disarmed by
+  // GradientsReady / ResetBuckets): a scatter that runs on this device for anybody else -- a test's f2n_hash_bwd, a second
+  // runner, a taped backward outside TrainStepAutograd -- must not start all-reduces the other ranks never issue (round-5 advisor).
   std::function<void(int bucket, int n_buckets)> bucket;
   int buckets_sent() const { return buckets_sent_; }
+  bool armed() const { return armed_; }
+  void ArmBuckets() {
+    buckets_sent_ = 0;
+    armed_ = Installed();
+  }
   void BucketReady(int b, int n) {
-    if (!bucket) return;
+    if (!bucket || !armed_) return;
     if (b != buckets_sent_ || b >= n) throw std::logic_error("GradSyncPipeline: gradient bucket out of order");
     bucket(b, n);
     buckets_sent_ = b + 1;
@@ -38,9 +46,12 @@ class GradSyncPipeline {
 
   // Top of a step.  `presample` (may be empty) issues this step's ray sampling, which reads neither parameters nor
   // gradients: in pipelined mode it goes first, so that it runs underneath the exchange that is still in flight.
-  void ResetBuckets() { buckets_sent_ = 0; }
+  void ResetBuckets() {
+    buckets_sent_ = 0;
+    armed_ = false;
+  }
   void BeginStep(bool apply_optimizer, const std::function<void()>& presample) {
-    buckets_sent_ = 0;  // (a step that threw behind a bucket must not leave its count behind)
+    ArmBuckets();  // (also: a step that threw behind a bucket must not leave its count behind)
     if (pipelined && apply_optimizer && presample) presample();
     FinishPendingStep();
   }
@@ -49,16 +60,23 @@ class GradSyncPipeline {
   // exchange was started and the step is completed by the next BeginStep / FinishPendingStep.
   bool GradientsReady(bool apply_optimizer, float lr) {
     struct Reset {
-      int& n;
-      ~Reset() { n = 0; }
-    } reset{buckets_sent_};  // (begin / blocking read buckets_sent(): what is left to send)
+      GradSyncPipeline& p;
+      ~Reset() { p.ResetBuckets(); }
+    } reset{*this};  // (begin / blocking read buckets_sent(): what is left to send)
     if (pipelined && apply_optimizer) {
       if (begin) begin();
       pending_ = true;
       pending_lr_ = lr;
       return false;
     }
+    // A step that does not apply the optimiser (gradient inspection) still exchanges: with the pipelined pair back to back --
+    // the table buckets its scatter reported are on their way, and a rank that skipped the rest would leave the others' collectives
+    // without a partner (round-5 advisor, medium).
     if (blocking) blocking();
+    else if (begin) {
+      begin();
+      if (end) end();
+    }
     if (apply) apply(apply_optimizer, lr);
     return true;
   }
@@ -77,6 +95,7 @@ class GradSyncPipeline {
   bool pending_ = false;
   float pending_lr_ = 0.f;
   int buckets_sent_ = 0;
+  bool armed_ = false;
 };
 
 }  // namespace f2n

@@ -32,7 +32,7 @@ py::dict StatsToDict(const TrainStats& s) {
 
 // the ABI version this host layer was compiled against (include/f2n_abi.h); a kernel library of another version next to it
 // means one of the two was not rebuilt -- calls would pass the wrong argument lists (observed once: a memory fault)
-#define F2N_HOST_EXPECTS_ABI 12
+#define F2N_HOST_EXPECTS_ABI 13
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "f2-nerf hot path: C++/LibTorch host layer over libf2n_hip.so";

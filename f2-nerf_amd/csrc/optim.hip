@@ -498,7 +498,7 @@ int f2n_debug_spin(void* stream, int microseconds) {
 }
 #endif
 
-int f2n_abi_version(void) { return 12; }
+int f2n_abi_version(void) { return 13; }
 #ifndef F2N_REFERENCE_NUMERICS
 #define F2N_REFERENCE_NUMERICS 0
 #endif

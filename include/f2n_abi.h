@@ -64,6 +64,10 @@ const char* f2n_build_info(void);
  * sends what is left when the backward returns (host/DataParallel.cpp). */
 typedef void (*f2n_bucket_fn)(void* user, int bucket, int n_buckets);
 int f2n_set_scatter_buckets(int n_buckets, f2n_bucket_fn fn, void* user);
+/* ABI v13 (round-5 advisor): the hook is for ONE gradient table -- only a scatter into grad_table_h16 is cut into buckets and
+ * reports them; any other f2n_hash_bwd / f2n_field_bwd on the device (a second runner, a test, a taped backward into another
+ * buffer) runs its owner launch in one piece and calls nobody.  grad_table_h16 == NULL: whatever table (the v12 behaviour). */
+int f2n_set_scatter_buckets_for(int n_buckets, f2n_bucket_fn fn, void* user, const void* grad_table_h16);
 /* Diagnostics (host-only, synchronous; no reference counterpart): eight device-side event counters copied to host memory,
  * optionally reset.  [0] = scatter records of f2n_hash_bwd's owner-binned path that found their queue segment full and were
  * applied by a packed-f16 atomic instead (the only order-dependent addition of that path).  The rest are reserved (0). */

@@ -3,7 +3,7 @@
 idle gap >= 100 ms (the script pauses 0.3 s in front of each phase's timed steps; the part in front of the first pause -- the
 20 000 training iterations -- is dropped), a phase's steps end with adam_fused_kernel, and every kernel's mean duration per launch
 and launches per step are printed per phase.  Usage: sweep_rocpd.py <db> [label label ...]  (labels: e.g. the phases' sample counts)"""
-import collections, sqlite3, sys
+import collections, re, sqlite3, sys
 
 db = sys.argv[1]
 labels = sys.argv[2:]
@@ -19,7 +19,9 @@ phases = [rows[a:b] for a, b in zip(cuts, cuts[1:] + [len(rows)])]
 # the sweep pauses in front of AND behind each phase's timed steps: segments 1, 3, 5, ... are the timed steps, the even ones the training
 # run / the next phase's batch draws and warm-up steps
 phases = phases[1::2]
-short = lambda n: n.split("(")[0].replace("void ", "").split("<")[0][-38:]
+def short(n):  # mangled or demangled: the kernel's own name (+ its template arguments as they are mangled)
+    m = re.search(r"([a-z][a-z0-9_]*_kernel)(I[A-Za-z0-9_]*?E(?=v|E))?", n)
+    return (m.group(1) + (m.group(2) or "")) if m else n.split("(")[0].replace("void ", "")[:38]
 table = collections.OrderedDict()
 steps = []
 for pi, p in enumerate(phases):

@@ -3,7 +3,7 @@
 dispatch after the last idle gap >= 100 ms, with its queue, start (relative, us) and duration; then per-step spans (a step
 ends with the Adam kernel: adam_fused_kernel, or adam_h16grad_kernel in older traces) and, per kernel, mean duration and how much of it ran while the OTHER queue was busy too.
 Usage: timeline_rocpd.py <db> [n_steps_to_print]"""
-import collections, sqlite3, sys
+import collections, re, sqlite3, sys
 
 db = sys.argv[1]
 n_print = int(sys.argv[2]) if len(sys.argv) > 2 else 2
@@ -18,7 +18,9 @@ for i in range(1, len(rows)):
         cut = i
 rows = rows[cut:]
 t0 = rows[0][1]
-short = lambda n: n.split("(")[0].replace("void ", "").split("<")[0][-34:]
+def short(n):  # mangled or demangled: the kernel's own name (+ its template arguments as they are mangled)
+    m = re.search(r"([a-z][a-z0-9_]*_kernel)(I[A-Za-z0-9_]*?E(?=v|E))?", n)
+    return (m.group(1) + (m.group(2) or "")) if m else n.split("(")[0].replace("void ", "")[:38]
 steps, cur_step = [], []
 for r in rows:
     cur_step.append(r)

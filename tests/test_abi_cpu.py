@@ -38,7 +38,7 @@ def test_reference_numerics_variant_exports_the_same_abi():
     ref = ctypes.CDLL(build.build_hip(variant="refnum"))
     missing = [n for n in declared() if not hasattr(ref, n)]
     assert not missing, missing
-    assert ref.f2n_numerics_mode() == 1 and ref.f2n_abi_version() == 12
+    assert ref.f2n_numerics_mode() == 1 and ref.f2n_abi_version() == 13
     ref.f2n_build_info.restype = ctypes.c_char_p
     assert b"REFERENCE-NUMERICS" in ref.f2n_build_info()
     assert os.path.exists(build.host_module_path("refnum")) or True  # (built by __graft_entry__.build())
@@ -65,7 +65,7 @@ def test_debug_variant_is_the_product_abi_plus_the_debugging_launches(lib):
 
 def test_host_only_queries(lib):
     assert lib.f2n_numerics_mode() == 0
-    assert lib.f2n_abi_version() == 12
+    assert lib.f2n_abi_version() == 13
     lib.f2n_build_info.restype = ctypes.c_char_p
     assert b"gfx950" in lib.f2n_build_info()
     assert lib.f2n_mlp_n_params(32, 64, 1) == 3072      # field MLP, SURVEY 8(a) a12
@@ -124,7 +124,7 @@ def test_binding_and_host_extension_refuse_a_library_of_another_abi_version():
     both check f2n_abi_version() when they load."""
     import f2_nerf_amd  # noqa: F401
     from f2_nerf_amd import capi, runtime
-    assert capi.ABI_VERSION == capi.lib().f2n_abi_version() == runtime.host().abi_version == 12
+    assert capi.ABI_VERSION == capi.lib().f2n_abi_version() == runtime.host().abi_version == 13
 
 
 def test_no_kernel_of_the_product_spills_vector_registers_or_uses_scratch(lib):

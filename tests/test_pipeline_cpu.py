@@ -240,12 +240,13 @@ def test_step_and_gradient_exchange_interleave_in_the_documented_order():
     p.finish_pending_step()  # flush (FinishPending / states() / render)
     p.finish_pending_step()
     assert log == ["end", "adam(apply=1, lr=0.020)", "defer_flags"] and not p.pending()
-    # a step that does not apply the optimiser (tests, gradient inspection) never leaves an exchange in flight, and first
-    # completes the one that is
+    # a step that does not apply the optimiser (tests, gradient inspection) never leaves an exchange in flight, first completes
+    # the one that is -- and still exchanges its own gradients, begin / end back to back (round 6: every rank must issue the same
+    # collectives whether or not the step applies; before, the table buckets its scatter reported went out without the rest)
     del log[:]
     assert step(p, 0.03) is False
     assert step(p, 0.04, apply=False) is True and not p.pending()
-    assert log == ["sample", "fwd_bwd", "begin", "end", "adam(apply=1, lr=0.030)", "defer_flags", "fwd_bwd", "adam(apply=0, lr=0.040)"]
+    assert log == ["sample", "fwd_bwd", "begin", "end", "adam(apply=1, lr=0.030)", "defer_flags", "fwd_bwd", "begin", "end", "adam(apply=0, lr=0.040)"]
 
 
 def test_table_gradient_buckets_travel_in_order_and_the_exchange_sends_the_rest():
@@ -288,6 +289,24 @@ def test_table_gradient_buckets_travel_in_order_and_the_exchange_sends_the_rest(
         p.bucket_ready(2, N)  # skipping one
     p.begin_step(True, lambda: None)  # a new step starts from bucket 0 again
     p.bucket_ready(0, N)
+    p.gradients_ready(True, 0.01)
+    # A step that does NOT apply the optimiser (round-5 advisor, medium): the buckets its scatter reports and the rest of the
+    # exchange go out all the same -- b0 b1 b2 b3 flat, then the wait, then the (non-applying) optimiser call -- so a rank on the
+    # binned scatter path and a rank on the small-batch path keep issuing the same collectives.
+    for reported in (4, 1, 0):
+        del log[:]
+        p.begin_step(False, lambda: None)
+        log_before = list(log)  # (the pending step of the loop above completes here: wait + adam)
+        for b in range(reported):
+            p.bucket_ready(b, N)
+        assert p.gradients_ready(False, 0.01) is True and not p.pending()
+        mine = log[len(log_before):]
+        assert mine == want + ["wait", "adam"], mine
+    # OUTSIDE a step nobody's scatter starts an all-reduce: a test calling f2n_hash_bwd, a second runner on the device, a taped
+    # backward -- the notification is dropped (the other ranks would never issue its partner)
+    del log[:]
+    p.bucket_ready(0, N)
+    assert log == [] and p.buckets_sent == 0
     # without a bucket callback (one GPU, or the torch.distributed hooks) the notifications are ignored
     q = host.GradSyncPipeline()
     q.bucket_ready(3, N)

@@ -35,6 +35,8 @@ for f in [float(v) for v in args.factors.split(",")]:
     batches = [ds.rand_rays_data(R, 1) for _ in range(4)]
     def step(i):
         b, nb = batches[i % 4], batches[(i + 1) % 4]
+        if args.speculation == 0:  # no next batch: the sampler runs inside the step, on the main stream -- every kernel alone
+            return runner.train_step(b[0], b[1], b[2], b[3], b[4], True)
         return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
     for i in range(4):
         step(i)
