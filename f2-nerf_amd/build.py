@@ -38,7 +38,7 @@ LIB = lib_path()
 
 HIP_SOURCES = ["sampler.hip", "field.hip", "shade.hip", "render.hip", "optim.hip", "workspace.hip", "dataset.hip", "octree.hip",
                "mlp_generic.hip"]
-HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", "rows_dev.h", os.path.join(INCLUDE, "f2n_abi.h"), os.path.join(INCLUDE, "f2n_debug.h")]
+HIP_HEADERS = ["f2n_dev.h", "mlp_dev.h", "rows_dev.h", "adam_dev.h", os.path.join(INCLUDE, "f2n_abi.h"), os.path.join(INCLUDE, "f2n_debug.h")]
 # (-mllvm -amdgpu-mfma-vgpr-form=1 was tried: a third fewer instructions in the MLP backward kernels -- no
 # v_accvgpr_read of every MFMA result -- but 15 % SLOWER: those kernels are bound by dependency latency, not issue.)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -279,9 +279,9 @@ def ray_march_strided_rec(n_rays, max_hits, sample_l, scale_by_dis, rays_o, rays
 
 
 def ray_march_persistent(n_rays, max_hits, n_blocks, sample_l, scale_by_dis, rays_o, rays_d, noise, oct_se, oct_idx, oct_nf, tree_nodes,
-                         transes, counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, leaf_state, reached, order, counter):
-    """The strided march on n_blocks persistent one-wave blocks, rays sorted by leaf count (see f2n_abi.h)."""
-    _ck(lib().f2n_ray_march_persistent(_stream(), _i(n_rays), _i(max_hits), _i(n_blocks), _f(sample_l), _i(int(scale_by_dis)),
+                         transes, counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, leaf_state, reached, order, counter, block_waves=1):
+    """The strided march on n_blocks persistent waves (workgroups of block_waves), rays sorted by leaf count (see f2n_abi.h)."""
+    _ck(lib().f2n_ray_march_persistent(_stream(), _i(n_rays), _i(max_hits), _i(n_blocks), _i(block_waves), _f(sample_l), _i(int(scale_by_dis)),
                                        _p(rays_o, "f32"), _p(rays_d, "f32"), _p(noise, "f32"), _p(oct_se, "i32"), _p(oct_idx, "i32"),
                                        _p(oct_nf, "f32"), _p(tree_nodes, "u8"), _p(transes, "u8"), _p(counts, "i32"),
                                        _p(s_pts, "f32", True), _p(s_dt, "f32"), _p(s_t, "f32"), _p(s_anchors, "i32"),
@@ -626,6 +626,61 @@ def adam_fused(groups, table, step, lr, beta1, beta2, eps, zero_grad, skip_flag=
                              _p(t.get("grad_h"), "h16", True), _f(float(t.get("grad_scale", 1.0))), _p(t.get("exp_avg"), "f32", True),
                              _p(t.get("exp_avg_sq"), "f32", True), _p(t.get("param_h"), "h16", True), _i(step), _f(lr), _d(beta1),
                              _d(beta2), _f(eps), _i(int(zero_grad)), _p(skip_flag, "i32", True)), "f2n_adam_fused")
+
+
+def field_bwd_dyn(n_max, n_dev, n_off, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped, volume_idx,
+                  vol_stride, mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_scaled, grad_table_h, level_entries, defer_reduce):
+    _ck(lib().f2n_field_bwd_dyn(_stream(), _i(n_max), _p(n_dev, "i32", True), _i(n_off), _i(n_volumes), _p(prim_pool, "i32"),
+                                _p(local_idx, "i32"), _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"),
+                                _p(pts_warped, "f32"), _p(volume_idx, "i32"), _i(vol_stride), _p(mlp_params_h, "h16"),
+                                _p(saved_x_h, "h16"), _p(dfeat, "f32"), _f(loss_scale), _p(dparams_scaled, "f32"),
+                                _p(grad_table_h, "h16"), _i(level_entries), _i(int(defer_reduce))), "f2n_field_bwd_dyn")
+
+
+class _StepTail(ctypes.Structure):
+    _fields_ = [("n_flags_a", ctypes.c_int), ("flags_grad_a", ctypes.c_void_p), ("n_flags_b", ctypes.c_int), ("flags_grad_b", ctypes.c_void_p),
+                ("flags", ctypes.c_void_p), ("flags_mirror", ctypes.c_void_p), ("n_groups", ctypes.c_int), ("groups", ctypes.c_void_p),
+                ("n_table", ctypes.c_int), ("table_param", ctypes.c_void_p), ("table_exp_avg", ctypes.c_void_p),
+                ("table_exp_avg_sq", ctypes.c_void_p), ("table_param_h", ctypes.c_void_p), ("table_grad_scale", ctypes.c_float),
+                ("step", ctypes.c_int), ("lr", ctypes.c_float), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_float)]
+
+
+def field_bwd_step_tail(n_max, n_dev, n_off, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped, volume_idx,
+                        vol_stride, mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_scaled, grad_table_h, level_entries, flags_a,
+                        flags_b, flags, groups, table, step, lr, beta1, beta2, eps, tail_stream=None, flags_mirror=None):
+    """f2n_field_bwd_step_tail: the field backward + the rest of the training step (deferred reductions, finiteness flags, Adam of
+    `groups` (as adam_fused) and of `table` = {param, exp_avg, exp_avg_sq, param_h, grad_scale, n}) re-ordered around the scatter.
+    Returns 1 when the scatter's owners stepped the table."""
+    arr = (_AdamGroup * max(len(groups), 1))()
+    for a, g in zip(arr, groups):
+        a.param = _p(g["param"], "f32").value
+        a.grad = _p(g["grad"], "f32").value
+        a.exp_avg = _p(g["exp_avg"], "f32").value
+        a.exp_avg_sq = _p(g["exp_avg_sq"], "f32").value
+        a.param_h = _p(g.get("param_h"), "h16", True).value
+        a.n = int(g["param"].numel())
+        a.grad_scale = float(g["grad_scale"])
+        a.weight_decay = float(g["weight_decay"])
+        a.grad_round_h16 = int(bool(g.get("grad_round_h16", False)))
+        a.check_finite = 0
+    t = _StepTail()
+    t.n_flags_a, t.flags_grad_a = int(flags_a.numel()), _p(flags_a, "f32").value
+    t.n_flags_b, t.flags_grad_b = int(flags_b.numel()), _p(flags_b, "f32").value
+    t.flags, t.flags_mirror = _p(flags, "i32").value, _mapped(flags_mirror).value
+    t.n_groups, t.groups = len(groups), ctypes.cast(arr, ctypes.c_void_p).value
+    t.n_table = int(table["n"])
+    t.table_param, t.table_exp_avg, t.table_exp_avg_sq = _p(table["param"], "f32").value, _p(table["exp_avg"], "f32").value, _p(table["exp_avg_sq"], "f32").value
+    t.table_param_h, t.table_grad_scale = _p(table["param_h"], "h16").value, float(table["grad_scale"])
+    t.step, t.lr, t.beta1, t.beta2, t.eps = int(step), float(lr), float(beta1), float(beta2), float(eps)
+    by_owners = ctypes.c_int(0)
+    ts = ctypes.c_void_p(tail_stream.cuda_stream) if tail_stream is not None else ctypes.c_void_p(0)
+    _ck(lib().f2n_field_bwd_step_tail(_stream(), ts, _i(n_max), _p(n_dev, "i32", True), _i(n_off), _i(n_volumes), _p(prim_pool, "i32"),
+                                      _p(local_idx, "i32"), _p(local_size, "i32"), _p(bias_pool, "f32"), _p(level_scale, "f32"),
+                                      _p(pts_warped, "f32"), _p(volume_idx, "i32"), _i(vol_stride), _p(mlp_params_h, "h16"),
+                                      _p(saved_x_h, "h16"), _p(dfeat, "f32"), _f(loss_scale), _p(dparams_scaled, "f32"),
+                                      _p(grad_table_h, "h16"), _i(level_entries), ctypes.byref(t), ctypes.byref(by_owners)),
+        "f2n_field_bwd_step_tail")
+    return by_owners.value
 
 
 def reduce_deferred():

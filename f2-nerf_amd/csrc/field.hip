@@ -6,6 +6,7 @@
 #include <math.h>
 #include <string.h>
 
+#include "adam_dev.h"
 #include "mlp_dev.h"
 
 struct F2nHashArgs {
@@ -817,9 +818,24 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) l * q.n_bins + i) * nb + B] = min(s_cnt[i], cap_nb);
 }
 
+// ADAM (round 6; f2n_field_bwd_step_tail): the owner does not write its slice's sums to the gradient table for a streaming
+// optimiser pass behind the step -- it steps the slice's parameters itself (adam_fused_kernel's table arithmetic, element for
+// element: gradient = the f16 value the table WOULD hold; widening, / 128, Adam, f16 refresh) and leaves the gradient table zero.
+// Every slice of the active prefix is stepped, also the ones nothing landed in (Adam moves a parameter on its moments alone).
+struct F2nOwnerAdam {
+  float2* param;       // fp32 master [entries][2]
+  float2* exp_avg;
+  float2* exp_avg_sq;
+  half2_t* param_h;    // the f16 working copy the gather reads
+  F2nAdamCoef k;
+  const int32_t* skip;  // flags[2] of the step's finiteness check: != 0 -> the iteration is dropped (ExpRunner.cpp:131-134)
+};
+
+template <bool ADAM>
 __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
                                                                   half_t* __restrict__ grad_table, int n,
-                                                                  const int32_t* __restrict__ n_dev, int n_off, int first_slice) {
+                                                                  const int32_t* __restrict__ n_dev, int n_off, int first_slice,
+                                                                  F2nOwnerAdam ad) {
   F2N_RAISE_PRIO();
   __shared__ double s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp64 image of this block's table slice
   int& s_total = *(int*) &s_acc[0];              // (the record total lives in the image's first word until the image is zeroed)
@@ -844,8 +860,9 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   if (lane == 0 && wsum > 0) atomicAdd(&s_total, wsum);
   __syncthreads();
   const int total = s_total;
-  if (total == 0) return;  // block-uniform: nothing landed in this slice
-  __syncthreads();         // (everyone has read the total before its word is zeroed with the image)
+  if (total == 0 && !ADAM) return;  // block-uniform: nothing landed in this slice
+  __syncthreads();                  // (everyone has read the total before its word is zeroed with the image)
+  if (total != 0) {
   for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.0;
   __syncthreads();
   // Segments in batches, the first 128 records of each with one coalesced 8-byte load per lane (the records were written
@@ -881,17 +898,46 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
       for (int i = lane + 256; i < cnt[u]; i += 64) add(r[u][i]);
   }
   __syncthreads();
+  }  // total != 0
   half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
+  const bool skip = ADAM && ad.skip != nullptr && *ad.skip != 0;
+  const size_t e_base = (size_t) g * F2N_BIN_ENTRIES;
   for (int e0 = tid; e0 < F2N_BIN_ENTRIES; e0 += 256 * 8) {  // eight independent table reads in flight per thread
     half2_t old[8];
+    float2 pp[8], mm[8], vv[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) old[u] = tab[e0 + 256 * u];
+    for (int u = 0; u < 8; u++) {
+      old[u] = tab[e0 + 256 * u];
+      if (ADAM && !skip) {
+        pp[u] = ad.param[e_base + e0 + 256 * u];
+        mm[u] = ad.exp_avg[e_base + e0 + 256 * u];
+        vv[u] = ad.exp_avg_sq[e_base + e0 + 256 * u];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int e = e0 + 256 * u;
-      const double a0 = s_acc[2 * e], a1 = s_acc[2 * e + 1];
-      if (a0 != 0.0 || a1 != 0.0)
-        tab[e] = half2_t{(half_t) (float) ((double) (float) old[u][0] + a0), (half_t) (float) ((double) (float) old[u][1] + a1)};
+      double a0 = 0.0, a1 = 0.0;
+      if (total != 0) {
+        a0 = s_acc[2 * e];
+        a1 = s_acc[2 * e + 1];
+      }
+      half2_t gh = old[u];  // the value the gradient table holds behind the plain owner
+      if (a0 != 0.0 || a1 != 0.0) gh = half2_t{(half_t) (float) ((double) (float) old[u][0] + a0), (half_t) (float) ((double) (float) old[u][1] + a1)};
+      if (!ADAM) {
+        if (a0 != 0.0 || a1 != 0.0) tab[e] = gh;
+      } else {
+        if (__builtin_bit_cast(uint32_t, old[u]) != 0u) tab[e] = half2_t{(half_t) 0.f, (half_t) 0.f};  // zero_grad (fallback atomics may have landed here)
+        if (!skip) {
+          float m0 = mm[u].x, m1 = mm[u].y, v0 = vv[u].x, v1 = vv[u].y;
+          const float p0 = f2n_adam_update(pp[u].x, (float) gh[0] * ad.k.grad_scale, m0, v0, ad.k);
+          const float p1 = f2n_adam_update(pp[u].y, (float) gh[1] * ad.k.grad_scale, m1, v1, ad.k);
+          ad.param[e_base + e] = make_float2(p0, p1);
+          ad.exp_avg[e_base + e] = make_float2(m0, m1);
+          ad.exp_avg_sq[e_base + e] = make_float2(v0, v1);
+          ad.param_h[e_base + e] = half2_t{(half_t) p0, (half_t) p1};
+        }
+      }
     }
   }
 }
@@ -1191,7 +1237,9 @@ static F2nBucketHook g_bucket_hook[16];
 static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const int32_t* local_idx, const int32_t* local_size,
                               const float* level_scale, const float* pts, int warped, const int32_t* volume_idx, int vol_stride,
                               const half_t* gx, long ss, long ps, const uint16_t* nz_mask, half_t* grad_table, int level_entries,
-                              const int32_t* n_dev = nullptr, int n_off = 0) {
+                              const int32_t* n_dev = nullptr, int n_off = 0, const F2nOwnerAdam* adam = nullptr,
+                              hipEvent_t wait_before_owners = nullptr, int* adam_applied = nullptr) {
+  if (adam_applied != nullptr) *adam_applied = 0;
   F2nBinQueues q;
 #if F2N_DEBUG_BUILD  // measurement knob of the debug variant: the producer chunk count whatever the sample count
   static const int nb_force = []() {
@@ -1224,14 +1272,20 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   if (hook.fn != nullptr && hook.n > 1 && S >= hook.n && (hook.table == nullptr || hook.table == (const void*) grad_table)) {
     for (int b = 0; b < hook.n; b++) {
       const int g0 = (int) ((long) b * S / hook.n), g1 = (int) ((long) (b + 1) * S / hook.n);
-      hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3(g1 - g0), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, g0);
+      hipLaunchKernelGGL(hash_bin_accumulate_kernel<false>, dim3(g1 - g0), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, g0, F2nOwnerAdam{});
       const int rc = f2n_launch_status();
       if (rc != F2N_OK) return rc;
       hook.fn(hook.user, b, hook.n);
     }
     return F2N_OK;
   }
-  hipLaunchKernelGGL(hash_bin_accumulate_kernel, dim3(S), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, 0);
+  if (adam != nullptr) {  // (no bucket hook on this table: checked above)
+    if (wait_before_owners != nullptr && hipStreamWaitEvent(st, wait_before_owners, 0) != hipSuccess) return F2N_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(hash_bin_accumulate_kernel<true>, dim3(S), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, 0, *adam);
+    if (adam_applied != nullptr) *adam_applied = 1;
+    return f2n_launch_status();
+  }
+  hipLaunchKernelGGL(hash_bin_accumulate_kernel<false>, dim3(S), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, 0, F2nOwnerAdam{});
   return f2n_launch_status();
 }
 
@@ -1570,46 +1624,139 @@ int f2n_field_bwd(void* stream, int n, int n_volumes, const int32_t* prim_pool, 
                            level_entries, 0);
 }
 
-int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, int n_volumes, const int32_t* prim_pool,
-                      const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
-                      const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
-                      const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h,
-                      int level_entries, int defer_reduce) {
+// f2n_field_bwd_dyn, and -- with a tail -- f2n_field_bwd_step_tail (include/f2n_abi.h): the rest of the training step re-ordered
+// around it.
+static int f2n_field_bwd_impl(void* stream, void* tail_stream, int n_max, const int32_t* n_dev, int n_off, int n_volumes,
+                              const int32_t* prim_pool, const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                              const float* level_scale, const float* pts_warped, const int32_t* volume_idx, int vol_stride,
+                              const void* mlp_params_h, const void* saved_x_h, const float* dfeat, float loss_scale,
+                              float* dparams_f32_scaled, void* grad_table_h, int level_entries, int defer_reduce,
+                              const F2nStepTail* tail, int* table_stepped) {
   const int n = n_max;
+  if (table_stepped != nullptr) *table_stepped = 0;
   if (n < 0 || n_volumes <= 0 || vol_stride < 1 || !(loss_scale > 0.f) || level_entries < 0 || ((uintptr_t) mlp_params_h & 15))
     return F2N_ERR_INVALID_ARG;
-  if (n == 0) return F2N_OK;
+  if (tail != nullptr && (tail->flags == nullptr || tail->n_groups < 0 || tail->n_groups > 4 || tail->step < 1 || tail->n_table < 0 ||
+                          (tail->n_table > 0 && (tail->table_param == nullptr || tail->table_exp_avg == nullptr ||
+                                                 tail->table_exp_avg_sq == nullptr || tail->table_param_h == nullptr))))
+    return F2N_ERR_INVALID_ARG;
+  if (n == 0 && tail == nullptr) return F2N_OK;
   F2nHashArgs h = {nullptr, prim_pool, bias_pool, n_volumes};
-  const bool bins = f2n_use_bins(n, level_entries);
-  const unsigned blocks = f2n_bwd_grid((n + 31) / 32, bins ? 3 : 2);  // 154 / 186 registers: three / two resident blocks per CU
+  const bool bins = n > 0 && f2n_use_bins(n, level_entries);
+  int rc = F2N_OK;
   const int n_params = f2n_mlp_n_params(F2N_D_IN, F2N_D_HID, 1);
-  float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) blocks * n_params);
-  if (partials == nullptr) return F2N_ERR_INVALID_ARG;
   half_t* dx_planes = nullptr;
   uint16_t* nz_mask = nullptr;
-  if (bins) {  // planes [8][n][4] followed by one non-zero bit per sample
-    const size_t plane_bytes = sizeof(half_t) * 32 * (size_t) n;
-    dx_planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, plane_bytes + sizeof(uint16_t) * ((size_t) n / 16 + 2));
-    if (dx_planes == nullptr) return F2N_ERR_INVALID_ARG;
-    nz_mask = (uint16_t*) ((char*) dx_planes + plane_bytes);
-  }
+  if (n > 0) {
+    const unsigned blocks = f2n_bwd_grid((n + 31) / 32, bins ? 3 : 2);  // 154 / 186 registers: three / two resident blocks per CU
+    float* partials = (float*) f2n_ws_get(F2N_WS_FIELD_DW, sizeof(float) * (size_t) blocks * n_params);
+    if (partials == nullptr) return F2N_ERR_INVALID_ARG;
+    if (bins) {  // planes [8][n][4] followed by one non-zero bit per sample
+      const size_t plane_bytes = sizeof(half_t) * 32 * (size_t) n;
+      dx_planes = (half_t*) f2n_ws_get(F2N_WS_FIELD_PLANES, plane_bytes + sizeof(uint16_t) * ((size_t) n / 16 + 2));
+      if (dx_planes == nullptr) return F2N_ERR_INVALID_ARG;
+      nz_mask = (uint16_t*) ((char*) dx_planes + plane_bytes);
+    }
 #define F2N_LAUNCH_FIELD_BWD(HASH, BPC)                                                                                      \
   hipLaunchKernelGGL((field_bwd_kernel<1, HASH, BPC>), dim3(blocks), dim3(F2N_BWD_THREADS), 0, (hipStream_t) stream, n, h,  \
                      local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, (const half_t*) mlp_params_h, \
                      (const half_t*) saved_x_h, nullptr, dfeat, loss_scale, partials, nullptr, (half_t*) grad_table_h,       \
                      dx_planes, nz_mask, n_dev, n_off)
-  if (!bins) F2N_LAUNCH_FIELD_BWD(1, 2);
-  else F2N_LAUNCH_FIELD_BWD(2, 3);
+    if (!bins) F2N_LAUNCH_FIELD_BWD(1, 2);
+    else F2N_LAUNCH_FIELD_BWD(2, 3);
 #undef F2N_LAUNCH_FIELD_BWD
-  int rc = f2n_launch_status();
-  if (rc != F2N_OK) return rc;
-  if (dx_planes != nullptr) {  // planes [8][n][4]: pair (l, ch) at (l>>1)*4n + 4*s + 2*(l&1) + ch
-    rc = f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
-                            dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries, n_dev, n_off);
+    rc = f2n_launch_status();
+    if (rc != F2N_OK) return rc;
+    if (tail == nullptr && !defer_reduce) {
+      if (dx_planes != nullptr) {
+        rc = f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride,
+                                dx_planes, 4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries, n_dev, n_off);
+        if (rc != F2N_OK) return rc;
+      }
+      return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
+    }
+    rc = f2n_defer_reduction(n_params, (int) blocks, partials, dparams_f32_scaled);
     if (rc != F2N_OK) return rc;
   }
-  if (defer_reduce) return f2n_defer_reduction(n_params, (int) blocks, partials, dparams_f32_scaled);
-  return f2n_reduce_partials(stream, n_params, (int) blocks, partials, dparams_f32_scaled);
+  if (tail == nullptr) {  // f2n_field_bwd_dyn with defer_reduce: the scatter, nothing else
+    if (dx_planes == nullptr) return F2N_OK;
+    return f2n_binned_scatter((hipStream_t) stream, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, dx_planes,
+                              4, 4 * (long) n, nz_mask, (half_t*) grad_table_h, level_entries, n_dev, n_off);
+  }
+  // ---- the step's tail: the MLPs' gradients are complete (every deferring backward has been queued on `stream`) ----
+  hipStream_t st = (hipStream_t) stream, ts = tail_stream != nullptr ? (hipStream_t) tail_stream : st;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  if (ts != st) {
+    int dev = 0;
+    static hipEvent_t evs[16][2];
+    static bool made[16];
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return F2N_ERR_INVALID_ARG;
+    if (!made[dev]) {
+      if (hipEventCreateWithFlags(&evs[dev][0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evs[dev][1], hipEventDisableTiming) != hipSuccess)
+        return F2N_ERR_UNSUPPORTED;
+      made[dev] = true;
+    }
+    ev_fork = evs[dev][0];
+    ev_join = evs[dev][1];
+    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(ts, ev_fork, 0) != hipSuccess) return F2N_ERR_INVALID_ARG;
+  }
+  rc = f2n_reduce_deferred(ts);
+  if (rc != F2N_OK) return rc;
+  rc = f2n_nonfinite_flags_ex(ts, tail->n_flags_a, tail->flags_grad_a, tail->n_flags_b, tail->flags_grad_b, tail->flags, tail->flags_mirror);
+  if (rc != F2N_OK) return rc;
+  const int32_t* skip = tail->flags + 2;
+  rc = f2n_adam_fused(ts, tail->n_groups, tail->groups, 0, nullptr, nullptr, 1.f, nullptr, nullptr, nullptr, tail->step, tail->lr, tail->beta1,
+                      tail->beta2, tail->eps, /*zero_grad=*/1, skip);
+  if (rc != F2N_OK) return rc;
+  if (ts != st && hipEventRecord(ev_join, ts) != hipSuccess) return F2N_ERR_INVALID_ARG;
+  int by_owners = 0;
+  if (dx_planes != nullptr) {
+    // the owners step the table when its active prefix is exactly the slices they own (17 half levels of the reference's layout)
+    const long S = (long) (F2N_N_LEVELS + 1) * ((level_entries >> F2N_BIN_SHIFT) / 2);
+    F2nOwnerAdam ad;
+    ad.param = (float2*) tail->table_param;
+    ad.exp_avg = (float2*) tail->table_exp_avg;
+    ad.exp_avg_sq = (float2*) tail->table_exp_avg_sq;
+    ad.param_h = (half2_t*) tail->table_param_h;
+    ad.k = f2n_adam_coef(tail->step, tail->lr, tail->beta1, tail->beta2, tail->eps, 0.f, tail->table_grad_scale);
+    ad.skip = skip;
+    const bool can = tail->n_table > 0 && (long) tail->n_table == S * 2 * F2N_BIN_ENTRIES;
+    rc = f2n_binned_scatter(st, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, dx_planes, 4, 4 * (long) n, nz_mask,
+                            (half_t*) grad_table_h, level_entries, n_dev, n_off, can ? &ad : nullptr, ev_join, &by_owners);
+    if (rc != F2N_OK) return rc;
+  }
+  if (!by_owners) {  // small batches, odd tables, a bucket hook: the ordinary table pass behind the scatter
+    if (ts != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return F2N_ERR_INVALID_ARG;
+    if (tail->n_table > 0) {
+      rc = f2n_adam_fused(st, 0, nullptr, tail->n_table, tail->table_param, grad_table_h, tail->table_grad_scale, tail->table_exp_avg,
+                          tail->table_exp_avg_sq, tail->table_param_h, tail->step, tail->lr, tail->beta1, tail->beta2, tail->eps, /*zero_grad=*/1, skip);
+      if (rc != F2N_OK) return rc;
+    }
+  }
+  if (table_stepped != nullptr) *table_stepped = by_owners;
+  return F2N_OK;
+}
+
+int f2n_field_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, int n_off, int n_volumes, const int32_t* prim_pool,
+                      const int32_t* local_idx, const int32_t* local_size, const float* bias_pool, const float* level_scale,
+                      const float* pts_warped, const int32_t* volume_idx, int vol_stride, const void* mlp_params_h,
+                      const void* saved_x_h, const float* dfeat, float loss_scale, float* dparams_f32_scaled, void* grad_table_h,
+                      int level_entries, int defer_reduce) {
+  return f2n_field_bwd_impl(stream, nullptr, n_max, n_dev, n_off, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped,
+                            volume_idx, vol_stride, mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_f32_scaled, grad_table_h, level_entries,
+                            defer_reduce, nullptr, nullptr);
+}
+
+int f2n_field_bwd_step_tail(void* stream, void* tail_stream, int n_max, const int32_t* n_dev, int n_off, int n_volumes,
+                            const int32_t* prim_pool, const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                            const float* level_scale, const float* pts_warped, const int32_t* volume_idx, int vol_stride,
+                            const void* mlp_params_h, const void* saved_x_h, const float* dfeat, float loss_scale,
+                            float* dparams_f32_scaled, void* grad_table_h, int level_entries, const F2nStepTail* tail,
+                            int* table_stepped_by_owners) {
+  if (tail == nullptr) return F2N_ERR_INVALID_ARG;
+  return f2n_field_bwd_impl(stream, tail_stream, n_max, n_dev, n_off, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale,
+                            pts_warped, volume_idx, vol_stride, mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_f32_scaled, grad_table_h,
+                            level_entries, 1, tail, table_stepped_by_owners);
 }
 
 }  // extern "C"

@@ -180,15 +180,11 @@ void ExpRunner::ResetStepSequence(int64_t seq) {
 
 // One optimiser step.  compute_flags (device int32[3], or NULL): the finiteness flags of the two MLP gradients are
 // computed inside the small-groups launch and every update of this step is predicated on them (flags[2]).
-void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
-  optim_steps_ += 1;
-  void* st = CurStream();
+void ExpRunner::BuildAdamPlan(AdamPlan& plan) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
-  torch::NoGradGuard no_grad;
+  plan = AdamPlan();
   // the small fp32 groups (field MLP, colour MLP, app_emb), in the order the flag layout names them
-  F2nAdamGroup small[4];
-  int n_small = 0;
   auto add_small = [&](size_t i) {
     auto& g = groups_[i];
     float scale = g.grad_scale;
@@ -204,8 +200,8 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
     d.weight_decay = g.weight_decay;
     d.grad_round_h16 = g.grad_round_h16 ? 1 : 0;
     d.check_finite = 0;
-    TORCH_CHECK(n_small < 4, "too many small parameter groups");
-    small[n_small++] = d;
+    TORCH_CHECK(plan.n_small < 4, "too many small parameter groups");
+    plan.small[plan.n_small++] = d;
   };
   for (size_t i = 0; i < groups_.size(); i++)
     if (groups_[i].name == "field_mlp") add_small(i);
@@ -218,6 +214,25 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
     if (!groups_[i].grad_is_h16 && groups_[i].name != "field_mlp" && groups_[i].name != "color_mlp" &&
         (groups_[i].name != "app_emb" || renderer_->use_app_emb_))
       add_small(i);
+  for (size_t i = 0; i < groups_.size(); i++) {
+    auto& g = groups_[i];
+    if (!g.grad_is_h16) continue;
+    TORCH_CHECK(plan.n_table == 0, "one h16-gradient table group expected");
+    plan.n_table = (int) (g.active > 0 ? g.active : g.param.numel());
+    plan.tp = F32P(g.param); plan.tg = VoidP(g.grad); plan.tm = F32P(exp_avg_[i]); plan.tv = F32P(exp_avg_sq_[i]); plan.th = VoidP(g.param_h);
+    plan.tscale = g.grad_scale;
+    TORCH_CHECK(g.weight_decay == 0.f, "the table group has no weight decay (Hash3DAnchored.cpp:124-150)");
+  }
+}
+
+void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
+  optim_steps_ += 1;
+  void* st = CurStream();
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  torch::NoGradGuard no_grad;
+  AdamPlan plan;
+  BuildAdamPlan(plan);
   // TCNNWP.cpp:234-240 on the device: flags = {field MLP gradient non-finite, colour MLP gradient non-finite, either}; every
   // update of this step is predicated on flags[2] -- computed by its own small launch so that the ONE launch that steps all
   // groups (f2n_adam_fused) has no block-wide dependency in it
@@ -227,23 +242,41 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
                                                   F32P(shader->mlp_->grad_scaled_), compute_flags, NextFlagMirror()));
     skip = compute_flags + 2;
   }
-  int n_table = 0;
-  float *tp = nullptr, *tm = nullptr, *tv = nullptr;
-  void *tg = nullptr, *th = nullptr;
-  float tscale = 1.f;
-  for (size_t i = 0; i < groups_.size(); i++) {
-    auto& g = groups_[i];
-    if (!g.grad_is_h16) continue;
-    TORCH_CHECK(n_table == 0, "one h16-gradient table group expected");
-    n_table = (int) (g.active > 0 ? g.active : g.param.numel());
-    tp = F32P(g.param); tg = VoidP(g.grad); tm = F32P(exp_avg_[i]); tv = F32P(exp_avg_sq_[i]); th = VoidP(g.param_h);
-    tscale = g.grad_scale;
-    TORCH_CHECK(g.weight_decay == 0.f, "the table group has no weight decay (Hash3DAnchored.cpp:124-150)");
-    if (g.name == "feat_pool") field->grad_clean_ = true;
-  }
-  F2N_TIMED_CALL("adam_table", f2n_adam_fused(st, n_small, small, n_table, tp, tg, tscale, tm, tv, th, optim_steps_, cur_lr_, /*betas: doubles, as AdamOptions holds them*/ 0.9, 0.99,
-                                              1e-15f, /*zero_grad=*/1, skip));
+  if (plan.n_table > 0) field->grad_clean_ = true;
+  F2N_TIMED_CALL("adam_table", f2n_adam_fused(st, plan.n_small, plan.small, plan.n_table, plan.tp, plan.tg, plan.tscale, plan.tm, plan.tv, plan.th, optim_steps_, cur_lr_,
+                                              /*betas: doubles, as AdamOptions holds them*/ 0.9, 0.99, 1e-15f, /*zero_grad=*/1, skip));
   renderer_->small_grads_clean_ = true;  // every group's gradient was consumed and cleared (also on the skipped path)
+}
+
+// The arguments of f2n_field_bwd_step_tail for the step that is being queued (called from Renderer::TrainForwardBackward in front of
+// the field backward: the previous step's flags have been resolved by then, so the loss scales and the step count are this step's).
+bool ExpRunner::BuildStepTail(F2nStepTail* t) {
+  auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
+  auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
+  if (!fused_tail_ || !check_nan_ || sync_.Installed()) return false;
+  if (!nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
+  BuildAdamPlan(tail_plan_);
+  if (tail_plan_.n_table <= 0) return false;
+  t->n_flags_a = field->mlp_->n_params_;
+  t->flags_grad_a = F32P(field->mlp_->grad_scaled_);
+  t->n_flags_b = shader->mlp_->n_params_;
+  t->flags_grad_b = F32P(shader->mlp_->grad_scaled_);
+  t->flags = I32P(nan_flags_);
+  t->flags_mirror = NextFlagMirror();
+  t->n_groups = tail_plan_.n_small;
+  t->groups = tail_plan_.small;
+  t->n_table = tail_plan_.n_table;
+  t->table_param = tail_plan_.tp;
+  t->table_exp_avg = tail_plan_.tm;
+  t->table_exp_avg_sq = tail_plan_.tv;
+  t->table_param_h = tail_plan_.th;
+  t->table_grad_scale = tail_plan_.tscale;
+  t->step = optim_steps_ + 1;
+  t->lr = cur_lr_;
+  t->beta1 = 0.9;
+  t->beta2 = 0.99;
+  t->eps = 1e-15f;
+  return true;
 }
 
 // Loss weights of the current iteration (ExpRunner.cpp:108-114).
@@ -310,6 +343,9 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   // (f2n_*_dyn entry points), the host queues the whole iteration without a device round trip and learns the count -- for
   // the meaningful-samples EMA and the counters -- at the start of the next step (Renderer::ResolvePendingCount).
   renderer_->async_count_ = (prefetch && async_counts_ == 1) || async_counts_ == 2;
+  renderer_->step_tail_done_ = false;
+  renderer_->step_tail_builder_ = nullptr;
+  if (apply_optimizer && fused_tail_) renderer_->step_tail_builder_ = [this](F2nStepTail* t) { return BuildStepTail(t); };
   TrainOutputs out;
   {
     F2N_HOST_SCOPE("step.fwd_bwd");
@@ -318,6 +354,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   }
   renderer_->async_count_ = false;
   renderer_->after_octree_update_ = nullptr;
+  renderer_->step_tail_builder_ = nullptr;
   if (prefetch && out.has_samples) renderer_->SpecBeginAtStepEnd();  // (small trees: the batch after next, see Renderer.h)
   renderer_->next_batch_ = renderer_->next2_batch_ = Renderer::NextBatch();
   ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)
@@ -406,7 +443,13 @@ void ExpRunner::EnqueueApply(bool apply_optimizer) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
   if (check_nan_ && !nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
-  if (apply_optimizer) {  // the flags are computed by the small-groups launch itself; a no-op on the device when they say so
+  if (apply_optimizer && renderer_->step_tail_done_) {
+    // the field backward's call has queued all of it (f2n_field_bwd_step_tail): what is left is the host's own bookkeeping
+    renderer_->step_tail_done_ = false;
+    optim_steps_ += 1;
+    field->grad_clean_ = true;
+    renderer_->small_grads_clean_ = true;
+  } else if (apply_optimizer) {  // the flags are computed by the small-groups launch itself; a no-op on the device when they say so
     OptimStep(nullptr, check_nan_ ? I32P(nan_flags_) : nullptr);
   } else if (check_nan_) {
     F2N_CALL(f2n_nonfinite_flags_ex(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,

@@ -81,6 +81,24 @@ class ExpRunner {
   float FinenessAt(int iter) const;
   // skip_flag: device int, != 0 drops the update; compute_flags: device int32[3], finiteness flags computed (and obeyed) in the step
   void OptimStep(const int32_t* skip_flag = nullptr, int32_t* compute_flags = nullptr);
+  // One optimiser step's arguments as the C-ABI takes them (f2n_adam_fused / F2nStepTail): the small fp32 groups in the order the
+  // flag layout names them, the h16-gradient table group, the scalars of step `step`.
+  struct AdamPlan {
+    F2nAdamGroup small[4];
+    int n_small = 0, n_table = 0;
+    float *tp = nullptr, *tm = nullptr, *tv = nullptr;
+    void *tg = nullptr, *th = nullptr;
+    float tscale = 1.f;
+  };
+  void BuildAdamPlan(AdamPlan& plan);
+  // The step's tail inside the field backward's call (round 6; f2n_field_bwd_step_tail): finiteness flags and the small groups'
+  // Adam on a second stream behind the field-MLP backward, the table's Adam in the scatter's owner blocks.  Single-GPU streaming
+  // steps that apply the optimiser take it; a data-parallel step (the gradients travel first), a step that only inspects
+  // gradients, the diagnostics taps and check_nan == false keep the separate launches.  Same parameters, bit for bit
+  // (tests/test_gpu_e2e.py::test_fused_step_tail_equals_separate_launches).
+  bool fused_tail_ = true;
+  bool BuildStepTail(F2nStepTail* tail);
+  AdamPlan tail_plan_;
   void BuildOptimizer();
   Tensor FlattenSmallGrads();
   int CurBatchSize() const;

@@ -202,7 +202,7 @@ void PersSampler::BeginSamples(const Tensor& rays_o_raw, const Tensor& rays_d_ra
       p.leaf_state = torch::empty({k_cap, 2}, DevI32());
       p.reached = torch::empty({n_rays}, DevI32());
     }
-    F2N_TIMED_CALL("ray_march", f2n_ray_march_persistent(st, n_rays, max_oct_intersect_per_ray_, persistent_blocks, sample_l_, scale_by_dis_,
+    F2N_TIMED_CALL("ray_march", f2n_ray_march_persistent(st, n_rays, max_oct_intersect_per_ray_, persistent_blocks, march_block_waves_, sample_l_, scale_by_dis_,
                                    F32P(rays_o), F32P(rays_d), F32P(rays_noise), I32P(oct_se), I32P(oct_idx), F32P(oct_nf),
                                    VoidP(oct.tree_nodes_gpu_), VoidP(oct.pers_trans_gpu_), I32P(counts), nullptr, F32P(s_dt), F32P(s_t),
                                    I32P(s_anchors), F32P(first_oct_dis), I32P(oct_tr), tail ? VoidP(p.leaf_state) : nullptr,

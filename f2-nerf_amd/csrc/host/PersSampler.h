@@ -125,6 +125,7 @@ class PersSampler : public PtsSampler {
   // > 0: speculative batches are marched by this many persistent one-wave blocks, rays sorted by leaf count
   // (f2n_ray_march_persistent): a small footprint underneath the main queue's kernels, for batches that have two steps to finish
   int march_blocks_ = 512;
+  int march_block_waves_ = 4;  // (measured: profiles/r06_march_block_waves.txt) the persistent march's waves come in workgroups of this many (one CU each): see f2n_ray_march_persistent
   bool persistent_march_ = false;  // set by the Renderer around the BeginSamples of a batch that is begun two steps ahead
   int LdsWalkMaxInterior() const { return f2n_oct_lds_max_interior(); }  // small trees are walked out of LDS (same bits either way)
   // a FinishOctUpdate of the iteration in progress or of one of the `ahead` iterations behind it runs ProcOctree

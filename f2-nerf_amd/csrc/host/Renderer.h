@@ -275,6 +275,7 @@ class Renderer : public Pipe {
   // Renderer: memory one Renderer returns to a shared pool may be handed to another Renderer's side-stream kernels (round-4 advisor).
   struct SideShared {
     std::shared_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> stream[kPendingSlots];
+    std::shared_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> tail;  // (created with the first fused step tail)
     at::cuda::CUDAEvent consumed;
     uint64_t seq = 0, waited[kPendingSlots] = {0, 0};
   };
@@ -283,6 +284,11 @@ class Renderer : public Pipe {
   void SideWaitConsumed(int slot);
   bool small_grads_clean_ = false;  // set by ExpRunner::OptimStep (fused zero_grad), consumed by the next ZeroGrad()
   std::function<void()> after_count_readback_;  // ExpRunner: reads the previous step's finiteness flags here (no extra wait)
+  // ExpRunner: the step's tail -- finiteness flags, Adam -- as arguments of the field backward's call (f2n_field_bwd_step_tail);
+  // false: this step keeps the separate launches.  step_tail_done_: the call has queued them (ExpRunner::EnqueueApply's cue).
+  std::function<bool(F2nStepTail*)> step_tail_builder_;
+  bool step_tail_done_ = false;
+  c10::hip::HIPStreamMasqueradingAsCUDA* TailStream();  // the device's third side stream (flags + small Adam beside the scatter)
   MappedWords n_kept_words_;  // [1]: the surviving-sample count, written by the survivor scan itself, read behind n_kept_ev_
   std::shared_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> side_[kPendingSlots];  // (shared by every Renderer of the device)
   void EnsureSideStream(int slot);

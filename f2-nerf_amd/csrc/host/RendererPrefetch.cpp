@@ -104,6 +104,17 @@ void Renderer::EnsureSideStream(int slot) {
   side_[slot] = shared[dev]->stream[slot];
 }
 
+// The stream the step's tail chain (deferred reductions -> finiteness flags -> Adam of the small groups) runs on beside the scatter's
+// producers: per device like the sampler's two (and the fourth stream of a single-GPU process: HIP's hardware queues are four).
+c10::hip::HIPStreamMasqueradingAsCUDA* Renderer::TailStream() {
+  EnsureSideStream(0);  // (side_shared_)
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!side_shared_->tail)
+    side_shared_->tail = std::make_shared<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+  return side_shared_->tail.get();
+}
+
 // A side stream's buffers may be handed the memory of samples the main stream is still reading: it waits for the last
 // recording of the device's `consumed` event it has not waited for yet.
 void Renderer::SideWaitConsumed(int slot) {

@@ -123,7 +123,19 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
     DigestTap(TAP_PTS_ALL_PRE, fr.pts_all.view(torch::kInt32).sum(1, false, torch::kInt64) * live);
     DigestTap(TAP_VOL_ALL_PRE, fr.vol_all.to(torch::kInt64) * live);
   }
-  if (fr.dyn) {
+  F2nStepTail tail;
+  const bool fused_tail = fr.dyn && step_tail_builder_ && !digest_taps_ && step_tail_builder_(&tail);
+  if (fused_tail) {
+    // the field backward and the REST of the step in one call: the three deferred reductions, the finiteness flags and the small
+    // groups' Adam on the tail stream beside the scatter's producers, the table's Adam inside the scatter's owners
+    field->grad_clean_ = false;
+    F2N_TIMED_CALL("field_bwd", f2n_field_bwd_step_tail(st, TailStream()->stream(), n, n_dev, 2 * n_edge, field->n_volumes_, I32P(field->prim_pool_),
+                           I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),
+                           F32P(field->level_scale_), F32P(fr.pts_all), I32P(fr.vol_all), 1, VoidP(field->mlp_->params_h_),
+                           VoidP(field_x), F32P(dfeat), field->mlp_->loss_scale_, F32P(field->mlp_->grad_scaled_),
+                           VoidP(field->grad_h_), field->pool_size_ / N_LEVELS, &tail, nullptr));
+    step_tail_done_ = true;
+  } else if (fr.dyn) {
     field->grad_clean_ = false;
     F2N_TIMED_CALL("field_bwd", f2n_field_bwd_dyn(st, n, n_dev, 2 * n_edge, field->n_volumes_, I32P(field->prim_pool_),
                            I32P(field->feat_local_idx_), I32P(field->feat_local_size_), F32P(field->bias_pool_),

@@ -5,19 +5,8 @@
 // in ONE streaming pass that also does what the reference spends separate full-table passes on: the fp16->fp32
 // widening and /128 of the hash gradient (Hash3DAnchored.cu:232), the fp32->fp16 refresh of the working table
 // (Hash3DAnchored.cu:186 / TCNNWP.cpp:111) and the re-zeroing of the gradient buffer (Hash3DAnchored.cu:222).
-#include "f2n_dev.h"
+#include "adam_dev.h"
 
-struct F2nAdamCoef {
-  float lr_over_bc1, sqrt_bc2, beta1, beta2, one_m_beta1, one_m_beta2, eps, weight_decay, grad_scale;
-};
-
-__device__ __forceinline__ float f2n_adam_update(float p, float g, float& m, float& v, const F2nAdamCoef& k) {
-  if (k.weight_decay != 0.f) g = g + k.weight_decay * p;
-  m = m * k.beta1 + k.one_m_beta1 * g;
-  v = v * k.beta2 + k.one_m_beta2 * g * g;
-  const float denom = sqrtf(v) / k.sqrt_bc2 + k.eps;
-  return p + (-k.lr_over_bc1) * (m / denom);
-}
 
 // grad_round_h16: reproduce the two binary16 roundings the reference applies to MLP parameter gradients
 // (tcnn writes dL/dparams in param precision while still loss-scaled, Field/TCNNWP.cpp:214-215; autograd then
@@ -327,7 +316,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(F2nAdamGroupsDev gs, in
 // corrections `1 - pow(beta, step)` are double expressions, step_size = lr / bias_correction1 as well; each is narrowed to float only
 // where it meets a float tensor (mul_(beta1), add_(grad, 1 - beta1), addcmul_(..., 1 - beta2), div by sqrt(bias_correction2),
 // addcdiv_(..., -step_size)).
-static F2nAdamCoef f2n_adam_coef(int step, float lr, double beta1, double beta2, float eps, float wd, float grad_scale) {
+F2nAdamCoef f2n_adam_coef(int step, float lr, double beta1, double beta2, float eps, float wd, float grad_scale) {
   const double bc1 = 1.0 - pow(beta1, (double) step);
   const double bc2 = 1.0 - pow(beta2, (double) step);
   F2nAdamCoef k;

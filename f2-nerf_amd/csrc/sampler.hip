@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64) void ray_march_kernel(
 // shade_bwd, field_shade_fwd, compositing) lose most of their resident waves to them.  A batch that is sampled two steps
 // ahead of its use has ~1.5 ms to finish: a few hundred waves do it, one per CU or two.  Same per-ray code, same bits.
 template <bool TAIL>
-__global__ __launch_bounds__(64) void ray_march_persistent_kernel(
+__global__ __launch_bounds__(1024) void ray_march_persistent_kernel(
     int n_rays, float sample_l, int scale_by_dis, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ noise_all, const int32_t* __restrict__ oct_start_end, const int32_t* __restrict__ oct_idx_all,
     const float* __restrict__ near_far_all, const F2nTreeNode* __restrict__ nodes, const F2nTransInfo* __restrict__ transes,
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64) void ray_march_persistent_kernel(
     if ((threadIdx.x & 63) == 0) g = atomicAdd(counter, 1);
     g = __builtin_amdgcn_readfirstlane(g);
     if (g >= n_groups) break;
-    const int slot = g * 4 + (threadIdx.x >> 4);
+    const int slot = g * 4 + ((threadIdx.x & 63) >> 4);  // (every wave of the workgroup on its own)
     if (slot < n_rays) {
       const int ray = order != nullptr ? order[slot] : slot;
       f2n_march_ray<2, TAIL>(ray, 0, sample_l, scale_by_dis, rays_o, rays_d, noise_all, oct_start_end, oct_idx_all, near_far_all, nodes,
@@ -1538,25 +1538,26 @@ int f2n_ray_march_strided_rec(void* stream, int n_rays, int max_hits, float samp
   return f2n_launch_status();
 }
 
-int f2n_ray_march_persistent(void* stream, int n_rays, int max_hits, int n_blocks, float sample_l, int scale_by_dis, const float* rays_o,
+int f2n_ray_march_persistent(void* stream, int n_rays, int max_hits, int n_blocks, int block_waves, float sample_l, int scale_by_dis, const float* rays_o,
                              const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
                              const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
                              float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
                              void* leaf_state, int32_t* reached, int32_t* order, int32_t* counter) {
-  if (n_rays < 0 || n_blocks < 1 || max_hits < 1 || max_hits > 2048 || order == nullptr || counter == nullptr ||
-      (leaf_state == nullptr) != (reached == nullptr))
+  if (n_rays < 0 || n_blocks < 1 || block_waves < 1 || block_waves > 16 || max_hits < 1 || max_hits > 2048 || order == nullptr ||
+      counter == nullptr || (leaf_state == nullptr) != (reached == nullptr))
     return F2N_ERR_INVALID_ARG;
   if (n_rays == 0) return F2N_OK;
   hipLaunchKernelGGL(sort_rays_by_hits_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, n_rays, max_hits, oct_start_end, order,
                      counter);
-  const int blocks = min(n_blocks, f2n_div_up(n_rays, 4));
+  const int waves = min(n_blocks, f2n_div_up(n_rays, 4));
+  const int blocks = f2n_div_up(waves, block_waves), threads = 64 * min(block_waves, waves);
   if (leaf_state != nullptr) {
-    hipLaunchKernelGGL(ray_march_persistent_kernel<true>, dim3(blocks), dim3(64), 0, (hipStream_t) stream, n_rays, sample_l,
+    hipLaunchKernelGGL(ray_march_persistent_kernel<true>, dim3(blocks), dim3(threads), 0, (hipStream_t) stream, n_rays, sample_l,
                        scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx, oct_near_far, (const F2nTreeNode*) tree_nodes,
                        (const F2nTransInfo*) transes, pts_counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans,
                        (uint2*) leaf_state, reached, order, counter);
   } else {
-    hipLaunchKernelGGL(ray_march_persistent_kernel<false>, dim3(blocks), dim3(64), 0, (hipStream_t) stream, n_rays, sample_l,
+    hipLaunchKernelGGL(ray_march_persistent_kernel<false>, dim3(blocks), dim3(threads), 0, (hipStream_t) stream, n_rays, sample_l,
                        scale_by_dis, rays_o, rays_d, noise, oct_start_end, oct_idx, oct_near_far, (const F2nTreeNode*) tree_nodes,
                        (const F2nTransInfo*) transes, pts_counts, s_pts, s_dt, s_t, s_anchors, first_oct_dis, oct_trans, nullptr,
                        nullptr, order, counter);

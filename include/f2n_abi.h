@@ -307,12 +307,14 @@ int f2n_ray_march_strided_rec(void* stream, int n_rays, int max_hits, float samp
                               const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
                               float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
                               void* leaf_state /*[R * max_hits] 8-byte records*/, int32_t* reached /*[R]*/);
-/* f2n_ray_march_strided[_rec] on a small persistent grid: n_blocks one-wave blocks take groups of four rays off counter[0], rays
+/* f2n_ray_march_strided[_rec] on a small persistent grid: n_blocks persistent WAVES (in workgroups of block_waves waves, 1..16:
+ * ABI v13 -- a workgroup's waves land on one CU, so 512 waves in blocks of 8 leave three quarters of the chip's CUs to the
+ * register-hungry kernels of the main queue instead of parking one or two march waves on every CU) take groups of four rays off counter[0], rays
  * ordered by leaf count, longest first (order[R]: scratch, filled here; counter[1]: scratch, zeroed here).  For batches that are
  * sampled well ahead of their use (two-deep pipeline): a few hundred resident waves instead of R / 4, so that the occupancy-bound
  * kernels the march runs underneath keep their wave slots.  leaf_state / reached both NULL: no recording.  Same slots, same
  * bits (tests/test_gpu_scale.py::test_persistent_march). */
-int f2n_ray_march_persistent(void* stream, int n_rays, int max_hits, int n_blocks, float sample_l, int scale_by_dis, const float* rays_o,
+int f2n_ray_march_persistent(void* stream, int n_rays, int max_hits, int n_blocks, int block_waves, float sample_l, int scale_by_dis, const float* rays_o,
                              const float* rays_d, const float* noise, const int32_t* oct_start_end, const int32_t* oct_idx,
                              const float* oct_near_far, const void* tree_nodes, const void* transes, int32_t* pts_counts, float* s_pts,
                              float* s_dt, float* s_t, int32_t* s_anchors, float* first_oct_dis, const int32_t* oct_trans,
@@ -708,6 +710,49 @@ int f2n_adam_small_groups(void* stream, int n_groups, const F2nAdamGroup* groups
 int f2n_adam_fused(void* stream, int n_groups, const F2nAdamGroup* groups, int n_table, float* table_param, void* table_grad_h,
                    float table_grad_scale, float* table_exp_avg, float* table_exp_avg_sq, void* table_param_h, int step, float lr,
                    double beta1, double beta2, float eps, int zero_grad, const int32_t* skip_flag /*device, or NULL*/);
+/* ---------------------------------------------------------------------------------------------------
+ * The TAIL of a training step in one call (ABI v13, round 6) -- f2n_field_bwd_dyn + f2n_reduce_deferred + f2n_nonfinite_flags_ex +
+ * f2n_adam_fused, re-ordered the way their data allows (ExpRunner.cpp:127-137: backward, finiteness check, optimizer->step(),
+ * zero_grad()):
+ *   stream:       field-MLP backward | hash_bin (scatter producers) ............... | owners: slice sums -> THE TABLE'S ADAM on that slice
+ *   tail_stream:                     | reduce_deferred -> flags -> Adam of the small groups |  (joined in front of the owners)
+ * The finiteness flags depend on the two MLPs' parameter gradients only (TCNNWP.cpp:234-240), which are complete once the
+ * field-MLP backward kernel has run -- not on the scatter that follows it; and an owner block of the binned scatter holds the
+ * finished gradient sums of its 4096-entry table slice in LDS, so it steps that slice's parameters itself (fp16->fp32 widening,
+ * /128, Adam, fp32->fp16 refresh, the gradient table left zero: f2n_adam_step_h16grad's arithmetic, element for element)
+ * instead of writing the sums to the gradient table for a 267 MB streaming pass behind the step's last kernel.  Parameters,
+ * moments, working copies, flags and the (zero) gradient buffers end bit-identical to the four separate calls
+ * (tests/test_gpu_parity.py::test_step_tail_equals_separate_launches).
+ * tail_stream NULL: everything on `stream` (same results).  A batch that does not take the binned scatter (f2n_hash_bwd's
+ * small-batch path), a table whose active prefix is not whole 4096-entry slices, or a bucket hook on this gradient table
+ * (f2n_set_scatter_buckets_for: data-parallel runs all-reduce the gradient first) steps the table with the ordinary launch
+ * behind the scatter.  `tail->groups`: HOST array as for f2n_adam_fused; every update is predicated on flags[2]. */
+typedef struct F2nStepTail {
+  int n_flags_a;                 /* f2n_nonfinite_flags_ex: field-MLP gradient ... */
+  const float* flags_grad_a;
+  int n_flags_b;                 /* ... colour-MLP gradient */
+  const float* flags_grad_b;
+  int32_t* flags;                /* device int32[3] */
+  int32_t* flags_mirror;         /* mapped host words, or NULL */
+  int n_groups;                  /* the small fp32 groups (0..4) */
+  const F2nAdamGroup* groups;
+  int n_table;                   /* halves of the table group's active prefix */
+  float* table_param;
+  float* table_exp_avg;
+  float* table_exp_avg_sq;
+  void* table_param_h;
+  float table_grad_scale;
+  int step;
+  float lr;
+  double beta1, beta2;
+  float eps;
+} F2nStepTail;
+int f2n_field_bwd_step_tail(void* stream, void* tail_stream /* or NULL */, int n_max, const int32_t* n_dev, int n_off, int n_volumes,
+                            const int32_t* prim_pool, const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,
+                            const float* level_scale, const float* pts_warped, const int32_t* volume_idx, int vol_stride,
+                            const void* mlp_params_h, const void* saved_x_h, const float* dfeat, float loss_scale,
+                            float* dparams_f32_scaled, void* grad_table_h, int level_entries, const F2nStepTail* tail,
+                            int* table_stepped_by_owners /* out, or NULL: 1 when the owners applied the table's Adam */);
 /* h16 gradient table produced by f2n_hash_bwd / f2n_field_bwd (true gradient = float(grad_h) * grad_scale,
  * grad_scale = 1/128): fuses the fp16->fp32 cast, the /128 (Hash3DAnchored.cu:232), Adam, the fp32->fp16
  * refresh of the table (Hash3DAnchored.cu:186) and the re-zeroing of the gradient (:222) in one pass. */

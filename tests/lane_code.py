@@ -25,8 +25,8 @@ PIECES = [("f2n_dev.h", "struct F2nTransInfo"), ("f2n_dev.h", "f2n_philox4x32"),
           ("f2n_dev.h", "f2n_sum4"), ("f2n_dev.h", "f2n_sum12"), ("f2n_dev.h", "f2n_norm3"), ("f2n_dev.h", "f2n_f2u_sat"),
           ("f2n_dev.h", "f2n_proj"), ("f2n_dev.h", "f2n_warp"), ("f2n_dev.h", "f2n_warp_jac"), ("sampler.hip", "f2n_slab"),
           ("field.hip", "struct F2nCell"), ("field.hip", "f2n_hash_cell"), ("shade.hip", "f2n_sh16"), ("shade.hip", "f2n_sh_high"),
-          ("dataset.hip", "f2n_distort"), ("dataset.hip", "f2n_undistort"), ("optim.hip", "struct F2nAdamCoef"),
-          ("optim.hip", "f2n_adam_update")]
+          ("dataset.hip", "f2n_distort"), ("dataset.hip", "f2n_undistort"), ("adam_dev.h", "struct F2nAdamCoef"),
+          ("adam_dev.h", "f2n_adam_update")]
 
 PRELUDE = r"""
 #include <cmath>

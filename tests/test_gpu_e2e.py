@@ -645,6 +645,47 @@ def test_bucketed_table_exchange_on_one_gpu(rt, fox_state):
         dist.destroy_process_group()
 
 
+def test_fused_step_tail_equals_separate_launches(rt, fox_state):
+    """The step's tail inside the field backward's call (round 6; ExpRunner.fused_tail, f2n_field_bwd_step_tail: deferred reductions,
+    finiteness flags and the small groups' Adam on the tail stream beside the scatter's producers, the table's Adam in the scatter's
+    owner blocks) against the separate launches behind the scatter (reduce -> flags -> f2n_adam_fused): streaming steps at a batch
+    that takes the owner-binned scatter and at one that does not, one of them with a non-finite loss (dropped on the device, taken
+    back by the host one step later) -- every state tensor, the iteration counter and the loss scales end identical."""
+    from f2_nerf_amd import runtime
+    st = fox_state
+    rng = np.random.default_rng(15)
+    big = [runtime.to_dev(*runtime.synthetic_ray_batch(st, 2048, rng)) for _ in range(5)]
+    small = [runtime.to_dev(*runtime.synthetic_ray_batch(st, 128, rng)) for _ in range(3)]
+    bad_gt = big[2][3].clone()
+    bad_gt[5, 1] = float("nan")
+    outs = {}
+    for fused in (True, False):
+        runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=15"], seed=3, table_init=0.3)
+        torch.manual_seed(9)
+        runner.fused_tail = fused
+        losses = []
+        for i in range(4):
+            b, nb = big[i], big[i + 1]
+            s = runner.train_step(b[0], b[1], b[2], bad_gt if i == 2 else b[3], b[4], True, nb[0], nb[1], nb[2])
+            assert s["n_samples"] >= 32768, s["n_samples"]  # (the owner-binned scatter: F2N_BIN_MIN_N)
+            losses.append(float(s["loss"]))
+        for i in range(2):  # small batches: the scatter's atomics, the ordinary table pass behind them
+            b, nb = small[i], small[i + 1]
+            s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+            assert 0 < s["n_samples"] < 32768
+            losses.append(float(s["loss"]))
+        runner.flush()
+        outs[fused] = ([t.clone() for t in runner.states()], runner.iter_step, losses, {k: v.clone() for k, v in runner.grads().items()})
+        del runner
+    assert outs[True][1] == outs[False][1] == 5  # six steps, one taken back
+    a, b = outs[True], outs[False]
+    assert [x for x in a[2] if x == x] == [x for x in b[2] if x == x] and sum(x != x for x in a[2]) == 1
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]) and float(a[3][k].abs().sum()) == 0.0, k  # every gradient buffer consumed and cleared
+
+
 def test_two_rank_bench_when_two_gpus_are_visible():
     """bench.py --gpus 2 through its own torch.distributed.run launch: two ranks over RCCL (the native communicator of
     csrc/host/DataParallel.cpp), replicas bit-identical after 20 pipelined steps.  Needs two devices: on a one-GPU lease

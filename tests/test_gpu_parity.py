@@ -1239,6 +1239,90 @@ def test_adam_fused_equals_separate_launches(hip):
             assert_same(N(tb2["p"]), tab["p"])
 
 
+@pytest.mark.parametrize("n_use,bad,side,dirty", [(40000, False, False, False), (40000, False, True, True), (40000, True, True, False),
+                                                   (33000, False, False, True), (900, False, True, False), (900, True, False, False)])
+def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, bad, side, dirty):
+    """f2n_field_bwd_step_tail (round 6) -- the field backward with the REST of the training step re-ordered around its scatter:
+    deferred reductions, finiteness flags and the small groups' Adam behind the field-MLP backward (on a second stream when one is
+    given), the hash table's Adam applied by the scatter's owner blocks to the slices they have just summed -- leaves every
+    parameter, moment, f16 working copy, flag and (zeroed) gradient buffer bit-identical to f2n_field_bwd_dyn -> f2n_reduce_deferred
+    -> f2n_nonfinite_flags -> f2n_adam_fused.  Large batch (binned scatter: the owners step the table) and small batch (atomics: the
+    ordinary table pass runs behind them), applied and dropped (non-finite MLP gradient) iterations, a gradient table that was
+    not clean on entry (what the full-queue fallback's atomics leave: summed in, then cleared)."""
+    st, g = fox_state, fox_golden
+    rng = np.random.default_rng(64)
+    LOG2 = 14
+    grid = make_grid(st, rng, LOG2, scale=0.5)
+    gd = grid_dev(grid)
+    fparams = rand_params(rng, 1)
+    idx = rng.integers(0, len(g["march_pts"]), n_use)
+    pts, anchors = np.ascontiguousarray(g["march_pts"][idx]), np.ascontiguousarray(g["march_anchors"][idx])
+    n = n_use
+    ph = T(oc.f2h(fparams).view(np.float16))
+    sx = T(oc.f2h((rng.standard_normal((n, 32)) * 0.3).astype(F32)).view(np.float16))
+    dfeat = (rng.standard_normal((n, 16)) * 1e-3).astype(F32)
+    if bad:
+        dfeat[7, 3] = np.inf
+    n_tab = 17 << LOG2
+    n_full = grid.table_f32.size
+    sizes = (3072, 7168, 800)
+    base = [dict(p=rng.standard_normal(k).astype(F32), m=rng.standard_normal(k).astype(F32) * F32(0.1), v=rng.random(k, dtype=F32) * F32(0.01)) for k in sizes]
+    g_pre = [None, (rng.standard_normal(sizes[1]) * 0.1).astype(F32), (rng.standard_normal(sizes[2]) * 0.1).astype(F32)]  # (what shade_bwd left)
+    tab = dict(p=(rng.standard_normal(n_full) * 1e-2).astype(F32), m=(rng.standard_normal(n_full) * 1e-3).astype(F32), v=rng.random(n_full, dtype=F32) * F32(1e-6))
+    g0 = np.zeros(n_full, np.float16)
+    if dirty:
+        where = rng.integers(0, n_tab, 500)
+        g0[where] = (rng.standard_normal(500) * 0.05).astype(np.float16)
+    scales, wds, rounds = (1.0 / 128, 1.0 / 128, 1.0), (1e-6, 1e-6, 1e-6), (True, True, False)
+    tail_stream = torch.cuda.Stream() if side else None
+    out = []
+    for fused in (False, True):
+        grp = [{k: T(v) for k, v in b.items()} for b in base]
+        grads = [torch.zeros(sizes[0], device=DEV), T(g_pre[1]), T(g_pre[2])]
+        hs = [torch.zeros(k, dtype=torch.float16, device=DEV) for k in sizes]
+        tb = {k: T(v) for k, v in tab.items()}
+        th = T(oc.f2h(tab["p"]).view(np.float16))
+        gtab = T(g0.copy())
+        flags = torch.full((4,), -7, dtype=torch.int32, device=DEV)
+        groups = [dict(param=grp[k]["p"], grad=grads[k], exp_avg=grp[k]["m"], exp_avg_sq=grp[k]["v"], param_h=hs[k] if k < 2 else None,
+                       grad_scale=scales[k], weight_decay=wds[k], grad_round_h16=rounds[k]) for k in range(3)]
+        args = (n, None, 0, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts), T(anchors), 3, ph, sx, T(dfeat), 128.0,
+                grads[0], gtab, 1 << LOG2)
+        hip.deferred_reset()
+        by_owners = None
+        if fused:
+            by_owners = hip.field_bwd_step_tail(*args, grads[0], grads[1], flags, groups,
+                                                dict(param=tb["p"], exp_avg=tb["m"], exp_avg_sq=tb["v"], param_h=th, grad_scale=1.0 / 128, n=n_tab),
+                                                7, 3e-3, 0.9, 0.99, 1e-15, tail_stream=tail_stream)
+        else:
+            hip.field_bwd_dyn(*args, 1)
+            hip.reduce_deferred()
+            hip.nonfinite_flags(sizes[0], grads[0], sizes[1], grads[1], flags)
+            hip.adam_fused(groups, dict(param=tb["p"], grad_h=gtab, exp_avg=tb["m"], exp_avg_sq=tb["v"], param_h=th, grad_scale=1.0 / 128, n=n_tab),
+                           7, 3e-3, 0.9, 0.99, 1e-15, True, flags[2:3])
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out.append((grp, grads, hs, tb, th, gtab, flags, by_owners))
+    (ga, gra, ha, ta, tha, gta, fa, _), (gb, grb, hb, tb2, thb, gtb, fb, by_owners) = out
+    assert by_owners == (1 if n_use >= 32768 else 0)
+    assert (N(fa)[:3] == N(fb)[:3]).all() and int(N(fa)[2]) == (1 if bad else 0)
+    for k in range(3):
+        for key in ("p", "m", "v"):
+            assert_same(N(ga[k][key]), N(gb[k][key]), "group %d %s" % (k, key))
+        assert (N(gra[k]) == 0).all() and (N(grb[k]) == 0).all()  # zero_grad, also on the dropped path
+        if k < 2:
+            assert_same(N(ha[k]).view(np.uint16), N(hb[k]).view(np.uint16))
+    for key in ("p", "m", "v"):
+        assert_same(N(ta[key]), N(tb2[key]), "table " + key)
+    assert_same(N(tha).view(np.uint16), N(thb).view(np.uint16), "f16 working table")
+    assert (N(gta).view(np.uint16)[:n_tab] == 0).all() and (N(gtb).view(np.uint16)[:n_tab] == 0).all()
+    if bad:
+        assert_same(N(tb2["p"]), tab["p"])
+    else:
+        assert (N(tb2["p"])[:n_tab] != tab["p"][:n_tab]).mean() > 0.99  # every slice was stepped, also the ones nothing landed in
+        assert_same(N(tb2["p"])[n_tab:], tab["p"][n_tab:], "beyond the active prefix")
+
+
 def test_img2world_rays_and_pixel_gather(hip, fox_state, fox_golden):
     """Dataset.cu:93-123 on the device: bit-exact against the oracle (itself pinned on the reference kernel), for the fox
     cameras, for strongly distorted synthetic cameras, and against the committed golden rays."""

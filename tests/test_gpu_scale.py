@@ -892,10 +892,11 @@ def test_speculative_walk_that_saw_a_later_tree(hip, view, max_hits):
     assert not same_bits(first["cnt"], fresh["cnt"])
 
 
-@pytest.mark.parametrize("n_blocks,record", [(64, True), (512, False)])
-def test_persistent_march(hip, n_blocks, record):
-    """f2n_ray_march_persistent (a few persistent one-wave blocks, rays sorted by leaf count, groups of four off a counter) fills
-    the same slots, counts and -- when recording -- the same resumable states as one block per four rays."""
+@pytest.mark.parametrize("n_blocks,record,block_waves", [(64, True, 1), (512, False, 1), (512, True, 8), (100, False, 16)])
+def test_persistent_march(hip, n_blocks, record, block_waves):
+    """f2n_ray_march_persistent (a few persistent waves -- one per workgroup or, round 6, workgroups of several --, rays sorted by
+    leaf count, groups of four off a counter) fills the same slots, counts and -- when recording -- the same resumable states as
+    one block per four rays."""
     z = dict(np.load(os.path.join(ROOT, "tools", "data", "converged_sampler.npz")))
     n = z["rays_o"].shape[0]
     rd_np = oc.normalize_dirs(z["rays_d"])
@@ -918,7 +919,7 @@ def test_persistent_march(hip, n_blocks, record):
     order = torch.zeros(n, dtype=torch.int32, device=DEV); counter = torch.full((1,), 12345, dtype=torch.int32, device=DEV)
     hip.ray_march_persistent(n, 1024, n_blocks, 1. / 256., True, ro, rd, nz, got["se"], got["oi"], got["nf"], tn, tr, got["cnt"], None,
                              got["s_dt"], got["s_t"], got["s_an"], got["fod"], got["otr"], ls_g if record else None,
-                             re_g if record else None, order, counter)
+                             re_g if record else None, order, counter, block_waves=block_waves)
     a, b = _filled_prefixes(want, n), _filled_prefixes(got, n)
     for k in a:
         assert same_bits(a[k], b[k]), k

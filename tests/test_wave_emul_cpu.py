@@ -154,6 +154,7 @@ _TESTS = {
     "test_nonfinite_flags_and_skipped_adam": None,
     "test_adam_small_groups_equals_separate_launches": None,
     "test_adam_fused_equals_separate_launches": None,
+    "test_step_tail_equals_separate_launches": ("n_use,bad,side,dirty", [(33000, False, False, True), (900, True, False, False)]),
     "test_img2world_rays_and_pixel_gather": None,
     "test_empty_and_ragged_inputs": None,
 }
@@ -167,7 +168,7 @@ _MORE = [
     (gscale, "test_speculative_sampling_repair", None),
     (gscale, "test_speculative_tail_repair", None),
     (gscale, "test_speculative_walk_that_saw_a_later_tree", None),
-    (gscale, "test_persistent_march", None),
+    (gscale, "test_persistent_march", ("n_blocks,record,block_waves", [(64, True, 1), (64, True, 4), (30, False, 16)])),
     (gmlp, "test_general_mlp_forward_and_backward", ("d_in,d_hidden,n_hidden,n", [sh + (31,) for sh in gmlp.SHAPES] + [(17, 64, 2, 4099), (48, 16, 5, 4099)])),
     (gmlp, "test_unsupported_shapes_still_say_so", None),
     # the run-combining / cost-balanced gather (every training iteration from fineness ~4 down takes it)

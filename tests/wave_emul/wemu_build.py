@@ -22,7 +22,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 SOURCES = ["sampler.hip", "render.hip", "dataset.hip", "octree.hip", "optim.hip", "workspace.hip", "field.hip", "shade.hip",
            "mlp_generic.hip"]
-HEADERS = ["f2n_dev.h", "rows_dev.h", "mlp_dev.h"]
+HEADERS = ["f2n_dev.h", "rows_dev.h", "mlp_dev.h", "adam_dev.h"]
 REWRITES = [
     (re.compile(r"extern\s+__shared__\s+([A-Za-z_][A-Za-z_0-9 ]*?)\s+([A-Za-z_][A-Za-z_0-9]*)\s*\[\s*\]\s*;"),
      r"\1* \2 = (\1*) wemu::dyn_lds();"),

@@ -16,6 +16,8 @@ ap.add_argument("--overrides", nargs="*", default=[])
 ap.add_argument("--kernel-timing", action="store_true")
 ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 auto (default: the host's default)")
 ap.add_argument("--march-blocks-sweep", default="", help="v1,v2,...: repeat the timed steps with the speculative march on that many persistent blocks (0: classic)")
+ap.add_argument("--block-waves-sweep", default="", help="v1,v2,...: repeat the timed steps with the persistent march in workgroups of that many waves")
+ap.add_argument("--fused-tail-sweep", action="store_true", help="repeat the timed steps with the step's tail fused into the field backward's call / as separate launches")
 ap.add_argument("--native", action="store_true", help="time ExpRunner::Train's own loop (fresh batches drawn on the device every iteration) instead of python-driven steps on resident batches")
 ap.add_argument("--depth", type=int, default=-1, help="sampling pipeline depth of the timed steps (1 / 2; default: the host's)")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob (knobs exist in the debug variant only: F2N_DEBUG_BUILD=1; most are read once per process)")
@@ -79,6 +81,16 @@ elif args.march_blocks_sweep:
         for v in args.march_blocks_sweep.split(","):
             runner.march_blocks = int(v)
             timed("march_blocks=%s: " % v)
+elif args.block_waves_sweep:
+    for rep in range(2):
+        for v in args.block_waves_sweep.split(","):
+            runner.march_block_waves = int(v)
+            timed("march_block_waves=%s: " % v)
+elif args.fused_tail_sweep:
+    for rep in range(3):
+        for v in (True, False):
+            runner.fused_tail = v
+            timed("fused_tail=%s: " % v)
 elif args.env_sweep:
     name, vals = args.env_sweep.split("=")
     for rep in range(2):
