@@ -831,6 +831,23 @@ struct F2nOwnerAdam {
   const int32_t* skip;  // flags[2] of the step's finiteness check: != 0 -> the iteration is dropped (ExpRunner.cpp:131-134)
 };
 
+// one round of the owner's Adam: eight entries per thread (old gradient pair, master pair, both moments)
+struct F2nOwnerRound {
+  half2_t old[8];
+  float2 p[8], m[8], v[8];
+};
+__device__ __forceinline__ void f2n_owner_fetch(F2nOwnerRound& r, const half2_t* __restrict__ tab, const F2nOwnerAdam& ad, size_t e_base, int e0, bool skip) {
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    r.old[u] = tab[e0 + 256 * u];
+    if (!skip) {
+      r.p[u] = ad.param[e_base + e0 + 256 * u];
+      r.m[u] = ad.exp_avg[e_base + e0 + 256 * u];
+      r.v[u] = ad.exp_avg_sq[e_base + e0 + 256 * u];
+    }
+  }
+}
+
 template <bool ADAM>
 __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
                                                                   half_t* __restrict__ grad_table, int n,
@@ -862,6 +879,10 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   const int total = s_total;
   if (total == 0 && !ADAM) return;  // block-uniform: nothing landed in this slice
   __syncthreads();                  // (everyone has read the total before its word is zeroed with the image)
+  // ADAM: the first round's table / parameter / moment operands travel while the records are read and summed
+  const bool skip = ADAM && ad.skip != nullptr && *ad.skip != 0;
+  F2nOwnerRound ro0;
+  if (ADAM) f2n_owner_fetch(ro0, (const half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES, ad, (size_t) g * F2N_BIN_ENTRIES, tid, skip);
   if (total != 0) {
   for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.0;
   __syncthreads();
@@ -900,20 +921,26 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   __syncthreads();
   }  // total != 0
   half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
-  const bool skip = ADAM && ad.skip != nullptr && *ad.skip != 0;
-  const size_t e_base = (size_t) g * F2N_BIN_ENTRIES;
-  for (int e0 = tid; e0 < F2N_BIN_ENTRIES; e0 += 256 * 8) {  // eight independent table reads in flight per thread
-    half2_t old[8];
-    float2 pp[8], mm[8], vv[8];
+  if (!ADAM) {
+    for (int e0 = tid; e0 < F2N_BIN_ENTRIES; e0 += 256 * 8) {  // eight independent table reads in flight per thread
+      half2_t old[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      old[u] = tab[e0 + 256 * u];
-      if (ADAM && !skip) {
-        pp[u] = ad.param[e_base + e0 + 256 * u];
-        mm[u] = ad.exp_avg[e_base + e0 + 256 * u];
-        vv[u] = ad.exp_avg_sq[e_base + e0 + 256 * u];
+      for (int u = 0; u < 8; u++) old[u] = tab[e0 + 256 * u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + 256 * u;
+        const double a0 = s_acc[2 * e], a1 = s_acc[2 * e + 1];
+        if (a0 != 0.0 || a1 != 0.0)
+          tab[e] = half2_t{(half_t) (float) ((double) (float) old[u][0] + a0), (half_t) (float) ((double) (float) old[u][1] + a1)};
       }
     }
+    return;
+  }
+  // ---- ADAM: the slice's 4096 entries in two rounds of eight per thread; round 0's operands were fetched before the records (ro0 above) ----
+  const size_t e_base = (size_t) g * F2N_BIN_ENTRIES;
+  F2nOwnerRound ro1;
+  f2n_owner_fetch(ro1, tab, ad, e_base, tid + 256 * 8, skip);
+  auto step_round = [&](const F2nOwnerRound& ro, int e0) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int e = e0 + 256 * u;
@@ -922,24 +949,23 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
         a0 = s_acc[2 * e];
         a1 = s_acc[2 * e + 1];
       }
-      half2_t gh = old[u];  // the value the gradient table holds behind the plain owner
-      if (a0 != 0.0 || a1 != 0.0) gh = half2_t{(half_t) (float) ((double) (float) old[u][0] + a0), (half_t) (float) ((double) (float) old[u][1] + a1)};
-      if (!ADAM) {
-        if (a0 != 0.0 || a1 != 0.0) tab[e] = gh;
-      } else {
-        if (__builtin_bit_cast(uint32_t, old[u]) != 0u) tab[e] = half2_t{(half_t) 0.f, (half_t) 0.f};  // zero_grad (fallback atomics may have landed here)
-        if (!skip) {
-          float m0 = mm[u].x, m1 = mm[u].y, v0 = vv[u].x, v1 = vv[u].y;
-          const float p0 = f2n_adam_update(pp[u].x, (float) gh[0] * ad.k.grad_scale, m0, v0, ad.k);
-          const float p1 = f2n_adam_update(pp[u].y, (float) gh[1] * ad.k.grad_scale, m1, v1, ad.k);
-          ad.param[e_base + e] = make_float2(p0, p1);
-          ad.exp_avg[e_base + e] = make_float2(m0, m1);
-          ad.exp_avg_sq[e_base + e] = make_float2(v0, v1);
-          ad.param_h[e_base + e] = half2_t{(half_t) p0, (half_t) p1};
-        }
+      half2_t gh = ro.old[u];  // the value the gradient table holds behind the plain owner
+      if (a0 != 0.0 || a1 != 0.0)
+        gh = half2_t{(half_t) (float) ((double) (float) ro.old[u][0] + a0), (half_t) (float) ((double) (float) ro.old[u][1] + a1)};
+      if (__builtin_bit_cast(uint32_t, ro.old[u]) != 0u) tab[e] = half2_t{(half_t) 0.f, (half_t) 0.f};  // zero_grad (fallback atomics landed here)
+      if (!skip) {
+        float m0 = ro.m[u].x, m1 = ro.m[u].y, v0 = ro.v[u].x, v1 = ro.v[u].y;
+        const float p0 = f2n_adam_update(ro.p[u].x, (float) gh[0] * ad.k.grad_scale, m0, v0, ad.k);
+        const float p1 = f2n_adam_update(ro.p[u].y, (float) gh[1] * ad.k.grad_scale, m1, v1, ad.k);
+        ad.param[e_base + e] = make_float2(p0, p1);
+        ad.exp_avg[e_base + e] = make_float2(m0, m1);
+        ad.exp_avg_sq[e_base + e] = make_float2(v0, v1);
+        ad.param_h[e_base + e] = half2_t{(half_t) p0, (half_t) p1};
       }
     }
-  }
+  };
+  step_round(ro0, tid);
+  step_round(ro1, tid + 256 * 8);
 }
 
 __device__ __forceinline__ void f2n_load_point(const float* __restrict__ pts, int s, bool warped, float* p01) {

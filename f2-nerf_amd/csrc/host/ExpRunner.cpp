@@ -446,12 +446,15 @@ void ExpRunner::EnqueueApply(bool apply_optimizer) {
   if (apply_optimizer && renderer_->step_tail_done_) {
     // the field backward's call has queued all of it (f2n_field_bwd_step_tail): what is left is the host's own bookkeeping
     renderer_->step_tail_done_ = false;
+    flags_on_tail_stream_ = true;
     optim_steps_ += 1;
     field->grad_clean_ = true;
     renderer_->small_grads_clean_ = true;
   } else if (apply_optimizer) {  // the flags are computed by the small-groups launch itself; a no-op on the device when they say so
+    flags_on_tail_stream_ = false;
     OptimStep(nullptr, check_nan_ ? I32P(nan_flags_) : nullptr);
   } else if (check_nan_) {
+    flags_on_tail_stream_ = false;
     F2N_CALL(f2n_nonfinite_flags_ex(CurStream(), field->mlp_->n_params_, F32P(field->mlp_->grad_scaled_), shader->mlp_->n_params_,
                                     F32P(shader->mlp_->grad_scaled_), I32P(nan_flags_), NextFlagMirror()));
   }
@@ -496,7 +499,9 @@ void ExpRunner::FinishPendingStep() { sync_.FinishPendingStep(); }
 void ExpRunner::DeferFlags(bool apply_optimizer) {
   if (flags_deferred_) ResolveDeferredFlags();  // (one set in flight at a time)
   deferred_flag_slot_ = last_flag_slot_;  // (written by the flag kernel EnqueueApply has just queued)
-  nan_flags_ev_.record();
+  // (a fused step tail ran the flag kernel on the tail stream: recorded there, the main queue is spared the packet)
+  if (flags_on_tail_stream_) nan_flags_ev_.record(*renderer_->TailStream());
+  else nan_flags_ev_.record();
   flags_deferred_ = true;
   deferred_apply_ = apply_optimizer;
 }

@@ -99,6 +99,7 @@ class ExpRunner {
   bool fused_tail_ = true;
   bool BuildStepTail(F2nStepTail* tail);
   AdamPlan tail_plan_;
+  bool flags_on_tail_stream_ = false;  // where the last finiteness-flag kernel was queued (DeferFlags records its event there)
   void BuildOptimizer();
   Tensor FlattenSmallGrads();
   int CurBatchSize() const;

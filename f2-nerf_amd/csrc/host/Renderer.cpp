@@ -136,7 +136,7 @@ void Renderer::ResolvePendingCount() {
   count_pending_ = false;
   {
     F2N_HOST_SCOPE("wait.kept");
-    n_kept_ev_.synchronize();  // long since recorded: this is the previous step's count
+    kept_wait_ev_->synchronize();  // long since recorded: this is the previous step's count
   }
   const int n_kept = n_kept_words_.Read(1);
   last_n_kept_pts_ = n_kept;
@@ -321,6 +321,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       } else {
         F2N_CALL(f2n_segment_scan_ex(CurStream(), 0, nullptr, nullptr, I32P(total), n_kept_words_.Dev(1), nullptr, 0));
       }
+      kept_wait_ev_ = &n_kept_ev_;
       n_kept_ev_.record();
       dp_count_ = total;
       dp_count_rays_ = n_rays;
@@ -464,7 +465,9 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     } else {
       F2N_CALL(f2n_segment_scan_ex(st, n_rays, I32P(kept), I32P(new_se), I32P(total), n_kept_words_.Dev(1), nullptr, 0));
     }
-    n_kept_ev_.record();
+    // (octree_first: octree_ready_ev_ was recorded behind the launch that holds the scan -- the count hides behind that recording)
+    kept_wait_ev_ = scan_issued ? &octree_ready_ev_ : &n_kept_ev_;
+    if (!scan_issued) n_kept_ev_.record();
     if (digest_taps_ && train) DigestTap(TAP_SURVIVORS, new_se);
     if (dp_lagged) {  // this step's count: summed over the ranks inside the NEXT step's occupancy exchange (in place)
       dp_count_ = total;
@@ -490,7 +493,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
       fr.dyn = true;
       fr.n_kept_dev = total;
     } else {
-      n_kept_ev_.synchronize();
+      kept_wait_ev_->synchronize();
       n_kept = n_kept_words_.Read(1);
       if (train && after_count_readback_) after_count_readback_();  // everything queued before this point has finished
       last_n_kept_pts_ = n_kept;
@@ -539,13 +542,21 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   fr.side_pool_buffers = pregen;
   fr.emb = train && use_app_emb_ && emb_idx.defined();
   if (!fr.emb) fr.sample_emb_idx = torch::empty({0}, DevI32());  // autograd::Function inputs must be defined tensors
+  const bool streaming_train = train && fr.dyn;  // (TrainForwardBackward follows and records `consumed` behind its last kernel)
+  if (streaming_train && consumed_side_samples_) {
+    fr.presamples_keepalive = std::move(sample_result_);
+    fr.consumed_deferred = true;
+    consumed_side_samples_ = false;
+  }
   sample_result_ = SampleResultFlex();  // drop the pre-early-stop buffers
   if (consumed_side_samples_) {         // (see above: every reader of the side stream's sample buffers has been queued)
     side_shared_->consumed.record();
     consumed_side_samples_ = false;
     side_shared_->seq++;
   }
-  octree_ready_ev_.record();            // everything the NEXT step's ray sampling depends on has been issued
+  // everything the NEXT step's ray sampling depends on has been issued (a streaming step recorded this behind its stat update
+  // already, and nothing since has touched the tree: no second packet)
+  if (!streaming_train) octree_ready_ev_.record();
   return fr;
 }
 

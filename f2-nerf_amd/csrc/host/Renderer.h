@@ -56,6 +56,12 @@ struct RenderFront {
   // pts_all / vol_all / bg_color came out of a side stream's allocator pool (Renderer::PreGenerateStepDraws) and are read by the
   // step's LAST kernels (compositing, the scatter): the device's `consumed` event is recorded once more behind those
   bool side_pool_buffers = false;
+  // Streaming training steps (round 6, one event packet less on the main queue): the pre-early-stop sample buffers -- side-stream
+  // pool memory as well -- stay alive in here until the step's last kernel has been queued, and ONE recording of the `consumed`
+  // event behind that kernel covers them and the buffers above (an event recorded between two kernels of a stream costs the
+  // command processor ~5 us: profiles/r06_event_cost.txt).
+  SampleResultFlex presamples_keepalive;
+  bool consumed_deferred = false;
 };
 
 struct TrainOutputs {
@@ -268,6 +274,9 @@ class Renderer : public Pipe {
   Tensor presample_rays_o_, presample_rays_d_;  // the rays the presample belongs to (held: see PresampleMatches)
   bool PresampleMatches(const Tensor& rays_o, const Tensor& rays_d) const;
   at::cuda::CUDAEvent octree_ready_ev_, presample_done_ev_[kPendingSlots], n_kept_ev_;
+  // which event the pending survivor count hides behind: n_kept_ev_, or -- streaming steps, whose survivor scan rides in the stat
+  // update's launch -- the octree event recorded behind that very launch (one packet instead of two)
+  at::cuda::CUDAEvent* kept_wait_ev_ = &n_kept_ev_;
   // The two side streams -- and so their allocator pools -- are per DEVICE (EnsureSideStream), and so is the protocol that stands in
   // for record_stream on the sample buffers that cross from a side stream's pool to the main stream: `consumed` is recorded on the
   // main stream once the last reader of such buffers has been queued and awaited by a side stream before its next kernels, once

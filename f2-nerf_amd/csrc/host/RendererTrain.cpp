@@ -163,7 +163,7 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
     DigestTap(TAP_TABLE_GRAD, field->grad_h_);
     DigestTap(TAP_SMALL_GRADS, small_grads_flat_);
   }
-  if (fr.side_pool_buffers && side_shared_) {  // (see RenderFront: their last readers have been queued only now)
+  if ((fr.side_pool_buffers || fr.consumed_deferred) && side_shared_) {  // (see RenderFront: their last readers have been queued only now)
     side_shared_->consumed.record();
     side_shared_->seq++;
   }
