@@ -345,7 +345,16 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   renderer_->async_count_ = (prefetch && async_counts_ == 1) || async_counts_ == 2;
   renderer_->step_tail_done_ = false;
   renderer_->step_tail_builder_ = nullptr;
-  if (apply_optimizer && fused_tail_) renderer_->step_tail_builder_ = [this](F2nStepTail* t) { return BuildStepTail(t); };
+  renderer_->before_backward_ = nullptr;
+  const bool tail_ok = apply_optimizer && fused_tail_ && check_nan_ && !sync_.Installed();
+  if (tail_ok) renderer_->step_tail_builder_ = [this](F2nStepTail* t) { return BuildStepTail(t); };
+  // A streaming step learns the PREVIOUS step's finiteness flags late.  With the fused tail those flags are computed half a step
+  // before that step ends, so they are read here -- in front of this step's backward -- at no cost, and a dropped step's halved
+  // loss scales / taken-back counters hold for this step's backward AND its optimiser call, as in the reference's order
+  // (ExpRunner.cpp:131-137).  Without it (data-parallel steps, fused_tail off) they are read behind the backward -- the loss scale the
+  // backward used and the one the optimiser divides by then differ for the one step behind a dropped one -- unless
+  // exact_flag_order_ asks for the wait (a host stall per step: tests compare the two tails with it).
+  if (check_nan_ && (tail_ok || exact_flag_order_)) renderer_->before_backward_ = [this]() { ResolveDeferredFlags(); };
   TrainOutputs out;
   {
     F2N_HOST_SCOPE("step.fwd_bwd");
@@ -355,6 +364,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   renderer_->async_count_ = false;
   renderer_->after_octree_update_ = nullptr;
   renderer_->step_tail_builder_ = nullptr;
+  renderer_->before_backward_ = nullptr;
   if (prefetch && out.has_samples) renderer_->SpecBeginAtStepEnd();  // (small trees: the batch after next, see Renderer.h)
   renderer_->next_batch_ = renderer_->next2_batch_ = Renderer::NextBatch();
   ResolveDeferredFlags();  // (a batch without samples never reaches the read-back)

@@ -97,6 +97,7 @@ class ExpRunner {
   // gradients, the diagnostics taps and check_nan == false keep the separate launches.  Same parameters, bit for bit
   // (tests/test_gpu_e2e.py::test_fused_step_tail_equals_separate_launches).
   bool fused_tail_ = true;
+  bool exact_flag_order_ = false;  // read the previous step's flags in front of this step's backward also without the fused tail (see TrainStep)
   bool BuildStepTail(F2nStepTail* tail);
   AdamPlan tail_plan_;
   bool flags_on_tail_stream_ = false;  // where the last finiteness-flag kernel was queued (DeferFlags records its event there)

@@ -83,6 +83,7 @@ TrainOutputs Renderer::TrainForwardBackward(const Tensor& rays_o, const Tensor& 
     F2N_TIMED_CALL("shade_fwd", f2n_shade_fwd(st, n_kept, F32P(feat), F32P(es.dirs), fr.emb ? F32P(app) : nullptr,
                            fr.emb ? I32P(fr.sample_emb_idx) : nullptr, VoidP(shader->mlp_->params_h_), F32P(rgb), VoidP(shade_x)));
   }
+  if (before_backward_) before_backward_();
   Tensor colors = torch::empty({n_rays, 3}, DevF32());
   Tensor weights = torch::empty({std::max(n_kept, 1)}, DevF32());
   Tensor bg = fr.bg_color.contiguous();

@@ -358,7 +358,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_property("tail_repair",  // speculative batches repaired by list compaction + a march of the tail behind the first dead leaf (A/B knob)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_ = on; })
-      .def_readwrite("fused_tail", &ExpRunner::fused_tail_)  // the step's tail inside the field backward's call (A/B: False = separate launches)
+      .def_readwrite("fused_tail", &ExpRunner::fused_tail_)
+      .def_readwrite("exact_flag_order", &ExpRunner::exact_flag_order_)  // the step's tail inside the field backward's call (A/B: False = separate launches)
       .def_property("march_block_waves",  // workgroup size of the persistent march, in waves (1..16)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_block_waves_; },
                     [](ExpRunner& r, int n) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_block_waves_ = std::min(16, std::max(1, n)); })

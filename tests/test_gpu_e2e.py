@@ -663,27 +663,37 @@ def test_fused_step_tail_equals_separate_launches(rt, fox_state):
         runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=15"], seed=3, table_init=0.3)
         torch.manual_seed(9)
         runner.fused_tail = fused
+        runner.exact_flag_order = True  # (the fused tail reads the previous step's flags in front of the backward: ask the other for the same)
         losses = []
         for i in range(4):
             b, nb = big[i], big[i + 1]
             s = runner.train_step(b[0], b[1], b[2], bad_gt if i == 2 else b[3], b[4], True, nb[0], nb[1], nb[2])
             assert s["n_samples"] >= 32768, s["n_samples"]  # (the owner-binned scatter: F2N_BIN_MIN_N)
             losses.append(float(s["loss"]))
+        runner.flush()
+        mid = ([t.clone() for t in runner.states()], runner.iter_step)
         for i in range(2):  # small batches: the scatter's atomics, the ordinary table pass behind them
             b, nb = small[i], small[i + 1]
             s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
             assert 0 < s["n_samples"] < 32768
             losses.append(float(s["loss"]))
         runner.flush()
-        outs[fused] = ([t.clone() for t in runner.states()], runner.iter_step, losses, {k: v.clone() for k, v in runner.grads().items()})
+        outs[fused] = (mid, [t.clone() for t in runner.states()], runner.iter_step, losses, {k: v.clone() for k, v in runner.grads().items()})
         del runner
-    assert outs[True][1] == outs[False][1] == 5  # six steps, one taken back
     a, b = outs[True], outs[False]
-    assert [x for x in a[2] if x == x] == [x for x in b[2] if x == x] and sum(x != x for x in a[2]) == 1
-    for x, y in zip(a[0], b[0]):
+    assert a[0][1] == b[0][1] == 3 and a[2] == b[2] == 5  # four steps, one taken back; two more
+    assert [x for x in a[3][:4] if x == x] == [x for x in b[3][:4] if x == x] and sum(x != x for x in a[3]) == 1
+    for x, y in zip(a[0][0], b[0][0]):  # behind the owner-binned steps: identical
         assert torch.equal(x, y)
-    for k in a[3]:
-        assert torch.equal(a[3][k], b[3][k]) and float(a[3][k].abs().sum()) == 0.0, k  # every gradient buffer consumed and cleared
+    # behind the small batches: their scatter adds f16 atomics in arrival order, two runs of ONE program differ in low-order bits
+    for x, y in zip(a[1], b[1]):
+        if x.dtype.is_floating_point:
+            assert float((x.double() - y.double()).abs().max()) <= 1e-4
+        else:
+            assert torch.equal(x, y)
+    assert max(abs(u - v) for u, v in zip(a[3][4:], b[3][4:])) <= 1e-5
+    for k in a[4]:
+        assert float(a[4][k].abs().sum()) == 0.0 and float(b[4][k].abs().sum()) == 0.0, k  # every gradient buffer consumed and cleared
 
 
 def test_two_rank_bench_when_two_gpus_are_visible():
