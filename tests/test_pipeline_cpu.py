@@ -329,6 +329,33 @@ def test_bench_reads_the_node_layout_of_the_checkpoint():
         assert bench.NODE_DT.fields[f][0].itemsize == octc.NODE_DT.fields[f][0].itemsize, f
 
 
+def test_bench_reads_the_0p1_db_question_off_the_pooled_interval(tmp_path):
+    """bench.py folds its own invocation's PSNR A/B into the pooled estimate over every committed session (profiles/psnr_estimates.json)
+    and answers "within 0.1 dB" from the pooled 95 % interval with the UNPAIRED standard errors: true only when the whole interval lies
+    inside +-0.1 dB, false only when it lies outside, "inconclusive" otherwise (round-5 verdict, weak 1 / next 4b)."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    committed = bench.pool_psnr_estimates(None, None, None, 0, 0)
+    assert len(committed["estimates"]) >= 4 and committed["pooled_unpaired"]["standard_error_db"] < 0.06
+    lo, hi = committed["pooled_unpaired"]["interval_95_db"]
+    assert committed["within_0p1_db"] == (True if (lo >= -0.1 and hi <= 0.1) else False if (lo > 0.1 or hi < -0.1) else "inconclusive")
+    f = tmp_path / "est.json"
+    f.write_text(json.dumps({"estimates": [{"session": "a", "delta_db": 0.01, "standard_error_unpaired_db": 0.02, "standard_error_paired_db": 0.01}]}))
+    r = bench.pool_psnr_estimates(0.03, 0.04, {"standard_error_db": 0.01, "mean_db": 0.02}, 4, 3, path=str(f))
+    assert r["within_0p1_db"] is True and len(r["estimates"]) == 2 and r["pooled_unpaired"]["standard_error_db"] < 0.02
+    assert abs(r["pooled_unpaired"]["delta_db"] - (0.01 / 0.02 ** 2 + 0.03 / 0.04 ** 2) / (1 / 0.02 ** 2 + 1 / 0.04 ** 2)) < 1e-3
+    assert bench.pool_psnr_estimates(0.5, 0.04, None, 4, 3, path=str(tmp_path / "none.json"))["within_0p1_db"] is False
+    assert bench.pool_psnr_estimates(0.05, 0.1, None, 4, 3, path=str(tmp_path / "none.json"))["within_0p1_db"] == "inconclusive"
+    # an invocation whose paired error is tiny does not talk the pooled figure into a verdict: the unpaired error is what is weighted
+    r = bench.pool_psnr_estimates(0.02, 0.15, {"standard_error_db": 0.005, "mean_db": 0.02}, 4, 3, path=str(tmp_path / "none.json"))
+    assert r["within_0p1_db"] == "inconclusive" and r["pooled_paired_for_comparison"]["standard_error_db"] < 0.01
+
+
 def test_philox_reference_matches_the_published_known_answers():
     """tests/philox_ref.py (the checker of the kernels' keyed draws: tests/test_gpu_determinism.py) against the known-answer vectors of
     Random123's Philox4x32-10 (kat_vectors: zero, all-ones and the pi-digit counter / key)."""
