@@ -522,6 +522,9 @@ def main():
         host.ExpRunner.enable_kernel_timing([DOMINANT, "field_mlp_prepass", "field_fwd_cached", "field_fwd", "field_bwd",
                                              "shade_fwd", "shade_bwd"])
     c0 = runner.counters()  # (flushes)
+    if dp:  # per-rank diagnostics of the gradient exchange (DataParallel::EnableTiming): what it took, what of it was exposed
+        runner.dp_enable_timing(True)
+        runner.dp_collect_timing()
     barrier()
     if args.marker_pause:
         time.sleep(0.3)
@@ -534,6 +537,18 @@ def main():
     c1 = runner.counters()
     n_marched = c1["total_marched"] - c0["total_marched"]
     n_meaningful = c1["total_meaningful"] - c0["total_meaningful"]
+    dp_diag = None
+    if dp:
+        n_ex, ex_ms, n_wt, wt_ms = runner.dp_collect_timing()
+        runner.dp_enable_timing(False)
+        mine = torch.tensor([ex_ms / max(n_ex, 1), wt_ms / max(n_wt, 1), n_ex], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        dp_diag = {"dp_exchange_ms": [round(float(t[0]), 4) for t in allt], "dp_wait_ms": [round(float(t[1]), 4) for t in allt],
+                   "exchanges_timed": [int(t[2]) for t in allt],
+                   "note": "per rank, per step: dp_exchange_ms = first table bucket started -> flat small-gradient buffer reduced, on the "
+                           "communicator's stream (its waits for the scatter's later buckets included); dp_wait_ms = what the compute stream "
+                           "waited for that exchange at the top of the next step (the part of it the step did not hide)"}
     timing = host.ExpRunner.collect_kernel_timing() if rank == 0 else {}
     host.ExpRunner.disable_kernel_timing()
 
@@ -679,6 +694,7 @@ def main():
                        "meaningful_samples_per_step": n_meaningful / args.steps},
             "training_representative": training_representative,
             "steady_state": steady, "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged, "replicas": replicas,
+            "data_parallel": dp_diag,
             "other_configs": others,
             # buffers are sized for the worst case on purpose (1024 sample slots per ray, scatter queues): what that costs of 288 GB
             "peak_hbm_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

@@ -67,6 +67,11 @@ void DataParallel::SendBucket(int b) {
   auto& ev = bucket_ev_[b];
   ev.record();  // the kernels that complete this range have been queued on the compute stream
   ev.block(*comm_stream_);
+  if (timing_ && !span_open_ && exchange_spans_.size() < 65536) {  // the step's exchange starts on the communicator's stream here
+    exchange_spans_.push_back(std::make_unique<TimedSpan>());
+    exchange_spans_.back()->a.record(*comm_stream_);
+    span_open_ = true;
+  }
   const auto r = BucketRange(b);
   at::Half* base = table_prefix_.data_ptr<at::Half>() + r.first;
   F2N_NCCL(ncclAllReduce(base, base, (size_t) r.second, ncclHalf, ncclAvg, comm, comm_stream_->stream()));
@@ -159,10 +164,52 @@ void DataParallel::GradSyncBegin() {
   grads_ready_ev_.block(*comm_stream_);
   F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, comm_stream_->stream()));
   reduced_ev_.record(*comm_stream_);
+  if (span_open_) {
+    exchange_spans_.back()->b.record(*comm_stream_);
+    exchange_spans_.back()->closed = true;
+    span_open_ = false;
+  }
 }
 
 void DataParallel::GradSyncEnd() {
-  reduced_ev_.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());  // the compute stream waits; the host does not
+  auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
+  if (timing_ && wait_spans_.size() < 65536) {  // what the compute stream waits here is what the step could not hide
+    wait_spans_.push_back(std::make_unique<TimedSpan>());
+    wait_spans_.back()->a.record(cur);
+    reduced_ev_.block(cur);
+    wait_spans_.back()->b.record(cur);
+    return;
+  }
+  reduced_ev_.block(cur);  // the compute stream waits; the host does not
+}
+
+void DataParallel::EnableTiming(bool on) {
+  timing_ = on;
+  if (!on) {
+    exchange_spans_.clear();
+    wait_spans_.clear();
+    span_open_ = false;
+  }
+}
+
+std::vector<double> DataParallel::CollectTiming() {
+  double ex = 0, wt = 0;
+  size_t n = 0;
+  for (auto& s : exchange_spans_) {
+    if (!s->closed) continue;  // (an exchange that has begun and not ended: the pending step)
+    s->b.synchronize();
+    ex += s->a.elapsed_time(s->b);
+    n++;
+  }
+  for (auto& s : wait_spans_) {
+    s->b.synchronize();
+    wt += s->a.elapsed_time(s->b);
+  }
+  const double n_wait = (double) wait_spans_.size();
+  exchange_spans_.clear();
+  wait_spans_.clear();
+  span_open_ = false;
+  return {(double) n, ex, n_wait, wt};
 }
 
 void DataParallel::OccupancySync(Tensor occ) {

@@ -38,6 +38,13 @@ class DataParallel {
   // table all-reduce buckets of the NEXT Attach (default kTableBuckets; 1 = the whole prefix in one all-reduce: A/B, bench.py --dp-buckets)
   static int table_buckets;
   int CommRanks() const;
+  // Diagnostics of the first measured multi-GPU run (round-5 verdict, next 6): with timing on, every step's gradient exchange is
+  // bracketed by two timing events on the communicator's stream (first table bucket started -> flat buffer reduced: what the
+  // exchange took, its waits for the scatter's later buckets included) and the compute stream's wait for it at the top of the next
+  // step by two on the compute stream (what of it was NOT hidden).  CollectTiming synchronises and returns
+  // {steps, exchange ms total, exposed wait ms total} since the last call.  ~4 event packets per step: off by default.
+  void EnableTiming(bool on);
+  std::vector<double> CollectTiming();
   int64_t BucketCallbacks() const { return n_bucket_callbacks_; }  // table ranges the scatter reported while it ran            // what RCCL itself reports for the communicator (ncclCommCount)
 
  private:
@@ -60,6 +67,12 @@ class DataParallel {
   std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> comm_stream_;
   at::cuda::CUDAEvent grads_ready_ev_, reduced_ev_;
   std::vector<at::cuda::CUDAEvent> bucket_ev_;
+  bool timing_ = false, span_open_ = false;
+  struct TimedSpan {
+    at::cuda::CUDAEvent a{0u}, b{0u};  // (flags 0 = hipEventDefault: timing enabled)
+    bool closed = false;
+  };
+  std::vector<std::unique_ptr<TimedSpan>> exchange_spans_, wait_spans_;
 };
 
 }  // namespace f2n

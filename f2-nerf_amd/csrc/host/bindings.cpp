@@ -259,6 +259,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("overlap") = true, py::arg("hooks_for_one_rank") = false)
       .def("dp_bucket_callbacks",  // table-gradient ranges the scatter reported while it ran (bucketed exchange, DataParallel.h)
            [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->BucketCallbacks() : (int64_t) 0; })
+      .def("dp_enable_timing",  // bracket every gradient exchange / every wait for it with timing events (DataParallel::EnableTiming)
+           [](ExpRunner& r, bool on) { if (r.data_parallel_) std::static_pointer_cast<DataParallel>(r.data_parallel_)->EnableTiming(on); })
+      .def("dp_collect_timing",  // [exchanges, exchange ms total, waits, exposed wait ms total] since the last call (synchronises)
+           [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->CollectTiming() : std::vector<double>{0, 0, 0, 0}; })
       .def("dp_comm_ranks",  // ranks of the native RCCL communicator as RCCL reports them (0: none attached)
            [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->CommRanks() : 0; })
       .def("set_occupancy_sync_hook",  // all-reduce(MAX) of the per-node votes so that every replica prunes identically

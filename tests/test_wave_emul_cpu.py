@@ -921,6 +921,10 @@ def test_bench_with_two_ranks_on_the_emulator(emul_host):
     rep = line["replicas"]
     assert rep["identical"] is True and rep["rccl_comm_ranks"] == 2 and rep["torch_distributed_world"] == 2 and len(rep["checksums_table_fieldmlp_colormlp_nodes_nnodes"]) == 2
     assert line["value"] > 0 and line["cpu_baseline"] is None and line["converged"] is None and line["other_configs"] is None
+    # the per-rank diagnostics of the exchange (round-5 verdict, next 6): both fields, one entry per rank, every timed step's exchange
+    diag = line["data_parallel"]
+    assert len(diag["dp_exchange_ms"]) == 2 and len(diag["dp_wait_ms"]) == 2 and all(v > 0 for v in diag["dp_exchange_ms"])
+    assert all(n >= 3 for n in diag["exchanges_timed"])
     # whole-job aggregate: the samples of BOTH ranks over the slower rank's time
     assert abs(line["value"] - line["config"]["meaningful_samples_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
     assert line["config"]["rays_per_s"] > 0 and abs(line["config"]["rays_per_s"] - 48 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["config"]["rays_per_s"]
