@@ -49,7 +49,7 @@ ALGO_BYTES = {"hash_gather": 512 + 12 + 4 + 64}
 # HBM-side bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate counter passes,
 # profiles/run_profiles.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), recorded per round in
 # profiles/<tag>_traffic.json; null when that file is absent.
-TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r05_traffic.json"), os.path.join(ROOT, "profiles", "r04_traffic.json"), os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json"),
+TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r06_traffic.json"), os.path.join(ROOT, "profiles", "r05_traffic.json"), os.path.join(ROOT, "profiles", "r04_traffic.json"), os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json"),
                                  os.path.join(ROOT, "profiles", "r01_traffic.json")) if os.path.exists(p)), "")
 HBM_PEAK_GBS = 8000.0
 # What actually bounds that kernel: 128 independent 4-byte reads per sample from an L2-resident table slice.  The chip
@@ -606,7 +606,7 @@ def main():
             tfile = TRAFFIC_FILE
             if args.preset == "wanjinyou_big":  # (2^21 and up: the slice-binned gather of round 4, four kernels behind one call)
                 # (the newest counter pass of this table size: round 5 re-took 2^20 after the binned gather was extended to it)
-                tfile = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_big%d_traffic.json" % (r, log2)) for r in (5, 4, 3)) if os.path.exists(f)), "")
+                tfile = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_big%d_traffic.json" % (r, log2)) for r in (6, 5, 4, 3)) if os.path.exists(f)), "")
             elif args.preset != "wanjinyou" or args.log2 not in (0, 19) or args.rays != 8192:
                 tfile = ""  # (no counters were collected for this workload)
             traffic_source = None

@@ -700,20 +700,26 @@ void ExpRunner::SaveCheckpoint(const std::string& dir) {
   std::vector<Tensor> states = States();
   for (auto& t : states) t = t.detach().contiguous();
   torch::save(states, dir + "/renderer.pt");
-  Tensor scalars = torch::empty({1}, CpuF32());
+  // [0] = iter_step, all the reference reads (ExpRunner.cpp:196-199: scalars[0]); [1] = the step sequence number the keyed draws
+  // continue from -- it counts the steps that were dropped for non-finite gradients as well, so it can be ahead of [0] (round-5 advisor)
+  Tensor scalars = torch::empty({2}, CpuF32());
   scalars.index_put_({0}, float(iter_step_));
+  scalars.index_put_({1}, float(step_seq_));
   torch::save(scalars, dir + "/scalars.pt");
 }
 
 void ExpRunner::LoadCheckpoint(const std::string& dir) {
   FinishPending();
+  int64_t resume_seq = 0;
   {
     Tensor scalars;
     torch::load(scalars, dir + "/scalars.pt");
     iter_step_ = (int) std::round(scalars[0].item<float>());
     UpdateAdaParams();
+    // (a checkpoint of the reference, or of an earlier round, holds the iteration only: the sequence restarts there)
+    resume_seq = scalars.numel() >= 2 ? (int64_t) std::llround(scalars[1].item<float>()) : (int64_t) iter_step_;
   }
-  ResetStepSequence(iter_step_);
+  ResetStepSequence(std::max<int64_t>(resume_seq, iter_step_));
   std::vector<Tensor> states;
   torch::load(states, dir + "/renderer.pt");
   LoadStates(states);

@@ -110,8 +110,10 @@ c10::hip::HIPStreamMasqueradingAsCUDA* Renderer::TailStream() {
   EnsureSideStream(0);  // (side_shared_)
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
+  // (high priority: its three small kernels run beside the scatter's 1024 producer blocks and must not queue behind them -- the
+  // owners wait for the flags; measured at default priority: the 9 us reduction took 67 us, profiles/r06_converged_timeline.txt)
   if (!side_shared_->tail)
-    side_shared_->tail = std::make_shared<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
+    side_shared_->tail = std::make_shared<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA(/*isHighPriority=*/true));
   return side_shared_->tail.get();
 }
 

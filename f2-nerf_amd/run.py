@@ -116,7 +116,10 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        import datetime
+        # (the ranks' last rendezvous waits for rank 0's test / path renders: minutes at full resolution -- the default watchdog of ten
+        # minutes would abort a healthy job; round-5 advisor)
+        dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(hours=6))
     torch.cuda.set_device(dev)
     torch.manual_seed(2022)  # main.cpp:9 (the same on every rank: the replicas' octree and parameters come from it)
     sc, ds = load_dataset(cfg, data_path)
@@ -154,51 +157,56 @@ def main(argv=None):
         print("Mean psnr: %s" % views[-1])
         return out
 
-    if rank != 0 and mode != "train":
-        pass  # (the rendering modes are one rank's work; the others wait at the barrier below)
-    elif mode == "train":
-        t = cfg["train"]
-        end, save_freq, report = int(t["end_iter"]), int(t["save_freq"]), int(t["report_freq"])
-        t0 = time.time()
-        psnr_smooth = -1.0
-        while runner.iter_step < end:
-            # the native loop runs up to the next report / checkpoint boundary (ExpRunner.cpp:157-172); the reference smooths
-            # the PSNR over every iteration (one host read-back each: :120-122) -- here the loss stays on the device inside
-            # the loop, so the same 0.9 / 0.1 smoothing is applied over the report boundaries' batches instead
-            nxt = min(end, (runner.iter_step // report + 1) * report, (runner.iter_step // save_freq + 1) * save_freq)
-            s = runner.train(ds, nxt, 1)
-            if rank == 0 and (runner.iter_step % report == 0 or runner.iter_step >= end):
-                torch.cuda.synchronize()
-                mse = max(float(s["mse"]), 1e-12)
-                psnr = 20 * np.log10(1 / np.sqrt(mse))
-                psnr_smooth = psnr if psnr_smooth < 0 else psnr * .1 + psnr_smooth * .9
-                # (labelled differently from the reference's per-iteration EMA, with which it is not comparable line by line)
-                print("Iter: %6d PSNR(report-batch EMA): %.2f NRays: %5d OctSamples: %.1f Samples: %.1f MeaningfulSamples: %.1f IPS: %.1f LR: %.4f" % (
-                    runner.iter_step, psnr_smooth, s["n_rays"], runner.oct_per_ray, runner.sampled_per_ray,
-                    runner.meaningful_per_ray, runner.iter_step / max(time.time() - t0, 1e-9), runner.cur_lr), flush=True)
-            if runner.iter_step % save_freq == 0:
-                save_checkpoint()
-        if rank == 0:
-            with open(os.path.join(exp_dir, "train_info.txt"), "w") as f:
-                f.write("%f\n" % (time.time() - t0))
-            print("Train done, test.")
-        test_images()
-    elif mode == "test":
-        test_images()
-    elif mode == "render_path":
-        if "render_poses" not in sc:
-            raise FileNotFoundError("poses_render.npy not found under " + data_path)
-        runner.render_path(ds, torch.from_numpy(sc["render_poses"]),
-                           lambda i, img: save_png(os.path.join(exp_dir, "novel_images", "%d_%03d.png" % (runner.iter_step, i)), img), 1)
-    elif mode == "render_all":  # ExpRunner::RenderAllImages (ExpRunner.cpp:295-299): every image of the data set, as VisualizeImage writes it
-        for idx in range(int(ds.n_images)):
-            save_png(os.path.join(exp_dir, "images", "%d_%d.png" % (runner.iter_step, idx)), runner.visualize_image(ds, idx))
-    else:
-        raise ValueError("unknown mode: %s" % mode)
-    if world > 1:
-        runner.flush()
-        dist.barrier()  # (rank 0 may still be rendering its test images)
-        dist.destroy_process_group()
+    try:
+        if rank != 0 and mode != "train":
+            pass  # (the rendering modes are one rank's work; the others wait at the barrier below)
+        elif mode == "train":
+            t = cfg["train"]
+            end, save_freq, report = int(t["end_iter"]), int(t["save_freq"]), int(t["report_freq"])
+            t0 = time.time()
+            psnr_smooth = -1.0
+            while runner.iter_step < end:
+                # the native loop runs up to the next report / checkpoint boundary (ExpRunner.cpp:157-172); the reference smooths
+                # the PSNR over every iteration (one host read-back each: :120-122) -- here the loss stays on the device inside
+                # the loop, so the same 0.9 / 0.1 smoothing is applied over the report boundaries' batches instead
+                nxt = min(end, (runner.iter_step // report + 1) * report, (runner.iter_step // save_freq + 1) * save_freq)
+                s = runner.train(ds, nxt, 1)
+                if rank == 0 and (runner.iter_step % report == 0 or runner.iter_step >= end):
+                    torch.cuda.synchronize()
+                    mse = max(float(s["mse"]), 1e-12)
+                    psnr = 20 * np.log10(1 / np.sqrt(mse))
+                    psnr_smooth = psnr if psnr_smooth < 0 else psnr * .1 + psnr_smooth * .9
+                    # (labelled differently from the reference's per-iteration EMA, with which it is not comparable line by line)
+                    print("Iter: %6d PSNR(report-batch EMA): %.2f NRays: %5d OctSamples: %.1f Samples: %.1f MeaningfulSamples: %.1f IPS: %.1f LR: %.4f" % (
+                        runner.iter_step, psnr_smooth, s["n_rays"], runner.oct_per_ray, runner.sampled_per_ray,
+                        runner.meaningful_per_ray, runner.iter_step / max(time.time() - t0, 1e-9), runner.cur_lr), flush=True)
+                if runner.iter_step % save_freq == 0:
+                    save_checkpoint()
+            if rank == 0:
+                with open(os.path.join(exp_dir, "train_info.txt"), "w") as f:
+                    f.write("%f\n" % (time.time() - t0))
+                print("Train done, test.")
+            test_images()
+        elif mode == "test":
+            test_images()
+        elif mode == "render_path":
+            if "render_poses" not in sc:
+                raise FileNotFoundError("poses_render.npy not found under " + data_path)
+            runner.render_path(ds, torch.from_numpy(sc["render_poses"]),
+                               lambda i, img: save_png(os.path.join(exp_dir, "novel_images", "%d_%03d.png" % (runner.iter_step, i)), img), 1)
+        elif mode == "render_all":  # ExpRunner::RenderAllImages (ExpRunner.cpp:295-299): every image of the data set, as VisualizeImage writes it
+            for idx in range(int(ds.n_images)):
+                save_png(os.path.join(exp_dir, "images", "%d_%d.png" % (runner.iter_step, idx)), runner.visualize_image(ds, idx))
+        else:
+            raise ValueError("unknown mode: %s" % mode)
+    finally:
+        # every rank reaches the rendezvous, also when its own work threw: the others are waiting there (rank 0 renders alone)
+        if world > 1:
+            try:
+                runner.flush()
+            finally:
+                dist.barrier()
+                dist.destroy_process_group()
     return 0
 
 
