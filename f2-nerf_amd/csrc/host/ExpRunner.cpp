@@ -253,7 +253,7 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
 bool ExpRunner::BuildStepTail(F2nStepTail* t) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
-  if (!fused_tail_ || !check_nan_ || sync_.Installed()) return false;
+  if (fused_tail_ == 0 || !check_nan_ || sync_.Installed()) return false;
   if (!nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
   BuildAdamPlan(tail_plan_);
   if (tail_plan_.n_table <= 0) return false;
@@ -346,7 +346,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   renderer_->step_tail_done_ = false;
   renderer_->step_tail_builder_ = nullptr;
   renderer_->before_backward_ = nullptr;
-  const bool tail_ok = apply_optimizer && fused_tail_ && check_nan_ && !sync_.Installed();
+  const bool tail_ok = apply_optimizer && check_nan_ && !sync_.Installed() && (fused_tail_ == 1 || (fused_tail_ == 2 && prefetch && renderer_->TwoDeepRegime()));
   if (tail_ok) renderer_->step_tail_builder_ = [this](F2nStepTail* t) { return BuildStepTail(t); };
   // A streaming step learns the PREVIOUS step's finiteness flags late.  With the fused tail those flags are computed half a step
   // before that step ends, so they are read here -- in front of this step's backward -- at no cost, and a dropped step's halved

@@ -96,7 +96,13 @@ class ExpRunner {
   // steps that apply the optimiser take it; a data-parallel step (the gradients travel first), a step that only inspects
   // gradients, the diagnostics taps and check_nan == false keep the separate launches.  Same parameters, bit for bit
   // (tests/test_gpu_e2e.py::test_fused_step_tail_equals_separate_launches).
-  bool fused_tail_ = true;
+  // 0: never; 1: whenever legal; 2 (default): in the two-deep sampling regime only.  A young scene samples ONE batch ahead and
+  // issues the head of that batch's chain (noise, prologue, walk) at the END of the step precisely so that it runs under the Adam /
+  // reduction tail -- bandwidth-bound, vector units idle; with the tail folded away the walk lands on the next gather instead:
+  // measured 1.129-1.141 against 1.112-1.115 ms on the fresh fox scene, 2.47 against 2.29 ms on the llff rig
+  // (profiles/r06_fused_tail_ab.txt).  In the two-deep regime the next batches' chains start at the TOP of a step whatever its
+  // tail looks like, and the fold is worth 2-3 % there.
+  int fused_tail_ = 2;
   bool exact_flag_order_ = false;  // read the previous step's flags in front of this step's backward also without the fused tail (see TrainStep)
   bool BuildStepTail(F2nStepTail* tail);
   AdamPlan tail_plan_;

@@ -296,6 +296,8 @@ class Renderer : public Pipe {
   // ExpRunner: the step's tail -- finiteness flags, Adam -- as arguments of the field backward's call (f2n_field_bwd_step_tail);
   // false: this step keeps the separate launches.  step_tail_done_: the call has queued them (ExpRunner::EnqueueApply's cue).
   std::function<bool(F2nStepTail*)> step_tail_builder_;
+  // two batches in flight (the walk + march of the batch after next begin at the TOP of a step): see spec_depth_
+  bool TwoDeepRegime();
   // ExpRunner: called once the step's forward has been queued and before anything of its backward is (loss scales, the step count
   // and the schedule the backward and the optimiser read are settled there: the previous step's finiteness flags)
   std::function<void()> before_backward_;

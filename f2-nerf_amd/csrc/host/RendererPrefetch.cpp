@@ -180,6 +180,12 @@ void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& 
   pend_[slot].rays_d = rays_d;
 }
 
+bool Renderer::TwoDeepRegime() {
+  auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
+  const bool big_tree = ps->pers_octree_->n_interior_ > ps->LdsWalkMaxInterior();
+  return speculative_sampling_ != 0 && (spec_depth_ >= 3 || (spec_depth_ == 2 && big_tree));
+}
+
 void Renderer::SpecBeginAtStepEnd() {
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
   auto* gdp = global_data_pool_;
