@@ -552,6 +552,8 @@ int f2n_shade_bwd_dyn(void* stream, int n_max, const int32_t* n_dev, const float
   if (n == 0) return F2N_OK;
   unsigned blocks = f2n_shade_grid((n + 31) / 32, 4);
   if (blocks > 512) blocks = 512;  // two resident blocks per CU (254 registers per lane)
+  // (fewer blocks for smaller batches -- 256 / 384 at the 2.6e5 samples of a converged step, so that a block would fit next to the
+  // sampler's march waves -- measured: nothing, 0.700-0.703 against 0.701-0.714 ms per step; profiles/r06_backward_grid_ab.txt)
   const int n_params = F2N_D_HID * F2N_D_IN + F2N_D_HID * F2N_D_HID + F2N_D_OUT * F2N_D_HID;
   float* partials = (float*) f2n_ws_get(F2N_WS_SHADE_DW, sizeof(float) * (size_t) blocks * n_params);
   float* emb_partials = nullptr;

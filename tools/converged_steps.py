@@ -18,6 +18,7 @@ ap.add_argument("--speculation", type=int, default=-1, help="0 off / 1 on / 2 au
 ap.add_argument("--march-blocks-sweep", default="", help="v1,v2,...: repeat the timed steps with the speculative march on that many persistent blocks (0: classic)")
 ap.add_argument("--block-waves-sweep", default="", help="v1,v2,...: repeat the timed steps with the persistent march in workgroups of that many waves")
 ap.add_argument("--fused-tail-sweep", action="store_true", help="repeat the timed steps with the step's tail fused into the field backward's call / as separate launches")
+ap.add_argument("--restore", action="store_true", help="sweeps: restart every phase from the state the training left (same batches, same work)")
 ap.add_argument("--native", action="store_true", help="time ExpRunner::Train's own loop (fresh batches drawn on the device every iteration) instead of python-driven steps on resident batches")
 ap.add_argument("--depth", type=int, default=-1, help="sampling pipeline depth of the timed steps (1 / 2; default: the host's)")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob (knobs exist in the debug variant only: F2N_DEBUG_BUILD=1; most are read once per process)")
@@ -42,7 +43,18 @@ def step(i):
     if runner.speculation_depth >= 2:
         return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2], nb2[0], nb2[1])
     return runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
+_snapshot = None
 def timed(tag=""):
+    # every phase of a sweep starts from the SAME state (parameters, octree, optimiser position): a training that carries on between the
+    # phases drifts -- fewer samples per step, a compaction -- by more than the differences a sweep is after
+    global _snapshot
+    if args.restore:
+        if _snapshot is None:
+            _snapshot = ([t.clone() for t in runner.states()], runner.iter_step)
+        else:
+            runner.load_states([t.clone() for t in _snapshot[0]])
+            runner.iter_step = _snapshot[1]
+            runner.update_ada_params()
     for i in range(6):
         step(i)
     c0 = runner.counters(); torch.cuda.synchronize(); time.sleep(0.3)

@@ -16,6 +16,7 @@ ap.add_argument("--iters", type=int, default=20000)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--factors", default="0.46,1,2,3")
 ap.add_argument("--speculation", type=int, default=0)
+ap.add_argument("--fused-tail", type=int, default=1, help="0: reduce / flags / adam_fused as separate launches behind the scatter; 1: f2n_field_bwd_step_tail")
 ap.add_argument("--overrides", nargs="*", default=[])
 ap.add_argument("--no-events", action="store_true", help="no HIP-event timers (for a run under rocprofv3 --kernel-trace)")
 args = ap.parse_args()
@@ -28,6 +29,11 @@ if args.iters > 0:
     runner.train(ds, args.iters, 1)
     torch.cuda.synchronize()
 runner.speculative_sampling = args.speculation
+if args.speculation == 0:
+    # the STREAMING step's kernels (survivor count on the device: field_shade_fwd, composite_train, the fused tail) without a next batch to
+    # prefetch -- the sampler then runs inside the step on the main stream and nothing runs underneath anything
+    runner.async_counts = 2
+    runner.fused_tail = args.fused_tail
 R0 = max(16, runner.cur_batch_size())
 H = runtime.host().ExpRunner
 for f in [float(v) for v in args.factors.split(",")]:
