@@ -98,15 +98,8 @@ void Renderer::EnsureSideStream(int slot) {
   TORCH_CHECK(dev >= 0 && dev < 16, "device index out of range");
   std::lock_guard<std::mutex> lock(mu);
   if (!shared[dev]) shared[dev] = std::make_shared<SideShared>();
-#if F2N_DEBUG_BUILD  // (measurement knob: the sampler's side streams at LOW queue priority -- F2N_SIDE_PRIO=1)
-  if (!shared[dev]->stream[slot] && getenv("F2N_SIDE_PRIO") != nullptr && atoi(getenv("F2N_SIDE_PRIO")) != 0) {
-    int least = 0, greatest = 0;
-    hipStream_t s = nullptr;
-    TORCH_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) == hipSuccess,
-                "low-priority stream");
-    shared[dev]->stream[slot] = std::make_shared<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromExternalMasqueradingAsCUDA(s, (c10::DeviceIndex) dev));
-  }
-#endif
+  // (the sampler's streams at LOW queue priority -- hipStreamCreateWithPriority -- were measured in round 6: nothing, 0.702-0.708 against
+  // 0.699-0.708 ms per converged step, 1.136 against 1.129 ms fresh: profiles/r06_backward_grid_ab.txt)
   if (!shared[dev]->stream[slot])
     shared[dev]->stream[slot] = std::make_shared<c10::hip::HIPStreamMasqueradingAsCUDA>(c10::hip::getStreamFromPoolMasqueradingAsCUDA());
   side_shared_ = shared[dev];
