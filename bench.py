@@ -90,7 +90,8 @@ def psnr_runs(args, n_runs):
     ds = runtime.make_dataset(sc, images)
     runs, leaf_sets = [], []
     rerun_seed = not getattr(args, "psnr_no_rerun", False)
-    seeds = [2022 + r for r in range(n_runs)] + ([2022] if (n_runs > 0 and rerun_seed) else [])
+    seed0 = int(getattr(args, "psnr_seed0", 2022))
+    seeds = [seed0 + r for r in range(n_runs)] + ([seed0] if (n_runs > 0 and rerun_seed) else [])
     partial = getattr(args, "psnr_partial", "")
     for seed in seeds:
         runner, cfg, _ = runtime.make_runner(st, args.preset, ["train.end_iter=%d" % args.train_iters], seed=2022)
@@ -129,7 +130,7 @@ def psnr_runs(args, n_runs):
             first_diff = int(stop)
             break
     inter0 = len(np.intersect1d(leaf_sets[0], rerun_leaves, assume_unique=True))
-    same_seed = {"seed": 2022, "psnr_run0": runs[0]["psnr_test_mean"], "psnr_rerun": rerun["psnr_test_mean"],
+    same_seed = {"seed": seed0, "psnr_run0": runs[0]["psnr_test_mean"], "psnr_rerun": rerun["psnr_test_mean"],
                  "checksums_part_at_checkpoint": first_diff,
                  "identical": (first_diff is None and runs[0]["psnr_test_mean"] == rerun["psnr_test_mean"]) if rerun_seed else None,
                  "surviving_leaf_sets_jaccard": round(inter0 / max(len(leaf_sets[0]) + len(rerun_leaves) - inter0, 1), 4)}
@@ -405,6 +406,7 @@ def main():
     ap.add_argument("--psnr-ref-runs", type=int, default=3, help="... with the reference-numerics build of the kernel library (0: skip)")
     ap.add_argument("--psnr-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: run N trainings, print their summary
     ap.add_argument("--psnr-no-rerun", action="store_true", help=argparse.SUPPRESS)  # worker: no repeat of seed 2022 at the end
+    ap.add_argument("--psnr-seed0", type=int, default=2022, help=argparse.SUPPRESS)  # worker: run r trains from seed psnr_seed0 + r
     ap.add_argument("--psnr-partial", default="", help=argparse.SUPPRESS)  # worker: file that holds the runs finished so far
     ap.add_argument("--other-configs", type=int, default=1, help="1: also run BASELINE configs 3-5 briefly (own processes) and report "
                     "them in the line (N=1, default preset only); 0: skip")

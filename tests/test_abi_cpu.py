@@ -146,7 +146,7 @@ def test_no_kernel_of_the_product_spills_vector_registers_or_uses_scratch(lib):
     assert all(r["kernel"].startswith("ray_march_persistent_kernel") for r in rows if r["sgpr_spill"])
     for k in ("hash_gather_planes_kernel<true, false>", "hash_gather_planes_kernel<true, true>", "adam_fused_kernel"):
         assert by[k]["waves_per_simd"] == 8, (k, by[k])
-    for k in ("shade_bwd_kernel", "field_bwd_kernel<2, 0, 2>", "hash_bin_accumulate_kernel"):
+    for k in ("shade_bwd_kernel", "field_bwd_kernel<2, 0, 2>", "hash_bin_accumulate_kernel<false>", "hash_bin_accumulate_kernel<true>"):
         assert by[k]["waves_per_simd"] >= 2 and by[k]["vgpr"] + by[k]["agpr"] <= 256, (k, by[k])
     assert by["field_shade_fwd_kernel"]["waves_per_simd"] >= 5  # (weights in LDS: 152 -> 80 registers)
     assert by["hash_bin_kernel"]["waves_per_simd"] >= 4
