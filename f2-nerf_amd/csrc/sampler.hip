@@ -922,6 +922,34 @@ __global__ void edge_samples_kernel(int n_pts, const F2nEdgePool* __restrict__ e
 // ---------------------------------------------------------------------------------------------------
 // Occupancy votes, PersSampler.cu:475-526 (integer atomic maxima).
 // ---------------------------------------------------------------------------------------------------
+// Votes into LDS images (mark == nullptr) are cast where they arise.  Votes into the GLOBAL buffers (trees too large for the block-local
+// images: every converged scene) are not (round 6): on gfx9 a global atomic counts in vmcnt like a load, and vmcnt retires in order, so
+// an atomic issued in chunk k made chunk k+1's wait for its (prefetched) samples a wait for that atomic's trip to the memory-side atomic
+// unit -- the walk of the batch's longest ray paid ~1 us per chunk, 22 of mark_visit's 32 us (tools/probe/rowwalk_tail.py,
+// profiles/r06_row_walks.txt).  A row now QUEUES its votes in LDS (F2N_VOTE_CAP records of 8 bytes, appended with a row ballot, no
+// atomics) and casts them behind its walk; and since a maximum only ever grows, a vote the buffer's current value already covers is
+// dropped after a plain load (all four words fetched together; a stale -- lower -- read costs a redundant atomic, never a lost vote): a
+// leaf is voted on by hundreds of rays per batch and only the first few votes change anything, while every atomic goes through the
+// memory-side unit (~21 G/s chip-wide: 3.8e5 per converged batch were 18 us).
+#define F2N_VOTE_CAP 96
+__device__ __forceinline__ void f2n_vote_global(int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt, int node, int vw, int va,
+                                                int visits) {
+  const int cw = __hip_atomic_load(w_adder + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (agent scope: read past the CU's L1)
+  const int ca = __hip_atomic_load(a_adder + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int cc = __hip_atomic_load(cnt + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int cm = __hip_atomic_load(mark + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (cw < vw) atomicMax(w_adder + node, vw);
+  if (ca < va) atomicMax(a_adder + node, va);
+  if (cc < visits) atomicMax(cnt + node, visits);
+  if (cm != 1) mark[node] = 1;
+}
+// the row's queued votes: lane c takes records c, c + 16, ...
+__device__ __forceinline__ void f2n_votes_flush_row(const uint2* list, int n, int c, int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt) {
+  for (int k = c; k < n; k += 16) {
+    const uint2 r = list[k];
+    f2n_vote_global(w_adder, a_adder, mark, cnt, (int) r.x, (r.y & 1u) ? 512 : -1, (r.y & 2u) ? 32 : -1, (int) (r.y >> 2));
+  }
+}
 __device__ __forceinline__ void f2n_vote(int32_t* w_adder, int32_t* a_adder, int32_t* mark, int32_t* cnt, int node,
                                          float w, float a, float w_thres, float a_thres, int visits) {
   atomicMax(w_adder + node, w > w_thres ? 512 : -1);  // OCC_WEIGHT_BASE
@@ -937,7 +965,9 @@ __device__ __forceinline__ void f2n_vote(int32_t* w_adder, int32_t* a_adder, int
 // cast by the run's last sample, which learns the run's maxima and start from a segmented max-scan over DPP row shifts.
 __device__ __forceinline__ void f2n_ray_votes(int s, int e, int c, float mw, float ma, const int32_t* __restrict__ anchors,
                                               int anchor_stride, const float* weights, const float* alphas, int32_t* w_adder,
-                                              int32_t* a_adder, int32_t* mark, int32_t* cnt) {
+                                              int32_t* a_adder, int32_t* mark, int32_t* cnt, uint2* vote_list = nullptr) {
+  // vote_list != nullptr: this row's F2N_VOTE_CAP queue slots in LDS (global vote buffers, see f2n_vote_global)
+  int n_queued = 0;
   // 0.1 / 0.01 / 0.02 are double literals in the reference (:12-17): float*double, then narrowed by fminf
   const float w_thres = fminf((float) ((double) mw * 0.1), (float) 0.01);
   const float a_thres = fminf((float) ((double) ma * 0.1), (float) 0.02);
@@ -948,26 +978,33 @@ __device__ __forceinline__ void f2n_ray_votes(int s, int e, int c, float mw, flo
   float carry_w = 0.f, carry_a = 0.f;
   int carry_start = s, carry_node = -1;
   auto rot1 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false); };  // lane 0 <- lane 15
-  int n_node;
-  float n_w, n_a;
-  {
-    const int i0 = min(s + c, e - 1);
-    n_node = anchors[(size_t) i0 * anchor_stride + 1];
-    n_w = weights[i0];
-    n_a = alphas[i0];
-  }
+  // A window of FOUR chunks in flight: the walk's body is ~0.2 us of instructions against a ~0.9 us round trip, and with one chunk
+  // ahead the longest ray paid the difference 25 times over (mark_visit 32.6 us with a 396-sample ray in the batch, 13.8 us with rays
+  // clipped at 128: tools/probe/rowwalk_tail.py).  Indices are clamped into the ray: a chunk past its end is a harmless re-read.
+  struct Chunk {
+    int node;
+    float w, a;
+  };
+  auto fetch_chunk = [&](int b) {
+    const int j = min(b + c, e - 1);
+    Chunk q;
+    q.node = anchors[(size_t) j * anchor_stride + 1];
+    q.w = weights[j];
+    q.a = alphas[j];
+    return q;
+  };
+  Chunk q0 = fetch_chunk(s), q1 = fetch_chunk(s + 16), q2 = fetch_chunk(s + 32), q3 = fetch_chunk(s + 48);
   for (int base = s; base < e; base += 16) {
     const int i = base + c;
     const bool in = i < e;
     const int ic = in ? i : e - 1;
-    const int node = n_node;
-    const float c_w = n_w, c_a = n_a;
-    if (base + 16 < e) {
-      const int j = min(i + 16, e - 1);
-      n_node = anchors[(size_t) j * anchor_stride + 1];
-      n_w = weights[j];
-      n_a = alphas[j];
-    }
+    const int node = q0.node;
+    const float c_w = q0.w, c_a = q0.a;
+    q0 = q1;
+    q1 = q2;
+    q2 = q3;
+    q3 = fetch_chunk(base + 64);
+    const int n_node = q0.node;  // (the next chunk's leaves: lane 15's right-hand neighbour)
     // lane 0: the previous chunk's last leaf (no leaf in front of the ray's first sample); lane 15: the next chunk's first
     const int prev = __builtin_amdgcn_update_dpp(base > s ? carry_node : -1, node, 0x111, 0xF, 0xF, false);
     const int nx0 = __builtin_amdgcn_update_dpp(0, n_node, 0x12F, 0xF, 0xF, false);  // lane 15 <- lane 0
@@ -1000,12 +1037,27 @@ __device__ __forceinline__ void f2n_ray_votes(int s, int e, int c, float mw, flo
     F2N_SEGMAX_STEP(4)
     F2N_SEGMAX_STEP(8)
 #undef F2N_SEGMAX_STEP
-    if (in && node != next) f2n_vote(w_adder, a_adder, mark, cnt, node, cw, ca, w_thres, a_thres, ic - start + 1);
+    const bool votes = in && node != next;
+    if (vote_list == nullptr) {
+      if (votes) f2n_vote(w_adder, a_adder, mark, cnt, node, cw, ca, w_thres, a_thres, ic - start + 1);
+    } else {
+      const unsigned row_bits = (unsigned) ((__ballot(votes) >> (threadIdx.x & 48)) & 0xFFFFull);  // (the rows of a wave loop independently)
+      const int n_new = __popc(row_bits);
+      if (n_queued + n_new > F2N_VOTE_CAP) {  // (row-uniform; a ray of more than ~F2N_VOTE_CAP leaf runs)
+        f2n_votes_flush_row(vote_list, n_queued, c, w_adder, a_adder, mark, cnt);
+        n_queued = 0;
+      }
+      if (votes)
+        vote_list[n_queued + __popc(row_bits & ((1u << c) - 1u))] =
+            make_uint2((unsigned) node, (cw > w_thres ? 1u : 0u) | (ca > a_thres ? 2u : 0u) | ((unsigned) (ic - start + 1) << 2));
+      n_queued += n_new;
+    }
     carry_w = __int_as_float(rot1(__float_as_int(cw)));
     carry_a = __int_as_float(rot1(__float_as_int(ca)));
     carry_start = rot1(start);
     carry_node = rot1(node);
   }
+  if (vote_list != nullptr) f2n_votes_flush_row(vote_list, n_queued, c, w_adder, a_adder, mark, cnt);
 }
 
 // USE_LDS: block-local vote images (see mark_visit_kernel) -- set up / flushed by these two.
@@ -1037,6 +1089,7 @@ __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __rest
                                   const float* __restrict__ alphas, int32_t* g_w_adder, int32_t* g_a_adder, int32_t* g_mark,
                                   int32_t* g_cnt) {
   extern __shared__ int32_t s_votes[];  // [3][n_nodes]: weight vote, alpha vote, visit count
+  __shared__ uint2 s_vote_list[USE_LDS ? 1 : 16 * F2N_VOTE_CAP];  // global vote buffers: the 16 rows' queues (256-thread blocks)
   int32_t* w_adder = USE_LDS ? s_votes : g_w_adder;
   int32_t* a_adder = USE_LDS ? s_votes + n_nodes : g_a_adder;
   int32_t* cnt = USE_LDS ? s_votes + 2 * n_nodes : g_cnt;
@@ -1061,7 +1114,8 @@ __global__ void mark_visit_kernel(int n_rays, int n_nodes, const int32_t* __rest
       mw = fmaxf(mw, __shfl_xor(mw, off, 16));
       ma = fmaxf(ma, __shfl_xor(ma, off, 16));
     }
-    f2n_ray_votes(s, e, c, mw, ma, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, cnt);
+    f2n_ray_votes(s, e, c, mw, ma, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, cnt,
+                  USE_LDS ? nullptr : s_vote_list + (threadIdx.x >> 4) * F2N_VOTE_CAP);
   }
   if (USE_LDS) f2n_votes_lds_flush(s_votes, n_nodes, g_w_adder, g_a_adder, g_mark, g_cnt);
 }
@@ -1079,6 +1133,7 @@ __global__ void early_stop_votes_kernel(int n_rays, int n_nodes, const int32_t* 
                                         const int32_t* __restrict__ anchors, int anchor_stride, int32_t* g_w_adder,
                                         int32_t* g_a_adder, int32_t* g_mark, int32_t* g_cnt) {
   extern __shared__ int32_t s_votes[];
+  __shared__ uint2 s_vote_list[USE_LDS ? 1 : 16 * F2N_VOTE_CAP];  // global vote buffers: the 16 rows' queues (256-thread blocks)
   int32_t* w_adder = USE_LDS ? s_votes : g_w_adder;
   int32_t* a_adder = USE_LDS ? s_votes + n_nodes : g_a_adder;
   int32_t* cnt_v = USE_LDS ? s_votes + 2 * n_nodes : g_cnt;
@@ -1134,7 +1189,9 @@ __global__ void early_stop_votes_kernel(int n_rays, int n_nodes, const int32_t* 
   }
   if (ray < n_rays && c == 0) kept[ray] = cnt;
   // ---- votes: the walk of mark_visit_kernel over what this row has just written ----
-  if (s < e) f2n_ray_votes(s, e, c, mw, ma, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, cnt_v);
+  if (s < e)
+    f2n_ray_votes(s, e, c, mw, ma, anchors, anchor_stride, weights, alphas, w_adder, a_adder, mark, cnt_v,
+                  USE_LDS ? nullptr : s_vote_list + (threadIdx.x >> 4) * F2N_VOTE_CAP);
   if (USE_LDS) f2n_votes_lds_flush(s_votes, n_nodes, g_w_adder, g_a_adder, g_mark, g_cnt);
 }
 
