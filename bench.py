@@ -547,7 +547,7 @@ def main():
         allt = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allt, mine)
         dp_diag = {"dp_exchange_ms": [round(float(t[0]), 4) for t in allt], "dp_wait_ms": [round(float(t[1]), 4) for t in allt],
-                   "exchanges_timed": [int(t[2]) for t in allt],
+                   "exchanges_timed": [int(t[2]) for t in allt], "small_buffers_exchanged_beside_the_scatter_rank0": int(runner.dp_small_exchanges_early()),
                    "note": "per rank, per step: dp_exchange_ms = first table bucket started -> flat small-gradient buffer reduced, on the "
                            "communicator's stream (its waits for the scatter's later buckets included); dp_wait_ms = what the compute stream "
                            "waited for that exchange at the top of the next step (the part of it the step did not hide)"}

@@ -642,12 +642,14 @@ class _StepTail(ctypes.Structure):
                 ("flags", ctypes.c_void_p), ("flags_mirror", ctypes.c_void_p), ("n_groups", ctypes.c_int), ("groups", ctypes.c_void_p),
                 ("n_table", ctypes.c_int), ("table_param", ctypes.c_void_p), ("table_exp_avg", ctypes.c_void_p),
                 ("table_exp_avg_sq", ctypes.c_void_p), ("table_param_h", ctypes.c_void_p), ("table_grad_scale", ctypes.c_float),
-                ("step", ctypes.c_int), ("lr", ctypes.c_float), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_float)]
+                ("step", ctypes.c_int), ("lr", ctypes.c_float), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_float),
+                ("after_reduce", ctypes.c_void_p), ("after_reduce_user", ctypes.c_void_p), ("leave_table_to_caller", ctypes.c_int)]
 
 
 def field_bwd_step_tail(n_max, n_dev, n_off, n_volumes, prim_pool, local_idx, local_size, bias_pool, level_scale, pts_warped, volume_idx,
                         vol_stride, mlp_params_h, saved_x_h, dfeat, loss_scale, dparams_scaled, grad_table_h, level_entries, flags_a,
-                        flags_b, flags, groups, table, step, lr, beta1, beta2, eps, tail_stream=None, flags_mirror=None):
+                        flags_b, flags, groups, table, step, lr, beta1, beta2, eps, tail_stream=None, flags_mirror=None, leave_table_to_caller=False,
+                        after_reduce=None):
     """f2n_field_bwd_step_tail: the field backward + the rest of the training step (deferred reductions, finiteness flags, Adam of
     `groups` (as adam_fused) and of `table` = {param, exp_avg, exp_avg_sq, param_h, grad_scale, n}) re-ordered around the scatter.
     Returns 1 when the scatter's owners stepped the table."""
@@ -672,6 +674,11 @@ def field_bwd_step_tail(n_max, n_dev, n_off, n_volumes, prim_pool, local_idx, lo
     t.table_param, t.table_exp_avg, t.table_exp_avg_sq = _p(table["param"], "f32").value, _p(table["exp_avg"], "f32").value, _p(table["exp_avg_sq"], "f32").value
     t.table_param_h, t.table_grad_scale = _p(table["param_h"], "h16").value, float(table["grad_scale"])
     t.step, t.lr, t.beta1, t.beta2, t.eps = int(step), float(lr), float(beta1), float(beta2), float(eps)
+    t.leave_table_to_caller = int(bool(leave_table_to_caller))
+    cb = None
+    if after_reduce is not None:  # (python callable(chain_stream_handle): what a data-parallel host does between the reductions and the flags)
+        cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)(lambda user, chain: after_reduce(chain))
+        t.after_reduce = ctypes.cast(cb, ctypes.c_void_p).value
     by_owners = ctypes.c_int(0)
     ts = ctypes.c_void_p(tail_stream.cuda_stream) if tail_stream is not None else ctypes.c_void_p(0)
     _ck(lib().f2n_field_bwd_step_tail(_stream(), ts, _i(n_max), _p(n_dev, "i32", True), _i(n_off), _i(n_volumes), _p(prim_pool, "i32"),

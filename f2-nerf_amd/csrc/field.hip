@@ -1728,6 +1728,7 @@ static int f2n_field_bwd_impl(void* stream, void* tail_stream, int n_max, const 
   }
   rc = f2n_reduce_deferred(ts);
   if (rc != F2N_OK) return rc;
+  if (tail->after_reduce != nullptr) tail->after_reduce(tail->after_reduce_user, (void*) ts);  // (data-parallel: the small buffers' exchange)
   rc = f2n_nonfinite_flags_ex(ts, tail->n_flags_a, tail->flags_grad_a, tail->n_flags_b, tail->flags_grad_b, tail->flags, tail->flags_mirror);
   if (rc != F2N_OK) return rc;
   const int32_t* skip = tail->flags + 2;
@@ -1746,14 +1747,14 @@ static int f2n_field_bwd_impl(void* stream, void* tail_stream, int n_max, const 
     ad.param_h = (half2_t*) tail->table_param_h;
     ad.k = f2n_adam_coef(tail->step, tail->lr, tail->beta1, tail->beta2, tail->eps, 0.f, tail->table_grad_scale);
     ad.skip = skip;
-    const bool can = tail->n_table > 0 && (long) tail->n_table == S * 2 * F2N_BIN_ENTRIES;
+    const bool can = !tail->leave_table_to_caller && tail->n_table > 0 && (long) tail->n_table == S * 2 * F2N_BIN_ENTRIES;
     rc = f2n_binned_scatter(st, n, h, local_idx, local_size, level_scale, pts_warped, 1, volume_idx, vol_stride, dx_planes, 4, 4 * (long) n, nz_mask,
                             (half_t*) grad_table_h, level_entries, n_dev, n_off, can ? &ad : nullptr, ev_join, &by_owners);
     if (rc != F2N_OK) return rc;
   }
   if (!by_owners) {  // small batches, odd tables, a bucket hook: the ordinary table pass behind the scatter
     if (ts != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return F2N_ERR_INVALID_ARG;
-    if (tail->n_table > 0) {
+    if (tail->n_table > 0 && !tail->leave_table_to_caller) {
       rc = f2n_adam_fused(st, 0, nullptr, tail->n_table, tail->table_param, grad_table_h, tail->table_grad_scale, tail->table_exp_avg,
                           tail->table_exp_avg_sq, tail->table_param_h, tail->step, tail->lr, tail->beta1, tail->beta2, tail->eps, /*zero_grad=*/1, skip);
       if (rc != F2N_OK) return rc;

@@ -21,6 +21,7 @@ static GradSyncPipeline GradSyncPipelineHooksRemoved(GradSyncPipeline p) {
   p.begin = nullptr;
   p.end = nullptr;
   p.bucket = nullptr;
+  p.small_exchange = nullptr;
   p.pipelined = false;
   p.ResetBuckets();
   return p;
@@ -118,6 +119,7 @@ void DataParallel::Attach(ExpRunner* runner, int rank, int world, const std::vec
   if (n_buckets_ > 1)  // (for THIS runner's gradient table only: another scatter on the device reports to nobody)
     F2N_CALL(f2n_set_scatter_buckets_for(n_buckets_, [](void* user, int b, int n) { static_cast<DataParallel*>(user)->runner_->sync_.BucketReady(b, n); }, this,
                                          table_prefix_.data_ptr()));
+  runner->sync_.small_exchange = [this](void* chain_stream) { SmallGradsExchange(chain_stream); };
   if (overlap) {
     runner->sync_.begin = [this]() { GradSyncBegin(); };
     runner->sync_.end = [this]() { GradSyncEnd(); };
@@ -155,14 +157,37 @@ void DataParallel::BroadcastStates() {
   runner_->LoadAuxStates(bcast(runner_->AuxStates()));
 }
 
+// The flat small-gradient buffer's all-reduce, started where that buffer is complete: behind the deferred reductions on the step's tail
+// stream, while the scatter's producers run (round 6; until then it left behind the step's LAST kernel and its ~90 us sat, exposed,
+// between the table's exchange and the optimiser: profiles/r06_dp_one_rank.txt).  The chain stream is left ordered behind it: the
+// finiteness flags and the small groups' Adam that f2n_field_bwd_step_tail queues next see the averaged gradients.
+void DataParallel::SmallGradsExchange(void* chain_stream) {
+  auto comm = reinterpret_cast<ncclComm_t>(comm_);
+  auto& chain = *runner_->renderer_->TailStream();  // (what Renderer::TrainForwardBackward hands f2n_field_bwd_step_tail as its tail stream)
+  TORCH_CHECK((void*) chain.stream() == chain_stream, "the step's tail chain runs on another stream than the renderer's tail stream");
+  small_ready_ev_.record(chain);
+  small_ready_ev_.block(*comm_stream_);
+  if (timing_ && !span_open_ && exchange_spans_.size() < 65536) {
+    exchange_spans_.push_back(std::make_unique<TimedSpan>());
+    exchange_spans_.back()->a.record(*comm_stream_);
+    span_open_ = true;
+  }
+  F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, comm_stream_->stream()));
+  small_done_ev_.record(*comm_stream_);
+  small_done_ev_.block(chain);
+  n_small_early_++;
+}
+
 void DataParallel::GradSyncBegin() {
   auto comm = reinterpret_cast<ncclComm_t>(comm_);
   // the table buckets the scatter did not report while it ran (all of them for a batch that took the small-batch path or had no
   // samples): every rank issues n_buckets_ table all-reduces and one for the flat small-gradient buffer per step, in this order
   for (int b = runner_->sync_.buckets_sent(); b < n_buckets_; b++) SendBucket(b);
-  grads_ready_ev_.record();  // backward has been queued on the compute stream
-  grads_ready_ev_.block(*comm_stream_);
-  F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, comm_stream_->stream()));
+  if (!runner_->sync_.small_sent()) {  // (a step that did not go through f2n_field_bwd_step_tail: taped steps, steps that only inspect gradients)
+    grads_ready_ev_.record();  // backward has been queued on the compute stream
+    grads_ready_ev_.block(*comm_stream_);
+    F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, comm_stream_->stream()));
+  }
   reduced_ev_.record(*comm_stream_);
   if (span_open_) {
     exchange_spans_.back()->b.record(*comm_stream_);

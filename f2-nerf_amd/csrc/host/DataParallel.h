@@ -45,6 +45,7 @@ class DataParallel {
   // {steps, exchange ms total, exposed wait ms total} since the last call.  ~4 event packets per step: off by default.
   void EnableTiming(bool on);
   std::vector<double> CollectTiming();
+  int64_t SmallExchangesEarly() const { return n_small_early_; }  // steps whose small buffers travelled beside the scatter (SmallGradsExchange)
   int64_t BucketCallbacks() const { return n_bucket_callbacks_; }  // table ranges the scatter reported while it ran            // what RCCL itself reports for the communicator (ncclCommCount)
 
  private:
@@ -52,8 +53,10 @@ class DataParallel {
   static constexpr int kTableBuckets = 4;
   int n_buckets_ = 1;
   int64_t n_bucket_callbacks_ = 0;  // table ranges the scatter reported while it ran (the rest went with GradSyncBegin)
+  int64_t n_small_early_ = 0;
   std::pair<int64_t, int64_t> BucketRange(int b) const;
   void SendBucket(int b);
+  void SmallGradsExchange(void* chain_stream);  // GradSyncPipeline::small_exchange: the flat buffer's all-reduce, early
   void GradSyncBegin();
   void GradSyncEnd();
   void OccupancySync(Tensor occ);
@@ -65,7 +68,7 @@ class DataParallel {
   int rank_ = 0, world_ = 1;
   Tensor table_prefix_, flat_;
   std::unique_ptr<c10::hip::HIPStreamMasqueradingAsCUDA> comm_stream_;
-  at::cuda::CUDAEvent grads_ready_ev_, reduced_ev_;
+  at::cuda::CUDAEvent grads_ready_ev_, reduced_ev_, small_ready_ev_, small_done_ev_;
   std::vector<at::cuda::CUDAEvent> bucket_ev_;
   bool timing_ = false, span_open_ = false;
   struct TimedSpan {

@@ -253,7 +253,9 @@ void ExpRunner::OptimStep(const int32_t* skip_flag, int32_t* compute_flags) {
 bool ExpRunner::BuildStepTail(F2nStepTail* t) {
   auto* field = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get());
   auto* shader = static_cast<SHShader*>(renderer_->shader_.get());
-  if (fused_tail_ == 0 || !check_nan_ || sync_.Installed()) return false;
+  // data-parallel: only with an exchange that can take the small buffers early (the native RCCL one), and the table's Adam stays ours
+  const bool dp = sync_.Installed();
+  if (fused_tail_ == 0 || !check_nan_ || (dp && !sync_.small_exchange)) return false;
   if (!nan_flags_.defined()) nan_flags_ = torch::zeros({4}, DevI32());
   BuildAdamPlan(tail_plan_);
   if (tail_plan_.n_table <= 0) return false;
@@ -276,6 +278,18 @@ bool ExpRunner::BuildStepTail(F2nStepTail* t) {
   t->beta1 = 0.9;
   t->beta2 = 0.99;
   t->eps = 1e-15f;
+  t->after_reduce = nullptr;
+  t->after_reduce_user = nullptr;
+  t->leave_table_to_caller = 0;
+  tail_table_left_ = false;
+  if (dp) {
+    // The gradients travel before anything is stepped: the small buffers' exchange goes between the reductions and the flags (beside
+    // the scatter's producers), the table's Adam stays a launch of this host's -- behind the table's exchange (EnqueueApply).
+    t->after_reduce = [](void* user, void* chain_stream) { static_cast<ExpRunner*>(user)->sync_.SmallGradsReady(chain_stream); };
+    t->after_reduce_user = this;
+    t->leave_table_to_caller = 1;
+    tail_table_left_ = true;
+  }
   return true;
 }
 
@@ -346,7 +360,10 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   renderer_->step_tail_done_ = false;
   renderer_->step_tail_builder_ = nullptr;
   renderer_->before_backward_ = nullptr;
-  const bool tail_ok = apply_optimizer && check_nan_ && !sync_.Installed() && (fused_tail_ == 1 || (fused_tail_ == 2 && prefetch && renderer_->TwoDeepRegime()));
+  // (a data-parallel step takes the tail in every regime: what it moves off the main queue there -- the small buffers' exchange, the
+  // flags, the small Adam -- sat exposed between the table's exchange and the optimiser)
+  const bool tail_ok = apply_optimizer && check_nan_ && (sync_.Installed() ? (fused_tail_ != 0 && (bool) sync_.small_exchange && prefetch)
+                                                                            : (fused_tail_ == 1 || (fused_tail_ == 2 && prefetch && renderer_->TwoDeepRegime())));
   if (tail_ok) renderer_->step_tail_builder_ = [this](F2nStepTail* t) { return BuildStepTail(t); };
   // A streaming step learns the PREVIOUS step's finiteness flags late.  With the fused tail those flags are computed half a step
   // before that step ends, so they are read here -- in front of this step's backward -- at no cost, and a dropped step's halved
@@ -458,6 +475,12 @@ void ExpRunner::EnqueueApply(bool apply_optimizer) {
     renderer_->step_tail_done_ = false;
     flags_on_tail_stream_ = true;
     optim_steps_ += 1;
+    if (tail_table_left_) {  // (data-parallel: the table's pass, behind the table's exchange; the flags were computed beside the scatter)
+      const AdamPlan& p = tail_plan_;
+      F2N_TIMED_CALL("adam_table", f2n_adam_fused(CurStream(), 0, nullptr, p.n_table, p.tp, p.tg, p.tscale, p.tm, p.tv, p.th, optim_steps_, cur_lr_, 0.9, 0.99, 1e-15f,
+                                                  /*zero_grad=*/1, I32P(nan_flags_) + 2));
+      tail_table_left_ = false;
+    }
     field->grad_clean_ = true;
     renderer_->small_grads_clean_ = true;
   } else if (apply_optimizer) {  // the flags are computed by the small-groups launch itself; a no-op on the device when they say so

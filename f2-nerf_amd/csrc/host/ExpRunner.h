@@ -106,6 +106,7 @@ class ExpRunner {
   bool exact_flag_order_ = false;  // read the previous step's flags in front of this step's backward also without the fused tail (see TrainStep)
   bool BuildStepTail(F2nStepTail* tail);
   AdamPlan tail_plan_;
+  bool tail_table_left_ = false;  // the step tail in flight left the table's Adam to EnqueueApply (F2nStepTail::leave_table_to_caller)
   bool flags_on_tail_stream_ = false;  // where the last finiteness-flag kernel was queued (DeferFlags records its event there)
   void BuildOptimizer();
   Tensor FlattenSmallGrads();

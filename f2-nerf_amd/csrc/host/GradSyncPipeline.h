@@ -25,10 +25,22 @@ class GradSyncPipeline {
   // GradientsReady / ResetBuckets): a scatter that runs on this device for anybody else -- a test's f2n_hash_bwd, a second
   // runner, a taped backward outside TrainStepAutograd -- must not start all-reduces the other ranks never issue (round-5 advisor).
   std::function<void(int bucket, int n_buckets)> bucket;
+  // The small gradient buffers (the two MLPs, the appearance embedding) are complete long before the table is -- behind the field-MLP
+  // backward, in front of the whole scatter --: a runner that queues the step's tail through f2n_field_bwd_step_tail hands their
+  // exchange this callback (round 6).  It is called with the stream the deferred reductions were queued on and must leave that stream
+  // ordered behind the exchange; `begin` / `blocking` then send the table only.  Same rule as for the buckets: only inside an armed step.
+  std::function<void(void* chain_stream)> small_exchange;
+  bool small_sent() const { return small_sent_; }
+  void SmallGradsReady(void* chain_stream) {
+    if (!small_exchange || !armed_ || small_sent_) return;
+    small_exchange(chain_stream);
+    small_sent_ = true;
+  }
   int buckets_sent() const { return buckets_sent_; }
   bool armed() const { return armed_; }
   void ArmBuckets() {
     buckets_sent_ = 0;
+    small_sent_ = false;
     armed_ = Installed();
   }
   void BucketReady(int b, int n) {
@@ -48,6 +60,7 @@ class GradSyncPipeline {
   // gradients: in pipelined mode it goes first, so that it runs underneath the exchange that is still in flight.
   void ResetBuckets() {
     buckets_sent_ = 0;
+    small_sent_ = false;
     armed_ = false;
   }
   void BeginStep(bool apply_optimizer, const std::function<void()>& presample) {
@@ -95,7 +108,7 @@ class GradSyncPipeline {
   bool pending_ = false;
   float pending_lr_ = 0.f;
   int buckets_sent_ = 0;
-  bool armed_ = false;
+  bool armed_ = false, small_sent_ = false;
 };
 
 }  // namespace f2n

@@ -259,6 +259,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("overlap") = true, py::arg("hooks_for_one_rank") = false)
       .def("dp_bucket_callbacks",  // table-gradient ranges the scatter reported while it ran (bucketed exchange, DataParallel.h)
            [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->BucketCallbacks() : (int64_t) 0; })
+      .def("dp_small_exchanges_early",  // steps whose small gradient buffers were exchanged beside the scatter (DataParallel::SmallGradsExchange)
+           [](ExpRunner& r) { return r.data_parallel_ ? std::static_pointer_cast<DataParallel>(r.data_parallel_)->SmallExchangesEarly() : (int64_t) 0; })
       .def("dp_enable_timing",  // bracket every gradient exchange / every wait for it with timing events (DataParallel::EnableTiming)
            [](ExpRunner& r, bool on) { if (r.data_parallel_) std::static_pointer_cast<DataParallel>(r.data_parallel_)->EnableTiming(on); })
       .def("dp_collect_timing",  // [exchanges, exchange ms total, waits, exposed wait ms total] since the last call (synchronises)

@@ -746,6 +746,17 @@ typedef struct F2nStepTail {
   float lr;
   double beta1, beta2;
   float eps;
+  /* Data-parallel hosts (the gradients travel before anything is stepped):
+   * after_reduce != NULL: called on the calling host thread once the deferred reductions have been QUEUED on the tail stream (or on
+   *   `stream` when there is none) -- the small gradient buffers are complete behind that point of that stream -- and before the flag
+   *   kernel is: the host orders its exchange of the small buffers in between (event on that stream -> communicator stream -> event ->
+   *   back), so that it travels beside the scatter's producers instead of behind the step;
+   * leave_table_to_caller != 0: everything BUT the table's Adam -- the owners write their sums to the gradient table as
+   *   f2n_field_bwd_dyn's do (a bucket hook on the table reports as usual), `stream` is left waiting for the tail chain, and the caller
+   *   steps the table itself (f2n_adam_fused with no small groups, skip flag = flags + 2) once ITS exchange is through. */
+  void (*after_reduce)(void* user, void* chain_stream);
+  void* after_reduce_user;
+  int leave_table_to_caller;
 } F2nStepTail;
 int f2n_field_bwd_step_tail(void* stream, void* tail_stream /* or NULL */, int n_max, const int32_t* n_dev, int n_off, int n_volumes,
                             const int32_t* prim_pool, const int32_t* local_idx, const int32_t* local_size, const float* bias_pool,

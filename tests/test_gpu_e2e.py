@@ -635,6 +635,8 @@ def test_bucketed_table_exchange_on_one_gpu(rt, fox_state):
                 s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
                 assert s["n_samples"] >= 32768, s["n_samples"]  # (the owner-binned scatter: F2N_BIN_MIN_N)
             outs[mode] = ([t.clone() for t in runner.states()], runner.dp_bucket_callbacks())
+            if mode != "none":  # (round 6: every step's small gradient buffers left from the step's tail chain, beside the scatter)
+                assert runner.dp_small_exchanges_early() == 3, (mode, runner.dp_small_exchanges_early())
             del runner
         for mode in ("native", "native-blocking"):
             assert outs[mode][1] == 12, (mode, outs[mode][1])

@@ -1239,16 +1239,19 @@ def test_adam_fused_equals_separate_launches(hip):
             assert_same(N(tb2["p"]), tab["p"])
 
 
-@pytest.mark.parametrize("n_use,bad,side,dirty", [(40000, False, False, False), (40000, False, True, True), (40000, True, True, False),
-                                                   (33000, False, False, True), (900, False, True, False), (900, True, False, False)])
-def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, bad, side, dirty):
+@pytest.mark.parametrize("n_use,bad,side,dirty,leave", [(40000, False, False, False, False), (40000, False, True, True, False), (40000, True, True, False, False),
+                                                         (33000, False, False, True, False), (900, False, True, False, False), (900, True, False, False, False),
+                                                         (40000, False, True, True, True), (40000, True, False, False, True)])
+def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, bad, side, dirty, leave):
     """f2n_field_bwd_step_tail (round 6) -- the field backward with the REST of the training step re-ordered around its scatter:
     deferred reductions, finiteness flags and the small groups' Adam behind the field-MLP backward (on a second stream when one is
     given), the hash table's Adam applied by the scatter's owner blocks to the slices they have just summed -- leaves every
     parameter, moment, f16 working copy, flag and (zeroed) gradient buffer bit-identical to f2n_field_bwd_dyn -> f2n_reduce_deferred
     -> f2n_nonfinite_flags -> f2n_adam_fused.  Large batch (binned scatter: the owners step the table) and small batch (atomics: the
     ordinary table pass runs behind them), applied and dropped (non-finite MLP gradient) iterations, a gradient table that was
-    not clean on entry (what the full-queue fallback's atomics leave: summed in, then cleared)."""
+    not clean on entry (what the full-queue fallback's atomics leave: summed in, then cleared).  leave: a data-parallel host's form of the
+    call -- everything but the table's Adam, which the caller launches itself once its exchange is through (F2nStepTail::
+    leave_table_to_caller), and a callback between the reductions and the flags (after_reduce: where the small buffers' exchange goes)."""
     st, g = fox_state, fox_golden
     rng = np.random.default_rng(64)
     LOG2 = 14
@@ -1290,10 +1293,16 @@ def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, b
                 grads[0], gtab, 1 << LOG2)
         hip.deferred_reset()
         by_owners = None
+        called = []
         if fused:
             by_owners = hip.field_bwd_step_tail(*args, grads[0], grads[1], flags, groups,
                                                 dict(param=tb["p"], exp_avg=tb["m"], exp_avg_sq=tb["v"], param_h=th, grad_scale=1.0 / 128, n=n_tab),
-                                                7, 3e-3, 0.9, 0.99, 1e-15, tail_stream=tail_stream)
+                                                7, 3e-3, 0.9, 0.99, 1e-15, tail_stream=tail_stream, leave_table_to_caller=leave,
+                                                after_reduce=(lambda chain: called.append(chain)) if leave else None)
+            if leave:
+                assert by_owners == 0 and len(called) == 1
+                hip.adam_fused([], dict(param=tb["p"], grad_h=gtab, exp_avg=tb["m"], exp_avg_sq=tb["v"], param_h=th, grad_scale=1.0 / 128, n=n_tab),
+                               7, 3e-3, 0.9, 0.99, 1e-15, True, flags[2:3])
         else:
             hip.field_bwd_dyn(*args, 1)
             hip.reduce_deferred()
@@ -1304,7 +1313,7 @@ def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, b
             torch.cuda.synchronize()
         out.append((grp, grads, hs, tb, th, gtab, flags, by_owners))
     (ga, gra, ha, ta, tha, gta, fa, _), (gb, grb, hb, tb2, thb, gtb, fb, by_owners) = out
-    assert by_owners == (1 if n_use >= 32768 else 0)
+    assert by_owners == (1 if (n_use >= 32768 and not leave) else 0)
     assert (N(fa)[:3] == N(fb)[:3]).all() and int(N(fa)[2]) == (1 if bad else 0)
     for k in range(3):
         for key in ("p", "m", "v"):

@@ -154,7 +154,7 @@ _TESTS = {
     "test_nonfinite_flags_and_skipped_adam": None,
     "test_adam_small_groups_equals_separate_launches": None,
     "test_adam_fused_equals_separate_launches": None,
-    "test_step_tail_equals_separate_launches": ("n_use,bad,side,dirty", [(33000, False, False, True), (900, True, False, False)]),
+    "test_step_tail_equals_separate_launches": ("n_use,bad,side,dirty,leave", [(33000, False, False, True, False), (900, True, False, False, False), (33000, False, False, True, True)]),
     "test_img2world_rays_and_pixel_gather": None,
     "test_empty_and_ragged_inputs": None,
 }
@@ -925,6 +925,7 @@ def test_bench_with_two_ranks_on_the_emulator(emul_host):
     diag = line["data_parallel"]
     assert len(diag["dp_exchange_ms"]) == 2 and len(diag["dp_wait_ms"]) == 2 and all(v > 0 for v in diag["dp_exchange_ms"])
     assert all(n >= 3 for n in diag["exchanges_timed"])
+    assert diag["small_buffers_exchanged_beside_the_scatter_rank0"] >= 3  # (round 6: the flat buffer's all-reduce leaves from the step's tail chain)
     # whole-job aggregate: the samples of BOTH ranks over the slower rank's time
     assert abs(line["value"] - line["config"]["meaningful_samples_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
     assert line["config"]["rays_per_s"] > 0 and abs(line["config"]["rays_per_s"] - 48 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["config"]["rays_per_s"]
