@@ -609,6 +609,9 @@ def main():
             if args.preset == "wanjinyou_big":  # (2^21 and up: the slice-binned gather of round 4, four kernels behind one call)
                 # (the newest counter pass of this table size: round 5 re-took 2^20 after the binned gather was extended to it)
                 tfile = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_big%d_traffic.json" % (r, log2)) for r in (6, 5, 4, 3)) if os.path.exists(f)), "")
+            elif args.preset in ("llff", "nerf-360") and args.log2 in (0, 19) and args.rays == 8192:
+                # (round 6: the rigs' own counter passes -- BENCH_EXTRA="--preset llff" bash profiles/run_profiles.sh r06_llff)
+                tfile = os.path.join(ROOT, "profiles", "r06_%s_traffic.json" % args.preset)
             elif args.preset != "wanjinyou" or args.log2 not in (0, 19) or args.rays != 8192:
                 tfile = ""  # (no counters were collected for this workload)
             traffic_source = None
