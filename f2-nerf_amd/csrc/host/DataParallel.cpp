@@ -182,12 +182,25 @@ void DataParallel::GradSyncBegin() {
   auto comm = reinterpret_cast<ncclComm_t>(comm_);
   // the table buckets the scatter did not report while it ran (all of them for a batch that took the small-batch path or had no
   // samples): every rank issues n_buckets_ table all-reduces and one for the flat small-gradient buffer per step, in this order
-  for (int b = runner_->sync_.buckets_sent(); b < n_buckets_; b++) SendBucket(b);
-  if (!runner_->sync_.small_sent()) {  // (a step that did not go through f2n_field_bwd_step_tail: taped steps, steps that only inspect gradients)
+  auto send_flat = [&]() {
     grads_ready_ev_.record();  // backward has been queued on the compute stream
     grads_ready_ev_.block(*comm_stream_);
+    if (timing_ && !span_open_ && exchange_spans_.size() < 65536) {
+      exchange_spans_.push_back(std::make_unique<TimedSpan>());
+      exchange_spans_.back()->a.record(*comm_stream_);
+      span_open_ = true;
+    }
     F2N_NCCL(ncclAllReduce(flat_.data_ptr(), flat_.data_ptr(), (size_t) flat_.numel(), ncclFloat, ncclAvg, comm, comm_stream_->stream()));
+  };
+  // the small buffers, unless the step's tail chain sent them (taped steps, steps that only inspect gradients, a batch that missed the
+  // scene): in the position this step's order gives them on EVERY rank (GradSyncPipeline::small_first)
+  const bool need_small = !runner_->sync_.small_sent();
+  if (need_small && runner_->sync_.small_first) {
+    TORCH_CHECK(runner_->sync_.buckets_sent() == 0, "table buckets left before the small buffers in a step that sends those first");
+    send_flat();
   }
+  for (int b = runner_->sync_.buckets_sent(); b < n_buckets_; b++) SendBucket(b);
+  if (need_small && !runner_->sync_.small_first) send_flat();
   reduced_ev_.record(*comm_stream_);
   if (span_open_) {
     exchange_spans_.back()->b.record(*comm_stream_);

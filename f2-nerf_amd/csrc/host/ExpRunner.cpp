@@ -365,6 +365,7 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   const bool tail_ok = apply_optimizer && check_nan_ && (sync_.Installed() ? (fused_tail_ != 0 && (bool) sync_.small_exchange && prefetch)
                                                                             : (fused_tail_ == 1 || (fused_tail_ == 2 && prefetch && renderer_->TwoDeepRegime())));
   if (tail_ok) renderer_->step_tail_builder_ = [this](F2nStepTail* t) { return BuildStepTail(t); };
+  sync_.small_first = tail_ok && sync_.Installed();  // (the collective order of this step: the same on every rank, GradSyncPipeline.h)
   // A streaming step learns the PREVIOUS step's finiteness flags late.  With the fused tail those flags are computed half a step
   // before that step ends, so they are read here -- in front of this step's backward -- at no cost, and a dropped step's halved
   // loss scales / taken-back counters hold for this step's backward AND its optimiser call, as in the reference's order
@@ -550,6 +551,7 @@ TrainStats ExpRunner::TrainStepAutograd(const Tensor& rays_o, const Tensor& rays
   const int batch = rays_o.size(0);
   renderer_->cur_seq_ = step_seq_++;
   sync_.ArmBuckets();  // (the taped backward's scatter reports its table buckets to the exchange below)
+  sync_.small_first = false;  // (a taped step sends the small buffers behind the table, on every rank)
   auto rr = renderer_->Render(rays_o, rays_d, bounds, emb_idx);
   renderer_->cur_seq_ = -1;
   TrainStats stats;

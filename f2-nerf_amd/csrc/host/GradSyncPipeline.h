@@ -30,6 +30,11 @@ class GradSyncPipeline {
   // exchange this callback (round 6).  It is called with the stream the deferred reductions were queued on and must leave that stream
   // ordered behind the exchange; `begin` / `blocking` then send the table only.  Same rule as for the buckets: only inside an armed step.
   std::function<void(void* chain_stream)> small_exchange;
+  // The ORDER every rank must keep: a step that is eligible for the early exchange sends the small buffers FIRST, then the table's
+  // buckets -- also on a rank whose batch missed the scene and never reached its backward (`begin` / `blocking` send the small buffers in
+  // front of the buckets then); every other step sends them last, as before.  Set by the runner per step, from arguments that are the same
+  // on every rank.
+  bool small_first = false;
   bool small_sent() const { return small_sent_; }
   void SmallGradsReady(void* chain_stream) {
     if (!small_exchange || !armed_ || small_sent_) return;

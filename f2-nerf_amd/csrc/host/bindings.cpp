@@ -127,6 +127,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("set_defer_flags", [](GradSyncPipeline& p, py::function f) { p.defer_flags = [f]() { f(); }; })
       .def("set_bucket", [](GradSyncPipeline& p, py::function f) { p.bucket = [f](int b, int n) { f(b, n); }; })
       .def("bucket_ready", &GradSyncPipeline::BucketReady)
+      .def("set_small_exchange", [](GradSyncPipeline& p, py::function f) { p.small_exchange = [f](void*) { f(); }; })
+      .def("small_grads_ready", [](GradSyncPipeline& p) { p.SmallGradsReady(nullptr); })
+      .def_readwrite("small_first", &GradSyncPipeline::small_first)
+      .def_property_readonly("small_sent", &GradSyncPipeline::small_sent)
       .def_property_readonly("buckets_sent", &GradSyncPipeline::buckets_sent)
       .def("installed", &GradSyncPipeline::Installed)
       .def("pending", &GradSyncPipeline::Pending)

@@ -313,6 +313,64 @@ def test_table_gradient_buckets_travel_in_order_and_the_exchange_sends_the_rest(
     assert q.buckets_sent == 0
 
 
+def test_small_gradient_buffers_travel_first_on_every_rank_of_a_tail_step():
+    """Round 6: a data-parallel step that goes through f2n_field_bwd_step_tail exchanges the small gradient buffers from the step's tail
+    chain, beside the scatter -- BEFORE the table's buckets.  A rank whose batch missed the scene never reaches that chain; its `begin`
+    must then send the small buffers in front of the buckets all the same (GradSyncPipeline::small_first), or the ranks' collectives
+    pair up wrongly.  The sequence a rank issues, whatever happened to its batch: flat, b0 .. b3 in a tail step; b0 .. b3, flat otherwise."""
+    import f2_nerf_amd  # noqa: F401
+    from f2_nerf_amd import runtime
+    host = runtime.host()
+    N = 4
+
+    def make(log):
+        p = host.GradSyncPipeline()
+        p.set_apply(lambda a, lr: None)
+        p.set_defer_flags(lambda: None)
+        p.set_bucket(lambda b, n: log.append("b%d" % b))
+        p.set_small_exchange(lambda: log.append("flat"))
+
+        def begin():  # DataParallel::GradSyncBegin
+            need = not p.small_sent
+            if need and p.small_first:
+                assert p.buckets_sent == 0
+                log.append("flat")
+            for b in range(p.buckets_sent, N):
+                log.append("b%d" % b)
+            if need and not p.small_first:
+                log.append("flat")
+        p.set_begin_end(begin, lambda: None)
+        p.pipelined = True
+        return p
+    want_tail = ["flat"] + ["b%d" % b for b in range(N)]
+    for reported, has_samples in ((4, True), (2, True), (0, True), (0, False)):
+        log = []
+        p = make(log)
+        p.begin_step(True, lambda: None)
+        p.small_first = True                 # ExpRunner::TrainStep: this step is eligible for the early exchange
+        if has_samples:
+            p.small_grads_ready()            # f2n_field_bwd_step_tail's after_reduce
+            p.small_grads_ready()            # (at most once per step)
+            for b in range(reported):
+                p.bucket_ready(b, N)
+        p.gradients_ready(True, 0.01)
+        assert log == want_tail, (reported, has_samples, log)
+        assert not p.small_sent and p.buckets_sent == 0
+    # a step that is not eligible (taped, gradient inspection): the small buffers behind the table, as before
+    log = []
+    p = make(log)
+    p.begin_step(True, lambda: None)
+    p.small_first = False
+    p.bucket_ready(0, N)
+    p.gradients_ready(True, 0.01)
+    assert log == ["b%d" % b for b in range(N)] + ["flat"]
+    # outside a step the early exchange is ignored like a stray bucket
+    log = []
+    p = make(log)
+    p.small_grads_ready()
+    assert log == []
+
+
 def test_bench_reads_the_node_layout_of_the_checkpoint():
     """bench.py's PSNR study identifies surviving leaves from the raw TreeNode bytes with its own numpy dtype (it may not import the
     oracle): field offsets and size must be those of the 64-byte checkpoint layout (PersSampler.h:22-29)."""
