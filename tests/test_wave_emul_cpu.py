@@ -881,6 +881,7 @@ def test_two_rank_data_parallel_training_on_the_emulator(emul_host, overlap):
     for k in ("table", "field_mlp", "color_mlp", "app_emb", "nodes", "n_nodes", "meaningful_per_ray"):
         assert a[k] == b[k], (k, a[k], b[k])  # bit-identical replicas after the run: parameters, octree, the batch-sizing average
     assert a["n_nodes"] != 897  # (the compaction / subdivision ran on both)
+    assert a["empty_steps"] == 0 and b["empty_steps"] == 1  # (one of rank 1's batches missed the scene: its collectives still paired with rank 0's)
     assert a["losses"] != b["losses"] and all(np.isfinite(a["losses"] + b["losses"]))  # (each rank trained on its own rays)
     # one rank alone, same seed and rays as rank 0: another training (the exchange did change what rank 0 learnt)
     solo = _run_ranks(1, steps, rays, -1, uid)[0]

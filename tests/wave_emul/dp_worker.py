@@ -42,8 +42,14 @@ def main():
     for _ in range(steps + 2):
         ro, rd, bounds, cam = e2e.fox_batch(st, rng, rays)
         batches.append([torch.from_numpy(np.ascontiguousarray(a)) for a in (ro, rd, bounds, rng.random((rays, 3), dtype=np.float32), cam)])
+    if world > 1 and rank == 1 and steps >= 5:
+        # one of THIS rank's batches misses the scene altogether (no sample, no backward, no step-tail call): its collectives must still pair
+        # with the other ranks' -- the small buffers first, then the table's buckets, from GradSyncBegin (round 6)
+        batches[3][0] = torch.full_like(batches[3][0], 100.0)
+        batches[3][1] = torch.tensor([[1.0, 0.0, 0.0]]).repeat(rays, 1)
     torch.manual_seed(2022)
     losses = []
+    empty_steps = 0
     for i in range(steps):
         b, nb, nb2 = batches[i], batches[i + 1], batches[i + 2]
         if runner.speculation_depth >= 2:
@@ -51,6 +57,7 @@ def main():
         else:
             s = runner.train_step(b[0], b[1], b[2], b[3], b[4], True, nb[0], nb[1], nb[2])
         losses.append(float(s["loss"]))
+        empty_steps += int(s["n_samples"] == 0)
     runner.flush()
     stt = runner.states()
     csum = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum())  # noqa: E731
@@ -58,7 +65,7 @@ def main():
     print(json.dumps(dict(rank=rank, table_before_attach=before, table=csum(stt[4]), field_mlp=csum(stt[8]), color_mlp=csum(stt[9]), app_emb=csum(stt[10]),
                           nodes=int(stt[0].to(torch.int64).sum()), n_nodes=runner.n_nodes(), comm_ranks=int(runner.dp_comm_ranks()), losses=losses,
                           meaningful=c["total_meaningful"], marched=c["total_marched"], spec=dict(runner.speculation_counters()),
-                          meaningful_per_ray=float(runner.meaningful_per_ray))), flush=True)
+                          meaningful_per_ray=float(runner.meaningful_per_ray), empty_steps=empty_steps)), flush=True)
 
 
 if __name__ == "__main__":
