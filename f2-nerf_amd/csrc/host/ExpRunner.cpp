@@ -360,10 +360,13 @@ TrainStats ExpRunner::TrainStep(const Tensor& rays_o, const Tensor& rays_d, cons
   renderer_->step_tail_done_ = false;
   renderer_->step_tail_builder_ = nullptr;
   renderer_->before_backward_ = nullptr;
+  // (tables of 2^21 entries per level and more: the table's Adam is a 0.2-0.45 ms pass, and folding it into the owners wins in a young
+  // scene too -- 2.29 -> 2.05 ms per step at 2^22, 1.66 -> 1.58 at 2^21, nothing at 2^20: profiles/r06_fused_tail_ab.txt)
+  const bool big_table = static_cast<Hash3DAnchored*>(renderer_->scene_field_.get())->pool_size_ / N_LEVELS >= (1 << 21);
   // (a data-parallel step takes the tail in every regime: what it moves off the main queue there -- the small buffers' exchange, the
   // flags, the small Adam -- sat exposed between the table's exchange and the optimiser)
   const bool tail_ok = apply_optimizer && check_nan_ && (sync_.Installed() ? (fused_tail_ != 0 && (bool) sync_.small_exchange && prefetch)
-                                                                            : (fused_tail_ == 1 || (fused_tail_ == 2 && prefetch && renderer_->TwoDeepRegime())));
+                                                                            : (fused_tail_ == 1 || (fused_tail_ == 2 && prefetch && (renderer_->TwoDeepRegime() || big_table))));
   if (tail_ok) renderer_->step_tail_builder_ = [this](F2nStepTail* t) { return BuildStepTail(t); };
   sync_.small_first = tail_ok && sync_.Installed();  // (the collective order of this step: the same on every rank, GradSyncPipeline.h)
   // A streaming step learns the PREVIOUS step's finiteness flags late.  With the fused tail those flags are computed half a step

@@ -96,7 +96,8 @@ class ExpRunner {
   // steps that apply the optimiser take it; a data-parallel step (the gradients travel first), a step that only inspects
   // gradients, the diagnostics taps and check_nan == false keep the separate launches.  Same parameters, bit for bit
   // (tests/test_gpu_e2e.py::test_fused_step_tail_equals_separate_launches).
-  // 0: never; 1: whenever legal; 2 (default): in the two-deep sampling regime only.  A young scene samples ONE batch ahead and
+  // 0: never; 1: whenever legal; 2 (default): in the two-deep sampling regime, and at any time for tables of 2^21 entries per level and
+  // more (where the table's Adam is the longer half of the tail).  A young scene samples ONE batch ahead and
   // issues the head of that batch's chain (noise, prologue, walk) at the END of the step precisely so that it runs under the Adam /
   // reduction tail -- bandwidth-bound, vector units idle; with the tail folded away the walk lands on the next gather instead:
   // measured 1.129-1.141 against 1.112-1.115 ms on the fresh fox scene, 2.47 against 2.29 ms on the llff rig

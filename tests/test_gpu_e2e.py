@@ -647,7 +647,8 @@ def test_bucketed_table_exchange_on_one_gpu(rt, fox_state):
         dist.destroy_process_group()
 
 
-def test_fused_step_tail_equals_separate_launches(rt, fox_state):
+@pytest.mark.parametrize("log2", [15, 21])
+def test_fused_step_tail_equals_separate_launches(rt, fox_state, log2):
     """The step's tail inside the field backward's call (round 6; ExpRunner.fused_tail, f2n_field_bwd_step_tail: deferred reductions,
     finiteness flags and the small groups' Adam on the tail stream beside the scatter's producers, the table's Adam in the scatter's
     owner blocks) against the separate launches behind the scatter (reduce -> flags -> f2n_adam_fused): streaming steps at a batch
@@ -662,7 +663,7 @@ def test_fused_step_tail_equals_separate_launches(rt, fox_state):
     bad_gt[5, 1] = float("nan")
     outs = {}
     for fused in (True, False):
-        runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=15"], seed=3, table_init=0.3)
+        runner, cfg, _ = rt.make_runner(st, "wanjinyou", ["field.log2_table_size=%d" % log2], seed=3, table_init=0.3)  # (21: 8704 owner blocks)
         torch.manual_seed(9)
         runner.fused_tail = fused
         runner.exact_flag_order = True  # (the fused tail reads the previous step's flags in front of the backward: ask the other for the same)
