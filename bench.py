@@ -387,6 +387,15 @@ def converged_leg(args, st, dev):
     return out
 
 
+def _scatter_counters():
+    from f2_nerf_amd import capi
+    c = capi.debug_counters()
+    import numpy as np
+    return {"records_applied_by_atomics": c[0], "slices_summed_in_fp64_instead_of_fixed_point": c[1],
+            # (debug variant of the library only; 0 otherwise) the largest sum of |addend| any slice's owner saw: the fixed-point route holds < 96
+            "largest_slice_sum_of_abs_addends": float(np.array(c[2], np.int32).view(np.float32))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -701,6 +710,8 @@ def main():
             "steady_state": steady, "roofline": roofline, "cpu_baseline": cpu_baseline, "converged": converged, "replicas": replicas,
             "data_parallel": dp_diag,
             "other_configs": others,
+            # whole process so far (timed steps, converged leg, other configs): 0 atomic records = every hash-gradient sum was order-free
+            "scatter_counters": _scatter_counters(),
             # buffers are sized for the worst case on purpose (1024 sample slots per ray, scatter queues): what that costs of 288 GB
             "peak_hbm_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                              "reserved_by_allocator": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2),

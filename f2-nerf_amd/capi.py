@@ -68,7 +68,8 @@ def build_info():
 
 
 def debug_counters(reset=False):
-    """Diagnostic event counters of the library (f2n_debug_counters): [0] = scatter records applied by the atomic fallback."""
+    """Diagnostic event counters of the library (f2n_debug_counters): [0] = scatter records applied by the atomic fallback,
+    [1] = table slices whose owner summed in fp64 instead of its packed fixed-point image (same bits, slower)."""
     out = (ctypes.c_int32 * 8)()
     torch.cuda.synchronize()
     _ck(lib().f2n_debug_counters(out, _i(1 if reset else 0)), "f2n_debug_counters")

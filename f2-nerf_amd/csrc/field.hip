@@ -695,6 +695,7 @@ struct F2nBinQueues {
   int32_t* cnt;    // [16 levels][n_bins][NB]
   int cap, n_bins;
   int nb_force;  // 0, or the chunk count to use whatever the sample count (F2N_BIN_NB: measurement knob)
+  int force_f64;  // != 0: the owners sum every slice on their fp64 route (F2N_OWNER_F64: test knob of the debug variant)
 };
 
 __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHashArgs h, const int32_t* __restrict__ local_idx,
@@ -831,34 +832,61 @@ struct F2nOwnerAdam {
   const int32_t* skip;  // flags[2] of the step's finiteness check: != 0 -> the iteration is dropped (ExpRunner.cpp:131-134)
 };
 
-// one round of the owner's Adam: eight entries per thread (old gradient pair, master pair, both moments)
+// one round of the owner's Adam: F2N_OWNER_U entries per thread (old gradient pair, master pair, both moments: 7 registers per entry --
+// four entries, so that a round in flight under the record reads still leaves the kernel at four waves per SIMD)
+#define F2N_OWNER_U 4
+#define F2N_OWNER_ROUNDS (F2N_BIN_ENTRIES / (256 * F2N_OWNER_U))
 struct F2nOwnerRound {
-  half2_t old[8];
-  float2 p[8], m[8], v[8];
+  half2_t old[F2N_OWNER_U];
+  float2 p[F2N_OWNER_U], m[F2N_OWNER_U], v[F2N_OWNER_U];
 };
-__device__ __forceinline__ void f2n_owner_fetch(F2nOwnerRound& r, const half2_t* __restrict__ tab, const F2nOwnerAdam& ad, size_t e_base, int e0, bool skip) {
+// (`second_moment` false: everything but exp_avg_sq -- what is fetched in front of the record reads; the rest follows behind them)
+__device__ __forceinline__ void f2n_owner_fetch(F2nOwnerRound& r, const half2_t* __restrict__ tab, const F2nOwnerAdam& ad, size_t e_base, int e0, bool skip,
+                                                bool first_part = true, bool second_moment = true) {
 #pragma unroll
-  for (int u = 0; u < 8; u++) {
-    r.old[u] = tab[e0 + 256 * u];
+  for (int u = 0; u < F2N_OWNER_U; u++) {
+    if (first_part) r.old[u] = tab[e0 + 256 * u];
     if (!skip) {
-      r.p[u] = ad.param[e_base + e0 + 256 * u];
-      r.m[u] = ad.exp_avg[e_base + e0 + 256 * u];
-      r.v[u] = ad.exp_avg_sq[e_base + e0 + 256 * u];
+      if (first_part) {
+        r.p[u] = ad.param[e_base + e0 + 256 * u];
+        r.m[u] = ad.exp_avg[e_base + e0 + 256 * u];
+      }
+      if (second_moment) r.v[u] = ad.exp_avg_sq[e_base + e0 + 256 * u];
     }
   }
 }
 
+// THE IMAGE (round 6): one 64-bit integer per table entry, both channels of a record in ONE ds_add_u64 -- channel 0 in the low 32 bits,
+// channel 1 in the high 32, each a signed count of 2^-24 (every f16 is a whole multiple of 2^-24, so every addend is exact; integer sums
+// are order-free; a borrow out of the low field is undone when the fields are taken apart, as long as both TRUE sums fit 32 bits).
+// 32 KB instead of the 64 KB of two fp64 sums per entry: four owner blocks per CU instead of two -- twice the record reads in flight,
+// which is what the owner's time is made of -- and half the LDS atomics.  The fields hold |sum| < 128 (loss-scaled f16 gradients sit
+// far below).  Guarantee, not hope: every lane keeps the sum of |addend| it has cast; if the block's total could reach the field's
+// range (>= 96, a quarter of slack for the fp32 rounding of that running sum; NaN / Inf land here too) NO entry of the image is trusted
+// and the slice is summed again one channel at a time in a 4096-entry fp64 image (the arithmetic of rounds 1-5: fp64 sums of f16 addends
+// are exact too, so both routes end in the same bits) -- counted in f2n_debug_counters()[1].
+#define F2N_OWNER_FIXED_ONE 16777216.f  // 2^24
+#define F2N_OWNER_MAG_LIMIT 96.f
+
 template <bool ADAM>
-__global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
+__global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
                                                                   half_t* __restrict__ grad_table, int n,
                                                                   const int32_t* __restrict__ n_dev, int n_off, int first_slice,
                                                                   F2nOwnerAdam ad) {
   F2N_RAISE_PRIO();
-  __shared__ double s_acc[2 * F2N_BIN_ENTRIES];  // 64 KB: the fp64 image of this block's table slice
-  int& s_total = *(int*) &s_acc[0];              // (the record total lives in the image's first word until the image is zeroed)
+  __shared__ unsigned long long s_acc[F2N_BIN_ENTRIES];  // 32 KB: the fixed-point image of this block's table slice
+  __shared__ int s_total;
+  __shared__ float s_mag[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // table slice g <- (level l1 = g / H, local slice g - l1*H) and (level l1 - 1, local slice g - l1*H + H)
-  const int H = slices_per_half_level, g = first_slice + (int) blockIdx.x;  // (a launch may cover a bucket of the table's slices)
+  const int H = slices_per_half_level;
+  int g = first_slice + (int) blockIdx.x;  // (a launch may cover a bucket of the table's slices)
+  // A launch over the whole table is ~6 % more blocks than the chip holds at once: the stragglers should be the LIGHT slices -- the
+  // table's first and last half level receive records from one level, not two -- so those 2H blocks are dispatched last.
+  if (first_slice == 0 && (int) gridDim.x == (F2N_N_LEVELS + 1) * H) {
+    const int b = (int) blockIdx.x;
+    g = b < (F2N_N_LEVELS - 1) * H ? b + H : b < F2N_N_LEVELS * H ? b - (F2N_N_LEVELS - 1) * H : b;
+  }
   const int l1 = g / H, b1 = g - l1 * H;
   if (n_dev != nullptr) n = min(n, *n_dev + n_off);
   const int nb = f2n_bin_nb(n, q.nb_force), cap_nb = q.cap * (F2N_BIN_NB / nb);  // the producers' choice (same function of the same count)
@@ -878,50 +906,108 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
   __syncthreads();
   const int total = s_total;
   if (total == 0 && !ADAM) return;  // block-uniform: nothing landed in this slice
-  __syncthreads();                  // (everyone has read the total before its word is zeroed with the image)
   // ADAM: the first round's table / parameter / moment operands travel while the records are read and summed
   const bool skip = ADAM && ad.skip != nullptr && *ad.skip != 0;
+  half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
   F2nOwnerRound ro0;
-  if (ADAM) f2n_owner_fetch(ro0, (const half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES, ad, (size_t) g * F2N_BIN_ENTRIES, tid, skip);
+  if (ADAM) f2n_owner_fetch(ro0, tab, ad, (size_t) g * F2N_BIN_ENTRIES, tid, skip, true, false);
+  bool packed = total != 0;  // the image holds this slice's sums (block-uniform)
   if (total != 0) {
-  for (int i = tid; i < 2 * F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0.0;
-  __syncthreads();
-  // Segments in batches, the first 128 records of each with one coalesced 8-byte load per lane (the records were written
-  // by other XCDs a moment ago -- every read is a fabric round trip, so as many as possible are kept in flight).
-  auto add = [&](uint2 rec) {
-    if (rec.y != 0u) {  // a stored record is never (+0, +0); padding is
-      const half2_t val = __builtin_bit_cast(half2_t, rec.y);
-      atomicAdd(&s_acc[2 * rec.x], (double) val[0]);
-      atomicAdd(&s_acc[2 * rec.x + 1], (double) val[1]);
+    for (int i = tid; i < F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0ull;
+    __syncthreads();
+    float mag = 0.f;
+    auto add = [&](uint2 rec) {
+      if (rec.y != 0u) {  // a stored record is never (+0, +0); padding is
+        const half2_t val = __builtin_bit_cast(half2_t, rec.y);
+        const float f0 = (float) val[0], f1 = (float) val[1];
+        mag += fabsf(f0) + fabsf(f1);
+        // (clamped: the conversion stays defined for addends the fields cannot hold -- those slices are summed again below)
+        const int i0 = (int) fminf(fmaxf(f0 * F2N_OWNER_FIXED_ONE, -2147483648.f), 2147483520.f);
+        const int i1 = (int) fminf(fmaxf(f1 * F2N_OWNER_FIXED_ONE, -2147483648.f), 2147483520.f);
+        atomicAdd(&s_acc[rec.x], (unsigned long long) (((long long) i1 << 32) + (long long) i0));
+      }
+    };
+    // Eight segments at a time, the first 256 records of each with FOUR coalesced 8-byte loads per lane, all 32 of them issued
+    // before any record is added (the records were written by other XCDs a moment ago -- every read is a fabric round trip, so as
+    // many as possible are kept in flight): a segment holds ~150 records at the 2.6e5 samples of an ExpRunner::Train batch.
+    // (Measured: the kernel's time is the volume of these reads -- 76 us with them, 13 us without, the LDS adds hidden underneath --
+    // not their scheduling: profiles/r04_pipeline_experiments.txt item 7.)
+    for (int sg = 0; sg < nb / 2; sg += 8) {
+      uint2 rec[32];
+      int longest = 0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int cnt = __shfl(my_cnt, sg + u);
+        const uint2* r = q.rec + (size_t) __shfl((unsigned) my_seg, sg + u) * cap_nb;
+        longest = max(longest, cnt);
+#pragma unroll
+        for (int k = 0; k < 4; k++) rec[4 * u + k] = lane + 64 * k < cnt ? r[lane + 64 * k] : uint2{0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < 32; u++) add(rec[u]);
+      if (longest > 256) {  // long segments: the rest (wave-uniform)
+        for (int u = 0; u < 8; u++) {
+          const int cnt = __shfl(my_cnt, sg + u);
+          const uint2* r = q.rec + (size_t) __shfl((unsigned) my_seg, sg + u) * cap_nb;
+          for (int i = lane + 256; i < cnt; i += 64) add(r[i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mag += __shfl_xor(mag, off);
+    if (lane == 0) s_mag[wave] = mag;
+    __syncthreads();
+    const float mag_all = (s_mag[0] + s_mag[1]) + (s_mag[2] + s_mag[3]);
+#if F2N_DEBUG_BUILD  // how close a run's slices come to the limit: f2n_debug_counters()[2] = the largest total, as float bits
+    if (tid == 0 && mag_all == mag_all) atomicMax(&f2n_dbg_counters[2], __float_as_int(mag_all));
+#endif
+    if (!(mag_all < F2N_OWNER_MAG_LIMIT) || q.force_f64 != 0) {
+      // ---- a field could have overflowed: the slice again, one channel at a time, exact fp64 sums folded into the gradient table ----
+      packed = false;
+      if (tid == 0) atomicAdd(&f2n_dbg_counters[1], 1);
+      double* s_f64 = (double*) s_acc;
+      half_t* tab_h = (half_t*) tab;
+      for (int ch = 0; ch < 2; ch++) {
+        __syncthreads();
+        for (int i = tid; i < F2N_BIN_ENTRIES; i += 256) s_f64[i] = 0.0;
+        __syncthreads();
+        for (int sg = 0; sg < nb / 2; sg++) {
+          const int cnt = __shfl(my_cnt, sg);
+          const uint2* r = q.rec + (size_t) __shfl((unsigned) my_seg, sg) * cap_nb;
+          for (int i = lane; i < cnt; i += 64) {
+            const uint2 rec = r[i];
+            const half2_t val = __builtin_bit_cast(half2_t, rec.y);
+            atomicAdd(&s_f64[rec.x], (double) val[ch]);
+          }
+        }
+        __syncthreads();
+        for (int e = tid; e < F2N_BIN_ENTRIES; e += 256) {
+          const double a = s_f64[e];
+          if (a != 0.0) tab_h[2 * e + ch] = (half_t) (float) ((double) (float) tab_h[2 * e + ch] + a);
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (ADAM) {  // the gradient pairs this block has just written (its own stores: visible to it)
+#pragma unroll
+        for (int u = 0; u < F2N_OWNER_U; u++) ro0.old[u] = tab[tid + 256 * u];
+      }
+    }
+  }  // total != 0
+  // the two sums of entry e (exact; what the fp64 pair of rounds 1-5 held)
+  auto sums_of = [&](int e, double& a0, double& a1) {
+    a0 = 0.0;
+    a1 = 0.0;
+    if (packed) {
+      const long long t = (long long) s_acc[e];
+      const int lo = (int) (unsigned) (unsigned long long) t;
+      const long long hi = (t - (long long) lo) >> 32;
+      a0 = (double) lo * (1.0 / 16777216.0);
+      a1 = (double) (int) hi * (1.0 / 16777216.0);
     }
   };
-  // Eight segments at a time, the first 256 records of each with FOUR coalesced 8-byte loads per lane, all 32 of them issued
-  // before any record is added: a segment holds ~150 records at the 2.6e5 samples of an ExpRunner::Train batch, so two rounds left
-  // most segments to the "rest" loop below (one dependent fabric round trip per segment and 64 records).  (Measured: the kernel's
-  // time is the volume of these reads -- 76 us with them, 13 us without, the LDS adds hidden underneath -- not their scheduling:
-  // profiles/r04_pipeline_experiments.txt item 7.)
-  for (int sg = 0; sg < nb / 2; sg += 8) {
-    uint2 rec[32];
-    int cnt[8];
-    const uint2* r[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      cnt[u] = __shfl(my_cnt, sg + u);
-      const unsigned long long sidx = __shfl((unsigned long long) my_seg, sg + u);
-      r[u] = q.rec + sidx * cap_nb;
-#pragma unroll
-      for (int k = 0; k < 4; k++) rec[4 * u + k] = lane + 64 * k < cnt[u] ? r[u][lane + 64 * k] : uint2{0u, 0u};
-    }
-#pragma unroll
-    for (int u = 0; u < 32; u++) add(rec[u]);
-#pragma unroll
-    for (int u = 0; u < 8; u++)  // long segments: the rest
-      for (int i = lane + 256; i < cnt[u]; i += 64) add(r[u][i]);
-  }
-  __syncthreads();
-  }  // total != 0
-  half2_t* tab = (half2_t*) grad_table + (size_t) g * F2N_BIN_ENTRIES;
   if (!ADAM) {
+    if (!packed) return;
     for (int e0 = tid; e0 < F2N_BIN_ENTRIES; e0 += 256 * 8) {  // eight independent table reads in flight per thread
       half2_t old[8];
 #pragma unroll
@@ -929,26 +1015,23 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int e = e0 + 256 * u;
-        const double a0 = s_acc[2 * e], a1 = s_acc[2 * e + 1];
+        double a0, a1;
+        sums_of(e, a0, a1);
         if (a0 != 0.0 || a1 != 0.0)
           tab[e] = half2_t{(half_t) (float) ((double) (float) old[u][0] + a0), (half_t) (float) ((double) (float) old[u][1] + a1)};
       }
     }
     return;
   }
-  // ---- ADAM: the slice's 4096 entries in two rounds of eight per thread; round 0's operands were fetched before the records (ro0 above) ----
+  // ---- ADAM: the slice's 4096 entries in rounds of F2N_OWNER_U per thread; round 0's operands were fetched before the records (ro0
+  // above), round r + 1's travel while round r is stepped ----
   const size_t e_base = (size_t) g * F2N_BIN_ENTRIES;
-  F2nOwnerRound ro1;
-  f2n_owner_fetch(ro1, tab, ad, e_base, tid + 256 * 8, skip);
   auto step_round = [&](const F2nOwnerRound& ro, int e0) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < F2N_OWNER_U; u++) {
       const int e = e0 + 256 * u;
-      double a0 = 0.0, a1 = 0.0;
-      if (total != 0) {
-        a0 = s_acc[2 * e];
-        a1 = s_acc[2 * e + 1];
-      }
+      double a0, a1;
+      sums_of(e, a0, a1);
       half2_t gh = ro.old[u];  // the value the gradient table holds behind the plain owner
       if (a0 != 0.0 || a1 != 0.0)
         gh = half2_t{(half_t) (float) ((double) (float) ro.old[u][0] + a0), (half_t) (float) ((double) (float) ro.old[u][1] + a1)};
@@ -964,8 +1047,15 @@ __global__ __launch_bounds__(256) void hash_bin_accumulate_kernel(F2nBinQueues q
       }
     }
   };
-  step_round(ro0, tid);
-  step_round(ro1, tid + 256 * 8);
+  f2n_owner_fetch(ro0, tab, ad, e_base, tid, skip, false, true);
+  F2nOwnerRound ro1;
+#pragma unroll
+  for (int r = 0; r < F2N_OWNER_ROUNDS; r += 2) {
+    f2n_owner_fetch(ro1, tab, ad, e_base, tid + 256 * F2N_OWNER_U * (r + 1), skip);
+    step_round(ro0, tid + 256 * F2N_OWNER_U * r);
+    if (r + 2 < F2N_OWNER_ROUNDS) f2n_owner_fetch(ro0, tab, ad, e_base, tid + 256 * F2N_OWNER_U * (r + 2), skip);
+    step_round(ro1, tid + 256 * F2N_OWNER_U * (r + 1));
+  }
 }
 
 __device__ __forceinline__ void f2n_load_point(const float* __restrict__ pts, int s, bool warped, float* p01) {
@@ -1274,8 +1364,14 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
     return (v == 32 || v == 64 || v == 128) ? v : 0;
   }();
   q.nb_force = nb_force;
+  static const int force_f64 = []() {
+    const char* e = getenv("F2N_OWNER_F64");
+    return e != nullptr && atoi(e) != 0 ? 1 : 0;
+  }();
+  q.force_f64 = force_f64;
 #else
   q.nb_force = 0;
+  q.force_f64 = 0;
 #endif
 
 

@@ -70,7 +70,9 @@ int f2n_set_scatter_buckets(int n_buckets, f2n_bucket_fn fn, void* user);
 int f2n_set_scatter_buckets_for(int n_buckets, f2n_bucket_fn fn, void* user, const void* grad_table_h16);
 /* Diagnostics (host-only, synchronous; no reference counterpart): eight device-side event counters copied to host memory,
  * optionally reset.  [0] = scatter records of f2n_hash_bwd's owner-binned path that found their queue segment full and were
- * applied by a packed-f16 atomic instead (the only order-dependent addition of that path).  The rest are reserved (0). */
+ * applied by a packed-f16 atomic instead (the only order-dependent addition of that path); [1] = table slices whose owner left
+ * its packed fixed-point image for exact fp64 sums because the slice's addends could have left the 32-bit fields' range (same
+ * bits either way: a cost counter, not an error counter).  The rest are reserved (0). */
 int f2n_debug_counters(int32_t* out8_host /* or NULL */, int reset);
 /* (The two debugging launches of rounds 3-4 -- a delay on a stream, a launch that leaves garbage in every CU's LDS and registers
  * -- are not part of this ABI: include/f2n_debug.h, compiled into the debug variant of the library only.) */

@@ -98,3 +98,60 @@ def test_reference_numerics_build_on_the_device():
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=900)
     print(r.stdout[-3000:])
     assert r.returncode == 0 and "REFNUM_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+OWNER_CHILD = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["F2N_ROOT"]); sys.path.insert(0, os.path.join(os.environ["F2N_ROOT"], "tests"))
+import f2_nerf_amd
+from f2_nerf_amd import capi
+from oracle import pipeline as op
+F32 = np.float32
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+st = dict(np.load(os.path.join(os.environ["F2N_ROOT"], "tests", "golden", "fox_state.npz")))
+g = dict(np.load(os.path.join(os.environ["F2N_ROOT"], "tests", "golden", "fox_golden.npz")))
+rng = np.random.default_rng(5)
+out = {}
+for log2, reps, amp in ((14, 12, 2e-4), (19, 12, 0.05), (19, 12, 3.0)):
+    grid = op.HashGrid(np.zeros((16 << log2, 2), F32), st["prim_pool"], st["bias_pool"], int(st["n_volumes"]), log2)
+    pts = np.tile(g["march_pts"], (reps, 1)); vol = np.tile(np.ascontiguousarray(g["march_anchors"][:, 0]), reps)
+    n = len(pts)
+    gin = (rng.standard_normal((n, 32)) * amp).astype(np.float16)
+    gin[rng.random(n) < 0.3] = 0
+    gtab = torch.zeros(grid.table_f32.size, dtype=torch.float16, device="cuda")
+    capi.debug_counters(reset=True)
+    for _ in range(2):   # the second call adds to what the first left (old != 0)
+        capi.hash_bwd(n, grid.n_volumes, T(grid.prim_pool), T(grid.local_idx), T(grid.local_size), T(grid.bias_pool), T(grid.scales), T(pts), True,
+                      T(vol), 1, T(gin), gtab, 1 << log2)
+    torch.cuda.synchronize()
+    c = capi.debug_counters()
+    out["tab_%d_%g" % (log2, amp)] = gtab.cpu().numpy().view(np.uint16)
+    out["cnt_%d_%g" % (log2, amp)] = np.array([c[0], c[1]])
+np.savez(os.environ["F2N_OUT"], **out)
+'''
+
+
+def test_owner_fixed_point_route_equals_fp64_route(tmp_path):
+    """The scatter's owners (round 6) sum a slice in a packed fixed-point image -- one 64-bit integer add per record -- and fall back
+    to fp64 sums, one channel at a time, when the slice's addends could leave the fields' range.  Both are exact sums of the same
+    f16 addends: the debug variant with every slice forced onto the fp64 route (F2N_OWNER_F64=1) must leave the same bits as the
+    default; small gradients stay on the integer route, large ones leave it (f2n_debug_counters()[1]), by themselves."""
+    import numpy as np
+    res = {}
+    for name, env_extra in (("default", {}), ("f64", {"F2N_OWNER_F64": "1"})):
+        out = str(tmp_path / (name + ".npz"))
+        env = dict(os.environ, F2N_DEBUG_BUILD="1", F2N_ROOT=ROOT, F2N_OUT=out, **env_extra)
+        env.pop("F2N_REFERENCE_NUMERICS", None)
+        r = subprocess.run([sys.executable, "-c", OWNER_CHILD], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res[name] = dict(np.load(out))
+    keys = [k for k in res["default"] if k.startswith("tab_")]
+    assert len(keys) == 3
+    for k in keys:
+        assert (res["default"][k] != 0).any()
+        assert (res["default"][k] == res["f64"][k]).all(), k
+    d, f = res["default"], res["f64"]
+    assert (d["cnt_14_0.0002"] == 0).all() and d["cnt_19_0.05"][0] == 0    # no atomic fallback; tiny gradients: integer route only
+    assert d["cnt_19_3"][1] > 0                                             # large gradients: slices leave the integer route
+    assert f["cnt_14_0.0002"][1] > 0 and f["cnt_19_0.05"][1] > 0            # forced: every slice with records

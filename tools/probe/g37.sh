@@ -1,0 +1,26 @@
+mkdir -p gpurun_out/s37
+O=gpurun_out/s37
+cp f2-nerf_amd/libf2n_hip.so tools/probe/libf2n_hip_new.so
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_refnum.py -x -q -k "hash_backward or step_tail or adam or owner" 2>&1 | tail -5 > $O/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_converged.py -x -q -k "fused_step or full_iteration or log2" 2>&1 | tail -5 >> $O/pytest.txt
+for rep in 1 2; do
+for v in prev new; do
+  cp tools/probe/libf2n_hip_$v.so f2-nerf_amd/libf2n_hip.so
+  echo "== $v" >> $O/ab.txt
+  [ $rep = 1 ] && timeout 300 python tools/scatter_bench.py --reps 50 2>&1 | grep scatter_bench >> $O/ab.txt
+  timeout 300 python tools/converged_steps.py --native --steps 400 2>&1 | grep "native loop" >> $O/ab.txt
+  timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-converged --other-configs 0 2>/dev/null | python -c "
+import sys, json
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('fresh', round(j['ms_per_step'],4), j['roofline']['timed_calls_ms_per_step'])" >> $O/ab.txt
+  [ $rep = 1 ] && timeout 300 python bench.py --preset wanjinyou_big --log2 22 --steps 100 --warmup 20 --no-cpu-baseline --no-converged --other-configs 0 2>/dev/null | python -c "
+import sys, json
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('big22', round(j['ms_per_step'],4), j['roofline']['timed_calls_ms_per_step'])" >> $O/ab.txt
+done
+done
+cp tools/probe/libf2n_hip_new.so f2-nerf_amd/libf2n_hip.so
+python - >> $O/ab.txt 2>&1 <<'PY'
+import sys; sys.path.insert(0, '.')
+import f2_nerf_amd
+from f2_nerf_amd import capi
+print('counters after nothing', capi.debug_counters())
+PY
