@@ -389,7 +389,10 @@ def converged_leg(args, st, dev):
 
 def _scatter_counters():
     from f2_nerf_amd import capi
-    c = capi.debug_counters()
+    try:
+        c = capi.debug_counters()
+    except Exception as e:  # (a diagnostic: never the reason a bench line is lost)
+        return {"error": str(e)[:200]}
     import numpy as np
     return {"records_applied_by_atomics": c[0], "slices_summed_in_fp64_instead_of_fixed_point": c[1],
             # (debug variant of the library only; 0 otherwise) the largest sum of |addend| any slice's owner saw: the fixed-point route holds < 96

@@ -760,7 +760,16 @@ void ExpRunner::LoadCheckpoint(const std::string& dir) {
 int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   const int target = until_iter > 0 ? std::min(until_iter, end_iter_) : end_iter_;
   int executed = 0;
-  auto draw = [&](int64_t seq) { return dataset.RandRaysData(std::max(16, BatchSizeFor(seq)), sets, seq); };
+  // The draw's one kernel does not sit on the step's main queue (round 6: 7-9 us per step there, in front of the gather): it runs on the
+  // device's tail stream, which is idle at the top of a step (Renderer::BeginDraw / EndDraw: ordering and the pool's protection).
+  auto draw = [&](int64_t seq) {
+    const int n_rays = std::max(16, BatchSizeFor(seq));
+    if (!draws_off_main_) return dataset.RandRaysData(n_rays, sets, seq);
+    c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*renderer_->BeginDraw());
+    auto batch = dataset.RandRaysData(n_rays, sets, seq);
+    renderer_->EndDraw();
+    return batch;
+  };
   // The batches of the next iteration AND (two-deep sampling pipeline, Renderer::next2_batch_) of the one after it are drawn
   // ahead: one draw per iteration, right before the step, as before -- but the adaptive ray count of a batch now comes from the
   // meaningful-samples average at a fixed lag (BatchSizeFor; the reference: the step before, ExpRunner.cpp:86), because its rays
@@ -772,6 +781,11 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
   std::deque<decltype(draw(0))> ahead;
   last_train_meaningful_ = last_train_marched_ = last_train_rays_ = 0;
   FinishPending();
+  struct RaysOffMain {  // (also when a step throws)
+    Renderer* r;
+    RaysOffMain(Renderer* r_, bool on) : r(r_) { r->rays_off_main_ = on; }
+    ~RaysOffMain() { r->rays_off_main_ = false; }
+  } rays_off_main(renderer_.get(), false);  // (on from this call's second step: whatever the caller queued before this call is behind the first's event)
   const int64_t kept0 = renderer_->total_kept_pts_;
   const int give_up = 4 * (target + 16);  // every iteration non-finite: stop instead of spinning
   while (true) {
@@ -786,9 +800,13 @@ int ExpRunner::Train(Dataset& dataset, int until_iter, int sets) {
     const BoundedRays& nr = std::get<0>(ahead[1]);
     Tensor gt = std::get<1>(cur);
     TORCH_CHECK(gt.defined(), "Train needs resident ground-truth images in the Dataset");
+    const uint64_t consumed_seq = renderer_->ConsumedSeq();
     TrainStats s = two_deep ? TrainStep(r.origins, r.dirs, r.bounds, gt, std::get<2>(cur), true, nr.origins, nr.dirs, nr.bounds,
                                         std::get<0>(ahead[2]).origins, std::get<0>(ahead[2]).dirs)
                             : TrainStep(r.origins, r.dirs, r.bounds, gt, std::get<2>(cur), true, nr.origins, nr.dirs, nr.bounds);
+    // (the batch's tensors come from the tail stream's pool and are released below: every step of this loop leaves a `consumed` behind)
+    if (draws_off_main_) renderer_->ConsumedBehindStep(consumed_seq);
+    renderer_->rays_off_main_ = draws_off_main_ && spec_start_without_event_;
     ahead.pop_front();
     last_train_marched_ += s.n_samples;
     last_train_rays_ += s.n_rays;

@@ -104,6 +104,8 @@ class ExpRunner {
   // (profiles/r06_fused_tail_ab.txt).  In the two-deep regime the next batches' chains start at the TOP of a step whatever its
   // tail looks like, and the fold is worth 2-3 % there.
   int fused_tail_ = 2;
+  bool draws_off_main_ = true;  // Train(): the batch draws on the tail stream instead of the main queue (A/B knob)
+  bool spec_start_without_event_ = true;  // ... and then no spec_start event at the top of a step (A/B knob)
   bool exact_flag_order_ = false;  // read the previous step's flags in front of this step's backward also without the fused tail (see TrainStep)
   bool BuildStepTail(F2nStepTail* tail);
   AdamPlan tail_plan_;

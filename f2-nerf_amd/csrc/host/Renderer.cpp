@@ -182,8 +182,12 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
   // sequence -- background / edge samples of this step, then the next batch's march noise -- whichever way the next batch is
   // sampled; only the event moves.)
   spec_start_recorded_ = false;
+  spec_start_is_consumed_ = false;
   if (train && async_count && (next_batch_.valid || next2_batch_.valid) && speculative_sampling_ != 0) {
-    spec_start_ev_.record();
+    // (ExpRunner::Train with its draws on the tail stream: the main stream has been handed nothing since the previous step's `consumed`,
+    // which every side stream waits for at a begin anyway -- that recording IS this point, and the packet is saved)
+    if (rays_off_main_ && side_shared_ && side_shared_->seq > 0) spec_start_is_consumed_ = true;
+    else spec_start_ev_.record();
     spec_start_recorded_ = true;
   }
   // A prefetch whose kernels were queued by the previous step: only now does the host wait for its count (everything between
@@ -226,6 +230,7 @@ RenderFront Renderer::SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d
     presample_rays_o_ = presample_rays_d_ = Tensor();
     static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
     static_cast<PersSampler*>(pts_sampler_.get())->keyed_seq_ = train ? cur_seq_ : -1;
+    if (draw_ev_recorded_) draw_ev_.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());  // (rays drawn on the tail stream)
     sample_result_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
   }
   // Random draws of the step (Renderer.cpp:67-81 background, PersSampler.cu:456-457 edge samples): ONE uniform launch for both

@@ -185,6 +185,19 @@ class Renderer : public Pipe {
   bool PreSampleSpecComplete(int slot);  // false: could not be repaired (tree re-numbered): dropped
   at::cuda::CUDAEvent spec_start_ev_;
   bool spec_start_recorded_ = false;
+  // ExpRunner::Train's batch draws OFF the main queue (round 6): Dataset::RandRaysData's one kernel runs on the device's tail stream
+  // -- idle at the top of a step -- out of that stream's pool; a batch's rays are read first by its sampling on a side stream (which
+  // waits for draw_ev_ at its begin) and two steps later by the main stream, which is ordered behind the draw through that batch's
+  // presample_done_ev_ or, when it samples the batch itself, waits for draw_ev_.  The pool's memory is protected like the sampler's:
+  // the tail stream waits for `consumed` in front of every draw, and a step of such a loop records `consumed` whatever its path.
+  c10::hip::HIPStreamMasqueradingAsCUDA* BeginDraw();
+  void EndDraw();
+  void ConsumedBehindStep(uint64_t seq_before);  // records `consumed` if the step that has just been queued did not
+  uint64_t ConsumedSeq() { return side_shared_ ? side_shared_->seq : 0; }
+  at::cuda::CUDAEvent draw_ev_;
+  bool draw_ev_recorded_ = false;
+  bool rays_off_main_ = false;          // set by ExpRunner::Train around its loop: the main stream starts a step with nothing queued since `consumed`
+  bool spec_start_is_consumed_ = false;  // this step's "start" point for speculative begins is the previous step's `consumed` (no event of its own)
   RenderFront SampleAndFilter(const Tensor& rays_o, const Tensor& rays_d, const Tensor& bounds, const Tensor& emb_idx,
                               bool async_count = false);
   // The survivor count of an async SampleAndFilter arrives in pinned memory; the host-side bookkeeping that depends on it

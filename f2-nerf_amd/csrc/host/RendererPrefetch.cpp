@@ -31,6 +31,7 @@ void Renderer::PreSample(const Tensor& rays_o, const Tensor& rays_d, const Tenso
     PreSampleFinish(slot);
     if (PresampleMatches(rays_o, rays_d)) return;
   }
+  if (draw_ev_recorded_) draw_ev_.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());  // (rays drawn on the tail stream)
   static_cast<PersSampler*>(pts_sampler_.get())->extra_sample_rows_ = 2 * n_edge_pts_;
   static_cast<PersSampler*>(pts_sampler_.get())->keyed_seq_ = cur_seq_;
   presampled_ = pts_sampler_->GetSamples(rays_o, rays_d, bounds);
@@ -119,6 +120,24 @@ c10::hip::HIPStreamMasqueradingAsCUDA* Renderer::TailStream() {
   return side_shared_->tail.get();
 }
 
+c10::hip::HIPStreamMasqueradingAsCUDA* Renderer::BeginDraw() {
+  auto* tail = TailStream();
+  if (side_shared_->seq > 0) side_shared_->consumed.block(*tail);  // (the pool's blocks: their last readers on the main stream)
+  return tail;
+}
+
+void Renderer::EndDraw() {
+  draw_ev_.record(*TailStream());
+  draw_ev_recorded_ = true;
+}
+
+void Renderer::ConsumedBehindStep(uint64_t seq_before) {
+  EnsureSideStream(0);
+  if (side_shared_->seq != seq_before) return;
+  side_shared_->consumed.record();
+  side_shared_->seq++;
+}
+
 // A side stream's buffers may be handed the memory of samples the main stream is still reading: it waits for the last
 // recording of the device's `consumed` event it has not waited for yet.
 void Renderer::SideWaitConsumed(int slot) {
@@ -146,6 +165,7 @@ void Renderer::PreSampleBegin(const Tensor& rays_o, const Tensor& rays_d, const 
   }
   EnsureSideStream(slot);
   octree_ready_ev_.block(*side_[slot]);  // the only dependency on this step: its occupancy update / ProcOctree
+  if (draw_ev_recorded_) draw_ev_.block(*side_[slot]);  // (rays drawn on the tail stream)
   SideWaitConsumed(slot);
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());
@@ -169,8 +189,10 @@ void Renderer::PreSampleSpecBegin(int slot, const Tensor& rays_o, const Tensor& 
   if (!spec_start_recorded_) {  // (else: recorded at the top of this step, ahead of its random draws)
     spec_start_ev_.record();
     spec_start_recorded_ = true;  // (a second batch begun in the same step waits for the same point)
+    spec_start_is_consumed_ = false;
   }
-  spec_start_ev_.block(*side_[slot]);
+  if (!(spec_start_recorded_ && spec_start_is_consumed_)) spec_start_ev_.block(*side_[slot]);
+  if (draw_ev_recorded_) draw_ev_.block(*side_[slot]);  // (rays drawn on the tail stream)
   SideWaitConsumed(slot);
   c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*side_[slot]);
   auto* ps = static_cast<PersSampler*>(pts_sampler_.get());

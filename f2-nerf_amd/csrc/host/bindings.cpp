@@ -369,6 +369,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_; },
                     [](ExpRunner& r, bool on) { static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->tail_repair_ = on; })
       .def_readwrite("fused_tail", &ExpRunner::fused_tail_)
+      .def_readwrite("spec_start_without_event", &ExpRunner::spec_start_without_event_)
+      .def_readwrite("draws_off_main", &ExpRunner::draws_off_main_)  // ExpRunner::Train's batch draws on the tail stream (A/B: False = main queue)
       .def_readwrite("exact_flag_order", &ExpRunner::exact_flag_order_)  // the step's tail inside the field backward's call (A/B: False = separate launches)
       .def_property("march_block_waves",  // workgroup size of the persistent march, in waves (1..16)
                     [](ExpRunner& r) { return static_cast<PersSampler*>(r.renderer_->pts_sampler_.get())->march_block_waves_; },

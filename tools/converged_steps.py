@@ -21,6 +21,8 @@ ap.add_argument("--fused-tail-sweep", action="store_true", help="repeat the time
 ap.add_argument("--restore", action="store_true", help="sweeps: restart every phase from the state the training left (same batches, same work)")
 ap.add_argument("--native", action="store_true", help="time ExpRunner::Train's own loop (fresh batches drawn on the device every iteration) instead of python-driven steps on resident batches")
 ap.add_argument("--depth", type=int, default=-1, help="sampling pipeline depth of the timed steps (1 / 2; default: the host's)")
+ap.add_argument("--draws-on-main", action="store_true", help="ExpRunner::Train's batch draws on the main queue (rounds 4-5) instead of the tail stream")
+ap.add_argument("--spec-start-event", action="store_true", help="keep the spec_start event at the top of a step although the draws are off the main queue")
 ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: repeat the timed steps once per value of an environment knob (knobs exist in the debug variant only: F2N_DEBUG_BUILD=1; most are read once per process)")
 args = ap.parse_args()
 st = fox_data.load_state()
@@ -32,6 +34,10 @@ if args.iters > 0:
     torch.cuda.synchronize(); _t0 = time.perf_counter()
     runner.train(ds, args.iters, 1)
     torch.cuda.synchronize(); print("trained %d iterations in %.2f s" % (args.iters, time.perf_counter() - _t0), flush=True)
+if args.draws_on_main:
+    runner.draws_off_main = False
+if args.spec_start_event:
+    runner.spec_start_without_event = False
 if args.speculation >= 0:
     runner.speculative_sampling = args.speculation
 R = max(16, runner.cur_batch_size())

@@ -13,6 +13,9 @@ import importlib.util
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--zero-frac", type=float, default=0.3)
+ap.add_argument("--amps", default="2e-4,0.05", help="standard deviations of the synthetic f16 gradients: a training's loss-scaled gradients sum to "
+                "~1 per table slice (f2n_debug_counters()[2] of the debug variant: 0.6 converged, 1.2 fresh), which 2e-4 reproduces; "
+                "0.05 drives every slice's sum of |addend| past the fixed-point route's range, i.e. times the owners' fp64 route")
 args = ap.parse_args()
 dev = "cuda"
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -45,14 +48,16 @@ def front_part(smp, keep):
 
 sets = {"converged, 47% of every ray": front_part(conv, 0.47), "converged, 24% of every ray": front_part(conv, 0.24),
         "fresh, all samples": (fresh["pts"], fresh["anchors"])}
-for name, (pts, anchors) in sets.items():
-    n = pts.shape[0]
-    g = (torch.randn((n, 32), device=dev) * 0.05).to(torch.float16)
-    g[torch.rand(n, device=dev) < args.zero_frac] = 0
-    table = torch.zeros(16 << (log2 + 1), dtype=torch.float16, device=dev)
-    f = lambda: capi.hash_bwd(n, nvol, prim, lidx, lsize, bias, scale, pts, True, anchors, 3, g, table, 1 << log2)
-    capi.debug_counters(reset=True)
-    ms = timeit(f, args.reps)
-    table.zero_(); f()
-    print("scatter_bench %-30s n %7d  %.4f ms per scatter (both kernels)  checksum of one scatter %d  records that fell back to atomics %d" %
-          (name, n, ms, int(table.view(torch.int32).to(torch.int64).sum()), capi.debug_counters()[0]), flush=True)
+for amp in [float(a) for a in args.amps.split(",")]:
+    for name, (pts, anchors) in sets.items():
+        n = pts.shape[0]
+        g = (torch.randn((n, 32), device=dev) * amp).to(torch.float16)
+        g[torch.rand(n, device=dev) < args.zero_frac] = 0
+        table = torch.zeros(16 << (log2 + 1), dtype=torch.float16, device=dev)
+        f = lambda: capi.hash_bwd(n, nvol, prim, lidx, lsize, bias, scale, pts, True, anchors, 3, g, table, 1 << log2)
+        ms = timeit(f, args.reps)
+        capi.debug_counters(reset=True)
+        table.zero_(); f()
+        c = capi.debug_counters()
+        print("scatter_bench gradients ~ N(0, %g^2)  %-30s n %7d  %.4f ms per scatter (both kernels)  checksum of one scatter %d  records applied by atomics %d  "
+              "slices summed on the fp64 route %d of %d" % (amp, name, n, ms, int(table.view(torch.int32).to(torch.int64).sum()), c[0], c[1], 17 * (1 << log2) // 8192), flush=True)
