@@ -1,0 +1,16 @@
+mkdir -p gpurun_out/s42
+O=gpurun_out/s42
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_refnum.py -x -q -k "hash_backward or step_tail or owner" 2>&1 | tail -3 > $O/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_converged.py tests/test_gpu_determinism.py -x -q 2>&1 | tail -3 >> $O/pytest.txt
+for rep in 1 2 3; do
+for v in cur wave; do
+  cp tools/probe/libf2n_hip_$v.so f2-nerf_amd/libf2n_hip.so
+  echo "== $v" >> $O/ab.txt
+  [ $rep = 1 ] && timeout 300 python tools/scatter_bench.py --reps 50 2>&1 | grep scatter_bench >> $O/ab.txt
+  timeout 300 python tools/converged_steps.py --native --steps 400 2>&1 | grep "native loop" | cut -c1-60 >> $O/ab.txt
+  [ $rep != 3 ] && timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-converged --other-configs 0 2>/dev/null | python -c "
+import sys, json
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('fresh', round(j['ms_per_step'],4), j['roofline']['timed_calls_ms_per_step'])" >> $O/ab.txt
+done
+done
+cp tools/probe/libf2n_hip_wave.so f2-nerf_amd/libf2n_hip.so
