@@ -394,7 +394,7 @@ def _scatter_counters():
     except Exception as e:  # (a diagnostic: never the reason a bench line is lost)
         return {"error": str(e)[:200]}
     import numpy as np
-    return {"records_applied_by_atomics": c[0], "slices_summed_in_fp64_instead_of_fixed_point": c[1],
+    return {"records_applied_by_atomics": c[0], "slices_summed_in_fp64_instead_of_fixed_point": c[1], "records_through_overflow_lists": c[3],
             # (debug variant of the library only; 0 otherwise) the largest sum of |addend| any slice's owner saw: the fixed-point route holds < 96
             "largest_slice_sum_of_abs_addends": float(np.array(c[2], np.int32).view(np.float32))}
 

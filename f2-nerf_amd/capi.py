@@ -69,7 +69,8 @@ def build_info():
 
 def debug_counters(reset=False):
     """Diagnostic event counters of the library (f2n_debug_counters): [0] = scatter records applied by the atomic fallback,
-    [1] = table slices whose owner summed in fp64 instead of its packed fixed-point image (same bits, slower)."""
+    [1] = table slices whose owner summed in fp64 instead of its packed fixed-point image (same bits, slower), [2] = (debug variant) the
+    largest per-slice sum of |addend| as float bits, [3] = records that travelled through an overflow list (exact, order-free)."""
     out = (ctypes.c_int32 * 8)()
     torch.cuda.synchronize()
     _ck(lib().f2n_debug_counters(out, _i(1 if reset else 0)), "f2n_debug_counters")

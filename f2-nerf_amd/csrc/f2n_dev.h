@@ -116,7 +116,8 @@ int f2n_defer_reduction(int n, int n_blocks, const float* partials, float* out);
 #define F2N_WS_MLPG_ACTS 9  // ... saved activations and hidden gradients (tile-transposed f16)
 #define F2N_WS_MLPG_DW 10   // ... per-block partial weight gradients
 #define F2N_WS_GATHER_BINS 11  // field.hip: request / result queues and slot lists of the slice-binned gather (big tables)
-#define F2N_WS_SLOTS 12
+#define F2N_WS_BIN_OVF 12      // field.hip: the scatter's overflow lists (records that found their queue segment full)
+#define F2N_WS_SLOTS 13
 // mlp_generic.hip: the tcnn FullyFusedMLP shapes the two specialised kernels do not cover
 bool f2n_mlpg_shape_ok(int d_in, int d_hidden, int n_hidden);
 int f2n_mlpg_fwd(void* stream, int n, int d_in, int d_hidden, int n_hidden, const void* params_h, const float* x, void* out_h);

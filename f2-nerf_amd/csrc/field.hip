@@ -4,6 +4,7 @@
 // the K-slots of the MFMA fragment it has to supply (mlp_dev.h), so features go from the L2/Infinity-Cache
 // resident table straight into matrix-core operands: no LDS staging, no HBM round trip of the [n,32] features.
 #include <math.h>
+#include <atomic>
 #include <string.h>
 
 #include "adam_dev.h"
@@ -670,7 +671,7 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 // and adds the image to the f16 gradient table with plain loads and stores; nobody else touches those entries.
 // Level l addresses table pairs [l*E/2, l*E/2 + E) (E = entries per level, the reference's 50% level overlap,
 // Hash3DAnchored.cpp:60-70), so a table slice receives records from at most two levels.
-// A full segment (cannot happen for hashed positions short of adversarial input) falls back to the atomic.
+// A full segment (the hot slices of a big table's coarse levels) sends the record to its producer block's overflow list (F2nBinQueues).
 // ---------------------------------------------------------------------------------------------------
 #define F2N_BIN_SHIFT 12
 #define F2N_BIN_ENTRIES (1 << F2N_BIN_SHIFT)
@@ -684,10 +685,13 @@ __device__ __forceinline__ int f2n_bin_nb(int n_true, int force = 0) {
   return force > 0 ? force : n_true > 393216 ? 128 : n_true > 131072 ? 64 : 32;
 }
 #define F2N_BIN_MAX_BINS 1024  // tables up to 2^22 entries per level (BASELINE config 5)
+#define F2N_BIN_OVF_CAP 4096   // records per overflow list (32 KB; 64 MB of address space for the 2048 lists, touched only where used)
 #define F2N_BIN_MAX_CHUNK 16384  // samples per producer block (the compacted index list lives in LDS)
 
-// Diagnostic counters (f2n_debug_counters): [0] scatter records that found their queue segment full and fell back to the
-// packed-f16 global atomic -- the one place where the owner-binned scatter's result depends on the order of arrival.
+// Diagnostic counters (f2n_debug_counters): [0] scatter records that found their queue segment AND their block's overflow list full
+// and fell back to the packed-f16 global atomic -- the one place where the owner-binned scatter's result depends on the order of
+// arrival; [1] slices summed on the owners' fp64 route; [2] (debug variant) the largest per-slice sum of |addend|; [3] records that
+// travelled through an overflow list.
 __device__ int f2n_dbg_counters[8];
 
 struct F2nBinQueues {
@@ -695,6 +699,15 @@ struct F2nBinQueues {
   int32_t* cnt;    // [16 levels][n_bins][NB]
   int cap, n_bins;
   int nb_force;  // 0, or the chunk count to use whatever the sample count (F2N_BIN_NB: measurement knob)
+  // OVERFLOW LISTS (round 6).  A record that finds its segment full -- the coarse levels of a big table put a chunk's records into a
+  // few hundred hot slices -- goes to the private list of its producer block (level, chunk) with its full position instead of to a
+  // packed-f16 atomic (whose sum depends on the order of arrival: ~130 records per step at 2^22 entries per level).  A level whose
+  // producers overflowed in THIS launch carries the launch's stamp in ovf_any[level] (no zeroing pass); only then do that level's
+  // owners read the lists' lengths and pick their slice's records out of the non-empty ones.
+  uint2* ovf_rec;    // [16 levels][F2N_BIN_NB][F2N_BIN_OVF_CAP]  {entry index inside the LEVEL, packed f16 pair}
+  int32_t* ovf_cnt;  // [16 levels][F2N_BIN_NB]
+  int32_t* ovf_any;  // [16 levels]
+  int stamp;         // this launch (never 0)
   int force_f64;  // != 0: the owners sum every slice on their fp64 route (F2N_OWNER_F64: test knob of the debug variant)
 };
 
@@ -716,10 +729,11 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   __shared__ F2nLevelTab lt;
   __shared__ int s_cnt[F2N_BIN_MAX_BINS];
   __shared__ uint16_t s_idx[F2N_BIN_MAX_CHUNK];  // offsets (inside the chunk) of the samples with a non-zero gradient
-  __shared__ int s_wave_tot[4], s_n_nz;
+  __shared__ int s_wave_tot[4], s_n_nz, s_ovf;
   const int tid = threadIdx.x, c = tid & 15;
   f2n_level_tab_fill(lt, level_scale, local_idx, local_size, tid);
   for (int i = tid; i < q.n_bins; i += 256) s_cnt[i] = 0;
+  if (tid == 0) s_ovf = 0;
   __syncthreads();
   const int s_begin = B * chunk, s_end = min(n, s_begin + chunk);
   const half_t* gl = gx + (size_t) (l >> 1) * gx_pair_stride + 2 * (l & 1);
@@ -806,8 +820,13 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
               r.y = bits;
               my_rec[(size_t) bin * bin_stride + slot] = r;
             } else {
-              atomicAdd(&f2n_dbg_counters[0], 1);
-              __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (tab + pos), val);
+              const int os = atomicAdd(&s_ovf, 1);
+              if (os < F2N_BIN_OVF_CAP) {
+                q.ovf_rec[((size_t) l * F2N_BIN_NB + B) * F2N_BIN_OVF_CAP + os] = uint2{pos, bits};
+              } else {  // (an overflow list full as well: the one order-dependent addition that is left, counted)
+                atomicAdd(&f2n_dbg_counters[0], 1);
+                __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*) (tab + pos), val);
+              }
             }
           }
         }
@@ -817,6 +836,13 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   }
   __syncthreads();
   for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) l * q.n_bins + i) * nb + B] = min(s_cnt[i], cap_nb);
+  if (tid == 0) {
+    q.ovf_cnt[l * F2N_BIN_NB + B] = min(s_ovf, F2N_BIN_OVF_CAP);
+    if (s_ovf > 0) {
+      q.ovf_any[l] = q.stamp;  // (every writer of a launch stores the same value)
+      atomicAdd(&f2n_dbg_counters[3], min(s_ovf, F2N_BIN_OVF_CAP));
+    }
+  }
 }
 
 // ADAM (round 6; f2n_field_bwd_step_tail): the owner does not write its slice's sums to the gradient table for a streaming
@@ -907,6 +933,23 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
   F2nOwnerRound ro0;
   if (ADAM) f2n_owner_fetch(ro0, tab, ad, (size_t) g * F2N_BIN_ENTRIES, tid, skip, true, false);
   bool packed = total != 0;  // the image holds this slice's sums (block-uniform)
+  // overflow lists (F2nBinQueues): only when a producer of one of this slice's two levels overflowed in this launch
+  const bool ovf = (l1 < F2N_N_LEVELS && q.ovf_any[min(l1, F2N_N_LEVELS - 1)] == q.stamp) || (l1 >= 1 && q.ovf_any[max(l1 - 1, 0)] == q.stamp);
+  auto for_overflow = [&](auto&& f) {
+    if (!ovf) return;  // (block-uniform)
+    const int my_ocnt = live ? q.ovf_cnt[l * F2N_BIN_NB + B] : 0;  // lane j of wave w: the list of segment w + 4j's producer block
+    unsigned long long m = __ballot(my_ocnt > 0);
+    while (m != 0ull) {
+      const int j = __ffsll((long long) m) - 1;
+      m &= m - 1ull;
+      const int cnt = __shfl(my_ocnt, j), bj = __shfl(bl, j);
+      const uint2* r = q.ovf_rec + (size_t) __shfl(l * F2N_BIN_NB + B, j) * F2N_BIN_OVF_CAP;
+      for (int i = lane; i < cnt; i += 64) {
+        const uint2 rec = r[i];
+        if ((int) (rec.x >> F2N_BIN_SHIFT) == bj) f(uint2{rec.x & (F2N_BIN_ENTRIES - 1), rec.y});
+      }
+    }
+  };
   if (total != 0) {
     for (int i = tid; i < F2N_BIN_ENTRIES; i += 256) s_acc[i] = 0ull;
     __syncthreads();
@@ -948,6 +991,7 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
         }
       }
     }
+    for_overflow(add);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mag += __shfl_xor(mag, off);
     if (lane == 0) s_mag[wave] = mag;
@@ -975,6 +1019,7 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
             atomicAdd(&s_f64[rec.x], (double) val[ch]);
           }
         }
+        for_overflow([&](uint2 rec) { atomicAdd(&s_f64[rec.x], (double) __builtin_bit_cast(half2_t, rec.y)[ch]); });
         __syncthreads();
         for (int e = tid; e < F2N_BIN_ENTRIES; e += 256) {
           const double a = s_f64[e];
@@ -1376,7 +1421,13 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   const size_t n_seg = (size_t) F2N_N_LEVELS * q.n_bins * F2N_BIN_NB;
   q.rec = (uint2*) f2n_ws_get(F2N_WS_BIN_REC, n_seg * q.cap * sizeof(uint2));
   q.cnt = (int32_t*) f2n_ws_get(F2N_WS_BIN_CNT, n_seg * sizeof(int32_t));
-  if (q.rec == nullptr || q.cnt == nullptr) return F2N_ERR_INVALID_ARG;
+  const size_t n_lists = (size_t) F2N_N_LEVELS * F2N_BIN_NB;
+  q.ovf_rec = (uint2*) f2n_ws_get(F2N_WS_BIN_OVF, n_lists * F2N_BIN_OVF_CAP * sizeof(uint2) + (n_lists + F2N_N_LEVELS) * sizeof(int32_t));
+  if (q.rec == nullptr || q.cnt == nullptr || q.ovf_rec == nullptr) return F2N_ERR_INVALID_ARG;
+  q.ovf_cnt = (int32_t*) (q.ovf_rec + n_lists * F2N_BIN_OVF_CAP);
+  q.ovf_any = q.ovf_cnt + n_lists;
+  static std::atomic<int> g_scatter_stamp{0};
+  q.stamp = (g_scatter_stamp.fetch_add(1) & 0x3fffffff) + 1;  // (the workspace starts out zeroed: never a launch's stamp)
   hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
                      level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table, n_dev, n_off);
   const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels

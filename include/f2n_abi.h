@@ -72,7 +72,10 @@ int f2n_set_scatter_buckets_for(int n_buckets, f2n_bucket_fn fn, void* user, con
  * optionally reset.  [0] = scatter records of f2n_hash_bwd's owner-binned path that found their queue segment full and were
  * applied by a packed-f16 atomic instead (the only order-dependent addition of that path); [1] = table slices whose owner left
  * its packed fixed-point image for exact fp64 sums because the slice's addends could have left the 32-bit fields' range (same
- * bits either way: a cost counter, not an error counter).  The rest are reserved (0). */
+ * bits either way: a cost counter, not an error counter); [2] (debug variant only) = the largest sum of |addend| an owner saw in
+ * a slice, as float bits; [3] = scatter records that found their queue segment full and travelled through their producer block's
+ * overflow list instead (summed by the owners like every other record: order-free; [0] counts only what found that list full
+ * too).  The rest are reserved (0). */
 int f2n_debug_counters(int32_t* out8_host /* or NULL */, int reset);
 /* (The two debugging launches of rounds 3-4 -- a delay on a stream, a launch that leaves garbage in every CU's LDS and registers
  * -- are not part of this ABI: include/f2n_debug.h, compiled into the debug variant of the library only.) */

@@ -516,6 +516,37 @@ def test_hash_backward_owner_binned(hip, fox_state, log2):
     assert np.abs(N(g_binned).astype(F32) - 2 * ref32).max() <= 2.0 ** -8 * np.abs(ref32).max()
 
 
+@pytest.mark.parametrize("log2", [16, 22])
+def test_hash_backward_overflow_lists_keep_the_sums_order_free(hip, fox_state, log2):
+    """Records that find their queue segment full (round 6): every sample inside one tiny cube, consecutive samples in alternating
+    transforms so that no run combines -- a level's 8 x chunk records go to 16 table entries, i.e. to a few slices, far more than a
+    segment's share.  They travel through their producer block's overflow list and are summed by the owners like every other record:
+    no packed-f16 atomic (f2n_debug_counters()[0] stays 0), the table within f16 resolution of the fp32-accumulated oracle, and two
+    scatters of the same input leave the same bits."""
+    rng = np.random.default_rng(77)
+    grid = make_grid(fox_state, rng, log2, zeros=True)
+    n = 32768 + 1024 + 5
+    q = (F32(0.371) + rng.random((n, 3), dtype=F32) * F32(2e-4)).astype(F32)
+    vol = (np.arange(n) % 2).astype(np.int32)
+    gin = (rng.standard_normal((n, 32)) * 0.01).astype(np.float16)
+    gd = grid_dev(grid)
+    args = (n, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(q), False, T(vol), 1, T(gin))
+    tabs = []
+    hip.debug_counters(reset=True)
+    for _ in range(2):
+        g_binned = torch.zeros(grid.table_f32.size, dtype=torch.float16, device=DEV)
+        hip.hash_bwd(*args, g_binned, 1 << log2)
+        tabs.append(N(g_binned).view(np.uint16).copy())
+    c = hip.debug_counters()
+    assert c[0] == 0 and c[3] > 0, c  # nothing through the atomics, something through the lists
+    assert (tabs[0] == tabs[1]).all()
+    ref32 = oc.hash_bwd(grid.table_f32.size, grid.prim_pool, grid.local_idx, grid.local_size, grid.bias_pool, q, vol,
+                        grid.n_volumes, gin.view(np.uint16), fp32_accumulate=True)
+    got = tabs[0].view(np.float16).astype(F32)
+    assert ((got != 0) == (ref32 != 0)).all()
+    assert np.abs(got - ref32).max() <= 2.0 ** -9 * np.abs(ref32).max(), float(np.abs(got - ref32).max())
+
+
 # ---------------------------------------------------------------------------------------------------
 # MLP
 # ---------------------------------------------------------------------------------------------------

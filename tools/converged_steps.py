@@ -93,10 +93,10 @@ if args.native:
     hp = runtime.host().ExpRunner.host_profile(False)
     print("host thread, us per iteration: " + "  ".join("%s %.1f (x%.1f)" % (k, v[1] / args.steps * 1e6, v[0] / args.steps) for k, v in sorted(hp.items())))
     c1 = runner.counters()
-    print("native loop: %.3f ms/step  marched/step %d meaningful/step %d nodes %d  spec %s  scatter [atomic records, fp64 slices] %s" % (
+    print("native loop: %.3f ms/step  marched/step %d meaningful/step %d nodes %d  spec %s  scatter [atomic records, fp64 slices, largest slice sum, overflow-list records] %s" % (
         el / args.steps * 1e3, (c1["total_marched"] - c0["total_marched"]) // args.steps,
         (c1["total_meaningful"] - c0["total_meaningful"]) // args.steps, runner.n_nodes(), dict(runner.speculation_counters()),
-        _capi.debug_counters()[:2] + [float(np.array(_capi.debug_counters()[2], np.int32).view(np.float32))]), flush=True)
+        _capi.debug_counters()[:2] + [float(np.array(_capi.debug_counters()[2], np.int32).view(np.float32)), _capi.debug_counters()[3]]), flush=True)
 elif args.march_blocks_sweep:
     for rep in range(2):
         for v in args.march_blocks_sweep.split(","):
