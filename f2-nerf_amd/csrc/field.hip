@@ -711,6 +711,10 @@ struct F2nBinQueues {
   int force_f64;  // != 0: the owners sum every slice on their fp64 route (F2N_OWNER_F64: test knob of the debug variant)
 };
 
+// OVF: with overflow lists (F2nBinQueues) -- tables of more than 2^19 entries per level, where segments do fill up (f2n_bin_ovf); the
+// benched 2^19 tables keep the code without them (their trainings never filled a segment, and the lists' code, cold as it is, cost the
+// converged step ~5 us: 0.678-0.682 against 0.667-0.674 ms).
+template <bool OVF>
 __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHashArgs h, const int32_t* __restrict__ local_idx,
                                                        const int32_t* __restrict__ local_size,
                                                        const float* __restrict__ level_scale, const float* __restrict__ pts,
@@ -820,8 +824,8 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
               r.y = bits;
               my_rec[(size_t) bin * bin_stride + slot] = r;
             } else {
-              const int os = atomicAdd(&s_ovf, 1);
-              if (os < F2N_BIN_OVF_CAP) {
+              const int os = OVF ? atomicAdd(&s_ovf, 1) : F2N_BIN_OVF_CAP;
+              if (OVF && os < F2N_BIN_OVF_CAP) {
                 q.ovf_rec[((size_t) l * F2N_BIN_NB + B) * F2N_BIN_OVF_CAP + os] = uint2{pos, bits};
               } else {  // (an overflow list full as well: the one order-dependent addition that is left, counted)
                 atomicAdd(&f2n_dbg_counters[0], 1);
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   }
   __syncthreads();
   for (int i = tid; i < q.n_bins; i += 256) q.cnt[((size_t) l * q.n_bins + i) * nb + B] = min(s_cnt[i], cap_nb);
-  if (tid == 0) {
+  if (OVF && tid == 0) {
     q.ovf_cnt[l * F2N_BIN_NB + B] = min(s_ovf, F2N_BIN_OVF_CAP);
     if (s_ovf > 0) {
       q.ovf_any[l] = q.stamp;  // (every writer of a launch stores the same value)
@@ -894,7 +898,7 @@ __device__ __forceinline__ void f2n_owner_fetch(F2nOwnerRound& r, const half2_t*
 #define F2N_OWNER_FIXED_ONE 16777216.f  // 2^24
 #define F2N_OWNER_MAG_LIMIT 96.f
 
-template <bool ADAM>
+template <bool ADAM, bool OVF>
 __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueues q, int slices_per_half_level,
                                                                   half_t* __restrict__ grad_table, int n,
                                                                   const int32_t* __restrict__ n_dev, int n_off, int first_slice,
@@ -934,9 +938,9 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
   if (ADAM) f2n_owner_fetch(ro0, tab, ad, (size_t) g * F2N_BIN_ENTRIES, tid, skip, true, false);
   bool packed = total != 0;  // the image holds this slice's sums (block-uniform)
   // overflow lists (F2nBinQueues): only when a producer of one of this slice's two levels overflowed in this launch
-  const bool ovf = (l1 < F2N_N_LEVELS && q.ovf_any[min(l1, F2N_N_LEVELS - 1)] == q.stamp) || (l1 >= 1 && q.ovf_any[max(l1 - 1, 0)] == q.stamp);
+  const bool ovf = OVF && ((l1 < F2N_N_LEVELS && q.ovf_any[min(l1, F2N_N_LEVELS - 1)] == q.stamp) || (l1 >= 1 && q.ovf_any[max(l1 - 1, 0)] == q.stamp));
   auto for_overflow = [&](auto&& f) {
-    if (!ovf) return;  // (block-uniform)
+    if (!OVF || !ovf) return;  // (block-uniform)
     const int my_ocnt = live ? q.ovf_cnt[l * F2N_BIN_NB + B] : 0;  // lane j of wave w: the list of segment w + 4j's producer block
     unsigned long long m = __ballot(my_ocnt > 0);
     while (m != 0ull) {
@@ -1428,8 +1432,18 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   q.ovf_any = q.ovf_cnt + n_lists;
   static std::atomic<int> g_scatter_stamp{0};
   q.stamp = (g_scatter_stamp.fetch_add(1) & 0x3fffffff) + 1;  // (the workspace starts out zeroed: never a launch's stamp)
-  hipLaunchKernelGGL(hash_bin_kernel, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
-                     level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table, n_dev, n_off);
+  const bool ovf = level_entries > (1 << 19);  // (see hash_bin_kernel)
+  if (ovf)
+    hipLaunchKernelGGL(hash_bin_kernel<true>, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
+                       level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table, n_dev, n_off);
+  else
+    hipLaunchKernelGGL(hash_bin_kernel<false>, dim3(F2N_N_LEVELS * F2N_BIN_NB), dim3(256), 0, st, n, chunk, h, local_idx, local_size,
+                       level_scale, pts, warped, volume_idx, vol_stride, gx, ss, ps, nz_mask, q, grad_table, n_dev, n_off);
+#define F2N_LAUNCH_OWNERS(ADAM_, GRID, FIRST, AD)                                                                                         \
+  do {                                                                                                                                    \
+    if (ovf) hipLaunchKernelGGL((hash_bin_accumulate_kernel<ADAM_, true>), dim3(GRID), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, FIRST, AD);  \
+    else hipLaunchKernelGGL((hash_bin_accumulate_kernel<ADAM_, false>), dim3(GRID), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, FIRST, AD);     \
+  } while (0)
   const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels
   // Data-parallel runs ask for the owner launch in BUCKETS of table slices (f2n_set_scatter_buckets): after each bucket's launch the
   // host is called back and starts that range's all-reduce while the next bucket's owners still run.
@@ -1440,7 +1454,7 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   if (hook.fn != nullptr && hook.n > 1 && S >= hook.n && (hook.table == nullptr || hook.table == (const void*) grad_table)) {
     for (int b = 0; b < hook.n; b++) {
       const int g0 = (int) ((long) b * S / hook.n), g1 = (int) ((long) (b + 1) * S / hook.n);
-      hipLaunchKernelGGL(hash_bin_accumulate_kernel<false>, dim3(g1 - g0), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, g0, F2nOwnerAdam{});
+      F2N_LAUNCH_OWNERS(false, g1 - g0, g0, F2nOwnerAdam{});
       const int rc = f2n_launch_status();
       if (rc != F2N_OK) return rc;
       hook.fn(hook.user, b, hook.n);
@@ -1449,11 +1463,12 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
   }
   if (adam != nullptr) {  // (no bucket hook on this table: checked above)
     if (wait_before_owners != nullptr && hipStreamWaitEvent(st, wait_before_owners, 0) != hipSuccess) return F2N_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(hash_bin_accumulate_kernel<true>, dim3(S), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, 0, *adam);
+    F2N_LAUNCH_OWNERS(true, S, 0, *adam);
     if (adam_applied != nullptr) *adam_applied = 1;
     return f2n_launch_status();
   }
-  hipLaunchKernelGGL(hash_bin_accumulate_kernel<false>, dim3(S), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, 0, F2nOwnerAdam{});
+  F2N_LAUNCH_OWNERS(false, S, 0, F2nOwnerAdam{});
+#undef F2N_LAUNCH_OWNERS
   return f2n_launch_status();
 }
 

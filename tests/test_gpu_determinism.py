@@ -24,6 +24,10 @@ MODES = {
     "always_two_ahead":   (1, 3, True, ITERS),
     "auto_two_ahead_full_repair_chunks_of_37": (2, 3, False, 37),
     "default_chunks_of_100": (2, 2, True, 100),
+    # (round 6) ExpRunner::Train draws its batches on the tail stream; here on the main queue as in rounds 4-5, and on the tail
+    # stream with the spec_start event kept
+    "default_draws_on_the_main_queue": (2, 2, True, ITERS, False, True),
+    "two_ahead_draws_off_main_with_the_start_event": (1, 3, True, 61, True, False),
 }
 
 
@@ -42,12 +46,15 @@ def fox_scene():
 def _train(fox_scene, mode):
     from f2_nerf_amd import runtime
     st, sc, images = fox_scene
-    spec, depth, tail, chunk = MODES[mode]
+    spec, depth, tail, chunk = MODES[mode][:4]
+    draws_off_main, no_start_event = (MODES[mode][4:] + (True, True))[:2]
     ds = runtime.make_dataset(sc, images)
     runner, cfg, _ = runtime.make_runner(st, "wanjinyou", ["train.end_iter=20000"], seed=2022)
     runner.speculative_sampling = spec
     runner.speculation_depth = depth
     runner.tail_repair = tail
+    runner.draws_off_main = draws_off_main
+    runner.spec_start_without_event = no_start_event
     runner.digest_table = True
     torch.manual_seed(2022)
     it = 0

@@ -516,18 +516,18 @@ def test_hash_backward_owner_binned(hip, fox_state, log2):
     assert np.abs(N(g_binned).astype(F32) - 2 * ref32).max() <= 2.0 ** -8 * np.abs(ref32).max()
 
 
-@pytest.mark.parametrize("log2", [16, 22])
+@pytest.mark.parametrize("log2", [20, 22])
 def test_hash_backward_overflow_lists_keep_the_sums_order_free(hip, fox_state, log2):
-    """Records that find their queue segment full (round 6): every sample inside one tiny cube, consecutive samples in alternating
-    transforms so that no run combines -- a level's 8 x chunk records go to 16 table entries, i.e. to a few slices, far more than a
-    segment's share.  They travel through their producer block's overflow list and are summed by the owners like every other record:
+    """Records that find their queue segment full (round 6; tables of more than 2^19 entries per level): every sample inside one tiny
+    cube, consecutive samples in four alternating transforms so that no run combines -- a level's 8 x chunk records go to 32 table
+    entries, i.e. to a few slices, more than a segment's share.  They travel through their producer block's overflow list and are summed by the owners like every other record:
     no packed-f16 atomic (f2n_debug_counters()[0] stays 0), the table within f16 resolution of the fp32-accumulated oracle, and two
     scatters of the same input leave the same bits."""
     rng = np.random.default_rng(77)
     grid = make_grid(fox_state, rng, log2, zeros=True)
     n = 32768 + 1024 + 5
     q = (F32(0.371) + rng.random((n, 3), dtype=F32) * F32(2e-4)).astype(F32)
-    vol = (np.arange(n) % 2).astype(np.int32)
+    vol = (np.arange(n) % 4).astype(np.int32)
     gin = (rng.standard_normal((n, 32)) * 0.01).astype(np.float16)
     gd = grid_dev(grid)
     args = (n, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(q), False, T(vol), 1, T(gin))
@@ -1270,10 +1270,11 @@ def test_adam_fused_equals_separate_launches(hip):
             assert_same(N(tb2["p"]), tab["p"])
 
 
-@pytest.mark.parametrize("n_use,bad,side,dirty,leave", [(40000, False, False, False, False), (40000, False, True, True, False), (40000, True, True, False, False),
-                                                         (33000, False, False, True, False), (900, False, True, False, False), (900, True, False, False, False),
-                                                         (40000, False, True, True, True), (40000, True, False, False, True)])
-def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, bad, side, dirty, leave):
+@pytest.mark.parametrize("n_use,bad,side,dirty,leave,amp", [(40000, False, False, False, False, 1e-3), (40000, False, True, True, False, 1e-3), (40000, True, True, False, False, 1e-3),
+                                                             (33000, False, False, True, False, 1e-3), (900, False, True, False, False, 1e-3), (900, True, False, False, False, 1e-3),
+                                                             (40000, False, True, True, True, 1e-3), (40000, True, False, False, True, 1e-3),
+                                                             (33000, False, False, True, False, 1e-6), (40000, False, True, False, False, 1e-6)])
+def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, bad, side, dirty, leave, amp):
     """f2n_field_bwd_step_tail (round 6) -- the field backward with the REST of the training step re-ordered around its scatter:
     deferred reductions, finiteness flags and the small groups' Adam behind the field-MLP backward (on a second stream when one is
     given), the hash table's Adam applied by the scatter's owner blocks to the slices they have just summed -- leaves every
@@ -1294,7 +1295,9 @@ def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, b
     n = n_use
     ph = T(oc.f2h(fparams).view(np.float16))
     sx = T(oc.f2h((rng.standard_normal((n, 32)) * 0.3).astype(F32)).view(np.float16))
-    dfeat = (rng.standard_normal((n, 16)) * 1e-3).astype(F32)
+    # amp (round 6): 1e-3 puts ~500 of |addend| into each of this small table's 68 slices -- the owners leave their fixed-point image for
+    # the fp64 route, with and without the table's Adam --, 1e-6 keeps them on it (f2n_debug_counters()[1])
+    dfeat = (rng.standard_normal((n, 16)) * amp).astype(F32)
     if bad:
         dfeat[7, 3] = np.inf
     n_tab = 17 << LOG2
@@ -1323,6 +1326,7 @@ def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, b
         args = (n, None, 0, grid.n_volumes, gd["prim"], gd["lidx"], gd["lsize"], gd["bias"], gd["scale"], T(pts), T(anchors), 3, ph, sx, T(dfeat), 128.0,
                 grads[0], gtab, 1 << LOG2)
         hip.deferred_reset()
+        hip.debug_counters(reset=True)
         by_owners = None
         called = []
         if fused:
@@ -1342,6 +1346,9 @@ def test_step_tail_equals_separate_launches(hip, fox_state, fox_golden, n_use, b
                            7, 3e-3, 0.9, 0.99, 1e-15, True, flags[2:3])
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+        if n_use >= 32768:  # (the binned scatter ran: which route its owners took)
+            f64_slices = hip.debug_counters()[1]
+            assert (f64_slices == 0) if (amp < 1e-5 and not bad) else (f64_slices > 0), (fused, amp, f64_slices)
         out.append((grp, grads, hs, tb, th, gtab, flags, by_owners))
     (ga, gra, ha, ta, tha, gta, fa, _), (gb, grb, hb, tb2, thb, gtb, fb, by_owners) = out
     assert by_owners == (1 if (n_use >= 32768 and not leave) else 0)
