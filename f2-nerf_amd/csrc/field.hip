@@ -667,7 +667,8 @@ __device__ __forceinline__ void f2n_scatter_frag(const F2nHashArgs& h, const F2n
 // samples, combines runs, and appends every non-zero contribution as an 8-byte record {entry index inside its
 // 4096-entry slice, packed f16 pair} to the private queue segment (l, slice, B) -- slots come from LDS integer
 // counters, so no global atomic and no synchronisation between blocks.  (2) hash_bin_accumulate_kernel: one owner
-// block per 4096-entry slice of the TABLE sums every record that lands there into a 64 KB fp64 LDS image (ds_add_f64)
+// block per 4096-entry slice of the TABLE sums every record that lands there into an LDS image (round 6: a packed fixed-point image,
+// one ds_add_u64 per record -- THE IMAGE below; rounds 1-5: 64 KB of fp64 pairs, two ds_add_f64 per record)
 // and adds the image to the f16 gradient table with plain loads and stores; nobody else touches those entries.
 // Level l addresses table pairs [l*E/2, l*E/2 + E) (E = entries per level, the reference's 50% level overlap,
 // Hash3DAnchored.cpp:60-70), so a table slice receives records from at most two levels.
