@@ -710,6 +710,8 @@ struct F2nBinQueues {
   int32_t* ovf_any;  // [16 levels]
   int stamp;         // this launch (never 0)
   int force_f64;  // != 0: the owners sum every slice on their fp64 route (F2N_OWNER_F64: test knob of the debug variant)
+  int dissect;    // debug variant, timing only (F2N_BIN_DISSECT; results are garbage): 1 = the producers do everything but the record stores, 2 = neither slot atomics nor stores, +4 = no owner launch
+  int producer_major;  // record layout: 1 = [level][chunk][slice][slot] (a producer block's 128 segments contiguous), 0 = [level][slice][chunk][slot] (an owner's, rounds 1-5)
 };
 
 // OVF: with overflow lists (F2nBinQueues) -- tables of more than 2^19 entries per level, where segments do fill up (f2n_bin_ovf); the
@@ -743,8 +745,9 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
   const int s_begin = B * chunk, s_end = min(n, s_begin + chunk);
   const half_t* gl = gx + (size_t) (l >> 1) * gx_pair_stride + 2 * (l & 1);
   half2_t* tab = (half2_t*) (grad_table + lt.base[l]);
-  uint2* my_rec = q.rec + ((size_t) l * q.n_bins * nb + B) * cap_nb;  // segment (l, bin, B) = my_rec + bin * bin_stride
-  const size_t bin_stride = (size_t) nb * cap_nb;
+  // segment (l, bin, B) = my_rec + bin * bin_stride
+  uint2* my_rec = q.producer_major ? q.rec + ((size_t) l * nb + B) * q.n_bins * cap_nb : q.rec + ((size_t) l * q.n_bins * nb + B) * cap_nb;
+  const size_t bin_stride = q.producer_major ? (size_t) cap_nb : (size_t) nb * cap_nb;
   // Samples whose whole f16 gradient is zero (most of them while the loss-scaled gradients sit at the f16 underflow
   // boundary) are dropped up front: nz_mask has one bit per sample (16-sample words, written by the MLP backward).
   // Order is preserved, so runs of equal cells stay adjacent.
@@ -818,7 +821,19 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
           if ((bits & 0x7fff7fffu) != 0u) {  // not (+-0, +-0)
             const uint32_t pos = cell.pos[d];
             const int bin = (int) (pos >> F2N_BIN_SHIFT);
+#if F2N_DEBUG_BUILD
+            if ((q.dissect & 3) == 2) {
+              if ((pos ^ bits) == 0x12345u) s_cnt[bin] = 1;  // (keeps the record's operands alive)
+              continue;
+            }
+#endif
             const int slot = atomicAdd(&s_cnt[bin], 1);
+#if F2N_DEBUG_BUILD
+            if ((q.dissect & 3) == 1) {
+              if (((unsigned) slot ^ pos ^ bits) == 0x12345u) s_cnt[bin] = 1;
+              continue;
+            }
+#endif
             if (slot < cap_nb) {
               uint2 r;
               r.x = pos & (F2N_BIN_ENTRIES - 1);
@@ -923,6 +938,8 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
   const bool live = seg < 2 * nb && l >= 0 && l < F2N_N_LEVELS && bl < q.n_bins;
   const size_t my_seg = ((size_t) (live ? l : 0) * q.n_bins + (live ? bl : 0)) * nb + (live ? B : 0);
   const int my_cnt = live ? q.cnt[my_seg] : 0;
+  // where that segment's records are (F2nBinQueues::producer_major), in records / cap_nb
+  const unsigned my_rseg = q.producer_major ? (unsigned) (((live ? l : 0) * nb + (live ? B : 0)) * q.n_bins + (live ? bl : 0)) : (unsigned) my_seg;
   if (tid == 0) s_total = 0;
   __syncthreads();
   int wsum = my_cnt;
@@ -981,7 +998,7 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int cnt = __shfl(my_cnt, sg + u);
-        const uint2* r = q.rec + (size_t) __shfl((unsigned) my_seg, sg + u) * cap_nb;
+        const uint2* r = q.rec + (size_t) __shfl(my_rseg, sg + u) * cap_nb;
         longest = max(longest, cnt);
 #pragma unroll
         for (int k = 0; k < 4; k++) rec[4 * u + k] = lane + 64 * k < cnt ? r[lane + 64 * k] : uint2{0u, 0u};
@@ -991,7 +1008,7 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
       if (longest > 256) {  // long segments: the rest (wave-uniform)
         for (int u = 0; u < 8; u++) {
           const int cnt = __shfl(my_cnt, sg + u);
-          const uint2* r = q.rec + (size_t) __shfl((unsigned) my_seg, sg + u) * cap_nb;
+          const uint2* r = q.rec + (size_t) __shfl(my_rseg, sg + u) * cap_nb;
           for (int i = lane + 256; i < cnt; i += 64) add(r[i]);
         }
       }
@@ -1017,7 +1034,7 @@ __global__ __launch_bounds__(256, 4) void hash_bin_accumulate_kernel(F2nBinQueue
         __syncthreads();
         for (int sg = 0; sg < nb / 2; sg++) {
           const int cnt = __shfl(my_cnt, sg);
-          const uint2* r = q.rec + (size_t) __shfl((unsigned) my_seg, sg) * cap_nb;
+          const uint2* r = q.rec + (size_t) __shfl(my_rseg, sg) * cap_nb;
           for (int i = lane; i < cnt; i += 64) {
             const uint2 rec = r[i];
             const half2_t val = __builtin_bit_cast(half2_t, rec.y);
@@ -1414,9 +1431,21 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
     return e != nullptr && atoi(e) != 0 ? 1 : 0;
   }();
   q.force_f64 = force_f64;
+  static const int dissect = []() {
+    const char* e = getenv("F2N_BIN_DISSECT");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  q.dissect = dissect;
+  static const int layout = []() {
+    const char* e = getenv("F2N_BIN_LAYOUT");
+    return e != nullptr ? atoi(e) : 1;
+  }();
+  q.producer_major = layout;
 #else
   q.nb_force = 0;
   q.force_f64 = 0;
+  q.dissect = 0;
+  q.producer_major = 1;
 #endif
 
 
@@ -1445,6 +1474,9 @@ static int f2n_binned_scatter(hipStream_t st, int n, const F2nHashArgs& h, const
     if (ovf) hipLaunchKernelGGL((hash_bin_accumulate_kernel<ADAM_, true>), dim3(GRID), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, FIRST, AD);  \
     else hipLaunchKernelGGL((hash_bin_accumulate_kernel<ADAM_, false>), dim3(GRID), dim3(256), 0, st, q, H, grad_table, n, n_dev, n_off, FIRST, AD);     \
   } while (0)
+#if F2N_DEBUG_BUILD
+  if (q.dissect & 4) return f2n_launch_status();  // (timing only: the producers alone)
+#endif
   const int H = q.n_bins / 2;  // table slices per half level; the table spans (16 + 1) half levels
   // Data-parallel runs ask for the owner launch in BUCKETS of table slices (f2n_set_scatter_buckets): after each bucket's launch the
   // host is called back and starts that range's all-reduce while the next bucket's owners still run.

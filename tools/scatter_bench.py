@@ -13,6 +13,7 @@ import importlib.util
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--zero-frac", type=float, default=0.3)
+ap.add_argument("--only", default="", help="substring of the one sample set to run (e.g. '47%')")
 ap.add_argument("--amps", default="2e-4,0.05", help="standard deviations of the synthetic f16 gradients: a training's loss-scaled gradients sum to "
                 "~1 per table slice (f2n_debug_counters()[2] of the debug variant: 0.6 converged, 1.2 fresh), which 2e-4 reproduces; "
                 "0.05 drives every slice's sum of |addend| past the fixed-point route's range, i.e. times the owners' fp64 route")
@@ -50,6 +51,8 @@ sets = {"converged, 47% of every ray": front_part(conv, 0.47), "converged, 24% o
         "fresh, all samples": (fresh["pts"], fresh["anchors"])}
 for amp in [float(a) for a in args.amps.split(",")]:
     for name, (pts, anchors) in sets.items():
+        if args.only and args.only not in name:
+            continue
         n = pts.shape[0]
         g = (torch.randn((n, 32), device=dev) * amp).to(torch.float16)
         g[torch.rand(n, device=dev) < args.zero_frac] = 0
