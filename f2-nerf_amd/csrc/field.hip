@@ -710,7 +710,7 @@ struct F2nBinQueues {
   int32_t* ovf_any;  // [16 levels]
   int stamp;         // this launch (never 0)
   int force_f64;  // != 0: the owners sum every slice on their fp64 route (F2N_OWNER_F64: test knob of the debug variant)
-  int dissect;    // debug variant, timing only (F2N_BIN_DISSECT; results are garbage): 1 = the producers do everything but the record stores, 2 = neither slot atomics nor stores, +4 = no owner launch
+  int dissect;    // debug variant, timing only (F2N_BIN_DISSECT; results are garbage): 1 = the producers do everything but the record stores, 2 = neither slot atomics nor stores, +4 = no owner launch, +8 = 4-byte stores, +16 = 6-byte records
   int producer_major;  // record layout: 1 = [level][chunk][slice][slot] (a producer block's 128 segments contiguous), 0 = [level][slice][chunk][slot] (an owner's, rounds 1-5)
 };
 
@@ -831,6 +831,19 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
 #if F2N_DEBUG_BUILD
             if ((q.dissect & 3) == 1) {
               if (((unsigned) slot ^ pos ^ bits) == 0x12345u) s_cnt[bin] = 1;
+              continue;
+            }
+            if (q.dissect & 8) {  // half the bytes, as many stores: 4-byte "records" 4 bytes apart
+              if (slot < cap_nb) ((uint32_t*) (my_rec + (size_t) bin * bin_stride))[slot] = bits ^ pos;
+              continue;
+            }
+            if (q.dissect & 16) {  // 6-byte records 6 bytes apart, as a 4-byte and a 2-byte store
+              if (slot < cap_nb) {
+                uint16_t* r6 = (uint16_t*) (my_rec + (size_t) bin * bin_stride) + 3 * (size_t) slot;
+                r6[0] = (uint16_t) (pos & (F2N_BIN_ENTRIES - 1));
+                r6[1] = (uint16_t) bits;
+                r6[2] = (uint16_t) (bits >> 16);
+              }
               continue;
             }
 #endif
