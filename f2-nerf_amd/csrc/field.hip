@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
               uint2 r;
               r.x = pos & (F2N_BIN_ENTRIES - 1);
               r.y = bits;
-              my_rec[(size_t) bin * bin_stride + slot] = r;
+              my_rec[(uint32_t) bin * (uint32_t) bin_stride + (uint32_t) slot] = r;  // (a segment index inside the block's region fits 32 bits: one scalar base, one vector offset)
             } else {
               const int os = OVF ? atomicAdd(&s_ovf, 1) : F2N_BIN_OVF_CAP;
               if (OVF && os < F2N_BIN_OVF_CAP) {
