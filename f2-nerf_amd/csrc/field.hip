@@ -714,7 +714,7 @@ struct F2nBinQueues {
   int producer_major;  // record layout: 1 = [level][chunk][slice][slot] (a producer block's 128 segments contiguous), 0 = [level][slice][chunk][slot] (an owner's, rounds 1-5)
 };
 
-// OVF: with overflow lists (F2nBinQueues) -- tables of more than 2^19 entries per level, where segments do fill up (f2n_bin_ovf); the
+// OVF: with overflow lists (F2nBinQueues) -- tables of more than 2^19 entries per level, where segments do fill up (f2n_binned_scatter picks the instantiation); the
 // benched 2^19 tables keep the code without them (their trainings never filled a segment, and the lists' code, cold as it is, cost the
 // converged step ~5 us: 0.678-0.682 against 0.667-0.674 ms).
 template <bool OVF>
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void hash_bin_kernel(int n, int chunk, F2nHash
               if (slot < cap_nb) ((uint32_t*) (my_rec + (size_t) bin * bin_stride))[slot] = bits ^ pos;
               continue;
             }
-            if (q.dissect & 16) {  // 6-byte records 6 bytes apart, as a 4-byte and a 2-byte store
+            if (q.dissect & 16) {  // 6-byte records 6 bytes apart, as three 2-byte stores
               if (slot < cap_nb) {
                 uint16_t* r6 = (uint16_t*) (my_rec + (size_t) bin * bin_stride) + 3 * (size_t) slot;
                 r6[0] = (uint16_t) (pos & (F2N_BIN_ENTRIES - 1));
